@@ -1,0 +1,570 @@
+"""
+Tree containers for the ACR hot path.
+
+Two representations live here:
+
+* :class:`TreeNode` -- a minimal pointer tree that duck-types the subset of ``ete3.Tree`` that the reference's
+  ``acr()`` / ``ml.py`` touch (``traverse``, ``children``, ``up``, ``dist``, ``name``,
+  ``is_root``, ``is_leaf``, ``add_feature(s)``, ``del_feature``, ``features``, leaf iteration).  ete3 itself is not
+  installed on our boxes, so callers build trees with :func:`read_tree` / :func:`read_forest`
+  (reference: ``pastml/tree.py:176-222``).  Only newick reading/naming is provided; tree editing, dates, polytomy
+  resolution and nexus (``pastml/tree.py`` rest) are out of scope.
+
+* :class:`FlatForest` -- the structure-of-arrays form that is uploaded to the GPU: nodes are renumbered in
+  breadth-first (level) order over the whole forest so that (i) the children of a node are contiguous,
+  (ii) every depth level is a contiguous id range (top-down sweep), and (iii) the row order of the posterior
+  table equals ``tree.traverse()`` order (``pastml/ml.py:498-502``).  Bottom-up levels group the internal nodes by
+  height above their deepest tip.
+"""
+from collections import deque, Counter
+
+import numpy as np
+
+DEFAULT_DIST = 1.0
+
+
+class NewickError(ValueError):
+    pass
+
+
+class TreeNode(object):
+    """ete3-like tree node. The node *is* the (sub)tree rooted at it."""
+
+    __slots__ = ('children', 'up', 'dist', 'name', 'support', 'features', '__dict__', '_flat_cache')
+
+    def __init__(self, newick=None, format=None, name=None, dist=None, support=None, quoted_node_names=False):
+        self.children = []
+        self.up = None
+        self.dist = DEFAULT_DIST if dist is None else dist
+        self.name = name if name is not None else ''
+        self.support = 1.0 if support is None else support
+        self.features = {'dist', 'name', 'support'}
+        self._flat_cache = None
+        if newick is not None:
+            _parse_newick(newick, self)
+
+    # --- features -------------------------------------------------------------------------------------------------
+    def add_feature(self, pr_name, pr_value):
+        setattr(self, pr_name, pr_value)
+        self.features.add(pr_name)
+
+    def add_features(self, **features):
+        for k, v in features.items():
+            self.add_feature(k, v)
+
+    def del_feature(self, pr_name):
+        if pr_name in self.__dict__:
+            del self.__dict__[pr_name]
+        self.features.discard(pr_name)
+
+    # --- topology ---------------------------------------------------------------------------------------------------
+    def is_root(self):
+        return self.up is None
+
+    def is_leaf(self):
+        return not self.children
+
+    def add_child(self, child=None, name=None, dist=None, support=None):
+        if child is None:
+            child = TreeNode()
+        if name is not None:
+            child.name = name
+        if dist is not None:
+            child.dist = dist
+        if support is not None:
+            child.support = support
+        self.children.append(child)
+        child.up = self
+        return child
+
+    def remove_child(self, child):
+        self.children.remove(child)
+        child.up = None
+        return child
+
+    def get_tree_root(self):
+        n = self
+        while n.up is not None:
+            n = n.up
+        return n
+
+    # --- traversal (orders identical to ete3: children are visited left to right) ---------------------------------------
+    def traverse(self, strategy='levelorder'):
+        if strategy == 'preorder':
+            return self._iter_preorder()
+        if strategy == 'postorder':
+            return self._iter_postorder()
+        if strategy == 'levelorder':
+            return self._iter_levelorder()
+        raise ValueError('Unknown traversal strategy {}'.format(strategy))
+
+    def _iter_preorder(self):
+        stack = [self]
+        while stack:
+            n = stack.pop()
+            yield n
+            stack.extend(reversed(n.children))
+
+    def _iter_postorder(self):
+        stack = [(self, False)]
+        while stack:
+            n, expanded = stack.pop()
+            if expanded or not n.children:
+                yield n
+            else:
+                stack.append((n, True))
+                stack.extend((c, False) for c in reversed(n.children))
+
+    def _iter_levelorder(self):
+        queue = deque([self])
+        while queue:
+            n = queue.popleft()
+            yield n
+            queue.extend(n.children)
+
+    def iter_leaves(self):
+        for n in self._iter_preorder():
+            if not n.children:
+                yield n
+
+    def get_leaves(self):
+        return list(self.iter_leaves())
+
+    def iter_descendants(self, strategy='levelorder'):
+        for n in self.traverse(strategy):
+            if n is not self:
+                yield n
+
+    def __iter__(self):
+        return self.iter_leaves()
+
+    def __len__(self):
+        return sum(1 for _ in self.iter_leaves())
+
+    def __bool__(self):
+        return True
+
+    def __repr__(self):
+        return 'TreeNode({!r})'.format(self.name)
+
+    def copy(self):
+        """Deep copy of topology, names, lengths and features (feature values are shared)."""
+        mapping = {}
+        for n in self._iter_preorder():
+            c = TreeNode(name=n.name, dist=n.dist, support=n.support)
+            for f in n.features:
+                if f not in ('dist', 'name', 'support'):
+                    c.add_feature(f, getattr(n, f))
+            mapping[id(n)] = c
+            if n is not self:
+                mapping[id(n.up)].add_child(c)
+        return mapping[id(self)]
+
+    def write(self, format=3):
+        """Newick with all names and branch lengths."""
+        out = {}
+        for n in self._iter_postorder():
+            label = '{}:{}'.format(n.name, repr(float(n.dist)) if n.dist != int(n.dist) else '{:g}'.format(n.dist))
+            if n.children:
+                out[id(n)] = '({}){}'.format(','.join(out.pop(id(c)) for c in n.children), label)
+            else:
+                out[id(n)] = label
+        return out[id(self)] + ';'
+
+
+Tree = TreeNode
+
+
+def _parse_newick(text, root):
+    """
+    Iterative newick reader (no recursion, so million-tip trees are fine).
+    Labels may be quoted with single quotes; ``[...]`` comments are skipped; missing branch lengths get ete3's default
+    (1.0), a missing root length is 0.
+    """
+    if '\n' not in text and not text.lstrip().startswith('(') and not text.rstrip().endswith(';'):
+        # a path
+        with open(text, 'r') as f:
+            text = f.read()
+    s = text.strip()
+    if not s.endswith(';'):
+        raise NewickError('Newick string must end with ";"')
+    i, n = 0, len(s)
+    node = root
+    root.dist = 0.0
+    depth = 0
+
+    def read_label(i):
+        # returns (name, dist or None, next index)
+        name_chars = []
+        if i < n and s[i] == "'":
+            j = s.index("'", i + 1)
+            name_chars.append(s[i + 1:j])
+            i = j + 1
+        while i < n and s[i] not in ':,();[':
+            name_chars.append(s[i])
+            i += 1
+        name = ''.join(name_chars).strip()
+        dist = None
+        while i < n and s[i] in ':[':
+            if s[i] == '[':
+                i = s.index(']', i) + 1
+                continue
+            i += 1
+            j = i
+            while j < n and s[j] not in ',();[':
+                j += 1
+            try:
+                dist = float(s[i:j])
+            except ValueError:
+                raise NewickError('Bad branch length "{}"'.format(s[i:j]))
+            i = j
+        return name, dist, i
+
+    expecting_node = True
+    while i < n:
+        ch = s[i]
+        if ch.isspace():
+            i += 1
+        elif ch == '(':
+            if not expecting_node:
+                raise NewickError('Unexpected "(" at position {}'.format(i))
+            child = TreeNode()
+            node.add_child(child)
+            node = child
+            depth += 1
+            i += 1
+        elif ch == ',':
+            if depth == 0:
+                raise NewickError('Unexpected "," at top level')
+            child = TreeNode()
+            node.up.add_child(child)
+            node = child
+            expecting_node = True
+            i += 1
+        elif ch == ')':
+            if depth == 0:
+                raise NewickError('Unbalanced ")"')
+            node = node.up
+            depth -= 1
+            i += 1
+            name, dist, i = read_label(i)
+            # internal labels that are numbers are supports in some formats; we keep them as names only if non-numeric
+            node.name = name
+            if dist is not None:
+                node.dist = dist
+            expecting_node = False
+        elif ch == ';':
+            break
+        else:
+            name, dist, i = read_label(i)
+            node.name = name
+            if dist is not None:
+                node.dist = dist
+            expecting_node = False
+    if depth != 0:
+        raise NewickError('Unbalanced parentheses')
+    return root
+
+
+def read_tree(tree_path, columns=None):
+    """Reads one newick tree from a path or a string (reference: pastml/tree.py:202-222)."""
+    try:
+        tree = TreeNode(tree_path)
+    except (NewickError, OSError) as e:
+        raise ValueError('Could not read the tree {}. Is it a valid newick? ({})'.format(tree_path, e))
+    if columns:
+        for n in tree.traverse():
+            for c in columns:
+                vs = set(getattr(n, c).split('|')) if hasattr(n, c) else set()
+                if vs:
+                    n.add_feature(c, vs)
+    return tree
+
+
+def read_forest(tree_path, columns=None):
+    """Reads all the newick trees of a file; negative branches are set to zero (reference: pastml/tree.py:176-199)."""
+    with open(tree_path, 'r') as f:
+        nwks = f.read().replace('\n', '').split(';')
+    if not nwks or not nwks[:-1]:
+        raise ValueError('Could not find any trees (in newick format) in the file {}.'.format(tree_path))
+    roots = [read_tree(nwk + ';', columns) for nwk in nwks[:-1]]
+    for root in roots:
+        for _ in root.traverse():
+            if _.dist < 0:
+                _.dist = 0
+    return roots
+
+
+def name_tree(tree, suffix=""):
+    """
+    Gives unique names to unnamed / non-uniquely named nodes (reference: pastml/tree.py:76-105).
+    """
+    existing_names = Counter()
+    n_nodes = 0
+    for _ in tree.traverse():
+        n_nodes += 1
+        if _.name:
+            existing_names[_.name] += 1
+    if n_nodes == len(existing_names):
+        return
+    i = 0
+    new_existing_names = Counter()
+    for node in tree.traverse('preorder'):
+        name_prefix = node.name if node.name and existing_names[node.name] < 10 \
+            else '{}{}{}'.format('t' if node.is_leaf() else 'n', i, suffix)
+        name = 'root{}'.format(suffix) if node.is_root() else name_prefix
+        while name is None or name in new_existing_names:
+            name = '{}{}{}'.format(name_prefix, i, suffix)
+            i += 1
+        node.name = name
+        new_existing_names[name] += 1
+
+
+# =====================================================================================================================
+# Flat (structure-of-arrays) forest
+# =====================================================================================================================
+
+class FlatForest(object):
+    """
+    Level-ordered structure-of-arrays forest.
+
+    Node ids are breadth-first over the whole forest: all roots, then all depth-1 nodes (in parent order, children
+    left to right), etc.  Hence ``first_child[p] .. first_child[p] + n_children[p] - 1`` are p's children and depth
+    levels are contiguous ranges ``td_offsets[d] .. td_offsets[d+1]``.
+
+    Attributes (numpy arrays, N = number of nodes):
+        parent       int32[N]   parent id, -1 for roots
+        first_child  int32[N]   id of the first child (undefined for tips)
+        n_children   int32[N]
+        dist         float64[N] branch length above the node
+        depth        int32[N]   0 for roots
+        height       int32[N]   0 for tips, 1 + max child height otherwise
+        tree_id      int32[N]   index of the tree in the forest
+        roots        int32[R]
+        tips         int32[T]   ids of the tips, ascending
+        bu_order     int32[N-T] internal nodes sorted by (height, id); bu_offsets int32[H+1] delimits height 1..H
+        td_parents   int32[N-T] internal nodes sorted by id (== by depth);  td_parent_offsets int32[D+1] per depth
+        td_offsets   int32[D+2] id range of each depth level
+        post_rank    int32[N]   position of the node in the reference's processing order
+                                (trees one after another, each in post-order; pastml/ml.py:109,206)
+    ``nodes`` (optional) is the list of TreeNode objects in id order.
+    """
+
+    def __init__(self, parent, n_children, first_child, dist, roots, nodes=None):
+        self.parent = np.ascontiguousarray(parent, dtype=np.int32)
+        self.n_children = np.ascontiguousarray(n_children, dtype=np.int32)
+        self.first_child = np.ascontiguousarray(first_child, dtype=np.int32)
+        self.dist = np.ascontiguousarray(dist, dtype=np.float64)
+        self.roots = np.ascontiguousarray(roots, dtype=np.int32)
+        self.nodes = nodes
+        self.n_nodes = len(self.parent)
+        self._derive()
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def _derive(self):
+        N = self.n_nodes
+        parent = self.parent
+        depth = np.zeros(N, dtype=np.int32)
+        tree_id = np.zeros(N, dtype=np.int32)
+        # ids are BFS ordered, so depth is non-decreasing in id and a parent's depth is known before its children's
+        # level boundaries: roots are the first R ids
+        R = len(self.roots)
+        if not np.array_equal(self.roots, np.arange(R, dtype=np.int32)):
+            raise ValueError('FlatForest expects roots to be ids 0..R-1 (breadth-first numbering)')
+        tree_id[:R] = np.arange(R)
+        offsets = [0, R]
+        lo, hi = 0, R
+        d = 0
+        while hi < N:
+            # children of level [lo, hi) are the next contiguous block
+            cnt = int(self.n_children[lo:hi].sum())
+            if cnt == 0:
+                raise ValueError('Disconnected nodes in FlatForest')
+            d += 1
+            depth[hi:hi + cnt] = d
+            tree_id[hi:hi + cnt] = tree_id[parent[hi:hi + cnt]]
+            lo, hi = hi, hi + cnt
+            offsets.append(hi)
+        self.depth = depth
+        self.tree_id = tree_id
+        self.td_offsets = np.asarray(offsets, dtype=np.int32)
+        n_depths = len(offsets) - 1
+
+        is_tip = self.n_children == 0
+        self.is_tip = is_tip
+        self.tips = np.flatnonzero(is_tip).astype(np.int32)
+        self.n_tips = len(self.tips)
+
+        height = np.zeros(N, dtype=np.int32)
+        for lvl in range(n_depths - 1, 0, -1):
+            a, b = offsets[lvl], offsets[lvl + 1]
+            np.maximum.at(height, parent[a:b], height[a:b] + 1)
+        self.height = height
+
+        internal = np.flatnonzero(~is_tip).astype(np.int32)
+        order = np.lexsort((internal, height[internal]))
+        self.bu_order = internal[order].astype(np.int32)
+        H = int(height.max()) if N else 0
+        counts = np.bincount(height[internal], minlength=H + 1)[1:] if H > 0 else np.zeros(0, dtype=np.int64)
+        self.bu_offsets = np.concatenate(([0], np.cumsum(counts))).astype(np.int32)
+
+        self.td_parents = internal
+        pd_counts = np.bincount(depth[internal], minlength=n_depths) if len(internal) else np.zeros(n_depths, int)
+        self.td_parent_offsets = np.concatenate(([0], np.cumsum(pd_counts))).astype(np.int32)
+
+        # subtree sizes -> preorder -> postorder ranks (post = pre - depth + size - 1 within a tree)
+        size = np.ones(N, dtype=np.int64)
+        for lvl in range(n_depths - 1, 0, -1):
+            a, b = offsets[lvl], offsets[lvl + 1]
+            np.add.at(size, parent[a:b], size[a:b])
+        pre = np.zeros(N, dtype=np.int64)
+        tree_sizes = size[:R]
+        tree_offset = np.concatenate(([0], np.cumsum(tree_sizes)))[:-1]
+        for lvl in range(1, n_depths):
+            a, b = offsets[lvl], offsets[lvl + 1]
+            # exclusive cumsum of sibling sizes within each parent group
+            sz = size[a:b]
+            cs = np.cumsum(sz) - sz
+            p = parent[a:b]
+            first = self.first_child[p] - a  # index of the first sibling inside this level
+            pre[a:b] = pre[p] + 1 + (cs - cs[first])
+        post = pre - depth + size - 1
+        self.post_rank = (post + tree_offset[tree_id]).astype(np.int32)
+        self.subtree_size = size
+
+    # ------------------------------------------------------------------------------------------------------------------
+    @property
+    def n_bu_levels(self):
+        return len(self.bu_offsets) - 1
+
+    @property
+    def n_td_levels(self):
+        return len(self.td_offsets) - 1
+
+    @property
+    def forest_length(self):
+        return float(self.dist.sum())
+
+    def to_tree_nodes(self, names=None):
+        """Builds TreeNode objects (and remembers them in ``self.nodes``); names default to ROOT / n<i> / t<i>."""
+        nodes = []
+        for i in range(self.n_nodes):
+            if names is not None:
+                name = names[i]
+            elif self.parent[i] < 0:
+                name = 'ROOT' if len(self.roots) == 1 else 'ROOT{}'.format(i)
+            else:
+                name = ('t{}' if self.n_children[i] == 0 else 'n{}').format(i)
+            node = TreeNode(name=name, dist=float(self.dist[i]))
+            nodes.append(node)
+            if self.parent[i] >= 0:
+                nodes[self.parent[i]].add_child(node)
+        self.nodes = nodes
+        return [nodes[r] for r in self.roots]
+
+    # ------------------------------------------------------------------------------------------------------------------
+    @classmethod
+    def from_trees(cls, forest):
+        """Flattens TreeNode trees (one tree or a list). Node ids follow forest-wide level order."""
+        if isinstance(forest, TreeNode):
+            forest = [forest]
+        nodes = list(forest)
+        parent = [-1] * len(nodes)
+        i = 0
+        first_child, n_children, dist = [], [], []
+        while i < len(nodes):
+            n = nodes[i]
+            first_child.append(len(nodes))
+            n_children.append(len(n.children))
+            dist.append(n.dist)
+            for c in n.children:
+                nodes.append(c)
+                parent.append(i)
+            i += 1
+        return cls(parent, n_children, first_child, dist, np.arange(len(forest)), nodes=nodes)
+
+    @classmethod
+    def balanced(cls, n_levels, seed=42, lo=0.01, hi=0.2):
+        """
+        Perfectly balanced binary tree with 2**n_levels tips: ids in level order, root
+        dist 0, branch lengths uniform(lo, hi) drawn in id order from default_rng(seed).
+        """
+        T = 1 << n_levels
+        N = 2 * T - 1
+        ids = np.arange(N, dtype=np.int64)
+        parent = ((ids - 1) // 2).astype(np.int32)
+        parent[0] = -1
+        n_children = np.where(ids < T - 1, 2, 0).astype(np.int32)
+        first_child = (2 * ids + 1).astype(np.int32)
+        rng = np.random.default_rng(seed)
+        dist = rng.uniform(lo, hi, size=N)
+        dist[0] = 0.0
+        return cls(parent, n_children, first_child, dist, np.array([0]))
+
+    @classmethod
+    def random(cls, n_tips, seed=0, max_arity=2, zero_frac=0.0, lo=0.001, hi=0.3, n_trees=1):
+        """
+        Random (unbalanced) forest for tests: grows by splitting random tips; arity in [2, max_arity];
+        a fraction zero_frac of the branches gets length 0.
+        """
+        rng = np.random.default_rng(seed)
+        roots = []
+        for _ in range(n_trees):
+            root = TreeNode(name='', dist=0.0)
+            leaves = [root]
+            while len(leaves) < max(2, n_tips // n_trees):
+                idx = int(rng.integers(len(leaves)))
+                leaf = leaves.pop(idx)
+                for _c in range(int(rng.integers(2, max_arity + 1))):
+                    d = 0.0 if rng.random() < zero_frac else float(rng.uniform(lo, hi))
+                    leaves.append(leaf.add_child(dist=d))
+            roots.append(root)
+        for ti, root in enumerate(roots):
+            for i, n in enumerate(root.traverse('preorder')):
+                n.name = 't{}_{}'.format(ti, i) if n.is_leaf() else 'n{}_{}'.format(ti, i)
+        return cls.from_trees(roots)
+
+    def children_of(self, i):
+        a = self.first_child[i]
+        return range(a, a + self.n_children[i])
+
+    def postorder_ids(self):
+        """Node ids in the reference's processing order."""
+        return np.argsort(self.post_rank, kind='stable').astype(np.int32)
+
+
+def get_flat_forest(forest):
+    """
+    Returns the (cached) FlatForest of a list of TreeNode roots. The cache lives on the first root and is keyed by
+    the identity of the roots, the number of nodes and the branch lengths, so that editing a tree invalidates it.
+    """
+    if isinstance(forest, TreeNode):
+        forest = [forest]
+    holder = forest[0]
+    key_roots = tuple(id(t) for t in forest)
+    cache = getattr(holder, '_flat_cache', None)
+    if cache is not None and cache[0] == key_roots:
+        flat = cache[1]
+        # validation: same node objects, same child lists, same branch lengths
+        nodes = flat.nodes
+        ok = all(nodes[r] is t for r, t in enumerate(forest))
+        if ok:
+            dist, n_children, first_child = flat.dist, flat.n_children, flat.first_child
+            for i, n in enumerate(nodes):
+                ch = n.children
+                if n.dist != dist[i] or len(ch) != n_children[i]:
+                    ok = False
+                    break
+                fc = first_child[i]
+                for j, c in enumerate(ch):
+                    if nodes[fc + j] is not c:
+                        ok = False
+                        break
+                if not ok:
+                    break
+        if ok:
+            return flat
+    flat = FlatForest.from_trees(forest)
+    # ids must follow per-tree level order for single trees; for forests the order is forest-wide level order
+    holder._flat_cache = (key_roots, flat)
+    return flat

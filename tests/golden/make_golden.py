@@ -1,0 +1,534 @@
+#!/usr/bin/env python3
+"""
+Generates the golden vectors under tests/golden/ by running the REAL reference (evolbioinfo/pastml, imported
+unmodified from /root/reference) in this container.  Run as:
+
+    python3 -B tests/golden/make_golden.py [case ...]
+
+Nothing of the reference is copied: ete3 / Bio / itolapi (absent here) are replaced in sys.modules by thin stand-ins
+(our own TreeNode plays ete3.Tree), the reference package is imported from /root/reference, its functions are called
+and inputs + outputs are stored as .npz.  The small data files the reference's own tests use
+(tests/data/Albanian.tree.152tax.tre, data.txt, the two simulated nucleotide trees) are copied as fixtures.
+
+All arrays indexed by node follow the forest-wide level order of pastml_amd.tree.FlatForest (== tree.traverse()).
+"""
+import os
+import shutil
+import sys
+import types
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = '/root/reference'
+sys.path.insert(0, REPO)
+
+import numpy as np
+import pandas as pd
+
+from pastml_amd import tree as our_tree
+from pastml_amd import synthetic
+
+
+def install_stubs():
+    ete3 = types.ModuleType('ete3')
+    ete3.Tree = our_tree.TreeNode
+    ete3.TreeNode = our_tree.TreeNode
+    parser = types.ModuleType('ete3.parser')
+    newick = types.ModuleType('ete3.parser.newick')
+    newick.NewickError = our_tree.NewickError
+    parser.newick = newick
+    ete3.parser = parser
+    sys.modules.update({'ete3': ete3, 'ete3.parser': parser, 'ete3.parser.newick': newick})
+    bio = types.ModuleType('Bio')
+    phylo = types.ModuleType('Bio.Phylo')
+    nio = types.ModuleType('Bio.Phylo.NewickIO')
+    import io
+    nio.StringIO = io.StringIO
+    phylo.NewickIO = nio
+    phylo.write = lambda *a, **k: None
+    phylo.parse = lambda *a, **k: iter(())
+    bio.Phylo = phylo
+    sys.modules.update({'Bio': bio, 'Bio.Phylo': phylo, 'Bio.Phylo.NewickIO': nio})
+    itol = types.ModuleType('itolapi')
+    itol.Itol = object
+    sys.modules['itolapi'] = itol
+
+
+install_stubs()
+sys.path.insert(0, REF)
+import pastml  # noqa: E402
+from pastml import ml as rml  # noqa: E402
+from pastml.acr import acr as racr  # noqa: E402
+from pastml.annotation import ForestStats as RForestStats  # noqa: E402
+from pastml.models.F81Model import F81Model as RF81  # noqa: E402
+from pastml.models.JCModel import JCModel as RJC  # noqa: E402
+from pastml.models.EFTModel import EFTModel as REFT  # noqa: E402
+from pastml.models.HKYModel import HKYModel as RHKY  # noqa: E402
+from pastml.models.JTTModel import JTTModel as RJTT, JTT_STATES  # noqa: E402
+from pastml.models.CustomRatesModel import CustomRatesModel as RCR  # noqa: E402
+
+assert pastml.__file__.startswith(REF)
+
+DATA = os.path.join(HERE, 'data')
+os.makedirs(DATA, exist_ok=True)
+
+
+def feat(character, name):
+    return '{}_{}'.format(character, name)
+
+
+def copy_data():
+    for f in ('Albanian.tree.152tax.tre', 'data.txt',
+              'tree.152taxa.sf_0.5.A_0.6.C_0.15.G_0.2.T_0.05.nwk',
+              'tree.152taxa.sf_0.5.A_0.6.C_0.15.G_0.2.T_0.05.pastml.tab',
+              'tree.152taxa.sf_0.5.A_0.25.C_0.25.G_0.25.T_0.25.nwk',
+              'tree.152taxa.sf_0.5.A_0.25.C_0.25.G_0.25.T_0.25.pastml.tab'):
+        shutil.copy(os.path.join(REF, 'tests', 'data', f), os.path.join(DATA, f))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def model_arrays(model):
+    out = dict(model_name=model.name, sf=float(model.sf), tau=float(model.tau), tau_factor=float(model._tau_factor),
+               states=np.array(model.states, dtype=str))
+    if hasattr(model, 'frequencies'):
+        out['frequencies'] = np.array(model.frequencies, dtype=np.float64)
+    if hasattr(model, 'kappa'):
+        out['kappa'] = float(model.kappa)
+    if hasattr(model, 'D_DIAGONAL'):
+        out['eig_d'] = np.array(model.D_DIAGONAL)
+        out['eig_A'] = np.array(model.A)
+        out['eig_Ainv'] = np.array(model.A_INV)
+        out['rate_matrix'] = np.array(model.rate_matrix)
+    return out
+
+
+def collect(nodes, name, k=None, dtype=np.float64):
+    vals = [getattr(n, name) for n in nodes]
+    return np.array(vals, dtype=dtype)
+
+
+def sweep_capture(forest, character, model, force_joint=True, prefix=''):
+    """
+    Re-runs the steps of pastml.ml.ml_acr (ml.py:640-750) for fixed parameters with the reference's own functions,
+    capturing every intermediate the kernels must reproduce.
+    """
+    flat = our_tree.FlatForest.from_trees(forest)
+    nodes = flat.nodes
+    states = model.states
+    k = len(states)
+    out = {}
+    A = feat(character, rml.ALLOWED_STATES)
+
+    for tree in forest:
+        rml.initialize_allowed_states(tree, character, states)
+    out['masks_initial'] = collect(nodes, A, dtype=np.int8)
+
+    # marginal log-likelihood with alteration (what the optimiser evaluates)
+    out['loglik'] = sum(rml.get_bottom_up_loglikelihood(tree=t, character=character, model=model,
+                                                        is_marginal=True, alter=True) for t in forest)
+    # joint sweep
+    out['loglik_joint'] = sum(rml.get_bottom_up_loglikelihood(tree=t, character=character, model=model,
+                                                              is_marginal=False, alter=True) for t in forest)
+    out['masks_after_joint_sweep'] = collect(nodes, A, dtype=np.int8)
+    jt = np.full((len(nodes), k), -1, dtype=np.int64)
+    JS = feat(character, rml.BU_LH_JOINT_STATES)
+    for i, n in enumerate(nodes):
+        if hasattr(n, JS):
+            jt[i] = getattr(n, JS)
+    out['joint_table'] = jt
+    out['bu_joint'] = collect(nodes, feat(character, rml.BU_LH))
+    out['bu_joint_sf'] = collect(nodes, feat(character, rml.BU_LH_SF))
+    for t in forest:
+        rml.choose_ancestral_states_joint(t, character, states, model.frequencies)
+    out['joint_state'] = collect(nodes, feat(character, rml.JOINT_STATE), dtype=np.int64)
+
+    # marginal: explicit alteration, BU (alter=False), TD, marginals
+    altered_all = []
+    for t in forest:
+        rml.initialize_allowed_states(t, character, states)
+        altered = []
+        if 0 == model.tau:
+            altered = rml.alter_zero_node_allowed_states(t, character)
+        altered_all.extend(altered)
+    out['masks_altered'] = collect(nodes, A, dtype=np.int8)
+    ids = {id(n): i for i, n in enumerate(nodes)}
+    out['altered_nodes'] = np.array(sorted(ids[id(n)] for n in altered_all), dtype=np.int32)
+    for t in forest:
+        rml.get_bottom_up_loglikelihood(tree=t, character=character, is_marginal=True, model=model, alter=False)
+        rml.calculate_top_down_likelihood(t, character, model=model)
+        rml.calculate_marginal_likelihoods(t, character, model.frequencies, clean_up=False)
+    out['bu'] = collect(nodes, feat(character, rml.BU_LH))
+    out['bu_sf'] = collect(nodes, feat(character, rml.BU_LH_SF))
+    out['td'] = collect(nodes, feat(character, rml.TD_LH))
+    out['td_sf'] = collect(nodes, feat(character, rml.TD_LH_SF))
+    out['lh'] = collect(nodes, feat(character, rml.LH))
+    out['lh_sf'] = collect(nodes, feat(character, rml.LH_SF))
+    mps = [rml.convert_likelihoods_to_probabilities(t, character, states) for t in forest]
+    mp = pd.concat(mps) if len(mps) > 1 else mps[0]
+    # forest-wide level order
+    out['posterior'] = np.array([mp.loc[n.name].values if mp.index.is_unique else None for n in nodes]) \
+        if mp.index.is_unique else mp.values
+    if altered_all:
+        rml.unalter_zero_node_allowed_states(altered_all, character)
+    for t in forest:
+        rml.choose_ancestral_states_map(t, character, states)
+    out['masks_map'] = collect(nodes, A, dtype=np.int8)
+    out['loglik_restricted_MAP'] = sum(rml.get_bottom_up_loglikelihood(tree=t, character=character, model=model,
+                                                                       is_marginal=True, alter=True) for t in forest)
+    ns, nun, nst = 1, 0, 0
+    for t in forest:
+        a, b, c = rml.choose_ancestral_states_mppa(t, character, states, force_joint=force_joint)
+        ns, nun, nst = ns * a, nun + b, nst + c
+    out['masks_mppa'] = collect(nodes, A, dtype=np.int8)
+    out['mppa_log_num_scenarios'] = float(np.sum(np.log(out['masks_mppa'].sum(axis=1).astype(np.float64))))
+    out['mppa_num_unresolved'] = nun
+    out['mppa_num_states'] = nst
+    out['loglik_restricted_MPPA'] = sum(rml.get_bottom_up_loglikelihood(tree=t, character=character, model=model,
+                                                                        is_marginal=True, alter=True) for t in forest)
+    out['force_joint'] = force_joint
+    return flat, {prefix + k_: v for k_, v in out.items()}
+
+
+def tree_arrays(flat):
+    return dict(parent=flat.parent, first_child=flat.first_child, n_children=flat.n_children, dist=flat.dist,
+                n_roots=len(flat.roots), node_names=np.array([n.name for n in flat.nodes], dtype=str))
+
+
+def forest_stats_arrays(fs):
+    return dict(fs_avg_nonzero_brlen=fs.avg_nonzero_brlen, fs_num_nodes=fs.num_nodes, fs_num_tips=fs.num_tips,
+                fs_forest_length=fs.forest_length)
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **arrays)
+    print('wrote', path, '{:.1f} KB'.format(os.path.getsize(path) / 1024))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# cases
+# ---------------------------------------------------------------------------------------------------------------------
+class FS(object):
+    """forest_stats stand-in for P(t)-only cases."""
+
+    def __init__(self, length=10., nodes=20, tips=11, avg=0.5):
+        self.forest_length, self.num_nodes, self.num_tips, self.avg_nonzero_brlen = length, nodes, tips, avg
+
+
+def case_pij():
+    rng = np.random.default_rng(7)
+    ts = np.array([0, 1e-6, 1e-3, 0.1, 1, 10], dtype=np.float64)
+    out = {'ts': ts}
+    idx = 0
+    names = []
+
+    def add(label, model):
+        nonlocal idx
+        P = np.array([model.get_Pij_t(t) for t in ts])
+        pre = 'c{}_'.format(idx)
+        names.append(label)
+        for k_, v in model_arrays(model).items():
+            out[pre + k_] = v
+        out[pre + 'P'] = P
+        idx += 1
+
+    for tau in (0, 0.05):
+        fs = FS()
+        for k in (4, 5, 64):
+            pi = rng.dirichlet(np.ones(k))
+            add('F81_k{}_tau{}'.format(k, tau),
+                RF81(states=synthetic.state_names(k), forest_stats=fs, sf=1.3, frequencies=pi, tau=tau))
+        add('JC_k4_tau{}'.format(tau), RJC(states=synthetic.state_names(4), forest_stats=fs, sf=0.7, tau=tau))
+        add('JC_k1_tau{}'.format(tau), RJC(states=synthetic.state_names(1), forest_stats=fs, sf=0.7, tau=tau))
+        for kappa in (1., 4.):
+            add('HKY_kappa{}_tau{}'.format(kappa, tau),
+                RHKY(forest_stats=fs, sf=2., frequencies=rng.dirichlet(np.ones(4)), kappa=kappa, tau=tau))
+        add('JTT_tau{}'.format(tau), RJTT(forest_stats=fs, sf=1.1, tau=tau))
+        k = 10
+        R = rng.uniform(0.1, 3, size=(k, k))
+        R = np.triu(R, 1)
+        R = R + R.T
+        add('CUSTOM_k10_tau{}'.format(tau),
+            RCR(forest_stats=fs, sf=0.9, frequencies=rng.dirichlet(np.ones(k)), rate_matrix=R,
+                states=synthetic.state_names(k), tau=tau))
+    out['labels'] = np.array(names, dtype=str)
+    save('pij', **out)
+
+
+def albania_inputs():
+    tree = our_tree.read_tree(os.path.join(DATA, 'Albanian.tree.152tax.tre'))
+    df = pd.read_csv(os.path.join(DATA, 'data.txt'), index_col=0, header=0)[['Country']]
+    return tree, df
+
+
+def case_albania():
+    """Albania 152-tip tree, Country: optimised (acr() end to end) + fixed-parameter intermediates, F81/JC/EFT."""
+    for model_name in ('F81', 'JC', 'EFT'):
+        tree, df = albania_inputs()
+        res = racr(tree, df, prediction_method='MPPA', model=model_name, threads=1)[0]
+        model = res['model']
+        flat = our_tree.FlatForest.from_trees([tree])
+        nodes = flat.nodes
+        out = dict(tree_arrays(flat))
+        out.update(forest_stats_arrays(model.forest_stats))
+        out.update({'opt_' + k: v for k, v in model_arrays(model).items()})
+        out['opt_loglik'] = res['log_likelihood']
+        out['opt_loglik_restricted_JOINT'] = res['log_likelihood_restricted_JOINT']
+        out['opt_loglik_restricted_MAP'] = res['log_likelihood_restricted_MAP']
+        out['opt_loglik_restricted_MPPA'] = res['log_likelihood_restricted_MPPA']
+        out['opt_num_scenarios'] = float(res['num_scenarios'])
+        out['opt_num_unresolved_nodes'] = res['num_unresolved_nodes']
+        out['opt_num_states_per_node_avg'] = res['num_states_per_node_avg']
+        mp = res['marginal_probabilities']
+        out['opt_posterior'] = mp.loc[[n.name for n in nodes]].values
+        out['opt_posterior_index'] = np.array(mp.index, dtype=str)
+        states = model.states
+        s2i = {s: i for i, s in enumerate(states)}
+        sel = np.zeros((len(nodes), len(states)), dtype=np.int8)
+        for i, n in enumerate(nodes):
+            for s in getattr(n, 'Country'):
+                sel[i, s2i[s]] = 1
+        out['opt_selected_mppa'] = sel
+        out['opt_lh'] = collect(nodes, 'Country_LIKELIHOOD')
+        out['opt_lh_sf'] = collect(nodes, 'Country_LIKELIHOOD_SF')
+        out['opt_joint_state'] = collect(nodes, 'Country_JOINT_STATE', dtype=np.int64)
+
+        # tip annotation as given to acr (sets of state names -> mask), observed frequencies
+        tree2, df2 = albania_inputs()
+        from pastml.annotation import preannotate_forest
+        preannotate_forest([tree2], df=df2)
+        flat2 = our_tree.FlatForest.from_trees([tree2])
+        ann = np.zeros((flat2.n_nodes, len(states)), dtype=np.int8)
+        for i, n in enumerate(flat2.nodes):
+            for s in getattr(n, 'Country', set()):
+                ann[i, s2i[s]] = 1
+        out['annotation'] = ann
+        from pastml.acr import calculate_observed_freqs
+        _, obs, _ = calculate_observed_freqs('Country', [tree2], states)
+        out['observed_frequencies'] = obs
+
+        # fixed-parameter intermediates at the optimum
+        model.freeze()
+        _, cap = sweep_capture([tree2], 'Country', model, force_joint=True, prefix='fix_')
+        out.update(cap)
+        # and with tau > 0 (no alteration)
+        tree3, df3 = albania_inputs()
+        preannotate_forest([tree3], df=df3)
+        fs3 = RForestStats([tree3])
+        kwargs = dict(states=states, forest_stats=fs3, sf=float(model.sf), tau=0.01)
+        if model_name == 'F81':
+            m3 = RF81(frequencies=np.array(model.frequencies), **kwargs)
+        elif model_name == 'JC':
+            m3 = RJC(**kwargs)
+        else:
+            m3 = REFT(observed_frequencies=obs, **kwargs)
+        m3.freeze()
+        _, cap = sweep_capture([tree3], 'Country', m3, force_joint=False, prefix='tau_')
+        out.update(cap)
+        out.update({'tau_' + k: v for k, v in model_arrays(m3).items()})
+        save('albania_{}'.format(model_name), **out)
+
+
+def annotate_synthetic(flat, roots, character, k, char_index, missing_frac=0.0, seed=0):
+    states = synthetic.state_names(k)
+    tips_states = synthetic.tip_states(flat.n_tips, k, char_index)
+    rng = np.random.default_rng(seed)
+    for j, t in enumerate(flat.tips):
+        node = flat.nodes[t]
+        if missing_frac and rng.random() < missing_frac:
+            continue
+        node.add_feature(character, {states[tips_states[j]]})
+    return states, tips_states
+
+
+def case_synthetic_small():
+    """Balanced trees at reduced size, every intermediate stored (cfg2/cfg3/cfg4 shapes)."""
+    # cfg2 shape: JC k=4
+    for tag, n_levels, k, model_kind in (('jc_k4_L10', 10, 4, 'JC'), ('f81_k64_L8', 8, 64, 'F81'),
+                                        ('jtt_k20_L8', 8, 20, 'JTT'), ('hky_L8', 8, 4, 'HKY'),
+                                        ('f81_k5_L9', 9, 5, 'F81'), ('f81_k67_L5', 5, 67, 'F81'),
+                                        ('f81_k130_L4', 4, 130, 'F81')):
+        flat = synthetic.balanced_forest(n_levels)
+        roots = flat.to_tree_nodes()
+        fs = RForestStats(roots)
+        if model_kind == 'JTT':
+            states = JTT_STATES
+            tips_states = synthetic.tip_states(flat.n_tips, 20, 0)
+            for j, t in enumerate(flat.tips):
+                flat.nodes[t].add_feature('c0', {states[tips_states[j]]})
+            model = RJTT(forest_stats=fs, sf=1.)
+        elif model_kind == 'HKY':
+            from pastml.models.HKYModel import HKY_STATES
+            states = HKY_STATES
+            tips_states = synthetic.tip_states(flat.n_tips, 4, 0)
+            for j, t in enumerate(flat.tips):
+                flat.nodes[t].add_feature('c0', {states[tips_states[j]]})
+            model = RHKY(forest_stats=fs, sf=1., frequencies=synthetic.f81_frequencies(4, 0), kappa=3.)
+        else:
+            states, tips_states = annotate_synthetic(flat, roots, 'c0', k, 0)
+            if model_kind == 'JC':
+                model = RJC(states=states, forest_stats=fs, sf=1.)
+            else:
+                model = RF81(states=states, forest_stats=fs, sf=1., frequencies=synthetic.f81_frequencies(k, 0))
+        model.freeze()
+        flat2, cap = sweep_capture(roots, 'c0', model)
+        out = dict(tree_arrays(flat2))
+        out.update(forest_stats_arrays(fs))
+        out.update(model_arrays(model))
+        out.update(cap)
+        out['tip_states'] = tips_states
+        out['n_levels'] = n_levels
+        save('synthetic_' + tag, **out)
+
+
+def case_synthetic_large():
+    """cfg2 at full size (65 536 tips, JC k=4): lnL + strided samples; F81 k=64 at 16 384 tips for 2 characters."""
+    stride = 4099
+    flat = synthetic.balanced_forest(16)
+    roots = flat.to_tree_nodes()
+    fs = RForestStats(roots)
+    states, tips_states = annotate_synthetic(flat, roots, 'c0', 4, 0)
+    model = RJC(states=states, forest_stats=fs, sf=1.)
+    model.freeze()
+    flat2, cap = sweep_capture(roots, 'c0', model)
+    out = dict(forest_stats_arrays(fs))
+    out.update(model_arrays(model))
+    sample = np.arange(0, flat.n_nodes, stride)
+    out['sample'] = sample
+    for key, v in cap.items():
+        if isinstance(v, np.ndarray) and v.ndim >= 1 and len(v) == flat.n_nodes:
+            out[key] = v[sample]
+        else:
+            out[key] = v
+    out['n_levels'] = 16
+    save('synthetic_cfg2_full', **out)
+
+    flat = synthetic.balanced_forest(14)
+    for c in (0, 1):
+        roots = flat.to_tree_nodes()
+        fs = RForestStats(roots)
+        states, tips_states = annotate_synthetic(flat, roots, 'c', 64, c)
+        model = RF81(states=states, forest_stats=fs, sf=1., frequencies=synthetic.f81_frequencies(64, c))
+        model.freeze()
+        flat2, cap = sweep_capture(roots, 'c', model)
+        out = dict(forest_stats_arrays(fs))
+        out.update(model_arrays(model))
+        sample = np.arange(0, flat.n_nodes, 257)
+        out['sample'] = sample
+        for key, v in cap.items():
+            if isinstance(v, np.ndarray) and v.ndim >= 1 and len(v) == flat.n_nodes:
+                out[key] = v[sample]
+            else:
+                out[key] = v
+        out['n_levels'] = 14
+        out['character'] = c
+        save('synthetic_cfg4_L14_c{}'.format(c), **out)
+
+
+def case_edge():
+    """Polytomies, zero branches with conflicting annotations, missing / multi-state tips, forests, tau > 0."""
+    rng = np.random.default_rng(11)
+    for tag, kwargs, k, tau in (('poly', dict(n_tips=60, seed=3, max_arity=5, zero_frac=0.0), 6, 0),
+                                ('zero', dict(n_tips=80, seed=4, max_arity=3, zero_frac=0.3), 4, 0),
+                                ('zero_tau', dict(n_tips=80, seed=4, max_arity=3, zero_frac=0.3), 4, 0.02),
+                                ('forest', dict(n_tips=90, seed=5, max_arity=4, zero_frac=0.15, n_trees=3), 5, 0)):
+        flat = our_tree.FlatForest.random(**kwargs)
+        roots = [flat.nodes[r] for r in flat.roots]
+        states = synthetic.state_names(k)
+        # tips: 10% missing, 10% two states; a few internal nodes annotated too
+        for i, n in enumerate(flat.nodes):
+            u = rng.random()
+            if n.is_leaf():
+                if u < 0.1:
+                    continue
+                if u < 0.2:
+                    n.add_feature('ch', set(rng.choice(states, size=2, replace=False)))
+                else:
+                    n.add_feature('ch', {states[int(rng.integers(k))]})
+            elif u < 0.08:
+                n.add_feature('ch', {states[int(rng.integers(k))]})
+        # the annotation as given (sets of states per node), before any state selection overwrites the feature
+        ann = np.zeros((flat.n_nodes, k), dtype=np.int8)
+        s2i = {s: i for i, s in enumerate(states)}
+        for i, n in enumerate(flat.nodes):
+            for s in getattr(n, 'ch', set()):
+                ann[i, s2i[s]] = 1
+        fs = RForestStats(roots)
+        model = RF81(states=states, forest_stats=fs, frequencies=rng.dirichlet(np.ones(k)), tau=tau)
+        model.freeze()
+        out = {}
+        try:
+            flat2, cap = sweep_capture(roots, 'ch', model)
+            out.update(cap)
+            out['raised'] = False
+        except rml.PastMLLikelihoodError as e:
+            flat2 = our_tree.FlatForest.from_trees(roots)
+            out['raised'] = True
+            out['error_message'] = str(e)
+        out.update(tree_arrays(flat2))
+        out.update(forest_stats_arrays(fs))
+        out.update(model_arrays(model))
+        out['annotation'] = ann
+        save('edge_' + tag, **out)
+
+    # non-intersecting states across a zero-length internal branch whose nodes are both annotated ... with tau == 0
+    # the alteration rescues it; a genuine zero likelihood needs a zero branch to an *unannotated-cluster* conflict:
+    t = our_tree.read_tree('((a:0.1,b:0.2)i1:0,(c:0.1,d:0.3)i2:0.2)r:0;')
+    for n in t.traverse():
+        n.del_feature('ch')
+    states = synthetic.state_names(3)
+    byname = {n.name: n for n in t.traverse()}
+    byname['a'].add_feature('ch', {states[0]})
+    byname['b'].add_feature('ch', {states[0]})
+    byname['c'].add_feature('ch', {states[1]})
+    byname['d'].add_feature('ch', {states[2]})
+    fs = RForestStats([t])
+    model = RF81(states=states, forest_stats=fs, frequencies=np.array([0.2, 0.3, 0.5]))
+    model.freeze()
+    # restrict the root to state 1 and i1 (zero branch below the root) to state 0 *after* initialisation, without the
+    # annotation feature, so that alteration does not see them
+    rml.initialize_allowed_states(t, 'ch', states)
+    byname['r'].add_feature('ch_ALLOWED_STATES', np.array([0, 1, 0]))
+    byname['i1'].add_feature('ch_ALLOWED_STATES', np.array([1, 0, 0]))
+    flat = our_tree.FlatForest.from_trees([t])
+    masks = collect(flat.nodes, 'ch_ALLOWED_STATES', dtype=np.int8)
+    try:
+        rml.get_bottom_up_loglikelihood(t, 'ch', model, is_marginal=True, alter=True)
+        raised, msg = False, ''
+    except rml.PastMLLikelihoodError as e:
+        raised, msg = True, str(e)
+    out = dict(tree_arrays(flat))
+    out.update(model_arrays(model))
+    out.update(masks=masks, raised=raised, error_message=msg)
+    save('edge_zero_likelihood', **out)
+
+
+def case_hky_nucleotide():
+    """The reference's simulated nucleotide tree (tests/HKYF81Test.py): optimised F81 and HKY results."""
+    tab = 'tree.152taxa.sf_0.5.A_0.6.C_0.15.G_0.2.T_0.05'
+    df = pd.read_csv(os.path.join(DATA, tab + '.pastml.tab'), index_col=0, header=0, sep='\t')[['ACR']]
+    out = {}
+    for label, kw in (('f81', dict(model='F81')), ('hky_k1', dict(model='HKY', column2parameters={'ACR': {'kappa': 1}})),
+                      ('hky', dict(model='HKY'))):
+        tree = our_tree.read_tree(os.path.join(DATA, tab + '.nwk'))
+        res = racr(tree, df.copy(), prediction_method='MPPA', threads=1, **kw)[0]
+        model = res['model']
+        out.update({label + '_' + k: v for k, v in model_arrays(model).items()})
+        out[label + '_loglik'] = res['log_likelihood']
+        out[label + '_loglik_restricted_MPPA'] = res['log_likelihood_restricted_MPPA']
+        flat = our_tree.FlatForest.from_trees([tree])
+        out[label + '_posterior'] = res['marginal_probabilities'].loc[[n.name for n in flat.nodes]].values
+        out['node_names'] = np.array([n.name for n in flat.nodes], dtype=str)
+    save('nucleotide_hky_f81', **out)
+
+
+CASES = dict(data=copy_data, pij=case_pij, albania=case_albania, synthetic_small=case_synthetic_small,
+             synthetic_large=case_synthetic_large, edge=case_edge, nucleotide=case_hky_nucleotide)
+
+if __name__ == '__main__':
+    np.random.seed(239)
+    todo = sys.argv[1:] or list(CASES)
+    for name in todo:
+        print('=== ', name)
+        CASES[name]()

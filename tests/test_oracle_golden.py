@@ -1,0 +1,141 @@
+"""
+Pins the oracle (oracle/pastml_oracle.py) against the golden vectors produced by the real reference
+(tests/golden/make_golden.py).  CPU only.
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden, golden_forest, golden_spec
+from oracle import pastml_oracle as orc
+
+RTOL = 1e-11
+
+SWEEP_CASES = [('albania_F81', 'fix_'), ('albania_JC', 'fix_'), ('albania_EFT', 'fix_'),
+               ('albania_F81', 'tau_'), ('albania_JC', 'tau_'), ('albania_EFT', 'tau_'),
+               ('synthetic_jc_k4_L10', ''), ('synthetic_f81_k64_L8', ''), ('synthetic_jtt_k20_L8', ''),
+               ('synthetic_hky_L8', ''), ('synthetic_f81_k5_L9', ''), ('synthetic_f81_k67_L5', ''),
+               ('synthetic_f81_k130_L4', ''),
+               ('edge_poly', ''), ('edge_zero', ''), ('edge_zero_tau', ''), ('edge_forest', '')]
+
+
+def _spec(z, prefix):
+    # albania 'fix_' sweeps use the optimised model ('opt_' arrays); 'tau_' ones have their own
+    mp = {'fix_': 'opt_', 'tau_': 'tau_', '': ''}[prefix]
+    return golden_spec(z, mp)
+
+
+def test_pij_matches_reference():
+    z = load_golden('pij')
+    ts = z['ts']
+    for i, label in enumerate(z['labels']):
+        spec, (sf, tau, tf) = golden_spec(z, 'c{}_'.format(i))
+        P = np.array([orc.pij(spec, t, sf, tau, tf) for t in ts])
+        np.testing.assert_allclose(P, z['c{}_P'.format(i)], rtol=1e-13, atol=1e-15, err_msg=str(label))
+        np.testing.assert_allclose(P.sum(axis=2), 1, rtol=1e-12)
+
+
+def test_diagonalisation_matches_reference():
+    z = load_golden('pij')
+    for i, label in enumerate(z['labels']):
+        if 'c{}_rate_matrix'.format(i) not in z:
+            continue
+        d, a, ainv = orc.diagonalise(z['c{}_frequencies'.format(i)], z['c{}_rate_matrix'.format(i)])
+        assert np.array_equal(d, z['c{}_eig_d'.format(i)])
+        assert np.array_equal(a, z['c{}_eig_A'.format(i)])
+        assert np.array_equal(ainv, z['c{}_eig_Ainv'.format(i)])
+
+
+@pytest.mark.parametrize('name,prefix', SWEEP_CASES)
+def test_sweeps_match_reference(name, prefix):
+    z = load_golden(name)
+    forest = golden_forest(z)
+    spec, (sf, tau, tf) = _spec(z, prefix)
+    g = lambda key: z[prefix + key]
+    masks = g('masks_altered').astype(int)
+
+    r = orc.full_marginal_pass(forest, masks, spec, sf, tau, tf)
+    np.testing.assert_allclose(r['loglik'], g('loglik'), rtol=RTOL)
+    np.testing.assert_allclose(r['bu'], g('bu'), rtol=RTOL, atol=1e-300)
+    np.testing.assert_allclose(r['bu_sf'], g('bu_sf'), rtol=RTOL, atol=1e-9)
+    np.testing.assert_allclose(r['td'], g('td'), rtol=1e-9, atol=1e-300)
+    np.testing.assert_allclose(r['td_sf'], g('td_sf'), rtol=RTOL, atol=1e-9)
+    np.testing.assert_allclose(r['lh'], g('lh'), rtol=1e-9, atol=1e-300)
+    np.testing.assert_allclose(r['lh_sf'], g('lh_sf'), rtol=RTOL, atol=1e-9)
+    np.testing.assert_allclose(r['posterior'], g('posterior'), rtol=1e-9, atol=1e-300)
+    # invariant of pastml/ml.py:468-483: every node sees the same total likelihood
+    tot = np.log10(r['lh'].sum(axis=1)) - r['lh_sf']
+    np.testing.assert_allclose(tot, r['loglik_per_tree'][forest.tree_id] / np.log(10), rtol=1e-9)
+
+    # joint
+    j = orc.bottom_up(forest, masks, spec, sf, tau, tf, is_marginal=False)
+    np.testing.assert_allclose(j['loglik'], g('loglik_joint'), rtol=RTOL)
+    table = j['joint_table']
+    altered = g('altered_nodes')
+    orc.unalter_joint_table(table, g('masks_initial'), altered)
+    nonroot = forest.parent >= 0
+    assert np.array_equal(table[nonroot], g('joint_table')[nonroot])
+    state = orc.joint_backtrace(forest, j['bu'], table, spec['pi'])
+    assert np.array_equal(state, g('joint_state'))
+
+    # MAP / MPPA selection on the likelihoods multiplied by the initial masks of the altered nodes
+    lh = r['lh'].copy()
+    lh[altered] *= g('masks_initial')[altered]
+    sel_map = orc.choose_map(lh)
+    assert np.array_equal(sel_map, g('masks_map').argmax(axis=1))
+    assert np.all(g('masks_map').sum(axis=1) == 1)
+    sel, best_k = orc.choose_mppa(lh, state if bool(g('force_joint')) else None)
+    if len(altered) == 0:
+        # (with altered nodes the reference's MPPA also sees the masks saved by the restricted-MAP sweep,
+        #  ml.py:541-542 after :675-680 -- that stateful path is covered in tests/test_host_logic.py)
+        assert np.array_equal(sel, g('masks_mppa'))
+        assert int((best_k > 1).sum()) == int(g('mppa_num_unresolved'))
+        assert int(best_k.sum()) == int(g('mppa_num_states'))
+
+    # restricted likelihoods: marginal sweep with the selected masks (alter=True in the reference)
+    # (when nodes were altered the reference re-alters the *selected* masks: covered in tests/test_host_logic.py)
+    if len(altered) == 0:
+        for key, m in (('loglik_restricted_MAP', g('masks_map')), ('loglik_restricted_MPPA', g('masks_mppa'))):
+            rr = orc.bottom_up(forest, m.astype(int), spec, sf, tau, tf, True)
+            np.testing.assert_allclose(rr['loglik'], g(key), rtol=RTOL)
+
+
+def test_zero_likelihood_raises_like_reference():
+    z = load_golden('edge_zero_likelihood')
+    forest = golden_forest(z)
+    spec, (sf, tau, tf) = golden_spec(z)
+    assert bool(z['raised'])
+    with pytest.raises(orc.OracleLikelihoodError) as e:
+        orc.bottom_up(forest, z['masks'].astype(int), spec, sf, tau, tf, True)
+    names = z['node_names']
+    msg = str(z['error_message'])
+    assert 'parent node {} and its child node {}'.format(names[e.value.parent], names[e.value.child]) in msg
+
+
+def test_reference_pinned_values():
+    """The numbers the reference's own unit tests assert hold in the fixtures."""
+    for model, lnl, restricted, sf in (('F81', -110.178, -111.662, 3.841), ('JC', -121.873, -123.421, 4.951),
+                                      ('EFT', -123.173, -125.359, 5.38)):
+        z = load_golden('albania_' + model)
+        assert round(float(z['opt_loglik']), 3) == lnl
+        assert round(float(z['opt_loglik_restricted_MPPA']), 3) == restricted
+        assert abs(float(z['opt_sf']) - sf) < 1e-3
+        # and the oracle reproduces them from the optimised parameters
+        forest = golden_forest(z)
+        spec, (s, tau, tf) = golden_spec(z, 'opt_')
+        r = orc.bottom_up(forest, z['fix_masks_altered'].astype(int), spec, s, tau, tf, True)
+        np.testing.assert_allclose(r['loglik'], z['opt_loglik'], rtol=1e-12)
+
+
+def test_large_samples():
+    """cfg2 at full size and cfg4 shape at 16 384 tips: strided samples of the reference's posteriors."""
+    from pastml_amd import synthetic
+    z = load_golden('synthetic_cfg4_L14_c1')
+    flat = synthetic.balanced_forest(int(z['n_levels']))
+    c = int(z['character'])
+    masks = synthetic.one_hot_masks(flat, 64, synthetic.tip_states(flat.n_tips, 64, c))
+    spec, (sf, tau, tf) = golden_spec(z)
+    np.testing.assert_array_equal(spec['pi'], synthetic.f81_frequencies(64, c))
+    # a 4 096-tip subtree would not contain the sampled nodes; run the BU sweep only (about 10 s)
+    r = orc.bottom_up(flat, masks.astype(int), spec, sf, tau, tf, True)
+    np.testing.assert_allclose(r['loglik'], z['loglik'], rtol=1e-12)
+    np.testing.assert_allclose(r['bu'][z['sample']], z['bu'], rtol=1e-10, atol=1e-300)
