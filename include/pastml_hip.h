@@ -1,0 +1,153 @@
+/*
+ * pastml_hip.h -- C-ABI of libpastml_hip.so: the MI355X (gfx950) implementation of PastML's maximum-likelihood ACR
+ * hot path.  Plain pointers and sizes only; the caller owns every host buffer, the library owns the device buffers
+ * behind the opaque pml_ctx.  Every function returns a status (0 = PML_OK); pml_last_error() gives the message of the
+ * last failure on the calling thread.  A ctx may be used from one thread at a time; different ctxs are independent
+ * (each has its own HIP stream), which is how pastml.acr.acr()'s per-character thread pool (pastml/acr.py:226-231)
+ * maps onto the device.
+ *
+ * The reference (evolbioinfo/pastml) is pure Python and has no FFI: each entry point below names the reference
+ * function(s) whose arithmetic it replaces (paths relative to the reference repository).
+ *
+ * Layout conventions
+ *   nodes     forest-wide level (breadth-first) order: roots are ids 0..n_roots-1, the children of a node are
+ *             contiguous (first_child[n] .. first_child[n]+n_children[n]-1), every depth is a contiguous id range
+ *   columns   the batch axis: one column = one character (with its own masks and model parameters); all columns of
+ *             a ctx share the tree, the number of states k and the model kind
+ *   masks     allowed-state bit sets, W = (k+63)/64 uint64 words per (column, node), bit s of word s/64 = state s
+ *   vectors   double[k] per (column, node), column-major: index ((col * n_nodes + node) * k + state)
+ *   scales    every likelihood vector v carries a base-2 exponent E (true value = v * 2^E); the *_sf outputs are
+ *             converted to the reference's convention (base-10, true = v / 10^sf, pastml/ml.py:121,148)
+ */
+#ifndef PASTML_HIP_H
+#define PASTML_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pml_ctx pml_ctx;
+
+enum {
+    PML_OK = 0,
+    PML_ERR_INVALID = 1,      /* bad argument / call order */
+    PML_ERR_HIP = 2,          /* HIP runtime failure (message has the HIP error string) */
+    PML_ERR_UNSUPPORTED = 3,  /* e.g. k > 256 */
+    PML_ZERO_LIKELIHOOD = 4   /* pastml/ml.py:139-145: a parent/child pair has non-intersecting states */
+};
+
+enum { PML_MODEL_F81 = 0, PML_MODEL_HKY = 1, PML_MODEL_EIGEN = 2 };
+
+/* what pml_download() can fetch (debug / tests / host-side state selection) */
+enum {
+    PML_BUF_BU = 0,          /* double[n_nodes][k]  bottom-up vectors of one column (tips: their masks as 0/1)      */
+    PML_BUF_BU_SF = 1,       /* double[n_nodes]     their base-10 scale (reference BU_LH_SF convention)              */
+    PML_BUF_TD = 2,          /* double[n_nodes][k]  top-down vectors (defined for internal nodes; tips: NaN)         */
+    PML_BUF_TD_SF = 3,       /* double[n_nodes]                                                                        */
+    PML_BUF_POSTERIOR = 4,   /* double[n_nodes][k]  marginal posteriors                                                */
+    PML_BUF_LH_SUM = 5,      /* double[n_nodes]     sum of the (scaled) marginal likelihoods, in [1, 2)                */
+    PML_BUF_LH_SF = 6,       /* double[n_nodes]     base-10 scale of the marginal likelihoods (reference LH_SF)        */
+    PML_BUF_JOINT_TABLE = 7, /* int32[n_nodes][k]   argmax tables of the joint sweep (roots: undefined)               */
+    PML_BUF_JOINT_STATE = 8, /* int32[n_nodes]                                                                          */
+    PML_BUF_BRANCH_EXP = 9   /* double[n_nodes]     F81 family: e = exp(-mu t') per branch                             */
+};
+
+const char* pml_last_error(void);
+int pml_version(void);
+int pml_device_count(int* count);
+
+/* ---- context ------------------------------------------------------------------------------------------------- */
+int pml_ctx_create(int device, pml_ctx** out);
+int pml_ctx_destroy(pml_ctx* ctx);
+int pml_ctx_sync(pml_ctx* ctx);
+/* bytes of device memory currently held by the ctx / free on its device */
+int pml_ctx_memory(pml_ctx* ctx, uint64_t* held, uint64_t* device_free);
+
+/* ---- tree (replaces the ete3 traversals of pastml/ml.py:109,269,449) ------------------------------------------ */
+/*
+ * bu_order        internal nodes sorted by height (1..n_bu_levels); bu_offsets[n_bu_levels+1] delimits the levels
+ * td_parents      internal nodes sorted by depth; td_parent_offsets[n_td_levels+1] delimits them per depth
+ * td_offsets      [n_td_levels+1] id range of every depth level
+ * post_rank       rank of each node in the reference's processing order (trees in turn, post-order each); only used
+ *                 to report the same (parent, child) pair as pastml/ml.py:139-145 when the likelihood is zero
+ */
+int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots,
+                    const int32_t* parent, const int32_t* first_child, const int32_t* n_children, const double* dist,
+                    int32_t n_bu_levels, const int32_t* bu_offsets, const int32_t* bu_order,
+                    int32_t n_td_levels, const int32_t* td_offsets,
+                    const int32_t* td_parent_offsets, const int32_t* td_parents,
+                    const int32_t* post_rank);
+
+/* ---- characters (replaces initialize_allowed_states, pastml/ml.py:293-318) ------------------------------------- */
+int pml_chars_alloc(pml_ctx* ctx, int32_t n_cols, int32_t k);
+/* masks[col_end-col_begin][n_nodes][W] */
+int pml_masks_upload(pml_ctx* ctx, int32_t col_begin, int32_t col_end, const uint64_t* masks);
+/* fast path: internal nodes all ones, tip j (node id tip_ids[j]) one-hot at states[col][j], or all ones if < 0 */
+int pml_masks_from_tip_states(pml_ctx* ctx, int32_t col_begin, int32_t col_end,
+                              int32_t n_tips, const int32_t* tip_ids, const int32_t* states);
+/*
+ * Masks before zero-branch alteration (pastml/ml.py:352-387), needed only by the joint sweep to rewrite the argmax
+ * tables of altered nodes (unalter_zero_node_joint_states, pastml/ml.py:408-428).  NULL clears them.
+ */
+int pml_masks_initial_upload(pml_ctx* ctx, int32_t col_begin, int32_t col_end, const uint64_t* masks);
+
+/* ---- model parameters (replaces Model.transform_t + get_Pij_t state, pastml/models/__init__.py:269) -------------- */
+/* per column: pi[k]; scalars sf, tau, tau_factor (t' = (t + tau) * tau_factor * sf) */
+int pml_model_set_f81(pml_ctx* ctx, int32_t col_begin, int32_t col_end, const double* pi,
+                      const double* sf, const double* tau, const double* tau_factor);
+int pml_model_set_hky(pml_ctx* ctx, int32_t col_begin, int32_t col_end, const double* pi, const double* kappa,
+                      const double* sf, const double* tau, const double* tau_factor);
+/* d[k], A[k][k], Ainv[k][k] (row-major) per column: pastml/models/generator.py:16-30 */
+int pml_model_set_eigen(pml_ctx* ctx, int32_t col_begin, int32_t col_end, const double* pi,
+                        const double* d, const double* A, const double* Ainv,
+                        const double* sf, const double* tau, const double* tau_factor);
+
+/* ---- P(t) ---------------------------------------------------------------------------------------------------------- */
+/*
+ * P(t) of column col for n_t explicit branch lengths -> P_out[n_t][k][k] row-major.
+ * Replaces Model.get_Pij_t: pastml/models/F81Model.py:28-46, HKYModel.py:44-82, CustomRatesModel.py:70-79 +
+ * generator.py:54-65.
+ */
+int pml_pij(pml_ctx* ctx, int32_t col, int32_t n_t, const double* t, double* P_out);
+/*
+ * Materialises the per-branch transition data of every column on the device (F81 family: e = exp(-mu t') per
+ * branch; HKY / eigen models: the full k x k matrix per branch).  The sweeps call it implicitly when the model or
+ * the tree changed.  If P_out != NULL, additionally copies out P for every branch: P_out[n_cols][n_nodes][k][k].
+ */
+int pml_pij_batch(pml_ctx* ctx, double* P_out);
+
+/* ---- sweeps --------------------------------------------------------------------------------------------------------- */
+/*
+ * Bottom-up (Felsenstein / Pupko) sweep over all columns: pastml/ml.py:82-148 (get_bottom_up_loglikelihood,
+ * calc_node_bu_likelihood, rescale_log).  is_marginal != 0: sum over child states; == 0: max + argmax tables.
+ * loglik_out[n_cols] = sum over the trees of the forest of ln L.
+ * On PML_ZERO_LIKELIHOOD err_parent[col] / err_child[col] (node ids, -1 if the column is fine) name the pair the
+ * reference would have raised PastMLLikelihoodError for.
+ */
+int pml_bottom_up(pml_ctx* ctx, int is_marginal, double* loglik_out, int32_t* err_parent, int32_t* err_child);
+/*
+ * Top-down sweep + marginal likelihoods + posteriors, fused: pastml/ml.py:240-290 (calculate_top_down_likelihood),
+ * :431-465 (calculate_marginal_likelihoods), :486-502 (convert_likelihoods_to_probabilities).  Needs a preceding
+ * marginal pml_bottom_up with the same masks.  Outputs are optional (NULL = keep on the device only):
+ * posterior_out[n_cols][n_nodes][k], lh_sum_out / lh_sf_out[n_cols][n_nodes] such that
+ * log10(lh_sum) - lh_sf is the node's total log10-likelihood (the invariant of pastml/ml.py:468-483).
+ */
+int pml_top_down_marginals(pml_ctx* ctx, double* posterior_out, double* lh_sum_out, double* lh_sf_out);
+/*
+ * Joint reconstruction after a joint pml_bottom_up: pastml/ml.py:598-622 (choose_ancestral_states_joint).
+ * joint_state_out[n_cols][n_nodes].
+ */
+int pml_joint_backtrace(pml_ctx* ctx, int32_t* joint_state_out);
+
+/* ---- inspection ------------------------------------------------------------------------------------------------------ */
+int pml_download(pml_ctx* ctx, int what, int32_t col, void* out);
+/* HIP-event timer on the ctx's stream */
+int pml_timer_start(pml_ctx* ctx);
+int pml_timer_stop(pml_ctx* ctx, float* milliseconds);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

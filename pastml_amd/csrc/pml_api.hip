@@ -1,0 +1,949 @@
+// libpastml_hip.so -- C-ABI (include/pastml_hip.h) over the HIP kernels.  gfx950 only.
+#include "../../include/pastml_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "pml_kernels_pij.h"
+
+#define PML_VERSION 100
+
+static thread_local std::string g_last_error;
+
+static int fail(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                         \
+    do {                                                                                                      \
+        hipError_t _e = (expr);                                                                               \
+        if (_e != hipSuccess)                                                                                 \
+            return fail(PML_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+#define PML_TRY(expr)            \
+    do {                         \
+        int _s = (expr);         \
+        if (_s != PML_OK) return _s; \
+    } while (0)
+
+struct pml_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<void*> allocs;
+    size_t held = 0;
+
+    // tree
+    int N = 0, n_roots = 0, n_bu_levels = 0, n_td_levels = 0;
+    int *d_parent = nullptr, *d_first_child = nullptr, *d_n_children = nullptr, *d_post_rank = nullptr;
+    int *d_bu_order = nullptr, *d_td_parents = nullptr;
+    double* d_dist = nullptr;
+    std::vector<int> bu_offsets, td_offsets, td_parent_offsets, h_parent, h_n_children;
+
+    // columns
+    int C = 0, k = 0, ks = 0, W = 0, G = 0, R = 0;
+    u64 *d_masks = nullptr, *d_masks_init = nullptr;
+    bool has_init = false;
+    int kind = -1;
+    double *d_pi = nullptr, *d_mu = nullptr, *d_kappa = nullptr, *d_d = nullptr, *d_A = nullptr, *d_Ainv = nullptr;
+    double *d_sf = nullptr, *d_tau = nullptr, *d_tauf = nullptr;
+    std::vector<char> model_set;  // per column
+    bool prep_dirty = true;
+
+    // state
+    double *d_E = nullptr, *d_P = nullptr, *d_bu = nullptr, *d_S = nullptr, *d_td = nullptr, *d_post = nullptr,
+           *d_lhsum = nullptr, *d_loglik = nullptr;
+    i64 *d_be = nullptr, *d_te = nullptr, *d_lhe = nullptr;
+    int *d_J = nullptr, *d_js = nullptr;
+    u64* d_err = nullptr;
+    int bu_mode = -1;  // -1 invalid, 1 marginal, 0 joint
+    bool td_valid = false, js_valid = false;
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T>
+static int dev_alloc(pml_ctx* ctx, T** p, size_t count) {
+    *p = nullptr;
+    if (count == 0) count = 1;
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, count * sizeof(T));
+    if (e != hipSuccess)
+        return fail(PML_ERR_HIP, "hipMalloc of %zu bytes failed: %s", count * sizeof(T), hipGetErrorString(e));
+    ctx->allocs.push_back(q);
+    ctx->held += count * sizeof(T);
+    *p = (T*)q;
+    return PML_OK;
+}
+
+static void free_all(pml_ctx* ctx) {
+    for (void* p : ctx->allocs) (void)hipFree(p);
+    ctx->allocs.clear();
+    ctx->held = 0;
+}
+
+template <typename T>
+static int upload(pml_ctx* ctx, T* dst, const T* src, size_t count) {
+    HIP_TRY(hipMemcpyAsync(dst, src, count * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    return PML_OK;
+}
+
+static void pick_group(int k, int& G, int& R) {
+    R = k <= 32 ? 1 : (k <= 128 ? 2 : 4);
+    const int need = (k + R - 1) / R;
+    G = 1;
+    while (G < need) G <<= 1;
+}
+
+static int grid_for(int n_units, int units_per_block, int C) {
+    int blocks = (n_units + units_per_block - 1) / units_per_block;
+    int cap = 8192 / (C < 1 ? 1 : C);
+    if (cap < 8) cap = 8;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return blocks;
+}
+
+static PmlTree tree_of(const pml_ctx* c) {
+    PmlTree t;
+    t.N = c->N;
+    t.n_roots = c->n_roots;
+    t.parent = c->d_parent;
+    t.first_child = c->d_first_child;
+    t.n_children = c->d_n_children;
+    t.dist = c->d_dist;
+    t.post_rank = c->d_post_rank;
+    return t;
+}
+
+static PmlCols cols_of(const pml_ctx* c) {
+    PmlCols s;
+    s.k = c->k;
+    s.ks = c->ks;
+    s.W = c->W;
+    s.masks = c->d_masks;
+    s.masks_init = c->has_init ? c->d_masks_init : nullptr;
+    s.pi = c->d_pi;
+    return s;
+}
+
+static PmlState state_of(const pml_ctx* c) {
+    PmlState s;
+    s.E = c->d_E;
+    s.bu = c->d_bu;
+    s.S = c->d_S;
+    s.be = c->d_be;
+    s.td = c->d_td;
+    s.te = c->d_te;
+    s.post = c->d_post;
+    s.lhsum = c->d_lhsum;
+    s.lhe = c->d_lhe;
+    s.J = c->d_J;
+    s.js = c->d_js;
+    s.err = c->d_err;
+    return s;
+}
+
+static PmlModel model_of(const pml_ctx* c) {
+    PmlModel m;
+    m.kind = c->kind;
+    m.mu = c->d_mu;
+    m.kappa = c->d_kappa;
+    m.d = c->d_d;
+    m.A = c->d_A;
+    m.Ainv = c->d_Ainv;
+    m.sf = c->d_sf;
+    m.tau = c->d_tau;
+    m.tauf = c->d_tauf;
+    return m;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// (G, R) dispatch
+// ---------------------------------------------------------------------------------------------------------------------
+#define PML_GR_CASES(X)  \
+    X(1, 1)              \
+    X(2, 1)              \
+    X(4, 1)              \
+    X(8, 1)              \
+    X(16, 1)             \
+    X(32, 1)             \
+    X(64, 1)             \
+    X(32, 2)             \
+    X(64, 2)             \
+    X(64, 4)
+
+enum SweepKind { SW_BU_MARG, SW_BU_JOINT, SW_TD, SW_ROOTS };
+
+template <int G, int R>
+static void launch_sweep(pml_ctx* ctx, SweepKind what, const int* level, int n_level) {
+    const PmlTree t = tree_of(ctx);
+    const PmlCols c = cols_of(ctx);
+    const PmlState st = state_of(ctx);
+    const int upb = PML_WAVES_PER_BLOCK * (64 / G);
+    dim3 grid(grid_for(n_level, upb, ctx->C), ctx->C), block(PML_BLOCK);
+    const bool f81 = ctx->kind == PML_MODEL_F81;
+    switch (what) {
+        case SW_BU_MARG:
+            if (f81)
+                hipLaunchKernelGGL((bu_f81_kernel<G, R, false>), grid, block, 0, ctx->stream, t, c, st, level, n_level);
+            else
+                hipLaunchKernelGGL((bu_matrix_kernel<G, R, false>), grid, block, 0, ctx->stream, t, c, st, ctx->d_P,
+                                   level, n_level);
+            break;
+        case SW_BU_JOINT:
+            if (f81)
+                hipLaunchKernelGGL((bu_f81_kernel<G, R, true>), grid, block, 0, ctx->stream, t, c, st, level, n_level);
+            else
+                hipLaunchKernelGGL((bu_matrix_kernel<G, R, true>), grid, block, 0, ctx->stream, t, c, st, ctx->d_P,
+                                   level, n_level);
+            break;
+        case SW_TD:
+            if (f81)
+                hipLaunchKernelGGL((td_f81_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, level, n_level);
+            else
+                hipLaunchKernelGGL((td_matrix_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, ctx->d_P, level,
+                                   n_level);
+            break;
+        case SW_ROOTS:
+            hipLaunchKernelGGL((td_roots_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st);
+            break;
+    }
+}
+
+static int dispatch_sweep(pml_ctx* ctx, SweepKind what, const int* level, int n_level) {
+    if (n_level <= 0) return PML_OK;
+#define X(G_, R_)                                             \
+    if (ctx->G == G_ && ctx->R == R_) {                       \
+        launch_sweep<G_, R_>(ctx, what, level, n_level);      \
+        HIP_TRY(hipGetLastError());                           \
+        return PML_OK;                                        \
+    }
+    PML_GR_CASES(X)
+#undef X
+    return fail(PML_ERR_UNSUPPORTED, "no kernel for G=%d R=%d", ctx->G, ctx->R);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* pml_last_error(void) { return g_last_error.c_str(); }
+
+int pml_version(void) { return PML_VERSION; }
+
+int pml_device_count(int* count) {
+    if (!count) return fail(PML_ERR_INVALID, "count is NULL");
+    HIP_TRY(hipGetDeviceCount(count));
+    return PML_OK;
+}
+
+int pml_ctx_create(int device, pml_ctx** out) {
+    if (!out) return fail(PML_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return fail(PML_ERR_INVALID, "device %d out of range (0..%d)", device, n - 1);
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(PML_ERR_UNSUPPORTED, "device %d is %s; this library is built for gfx950 (MI355X) only", device,
+                    prop.gcnArchName);
+    pml_ctx* ctx = new pml_ctx();
+    ctx->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
+    if (e != hipSuccess) {
+        delete ctx;
+        return fail(PML_ERR_HIP, "stream/event creation failed: %s", hipGetErrorString(e));
+    }
+    *out = ctx;
+    return PML_OK;
+}
+
+int pml_ctx_destroy(pml_ctx* ctx) {
+    if (!ctx) return PML_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    free_all(ctx);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return PML_OK;
+}
+
+int pml_ctx_sync(pml_ctx* ctx) {
+    if (!ctx) return fail(PML_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PML_OK;
+}
+
+int pml_ctx_memory(pml_ctx* ctx, uint64_t* held, uint64_t* device_free) {
+    if (!ctx) return fail(PML_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    size_t f = 0, tot = 0;
+    HIP_TRY(hipMemGetInfo(&f, &tot));
+    if (held) *held = ctx->held;
+    if (device_free) *device_free = f;
+    return PML_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_t* parent, const int32_t* first_child,
+                    const int32_t* n_children, const double* dist, int32_t n_bu_levels, const int32_t* bu_offsets,
+                    const int32_t* bu_order, int32_t n_td_levels, const int32_t* td_offsets,
+                    const int32_t* td_parent_offsets, const int32_t* td_parents, const int32_t* post_rank) {
+    if (!ctx) return fail(PML_ERR_INVALID, "ctx is NULL");
+    if (n_nodes <= 0 || n_roots <= 0 || n_roots > n_nodes) return fail(PML_ERR_INVALID, "bad node/root counts");
+    if (!parent || !first_child || !n_children || !dist || !bu_offsets || !td_offsets || !td_parent_offsets ||
+        !post_rank)
+        return fail(PML_ERR_INVALID, "NULL tree array");
+    if (n_bu_levels < 0 || n_td_levels < 1) return fail(PML_ERR_INVALID, "bad level counts");
+    // host-side validation of everything the kernels index with (a bad index would fault the GPU)
+    int n_internal = 0;
+    for (int i = 0; i < n_nodes; ++i) {
+        const int nc = n_children[i];
+        if (nc < 0) return fail(PML_ERR_INVALID, "n_children[%d] < 0", i);
+        if (nc > 0) {
+            ++n_internal;
+            const long long fc = first_child[i];
+            if (fc <= i || fc + nc > n_nodes) return fail(PML_ERR_INVALID, "children of node %d out of range", i);
+            for (int j = 0; j < nc; ++j)
+                if (parent[fc + j] != i) return fail(PML_ERR_INVALID, "parent/child arrays disagree at node %d", i);
+        }
+        if (i < n_roots ? parent[i] != -1 : (parent[i] < 0 || parent[i] >= i))
+            return fail(PML_ERR_INVALID, "parent[%d] = %d is not valid for level-ordered ids", i, parent[i]);
+        if (!(dist[i] >= 0.0)) return fail(PML_ERR_INVALID, "dist[%d] is negative or NaN", i);
+        if (post_rank[i] < 0 || post_rank[i] >= n_nodes) return fail(PML_ERR_INVALID, "post_rank[%d] out of range", i);
+    }
+    if (bu_offsets[0] != 0 || bu_offsets[n_bu_levels] != n_internal)
+        return fail(PML_ERR_INVALID, "bu_offsets must cover the %d internal nodes", n_internal);
+    if (td_parent_offsets[0] != 0 || td_parent_offsets[n_td_levels] != n_internal)
+        return fail(PML_ERR_INVALID, "td_parent_offsets must cover the %d internal nodes", n_internal);
+    if (td_offsets[0] != 0 || td_offsets[1] != n_roots || td_offsets[n_td_levels] != n_nodes)
+        return fail(PML_ERR_INVALID, "td_offsets must start with the roots and cover all nodes");
+    if (n_internal > 0 && (!bu_order || !td_parents)) return fail(PML_ERR_INVALID, "NULL level array");
+    {
+        std::vector<char> seen(n_nodes, 0);
+        std::vector<int> height(n_nodes, 0);
+        for (int l = 0; l < n_bu_levels; ++l) {
+            if (bu_offsets[l + 1] < bu_offsets[l]) return fail(PML_ERR_INVALID, "bu_offsets not monotone");
+            for (int q = bu_offsets[l]; q < bu_offsets[l + 1]; ++q) {
+                const int n = bu_order[q];
+                if (n < 0 || n >= n_nodes || n_children[n] == 0 || seen[n])
+                    return fail(PML_ERR_INVALID, "bu_order[%d] = %d is not a distinct internal node", q, n);
+                seen[n] = 1;
+                // every internal child must sit in an earlier level
+                for (int j = 0; j < n_children[n]; ++j) {
+                    const int ch = first_child[n] + j;
+                    if (n_children[ch] > 0 && (!seen[ch] || height[ch] >= l + 1))
+                        return fail(PML_ERR_INVALID, "bu level %d: node %d precedes its child %d", l, n, ch);
+                }
+                height[n] = l + 1;
+            }
+        }
+        std::fill(seen.begin(), seen.end(), 0);
+        for (int l = 0; l < n_td_levels; ++l) {
+            if (td_parent_offsets[l + 1] < td_parent_offsets[l] || td_offsets[l + 1] < td_offsets[l])
+                return fail(PML_ERR_INVALID, "td offsets not monotone");
+            for (int q = td_parent_offsets[l]; q < td_parent_offsets[l + 1]; ++q) {
+                const int n = td_parents[q];
+                if (n < td_offsets[l] || n >= td_offsets[l + 1] || n_children[n] == 0 || seen[n])
+                    return fail(PML_ERR_INVALID, "td_parents[%d] = %d is not a distinct internal node of depth %d", q,
+                                n, l);
+                seen[n] = 1;
+            }
+        }
+    }
+
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    // a new tree resets everything the ctx holds
+    free_all(ctx);
+    hipStream_t stream = ctx->stream;
+    hipEvent_t e0 = ctx->ev0, e1 = ctx->ev1;
+    int device = ctx->device;
+    *ctx = pml_ctx();
+    ctx->stream = stream;
+    ctx->ev0 = e0;
+    ctx->ev1 = e1;
+    ctx->device = device;
+
+    ctx->N = n_nodes;
+    ctx->n_roots = n_roots;
+    ctx->n_bu_levels = n_bu_levels;
+    ctx->n_td_levels = n_td_levels;
+    ctx->bu_offsets.assign(bu_offsets, bu_offsets + n_bu_levels + 1);
+    ctx->td_offsets.assign(td_offsets, td_offsets + n_td_levels + 1);
+    ctx->td_parent_offsets.assign(td_parent_offsets, td_parent_offsets + n_td_levels + 1);
+    ctx->h_parent.assign(parent, parent + n_nodes);
+    ctx->h_n_children.assign(n_children, n_children + n_nodes);
+    PML_TRY(dev_alloc(ctx, &ctx->d_parent, n_nodes));
+    PML_TRY(dev_alloc(ctx, &ctx->d_first_child, n_nodes));
+    PML_TRY(dev_alloc(ctx, &ctx->d_n_children, n_nodes));
+    PML_TRY(dev_alloc(ctx, &ctx->d_post_rank, n_nodes));
+    PML_TRY(dev_alloc(ctx, &ctx->d_dist, n_nodes));
+    PML_TRY(dev_alloc(ctx, &ctx->d_bu_order, n_internal));
+    PML_TRY(dev_alloc(ctx, &ctx->d_td_parents, n_internal));
+    PML_TRY(upload(ctx, ctx->d_parent, parent, n_nodes));
+    PML_TRY(upload(ctx, ctx->d_first_child, first_child, n_nodes));
+    PML_TRY(upload(ctx, ctx->d_n_children, n_children, n_nodes));
+    PML_TRY(upload(ctx, ctx->d_post_rank, post_rank, n_nodes));
+    PML_TRY(upload(ctx, ctx->d_dist, dist, n_nodes));
+    if (n_internal) {
+        PML_TRY(upload(ctx, ctx->d_bu_order, bu_order, n_internal));
+        PML_TRY(upload(ctx, ctx->d_td_parents, td_parents, n_internal));
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PML_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+int pml_chars_alloc(pml_ctx* ctx, int32_t n_cols, int32_t k) {
+    if (!ctx || ctx->N == 0) return fail(PML_ERR_INVALID, "upload the tree first");
+    if (n_cols <= 0 || n_cols > 65535) return fail(PML_ERR_INVALID, "n_cols must be in 1..65535");
+    if (k <= 0) return fail(PML_ERR_INVALID, "k must be positive");
+    if (k > PML_MAX_STATES) return fail(PML_ERR_UNSUPPORTED, "k = %d states; at most %d are supported", k, PML_MAX_STATES);
+    if (ctx->C != 0) return fail(PML_ERR_INVALID, "columns already allocated for this tree (upload the tree again to reset)");
+    HIP_TRY(hipSetDevice(ctx->device));
+    ctx->C = n_cols;
+    ctx->k = k;
+    pick_group(k, ctx->G, ctx->R);
+    ctx->ks = (k + ctx->R - 1) / ctx->R * ctx->R;
+    ctx->W = (k + 63) / 64;
+    const size_t CN = (size_t)n_cols * ctx->N;
+    PML_TRY(dev_alloc(ctx, &ctx->d_masks, CN * ctx->W));
+    PML_TRY(dev_alloc(ctx, &ctx->d_pi, (size_t)n_cols * ctx->ks));
+    PML_TRY(dev_alloc(ctx, &ctx->d_sf, n_cols));
+    PML_TRY(dev_alloc(ctx, &ctx->d_tau, n_cols));
+    PML_TRY(dev_alloc(ctx, &ctx->d_tauf, n_cols));
+    PML_TRY(dev_alloc(ctx, &ctx->d_mu, n_cols));
+    PML_TRY(dev_alloc(ctx, &ctx->d_kappa, n_cols));
+    PML_TRY(dev_alloc(ctx, &ctx->d_loglik, n_cols));
+    PML_TRY(dev_alloc(ctx, &ctx->d_err, n_cols));
+    PML_TRY(dev_alloc(ctx, &ctx->d_bu, CN * ctx->ks));
+    PML_TRY(dev_alloc(ctx, &ctx->d_S, CN));
+    PML_TRY(dev_alloc(ctx, &ctx->d_be, CN));
+    PML_TRY(dev_alloc(ctx, &ctx->d_E, CN));
+    HIP_TRY(hipMemsetAsync(ctx->d_pi, 0, (size_t)n_cols * ctx->ks * sizeof(double), ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->d_be, 0, CN * sizeof(i64), ctx->stream));
+    // default masks: everything allowed
+    {
+        dim3 grid(grid_for((int)std::min<size_t>((size_t)ctx->N * ctx->W, 1u << 30), PML_BLOCK, n_cols), n_cols);
+        hipLaunchKernelGGL(masks_fill_kernel, grid, dim3(PML_BLOCK), 0, ctx->stream, ctx->N, ctx->W, ctx->k,
+                           ctx->d_masks, 0);
+        HIP_TRY(hipGetLastError());
+    }
+    ctx->model_set.assign(n_cols, 0);
+    ctx->prep_dirty = true;
+    ctx->bu_mode = -1;
+    ctx->td_valid = ctx->js_valid = false;
+    return PML_OK;
+}
+
+static int check_cols(pml_ctx* ctx, int cb, int ce) {
+    if (!ctx || ctx->C == 0) return fail(PML_ERR_INVALID, "allocate the columns first");
+    if (cb < 0 || ce > ctx->C || cb >= ce) return fail(PML_ERR_INVALID, "column range [%d, %d) out of 0..%d", cb, ce, ctx->C);
+    HIP_TRY(hipSetDevice(ctx->device));
+    return PML_OK;
+}
+
+static void invalidate(pml_ctx* ctx) {
+    ctx->prep_dirty = true;
+    ctx->bu_mode = -1;
+    ctx->td_valid = ctx->js_valid = false;
+}
+
+int pml_masks_upload(pml_ctx* ctx, int32_t col_begin, int32_t col_end, const uint64_t* masks) {
+    PML_TRY(check_cols(ctx, col_begin, col_end));
+    if (!masks) return fail(PML_ERR_INVALID, "masks is NULL");
+    const size_t per_col = (size_t)ctx->N * ctx->W;
+    // bits beyond k must be clear: the kernels trust the words
+    if (ctx->k % 64) {
+        const u64 valid = (1ull << (ctx->k % 64)) - 1ull;
+        const size_t n = per_col * (col_end - col_begin);
+        for (size_t i = ctx->W - 1; i < n; i += ctx->W)
+            if (masks[i] & ~valid) return fail(PML_ERR_INVALID, "mask word %zu has bits beyond k = %d", i, ctx->k);
+    }
+    PML_TRY(upload(ctx, ctx->d_masks + col_begin * per_col, (const u64*)masks, per_col * (col_end - col_begin)));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    invalidate(ctx);
+    return PML_OK;
+}
+
+int pml_masks_from_tip_states(pml_ctx* ctx, int32_t col_begin, int32_t col_end, int32_t n_tips,
+                              const int32_t* tip_ids, const int32_t* states) {
+    PML_TRY(check_cols(ctx, col_begin, col_end));
+    if (n_tips < 0 || (n_tips > 0 && (!tip_ids || !states))) return fail(PML_ERR_INVALID, "bad tip arrays");
+    const int nc = col_end - col_begin;
+    for (int j = 0; j < n_tips; ++j)
+        if (tip_ids[j] < 0 || tip_ids[j] >= ctx->N || ctx->h_n_children[tip_ids[j]] != 0)
+            return fail(PML_ERR_INVALID, "tip_ids[%d] = %d is not a tip", j, tip_ids[j]);
+    for (size_t i = 0; i < (size_t)nc * n_tips; ++i)
+        if (states[i] >= ctx->k) return fail(PML_ERR_INVALID, "state %d out of range (k = %d)", states[i], ctx->k);
+    dim3 grid(grid_for((int)std::min<size_t>((size_t)ctx->N * ctx->W, 1u << 30), PML_BLOCK, nc), nc);
+    hipLaunchKernelGGL(masks_fill_kernel, grid, dim3(PML_BLOCK), 0, ctx->stream, ctx->N, ctx->W, ctx->k, ctx->d_masks,
+                       col_begin);
+    HIP_TRY(hipGetLastError());
+    if (n_tips > 0) {
+        int *d_ids = nullptr, *d_states = nullptr;
+        HIP_TRY(hipMalloc((void**)&d_ids, sizeof(int) * n_tips));
+        hipError_t e = hipMalloc((void**)&d_states, sizeof(int) * (size_t)nc * n_tips);
+        if (e != hipSuccess) {
+            (void)hipFree(d_ids);
+            return fail(PML_ERR_HIP, "hipMalloc failed: %s", hipGetErrorString(e));
+        }
+        e = hipMemcpyAsync(d_ids, tip_ids, sizeof(int) * n_tips, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(d_states, states, sizeof(int) * (size_t)nc * n_tips, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) {
+            dim3 g2(grid_for(n_tips, PML_BLOCK, nc), nc);
+            hipLaunchKernelGGL(masks_tips_kernel, g2, dim3(PML_BLOCK), 0, ctx->stream, ctx->N, ctx->W, ctx->k,
+                               ctx->d_masks, col_begin, n_tips, d_ids, d_states);
+            e = hipGetLastError();
+        }
+        hipError_t e2 = hipStreamSynchronize(ctx->stream);
+        (void)hipFree(d_ids);
+        (void)hipFree(d_states);
+        if (e != hipSuccess) return fail(PML_ERR_HIP, "tip mask upload failed: %s", hipGetErrorString(e));
+        if (e2 != hipSuccess) return fail(PML_ERR_HIP, "tip mask upload failed: %s", hipGetErrorString(e2));
+    }
+    invalidate(ctx);
+    return PML_OK;
+}
+
+int pml_masks_initial_upload(pml_ctx* ctx, int32_t col_begin, int32_t col_end, const uint64_t* masks) {
+    PML_TRY(check_cols(ctx, col_begin, col_end));
+    if (!masks) {
+        ctx->has_init = false;
+        return PML_OK;
+    }
+    const size_t per_col = (size_t)ctx->N * ctx->W;
+    if (!ctx->d_masks_init) {
+        PML_TRY(dev_alloc(ctx, &ctx->d_masks_init, per_col * ctx->C));
+        // columns never given initial masks compare equal to nothing altered: start from the current masks
+        HIP_TRY(hipMemcpyAsync(ctx->d_masks_init, ctx->d_masks, per_col * ctx->C * sizeof(u64), hipMemcpyDeviceToDevice,
+                               ctx->stream));
+    }
+    if (ctx->k % 64) {
+        const u64 valid = (1ull << (ctx->k % 64)) - 1ull;
+        const size_t n = per_col * (col_end - col_begin);
+        for (size_t i = ctx->W - 1; i < n; i += ctx->W)
+            if (masks[i] & ~valid) return fail(PML_ERR_INVALID, "mask word %zu has bits beyond k = %d", i, ctx->k);
+    }
+    PML_TRY(upload(ctx, ctx->d_masks_init + col_begin * per_col, (const u64*)masks, per_col * (col_end - col_begin)));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->has_init = true;
+    ctx->bu_mode = -1;
+    return PML_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+static int set_common(pml_ctx* ctx, int kind, int cb, int ce, const double* pi, const double* sf, const double* tau,
+                      const double* tauf) {
+    PML_TRY(check_cols(ctx, cb, ce));
+    if (!pi || !sf || !tau || !tauf) return fail(PML_ERR_INVALID, "NULL parameter array");
+    if (ctx->kind != -1 && ctx->kind != kind) return fail(PML_ERR_INVALID, "all columns of a ctx must use one model kind");
+    if (kind == PML_MODEL_HKY && ctx->k != 4) return fail(PML_ERR_INVALID, "HKY needs k = 4");
+    const int nc = ce - cb;
+    for (int i = 0; i < nc; ++i)
+        if (!(sf[i] > 0.0) || !(tau[i] >= 0.0) || !(tauf[i] > 0.0) || !std::isfinite(sf[i]) || !std::isfinite(tau[i]))
+            return fail(PML_ERR_INVALID, "bad sf/tau/tau_factor for column %d", cb + i);
+    ctx->kind = kind;
+    if (ctx->ks == ctx->k) {
+        PML_TRY(upload(ctx, ctx->d_pi + (size_t)cb * ctx->ks, pi, (size_t)nc * ctx->k));
+    } else {
+        HIP_TRY(hipMemcpy2DAsync(ctx->d_pi + (size_t)cb * ctx->ks, ctx->ks * sizeof(double), pi, ctx->k * sizeof(double),
+                                 ctx->k * sizeof(double), nc, hipMemcpyHostToDevice, ctx->stream));
+    }
+    PML_TRY(upload(ctx, ctx->d_sf + cb, sf, nc));
+    PML_TRY(upload(ctx, ctx->d_tau + cb, tau, nc));
+    PML_TRY(upload(ctx, ctx->d_tauf + cb, tauf, nc));
+    for (int i = cb; i < ce; ++i) ctx->model_set[i] = 1;
+    invalidate(ctx);
+    return PML_OK;
+}
+
+int pml_model_set_f81(pml_ctx* ctx, int32_t col_begin, int32_t col_end, const double* pi, const double* sf,
+                      const double* tau, const double* tau_factor) {
+    PML_TRY(set_common(ctx, PML_MODEL_F81, col_begin, col_end, pi, sf, tau, tau_factor));
+    const int nc = col_end - col_begin;
+    std::vector<double> mu(nc);
+    for (int c = 0; c < nc; ++c) {
+        // mu = 1 / (1 - sum pi^2), F81Model.py:18-26 (numpy dot)
+        double dot = 0.0;
+        for (int s = 0; s < ctx->k; ++s) dot += pi[(size_t)c * ctx->k + s] * pi[(size_t)c * ctx->k + s];
+        mu[c] = 1.0 / (1.0 - dot);
+    }
+    PML_TRY(upload(ctx, ctx->d_mu + col_begin, mu.data(), nc));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PML_OK;
+}
+
+int pml_model_set_hky(pml_ctx* ctx, int32_t col_begin, int32_t col_end, const double* pi, const double* kappa,
+                      const double* sf, const double* tau, const double* tau_factor) {
+    if (!kappa) return fail(PML_ERR_INVALID, "kappa is NULL");
+    PML_TRY(set_common(ctx, PML_MODEL_HKY, col_begin, col_end, pi, sf, tau, tau_factor));
+    PML_TRY(upload(ctx, ctx->d_kappa + col_begin, kappa, col_end - col_begin));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PML_OK;
+}
+
+int pml_model_set_eigen(pml_ctx* ctx, int32_t col_begin, int32_t col_end, const double* pi, const double* d,
+                        const double* A, const double* Ainv, const double* sf, const double* tau,
+                        const double* tau_factor) {
+    if (!d || !A || !Ainv) return fail(PML_ERR_INVALID, "NULL eigen array");
+    PML_TRY(set_common(ctx, PML_MODEL_EIGEN, col_begin, col_end, pi, sf, tau, tau_factor));
+    const size_t k = ctx->k;
+    if (!ctx->d_d) {
+        PML_TRY(dev_alloc(ctx, &ctx->d_d, (size_t)ctx->C * k));
+        PML_TRY(dev_alloc(ctx, &ctx->d_A, (size_t)ctx->C * k * k));
+        PML_TRY(dev_alloc(ctx, &ctx->d_Ainv, (size_t)ctx->C * k * k));
+    }
+    const int nc = col_end - col_begin;
+    PML_TRY(upload(ctx, ctx->d_d + col_begin * k, d, nc * k));
+    PML_TRY(upload(ctx, ctx->d_A + col_begin * k * k, A, nc * k * k));
+    PML_TRY(upload(ctx, ctx->d_Ainv + col_begin * k * k, Ainv, nc * k * k));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PML_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+static int require_model(pml_ctx* ctx) {
+    if (!ctx || ctx->C == 0) return fail(PML_ERR_INVALID, "allocate the columns first");
+    for (int i = 0; i < ctx->C; ++i)
+        if (!ctx->model_set[i]) return fail(PML_ERR_INVALID, "model parameters of column %d were never set", i);
+    HIP_TRY(hipSetDevice(ctx->device));
+    return PML_OK;
+}
+
+static int run_prep(pml_ctx* ctx) {
+    if (!ctx->prep_dirty) return PML_OK;
+    const PmlTree t = tree_of(ctx);
+    const PmlCols c = cols_of(ctx);
+    const PmlModel m = model_of(ctx);
+    if (ctx->kind == PML_MODEL_F81) {
+        dim3 grid(grid_for(ctx->N, PML_BLOCK, ctx->C), ctx->C);
+        hipLaunchKernelGGL(f81_prep_kernel, grid, dim3(PML_BLOCK), 0, ctx->stream, t, c, ctx->d_mu, ctx->d_sf,
+                           ctx->d_tau, ctx->d_tauf, state_of(ctx));
+        HIP_TRY(hipGetLastError());
+    } else {
+        if (!ctx->d_P) PML_TRY(dev_alloc(ctx, &ctx->d_P, (size_t)ctx->C * ctx->N * ctx->k * ctx->ks));
+        if (ctx->kind == PML_MODEL_HKY) {
+            dim3 grid(grid_for(ctx->N, PML_BLOCK, ctx->C), ctx->C);
+            hipLaunchKernelGGL(pij_hky_kernel, grid, dim3(PML_BLOCK), 0, ctx->stream, t, c, m, ctx->d_P);
+        } else {
+            const int k = ctx->k;
+            size_t lds = ((size_t)2 * k * (k + 1) + k) * sizeof(double);
+            int use_lds = 1;
+            if (lds > 64 * 1024) {  // default dynamic-LDS limit; larger state spaces read A / Ainv through the caches
+                use_lds = 0;
+                lds = (size_t)k * sizeof(double);
+            }
+            int bpb = (ctx->N + 2047) / 2048;
+            if (bpb < 16) bpb = 16;
+            dim3 grid((ctx->N + bpb - 1) / bpb, ctx->C);
+            hipLaunchKernelGGL(pij_eigen_kernel, grid, dim3(PML_BLOCK), lds, ctx->stream, t, c, m, ctx->d_P, bpb, use_lds);
+        }
+        HIP_TRY(hipGetLastError());
+    }
+    ctx->prep_dirty = false;
+    return PML_OK;
+}
+
+int pml_pij(pml_ctx* ctx, int32_t col, int32_t n_t, const double* ts, double* P_out) {
+    PML_TRY(require_model(ctx));
+    if (col < 0 || col >= ctx->C) return fail(PML_ERR_INVALID, "column out of range");
+    if (n_t <= 0 || !ts || !P_out) return fail(PML_ERR_INVALID, "bad t / output arrays");
+    const size_t kk = (size_t)ctx->k * ctx->k;
+    double *d_t = nullptr, *d_out = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_t, sizeof(double) * n_t));
+    hipError_t e = hipMalloc((void**)&d_out, sizeof(double) * kk * n_t);
+    if (e != hipSuccess) {
+        (void)hipFree(d_t);
+        return fail(PML_ERR_HIP, "hipMalloc failed: %s", hipGetErrorString(e));
+    }
+    e = hipMemcpyAsync(d_t, ts, sizeof(double) * n_t, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        const size_t total = kk * n_t;
+        dim3 grid((unsigned)std::min<size_t>((total + PML_BLOCK - 1) / PML_BLOCK, 65535));
+        hipLaunchKernelGGL(pij_explicit_kernel, grid, dim3(PML_BLOCK), 0, ctx->stream, cols_of(ctx), model_of(ctx), col,
+                           n_t, d_t, d_out);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(P_out, d_out, sizeof(double) * kk * n_t, hipMemcpyDeviceToHost, ctx->stream);
+    hipError_t e2 = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_t);
+    (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(PML_ERR_HIP, "pml_pij failed: %s", hipGetErrorString(e));
+    if (e2 != hipSuccess) return fail(PML_ERR_HIP, "pml_pij failed: %s", hipGetErrorString(e2));
+    return PML_OK;
+}
+
+int pml_pij_batch(pml_ctx* ctx, double* P_out) {
+    PML_TRY(require_model(ctx));
+    PML_TRY(run_prep(ctx));
+    if (P_out) {
+        const size_t kk = (size_t)ctx->k * ctx->k;
+        double* d_out = nullptr;
+        HIP_TRY(hipMalloc((void**)&d_out, sizeof(double) * kk * ctx->N));
+        hipError_t e = hipSuccess;
+        for (int col = 0; col < ctx->C && e == hipSuccess; ++col) {
+            if (ctx->kind == PML_MODEL_F81) {
+                // expand the stored e per branch: same arithmetic as the explicit kernel
+                const size_t total = kk * ctx->N;
+                dim3 grid((unsigned)std::min<size_t>((total + PML_BLOCK - 1) / PML_BLOCK, 65535));
+                hipLaunchKernelGGL(pij_explicit_kernel, grid, dim3(PML_BLOCK), 0, ctx->stream, cols_of(ctx),
+                                   model_of(ctx), col, ctx->N, ctx->d_dist, d_out);
+                e = hipGetLastError();
+                if (e == hipSuccess)
+                    e = hipMemcpyAsync(P_out + (size_t)col * ctx->N * kk, d_out, sizeof(double) * kk * ctx->N,
+                                       hipMemcpyDeviceToHost, ctx->stream);
+            } else {
+                // the matrices the sweeps use, transposed back on the host
+                std::vector<double> tmp((size_t)ctx->N * ctx->k * ctx->ks);
+                e = hipMemcpyAsync(tmp.data(), ctx->d_P + (size_t)col * ctx->N * ctx->k * ctx->ks,
+                                   tmp.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+                if (e == hipSuccess) {
+                    double* out = P_out + (size_t)col * ctx->N * kk;
+                    for (int n = 0; n < ctx->N; ++n)
+                        for (int i = 0; i < ctx->k; ++i)
+                            for (int j = 0; j < ctx->k; ++j)
+                                out[(size_t)n * kk + (size_t)i * ctx->k + j] =
+                                    tmp[((size_t)n * ctx->k + j) * ctx->ks + i];
+                }
+            }
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        }
+        (void)hipFree(d_out);
+        if (e != hipSuccess) return fail(PML_ERR_HIP, "pml_pij_batch failed: %s", hipGetErrorString(e));
+    }
+    return PML_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+int pml_bottom_up(pml_ctx* ctx, int is_marginal, double* loglik_out, int32_t* err_parent, int32_t* err_child) {
+    PML_TRY(require_model(ctx));
+    if (!loglik_out) return fail(PML_ERR_INVALID, "loglik_out is NULL");
+    PML_TRY(run_prep(ctx));
+    const size_t CN = (size_t)ctx->C * ctx->N;
+    if (!is_marginal && !ctx->d_J) {
+        PML_TRY(dev_alloc(ctx, &ctx->d_J, CN * ctx->ks));
+        PML_TRY(dev_alloc(ctx, &ctx->d_js, CN));
+    }
+    ctx->bu_mode = -1;
+    ctx->td_valid = ctx->js_valid = false;
+    HIP_TRY(hipMemsetAsync(ctx->d_err, 0xFF, sizeof(u64) * ctx->C, ctx->stream));
+    for (int l = 0; l < ctx->n_bu_levels; ++l) {
+        const int a = ctx->bu_offsets[l], b = ctx->bu_offsets[l + 1];
+        PML_TRY(dispatch_sweep(ctx, is_marginal ? SW_BU_MARG : SW_BU_JOINT, ctx->d_bu_order + a, b - a));
+    }
+    hipLaunchKernelGGL(loglik_kernel, dim3((ctx->C + PML_BLOCK - 1) / PML_BLOCK), dim3(PML_BLOCK), 0, ctx->stream,
+                       tree_of(ctx), cols_of(ctx), state_of(ctx), ctx->C, is_marginal ? 1 : 0, ctx->d_loglik);
+    HIP_TRY(hipGetLastError());
+    std::vector<u64> err(ctx->C);
+    HIP_TRY(hipMemcpyAsync(loglik_out, ctx->d_loglik, sizeof(double) * ctx->C, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(err.data(), ctx->d_err, sizeof(u64) * ctx->C, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    int status = PML_OK;
+    for (int c = 0; c < ctx->C; ++c) {
+        int ep = -1, ec = -1;
+        if (err[c] != ~0ull) {
+            ec = (int)(err[c] & 0xffffffffull);
+            ep = ctx->h_parent[ec];
+            if (status == PML_OK)
+                status = fail(PML_ZERO_LIKELIHOOD, "zero likelihood in column %d between parent %d and child %d", c, ep, ec);
+        }
+        if (err_parent) err_parent[c] = ep;
+        if (err_child) err_child[c] = ec;
+    }
+    if (status == PML_OK) ctx->bu_mode = is_marginal ? 1 : 0;
+    return status;
+}
+
+int pml_top_down_marginals(pml_ctx* ctx, double* posterior_out, double* lh_sum_out, double* lh_sf_out) {
+    PML_TRY(require_model(ctx));
+    if (ctx->bu_mode != 1) return fail(PML_ERR_INVALID, "pml_top_down_marginals needs a successful marginal pml_bottom_up first");
+    const size_t CN = (size_t)ctx->C * ctx->N;
+    if (!ctx->d_td) {
+        PML_TRY(dev_alloc(ctx, &ctx->d_td, CN * ctx->ks));
+        PML_TRY(dev_alloc(ctx, &ctx->d_te, CN));
+        PML_TRY(dev_alloc(ctx, &ctx->d_post, CN * ctx->ks));
+        PML_TRY(dev_alloc(ctx, &ctx->d_lhsum, CN));
+        PML_TRY(dev_alloc(ctx, &ctx->d_lhe, CN));
+    }
+    PML_TRY(dispatch_sweep(ctx, SW_ROOTS, nullptr, ctx->n_roots));
+    for (int l = 0; l < ctx->n_td_levels; ++l) {
+        const int a = ctx->td_parent_offsets[l], b = ctx->td_parent_offsets[l + 1];
+        PML_TRY(dispatch_sweep(ctx, SW_TD, ctx->d_td_parents + a, b - a));
+    }
+    ctx->td_valid = true;
+    if (posterior_out) {
+        if (ctx->ks == ctx->k) {
+            HIP_TRY(hipMemcpyAsync(posterior_out, ctx->d_post, CN * ctx->k * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        } else {
+            HIP_TRY(hipMemcpy2DAsync(posterior_out, ctx->k * sizeof(double), ctx->d_post, ctx->ks * sizeof(double),
+                                     ctx->k * sizeof(double), CN, hipMemcpyDeviceToHost, ctx->stream));
+        }
+    }
+    if (lh_sum_out)
+        HIP_TRY(hipMemcpyAsync(lh_sum_out, ctx->d_lhsum, CN * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<i64> lhe;
+    if (lh_sf_out) {
+        lhe.resize(CN);
+        HIP_TRY(hipMemcpyAsync(lhe.data(), ctx->d_lhe, CN * sizeof(i64), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (lh_sf_out) {
+        const double l2 = std::log10(2.0);
+        for (size_t i = 0; i < CN; ++i) lh_sf_out[i] = -(double)lhe[i] * l2;
+    }
+    return PML_OK;
+}
+
+int pml_joint_backtrace(pml_ctx* ctx, int32_t* joint_state_out) {
+    PML_TRY(require_model(ctx));
+    if (ctx->bu_mode != 0) return fail(PML_ERR_INVALID, "pml_joint_backtrace needs a successful joint pml_bottom_up first");
+    for (int l = 1; l < ctx->n_td_levels; ++l) {
+        const int a = ctx->td_offsets[l], b = ctx->td_offsets[l + 1];
+        if (b <= a) continue;
+        dim3 grid(grid_for(b - a, PML_BLOCK, ctx->C), ctx->C);
+        hipLaunchKernelGGL(joint_backtrace_kernel, grid, dim3(PML_BLOCK), 0, ctx->stream, tree_of(ctx), cols_of(ctx),
+                           state_of(ctx), a, b);
+        HIP_TRY(hipGetLastError());
+    }
+    ctx->js_valid = true;
+    if (joint_state_out)
+        HIP_TRY(hipMemcpyAsync(joint_state_out, ctx->d_js, (size_t)ctx->C * ctx->N * sizeof(int), hipMemcpyDeviceToHost,
+                               ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PML_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+static int fetch_vectors(pml_ctx* ctx, const double* src, int col, double* out) {
+    const size_t N = ctx->N;
+    if (ctx->ks == ctx->k) {
+        HIP_TRY(hipMemcpyAsync(out, src + (size_t)col * N * ctx->ks, N * ctx->k * sizeof(double), hipMemcpyDeviceToHost,
+                               ctx->stream));
+    } else {
+        HIP_TRY(hipMemcpy2DAsync(out, ctx->k * sizeof(double), src + (size_t)col * N * ctx->ks, ctx->ks * sizeof(double),
+                                 ctx->k * sizeof(double), N, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PML_OK;
+}
+
+static int fetch_exponents(pml_ctx* ctx, const i64* src, int col, double* out) {
+    std::vector<i64> tmp(ctx->N);
+    HIP_TRY(hipMemcpyAsync(tmp.data(), src + (size_t)col * ctx->N, ctx->N * sizeof(i64), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const double l2 = std::log10(2.0);
+    for (int i = 0; i < ctx->N; ++i) out[i] = -(double)tmp[i] * l2;
+    return PML_OK;
+}
+
+int pml_download(pml_ctx* ctx, int what, int32_t col, void* out) {
+    PML_TRY(require_model(ctx));
+    if (col < 0 || col >= ctx->C || !out) return fail(PML_ERR_INVALID, "bad column / output");
+    const size_t N = ctx->N;
+    const double nan = std::numeric_limits<double>::quiet_NaN();
+    switch (what) {
+        case PML_BUF_BU: {
+            if (ctx->bu_mode < 0) return fail(PML_ERR_INVALID, "no valid bottom-up sweep");
+            double* o = (double*)out;
+            PML_TRY(fetch_vectors(ctx, ctx->d_bu, col, o));
+            std::vector<u64> m(N * ctx->W);
+            HIP_TRY(hipMemcpy(m.data(), ctx->d_masks + (size_t)col * N * ctx->W, m.size() * sizeof(u64), hipMemcpyDeviceToHost));
+            for (size_t n = 0; n < N; ++n)
+                if (ctx->h_n_children[n] == 0)
+                    for (int s = 0; s < ctx->k; ++s) o[n * ctx->k + s] = (double)((m[n * ctx->W + (s >> 6)] >> (s & 63)) & 1ull);
+            return PML_OK;
+        }
+        case PML_BUF_BU_SF: {
+            if (ctx->bu_mode < 0) return fail(PML_ERR_INVALID, "no valid bottom-up sweep");
+            PML_TRY(fetch_exponents(ctx, ctx->d_be, col, (double*)out));
+            for (size_t n = 0; n < N; ++n)
+                if (ctx->h_n_children[n] == 0) ((double*)out)[n] = 0.0;
+            return PML_OK;
+        }
+        case PML_BUF_TD: {
+            if (!ctx->td_valid) return fail(PML_ERR_INVALID, "no valid top-down sweep");
+            double* o = (double*)out;
+            PML_TRY(fetch_vectors(ctx, ctx->d_td, col, o));
+            for (size_t n = 0; n < N; ++n)
+                if (ctx->h_n_children[n] == 0 && ctx->h_parent[n] >= 0)
+                    for (int s = 0; s < ctx->k; ++s) o[n * ctx->k + s] = nan;
+            return PML_OK;
+        }
+        case PML_BUF_TD_SF: {
+            if (!ctx->td_valid) return fail(PML_ERR_INVALID, "no valid top-down sweep");
+            PML_TRY(fetch_exponents(ctx, ctx->d_te, col, (double*)out));
+            for (size_t n = 0; n < N; ++n)
+                if (ctx->h_n_children[n] == 0 && ctx->h_parent[n] >= 0) ((double*)out)[n] = nan;
+            return PML_OK;
+        }
+        case PML_BUF_POSTERIOR:
+            if (!ctx->td_valid) return fail(PML_ERR_INVALID, "no valid top-down sweep");
+            return fetch_vectors(ctx, ctx->d_post, col, (double*)out);
+        case PML_BUF_LH_SUM:
+            if (!ctx->td_valid) return fail(PML_ERR_INVALID, "no valid top-down sweep");
+            HIP_TRY(hipMemcpy(out, ctx->d_lhsum + (size_t)col * N, N * sizeof(double), hipMemcpyDeviceToHost));
+            return PML_OK;
+        case PML_BUF_LH_SF:
+            if (!ctx->td_valid) return fail(PML_ERR_INVALID, "no valid top-down sweep");
+            return fetch_exponents(ctx, ctx->d_lhe, col, (double*)out);
+        case PML_BUF_JOINT_TABLE: {
+            if (ctx->bu_mode != 0) return fail(PML_ERR_INVALID, "no valid joint sweep");
+            HIP_TRY(hipMemcpy2D(out, ctx->k * sizeof(int), ctx->d_J + (size_t)col * N * ctx->ks, ctx->ks * sizeof(int),
+                                ctx->k * sizeof(int), N, hipMemcpyDeviceToHost));
+            return PML_OK;
+        }
+        case PML_BUF_JOINT_STATE:
+            if (!ctx->js_valid) return fail(PML_ERR_INVALID, "no valid joint back-trace");
+            HIP_TRY(hipMemcpy(out, ctx->d_js + (size_t)col * N, N * sizeof(int), hipMemcpyDeviceToHost));
+            return PML_OK;
+        case PML_BUF_BRANCH_EXP:
+            if (ctx->kind != PML_MODEL_F81) return fail(PML_ERR_INVALID, "branch exponentials exist for the F81 family only");
+            PML_TRY(run_prep(ctx));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            HIP_TRY(hipMemcpy(out, ctx->d_E + (size_t)col * N, N * sizeof(double), hipMemcpyDeviceToHost));
+            return PML_OK;
+        default:
+            return fail(PML_ERR_INVALID, "unknown buffer id %d", what);
+    }
+}
+
+int pml_timer_start(pml_ctx* ctx) {
+    if (!ctx) return fail(PML_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+    return PML_OK;
+}
+
+int pml_timer_stop(pml_ctx* ctx, float* milliseconds) {
+    if (!ctx || !milliseconds) return fail(PML_ERR_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+    HIP_TRY(hipEventSynchronize(ctx->ev1));
+    HIP_TRY(hipEventElapsedTime(milliseconds, ctx->ev0, ctx->ev1));
+    return PML_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,141 @@
+// Device-side helpers shared by the sweep kernels (gfx950, wave64).
+//
+// Work decomposition used everywhere: a *unit* is one (node, column) pair; it is processed by a group of G
+// consecutive lanes of one wavefront (G a power of two, 1..64), each lane owning R consecutive states
+// (state = g * R + r).  G * R >= k.  64 / G units share a wavefront; reductions over the states of a unit are
+// butterflies over the G lanes, so they are deterministic (fixed order) and never leave the wavefront.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define PML_BLOCK 256
+#define PML_WAVES_PER_BLOCK 4
+
+typedef unsigned long long u64;
+typedef long long i64;
+
+// lazy rescaling band: a vector is renormalised (max -> [1, 2)) when a non-zero entry leaves [2^-PML_BAND, 2^PML_BAND]
+#define PML_BAND 200
+
+template <int G>
+__device__ __forceinline__ double group_sum(double v) {
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <int G>
+__device__ __forceinline__ double group_max(double v) {
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// (value, index) arg-max with numpy semantics: the first (lowest) index among equal maxima wins
+template <int G>
+__device__ __forceinline__ void group_argmax_first(double& v, int& idx) {
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) {
+        double ov = __shfl_xor(v, o, 64);
+        int oi = __shfl_xor(idx, o, 64);
+        if (ov > v || (ov == v && oi < idx)) {
+            v = ov;
+            idx = oi;
+        }
+    }
+}
+
+template <int G>
+__device__ __forceinline__ bool group_any(bool p) {
+    u64 b = __ballot(p);
+    if (G == 64) return b != 0ull;
+    const int base = (threadIdx.x & 63) & ~(G - 1);
+    return ((b >> base) & ((1ull << (G & 63)) - 1ull)) != 0ull;
+}
+
+template <int R>
+__device__ __forceinline__ void load_vec(const double* __restrict__ p, double (&v)[R]) {
+    if (R == 1) {
+        v[0] = p[0];
+    } else if (R == 2) {
+        double2 t = *reinterpret_cast<const double2*>(p);
+        v[0] = t.x;
+        v[1] = t.y;
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; r += 2) {
+            double2 t = *reinterpret_cast<const double2*>(p + r);
+            v[r] = t.x;
+            v[r + 1] = t.y;
+        }
+    }
+}
+
+template <int R>
+__device__ __forceinline__ void store_vec(double* __restrict__ p, const double (&v)[R]) {
+    if (R == 1) {
+        p[0] = v[0];
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; r += 2) {
+            double2 t;
+            t.x = v[r];
+            t.y = v[r + 1];
+            *reinterpret_cast<double2*>(p + r) = t;
+        }
+    }
+}
+
+template <int R>
+__device__ __forceinline__ void store_vec_i32(int* __restrict__ p, const int (&v)[R]) {
+    if (R == 1) {
+        p[0] = v[0];
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; r += 2) {
+            int2 t;
+            t.x = v[r];
+            t.y = v[r + 1];
+            *reinterpret_cast<int2*>(p + r) = t;
+        }
+    }
+}
+
+// mask bits of the R states owned by a lane -> 0.0 / 1.0 (R divides 64, so they share a word)
+template <int R>
+__device__ __forceinline__ void mask_to_vec(u64 word, int s0, int k, double (&v)[R]) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int s = s0 + r;
+        v[r] = (s < k && ((word >> (s & 63)) & 1ull)) ? 1.0 : 0.0;
+    }
+}
+
+// Renormalises acc (max -> [1, 2)) if any non-zero entry left the band; returns the exponent taken out
+// (true value = acc * 2^returned).
+template <int G, int R>
+__device__ __forceinline__ int lazy_rescale(double (&acc)[R]) {
+    bool out_of_band = false;
+    double m = 0.0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const double a = acc[r];
+        m = fmax(m, a);
+        out_of_band |= (a != 0.0) && (a < 0x1p-200 || a > 0x1p+200);
+    }
+    if (!group_any<G>(out_of_band)) return 0;
+    m = group_max<G>(m);
+    if (!(m > 0.0) || isinf(m)) return 0;
+    const int ex = ilogb(m);
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = scalbn(acc[r], -ex);
+    return ex;
+}
+
+// first allowed state of a multi-word mask (== np.argmax of the 0/1 array, pastml/ml.py:421)
+__device__ __forceinline__ int first_allowed(const u64* __restrict__ m, int W) {
+    for (int w = 0; w < W; ++w) {
+        if (m[w]) return w * 64 + __builtin_ctzll(m[w]);
+    }
+    return 0;
+}

@@ -1,0 +1,140 @@
+// Per-branch transition matrices P(t) = exp(Q t').
+#pragma once
+#include "pml_kernels_matrix.h"
+
+struct PmlModel {
+    int kind;
+    const double* mu;     // [C]        F81
+    const double* kappa;  // [C]        HKY
+    const double* d;      // [C][k]     eigen
+    const double* A;      // [C][k][k]
+    const double* Ainv;   // [C][k][k]
+    const double* sf;     // [C]
+    const double* tau;    // [C]
+    const double* tauf;   // [C]
+};
+
+// HKY85 closed form (pastml/models/HKYModel.py:55-82); states A, C, G, T = 0..3.  p[i][j].
+__device__ __forceinline__ void hky_matrix(const double* __restrict__ pi, double kappa, double tt, double (&p)[4][4]) {
+    const double pa = pi[0], pc = pi[1], pg = pi[2], pt = pi[3];
+    const double pag = pa + pg, pct = pc + pt;
+    const double beta = .5 / (pag * pct + kappa * (pa * pg + pc * pt));
+    const double eb = exp(-beta * tt);
+    const double ect = exp(-beta * tt * (1. + pct * (kappa - 1.))) / pct;
+    const double eag = exp(-beta * tt * (1. + pag * (kappa - 1.))) / pag;
+    const double sct = (pct + pag * eb) / pct;
+    const double sag = (pag + pct * eb) / pag;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) p[i][j] = (1. - eb) * pi[j];
+    p[3][3] = pt * sct + pc * ect;
+    p[3][1] = pc * sct - pc * ect;
+    p[1][3] = pt * sct - pt * ect;
+    p[1][1] = pc * sct + pt * ect;
+    p[0][0] = pa * sag + pg * eag;
+    p[0][2] = pg * sag - pg * eag;
+    p[2][0] = pa * sag - pa * eag;
+    p[2][2] = pg * sag + pa * eag;
+}
+
+// HKY: one thread per (branch, column); stores the transposed 4x4 (row stride ks = 4)
+__global__ void __launch_bounds__(PML_BLOCK)
+pij_hky_kernel(PmlTree t, PmlCols c, PmlModel m, double* __restrict__ P) {
+    const int col = blockIdx.y;
+    const size_t colN = (size_t)col * t.N;
+    const double* pi = c.pi + (size_t)col * c.ks;
+    for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < t.N; n += gridDim.x * blockDim.x) {
+        const double tt = (t.dist[n] + m.tau[col]) * m.tauf[col] * m.sf[col];
+        double p[4][4];
+        hky_matrix(pi, m.kappa[col], tt, p);
+        double* out = P + (colN + n) * 16;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) out[j * 4 + i] = p[i][j];
+    }
+}
+
+// Eigen models: P = A diag(exp(d t')) Ainv (pastml/models/generator.py:54-65).
+// One workgroup walks a chunk of branches of one column; A and Ainv^T are staged once in LDS (rows padded by one
+// double against bank conflicts), exp(d t') per branch in LDS; thread e computes output element (i = e % k, j = e / k)
+// so that the transposed store Pt[j][i] is coalesced.
+__global__ void __launch_bounds__(PML_BLOCK)
+pij_eigen_kernel(PmlTree t, PmlCols c, PmlModel m, double* __restrict__ P, int branches_per_block, int use_lds) {
+    extern __shared__ double smem[];
+    const int k = c.k, ks = c.ks;
+    const int col = blockIdx.y;
+    const size_t colN = (size_t)col * t.N;
+    const int ldk = k + 1;
+    double* sA = smem;                                // [k][k+1]   A[i][m]
+    double* sBt = sA + (use_lds ? k * ldk : 0);       // [k][k+1]   Ainv^T[j][m] = Ainv[m][j]
+    double* sE = sBt + (use_lds ? k * ldk : 0);       // [k]
+    const double* gA = m.A + (size_t)col * k * k;
+    const double* gB = m.Ainv + (size_t)col * k * k;
+    const double* gd = m.d + (size_t)col * k;
+    if (use_lds) {
+        for (int e = threadIdx.x; e < k * k; e += blockDim.x) {
+            const int r = e / k, q = e % k;
+            sA[r * ldk + q] = gA[e];
+            sBt[q * ldk + r] = gB[e];  // gB[r][q] = Ainv[m=r][j=q]
+        }
+    }
+    const double sfc = m.sf[col], tau = m.tau[col], tf = m.tauf[col];
+    const int b0 = blockIdx.x * branches_per_block;
+    const int b1 = min(t.N, b0 + branches_per_block);
+    for (int n = b0; n < b1; ++n) {
+        const double tt = (t.dist[n] + tau) * tf * sfc;
+        __syncthreads();
+        for (int q = threadIdx.x; q < k; q += blockDim.x) sE[q] = exp(gd[q] * tt);
+        __syncthreads();
+        double* out = P + (colN + n) * (size_t)k * ks;
+        for (int e = threadIdx.x; e < k * k; e += blockDim.x) {
+            const int i = e % k, j = e / k;
+            double acc = 0.0;
+            if (use_lds) {
+                const double* a = sA + i * ldk;
+                const double* b = sBt + j * ldk;
+                for (int q = 0; q < k; ++q) acc += (a[q] * sE[q]) * b[q];
+            } else {
+                for (int q = 0; q < k; ++q) acc += (gA[i * k + q] * sE[q]) * gB[q * k + j];
+            }
+            out[(size_t)j * ks + i] = acc;
+        }
+        if (ks > k) {
+            const int pad = ks - k;
+            for (int e = threadIdx.x; e < k * pad; e += blockDim.x) out[(size_t)(e / pad) * ks + k + e % pad] = 0.0;
+        }
+    }
+}
+
+// Explicit row-major P for a list of branch lengths (API get_Pij_t, tests): one thread per output element.
+__global__ void __launch_bounds__(PML_BLOCK)
+pij_explicit_kernel(PmlCols c, PmlModel m, int col, int n_t, const double* __restrict__ ts, double* __restrict__ out) {
+    const int k = c.k;
+    const size_t total = (size_t)n_t * k * k;
+    const double* pi = c.pi + (size_t)col * c.ks;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int j = (int)(e % k);
+        const int i = (int)((e / k) % k);
+        const size_t b = e / ((size_t)k * k);
+        const double tt = (ts[b] + m.tau[col]) * m.tauf[col] * m.sf[col];
+        double v;
+        if (m.kind == 0) {
+            const double mu = m.mu[col];
+            const double ex = isinf(mu) ? 0.0 : exp(-mu * tt);
+            v = (1.0 - ex) * pi[j] + (i == j ? ex : 0.0);
+        } else if (m.kind == 1) {
+            double p[4][4];
+            hky_matrix(pi, m.kappa[col], tt, p);
+            v = p[i][j];
+        } else {
+            const double* A = m.A + (size_t)col * k * k;
+            const double* B = m.Ainv + (size_t)col * k * k;
+            const double* d = m.d + (size_t)col * k;
+            v = 0.0;
+            for (int q = 0; q < k; ++q) v += (A[i * k + q] * exp(d[q] * tt)) * B[q * k + j];
+        }
+        out[e] = v;
+    }
+}

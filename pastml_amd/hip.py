@@ -1,0 +1,365 @@
+"""
+ctypes binding of libpastml_hip.so (C-ABI: include/pastml_hip.h) and the :class:`Engine` that owns one device
+context (= one tree + one batch of columns sharing k and the model kind).
+
+There is no CPU fallback: if the shared library is missing or no MI355X is visible, every entry point raises
+:class:`HipUnavailableError`.
+"""
+import ctypes
+import os
+import threading
+
+import numpy as np
+
+from pastml_amd.models import KIND_F81, KIND_HKY, KIND_EIGEN
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libpastml_hip.so')
+
+PML_OK, PML_ERR_INVALID, PML_ERR_HIP, PML_ERR_UNSUPPORTED, PML_ZERO_LIKELIHOOD = 0, 1, 2, 3, 4
+
+BUF_BU, BUF_BU_SF, BUF_TD, BUF_TD_SF, BUF_POSTERIOR, BUF_LH_SUM, BUF_LH_SF, BUF_JOINT_TABLE, BUF_JOINT_STATE, \
+    BUF_BRANCH_EXP = range(10)
+
+MAX_STATES = 256
+
+
+class HipUnavailableError(RuntimeError):
+    pass
+
+
+class HipError(RuntimeError):
+    def __init__(self, status, message):
+        RuntimeError.__init__(self, 'libpastml_hip: {} (status {})'.format(message, status))
+        self.status = status
+
+
+class ZeroLikelihoodError(HipError):
+    """PML_ZERO_LIKELIHOOD: carries, per column, the (parent, child) node ids (or -1)."""
+
+    def __init__(self, message, err_parent, err_child):
+        HipError.__init__(self, PML_ZERO_LIKELIHOOD, message)
+        self.err_parent = err_parent
+        self.err_child = err_child
+
+
+_c_int32_p = ctypes.POINTER(ctypes.c_int32)
+_c_double_p = ctypes.POINTER(ctypes.c_double)
+_c_uint64_p = ctypes.POINTER(ctypes.c_uint64)
+_ctx_p = ctypes.c_void_p
+
+# name -> argument types (all functions return int unless listed in _RESTYPES)
+SIGNATURES = {
+    'pml_last_error': [],
+    'pml_version': [],
+    'pml_device_count': [ctypes.POINTER(ctypes.c_int)],
+    'pml_ctx_create': [ctypes.c_int, ctypes.POINTER(_ctx_p)],
+    'pml_ctx_destroy': [_ctx_p],
+    'pml_ctx_sync': [_ctx_p],
+    'pml_ctx_memory': [_ctx_p, _c_uint64_p, _c_uint64_p],
+    'pml_tree_upload': [_ctx_p, ctypes.c_int32, ctypes.c_int32, _c_int32_p, _c_int32_p, _c_int32_p, _c_double_p,
+                        ctypes.c_int32, _c_int32_p, _c_int32_p, ctypes.c_int32, _c_int32_p, _c_int32_p, _c_int32_p,
+                        _c_int32_p],
+    'pml_chars_alloc': [_ctx_p, ctypes.c_int32, ctypes.c_int32],
+    'pml_masks_upload': [_ctx_p, ctypes.c_int32, ctypes.c_int32, _c_uint64_p],
+    'pml_masks_from_tip_states': [_ctx_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _c_int32_p, _c_int32_p],
+    'pml_masks_initial_upload': [_ctx_p, ctypes.c_int32, ctypes.c_int32, _c_uint64_p],
+    'pml_model_set_f81': [_ctx_p, ctypes.c_int32, ctypes.c_int32, _c_double_p, _c_double_p, _c_double_p, _c_double_p],
+    'pml_model_set_hky': [_ctx_p, ctypes.c_int32, ctypes.c_int32, _c_double_p, _c_double_p, _c_double_p, _c_double_p,
+                          _c_double_p],
+    'pml_model_set_eigen': [_ctx_p, ctypes.c_int32, ctypes.c_int32, _c_double_p, _c_double_p, _c_double_p,
+                            _c_double_p, _c_double_p, _c_double_p, _c_double_p],
+    'pml_pij': [_ctx_p, ctypes.c_int32, ctypes.c_int32, _c_double_p, _c_double_p],
+    'pml_pij_batch': [_ctx_p, _c_double_p],
+    'pml_bottom_up': [_ctx_p, ctypes.c_int, _c_double_p, _c_int32_p, _c_int32_p],
+    'pml_top_down_marginals': [_ctx_p, _c_double_p, _c_double_p, _c_double_p],
+    'pml_joint_backtrace': [_ctx_p, _c_int32_p],
+    'pml_download': [_ctx_p, ctypes.c_int, ctypes.c_int32, ctypes.c_void_p],
+    'pml_timer_start': [_ctx_p],
+    'pml_timer_stop': [_ctx_p, ctypes.POINTER(ctypes.c_float)],
+}
+_RESTYPES = {'pml_last_error': ctypes.c_char_p}
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def library_path():
+    return _LIB_PATH
+
+
+def load_library():
+    """Loads libpastml_hip.so (without touching the GPU) and declares the prototypes."""
+    global _lib
+    with _lib_lock:
+        if _lib is None:
+            if not os.path.exists(_LIB_PATH):
+                raise HipUnavailableError(
+                    '{} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                    '(hipcc --offload-arch=gfx950). There is no CPU fallback for the likelihood path.'.format(_LIB_PATH))
+            lib = ctypes.CDLL(_LIB_PATH)
+            for name, argtypes in SIGNATURES.items():
+                fn = getattr(lib, name)
+                fn.argtypes = argtypes
+                fn.restype = _RESTYPES.get(name, ctypes.c_int)
+            _lib = lib
+    return _lib
+
+
+def _check(status):
+    if status != PML_OK:
+        raise HipError(status, load_library().pml_last_error().decode())
+
+
+def device_count():
+    n = ctypes.c_int(0)
+    lib = load_library()
+    if lib.pml_device_count(ctypes.byref(n)) != PML_OK:
+        return 0
+    return n.value
+
+
+def default_device():
+    for var in ('PASTML_HIP_DEVICE', 'LOCAL_RANK'):
+        if var in os.environ:
+            return int(os.environ[var])
+    return 0
+
+
+def _as(arr, dtype):
+    return np.ascontiguousarray(arr, dtype=dtype)
+
+
+def _ptr(arr, ctype):
+    return arr.ctypes.data_as(ctypes.POINTER(ctype))
+
+
+def pack_masks(masks, k):
+    """0/1 array [..., k] -> uint64 words [..., W] (bit s of word s // 64 = state s)."""
+    masks = np.asarray(masks)
+    W = (k + 63) // 64
+    bits = np.packbits(masks.astype(bool), axis=-1, bitorder='little')
+    pad = W * 8 - bits.shape[-1]
+    if pad:
+        bits = np.concatenate([bits, np.zeros(bits.shape[:-1] + (pad,), dtype=np.uint8)], axis=-1)
+    return np.ascontiguousarray(bits).view('<u8').reshape(masks.shape[:-1] + (W,))
+
+
+class Engine(object):
+    """
+    One device context: a flat forest, ``n_cols`` columns with ``k`` states each, one model kind.
+
+    >>> eng = Engine(flat, n_cols=1, k=5)
+    >>> eng.set_masks(masks)                 # [n_cols, N, k] 0/1
+    >>> eng.set_models([model])              # objects with kernel_spec() / rate_params(), or (spec, rates) tuples
+    >>> lnl = eng.bottom_up()                # [n_cols]
+    >>> post, lh_sum, lh_sf = eng.top_down_marginals()
+    """
+
+    def __init__(self, flat, n_cols, k, device=None):
+        lib = load_library()
+        if device_count() < 1:
+            raise HipUnavailableError('no HIP device visible: the likelihood path needs an MI355X (gfx950)')
+        self._lib = lib
+        self._ctx = _ctx_p()
+        self.device = default_device() if device is None else device
+        _check(lib.pml_ctx_create(self.device, ctypes.byref(self._ctx)))
+        self.flat = flat
+        self.n_nodes = flat.n_nodes
+        self.n_cols = n_cols
+        self.k = k
+        self.kind = None
+        i32 = ctypes.c_int32
+        arrays = dict(parent=_as(flat.parent, np.int32), first_child=_as(flat.first_child, np.int32),
+                      n_children=_as(flat.n_children, np.int32), dist=_as(flat.dist, np.float64),
+                      bu_offsets=_as(flat.bu_offsets, np.int32), bu_order=_as(flat.bu_order, np.int32),
+                      td_offsets=_as(flat.td_offsets, np.int32),
+                      td_parent_offsets=_as(flat.td_parent_offsets, np.int32),
+                      td_parents=_as(flat.td_parents, np.int32), post_rank=_as(flat.post_rank, np.int32))
+        try:
+            _check(lib.pml_tree_upload(
+                self._ctx, flat.n_nodes, len(flat.roots), _ptr(arrays['parent'], i32), _ptr(arrays['first_child'], i32),
+                _ptr(arrays['n_children'], i32), _ptr(arrays['dist'], ctypes.c_double),
+                flat.n_bu_levels, _ptr(arrays['bu_offsets'], i32), _ptr(arrays['bu_order'], i32),
+                flat.n_td_levels, _ptr(arrays['td_offsets'], i32), _ptr(arrays['td_parent_offsets'], i32),
+                _ptr(arrays['td_parents'], i32), _ptr(arrays['post_rank'], i32)))
+            _check(lib.pml_chars_alloc(self._ctx, n_cols, k))
+        except Exception:
+            self.close()
+            raise
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, '_ctx', None) is not None and self._ctx.value is not None:
+            self._lib.pml_ctx_destroy(self._ctx)
+            self._ctx = _ctx_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def sync(self):
+        _check(self._lib.pml_ctx_sync(self._ctx))
+
+    def memory(self):
+        held, free = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        _check(self._lib.pml_ctx_memory(self._ctx, ctypes.byref(held), ctypes.byref(free)))
+        return held.value, free.value
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def set_masks(self, masks, col_begin=0):
+        """masks: 0/1 array [n, N, k] (or [N, k] for one column)."""
+        masks = np.asarray(masks)
+        if masks.ndim == 2:
+            masks = masks[None]
+        if masks.shape[1:] != (self.n_nodes, self.k):
+            raise ValueError('masks must be [cols, {}, {}], got {}'.format(self.n_nodes, self.k, masks.shape))
+        words = pack_masks(masks, self.k)
+        _check(self._lib.pml_masks_upload(self._ctx, col_begin, col_begin + len(masks), _ptr(words, ctypes.c_uint64)))
+
+    def set_initial_masks(self, masks, col_begin=0):
+        """Masks before zero-branch alteration (joint sweeps only); None clears them."""
+        if masks is None:
+            _check(self._lib.pml_masks_initial_upload(self._ctx, 0, self.n_cols, None))
+            return
+        masks = np.asarray(masks)
+        if masks.ndim == 2:
+            masks = masks[None]
+        words = pack_masks(masks, self.k)
+        _check(self._lib.pml_masks_initial_upload(self._ctx, col_begin, col_begin + len(masks),
+                                                  _ptr(words, ctypes.c_uint64)))
+
+    def set_tip_states(self, states, col_begin=0):
+        """states: int [n, n_tips] state index of every tip of ``flat.tips`` (-1 = missing); internal nodes free."""
+        states = _as(states, np.int32)
+        if states.ndim == 1:
+            states = states[None]
+        tips = _as(self.flat.tips, np.int32)
+        if states.shape[1] != len(tips):
+            raise ValueError('expected {} tip states per column'.format(len(tips)))
+        _check(self._lib.pml_masks_from_tip_states(self._ctx, col_begin, col_begin + len(states), len(tips),
+                                                   _ptr(tips, ctypes.c_int32), _ptr(states, ctypes.c_int32)))
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def set_models(self, models, col_begin=0):
+        """models: list (one per column) of Model objects or (spec dict, (sf, tau, tau_factor)) tuples."""
+        specs, rates = [], []
+        for m in models:
+            if isinstance(m, tuple):
+                spec, r = m
+            else:
+                spec, r = m.kernel_spec(), m.rate_params()
+            specs.append(spec)
+            rates.append(r)
+        kinds = {s['kind'] for s in specs}
+        if len(kinds) != 1:
+            raise ValueError('all columns of an Engine must use the same model kind')
+        kind = kinds.pop()
+        n = len(specs)
+        dbl = ctypes.c_double
+        pi = _as(np.stack([s['pi'] for s in specs]), np.float64)
+        if pi.shape != (n, self.k):
+            raise ValueError('frequencies must have {} entries'.format(self.k))
+        sf = _as([r[0] for r in rates], np.float64)
+        tau = _as([r[1] for r in rates], np.float64)
+        tf = _as([r[2] for r in rates], np.float64)
+        cb, ce = col_begin, col_begin + n
+        if kind == KIND_F81:
+            _check(self._lib.pml_model_set_f81(self._ctx, cb, ce, _ptr(pi, dbl), _ptr(sf, dbl), _ptr(tau, dbl),
+                                               _ptr(tf, dbl)))
+        elif kind == KIND_HKY:
+            kappa = _as([s['kappa'] for s in specs], np.float64)
+            _check(self._lib.pml_model_set_hky(self._ctx, cb, ce, _ptr(pi, dbl), _ptr(kappa, dbl), _ptr(sf, dbl),
+                                               _ptr(tau, dbl), _ptr(tf, dbl)))
+        elif kind == KIND_EIGEN:
+            for s in specs:
+                if np.iscomplexobj(s['d']) or np.iscomplexobj(s['A']):
+                    raise ValueError('complex eigen-decomposition: the rate matrix is not reversible')
+            d = _as(np.stack([s['d'] for s in specs]), np.float64)
+            A = _as(np.stack([s['A'] for s in specs]), np.float64)
+            Ainv = _as(np.stack([s['Ainv'] for s in specs]), np.float64)
+            _check(self._lib.pml_model_set_eigen(self._ctx, cb, ce, _ptr(pi, dbl), _ptr(d, dbl), _ptr(A, dbl),
+                                                 _ptr(Ainv, dbl), _ptr(sf, dbl), _ptr(tau, dbl), _ptr(tf, dbl)))
+        else:
+            raise ValueError('unknown model kind {}'.format(kind))
+        self.kind = kind
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def pij(self, ts, col=0):
+        ts = _as(ts, np.float64)
+        out = np.empty((len(ts), self.k, self.k), dtype=np.float64)
+        _check(self._lib.pml_pij(self._ctx, col, len(ts), _ptr(ts, ctypes.c_double), _ptr(out, ctypes.c_double)))
+        return out
+
+    def pij_batch(self, copy_out=False):
+        out = None
+        if copy_out:
+            out = np.empty((self.n_cols, self.n_nodes, self.k, self.k), dtype=np.float64)
+        _check(self._lib.pml_pij_batch(self._ctx, None if out is None else _ptr(out, ctypes.c_double)))
+        return out
+
+    def bottom_up(self, is_marginal=True):
+        lnl = np.empty(self.n_cols, dtype=np.float64)
+        ep = np.empty(self.n_cols, dtype=np.int32)
+        ec = np.empty(self.n_cols, dtype=np.int32)
+        status = self._lib.pml_bottom_up(self._ctx, 1 if is_marginal else 0, _ptr(lnl, ctypes.c_double),
+                                         _ptr(ep, ctypes.c_int32), _ptr(ec, ctypes.c_int32))
+        if status == PML_ZERO_LIKELIHOOD:
+            raise ZeroLikelihoodError(self._lib.pml_last_error().decode(), ep, ec)
+        _check(status)
+        return lnl
+
+    def top_down_marginals(self, posterior=True, lh=True):
+        CN = (self.n_cols, self.n_nodes)
+        post = np.empty(CN + (self.k,), dtype=np.float64) if posterior else None
+        lh_sum = np.empty(CN, dtype=np.float64) if lh else None
+        lh_sf = np.empty(CN, dtype=np.float64) if lh else None
+        dbl = ctypes.c_double
+        _check(self._lib.pml_top_down_marginals(self._ctx, None if post is None else _ptr(post, dbl),
+                                                None if lh_sum is None else _ptr(lh_sum, dbl),
+                                                None if lh_sf is None else _ptr(lh_sf, dbl)))
+        return post, lh_sum, lh_sf
+
+    def joint_backtrace(self, copy_out=True):
+        out = np.empty((self.n_cols, self.n_nodes), dtype=np.int32) if copy_out else None
+        _check(self._lib.pml_joint_backtrace(self._ctx, None if out is None else _ptr(out, ctypes.c_int32)))
+        return out
+
+    def download(self, what, col=0):
+        N, k = self.n_nodes, self.k
+        if what in (BUF_BU, BUF_TD, BUF_POSTERIOR):
+            out = np.empty((N, k), dtype=np.float64)
+        elif what == BUF_JOINT_TABLE:
+            out = np.empty((N, k), dtype=np.int32)
+        elif what == BUF_JOINT_STATE:
+            out = np.empty(N, dtype=np.int32)
+        else:
+            out = np.empty(N, dtype=np.float64)
+        _check(self._lib.pml_download(self._ctx, what, col, out.ctypes.data_as(ctypes.c_void_p)))
+        return out
+
+    def timer_start(self):
+        _check(self._lib.pml_timer_start(self._ctx))
+
+    def timer_stop(self):
+        ms = ctypes.c_float(0)
+        _check(self._lib.pml_timer_stop(self._ctx, ctypes.byref(ms)))
+        return ms.value
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def pij(model, ts):
+    """P(t) for a Model object and an array of branch lengths, through pml_pij (used by Model.get_Pij_t)."""
+    from pastml_amd.tree import FlatForest
+    k = len(model.states)
+    flat = FlatForest([-1], [0], [1], [0.0], [0])
+    with Engine(flat, 1, k) as eng:
+        eng.set_models([model])
+        return eng.pij(ts)

@@ -1,0 +1,339 @@
+"""
+GPU parity tests (run with ``-m gpu`` on an MI355X): the HIP path, called through the C-ABI, against
+(1) the golden vectors produced by the real reference, (2) the oracle on seeded random inputs,
+(3) size-independent invariants at BASELINE.json's full sizes.
+
+Tolerances.  north_star asks for 1e-6 relative on posteriors and log-likelihoods; we hold the kernels to
+1e-9 relative on posteriors, 2e-10 in log10 units (5e-10 relative) on every likelihood vector entry and 1e-11 relative
+on log-likelihoods.  Integer outputs (arg-max tables, joint states, selected states) must be identical.
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden, golden_forest, golden_spec
+from oracle import pastml_oracle as orc
+from pastml_amd import hip, synthetic
+from pastml_amd.tree import FlatForest
+
+pytestmark = pytest.mark.gpu
+
+LOG10_ATOL = 2e-10
+POST_RTOL = 1e-9
+LNL_RTOL = 1e-11
+
+
+def log_true(vec, sf):
+    """log10 of the true (unscaled) values of a scaled vector array [N, k] with base-10 scales [N]."""
+    with np.errstate(divide='ignore'):
+        return np.log10(vec) - sf[:, None]
+
+
+def assert_same_scaled(ours, ours_sf, ref, ref_sf, rows=None, what=''):
+    a, b = log_true(ours, ours_sf), log_true(ref, ref_sf)
+    if rows is not None:
+        a, b = a[rows], b[rows]
+    assert np.array_equal(np.isneginf(a), np.isneginf(b)), what + ': zero patterns differ'
+    fin = np.isfinite(b)
+    np.testing.assert_allclose(a[fin], b[fin], rtol=0, atol=LOG10_ATOL, err_msg=what)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def test_pij_matches_reference():
+    z = load_golden('pij')
+    ts = z['ts']
+    flat = FlatForest([-1], [0], [1], [0.0], [0])
+    for i, label in enumerate(z['labels']):
+        spec, rates = golden_spec(z, 'c{}_'.format(i))
+        k = len(spec['pi'])
+        with hip.Engine(flat, 1, k) as eng:
+            eng.set_models([(spec, rates)])
+            P = eng.pij(ts)
+        np.testing.assert_allclose(P, z['c{}_P'.format(i)], rtol=1e-12, atol=2e-15, err_msg=str(label))
+
+
+def test_pij_batch_matches_pij():
+    """The per-branch matrices the sweeps consume == the explicit ones (all kinds)."""
+    z = load_golden('pij')
+    flat = FlatForest.random(40, seed=8, max_arity=3, zero_frac=0.2)
+    for i, label in enumerate(z['labels']):
+        spec, rates = golden_spec(z, 'c{}_'.format(i))
+        k = len(spec['pi'])
+        with hip.Engine(flat, 2, k) as eng:
+            eng.set_models([(spec, rates), (spec, (rates[0] * 2, rates[1], rates[2]))])
+            Pb = eng.pij_batch(copy_out=True)
+            for col in (0, 1):
+                np.testing.assert_allclose(Pb[col], eng.pij(flat.dist, col), rtol=1e-12, atol=2e-15, err_msg=str(label))
+        ref = np.array([orc.pij(spec, t, *rates) for t in flat.dist])
+        np.testing.assert_allclose(Pb[0], ref, rtol=1e-12, atol=2e-15, err_msg=str(label))
+
+
+SWEEP_CASES = [('albania_F81', 'fix_'), ('albania_JC', 'fix_'), ('albania_EFT', 'fix_'),
+               ('albania_F81', 'tau_'), ('albania_JC', 'tau_'), ('albania_EFT', 'tau_'),
+               ('synthetic_jc_k4_L10', ''), ('synthetic_f81_k64_L8', ''), ('synthetic_jtt_k20_L8', ''),
+               ('synthetic_hky_L8', ''), ('synthetic_f81_k5_L9', ''), ('synthetic_f81_k67_L5', ''),
+               ('synthetic_f81_k130_L4', ''),
+               ('edge_poly', ''), ('edge_zero', ''), ('edge_zero_tau', ''), ('edge_forest', '')]
+
+
+@pytest.mark.parametrize('name,prefix', SWEEP_CASES)
+def test_sweeps_match_reference(name, prefix):
+    z = load_golden(name)
+    flat = golden_forest(z)
+    spec, rates = golden_spec(z, {'fix_': 'opt_', 'tau_': 'tau_', '': ''}[prefix])
+    g = lambda key: z[prefix + key]
+    k = len(spec['pi'])
+    internal = ~flat.is_tip
+    with hip.Engine(flat, 1, k) as eng:
+        eng.set_models([(spec, rates)])
+        eng.set_masks(g('masks_altered'))
+        # ---- marginal
+        lnl = eng.bottom_up(True)
+        np.testing.assert_allclose(lnl[0], g('loglik'), rtol=LNL_RTOL)
+        assert_same_scaled(eng.download(hip.BUF_BU), eng.download(hip.BUF_BU_SF), g('bu'), g('bu_sf'), what='BU')
+        post, lh_sum, lh_sf = eng.top_down_marginals()
+        assert_same_scaled(eng.download(hip.BUF_TD), eng.download(hip.BUF_TD_SF), g('td'), g('td_sf'),
+                           rows=internal, what='TD')
+        np.testing.assert_allclose(post[0], g('posterior'), rtol=POST_RTOL, atol=1e-300)
+        # LH / LH_SF as the host rebuilds them: posterior * lh_sum with scale lh_sf
+        assert_same_scaled(post[0] * lh_sum[0][:, None], lh_sf[0], g('lh'), g('lh_sf'), what='LH')
+        # ---- joint
+        eng.set_initial_masks(g('masks_initial'))
+        lnl_j = eng.bottom_up(False)
+        np.testing.assert_allclose(lnl_j[0], g('loglik_joint'), rtol=LNL_RTOL)
+        table = eng.download(hip.BUF_JOINT_TABLE)
+        nonroot = flat.parent >= 0
+        assert np.array_equal(table[nonroot], g('joint_table')[nonroot])
+        assert_same_scaled(eng.download(hip.BUF_BU), eng.download(hip.BUF_BU_SF), g('bu_joint'), g('bu_joint_sf'),
+                           what='BU joint')
+        states = eng.joint_backtrace()
+        assert np.array_equal(states[0], g('joint_state'))
+        eng.set_initial_masks(None)
+        # ---- restricted likelihoods (when nothing is altered the selected masks are swept as they are)
+        if len(g('altered_nodes')) == 0:
+            for key, m in (('loglik_restricted_MAP', g('masks_map')), ('loglik_restricted_MPPA', g('masks_mppa'))):
+                eng.set_masks(m)
+                np.testing.assert_allclose(eng.bottom_up(True)[0], g(key), rtol=LNL_RTOL)
+
+
+def test_zero_likelihood_reports_reference_pair():
+    z = load_golden('edge_zero_likelihood')
+    flat = golden_forest(z)
+    spec, rates = golden_spec(z)
+    with hip.Engine(flat, 2, len(spec['pi'])) as eng:
+        eng.set_models([(spec, rates)] * 2)
+        ok = np.ones_like(z['masks'])
+        ok[flat.tips] = z['masks'][flat.tips]
+        eng.set_masks(np.stack([ok, z['masks']]))
+        with pytest.raises(hip.ZeroLikelihoodError) as e:
+            eng.bottom_up(True)
+        assert e.value.err_parent[0] == -1 and e.value.err_child[0] == -1
+        names = z['node_names']
+        msg = str(z['error_message'])
+        assert 'parent node {} and its child node {}'.format(names[e.value.err_parent[1]],
+                                                             names[e.value.err_child[1]]) in msg
+        # the healthy column is still right
+        eng.set_masks(np.stack([ok, ok]))
+        lnl = eng.bottom_up(True)
+        ref = orc.bottom_up(flat, ok.astype(int), spec, *rates)['loglik']
+        np.testing.assert_allclose(lnl, [ref, ref], rtol=LNL_RTOL)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def random_spec(kind, k, rng):
+    pi = rng.dirichlet(np.ones(k) * 2)
+    if kind == 'F81':
+        return dict(kind=0, pi=pi)
+    if kind == 'HKY':
+        return dict(kind=1, pi=pi, kappa=float(rng.uniform(0.5, 8)))
+    R = np.triu(rng.uniform(0.05, 3, size=(k, k)), 1)
+    R = R + R.T
+    d, a, ainv = orc.diagonalise(pi, R)
+    return dict(kind=2, pi=pi, d=d, A=a, Ainv=ainv)
+
+
+def random_masks(flat, k, rng, missing=0.1, multi=0.1, internal=0.05):
+    masks = np.ones((flat.n_nodes, k), dtype=np.int8)
+    for n in range(flat.n_nodes):
+        u = rng.random()
+        if flat.is_tip[n]:
+            if u < missing:
+                continue
+            masks[n] = 0
+            if u < missing + multi and k > 1:
+                masks[n, rng.choice(k, size=2, replace=False)] = 1
+            else:
+                masks[n, rng.integers(k)] = 1
+        elif u < internal:
+            masks[n] = 0
+            masks[n, rng.integers(k)] = 1
+    return masks
+
+
+@pytest.mark.parametrize('kind,k', [('F81', 1), ('F81', 2), ('F81', 3), ('F81', 7), ('F81', 12), ('F81', 20),
+                                    ('F81', 32), ('F81', 33), ('F81', 64), ('F81', 65), ('F81', 100), ('F81', 129),
+                                    ('F81', 200), ('F81', 256), ('HKY', 4), ('EIGEN', 2), ('EIGEN', 5), ('EIGEN', 20),
+                                    ('EIGEN', 36), ('EIGEN', 67), ('EIGEN', 130)])
+def test_random_forests_vs_oracle(kind, k):
+    """Seeded random forests (polytomies, missing / ambiguous tips, restricted internal nodes), 3 columns at once."""
+    rng = np.random.default_rng(1000 + k)
+    n_tips = 120 if k <= 67 else 40
+    flat = FlatForest.random(n_tips, seed=k, max_arity=4, zero_frac=0.0, n_trees=2)
+    C = 3
+    specs = [random_spec(kind, k, rng) for _ in range(C)]
+    rates = [(float(rng.uniform(0.5, 3)), 0.0, 1.0), (float(rng.uniform(0.5, 3)), 0.01, 0.9), (1.0, 0.0, 1.0)]
+    masks = np.stack([random_masks(flat, k, rng) for _ in range(C)])
+    with hip.Engine(flat, C, k) as eng:
+        eng.set_models(list(zip(specs, rates)))
+        eng.set_masks(masks)
+        lnl = eng.bottom_up(True)
+        post, lh_sum, lh_sf = eng.top_down_marginals()
+        bus = [(eng.download(hip.BUF_BU, c), eng.download(hip.BUF_BU_SF, c)) for c in range(C)]
+        lnl_j = eng.bottom_up(False)
+        tables = [eng.download(hip.BUF_JOINT_TABLE, c) for c in range(C)]
+        states = eng.joint_backtrace()
+    nonroot = flat.parent >= 0
+    for c in range(C):
+        r = orc.full_marginal_pass(flat, masks[c].astype(int), specs[c], *rates[c])
+        np.testing.assert_allclose(lnl[c], r['loglik'], rtol=LNL_RTOL)
+        assert_same_scaled(bus[c][0], bus[c][1], r['bu'], r['bu_sf'], what='BU col {}'.format(c))
+        np.testing.assert_allclose(post[c], r['posterior'], rtol=POST_RTOL, atol=1e-300)
+        tot = np.log10(lh_sum[c]) - lh_sf[c]
+        np.testing.assert_allclose(tot, r['loglik_per_tree'][flat.tree_id] / np.log(10), rtol=1e-11)
+        j = orc.bottom_up(flat, masks[c].astype(int), specs[c], *rates[c], is_marginal=False)
+        np.testing.assert_allclose(lnl_j[c], j['loglik'], rtol=LNL_RTOL)
+        if kind != 'EIGEN':
+            assert np.array_equal(tables[c][nonroot], j['joint_table'][nonroot])
+            assert np.array_equal(states[c], orc.joint_backtrace(flat, j['bu'], j['joint_table'], specs[c]['pi']))
+        else:
+            # eigen P(t) differs from numpy's BLAS in the last bits: allow arg-max flips only between products that
+            # are equal to 1e-12
+            diff = np.argwhere(tables[c] != j['joint_table'])
+            for n, i in diff:
+                if not nonroot[n]:
+                    continue
+                prod = orc.pij(specs[c], flat.dist[n], *rates[c])[i] * j['bu'][n]
+                assert abs(prod[tables[c][n, i]] - prod.max()) <= 1e-12 * prod.max()
+
+
+def test_deep_caterpillar_rescaling():
+    """A 3000-level caterpillar drives the likelihoods through ~1e-2000: exercises the exponent bookkeeping."""
+    n = 3000
+    # ids in level order: level d has one internal node (2d-1 ... ) -- build with objects then flatten
+    from pastml_amd.tree import TreeNode
+    root = TreeNode(name='r', dist=0.0)
+    cur = root
+    for d in range(n):
+        cur.add_child(name='t{}'.format(d), dist=0.3)
+        cur = cur.add_child(name='i{}'.format(d), dist=0.05)
+    cur.add_child(name='ta', dist=0.1)
+    cur.add_child(name='tb', dist=0.1)
+    flat = FlatForest.from_trees([root])
+    k = 6
+    rng = np.random.default_rng(5)
+    spec = random_spec('F81', k, rng)
+    masks = random_masks(flat, k, rng, missing=0.0, multi=0.0, internal=0.0)
+    with hip.Engine(flat, 1, k) as eng:
+        eng.set_models([(spec, (1.0, 0.0, 1.0))])
+        eng.set_masks(masks)
+        lnl = eng.bottom_up(True)
+        post, lh_sum, lh_sf = eng.top_down_marginals()
+    r = orc.full_marginal_pass(flat, masks.astype(int), spec)
+    assert r['loglik'] < -4000
+    np.testing.assert_allclose(lnl[0], r['loglik'], rtol=LNL_RTOL)
+    np.testing.assert_allclose(post[0], r['posterior'], rtol=POST_RTOL, atol=1e-300)
+    np.testing.assert_allclose(np.log10(lh_sum[0]) - lh_sf[0], r['loglik'] / np.log(10), rtol=1e-11)
+
+
+def test_determinism():
+    """tests/CUSTOM_RATESTest.py:59,84,89 require bit-identical reruns."""
+    z = load_golden('synthetic_jtt_k20_L8')
+    flat = golden_forest(z)
+    spec, rates = golden_spec(z)
+    outs = []
+    for _ in range(2):
+        with hip.Engine(flat, 1, 20) as eng:
+            eng.set_models([(spec, rates)])
+            eng.set_masks(z['masks_altered'])
+            lnl = eng.bottom_up(True)
+            post, _, _ = eng.top_down_marginals()
+            outs.append((lnl.copy(), post.copy()))
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert np.array_equal(outs[0][1], outs[1][1])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def test_cfg2_full_size_matches_reference_sample():
+    """BASELINE config 2: 65 536 tips, JC k=4, marginal; reference posteriors at every 4 099th node."""
+    z = load_golden('synthetic_cfg2_full')
+    flat = synthetic.balanced_forest(int(z['n_levels']))
+    spec, rates = golden_spec(z)
+    with hip.Engine(flat, 1, 4) as eng:
+        eng.set_models([(spec, rates)])
+        eng.set_tip_states(synthetic.tip_states(flat.n_tips, 4, 0))
+        lnl = eng.bottom_up(True)
+        post, lh_sum, lh_sf = eng.top_down_marginals()
+        lnl_j = eng.bottom_up(False)
+        states = eng.joint_backtrace()
+    s = z['sample']
+    np.testing.assert_allclose(lnl[0], z['loglik'], rtol=LNL_RTOL)
+    np.testing.assert_allclose(post[0][s], z['posterior'], rtol=POST_RTOL, atol=1e-300)
+    np.testing.assert_allclose(lnl_j[0], z['loglik_joint'], rtol=LNL_RTOL)
+    assert np.array_equal(states[0][s], z['joint_state'])
+    np.testing.assert_allclose(post[0].sum(axis=1), 1, rtol=1e-12)
+    np.testing.assert_allclose(np.log10(lh_sum[0]) - lh_sf[0], lnl[0] / np.log(10), rtol=1e-11)
+
+
+def test_cfg4_shape_matches_reference_sample():
+    """BASELINE config 4's shape (F81, k=64, independent parameters per character) on 16 384 tips, 2 characters."""
+    zs = [load_golden('synthetic_cfg4_L14_c{}'.format(c)) for c in (0, 1)]
+    flat = synthetic.balanced_forest(int(zs[0]['n_levels']))
+    with hip.Engine(flat, 2, 64) as eng:
+        eng.set_models([golden_spec(z) for z in zs])
+        eng.set_tip_states(np.stack([synthetic.tip_states(flat.n_tips, 64, c) for c in (0, 1)]))
+        lnl = eng.bottom_up(True)
+        post, lh_sum, lh_sf = eng.top_down_marginals()
+    for c, z in enumerate(zs):
+        s = z['sample']
+        np.testing.assert_allclose(lnl[c], z['loglik'], rtol=LNL_RTOL)
+        np.testing.assert_allclose(post[c][s], z['posterior'], rtol=POST_RTOL, atol=1e-300)
+
+
+def test_cfg4_full_tree_invariants():
+    """
+    Config 4 at full tree size (1 048 576 tips, k=64, F81), 2 characters: properties that need no oracle --
+    posteriors sum to one; every node sees the same total likelihood (pastml/ml.py:468-483), equal to the
+    bottom-up log-likelihood; tips keep their observed state; a 4 096-tip subtree's bottom-up vectors equal the
+    oracle's on that subtree.
+    """
+    L = 20
+    flat = synthetic.balanced_forest(L)
+    C, k = 2, 64
+    states = np.stack([synthetic.tip_states(flat.n_tips, k, c) for c in range(C)])
+    specs = [dict(kind=0, pi=synthetic.f81_frequencies(k, c)) for c in range(C)]
+    with hip.Engine(flat, C, k) as eng:
+        eng.set_models([(s, (1.0, 0.0, 1.0)) for s in specs])
+        eng.set_tip_states(states)
+        lnl = eng.bottom_up(True)
+        post, lh_sum, lh_sf = eng.top_down_marginals()
+        # subtree rooted at the first node of depth 8 (id 255): its 4 096 tips
+        sub_root = 255
+        bu = eng.download(hip.BUF_BU, 0)
+        bu_sf = eng.download(hip.BUF_BU_SF, 0)
+    for c in range(C):
+        np.testing.assert_allclose(post[c].sum(axis=1), 1, rtol=1e-12)
+        np.testing.assert_allclose(np.log10(lh_sum[c]) - lh_sf[c], lnl[c] / np.log(10), rtol=1e-11)
+        tip_post = post[c][flat.tips]
+        assert np.array_equal(tip_post.argmax(axis=1), states[c])
+        assert np.all(tip_post.max(axis=1) == 1.0)
+    # subtree ids: level d of the subtree = ids [(sub_root+1) * 2^d - 1, ... + 2^d)
+    ids = np.concatenate([np.arange((sub_root + 1) * (1 << d) - 1, (sub_root + 1) * (1 << d) - 1 + (1 << d))
+                          for d in range(L - 8 + 1)])
+    sub = synthetic.balanced_forest(L - 8)
+    sub.dist[:] = flat.dist[ids]
+    sub.dist[0] = 0
+    masks = np.ones((sub.n_nodes, k), dtype=int)
+    tip_pos = ids[sub.tips] - flat.tips[0]
+    masks[sub.tips] = 0
+    masks[sub.tips, states[0][tip_pos]] = 1
+    r = orc.bottom_up(sub, masks, specs[0])
+    assert_same_scaled(bu[ids], bu_sf[ids], r['bu'], r['bu_sf'], what='subtree BU')
