@@ -194,13 +194,13 @@ def test_random_forests_vs_oracle(kind, k):
     nonroot = flat.parent >= 0
     for c in range(C):
         r = orc.full_marginal_pass(flat, masks[c].astype(int), specs[c], *rates[c])
-        np.testing.assert_allclose(lnl[c], r['loglik'], rtol=LNL_RTOL)
+        np.testing.assert_allclose(lnl[c], r['loglik'], rtol=LNL_RTOL, atol=1e-12)
         assert_same_scaled(bus[c][0], bus[c][1], r['bu'], r['bu_sf'], what='BU col {}'.format(c))
         np.testing.assert_allclose(post[c], r['posterior'], rtol=POST_RTOL, atol=1e-300)
         tot = np.log10(lh_sum[c]) - lh_sf[c]
-        np.testing.assert_allclose(tot, r['loglik_per_tree'][flat.tree_id] / np.log(10), rtol=1e-11)
+        np.testing.assert_allclose(tot, r['loglik_per_tree'][flat.tree_id] / np.log(10), rtol=1e-11, atol=1e-12)
         j = orc.bottom_up(flat, masks[c].astype(int), specs[c], *rates[c], is_marginal=False)
-        np.testing.assert_allclose(lnl_j[c], j['loglik'], rtol=LNL_RTOL)
+        np.testing.assert_allclose(lnl_j[c], j['loglik'], rtol=LNL_RTOL, atol=1e-12)
         if kind != 'EIGEN':
             assert np.array_equal(tables[c][nonroot], j['joint_table'][nonroot])
             assert np.array_equal(states[c], orc.joint_backtrace(flat, j['bu'], j['joint_table'], specs[c]['pi']))
