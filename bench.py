@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""
+Benchmark of the ML-ACR hot path on MI355X (contract: see the task description; metric of BASELINE.json).
+
+Workload (BASELINE config 4, weak scaling): synthetic balanced tree with 1 048 576 tips (2 097 151 nodes), k = 64
+states, F81 with independent frequencies per character, 32 characters per GPU (= 256 characters on 8 GPUs).
+One "step" = one full marginal pass over the rank's characters: per-branch transition data, bottom-up sweep
+(log-likelihoods returned to the host), top-down sweep, marginal likelihoods and posteriors for every node, left in HBM.
+With N > 1 GPUs the characters are sharded over the ranks (no data-path collective); the summed log-likelihood is
+all-reduced over RCCL after every step, as the host optimiser would need it.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 TB/s achievable)
+BYTES_BU = 16                    # algorithmic bytes per node.state.char, bottom-up sweep
+BYTES_TD = 32                    # ... top-down + marginals + posterior part of the full pass (48 - 16)
+
+WORKLOADS = {
+    # name: (tree levels, k, characters per GPU)
+    'cfg4': (20, 64, 32),
+    'cfg4_small': (14, 64, 8),
+    'cfg2': (16, 4, 1),
+}
+
+
+def parse_args():
+    p = argparse.ArgumentParser()
+    p.add_argument('--gpus', type=int, default=1)
+    p.add_argument('--steps', type=int, default=5)
+    p.add_argument('--warmup', type=int, default=2)
+    p.add_argument('--workload', default='cfg4', choices=sorted(WORKLOADS))
+    p.add_argument('--chars-per-gpu', type=int, default=None)
+    p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--cpu-baseline-levels', type=int, default=None,
+                   help='tree levels of the subtree the CPU baseline is timed on (default: about 15 s of work)')
+    return p.parse_args()
+
+
+def cpu_baseline(k, levels, model):
+    """
+    PastML-style numpy CPU path (oracle/pastml_oracle.py, the per-node restatement of pastml/ml.py) timed on this
+    box's host cores: one character of the same workload on a balanced subtree, full marginal pass, one thread.
+    """
+    from oracle import pastml_oracle as orc
+    from pastml_amd import synthetic
+    flat = synthetic.balanced_forest(levels)
+    if model == 'JC':
+        spec = dict(kind=0, pi=np.ones(k) / k)
+    else:
+        spec = dict(kind=0, pi=synthetic.f81_frequencies(k, 0))
+    masks = synthetic.one_hot_masks(flat, k, synthetic.tip_states(flat.n_tips, k, 0)).astype(int)
+    t0 = time.perf_counter()
+    r = orc.full_marginal_pass(flat, masks, spec)
+    dt = time.perf_counter() - t0
+    units = flat.n_nodes * k
+    return dict(value=units / dt, unit='node*state*char/s', cores=1, kind='port',
+                sample='1 character, balanced {}-tip tree ({} nodes), k={}, full marginal pass (BU+TD+posteriors), '
+                       'numpy per-node port of pastml/ml.py, {:.1f} s on 1 of {} host cores'
+                       .format(flat.n_tips, flat.n_nodes, k, dt, os.cpu_count()),
+                seconds=dt, us_per_node=dt / flat.n_nodes * 1e6, loglik=float(r['loglik']))
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node {} '
+                             '--master-addr 127.0.0.1 --master-port P bench.py --gpus {} ...'.format(args.gpus, args.gpus))
+        raise SystemExit('--gpus {} but WORLD_SIZE={}'.format(args.gpus, world))
+
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
+
+    from pastml_amd import hip, synthetic
+
+    levels, k, cpg = WORKLOADS[args.workload]
+    if args.chars_per_gpu:
+        cpg = args.chars_per_gpu
+    model = 'JC' if args.workload == 'cfg2' else 'F81'
+    flat = synthetic.balanced_forest(levels)
+    N = flat.n_nodes
+    chars = [rank * cpg + i for i in range(cpg)]
+
+    eng = hip.Engine(flat, cpg, k, device=local_rank)
+    if model == 'JC':
+        specs = [dict(kind=0, pi=np.ones(k) / k) for _ in chars]
+    else:
+        specs = [dict(kind=0, pi=synthetic.f81_frequencies(k, c)) for c in chars]
+    eng.set_models([(s, (1.0, 0.0, 1.0)) for s in specs])
+    eng.set_tip_states(np.stack([synthetic.tip_states(flat.n_tips, k, c) for c in chars]))
+    eng.sync()
+
+    lnl_dev = torch.zeros(1, dtype=torch.float64, device='cuda:{}'.format(local_rank))
+
+    def step():
+        # model parameters are re-sent every step, as an optimiser iteration would: forces the per-branch
+        # transition data to be recomputed inside the step
+        eng.set_models([(s, (1.0, 0.0, 1.0)) for s in specs])
+        lnl = eng.bottom_up(True)                       # inputs resident in HBM; returns ln L per character
+        eng.top_down_marginals(posterior=False, lh=False)  # TD + marginals + posteriors, outputs stay in HBM
+        total = float(lnl.sum())
+        if dist is not None:
+            lnl_dev.fill_(total)
+            dist.all_reduce(lnl_dev)                    # the one collective of the path: summed log-likelihood
+            total = float(lnl_dev.item())
+        return total, lnl
+
+    def fence():
+        eng.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    eng.profile_enable(True)
+    for w in (0, 1, 2):
+        eng.profile_read(w, reset=True)
+    fence()
+    t0 = time.perf_counter()
+    total = None
+    for _ in range(args.steps):
+        total, lnl = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device='cuda:{}'.format(local_rank))
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    bu_ms, bu_launches = eng.profile_read(0)
+    td_ms, td_launches = eng.profile_read(1)
+    prep_ms, prep_launches = eng.profile_read(2)
+    held, free = eng.memory()
+
+    if rank == 0:
+        units_per_step = N * k * cpg * world
+        value = units_per_step * args.steps / dt
+        # dominant kernel: the top-down + marginals level kernel (td_f81_kernel): every non-root node is finished once
+        td_bytes_per_step = BYTES_TD * (N - 1) * k * cpg
+        bu_bytes_per_step = BYTES_BU * (N - 1) * k * cpg
+        td_gbs = td_bytes_per_step * args.steps / (td_ms * 1e-3) / 1e9 if td_ms > 0 else None
+        bu_gbs = bu_bytes_per_step * args.steps / (bu_ms * 1e-3) / 1e9 if bu_ms > 0 else None
+        traffic = None
+        tpath = os.path.join(REPO, 'profiles', 'traffic.json')
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(args.workload, {}).get('td_bytes_per_launch')
+            except Exception:
+                traffic = None
+        out = {
+            'metric': 'ACR nodes*states*chars/sec (full marginal pass: P(t) + bottom-up + top-down + posteriors)',
+            'value': value,
+            'unit': 'node*state*char/s',
+            'n_gpus': world,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': dt / args.steps * 1e3,
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': 'f64',
+            'data': 'synthetic',
+            'config': {'workload': 'BASELINE config 4 shard: balanced tree, {} tips ({} nodes), k={} states, {}, '
+                                   '{} characters per GPU ({} in total), marginal (BU+TD+posteriors)'
+                                   .format(flat.n_tips, N, k, model, cpg, cpg * world),
+                       'tips': int(flat.n_tips), 'nodes': int(N), 'states': k, 'chars_per_gpu': cpg,
+                       'chars_total': cpg * world, 'model': model,
+                       'sharding': 'characters over ranks, no data-path collective; 1 all-reduce (8 B) per step'},
+            'loglik_sum': total,
+            'roofline': {
+                'bound': 'hbm', 'kernel': 'td_f81_kernel (top-down + marginals + posteriors, one launch per depth level)',
+                'achieved': td_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': (td_gbs / HBM_PEAK_GBS) if td_gbs else None,
+                'traffic': traffic,
+                'algorithmic_bytes_per_launch': td_bytes_per_step / max(1, td_launches / args.steps),
+                'avg_launch_ms': td_ms / max(1, td_launches),
+                'launches': td_launches,
+                'bytes_per_unit': BYTES_TD,
+            },
+            'roofline_bottom_up': {
+                'kernel': 'bu_f81_kernel (bottom-up, one launch per height level)', 'achieved': bu_gbs,
+                'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': (bu_gbs / HBM_PEAK_GBS) if bu_gbs else None,
+                'avg_launch_ms': bu_ms / max(1, bu_launches), 'launches': bu_launches, 'bytes_per_unit': BYTES_BU,
+            },
+            'kernel_ms_per_step': {'bottom_up': bu_ms / args.steps, 'top_down': td_ms / args.steps,
+                                   'prep': prep_ms / args.steps},
+            'device_memory_gb': held / 1e9,
+        }
+        if not args.no_cpu_baseline:
+            cl = args.cpu_baseline_levels
+            if cl is None:
+                cl = min(levels, 16 if k >= 32 else 17)
+            out['cpu_baseline'] = cpu_baseline(k, cl, model)
+            out['speedup_vs_cpu_baseline'] = value / out['cpu_baseline']['value']
+        print(json.dumps(out))
+    eng.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

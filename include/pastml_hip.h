@@ -146,6 +146,15 @@ int pml_download(pml_ctx* ctx, int what, int32_t col, void* out);
 /* HIP-event timer on the ctx's stream */
 int pml_timer_start(pml_ctx* ctx);
 int pml_timer_stop(pml_ctx* ctx, float* milliseconds);
+/*
+ * Kernel-time accounting with HIP events on the ctx's stream (the stream the kernels are launched on).
+ * While enabled, every pml_bottom_up / pml_top_down_marginals / pml_pij_batch call brackets its level-kernel
+ * launches with an event pair and adds the elapsed time to an accumulator.
+ * which: 0 = bottom-up level kernels, 1 = top-down level kernels, 2 = P(t) / prep kernels.
+ * launches counts kernel launches.  reset != 0 clears the accumulator after reading.
+ */
+int pml_profile_enable(pml_ctx* ctx, int on);
+int pml_profile_read(pml_ctx* ctx, int which, double* total_ms, int64_t* launches, int reset);
 
 #ifdef __cplusplus
 }

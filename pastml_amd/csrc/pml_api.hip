@@ -44,6 +44,10 @@ struct pml_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t pev[2] = {nullptr, nullptr};
+    bool profile = false;
+    double prof_ms[3] = {0, 0, 0};
+    long long prof_launches[3] = {0, 0, 0};
     std::vector<void*> allocs;
     size_t held = 0;
 
@@ -171,6 +175,22 @@ static PmlModel model_of(const pml_ctx* c) {
     return m;
 }
 
+static int prof_begin(pml_ctx* ctx) {
+    if (ctx->profile) HIP_TRY(hipEventRecord(ctx->pev[0], ctx->stream));
+    return PML_OK;
+}
+
+static int prof_end(pml_ctx* ctx, int which, long long launches) {
+    if (!ctx->profile) return PML_OK;
+    HIP_TRY(hipEventRecord(ctx->pev[1], ctx->stream));
+    HIP_TRY(hipEventSynchronize(ctx->pev[1]));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, ctx->pev[0], ctx->pev[1]));
+    ctx->prof_ms[which] += ms;
+    ctx->prof_launches[which] += launches;
+    return PML_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // (G, R) dispatch
 // ---------------------------------------------------------------------------------------------------------------------
@@ -267,6 +287,8 @@ int pml_ctx_create(int device, pml_ctx** out) {
     hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->pev[0]);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->pev[1]);
     if (e != hipSuccess) {
         delete ctx;
         return fail(PML_ERR_HIP, "stream/event creation failed: %s", hipGetErrorString(e));
@@ -282,6 +304,8 @@ int pml_ctx_destroy(pml_ctx* ctx) {
     free_all(ctx);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    for (int i = 0; i < 2; ++i)
+        if (ctx->pev[i]) (void)hipEventDestroy(ctx->pev[i]);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return PML_OK;
@@ -376,12 +400,16 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
     // a new tree resets everything the ctx holds
     free_all(ctx);
     hipStream_t stream = ctx->stream;
-    hipEvent_t e0 = ctx->ev0, e1 = ctx->ev1;
+    hipEvent_t e0 = ctx->ev0, e1 = ctx->ev1, p0 = ctx->pev[0], p1 = ctx->pev[1];
     int device = ctx->device;
+    const bool profile = ctx->profile;
     *ctx = pml_ctx();
     ctx->stream = stream;
     ctx->ev0 = e0;
     ctx->ev1 = e1;
+    ctx->pev[0] = p0;
+    ctx->pev[1] = p1;
+    ctx->profile = profile;
     ctx->device = device;
 
     ctx->N = n_nodes;
@@ -637,13 +665,15 @@ static int run_prep(pml_ctx* ctx) {
     const PmlTree t = tree_of(ctx);
     const PmlCols c = cols_of(ctx);
     const PmlModel m = model_of(ctx);
+    if (ctx->kind != PML_MODEL_F81 && !ctx->d_P)
+        PML_TRY(dev_alloc(ctx, &ctx->d_P, (size_t)ctx->C * ctx->N * ctx->k * ctx->ks));
+    PML_TRY(prof_begin(ctx));
     if (ctx->kind == PML_MODEL_F81) {
         dim3 grid(grid_for(ctx->N, PML_BLOCK, ctx->C), ctx->C);
         hipLaunchKernelGGL(f81_prep_kernel, grid, dim3(PML_BLOCK), 0, ctx->stream, t, c, ctx->d_mu, ctx->d_sf,
                            ctx->d_tau, ctx->d_tauf, state_of(ctx));
         HIP_TRY(hipGetLastError());
     } else {
-        if (!ctx->d_P) PML_TRY(dev_alloc(ctx, &ctx->d_P, (size_t)ctx->C * ctx->N * ctx->k * ctx->ks));
         if (ctx->kind == PML_MODEL_HKY) {
             dim3 grid(grid_for(ctx->N, PML_BLOCK, ctx->C), ctx->C);
             hipLaunchKernelGGL(pij_hky_kernel, grid, dim3(PML_BLOCK), 0, ctx->stream, t, c, m, ctx->d_P);
@@ -662,6 +692,7 @@ static int run_prep(pml_ctx* ctx) {
         }
         HIP_TRY(hipGetLastError());
     }
+    PML_TRY(prof_end(ctx, 2, 1));
     ctx->prep_dirty = false;
     return PML_OK;
 }
@@ -750,10 +781,12 @@ int pml_bottom_up(pml_ctx* ctx, int is_marginal, double* loglik_out, int32_t* er
     ctx->bu_mode = -1;
     ctx->td_valid = ctx->js_valid = false;
     HIP_TRY(hipMemsetAsync(ctx->d_err, 0xFF, sizeof(u64) * ctx->C, ctx->stream));
+    PML_TRY(prof_begin(ctx));
     for (int l = 0; l < ctx->n_bu_levels; ++l) {
         const int a = ctx->bu_offsets[l], b = ctx->bu_offsets[l + 1];
         PML_TRY(dispatch_sweep(ctx, is_marginal ? SW_BU_MARG : SW_BU_JOINT, ctx->d_bu_order + a, b - a));
     }
+    PML_TRY(prof_end(ctx, 0, ctx->n_bu_levels));
     hipLaunchKernelGGL(loglik_kernel, dim3((ctx->C + PML_BLOCK - 1) / PML_BLOCK), dim3(PML_BLOCK), 0, ctx->stream,
                        tree_of(ctx), cols_of(ctx), state_of(ctx), ctx->C, is_marginal ? 1 : 0, ctx->d_loglik);
     HIP_TRY(hipGetLastError());
@@ -789,10 +822,14 @@ int pml_top_down_marginals(pml_ctx* ctx, double* posterior_out, double* lh_sum_o
         PML_TRY(dev_alloc(ctx, &ctx->d_lhe, CN));
     }
     PML_TRY(dispatch_sweep(ctx, SW_ROOTS, nullptr, ctx->n_roots));
+    PML_TRY(prof_begin(ctx));
+    long long n_launch = 0;
     for (int l = 0; l < ctx->n_td_levels; ++l) {
         const int a = ctx->td_parent_offsets[l], b = ctx->td_parent_offsets[l + 1];
         PML_TRY(dispatch_sweep(ctx, SW_TD, ctx->d_td_parents + a, b - a));
+        if (b > a) ++n_launch;
     }
+    PML_TRY(prof_end(ctx, 1, n_launch));
     ctx->td_valid = true;
     if (posterior_out) {
         if (ctx->ks == ctx->k) {
@@ -928,6 +965,23 @@ int pml_download(pml_ctx* ctx, int what, int32_t col, void* out) {
         default:
             return fail(PML_ERR_INVALID, "unknown buffer id %d", what);
     }
+}
+
+int pml_profile_enable(pml_ctx* ctx, int on) {
+    if (!ctx) return fail(PML_ERR_INVALID, "ctx is NULL");
+    ctx->profile = on != 0;
+    return PML_OK;
+}
+
+int pml_profile_read(pml_ctx* ctx, int which, double* total_ms, int64_t* launches, int reset) {
+    if (!ctx || which < 0 || which > 2) return fail(PML_ERR_INVALID, "bad profile slot");
+    if (total_ms) *total_ms = ctx->prof_ms[which];
+    if (launches) *launches = ctx->prof_launches[which];
+    if (reset) {
+        ctx->prof_ms[which] = 0;
+        ctx->prof_launches[which] = 0;
+    }
+    return PML_OK;
 }
 
 int pml_timer_start(pml_ctx* ctx) {

@@ -76,6 +76,8 @@ SIGNATURES = {
     'pml_download': [_ctx_p, ctypes.c_int, ctypes.c_int32, ctypes.c_void_p],
     'pml_timer_start': [_ctx_p],
     'pml_timer_stop': [_ctx_p, ctypes.POINTER(ctypes.c_float)],
+    'pml_profile_enable': [_ctx_p, ctypes.c_int],
+    'pml_profile_read': [_ctx_p, ctypes.c_int, _c_double_p, ctypes.POINTER(ctypes.c_int64), ctypes.c_int],
 }
 _RESTYPES = {'pml_last_error': ctypes.c_char_p}
 
@@ -344,6 +346,15 @@ class Engine(object):
             out = np.empty(N, dtype=np.float64)
         _check(self._lib.pml_download(self._ctx, what, col, out.ctypes.data_as(ctypes.c_void_p)))
         return out
+
+    def profile_enable(self, on=True):
+        _check(self._lib.pml_profile_enable(self._ctx, 1 if on else 0))
+
+    def profile_read(self, which, reset=False):
+        """(total milliseconds, launches) of slot which: 0 bottom-up, 1 top-down, 2 P(t)/prep kernels."""
+        ms, n = ctypes.c_double(0), ctypes.c_int64(0)
+        _check(self._lib.pml_profile_read(self._ctx, which, ctypes.byref(ms), ctypes.byref(n), 1 if reset else 0))
+        return ms.value, n.value
 
     def timer_start(self):
         _check(self._lib.pml_timer_start(self._ctx))
