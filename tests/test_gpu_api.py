@@ -1,0 +1,355 @@
+"""
+GPU tests of the drop-in boundary: ``pastml_amd.acr.acr()`` / ``ml.ml_acr()`` and the stand-alone functions, written
+after the reference's own unit tests (tests/ACRParameterOptimisationMPPA*Test.py, ACRState*Test.py, HKYF81Test.py,
+CUSTOM_RATESTest.py, PijTest.py) with the reference's pinned numbers and the golden outputs of the real reference.
+"""
+import os
+from collections import Counter
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from conftest import load_golden, GOLDEN
+from pastml_amd import get_personalized_feature_name, STATES
+from pastml_amd.acr import acr
+from pastml_amd.annotation import ForestStats
+from pastml_amd.ml import LH, LH_SF, MPPA, MAP, JOINT, ML, LOG_LIKELIHOOD, RESTRICTED_LOG_LIKELIHOOD_FORMAT_STR, \
+    MARGINAL_PROBABILITIES, MODEL, PastMLLikelihoodError
+from pastml_amd import ml
+from pastml_amd.models.CustomRatesModel import CustomRatesModel, CUSTOM_RATES
+from pastml_amd.models.F81Model import F81Model, F81
+from pastml_amd.models.HKYModel import HKYModel, HKY, KAPPA, HKY_STATES, A, C, G, T
+from pastml_amd.models.JCModel import JCModel, JC
+from pastml_amd.models.EFTModel import EFT
+from pastml_amd.models.JTTModel import JTTModel, JTT, JTT_STATES, JTT_RATE_MATRIX
+from pastml_amd.models.generator import save_matrix
+from pastml_amd.tree import read_tree, FlatForest
+
+pytestmark = pytest.mark.gpu
+
+DATA = os.path.join(GOLDEN, 'data')
+TREE_NWK = os.path.join(DATA, 'Albanian.tree.152tax.tre')
+STATES_INPUT = os.path.join(DATA, 'data.txt')
+feature = 'Country'
+
+
+def albania_df():
+    return pd.read_csv(STATES_INPUT, index_col=0, header=0)[[feature]]
+
+
+_cache = {}
+
+
+def albania_result(model, method=MPPA):
+    key = (model, method)
+    if key not in _cache:
+        tree = read_tree(TREE_NWK)
+        _cache[key] = (tree, acr(tree, albania_df(), prediction_method=method, model=model))
+    return _cache[key]
+
+
+# pinned by the reference's tests
+PINNED = {F81: dict(lnl=-110.178, restricted=-111.662, sf=3.841,
+                    root={'Africa': 0.952, 'Albania': 0.001, 'EastEurope': 0.011, 'Greece': 0.011, 'WestEurope': 0.025},
+                    node_4={'Africa': 0.944, 'Albania': 0.000, 'EastEurope': 0.000, 'Greece': 0.001, 'WestEurope': 0.054},
+                    freqs={'Africa': 0.082, 'Albania': 0.028, 'EastEurope': 0.081, 'Greece': 0.365, 'WestEurope': 0.444}),
+          JC: dict(lnl=-121.873, restricted=-123.421, sf=4.951),
+          EFT: dict(lnl=-123.173, restricted=-125.359, sf=5.38)}
+
+
+@pytest.mark.parametrize('model', [F81, JC, EFT])
+def test_acr_mppa_albania_pinned_values(model):
+    tree, results = albania_result(model)
+    res = results[0]
+    pin = PINNED[model]
+    assert abs(res[LOG_LIKELIHOOD] - pin['lnl']) < 5e-4
+    assert abs(res[RESTRICTED_LOG_LIKELIHOOD_FORMAT_STR.format(MPPA)] - pin['restricted']) < 5e-4
+    assert abs(res[MODEL].sf - pin['sf']) < 5e-3
+    assert abs(res[MODEL].frequencies.sum() - 1) < 1e-9
+    mps = res[MARGINAL_PROBABILITIES]
+    if 'root' in pin:
+        for loc, v in pin['root'].items():
+            assert abs(mps.loc['ROOT', loc] - v) < 5e-4
+        for loc, v in pin['node_4'].items():
+            assert abs(mps.loc['node_4', loc] - v) < 5e-4
+        for loc, v in pin['freqs'].items():
+            assert abs(res[MODEL].frequencies[np.where(res[STATES] == loc)][0] - v) < 5e-4
+    for loc in res[STATES]:
+        assert abs(mps.loc['02ALAY1660', loc] - (1 if loc == 'Albania' else 0)) < 1e-12
+
+
+@pytest.mark.parametrize('model', [F81, JC, EFT])
+def test_acr_mppa_albania_matches_reference_run(model):
+    """Against the golden end-to-end output of the real reference (same scipy), far tighter than the pinned digits."""
+    tree, results = albania_result(model)
+    res = results[0]
+    z = load_golden('albania_' + model)
+    assert res[MODEL].name == str(z['opt_model_name'])
+    np.testing.assert_allclose(res[LOG_LIKELIHOOD], z['opt_loglik'], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(res[MODEL].sf, z['opt_sf'], rtol=2e-4)
+    np.testing.assert_allclose(res[MODEL].frequencies, z['opt_frequencies'], atol=2e-5)
+    for m in (JOINT, MAP, MPPA):
+        np.testing.assert_allclose(res[RESTRICTED_LOG_LIKELIHOOD_FORMAT_STR.format(m)],
+                                   z['opt_loglik_restricted_' + m], rtol=0, atol=1e-4)
+    flat = FlatForest.from_trees([tree])
+    nodes = flat.nodes
+    mps = res[MARGINAL_PROBABILITIES]
+    assert list(mps.index) == [n.name for n in nodes]
+    assert list(mps.columns) == list(z['opt_states'])
+    np.testing.assert_allclose(mps.values, z['opt_posterior'], rtol=0, atol=2e-5)
+    # selected states, joint states, scenario statistics
+    s2i = {s: i for i, s in enumerate(res[STATES])}
+    sel = np.zeros((len(nodes), len(s2i)), dtype=np.int8)
+    for i, n in enumerate(nodes):
+        for s in getattr(n, feature):
+            sel[i, s2i[s]] = 1
+    assert np.array_equal(sel, z['opt_selected_mppa'])
+    assert np.array_equal([getattr(n, feature + '_JOINT_STATE') for n in nodes], z['opt_joint_state'])
+    assert res['num_unresolved_nodes'] == int(z['opt_num_unresolved_nodes'])
+    assert float(res['num_scenarios']) == float(z['opt_num_scenarios'])
+    np.testing.assert_allclose(res['num_states_per_node_avg'], z['opt_num_states_per_node_avg'])
+    assert abs(res['percentage_of_unresolved_nodes'] - 100 * int(z['opt_num_unresolved_nodes']) / 305) < 1e-12
+
+
+def test_likelihood_same_for_all_nodes():
+    """tests/ACRParameterOptimisationMPPAF81Test.py:108-122."""
+    tree, results = albania_result(F81)
+    lh_feature = get_personalized_feature_name(feature, LH)
+    lh_sf_feature = get_personalized_feature_name(feature, LH_SF)
+    for node in tree.traverse():
+        if not node.is_root() and not (node.is_leaf() and node.dist == 0):
+            node_loglh = np.log10(getattr(node, lh_feature).sum()) - getattr(node, lh_sf_feature)
+            parent_loglh = np.log10(getattr(node.up, lh_feature).sum()) - getattr(node.up, lh_sf_feature)
+            assert round(abs(node_loglh - parent_loglh), 2) == 0
+    root_loglh = np.log10(getattr(tree, lh_feature).sum()) - getattr(tree, lh_sf_feature)
+    assert abs(root_loglh - results[0][LOG_LIKELIHOOD] / np.log(10)) < 1e-9
+
+
+def test_state_selection_albania_mppa_f81():
+    """tests/ACRStateMPPAF81Test.py:40-104 (on the uncollapsed tree: named nodes only)."""
+    tree, _ = albania_result(F81)
+    by_name = {n.name: n for n in tree.traverse()}
+    assert getattr(tree, feature) == {'Africa'}
+    assert getattr(by_name['node_48'], feature) == {'Africa', 'Greece', 'WestEurope'}
+    assert getattr(by_name['node_32'], feature) == {'WestEurope', 'Greece'}
+    assert getattr(by_name['node_80'], feature) == {'Greece'}
+    assert getattr(by_name['01ALAY1715'], feature) == {'Albania'}
+    assert getattr(by_name['94SEAF9671'], feature) == {'WestEurope'}
+
+
+@pytest.mark.parametrize('method', [JOINT, MAP])
+def test_state_selection_other_methods(method):
+    """JOINT / MAP runs end to end and agree with the golden joint states / MAP masks at the reference optimum."""
+    tree, results = albania_result(F81, method)
+    res = results[0]
+    assert res['method'] == method and res['character'] == feature
+    z = load_golden('albania_F81')
+    np.testing.assert_allclose(res[LOG_LIKELIHOOD], z['opt_loglik'], atol=2e-6)
+    nodes = FlatForest.from_trees([tree]).nodes
+    s2i = {s: i for i, s in enumerate(res[STATES])}
+    chosen = np.array([s2i[next(iter(getattr(n, feature)))] for n in nodes])
+    assert all(len(getattr(n, feature)) == 1 for n in nodes)
+    if method == JOINT:
+        assert np.array_equal(chosen, z['fix_joint_state'])
+        assert MARGINAL_PROBABILITIES not in res
+    else:
+        assert np.array_equal(chosen, z['fix_masks_map'].argmax(axis=1))
+        assert RESTRICTED_LOG_LIKELIHOOD_FORMAT_STR.format(JOINT) not in res
+
+
+def test_meta_method_ml_returns_three_results():
+    tree = read_tree(TREE_NWK)
+    results = acr(tree, albania_df(), prediction_method=ML, model=JC)
+    assert [r['method'] for r in results] == [JOINT, MAP, MPPA]
+    assert [r['character'] for r in results] == [feature + '_' + m for m in (JOINT, MAP, MPPA)]
+    for m in (JOINT, MAP, MPPA):
+        assert all(hasattr(n, feature + '_' + m) for n in tree.traverse())
+
+
+def test_fixed_parameters_skip_the_optimiser():
+    z = load_golden('albania_F81')
+    params = {'scaling_factor': float(z['opt_sf'])}
+    params.update({s: f for s, f in zip(z['opt_states'], z['opt_frequencies'])})
+    tree = read_tree(TREE_NWK)
+    res = acr(tree, albania_df(), prediction_method=MPPA, model=F81, column2parameters={feature: params})[0]
+    assert res[MODEL].get_num_params() == 0
+    np.testing.assert_allclose(res[LOG_LIKELIHOOD], z['opt_loglik'], rtol=1e-11)
+    np.testing.assert_allclose(res[MARGINAL_PROBABILITIES].values, z['opt_posterior'], rtol=1e-8, atol=1e-300)
+    np.testing.assert_allclose(res[RESTRICTED_LOG_LIKELIHOOD_FORMAT_STR.format(MPPA)],
+                               z['opt_loglik_restricted_MPPA'], rtol=1e-11)
+
+
+def test_tau_smoothing_run():
+    """tau > 0: no state alteration, branch lengths smoothed (models/__init__.py:39-42)."""
+    z = load_golden('albania_F81')
+    params = {'scaling_factor': float(z['tau_sf']), 'smoothing_factor': float(z['tau_tau'])}
+    params.update({s: f for s, f in zip(z['tau_states'], z['tau_frequencies'])})
+    tree = read_tree(TREE_NWK)
+    res = acr(tree, albania_df(), prediction_method=MPPA, model=F81, column2parameters={feature: params},
+              force_joint=False)[0]
+    np.testing.assert_allclose(res[MODEL]._tau_factor, z['tau_tau_factor'], rtol=1e-14)
+    np.testing.assert_allclose(res[LOG_LIKELIHOOD], z['tau_loglik'], rtol=1e-11)
+    np.testing.assert_allclose(res[MARGINAL_PROBABILITIES].values, z['tau_posterior'], rtol=1e-8, atol=1e-300)
+    np.testing.assert_allclose(res[RESTRICTED_LOG_LIKELIHOOD_FORMAT_STR.format(MPPA)],
+                               z['tau_loglik_restricted_MPPA'], rtol=1e-11)
+    assert res['num_unresolved_nodes'] == int(z['tau_mppa_num_unresolved'])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def test_pij_model_identities():
+    """tests/PijTest.py: the eigen-decomposed CUSTOM_RATES P(t) equals the closed forms of F81 / JC / HKY."""
+    rng = np.random.default_rng(17)
+    states10 = np.array(list('ABCDEFGHIJ'))
+    for _ in range(5):
+        t = 10 * rng.random()
+        freqs = rng.random(10)
+        freqs /= freqs.sum()
+        ones = np.ones((10, 10)) - np.eye(10)
+        p_cr = CustomRatesModel(sf=1, states=states10, forest_stats=None, frequencies=freqs, rate_matrix=ones).get_Pij_t(t)
+        p_f81 = F81Model(sf=1, forest_stats=None, frequencies=freqs, states=states10).get_Pij_t(t)
+        assert p_cr.shape == (10, 10) and np.allclose(p_cr, p_f81)
+        eq = np.ones(10) / 10
+        p_cr = CustomRatesModel(sf=1, states=states10, forest_stats=None, frequencies=eq, rate_matrix=ones).get_Pij_t(t)
+        assert np.allclose(p_cr, JCModel(sf=1, forest_stats=None, states=states10).get_Pij_t(t))
+        kappa = 20 * rng.random()
+        f4 = rng.random(4)
+        f4 /= f4.sum()
+        rm = np.ones((4, 4)) - np.eye(4)
+        rm[A, G] = rm[G, A] = rm[C, T] = rm[T, C] = kappa
+        p_cr = CustomRatesModel(sf=1, states=HKY_STATES, forest_stats=None, frequencies=f4, rate_matrix=rm).get_Pij_t(t)
+        assert np.allclose(p_cr, HKYModel(sf=1, forest_stats=None, kappa=kappa, frequencies=f4).get_Pij_t(t))
+
+
+def test_hky_vs_f81_on_nucleotide_tree():
+    """tests/HKYF81Test.py: HKY with kappa fixed to 1 reproduces F81; free kappa fits better."""
+    tab = 'tree.152taxa.sf_0.5.A_0.6.C_0.15.G_0.2.T_0.05'
+    df = pd.read_csv(os.path.join(DATA, tab + '.pastml.tab'), index_col=0, header=0, sep='\t')[['ACR']]
+    nwk = os.path.join(DATA, tab + '.nwk')
+    r_f81 = acr(read_tree(nwk), df.copy(), prediction_method=MPPA, model=F81)[0]
+    tree = read_tree(nwk)
+    r_hky1 = acr(tree, df.copy(), prediction_method=MPPA, model=HKY, column2parameters={'ACR': {KAPPA: 1}})[0]
+    r_hky = acr(read_tree(nwk), df.copy(), prediction_method=MPPA, model=HKY)[0]
+    z = load_golden('nucleotide_hky_f81')
+    for label, r in (('f81', r_f81), ('hky_k1', r_hky1), ('hky', r_hky)):
+        np.testing.assert_allclose(r[LOG_LIKELIHOOD], z[label + '_loglik'], atol=5e-5)
+        np.testing.assert_allclose(r[MODEL].sf, z[label + '_sf'], rtol=2e-3)
+        np.testing.assert_allclose(r[MARGINAL_PROBABILITIES].values, z[label + '_posterior'], atol=2e-4)
+    np.testing.assert_allclose(r_hky[MODEL].kappa, z['hky_kappa'], rtol=2e-3)
+    for param in (LOG_LIKELIHOOD, RESTRICTED_LOG_LIKELIHOOD_FORMAT_STR.format(MPPA)):
+        assert abs(r_hky1[param] - r_f81[param]) < 5e-4
+    assert abs(r_hky1[MODEL].sf - r_f81[MODEL].sf) < 5e-3
+    assert r_hky[LOG_LIKELIHOOD] > r_hky1[LOG_LIKELIHOOD]
+    np.testing.assert_allclose(r_hky1[MODEL].frequencies, r_f81[MODEL].frequencies, atol=5e-4)
+    for name in ('ROOT', 'node_4'):
+        np.testing.assert_allclose(r_hky1[MARGINAL_PROBABILITIES].loc[name].values,
+                                   r_f81[MARGINAL_PROBABILITIES].loc[name].values, atol=5e-4)
+
+
+def test_jtt_equals_custom_rates_with_jtt_matrix(tmp_path):
+    """
+    tests/CUSTOM_RATESTest.py:40-93: JTT and CUSTOM_RATES fed with the JTT matrix and the JTT run's parameter file give
+    *identical* log-likelihoods (assertEqual) and marginal probabilities (np.all(==)): determinism, bit for bit.
+    """
+    rng = np.random.default_rng(4)
+    tree = read_tree(TREE_NWK)
+    for tip in tree:
+        s = {JTT_STATES[int(rng.integers(20))]}
+        tip.add_feature('state1', s)
+        tip.add_feature('state2', set(s))
+    r_jtt = acr(tree, columns=['state1'], column2states={'state1': JTT_STATES}, prediction_method=MPPA, model=JTT)[0]
+    params = str(tmp_path / 'params.tab')
+    with open(params, 'w') as f:
+        f.write('parameter\tvalue\n')
+        r_jtt[MODEL].save_parameters(f)
+    rm = str(tmp_path / 'rate_matrix.txt')
+    save_matrix(JTT_STATES, JTT_RATE_MATRIX, rm)
+    r_cr = acr(tree, columns=['state2'], prediction_method=MPPA, model=CUSTOM_RATES,
+               column2parameters={'state2': params}, column2rates={'state2': rm},
+               column2states={'state2': JTT_STATES})[0]
+    assert r_cr[MODEL].name == CUSTOM_RATES and r_cr[MODEL].get_num_params() == 0
+    assert r_jtt[LOG_LIKELIHOOD] == r_cr[LOG_LIKELIHOOD]
+    assert np.all(r_jtt[MARGINAL_PROBABILITIES].values == r_cr[MARGINAL_PROBABILITIES].values)
+
+
+def test_zero_likelihood_raises_pastml_error():
+    z = load_golden('edge_zero_likelihood')
+    t = read_tree('((a:0.1,b:0.2)i1:0,(c:0.1,d:0.3)i2:0.2)r:0;')
+    states = z['states']
+    by = {n.name: n for n in t.traverse()}
+    by['a'].add_feature('ch', {states[0]})
+    by['b'].add_feature('ch', {states[0]})
+    by['c'].add_feature('ch', {states[1]})
+    by['d'].add_feature('ch', {states[2]})
+    model = F81Model(states=states, forest_stats=ForestStats([t]), frequencies=z['frequencies'])
+    model.freeze()
+    ml.initialize_allowed_states(t, 'ch', states)
+    by['r'].add_feature('ch_ALLOWED_STATES', np.array([0, 1, 0]))
+    by['i1'].add_feature('ch_ALLOWED_STATES', np.array([1, 0, 0]))
+    with pytest.raises(PastMLLikelihoodError) as e:
+        ml.get_bottom_up_loglikelihood(t, 'ch', model, is_marginal=True, alter=True)
+    assert str(e.value) == str(z['error_message'])
+
+
+def test_standalone_sweep_functions_on_tree_features():
+    """The importable functions of ml.py used one by one, as utilities/transition_counter.py does."""
+    z = load_golden('albania_F81')
+    tree = read_tree(TREE_NWK)
+    from pastml_amd.annotation import preannotate_forest
+    preannotate_forest([tree], df=albania_df())
+    model = F81Model(states=z['opt_states'], forest_stats=ForestStats([tree]), sf=float(z['opt_sf']),
+                     frequencies=z['opt_frequencies'])
+    model.freeze()
+    ml.initialize_allowed_states(tree, feature, model.states)
+    lnl = ml.get_bottom_up_loglikelihood(tree, feature, model, is_marginal=True, alter=True)
+    np.testing.assert_allclose(lnl, z['fix_loglik'], rtol=1e-11)
+    # explicit alteration + alter=False, as ml_acr / marginal_counts do (ml.py:700-706)
+    flat = FlatForest.from_trees([tree])
+    problem = ml._problem_of(tree, feature, model)
+    ml._pull_masks_from_features(problem, tree, feature)
+    altered = problem.alter_zero_node_allowed_states()
+    ml._push_masks_to_features(problem, feature)
+    ml.get_bottom_up_loglikelihood(tree, feature, model, is_marginal=True, alter=False)
+    bu = np.array([getattr(n, feature + '_BOTTOM_UP_LIKELIHOOD') for n in flat.nodes])
+    bu_sf = np.array([getattr(n, feature + '_BOTTOM_UP_LIKELIHOOD_SF') for n in flat.nodes])
+    with np.errstate(divide='ignore'):
+        ours, ref = np.log10(bu) - bu_sf[:, None], np.log10(z['fix_bu']) - z['fix_bu_sf'][:, None]
+    fin = np.isfinite(ref)
+    np.testing.assert_allclose(ours[fin], ref[fin], atol=2e-10)
+    ml.calculate_top_down_likelihood(tree, feature, model)
+    ml.calculate_marginal_likelihoods(tree, feature, model.frequencies)
+    assert not hasattr(tree, feature + '_BOTTOM_UP_LIKELIHOOD')
+    mp = ml.convert_likelihoods_to_probabilities(tree, feature, model.states)
+    np.testing.assert_allclose(mp.values, z['fix_posterior'], rtol=1e-9, atol=1e-300)
+    assert list(mp.index) == list(z['node_names'])
+    assert sorted(altered.tolist()) == list(z['fix_altered_nodes'])
+
+
+def test_forest_of_trees_and_threads():
+    """Several trees and several characters in one acr() call (thread pool over characters, acr.py:226-231)."""
+    z = load_golden('edge_forest')
+    flat = FlatForest(z['parent'], z['n_children'], z['first_child'], z['dist'], np.arange(int(z['n_roots'])))
+    roots = flat.to_tree_nodes(names=list(z['node_names']))
+    states = z['states']
+    ann = z['annotation']
+    for i, n in enumerate(flat.nodes):
+        if ann[i].any():
+            n.add_feature('ch', set(states[ann[i].astype(bool)]))
+            n.add_feature('ch2', set(states[ann[i].astype(bool)]))
+    params = {'scaling_factor': float(z['sf'])}
+    params.update({s: f for s, f in zip(states, z['frequencies'])})
+    res = acr(roots, columns=['ch', 'ch2'], column2states={'ch': states, 'ch2': states}, prediction_method=MPPA,
+              model=F81, column2parameters={'ch': params, 'ch2': params}, threads=3)
+    assert [r['character'] for r in res] == ['ch', 'ch2']
+    for r in res:
+        np.testing.assert_allclose(r[LOG_LIKELIHOOD], z['loglik'], rtol=1e-11)
+        np.testing.assert_allclose(r[RESTRICTED_LOG_LIKELIHOOD_FORMAT_STR.format(MPPA)], z['loglik_restricted_MPPA'],
+                                   rtol=1e-11)
+        mp = r[MARGINAL_PROBABILITIES]
+        # rows tree by tree (pd.concat of the per-tree tables, ml.py:713)
+        order = np.lexsort((np.arange(flat.n_nodes), flat.tree_id))
+        assert list(mp.index) == [z['node_names'][i] for i in order]
+        np.testing.assert_allclose(mp.values, z['posterior'][order], rtol=1e-9, atol=1e-300)
+        assert r['num_unresolved_nodes'] == int(z['mppa_num_unresolved'])
+    sel = np.array([[s in getattr(n, 'ch') for s in states] for n in flat.nodes], dtype=np.int8)
+    assert np.array_equal(sel, z['masks_mppa'])

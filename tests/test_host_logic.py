@@ -1,0 +1,182 @@
+"""
+CPU-only tests of the host-side logic of the boundary (no sweep is computed here): forest statistics, observed
+frequencies, masks and their zero-branch alteration, MAP / MPPA selection including the reference's stateful
+'.initial' behaviour -- all against golden vectors produced by the real reference.
+"""
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from conftest import load_golden, golden_forest, GOLDEN
+from pastml_amd import ml
+from pastml_amd.acr import calculate_observed_freqs
+from pastml_amd.annotation import ForestStats, preannotate_forest
+from pastml_amd.tree import read_tree, FlatForest, TreeNode, name_tree
+
+DATA = os.path.join(GOLDEN, 'data')
+
+
+def albania():
+    tree = read_tree(os.path.join(DATA, 'Albanian.tree.152tax.tre'))
+    df = pd.read_csv(os.path.join(DATA, 'data.txt'), index_col=0, header=0)[['Country']]
+    return tree, df
+
+
+def test_newick_and_flat_forest_match_reference_tree():
+    tree, _ = albania()
+    z = load_golden('albania_F81')
+    flat = FlatForest.from_trees([tree])
+    assert flat.n_nodes == 305 and flat.n_tips == 154 and flat.n_bu_levels == 25
+    assert np.array_equal(flat.parent, z['parent'])
+    assert np.array_equal(flat.first_child[~flat.is_tip], z['first_child'][~flat.is_tip])
+    assert np.array_equal(flat.dist, z['dist'])
+    assert [n.name for n in flat.nodes] == list(z['node_names'])
+    # traversal orders of the container
+    assert [n.name for n in tree.traverse()] == list(z['node_names'])
+    post = [n for n in tree.traverse('postorder')]
+    ids = {id(n): i for i, n in enumerate(flat.nodes)}
+    assert [ids[id(n)] for n in post] == list(flat.postorder_ids())
+    # newick round trip
+    again = read_tree(tree.write())
+    assert [n.name for n in again.traverse()] == list(z['node_names'])
+    assert np.array_equal(FlatForest.from_trees([again]).dist, flat.dist)
+
+
+def test_forest_stats_and_observed_frequencies():
+    tree, df = albania()
+    z = load_golden('albania_F81')
+    preannotate_forest([tree], df=df)
+    fs = ForestStats([tree])
+    assert fs.avg_nonzero_brlen == float(z['fs_avg_nonzero_brlen'])
+    assert fs.forest_length == float(z['fs_forest_length'])
+    assert (fs.num_nodes, fs.num_tips) == (int(z['fs_num_nodes']), int(z['fs_num_tips']))
+    states = z['opt_states']
+    _, obs, _ = calculate_observed_freqs('Country', [tree], states)
+    assert np.array_equal(obs, z['observed_frequencies'])
+
+
+def test_initialize_and_alter_albania():
+    tree, df = albania()
+    z = load_golden('albania_F81')
+    preannotate_forest([tree], df=df)
+    p = ml.ForestProblem([tree], 'Country', z['opt_states'])
+    p.initialize_allowed_states()
+    assert np.array_equal(p.masks, z['fix_masks_initial'])
+    assert np.array_equal(p.annotated, z['annotation'].any(axis=1))
+    altered = p.alter_zero_node_allowed_states()
+    assert sorted(altered.tolist()) == list(z['fix_altered_nodes'])
+    assert np.array_equal(p.masks, z['fix_masks_altered'])
+    p.unalter_zero_node_allowed_states(altered)
+    assert np.array_equal(p.masks, z['fix_masks_initial'])
+    # the reference-style feature API agrees
+    ml.initialize_allowed_states(tree, 'Country', z['opt_states'])
+    got = np.array([getattr(n, 'Country_ALLOWED_STATES') for n in p.nodes])
+    assert np.array_equal(got, z['fix_masks_initial'])
+
+
+CASES = [('albania_F81', 'fix_'), ('albania_JC', 'fix_'), ('albania_EFT', 'fix_'), ('albania_F81', 'tau_'),
+         ('edge_poly', ''), ('edge_zero', ''), ('edge_zero_tau', ''), ('edge_forest', ''),
+         ('synthetic_f81_k5_L9', ''), ('synthetic_jtt_k20_L8', ''), ('synthetic_f81_k64_L8', '')]
+
+
+@pytest.mark.parametrize('name,prefix', CASES)
+def test_selection_pipeline_matches_reference(name, prefix):
+    """
+    Replays the mask bookkeeping of ml_acr (ml.py:697-748) on the reference's likelihood arrays: alteration, MAP,
+    the alteration performed by the restricted-MAP sweep, MPPA and its statistics.
+    """
+    z = load_golden(name)
+    g = lambda key: z[prefix + key]
+    flat = golden_forest(z)
+    k = g('masks_initial').shape[1]
+    p = ml.ForestProblem([], 'ch', np.arange(k), flat=flat)
+    p.masks = g('masks_initial').copy()
+    p.annotated = z['annotation'].any(axis=1) if 'annotation' in z else ~np.all(g('masks_initial') == 1, axis=1)
+    tau = float(z[{'fix_': 'opt_', 'tau_': 'tau_', '': ''}[prefix] + 'tau'])
+    altered = p.alter_zero_node_allowed_states() if tau == 0 else np.zeros(0, dtype=int)
+    assert sorted(altered.tolist()) == list(g('altered_nodes'))
+    assert np.array_equal(p.masks, g('masks_altered'))
+    p.unalter_zero_node_allowed_states(altered)
+    lh = g('lh').copy()
+    lh[p.has_init] *= p.init_masks[p.has_init]
+    p.masks = ml.select_map(lh)
+    assert np.array_equal(p.masks, g('masks_map'))
+    # restricted-MAP sweep with alter=True
+    if tau == 0:
+        a2 = p.alter_zero_node_allowed_states()
+        p.unalter_zero_node_allowed_states(a2)
+        assert np.array_equal(p.masks, g('masks_map'))
+    lh[p.has_init] *= p.init_masks[p.has_init]
+    masks, best_k = ml.select_mppa(lh, g('joint_state') if bool(g('force_joint')) else None)
+    assert np.array_equal(masks, g('masks_mppa'))
+    assert int((best_k > 1).sum()) == int(g('mppa_num_unresolved'))
+    assert int(best_k.sum()) == int(g('mppa_num_states'))
+    np.testing.assert_allclose(np.log(best_k.astype(float)).sum(), float(g('mppa_log_num_scenarios')), rtol=1e-12)
+
+
+def test_select_mppa_agrees_with_per_node_rule():
+    """Vectorised MPPA == the per-node restatement in the oracle on random likelihoods with ties."""
+    from oracle import pastml_oracle as orc
+    rng = np.random.default_rng(3)
+    for k in (2, 3, 7, 20):
+        lh = rng.dirichlet(np.ones(k) * 0.3, size=400)
+        lh[::7] = np.round(lh[::7], 1) + 1e-3  # ties
+        lh[::11, 0] = 0
+        js = rng.integers(0, k, size=len(lh))
+        for joint in (None, js):
+            a, ak = ml.select_mppa(lh, joint)
+            b, bk = orc.choose_mppa(lh, joint)
+            assert np.array_equal(a, b) and np.array_equal(ak, bk)
+
+
+def test_models_parameter_vectors():
+    """Parameter vector / bounds layout of the host models (models/__init__.py:145-181, 311-363; HKYModel.py:84-130)."""
+    from pastml_amd.models.F81Model import F81Model
+    from pastml_amd.models.JCModel import JCModel
+    from pastml_amd.models.HKYModel import HKYModel
+    from pastml_amd.models.JTTModel import JTTModel, JTT_RATE_MATRIX
+
+    class FS:
+        forest_length, num_nodes, num_tips, avg_nonzero_brlen = 10., 21, 11, 0.5
+
+    m = F81Model(states=np.array(list('cab')), forest_stats=FS(), frequencies=np.array([.2, .3, .5]))
+    assert list(m.states) == ['a', 'b', 'c']
+    assert m.sf == 2.0 and m.tau == 0
+    assert m.get_num_params() == 3
+    np.testing.assert_allclose(m.get_optimised_parameters(), [2.0, .4, .6])
+    np.testing.assert_allclose(m.get_bounds(), [[0.002, 20.], [1e-6, 1e7], [1e-6, 1e7]])
+    m.fix_extra_params()
+    assert m.get_num_params() == 3 and len(m.get_optimised_parameters()) == 1 and m.extra_params_fixed()
+    m.unfix_extra_params()
+    m.set_params_from_optimised(np.array([3., 1., 2.]))
+    np.testing.assert_allclose(m.frequencies, [.25, .5, .25])
+    assert m.sf == 3.
+    np.testing.assert_allclose(m.get_mu(), 1 / (1 - .375))
+    m.freeze()
+    assert m.get_num_params() == 0
+    with pytest.raises(NotImplementedError):
+        m.sf = 1.
+    jc = JCModel(states=np.array(list('abcd')), forest_stats=FS(), parameter_file={'scaling_factor': 1.5})
+    assert jc.sf == 1.5 and jc.get_num_params() == 0 and jc.basic_params_fixed()
+    jc2 = JCModel(states=np.array(list('abcd')), forest_stats=FS(), tau=0.1, optimise_tau=True)
+    assert jc2.get_num_params() == 2
+    np.testing.assert_allclose(jc2._tau_factor, 10. / (10. + 0.1 * 20))
+    hky = HKYModel(forest_stats=FS(), parameter_file={'kappa': 2., 'A': .1, 'C': .2, 'G': .3, 'T': .4})
+    assert hky.kappa == 2. and not hky._optimise_kappa and not hky._optimise_frequencies
+    assert hky.get_num_params() == 1
+    hky2 = HKYModel(forest_stats=FS())
+    assert hky2.get_num_params() == 5
+    np.testing.assert_allclose(hky2.get_bounds()[-1], [1e-6, 20.])
+    jtt = JTTModel(forest_stats=FS())
+    assert jtt.get_num_params() == 1 and np.array_equal(JTT_RATE_MATRIX, JTT_RATE_MATRIX.T)
+    spec = jtt.kernel_spec()
+    np.testing.assert_allclose(spec['A'].dot(np.diag(spec['d'])).dot(spec['Ainv']).sum(axis=1), 0, atol=1e-12)
+
+
+def test_name_tree():
+    t = read_tree('((a:1,b:1):1,(c:1,:1):1);')
+    name_tree(t)
+    names = [n.name for n in t.traverse('preorder')]
+    assert len(set(names)) == len(names) and names[0] == 'root' and all(names)
