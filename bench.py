@@ -91,6 +91,7 @@ def main():
         dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
 
     from pastml_amd import hip, synthetic
+    from pastml_amd.sharding import shard_characters, allreduce_sum
 
     levels, k, cpg = WORKLOADS[args.workload]
     if args.chars_per_gpu:
@@ -98,7 +99,7 @@ def main():
     model = 'JC' if args.workload == 'cfg2' else 'F81'
     flat = synthetic.balanced_forest(levels)
     N = flat.n_nodes
-    chars = [rank * cpg + i for i in range(cpg)]
+    chars = list(shard_characters(cpg * world, rank, world))  # contiguous block of characters per rank
 
     eng = hip.Engine(flat, cpg, k, device=local_rank)
     if model == 'JC':
@@ -109,7 +110,8 @@ def main():
     eng.set_tip_states(np.stack([synthetic.tip_states(flat.n_tips, k, c) for c in chars]))
     eng.sync()
 
-    lnl_dev = torch.zeros(1, dtype=torch.float64, device='cuda:{}'.format(local_rank))
+    dev = 'cuda:{}'.format(local_rank)
+    torch.zeros(1, device=dev)  # initialise torch's context on this GPU before timing
 
     def step():
         # model parameters are re-sent every step, as an optimiser iteration would: forces the per-branch
@@ -117,11 +119,8 @@ def main():
         eng.set_models([(s, (1.0, 0.0, 1.0)) for s in specs])
         lnl = eng.bottom_up(True)                       # inputs resident in HBM; returns ln L per character
         eng.top_down_marginals(posterior=False, lh=False)  # TD + marginals + posteriors, outputs stay in HBM
-        total = float(lnl.sum())
-        if dist is not None:
-            lnl_dev.fill_(total)
-            dist.all_reduce(lnl_dev)                    # the one collective of the path: summed log-likelihood
-            total = float(lnl_dev.item())
+        # the one collective of the path: summed log-likelihood over the ranks (RCCL all-reduce of 8 bytes)
+        total = allreduce_sum(float(lnl.sum()), device=dev)
         return total, lnl
 
     def fence():
@@ -144,7 +143,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device='cuda:{}'.format(local_rank))
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 

@@ -1,0 +1,77 @@
+"""
+CPU test of the N > 1 path: characters sharded over 2 ranks (gloo), per-rank log-likelihoods summed with the same
+all-reduce bench.py uses over RCCL.  The per-rank likelihoods come from the oracle (the checker), since there is no
+GPU here; the GPU ranks compute the same numbers (tests/test_gpu_parity.py).
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+from conftest import REPO
+from pastml_amd.sharding import shard_characters
+
+
+def test_shard_characters_partitions():
+    for n, w in ((256, 8), (10, 4), (3, 8), (32, 1)):
+        got = [list(shard_characters(n, r, w)) for r in range(w)]
+        assert sum(got, []) == list(range(n))
+        sizes = [len(g) for g in got]
+        assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_characters(4, 4, 4)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_chars, out):
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from oracle import pastml_oracle as orc
+    from pastml_amd import synthetic
+    from pastml_amd.sharding import allreduce_sum, gather_floats
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    flat = synthetic.balanced_forest(5)
+    k = 6
+    mine = []
+    for c in shard_characters(n_chars, rank, world):
+        masks = synthetic.one_hot_masks(flat, k, synthetic.tip_states(flat.n_tips, k, c)).astype(int)
+        mine.append(orc.bottom_up(flat, masks, dict(kind=0, pi=synthetic.f81_frequencies(k, c)))['loglik'])
+    total = allreduce_sum(sum(mine))
+    everyone = gather_floats(mine)
+    if rank == 0:
+        out.put((total, everyone))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_loglik_allreduce():
+    from oracle import pastml_oracle as orc
+    from pastml_amd import synthetic
+    n_chars, world = 4, 2
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_chars, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    total, everyone = out.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    flat = synthetic.balanced_forest(5)
+    k = 6
+    ref = [orc.bottom_up(flat, synthetic.one_hot_masks(flat, k, synthetic.tip_states(flat.n_tips, k, c)).astype(int),
+                         dict(kind=0, pi=synthetic.f81_frequencies(k, c)))['loglik'] for c in range(n_chars)]
+    np.testing.assert_allclose(everyone, ref, rtol=1e-14)
+    np.testing.assert_allclose(total, sum(ref), rtol=1e-14)
