@@ -44,7 +44,7 @@ enum { PML_MODEL_F81 = 0, PML_MODEL_HKY = 1, PML_MODEL_EIGEN = 2 };
 enum {
     PML_BUF_BU = 0,          /* double[n_nodes][k]  bottom-up vectors of one column (tips: their masks as 0/1)      */
     PML_BUF_BU_SF = 1,       /* double[n_nodes]     their base-10 scale (reference BU_LH_SF convention)              */
-    PML_BUF_TD = 2,          /* double[n_nodes][k]  top-down vectors (defined for internal nodes; tips: NaN)         */
+    PML_BUF_TD = 2,          /* double[n_nodes][k]  top-down vectors (stored internal nodes; others: NaN)           */
     PML_BUF_TD_SF = 3,       /* double[n_nodes]                                                                        */
     PML_BUF_POSTERIOR = 4,   /* double[n_nodes][k]  marginal posteriors                                                */
     PML_BUF_LH_SUM = 5,      /* double[n_nodes]     sum of the (scaled) marginal likelihoods, in [1, 2)                */
@@ -62,6 +62,13 @@ int pml_device_count(int* count);
 int pml_ctx_create(int device, pml_ctx** out);
 int pml_ctx_destroy(pml_ctx* ctx);
 int pml_ctx_sync(pml_ctx* ctx);
+/*
+ * Options (set before pml_tree_upload).  PML_OPT_CHERRY_FUSION (default 1): in the F81-family marginal sweeps,
+ * internal nodes whose children are all tips are recomputed in registers instead of being stored in HBM; their
+ * top-down vectors are then never materialised (pml_download(PML_BUF_TD) reports NaN for them, as for tips).
+ */
+enum { PML_OPT_CHERRY_FUSION = 1 };
+int pml_ctx_set_option(pml_ctx* ctx, int option, int value);
 /* bytes of device memory currently held by the ctx / free on its device */
 int pml_ctx_memory(pml_ctx* ctx, uint64_t* held, uint64_t* device_free);
 

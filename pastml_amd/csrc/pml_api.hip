@@ -57,6 +57,14 @@ struct pml_ctx {
     int *d_bu_order = nullptr, *d_td_parents = nullptr;
     double* d_dist = nullptr;
     std::vector<int> bu_offsets, td_offsets, td_parent_offsets, h_parent, h_n_children;
+    // cherry fusion (F81 marginal sweeps): node kinds and level lists over the stored internal nodes only
+    bool fuse = true;
+    unsigned char* d_kind = nullptr;
+    std::vector<unsigned char> h_kind;
+    int *d_bu_order_f = nullptr, *d_td_parents_f = nullptr, *d_cherries = nullptr;
+    std::vector<int> bu_offsets_f, td_parent_offsets_f;
+    int n_cherries = 0;
+    bool bu_fused = false;  // the last bottom-up sweep left the cherries unmaterialised
 
     // columns
     int C = 0, k = 0, ks = 0, W = 0, G = 0, R = 0;
@@ -121,8 +129,9 @@ static int grid_for(int n_units, int units_per_block, int C) {
     return blocks;
 }
 
-static PmlTree tree_of(const pml_ctx* c) {
+static PmlTree tree_of(const pml_ctx* c, bool fused = false) {
     PmlTree t;
+    t.kind = fused ? c->d_kind : nullptr;
     t.N = c->N;
     t.n_roots = c->n_roots;
     t.parent = c->d_parent;
@@ -206,17 +215,18 @@ static int prof_end(pml_ctx* ctx, int which, long long launches) {
     X(64, 2)             \
     X(64, 4)
 
-enum SweepKind { SW_BU_MARG, SW_BU_JOINT, SW_TD, SW_ROOTS };
+enum SweepKind { SW_BU_MARG, SW_BU_JOINT, SW_TD, SW_ROOTS, SW_BU_MARG_FUSED, SW_TD_FUSED };
 
 template <int G, int R>
 static void launch_sweep(pml_ctx* ctx, SweepKind what, const int* level, int n_level) {
-    const PmlTree t = tree_of(ctx);
+    const PmlTree t = tree_of(ctx, what == SW_BU_MARG_FUSED || what == SW_TD_FUSED);
     const PmlCols c = cols_of(ctx);
     const PmlState st = state_of(ctx);
     const int upb = PML_WAVES_PER_BLOCK * (64 / G);
     dim3 grid(grid_for(n_level, upb, ctx->C), ctx->C), block(PML_BLOCK);
     const bool f81 = ctx->kind == PML_MODEL_F81;
     switch (what) {
+        case SW_BU_MARG_FUSED:
         case SW_BU_MARG:
             if (f81)
                 hipLaunchKernelGGL((bu_f81_kernel<G, R, false>), grid, block, 0, ctx->stream, t, c, st, level, n_level);
@@ -231,6 +241,7 @@ static void launch_sweep(pml_ctx* ctx, SweepKind what, const int* level, int n_l
                 hipLaunchKernelGGL((bu_matrix_kernel<G, R, true>), grid, block, 0, ctx->stream, t, c, st, ctx->d_P,
                                    level, n_level);
             break;
+        case SW_TD_FUSED:
         case SW_TD:
             if (f81)
                 hipLaunchKernelGGL((td_f81_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, level, n_level);
@@ -309,6 +320,16 @@ int pml_ctx_destroy(pml_ctx* ctx) {
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return PML_OK;
+}
+
+int pml_ctx_set_option(pml_ctx* ctx, int option, int value) {
+    if (!ctx) return fail(PML_ERR_INVALID, "ctx is NULL");
+    if (option == PML_OPT_CHERRY_FUSION) {
+        if (ctx->N != 0) return fail(PML_ERR_INVALID, "PML_OPT_CHERRY_FUSION must be set before the tree is uploaded");
+        ctx->fuse = value != 0;
+        return PML_OK;
+    }
+    return fail(PML_ERR_INVALID, "unknown option %d", option);
 }
 
 int pml_ctx_sync(pml_ctx* ctx) {
@@ -403,7 +424,9 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
     hipEvent_t e0 = ctx->ev0, e1 = ctx->ev1, p0 = ctx->pev[0], p1 = ctx->pev[1];
     int device = ctx->device;
     const bool profile = ctx->profile;
+    const bool fuse = ctx->fuse;
     *ctx = pml_ctx();
+    ctx->fuse = fuse;
     ctx->stream = stream;
     ctx->ev0 = e0;
     ctx->ev1 = e1;
@@ -436,6 +459,71 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
     if (n_internal) {
         PML_TRY(upload(ctx, ctx->d_bu_order, bu_order, n_internal));
         PML_TRY(upload(ctx, ctx->d_td_parents, td_parents, n_internal));
+    }
+    // ---- cherry fusion tables: kind per node, level lists over the stored internal nodes
+    {
+        std::vector<unsigned char>& kind = ctx->h_kind;
+        kind.assign(n_nodes, PML_KIND_TIP);
+        std::vector<int> cherries, fh(n_nodes, 0);
+        for (int i = 0; i < n_nodes; ++i) {
+            if (n_children[i] == 0) continue;
+            bool all_tips = true;
+            for (int j = 0; j < n_children[i]; ++j) all_tips &= n_children[first_child[i] + j] == 0;
+            if (ctx->fuse && all_tips && parent[i] >= 0) {
+                kind[i] = PML_KIND_CHERRY;
+                cherries.push_back(i);
+            } else {
+                kind[i] = PML_KIND_STORED;
+            }
+        }
+        int max_h = 0;
+        for (int i = n_nodes - 1; i >= 0; --i) {  // children have larger ids than their parent
+            if (kind[i] != PML_KIND_STORED) continue;
+            int h = 0;
+            for (int j = 0; j < n_children[i]; ++j) {
+                const int ch = first_child[i] + j;
+                if (kind[ch] == PML_KIND_STORED && fh[ch] > h) h = fh[ch];
+            }
+            fh[i] = h + 1;
+            if (fh[i] > max_h) max_h = fh[i];
+        }
+        std::vector<int>& off = ctx->bu_offsets_f;
+        off.assign(max_h + 1, 0);
+        for (int i = 0; i < n_nodes; ++i)
+            if (kind[i] == PML_KIND_STORED) ++off[fh[i]];
+        // off[h] = count of height h (h >= 1) -> exclusive prefix: level l (0-based) = height l + 1
+        {
+            int run = 0;
+            for (int h = 1; h <= max_h; ++h) {
+                const int cnt = off[h];
+                off[h - 1] = run;
+                run += cnt;
+            }
+            off[max_h] = run;
+        }
+        const int n_stored = off[max_h];
+        std::vector<int> order(n_stored > 0 ? n_stored : 1), cursor(off.begin(), off.end());
+        for (int i = 0; i < n_nodes; ++i)
+            if (kind[i] == PML_KIND_STORED) order[cursor[fh[i] - 1]++] = i;
+        std::vector<int> tdp;
+        ctx->td_parent_offsets_f.assign(n_td_levels + 1, 0);
+        for (int l = 0; l < n_td_levels; ++l) {
+            for (int q = td_parent_offsets[l]; q < td_parent_offsets[l + 1]; ++q)
+                if (kind[td_parents[q]] == PML_KIND_STORED) tdp.push_back(td_parents[q]);
+            ctx->td_parent_offsets_f[l + 1] = (int)tdp.size();
+        }
+        ctx->n_cherries = (int)cherries.size();
+        PML_TRY(dev_alloc(ctx, &ctx->d_kind, n_nodes));
+        PML_TRY(dev_alloc(ctx, &ctx->d_bu_order_f, n_stored));
+        PML_TRY(dev_alloc(ctx, &ctx->d_td_parents_f, n_stored));
+        PML_TRY(dev_alloc(ctx, &ctx->d_cherries, cherries.size()));
+        PML_TRY(upload(ctx, ctx->d_kind, kind.data(), n_nodes));
+        if (n_stored) {
+            PML_TRY(upload(ctx, ctx->d_bu_order_f, order.data(), n_stored));
+            PML_TRY(upload(ctx, ctx->d_td_parents_f, tdp.data(), n_stored));
+        }
+        if (!cherries.empty()) PML_TRY(upload(ctx, ctx->d_cherries, cherries.data(), cherries.size()));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return PML_OK;
@@ -782,11 +870,22 @@ int pml_bottom_up(pml_ctx* ctx, int is_marginal, double* loglik_out, int32_t* er
     ctx->td_valid = ctx->js_valid = false;
     HIP_TRY(hipMemsetAsync(ctx->d_err, 0xFF, sizeof(u64) * ctx->C, ctx->stream));
     PML_TRY(prof_begin(ctx));
-    for (int l = 0; l < ctx->n_bu_levels; ++l) {
-        const int a = ctx->bu_offsets[l], b = ctx->bu_offsets[l + 1];
-        PML_TRY(dispatch_sweep(ctx, is_marginal ? SW_BU_MARG : SW_BU_JOINT, ctx->d_bu_order + a, b - a));
+    const bool fused = is_marginal && ctx->kind == PML_MODEL_F81;
+    if (fused) {
+        const int nl = (int)ctx->bu_offsets_f.size() - 1;
+        for (int l = 0; l < nl; ++l) {
+            const int a = ctx->bu_offsets_f[l], b = ctx->bu_offsets_f[l + 1];
+            PML_TRY(dispatch_sweep(ctx, SW_BU_MARG_FUSED, ctx->d_bu_order_f + a, b - a));
+        }
+        PML_TRY(prof_end(ctx, 0, nl));
+    } else {
+        for (int l = 0; l < ctx->n_bu_levels; ++l) {
+            const int a = ctx->bu_offsets[l], b = ctx->bu_offsets[l + 1];
+            PML_TRY(dispatch_sweep(ctx, is_marginal ? SW_BU_MARG : SW_BU_JOINT, ctx->d_bu_order + a, b - a));
+        }
+        PML_TRY(prof_end(ctx, 0, ctx->n_bu_levels));
     }
-    PML_TRY(prof_end(ctx, 0, ctx->n_bu_levels));
+    ctx->bu_fused = fused && ctx->n_cherries > 0;
     hipLaunchKernelGGL(loglik_kernel, dim3((ctx->C + PML_BLOCK - 1) / PML_BLOCK), dim3(PML_BLOCK), 0, ctx->stream,
                        tree_of(ctx), cols_of(ctx), state_of(ctx), ctx->C, is_marginal ? 1 : 0, ctx->d_loglik);
     HIP_TRY(hipGetLastError());
@@ -824,9 +923,12 @@ int pml_top_down_marginals(pml_ctx* ctx, double* posterior_out, double* lh_sum_o
     PML_TRY(dispatch_sweep(ctx, SW_ROOTS, nullptr, ctx->n_roots));
     PML_TRY(prof_begin(ctx));
     long long n_launch = 0;
+    const bool td_fused = ctx->kind == PML_MODEL_F81;
     for (int l = 0; l < ctx->n_td_levels; ++l) {
-        const int a = ctx->td_parent_offsets[l], b = ctx->td_parent_offsets[l + 1];
-        PML_TRY(dispatch_sweep(ctx, SW_TD, ctx->d_td_parents + a, b - a));
+        const std::vector<int>& off = td_fused ? ctx->td_parent_offsets_f : ctx->td_parent_offsets;
+        const int a = off[l], b = off[l + 1];
+        PML_TRY(dispatch_sweep(ctx, td_fused ? SW_TD_FUSED : SW_TD,
+                               (td_fused ? ctx->d_td_parents_f : ctx->d_td_parents) + a, b - a));
         if (b > a) ++n_launch;
     }
     PML_TRY(prof_end(ctx, 1, n_launch));
@@ -896,9 +998,19 @@ static int fetch_exponents(pml_ctx* ctx, const i64* src, int col, double* out) {
     return PML_OK;
 }
 
+// after a fused sweep the cherries' bottom-up vectors only ever existed in registers: compute them for inspection
+static int materialize_cherries(pml_ctx* ctx) {
+    if (!ctx->bu_fused) return PML_OK;
+    PML_TRY(dispatch_sweep(ctx, SW_BU_MARG, ctx->d_cherries, ctx->n_cherries));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->bu_fused = false;
+    return PML_OK;
+}
+
 int pml_download(pml_ctx* ctx, int what, int32_t col, void* out) {
     PML_TRY(require_model(ctx));
     if (col < 0 || col >= ctx->C || !out) return fail(PML_ERR_INVALID, "bad column / output");
+    if (what == PML_BUF_BU || what == PML_BUF_BU_SF) PML_TRY(materialize_cherries(ctx));
     const size_t N = ctx->N;
     const double nan = std::numeric_limits<double>::quiet_NaN();
     switch (what) {
@@ -924,16 +1036,19 @@ int pml_download(pml_ctx* ctx, int what, int32_t col, void* out) {
             if (!ctx->td_valid) return fail(PML_ERR_INVALID, "no valid top-down sweep");
             double* o = (double*)out;
             PML_TRY(fetch_vectors(ctx, ctx->d_td, col, o));
+            const bool f81 = ctx->kind == PML_MODEL_F81;
             for (size_t n = 0; n < N; ++n)
-                if (ctx->h_n_children[n] == 0 && ctx->h_parent[n] >= 0)
+                if ((ctx->h_n_children[n] == 0 && ctx->h_parent[n] >= 0) || (f81 && ctx->h_kind[n] == PML_KIND_CHERRY))
                     for (int s = 0; s < ctx->k; ++s) o[n * ctx->k + s] = nan;
             return PML_OK;
         }
         case PML_BUF_TD_SF: {
             if (!ctx->td_valid) return fail(PML_ERR_INVALID, "no valid top-down sweep");
             PML_TRY(fetch_exponents(ctx, ctx->d_te, col, (double*)out));
+            const bool f81 = ctx->kind == PML_MODEL_F81;
             for (size_t n = 0; n < N; ++n)
-                if (ctx->h_n_children[n] == 0 && ctx->h_parent[n] >= 0) ((double*)out)[n] = nan;
+                if ((ctx->h_n_children[n] == 0 && ctx->h_parent[n] >= 0) || (f81 && ctx->h_kind[n] == PML_KIND_CHERRY))
+                    ((double*)out)[n] = nan;
             return PML_OK;
         }
         case PML_BUF_POSTERIOR:

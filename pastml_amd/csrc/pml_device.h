@@ -17,11 +17,51 @@ typedef long long i64;
 // lazy rescaling band: a vector is renormalised (max -> [1, 2)) when a non-zero entry leaves [2^-PML_BAND, 2^PML_BAND]
 #define PML_BAND 200
 
+// lane exchange inside a 16-lane row by a DPP modifier (VALU only, no LDS crossbar)
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+// x[row 2q] + x[row 2q+1] in both rows (v_permlane16_swap: odd rows of one operand <-> even rows of the other)
+__device__ __forceinline__ double row_pair_sum(double v) {
+    const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+}
+
+// x[lanes 0..31] + x[lanes 32..63] in both halves (v_permlane32_swap)
+__device__ __forceinline__ double half_pair_sum(double v) {
+    const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+}
+
+// Sum over the G lanes of a unit, result in every lane, fixed order (bit-reproducible).
+// quad_perm [1,0,3,2] / [2,3,0,1], row_half_mirror, row_mirror, then the two gfx950 swap instructions.
 template <int G>
 __device__ __forceinline__ double group_sum(double v) {
-#pragma unroll
-    for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (G >= 2) v += dpp_f64<0xB1>(v);
+    if (G >= 4) v += dpp_f64<0x4E>(v);
+    if (G >= 8) v += dpp_f64<0x141>(v);
+    if (G >= 16) v += dpp_f64<0x140>(v);
+    if (G >= 32) v = row_pair_sum(v);
+    if (G >= 64) v = half_pair_sum(v);
     return v;
+}
+
+// 1/x for normal positive x: v_rcp_f64 + two Newton steps (the sweeps never divide by denormals or zeros)
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-x, r, 1.0);
+    return fma(r, e, r);
 }
 
 template <int G>
@@ -111,6 +151,9 @@ __device__ __forceinline__ void mask_to_vec(u64 word, int s0, int k, double (&v)
     }
 }
 
+// floor(log2(x)) of a finite positive double (v_frexp_exp_i32_f64 returns the exponent of a mantissa in [0.5, 1))
+__device__ __forceinline__ int exponent_of(double x) { return __builtin_amdgcn_frexp_exp(x) - 1; }
+
 // Renormalises acc (max -> [1, 2)) if any non-zero entry left the band; returns the exponent taken out
 // (true value = acc * 2^returned).
 template <int G, int R>
@@ -126,9 +169,9 @@ __device__ __forceinline__ int lazy_rescale(double (&acc)[R]) {
     if (!group_any<G>(out_of_band)) return 0;
     m = group_max<G>(m);
     if (!(m > 0.0) || isinf(m)) return 0;
-    const int ex = ilogb(m);
+    const int ex = exponent_of(m);
 #pragma unroll
-    for (int r = 0; r < R; ++r) acc[r] = scalbn(acc[r], -ex);
+    for (int r = 0; r < R; ++r) acc[r] = __builtin_ldexp(acc[r], -ex);
     return ex;
 }
 

@@ -238,12 +238,12 @@ td_matrix_kernel(PmlTree t, PmlCols c, PmlState st, const double* __restrict__ P
                 if (lane_valid) store_vec<R>(st.td + (colN + ch) * c.ks + s0, tdc);
                 if (g == 0) st.te[colN + ch] = xe;
             }
-            const int lex = (lhs > 0.0 && !isinf(lhs)) ? ilogb(lhs) : 0;
+            const int lex = (lhs > 0.0 && !isinf(lhs)) ? exponent_of(lhs) : 0;
 #pragma unroll
             for (int r = 0; r < R; ++r) lh[r] = lh[r] / lhs;
             if (lane_valid) store_vec<R>(st.post + (colN + ch) * c.ks + s0, lh);
             if (g == 0) {
-                st.lhsum[colN + ch] = scalbn(lhs, -lex);
+                st.lhsum[colN + ch] = __builtin_ldexp(lhs, -lex);
                 st.lhe[colN + ch] = xe + bec + lex;
             }
             __builtin_amdgcn_wave_barrier();

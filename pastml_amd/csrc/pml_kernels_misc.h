@@ -63,7 +63,7 @@ td_roots_kernel(PmlTree t, PmlCols c, PmlState st) {
             lhs += lh[r];
         }
         lhs = group_sum<G>(lhs);
-        const int lex = (lhs > 0.0 && !isinf(lhs)) ? ilogb(lhs) : 0;
+        const int lex = (lhs > 0.0 && !isinf(lhs)) ? exponent_of(lhs) : 0;
 #pragma unroll
         for (int r = 0; r < R; ++r) lh[r] = lh[r] / lhs;
         if (lane_valid) {
@@ -72,7 +72,7 @@ td_roots_kernel(PmlTree t, PmlCols c, PmlState st) {
         }
         if (g == 0) {
             st.te[colN + n] = 0;
-            st.lhsum[colN + n] = scalbn(lhs, -lex);
+            st.lhsum[colN + n] = __builtin_ldexp(lhs, -lex);
             st.lhe[colN + n] = (tip ? 0 : st.be[colN + n]) + lex;
         }
     }

@@ -21,6 +21,7 @@ BUF_BU, BUF_BU_SF, BUF_TD, BUF_TD_SF, BUF_POSTERIOR, BUF_LH_SUM, BUF_LH_SF, BUF_
     BUF_BRANCH_EXP = range(10)
 
 MAX_STATES = 256
+OPT_CHERRY_FUSION = 1
 
 
 class HipUnavailableError(RuntimeError):
@@ -55,6 +56,7 @@ SIGNATURES = {
     'pml_ctx_create': [ctypes.c_int, ctypes.POINTER(_ctx_p)],
     'pml_ctx_destroy': [_ctx_p],
     'pml_ctx_sync': [_ctx_p],
+    'pml_ctx_set_option': [_ctx_p, ctypes.c_int, ctypes.c_int],
     'pml_ctx_memory': [_ctx_p, _c_uint64_p, _c_uint64_p],
     'pml_tree_upload': [_ctx_p, ctypes.c_int32, ctypes.c_int32, _c_int32_p, _c_int32_p, _c_int32_p, _c_double_p,
                         ctypes.c_int32, _c_int32_p, _c_int32_p, ctypes.c_int32, _c_int32_p, _c_int32_p, _c_int32_p,
@@ -157,7 +159,7 @@ class Engine(object):
     >>> post, lh_sum, lh_sf = eng.top_down_marginals()
     """
 
-    def __init__(self, flat, n_cols, k, device=None):
+    def __init__(self, flat, n_cols, k, device=None, cherry_fusion=True):
         lib = load_library()
         if device_count() < 1:
             raise HipUnavailableError('no HIP device visible: the likelihood path needs an MI355X (gfx950)')
@@ -165,6 +167,8 @@ class Engine(object):
         self._ctx = _ctx_p()
         self.device = default_device() if device is None else device
         _check(lib.pml_ctx_create(self.device, ctypes.byref(self._ctx)))
+        if not cherry_fusion:
+            _check(lib.pml_ctx_set_option(self._ctx, OPT_CHERRY_FUSION, 0))
         self.flat = flat
         self.n_nodes = flat.n_nodes
         self.n_cols = n_cols
