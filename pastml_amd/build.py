@@ -28,7 +28,7 @@ def is_stale():
 def build(force=False, verbose=False):
     if not force and not is_stale():
         return LIB
-    cmd = [find_hipcc(), '-O3', '--offload-arch=gfx950', '-std=c++17', '-shared', '-fPIC', '-o', LIB] + SOURCES
+    cmd = [find_hipcc(), '-O3', '--offload-arch=gfx950', '-std=c++17', '-ffp-contract=on', '-shared', '-fPIC', '-o', LIB] + SOURCES
     if verbose:
         print(' '.join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)

@@ -542,6 +542,11 @@ int pml_chars_alloc(pml_ctx* ctx, int32_t n_cols, int32_t k) {
     pick_group(k, ctx->G, ctx->R);
     ctx->ks = (k + ctx->R - 1) / ctx->R * ctx->R;
     ctx->W = (k + 63) / 64;
+    if ((size_t)ctx->N * ctx->ks >= (1ull << 31)) {
+        // the kernels address one column's slab with 32-bit element offsets
+        ctx->C = 0;
+        return fail(PML_ERR_UNSUPPORTED, "n_nodes * k = %zu exceeds 2^31 elements per column", (size_t)ctx->N * ctx->ks);
+    }
     const size_t CN = (size_t)n_cols * ctx->N;
     PML_TRY(dev_alloc(ctx, &ctx->d_masks, CN * ctx->W));
     PML_TRY(dev_alloc(ctx, &ctx->d_pi, (size_t)n_cols * ctx->ks));

@@ -6,6 +6,10 @@
 // needs it -- its parent in the bottom-up sweep, its parent again in the top-down sweep -- recomputes it in
 // registers; its own top-down vector only lives in registers while its tips are finished.  On a balanced tree half of
 // the internal nodes are cherries: the bottom-up traffic halves and the top-down traffic drops by ~40 %.
+//
+// Observed tips (exactly one allowed state s) are finished in closed form in the top-down sweep: their posterior is
+// the unit vector and their marginal likelihood needs only pi . (TD o BU) of the parent (one reduction per parent,
+// shared by all its observed tips) and the parent's entry at s -- no per-tip reduction.
 #pragma once
 #include "pml_device.h"
 
@@ -81,31 +85,57 @@ f81_prep_kernel(PmlTree t, PmlCols c, const double* __restrict__ mu, const doubl
     }
 }
 
-// Per-lane context of a unit's lane group.
+// Per-lane context of a unit's lane group: lane geometry and the column's slabs (element offsets inside one column
+// fit 32 bits: N * ks < 2^31 is checked on the host).
 template <int R>
 struct LaneCtx {
-    int col, g, s0, w0;
+    int col, g, s0, w0, group_base;
     bool lane_valid;
-    size_t colN;
     double pi_r[R];
+    const u64* mask;
+    const double* E;
+    double* S;
+    i64* be;
+    double* bu;
+    double* td;
+    i64* te;
+    double* post;
+    double* lhsum;
+    i64* lhe;
 };
 
 template <int G, int R>
-__device__ __forceinline__ void lane_ctx_init(LaneCtx<R>& L, const PmlTree& t, const PmlCols& c) {
+__device__ __forceinline__ void lane_ctx_init(LaneCtx<R>& L, const PmlTree& t, const PmlCols& c, const PmlState& st) {
     const int lane = threadIdx.x & 63;
     L.col = blockIdx.y;
     L.g = lane & (G - 1);
+    L.group_base = lane & ~(G - 1);
     L.s0 = L.g * R;
     L.w0 = L.s0 >> 6;
     L.lane_valid = L.s0 < c.ks;
-    L.colN = (size_t)L.col * t.N;
+    const size_t colN = (size_t)L.col * t.N;
+    L.mask = c.masks + colN * c.W;
+    L.E = st.E + colN;
+    L.S = st.S + colN;
+    L.be = st.be + colN;
+    L.bu = st.bu + colN * c.ks;
+    L.td = st.td + colN * c.ks;
+    L.te = st.te + colN;
+    L.post = st.post + colN * c.ks;
+    L.lhsum = st.lhsum + colN;
+    L.lhe = st.lhe + colN;
 #pragma unroll
     for (int r = 0; r < R; ++r) L.pi_r[r] = (L.s0 + r < c.k) ? c.pi[(size_t)L.col * c.ks + L.s0 + r] : 0.0;
 }
 
 template <int R>
+__device__ __forceinline__ unsigned vec_off(const LaneCtx<R>& L, const PmlCols& c, int n) {
+    return (unsigned)n * (unsigned)c.ks + (unsigned)L.s0;
+}
+
+template <int R>
 __device__ __forceinline__ void node_mask_vec(const LaneCtx<R>& L, const PmlCols& c, int n, double (&v)[R]) {
-    const u64 word = L.lane_valid ? c.masks[(L.colN + n) * c.W + L.w0] : 0ull;
+    const u64 word = L.lane_valid ? L.mask[(unsigned)n * (unsigned)c.W + (unsigned)L.w0] : 0ull;
     mask_to_vec<R>(word, L.s0, c.k, v);
 }
 
@@ -113,33 +143,41 @@ template <int R>
 __device__ __forceinline__ void node_load_vec(const LaneCtx<R>& L, const PmlCols& c, const double* base, int n,
                                               double (&v)[R]) {
     if (L.lane_valid) {
-        load_vec<R>(base + (L.colN + n) * c.ks + L.s0, v);
+        load_vec<R>(base + vec_off<R>(L, c, n), v);
     } else {
 #pragma unroll
         for (int r = 0; r < R; ++r) v[r] = 0.0;
     }
 }
 
-// Multiplies acc by the message of child ch (vector v, S = pi . v, branch factor e), then the zero check of
-// ml.py:139-145 and the lazy rescale.  Returns the exponent taken out.
 template <int G, int R>
-__device__ __forceinline__ int f81_absorb_child(const LaneCtx<R>& L, const PmlTree& t, const PmlState& st, int n,
-                                                int ch, double e, double s_child, const double (&v)[R],
-                                                double (&acc)[R], bool report) {
+__device__ __forceinline__ double pi_dot(const LaneCtx<R>& L, const double (&v)[R]) {
+    double s = 0.0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) s += L.pi_r[r] * v[r];
+    return group_sum<G>(s);
+}
+
+// Multiplies acc by the message of child ch (vector v, S = pi . v, branch factor e) and performs the zero check of
+// ml.py:139-145.  Every term of the closed form is >= 0, so the clamp of ml.py:137 is a no-op.
+template <int G, int R>
+__device__ __forceinline__ void f81_absorb_child(const LaneCtx<R>& L, const PmlTree& t, const PmlState& st, int n,
+                                                 int ch, double e, double s_child, const double (&v)[R],
+                                                 double (&acc)[R], bool report) {
     const double a = (1.0 - e) * s_child;
     bool nz = false;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        acc[r] *= a + e * v[r];  // every term of the closed form is >= 0: the clamp of ml.py:137 is a no-op
+        acc[r] *= a + e * v[r];
         nz |= acc[r] != 0.0;
     }
     if (report && !group_any<G>(nz)) {
         if (L.g == 0) atomicMin(&st.err[L.col], ((u64)(unsigned)t.post_rank[n] << 32) | (u64)(unsigned)ch);
     }
-    return lazy_rescale<G, R>(acc);
 }
 
 // Bottom-up vector of a cherry (all children are tips) in registers: mask * prod of tip messages (ml.py:124-148).
+// Messages of tips are >= (1 - e) pi_min, so the band is checked every fourth child only.
 template <int G, int R>
 __device__ __forceinline__ void f81_cherry_vector(const LaneCtx<R>& L, const PmlTree& t, const PmlCols& c,
                                                   const PmlState& st, int n, double (&acc)[R], i64& esum,
@@ -152,16 +190,138 @@ __device__ __forceinline__ void f81_cherry_vector(const LaneCtx<R>& L, const Pml
         const int ch = fc + j;
         double v[R];
         node_mask_vec<R>(L, c, ch, v);
-        esum += f81_absorb_child<G, R>(L, t, st, n, ch, st.E[L.colN + ch], st.S[L.colN + ch], v, acc, report);
+        f81_absorb_child<G, R>(L, t, st, n, ch, L.E[ch], L.S[ch], v, acc, report);
+        if ((j & 3) == 3 || j == nc - 1) esum += lazy_rescale<G, R>(acc);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Lane-parallel metadata gather.  The scalar data of a unit's children (kind, e, S, mask word, exponent, child range)
+// and of the tips below its cherry children are loaded by *different lanes* of the unit's lane group in two rounds --
+// lane j takes child j, lane j * GC + q takes tip q of child j -- and broadcast with ds_bpermute when needed, instead
+// of every lane walking the children one after the other (one dependent memory round trip per child and per tip).
+// Needs single-word masks (k <= 64), at most CH children and at most GC tips per cherry; other units take the
+// sequential path.  The arithmetic is the same sequence of operations, so both paths give identical bits.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int G>
+struct Gather {
+    static constexpr int GC = 4;
+    static constexpr int CH = (G / 4 < 8) ? G / 4 : 8;
+    static constexpr bool enabled = G >= 8;
+};
+
+struct ChildLane {  // what lane j holds about child j
+    int kind, fc, nc;
+    double e, s;
+    u64 mask;
+    i64 be;
+};
+
+struct TipLane {  // what lane j * GC + q holds about tip q of cherry child j
+    double e, s;
+    u64 mask;
+};
+
+template <int G, int R>
+__device__ __forceinline__ bool f81_gather(const LaneCtx<R>& L, const PmlTree& t, int fc, int nc, ChildLane& cl,
+                                           TipLane& tl) {
+    constexpr int GC = Gather<G>::GC;
+    const int j = L.g;
+    const bool has = j < nc;
+    const int ch = fc + (has ? j : 0);
+    cl.fc = t.first_child[ch];
+    cl.nc = has ? t.n_children[ch] : 0;
+    cl.kind = (t.kind != nullptr) ? (int)t.kind[ch] : (cl.nc == 0 ? PML_KIND_TIP : PML_KIND_STORED);
+    if (!has) cl.kind = PML_KIND_TIP;
+    cl.e = L.E[ch];
+    cl.s = L.S[ch];
+    cl.mask = L.mask[(unsigned)ch];
+    cl.be = L.be[ch];
+    if (group_any<G>(has && cl.kind == PML_KIND_CHERRY && cl.nc > GC)) return false;
+    const int jj = L.g / GC, q = L.g % GC;
+    const int src = L.group_base + jj;
+    const int ck = __shfl(cl.kind, src, 64);
+    const int cfc = __shfl(cl.fc, src, 64);
+    const int cnc = __shfl(cl.nc, src, 64);
+    const bool has_t = jj < nc && ck == PML_KIND_CHERRY && q < cnc;
+    const int tip = has_t ? cfc + q : fc;
+    tl.e = L.E[tip];
+    tl.s = L.S[tip];
+    tl.mask = L.mask[(unsigned)tip];
+    return true;
+}
+
+// cherry child jx of the unit rebuilt from the gathered tip data; same operation order as f81_cherry_vector
+template <int G, int R>
+__device__ __forceinline__ void f81_cherry_from_lanes(const LaneCtx<R>& L, const PmlTree& t, const PmlCols& c,
+                                                      const PmlState& st, const ChildLane& cl, const TipLane& tl,
+                                                      int jx, int cherry, double (&v)[R], i64& esum, bool report) {
+    constexpr int GC = Gather<G>::GC;
+    const int src = L.group_base + jx;
+    const u64 word = __shfl(cl.mask, src, 64);
+    mask_to_vec<R>(L.lane_valid ? word : 0ull, L.s0, c.k, v);
+    const int cfc = __shfl(cl.fc, src, 64);
+    const int cnc = __shfl(cl.nc, src, 64);
+    esum = 0;
+    for (int q = 0; q < cnc; ++q) {
+        const int ts = L.group_base + jx * GC + q;
+        const u64 tw = __shfl(tl.mask, ts, 64);
+        double tv[R];
+        mask_to_vec<R>(L.lane_valid ? tw : 0ull, L.s0, c.k, tv);
+        f81_absorb_child<G, R>(L, t, st, cherry, cfc + q, __shfl(tl.e, ts, 64), __shfl(tl.s, ts, 64), tv, v, report);
+        if ((q & 3) == 3 || q == cnc - 1) esum += lazy_rescale<G, R>(v);
     }
 }
 
 template <int G, int R>
-__device__ __forceinline__ double pi_dot(const LaneCtx<R>& L, const double (&v)[R]) {
-    double s = 0.0;
+__device__ __forceinline__ bool bu_f81_unit_fast(const LaneCtx<R>& L, const PmlTree& t, const PmlCols& c,
+                                                 const PmlState& st, int n) {
+    const int fc = t.first_child[n];
+    const int nc = t.n_children[n];
+    if (nc > Gather<G>::CH) return false;
+    double acc[R];
+    node_mask_vec<R>(L, c, n, acc);
+    ChildLane cl;
+    TipLane tl;
+    if (!f81_gather<G, R>(L, t, fc, nc, cl, tl)) return false;
+    i64 esum = 0;
+    double vn[R];
+    if (__shfl(cl.kind, L.group_base, 64) == PML_KIND_STORED) node_load_vec<R>(L, c, L.bu, fc, vn);
+    for (int jx = 0; jx < nc; ++jx) {
+        const int src = L.group_base + jx;
+        const int ch = fc + jx;
+        const int kd = __shfl(cl.kind, src, 64);
+        const double e = __shfl(cl.e, src, 64);
+        double v[R];
+        double s_child;
+        if (kd == PML_KIND_STORED) {
 #pragma unroll
-    for (int r = 0; r < R; ++r) s += L.pi_r[r] * v[r];
-    return group_sum<G>(s);
+            for (int r = 0; r < R; ++r) v[r] = vn[r];
+        }
+        if (jx + 1 < nc && __shfl(cl.kind, src + 1, 64) == PML_KIND_STORED) node_load_vec<R>(L, c, L.bu, ch + 1, vn);
+        if (kd == PML_KIND_TIP) {
+            const u64 word = __shfl(cl.mask, src, 64);
+            mask_to_vec<R>(L.lane_valid ? word : 0ull, L.s0, c.k, v);
+            s_child = __shfl(cl.s, src, 64);
+        } else if (kd == PML_KIND_STORED) {
+            esum += __shfl(cl.be, src, 64);
+            s_child = __shfl(cl.s, src, 64);
+        } else {
+            i64 ce;
+            f81_cherry_from_lanes<G, R>(L, t, c, st, cl, tl, jx, ch, v, ce, true);
+            esum += ce;
+            s_child = pi_dot<G, R>(L, v);
+        }
+        f81_absorb_child<G, R>(L, t, st, n, ch, e, s_child, v, acc, true);
+        if ((jx & 1) == 1 || jx == nc - 1) esum += lazy_rescale<G, R>(acc);
+    }
+    const double s = pi_dot<G, R>(L, acc);
+    if (L.g == 0) {
+        L.S[n] = s;
+        L.be[n] = esum;
+    }
+    if (L.lane_valid) store_vec<R>(L.bu + vec_off<R>(L, c, n), acc);
+    return true;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -176,13 +336,16 @@ bu_f81_kernel(PmlTree t, PmlCols c, PmlState st, const int* __restrict__ level_n
     const int wave = threadIdx.x >> 6;
     const int sub = (threadIdx.x & 63) / G;
     LaneCtx<R> L;
-    lane_ctx_init<G, R>(L, t, c);
+    lane_ctx_init<G, R>(L, t, c, st);
 
     const int stride = gridDim.x * PML_WAVES_PER_BLOCK * UW;
     for (int base = (blockIdx.x * PML_WAVES_PER_BLOCK + wave) * UW; base < n_level; base += stride) {
         const int idx = base + sub;
         if (idx >= n_level) continue;  // whole groups drop out together
         const int n = level_nodes[idx];
+        if (!JOINT && Gather<G>::enabled && c.W == 1) {
+            if (bu_f81_unit_fast<G, R>(L, t, c, st, n)) continue;
+        }
 
         double acc[R];
         node_mask_vec<R>(L, c, n, acc);
@@ -191,17 +354,17 @@ bu_f81_kernel(PmlTree t, PmlCols c, PmlState st, const int* __restrict__ level_n
         const int nc = t.n_children[n];
         for (int j = 0; j < nc; ++j) {
             const int ch = fc + j;
-            const double e = st.E[L.colN + ch];
+            const double e = L.E[ch];
             const int kd = node_kind(t, ch);
             double v[R];
             double s_child = 0.0;
             if (kd == PML_KIND_TIP) {
                 node_mask_vec<R>(L, c, ch, v);
-                if (!JOINT) s_child = st.S[L.colN + ch];
+                if (!JOINT) s_child = L.S[ch];
             } else if (kd == PML_KIND_STORED) {
-                node_load_vec<R>(L, c, st.bu, ch, v);
-                esum += st.be[L.colN + ch];
-                if (!JOINT) s_child = st.S[L.colN + ch];
+                node_load_vec<R>(L, c, L.bu, ch, v);
+                esum += L.be[ch];
+                if (!JOINT) s_child = L.S[ch];
             } else {
                 i64 ce;
                 f81_cherry_vector<G, R>(L, t, c, st, ch, v, ce, true);
@@ -209,7 +372,10 @@ bu_f81_kernel(PmlTree t, PmlCols c, PmlState st, const int* __restrict__ level_n
                 s_child = pi_dot<G, R>(L, v);
             }
             if (!JOINT) {
-                esum += f81_absorb_child<G, R>(L, t, st, n, ch, e, s_child, v, acc, true);
+                f81_absorb_child<G, R>(L, t, st, n, ch, e, s_child, v, acc, true);
+                // stored vectors and cherry vectors are in band, tips are 0/1: two factors cannot leave the
+                // double range, so the band is checked every second child and at the end
+                if ((j & 1) == 1 || j == nc - 1) esum += lazy_rescale<G, R>(acc);
             } else {
                 // row i of P * diag(v): off-diagonal entries w_j = ((1-e) pi_j) v_j, diagonal ((1-e) pi_i + e) v_i
                 // (same rounding sequence as the reference's P * v broadcast, ml.py:130 with F81Model.py:46)
@@ -264,8 +430,9 @@ bu_f81_kernel(PmlTree t, PmlCols c, PmlState st, const int* __restrict__ level_n
                 }
                 // altered nodes get their tables rewritten w.r.t. their initial masks (ml.py:408-428)
                 if (c.masks_init != nullptr) {
-                    const u64* mi = c.masks_init + (L.colN + ch) * c.W;
-                    const u64* mc = c.masks + (L.colN + ch) * c.W;
+                    const size_t mo_ = ((size_t)L.col * t.N + ch) * c.W;
+                    const u64* mi = c.masks_init + mo_;
+                    const u64* mc = c.masks + mo_;
                     bool altered = false;
                     for (int w_ = 0; w_ < c.W; ++w_) altered |= (mi[w_] != mc[w_]);
                     if (altered) {
@@ -277,7 +444,7 @@ bu_f81_kernel(PmlTree t, PmlCols c, PmlState st, const int* __restrict__ level_n
                         }
                     }
                 }
-                if (L.lane_valid) store_vec_i32<R>(st.J + (L.colN + ch) * c.ks + L.s0, jj);
+                if (L.lane_valid) store_vec_i32<R>(st.J + ((size_t)L.col * t.N + ch) * c.ks + L.s0, jj);
                 if (!group_any<G>(nz)) {
                     if (L.g == 0)
                         atomicMin(&st.err[L.col], ((u64)(unsigned)t.post_rank[n] << 32) | (u64)(unsigned)ch);
@@ -287,10 +454,10 @@ bu_f81_kernel(PmlTree t, PmlCols c, PmlState st, const int* __restrict__ level_n
         }
         if (!JOINT) {
             const double s = pi_dot<G, R>(L, acc);
-            if (L.g == 0) st.S[L.colN + n] = s;
+            if (L.g == 0) L.S[n] = s;
         }
-        if (L.lane_valid) store_vec<R>(st.bu + (L.colN + n) * c.ks + L.s0, acc);
-        if (L.g == 0) st.be[L.colN + n] = esum;
+        if (L.lane_valid) store_vec<R>(L.bu + vec_off<R>(L, c, n), acc);
+        if (L.g == 0) L.be[n] = esum;
     }
 }
 
@@ -300,12 +467,13 @@ bu_f81_kernel(PmlTree t, PmlCols c, PmlState st, const int* __restrict__ level_n
 // f81_finish_child: given prod = TD_parent o BU_parent (exponent pe) and the child's own data, divides the child's
 // message out of the parent (ml.py:279-283), pushes the result through the child's branch (ml.py:287-289), forms the
 // marginal likelihoods pi o mask o BU o TD (ml.py:456-460) and stores the posteriors (ml.py:498-500).
+// NORMALISE: bring the child's TD vector back into the band (only needed when it is stored for the next level).
 // ---------------------------------------------------------------------------------------------------------------------
-template <int G, int R>
-__device__ __forceinline__ void f81_finish_child(const LaneCtx<R>& L, const PmlCols& c, const PmlState& st,
-                                                 const double (&prod)[R], i64 pe, int ch, double e, double s_child,
-                                                 i64 bec, const double (&v)[R], const double (&mb)[R],
-                                                 double (&tdc)[R], i64& xe) {
+template <int G, int R, bool NORMALISE>
+__device__ __forceinline__ void f81_finish_child(const LaneCtx<R>& L, const PmlCols& c, const double (&prod)[R],
+                                                 i64 pe, int ch, double e, double s_child, i64 bec,
+                                                 const double (&v)[R], const double (&mb)[R], double (&tdc)[R],
+                                                 i64& xe) {
     const double a = (1.0 - e) * s_child;
     double x[R];
 #pragma unroll
@@ -315,13 +483,14 @@ __device__ __forceinline__ void f81_finish_child(const LaneCtx<R>& L, const PmlC
         x[r] = prod[r] * fast_rcp(cn);
     }
     xe = pe - bec;
-    xe += lazy_rescale<G, R>(x);
     const double b = (1.0 - e) * pi_dot<G, R>(L, x);
+#pragma unroll
+    for (int r = 0; r < R; ++r) tdc[r] = b + e * x[r];  // >= 0 by construction (ml.py:289's clamp is a no-op)
+    if (NORMALISE) xe += lazy_rescale<G, R>(tdc);
     double lh[R];
     double lhs = 0.0;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        tdc[r] = b + e * x[r];  // >= 0 by construction (ml.py:289's clamp is a no-op for the closed form)
         lh[r] = v[r] * tdc[r] * (L.pi_r[r] * mb[r]);
         lhs += lh[r];
     }
@@ -330,15 +499,151 @@ __device__ __forceinline__ void f81_finish_child(const LaneCtx<R>& L, const PmlC
     const double inv = fast_rcp(lhs);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        // correctly rounded lh / lhs (one residual step), so that an observed tip gets exactly 1.0
+        // correctly rounded lh / lhs (one residual step)
         const double q = lh[r] * inv;
         lh[r] = fma(fma(-lhs, q, lh[r]), inv, q);
     }
-    if (L.lane_valid) store_vec<R>(st.post + (L.colN + ch) * c.ks + L.s0, lh);
+    if (L.lane_valid) store_vec<R>(L.post + vec_off<R>(L, c, ch), lh);
     if (L.g == 0) {
-        st.lhsum[L.colN + ch] = __builtin_ldexp(lhs, -lex);
-        st.lhe[L.colN + ch] = xe + bec + lex;
+        L.lhsum[ch] = __builtin_ldexp(lhs, -lex);
+        L.lhe[ch] = xe + bec + lex;
     }
+}
+
+// A tip below a parent with prod = TD_parent o BU_parent.  Observed tips (one allowed state s) in closed form:
+// with c0 = (1 - e) pi_s, c1 = c0 + e the divided vector is X_i = prod_i / (i == s ? c1 : c0), hence
+// pi . X = (P - pi_s prod_s) / c0 + pi_s prod_s / c1 with P = pi . prod (computed once per parent), the tip's
+// TD_s = (1 - e) pi . X + e prod_s / c1, its marginal likelihood vector is TD_s pi_s at s and 0 elsewhere, and its
+// posterior is exactly the unit vector (what lh / lh.sum() gives in the reference, ml.py:500).
+// Observed-tip closed form / general tip, given the tip's data (single mask word: k <= 64).
+template <int G, int R>
+__device__ __forceinline__ void f81_finish_tip_word(const LaneCtx<R>& L, const PmlCols& c, const double (&prod)[R],
+                                                    i64 pe, double& P, bool& have_P, int tip, u64 word, double e,
+                                                    double pis) {
+    if (__popcll(word) == 1) {
+        const int s = __builtin_ctzll(word);
+        if (!have_P) {
+            P = pi_dot<G, R>(L, prod);
+            have_P = true;
+        }
+        double mine = prod[0];
+#pragma unroll
+        for (int r = 1; r < R; ++r)
+            if ((s & (R - 1)) == r) mine = prod[r];
+        const double ps = __shfl(mine, L.group_base + s / R, 64);
+        const double q = pis * ps;
+        double c0 = (1.0 - e) * pis;
+        const double c1 = c0 + e;
+        if (!(c0 > 0.0)) c0 = 1.0;
+        const double r1 = fast_rcp(c1);
+        const double sx = (P - q) * fast_rcp(c0) + q * r1;
+        const double tds = (1.0 - e) * sx + e * (ps * r1);
+        const double lhs = tds * pis;
+        const bool ok = lhs > 0.0 && !isinf(lhs);
+        const int lex = ok ? exponent_of(lhs) : 0;
+        double out[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) out[r] = ok ? ((L.s0 + r == s) ? 1.0 : 0.0) : __builtin_nan("");
+        if (L.lane_valid) store_vec<R>(L.post + vec_off<R>(L, c, tip), out);
+        if (L.g == 0) {
+            L.lhsum[tip] = __builtin_ldexp(lhs, -lex);
+            L.lhe[tip] = pe + lex;
+        }
+    } else {
+        double mt[R], tdt[R];
+        mask_to_vec<R>(L.lane_valid ? word : 0ull, L.s0, c.k, mt);
+        i64 xt;
+        f81_finish_child<G, R, false>(L, c, prod, pe, tip, e, pis, 0, mt, mt, tdt, xt);
+    }
+}
+
+// A tip below a parent with prod = TD_parent o BU_parent.  Observed tips (one allowed state s) in closed form:
+// with c0 = (1 - e) pi_s, c1 = c0 + e the divided vector is X_i = prod_i / (i == s ? c1 : c0), hence
+// pi . X = (P - pi_s prod_s) / c0 + pi_s prod_s / c1 with P = pi . prod (computed once per parent), the tip's
+// TD_s = (1 - e) pi . X + e prod_s / c1, its marginal likelihood vector is TD_s pi_s at s and 0 elsewhere, and its
+// posterior is exactly the unit vector (what lh / lh.sum() gives in the reference, ml.py:500).
+template <int G, int R>
+__device__ __forceinline__ void f81_finish_tip(const LaneCtx<R>& L, const PmlCols& c, const double (&prod)[R], i64 pe,
+                                               double& P, bool& have_P, int tip) {
+    const double e = L.E[tip];
+    const double pis = L.S[tip];
+    if (c.W == 1) {
+        f81_finish_tip_word<G, R>(L, c, prod, pe, P, have_P, tip, L.mask[(unsigned)tip], e, pis);
+    } else {
+        // k > 64: general path (the closed form above would need the state's word; not worth a special case)
+        double mt[R], tdt[R];
+        node_mask_vec<R>(L, c, tip, mt);
+        i64 xt;
+        f81_finish_child<G, R, false>(L, c, prod, pe, tip, e, pis, 0, mt, mt, tdt, xt);
+    }
+}
+
+template <int G, int R>
+__device__ __forceinline__ bool td_f81_unit_fast(const LaneCtx<R>& L, const PmlTree& t, const PmlCols& c,
+                                                 const PmlState& st, int p) {
+    constexpr int GC = Gather<G>::GC;
+    const int fc = t.first_child[p];
+    const int nc = t.n_children[p];
+    if (nc > Gather<G>::CH) return false;
+    double bp[R], tp[R];
+    node_load_vec<R>(L, c, L.bu, p, bp);
+    node_load_vec<R>(L, c, L.td, p, tp);
+    const i64 pe = L.te[p] + L.be[p];
+    ChildLane cl;
+    TipLane tl;
+    if (!f81_gather<G, R>(L, t, fc, nc, cl, tl)) return false;
+    double vn[R];
+    if (__shfl(cl.kind, L.group_base, 64) == PML_KIND_STORED) node_load_vec<R>(L, c, L.bu, fc, vn);
+    double prod[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) prod[r] = tp[r] * bp[r];
+    double P = 0.0;
+    bool have_P = false;
+    for (int jx = 0; jx < nc; ++jx) {
+        const int src = L.group_base + jx;
+        const int ch = fc + jx;
+        const int kd = __shfl(cl.kind, src, 64);
+        const double e = __shfl(cl.e, src, 64);
+        const u64 word = __shfl(cl.mask, src, 64);
+        double v[R];
+        if (kd == PML_KIND_STORED) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) v[r] = vn[r];
+        }
+        if (jx + 1 < nc && __shfl(cl.kind, src + 1, 64) == PML_KIND_STORED) node_load_vec<R>(L, c, L.bu, ch + 1, vn);
+        if (kd == PML_KIND_TIP) {
+            f81_finish_tip_word<G, R>(L, c, prod, pe, P, have_P, ch, word, e, __shfl(cl.s, src, 64));
+            continue;
+        }
+        double mb[R], tdc[R];
+        mask_to_vec<R>(L.lane_valid ? word : 0ull, L.s0, c.k, mb);
+        i64 xe;
+        if (kd == PML_KIND_STORED) {
+            f81_finish_child<G, R, true>(L, c, prod, pe, ch, e, __shfl(cl.s, src, 64), __shfl(cl.be, src, 64), v, mb,
+                                         tdc, xe);
+            if (L.lane_valid) store_vec<R>(L.td + vec_off<R>(L, c, ch), tdc);
+            if (L.g == 0) L.te[ch] = xe;
+        } else {
+            i64 bec;
+            f81_cherry_from_lanes<G, R>(L, t, c, st, cl, tl, jx, ch, v, bec, false);
+            const double s_child = pi_dot<G, R>(L, v);
+            f81_finish_child<G, R, false>(L, c, prod, pe, ch, e, s_child, bec, v, mb, tdc, xe);
+            double prod2[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) prod2[r] = tdc[r] * v[r];
+            const i64 pe2 = xe + bec;
+            double P2 = 0.0;
+            bool have_P2 = false;
+            const int cfc = __shfl(cl.fc, src, 64);
+            const int cnc = __shfl(cl.nc, src, 64);
+            for (int q = 0; q < cnc; ++q) {
+                const int ts = L.group_base + jx * GC + q;
+                f81_finish_tip_word<G, R>(L, c, prod2, pe2, P2, have_P2, cfc + q, __shfl(tl.mask, ts, 64),
+                                          __shfl(tl.e, ts, 64), __shfl(tl.s, ts, 64));
+            }
+        }
+    }
+    return true;
 }
 
 // One unit = (stored internal node of the depth level, column): the parent's BU and TD vectors are loaded once and
@@ -352,60 +657,61 @@ td_f81_kernel(PmlTree t, PmlCols c, PmlState st, const int* __restrict__ level_p
     const int wave = threadIdx.x >> 6;
     const int sub = (threadIdx.x & 63) / G;
     LaneCtx<R> L;
-    lane_ctx_init<G, R>(L, t, c);
+    lane_ctx_init<G, R>(L, t, c, st);
 
     const int stride = gridDim.x * PML_WAVES_PER_BLOCK * UW;
     for (int base = (blockIdx.x * PML_WAVES_PER_BLOCK + wave) * UW; base < n_level; base += stride) {
         const int idx = base + sub;
         if (idx >= n_level) continue;
         const int p = level_parents[idx];
+        if (Gather<G>::enabled && c.W == 1) {
+            if (td_f81_unit_fast<G, R>(L, t, c, st, p)) continue;
+        }
 
         double prod[R];
         {
             double bp[R], tp[R];
-            node_load_vec<R>(L, c, st.bu, p, bp);
-            node_load_vec<R>(L, c, st.td, p, tp);
+            node_load_vec<R>(L, c, L.bu, p, bp);
+            node_load_vec<R>(L, c, L.td, p, tp);
 #pragma unroll
             for (int r = 0; r < R; ++r) prod[r] = tp[r] * bp[r];
         }
-        const i64 pe = st.te[L.colN + p] + st.be[L.colN + p];
+        const i64 pe = L.te[p] + L.be[p];
+        double P = 0.0;
+        bool have_P = false;
         const int fc = t.first_child[p];
         const int nc = t.n_children[p];
         for (int j = 0; j < nc; ++j) {
             const int ch = fc + j;
-            const double e = st.E[L.colN + ch];
             const int kd = node_kind(t, ch);
+            if (kd == PML_KIND_TIP) {
+                f81_finish_tip<G, R>(L, c, prod, pe, P, have_P, ch);
+                continue;
+            }
+            const double e = L.E[ch];
             double mb[R], v[R], tdc[R];
             node_mask_vec<R>(L, c, ch, mb);
             i64 xe;
-            if (kd == PML_KIND_TIP) {
-                f81_finish_child<G, R>(L, c, st, prod, pe, ch, e, st.S[L.colN + ch], 0, mb, mb, tdc, xe);
-            } else if (kd == PML_KIND_STORED) {
-                node_load_vec<R>(L, c, st.bu, ch, v);
-                f81_finish_child<G, R>(L, c, st, prod, pe, ch, e, st.S[L.colN + ch], st.be[L.colN + ch], v, mb, tdc,
-                                       xe);
-                if (L.lane_valid) store_vec<R>(st.td + (L.colN + ch) * c.ks + L.s0, tdc);
-                if (L.g == 0) st.te[L.colN + ch] = xe;
+            if (kd == PML_KIND_STORED) {
+                node_load_vec<R>(L, c, L.bu, ch, v);
+                f81_finish_child<G, R, true>(L, c, prod, pe, ch, e, L.S[ch], L.be[ch], v, mb, tdc, xe);
+                if (L.lane_valid) store_vec<R>(L.td + vec_off<R>(L, c, ch), tdc);
+                if (L.g == 0) L.te[ch] = xe;
             } else {
                 // cherry: rebuild its bottom-up vector, finish it, then finish its tips from registers
                 i64 bec;
                 f81_cherry_vector<G, R>(L, t, c, st, ch, v, bec, false);
                 const double s_child = pi_dot<G, R>(L, v);
-                f81_finish_child<G, R>(L, c, st, prod, pe, ch, e, s_child, bec, v, mb, tdc, xe);
+                f81_finish_child<G, R, false>(L, c, prod, pe, ch, e, s_child, bec, v, mb, tdc, xe);
                 double prod2[R];
 #pragma unroll
                 for (int r = 0; r < R; ++r) prod2[r] = tdc[r] * v[r];
                 const i64 pe2 = xe + bec;
+                double P2 = 0.0;
+                bool have_P2 = false;
                 const int fc2 = t.first_child[ch];
                 const int nc2 = t.n_children[ch];
-                for (int q = 0; q < nc2; ++q) {
-                    const int tip = fc2 + q;
-                    double mt[R], tdt[R];
-                    node_mask_vec<R>(L, c, tip, mt);
-                    i64 xt;
-                    f81_finish_child<G, R>(L, c, st, prod2, pe2, tip, st.E[L.colN + tip], st.S[L.colN + tip], 0, mt,
-                                           mt, tdt, xt);
-                }
+                for (int q = 0; q < nc2; ++q) f81_finish_tip<G, R>(L, c, prod2, pe2, P2, have_P2, fc2 + q);
             }
         }
     }
