@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <string>
@@ -68,6 +69,7 @@ struct pml_ctx {
 
     // columns
     int C = 0, k = 0, ks = 0, W = 0, G = 0, R = 0;
+    int Gf = 0, Rf = 0;  // lane-group shape of the F81-family kernels (chunked state ownership)
     u64 *d_masks = nullptr, *d_masks_init = nullptr;
     bool has_init = false;
     int kind = -1;
@@ -217,46 +219,86 @@ static int prof_end(pml_ctx* ctx, int which, long long launches) {
 
 enum SweepKind { SW_BU_MARG, SW_BU_JOINT, SW_TD, SW_ROOTS, SW_BU_MARG_FUSED, SW_TD_FUSED };
 
+// matrix-model sweeps and the roots kernel: contiguous state ownership (state = g * R + r)
 template <int G, int R>
 static void launch_sweep(pml_ctx* ctx, SweepKind what, const int* level, int n_level) {
+    const PmlTree t = tree_of(ctx, false);
+    const PmlCols c = cols_of(ctx);
+    const PmlState st = state_of(ctx);
+    const int upb = PML_WAVES_PER_BLOCK * (64 / G);
+    dim3 grid(grid_for(n_level, upb, ctx->C), ctx->C), block(PML_BLOCK);
+    switch (what) {
+        case SW_BU_MARG:
+            hipLaunchKernelGGL((bu_matrix_kernel<G, R, false>), grid, block, 0, ctx->stream, t, c, st, ctx->d_P, level,
+                               n_level);
+            break;
+        case SW_BU_JOINT:
+            hipLaunchKernelGGL((bu_matrix_kernel<G, R, true>), grid, block, 0, ctx->stream, t, c, st, ctx->d_P, level,
+                               n_level);
+            break;
+        case SW_TD:
+            hipLaunchKernelGGL((td_matrix_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, ctx->d_P, level,
+                               n_level);
+            break;
+        case SW_ROOTS:
+            hipLaunchKernelGGL((td_roots_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st);
+            break;
+        default:
+            break;
+    }
+}
+
+// F81-family sweeps: chunked state ownership (pml_kernels_f81.h), their own (G, R)
+template <int G, int R>
+static void launch_sweep_f81(pml_ctx* ctx, SweepKind what, const int* level, int n_level) {
     const PmlTree t = tree_of(ctx, what == SW_BU_MARG_FUSED || what == SW_TD_FUSED);
     const PmlCols c = cols_of(ctx);
     const PmlState st = state_of(ctx);
     const int upb = PML_WAVES_PER_BLOCK * (64 / G);
     dim3 grid(grid_for(n_level, upb, ctx->C), ctx->C), block(PML_BLOCK);
-    const bool f81 = ctx->kind == PML_MODEL_F81;
     switch (what) {
         case SW_BU_MARG_FUSED:
         case SW_BU_MARG:
-            if (f81)
-                hipLaunchKernelGGL((bu_f81_kernel<G, R, false>), grid, block, 0, ctx->stream, t, c, st, level, n_level);
-            else
-                hipLaunchKernelGGL((bu_matrix_kernel<G, R, false>), grid, block, 0, ctx->stream, t, c, st, ctx->d_P,
-                                   level, n_level);
+            hipLaunchKernelGGL((bu_f81_kernel<G, R, false>), grid, block, 0, ctx->stream, t, c, st, level, n_level);
             break;
         case SW_BU_JOINT:
-            if (f81)
-                hipLaunchKernelGGL((bu_f81_kernel<G, R, true>), grid, block, 0, ctx->stream, t, c, st, level, n_level);
-            else
-                hipLaunchKernelGGL((bu_matrix_kernel<G, R, true>), grid, block, 0, ctx->stream, t, c, st, ctx->d_P,
-                                   level, n_level);
+            hipLaunchKernelGGL((bu_f81_kernel<G, R, true>), grid, block, 0, ctx->stream, t, c, st, level, n_level);
             break;
         case SW_TD_FUSED:
         case SW_TD:
-            if (f81)
-                hipLaunchKernelGGL((td_f81_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, level, n_level);
-            else
-                hipLaunchKernelGGL((td_matrix_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, ctx->d_P, level,
-                                   n_level);
+            hipLaunchKernelGGL((td_f81_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, level, n_level);
             break;
-        case SW_ROOTS:
-            hipLaunchKernelGGL((td_roots_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st);
+        default:
             break;
     }
 }
 
+#define PML_F81_CASES(X) \
+    X(1, 1)              \
+    X(1, 2)              \
+    X(1, 4)              \
+    X(2, 4)              \
+    X(4, 4)              \
+    X(8, 4)              \
+    X(16, 4)             \
+    X(32, 4)             \
+    X(64, 4)             \
+    X(32, 2)             \
+    X(8, 8)
+
 static int dispatch_sweep(pml_ctx* ctx, SweepKind what, const int* level, int n_level) {
     if (n_level <= 0) return PML_OK;
+    if (ctx->kind == PML_MODEL_F81 && what != SW_ROOTS) {
+#define X(G_, R_)                                                \
+    if (ctx->Gf == G_ && ctx->Rf == R_) {                        \
+        launch_sweep_f81<G_, R_>(ctx, what, level, n_level);     \
+        HIP_TRY(hipGetLastError());                              \
+        return PML_OK;                                           \
+    }
+        PML_F81_CASES(X)
+#undef X
+        return fail(PML_ERR_UNSUPPORTED, "no F81 kernel for G=%d R=%d", ctx->Gf, ctx->Rf);
+    }
 #define X(G_, R_)                                             \
     if (ctx->G == G_ && ctx->R == R_) {                       \
         launch_sweep<G_, R_>(ctx, what, level, n_level);      \
@@ -541,6 +583,20 @@ int pml_chars_alloc(pml_ctx* ctx, int32_t n_cols, int32_t k) {
     ctx->k = k;
     pick_group(k, ctx->G, ctx->R);
     ctx->ks = (k + ctx->R - 1) / ctx->R * ctx->R;
+    {
+        // F81 family: 4 states per lane (two 16-byte pairs); PASTML_HIP_F81_R = 2 / 8 selects the tuning variants
+        int rf = k >= 3 ? 4 : k;
+        if (const char* env = getenv("PASTML_HIP_F81_R")) {
+            const int v = atoi(env);
+            if (v == 2 && k > 32 && k <= 64) rf = 2;
+            if (v == 8 && k > 32 && k <= 64) rf = 8;
+        }
+        ctx->Rf = rf;
+        const int need = (k + rf - 1) / rf;
+        ctx->Gf = 1;
+        while (ctx->Gf < need) ctx->Gf <<= 1;
+        if (rf >= 2 && (ctx->ks & 1)) ctx->ks += 1;  // 16-byte lane accesses
+    }
     ctx->W = (k + 63) / 64;
     if ((size_t)ctx->N * ctx->ks >= (1ull << 31)) {
         // the kernels address one column's slab with 32-bit element offsets

@@ -87,10 +87,12 @@ f81_prep_kernel(PmlTree t, PmlCols c, const double* __restrict__ mu, const doubl
 
 // Per-lane context of a unit's lane group: lane geometry and the column's slabs (element offsets inside one column
 // fit 32 bits: N * ks < 2^31 is checked on the host).
-template <int R>
+//
+// State ownership ("chunked"): a lane owns R states, in R/2 pairs; pair q of lane g is states q*2G + 2g, +1.  So for
+// every q the G lanes of a unit read one contiguous run of 2G doubles with 16-byte lane loads (R = 1: state g).
+template <int G, int R>
 struct LaneCtx {
-    int col, g, s0, w0, group_base;
-    bool lane_valid;
+    int col, g, group_base;
     double pi_r[R];
     const u64* mask;
     const double* E;
@@ -102,17 +104,16 @@ struct LaneCtx {
     double* post;
     double* lhsum;
     i64* lhe;
+    __device__ __forceinline__ int st(int r) const { return R == 1 ? g : ((r >> 1) * 2 * G + 2 * g + (r & 1)); }
 };
 
 template <int G, int R>
-__device__ __forceinline__ void lane_ctx_init(LaneCtx<R>& L, const PmlTree& t, const PmlCols& c, const PmlState& st) {
+__device__ __forceinline__ void lane_ctx_init(LaneCtx<G, R>& L, const PmlTree& t, const PmlCols& c,
+                                              const PmlState& st) {
     const int lane = threadIdx.x & 63;
     L.col = blockIdx.y;
     L.g = lane & (G - 1);
     L.group_base = lane & ~(G - 1);
-    L.s0 = L.g * R;
-    L.w0 = L.s0 >> 6;
-    L.lane_valid = L.s0 < c.ks;
     const size_t colN = (size_t)L.col * t.N;
     L.mask = c.masks + colN * c.W;
     L.E = st.E + colN;
@@ -125,33 +126,74 @@ __device__ __forceinline__ void lane_ctx_init(LaneCtx<R>& L, const PmlTree& t, c
     L.lhsum = st.lhsum + colN;
     L.lhe = st.lhe + colN;
 #pragma unroll
-    for (int r = 0; r < R; ++r) L.pi_r[r] = (L.s0 + r < c.k) ? c.pi[(size_t)L.col * c.ks + L.s0 + r] : 0.0;
+    for (int r = 0; r < R; ++r) L.pi_r[r] = (L.st(r) < c.k) ? c.pi[(size_t)L.col * c.ks + L.st(r)] : 0.0;
 }
 
-template <int R>
-__device__ __forceinline__ unsigned vec_off(const LaneCtx<R>& L, const PmlCols& c, int n) {
-    return (unsigned)n * (unsigned)c.ks + (unsigned)L.s0;
-}
-
-template <int R>
-__device__ __forceinline__ void node_mask_vec(const LaneCtx<R>& L, const PmlCols& c, int n, double (&v)[R]) {
-    const u64 word = L.lane_valid ? L.mask[(unsigned)n * (unsigned)c.W + (unsigned)L.w0] : 0ull;
-    mask_to_vec<R>(word, L.s0, c.k, v);
-}
-
-template <int R>
-__device__ __forceinline__ void node_load_vec(const LaneCtx<R>& L, const PmlCols& c, const double* base, int n,
-                                              double (&v)[R]) {
-    if (L.lane_valid) {
-        load_vec<R>(base + vec_off<R>(L, c, n), v);
-    } else {
+// 0/1 vector of the lane's states from a single mask word (k <= 64)
+template <int G, int R>
+__device__ __forceinline__ void word_to_vec(const LaneCtx<G, R>& L, const PmlCols& c, u64 word, double (&v)[R]) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) v[r] = 0.0;
+    for (int r = 0; r < R; ++r) {
+        const int s = L.st(r);
+        v[r] = (s < c.k && ((word >> (s & 63)) & 1ull)) ? 1.0 : 0.0;
     }
 }
 
 template <int G, int R>
-__device__ __forceinline__ double pi_dot(const LaneCtx<R>& L, const double (&v)[R]) {
+__device__ __forceinline__ void node_mask_vec(const LaneCtx<G, R>& L, const PmlCols& c, int n, double (&v)[R]) {
+    if (c.W == 1) {
+        word_to_vec<G, R>(L, c, L.mask[(unsigned)n], v);
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int s = L.st(r);
+            const u64 word = s < c.k ? L.mask[(unsigned)n * (unsigned)c.W + (unsigned)(s >> 6)] : 0ull;
+            v[r] = ((word >> (s & 63)) & 1ull) ? 1.0 : 0.0;
+        }
+    }
+}
+
+template <int G, int R>
+__device__ __forceinline__ void node_load_vec(const LaneCtx<G, R>& L, const PmlCols& c, const double* base, int n,
+                                              double (&v)[R]) {
+    const double* p = base + (unsigned)n * (unsigned)c.ks;
+    if (R == 1) {
+        v[0] = L.st(0) < c.ks ? p[L.st(0)] : 0.0;
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; r += 2) {
+            if (L.st(r) < c.ks) {
+                const double2 t2 = *reinterpret_cast<const double2*>(p + L.st(r));
+                v[r] = t2.x;
+                v[r + 1] = t2.y;
+            } else {
+                v[r] = v[r + 1] = 0.0;
+            }
+        }
+    }
+}
+
+template <int G, int R>
+__device__ __forceinline__ void node_store_vec(const LaneCtx<G, R>& L, const PmlCols& c, double* base, int n,
+                                               const double (&v)[R]) {
+    double* p = base + (unsigned)n * (unsigned)c.ks;
+    if (R == 1) {
+        if (L.st(0) < c.ks) p[L.st(0)] = v[0];
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; r += 2) {
+            if (L.st(r) < c.ks) {
+                double2 t2;
+                t2.x = v[r];
+                t2.y = v[r + 1];
+                *reinterpret_cast<double2*>(p + L.st(r)) = t2;
+            }
+        }
+    }
+}
+
+template <int G, int R>
+__device__ __forceinline__ double pi_dot(const LaneCtx<G, R>& L, const double (&v)[R]) {
     double s = 0.0;
 #pragma unroll
     for (int r = 0; r < R; ++r) s += L.pi_r[r] * v[r];
@@ -161,7 +203,7 @@ __device__ __forceinline__ double pi_dot(const LaneCtx<R>& L, const double (&v)[
 // Multiplies acc by the message of child ch (vector v, S = pi . v, branch factor e) and performs the zero check of
 // ml.py:139-145.  Every term of the closed form is >= 0, so the clamp of ml.py:137 is a no-op.
 template <int G, int R>
-__device__ __forceinline__ void f81_absorb_child(const LaneCtx<R>& L, const PmlTree& t, const PmlState& st, int n,
+__device__ __forceinline__ void f81_absorb_child(const LaneCtx<G, R>& L, const PmlTree& t, const PmlState& st, int n,
                                                  int ch, double e, double s_child, const double (&v)[R],
                                                  double (&acc)[R], bool report) {
     const double a = (1.0 - e) * s_child;
@@ -179,17 +221,17 @@ __device__ __forceinline__ void f81_absorb_child(const LaneCtx<R>& L, const PmlT
 // Bottom-up vector of a cherry (all children are tips) in registers: mask * prod of tip messages (ml.py:124-148).
 // Messages of tips are >= (1 - e) pi_min, so the band is checked every fourth child only.
 template <int G, int R>
-__device__ __forceinline__ void f81_cherry_vector(const LaneCtx<R>& L, const PmlTree& t, const PmlCols& c,
+__device__ __forceinline__ void f81_cherry_vector(const LaneCtx<G, R>& L, const PmlTree& t, const PmlCols& c,
                                                   const PmlState& st, int n, double (&acc)[R], i64& esum,
                                                   bool report) {
-    node_mask_vec<R>(L, c, n, acc);
+    node_mask_vec<G, R>(L, c, n, acc);
     esum = 0;
     const int fc = t.first_child[n];
     const int nc = t.n_children[n];
     for (int j = 0; j < nc; ++j) {
         const int ch = fc + j;
         double v[R];
-        node_mask_vec<R>(L, c, ch, v);
+        node_mask_vec<G, R>(L, c, ch, v);
         f81_absorb_child<G, R>(L, t, st, n, ch, L.E[ch], L.S[ch], v, acc, report);
         if ((j & 3) == 3 || j == nc - 1) esum += lazy_rescale<G, R>(acc);
     }
@@ -223,7 +265,7 @@ struct TipLane {  // what lane j * GC + q holds about tip q of cherry child j
 };
 
 template <int G, int R>
-__device__ __forceinline__ bool f81_gather(const LaneCtx<R>& L, const PmlTree& t, int fc, int nc, ChildLane& cl,
+__device__ __forceinline__ bool f81_gather(const LaneCtx<G, R>& L, const PmlTree& t, int fc, int nc, ChildLane& cl,
                                            TipLane& tl) {
     constexpr int GC = Gather<G>::GC;
     const int j = L.g;
@@ -253,13 +295,13 @@ __device__ __forceinline__ bool f81_gather(const LaneCtx<R>& L, const PmlTree& t
 
 // cherry child jx of the unit rebuilt from the gathered tip data; same operation order as f81_cherry_vector
 template <int G, int R>
-__device__ __forceinline__ void f81_cherry_from_lanes(const LaneCtx<R>& L, const PmlTree& t, const PmlCols& c,
+__device__ __forceinline__ void f81_cherry_from_lanes(const LaneCtx<G, R>& L, const PmlTree& t, const PmlCols& c,
                                                       const PmlState& st, const ChildLane& cl, const TipLane& tl,
                                                       int jx, int cherry, double (&v)[R], i64& esum, bool report) {
     constexpr int GC = Gather<G>::GC;
     const int src = L.group_base + jx;
     const u64 word = __shfl(cl.mask, src, 64);
-    mask_to_vec<R>(L.lane_valid ? word : 0ull, L.s0, c.k, v);
+    word_to_vec<G, R>(L, c, word, v);
     const int cfc = __shfl(cl.fc, src, 64);
     const int cnc = __shfl(cl.nc, src, 64);
     esum = 0;
@@ -267,26 +309,26 @@ __device__ __forceinline__ void f81_cherry_from_lanes(const LaneCtx<R>& L, const
         const int ts = L.group_base + jx * GC + q;
         const u64 tw = __shfl(tl.mask, ts, 64);
         double tv[R];
-        mask_to_vec<R>(L.lane_valid ? tw : 0ull, L.s0, c.k, tv);
+        word_to_vec<G, R>(L, c, tw, tv);
         f81_absorb_child<G, R>(L, t, st, cherry, cfc + q, __shfl(tl.e, ts, 64), __shfl(tl.s, ts, 64), tv, v, report);
         if ((q & 3) == 3 || q == cnc - 1) esum += lazy_rescale<G, R>(v);
     }
 }
 
 template <int G, int R>
-__device__ __forceinline__ bool bu_f81_unit_fast(const LaneCtx<R>& L, const PmlTree& t, const PmlCols& c,
+__device__ __forceinline__ bool bu_f81_unit_fast(const LaneCtx<G, R>& L, const PmlTree& t, const PmlCols& c,
                                                  const PmlState& st, int n) {
     const int fc = t.first_child[n];
     const int nc = t.n_children[n];
     if (nc > Gather<G>::CH) return false;
     double acc[R];
-    node_mask_vec<R>(L, c, n, acc);
+    node_mask_vec<G, R>(L, c, n, acc);
     ChildLane cl;
     TipLane tl;
     if (!f81_gather<G, R>(L, t, fc, nc, cl, tl)) return false;
     i64 esum = 0;
     double vn[R];
-    if (__shfl(cl.kind, L.group_base, 64) == PML_KIND_STORED) node_load_vec<R>(L, c, L.bu, fc, vn);
+    if (__shfl(cl.kind, L.group_base, 64) == PML_KIND_STORED) node_load_vec<G, R>(L, c, L.bu, fc, vn);
     for (int jx = 0; jx < nc; ++jx) {
         const int src = L.group_base + jx;
         const int ch = fc + jx;
@@ -298,10 +340,10 @@ __device__ __forceinline__ bool bu_f81_unit_fast(const LaneCtx<R>& L, const PmlT
 #pragma unroll
             for (int r = 0; r < R; ++r) v[r] = vn[r];
         }
-        if (jx + 1 < nc && __shfl(cl.kind, src + 1, 64) == PML_KIND_STORED) node_load_vec<R>(L, c, L.bu, ch + 1, vn);
+        if (jx + 1 < nc && __shfl(cl.kind, src + 1, 64) == PML_KIND_STORED) node_load_vec<G, R>(L, c, L.bu, ch + 1, vn);
         if (kd == PML_KIND_TIP) {
             const u64 word = __shfl(cl.mask, src, 64);
-            mask_to_vec<R>(L.lane_valid ? word : 0ull, L.s0, c.k, v);
+            word_to_vec<G, R>(L, c, word, v);
             s_child = __shfl(cl.s, src, 64);
         } else if (kd == PML_KIND_STORED) {
             esum += __shfl(cl.be, src, 64);
@@ -320,7 +362,7 @@ __device__ __forceinline__ bool bu_f81_unit_fast(const LaneCtx<R>& L, const PmlT
         L.S[n] = s;
         L.be[n] = esum;
     }
-    if (L.lane_valid) store_vec<R>(L.bu + vec_off<R>(L, c, n), acc);
+    node_store_vec<G, R>(L, c, L.bu, n, acc);
     return true;
 }
 
@@ -335,7 +377,7 @@ bu_f81_kernel(PmlTree t, PmlCols c, PmlState st, const int* __restrict__ level_n
     constexpr int UW = 64 / G;  // units per wave
     const int wave = threadIdx.x >> 6;
     const int sub = (threadIdx.x & 63) / G;
-    LaneCtx<R> L;
+    LaneCtx<G, R> L;
     lane_ctx_init<G, R>(L, t, c, st);
 
     const int stride = gridDim.x * PML_WAVES_PER_BLOCK * UW;
@@ -348,7 +390,7 @@ bu_f81_kernel(PmlTree t, PmlCols c, PmlState st, const int* __restrict__ level_n
         }
 
         double acc[R];
-        node_mask_vec<R>(L, c, n, acc);
+        node_mask_vec<G, R>(L, c, n, acc);
         i64 esum = 0;
         const int fc = t.first_child[n];
         const int nc = t.n_children[n];
@@ -359,10 +401,10 @@ bu_f81_kernel(PmlTree t, PmlCols c, PmlState st, const int* __restrict__ level_n
             double v[R];
             double s_child = 0.0;
             if (kd == PML_KIND_TIP) {
-                node_mask_vec<R>(L, c, ch, v);
+                node_mask_vec<G, R>(L, c, ch, v);
                 if (!JOINT) s_child = L.S[ch];
             } else if (kd == PML_KIND_STORED) {
-                node_load_vec<R>(L, c, L.bu, ch, v);
+                node_load_vec<G, R>(L, c, L.bu, ch, v);
                 esum += L.be[ch];
                 if (!JOINT) s_child = L.S[ch];
             } else {
@@ -386,12 +428,12 @@ bu_f81_kernel(PmlTree t, PmlCols c, PmlState st, const int* __restrict__ level_n
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const double a = ome * L.pi_r[r];
-                    const bool ok = L.s0 + r < c.k;
+                    const bool ok = L.st(r) < c.k;
                     w[r] = ok ? a * v[r] : -INFINITY;
                     dg[r] = (a + e) * v[r];
                     if (ok && w[r] > m1) {
                         m1 = w[r];
-                        j1 = L.s0 + r;
+                        j1 = L.st(r);
                     }
                 }
                 group_argmax_first<G>(m1, j1);
@@ -399,9 +441,9 @@ bu_f81_kernel(PmlTree t, PmlCols c, PmlState st, const int* __restrict__ level_n
                 int j2 = 0x7fffffff;
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    if (L.s0 + r < c.k && L.s0 + r != j1 && w[r] > m2) {
+                    if (L.st(r) < c.k && L.st(r) != j1 && w[r] > m2) {
                         m2 = w[r];
-                        j2 = L.s0 + r;
+                        j2 = L.st(r);
                     }
                 }
                 group_argmax_first<G>(m2, j2);
@@ -409,7 +451,7 @@ bu_f81_kernel(PmlTree t, PmlCols c, PmlState st, const int* __restrict__ level_n
                 bool nz = false;
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    const int i = L.s0 + r;
+                    const int i = L.st(r);
                     const double mo = (i == j1) ? m2 : m1;
                     const int jo = (i == j1) ? j2 : j1;
                     double msg;
@@ -444,7 +486,22 @@ bu_f81_kernel(PmlTree t, PmlCols c, PmlState st, const int* __restrict__ level_n
                         }
                     }
                 }
-                if (L.lane_valid) store_vec_i32<R>(st.J + ((size_t)L.col * t.N + ch) * c.ks + L.s0, jj);
+                {
+                    int* jp = st.J + ((size_t)L.col * t.N + ch) * c.ks;
+                    if (R == 1) {
+                        if (L.st(0) < c.ks) jp[L.st(0)] = jj[0];
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < R; r += 2) {
+                            if (L.st(r) < c.ks) {
+                                int2 t2;
+                                t2.x = jj[r];
+                                t2.y = jj[r + 1];
+                                *reinterpret_cast<int2*>(jp + L.st(r)) = t2;
+                            }
+                        }
+                    }
+                }
                 if (!group_any<G>(nz)) {
                     if (L.g == 0)
                         atomicMin(&st.err[L.col], ((u64)(unsigned)t.post_rank[n] << 32) | (u64)(unsigned)ch);
@@ -456,7 +513,7 @@ bu_f81_kernel(PmlTree t, PmlCols c, PmlState st, const int* __restrict__ level_n
             const double s = pi_dot<G, R>(L, acc);
             if (L.g == 0) L.S[n] = s;
         }
-        if (L.lane_valid) store_vec<R>(L.bu + vec_off<R>(L, c, n), acc);
+        node_store_vec<G, R>(L, c, L.bu, n, acc);
         if (L.g == 0) L.be[n] = esum;
     }
 }
@@ -470,7 +527,7 @@ bu_f81_kernel(PmlTree t, PmlCols c, PmlState st, const int* __restrict__ level_n
 // NORMALISE: bring the child's TD vector back into the band (only needed when it is stored for the next level).
 // ---------------------------------------------------------------------------------------------------------------------
 template <int G, int R, bool NORMALISE>
-__device__ __forceinline__ void f81_finish_child(const LaneCtx<R>& L, const PmlCols& c, const double (&prod)[R],
+__device__ __forceinline__ void f81_finish_child(const LaneCtx<G, R>& L, const PmlCols& c, const double (&prod)[R],
                                                  i64 pe, int ch, double e, double s_child, i64 bec,
                                                  const double (&v)[R], const double (&mb)[R], double (&tdc)[R],
                                                  i64& xe) {
@@ -503,7 +560,7 @@ __device__ __forceinline__ void f81_finish_child(const LaneCtx<R>& L, const PmlC
         const double q = lh[r] * inv;
         lh[r] = fma(fma(-lhs, q, lh[r]), inv, q);
     }
-    if (L.lane_valid) store_vec<R>(L.post + vec_off<R>(L, c, ch), lh);
+    node_store_vec<G, R>(L, c, L.post, ch, lh);
     if (L.g == 0) {
         L.lhsum[ch] = __builtin_ldexp(lhs, -lex);
         L.lhe[ch] = xe + bec + lex;
@@ -517,7 +574,7 @@ __device__ __forceinline__ void f81_finish_child(const LaneCtx<R>& L, const PmlC
 // posterior is exactly the unit vector (what lh / lh.sum() gives in the reference, ml.py:500).
 // Observed-tip closed form / general tip, given the tip's data (single mask word: k <= 64).
 template <int G, int R>
-__device__ __forceinline__ void f81_finish_tip_word(const LaneCtx<R>& L, const PmlCols& c, const double (&prod)[R],
+__device__ __forceinline__ void f81_finish_tip_word(const LaneCtx<G, R>& L, const PmlCols& c, const double (&prod)[R],
                                                     i64 pe, double& P, bool& have_P, int tip, u64 word, double e,
                                                     double pis) {
     if (__popcll(word) == 1) {
@@ -526,11 +583,14 @@ __device__ __forceinline__ void f81_finish_tip_word(const LaneCtx<R>& L, const P
             P = pi_dot<G, R>(L, prod);
             have_P = true;
         }
+        // owner of state s: pair q = s / 2G, lane (s % 2G) / 2, slot 2q + (s & 1)   (R = 1: lane s)
+        const int owner_r = R == 1 ? 0 : 2 * (s / (2 * G)) + (s & 1);
+        const int owner_g = R == 1 ? s : (s % (2 * G)) >> 1;
         double mine = prod[0];
 #pragma unroll
         for (int r = 1; r < R; ++r)
-            if ((s & (R - 1)) == r) mine = prod[r];
-        const double ps = __shfl(mine, L.group_base + s / R, 64);
+            if (owner_r == r) mine = prod[r];
+        const double ps = __shfl(mine, L.group_base + owner_g, 64);
         const double q = pis * ps;
         double c0 = (1.0 - e) * pis;
         const double c1 = c0 + e;
@@ -543,15 +603,15 @@ __device__ __forceinline__ void f81_finish_tip_word(const LaneCtx<R>& L, const P
         const int lex = ok ? exponent_of(lhs) : 0;
         double out[R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) out[r] = ok ? ((L.s0 + r == s) ? 1.0 : 0.0) : __builtin_nan("");
-        if (L.lane_valid) store_vec<R>(L.post + vec_off<R>(L, c, tip), out);
+        for (int r = 0; r < R; ++r) out[r] = ok ? ((L.st(r) == s) ? 1.0 : 0.0) : __builtin_nan("");
+        node_store_vec<G, R>(L, c, L.post, tip, out);
         if (L.g == 0) {
             L.lhsum[tip] = __builtin_ldexp(lhs, -lex);
             L.lhe[tip] = pe + lex;
         }
     } else {
         double mt[R], tdt[R];
-        mask_to_vec<R>(L.lane_valid ? word : 0ull, L.s0, c.k, mt);
+        word_to_vec<G, R>(L, c, word, mt);
         i64 xt;
         f81_finish_child<G, R, false>(L, c, prod, pe, tip, e, pis, 0, mt, mt, tdt, xt);
     }
@@ -563,7 +623,7 @@ __device__ __forceinline__ void f81_finish_tip_word(const LaneCtx<R>& L, const P
 // TD_s = (1 - e) pi . X + e prod_s / c1, its marginal likelihood vector is TD_s pi_s at s and 0 elsewhere, and its
 // posterior is exactly the unit vector (what lh / lh.sum() gives in the reference, ml.py:500).
 template <int G, int R>
-__device__ __forceinline__ void f81_finish_tip(const LaneCtx<R>& L, const PmlCols& c, const double (&prod)[R], i64 pe,
+__device__ __forceinline__ void f81_finish_tip(const LaneCtx<G, R>& L, const PmlCols& c, const double (&prod)[R], i64 pe,
                                                double& P, bool& have_P, int tip) {
     const double e = L.E[tip];
     const double pis = L.S[tip];
@@ -572,28 +632,28 @@ __device__ __forceinline__ void f81_finish_tip(const LaneCtx<R>& L, const PmlCol
     } else {
         // k > 64: general path (the closed form above would need the state's word; not worth a special case)
         double mt[R], tdt[R];
-        node_mask_vec<R>(L, c, tip, mt);
+        node_mask_vec<G, R>(L, c, tip, mt);
         i64 xt;
         f81_finish_child<G, R, false>(L, c, prod, pe, tip, e, pis, 0, mt, mt, tdt, xt);
     }
 }
 
 template <int G, int R>
-__device__ __forceinline__ bool td_f81_unit_fast(const LaneCtx<R>& L, const PmlTree& t, const PmlCols& c,
+__device__ __forceinline__ bool td_f81_unit_fast(const LaneCtx<G, R>& L, const PmlTree& t, const PmlCols& c,
                                                  const PmlState& st, int p) {
     constexpr int GC = Gather<G>::GC;
     const int fc = t.first_child[p];
     const int nc = t.n_children[p];
     if (nc > Gather<G>::CH) return false;
     double bp[R], tp[R];
-    node_load_vec<R>(L, c, L.bu, p, bp);
-    node_load_vec<R>(L, c, L.td, p, tp);
+    node_load_vec<G, R>(L, c, L.bu, p, bp);
+    node_load_vec<G, R>(L, c, L.td, p, tp);
     const i64 pe = L.te[p] + L.be[p];
     ChildLane cl;
     TipLane tl;
     if (!f81_gather<G, R>(L, t, fc, nc, cl, tl)) return false;
     double vn[R];
-    if (__shfl(cl.kind, L.group_base, 64) == PML_KIND_STORED) node_load_vec<R>(L, c, L.bu, fc, vn);
+    if (__shfl(cl.kind, L.group_base, 64) == PML_KIND_STORED) node_load_vec<G, R>(L, c, L.bu, fc, vn);
     double prod[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) prod[r] = tp[r] * bp[r];
@@ -610,18 +670,18 @@ __device__ __forceinline__ bool td_f81_unit_fast(const LaneCtx<R>& L, const PmlT
 #pragma unroll
             for (int r = 0; r < R; ++r) v[r] = vn[r];
         }
-        if (jx + 1 < nc && __shfl(cl.kind, src + 1, 64) == PML_KIND_STORED) node_load_vec<R>(L, c, L.bu, ch + 1, vn);
+        if (jx + 1 < nc && __shfl(cl.kind, src + 1, 64) == PML_KIND_STORED) node_load_vec<G, R>(L, c, L.bu, ch + 1, vn);
         if (kd == PML_KIND_TIP) {
             f81_finish_tip_word<G, R>(L, c, prod, pe, P, have_P, ch, word, e, __shfl(cl.s, src, 64));
             continue;
         }
         double mb[R], tdc[R];
-        mask_to_vec<R>(L.lane_valid ? word : 0ull, L.s0, c.k, mb);
+        word_to_vec<G, R>(L, c, word, mb);
         i64 xe;
         if (kd == PML_KIND_STORED) {
             f81_finish_child<G, R, true>(L, c, prod, pe, ch, e, __shfl(cl.s, src, 64), __shfl(cl.be, src, 64), v, mb,
                                          tdc, xe);
-            if (L.lane_valid) store_vec<R>(L.td + vec_off<R>(L, c, ch), tdc);
+            node_store_vec<G, R>(L, c, L.td, ch, tdc);
             if (L.g == 0) L.te[ch] = xe;
         } else {
             i64 bec;
@@ -656,7 +716,7 @@ td_f81_kernel(PmlTree t, PmlCols c, PmlState st, const int* __restrict__ level_p
     constexpr int UW = 64 / G;
     const int wave = threadIdx.x >> 6;
     const int sub = (threadIdx.x & 63) / G;
-    LaneCtx<R> L;
+    LaneCtx<G, R> L;
     lane_ctx_init<G, R>(L, t, c, st);
 
     const int stride = gridDim.x * PML_WAVES_PER_BLOCK * UW;
@@ -671,8 +731,8 @@ td_f81_kernel(PmlTree t, PmlCols c, PmlState st, const int* __restrict__ level_p
         double prod[R];
         {
             double bp[R], tp[R];
-            node_load_vec<R>(L, c, L.bu, p, bp);
-            node_load_vec<R>(L, c, L.td, p, tp);
+            node_load_vec<G, R>(L, c, L.bu, p, bp);
+            node_load_vec<G, R>(L, c, L.td, p, tp);
 #pragma unroll
             for (int r = 0; r < R; ++r) prod[r] = tp[r] * bp[r];
         }
@@ -690,12 +750,12 @@ td_f81_kernel(PmlTree t, PmlCols c, PmlState st, const int* __restrict__ level_p
             }
             const double e = L.E[ch];
             double mb[R], v[R], tdc[R];
-            node_mask_vec<R>(L, c, ch, mb);
+            node_mask_vec<G, R>(L, c, ch, mb);
             i64 xe;
             if (kd == PML_KIND_STORED) {
-                node_load_vec<R>(L, c, L.bu, ch, v);
+                node_load_vec<G, R>(L, c, L.bu, ch, v);
                 f81_finish_child<G, R, true>(L, c, prod, pe, ch, e, L.S[ch], L.be[ch], v, mb, tdc, xe);
-                if (L.lane_valid) store_vec<R>(L.td + vec_off<R>(L, c, ch), tdc);
+                node_store_vec<G, R>(L, c, L.td, ch, tdc);
                 if (L.g == 0) L.te[ch] = xe;
             } else {
                 // cherry: rebuild its bottom-up vector, finish it, then finish its tips from registers
