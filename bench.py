@@ -192,6 +192,11 @@ def main():
                 'achieved': td_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': (td_gbs / HBM_PEAK_GBS) if td_gbs else None,
                 'traffic': traffic,
+                # real HBM rate of the kernel = PMC bytes per launch / measured launch time (the cherry-fused schedule
+                # moves fewer bytes than the algorithmic 32 B/unit model, hence achieved can exceed the real rate)
+                'traffic_gbs': (traffic / (td_ms / max(1, td_launches) * 1e-3) / 1e9) if traffic and td_ms > 0 else None,
+                'traffic_frac': (traffic / (td_ms / max(1, td_launches) * 1e-3) / 1e9 / HBM_PEAK_GBS)
+                if traffic and td_ms > 0 else None,
                 'algorithmic_bytes_per_launch': td_bytes_per_step / max(1, td_launches / args.steps),
                 'avg_launch_ms': td_ms / max(1, td_launches),
                 'launches': td_launches,

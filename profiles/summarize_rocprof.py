@@ -22,7 +22,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def pmc(directory, counter):
-    path = glob.glob(os.path.join(directory, '**', '*_counter_collection.csv'), recursive=True)[0]
+    path = max(glob.glob(os.path.join(directory, '**', '*_counter_collection.csv'), recursive=True), key=os.path.getmtime)
     acc = collections.OrderedDict()
     for r in csv.DictReader(open(path)):
         if r['Counter_Name'] != counter:
@@ -36,7 +36,7 @@ def pmc(directory, counter):
 def main():
     tag, kt, pf, pw = sys.argv[1:5]
     workload = sys.argv[5] if len(sys.argv) > 5 else 'cfg4'
-    stats = glob.glob(os.path.join(kt, '**', '*_kernel_stats.csv'), recursive=True)[0]
+    stats = max(glob.glob(os.path.join(kt, '**', '*_kernel_stats.csv'), recursive=True), key=os.path.getmtime)
     shutil.copy(stats, os.path.join(HERE, tag + '_kernel_stats.csv'))
     fetch, write = pmc(pf, 'FETCH_SIZE'), pmc(pw, 'WRITE_SIZE')
     lines = ['# HBM traffic per kernel ({}; workload {}; one bench step, --pmc FETCH_SIZE and --pmc WRITE_SIZE in '
