@@ -63,6 +63,8 @@ struct pml_ctx {
     unsigned char* d_kind = nullptr;
     std::vector<unsigned char> h_kind;
     int *d_bu_order_f = nullptr, *d_td_parents_f = nullptr, *d_cherries = nullptr;
+    int *d_bu_offsets_f = nullptr, *d_td_parent_offsets_f = nullptr;  // level tables for the single-launch kernels
+    bool small = false;  // forest small enough for the one-launch-per-sweep kernels
     std::vector<int> bu_offsets_f, td_parent_offsets_f;
     int n_cherries = 0;
     bool bu_fused = false;  // the last bottom-up sweep left the cherries unmaterialised
@@ -273,6 +275,21 @@ static void launch_sweep_f81(pml_ctx* ctx, SweepKind what, const int* level, int
     }
 }
 
+template <int G, int R>
+static void launch_small_f81(pml_ctx* ctx, bool bottom_up, int do_prep) {
+    const PmlTree t = tree_of(ctx, true);
+    const PmlCols c = cols_of(ctx);
+    const PmlState st = state_of(ctx);
+    dim3 grid(1, ctx->C), block(PML_SMALL_BLOCK);
+    if (bottom_up)
+        hipLaunchKernelGGL((bu_f81_small_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, ctx->d_mu, ctx->d_sf,
+                           ctx->d_tau, ctx->d_tauf, do_prep, ctx->d_bu_order_f, ctx->d_bu_offsets_f,
+                           (int)ctx->bu_offsets_f.size() - 1, ctx->d_loglik);
+    else
+        hipLaunchKernelGGL((td_f81_small_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, ctx->d_td_parents_f,
+                           ctx->d_td_parent_offsets_f, ctx->n_td_levels);
+}
+
 #define PML_F81_CASES(X) \
     X(1, 1)              \
     X(1, 2)              \
@@ -285,6 +302,18 @@ static void launch_sweep_f81(pml_ctx* ctx, SweepKind what, const int* level, int
     X(64, 4)             \
     X(32, 2)             \
     X(8, 8)
+
+static int dispatch_small_f81(pml_ctx* ctx, bool bottom_up, int do_prep) {
+#define X(G_, R_)                                            \
+    if (ctx->Gf == G_ && ctx->Rf == R_) {                    \
+        launch_small_f81<G_, R_>(ctx, bottom_up, do_prep);   \
+        HIP_TRY(hipGetLastError());                          \
+        return PML_OK;                                       \
+    }
+    PML_F81_CASES(X)
+#undef X
+    return fail(PML_ERR_UNSUPPORTED, "no F81 kernel for G=%d R=%d", ctx->Gf, ctx->Rf);
+}
 
 static int dispatch_sweep(pml_ctx* ctx, SweepKind what, const int* level, int n_level) {
     if (n_level <= 0) return PML_OK;
@@ -565,6 +594,15 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
             PML_TRY(upload(ctx, ctx->d_td_parents_f, tdp.data(), n_stored));
         }
         if (!cherries.empty()) PML_TRY(upload(ctx, ctx->d_cherries, cherries.data(), cherries.size()));
+        PML_TRY(dev_alloc(ctx, &ctx->d_bu_offsets_f, ctx->bu_offsets_f.size()));
+        PML_TRY(dev_alloc(ctx, &ctx->d_td_parent_offsets_f, ctx->td_parent_offsets_f.size()));
+        PML_TRY(upload(ctx, ctx->d_bu_offsets_f, ctx->bu_offsets_f.data(), ctx->bu_offsets_f.size()));
+        PML_TRY(upload(ctx, ctx->d_td_parent_offsets_f, ctx->td_parent_offsets_f.data(), ctx->td_parent_offsets_f.size()));
+        {
+            const char* env = getenv("PASTML_HIP_SMALL_MAX_NODES");
+            const int limit = env ? atoi(env) : 2048;
+            ctx->small = n_nodes <= limit;
+        }
         HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -921,7 +959,8 @@ int pml_pij_batch(pml_ctx* ctx, double* P_out) {
 int pml_bottom_up(pml_ctx* ctx, int is_marginal, double* loglik_out, int32_t* err_parent, int32_t* err_child) {
     PML_TRY(require_model(ctx));
     if (!loglik_out) return fail(PML_ERR_INVALID, "loglik_out is NULL");
-    PML_TRY(run_prep(ctx));
+    const bool small_path = ctx->small && is_marginal && ctx->kind == PML_MODEL_F81;
+    if (!small_path) PML_TRY(run_prep(ctx));
     const size_t CN = (size_t)ctx->C * ctx->N;
     if (!is_marginal && !ctx->d_J) {
         PML_TRY(dev_alloc(ctx, &ctx->d_J, CN * ctx->ks));
@@ -932,7 +971,12 @@ int pml_bottom_up(pml_ctx* ctx, int is_marginal, double* loglik_out, int32_t* er
     HIP_TRY(hipMemsetAsync(ctx->d_err, 0xFF, sizeof(u64) * ctx->C, ctx->stream));
     PML_TRY(prof_begin(ctx));
     const bool fused = is_marginal && ctx->kind == PML_MODEL_F81;
-    if (fused) {
+    if (small_path) {
+        // prep + every level + ln L in one launch
+        PML_TRY(dispatch_small_f81(ctx, true, ctx->prep_dirty ? 1 : 0));
+        ctx->prep_dirty = false;
+        PML_TRY(prof_end(ctx, 0, 1));
+    } else if (fused) {
         const int nl = (int)ctx->bu_offsets_f.size() - 1;
         for (int l = 0; l < nl; ++l) {
             const int a = ctx->bu_offsets_f[l], b = ctx->bu_offsets_f[l + 1];
@@ -947,9 +991,11 @@ int pml_bottom_up(pml_ctx* ctx, int is_marginal, double* loglik_out, int32_t* er
         PML_TRY(prof_end(ctx, 0, ctx->n_bu_levels));
     }
     ctx->bu_fused = fused && ctx->n_cherries > 0;
-    hipLaunchKernelGGL(loglik_kernel, dim3((ctx->C + PML_BLOCK - 1) / PML_BLOCK), dim3(PML_BLOCK), 0, ctx->stream,
-                       tree_of(ctx), cols_of(ctx), state_of(ctx), ctx->C, is_marginal ? 1 : 0, ctx->d_loglik);
-    HIP_TRY(hipGetLastError());
+    if (!small_path) {
+        hipLaunchKernelGGL(loglik_kernel, dim3((ctx->C + PML_BLOCK - 1) / PML_BLOCK), dim3(PML_BLOCK), 0, ctx->stream,
+                           tree_of(ctx), cols_of(ctx), state_of(ctx), ctx->C, is_marginal ? 1 : 0, ctx->d_loglik);
+        HIP_TRY(hipGetLastError());
+    }
     std::vector<u64> err(ctx->C);
     HIP_TRY(hipMemcpyAsync(loglik_out, ctx->d_loglik, sizeof(double) * ctx->C, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(err.data(), ctx->d_err, sizeof(u64) * ctx->C, hipMemcpyDeviceToHost, ctx->stream));
@@ -981,11 +1027,16 @@ int pml_top_down_marginals(pml_ctx* ctx, double* posterior_out, double* lh_sum_o
         PML_TRY(dev_alloc(ctx, &ctx->d_lhsum, CN));
         PML_TRY(dev_alloc(ctx, &ctx->d_lhe, CN));
     }
-    PML_TRY(dispatch_sweep(ctx, SW_ROOTS, nullptr, ctx->n_roots));
+    const bool td_small = ctx->small && ctx->kind == PML_MODEL_F81;
+    if (!td_small) PML_TRY(dispatch_sweep(ctx, SW_ROOTS, nullptr, ctx->n_roots));
     PML_TRY(prof_begin(ctx));
     long long n_launch = 0;
     const bool td_fused = ctx->kind == PML_MODEL_F81;
-    for (int l = 0; l < ctx->n_td_levels; ++l) {
+    if (td_small) {
+        PML_TRY(dispatch_small_f81(ctx, false, 0));
+        n_launch = 1;
+    }
+    for (int l = 0; l < (td_small ? 0 : ctx->n_td_levels); ++l) {
         const std::vector<int>& off = td_fused ? ctx->td_parent_offsets_f : ctx->td_parent_offsets;
         const int a = off[l], b = off[l + 1];
         PML_TRY(dispatch_sweep(ctx, td_fused ? SW_TD_FUSED : SW_TD,

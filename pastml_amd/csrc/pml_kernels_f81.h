@@ -371,6 +371,142 @@ __device__ __forceinline__ bool bu_f81_unit_fast(const LaneCtx<G, R>& L, const P
 // replaces calc_node_bu_likelihood (pastml/ml.py:124-148) for the F81 family.
 // JOINT: Pupko's max / arg-max variant (never fused: t.kind is null there).
 // ---------------------------------------------------------------------------------------------------------------------
+// One bottom-up unit: node n of the current level, this lane group's column.
+template <int G, int R, bool JOINT>
+__device__ __forceinline__ void bu_f81_unit(const LaneCtx<G, R>& L, const PmlTree& t, const PmlCols& c,
+                                            const PmlState& st, int n) {
+    if (!JOINT && Gather<G>::enabled && c.W == 1) {
+        if (bu_f81_unit_fast<G, R>(L, t, c, st, n)) return;
+    }
+
+    double acc[R];
+    node_mask_vec<G, R>(L, c, n, acc);
+    i64 esum = 0;
+    const int fc = t.first_child[n];
+    const int nc = t.n_children[n];
+    for (int j = 0; j < nc; ++j) {
+        const int ch = fc + j;
+        const double e = L.E[ch];
+        const int kd = node_kind(t, ch);
+        double v[R];
+        double s_child = 0.0;
+        if (kd == PML_KIND_TIP) {
+            node_mask_vec<G, R>(L, c, ch, v);
+            if (!JOINT) s_child = L.S[ch];
+        } else if (kd == PML_KIND_STORED) {
+            node_load_vec<G, R>(L, c, L.bu, ch, v);
+            esum += L.be[ch];
+            if (!JOINT) s_child = L.S[ch];
+        } else {
+            i64 ce;
+            f81_cherry_vector<G, R>(L, t, c, st, ch, v, ce, true);
+            esum += ce;
+            s_child = pi_dot<G, R>(L, v);
+        }
+        if (!JOINT) {
+            f81_absorb_child<G, R>(L, t, st, n, ch, e, s_child, v, acc, true);
+            // stored vectors and cherry vectors are in band, tips are 0/1: two factors cannot leave the
+            // double range, so the band is checked every second child and at the end
+            if ((j & 1) == 1 || j == nc - 1) esum += lazy_rescale<G, R>(acc);
+        } else {
+            // row i of P * diag(v): off-diagonal entries w_j = ((1-e) pi_j) v_j, diagonal ((1-e) pi_i + e) v_i
+            // (same rounding sequence as the reference's P * v broadcast, ml.py:130 with F81Model.py:46)
+            const double ome = 1.0 - e;
+            double w[R], dg[R];
+            double m1 = -INFINITY;
+            int j1 = 0x7fffffff;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const double a = ome * L.pi_r[r];
+                const bool ok = L.st(r) < c.k;
+                w[r] = ok ? a * v[r] : -INFINITY;
+                dg[r] = (a + e) * v[r];
+                if (ok && w[r] > m1) {
+                    m1 = w[r];
+                    j1 = L.st(r);
+                }
+            }
+            group_argmax_first<G>(m1, j1);
+            double m2 = -INFINITY;
+            int j2 = 0x7fffffff;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (L.st(r) < c.k && L.st(r) != j1 && w[r] > m2) {
+                    m2 = w[r];
+                    j2 = L.st(r);
+                }
+            }
+            group_argmax_first<G>(m2, j2);
+            int jj[R];
+            bool nz = false;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int i = L.st(r);
+                const double mo = (i == j1) ? m2 : m1;
+                const int jo = (i == j1) ? j2 : j1;
+                double msg;
+                int arg;
+                if (jo >= c.k || dg[r] > mo) {  // no off-diagonal candidate (k == 1) or the diagonal wins
+                    msg = dg[r];
+                    arg = i;
+                } else if (dg[r] < mo) {
+                    msg = mo;
+                    arg = jo;
+                } else {  // tie: numpy's argmax returns the first index
+                    msg = mo;
+                    arg = min(i, jo);
+                }
+                acc[r] *= fmax(msg, 0.0);
+                nz |= acc[r] != 0.0;
+                jj[r] = (i < c.k) ? arg : 0;
+            }
+            // altered nodes get their tables rewritten w.r.t. their initial masks (ml.py:408-428)
+            if (c.masks_init != nullptr) {
+                const size_t mo_ = ((size_t)L.col * t.N + ch) * c.W;
+                const u64* mi = c.masks_init + mo_;
+                const u64* mc = c.masks + mo_;
+                bool altered = false;
+                for (int w_ = 0; w_ < c.W; ++w_) altered |= (mi[w_] != mc[w_]);
+                if (altered) {
+                    const int fa = first_allowed(mi, c.W);
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const int a = jj[r];
+                        if (!((mi[a >> 6] >> (a & 63)) & 1ull)) jj[r] = fa;
+                    }
+                }
+            }
+            {
+                int* jp = st.J + ((size_t)L.col * t.N + ch) * c.ks;
+                if (R == 1) {
+                    if (L.st(0) < c.ks) jp[L.st(0)] = jj[0];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < R; r += 2) {
+                        if (L.st(r) < c.ks) {
+                            int2 t2;
+                            t2.x = jj[r];
+                            t2.y = jj[r + 1];
+                            *reinterpret_cast<int2*>(jp + L.st(r)) = t2;
+                        }
+                    }
+                }
+            }
+            if (!group_any<G>(nz)) {
+                if (L.g == 0)
+                    atomicMin(&st.err[L.col], ((u64)(unsigned)t.post_rank[n] << 32) | (u64)(unsigned)ch);
+            }
+            esum += lazy_rescale<G, R>(acc);
+        }
+    }
+    if (!JOINT) {
+        const double s = pi_dot<G, R>(L, acc);
+        if (L.g == 0) L.S[n] = s;
+    }
+    node_store_vec<G, R>(L, c, L.bu, n, acc);
+    if (L.g == 0) L.be[n] = esum;
+}
+
 template <int G, int R, bool JOINT>
 __global__ void __launch_bounds__(PML_BLOCK)
 bu_f81_kernel(PmlTree t, PmlCols c, PmlState st, const int* __restrict__ level_nodes, int n_level) {
@@ -379,142 +515,10 @@ bu_f81_kernel(PmlTree t, PmlCols c, PmlState st, const int* __restrict__ level_n
     const int sub = (threadIdx.x & 63) / G;
     LaneCtx<G, R> L;
     lane_ctx_init<G, R>(L, t, c, st);
-
     const int stride = gridDim.x * PML_WAVES_PER_BLOCK * UW;
     for (int base = (blockIdx.x * PML_WAVES_PER_BLOCK + wave) * UW; base < n_level; base += stride) {
         const int idx = base + sub;
-        if (idx >= n_level) continue;  // whole groups drop out together
-        const int n = level_nodes[idx];
-        if (!JOINT && Gather<G>::enabled && c.W == 1) {
-            if (bu_f81_unit_fast<G, R>(L, t, c, st, n)) continue;
-        }
-
-        double acc[R];
-        node_mask_vec<G, R>(L, c, n, acc);
-        i64 esum = 0;
-        const int fc = t.first_child[n];
-        const int nc = t.n_children[n];
-        for (int j = 0; j < nc; ++j) {
-            const int ch = fc + j;
-            const double e = L.E[ch];
-            const int kd = node_kind(t, ch);
-            double v[R];
-            double s_child = 0.0;
-            if (kd == PML_KIND_TIP) {
-                node_mask_vec<G, R>(L, c, ch, v);
-                if (!JOINT) s_child = L.S[ch];
-            } else if (kd == PML_KIND_STORED) {
-                node_load_vec<G, R>(L, c, L.bu, ch, v);
-                esum += L.be[ch];
-                if (!JOINT) s_child = L.S[ch];
-            } else {
-                i64 ce;
-                f81_cherry_vector<G, R>(L, t, c, st, ch, v, ce, true);
-                esum += ce;
-                s_child = pi_dot<G, R>(L, v);
-            }
-            if (!JOINT) {
-                f81_absorb_child<G, R>(L, t, st, n, ch, e, s_child, v, acc, true);
-                // stored vectors and cherry vectors are in band, tips are 0/1: two factors cannot leave the
-                // double range, so the band is checked every second child and at the end
-                if ((j & 1) == 1 || j == nc - 1) esum += lazy_rescale<G, R>(acc);
-            } else {
-                // row i of P * diag(v): off-diagonal entries w_j = ((1-e) pi_j) v_j, diagonal ((1-e) pi_i + e) v_i
-                // (same rounding sequence as the reference's P * v broadcast, ml.py:130 with F81Model.py:46)
-                const double ome = 1.0 - e;
-                double w[R], dg[R];
-                double m1 = -INFINITY;
-                int j1 = 0x7fffffff;
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const double a = ome * L.pi_r[r];
-                    const bool ok = L.st(r) < c.k;
-                    w[r] = ok ? a * v[r] : -INFINITY;
-                    dg[r] = (a + e) * v[r];
-                    if (ok && w[r] > m1) {
-                        m1 = w[r];
-                        j1 = L.st(r);
-                    }
-                }
-                group_argmax_first<G>(m1, j1);
-                double m2 = -INFINITY;
-                int j2 = 0x7fffffff;
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    if (L.st(r) < c.k && L.st(r) != j1 && w[r] > m2) {
-                        m2 = w[r];
-                        j2 = L.st(r);
-                    }
-                }
-                group_argmax_first<G>(m2, j2);
-                int jj[R];
-                bool nz = false;
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const int i = L.st(r);
-                    const double mo = (i == j1) ? m2 : m1;
-                    const int jo = (i == j1) ? j2 : j1;
-                    double msg;
-                    int arg;
-                    if (jo >= c.k || dg[r] > mo) {  // no off-diagonal candidate (k == 1) or the diagonal wins
-                        msg = dg[r];
-                        arg = i;
-                    } else if (dg[r] < mo) {
-                        msg = mo;
-                        arg = jo;
-                    } else {  // tie: numpy's argmax returns the first index
-                        msg = mo;
-                        arg = min(i, jo);
-                    }
-                    acc[r] *= fmax(msg, 0.0);
-                    nz |= acc[r] != 0.0;
-                    jj[r] = (i < c.k) ? arg : 0;
-                }
-                // altered nodes get their tables rewritten w.r.t. their initial masks (ml.py:408-428)
-                if (c.masks_init != nullptr) {
-                    const size_t mo_ = ((size_t)L.col * t.N + ch) * c.W;
-                    const u64* mi = c.masks_init + mo_;
-                    const u64* mc = c.masks + mo_;
-                    bool altered = false;
-                    for (int w_ = 0; w_ < c.W; ++w_) altered |= (mi[w_] != mc[w_]);
-                    if (altered) {
-                        const int fa = first_allowed(mi, c.W);
-#pragma unroll
-                        for (int r = 0; r < R; ++r) {
-                            const int a = jj[r];
-                            if (!((mi[a >> 6] >> (a & 63)) & 1ull)) jj[r] = fa;
-                        }
-                    }
-                }
-                {
-                    int* jp = st.J + ((size_t)L.col * t.N + ch) * c.ks;
-                    if (R == 1) {
-                        if (L.st(0) < c.ks) jp[L.st(0)] = jj[0];
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < R; r += 2) {
-                            if (L.st(r) < c.ks) {
-                                int2 t2;
-                                t2.x = jj[r];
-                                t2.y = jj[r + 1];
-                                *reinterpret_cast<int2*>(jp + L.st(r)) = t2;
-                            }
-                        }
-                    }
-                }
-                if (!group_any<G>(nz)) {
-                    if (L.g == 0)
-                        atomicMin(&st.err[L.col], ((u64)(unsigned)t.post_rank[n] << 32) | (u64)(unsigned)ch);
-                }
-                esum += lazy_rescale<G, R>(acc);
-            }
-        }
-        if (!JOINT) {
-            const double s = pi_dot<G, R>(L, acc);
-            if (L.g == 0) L.S[n] = s;
-        }
-        node_store_vec<G, R>(L, c, L.bu, n, acc);
-        if (L.g == 0) L.be[n] = esum;
+        if (idx < n_level) bu_f81_unit<G, R, JOINT>(L, t, c, st, level_nodes[idx]);  // whole groups drop out together
     }
 }
 
@@ -710,6 +714,62 @@ __device__ __forceinline__ bool td_f81_unit_fast(const LaneCtx<G, R>& L, const P
 // every child is finished from them; cherry children are recomputed and their tips finished in the same unit.
 // replaces calc_node_td_likelihood (ml.py:273-290), calc_node_marginal_likelihood (:454-460) and the normalisation
 // of convert_likelihoods_to_probabilities (:498-500) for the F81 family.
+// One top-down unit: stored internal node p of the current depth level.
+template <int G, int R>
+__device__ __forceinline__ void td_f81_unit(const LaneCtx<G, R>& L, const PmlTree& t, const PmlCols& c,
+                                            const PmlState& st, int p) {
+    if (Gather<G>::enabled && c.W == 1) {
+        if (td_f81_unit_fast<G, R>(L, t, c, st, p)) return;
+    }
+
+    double prod[R];
+    {
+        double bp[R], tp[R];
+        node_load_vec<G, R>(L, c, L.bu, p, bp);
+        node_load_vec<G, R>(L, c, L.td, p, tp);
+#pragma unroll
+        for (int r = 0; r < R; ++r) prod[r] = tp[r] * bp[r];
+    }
+    const i64 pe = L.te[p] + L.be[p];
+    double P = 0.0;
+    bool have_P = false;
+    const int fc = t.first_child[p];
+    const int nc = t.n_children[p];
+    for (int j = 0; j < nc; ++j) {
+        const int ch = fc + j;
+        const int kd = node_kind(t, ch);
+        if (kd == PML_KIND_TIP) {
+            f81_finish_tip<G, R>(L, c, prod, pe, P, have_P, ch);
+            continue;
+        }
+        const double e = L.E[ch];
+        double mb[R], v[R], tdc[R];
+        node_mask_vec<G, R>(L, c, ch, mb);
+        i64 xe;
+        if (kd == PML_KIND_STORED) {
+            node_load_vec<G, R>(L, c, L.bu, ch, v);
+            f81_finish_child<G, R, true>(L, c, prod, pe, ch, e, L.S[ch], L.be[ch], v, mb, tdc, xe);
+            node_store_vec<G, R>(L, c, L.td, ch, tdc);
+            if (L.g == 0) L.te[ch] = xe;
+        } else {
+            // cherry: rebuild its bottom-up vector, finish it, then finish its tips from registers
+            i64 bec;
+            f81_cherry_vector<G, R>(L, t, c, st, ch, v, bec, false);
+            const double s_child = pi_dot<G, R>(L, v);
+            f81_finish_child<G, R, false>(L, c, prod, pe, ch, e, s_child, bec, v, mb, tdc, xe);
+            double prod2[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) prod2[r] = tdc[r] * v[r];
+            const i64 pe2 = xe + bec;
+            double P2 = 0.0;
+            bool have_P2 = false;
+            const int fc2 = t.first_child[ch];
+            const int nc2 = t.n_children[ch];
+            for (int q = 0; q < nc2; ++q) f81_finish_tip<G, R>(L, c, prod2, pe2, P2, have_P2, fc2 + q);
+        }
+    }
+}
+
 template <int G, int R>
 __global__ void __launch_bounds__(PML_BLOCK)
 td_f81_kernel(PmlTree t, PmlCols c, PmlState st, const int* __restrict__ level_parents, int n_level) {
@@ -718,61 +778,154 @@ td_f81_kernel(PmlTree t, PmlCols c, PmlState st, const int* __restrict__ level_p
     const int sub = (threadIdx.x & 63) / G;
     LaneCtx<G, R> L;
     lane_ctx_init<G, R>(L, t, c, st);
-
     const int stride = gridDim.x * PML_WAVES_PER_BLOCK * UW;
     for (int base = (blockIdx.x * PML_WAVES_PER_BLOCK + wave) * UW; base < n_level; base += stride) {
         const int idx = base + sub;
-        if (idx >= n_level) continue;
-        const int p = level_parents[idx];
-        if (Gather<G>::enabled && c.W == 1) {
-            if (td_f81_unit_fast<G, R>(L, t, c, st, p)) continue;
-        }
+        if (idx < n_level) td_f81_unit<G, R>(L, t, c, st, level_parents[idx]);
+    }
+}
 
-        double prod[R];
-        {
-            double bp[R], tp[R];
-            node_load_vec<G, R>(L, c, L.bu, p, bp);
-            node_load_vec<G, R>(L, c, L.td, p, tp);
-#pragma unroll
-            for (int r = 0; r < R; ++r) prod[r] = tp[r] * bp[r];
-        }
-        const i64 pe = L.te[p] + L.be[p];
-        double P = 0.0;
-        bool have_P = false;
-        const int fc = t.first_child[p];
-        const int nc = t.n_children[p];
-        for (int j = 0; j < nc; ++j) {
-            const int ch = fc + j;
-            const int kd = node_kind(t, ch);
-            if (kd == PML_KIND_TIP) {
-                f81_finish_tip<G, R>(L, c, prod, pe, P, have_P, ch);
-                continue;
+// ---------------------------------------------------------------------------------------------------------------------
+// Small forests: the whole sweep in ONE launch.  One workgroup per column walks the levels with a workgroup barrier
+// between them, so a sweep costs one kernel launch instead of one per level (a 150-tip tree has ~16 levels of a few
+// nodes each: the level-per-launch schedule is pure launch latency there, and the optimiser repeats the bottom-up
+// sweep hundreds of times, pastml/ml.py:174-237).  Same unit functions, hence the same bits as the level kernels.
+// ---------------------------------------------------------------------------------------------------------------------
+#define PML_SMALL_BLOCK 512
+
+// ln L of one column (ml.py:112-121), shared by loglik_kernel and the single-launch kernels
+__device__ __forceinline__ double column_loglik(const PmlTree& t, const PmlCols& c, const PmlState& st, int col,
+                                                int is_marginal) {
+    const size_t colN = (size_t)col * t.N;
+    double total = 0.0;
+    for (int r = 0; r < t.n_roots; ++r) {
+        const bool tip = t.n_children[r] == 0;
+        const u64* m = c.masks + (colN + r) * c.W;
+        double term;
+        if (is_marginal) {
+            term = 0.0;
+            for (int s = 0; s < c.k; ++s) {
+                const double b = tip ? (double)((m[s >> 6] >> (s & 63)) & 1ull) : st.bu[(colN + r) * c.ks + s];
+                term += b * c.pi[(size_t)col * c.ks + s];
             }
-            const double e = L.E[ch];
-            double mb[R], v[R], tdc[R];
-            node_mask_vec<G, R>(L, c, ch, mb);
-            i64 xe;
-            if (kd == PML_KIND_STORED) {
-                node_load_vec<G, R>(L, c, L.bu, ch, v);
-                f81_finish_child<G, R, true>(L, c, prod, pe, ch, e, L.S[ch], L.be[ch], v, mb, tdc, xe);
-                node_store_vec<G, R>(L, c, L.td, ch, tdc);
-                if (L.g == 0) L.te[ch] = xe;
-            } else {
-                // cherry: rebuild its bottom-up vector, finish it, then finish its tips from registers
-                i64 bec;
-                f81_cherry_vector<G, R>(L, t, c, st, ch, v, bec, false);
-                const double s_child = pi_dot<G, R>(L, v);
-                f81_finish_child<G, R, false>(L, c, prod, pe, ch, e, s_child, bec, v, mb, tdc, xe);
-                double prod2[R];
-#pragma unroll
-                for (int r = 0; r < R; ++r) prod2[r] = tdc[r] * v[r];
-                const i64 pe2 = xe + bec;
-                double P2 = 0.0;
-                bool have_P2 = false;
-                const int fc2 = t.first_child[ch];
-                const int nc2 = t.n_children[ch];
-                for (int q = 0; q < nc2; ++q) f81_finish_tip<G, R>(L, c, prod2, pe2, P2, have_P2, fc2 + q);
+        } else {
+            term = -INFINITY;
+            int arg = 0;
+            for (int s = 0; s < c.k; ++s) {
+                const double b = tip ? (double)((m[s >> 6] >> (s & 63)) & 1ull) : st.bu[(colN + r) * c.ks + s];
+                const double v = b * c.pi[(size_t)col * c.ks + s];
+                if (v > term) {
+                    term = v;
+                    arg = s;
+                }
+            }
+            st.js[colN + r] = arg;
+        }
+        const double e2 = tip ? 0.0 : (double)st.be[colN + r];
+        total += log(term) + e2 * 0.693147180559945309417232121458;
+    }
+    return total;
+}
+
+template <int G, int R>
+__global__ void __launch_bounds__(PML_SMALL_BLOCK)
+bu_f81_small_kernel(PmlTree t, PmlCols c, PmlState st, const double* __restrict__ mu, const double* __restrict__ sf,
+                    const double* __restrict__ tau, const double* __restrict__ tauf, int do_prep,
+                    const int* __restrict__ level_nodes, const int* __restrict__ level_offsets, int n_levels,
+                    double* __restrict__ loglik) {
+    constexpr int UW = 64 / G;
+    const int col = blockIdx.y;
+    if (do_prep) {
+        const size_t colN = (size_t)col * t.N;
+        const double m = mu[col], s = sf[col], ta = tau[col], tf = tauf[col];
+        for (int n = threadIdx.x; n < t.N; n += blockDim.x) {
+            const double tt = (t.dist[n] + ta) * tf * s;
+            st.E[colN + n] = isinf(m) ? 0.0 : exp(-m * tt);
+            if (t.n_children[n] == 0) {
+                double acc = 0.0;
+                for (int w = 0; w < c.W; ++w) {
+                    u64 word = c.masks[(colN + n) * c.W + w];
+                    while (word) {
+                        const int b = __builtin_ctzll(word);
+                        acc += c.pi[(size_t)col * c.ks + w * 64 + b];
+                        word &= word - 1ull;
+                    }
+                }
+                st.S[colN + n] = acc;
+                st.be[colN + n] = 0;
             }
         }
+        __syncthreads();
+    }
+    const int wave = threadIdx.x >> 6;
+    const int n_waves = blockDim.x >> 6;
+    const int sub = (threadIdx.x & 63) / G;
+    LaneCtx<G, R> L;
+    lane_ctx_init<G, R>(L, t, c, st);
+    for (int l = 0; l < n_levels; ++l) {
+        const int a = level_offsets[l], n_level = level_offsets[l + 1] - a;
+        for (int base = wave * UW; base < n_level; base += n_waves * UW) {
+            const int idx = base + sub;
+            if (idx < n_level) bu_f81_unit<G, R, false>(L, t, c, st, level_nodes[a + idx]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loglik[col] = column_loglik(t, c, st, col, 1);
+}
+
+// root of a tree: TD = 1 with exponent 0 (ml.py:274-277), marginal likelihoods BU * pi * mask
+template <int G, int R>
+__device__ __forceinline__ void f81_root_unit(const LaneCtx<G, R>& L, const PmlTree& t, const PmlCols& c, int n) {
+    const bool tip = t.n_children[n] == 0;
+    double mb[R], v[R], one[R], lh[R];
+    node_mask_vec<G, R>(L, c, n, mb);
+    if (tip) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) v[r] = mb[r];
+    } else {
+        node_load_vec<G, R>(L, c, L.bu, n, v);
+    }
+    double lhs = 0.0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        one[r] = (L.st(r) < c.k) ? 1.0 : 0.0;
+        lh[r] = v[r] * (L.pi_r[r] * mb[r]);
+        lhs += lh[r];
+    }
+    lhs = group_sum<G>(lhs);
+    const int lex = (lhs > 0.0 && !isinf(lhs)) ? exponent_of(lhs) : 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) lh[r] = lh[r] / lhs;
+    node_store_vec<G, R>(L, c, L.td, n, one);
+    node_store_vec<G, R>(L, c, L.post, n, lh);
+    if (L.g == 0) {
+        L.te[n] = 0;
+        L.lhsum[n] = __builtin_ldexp(lhs, -lex);
+        L.lhe[n] = (tip ? 0 : L.be[n]) + lex;
+    }
+}
+
+template <int G, int R>
+__global__ void __launch_bounds__(PML_SMALL_BLOCK)
+td_f81_small_kernel(PmlTree t, PmlCols c, PmlState st, const int* __restrict__ level_parents,
+                    const int* __restrict__ level_offsets, int n_levels) {
+    constexpr int UW = 64 / G;
+    const int wave = threadIdx.x >> 6;
+    const int n_waves = blockDim.x >> 6;
+    const int sub = (threadIdx.x & 63) / G;
+    LaneCtx<G, R> L;
+    lane_ctx_init<G, R>(L, t, c, st);
+    for (int base = wave * UW; base < t.n_roots; base += n_waves * UW) {
+        const int idx = base + sub;
+        if (idx < t.n_roots) f81_root_unit<G, R>(L, t, c, idx);
+    }
+    __syncthreads();
+    for (int l = 0; l < n_levels; ++l) {
+        const int a = level_offsets[l], n_level = level_offsets[l + 1] - a;
+        for (int base = wave * UW; base < n_level; base += n_waves * UW) {
+            const int idx = base + sub;
+            if (idx < n_level) td_f81_unit<G, R>(L, t, c, st, level_parents[a + idx]);
+        }
+        __syncthreads();
     }
 }

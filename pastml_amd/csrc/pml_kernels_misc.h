@@ -85,35 +85,7 @@ __global__ void __launch_bounds__(PML_BLOCK)
 loglik_kernel(PmlTree t, PmlCols c, PmlState st, int n_cols, int is_marginal, double* __restrict__ loglik) {
     const int col = blockIdx.x * blockDim.x + threadIdx.x;
     if (col >= n_cols) return;
-    const size_t colN = (size_t)col * t.N;
-    double total = 0.0;
-    for (int r = 0; r < t.n_roots; ++r) {
-        const bool tip = t.n_children[r] == 0;
-        const u64* m = c.masks + (colN + r) * c.W;
-        double term;
-        if (is_marginal) {
-            term = 0.0;
-            for (int s = 0; s < c.k; ++s) {
-                const double b = tip ? (double)((m[s >> 6] >> (s & 63)) & 1ull) : st.bu[(colN + r) * c.ks + s];
-                term += b * c.pi[(size_t)col * c.ks + s];
-            }
-        } else {
-            term = -INFINITY;
-            int arg = 0;
-            for (int s = 0; s < c.k; ++s) {
-                const double b = tip ? (double)((m[s >> 6] >> (s & 63)) & 1ull) : st.bu[(colN + r) * c.ks + s];
-                const double v = b * c.pi[(size_t)col * c.ks + s];
-                if (v > term) {
-                    term = v;
-                    arg = s;
-                }
-            }
-            st.js[colN + r] = arg;
-        }
-        const double e2 = tip ? 0.0 : (double)st.be[colN + r];
-        total += log(term) + e2 * 0.693147180559945309417232121458;
-    }
-    loglik[col] = total;
+    loglik[col] = column_loglik(t, c, st, col, is_marginal);
 }
 
 // joint back-trace, one depth level per launch: state[n] = table[n][state[parent]] (ml.py:615-620)

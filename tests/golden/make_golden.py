@@ -523,7 +523,83 @@ def case_hky_nucleotide():
     save('nucleotide_hky_f81', **out)
 
 
-CASES = dict(data=copy_data, pij=case_pij, albania=case_albania, synthetic_small=case_synthetic_small,
+def case_hiv1c():
+    """
+    BASELINE config 5: examples/HIV1C (3 619 tips).  The tree and a 4-column subset of metadata.tab are copied as
+    fixtures; goldens: Loc (k=12) at the parameters stored in examples/HIV1C/data/pastml_params (pinned -3692.227),
+    Loc optimised by the reference (about 3 minutes), two binary drug-resistance columns optimised.
+    """
+    src = os.path.join(REF, 'examples', 'HIV1C', 'data')
+    dst = os.path.join(DATA, 'hiv1c')
+    os.makedirs(dst, exist_ok=True)
+    shutil.copy(os.path.join(src, 'best', 'pastml_phyml_tree.nwk'), os.path.join(dst, 'pastml_phyml_tree.nwk'))
+    columns = ['Loc', 'RT:K103N', 'RT:M184V', 'PR:L90M']
+    meta = pd.read_csv(os.path.join(src, 'metadata.tab'), sep='\t', index_col=0, header=0)[columns]
+    meta.to_csv(os.path.join(dst, 'metadata_subset.tab'), sep='\t')
+    stored = pd.read_csv(os.path.join(src, 'pastml_params', 'params.tree_pastml_phyml_tree.loc_Loc.tab'), sep='\t',
+                         index_col=0, header=0)['value']
+    stride = 37
+
+    def load():
+        tree = our_tree.read_tree(os.path.join(dst, 'pastml_phyml_tree.nwk'))
+        df = pd.read_csv(os.path.join(dst, 'metadata_subset.tab'), sep='\t', index_col=0, header=0)
+        df.index = df.index.map(str)
+        return tree, df
+
+    out = {}
+    # ---- Loc at the stored parameters
+    tree, df = load()
+    states = np.array(sorted([_ for _ in df['Loc'].unique() if not pd.isna(_) and '' != _]))
+    params = {'scaling_factor': float(stored['scaling_factor'])}
+    params.update({s: float(stored[s]) for s in states})
+    t0 = __import__('time').time()
+    res = racr(tree, df[['Loc']].copy(), prediction_method='MPPA', model='F81', column2parameters={'Loc': params},
+               threads=1)[0]
+    print('Loc fixed: {:.1f} s'.format(__import__('time').time() - t0))
+    flat = our_tree.FlatForest.from_trees([tree])
+    names = [n.name for n in flat.nodes]
+    sample = np.arange(0, flat.n_nodes, stride)
+    out['sample'] = sample
+    out['n_nodes'] = flat.n_nodes
+    out['stored_loglik'] = float(stored['log_likelihood'])
+    out['loc_states'] = np.array(states, dtype=str)
+    out['locfix_sf'] = float(res['model'].sf)
+    out['locfix_frequencies'] = np.array(res['model'].frequencies)
+    out['locfix_loglik'] = res['log_likelihood']
+    for m in ('JOINT', 'MAP', 'MPPA'):
+        out['locfix_loglik_restricted_' + m] = res['log_likelihood_restricted_' + m]
+    out['locfix_num_unresolved_nodes'] = res['num_unresolved_nodes']
+    out['locfix_num_states_per_node_avg'] = res['num_states_per_node_avg']
+    mp = res['marginal_probabilities']
+    out['locfix_posterior_sample'] = mp.loc[[names[i] for i in sample]].values
+    s2i = {s: i for i, s in enumerate(res['states'])}
+    sel = np.zeros((flat.n_nodes, len(s2i)), dtype=np.int8)
+    for i, n in enumerate(flat.nodes):
+        for s in getattr(n, 'Loc'):
+            sel[i, s2i[s]] = 1
+    out['locfix_selected_mppa'] = sel
+    out['locfix_joint_state'] = collect(flat.nodes, 'Loc_JOINT_STATE', dtype=np.int64)
+    out['forest_stats'] = np.array([res['model'].forest_stats.avg_nonzero_brlen, res['model'].forest_stats.num_nodes,
+                                    res['model'].forest_stats.num_tips, res['model'].forest_stats.forest_length])
+
+    # ---- optimised: two binary columns (seconds) and Loc (minutes)
+    for col, label in (('RT:K103N', 'k103n'), ('PR:L90M', 'l90m'), ('Loc', 'locopt')):
+        tree, df = load()
+        t0 = __import__('time').time()
+        res = racr(tree, df[[col]].copy(), prediction_method='MPPA', model='F81', threads=1)[0]
+        print('{} optimised: {:.1f} s'.format(col, __import__('time').time() - t0))
+        out[label + '_states'] = np.array(res['states'], dtype=str)
+        out[label + '_sf'] = float(res['model'].sf)
+        out[label + '_frequencies'] = np.array(res['model'].frequencies)
+        out[label + '_loglik'] = res['log_likelihood']
+        out[label + '_loglik_restricted_MPPA'] = res['log_likelihood_restricted_MPPA']
+        out[label + '_num_unresolved_nodes'] = res['num_unresolved_nodes']
+        out[label + '_posterior_sample'] = res['marginal_probabilities'].loc[[names[i] for i in sample]].values
+        out[label + '_reference_seconds'] = __import__('time').time() - t0
+    save('hiv1c', **out)
+
+
+CASES = dict(hiv1c=case_hiv1c, data=copy_data, pij=case_pij, albania=case_albania, synthetic_small=case_synthetic_small,
              synthetic_large=case_synthetic_large, edge=case_edge, nucleotide=case_hky_nucleotide)
 
 if __name__ == '__main__':

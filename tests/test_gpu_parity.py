@@ -364,3 +364,31 @@ def test_cherry_fusion_is_bit_identical(k):
         assert np.array_equal(a, b)
     # the fused run never materialised the cherries' top-down vectors
     assert np.isnan(out[0][6]).sum() > np.isnan(out[1][6]).sum()
+
+
+@pytest.mark.parametrize('k', [2, 5, 12, 64])
+def test_single_launch_path_matches_level_path(k, monkeypatch):
+    """Small forests run a whole sweep in one launch; the level-per-launch schedule must give the same bits."""
+    rng = np.random.default_rng(100 + k)
+    flat = FlatForest.random(400, seed=k + 7, max_arity=4, zero_frac=0.0, n_trees=2)
+    specs = [random_spec('F81', k, rng) for _ in range(3)]
+    rates = [(1.1, 0.0, 1.0), (0.7, 0.03, 0.9), (2.0, 0.0, 1.0)]
+    masks = np.stack([random_masks(flat, k, rng) for _ in range(3)])
+    out = []
+    for limit in ('1000000', '0'):
+        monkeypatch.setenv('PASTML_HIP_SMALL_MAX_NODES', limit)
+        with hip.Engine(flat, 3, k) as eng:
+            eng.set_models(list(zip(specs, rates)))
+            eng.set_masks(masks)
+            lnl = eng.bottom_up(True)
+            post, lh_sum, lh_sf = eng.top_down_marginals()
+            # a second sweep with new parameters re-runs the fused prep
+            eng.set_models(list(zip(specs[::-1], rates)))
+            lnl2 = eng.bottom_up(True)
+            out.append((lnl, post[:, flat.n_roots if False else 0:], lh_sf, lnl2))
+    nonroot = flat.parent >= 0
+    assert np.array_equal(out[0][0], out[1][0])
+    assert np.array_equal(out[0][3], out[1][3])
+    assert np.array_equal(out[0][1][:, nonroot], out[1][1][:, nonroot])
+    np.testing.assert_allclose(out[0][1], out[1][1], rtol=1e-14, atol=0)   # roots: different butterfly shape
+    assert np.array_equal(out[0][2], out[1][2])
