@@ -353,3 +353,61 @@ def test_forest_of_trees_and_threads():
         assert r['num_unresolved_nodes'] == int(z['mppa_num_unresolved'])
     sel = np.array([[s in getattr(n, 'ch') for s in states] for n in flat.nodes], dtype=np.int8)
     assert np.array_equal(sel, z['masks_mppa'])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE config 5: examples/HIV1C (3 619 tips)
+# ---------------------------------------------------------------------------------------------------------------------
+HIV = os.path.join(DATA, 'hiv1c')
+
+
+def hiv_inputs(column):
+    tree = read_tree(os.path.join(HIV, 'pastml_phyml_tree.nwk'))
+    df = pd.read_csv(os.path.join(HIV, 'metadata_subset.tab'), sep='\t', index_col=0, header=0)
+    df.index = df.index.map(str)
+    return tree, df[[column]].copy()
+
+
+def test_hiv1c_loc_at_stored_parameters():
+    """Loc (k=12) at the parameters of examples/HIV1C/data/pastml_params: pinned log-likelihood -3692.227."""
+    z = load_golden('hiv1c')
+    tree, df = hiv_inputs('Loc')
+    params = {'scaling_factor': float(z['locfix_sf'])}
+    params.update({s: f for s, f in zip(z['loc_states'], z['locfix_frequencies'])})
+    res = acr(tree, df, prediction_method=MPPA, model=F81, column2parameters={'Loc': params})[0]
+    fs = res[MODEL].forest_stats
+    np.testing.assert_array_equal([fs.avg_nonzero_brlen, fs.num_nodes, fs.num_tips, fs.forest_length],
+                                  z['forest_stats'])
+    assert abs(res[LOG_LIKELIHOOD] - (-3692.227)) < 5e-4
+    np.testing.assert_allclose(res[LOG_LIKELIHOOD], z['locfix_loglik'], rtol=1e-11)
+    for m in (JOINT, MAP, MPPA):
+        np.testing.assert_allclose(res[RESTRICTED_LOG_LIKELIHOOD_FORMAT_STR.format(m)],
+                                   z['locfix_loglik_restricted_' + m], rtol=1e-11)
+    flat = FlatForest.from_trees([tree])
+    mp = res[MARGINAL_PROBABILITIES]
+    np.testing.assert_allclose(mp.values[z['sample']], z['locfix_posterior_sample'], rtol=1e-8, atol=1e-300)
+    assert np.array_equal([getattr(n, 'Loc_JOINT_STATE') for n in flat.nodes], z['locfix_joint_state'])
+    s2i = {s: i for i, s in enumerate(res[STATES])}
+    sel = np.zeros((flat.n_nodes, len(s2i)), dtype=np.int8)
+    for i, n in enumerate(flat.nodes):
+        for s in getattr(n, 'Loc'):
+            sel[i, s2i[s]] = 1
+    assert np.array_equal(sel, z['locfix_selected_mppa'])
+    assert res['num_unresolved_nodes'] == int(z['locfix_num_unresolved_nodes'])
+    np.testing.assert_allclose(res['num_states_per_node_avg'], z['locfix_num_states_per_node_avg'])
+
+
+@pytest.mark.parametrize('column,label', [('RT:K103N', 'k103n'), ('PR:L90M', 'l90m'), ('Loc', 'locopt')])
+def test_hiv1c_optimised_columns(column, label):
+    """Full ml_acr with parameter optimisation (reference: 10 s per binary column, 245 s for Loc)."""
+    z = load_golden('hiv1c')
+    tree, df = hiv_inputs(column)
+    res = acr(tree, df, prediction_method=MPPA, model=F81)[0]
+    assert list(res[STATES]) == list(z[label + '_states'])
+    np.testing.assert_allclose(res[LOG_LIKELIHOOD], z[label + '_loglik'], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(res[MODEL].sf, z[label + '_sf'], rtol=1e-3)
+    np.testing.assert_allclose(res[MODEL].frequencies, z[label + '_frequencies'], atol=1e-4)
+    np.testing.assert_allclose(res[MARGINAL_PROBABILITIES].values[z['sample']], z[label + '_posterior_sample'],
+                               atol=2e-4)
+    np.testing.assert_allclose(res[RESTRICTED_LOG_LIKELIHOOD_FORMAT_STR.format(MPPA)],
+                               z[label + '_loglik_restricted_MPPA'], rtol=0, atol=5e-3)
