@@ -14,10 +14,12 @@ What stays on the host, as SURVEY.md section 8a prescribes: the allowed-state ma
 bookkeeping of results.
 """
 import logging
+import os
 
 import numpy as np
 import pandas as pd
 from scipy.optimize import minimize
+from scipy.optimize._numdiff import approx_derivative
 
 from pastml_amd import get_personalized_feature_name, CHARACTER, METHOD, NUM_SCENARIOS, NUM_UNRESOLVED_NODES, \
     NUM_STATES_PER_NODE, PERC_UNRESOLVED, STATES
@@ -143,6 +145,8 @@ class ForestProblem(object):
         if self._engine is not None:
             self._engine.close()
             self._engine = None
+        for slot in self.__dict__.pop('_batch_engines', {}).values():
+            slot['engine'].close()
 
     # ------------------------------------------------------------------------------------------------ masks
     def initialize_allowed_states(self):
@@ -243,6 +247,51 @@ class ForestProblem(object):
         if len(altered) and is_marginal:
             self.unalter_zero_node_allowed_states(altered)
         return float(lnl)
+
+    def batch_loglikelihoods(self, model, parameter_vectors):
+        """
+        Marginal log-likelihoods (alter=True semantics) for several parameter vectors of the optimiser at once:
+        one device column per vector, ONE bottom-up sweep for all of them.  This is what makes the finite-difference
+        gradient of the optimiser (pastml/ml.py:231, scipy's 2-point scheme: n_params + 1 evaluations) cost one launch
+        sequence instead of n_params + 1.  Every column is computed independently and deterministically, so the values
+        are bit-identical to evaluating the vectors one by one.  The model is left at the last vector.
+        """
+        C = len(parameter_vectors)
+        cache = self.__dict__.setdefault('_batch_engines', {})
+        if C not in cache:
+            cache[C] = dict(engine=hip.Engine(self.flat, C, self.k, device=self._device), masks=[None] * C)
+        slot = cache[C]
+        engine = slot['engine']
+        specs, variants = [], []
+        for ps in parameter_vectors:
+            model.set_params_from_optimised(ps)
+            specs.append((model.kernel_spec(), model.rate_params()))
+            variants.append(0 == model.tau)
+        # masks: altered (tau == 0) or as they are; the alteration does not depend on the other parameters
+        plain = self.masks
+        altered_masks = None
+        if any(variants):
+            keep = (self.masks.copy(), self.init_masks.copy(), self.has_init.copy())
+            altered = self.alter_zero_node_allowed_states()
+            altered_masks = self.masks.copy()
+            # the evaluation itself leaves masks as they were (marginal sweeps un-alter, ml.py:115-117), but the saved
+            # '.initial' masks stay, exactly as after a sequence of single evaluations
+            self.masks = keep[0]
+            if not len(altered):
+                self.init_masks, self.has_init = keep[1], keep[2]
+        for col, variant in enumerate(variants):
+            wanted = altered_masks if variant else plain
+            if slot['masks'][col] is None or not np.array_equal(slot['masks'][col], wanted):
+                engine.set_masks(wanted, col_begin=col)
+                slot['masks'][col] = wanted.copy()
+        engine.set_models(specs)
+        self.n_sweeps += C
+        try:
+            return engine.bottom_up(True)
+        except hip.ZeroLikelihoodError as e:
+            first = int(np.flatnonzero(e.err_child >= 0)[0])
+            e.err_parent, e.err_child = e.err_parent[first:first + 1], e.err_child[first:first + 1]
+            self._raise_likelihood_error(e)
 
     def joint_states(self):
         """Joint state of every node after a joint sweep (ml.py:598-622)."""
@@ -496,6 +545,35 @@ def optimize_likelihood_params(forest, character, observed_frequencies, model, p
 
         best_log_lh = max(log_lh_JC, log_lh_EFT)
 
+        lower, upper = bounds[:, 0], bounds[:, 1]
+
+        def get_v_and_gradient(ps):
+            """
+            Value and the 2-point finite-difference gradient scipy's L-BFGS-B would compute itself (abs_step 1e-8,
+            steps flipped at the bounds), with all n_params + 1 likelihoods evaluated in one batched device sweep.
+            scipy's own approx_derivative runs twice -- first to record the points it asks for, then on the table of
+            their values -- so points and arithmetic are scipy's, and the iterates are those of the unbatched run.
+            """
+            ps = np.asarray(ps, dtype=np.float64)
+            if np.any(pd.isnull(ps)):
+                return np.nan, np.full(len(ps), np.nan)
+            asked = []
+
+            def record(x):
+                asked.append(np.array(x, dtype=np.float64))
+                return 0.0
+
+            approx_derivative(record, ps, method='2-point', abs_step=1e-8, f0=0.0, bounds=(lower, upper))
+            values = problem.batch_loglikelihoods(model, [ps] + asked)
+            values = [np.inf if pd.isnull(v) else -v for v in values]
+            table = {x.tobytes(): v for x, v in zip(asked, values[1:])}
+            gradient = approx_derivative(lambda x: table[np.asarray(x, dtype=np.float64).tobytes()], ps,
+                                         method='2-point', abs_step=1e-8, f0=values[0], bounds=(lower, upper))
+            model.set_params_from_optimised(ps)
+            return values[0], gradient
+
+        batched = os.environ.get('PASTML_AMD_BATCHED_OPTIMISER', '1') != '0'
+
         for i in range(100):
             if i == 0:
                 vs = x0_JC
@@ -503,7 +581,10 @@ def optimize_likelihood_params(forest, character, observed_frequencies, model, p
                 vs = x0_EFT
             else:
                 vs = np.random.uniform(bounds[:, 0], bounds[:, 1])
-            fres = minimize(get_v, x0=vs, method='L-BFGS-B', bounds=bounds)
+            if batched:
+                fres = minimize(get_v_and_gradient, x0=vs, method='L-BFGS-B', bounds=bounds, jac=True)
+            else:
+                fres = minimize(get_v, x0=vs, method='L-BFGS-B', bounds=bounds)
             if fres.success and not np.any(np.isnan(fres.x)):
                 if -fres.fun >= best_log_lh:
                     model.set_params_from_optimised(fres.x)

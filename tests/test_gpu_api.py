@@ -411,3 +411,23 @@ def test_hiv1c_optimised_columns(column, label):
                                atol=2e-4)
     np.testing.assert_allclose(res[RESTRICTED_LOG_LIKELIHOOD_FORMAT_STR.format(MPPA)],
                                z[label + '_loglik_restricted_MPPA'], rtol=0, atol=5e-3)
+
+
+@pytest.mark.parametrize('model', [F81, JC])
+def test_batched_optimiser_reproduces_sequential_iterates(model, monkeypatch):
+    """
+    The optimiser evaluates the n_params + 1 finite-difference points of every L-BFGS-B gradient in one batched sweep;
+    since every column is computed independently, the optimum must be the one of the point-by-point run, bit for bit.
+    """
+    out = []
+    for flag in ('1', '0'):
+        monkeypatch.setenv('PASTML_AMD_BATCHED_OPTIMISER', flag)
+        tree = read_tree(TREE_NWK)
+        res = acr(tree, albania_df(), prediction_method=MPPA, model=model)[0]
+        out.append(res)
+    a, b = out
+    assert a[LOG_LIKELIHOOD] == b[LOG_LIKELIHOOD]
+    assert a[MODEL].sf == b[MODEL].sf
+    assert np.array_equal(a[MODEL].frequencies, b[MODEL].frequencies)
+    assert np.array_equal(a[MARGINAL_PROBABILITIES].values, b[MARGINAL_PROBABILITIES].values)
+    assert a[RESTRICTED_LOG_LIKELIHOOD_FORMAT_STR.format(MPPA)] == b[RESTRICTED_LOG_LIKELIHOOD_FORMAT_STR.format(MPPA)]
