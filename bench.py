@@ -87,8 +87,13 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
+        if os.environ.get('BENCH_ALL_RANKS_ON_GPU0') is None:
+            torch.cuda.set_device(local_rank)
+        backend = os.environ.get('BENCH_DIST_BACKEND', 'nccl')  # 'gloo' only for dry runs of the N > 1 path
+        if backend == 'nccl':
+            dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend=backend)
 
     from pastml_amd import hip, synthetic
     from pastml_amd.sharding import shard_characters, allreduce_sum
@@ -101,7 +106,7 @@ def main():
     N = flat.n_nodes
     chars = list(shard_characters(cpg * world, rank, world))  # contiguous block of characters per rank
 
-    eng = hip.Engine(flat, cpg, k, device=local_rank)
+    eng = hip.Engine(flat, cpg, k, device=local_rank if os.environ.get('BENCH_ALL_RANKS_ON_GPU0') is None else 0)
     if model == 'JC':
         specs = [dict(kind=0, pi=np.ones(k) / k) for _ in chars]
     else:
@@ -110,8 +115,10 @@ def main():
     eng.set_tip_states(np.stack([synthetic.tip_states(flat.n_tips, k, c) for c in chars]))
     eng.sync()
 
-    dev = 'cuda:{}'.format(local_rank)
+    gpu_index = local_rank if os.environ.get('BENCH_ALL_RANKS_ON_GPU0') is None else 0
+    dev = 'cuda:{}'.format(gpu_index)
     torch.zeros(1, device=dev)  # initialise torch's context on this GPU before timing
+    red_dev = dev if (dist is None or dist.get_backend() == 'nccl') else 'cpu'
 
     def step():
         # model parameters are re-sent every step, as an optimiser iteration would: forces the per-branch
@@ -120,7 +127,7 @@ def main():
         lnl = eng.bottom_up(True)                       # inputs resident in HBM; returns ln L per character
         eng.top_down_marginals(posterior=False, lh=False)  # TD + marginals + posteriors, outputs stay in HBM
         # the one collective of the path: summed log-likelihood over the ranks (RCCL all-reduce of 8 bytes)
-        total = allreduce_sum(float(lnl.sum()), device=dev)
+        total = allreduce_sum(float(lnl.sum()), device=red_dev)
         return total, lnl
 
     def fence():
@@ -143,7 +150,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
