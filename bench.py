@@ -221,7 +221,7 @@ def main():
         if not args.no_cpu_baseline:
             cl = args.cpu_baseline_levels
             if cl is None:
-                cl = min(levels, 16 if k >= 32 else 17)
+                cl = min(levels, 17 if k >= 32 else 16)  # 10-20 s of single-thread numpy on the GPU box
             out['cpu_baseline'] = cpu_baseline(k, cl, model)
             out['speedup_vs_cpu_baseline'] = value / out['cpu_baseline']['value']
         print(json.dumps(out))

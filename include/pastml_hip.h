@@ -148,6 +148,17 @@ int pml_top_down_marginals(pml_ctx* ctx, double* posterior_out, double* lh_sum_o
  */
 int pml_joint_backtrace(pml_ctx* ctx, int32_t* joint_state_out);
 
+/*
+ * State selection on the device after pml_top_down_marginals: method 0 = MAP (pastml/ml.py:577-595), 1 = MPPA
+ * (pastml/ml.py:505-574).  lh_mask (optional, [n_cols][n_nodes][W]): masks multiplied into the marginal likelihoods
+ * first, i.e. the '.initial' masks of the nodes altered by zero-branch handling and all ones elsewhere
+ * (ml.py:541-542, 593-594).  force_joint (MPPA): the joint states of the last pml_joint_backtrace are always kept.
+ * The selected masks REPLACE the columns' allowed-state masks on the device (ready for the restricted sweep) and are
+ * copied to masks_out[n_cols][n_nodes][W] / n_states_out[n_cols][n_nodes] if not NULL.
+ */
+int pml_select_states(pml_ctx* ctx, int method, int force_joint, const uint64_t* lh_mask, uint64_t* masks_out,
+                      int32_t* n_states_out);
+
 /* ---- inspection ------------------------------------------------------------------------------------------------------ */
 int pml_download(pml_ctx* ctx, int what, int32_t col, void* out);
 /* HIP-event timer on the ctx's stream */

@@ -87,6 +87,9 @@ struct pml_ctx {
     int *d_J = nullptr, *d_js = nullptr;
     u64* d_err = nullptr;
     int bu_mode = -1;  // -1 invalid, 1 marginal, 0 joint
+    bool js_ever = false;  // joint states of some earlier joint sweep are still in d_js
+    bool post_ever = false;  // posteriors of some earlier top-down sweep are still in d_post
+    int* d_nsel = nullptr;
     bool td_valid = false, js_valid = false;
 };
 
@@ -302,6 +305,14 @@ static void launch_small_f81(pml_ctx* ctx, bool bottom_up, int do_prep) {
     X(64, 4)             \
     X(32, 2)             \
     X(8, 8)
+
+template <int G, int R>
+static void launch_select(pml_ctx* ctx, int method, int force_joint, const u64* d_lh_mask) {
+    const int upb = PML_WAVES_PER_BLOCK * (64 / G);
+    dim3 grid(grid_for(ctx->N, upb, ctx->C), ctx->C), block(PML_BLOCK);
+    hipLaunchKernelGGL((select_states_kernel<G, R>), grid, block, 0, ctx->stream, ctx->N, ctx->k, ctx->ks, ctx->W,
+                       ctx->d_post, d_lh_mask, ctx->d_js, method, force_joint, ctx->d_masks, ctx->d_nsel);
+}
 
 static int dispatch_small_f81(pml_ctx* ctx, bool bottom_up, int do_prep) {
 #define X(G_, R_)                                            \
@@ -1045,6 +1056,7 @@ int pml_top_down_marginals(pml_ctx* ctx, double* posterior_out, double* lh_sum_o
     }
     PML_TRY(prof_end(ctx, 1, n_launch));
     ctx->td_valid = true;
+    ctx->post_ever = true;
     if (posterior_out) {
         if (ctx->ks == ctx->k) {
             HIP_TRY(hipMemcpyAsync(posterior_out, ctx->d_post, CN * ctx->k * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -1080,10 +1092,58 @@ int pml_joint_backtrace(pml_ctx* ctx, int32_t* joint_state_out) {
         HIP_TRY(hipGetLastError());
     }
     ctx->js_valid = true;
+    ctx->js_ever = true;
     if (joint_state_out)
         HIP_TRY(hipMemcpyAsync(joint_state_out, ctx->d_js, (size_t)ctx->C * ctx->N * sizeof(int), hipMemcpyDeviceToHost,
                                ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PML_OK;
+}
+
+int pml_select_states(pml_ctx* ctx, int method, int force_joint, const uint64_t* lh_mask, uint64_t* masks_out,
+                      int32_t* n_states_out) {
+    PML_TRY(require_model(ctx));
+    if (!ctx->post_ever) return fail(PML_ERR_INVALID, "pml_select_states needs pml_top_down_marginals first");
+    if (method != 0 && method != 1) return fail(PML_ERR_INVALID, "method must be 0 (MAP) or 1 (MPPA)");
+    if (method == 1 && force_joint && !ctx->js_ever)
+        return fail(PML_ERR_INVALID, "force_joint needs the joint states of a pml_joint_backtrace");
+    const size_t CN = (size_t)ctx->C * ctx->N;
+    if (!ctx->d_nsel) PML_TRY(dev_alloc(ctx, &ctx->d_nsel, CN));
+    u64* d_lh_mask = nullptr;
+    if (lh_mask) {
+        if (ctx->k % 64) {
+            const u64 valid = (1ull << (ctx->k % 64)) - 1ull;
+            for (size_t i = ctx->W - 1; i < CN * ctx->W; i += ctx->W)
+                if (lh_mask[i] & ~valid) return fail(PML_ERR_INVALID, "lh_mask word %zu has bits beyond k", i);
+        }
+        HIP_TRY(hipMalloc((void**)&d_lh_mask, CN * ctx->W * sizeof(u64)));
+        hipError_t e = hipMemcpyAsync(d_lh_mask, lh_mask, CN * ctx->W * sizeof(u64), hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) {
+            (void)hipFree(d_lh_mask);
+            return fail(PML_ERR_HIP, "lh_mask upload failed: %s", hipGetErrorString(e));
+        }
+    }
+    int status = PML_ERR_UNSUPPORTED;
+#define X(G_, R_)                                                      \
+    if (ctx->G == G_ && ctx->R == R_) {                                \
+        launch_select<G_, R_>(ctx, method, force_joint, d_lh_mask);    \
+        status = PML_OK;                                               \
+    }
+    PML_GR_CASES(X)
+#undef X
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && masks_out)
+        e = hipMemcpyAsync(masks_out, ctx->d_masks, CN * ctx->W * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && n_states_out)
+        e = hipMemcpyAsync(n_states_out, ctx->d_nsel, CN * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+    hipError_t e2 = hipStreamSynchronize(ctx->stream);
+    if (d_lh_mask) (void)hipFree(d_lh_mask);
+    if (status != PML_OK) return fail(status, "no selection kernel for G=%d R=%d", ctx->G, ctx->R);
+    if (e != hipSuccess) return fail(PML_ERR_HIP, "pml_select_states failed: %s", hipGetErrorString(e));
+    if (e2 != hipSuccess) return fail(PML_ERR_HIP, "pml_select_states failed: %s", hipGetErrorString(e2));
+    // the columns' masks changed: sweeps must be redone, the posteriors themselves stay valid for inspection
+    ctx->prep_dirty = true;
+    ctx->bu_mode = -1;
     return PML_OK;
 }
 

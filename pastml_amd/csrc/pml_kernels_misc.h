@@ -2,6 +2,8 @@
 #pragma once
 #include "pml_kernels_f81.h"
 
+#define PML_MAX_STATES_SEL 256
+
 // masks: internal nodes all ones; tip j one-hot at states[col][j] (all ones if negative = missing data)
 __global__ void __launch_bounds__(PML_BLOCK)
 masks_fill_kernel(int N, int W, int k, u64* __restrict__ masks, int col_begin) {
@@ -96,5 +98,140 @@ joint_backtrace_kernel(PmlTree t, PmlCols c, PmlState st, int begin, int end) {
     for (int n = begin + blockIdx.x * blockDim.x + threadIdx.x; n < end; n += gridDim.x * blockDim.x) {
         const int ps = st.js[colN + t.parent[n]];
         st.js[colN + n] = st.J[(colN + n) * c.ks + ps];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// State selection from the marginal posteriors: MAP (pastml/ml.py:577-595) and MPPA (pastml/ml.py:505-574).
+// One unit = (node, column), G lanes with R contiguous states each; the unit's vectors live in LDS.
+//   lh_i   = posterior_i * [i allowed by lh_mask]          (the reference multiplies LH by the '.initial' masks)
+//   MAP    : first arg-max of lh
+//   MPPA   : p = lh / sum(lh); q = p sorted ascending, with the joint state's probability moved last if force_joint;
+//            best m = first minimiser of sum_i (u_m[i] - q[i])^2, u_m = (0,..,0, 1/m x m); the m states with the
+//            largest lh are kept (ties: lower index first).
+// The selected masks replace the columns' allowed-state masks (ready for the restricted sweep).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int G, int R>
+__global__ void __launch_bounds__(PML_BLOCK)
+select_states_kernel(int N, int k, int ks, int W, const double* __restrict__ post, const u64* __restrict__ lh_mask,
+                     const int* __restrict__ js, int method, int force_joint, u64* __restrict__ masks,
+                     int* __restrict__ n_states) {
+    constexpr int UW = 64 / G;
+    constexpr int KP = G * R;
+    __shared__ double s_lh[PML_WAVES_PER_BLOCK * UW][KP];
+    __shared__ double s_q[PML_WAVES_PER_BLOCK * UW][KP];
+    __shared__ double s_p[PML_WAVES_PER_BLOCK * UW][KP];
+    __shared__ u64 s_words[PML_WAVES_PER_BLOCK * UW][(PML_MAX_STATES_SEL + 63) / 64];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int g = lane & (G - 1);
+    const int sub = lane / G;
+    const int col = blockIdx.y;
+    const size_t colN = (size_t)col * N;
+    const int s0 = g * R;
+    const int unit = wave * UW + sub;
+    double* lhv = s_lh[unit];
+    double* qv = s_q[unit];
+    double* pv = s_p[unit];
+    u64* words = s_words[unit];
+    const int stride = gridDim.x * PML_WAVES_PER_BLOCK * UW;
+    for (int base = (blockIdx.x * PML_WAVES_PER_BLOCK + wave) * UW; base < N; base += stride) {
+        const int n = base + sub;
+        if (n >= N) continue;
+        double lh[R];
+        double sum = 0.0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int s = s0 + r;
+            double v = 0.0;
+            if (s < k) {
+                v = post[(colN + n) * ks + s];
+                if (lh_mask != nullptr && !((lh_mask[(colN + n) * W + (s >> 6)] >> (s & 63)) & 1ull)) v = 0.0;
+            }
+            lh[r] = v;
+            sum += v;
+            lhv[s] = v;
+        }
+        if (g < W) words[g] = 0ull;
+        for (int w = G; w < W; w += G)
+            if (g + w < W) words[g + w] = 0ull;
+        sum = group_sum<G>(sum);
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (s0 + r < k) pv[s0 + r] = lh[r] / sum;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        int best_k = 1;
+        if (method != 0) {
+            const int ji = force_joint ? js[colN + n] : -1;
+            // ascending ranks (joint state last)
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int i = s0 + r;
+                if (i >= k) continue;
+                const double pi_ = pv[i];
+                int rank = 0;
+                if (i == ji) {
+                    rank = k - 1;
+                } else {
+                    for (int j = 0; j < k; ++j) {
+                        if (j == ji || j == i) continue;
+                        const double pj = pv[j];
+                        rank += (pj < pi_ || (pj == pi_ && j < i)) ? 1 : 0;
+                    }
+                }
+                qv[rank] = pi_;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            double best_c = INFINITY;
+            int best_m = 0x7fffffff;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int m = s0 + r + 1;
+                if (m > k) continue;
+                const double inv = 1.0 / (double)m;
+                double corr = 0.0;
+                for (int i = 0; i < k; ++i) {
+                    const double d = (i < k - m ? 0.0 : inv) - qv[i];
+                    corr += d * d;
+                }
+                if (corr < best_c) {  // ascending m inside a lane: strict < keeps the first minimum
+                    best_c = corr;
+                    best_m = m;
+                }
+            }
+            // first minimum over the lanes: smaller corr, ties -> smaller m (NaN never wins: m stays k as in numpy)
+#pragma unroll
+            for (int o = G / 2; o > 0; o >>= 1) {
+                const double oc = __shfl_xor(best_c, o, 64);
+                const int om = __shfl_xor(best_m, o, 64);
+                if (oc < best_c || (oc == best_c && om < best_m)) {
+                    best_c = oc;
+                    best_m = om;
+                }
+            }
+            best_k = (best_m > k) ? k : best_m;
+        }
+        // keep the best_k states with the largest lh (stable: ties go to the lower index)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int i = s0 + r;
+            if (i >= k) continue;
+            int rank = 0;
+            for (int j = 0; j < k; ++j) {
+                const double lj = lhv[j];
+                rank += (lj > lh[r] || (lj == lh[r] && j < i)) ? 1 : 0;
+            }
+            if (rank < best_k) atomicOr(&words[i >> 6], 1ull << (i & 63));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int w = g; w < W; w += G) masks[(colN + n) * W + w] = words[w];
+        if (g == 0) n_states[colN + n] = best_k;
+        __builtin_amdgcn_wave_barrier();
     }
 }

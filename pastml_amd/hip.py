@@ -75,6 +75,7 @@ SIGNATURES = {
     'pml_bottom_up': [_ctx_p, ctypes.c_int, _c_double_p, _c_int32_p, _c_int32_p],
     'pml_top_down_marginals': [_ctx_p, _c_double_p, _c_double_p, _c_double_p],
     'pml_joint_backtrace': [_ctx_p, _c_int32_p],
+    'pml_select_states': [_ctx_p, ctypes.c_int, ctypes.c_int, _c_uint64_p, _c_uint64_p, _c_int32_p],
     'pml_download': [_ctx_p, ctypes.c_int, ctypes.c_int32, ctypes.c_void_p],
     'pml_timer_start': [_ctx_p],
     'pml_timer_stop': [_ctx_p, ctypes.POINTER(ctypes.c_float)],
@@ -146,6 +147,12 @@ def pack_masks(masks, k):
     if pad:
         bits = np.concatenate([bits, np.zeros(bits.shape[:-1] + (pad,), dtype=np.uint8)], axis=-1)
     return np.ascontiguousarray(bits).view('<u8').reshape(masks.shape[:-1] + (W,))
+
+
+def unpack_masks(words, k):
+    """uint64 words [..., W] -> 0/1 int8 array [..., k]."""
+    b = np.ascontiguousarray(words).view(np.uint8).reshape(words.shape[:-1] + (words.shape[-1] * 8,))
+    return np.unpackbits(b, axis=-1, bitorder='little')[..., :k].astype(np.int8)
 
 
 class Engine(object):
@@ -337,6 +344,22 @@ class Engine(object):
         out = np.empty((self.n_cols, self.n_nodes), dtype=np.int32) if copy_out else None
         _check(self._lib.pml_joint_backtrace(self._ctx, None if out is None else _ptr(out, ctypes.c_int32)))
         return out
+
+    def select_states(self, method, force_joint=False, lh_masks=None):
+        """
+        MAP ('MAP') or MPPA ('MPPA') selection on the device from the last marginals; lh_masks: optional 0/1 array
+        [n_cols, N, k] multiplied into the marginal likelihoods first.  The selected masks become the columns' masks.
+        Returns (masks [n_cols, N, k] int8, n_states [n_cols, N]).
+        """
+        W = (self.k + 63) // 64
+        words = np.empty((self.n_cols, self.n_nodes, W), dtype=np.uint64)
+        nsel = np.empty((self.n_cols, self.n_nodes), dtype=np.int32)
+        lm = None if lh_masks is None else pack_masks(np.asarray(lh_masks).reshape(self.n_cols, self.n_nodes, self.k),
+                                                      self.k)
+        _check(self._lib.pml_select_states(self._ctx, {'MAP': 0, 'MPPA': 1}[method], 1 if force_joint else 0,
+                                           None if lm is None else _ptr(lm, ctypes.c_uint64),
+                                           _ptr(words, ctypes.c_uint64), _ptr(nsel, ctypes.c_int32)))
+        return unpack_masks(words, self.k), nsel
 
     def download(self, what, col=0):
         N, k = self.n_nodes, self.k

@@ -293,6 +293,21 @@ class ForestProblem(object):
             e.err_parent, e.err_child = e.err_parent[first:first + 1], e.err_child[first:first + 1]
             self._raise_likelihood_error(e)
 
+    def select_on_device(self, method, force_joint=False):
+        """
+        MAP / MPPA selection (ml.py:505-595) by ``pml_select_states`` from the posteriors of the last marginal pass;
+        the marginal likelihoods of nodes with saved ('.initial') masks are restricted to them first.  The selected
+        masks become both the device's and this object's masks.  Returns the number of selected states per node.
+        """
+        lh_masks = None
+        if np.any(self.has_init):
+            lh_masks = np.ones((1, self.N, self.k), dtype=np.int8)
+            lh_masks[0, self.has_init] = self.init_masks[self.has_init]
+        sel, nsel = self.engine.select_states(method, force_joint=force_joint, lh_masks=lh_masks)
+        self.masks = sel[0]
+        self._uploaded_masks = self.masks.copy()
+        return nsel[0].astype(np.int64)
+
     def joint_states(self):
         """Joint state of every node after a joint sweep (ml.py:598-622)."""
         return self.engine.joint_backtrace()[0].astype(np.int64)
@@ -716,15 +731,16 @@ def ml_acr(forest, character, prediction_method, model, observed_frequencies, fo
                                                           columns=states)
             if len(altered):
                 problem.unalter_zero_node_allowed_states(altered)
-            # MAP (ml.py:577-595): likelihoods of nodes that were ever altered are masked by their saved masks
+            # MAP (ml.py:577-595): likelihoods of nodes that were ever altered are masked by their saved masks;
+            # the selection itself runs on the device and leaves the selected masks there for the restricted sweep
             lh[problem.has_init] *= problem.init_masks[problem.has_init]
-            problem.masks = select_map(lh)
+            problem.select_on_device('MAP')
             process_restricted_likelihood_and_states(MAP)
 
             if MPPA == prediction_method or is_meta_ml(prediction_method):
                 # the restricted-MAP sweep may have saved new masks (ml.py:541-542 after :675-680)
                 lh[problem.has_init] *= problem.init_masks[problem.has_init]
-                problem.masks, best_k = select_mppa(lh, joint_state if force_joint else None)
+                best_k = problem.select_on_device('MPPA', force_joint=force_joint)
                 num_nodes = model.forest_stats.num_nodes
                 num_scenarios = 1
                 for m in best_k[best_k > 1].tolist():

@@ -392,3 +392,41 @@ def test_single_launch_path_matches_level_path(k, monkeypatch):
     assert np.array_equal(out[0][1][:, nonroot], out[1][1][:, nonroot])
     np.testing.assert_allclose(out[0][1], out[1][1], rtol=1e-14, atol=0)   # roots: different butterfly shape
     assert np.array_equal(out[0][2], out[1][2])
+
+
+@pytest.mark.parametrize('kind,k', [('F81', 2), ('F81', 5), ('F81', 20), ('F81', 64), ('F81', 130), ('EIGEN', 20)])
+def test_device_state_selection_matches_host_rules(kind, k):
+    """pml_select_states (MAP / MPPA, with and without force_joint and '.initial' masks) == the host restatement."""
+    from pastml_amd import ml
+    rng = np.random.default_rng(7 + k)
+    flat = FlatForest.random(250, seed=3 * k, max_arity=3, n_trees=2)
+    C = 2
+    specs = [random_spec(kind, k, rng) for _ in range(C)]
+    rates = [(1.0, 0.0, 1.0), (2.5, 0.0, 1.0)]
+    masks = np.stack([random_masks(flat, k, rng, missing=0.3, multi=0.3) for _ in range(C)])
+    lh_masks = np.ones_like(masks)
+    pick = rng.random((C, flat.n_nodes)) < 0.1
+    lh_masks[pick] = masks[pick]   # pretend these nodes were altered: their saved masks restrict the likelihoods
+    with hip.Engine(flat, C, k) as eng:
+        eng.set_models(list(zip(specs, rates)))
+        eng.set_masks(masks)
+        eng.bottom_up(False)
+        js = eng.joint_backtrace()
+        eng.bottom_up(True)
+        post, lh_sum, _ = eng.top_down_marginals()
+        for method, fj, lm in (('MAP', False, None), ('MPPA', False, None), ('MPPA', True, None),
+                               ('MPPA', True, lh_masks), ('MAP', False, lh_masks)):
+            sel, nsel = eng.select_states(method, force_joint=fj, lh_masks=lm)
+            for c in range(C):
+                lh = post[c] * (1 if lm is None else lm[c])
+                if method == 'MAP':
+                    ref, ref_k = ml.select_map(lh), np.ones(flat.n_nodes, dtype=int)
+                else:
+                    ref, ref_k = ml.select_mppa(lh, js[c].astype(np.int64) if fj else None)
+                assert np.array_equal(sel[c], ref), (method, fj, lm is not None, c)
+                assert np.array_equal(nsel[c], ref_k)
+            # the selection became the columns' masks: the restricted sweep runs on it directly
+            lnl = eng.bottom_up(True)
+            eng.set_masks(sel)
+            np.testing.assert_array_equal(lnl, eng.bottom_up(True))
+            eng.set_masks(masks)
