@@ -34,6 +34,38 @@ MP_METHODS = {'DOWNPASS', 'ACCTRAN', 'DELTRAN', 'MP'}
 warnings.filterwarnings("ignore", append=True)
 
 
+def _serialize_acr(args):
+    """
+    Writes the parameter table (and, for marginal methods, the marginal-probability table) of one ACR result into
+    ``work_dir``, in the reference's format (pastml/acr.py:45-73): the parameter file can be fed back through
+    ``column2parameters`` (to PastML or to this package).
+    """
+    from pastml_amd import PASTML_VERSION
+    from pastml_amd.file import get_pastml_parameter_file, get_pastml_marginal_prob_file
+    from pastml_amd.ml import MODEL
+    acr_result, work_dir = args
+    out_param_file = os.path.join(work_dir, get_pastml_parameter_file(
+        method=acr_result[METHOD], model=acr_result[MODEL].name if MODEL in acr_result else None,
+        column=acr_result[CHARACTER]))
+    with open(out_param_file, 'w+') as f:
+        f.write('parameter\tvalue\n')
+        f.write('pastml_version\t{}\n'.format(PASTML_VERSION))
+        for name in sorted(acr_result.keys()):
+            if name not in [STATES, MARGINAL_PROBABILITIES, METHOD, MODEL]:
+                f.write('{}\t{}\n'.format(name, acr_result[name]))
+        f.write('{}\t{}\n'.format(METHOD, acr_result[METHOD]))
+        if is_ml(acr_result[METHOD]):
+            acr_result[MODEL].save_parameters(f)
+    logging.getLogger('pastml').debug('Serialized ACR parameters and statistics for {} to {}.'
+                                      .format(acr_result[CHARACTER], out_param_file))
+    if is_marginal(acr_result[METHOD]):
+        out_mp_file = os.path.join(work_dir, get_pastml_marginal_prob_file(
+            method=acr_result[METHOD], model=acr_result[MODEL].name, column=acr_result[CHARACTER]))
+        acr_result[MARGINAL_PROBABILITIES].to_csv(out_mp_file, sep='\t', index_label='node')
+        logging.getLogger('pastml').debug('Serialized marginal probabilities for {} to {}.'
+                                          .format(acr_result[CHARACTER], out_mp_file))
+
+
 def calculate_observed_freqs(character, forest, states):
     """
     Tip-state frequencies (a tip with several states contributes 1/n to each) and the fraction of tips without a

@@ -431,3 +431,35 @@ def test_batched_optimiser_reproduces_sequential_iterates(model, monkeypatch):
     assert np.array_equal(a[MODEL].frequencies, b[MODEL].frequencies)
     assert np.array_equal(a[MARGINAL_PROBABILITIES].values, b[MARGINAL_PROBABILITIES].values)
     assert a[RESTRICTED_LOG_LIKELIHOOD_FORMAT_STR.format(MPPA)] == b[RESTRICTED_LOG_LIKELIHOOD_FORMAT_STR.format(MPPA)]
+
+
+def test_serialised_tables_round_trip(tmp_path):
+    """
+    pastml/acr.py:45-73: parameter + marginal-probability tables in the reference's format; the parameter file fed back
+    through column2parameters reproduces the run without optimisation (as tests/CUSTOM_RATESTest.py does), and the
+    tables of the reference's stored Albania run (examples/Albania/data/pastml/MPPA/F81, v1.9.15) parse the same way.
+    """
+    from pastml_amd.acr import _serialize_acr
+    from pastml_amd.file import get_pastml_parameter_file, get_pastml_marginal_prob_file
+    tree, results = albania_result(F81)
+    res = results[0]
+    _serialize_acr((res, str(tmp_path)))
+    pfile = tmp_path / get_pastml_parameter_file(MPPA, F81, feature)
+    mfile = tmp_path / get_pastml_marginal_prob_file(MPPA, F81, feature)
+    assert pfile.name == 'params.character_Country.method_MPPA.model_F81.tab'
+    assert mfile.name == 'marginal_probabilities.character_Country.model_F81.tab'
+    params = pd.read_csv(pfile, sep='\t', index_col=0, header=0)['value']
+    assert float(params['log_likelihood']) == res[LOG_LIKELIHOOD]
+    assert float(params['scaling_factor']) == res[MODEL].sf
+    assert int(params['num_nodes']) == 305 and int(params['num_tips']) == 154
+    for s, f in zip(res[STATES], res[MODEL].frequencies):
+        assert float(params[s]) == f
+    mp = pd.read_csv(mfile, sep='\t', index_col=0, header=0)
+    assert mp.index.name == 'node' and list(mp.columns) == list(res[STATES])
+    np.testing.assert_allclose(mp.values, res[MARGINAL_PROBABILITIES].values, rtol=1e-11)  # pandas' fast float parser
+    again = acr(read_tree(TREE_NWK), albania_df(), prediction_method=MPPA, model=F81,
+                column2parameters={feature: str(pfile)})[0]
+    assert again[MODEL].get_num_params() == 0
+    np.testing.assert_allclose(again[LOG_LIKELIHOOD], res[LOG_LIKELIHOOD], rtol=1e-12)
+    np.testing.assert_allclose(again[MARGINAL_PROBABILITIES].values, res[MARGINAL_PROBABILITIES].values, rtol=1e-9,
+                               atol=1e-300)
