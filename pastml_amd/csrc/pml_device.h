@@ -1,9 +1,10 @@
 // Device-side helpers shared by the sweep kernels (gfx950, wave64).
 //
 // Work decomposition used everywhere: a *unit* is one (node, column) pair; it is processed by a group of G
-// consecutive lanes of one wavefront (G a power of two, 1..64), each lane owning R consecutive states
-// (state = g * R + r).  G * R >= k.  64 / G units share a wavefront; reductions over the states of a unit are
-// butterflies over the G lanes, so they are deterministic (fixed order) and never leave the wavefront.
+// consecutive lanes of one wavefront (G a power of two, 1..64), each lane owning R states (F81 kernels: two 16-byte
+// pairs per lane, see pml_kernels_f81.h; matrix kernels: state = g * R + r).  G * R >= k.  64 / G units share a
+// wavefront; reductions over the states of a unit are butterflies over the G lanes, so they are deterministic
+// (fixed order) and never leave the wavefront.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -14,8 +15,7 @@
 typedef unsigned long long u64;
 typedef long long i64;
 
-// lazy rescaling band: a vector is renormalised (max -> [1, 2)) when a non-zero entry leaves [2^-PML_BAND, 2^PML_BAND]
-#define PML_BAND 200
+// lazy rescaling band: a vector is renormalised (max -> [1, 2)) when a non-zero entry leaves [2^-200, 2^200]
 
 // lane exchange inside a 16-lane row by a DPP modifier (VALU only, no LDS crossbar)
 template <int CTRL>
