@@ -129,7 +129,8 @@ static void pick_group(int k, int& G, int& R) {
 
 static int grid_for(int n_units, int units_per_block, int C) {
     int blocks = (n_units + units_per_block - 1) / units_per_block;
-    int cap = 8192 / (C < 1 ? 1 : C);
+    static const int total_cap = getenv("PASTML_HIP_GRID_CAP") ? atoi(getenv("PASTML_HIP_GRID_CAP")) : 32768;
+    int cap = total_cap / (C < 1 ? 1 : C);
     if (cap < 8) cap = 8;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
@@ -875,6 +876,24 @@ static int run_prep(pml_ctx* ctx) {
         if (ctx->kind == PML_MODEL_HKY) {
             dim3 grid(grid_for(ctx->N, PML_BLOCK, ctx->C), ctx->C);
             hipLaunchKernelGGL(pij_hky_kernel, grid, dim3(PML_BLOCK), 0, ctx->stream, t, c, m, ctx->d_P);
+        } else if (ctx->k >= 16 && ctx->k <= 32 && !getenv("PASTML_HIP_NO_MFMA")) {
+            // FP64 matrix-core path (BASELINE config 3: JTT, k = 20)
+            const int k = ctx->k;
+            const int KS = (k + 3) / 4, NT = (k + 15) / 16;
+            const size_t lds = ((size_t)KS * 4 * k + (size_t)PML_WAVES_PER_BLOCK * PML_MFMA_CHUNK * KS * 4) * sizeof(double);
+            int blocks = (ctx->N + PML_WAVES_PER_BLOCK * PML_MFMA_CHUNK - 1) / (PML_WAVES_PER_BLOCK * PML_MFMA_CHUNK);
+            if (blocks > 4096) blocks = 4096;
+            dim3 grid(blocks, ctx->C);
+#define PML_MFMA_CASE(NT_, KS_)                                                                                  \
+    if (NT == NT_ && KS == KS_)                                                                                  \
+        hipLaunchKernelGGL((pij_eigen_mfma_kernel<NT_, KS_>), grid, dim3(PML_BLOCK), lds, ctx->stream, t, c, m, \
+                           ctx->d_P);
+            PML_MFMA_CASE(1, 4)
+            PML_MFMA_CASE(2, 5)
+            PML_MFMA_CASE(2, 6)
+            PML_MFMA_CASE(2, 7)
+            PML_MFMA_CASE(2, 8)
+#undef PML_MFMA_CASE
         } else {
             const int k = ctx->k;
             size_t lds = ((size_t)2 * k * (k + 1) + k) * sizeof(double);

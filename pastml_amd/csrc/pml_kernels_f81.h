@@ -173,6 +173,27 @@ __device__ __forceinline__ void node_load_vec(const LaneCtx<G, R>& L, const PmlC
     }
 }
 
+// streaming (non-temporal) variant for data that is written once and not re-read soon (posteriors)
+template <int G, int R>
+__device__ __forceinline__ void node_store_vec_nt(const LaneCtx<G, R>& L, const PmlCols& c, double* base, int n,
+                                                  const double (&v)[R]) {
+    typedef double dbl2 __attribute__((ext_vector_type(2)));
+    double* p = base + (unsigned)n * (unsigned)c.ks;
+    if (R == 1) {
+        if (L.st(0) < c.ks) __builtin_nontemporal_store(v[0], p + L.st(0));
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; r += 2) {
+            if (L.st(r) < c.ks) {
+                dbl2 t2;
+                t2.x = v[r];
+                t2.y = v[r + 1];
+                __builtin_nontemporal_store(t2, reinterpret_cast<dbl2*>(p + L.st(r)));
+            }
+        }
+    }
+}
+
 template <int G, int R>
 __device__ __forceinline__ void node_store_vec(const LaneCtx<G, R>& L, const PmlCols& c, double* base, int n,
                                                const double (&v)[R]) {
@@ -564,7 +585,7 @@ __device__ __forceinline__ void f81_finish_child(const LaneCtx<G, R>& L, const P
         const double q = lh[r] * inv;
         lh[r] = fma(fma(-lhs, q, lh[r]), inv, q);
     }
-    node_store_vec<G, R>(L, c, L.post, ch, lh);
+    node_store_vec_nt<G, R>(L, c, L.post, ch, lh);
     if (L.g == 0) {
         L.lhsum[ch] = __builtin_ldexp(lhs, -lex);
         L.lhe[ch] = xe + bec + lex;
@@ -608,7 +629,7 @@ __device__ __forceinline__ void f81_finish_tip_word(const LaneCtx<G, R>& L, cons
         double out[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) out[r] = ok ? ((L.st(r) == s) ? 1.0 : 0.0) : __builtin_nan("");
-        node_store_vec<G, R>(L, c, L.post, tip, out);
+        node_store_vec_nt<G, R>(L, c, L.post, tip, out);
         if (L.g == 0) {
             L.lhsum[tip] = __builtin_ldexp(lhs, -lex);
             L.lhe[tip] = pe + lex;
@@ -897,7 +918,7 @@ __device__ __forceinline__ void f81_root_unit(const LaneCtx<G, R>& L, const PmlT
 #pragma unroll
     for (int r = 0; r < R; ++r) lh[r] = lh[r] / lhs;
     node_store_vec<G, R>(L, c, L.td, n, one);
-    node_store_vec<G, R>(L, c, L.post, n, lh);
+    node_store_vec_nt<G, R>(L, c, L.post, n, lh);
     if (L.g == 0) {
         L.te[n] = 0;
         L.lhsum[n] = __builtin_ldexp(lhs, -lex);

@@ -138,3 +138,98 @@ pij_explicit_kernel(PmlCols c, PmlModel m, int col, int n_t, const double* __res
         out[e] = v;
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Eigen models, 16 <= k <= 32: the P(t) batch as a tall GEMM on the FP64 matrix cores (v_mfma_f64_16x16x4_f64).
+//
+//   Pt_b[j][i] = sum_m (Ainv[m][j] * exp(d_m t_b)) * A[i][m]
+//
+// Stacking the branches of a chunk along the rows gives  [rows (b, j)] x [k]  times  A^T [k] x [i]: the right factor is
+// shared by all branches (held in registers as B fragments), the left factor is formed on the fly from Ainv (LDS) and
+// the chunk's exp(d_m t_b) (LDS, computed once per branch and eigenvalue).  K = k rounded up to 4 (k = 20: exact),
+// N = k rounded up to 16; rows are processed 16 at a time.  The 16x16 result tile has the output state i along the
+// lanes, so the transposed store Pt[b][j][16 consecutive i] is one 128-byte segment per row.
+// Operand layouts (cdna_hip_programming.md section 3): A[l & 15][l >> 4], B[l >> 4][l & 15],
+// D: col = l & 15, row = (l >> 4) + 4 * reg.
+// ---------------------------------------------------------------------------------------------------------------------
+#define PML_MFMA_CHUNK 16  // branches per wave pass
+
+typedef double pml_v4f64 __attribute__((ext_vector_type(4)));
+
+template <int NT, int KS>
+__global__ void __launch_bounds__(PML_BLOCK)
+pij_eigen_mfma_kernel(PmlTree t, PmlCols c, PmlModel m, double* __restrict__ P) {
+    extern __shared__ double smem[];
+    const int k = c.k, ks = c.ks;
+    const int col = blockIdx.y;
+    const size_t colN = (size_t)col * t.N;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int lo = lane & 15, hi = lane >> 4;
+    constexpr int KP = KS * 4;
+    double* sB = smem;                                  // Ainv padded: [KP][k]   (rows >= k are zero)
+    double* sE = sB + KP * k + wave * PML_MFMA_CHUNK * KP;  // per wave: exp(d_m t_b)  [CHUNK][KP]
+    const double* gA = m.A + (size_t)col * k * k;
+    const double* gB = m.Ainv + (size_t)col * k * k;
+    const double* gd = m.d + (size_t)col * k;
+    for (int e = threadIdx.x; e < KP * k; e += blockDim.x) sB[e] = (e / k < k) ? gB[e] : 0.0;
+    // B fragments of A^T: bfrag[nt][s] = A^T[4s + hi][16nt + lo] = A[16nt + lo][4s + hi]
+    double bfrag[NT][KS];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int i = 16 * nt + lo, mm = 4 * s + hi;
+            bfrag[nt][s] = (i < k && mm < k) ? gA[i * k + mm] : 0.0;
+        }
+    __syncthreads();
+    const double sfc = m.sf[col], tau = m.tau[col], tf = m.tauf[col];
+    const int waves_total = gridDim.x * PML_WAVES_PER_BLOCK;
+    for (int b0 = (blockIdx.x * PML_WAVES_PER_BLOCK + wave) * PML_MFMA_CHUNK; b0 < t.N;
+         b0 += waves_total * PML_MFMA_CHUNK) {
+        const int nb = min(PML_MFMA_CHUNK, t.N - b0);
+        // exp(d_m t_b) for the chunk: CHUNK * KP values over 64 lanes
+        for (int e = lane; e < PML_MFMA_CHUNK * KP; e += 64) {
+            const int q = e / KP, mm = e % KP;
+            double v = 0.0;
+            if (q < nb && mm < k) v = exp(gd[mm] * ((t.dist[b0 + q] + tau) * tf * sfc));
+            sE[e] = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int rows = nb * k;
+        for (int r0 = 0; r0 < rows; r0 += 16) {
+            // A operand row of this lane: (branch q, state j)
+            const int ra = r0 + lo;
+            const bool va = ra < rows;
+            const int qa = va ? ra / k : 0, ja = va ? ra % k : 0;
+            pml_v4f64 acc[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = (pml_v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const int mm = 4 * s + hi;
+                const double a = va ? sB[mm * k + ja] * sE[qa * KP + mm] : 0.0;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bfrag[nt][s], acc[nt], 0, 0, 0);
+            }
+            // D: row = hi + 4 * reg, col = lo  ->  Pt[b0 + q][j][16nt + lo]
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int rr = r0 + hi + 4 * reg;
+                if (rr < rows) {
+                    const int q = rr / k, j = rr % k;
+                    double* out = P + ((colN + b0 + q) * (size_t)k + j) * ks;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const int i = 16 * nt + lo;
+                        if (i < ks) out[i] = acc[nt][reg];  // columns k..ks-1 are exact zeros (zero B fragments)
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
