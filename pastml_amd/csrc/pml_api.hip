@@ -122,6 +122,7 @@ static int upload(pml_ctx* ctx, T* dst, const T* src, size_t count) {
 
 static void pick_group(int k, int& G, int& R) {
     R = k <= 32 ? 1 : (k <= 128 ? 2 : 4);
+    if (k > 16 && k <= 32 && !getenv("PASTML_HIP_MATRIX_R1")) R = 4;  // 8 lanes per unit: 8 units per wavefront
     const int need = (k + R - 1) / R;
     G = 1;
     while (G < need) G <<= 1;
@@ -212,6 +213,7 @@ static int prof_end(pml_ctx* ctx, int which, long long launches) {
 // (G, R) dispatch
 // ---------------------------------------------------------------------------------------------------------------------
 #define PML_GR_CASES(X)  \
+    X(8, 4)              \
     X(1, 1)              \
     X(2, 1)              \
     X(4, 1)              \
