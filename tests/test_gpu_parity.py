@@ -430,3 +430,25 @@ def test_device_state_selection_matches_host_rules(kind, k):
             eng.set_masks(sel)
             np.testing.assert_array_equal(lnl, eng.bottom_up(True))
             eng.set_masks(masks)
+
+
+@pytest.mark.parametrize('k', [20, 40, 64])
+def test_wide_polytomies_vs_oracle(k):
+    """Arity up to 9: units with more children / tips per cherry than the lane-parallel gather holds take the
+    sequential path inside the same launch; both paths must agree with the oracle."""
+    rng = np.random.default_rng(k)
+    flat = FlatForest.random(200, seed=50 + k, max_arity=9)
+    spec = random_spec('F81', k, rng)
+    masks = random_masks(flat, k, rng, internal=0.0)
+    assert flat.n_children.max() > 4
+    with hip.Engine(flat, 1, k) as eng:
+        eng.set_models([(spec, (1.2, 0.0, 1.0))])
+        eng.set_masks(masks)
+        lnl = eng.bottom_up(True)
+        post, lh_sum, lh_sf = eng.top_down_marginals()
+        bu, bu_sf = eng.download(hip.BUF_BU), eng.download(hip.BUF_BU_SF)
+    r = orc.full_marginal_pass(flat, masks.astype(int), spec, 1.2)
+    np.testing.assert_allclose(lnl[0], r['loglik'], rtol=LNL_RTOL)
+    assert_same_scaled(bu, bu_sf, r['bu'], r['bu_sf'], what='BU')
+    np.testing.assert_allclose(post[0], r['posterior'], rtol=POST_RTOL, atol=1e-300)
+    np.testing.assert_allclose(np.log10(lh_sum[0]) - lh_sf[0], r['loglik'] / np.log(10), rtol=1e-11)
