@@ -1,0 +1,180 @@
+"""
+Closed-form model families: F81 / JC / EFT (one exponential per branch, pastml/models/F81Model.py, JCModel.py,
+EFTModel.py) and HKY85 (pastml/models/HKYModel.py).  The classes carry parameters, bounds and (de)serialisation; the
+per-branch arithmetic runs on the device (kernel_spec() describes the model to libpastml_hip).
+"""
+import logging
+
+import numpy as np
+
+from pastml_amd.models import Model, ModelWithFrequencies, KIND_F81, KIND_HKY
+
+
+F81 = 'F81'
+
+
+class F81Model(ModelWithFrequencies):
+    """
+    P_ij(t) = pi_j (1 - exp(-mu t')) + [i == j] exp(-mu t'),  mu = 1 / (1 - sum_i pi_i^2)
+    (reference: F81Model.py:18-46).  On the device P is never materialised for this family: the sweeps use
+    P v = (1 - e)(pi . v) 1 + e v with e = exp(-mu t') precomputed per branch.
+    """
+
+    def __init__(self, states, forest_stats, sf=None, frequencies=None, tau=0,
+                 frequency_smoothing=False, optimise_tau=False, parameter_file=None, reoptimise=False, **kwargs):
+        ModelWithFrequencies.__init__(self, states=states, forest_stats=forest_stats, sf=sf, tau=tau,
+                                      frequencies=frequencies, optimise_tau=optimise_tau,
+                                      frequency_smoothing=frequency_smoothing, reoptimise=reoptimise,
+                                      parameter_file=parameter_file, **kwargs)
+        self.name = F81
+
+    def get_mu(self):
+        """mu = 1 / (1 - sum_i pi_i^2), so that the expected rate -mu * trace(Pi Q) is one (F81Model.py:18-26)."""
+        return 1. / (1. - self.frequencies.dot(self.frequencies))
+
+    def kernel_spec(self):
+        pi = np.ascontiguousarray(self.frequencies, dtype=np.float64)
+        with np.errstate(divide='ignore'):
+            mu = np.float64(1.) / (np.float64(1.) - pi.dot(pi))
+        return dict(kind=KIND_F81, pi=pi, mu=float(mu))
+
+
+JC = 'JC'
+
+
+class JCModel(F81Model):
+
+    def __init__(self, states, forest_stats, sf=None, tau=0, optimise_tau=False, parameter_file=None,
+                 reoptimise=False, **kwargs):
+        kwargs['frequency_smoothing'] = False
+        F81Model.__init__(self, states=states, forest_stats=forest_stats, sf=sf, tau=tau, optimise_tau=optimise_tau,
+                          frequencies=np.ones(len(states), dtype=np.float64) / len(states),
+                          reoptimise=reoptimise, parameter_file=parameter_file, **kwargs)
+        self._optimise_frequencies = False
+        self.name = JC
+
+    def parse_parameters(self, params, reoptimise=False):
+        # only sf / tau can be preset: frequencies are equal by definition (JCModel.py:28-40)
+        return Model.parse_parameters(self, params, reoptimise)
+
+    def _print_parameters(self):
+        return '{}\tfrequencies\tall equal to {:g}\t(fixed)\n'.format(Model._print_parameters(self),
+                                                                    1 / len(self.states))
+
+
+EFT = 'EFT'
+
+
+class EFTModel(F81Model):
+
+    def __init__(self, states, forest_stats, observed_frequencies, sf=None, tau=0, optimise_tau=False,
+                 parameter_file=None, reoptimise=False, **kwargs):
+        F81Model.__init__(self, states=states, forest_stats=forest_stats, sf=sf, tau=tau,
+                          optimise_tau=optimise_tau, frequencies=observed_frequencies,
+                          reoptimise=reoptimise, parameter_file=parameter_file, **kwargs)
+        self._optimise_frequencies = False
+        self._frequency_smoothing = False
+        self.name = EFT
+
+    def parse_parameters(self, params, reoptimise=False):
+        # only sf / tau can be preset: frequencies are the observed ones (EFTModel.py:27-40)
+        return Model.parse_parameters(self, params, reoptimise)
+
+    def _print_parameters(self):
+        return '{}\tfrequencies:\tobserved in the tree\t(fixed)\n'.format(Model._print_parameters(self))
+
+
+HKY = 'HKY'
+HKY_STATES = np.array(['A', 'C', 'G', 'T'])
+A, C, G, T = 0, 1, 2, 3
+KAPPA = 'kappa'
+
+
+class HKYModel(ModelWithFrequencies):
+    """
+    Four states A, C, G, T; parameters: frequencies and the transition/transversion ratio kappa (bounds [1e-6, 20],
+    HKYModel.py:121-130).  The closed-form P(t) (HKYModel.py:44-82) is evaluated per branch by the HIP library.
+    """
+
+    def __init__(self, forest_stats, sf=None, frequencies=None, kappa=4, tau=0,
+                 frequency_smoothing=False, optimise_tau=False, parameter_file=None, reoptimise=False, **kwargs):
+        self._kappa = None
+        self._optimise_kappa = True
+        kwargs['states'] = HKY_STATES
+        ModelWithFrequencies.__init__(self, forest_stats=forest_stats, sf=sf, tau=tau, optimise_tau=optimise_tau,
+                                      frequencies=frequencies, frequency_smoothing=frequency_smoothing,
+                                      reoptimise=reoptimise, parameter_file=parameter_file, **kwargs)
+        if self._kappa is None:
+            self._kappa = kappa
+        self.name = HKY
+
+    @property
+    def kappa(self):
+        return self._kappa
+
+    @kappa.setter
+    def kappa(self, kappa):
+        if not self._optimise_kappa:
+            raise NotImplementedError('The kappa value is preset and cannot be changed.')
+        self._kappa = kappa
+
+    @Model.states.setter
+    def states(self, states):
+        raise NotImplementedError("The HKY model is only implemented for nucleotides: "
+                                  "the states are A, C, G, T and cannot be reset")
+
+    # ---- optimiser vector: [basic..., frequency params..., kappa] (HKYModel.py:84-130)
+    def get_num_params(self):
+        return ModelWithFrequencies.get_num_params(self) + (1 if self._optimise_kappa else 0)
+
+    def set_params_from_optimised(self, ps, **kwargs):
+        if self.extra_params_fixed():
+            Model.set_params_from_optimised(self, ps, **kwargs)
+            return
+        ModelWithFrequencies.set_params_from_optimised(self, ps, **kwargs)
+        if self._optimise_kappa:
+            self.kappa = ps[ModelWithFrequencies.get_num_params(self)]
+
+    def get_optimised_parameters(self):
+        if self.extra_params_fixed():
+            return Model.get_optimised_parameters(self)
+        return np.hstack((ModelWithFrequencies.get_optimised_parameters(self),
+                          [self.kappa] if self._optimise_kappa else []))
+
+    def get_bounds(self):
+        if self.extra_params_fixed():
+            return Model.get_bounds(self)
+        return np.array((*ModelWithFrequencies.get_bounds(self),
+                         *([np.array([1e-6, 20.])] if self._optimise_kappa else [])))
+
+    def parse_parameters(self, params, reoptimise=False):
+        params = ModelWithFrequencies.parse_parameters(self, params, reoptimise)
+        if KAPPA in params:
+            logger = logging.getLogger('pastml')
+            raw = params[KAPPA]
+            try:
+                value = np.float64(raw)
+                if value <= 0:
+                    logger.error('Kappa cannot be negative, ignoring the value given in paramaters ({}).'.format(raw))
+                else:
+                    self._kappa = value
+                    self._optimise_kappa = reoptimise
+            except (TypeError, ValueError):
+                logger.error('Kappa ({}) given in parameters is not float, ignoring it.'.format(raw))
+        return params
+
+    def _print_parameters(self):
+        return '{}\tkappa\t{:.6f}\t{}\n'.format(ModelWithFrequencies._print_parameters(self), self.kappa,
+                                              '(optimised)' if self._optimise_kappa else '(fixed)')
+
+    def freeze(self):
+        ModelWithFrequencies.freeze(self)
+        self._optimise_kappa = False
+
+    def save_parameters(self, filehandle):
+        ModelWithFrequencies.save_parameters(self, filehandle)
+        filehandle.write('{}\t{:g}\n'.format(KAPPA, self.kappa))
+
+    def kernel_spec(self):
+        return dict(kind=KIND_HKY, pi=np.ascontiguousarray(self.frequencies, dtype=np.float64),
+                    kappa=float(self.kappa))
