@@ -767,3 +767,84 @@ def ml_acr(forest, character, prediction_method, model, observed_frequencies, fo
         return results
     finally:
         problem.close()
+
+
+# =====================================================================================================================
+# marginal_counts
+# =====================================================================================================================
+
+def marginal_counts(forest, character, model, n_repetitions=1_000):
+    """
+    Expected numbers of state changes i -> j along the trees, estimated by drawing ``n_repetitions`` ancestral
+    scenarios from the marginal posterior (API and sampling scheme of pastml/ml.py:753-862, used by
+    utilities/transition_counter.py).
+
+    The likelihood part -- bottom-up and top-down sweeps, root posteriors, per-branch P(t) -- runs on the GPU; the
+    scenario sampling (multinomial draws of child states given the parent's state counts, ml.py:818-857) stays on the
+    host with numpy's global generator, as in the reference, so only statistical parity is meaningful.
+
+    :return: k x k array, entry [i, j] = average number of i -> j changes per scenario
+    """
+    if isinstance(forest, TreeNode):
+        forest = [forest]
+    problem = ForestProblem(forest, character, model.states)
+    try:
+        k = problem.k
+        flat = problem.flat
+        problem.initialize_allowed_states()
+        altered = problem.alter_zero_node_allowed_states() if 0 == model.tau else np.zeros(0, dtype=np.int64)
+        problem.bottom_up_loglikelihood(model, is_marginal=True, alter=False)
+        posterior, _, _ = problem.top_down_marginals()
+        bu = problem.engine.download(hip.BUF_BU)
+        P = problem.engine.pij_batch(copy_out=True)[0]
+        frequencies = np.asarray(model.frequencies, dtype=np.float64)
+        is_altered = np.zeros(problem.N, dtype=bool)
+        is_altered[altered] = True
+        masks = problem.masks
+        initial = problem.init_masks
+
+        def restrict_to_initial(counts, n):
+            """ml.py:806-812 / 840-846: counts of an altered node projected on its own (unaltered) states."""
+            c = counts * initial[n]
+            if np.count_nonzero(c):
+                return n_repetitions * c / c.sum()
+            return n_repetitions * initial[n] / initial[n].sum()
+
+        result = np.zeros((k, k), dtype=float)
+        state_counts = np.zeros((problem.N, k), dtype=np.int64)
+        for parent in range(problem.N):
+            if flat.parent[parent] < 0:
+                state_counts[parent] = np.random.multinomial(n_repetitions, posterior[parent] / posterior[parent].sum())
+            nc = flat.n_children[parent]
+            if nc == 0:
+                continue
+            parent_counts = state_counts[parent]
+            ps_counts_initial = restrict_to_initial(parent_counts, parent) if is_altered[parent] else parent_counts
+            same_state_counts = np.zeros(k)
+            fc = flat.first_child[parent]
+            for node in range(fc, fc + nc):
+                # p(child = b | parent = a)  ~  BU_node[b] * P[b, a] * pi_b * mask_b   (ml.py:819-824)
+                weights = (bu[node] * frequencies * masks[node])[None, :] * P[node].T
+                with np.errstate(divide='ignore', invalid='ignore'):  # rows of impossible parent states are unused
+                    probs = weights / weights.sum(axis=1)[:, None]
+                update_results = not is_altered[parent] and not is_altered[node]
+                counts = np.zeros(k, dtype=np.int64)
+                for j in np.flatnonzero(parent_counts):
+                    drawn = np.random.multinomial(parent_counts[j], probs[j])
+                    counts += drawn
+                    if update_results:
+                        result[j, :] += drawn
+                        same_state_counts[j] += drawn[j]
+                if not update_results:
+                    counts_initial = restrict_to_initial(counts, node) if is_altered[node] else counts
+                    norm_counts = counts_initial / counts_initial.sum()
+                    for i in np.flatnonzero(ps_counts_initial > 0):
+                        adjusted = norm_counts * ps_counts_initial[i]
+                        result[i, :] += adjusted
+                        same_state_counts[i] += adjusted[i]
+                state_counts[node] = counts
+            for i in range(k):
+                result[i, i] -= min(ps_counts_initial[i], same_state_counts[i])
+        return result / n_repetitions
+    finally:
+        problem.close()

@@ -602,6 +602,37 @@ def case_hiv1c():
 CASES = dict(hiv1c=case_hiv1c, data=copy_data, pij=case_pij, albania=case_albania, synthetic_small=case_synthetic_small,
              synthetic_large=case_synthetic_large, edge=case_edge, nucleotide=case_hky_nucleotide)
 
+
+
+def case_marginal_counts():
+    """pastml.ml.marginal_counts (ml.py:753-862) with many repetitions: expected transition counts, for statistical parity."""
+    out = {}
+    np.random.seed(12345)
+    # balanced 64-tip tree, JC k=4
+    flat = synthetic.balanced_forest(6)
+    roots = flat.to_tree_nodes()
+    fs = RForestStats(roots)
+    states, tips_states = annotate_synthetic(flat, roots, 'c', 4, 3)
+    model = RJC(states=states, forest_stats=fs, sf=2.0)
+    model.freeze()
+    out['jc_counts'] = rml.marginal_counts(roots, 'c', model, n_repetitions=40000)
+    out['jc_sf'] = 2.0
+    out['jc_tip_states'] = tips_states
+    # Albania, F81 at the optimum (zero branches -> altered nodes)
+    z = np.load(os.path.join(HERE, 'albania_F81.npz'))
+    tree, df = albania_inputs()
+    from pastml.annotation import preannotate_forest
+    preannotate_forest([tree], df=df)
+    model = RF81(states=z['opt_states'], forest_stats=RForestStats([tree]), sf=float(z['opt_sf']),
+                 frequencies=z['opt_frequencies'])
+    model.freeze()
+    out['albania_counts'] = rml.marginal_counts([tree], 'Country', model, n_repetitions=40000)
+    out['n_repetitions'] = 40000
+    save('marginal_counts', **out)
+
+
+CASES['marginal_counts'] = case_marginal_counts
+
 if __name__ == '__main__':
     np.random.seed(239)
     todo = sys.argv[1:] or list(CASES)

@@ -463,3 +463,40 @@ def test_serialised_tables_round_trip(tmp_path):
     np.testing.assert_allclose(again[LOG_LIKELIHOOD], res[LOG_LIKELIHOOD], rtol=1e-12)
     np.testing.assert_allclose(again[MARGINAL_PROBABILITIES].values, res[MARGINAL_PROBABILITIES].values, rtol=1e-9,
                                atol=1e-300)
+
+
+def test_marginal_counts_statistical_parity():
+    """
+    ml.marginal_counts against the reference's estimate (40 000 repetitions each): the two are independent Monte-Carlo
+    estimates of the same expectation, so they must agree within sampling noise (tests/MRANDJCTest.py compares to 2
+    decimals in the same spirit).
+    """
+    from pastml_amd import synthetic
+    z = load_golden('marginal_counts')
+    n_rep = int(z['n_repetitions'])
+    np.random.seed(7)
+    flat = synthetic.balanced_forest(6)
+    roots = flat.to_tree_nodes()
+    states = synthetic.state_names(4)
+    for j, t in enumerate(flat.tips):
+        flat.nodes[t].add_feature('c', {states[z['jc_tip_states'][j]]})
+    model = JCModel(states=states, forest_stats=ForestStats(roots), sf=float(z['jc_sf']))
+    model.freeze()
+    ours = ml.marginal_counts(roots, 'c', model, n_repetitions=n_rep)
+    ref = z['jc_counts']
+    # every entry is a mean of n_rep scenario counts; a generous bound on its standard error
+    tol = 6 * np.sqrt(np.maximum(ref, 0.05) / n_rep) * 3 + 0.02
+    assert np.all(np.abs(ours - ref) < tol), np.abs(ours - ref).max()
+    assert abs(ours.sum() - ref.sum()) < 0.3
+
+    zz = load_golden('albania_F81')
+    tree = read_tree(TREE_NWK)
+    from pastml_amd.annotation import preannotate_forest
+    preannotate_forest([tree], df=albania_df())
+    model = F81Model(states=zz['opt_states'], forest_stats=ForestStats([tree]), sf=float(zz['opt_sf']),
+                     frequencies=zz['opt_frequencies'])
+    model.freeze()
+    ours = ml.marginal_counts([tree], feature, model, n_repetitions=n_rep)
+    ref = z['albania_counts']
+    tol = 6 * np.sqrt(np.maximum(ref, 0.05) / n_rep) * 3 + 0.03
+    assert np.all(np.abs(ours - ref) < tol), (np.abs(ours - ref).max(), ours.round(3), ref.round(3))
