@@ -374,6 +374,7 @@ __device__ __forceinline__ bool bu_f81_unit_fast(const LaneCtx<G, R>& L, const P
             f81_cherry_from_lanes<G, R>(L, t, c, st, cl, tl, jx, ch, v, ce, true);
             esum += ce;
             s_child = pi_dot<G, R>(L, v);
+            if (L.g == 0) L.S[ch] = s_child;  // 8 bytes kept for the top-down sweep (saves its reduction there)
         }
         f81_absorb_child<G, R>(L, t, st, n, ch, e, s_child, v, acc, true);
         if ((jx & 1) == 1 || jx == nc - 1) esum += lazy_rescale<G, R>(acc);
@@ -423,6 +424,7 @@ __device__ __forceinline__ void bu_f81_unit(const LaneCtx<G, R>& L, const PmlTre
             f81_cherry_vector<G, R>(L, t, c, st, ch, v, ce, true);
             esum += ce;
             s_child = pi_dot<G, R>(L, v);
+            if (L.g == 0) L.S[ch] = s_child;
         }
         if (!JOINT) {
             f81_absorb_child<G, R>(L, t, st, n, ch, e, s_child, v, acc, true);
@@ -711,7 +713,7 @@ __device__ __forceinline__ bool td_f81_unit_fast(const LaneCtx<G, R>& L, const P
         } else {
             i64 bec;
             f81_cherry_from_lanes<G, R>(L, t, c, st, cl, tl, jx, ch, v, bec, false);
-            const double s_child = pi_dot<G, R>(L, v);
+            const double s_child = __shfl(cl.s, src, 64);  // pi . v, stored by the bottom-up sweep
             f81_finish_child<G, R, false>(L, c, prod, pe, ch, e, s_child, bec, v, mb, tdc, xe);
             double prod2[R];
 #pragma unroll
@@ -776,7 +778,7 @@ __device__ __forceinline__ void td_f81_unit(const LaneCtx<G, R>& L, const PmlTre
             // cherry: rebuild its bottom-up vector, finish it, then finish its tips from registers
             i64 bec;
             f81_cherry_vector<G, R>(L, t, c, st, ch, v, bec, false);
-            const double s_child = pi_dot<G, R>(L, v);
+            const double s_child = L.S[ch];  // pi . v, stored by the bottom-up sweep
             f81_finish_child<G, R, false>(L, c, prod, pe, ch, e, s_child, bec, v, mb, tdc, xe);
             double prod2[R];
 #pragma unroll
