@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <limits>
 #include <string>
 #include <vector>
@@ -90,6 +91,16 @@ struct pml_ctx {
     bool js_ever = false;  // joint states of some earlier joint sweep are still in d_js
     bool post_ever = false;  // posteriors of some earlier top-down sweep are still in d_post
     int* d_nsel = nullptr;
+    // hipGraph replay of the launch sequence of a sweep (level kernels are launch-bound on mid-size trees)
+    struct GraphSlot {
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        bool has_init = false;
+    };
+    GraphSlot bu_graph[2], td_graph;
+    bool graphs = true;
+    double* h_loglik = nullptr;  // pinned staging of the per-column results
+    u64* h_err = nullptr;
     bool td_valid = false, js_valid = false;
 };
 
@@ -108,7 +119,21 @@ static int dev_alloc(pml_ctx* ctx, T** p, size_t count) {
     return PML_OK;
 }
 
+static void drop_graph(pml_ctx::GraphSlot& g) {
+    if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    if (g.graph) (void)hipGraphDestroy(g.graph);
+    g.exec = nullptr;
+    g.graph = nullptr;
+}
+
 static void free_all(pml_ctx* ctx) {
+    drop_graph(ctx->bu_graph[0]);
+    drop_graph(ctx->bu_graph[1]);
+    drop_graph(ctx->td_graph);
+    if (ctx->h_loglik) (void)hipHostFree(ctx->h_loglik);
+    if (ctx->h_err) (void)hipHostFree(ctx->h_err);
+    ctx->h_loglik = nullptr;
+    ctx->h_err = nullptr;
     for (void* p : ctx->allocs) (void)hipFree(p);
     ctx->allocs.clear();
     ctx->held = 0;
@@ -665,6 +690,9 @@ int pml_chars_alloc(pml_ctx* ctx, int32_t n_cols, int32_t k) {
     PML_TRY(dev_alloc(ctx, &ctx->d_kappa, n_cols));
     PML_TRY(dev_alloc(ctx, &ctx->d_loglik, n_cols));
     PML_TRY(dev_alloc(ctx, &ctx->d_err, n_cols));
+    HIP_TRY(hipHostMalloc((void**)&ctx->h_loglik, sizeof(double) * n_cols));
+    HIP_TRY(hipHostMalloc((void**)&ctx->h_err, sizeof(u64) * n_cols));
+    ctx->graphs = !(getenv("PASTML_HIP_NO_GRAPH"));
     PML_TRY(dev_alloc(ctx, &ctx->d_bu, CN * ctx->ks));
     PML_TRY(dev_alloc(ctx, &ctx->d_S, CN));
     PML_TRY(dev_alloc(ctx, &ctx->d_be, CN));
@@ -861,13 +889,18 @@ static int require_model(pml_ctx* ctx) {
     return PML_OK;
 }
 
-static int run_prep(pml_ctx* ctx) {
-    if (!ctx->prep_dirty) return PML_OK;
+static int ensure_transition_storage(pml_ctx* ctx) {
+    if (ctx->kind != PML_MODEL_F81 && !ctx->d_P)
+        PML_TRY(dev_alloc(ctx, &ctx->d_P, (size_t)ctx->C * ctx->N * ctx->k * ctx->ks));
+    return PML_OK;
+}
+
+static int run_prep(pml_ctx* ctx, bool force = false) {
+    if (!ctx->prep_dirty && !force) return PML_OK;
     const PmlTree t = tree_of(ctx);
     const PmlCols c = cols_of(ctx);
     const PmlModel m = model_of(ctx);
-    if (ctx->kind != PML_MODEL_F81 && !ctx->d_P)
-        PML_TRY(dev_alloc(ctx, &ctx->d_P, (size_t)ctx->C * ctx->N * ctx->k * ctx->ks));
+    PML_TRY(ensure_transition_storage(ctx));
     PML_TRY(prof_begin(ctx));
     if (ctx->kind == PML_MODEL_F81) {
         dim3 grid(grid_for(ctx->N, PML_BLOCK, ctx->C), ctx->C);
@@ -988,25 +1021,16 @@ int pml_pij_batch(pml_ctx* ctx, double* P_out) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-int pml_bottom_up(pml_ctx* ctx, int is_marginal, double* loglik_out, int32_t* err_parent, int32_t* err_child) {
-    PML_TRY(require_model(ctx));
-    if (!loglik_out) return fail(PML_ERR_INVALID, "loglik_out is NULL");
-    const bool small_path = ctx->small && is_marginal && ctx->kind == PML_MODEL_F81;
-    if (!small_path) PML_TRY(run_prep(ctx));
-    const size_t CN = (size_t)ctx->C * ctx->N;
-    if (!is_marginal && !ctx->d_J) {
-        PML_TRY(dev_alloc(ctx, &ctx->d_J, CN * ctx->ks));
-        PML_TRY(dev_alloc(ctx, &ctx->d_js, CN));
-    }
-    ctx->bu_mode = -1;
-    ctx->td_valid = ctx->js_valid = false;
-    HIP_TRY(hipMemsetAsync(ctx->d_err, 0xFF, sizeof(u64) * ctx->C, ctx->stream));
+// Everything a bottom-up sweep puts on the stream, without host synchronisation (so that it can be captured).
+static int enqueue_bottom_up(pml_ctx* ctx, int is_marginal, bool small_path, bool force_prep) {
+    hipLaunchKernelGGL(reset_err_kernel, dim3((ctx->C + 63) / 64), dim3(64), 0, ctx->stream, ctx->d_err, ctx->C);
+    HIP_TRY(hipGetLastError());
+    if (!small_path) PML_TRY(run_prep(ctx, force_prep));
     PML_TRY(prof_begin(ctx));
     const bool fused = is_marginal && ctx->kind == PML_MODEL_F81;
     if (small_path) {
         // prep + every level + ln L in one launch
-        PML_TRY(dispatch_small_f81(ctx, true, ctx->prep_dirty ? 1 : 0));
-        ctx->prep_dirty = false;
+        PML_TRY(dispatch_small_f81(ctx, true, (ctx->prep_dirty || force_prep) ? 1 : 0));
         PML_TRY(prof_end(ctx, 0, 1));
     } else if (fused) {
         const int nl = (int)ctx->bu_offsets_f.size() - 1;
@@ -1022,16 +1046,69 @@ int pml_bottom_up(pml_ctx* ctx, int is_marginal, double* loglik_out, int32_t* er
         }
         PML_TRY(prof_end(ctx, 0, ctx->n_bu_levels));
     }
-    ctx->bu_fused = fused && ctx->n_cherries > 0;
     if (!small_path) {
         hipLaunchKernelGGL(loglik_kernel, dim3((ctx->C + PML_BLOCK - 1) / PML_BLOCK), dim3(PML_BLOCK), 0, ctx->stream,
                            tree_of(ctx), cols_of(ctx), state_of(ctx), ctx->C, is_marginal ? 1 : 0, ctx->d_loglik);
         HIP_TRY(hipGetLastError());
     }
-    std::vector<u64> err(ctx->C);
-    HIP_TRY(hipMemcpyAsync(loglik_out, ctx->d_loglik, sizeof(double) * ctx->C, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(err.data(), ctx->d_err, sizeof(u64) * ctx->C, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->h_loglik, ctx->d_loglik, sizeof(double) * ctx->C, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->h_err, ctx->d_err, sizeof(u64) * ctx->C, hipMemcpyDeviceToHost, ctx->stream));
+    return PML_OK;
+}
+
+// Captures fn's stream work once and replays it afterwards; falls back to direct submission if capture fails.
+static int run_captured(pml_ctx* ctx, pml_ctx::GraphSlot& slot, const std::function<int()>& enqueue) {
+    if (slot.exec && slot.has_init != ctx->has_init) drop_graph(slot);
+    if (!slot.exec) {
+        HIP_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+        const int status = enqueue();
+        hipGraph_t graph = nullptr;
+        const hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
+        if (status != PML_OK) {
+            if (graph) (void)hipGraphDestroy(graph);
+            return status;
+        }
+        if (e != hipSuccess || !graph) return fail(PML_ERR_HIP, "stream capture failed: %s", hipGetErrorString(e));
+        hipGraphExec_t exec = nullptr;
+        const hipError_t e2 = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        if (e2 != hipSuccess) {
+            (void)hipGraphDestroy(graph);
+            return fail(PML_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e2));
+        }
+        slot.graph = graph;
+        slot.exec = exec;
+        slot.has_init = ctx->has_init;
+    }
+    HIP_TRY(hipGraphLaunch(slot.exec, ctx->stream));
+    return PML_OK;
+}
+
+int pml_bottom_up(pml_ctx* ctx, int is_marginal, double* loglik_out, int32_t* err_parent, int32_t* err_child) {
+    PML_TRY(require_model(ctx));
+    if (!loglik_out) return fail(PML_ERR_INVALID, "loglik_out is NULL");
+    const bool small_path = ctx->small && is_marginal && ctx->kind == PML_MODEL_F81;
+    const size_t CN = (size_t)ctx->C * ctx->N;
+    if (!is_marginal && !ctx->d_J) {
+        PML_TRY(dev_alloc(ctx, &ctx->d_J, CN * ctx->ks));
+        PML_TRY(dev_alloc(ctx, &ctx->d_js, CN));
+    }
+    PML_TRY(ensure_transition_storage(ctx));
+    ctx->bu_mode = -1;
+    ctx->td_valid = ctx->js_valid = false;
+    // mid-size forests: the level launches are latency-bound, replay them as one hipGraph
+    const int n_launches = small_path ? 1 : (is_marginal && ctx->kind == PML_MODEL_F81 ? (int)ctx->bu_offsets_f.size() - 1
+                                                                                          : ctx->n_bu_levels);
+    if (ctx->graphs && !ctx->profile && n_launches >= 4) {
+        PML_TRY(run_captured(ctx, ctx->bu_graph[is_marginal ? 1 : 0],
+                             [&]() { return enqueue_bottom_up(ctx, is_marginal, small_path, true); }));
+    } else {
+        PML_TRY(enqueue_bottom_up(ctx, is_marginal, small_path, false));
+    }
+    ctx->prep_dirty = false;
+    ctx->bu_fused = is_marginal && ctx->kind == PML_MODEL_F81 && ctx->n_cherries > 0;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    memcpy(loglik_out, ctx->h_loglik, sizeof(double) * ctx->C);
+    const u64* err = ctx->h_err;
     int status = PML_OK;
     for (int c = 0; c < ctx->C; ++c) {
         int ep = -1, ec = -1;
@@ -1060,22 +1137,30 @@ int pml_top_down_marginals(pml_ctx* ctx, double* posterior_out, double* lh_sum_o
         PML_TRY(dev_alloc(ctx, &ctx->d_lhe, CN));
     }
     const bool td_small = ctx->small && ctx->kind == PML_MODEL_F81;
-    if (!td_small) PML_TRY(dispatch_sweep(ctx, SW_ROOTS, nullptr, ctx->n_roots));
-    PML_TRY(prof_begin(ctx));
-    long long n_launch = 0;
     const bool td_fused = ctx->kind == PML_MODEL_F81;
-    if (td_small) {
-        PML_TRY(dispatch_small_f81(ctx, false, 0));
-        n_launch = 1;
+    auto enqueue = [&]() -> int {
+        if (!td_small) PML_TRY(dispatch_sweep(ctx, SW_ROOTS, nullptr, ctx->n_roots));
+        PML_TRY(prof_begin(ctx));
+        long long n_launch = 0;
+        if (td_small) {
+            PML_TRY(dispatch_small_f81(ctx, false, 0));
+            n_launch = 1;
+        }
+        for (int l = 0; l < (td_small ? 0 : ctx->n_td_levels); ++l) {
+            const std::vector<int>& off = td_fused ? ctx->td_parent_offsets_f : ctx->td_parent_offsets;
+            const int a = off[l], b = off[l + 1];
+            PML_TRY(dispatch_sweep(ctx, td_fused ? SW_TD_FUSED : SW_TD,
+                                   (td_fused ? ctx->d_td_parents_f : ctx->d_td_parents) + a, b - a));
+            if (b > a) ++n_launch;
+        }
+        PML_TRY(prof_end(ctx, 1, n_launch));
+        return PML_OK;
+    };
+    if (ctx->graphs && !ctx->profile && !td_small && ctx->n_td_levels >= 4) {
+        PML_TRY(run_captured(ctx, ctx->td_graph, enqueue));
+    } else {
+        PML_TRY(enqueue());
     }
-    for (int l = 0; l < (td_small ? 0 : ctx->n_td_levels); ++l) {
-        const std::vector<int>& off = td_fused ? ctx->td_parent_offsets_f : ctx->td_parent_offsets;
-        const int a = off[l], b = off[l + 1];
-        PML_TRY(dispatch_sweep(ctx, td_fused ? SW_TD_FUSED : SW_TD,
-                               (td_fused ? ctx->d_td_parents_f : ctx->d_td_parents) + a, b - a));
-        if (b > a) ++n_launch;
-    }
-    PML_TRY(prof_end(ctx, 1, n_launch));
     ctx->td_valid = true;
     ctx->post_ever = true;
     if (posterior_out) {

@@ -235,3 +235,9 @@ select_states_kernel(int N, int k, int ks, int W, const double* __restrict__ pos
         __builtin_amdgcn_wave_barrier();
     }
 }
+
+// err[col] = all ones (a kernel rather than a memset node so that the sweep's launch sequence captures cleanly)
+__global__ void reset_err_kernel(u64* __restrict__ err, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) err[i] = ~0ull;
+}
