@@ -633,6 +633,62 @@ def case_marginal_counts():
 
 CASES['marginal_counts'] = case_marginal_counts
 
+
+def case_eigen_optimised():
+    """acr() with the eigen-decomposed models on the Albanian tree with seeded random tip states:
+    JTT (sf free) and CUSTOM_RATES with a random symmetric 5-state rate matrix (sf + frequencies free)."""
+    import time
+    out = {}
+    rng = np.random.default_rng(2024)
+    # JTT
+    tree, _ = albania_inputs()
+    tips = list(tree.iter_leaves())
+    jtt_states = rng.integers(0, 20, size=len(tips))
+    for tip, s in zip(tips, jtt_states):
+        tip.add_feature('aa', {JTT_STATES[s]})
+    t0 = time.time()
+    res = racr(tree, columns=['aa'], column2states={'aa': JTT_STATES}, prediction_method='MPPA', model='JTT',
+               threads=1)[0]
+    out['jtt_seconds'] = time.time() - t0
+    flat = our_tree.FlatForest.from_trees([tree])
+    names = [n.name for n in flat.nodes]
+    out['jtt_tip_states'] = jtt_states
+    out['jtt_tip_names'] = np.array([t.name for t in tips], dtype=str)
+    out['jtt_loglik'] = res['log_likelihood']
+    out['jtt_sf'] = float(res['model'].sf)
+    out['jtt_loglik_restricted_MPPA'] = res['log_likelihood_restricted_MPPA']
+    out['jtt_posterior'] = res['marginal_probabilities'].loc[names].values
+    out['jtt_num_unresolved_nodes'] = res['num_unresolved_nodes']
+    # CUSTOM_RATES, k = 5
+    k = 5
+    states = synthetic.state_names(k)
+    R = np.triu(rng.uniform(0.2, 3, size=(k, k)), 1)
+    R = R + R.T
+    rate_file = os.path.join(DATA, 'custom_rates_k5.txt')
+    from pastml.models.generator import save_matrix
+    save_matrix(states, R, rate_file)
+    tree, _ = albania_inputs()
+    tips = list(tree.iter_leaves())
+    cr_states = rng.choice(k, size=len(tips), p=[0.4, 0.25, 0.2, 0.1, 0.05])
+    for tip, s in zip(tips, cr_states):
+        tip.add_feature('cr', {states[s]})
+    t0 = time.time()
+    res = racr(tree, columns=['cr'], column2states={'cr': states}, prediction_method='MPPA', model='CUSTOM_RATES',
+               column2rates={'cr': rate_file}, threads=1)[0]
+    out['cr_seconds'] = time.time() - t0
+    out['cr_tip_states'] = cr_states
+    out['cr_rate_matrix'] = R
+    out['cr_states'] = np.array(states, dtype=str)
+    out['cr_loglik'] = res['log_likelihood']
+    out['cr_sf'] = float(res['model'].sf)
+    out['cr_frequencies'] = np.array(res['model'].frequencies)
+    out['cr_loglik_restricted_MPPA'] = res['log_likelihood_restricted_MPPA']
+    out['cr_posterior'] = res['marginal_probabilities'].loc[names].values
+    save('eigen_optimised', **out)
+
+
+CASES['eigen_optimised'] = case_eigen_optimised
+
 if __name__ == '__main__':
     np.random.seed(239)
     todo = sys.argv[1:] or list(CASES)

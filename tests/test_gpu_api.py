@@ -500,3 +500,35 @@ def test_marginal_counts_statistical_parity():
     ref = z['albania_counts']
     tol = 6 * np.sqrt(np.maximum(ref, 0.05) / n_rep) * 3 + 0.03
     assert np.all(np.abs(ours - ref) < tol), (np.abs(ours - ref).max(), ours.round(3), ref.round(3))
+
+
+def test_eigen_models_optimised_match_reference():
+    """
+    acr() with JTT (sf free) and CUSTOM_RATES (sf + 4 frequency ratios free, the model is re-diagonalised at every
+    optimiser point) against the reference's end-to-end run; random tip states drive sf to its upper bound, which
+    exercises the bound handling of the batched finite differences.
+    """
+    z = load_golden('eigen_optimised')
+    tree = read_tree(TREE_NWK)
+    tips = {t.name: t for t in tree}
+    for name, s in zip(z['jtt_tip_names'], z['jtt_tip_states']):
+        tips[str(name)].add_feature('aa', {JTT_STATES[s]})
+    res = acr(tree, columns=['aa'], column2states={'aa': JTT_STATES}, prediction_method=MPPA, model=JTT)[0]
+    np.testing.assert_allclose(res[LOG_LIKELIHOOD], z['jtt_loglik'], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(res[MODEL].sf, z['jtt_sf'], rtol=1e-6)
+    np.testing.assert_allclose(res[MARGINAL_PROBABILITIES].values, z['jtt_posterior'], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(res[RESTRICTED_LOG_LIKELIHOOD_FORMAT_STR.format(MPPA)],
+                               z['jtt_loglik_restricted_MPPA'], rtol=0, atol=1e-5)
+    assert res['num_unresolved_nodes'] == int(z['jtt_num_unresolved_nodes'])
+
+    tree = read_tree(TREE_NWK)
+    tips = {t.name: t for t in tree}
+    states = z['cr_states']
+    for name, s in zip(z['jtt_tip_names'], z['cr_tip_states']):
+        tips[str(name)].add_feature('cr', {states[s]})
+    res = acr(tree, columns=['cr'], column2states={'cr': states}, prediction_method=MPPA, model=CUSTOM_RATES,
+              column2rates={'cr': os.path.join(DATA, 'custom_rates_k5.txt')})[0]
+    np.testing.assert_array_equal(res[MODEL].rate_matrix, z['cr_rate_matrix'])
+    np.testing.assert_allclose(res[LOG_LIKELIHOOD], z['cr_loglik'], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(res[MODEL].frequencies, z['cr_frequencies'], atol=2e-4)
+    np.testing.assert_allclose(res[MARGINAL_PROBABILITIES].values, z['cr_posterior'], rtol=0, atol=5e-4)
