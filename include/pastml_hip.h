@@ -66,8 +66,12 @@ int pml_ctx_sync(pml_ctx* ctx);
  * Options (set before pml_tree_upload).  PML_OPT_CHERRY_FUSION (default 1): in the F81-family marginal sweeps,
  * internal nodes whose children are all tips are recomputed in registers instead of being stored in HBM; their
  * top-down vectors are then never materialised (pml_download(PML_BUF_TD) reports NaN for them, as for tips).
+ * PML_OPT_KEEP_TD (default 0, may be changed at any time): the F81-family top-down sweep works from the stored
+ * posteriors of the level above (TD o BU = posterior * sum / pi) and does not write the top-down vectors themselves;
+ * with this option it stores them too.  pml_download(PML_BUF_TD / PML_BUF_TD_SF) switches it on and repeats the sweep
+ * when they are missing.  The matrix models (HKY, eigen) always store them.
  */
-enum { PML_OPT_CHERRY_FUSION = 1 };
+enum { PML_OPT_CHERRY_FUSION = 1, PML_OPT_KEEP_TD = 2 };
 int pml_ctx_set_option(pml_ctx* ctx, int option, int value);
 /* bytes of device memory currently held by the ctx / free on its device */
 int pml_ctx_memory(pml_ctx* ctx, uint64_t* held, uint64_t* device_free);

@@ -102,6 +102,8 @@ struct pml_ctx {
     double* h_loglik = nullptr;  // pinned staging of the per-column results
     u64* h_err = nullptr;
     bool td_valid = false, js_valid = false;
+    bool keep_td = false;      // PML_OPT_KEEP_TD (or a pml_download of the TD vectors asked for them)
+    bool td_vec_valid = false; // the TD vectors of the last top-down sweep are in d_td
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -193,8 +195,10 @@ static PmlState state_of(const pml_ctx* c) {
     s.bu = c->d_bu;
     s.S = c->d_S;
     s.be = c->d_be;
-    s.td = c->d_td;
-    s.te = c->d_te;
+    // F81 family: the top-down sweep runs on the stored posteriors; TD vectors are written only on request
+    const bool td_stored = c->kind != PML_MODEL_F81 || c->keep_td;
+    s.td = td_stored ? c->d_td : nullptr;
+    s.te = td_stored ? c->d_te : nullptr;
     s.post = c->d_post;
     s.lhsum = c->d_lhsum;
     s.lhe = c->d_lhe;
@@ -252,7 +256,7 @@ static int prof_end(pml_ctx* ctx, int which, long long launches) {
 
 enum SweepKind { SW_BU_MARG, SW_BU_JOINT, SW_TD, SW_ROOTS, SW_BU_MARG_FUSED, SW_TD_FUSED };
 
-// matrix-model sweeps and the roots kernel: contiguous state ownership (state = g * R + r)
+// matrix-model sweeps: contiguous state ownership (state = g * R + r)
 template <int G, int R>
 static void launch_sweep(pml_ctx* ctx, SweepKind what, const int* level, int n_level) {
     const PmlTree t = tree_of(ctx, false);
@@ -300,6 +304,9 @@ static void launch_sweep_f81(pml_ctx* ctx, SweepKind what, const int* level, int
         case SW_TD_FUSED:
         case SW_TD:
             hipLaunchKernelGGL((td_f81_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, level, n_level);
+            break;
+        case SW_ROOTS:
+            hipLaunchKernelGGL((td_f81_roots_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st);
             break;
         default:
             break;
@@ -356,7 +363,7 @@ static int dispatch_small_f81(pml_ctx* ctx, bool bottom_up, int do_prep) {
 
 static int dispatch_sweep(pml_ctx* ctx, SweepKind what, const int* level, int n_level) {
     if (n_level <= 0) return PML_OK;
-    if (ctx->kind == PML_MODEL_F81 && what != SW_ROOTS) {
+    if (ctx->kind == PML_MODEL_F81) {
 #define X(G_, R_)                                                \
     if (ctx->Gf == G_ && ctx->Rf == R_) {                        \
         launch_sweep_f81<G_, R_>(ctx, what, level, n_level);     \
@@ -437,6 +444,11 @@ int pml_ctx_set_option(pml_ctx* ctx, int option, int value) {
     if (option == PML_OPT_CHERRY_FUSION) {
         if (ctx->N != 0) return fail(PML_ERR_INVALID, "PML_OPT_CHERRY_FUSION must be set before the tree is uploaded");
         ctx->fuse = value != 0;
+        return PML_OK;
+    }
+    if (option == PML_OPT_KEEP_TD) {
+        if ((value != 0) != ctx->keep_td) drop_graph(ctx->td_graph);
+        ctx->keep_td = value != 0;
         return PML_OK;
     }
     return fail(PML_ERR_INVALID, "unknown option %d", option);
@@ -1125,13 +1137,15 @@ int pml_bottom_up(pml_ctx* ctx, int is_marginal, double* loglik_out, int32_t* er
     return status;
 }
 
-int pml_top_down_marginals(pml_ctx* ctx, double* posterior_out, double* lh_sum_out, double* lh_sf_out) {
-    PML_TRY(require_model(ctx));
-    if (ctx->bu_mode != 1) return fail(PML_ERR_INVALID, "pml_top_down_marginals needs a successful marginal pml_bottom_up first");
+// the top-down launches (shared by pml_top_down_marginals and the lazy TD materialisation of pml_download)
+static int run_top_down(pml_ctx* ctx) {
     const size_t CN = (size_t)ctx->C * ctx->N;
-    if (!ctx->d_td) {
+    const bool td_stored = ctx->kind != PML_MODEL_F81 || ctx->keep_td;
+    if (td_stored && !ctx->d_td) {
         PML_TRY(dev_alloc(ctx, &ctx->d_td, CN * ctx->ks));
         PML_TRY(dev_alloc(ctx, &ctx->d_te, CN));
+    }
+    if (!ctx->d_post) {
         PML_TRY(dev_alloc(ctx, &ctx->d_post, CN * ctx->ks));
         PML_TRY(dev_alloc(ctx, &ctx->d_lhsum, CN));
         PML_TRY(dev_alloc(ctx, &ctx->d_lhe, CN));
@@ -1162,7 +1176,26 @@ int pml_top_down_marginals(pml_ctx* ctx, double* posterior_out, double* lh_sum_o
         PML_TRY(enqueue());
     }
     ctx->td_valid = true;
+    ctx->td_vec_valid = td_stored;
     ctx->post_ever = true;
+    return PML_OK;
+}
+
+// F81 family: the sweep did not write its TD vectors; repeat it with the stores switched on (same arithmetic)
+static int materialize_td(pml_ctx* ctx) {
+    if (ctx->td_vec_valid) return PML_OK;
+    drop_graph(ctx->td_graph);
+    ctx->keep_td = true;
+    PML_TRY(run_top_down(ctx));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PML_OK;
+}
+
+int pml_top_down_marginals(pml_ctx* ctx, double* posterior_out, double* lh_sum_out, double* lh_sf_out) {
+    PML_TRY(require_model(ctx));
+    if (ctx->bu_mode != 1) return fail(PML_ERR_INVALID, "pml_top_down_marginals needs a successful marginal pml_bottom_up first");
+    const size_t CN = (size_t)ctx->C * ctx->N;
+    PML_TRY(run_top_down(ctx));
     if (posterior_out) {
         if (ctx->ks == ctx->k) {
             HIP_TRY(hipMemcpyAsync(posterior_out, ctx->d_post, CN * ctx->k * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -1312,6 +1345,7 @@ int pml_download(pml_ctx* ctx, int what, int32_t col, void* out) {
         }
         case PML_BUF_TD: {
             if (!ctx->td_valid) return fail(PML_ERR_INVALID, "no valid top-down sweep");
+            PML_TRY(materialize_td(ctx));
             double* o = (double*)out;
             PML_TRY(fetch_vectors(ctx, ctx->d_td, col, o));
             const bool f81 = ctx->kind == PML_MODEL_F81;
@@ -1322,6 +1356,7 @@ int pml_download(pml_ctx* ctx, int what, int32_t col, void* out) {
         }
         case PML_BUF_TD_SF: {
             if (!ctx->td_valid) return fail(PML_ERR_INVALID, "no valid top-down sweep");
+            PML_TRY(materialize_td(ctx));
             PML_TRY(fetch_exponents(ctx, ctx->d_te, col, (double*)out));
             const bool f81 = ctx->kind == PML_MODEL_F81;
             for (size_t n = 0; n < N; ++n)

@@ -40,7 +40,7 @@ struct PmlState {
     double* bu;     // [C][N][ks]  bottom-up vectors (stored internal nodes only; tips are their masks)
     double* S;      // [C][N]      F81 marginal: pi . bu (tips and stored internal nodes)
     i64* be;        // [C][N]      base-2 exponent of bu, accumulated over the subtree
-    double* td;     // [C][N][ks]
+    double* td;     // [C][N][ks]  top-down vectors; F81 sweeps write them only when asked to (null otherwise)
     i64* te;        // [C][N]
     double* post;   // [C][N][ks]
     double* lhsum;  // [C][N]
@@ -94,6 +94,7 @@ template <int G, int R>
 struct LaneCtx {
     int col, g, group_base;
     double pi_r[R];
+    double ipi_r[R];  // 1 / pi (0 where pi = 0): turns a stored posterior back into TD o BU (top-down sweep)
     const u64* mask;
     const double* E;
     double* S;
@@ -126,7 +127,26 @@ __device__ __forceinline__ void lane_ctx_init(LaneCtx<G, R>& L, const PmlTree& t
     L.lhsum = st.lhsum + colN;
     L.lhe = st.lhe + colN;
 #pragma unroll
-    for (int r = 0; r < R; ++r) L.pi_r[r] = (L.st(r) < c.k) ? c.pi[(size_t)L.col * c.ks + L.st(r)] : 0.0;
+    for (int r = 0; r < R; ++r) {
+        L.pi_r[r] = (L.st(r) < c.k) ? c.pi[(size_t)L.col * c.ks + L.st(r)] : 0.0;
+        L.ipi_r[r] = L.pi_r[r] > 0.0 ? 1.0 / L.pi_r[r] : 0.0;
+    }
+}
+
+// prod = TD_p o BU_p of a finished node p, recovered from what the sweep already stored for it: the marginal
+// likelihoods are lh = TD o BU o pi o mask (ml.py:456-460) and the posterior is lh / sum(lh), so
+// TD o BU = posterior * sum(lh) / pi wherever mask and pi are non-zero; elsewhere BU (hence the product) is 0 or the
+// state has pi = 0 and cannot reach any output below p.  One 512-byte read instead of the BU and TD vectors, and the
+// TD vectors need not be written at all.  Exponent of the result: lhe[p].
+template <int G, int R>
+__device__ __forceinline__ void f81_parent_prod(const LaneCtx<G, R>& L, const PmlCols& c, int p, double (&prod)[R],
+                                                i64& pe) {
+    double po[R];
+    node_load_vec<G, R>(L, c, L.post, p, po);
+    const double ls = L.lhsum[p];
+    pe = L.lhe[p];
+#pragma unroll
+    for (int r = 0; r < R; ++r) prod[r] = po[r] * (ls * L.ipi_r[r]);
 }
 
 // 0/1 vector of the lane's states from a single mask word (k <= 64)
@@ -551,13 +571,14 @@ bu_f81_kernel(PmlTree t, PmlCols c, PmlState st, const int* __restrict__ level_n
 // f81_finish_child: given prod = TD_parent o BU_parent (exponent pe) and the child's own data, divides the child's
 // message out of the parent (ml.py:279-283), pushes the result through the child's branch (ml.py:287-289), forms the
 // marginal likelihoods pi o mask o BU o TD (ml.py:456-460) and stores the posteriors (ml.py:498-500).
-// NORMALISE: bring the child's TD vector back into the band (only needed when it is stored for the next level).
+// The parent's prod arrives normalised (f81_parent_prod), so the child's TD vector stays within the bottom-up band of
+// the child and needs no rescaling of its own.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int G, int R, bool NORMALISE>
+template <int G, int R>
 __device__ __forceinline__ void f81_finish_child(const LaneCtx<G, R>& L, const PmlCols& c, const double (&prod)[R],
                                                  i64 pe, int ch, double e, double s_child, i64 bec,
                                                  const double (&v)[R], const double (&mb)[R], double (&tdc)[R],
-                                                 i64& xe) {
+                                                 i64& xe, double (&lh)[R], double& lsum, i64& le) {
     const double a = (1.0 - e) * s_child;
     double x[R];
 #pragma unroll
@@ -570,8 +591,6 @@ __device__ __forceinline__ void f81_finish_child(const LaneCtx<G, R>& L, const P
     const double b = (1.0 - e) * pi_dot<G, R>(L, x);
 #pragma unroll
     for (int r = 0; r < R; ++r) tdc[r] = b + e * x[r];  // >= 0 by construction (ml.py:289's clamp is a no-op)
-    if (NORMALISE) xe += lazy_rescale<G, R>(tdc);
-    double lh[R];
     double lhs = 0.0;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -588,9 +607,11 @@ __device__ __forceinline__ void f81_finish_child(const LaneCtx<G, R>& L, const P
         lh[r] = fma(fma(-lhs, q, lh[r]), inv, q);
     }
     node_store_vec_nt<G, R>(L, c, L.post, ch, lh);
+    lsum = __builtin_ldexp(lhs, -lex);
+    le = xe + bec + lex;
     if (L.g == 0) {
-        L.lhsum[ch] = __builtin_ldexp(lhs, -lex);
-        L.lhe[ch] = xe + bec + lex;
+        L.lhsum[ch] = lsum;
+        L.lhe[ch] = le;
     }
 }
 
@@ -637,10 +658,10 @@ __device__ __forceinline__ void f81_finish_tip_word(const LaneCtx<G, R>& L, cons
             L.lhe[tip] = pe + lex;
         }
     } else {
-        double mt[R], tdt[R];
+        double mt[R], tdt[R], pt[R], lt;
         word_to_vec<G, R>(L, c, word, mt);
-        i64 xt;
-        f81_finish_child<G, R, false>(L, c, prod, pe, tip, e, pis, 0, mt, mt, tdt, xt);
+        i64 xt, et;
+        f81_finish_child<G, R>(L, c, prod, pe, tip, e, pis, 0, mt, mt, tdt, xt, pt, lt, et);
     }
 }
 
@@ -658,10 +679,10 @@ __device__ __forceinline__ void f81_finish_tip(const LaneCtx<G, R>& L, const Pml
         f81_finish_tip_word<G, R>(L, c, prod, pe, P, have_P, tip, L.mask[(unsigned)tip], e, pis);
     } else {
         // k > 64: general path (the closed form above would need the state's word; not worth a special case)
-        double mt[R], tdt[R];
+        double mt[R], tdt[R], pt[R], lt;
         node_mask_vec<G, R>(L, c, tip, mt);
-        i64 xt;
-        f81_finish_child<G, R, false>(L, c, prod, pe, tip, e, pis, 0, mt, mt, tdt, xt);
+        i64 xt, et;
+        f81_finish_child<G, R>(L, c, prod, pe, tip, e, pis, 0, mt, mt, tdt, xt, pt, lt, et);
     }
 }
 
@@ -672,18 +693,14 @@ __device__ __forceinline__ bool td_f81_unit_fast(const LaneCtx<G, R>& L, const P
     const int fc = t.first_child[p];
     const int nc = t.n_children[p];
     if (nc > Gather<G>::CH) return false;
-    double bp[R], tp[R];
-    node_load_vec<G, R>(L, c, L.bu, p, bp);
-    node_load_vec<G, R>(L, c, L.td, p, tp);
-    const i64 pe = L.te[p] + L.be[p];
+    double prod[R];
+    i64 pe;
+    f81_parent_prod<G, R>(L, c, p, prod, pe);
     ChildLane cl;
     TipLane tl;
     if (!f81_gather<G, R>(L, t, fc, nc, cl, tl)) return false;
     double vn[R];
     if (__shfl(cl.kind, L.group_base, 64) == PML_KIND_STORED) node_load_vec<G, R>(L, c, L.bu, fc, vn);
-    double prod[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) prod[r] = tp[r] * bp[r];
     double P = 0.0;
     bool have_P = false;
     for (int jx = 0; jx < nc; ++jx) {
@@ -702,23 +719,26 @@ __device__ __forceinline__ bool td_f81_unit_fast(const LaneCtx<G, R>& L, const P
             f81_finish_tip_word<G, R>(L, c, prod, pe, P, have_P, ch, word, e, __shfl(cl.s, src, 64));
             continue;
         }
-        double mb[R], tdc[R];
+        double mb[R], tdc[R], po[R], ls;
         word_to_vec<G, R>(L, c, word, mb);
-        i64 xe;
+        i64 xe, le;
         if (kd == PML_KIND_STORED) {
-            f81_finish_child<G, R, true>(L, c, prod, pe, ch, e, __shfl(cl.s, src, 64), __shfl(cl.be, src, 64), v, mb,
-                                         tdc, xe);
-            node_store_vec<G, R>(L, c, L.td, ch, tdc);
-            if (L.g == 0) L.te[ch] = xe;
+            f81_finish_child<G, R>(L, c, prod, pe, ch, e, __shfl(cl.s, src, 64), __shfl(cl.be, src, 64), v, mb, tdc, xe,
+                                   po, ls, le);
+            if (st.td != nullptr) {
+                node_store_vec<G, R>(L, c, L.td, ch, tdc);
+                if (L.g == 0) L.te[ch] = xe;
+            }
         } else {
             i64 bec;
             f81_cherry_from_lanes<G, R>(L, t, c, st, cl, tl, jx, ch, v, bec, false);
             const double s_child = __shfl(cl.s, src, 64);  // pi . v, stored by the bottom-up sweep
-            f81_finish_child<G, R, false>(L, c, prod, pe, ch, e, s_child, bec, v, mb, tdc, xe);
+            f81_finish_child<G, R>(L, c, prod, pe, ch, e, s_child, bec, v, mb, tdc, xe, po, ls, le);
+            // same rounding as f81_parent_prod, so that the schedule without cherry fusion gives the same bits
             double prod2[R];
 #pragma unroll
-            for (int r = 0; r < R; ++r) prod2[r] = tdc[r] * v[r];
-            const i64 pe2 = xe + bec;
+            for (int r = 0; r < R; ++r) prod2[r] = po[r] * (ls * L.ipi_r[r]);
+            const i64 pe2 = le;
             double P2 = 0.0;
             bool have_P2 = false;
             const int cfc = __shfl(cl.fc, src, 64);
@@ -746,14 +766,8 @@ __device__ __forceinline__ void td_f81_unit(const LaneCtx<G, R>& L, const PmlTre
     }
 
     double prod[R];
-    {
-        double bp[R], tp[R];
-        node_load_vec<G, R>(L, c, L.bu, p, bp);
-        node_load_vec<G, R>(L, c, L.td, p, tp);
-#pragma unroll
-        for (int r = 0; r < R; ++r) prod[r] = tp[r] * bp[r];
-    }
-    const i64 pe = L.te[p] + L.be[p];
+    i64 pe;
+    f81_parent_prod<G, R>(L, c, p, prod, pe);
     double P = 0.0;
     bool have_P = false;
     const int fc = t.first_child[p];
@@ -766,24 +780,26 @@ __device__ __forceinline__ void td_f81_unit(const LaneCtx<G, R>& L, const PmlTre
             continue;
         }
         const double e = L.E[ch];
-        double mb[R], v[R], tdc[R];
+        double mb[R], v[R], tdc[R], po[R], ls;
         node_mask_vec<G, R>(L, c, ch, mb);
-        i64 xe;
+        i64 xe, le;
         if (kd == PML_KIND_STORED) {
             node_load_vec<G, R>(L, c, L.bu, ch, v);
-            f81_finish_child<G, R, true>(L, c, prod, pe, ch, e, L.S[ch], L.be[ch], v, mb, tdc, xe);
-            node_store_vec<G, R>(L, c, L.td, ch, tdc);
-            if (L.g == 0) L.te[ch] = xe;
+            f81_finish_child<G, R>(L, c, prod, pe, ch, e, L.S[ch], L.be[ch], v, mb, tdc, xe, po, ls, le);
+            if (st.td != nullptr) {
+                node_store_vec<G, R>(L, c, L.td, ch, tdc);
+                if (L.g == 0) L.te[ch] = xe;
+            }
         } else {
             // cherry: rebuild its bottom-up vector, finish it, then finish its tips from registers
             i64 bec;
             f81_cherry_vector<G, R>(L, t, c, st, ch, v, bec, false);
             const double s_child = L.S[ch];  // pi . v, stored by the bottom-up sweep
-            f81_finish_child<G, R, false>(L, c, prod, pe, ch, e, s_child, bec, v, mb, tdc, xe);
+            f81_finish_child<G, R>(L, c, prod, pe, ch, e, s_child, bec, v, mb, tdc, xe, po, ls, le);
             double prod2[R];
 #pragma unroll
-            for (int r = 0; r < R; ++r) prod2[r] = tdc[r] * v[r];
-            const i64 pe2 = xe + bec;
+            for (int r = 0; r < R; ++r) prod2[r] = po[r] * (ls * L.ipi_r[r]);
+            const i64 pe2 = le;
             double P2 = 0.0;
             bool have_P2 = false;
             const int fc2 = t.first_child[ch];
@@ -898,7 +914,8 @@ bu_f81_small_kernel(PmlTree t, PmlCols c, PmlState st, const double* __restrict_
 
 // root of a tree: TD = 1 with exponent 0 (ml.py:274-277), marginal likelihoods BU * pi * mask
 template <int G, int R>
-__device__ __forceinline__ void f81_root_unit(const LaneCtx<G, R>& L, const PmlTree& t, const PmlCols& c, int n) {
+__device__ __forceinline__ void f81_root_unit(const LaneCtx<G, R>& L, const PmlTree& t, const PmlCols& c,
+                                              const PmlState& st, int n) {
     const bool tip = t.n_children[n] == 0;
     double mb[R], v[R], one[R], lh[R];
     node_mask_vec<G, R>(L, c, n, mb);
@@ -919,12 +936,28 @@ __device__ __forceinline__ void f81_root_unit(const LaneCtx<G, R>& L, const PmlT
     const int lex = (lhs > 0.0 && !isinf(lhs)) ? exponent_of(lhs) : 0;
 #pragma unroll
     for (int r = 0; r < R; ++r) lh[r] = lh[r] / lhs;
-    node_store_vec<G, R>(L, c, L.td, n, one);
+    if (st.td != nullptr) node_store_vec<G, R>(L, c, L.td, n, one);
     node_store_vec_nt<G, R>(L, c, L.post, n, lh);
     if (L.g == 0) {
-        L.te[n] = 0;
+        if (st.td != nullptr) L.te[n] = 0;
         L.lhsum[n] = __builtin_ldexp(lhs, -lex);
         L.lhe[n] = (tip ? 0 : L.be[n]) + lex;
+    }
+}
+
+// roots of the level-per-launch schedule (same unit function as the single-launch kernel: same bits)
+template <int G, int R>
+__global__ void __launch_bounds__(PML_BLOCK)
+td_f81_roots_kernel(PmlTree t, PmlCols c, PmlState st) {
+    constexpr int UW = 64 / G;
+    const int wave = threadIdx.x >> 6;
+    const int sub = (threadIdx.x & 63) / G;
+    LaneCtx<G, R> L;
+    lane_ctx_init<G, R>(L, t, c, st);
+    const int stride = gridDim.x * PML_WAVES_PER_BLOCK * UW;
+    for (int base = (blockIdx.x * PML_WAVES_PER_BLOCK + wave) * UW; base < t.n_roots; base += stride) {
+        const int idx = base + sub;
+        if (idx < t.n_roots) f81_root_unit<G, R>(L, t, c, st, idx);
     }
 }
 
@@ -940,7 +973,7 @@ td_f81_small_kernel(PmlTree t, PmlCols c, PmlState st, const int* __restrict__ l
     lane_ctx_init<G, R>(L, t, c, st);
     for (int base = wave * UW; base < t.n_roots; base += n_waves * UW) {
         const int idx = base + sub;
-        if (idx < t.n_roots) f81_root_unit<G, R>(L, t, c, idx);
+        if (idx < t.n_roots) f81_root_unit<G, R>(L, t, c, st, idx);
     }
     __syncthreads();
     for (int l = 0; l < n_levels; ++l) {

@@ -69,11 +69,11 @@ td_roots_kernel(PmlTree t, PmlCols c, PmlState st) {
 #pragma unroll
         for (int r = 0; r < R; ++r) lh[r] = lh[r] / lhs;
         if (lane_valid) {
-            store_vec<R>(st.td + (colN + n) * c.ks + s0, one);
+            if (st.td != nullptr) store_vec<R>(st.td + (colN + n) * c.ks + s0, one);
             store_vec<R>(st.post + (colN + n) * c.ks + s0, lh);
         }
         if (g == 0) {
-            st.te[colN + n] = 0;
+            if (st.td != nullptr) st.te[colN + n] = 0;
             st.lhsum[colN + n] = __builtin_ldexp(lhs, -lex);
             st.lhe[colN + n] = (tip ? 0 : st.be[colN + n]) + lex;
         }

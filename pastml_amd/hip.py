@@ -22,6 +22,7 @@ BUF_BU, BUF_BU_SF, BUF_TD, BUF_TD_SF, BUF_POSTERIOR, BUF_LH_SUM, BUF_LH_SF, BUF_
 
 MAX_STATES = 256
 OPT_CHERRY_FUSION = 1
+OPT_KEEP_TD = 2
 
 
 class HipUnavailableError(RuntimeError):
@@ -166,7 +167,7 @@ class Engine(object):
     >>> post, lh_sum, lh_sf = eng.top_down_marginals()
     """
 
-    def __init__(self, flat, n_cols, k, device=None, cherry_fusion=True):
+    def __init__(self, flat, n_cols, k, device=None, cherry_fusion=True, keep_td=False):
         lib = load_library()
         if device_count() < 1:
             raise HipUnavailableError('no HIP device visible: the likelihood path needs an MI355X (gfx950)')
@@ -176,6 +177,8 @@ class Engine(object):
         _check(lib.pml_ctx_create(self.device, ctypes.byref(self._ctx)))
         if not cherry_fusion:
             _check(lib.pml_ctx_set_option(self._ctx, OPT_CHERRY_FUSION, 0))
+        if keep_td:
+            _check(lib.pml_ctx_set_option(self._ctx, OPT_KEEP_TD, 1))
         self.flat = flat
         self.n_nodes = flat.n_nodes
         self.n_cols = n_cols
