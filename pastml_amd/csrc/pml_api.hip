@@ -64,6 +64,8 @@ struct pml_ctx {
     unsigned char* d_kind = nullptr;
     std::vector<unsigned char> h_kind;
     int *d_bu_order_f = nullptr, *d_td_parents_f = nullptr, *d_cherries = nullptr;
+    // unit descriptors of the F81 kernels, parallel to d_bu_order_f / d_td_parents_f / d_bu_order
+    PmlUnit *d_bu_units_f = nullptr, *d_td_units_f = nullptr, *d_bu_units = nullptr, *d_cherry_units = nullptr;
     int *d_bu_offsets_f = nullptr, *d_td_parent_offsets_f = nullptr;  // level tables for the single-launch kernels
     bool small = false;  // forest small enough for the one-launch-per-sweep kernels
     std::vector<int> bu_offsets_f, td_parent_offsets_f;
@@ -254,7 +256,7 @@ static int prof_end(pml_ctx* ctx, int which, long long launches) {
     X(64, 2)             \
     X(64, 4)
 
-enum SweepKind { SW_BU_MARG, SW_BU_JOINT, SW_TD, SW_ROOTS, SW_BU_MARG_FUSED, SW_TD_FUSED };
+enum SweepKind { SW_BU_MARG, SW_BU_JOINT, SW_TD, SW_ROOTS, SW_BU_MARG_FUSED, SW_TD_FUSED, SW_BU_CHERRIES };
 
 // matrix-model sweeps: contiguous state ownership (state = g * R + r)
 template <int G, int R>
@@ -293,17 +295,23 @@ static void launch_sweep_f81(pml_ctx* ctx, SweepKind what, const int* level, int
     const PmlState st = state_of(ctx);
     const int upb = PML_WAVES_PER_BLOCK * (64 / G);
     dim3 grid(grid_for(n_level, upb, ctx->C), ctx->C), block(PML_BLOCK);
+    // the level is given as a position in one of the node lists; the kernels read the descriptor list parallel to it
+    const PmlUnit* units = nullptr;
+    if (what == SW_BU_MARG_FUSED) units = ctx->d_bu_units_f + (level - ctx->d_bu_order_f);
+    if (what == SW_BU_MARG || what == SW_BU_JOINT) units = ctx->d_bu_units + (level - ctx->d_bu_order);
+    if (what == SW_TD_FUSED) units = ctx->d_td_units_f + (level - ctx->d_td_parents_f);
+    if (what == SW_BU_CHERRIES) units = ctx->d_cherry_units + (level - ctx->d_cherries);
     switch (what) {
         case SW_BU_MARG_FUSED:
         case SW_BU_MARG:
-            hipLaunchKernelGGL((bu_f81_kernel<G, R, false>), grid, block, 0, ctx->stream, t, c, st, level, n_level);
+        case SW_BU_CHERRIES:
+            hipLaunchKernelGGL((bu_f81_kernel<G, R, false>), grid, block, 0, ctx->stream, t, c, st, units, n_level);
             break;
         case SW_BU_JOINT:
-            hipLaunchKernelGGL((bu_f81_kernel<G, R, true>), grid, block, 0, ctx->stream, t, c, st, level, n_level);
+            hipLaunchKernelGGL((bu_f81_kernel<G, R, true>), grid, block, 0, ctx->stream, t, c, st, units, n_level);
             break;
         case SW_TD_FUSED:
-        case SW_TD:
-            hipLaunchKernelGGL((td_f81_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, level, n_level);
+            hipLaunchKernelGGL((td_f81_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, units, n_level);
             break;
         case SW_ROOTS:
             hipLaunchKernelGGL((td_f81_roots_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st);
@@ -321,10 +329,10 @@ static void launch_small_f81(pml_ctx* ctx, bool bottom_up, int do_prep) {
     dim3 grid(1, ctx->C), block(PML_SMALL_BLOCK);
     if (bottom_up)
         hipLaunchKernelGGL((bu_f81_small_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, ctx->d_mu, ctx->d_sf,
-                           ctx->d_tau, ctx->d_tauf, do_prep, ctx->d_bu_order_f, ctx->d_bu_offsets_f,
+                           ctx->d_tau, ctx->d_tauf, do_prep, ctx->d_bu_units_f, ctx->d_bu_offsets_f,
                            (int)ctx->bu_offsets_f.size() - 1, ctx->d_loglik);
     else
-        hipLaunchKernelGGL((td_f81_small_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, ctx->d_td_parents_f,
+        hipLaunchKernelGGL((td_f81_small_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, ctx->d_td_units_f,
                            ctx->d_td_parent_offsets_f, ctx->n_td_levels);
 }
 
@@ -364,6 +372,7 @@ static int dispatch_small_f81(pml_ctx* ctx, bool bottom_up, int do_prep) {
 static int dispatch_sweep(pml_ctx* ctx, SweepKind what, const int* level, int n_level) {
     if (n_level <= 0) return PML_OK;
     if (ctx->kind == PML_MODEL_F81) {
+        if (what == SW_TD) return fail(PML_ERR_INVALID, "the F81 kernels walk descriptor lists: SW_TD has none");
 #define X(G_, R_)                                                \
     if (ctx->Gf == G_ && ctx->Rf == R_) {                        \
         launch_sweep_f81<G_, R_>(ctx, what, level, n_level);     \
@@ -635,6 +644,57 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
             ctx->td_parent_offsets_f[l + 1] = (int)tdp.size();
         }
         ctx->n_cherries = (int)cherries.size();
+        {
+            // unit descriptors (PmlUnit, pml_kernels_f81.h) for the three node lists the F81 kernels walk
+            auto describe = [&](const int* list, int count, bool use_kind, std::vector<PmlUnit>& out) {
+                out.resize(count > 0 ? count : 1);
+                for (int q = 0; q < count; ++q) {
+                    const int n = list[q];
+                    PmlUnit u;
+                    u.n = n;
+                    u.fc = first_child[n];
+                    u.pad = 0;
+                    const int nc = n_children[n];
+                    int packed = nc < 15 ? nc : 15;
+                    bool cherries_ok = true;
+                    for (int j = 0; j < 4; ++j) {
+                        u.cfc[j] = 0;
+                        if (j >= nc) continue;
+                        const int ch = u.fc + j;
+                        u.cfc[j] = first_child[ch];
+                        const int kd = use_kind ? (int)kind[ch] : (n_children[ch] == 0 ? PML_KIND_TIP : PML_KIND_STORED);
+                        int code = kd == PML_KIND_TIP ? 0 : 1;
+                        if (kd == PML_KIND_CHERRY) {
+                            if (n_children[ch] > 4) {
+                                cherries_ok = false;
+                                code = 2;
+                            } else {
+                                code = 1 + n_children[ch];
+                            }
+                        }
+                        packed |= code << (8 + 3 * j);
+                    }
+                    if (cherries_ok) packed |= 1 << 4;
+                    u.packed = packed;
+                    out[q] = u;
+                }
+                return 0;
+            };
+            std::vector<PmlUnit> ub_f, ut_f, ub, uc;
+            describe(cherries.data(), (int)cherries.size(), false, uc);
+            PML_TRY(dev_alloc(ctx, &ctx->d_cherry_units, uc.size()));
+            PML_TRY(upload(ctx, ctx->d_cherry_units, uc.data(), uc.size()));
+            describe(order.data(), n_stored, true, ub_f);
+            describe(tdp.data(), n_stored, true, ut_f);
+            describe(bu_order, n_internal, false, ub);
+            PML_TRY(dev_alloc(ctx, &ctx->d_bu_units_f, ub_f.size()));
+            PML_TRY(dev_alloc(ctx, &ctx->d_td_units_f, ut_f.size()));
+            PML_TRY(dev_alloc(ctx, &ctx->d_bu_units, ub.size()));
+            PML_TRY(upload(ctx, ctx->d_bu_units_f, ub_f.data(), ub_f.size()));
+            PML_TRY(upload(ctx, ctx->d_td_units_f, ut_f.data(), ut_f.size()));
+            PML_TRY(upload(ctx, ctx->d_bu_units, ub.data(), ub.size()));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));  // the vectors go out of scope
+        }
         PML_TRY(dev_alloc(ctx, &ctx->d_kind, n_nodes));
         PML_TRY(dev_alloc(ctx, &ctx->d_bu_order_f, n_stored));
         PML_TRY(dev_alloc(ctx, &ctx->d_td_parents_f, n_stored));
@@ -1312,7 +1372,7 @@ static int fetch_exponents(pml_ctx* ctx, const i64* src, int col, double* out) {
 // after a fused sweep the cherries' bottom-up vectors only ever existed in registers: compute them for inspection
 static int materialize_cherries(pml_ctx* ctx) {
     if (!ctx->bu_fused) return PML_OK;
-    PML_TRY(dispatch_sweep(ctx, SW_BU_MARG, ctx->d_cherries, ctx->n_cherries));
+    PML_TRY(dispatch_sweep(ctx, SW_BU_CHERRIES, ctx->d_cherries, ctx->n_cherries));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->bu_fused = false;
     return PML_OK;

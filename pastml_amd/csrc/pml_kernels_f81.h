@@ -293,8 +293,40 @@ struct Gather {
     static constexpr bool enabled = G >= 8;
 };
 
+// Unit descriptor, built once per tree on the host (pml_tree_upload): everything about the topology around node n that
+// a unit needs, so that all data loads of a unit can be issued in one round trip (and the descriptor of the wave's next
+// unit is fetched while the current one is computed) instead of chasing n -> first_child -> children -> their children.
+//   packed: bits 0-3 number of children (15 = 15 or more), bit 4 = every cherry among the first four children has
+//           1..GC tips, bits 8+3j..10+3j (j < 4) code of child j: 0 tip, 1 stored internal node, 2+m cherry with m+1 tips
+//   cfc[j]: first child of child j (j < 4), i.e. where the tips of a cherry child start
+struct __attribute__((aligned(32))) PmlUnit {
+    int n, fc, packed, pad;
+    int cfc[4];
+};
+
+struct UnitRegs {  // per lane: the descriptor's header and the cfc entry of the child this lane gathers tips for
+    int n, fc, packed, cfc;
+};
+
+template <int G>
+__device__ __forceinline__ UnitRegs load_unit(const PmlUnit* __restrict__ units, int idx, int g) {
+    const int4 h = *reinterpret_cast<const int4*>(units + idx);
+    UnitRegs u;
+    u.n = h.x;
+    u.fc = h.y;
+    u.packed = h.z;
+    u.cfc = units[idx].cfc[(g / Gather<G>::GC) & 3];
+    return u;
+}
+
+__device__ __forceinline__ int unit_nc(int packed) { return packed & 15; }
+__device__ __forceinline__ int unit_code(int packed, int j) { return (packed >> (8 + 3 * j)) & 7; }
+template <int G>
+__device__ __forceinline__ bool unit_is_fast(int packed) {
+    return unit_nc(packed) <= Gather<G>::CH && ((packed >> 4) & 1);
+}
+
 struct ChildLane {  // what lane j holds about child j
-    int kind, fc, nc;
     double e, s;
     u64 mask;
     i64 be;
@@ -306,45 +338,34 @@ struct TipLane {  // what lane j * GC + q holds about tip q of cherry child j
 };
 
 template <int G, int R>
-__device__ __forceinline__ bool f81_gather(const LaneCtx<G, R>& L, const PmlTree& t, int fc, int nc, ChildLane& cl,
-                                           TipLane& tl) {
+__device__ __forceinline__ void f81_gather(const LaneCtx<G, R>& L, const UnitRegs& u, ChildLane& cl, TipLane& tl) {
     constexpr int GC = Gather<G>::GC;
+    const int nc = unit_nc(u.packed);
     const int j = L.g;
-    const bool has = j < nc;
-    const int ch = fc + (has ? j : 0);
-    cl.fc = t.first_child[ch];
-    cl.nc = has ? t.n_children[ch] : 0;
-    cl.kind = (t.kind != nullptr) ? (int)t.kind[ch] : (cl.nc == 0 ? PML_KIND_TIP : PML_KIND_STORED);
-    if (!has) cl.kind = PML_KIND_TIP;
+    const int ch = u.fc + (j < nc ? j : 0);
     cl.e = L.E[ch];
     cl.s = L.S[ch];
     cl.mask = L.mask[(unsigned)ch];
     cl.be = L.be[ch];
-    if (group_any<G>(has && cl.kind == PML_KIND_CHERRY && cl.nc > GC)) return false;
     const int jj = L.g / GC, q = L.g % GC;
-    const int src = L.group_base + jj;
-    const int ck = __shfl(cl.kind, src, 64);
-    const int cfc = __shfl(cl.fc, src, 64);
-    const int cnc = __shfl(cl.nc, src, 64);
-    const bool has_t = jj < nc && ck == PML_KIND_CHERRY && q < cnc;
-    const int tip = has_t ? cfc + q : fc;
+    const int code = unit_code(u.packed, jj & 3);
+    const bool has_t = jj < nc && q < code - 1;  // code - 1 = number of tips of a cherry child (<= 0 otherwise)
+    const int tip = has_t ? u.cfc + q : u.fc;
     tl.e = L.E[tip];
     tl.s = L.S[tip];
     tl.mask = L.mask[(unsigned)tip];
-    return true;
 }
 
 // cherry child jx of the unit rebuilt from the gathered tip data; same operation order as f81_cherry_vector
 template <int G, int R>
 __device__ __forceinline__ void f81_cherry_from_lanes(const LaneCtx<G, R>& L, const PmlTree& t, const PmlCols& c,
                                                       const PmlState& st, const ChildLane& cl, const TipLane& tl,
-                                                      int jx, int cherry, double (&v)[R], i64& esum, bool report) {
+                                                      int jx, int cherry, int cfc, int cnc, double (&v)[R], i64& esum,
+                                                      bool report) {
     constexpr int GC = Gather<G>::GC;
     const int src = L.group_base + jx;
     const u64 word = __shfl(cl.mask, src, 64);
     word_to_vec<G, R>(L, c, word, v);
-    const int cfc = __shfl(cl.fc, src, 64);
-    const int cnc = __shfl(cl.nc, src, 64);
     esum = 0;
     for (int q = 0; q < cnc; ++q) {
         const int ts = L.group_base + jx * GC + q;
@@ -357,41 +378,42 @@ __device__ __forceinline__ void f81_cherry_from_lanes(const LaneCtx<G, R>& L, co
 }
 
 template <int G, int R>
-__device__ __forceinline__ bool bu_f81_unit_fast(const LaneCtx<G, R>& L, const PmlTree& t, const PmlCols& c,
-                                                 const PmlState& st, int n) {
-    const int fc = t.first_child[n];
-    const int nc = t.n_children[n];
-    if (nc > Gather<G>::CH) return false;
+__device__ __forceinline__ void bu_f81_unit_fast(const LaneCtx<G, R>& L, const PmlTree& t, const PmlCols& c,
+                                                 const PmlState& st, const UnitRegs& u) {
+    constexpr int GC = Gather<G>::GC;
+    const int n = u.n, fc = u.fc;
+    const int nc = unit_nc(u.packed);
     double acc[R];
     node_mask_vec<G, R>(L, c, n, acc);
     ChildLane cl;
     TipLane tl;
-    if (!f81_gather<G, R>(L, t, fc, nc, cl, tl)) return false;
+    f81_gather<G, R>(L, u, cl, tl);
     i64 esum = 0;
     double vn[R];
-    if (__shfl(cl.kind, L.group_base, 64) == PML_KIND_STORED) node_load_vec<G, R>(L, c, L.bu, fc, vn);
+    if (unit_code(u.packed, 0) == 1) node_load_vec<G, R>(L, c, L.bu, fc, vn);
     for (int jx = 0; jx < nc; ++jx) {
         const int src = L.group_base + jx;
         const int ch = fc + jx;
-        const int kd = __shfl(cl.kind, src, 64);
+        const int code = unit_code(u.packed, jx);
         const double e = __shfl(cl.e, src, 64);
         double v[R];
         double s_child;
-        if (kd == PML_KIND_STORED) {
+        if (code == 1) {
 #pragma unroll
             for (int r = 0; r < R; ++r) v[r] = vn[r];
         }
-        if (jx + 1 < nc && __shfl(cl.kind, src + 1, 64) == PML_KIND_STORED) node_load_vec<G, R>(L, c, L.bu, ch + 1, vn);
-        if (kd == PML_KIND_TIP) {
+        if (jx + 1 < nc && unit_code(u.packed, jx + 1) == 1) node_load_vec<G, R>(L, c, L.bu, ch + 1, vn);
+        if (code == 0) {
             const u64 word = __shfl(cl.mask, src, 64);
             word_to_vec<G, R>(L, c, word, v);
             s_child = __shfl(cl.s, src, 64);
-        } else if (kd == PML_KIND_STORED) {
+        } else if (code == 1) {
             esum += __shfl(cl.be, src, 64);
             s_child = __shfl(cl.s, src, 64);
         } else {
             i64 ce;
-            f81_cherry_from_lanes<G, R>(L, t, c, st, cl, tl, jx, ch, v, ce, true);
+            const int cfc = __shfl(u.cfc, L.group_base + jx * GC, 64);
+            f81_cherry_from_lanes<G, R>(L, t, c, st, cl, tl, jx, ch, cfc, code - 1, v, ce, true);
             esum += ce;
             s_child = pi_dot<G, R>(L, v);
             if (L.g == 0) L.S[ch] = s_child;  // 8 bytes kept for the top-down sweep (saves its reduction there)
@@ -405,7 +427,6 @@ __device__ __forceinline__ bool bu_f81_unit_fast(const LaneCtx<G, R>& L, const P
         L.be[n] = esum;
     }
     node_store_vec<G, R>(L, c, L.bu, n, acc);
-    return true;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -416,10 +437,12 @@ __device__ __forceinline__ bool bu_f81_unit_fast(const LaneCtx<G, R>& L, const P
 // One bottom-up unit: node n of the current level, this lane group's column.
 template <int G, int R, bool JOINT>
 __device__ __forceinline__ void bu_f81_unit(const LaneCtx<G, R>& L, const PmlTree& t, const PmlCols& c,
-                                            const PmlState& st, int n) {
-    if (!JOINT && Gather<G>::enabled && c.W == 1) {
-        if (bu_f81_unit_fast<G, R>(L, t, c, st, n)) return;
+                                            const PmlState& st, const UnitRegs& u) {
+    if (!JOINT && Gather<G>::enabled && c.W == 1 && unit_is_fast<G>(u.packed)) {
+        bu_f81_unit_fast<G, R>(L, t, c, st, u);
+        return;
     }
+    const int n = u.n;
 
     double acc[R];
     node_mask_vec<G, R>(L, c, n, acc);
@@ -551,17 +574,23 @@ __device__ __forceinline__ void bu_f81_unit(const LaneCtx<G, R>& L, const PmlTre
 }
 
 template <int G, int R, bool JOINT>
-__global__ void __launch_bounds__(PML_BLOCK)
-bu_f81_kernel(PmlTree t, PmlCols c, PmlState st, const int* __restrict__ level_nodes, int n_level) {
+__global__ void __launch_bounds__(PML_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)))
+bu_f81_kernel(PmlTree t, PmlCols c, PmlState st, const PmlUnit* __restrict__ units, int n_level) {
     constexpr int UW = 64 / G;  // units per wave
     const int wave = threadIdx.x >> 6;
     const int sub = (threadIdx.x & 63) / G;
     LaneCtx<G, R> L;
     lane_ctx_init<G, R>(L, t, c, st);
     const int stride = gridDim.x * PML_WAVES_PER_BLOCK * UW;
-    for (int base = (blockIdx.x * PML_WAVES_PER_BLOCK + wave) * UW; base < n_level; base += stride) {
-        const int idx = base + sub;
-        if (idx < n_level) bu_f81_unit<G, R, JOINT>(L, t, c, st, level_nodes[idx]);  // whole groups drop out together
+    int idx = (blockIdx.x * PML_WAVES_PER_BLOCK + wave) * UW + sub;
+    UnitRegs cur = load_unit<G>(units, idx < n_level ? idx : 0, L.g);
+    // wave-uniform trip count; whole groups drop out together; the next descriptor is in flight during the unit
+    for (int base = idx - sub; base < n_level; base += stride) {
+        const int nxt_idx = idx + stride;
+        const UnitRegs nxt = load_unit<G>(units, nxt_idx < n_level ? nxt_idx : 0, L.g);
+        if (idx < n_level) bu_f81_unit<G, R, JOINT>(L, t, c, st, cur);
+        cur = nxt;
+        idx = nxt_idx;
     }
 }
 
@@ -687,42 +716,41 @@ __device__ __forceinline__ void f81_finish_tip(const LaneCtx<G, R>& L, const Pml
 }
 
 template <int G, int R>
-__device__ __forceinline__ bool td_f81_unit_fast(const LaneCtx<G, R>& L, const PmlTree& t, const PmlCols& c,
-                                                 const PmlState& st, int p) {
+__device__ __forceinline__ void td_f81_unit_fast(const LaneCtx<G, R>& L, const PmlTree& t, const PmlCols& c,
+                                                 const PmlState& st, const UnitRegs& u) {
     constexpr int GC = Gather<G>::GC;
-    const int fc = t.first_child[p];
-    const int nc = t.n_children[p];
-    if (nc > Gather<G>::CH) return false;
+    const int p = u.n, fc = u.fc;
+    const int nc = unit_nc(u.packed);
     double prod[R];
     i64 pe;
     f81_parent_prod<G, R>(L, c, p, prod, pe);
     ChildLane cl;
     TipLane tl;
-    if (!f81_gather<G, R>(L, t, fc, nc, cl, tl)) return false;
+    f81_gather<G, R>(L, u, cl, tl);
     double vn[R];
-    if (__shfl(cl.kind, L.group_base, 64) == PML_KIND_STORED) node_load_vec<G, R>(L, c, L.bu, fc, vn);
+    if (unit_code(u.packed, 0) == 1) node_load_vec<G, R>(L, c, L.bu, fc, vn);
     double P = 0.0;
     bool have_P = false;
     for (int jx = 0; jx < nc; ++jx) {
         const int src = L.group_base + jx;
         const int ch = fc + jx;
-        const int kd = __shfl(cl.kind, src, 64);
+        const int code = unit_code(u.packed, jx);
         const double e = __shfl(cl.e, src, 64);
         const u64 word = __shfl(cl.mask, src, 64);
         double v[R];
-        if (kd == PML_KIND_STORED) {
+        if (code == 1) {
 #pragma unroll
             for (int r = 0; r < R; ++r) v[r] = vn[r];
         }
-        if (jx + 1 < nc && __shfl(cl.kind, src + 1, 64) == PML_KIND_STORED) node_load_vec<G, R>(L, c, L.bu, ch + 1, vn);
-        if (kd == PML_KIND_TIP) {
+        if (jx + 1 < nc && unit_code(u.packed, jx + 1) == 1) node_load_vec<G, R>(L, c, L.bu, ch + 1, vn);
+        if (code == 0) {
             f81_finish_tip_word<G, R>(L, c, prod, pe, P, have_P, ch, word, e, __shfl(cl.s, src, 64));
             continue;
         }
         double mb[R], tdc[R], po[R], ls;
         word_to_vec<G, R>(L, c, word, mb);
         i64 xe, le;
-        if (kd == PML_KIND_STORED) {
+        if (code == 1) {
             f81_finish_child<G, R>(L, c, prod, pe, ch, e, __shfl(cl.s, src, 64), __shfl(cl.be, src, 64), v, mb, tdc, xe,
                                    po, ls, le);
             if (st.td != nullptr) {
@@ -731,7 +759,9 @@ __device__ __forceinline__ bool td_f81_unit_fast(const LaneCtx<G, R>& L, const P
             }
         } else {
             i64 bec;
-            f81_cherry_from_lanes<G, R>(L, t, c, st, cl, tl, jx, ch, v, bec, false);
+            const int cfc = __shfl(u.cfc, L.group_base + jx * GC, 64);
+            const int cnc = code - 1;
+            f81_cherry_from_lanes<G, R>(L, t, c, st, cl, tl, jx, ch, cfc, cnc, v, bec, false);
             const double s_child = __shfl(cl.s, src, 64);  // pi . v, stored by the bottom-up sweep
             f81_finish_child<G, R>(L, c, prod, pe, ch, e, s_child, bec, v, mb, tdc, xe, po, ls, le);
             // same rounding as f81_parent_prod, so that the schedule without cherry fusion gives the same bits
@@ -741,8 +771,6 @@ __device__ __forceinline__ bool td_f81_unit_fast(const LaneCtx<G, R>& L, const P
             const i64 pe2 = le;
             double P2 = 0.0;
             bool have_P2 = false;
-            const int cfc = __shfl(cl.fc, src, 64);
-            const int cnc = __shfl(cl.nc, src, 64);
             for (int q = 0; q < cnc; ++q) {
                 const int ts = L.group_base + jx * GC + q;
                 f81_finish_tip_word<G, R>(L, c, prod2, pe2, P2, have_P2, cfc + q, __shfl(tl.mask, ts, 64),
@@ -750,7 +778,6 @@ __device__ __forceinline__ bool td_f81_unit_fast(const LaneCtx<G, R>& L, const P
             }
         }
     }
-    return true;
 }
 
 // One unit = (stored internal node of the depth level, column): the parent's BU and TD vectors are loaded once and
@@ -760,10 +787,12 @@ __device__ __forceinline__ bool td_f81_unit_fast(const LaneCtx<G, R>& L, const P
 // One top-down unit: stored internal node p of the current depth level.
 template <int G, int R>
 __device__ __forceinline__ void td_f81_unit(const LaneCtx<G, R>& L, const PmlTree& t, const PmlCols& c,
-                                            const PmlState& st, int p) {
-    if (Gather<G>::enabled && c.W == 1) {
-        if (td_f81_unit_fast<G, R>(L, t, c, st, p)) return;
+                                            const PmlState& st, const UnitRegs& u) {
+    if (Gather<G>::enabled && c.W == 1 && unit_is_fast<G>(u.packed)) {
+        td_f81_unit_fast<G, R>(L, t, c, st, u);
+        return;
     }
+    const int p = u.n;
 
     double prod[R];
     i64 pe;
@@ -811,16 +840,21 @@ __device__ __forceinline__ void td_f81_unit(const LaneCtx<G, R>& L, const PmlTre
 
 template <int G, int R>
 __global__ void __launch_bounds__(PML_BLOCK)
-td_f81_kernel(PmlTree t, PmlCols c, PmlState st, const int* __restrict__ level_parents, int n_level) {
+td_f81_kernel(PmlTree t, PmlCols c, PmlState st, const PmlUnit* __restrict__ units, int n_level) {
     constexpr int UW = 64 / G;
     const int wave = threadIdx.x >> 6;
     const int sub = (threadIdx.x & 63) / G;
     LaneCtx<G, R> L;
     lane_ctx_init<G, R>(L, t, c, st);
     const int stride = gridDim.x * PML_WAVES_PER_BLOCK * UW;
-    for (int base = (blockIdx.x * PML_WAVES_PER_BLOCK + wave) * UW; base < n_level; base += stride) {
-        const int idx = base + sub;
-        if (idx < n_level) td_f81_unit<G, R>(L, t, c, st, level_parents[idx]);
+    int idx = (blockIdx.x * PML_WAVES_PER_BLOCK + wave) * UW + sub;
+    UnitRegs cur = load_unit<G>(units, idx < n_level ? idx : 0, L.g);
+    for (int base = idx - sub; base < n_level; base += stride) {
+        const int nxt_idx = idx + stride;
+        const UnitRegs nxt = load_unit<G>(units, nxt_idx < n_level ? nxt_idx : 0, L.g);
+        if (idx < n_level) td_f81_unit<G, R>(L, t, c, st, cur);
+        cur = nxt;
+        idx = nxt_idx;
     }
 }
 
@@ -870,7 +904,7 @@ template <int G, int R>
 __global__ void __launch_bounds__(PML_SMALL_BLOCK)
 bu_f81_small_kernel(PmlTree t, PmlCols c, PmlState st, const double* __restrict__ mu, const double* __restrict__ sf,
                     const double* __restrict__ tau, const double* __restrict__ tauf, int do_prep,
-                    const int* __restrict__ level_nodes, const int* __restrict__ level_offsets, int n_levels,
+                    const PmlUnit* __restrict__ units, const int* __restrict__ level_offsets, int n_levels,
                     double* __restrict__ loglik) {
     constexpr int UW = 64 / G;
     const int col = blockIdx.y;
@@ -905,7 +939,7 @@ bu_f81_small_kernel(PmlTree t, PmlCols c, PmlState st, const double* __restrict_
         const int a = level_offsets[l], n_level = level_offsets[l + 1] - a;
         for (int base = wave * UW; base < n_level; base += n_waves * UW) {
             const int idx = base + sub;
-            if (idx < n_level) bu_f81_unit<G, R, false>(L, t, c, st, level_nodes[a + idx]);
+            if (idx < n_level) bu_f81_unit<G, R, false>(L, t, c, st, load_unit<G>(units, a + idx, L.g));
         }
         __syncthreads();
     }
@@ -963,7 +997,7 @@ td_f81_roots_kernel(PmlTree t, PmlCols c, PmlState st) {
 
 template <int G, int R>
 __global__ void __launch_bounds__(PML_SMALL_BLOCK)
-td_f81_small_kernel(PmlTree t, PmlCols c, PmlState st, const int* __restrict__ level_parents,
+td_f81_small_kernel(PmlTree t, PmlCols c, PmlState st, const PmlUnit* __restrict__ units,
                     const int* __restrict__ level_offsets, int n_levels) {
     constexpr int UW = 64 / G;
     const int wave = threadIdx.x >> 6;
@@ -980,7 +1014,7 @@ td_f81_small_kernel(PmlTree t, PmlCols c, PmlState st, const int* __restrict__ l
         const int a = level_offsets[l], n_level = level_offsets[l + 1] - a;
         for (int base = wave * UW; base < n_level; base += n_waves * UW) {
             const int idx = base + sub;
-            if (idx < n_level) td_f81_unit<G, R>(L, t, c, st, level_parents[a + idx]);
+            if (idx < n_level) td_f81_unit<G, R>(L, t, c, st, load_unit<G>(units, a + idx, L.g));
         }
         __syncthreads();
     }
