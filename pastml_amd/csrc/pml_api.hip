@@ -74,7 +74,8 @@ struct pml_ctx {
 
     // columns
     int C = 0, k = 0, ks = 0, W = 0, G = 0, R = 0;
-    int Gf = 0, Rf = 0;  // lane-group shape of the F81-family kernels (chunked state ownership)
+    int Gf = 0, Rf = 0;  // lane-group shape of the F81-family bottom-up kernels (chunked state ownership)
+    int Gt = 0, Rt = 0;  // ... and of the F81-family top-down kernels
     u64 *d_masks = nullptr, *d_masks_init = nullptr;
     bool has_init = false;
     int kind = -1;
@@ -358,30 +359,33 @@ static void launch_select(pml_ctx* ctx, int method, int force_joint, const u64* 
 }
 
 static int dispatch_small_f81(pml_ctx* ctx, bool bottom_up, int do_prep) {
+    const int g = bottom_up ? ctx->Gf : ctx->Gt, r = bottom_up ? ctx->Rf : ctx->Rt;
 #define X(G_, R_)                                            \
-    if (ctx->Gf == G_ && ctx->Rf == R_) {                    \
+    if (g == G_ && r == R_) {                                \
         launch_small_f81<G_, R_>(ctx, bottom_up, do_prep);   \
         HIP_TRY(hipGetLastError());                          \
         return PML_OK;                                       \
     }
     PML_F81_CASES(X)
 #undef X
-    return fail(PML_ERR_UNSUPPORTED, "no F81 kernel for G=%d R=%d", ctx->Gf, ctx->Rf);
+    return fail(PML_ERR_UNSUPPORTED, "no F81 kernel for G=%d R=%d", g, r);
 }
 
 static int dispatch_sweep(pml_ctx* ctx, SweepKind what, const int* level, int n_level) {
     if (n_level <= 0) return PML_OK;
     if (ctx->kind == PML_MODEL_F81) {
         if (what == SW_TD) return fail(PML_ERR_INVALID, "the F81 kernels walk descriptor lists: SW_TD has none");
+        const bool td = what == SW_TD_FUSED || what == SW_ROOTS;
+        const int g = td ? ctx->Gt : ctx->Gf, r = td ? ctx->Rt : ctx->Rf;
 #define X(G_, R_)                                                \
-    if (ctx->Gf == G_ && ctx->Rf == R_) {                        \
+    if (g == G_ && r == R_) {                                    \
         launch_sweep_f81<G_, R_>(ctx, what, level, n_level);     \
         HIP_TRY(hipGetLastError());                              \
         return PML_OK;                                           \
     }
         PML_F81_CASES(X)
 #undef X
-        return fail(PML_ERR_UNSUPPORTED, "no F81 kernel for G=%d R=%d", ctx->Gf, ctx->Rf);
+        return fail(PML_ERR_UNSUPPORTED, "no F81 kernel for G=%d R=%d", g, r);
     }
 #define X(G_, R_)                                             \
     if (ctx->G == G_ && ctx->R == R_) {                       \
@@ -733,18 +737,23 @@ int pml_chars_alloc(pml_ctx* ctx, int32_t n_cols, int32_t k) {
     pick_group(k, ctx->G, ctx->R);
     ctx->ks = (k + ctx->R - 1) / ctx->R * ctx->R;
     {
-        // F81 family: 4 states per lane (two 16-byte pairs); PASTML_HIP_F81_R = 2 / 8 selects the tuning variants
-        int rf = k >= 3 ? 4 : k;
-        if (const char* env = getenv("PASTML_HIP_F81_R")) {
-            const int v = atoi(env);
-            if (v == 2 && k > 32 && k <= 64) rf = 2;
-            if (v == 8 && k > 32 && k <= 64) rf = 8;
-        }
-        ctx->Rf = rf;
-        const int need = (k + rf - 1) / rf;
-        ctx->Gf = 1;
-        while (ctx->Gf < need) ctx->Gf <<= 1;
-        if (rf >= 2 && (ctx->ks & 1)) ctx->ks += 1;  // 16-byte lane accesses
+        // F81 family: 4 states per lane (two 16-byte pairs).  Most of a unit's work is scalar (per child, per tip), so
+        // the top-down kernels, which have the most of it, take 8 states per lane for 32 < k <= 64: 8 units per
+        // wavefront share each scalar instruction.  PASTML_HIP_F81_R / PASTML_HIP_F81_TD_R = 2 / 4 / 8: tuning variants
+        auto shape = [&](const char* var, int dflt, int& G, int& R) {
+            int rf = k >= 3 ? dflt : k;
+            if (const char* env = getenv(var)) {
+                const int v = atoi(env);
+                if ((v == 2 || v == 4 || v == 8) && k > 32 && k <= 64) rf = v;
+            }
+            R = rf;
+            const int need = (k + rf - 1) / rf;
+            G = 1;
+            while (G < need) G <<= 1;
+        };
+        shape("PASTML_HIP_F81_R", 4, ctx->Gf, ctx->Rf);
+        shape("PASTML_HIP_F81_TD_R", (k > 32 && k <= 64) ? 8 : 4, ctx->Gt, ctx->Rt);
+        if (k >= 2 && (ctx->ks & 1)) ctx->ks += 1;  // 16-byte lane accesses
     }
     ctx->W = (k + 63) / 64;
     if ((size_t)ctx->N * ctx->ks >= (1ull << 31)) {

@@ -574,7 +574,7 @@ __device__ __forceinline__ void bu_f81_unit(const LaneCtx<G, R>& L, const PmlTre
 }
 
 template <int G, int R, bool JOINT>
-__global__ void __launch_bounds__(PML_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)))
+__global__ void __launch_bounds__(PML_BLOCK) __attribute__((amdgpu_waves_per_eu(R >= 8 ? 2 : 4, R >= 8 ? 2 : 4)))
 bu_f81_kernel(PmlTree t, PmlCols c, PmlState st, const PmlUnit* __restrict__ units, int n_level) {
     constexpr int UW = 64 / G;  // units per wave
     const int wave = threadIdx.x >> 6;
