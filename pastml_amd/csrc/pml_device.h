@@ -64,6 +64,14 @@ __device__ __forceinline__ double fast_rcp(double x) {
     return fma(r, e, r);
 }
 
+// 1/x with one Newton step: relative error <= 2.2e-15 measured on gfx950 (v_rcp_f64 alone: 4.6e-8), used where the
+// result feeds quantities whose parity bar is 1e-6 and which are renormalised at every level (top-down sweep)
+__device__ __forceinline__ double rcp1(double x) {
+    const double r = __builtin_amdgcn_rcp(x);
+    const double e = fma(-x, r, 1.0);
+    return fma(r, e, r);
+}
+
 template <int G>
 __device__ __forceinline__ double group_max(double v) {
 #pragma unroll

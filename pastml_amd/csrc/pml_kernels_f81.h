@@ -149,13 +149,22 @@ __device__ __forceinline__ void f81_parent_prod(const LaneCtx<G, R>& L, const Pm
     for (int r = 0; r < R; ++r) prod[r] = po[r] * (ls * L.ipi_r[r]);
 }
 
-// 0/1 vector of the lane's states from a single mask word (k <= 64)
+__device__ __forceinline__ u64 state_bits(int k) { return k >= 64 ? ~0ull : (1ull << k) - 1ull; }
+
+// 0/1 vector of the lane's states from a single mask word (k <= 64, hence G * R <= 64): one 64-bit shift per state
+// pair, then bit b -> (0 or 0x3FF00000) as the high word of the double -- no compares, no selects.
 template <int G, int R>
 __device__ __forceinline__ void word_to_vec(const LaneCtx<G, R>& L, const PmlCols& c, u64 word, double (&v)[R]) {
+    if (R == 1) {
+        v[0] = (L.g < c.k && ((word >> (L.g & 63)) & 1ull)) ? 1.0 : 0.0;
+    } else {
+        const u64 w = word & state_bits(c.k);
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int s = L.st(r);
-        v[r] = (s < c.k && ((word >> (s & 63)) & 1ull)) ? 1.0 : 0.0;
+        for (int q = 0; q < R / 2; ++q) {
+            const unsigned t = (unsigned)(w >> ((2 * G * q + 2 * L.g) & 63));
+            v[2 * q] = __hiloint2double(((int)(t << 31) >> 31) & 0x3FF00000, 0);
+            v[2 * q + 1] = __hiloint2double(((int)(t << 30) >> 31) & 0x3FF00000, 0);
+        }
     }
 }
 
@@ -606,29 +615,37 @@ bu_f81_kernel(PmlTree t, PmlCols c, PmlState st, const PmlUnit* __restrict__ uni
 template <int G, int R>
 __device__ __forceinline__ void f81_finish_child(const LaneCtx<G, R>& L, const PmlCols& c, const double (&prod)[R],
                                                  i64 pe, int ch, double e, double s_child, i64 bec,
-                                                 const double (&v)[R], const double (&mb)[R], double (&tdc)[R],
-                                                 i64& xe, double (&lh)[R], double& lsum, i64& le) {
+                                                 const double (&v)[R], bool full_mask, const double (&mb)[R],
+                                                 double (&tdc)[R], i64& xe, double (&lh)[R], double& lsum, i64& le) {
     const double a = (1.0 - e) * s_child;
     double x[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        double cn = a + e * v[r];
-        if (!(cn > 0.0)) cn = 1.0;
-        x[r] = prod[r] * fast_rcp(cn);
+        // a zero message entry comes with a zero in prod (it is one of prod's factors): 0 * 2^1022 = 0
+        const double cn = fmax(a + e * v[r], 0x1p-1022);
+        x[r] = prod[r] * rcp1(cn);
     }
     xe = pe - bec;
     const double b = (1.0 - e) * pi_dot<G, R>(L, x);
 #pragma unroll
     for (int r = 0; r < R; ++r) tdc[r] = b + e * x[r];  // >= 0 by construction (ml.py:289's clamp is a no-op)
     double lhs = 0.0;
+    if (full_mask) {  // every state allowed (the usual case for an internal node): pi * 1.0 = pi, same bits
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        lh[r] = v[r] * tdc[r] * (L.pi_r[r] * mb[r]);
-        lhs += lh[r];
+        for (int r = 0; r < R; ++r) {
+            lh[r] = v[r] * tdc[r] * L.pi_r[r];
+            lhs += lh[r];
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            lh[r] = v[r] * tdc[r] * (L.pi_r[r] * mb[r]);
+            lhs += lh[r];
+        }
     }
     lhs = group_sum<G>(lhs);
     const int lex = (lhs > 0.0 && !isinf(lhs)) ? exponent_of(lhs) : 0;
-    const double inv = fast_rcp(lhs);
+    const double inv = rcp1(lhs);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         // correctly rounded lh / lhs (one residual step)
@@ -655,33 +672,32 @@ __device__ __forceinline__ void f81_finish_tip_word(const LaneCtx<G, R>& L, cons
                                                     i64 pe, double& P, bool& have_P, int tip, u64 word, double e,
                                                     double pis) {
     if (__popcll(word) == 1) {
-        const int s = __builtin_ctzll(word);
         if (!have_P) {
             P = pi_dot<G, R>(L, prod);
             have_P = true;
         }
-        // owner of state s: pair q = s / 2G, lane (s % 2G) / 2, slot 2q + (s & 1)   (R = 1: lane s)
-        const int owner_r = R == 1 ? 0 : 2 * (s / (2 * G)) + (s & 1);
-        const int owner_g = R == 1 ? s : (s % (2 * G)) >> 1;
-        double mine = prod[0];
+        // unit vector of the observed state: the posterior, and the tool that picks prod_s (sum of zeros and one term)
+        double oh[R];
+        word_to_vec<G, R>(L, c, word, oh);
+        double pick = 0.0;
 #pragma unroll
-        for (int r = 1; r < R; ++r)
-            if (owner_r == r) mine = prod[r];
-        const double ps = __shfl(mine, L.group_base + owner_g, 64);
+        for (int r = 0; r < R; ++r) pick = fma(oh[r], prod[r], pick);
+        const double ps = group_sum<G>(pick);
         const double q = pis * ps;
         double c0 = (1.0 - e) * pis;
         const double c1 = c0 + e;
         if (!(c0 > 0.0)) c0 = 1.0;
-        const double r1 = fast_rcp(c1);
-        const double sx = (P - q) * fast_rcp(c0) + q * r1;
+        const double r1 = rcp1(c1);
+        const double sx = (P - q) * rcp1(c0) + q * r1;
         const double tds = (1.0 - e) * sx + e * (ps * r1);
         const double lhs = tds * pis;
         const bool ok = lhs > 0.0 && !isinf(lhs);
         const int lex = ok ? exponent_of(lhs) : 0;
-        double out[R];
+        if (!ok) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) out[r] = ok ? ((L.st(r) == s) ? 1.0 : 0.0) : __builtin_nan("");
-        node_store_vec_nt<G, R>(L, c, L.post, tip, out);
+            for (int r = 0; r < R; ++r) oh[r] = __builtin_nan("");
+        }
+        node_store_vec_nt<G, R>(L, c, L.post, tip, oh);
         if (L.g == 0) {
             L.lhsum[tip] = __builtin_ldexp(lhs, -lex);
             L.lhe[tip] = pe + lex;
@@ -690,7 +706,7 @@ __device__ __forceinline__ void f81_finish_tip_word(const LaneCtx<G, R>& L, cons
         double mt[R], tdt[R], pt[R], lt;
         word_to_vec<G, R>(L, c, word, mt);
         i64 xt, et;
-        f81_finish_child<G, R>(L, c, prod, pe, tip, e, pis, 0, mt, mt, tdt, xt, pt, lt, et);
+        f81_finish_child<G, R>(L, c, prod, pe, tip, e, pis, 0, mt, false, mt, tdt, xt, pt, lt, et);
     }
 }
 
@@ -711,7 +727,7 @@ __device__ __forceinline__ void f81_finish_tip(const LaneCtx<G, R>& L, const Pml
         double mt[R], tdt[R], pt[R], lt;
         node_mask_vec<G, R>(L, c, tip, mt);
         i64 xt, et;
-        f81_finish_child<G, R>(L, c, prod, pe, tip, e, pis, 0, mt, mt, tdt, xt, pt, lt, et);
+        f81_finish_child<G, R>(L, c, prod, pe, tip, e, pis, 0, mt, false, mt, tdt, xt, pt, lt, et);
     }
 }
 
@@ -748,11 +764,12 @@ __device__ __forceinline__ void td_f81_unit_fast(const LaneCtx<G, R>& L, const P
             continue;
         }
         double mb[R], tdc[R], po[R], ls;
-        word_to_vec<G, R>(L, c, word, mb);
+        const bool full = (word & state_bits(c.k)) == state_bits(c.k);
+        if (!full) word_to_vec<G, R>(L, c, word, mb);
         i64 xe, le;
         if (code == 1) {
-            f81_finish_child<G, R>(L, c, prod, pe, ch, e, __shfl(cl.s, src, 64), __shfl(cl.be, src, 64), v, mb, tdc, xe,
-                                   po, ls, le);
+            f81_finish_child<G, R>(L, c, prod, pe, ch, e, __shfl(cl.s, src, 64), __shfl(cl.be, src, 64), v, full, mb,
+                                   tdc, xe, po, ls, le);
             if (st.td != nullptr) {
                 node_store_vec<G, R>(L, c, L.td, ch, tdc);
                 if (L.g == 0) L.te[ch] = xe;
@@ -763,7 +780,7 @@ __device__ __forceinline__ void td_f81_unit_fast(const LaneCtx<G, R>& L, const P
             const int cnc = code - 1;
             f81_cherry_from_lanes<G, R>(L, t, c, st, cl, tl, jx, ch, cfc, cnc, v, bec, false);
             const double s_child = __shfl(cl.s, src, 64);  // pi . v, stored by the bottom-up sweep
-            f81_finish_child<G, R>(L, c, prod, pe, ch, e, s_child, bec, v, mb, tdc, xe, po, ls, le);
+            f81_finish_child<G, R>(L, c, prod, pe, ch, e, s_child, bec, v, full, mb, tdc, xe, po, ls, le);
             // same rounding as f81_parent_prod, so that the schedule without cherry fusion gives the same bits
             double prod2[R];
 #pragma unroll
@@ -814,7 +831,7 @@ __device__ __forceinline__ void td_f81_unit(const LaneCtx<G, R>& L, const PmlTre
         i64 xe, le;
         if (kd == PML_KIND_STORED) {
             node_load_vec<G, R>(L, c, L.bu, ch, v);
-            f81_finish_child<G, R>(L, c, prod, pe, ch, e, L.S[ch], L.be[ch], v, mb, tdc, xe, po, ls, le);
+            f81_finish_child<G, R>(L, c, prod, pe, ch, e, L.S[ch], L.be[ch], v, false, mb, tdc, xe, po, ls, le);
             if (st.td != nullptr) {
                 node_store_vec<G, R>(L, c, L.td, ch, tdc);
                 if (L.g == 0) L.te[ch] = xe;
@@ -824,7 +841,7 @@ __device__ __forceinline__ void td_f81_unit(const LaneCtx<G, R>& L, const PmlTre
             i64 bec;
             f81_cherry_vector<G, R>(L, t, c, st, ch, v, bec, false);
             const double s_child = L.S[ch];  // pi . v, stored by the bottom-up sweep
-            f81_finish_child<G, R>(L, c, prod, pe, ch, e, s_child, bec, v, mb, tdc, xe, po, ls, le);
+            f81_finish_child<G, R>(L, c, prod, pe, ch, e, s_child, bec, v, false, mb, tdc, xe, po, ls, le);
             double prod2[R];
 #pragma unroll
             for (int r = 0; r < R; ++r) prod2[r] = po[r] * (ls * L.ipi_r[r]);
