@@ -386,14 +386,17 @@ __device__ __forceinline__ void f81_cherry_from_lanes(const LaneCtx<G, R>& L, co
     }
 }
 
+// Returns false when the unit's vector came out all zero: a product only ever gains zeros, so the zero check of
+// ml.py:139-145 is made once at the end, and the caller repeats the unit on the sequential path, which checks after
+// every child and reports the pair the reference would name.
 template <int G, int R>
-__device__ __forceinline__ void bu_f81_unit_fast(const LaneCtx<G, R>& L, const PmlTree& t, const PmlCols& c,
+__device__ __forceinline__ bool bu_f81_unit_fast(const LaneCtx<G, R>& L, const PmlTree& t, const PmlCols& c,
                                                  const PmlState& st, const UnitRegs& u) {
     constexpr int GC = Gather<G>::GC;
     const int n = u.n, fc = u.fc;
     const int nc = unit_nc(u.packed);
     double acc[R];
-    node_mask_vec<G, R>(L, c, n, acc);
+    word_to_vec<G, R>(L, c, L.mask[(unsigned)n], acc);
     ChildLane cl;
     TipLane tl;
     f81_gather<G, R>(L, u, cl, tl);
@@ -422,20 +425,25 @@ __device__ __forceinline__ void bu_f81_unit_fast(const LaneCtx<G, R>& L, const P
         } else {
             i64 ce;
             const int cfc = __shfl(u.cfc, L.group_base + jx * GC, 64);
-            f81_cherry_from_lanes<G, R>(L, t, c, st, cl, tl, jx, ch, cfc, code - 1, v, ce, true);
+            f81_cherry_from_lanes<G, R>(L, t, c, st, cl, tl, jx, ch, cfc, code - 1, v, ce, false);
             esum += ce;
             s_child = pi_dot<G, R>(L, v);
             if (L.g == 0) L.S[ch] = s_child;  // 8 bytes kept for the top-down sweep (saves its reduction there)
         }
-        f81_absorb_child<G, R>(L, t, st, n, ch, e, s_child, v, acc, true);
+        f81_absorb_child<G, R>(L, t, st, n, ch, e, s_child, v, acc, false);
         if ((jx & 1) == 1 || jx == nc - 1) esum += lazy_rescale<G, R>(acc);
     }
+    bool nz = false;
+#pragma unroll
+    for (int r = 0; r < R; ++r) nz |= acc[r] != 0.0 && L.st(r) < c.k;
+    if (!group_any<G>(nz)) return false;
     const double s = pi_dot<G, R>(L, acc);
     if (L.g == 0) {
         L.S[n] = s;
         L.be[n] = esum;
     }
     node_store_vec<G, R>(L, c, L.bu, n, acc);
+    return true;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -448,8 +456,7 @@ template <int G, int R, bool JOINT>
 __device__ __forceinline__ void bu_f81_unit(const LaneCtx<G, R>& L, const PmlTree& t, const PmlCols& c,
                                             const PmlState& st, const UnitRegs& u) {
     if (!JOINT && Gather<G>::enabled && c.W == 1 && unit_is_fast<G>(u.packed)) {
-        bu_f81_unit_fast<G, R>(L, t, c, st, u);
-        return;
+        if (bu_f81_unit_fast<G, R>(L, t, c, st, u)) return;
     }
     const int n = u.n;
 

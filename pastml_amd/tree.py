@@ -88,6 +88,52 @@ class TreeNode(object):
             n = n.up
         return n
 
+    def set_outgroup(self, outgroup):
+        """
+        Re-roots the tree (self must be its root) on the branch above ``outgroup``, at the branch's midpoint, like
+        ete3's ``set_outgroup`` that the reference's re-rooting test relies on
+        (tests/ACRParameterOptimisationMPPAF81Test.py:20-37): self stays the root object, its first child becomes
+        ``outgroup``; what used to hang under the old root moves into the sister subtree (a root with two children
+        dissolves: its two branches merge; otherwise an unnamed zero-length connector holds the remaining children).
+        """
+        if outgroup is self:
+            raise ValueError('Cannot set the root as outgroup')
+        path = []  # outgroup.up, ..., self
+        n = outgroup
+        while n.up is not None:
+            path.append(n.up)
+            n = n.up
+        if n is not self:
+            raise ValueError('The outgroup is not in this tree')
+        self._flat_cache = None
+        below_root = path[-2] if len(path) > 1 else outgroup
+        rest = [c for c in self.children if c is not below_root]
+        if len(rest) == 1:
+            connector = rest[0]
+        else:
+            connector = TreeNode(dist=0.0)
+            for c in rest:
+                connector.add_child(c)
+        if len(path) == 1:
+            sister = connector
+        else:
+            # turn the path outgroup.up -> ... -> below_root upside down: every node on it becomes the parent of its
+            # old parent, and the branch lengths move with the branches
+            sister = path[0]
+            sister.children.remove(outgroup)
+            carried = sister.dist
+            for child, parent in zip(path[:-2], path[1:-1]):
+                parent.children.remove(child)
+                carried, parent.dist = parent.dist, carried
+                child.add_child(parent)
+            path[-2].add_child(connector, dist=connector.dist + carried)
+            sister.dist = 0.0
+        half = (outgroup.dist + sister.dist) / 2.
+        self.children = []
+        self.add_child(outgroup, dist=half)
+        self.add_child(sister, dist=half)
+        return self
+
     # --- traversal (orders identical to ete3: children are visited left to right) ---------------------------------------
     def traverse(self, strategy='levelorder'):
         if strategy == 'preorder':

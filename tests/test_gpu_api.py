@@ -126,6 +126,59 @@ def test_likelihood_same_for_all_nodes():
     assert abs(root_loglh - results[0][LOG_LIKELIHOOD] / np.log(10)) < 1e-9
 
 
+def reroot_tree_randomly(rng):
+    """tests/ACRParameterOptimisationMPPAF81Test.py:20-37: drop the old root, re-root on a random branch."""
+    rerooted_tree = read_tree(TREE_NWK)
+    candidates = [_ for _ in rerooted_tree.traverse() if not _.is_root() and not _.up.is_root() and _.dist]
+    new_root = candidates[rng.integers(len(candidates))]
+    old_root_child = rerooted_tree.children[0]
+    old_root_child_dist = old_root_child.dist
+    other_children = list(rerooted_tree.children[1:])
+    old_root_child.up = None
+    for child in other_children:
+        child.up = None
+        old_root_child.add_child(child, dist=old_root_child_dist + child.dist)
+    old_root_child.set_outgroup(new_root)
+    new_root = new_root.up
+    for _ in new_root.traverse():
+        if not _.name:
+            _.name = 'unknown'
+    return new_root
+
+
+def test_rerooted_values_are_the_same():
+    """
+    tests/ACRParameterOptimisationMPPAF81Test.py:51-83: optimised likelihood, scaling factor, frequencies and marginal
+    probabilities do not depend on where the root is (2 decimals, as in the reference) -- and, stricter, at fixed
+    parameters the likelihood of a reversible model is the same for every root (Felsenstein's pulley principle).
+    """
+    tree, results = albania_result(F81)
+    acr_result = results[0]
+    rng = np.random.default_rng(20)
+    for _ in range(5):
+        rerooted_tree = reroot_tree_randomly(rng)
+        rerooted_acr_result = acr(rerooted_tree, albania_df(), prediction_method=MPPA, model=F81)[0]
+        for freq, refreq in zip(acr_result[MODEL].frequencies, rerooted_acr_result[MODEL].frequencies):
+            assert round(abs(freq - refreq), 2) == 0
+        assert round(abs(acr_result[LOG_LIKELIHOOD] - rerooted_acr_result[LOG_LIKELIHOOD]), 2) == 0
+        assert round(abs(acr_result[MODEL].sf - rerooted_acr_result[MODEL].sf), 2) == 0
+        mps = acr_result[MARGINAL_PROBABILITIES]
+        remps = rerooted_acr_result[MARGINAL_PROBABILITIES]
+        for node_name in ('node_4', '02ALAY1660'):
+            for loc in acr_result[STATES]:
+                assert round(abs(mps.loc[node_name, loc] - remps.loc[node_name, loc]), 2) == 0
+
+        # fixed parameters: same tree length, so the same sf means the same process on the unrooted tree
+        fixed = {feature: {'scaling_factor': acr_result[MODEL].sf,
+                           **dict(zip(acr_result[STATES], acr_result[MODEL].frequencies))}}
+        fixed_result = acr(reroot_tree_randomly(rng), albania_df(), prediction_method=MPPA, model=F81,
+                           column2parameters=fixed)[0]
+        assert abs(fixed_result[LOG_LIKELIHOOD] - acr_result[LOG_LIKELIHOOD]) < 1e-9 * abs(acr_result[LOG_LIKELIHOOD])
+        remps = fixed_result[MARGINAL_PROBABILITIES]
+        for node_name in ('node_4', '02ALAY1660', 'node_10'):
+            np.testing.assert_allclose(remps.loc[node_name].values, mps.loc[node_name].values, rtol=1e-8, atol=1e-12)
+
+
 def test_state_selection_albania_mppa_f81():
     """tests/ACRStateMPPAF81Test.py:40-104 (on the uncollapsed tree: named nodes only)."""
     tree, _ = albania_result(F81)

@@ -180,3 +180,47 @@ def test_name_tree():
     name_tree(t)
     names = [n.name for n in t.traverse('preorder')]
     assert len(set(names)) == len(names) and names[0] == 'root' and all(names)
+
+
+def _leaf_distances(tree):
+    """{leaf name: {other leaf name: path length}} by walking to the root (small trees only)."""
+    depth = {}
+    for n in tree.traverse('preorder'):
+        depth[id(n)] = (depth[id(n.up)] + n.dist) if n.up is not None else 0.0
+    leaves = list(tree)
+    anc = {id(l): [] for l in leaves}
+    for l in leaves:
+        n = l
+        while n is not None:
+            anc[id(l)].append(n)
+            n = n.up
+    out = {}
+    for a in sorted(leaves, key=lambda l: l.name)[:12]:
+        on_path = {id(x) for x in anc[id(a)]}
+        for b in leaves:
+            lca = next(x for x in anc[id(b)] if id(x) in on_path)
+            out[(a.name, b.name)] = depth[id(a)] + depth[id(b)] - 2 * depth[id(lca)]
+    return out
+
+
+@pytest.mark.parametrize('seed', range(6))
+def test_set_outgroup_keeps_the_unrooted_tree(seed):
+    """Re-rooting (used by the re-rooting invariance test of the reference) changes the root, not the tree."""
+    tree, _ = albania()
+    before = _leaf_distances(tree)
+    total = sum(n.dist for n in tree.traverse() if n.up is not None)
+    rng = np.random.default_rng(seed)
+    candidates = [n for n in tree.traverse() if n.up is not None]
+    target = candidates[rng.integers(len(candidates))]
+    half = target.dist / 2
+    assert tree.set_outgroup(target) is tree
+    assert tree.children[0] is target and len(tree.children) == 2
+    assert target.dist == pytest.approx(half) and tree.children[1].dist == pytest.approx(half)
+    for n in tree.traverse():
+        for c in n.children:
+            assert c.up is n
+    after = _leaf_distances(tree)
+    assert set(before) == set(after)
+    for key, d in before.items():
+        assert after[key] == pytest.approx(d, abs=1e-12)
+    assert sum(n.dist for n in tree.traverse() if n.up is not None) == pytest.approx(total, abs=1e-12)
