@@ -69,6 +69,7 @@ struct pml_ctx {
     int *d_bu_offsets_f = nullptr, *d_td_parent_offsets_f = nullptr;  // level tables for the single-launch kernels
     bool small = false;  // forest small enough for the one-launch-per-sweep kernels
     std::vector<int> bu_offsets_f, td_parent_offsets_f;
+    std::vector<char> bu_level_vec_f;  // per fused bottom-up level: some unit has a stored node as child 0 or 1
     int n_cherries = 0;
     bool bu_fused = false;  // the last bottom-up sweep left the cherries unmaterialised
 
@@ -257,7 +258,10 @@ static int prof_end(pml_ctx* ctx, int which, long long launches) {
     X(64, 2)             \
     X(64, 4)
 
-enum SweepKind { SW_BU_MARG, SW_BU_JOINT, SW_TD, SW_ROOTS, SW_BU_MARG_FUSED, SW_TD_FUSED, SW_BU_CHERRIES };
+enum SweepKind {
+    SW_BU_MARG, SW_BU_JOINT, SW_TD, SW_ROOTS, SW_BU_MARG_FUSED, SW_TD_FUSED, SW_BU_CHERRIES,
+    SW_BU_MARG_FUSED_NOVEC  // a fused level none of whose units has a stored node among its first two children
+};
 
 // matrix-model sweeps: contiguous state ownership (state = g * R + r)
 template <int G, int R>
@@ -291,25 +295,31 @@ static void launch_sweep(pml_ctx* ctx, SweepKind what, const int* level, int n_l
 // F81-family sweeps: chunked state ownership (pml_kernels_f81.h), their own (G, R)
 template <int G, int R>
 static void launch_sweep_f81(pml_ctx* ctx, SweepKind what, const int* level, int n_level) {
-    const PmlTree t = tree_of(ctx, what == SW_BU_MARG_FUSED || what == SW_TD_FUSED);
+    const PmlTree t = tree_of(ctx, what == SW_BU_MARG_FUSED || what == SW_BU_MARG_FUSED_NOVEC || what == SW_TD_FUSED);
     const PmlCols c = cols_of(ctx);
     const PmlState st = state_of(ctx);
     const int upb = PML_WAVES_PER_BLOCK * (64 / G);
     dim3 grid(grid_for(n_level, upb, ctx->C), ctx->C), block(PML_BLOCK);
     // the level is given as a position in one of the node lists; the kernels read the descriptor list parallel to it
     const PmlUnit* units = nullptr;
-    if (what == SW_BU_MARG_FUSED) units = ctx->d_bu_units_f + (level - ctx->d_bu_order_f);
+    if (what == SW_BU_MARG_FUSED || what == SW_BU_MARG_FUSED_NOVEC) units = ctx->d_bu_units_f + (level - ctx->d_bu_order_f);
     if (what == SW_BU_MARG || what == SW_BU_JOINT) units = ctx->d_bu_units + (level - ctx->d_bu_order);
     if (what == SW_TD_FUSED) units = ctx->d_td_units_f + (level - ctx->d_td_parents_f);
     if (what == SW_BU_CHERRIES) units = ctx->d_cherry_units + (level - ctx->d_cherries);
     switch (what) {
         case SW_BU_MARG_FUSED:
         case SW_BU_MARG:
+            hipLaunchKernelGGL((bu_f81_kernel<G, R, false, true>), grid, block, 0, ctx->stream, t, c, st, units,
+                               n_level);
+            break;
+        case SW_BU_MARG_FUSED_NOVEC:
         case SW_BU_CHERRIES:
-            hipLaunchKernelGGL((bu_f81_kernel<G, R, false>), grid, block, 0, ctx->stream, t, c, st, units, n_level);
+            hipLaunchKernelGGL((bu_f81_kernel<G, R, false, false>), grid, block, 0, ctx->stream, t, c, st, units,
+                               n_level);
             break;
         case SW_BU_JOINT:
-            hipLaunchKernelGGL((bu_f81_kernel<G, R, true>), grid, block, 0, ctx->stream, t, c, st, units, n_level);
+            hipLaunchKernelGGL((bu_f81_kernel<G, R, true, true>), grid, block, 0, ctx->stream, t, c, st, units,
+                               n_level);
             break;
         case SW_TD_FUSED:
             hipLaunchKernelGGL((td_f81_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, units, n_level);
@@ -660,7 +670,7 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
                     u.pad = 0;
                     const int nc = n_children[n];
                     int packed = nc < 15 ? nc : 15;
-                    bool cherries_ok = true;
+                    bool cherries_ok = true, stored_first_two_only = true;
                     for (int j = 0; j < 4; ++j) {
                         u.cfc[j] = 0;
                         if (j >= nc) continue;
@@ -677,8 +687,10 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
                             }
                         }
                         packed |= code << (8 + 3 * j);
+                        if (j >= 2 && code == 1) stored_first_two_only = false;
                     }
                     if (cherries_ok) packed |= 1 << 4;
+                    if (stored_first_two_only) packed |= 1 << 5;
                     u.packed = packed;
                     out[q] = u;
                 }
@@ -689,6 +701,12 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
             PML_TRY(dev_alloc(ctx, &ctx->d_cherry_units, uc.size()));
             PML_TRY(upload(ctx, ctx->d_cherry_units, uc.data(), uc.size()));
             describe(order.data(), n_stored, true, ub_f);
+            ctx->bu_level_vec_f.assign(max_h > 0 ? max_h : 1, 0);
+            for (int l = 0; l < max_h; ++l)
+                for (int q = off[l]; q < off[l + 1] && !ctx->bu_level_vec_f[l]; ++q) {
+                    const int pk = ub_f[q].packed;
+                    if (((pk >> 8) & 7) == 1 || ((pk >> 11) & 7) == 1) ctx->bu_level_vec_f[l] = 1;
+                }
             describe(tdp.data(), n_stored, true, ut_f);
             describe(bu_order, n_internal, false, ub);
             PML_TRY(dev_alloc(ctx, &ctx->d_bu_units_f, ub_f.size()));
@@ -1117,7 +1135,8 @@ static int enqueue_bottom_up(pml_ctx* ctx, int is_marginal, bool small_path, boo
         const int nl = (int)ctx->bu_offsets_f.size() - 1;
         for (int l = 0; l < nl; ++l) {
             const int a = ctx->bu_offsets_f[l], b = ctx->bu_offsets_f[l + 1];
-            PML_TRY(dispatch_sweep(ctx, SW_BU_MARG_FUSED, ctx->d_bu_order_f + a, b - a));
+            PML_TRY(dispatch_sweep(ctx, ctx->bu_level_vec_f[l] ? SW_BU_MARG_FUSED : SW_BU_MARG_FUSED_NOVEC,
+                                   ctx->d_bu_order_f + a, b - a));
         }
         PML_TRY(prof_end(ctx, 0, nl));
     } else {

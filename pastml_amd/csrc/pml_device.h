@@ -17,12 +17,14 @@ typedef long long i64;
 
 // lazy rescaling band: a vector is renormalised (max -> [1, 2)) when a non-zero entry leaves [2^-200, 2^200]
 
-// lane exchange inside a 16-lane row by a DPP modifier (VALU only, no LDS crossbar)
+// lane exchange inside a 16-lane row by a DPP modifier (VALU only, no LDS crossbar).  Every permutation used here
+// reads a lane of the same unit, and the lanes of a unit are always active together, so no lane ever needs the "old"
+// value: bound_ctrl lets the compiler drop the two copies that would otherwise initialise the destination.
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 

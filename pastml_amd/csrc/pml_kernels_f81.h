@@ -92,10 +92,11 @@ f81_prep_kernel(PmlTree t, PmlCols c, const double* __restrict__ mu, const doubl
 // every q the G lanes of a unit read one contiguous run of 2G doubles with 16-byte lane loads (R = 1: state g).
 template <int G, int R>
 struct LaneCtx {
-    int col, g, group_base;
+    int col, g, group_base, k;
     double pi_r[R];
     double ipi_r[R];  // 1 / pi (0 where pi = 0): turns a stored posterior back into TD o BU (top-down sweep)
     const u64* mask;
+    const double* pi;  // the column's frequency vector (ks doubles)
     const double* E;
     double* S;
     i64* be;
@@ -113,10 +114,12 @@ __device__ __forceinline__ void lane_ctx_init(LaneCtx<G, R>& L, const PmlTree& t
                                               const PmlState& st) {
     const int lane = threadIdx.x & 63;
     L.col = blockIdx.y;
+    L.k = c.k;
     L.g = lane & (G - 1);
     L.group_base = lane & ~(G - 1);
     const size_t colN = (size_t)L.col * t.N;
     L.mask = c.masks + colN * c.W;
+    L.pi = c.pi + (size_t)L.col * c.ks;
     L.E = st.E + colN;
     L.S = st.S + colN;
     L.be = st.be + colN;
@@ -151,14 +154,24 @@ __device__ __forceinline__ void f81_parent_prod(const LaneCtx<G, R>& L, const Pm
 
 __device__ __forceinline__ u64 state_bits(int k) { return k >= 64 ? ~0ull : (1ull << k) - 1ull; }
 
-// 0/1 vector of the lane's states from a single mask word (k <= 64, hence G * R <= 64): one 64-bit shift per state
-// pair, then bit b -> (0 or 0x3FF00000) as the high word of the double -- no compares, no selects.
+// 0/1 vector of the lane's states from a single mask word (k <= 64, hence G * R <= 64) whose bits >= k are clear:
+// bit b -> (0 or 0x3FF00000) as the high word of the double by one signed bit-field extract and one AND -- no
+// compares, no selects.  For G <= 16 a state pair never straddles the two halves of the word (2G divides 32), so the
+// half is known at compile time and no 64-bit shift is needed.
 template <int G, int R>
-__device__ __forceinline__ void word_to_vec(const LaneCtx<G, R>& L, const PmlCols& c, u64 word, double (&v)[R]) {
+__device__ __forceinline__ void clean_word_to_vec(const LaneCtx<G, R>& L, const PmlCols& c, u64 w, double (&v)[R]) {
     if (R == 1) {
-        v[0] = (L.g < c.k && ((word >> (L.g & 63)) & 1ull)) ? 1.0 : 0.0;
+        v[0] = (L.g < c.k && ((w >> (L.g & 63)) & 1ull)) ? 1.0 : 0.0;
+    } else if (G <= 16) {
+        const int lo = (int)(unsigned)w, hi = (int)(unsigned)(w >> 32);
+#pragma unroll
+        for (int q = 0; q < R / 2; ++q) {
+            const int half = ((2 * G * q) & 32) ? hi : lo;
+            const unsigned sh = (unsigned)(((2 * G * q) & 31) + 2 * L.g);
+            v[2 * q] = __hiloint2double(__builtin_amdgcn_sbfe(half, sh, 1u) & 0x3FF00000, 0);
+            v[2 * q + 1] = __hiloint2double(__builtin_amdgcn_sbfe(half, sh + 1u, 1u) & 0x3FF00000, 0);
+        }
     } else {
-        const u64 w = word & state_bits(c.k);
 #pragma unroll
         for (int q = 0; q < R / 2; ++q) {
             const unsigned t = (unsigned)(w >> ((2 * G * q + 2 * L.g) & 63));
@@ -166,6 +179,11 @@ __device__ __forceinline__ void word_to_vec(const LaneCtx<G, R>& L, const PmlCol
             v[2 * q + 1] = __hiloint2double(((int)(t << 30) >> 31) & 0x3FF00000, 0);
         }
     }
+}
+
+template <int G, int R>
+__device__ __forceinline__ void word_to_vec(const LaneCtx<G, R>& L, const PmlCols& c, u64 word, double (&v)[R]) {
+    clean_word_to_vec<G, R>(L, c, word & state_bits(c.k), v);
 }
 
 template <int G, int R>
@@ -298,7 +316,7 @@ __device__ __forceinline__ void f81_cherry_vector(const LaneCtx<G, R>& L, const 
 template <int G>
 struct Gather {
     static constexpr int GC = 4;
-    static constexpr int CH = (G / 4 < 8) ? G / 4 : 8;
+    static constexpr int CH = (G / 4 < 4) ? G / 4 : 4;  // the descriptor codes the first four children
     static constexpr bool enabled = G >= 8;
 };
 
@@ -306,7 +324,9 @@ struct Gather {
 // a unit needs, so that all data loads of a unit can be issued in one round trip (and the descriptor of the wave's next
 // unit is fetched while the current one is computed) instead of chasing n -> first_child -> children -> their children.
 //   packed: bits 0-3 number of children (15 = 15 or more), bit 4 = every cherry among the first four children has
-//           1..GC tips, bits 8+3j..10+3j (j < 4) code of child j: 0 tip, 1 stored internal node, 2+m cherry with m+1 tips
+//           1..GC tips, bit 5 = no stored internal node among children 2 and 3 (the bottom-up pipeline prefetches the
+//           vectors of children 0 and 1), bits 8+3j..10+3j (j < 4) code of child j: 0 tip, 1 stored internal node,
+//           2+m cherry with m+1 tips
 //   cfc[j]: first child of child j (j < 4), i.e. where the tips of a cherry child start
 struct __attribute__((aligned(32))) PmlUnit {
     int n, fc, packed, pad;
@@ -334,7 +354,14 @@ template <int G>
 __device__ __forceinline__ bool unit_is_fast(int packed) {
     return unit_nc(packed) <= Gather<G>::CH && ((packed >> 4) & 1);
 }
+template <int G, bool VEC>
+__device__ __forceinline__ bool unit_is_fast_bu(int packed) {
+    if (!VEC && (unit_code(packed, 0) == 1 || unit_code(packed, 1) == 1)) return false;  // vectors are not prefetched
+    return unit_nc(packed) <= Gather<G>::CH && ((packed >> 4) & 3) == 3;
+}
 
+// The mask words are stripped of their bits >= k when gathered, and the constant part a = (1 - e) S of a message
+// (1 - e) S + e v is formed by the lane that owns the data, before the broadcast, instead of by every lane after it.
 struct ChildLane {  // what lane j holds about child j
     double e, s;
     u64 mask;
@@ -342,12 +369,13 @@ struct ChildLane {  // what lane j holds about child j
 };
 
 struct TipLane {  // what lane j * GC + q holds about tip q of cherry child j
-    double e, s;
+    double e, s, a;
     u64 mask;
 };
 
 template <int G, int R>
-__device__ __forceinline__ void f81_gather(const LaneCtx<G, R>& L, const UnitRegs& u, ChildLane& cl, TipLane& tl) {
+__device__ __forceinline__ void f81_gather_issue(const LaneCtx<G, R>& L, const UnitRegs& u, ChildLane& cl,
+                                                 TipLane& tl) {
     constexpr int GC = Gather<G>::GC;
     const int nc = unit_nc(u.packed);
     const int j = L.g;
@@ -365,44 +393,104 @@ __device__ __forceinline__ void f81_gather(const LaneCtx<G, R>& L, const UnitReg
     tl.mask = L.mask[(unsigned)tip];
 }
 
-// cherry child jx of the unit rebuilt from the gathered tip data; same operation order as f81_cherry_vector
+// the part of the gather that needs the loaded values (kept apart so that the loads can be issued one unit ahead)
 template <int G, int R>
-__device__ __forceinline__ void f81_cherry_from_lanes(const LaneCtx<G, R>& L, const PmlTree& t, const PmlCols& c,
-                                                      const PmlState& st, const ChildLane& cl, const TipLane& tl,
-                                                      int jx, int cherry, int cfc, int cnc, double (&v)[R], i64& esum,
-                                                      bool report) {
+__device__ __forceinline__ void f81_gather_finish(const LaneCtx<G, R>& L, ChildLane& cl, TipLane& tl) {
+    const u64 kbits = state_bits(L.k);
+    cl.mask &= kbits;
+    tl.a = (1.0 - tl.e) * tl.s;
+    tl.mask &= kbits;
+}
+
+template <int G, int R>
+__device__ __forceinline__ void f81_gather(const LaneCtx<G, R>& L, const UnitRegs& u, ChildLane& cl, TipLane& tl) {
+    f81_gather_issue<G, R>(L, u, cl, tl);
+    f81_gather_finish<G, R>(L, cl, tl);
+}
+
+// cherry child jx of the unit rebuilt from the gathered tip data; same operations in the same order as
+// f81_cherry_vector.  Band check: every factor of a non-zero entry is a_q or a_q + e_q <= 1 with a_q = (1 - e_q) S_q,
+// so the non-zero entries lie in [prod a_q, 1]: when that product is >= 2^-200 (the usual case; one multiplication per
+// tip) nothing can have left the band and the per-state test is skipped -- lazy_rescale would have returned 0.
+template <int G, int R>
+__device__ __forceinline__ void f81_cherry_from_lanes(const LaneCtx<G, R>& L, const PmlCols& c, const ChildLane& cl,
+                                                      const TipLane& tl, int jx, int cnc, double (&v)[R], i64& esum) {
     constexpr int GC = Gather<G>::GC;
     const int src = L.group_base + jx;
-    const u64 word = __shfl(cl.mask, src, 64);
-    word_to_vec<G, R>(L, c, word, v);
+    clean_word_to_vec<G, R>(L, c, __shfl(cl.mask, src, 64), v);
     esum = 0;
-    for (int q = 0; q < cnc; ++q) {
+    double amin = 1.0;
+    for (int q = 0; q < cnc; ++q) {  // cnc <= GC = 4: one band check, after the last tip
         const int ts = L.group_base + jx * GC + q;
-        const u64 tw = __shfl(tl.mask, ts, 64);
         double tv[R];
-        word_to_vec<G, R>(L, c, tw, tv);
-        f81_absorb_child<G, R>(L, t, st, cherry, cfc + q, __shfl(tl.e, ts, 64), __shfl(tl.s, ts, 64), tv, v, report);
-        if ((q & 3) == 3 || q == cnc - 1) esum += lazy_rescale<G, R>(v);
+        clean_word_to_vec<G, R>(L, c, __shfl(tl.mask, ts, 64), tv);
+        const double e = __shfl(tl.e, ts, 64);
+        const double a = __shfl(tl.a, ts, 64);
+        amin *= a;
+#pragma unroll
+        for (int r = 0; r < R; ++r) v[r] *= a + e * tv[r];
+    }
+    if (!(amin >= 0x1p-200)) esum = lazy_rescale<G, R>(v);
+}
+
+// Everything a fast bottom-up unit reads, as issued loads: the gathered scalars, the unit's own mask word and the
+// vectors of its first two children where those are stored nodes.  Filled one unit ahead by the level kernel (software
+// pipeline: the loads of unit i + 1 are in flight while unit i is computed), on the spot elsewhere.
+template <int R>
+struct BuLoads {
+    ChildLane cl;
+    TipLane tl;
+    u64 own;
+    double v0[R], v1[R];
+};
+
+// Valid for every descriptor (fast or not): all addresses are those of existing nodes.  The number of loads is the
+// same for every unit (VEC: a child that is not a stored node reads the column's frequency vector instead, a cache
+// hit), so that the compiler can wait for exactly the loads of one unit while those of the next stay in flight.
+// VEC = false is for levels without stored children (the level that rebuilds cherries): no vector loads at all.
+template <int G, int R, bool VEC>
+__device__ __forceinline__ void bu_f81_issue(const LaneCtx<G, R>& L, const PmlCols& c, const UnitRegs& u,
+                                             BuLoads<R>& ld) {
+    f81_gather_issue<G, R>(L, u, ld.cl, ld.tl);
+    ld.own = L.mask[(unsigned)u.n];
+    if (VEC) {
+        const bool s0 = unit_code(u.packed, 0) == 1, s1 = unit_nc(u.packed) > 1 && unit_code(u.packed, 1) == 1;
+        node_load_vec<G, R>(L, c, s0 ? L.bu : L.pi, s0 ? u.fc : 0, ld.v0);
+        node_load_vec<G, R>(L, c, s1 ? L.bu : L.pi, s1 ? u.fc + 1 : 0, ld.v1);
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) ld.v0[r] = ld.v1[r] = 0.0;
+    }
+}
+
+// Makes every value of ld available here: the compiler places ONE s_waitcnt with the right count at this point (the
+// loads issued after ld's -- the next unit's -- stay in flight) instead of conservative vmcnt(0) waits wherever the
+// unit's control flow first touches a value.
+template <int R, bool VEC>
+__device__ __forceinline__ void bu_loads_arrived(BuLoads<R>& ld) {
+    asm volatile("" : "+v"(ld.cl.e), "+v"(ld.cl.s), "+v"(ld.cl.mask), "+v"(ld.cl.be), "+v"(ld.tl.e), "+v"(ld.tl.s),
+                      "+v"(ld.tl.mask), "+v"(ld.own));
+    if (VEC) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) asm volatile("" : "+v"(ld.v0[r]), "+v"(ld.v1[r]));
     }
 }
 
 // Returns false when the unit's vector came out all zero: a product only ever gains zeros, so the zero check of
 // ml.py:139-145 is made once at the end, and the caller repeats the unit on the sequential path, which checks after
 // every child and reports the pair the reference would name.
-template <int G, int R>
+template <int G, int R, bool VEC>
 __device__ __forceinline__ bool bu_f81_unit_fast(const LaneCtx<G, R>& L, const PmlTree& t, const PmlCols& c,
-                                                 const PmlState& st, const UnitRegs& u) {
-    constexpr int GC = Gather<G>::GC;
+                                                 const PmlState& st, const UnitRegs& u, BuLoads<R>& ld) {
     const int n = u.n, fc = u.fc;
     const int nc = unit_nc(u.packed);
+    bu_loads_arrived<R, VEC>(ld);
     double acc[R];
-    word_to_vec<G, R>(L, c, L.mask[(unsigned)n], acc);
-    ChildLane cl;
-    TipLane tl;
-    f81_gather<G, R>(L, u, cl, tl);
+    word_to_vec<G, R>(L, c, ld.own, acc);
+    ChildLane& cl = ld.cl;
+    TipLane& tl = ld.tl;
+    f81_gather_finish<G, R>(L, cl, tl);
     i64 esum = 0;
-    double vn[R];
-    if (unit_code(u.packed, 0) == 1) node_load_vec<G, R>(L, c, L.bu, fc, vn);
     for (int jx = 0; jx < nc; ++jx) {
         const int src = L.group_base + jx;
         const int ch = fc + jx;
@@ -410,22 +498,17 @@ __device__ __forceinline__ bool bu_f81_unit_fast(const LaneCtx<G, R>& L, const P
         const double e = __shfl(cl.e, src, 64);
         double v[R];
         double s_child;
-        if (code == 1) {
-#pragma unroll
-            for (int r = 0; r < R; ++r) v[r] = vn[r];
-        }
-        if (jx + 1 < nc && unit_code(u.packed, jx + 1) == 1) node_load_vec<G, R>(L, c, L.bu, ch + 1, vn);
         if (code == 0) {
-            const u64 word = __shfl(cl.mask, src, 64);
-            word_to_vec<G, R>(L, c, word, v);
+            clean_word_to_vec<G, R>(L, c, __shfl(cl.mask, src, 64), v);
             s_child = __shfl(cl.s, src, 64);
         } else if (code == 1) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) v[r] = jx == 0 ? ld.v0[r] : ld.v1[r];  // unit_is_fast_bu: jx < 2 here
             esum += __shfl(cl.be, src, 64);
             s_child = __shfl(cl.s, src, 64);
         } else {
             i64 ce;
-            const int cfc = __shfl(u.cfc, L.group_base + jx * GC, 64);
-            f81_cherry_from_lanes<G, R>(L, t, c, st, cl, tl, jx, ch, cfc, code - 1, v, ce, false);
+            f81_cherry_from_lanes<G, R>(L, c, cl, tl, jx, code - 1, v, ce);
             esum += ce;
             s_child = pi_dot<G, R>(L, v);
             if (L.g == 0) L.S[ch] = s_child;  // 8 bytes kept for the top-down sweep (saves its reduction there)
@@ -433,17 +516,24 @@ __device__ __forceinline__ bool bu_f81_unit_fast(const LaneCtx<G, R>& L, const P
         f81_absorb_child<G, R>(L, t, st, n, ch, e, s_child, v, acc, false);
         if ((jx & 1) == 1 || jx == nc - 1) esum += lazy_rescale<G, R>(acc);
     }
-    bool nz = false;
-#pragma unroll
-    for (int r = 0; r < R; ++r) nz |= acc[r] != 0.0 && L.st(r) < c.k;
-    if (!group_any<G>(nz)) return false;
     const double s = pi_dot<G, R>(L, acc);
+    if (!(s > 0.0)) {  // pi . acc > 0 already says that acc is not all zero
+        bool nz = false;
+#pragma unroll
+        for (int r = 0; r < R; ++r) nz |= acc[r] != 0.0 && L.st(r) < c.k;
+        if (!group_any<G>(nz)) return false;
+    }
     if (L.g == 0) {
         L.S[n] = s;
         L.be[n] = esum;
     }
     node_store_vec<G, R>(L, c, L.bu, n, acc);
     return true;
+}
+
+template <int G, int R, bool JOINT>
+__device__ __forceinline__ bool bu_f81_unit_is_fast(const PmlCols& c, const UnitRegs& u) {
+    return !JOINT && Gather<G>::enabled && c.W == 1 && unit_is_fast_bu<G, true>(u.packed);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -453,11 +543,24 @@ __device__ __forceinline__ bool bu_f81_unit_fast(const LaneCtx<G, R>& L, const P
 // ---------------------------------------------------------------------------------------------------------------------
 // One bottom-up unit: node n of the current level, this lane group's column.
 template <int G, int R, bool JOINT>
+__device__ __forceinline__ void bu_f81_unit_seq(const LaneCtx<G, R>& L, const PmlTree& t, const PmlCols& c,
+                                                const PmlState& st, const UnitRegs& u);
+
+template <int G, int R, bool JOINT>
 __device__ __forceinline__ void bu_f81_unit(const LaneCtx<G, R>& L, const PmlTree& t, const PmlCols& c,
                                             const PmlState& st, const UnitRegs& u) {
-    if (!JOINT && Gather<G>::enabled && c.W == 1 && unit_is_fast<G>(u.packed)) {
-        if (bu_f81_unit_fast<G, R>(L, t, c, st, u)) return;
+    if (bu_f81_unit_is_fast<G, R, JOINT>(c, u)) {
+        BuLoads<R> ld;
+        bu_f81_issue<G, R, true>(L, c, u, ld);
+        if (bu_f81_unit_fast<G, R, true>(L, t, c, st, u, ld)) return;
     }
+    bu_f81_unit_seq<G, R, JOINT>(L, t, c, st, u);
+}
+
+// the sequential path: any number of children, multi-word masks, the joint variant, per-child zero check
+template <int G, int R, bool JOINT>
+__device__ __forceinline__ void bu_f81_unit_seq(const LaneCtx<G, R>& L, const PmlTree& t, const PmlCols& c,
+                                                const PmlState& st, const UnitRegs& u) {
     const int n = u.n;
 
     double acc[R];
@@ -589,8 +692,13 @@ __device__ __forceinline__ void bu_f81_unit(const LaneCtx<G, R>& L, const PmlTre
     if (L.g == 0) L.be[n] = esum;
 }
 
-template <int G, int R, bool JOINT>
-__global__ void __launch_bounds__(PML_BLOCK) __attribute__((amdgpu_waves_per_eu(R >= 8 ? 2 : 4, R >= 8 ? 2 : 4)))
+// Level kernel.  Marginal sweeps with the lane-parallel gather run a two-stage software pipeline per wave: while unit i
+// is computed, every load of unit i + 1 (scalars, own mask, stored children's vectors) and the descriptor of unit
+// i + 2 are in flight, so a wave waits for memory once per sweep of its units instead of once per unit (the level that
+// rebuilds cherries spent 65 % of its wave cycles in s_waitcnt before).  The two halves of the loop body ping-pong
+// between two register sets instead of copying one into the other.
+template <int G, int R, bool JOINT, bool VEC>
+__global__ void __launch_bounds__(PML_BLOCK) __attribute__((amdgpu_waves_per_eu(R >= 8 ? 2 : 3, R >= 8 ? 2 : 4)))
 bu_f81_kernel(PmlTree t, PmlCols c, PmlState st, const PmlUnit* __restrict__ units, int n_level) {
     constexpr int UW = 64 / G;  // units per wave
     const int wave = threadIdx.x >> 6;
@@ -599,9 +707,43 @@ bu_f81_kernel(PmlTree t, PmlCols c, PmlState st, const PmlUnit* __restrict__ uni
     lane_ctx_init<G, R>(L, t, c, st);
     const int stride = gridDim.x * PML_WAVES_PER_BLOCK * UW;
     int idx = (blockIdx.x * PML_WAVES_PER_BLOCK + wave) * UW + sub;
+    int base = idx - sub;  // wave-uniform trip count; whole groups drop out together
+    if (!JOINT && Gather<G>::enabled && c.W == 1) {
+        UnitRegs ua = load_unit<G>(units, idx < n_level ? idx : 0, L.g);
+        UnitRegs ub = load_unit<G>(units, idx + stride < n_level ? idx + stride : 0, L.g);
+        BuLoads<R> la, lb;
+        bu_f81_issue<G, R, VEC>(L, c, ua, la);
+        while (base < n_level) {
+            {  // compute a; loads of b and the descriptor after b in flight
+                const int i2 = idx + 2 * stride;
+                const UnitRegs un = load_unit<G>(units, i2 < n_level ? i2 : 0, L.g);
+                bu_f81_issue<G, R, VEC>(L, c, ub, lb);
+                if (idx < n_level) {
+                    if (!unit_is_fast_bu<G, VEC>(ua.packed) || !bu_f81_unit_fast<G, R, VEC>(L, t, c, st, ua, la))
+                        bu_f81_unit_seq<G, R, false>(L, t, c, st, ua);
+                }
+                ua = un;
+                idx += stride;
+                base += stride;
+            }
+            if (base >= n_level) break;
+            {  // compute b; loads of a (the unit after b) in flight
+                const int i2 = idx + 2 * stride;
+                const UnitRegs un = load_unit<G>(units, i2 < n_level ? i2 : 0, L.g);
+                bu_f81_issue<G, R, VEC>(L, c, ua, la);
+                if (idx < n_level) {
+                    if (!unit_is_fast_bu<G, VEC>(ub.packed) || !bu_f81_unit_fast<G, R, VEC>(L, t, c, st, ub, lb))
+                        bu_f81_unit_seq<G, R, false>(L, t, c, st, ub);
+                }
+                ub = un;
+                idx += stride;
+                base += stride;
+            }
+        }
+        return;
+    }
     UnitRegs cur = load_unit<G>(units, idx < n_level ? idx : 0, L.g);
-    // wave-uniform trip count; whole groups drop out together; the next descriptor is in flight during the unit
-    for (int base = idx - sub; base < n_level; base += stride) {
+    for (; base < n_level; base += stride) {  // the next descriptor is in flight during the unit
         const int nxt_idx = idx + stride;
         const UnitRegs nxt = load_unit<G>(units, nxt_idx < n_level ? nxt_idx : 0, L.g);
         if (idx < n_level) bu_f81_unit<G, R, JOINT>(L, t, c, st, cur);
@@ -673,7 +815,7 @@ __device__ __forceinline__ void f81_finish_child(const LaneCtx<G, R>& L, const P
 // pi . X = (P - pi_s prod_s) / c0 + pi_s prod_s / c1 with P = pi . prod (computed once per parent), the tip's
 // TD_s = (1 - e) pi . X + e prod_s / c1, its marginal likelihood vector is TD_s pi_s at s and 0 elsewhere, and its
 // posterior is exactly the unit vector (what lh / lh.sum() gives in the reference, ml.py:500).
-// Observed-tip closed form / general tip, given the tip's data (single mask word: k <= 64).
+// Observed-tip closed form / general tip, given the tip's data (single mask word without bits >= k: k <= 64).
 template <int G, int R>
 __device__ __forceinline__ void f81_finish_tip_word(const LaneCtx<G, R>& L, const PmlCols& c, const double (&prod)[R],
                                                     i64 pe, double& P, bool& have_P, int tip, u64 word, double e,
@@ -685,7 +827,7 @@ __device__ __forceinline__ void f81_finish_tip_word(const LaneCtx<G, R>& L, cons
         }
         // unit vector of the observed state: the posterior, and the tool that picks prod_s (sum of zeros and one term)
         double oh[R];
-        word_to_vec<G, R>(L, c, word, oh);
+        clean_word_to_vec<G, R>(L, c, word, oh);
         double pick = 0.0;
 #pragma unroll
         for (int r = 0; r < R; ++r) pick = fma(oh[r], prod[r], pick);
@@ -711,7 +853,7 @@ __device__ __forceinline__ void f81_finish_tip_word(const LaneCtx<G, R>& L, cons
         }
     } else {
         double mt[R], tdt[R], pt[R], lt;
-        word_to_vec<G, R>(L, c, word, mt);
+        clean_word_to_vec<G, R>(L, c, word, mt);
         i64 xt, et;
         f81_finish_child<G, R>(L, c, prod, pe, tip, e, pis, 0, mt, false, mt, tdt, xt, pt, lt, et);
     }
@@ -728,7 +870,7 @@ __device__ __forceinline__ void f81_finish_tip(const LaneCtx<G, R>& L, const Pml
     const double e = L.E[tip];
     const double pis = L.S[tip];
     if (c.W == 1) {
-        f81_finish_tip_word<G, R>(L, c, prod, pe, P, have_P, tip, L.mask[(unsigned)tip], e, pis);
+        f81_finish_tip_word<G, R>(L, c, prod, pe, P, have_P, tip, L.mask[(unsigned)tip] & state_bits(c.k), e, pis);
     } else {
         // k > 64: general path (the closed form above would need the state's word; not worth a special case)
         double mt[R], tdt[R], pt[R], lt;
@@ -771,8 +913,8 @@ __device__ __forceinline__ void td_f81_unit_fast(const LaneCtx<G, R>& L, const P
             continue;
         }
         double mb[R], tdc[R], po[R], ls;
-        const bool full = (word & state_bits(c.k)) == state_bits(c.k);
-        if (!full) word_to_vec<G, R>(L, c, word, mb);
+        const bool full = word == state_bits(c.k);
+        if (!full) clean_word_to_vec<G, R>(L, c, word, mb);
         i64 xe, le;
         if (code == 1) {
             f81_finish_child<G, R>(L, c, prod, pe, ch, e, __shfl(cl.s, src, 64), __shfl(cl.be, src, 64), v, full, mb,
@@ -785,7 +927,7 @@ __device__ __forceinline__ void td_f81_unit_fast(const LaneCtx<G, R>& L, const P
             i64 bec;
             const int cfc = __shfl(u.cfc, L.group_base + jx * GC, 64);
             const int cnc = code - 1;
-            f81_cherry_from_lanes<G, R>(L, t, c, st, cl, tl, jx, ch, cfc, cnc, v, bec, false);
+            f81_cherry_from_lanes<G, R>(L, c, cl, tl, jx, cnc, v, bec);
             const double s_child = __shfl(cl.s, src, 64);  // pi . v, stored by the bottom-up sweep
             f81_finish_child<G, R>(L, c, prod, pe, ch, e, s_child, bec, v, full, mb, tdc, xe, po, ls, le);
             // same rounding as f81_parent_prod, so that the schedule without cherry fusion gives the same bits
