@@ -159,9 +159,13 @@ static void pick_group(int k, int& G, int& R) {
     while (G < need) G <<= 1;
 }
 
-static int grid_for(int n_units, int units_per_block, int C) {
+// Blocks along x for a level of n_units units per column (grid-stride loops take the rest).  The cap on the total
+// number of blocks was measured on cfg4 (MI355X): the pipelined bottom-up kernels like ~8192 (a wave then walks several
+// units and its prefetch stage pays off), everything else 32768; persistent-size grids (768-2048) were 5-15 % slower.
+static int grid_for(int n_units, int units_per_block, int C, bool pipelined = false) {
     int blocks = (n_units + units_per_block - 1) / units_per_block;
-    static const int total_cap = getenv("PASTML_HIP_GRID_CAP") ? atoi(getenv("PASTML_HIP_GRID_CAP")) : 32768;
+    static const int cap_env = getenv("PASTML_HIP_GRID_CAP") ? atoi(getenv("PASTML_HIP_GRID_CAP")) : 0;
+    const int total_cap = cap_env > 0 ? cap_env : (pipelined ? 8192 : 32768);
     int cap = total_cap / (C < 1 ? 1 : C);
     if (cap < 8) cap = 8;
     if (blocks > cap) blocks = cap;
@@ -299,7 +303,9 @@ static void launch_sweep_f81(pml_ctx* ctx, SweepKind what, const int* level, int
     const PmlCols c = cols_of(ctx);
     const PmlState st = state_of(ctx);
     const int upb = PML_WAVES_PER_BLOCK * (64 / G);
-    dim3 grid(grid_for(n_level, upb, ctx->C), ctx->C), block(PML_BLOCK);
+    const bool pipelined = what == SW_BU_MARG_FUSED || what == SW_BU_MARG_FUSED_NOVEC || what == SW_BU_MARG ||
+                           what == SW_BU_CHERRIES;
+    dim3 grid(grid_for(n_level, upb, ctx->C, pipelined), ctx->C), block(PML_BLOCK);
     // the level is given as a position in one of the node lists; the kernels read the descriptor list parallel to it
     const PmlUnit* units = nullptr;
     if (what == SW_BU_MARG_FUSED || what == SW_BU_MARG_FUSED_NOVEC) units = ctx->d_bu_units_f + (level - ctx->d_bu_order_f);
