@@ -74,10 +74,30 @@ __device__ __forceinline__ double rcp1(double x) {
     return fma(r, e, r);
 }
 
+__device__ __forceinline__ double row_pair_max(double v) {
+    const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return fmax(__hiloint2double(b[0], a[0]), __hiloint2double(b[1], a[1]));
+}
+
+__device__ __forceinline__ double half_pair_max(double v) {
+    const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return fmax(__hiloint2double(b[0], a[0]), __hiloint2double(b[1], a[1]));
+}
+
+// Max over the G lanes of a unit, result in every lane: same lane exchanges as group_sum (no index arithmetic and no
+// LDS crossbar, unlike __shfl_xor, whose address computation the compiler hoists into the common path).
 template <int G>
 __device__ __forceinline__ double group_max(double v) {
-#pragma unroll
-    for (int o = G / 2; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    if (G >= 2) v = fmax(v, dpp_f64<0xB1>(v));
+    if (G >= 4) v = fmax(v, dpp_f64<0x4E>(v));
+    if (G >= 8) v = fmax(v, dpp_f64<0x141>(v));
+    if (G >= 16) v = fmax(v, dpp_f64<0x140>(v));
+    if (G >= 32) v = row_pair_max(v);
+    if (G >= 64) v = half_pair_max(v);
     return v;
 }
 
