@@ -45,31 +45,61 @@ def parse_args():
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--cpu-baseline-levels', type=int, default=None,
                    help='tree levels of the subtree the CPU baseline is timed on (default: about 15 s of work)')
+    p.add_argument('--cpu-baseline-cores', type=int, default=None,
+                   help='worker processes of the CPU baseline (default: the cores this process may run on, at most 16)')
     return p.parse_args()
 
 
-def cpu_baseline(k, levels, model):
-    """
-    PastML-style numpy CPU path (oracle/pastml_oracle.py, the per-node restatement of pastml/ml.py) timed on this
-    box's host cores: one character of the same workload on a balanced subtree, full marginal pass, one thread.
-    """
+def _cpu_baseline_one(job):
+    """One character of the workload on a balanced subtree through the oracle (runs in a worker process: numpy only)."""
+    k, levels, model, char = job
     from oracle import pastml_oracle as orc
     from pastml_amd import synthetic
     flat = synthetic.balanced_forest(levels)
     if model == 'JC':
         spec = dict(kind=0, pi=np.ones(k) / k)
     else:
-        spec = dict(kind=0, pi=synthetic.f81_frequencies(k, 0))
-    masks = synthetic.one_hot_masks(flat, k, synthetic.tip_states(flat.n_tips, k, 0)).astype(int)
+        spec = dict(kind=0, pi=synthetic.f81_frequencies(k, char))
+    masks = synthetic.one_hot_masks(flat, k, synthetic.tip_states(flat.n_tips, k, char)).astype(int)
     t0 = time.perf_counter()
     r = orc.full_marginal_pass(flat, masks, spec)
-    dt = time.perf_counter() - t0
-    units = flat.n_nodes * k
-    return dict(value=units / dt, unit='node*state*char/s', cores=1, kind='port',
-                sample='1 character, balanced {}-tip tree ({} nodes), k={}, full marginal pass (BU+TD+posteriors), '
-                       'numpy per-node port of pastml/ml.py, {:.1f} s on 1 of {} host cores'
-                       .format(flat.n_tips, flat.n_nodes, k, dt, os.cpu_count()),
-                seconds=dt, us_per_node=dt / flat.n_nodes * 1e6, loglik=float(r['loglik']))
+    return time.perf_counter() - t0, flat.n_nodes, flat.n_tips, float(r['loglik'])
+
+
+def cpu_baseline(k, levels, model, cores=None):
+    """
+    PastML-style numpy CPU path (oracle/pastml_oracle.py, the per-node restatement of pastml/ml.py) timed on this
+    box's host cores.  Two figures on a bounded sample of the same workload (full marginal pass of one character per
+    task on a balanced subtree): one thread, and a pool of `cores` worker processes with one character each, which
+    is how the reference spreads characters (acr.py:210-231; it uses threads, processes are the kinder reading).
+    """
+    import multiprocessing as mp
+    dt1, n_nodes, n_tips, lnl = _cpu_baseline_one((k, levels, model, 0))
+    single = n_nodes * k / dt1
+    if cores is None:
+        # a 1-GPU box gives us 16 of the host's cores (os.cpu_count() reports all of them)
+        cores = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else os.cpu_count()))
+    out = dict(value=single, unit='node*state*char/s', cores=1, kind='port',
+               sample='1 character, balanced {}-tip tree ({} nodes), k={}, full marginal pass (BU+TD+posteriors), '
+                      'numpy per-node port of pastml/ml.py, {:.1f} s on 1 of {} host cores'
+                      .format(n_tips, n_nodes, k, dt1, os.cpu_count()),
+               seconds=dt1, us_per_node=dt1 / n_nodes * 1e6, loglik=lnl, single_core_value=single)
+    if cores > 1:
+        pl = max(10, levels - 1)  # half the tree per task: the pool leg costs about half the single-thread leg
+        ctx = mp.get_context('spawn')  # fresh interpreters: numpy and the oracle only
+        t0 = time.perf_counter()
+        with ctx.Pool(cores) as pool:
+            res = pool.map(_cpu_baseline_one, [(k, pl, model, c) for c in range(cores)])
+        wall = time.perf_counter() - t0
+        work = max(r[0] for r in res)  # slowest task, without interpreter start-up
+        pooled = sum(r[1] for r in res) * k / work
+        out.update(value=pooled, cores=cores, seconds=dt1 + wall,
+                   sample='{} characters in {} worker processes, one each, balanced {}-tip tree ({} nodes), k={}, full '
+                          'marginal pass (BU+TD+posteriors), numpy per-node port of pastml/ml.py: slowest task {:.1f} s '
+                          '(pool wall {:.1f} s); single thread on a {}-tip tree: {:.3g} units/s in {:.1f} s; host '
+                          'reports {} cores'.format(cores, cores, res[0][2], res[0][1], k, work, wall, n_tips, single,
+                                                    dt1, os.cpu_count()))
+    return out
 
 
 def main():
@@ -82,6 +112,20 @@ def main():
             raise SystemExit('launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node {} '
                              '--master-addr 127.0.0.1 --master-port P bench.py --gpus {} ...'.format(args.gpus, args.gpus))
         raise SystemExit('--gpus {} but WORLD_SIZE={}'.format(args.gpus, world))
+
+    levels, k, cpg = WORKLOADS[args.workload]
+    if args.chars_per_gpu:
+        cpg = args.chars_per_gpu
+    model = 'JC' if args.workload == 'cfg2' else 'F81'
+
+    # CPU baseline first, while this process has not touched the GPU yet (its worker processes are started from a
+    # process without a GPU context)
+    cpu = None
+    if not args.no_cpu_baseline and world == 1:
+        cl = args.cpu_baseline_levels
+        if cl is None:
+            cl = min(levels, 17 if k >= 32 else 16)  # 10-20 s of single-thread numpy on the GPU box
+        cpu = cpu_baseline(k, cl, model, args.cpu_baseline_cores)
 
     import torch
     dist = None
@@ -98,10 +142,6 @@ def main():
     from pastml_amd import hip, synthetic
     from pastml_amd.sharding import shard_characters, allreduce_sum
 
-    levels, k, cpg = WORKLOADS[args.workload]
-    if args.chars_per_gpu:
-        cpg = args.chars_per_gpu
-    model = 'JC' if args.workload == 'cfg2' else 'F81'
     flat = synthetic.balanced_forest(levels)
     N = flat.n_nodes
     chars = list(shard_characters(cpg * world, rank, world))  # contiguous block of characters per rank
@@ -218,12 +258,10 @@ def main():
                                    'prep': prep_ms / args.steps},
             'device_memory_gb': held / 1e9,
         }
-        if not args.no_cpu_baseline:
-            cl = args.cpu_baseline_levels
-            if cl is None:
-                cl = min(levels, 17 if k >= 32 else 16)  # 10-20 s of single-thread numpy on the GPU box
-            out['cpu_baseline'] = cpu_baseline(k, cl, model)
-            out['speedup_vs_cpu_baseline'] = value / out['cpu_baseline']['value']
+        if cpu is not None:
+            out['cpu_baseline'] = cpu
+            out['speedup_vs_cpu_baseline'] = value / cpu['value']
+            out['speedup_vs_cpu_baseline_single_core'] = value / cpu['single_core_value']
         print(json.dumps(out))
     eng.close()
     if dist is not None:
