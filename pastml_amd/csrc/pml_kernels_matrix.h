@@ -17,6 +17,11 @@ __device__ __forceinline__ void stage_vec(double* __restrict__ slot, int s0, con
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Rows of Pt are fetched PML_ROWS_AT_ONCE at a time (independent loads issued back to back, then consumed in order):
+// a unit waits for memory k / PML_ROWS_AT_ONCE times per child instead of k times.  The order of the arithmetic is
+// unchanged (j ascending), so the results are the bits of the one-row-at-a-time loop.
+#define PML_ROWS_AT_ONCE 8
+
 // out[i] = sum_j P[i][j] v[j]  (rows i = s0 .. s0+R-1 of this lane), v staged in LDS
 template <int R>
 __device__ __forceinline__ void matvec_rows(const double* __restrict__ Pt, int k, int ks, int s0, bool lane_valid,
@@ -24,12 +29,21 @@ __device__ __forceinline__ void matvec_rows(const double* __restrict__ Pt, int k
 #pragma unroll
     for (int r = 0; r < R; ++r) out[r] = 0.0;
     if (!lane_valid) return;
-    for (int j = 0; j < k; ++j) {
-        double p[R];
-        load_vec<R>(Pt + (size_t)j * ks + s0, p);
-        const double vj = slot[j];
+    for (int j0 = 0; j0 < k; j0 += PML_ROWS_AT_ONCE) {
+        double p[PML_ROWS_AT_ONCE][R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) out[r] += p[r] * vj;
+        for (int u = 0; u < PML_ROWS_AT_ONCE; ++u) {
+            const int j = j0 + u < k ? j0 + u : k - 1;  // rows past the end re-read the last one and are not used
+            load_vec<R>(Pt + (size_t)j * ks + s0, p[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < PML_ROWS_AT_ONCE; ++u) {
+            if (j0 + u < k) {
+                const double vj = slot[j0 + u];
+#pragma unroll
+                for (int r = 0; r < R; ++r) out[r] += p[u][r] * vj;
+            }
+        }
     }
 }
 
@@ -69,6 +83,77 @@ bu_matrix_kernel(PmlTree t, PmlCols c, PmlState st, const double* __restrict__ P
             const int ch = fc + j;
             const bool tip = t.n_children[ch] == 0;
             double v[R];
+            int observed = -1;  // state of an observed tip (exactly one allowed state)
+            if (tip) {
+                int cnt = 0, first = 0;
+                for (int w_ = 0; w_ < c.W; ++w_) {
+                    const u64 mw = c.masks[(colN + ch) * c.W + w_];
+                    if (cnt == 0 && mw) first = w_ * 64 + __builtin_ctzll(mw);
+                    cnt += __popcll(mw);
+                }
+                if (cnt == 1 && first < c.k) observed = first;
+            }
+            if (observed >= 0) {
+                // v is a unit vector: sum_j P[i][j] v[j] is P[i][s] exactly (the other terms are zeros), and the
+                // arg-max scan has a closed form, so one 8k-byte row of Pt is read instead of the whole matrix
+                const double* Pt = P + (colN + ch) * pstride;
+                double msg[R];
+                if (lane_valid) {
+                    load_vec<R>(Pt + (size_t)observed * c.ks + s0, msg);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) msg[r] = 0.0;
+                }
+                if (JOINT) {
+                    int jj[R];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        // numpy's first maximum of (.., 0, P[i][s], 0, ..): s if P[i][s] > 0, else the first zero
+                        const double pv = msg[r];
+                        if (pv > 0.0) {
+                            jj[r] = observed;
+                        } else if (observed != 0) {
+                            msg[r] = 0.0;
+                            jj[r] = 0;
+                        } else if (pv == 0.0 || c.k == 1) {
+                            jj[r] = 0;
+                        } else {
+                            msg[r] = 0.0;
+                            jj[r] = 1;
+                        }
+                        if (s0 + r >= c.k) {
+                            msg[r] = 0.0;
+                            jj[r] = 0;
+                        }
+                    }
+                    if (c.masks_init != nullptr) {
+                        const u64* mi = c.masks_init + (colN + ch) * c.W;
+                        const u64* mc = c.masks + (colN + ch) * c.W;
+                        bool altered = false;
+                        for (int w_ = 0; w_ < c.W; ++w_) altered |= (mi[w_] != mc[w_]);
+                        if (altered) {
+                            const int fa = first_allowed(mi, c.W);
+#pragma unroll
+                            for (int r = 0; r < R; ++r) {
+                                const int a = jj[r];
+                                if (!((mi[a >> 6] >> (a & 63)) & 1ull)) jj[r] = fa;
+                            }
+                        }
+                    }
+                    if (lane_valid) store_vec_i32<R>(st.J + (colN + ch) * c.ks + s0, jj);
+                }
+                bool nz = false;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    acc[r] *= fmax(msg[r], 0.0);
+                    nz |= acc[r] != 0.0;
+                }
+                if (!group_any<G>(nz)) {
+                    if (g == 0) atomicMin(&st.err[col], ((u64)(unsigned)t.post_rank[n] << 32) | (u64)(unsigned)ch);
+                }
+                esum += lazy_rescale<G, R>(acc);
+                continue;
+            }
             if (tip) {
                 const u64 word = lane_valid ? c.masks[(colN + ch) * c.W + w0] : 0ull;
                 mask_to_vec<R>(word, s0, c.k, v);
@@ -95,16 +180,26 @@ bu_matrix_kernel(PmlTree t, PmlCols c, PmlState st, const double* __restrict__ P
                 }
                 if (lane_valid) {
                     // sequential scan over j keeps numpy's first-maximum semantics (ml.py:134)
-                    for (int jc = 0; jc < c.k; ++jc) {
-                        double p[R];
-                        load_vec<R>(Pt + (size_t)jc * c.ks + s0, p);
-                        const double vj = slot[jc];
+                    for (int j0 = 0; j0 < c.k; j0 += PML_ROWS_AT_ONCE) {
+                        double p[PML_ROWS_AT_ONCE][R];
 #pragma unroll
-                        for (int r = 0; r < R; ++r) {
-                            const double pr = p[r] * vj;
-                            if (pr > msg[r]) {
-                                msg[r] = pr;
-                                jj[r] = jc;
+                        for (int u = 0; u < PML_ROWS_AT_ONCE; ++u) {
+                            const int jc = j0 + u < c.k ? j0 + u : c.k - 1;
+                            load_vec<R>(Pt + (size_t)jc * c.ks + s0, p[u]);
+                        }
+#pragma unroll
+                        for (int u = 0; u < PML_ROWS_AT_ONCE; ++u) {
+                            const int jc = j0 + u;
+                            if (jc < c.k) {
+                                const double vj = slot[jc];
+#pragma unroll
+                                for (int r = 0; r < R; ++r) {
+                                    const double pr = p[u][r] * vj;
+                                    if (pr > msg[r]) {
+                                        msg[r] = pr;
+                                        jj[r] = jc;
+                                    }
+                                }
                             }
                         }
                     }
