@@ -1,6 +1,7 @@
 // libpastml_hip.so -- C-ABI (include/pastml_hip.h) over the HIP kernels.  gfx950 only.
 #include "../../include/pastml_hip.h"
 
+#include <algorithm>
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -338,19 +339,21 @@ static void launch_sweep_f81(pml_ctx* ctx, SweepKind what, const int* level, int
     }
 }
 
+// Single-workgroup-per-column launch over a range of levels: the whole sweep of a small forest, or the narrow end of
+// a large one (bottom-up: levels first_level .. end, then ln L; top-down: roots, then levels 0 .. n_levels - 1).
 template <int G, int R>
-static void launch_small_f81(pml_ctx* ctx, bool bottom_up, int do_prep) {
+static void launch_small_f81(pml_ctx* ctx, bool bottom_up, int do_prep, int first_level, int n_levels) {
     const PmlTree t = tree_of(ctx, true);
     const PmlCols c = cols_of(ctx);
     const PmlState st = state_of(ctx);
     dim3 grid(1, ctx->C), block(PML_SMALL_BLOCK);
     if (bottom_up)
         hipLaunchKernelGGL((bu_f81_small_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, ctx->d_mu, ctx->d_sf,
-                           ctx->d_tau, ctx->d_tauf, do_prep, ctx->d_bu_units_f, ctx->d_bu_offsets_f,
-                           (int)ctx->bu_offsets_f.size() - 1, ctx->d_loglik);
+                           ctx->d_tau, ctx->d_tauf, do_prep, ctx->d_bu_units_f, ctx->d_bu_offsets_f + first_level,
+                           n_levels, ctx->d_loglik);
     else
         hipLaunchKernelGGL((td_f81_small_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, ctx->d_td_units_f,
-                           ctx->d_td_parent_offsets_f, ctx->n_td_levels);
+                           ctx->d_td_parent_offsets_f, n_levels);
 }
 
 #define PML_F81_CASES(X) \
@@ -374,13 +377,14 @@ static void launch_select(pml_ctx* ctx, int method, int force_joint, const u64* 
                        ctx->d_post, d_lh_mask, ctx->d_js, method, force_joint, ctx->d_masks, ctx->d_nsel);
 }
 
-static int dispatch_small_f81(pml_ctx* ctx, bool bottom_up, int do_prep) {
+static int dispatch_small_f81(pml_ctx* ctx, bool bottom_up, int do_prep, int first_level = 0, int n_levels = -1) {
     const int g = bottom_up ? ctx->Gf : ctx->Gt, r = bottom_up ? ctx->Rf : ctx->Rt;
-#define X(G_, R_)                                            \
-    if (g == G_ && r == R_) {                                \
-        launch_small_f81<G_, R_>(ctx, bottom_up, do_prep);   \
-        HIP_TRY(hipGetLastError());                          \
-        return PML_OK;                                       \
+    if (n_levels < 0) n_levels = bottom_up ? (int)ctx->bu_offsets_f.size() - 1 - first_level : ctx->n_td_levels;
+#define X(G_, R_)                                                                    \
+    if (g == G_ && r == R_) {                                                        \
+        launch_small_f81<G_, R_>(ctx, bottom_up, do_prep, first_level, n_levels);    \
+        HIP_TRY(hipGetLastError());                                                  \
+        return PML_OK;                                                               \
     }
     PML_F81_CASES(X)
 #undef X
@@ -1125,6 +1129,24 @@ int pml_pij_batch(pml_ctx* ctx, double* P_out) {
     return PML_OK;
 }
 
+// The narrow end of a large forest (the levels near the roots hold a handful of nodes each) is walked by ONE launch
+// with a workgroup barrier between levels instead of one latency-bound launch per level: returns the number of
+// consecutive levels, counted from the root end, that hold at most `limit` units each (0 if fewer than two do).
+// Measured on MI355X: with one column (cfg2, 65 536 tips) 512 units per level is the best cut (0.205 -> 0.181 ms per
+// marginal pass); one workgroup per column walks the levels, so with many columns the level kernels, which spread a
+// level over the whole chip, win earlier: the limit shrinks with the number of columns.
+static int narrow_levels(const std::vector<int>& off, int n_levels, bool from_front, int C) {
+    static const int limit_env = getenv("PASTML_HIP_NARROW_UNITS") ? atoi(getenv("PASTML_HIP_NARROW_UNITS")) : 0;
+    const int limit = limit_env > 0 ? limit_env : std::max(8, 512 / std::max(1, C));
+    int n = 0;
+    for (int q = 0; q < n_levels; ++q) {
+        const int l = from_front ? q : n_levels - 1 - q;
+        if (off[l + 1] - off[l] > limit) break;
+        ++n;
+    }
+    return n >= 2 ? n : 0;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Everything a bottom-up sweep puts on the stream, without host synchronisation (so that it can be captured).
 static int enqueue_bottom_up(pml_ctx* ctx, int is_marginal, bool small_path, bool force_prep) {
@@ -1133,18 +1155,24 @@ static int enqueue_bottom_up(pml_ctx* ctx, int is_marginal, bool small_path, boo
     if (!small_path) PML_TRY(run_prep(ctx, force_prep));
     PML_TRY(prof_begin(ctx));
     const bool fused = is_marginal && ctx->kind == PML_MODEL_F81;
+    bool loglik_done = small_path;
     if (small_path) {
         // prep + every level + ln L in one launch
         PML_TRY(dispatch_small_f81(ctx, true, (ctx->prep_dirty || force_prep) ? 1 : 0));
         PML_TRY(prof_end(ctx, 0, 1));
     } else if (fused) {
         const int nl = (int)ctx->bu_offsets_f.size() - 1;
-        for (int l = 0; l < nl; ++l) {
+        const int tail = narrow_levels(ctx->bu_offsets_f, nl, false, ctx->C);
+        for (int l = 0; l < nl - tail; ++l) {
             const int a = ctx->bu_offsets_f[l], b = ctx->bu_offsets_f[l + 1];
             PML_TRY(dispatch_sweep(ctx, ctx->bu_level_vec_f[l] ? SW_BU_MARG_FUSED : SW_BU_MARG_FUSED_NOVEC,
                                    ctx->d_bu_order_f + a, b - a));
         }
-        PML_TRY(prof_end(ctx, 0, nl));
+        if (tail > 0) {  // the levels next to the roots and ln L in one launch
+            PML_TRY(dispatch_small_f81(ctx, true, 0, nl - tail, tail));
+            loglik_done = true;
+        }
+        PML_TRY(prof_end(ctx, 0, nl - tail + (tail > 0 ? 1 : 0)));
     } else {
         for (int l = 0; l < ctx->n_bu_levels; ++l) {
             const int a = ctx->bu_offsets[l], b = ctx->bu_offsets[l + 1];
@@ -1152,7 +1180,7 @@ static int enqueue_bottom_up(pml_ctx* ctx, int is_marginal, bool small_path, boo
         }
         PML_TRY(prof_end(ctx, 0, ctx->n_bu_levels));
     }
-    if (!small_path) {
+    if (!loglik_done) {
         hipLaunchKernelGGL(loglik_kernel, dim3((ctx->C + PML_BLOCK - 1) / PML_BLOCK), dim3(PML_BLOCK), 0, ctx->stream,
                            tree_of(ctx), cols_of(ctx), state_of(ctx), ctx->C, is_marginal ? 1 : 0, ctx->d_loglik);
         HIP_TRY(hipGetLastError());
@@ -1247,14 +1275,20 @@ static int run_top_down(pml_ctx* ctx) {
     const bool td_small = ctx->small && ctx->kind == PML_MODEL_F81;
     const bool td_fused = ctx->kind == PML_MODEL_F81;
     auto enqueue = [&]() -> int {
-        if (!td_small) PML_TRY(dispatch_sweep(ctx, SW_ROOTS, nullptr, ctx->n_roots));
+        // F81 family: the roots and the levels right below them in one launch
+        const int head = (td_fused && !td_small && ctx->n_roots <= 64)
+                             ? narrow_levels(ctx->td_parent_offsets_f, ctx->n_td_levels, true, ctx->C) : 0;
+        if (!td_small && head == 0) PML_TRY(dispatch_sweep(ctx, SW_ROOTS, nullptr, ctx->n_roots));
         PML_TRY(prof_begin(ctx));
         long long n_launch = 0;
         if (td_small) {
             PML_TRY(dispatch_small_f81(ctx, false, 0));
             n_launch = 1;
+        } else if (head > 0) {
+            PML_TRY(dispatch_small_f81(ctx, false, 0, 0, head));
+            n_launch = 1;
         }
-        for (int l = 0; l < (td_small ? 0 : ctx->n_td_levels); ++l) {
+        for (int l = head; l < (td_small ? 0 : ctx->n_td_levels); ++l) {
             const std::vector<int>& off = td_fused ? ctx->td_parent_offsets_f : ctx->td_parent_offsets;
             const int a = off[l], b = off[l + 1];
             PML_TRY(dispatch_sweep(ctx, td_fused ? SW_TD_FUSED : SW_TD,
