@@ -88,7 +88,7 @@ struct pml_ctx {
 
     // state
     double *d_E = nullptr, *d_P = nullptr, *d_bu = nullptr, *d_S = nullptr, *d_td = nullptr, *d_post = nullptr,
-           *d_lhsum = nullptr, *d_loglik = nullptr;
+           *d_lhsum = nullptr;
     i64 *d_be = nullptr, *d_te = nullptr, *d_lhe = nullptr;
     int *d_J = nullptr, *d_js = nullptr;
     u64* d_err = nullptr;
@@ -105,6 +105,10 @@ struct pml_ctx {
     GraphSlot bu_graph[2], td_graph;
     bool graphs = true;
     double* h_loglik = nullptr;  // pinned staging of the per-column results
+    // pi, sf, tau, tau factor, mu, kappa of all columns live in ONE device block with a pinned host mirror of the same
+    // layout: a parameter update (every optimiser step) is one asynchronous copy and no synchronisation
+    double *d_params = nullptr, *h_params = nullptr;
+    size_t n_params = 0;
     u64* h_err = nullptr;
     bool td_valid = false, js_valid = false;
     bool keep_td = false;      // PML_OPT_KEEP_TD (or a pml_download of the TD vectors asked for them)
@@ -139,6 +143,8 @@ static void free_all(pml_ctx* ctx) {
     drop_graph(ctx->td_graph);
     if (ctx->h_loglik) (void)hipHostFree(ctx->h_loglik);
     if (ctx->h_err) (void)hipHostFree(ctx->h_err);
+    if (ctx->h_params) (void)hipHostFree(ctx->h_params);
+    ctx->h_params = nullptr;
     ctx->h_loglik = nullptr;
     ctx->h_err = nullptr;
     for (void* p : ctx->allocs) (void)hipFree(p);
@@ -350,7 +356,7 @@ static void launch_small_f81(pml_ctx* ctx, bool bottom_up, int do_prep, int firs
     if (bottom_up)
         hipLaunchKernelGGL((bu_f81_small_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, ctx->d_mu, ctx->d_sf,
                            ctx->d_tau, ctx->d_tauf, do_prep, ctx->d_bu_units_f, ctx->d_bu_offsets_f + first_level,
-                           n_levels, ctx->d_loglik);
+                           n_levels, ctx->h_loglik, ctx->h_err, first_level == 0 ? 1 : 0);
     else
         hipLaunchKernelGGL((td_f81_small_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, ctx->d_td_units_f,
                            ctx->d_td_parent_offsets_f, n_levels);
@@ -791,13 +797,16 @@ int pml_chars_alloc(pml_ctx* ctx, int32_t n_cols, int32_t k) {
     }
     const size_t CN = (size_t)n_cols * ctx->N;
     PML_TRY(dev_alloc(ctx, &ctx->d_masks, CN * ctx->W));
-    PML_TRY(dev_alloc(ctx, &ctx->d_pi, (size_t)n_cols * ctx->ks));
-    PML_TRY(dev_alloc(ctx, &ctx->d_sf, n_cols));
-    PML_TRY(dev_alloc(ctx, &ctx->d_tau, n_cols));
-    PML_TRY(dev_alloc(ctx, &ctx->d_tauf, n_cols));
-    PML_TRY(dev_alloc(ctx, &ctx->d_mu, n_cols));
-    PML_TRY(dev_alloc(ctx, &ctx->d_kappa, n_cols));
-    PML_TRY(dev_alloc(ctx, &ctx->d_loglik, n_cols));
+    ctx->n_params = (size_t)n_cols * (ctx->ks + 5);
+    PML_TRY(dev_alloc(ctx, &ctx->d_params, ctx->n_params));
+    HIP_TRY(hipHostMalloc((void**)&ctx->h_params, sizeof(double) * ctx->n_params));
+    memset(ctx->h_params, 0, sizeof(double) * ctx->n_params);
+    ctx->d_pi = ctx->d_params;
+    ctx->d_sf = ctx->d_pi + (size_t)n_cols * ctx->ks;
+    ctx->d_tau = ctx->d_sf + n_cols;
+    ctx->d_tauf = ctx->d_tau + n_cols;
+    ctx->d_mu = ctx->d_tauf + n_cols;
+    ctx->d_kappa = ctx->d_mu + n_cols;
     PML_TRY(dev_alloc(ctx, &ctx->d_err, n_cols));
     HIP_TRY(hipHostMalloc((void**)&ctx->h_loglik, sizeof(double) * n_cols));
     HIP_TRY(hipHostMalloc((void**)&ctx->h_err, sizeof(u64) * n_cols));
@@ -806,7 +815,7 @@ int pml_chars_alloc(pml_ctx* ctx, int32_t n_cols, int32_t k) {
     PML_TRY(dev_alloc(ctx, &ctx->d_S, CN));
     PML_TRY(dev_alloc(ctx, &ctx->d_be, CN));
     PML_TRY(dev_alloc(ctx, &ctx->d_E, CN));
-    HIP_TRY(hipMemsetAsync(ctx->d_pi, 0, (size_t)n_cols * ctx->ks * sizeof(double), ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->d_params, 0, ctx->n_params * sizeof(double), ctx->stream));
     HIP_TRY(hipMemsetAsync(ctx->d_be, 0, CN * sizeof(i64), ctx->stream));
     // default masks: everything allowed
     {
@@ -931,17 +940,27 @@ static int set_common(pml_ctx* ctx, int kind, int cb, int ce, const double* pi, 
         if (!(sf[i] > 0.0) || !(tau[i] >= 0.0) || !(tauf[i] > 0.0) || !std::isfinite(sf[i]) || !std::isfinite(tau[i]))
             return fail(PML_ERR_INVALID, "bad sf/tau/tau_factor for column %d", cb + i);
     ctx->kind = kind;
-    if (ctx->ks == ctx->k) {
-        PML_TRY(upload(ctx, ctx->d_pi + (size_t)cb * ctx->ks, pi, (size_t)nc * ctx->k));
-    } else {
-        HIP_TRY(hipMemcpy2DAsync(ctx->d_pi + (size_t)cb * ctx->ks, ctx->ks * sizeof(double), pi, ctx->k * sizeof(double),
-                                 ctx->k * sizeof(double), nc, hipMemcpyHostToDevice, ctx->stream));
+    // into the pinned mirror (the caller's arrays need not outlive the call); params_flush sends it
+    double* h = ctx->h_params;
+    const size_t C = ctx->C, ks = ctx->ks, k = ctx->k;
+    for (int i = 0; i < nc; ++i) {
+        double* row = h + (size_t)(cb + i) * ks;
+        memcpy(row, pi + (size_t)i * k, k * sizeof(double));
+        for (size_t q = k; q < ks; ++q) row[q] = 0.0;
     }
-    PML_TRY(upload(ctx, ctx->d_sf + cb, sf, nc));
-    PML_TRY(upload(ctx, ctx->d_tau + cb, tau, nc));
-    PML_TRY(upload(ctx, ctx->d_tauf + cb, tauf, nc));
+    memcpy(h + C * ks + cb, sf, nc * sizeof(double));
+    memcpy(h + C * ks + C + cb, tau, nc * sizeof(double));
+    memcpy(h + C * ks + 2 * C + cb, tauf, nc * sizeof(double));
     for (int i = cb; i < ce; ++i) ctx->model_set[i] = 1;
     invalidate(ctx);
+    return PML_OK;
+}
+
+// One asynchronous copy of the parameter block (small: (k + 5) doubles per column).  A copy still in flight when the
+// mirror is written again is harmless: copies are stream-ordered and the later one carries the final contents.
+static int params_flush(pml_ctx* ctx) {
+    HIP_TRY(hipMemcpyAsync(ctx->d_params, ctx->h_params, ctx->n_params * sizeof(double), hipMemcpyHostToDevice,
+                           ctx->stream));
     return PML_OK;
 }
 
@@ -949,25 +968,22 @@ int pml_model_set_f81(pml_ctx* ctx, int32_t col_begin, int32_t col_end, const do
                       const double* tau, const double* tau_factor) {
     PML_TRY(set_common(ctx, PML_MODEL_F81, col_begin, col_end, pi, sf, tau, tau_factor));
     const int nc = col_end - col_begin;
-    std::vector<double> mu(nc);
+    double* mu = ctx->h_params + (size_t)ctx->C * (ctx->ks + 3) + col_begin;
     for (int c = 0; c < nc; ++c) {
         // mu = 1 / (1 - sum pi^2), F81Model.py:18-26 (numpy dot)
         double dot = 0.0;
         for (int s = 0; s < ctx->k; ++s) dot += pi[(size_t)c * ctx->k + s] * pi[(size_t)c * ctx->k + s];
         mu[c] = 1.0 / (1.0 - dot);
     }
-    PML_TRY(upload(ctx, ctx->d_mu + col_begin, mu.data(), nc));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return PML_OK;
+    return params_flush(ctx);
 }
 
 int pml_model_set_hky(pml_ctx* ctx, int32_t col_begin, int32_t col_end, const double* pi, const double* kappa,
                       const double* sf, const double* tau, const double* tau_factor) {
     if (!kappa) return fail(PML_ERR_INVALID, "kappa is NULL");
     PML_TRY(set_common(ctx, PML_MODEL_HKY, col_begin, col_end, pi, sf, tau, tau_factor));
-    PML_TRY(upload(ctx, ctx->d_kappa + col_begin, kappa, col_end - col_begin));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return PML_OK;
+    memcpy(ctx->h_params + (size_t)ctx->C * (ctx->ks + 4) + col_begin, kappa, (col_end - col_begin) * sizeof(double));
+    return params_flush(ctx);
 }
 
 int pml_model_set_eigen(pml_ctx* ctx, int32_t col_begin, int32_t col_end, const double* pi, const double* d,
@@ -982,6 +998,7 @@ int pml_model_set_eigen(pml_ctx* ctx, int32_t col_begin, int32_t col_end, const 
         PML_TRY(dev_alloc(ctx, &ctx->d_Ainv, (size_t)ctx->C * k * k));
     }
     const int nc = col_end - col_begin;
+    PML_TRY(params_flush(ctx));
     PML_TRY(upload(ctx, ctx->d_d + col_begin * k, d, nc * k));
     PML_TRY(upload(ctx, ctx->d_A + col_begin * k * k, A, nc * k * k));
     PML_TRY(upload(ctx, ctx->d_Ainv + col_begin * k * k, Ainv, nc * k * k));
@@ -1150,9 +1167,11 @@ static int narrow_levels(const std::vector<int>& off, int n_levels, bool from_fr
 // ---------------------------------------------------------------------------------------------------------------------
 // Everything a bottom-up sweep puts on the stream, without host synchronisation (so that it can be captured).
 static int enqueue_bottom_up(pml_ctx* ctx, int is_marginal, bool small_path, bool force_prep) {
-    hipLaunchKernelGGL(reset_err_kernel, dim3((ctx->C + 63) / 64), dim3(64), 0, ctx->stream, ctx->d_err, ctx->C);
-    HIP_TRY(hipGetLastError());
-    if (!small_path) PML_TRY(run_prep(ctx, force_prep));
+    if (!small_path) {  // the single-launch kernel resets the error words itself
+        hipLaunchKernelGGL(reset_err_kernel, dim3((ctx->C + 63) / 64), dim3(64), 0, ctx->stream, ctx->d_err, ctx->C);
+        HIP_TRY(hipGetLastError());
+        PML_TRY(run_prep(ctx, force_prep));
+    }
     PML_TRY(prof_begin(ctx));
     const bool fused = is_marginal && ctx->kind == PML_MODEL_F81;
     bool loglik_done = small_path;
@@ -1182,12 +1201,11 @@ static int enqueue_bottom_up(pml_ctx* ctx, int is_marginal, bool small_path, boo
     }
     if (!loglik_done) {
         hipLaunchKernelGGL(loglik_kernel, dim3((ctx->C + PML_BLOCK - 1) / PML_BLOCK), dim3(PML_BLOCK), 0, ctx->stream,
-                           tree_of(ctx), cols_of(ctx), state_of(ctx), ctx->C, is_marginal ? 1 : 0, ctx->d_loglik);
+                           tree_of(ctx), cols_of(ctx), state_of(ctx), ctx->C, is_marginal ? 1 : 0, ctx->h_loglik,
+                           ctx->h_err);
         HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(hipMemcpyAsync(ctx->h_loglik, ctx->d_loglik, sizeof(double) * ctx->C, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(ctx->h_err, ctx->d_err, sizeof(u64) * ctx->C, hipMemcpyDeviceToHost, ctx->stream));
-    return PML_OK;
+    return PML_OK;  // ln L and the error words are written straight into pinned host memory by the last kernel
 }
 
 // Captures fn's stream work once and replays it afterwards; falls back to direct submission if capture fails.

@@ -1071,9 +1071,13 @@ __global__ void __launch_bounds__(PML_SMALL_BLOCK)
 bu_f81_small_kernel(PmlTree t, PmlCols c, PmlState st, const double* __restrict__ mu, const double* __restrict__ sf,
                     const double* __restrict__ tau, const double* __restrict__ tauf, int do_prep,
                     const PmlUnit* __restrict__ units, const int* __restrict__ level_offsets, int n_levels,
-                    double* __restrict__ loglik) {
+                    double* __restrict__ loglik, u64* __restrict__ err_out, int reset_err) {
     constexpr int UW = 64 / G;
     const int col = blockIdx.y;
+    if (reset_err) {  // whole sweep in this launch: the column's error word is reset here, not by a launch of its own
+        if (threadIdx.x == 0) st.err[col] = ~0ull;
+        __syncthreads();
+    }
     if (do_prep) {
         const size_t colN = (size_t)col * t.N;
         const double m = mu[col], s = sf[col], ta = tau[col], tf = tauf[col];
@@ -1109,7 +1113,11 @@ bu_f81_small_kernel(PmlTree t, PmlCols c, PmlState st, const double* __restrict_
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) loglik[col] = column_loglik(t, c, st, col, 1);
+    if (threadIdx.x == 0) {
+        // pinned host memory: the results land where the caller reads them
+        loglik[col] = column_loglik(t, c, st, col, 1);
+        err_out[col] = atomicMin(&st.err[col], ~0ull);  // the value in L2, whatever this CU's L1 holds
+    }
 }
 
 // root of a tree: TD = 1 with exponent 0 (ml.py:274-277), marginal likelihoods BU * pi * mask

@@ -84,10 +84,13 @@ td_roots_kernel(PmlTree t, PmlCols c, PmlState st) {
 // marginal: root term = sum_i pi_i BU_i; joint: max_i pi_i BU_i, whose first arg-max is the root's joint state
 // (ml.py:622).  One thread per column; forests have few roots.
 __global__ void __launch_bounds__(PML_BLOCK)
-loglik_kernel(PmlTree t, PmlCols c, PmlState st, int n_cols, int is_marginal, double* __restrict__ loglik) {
+loglik_kernel(PmlTree t, PmlCols c, PmlState st, int n_cols, int is_marginal, double* __restrict__ loglik,
+              u64* __restrict__ err_out) {
     const int col = blockIdx.x * blockDim.x + threadIdx.x;
     if (col >= n_cols) return;
+    // loglik / err_out are pinned host memory: the results land where the caller reads them, no copy is queued
     loglik[col] = column_loglik(t, c, st, col, is_marginal);
+    err_out[col] = st.err[col];
 }
 
 // joint back-trace, one depth level per launch: state[n] = table[n][state[parent]] (ml.py:615-620)
