@@ -77,6 +77,7 @@ struct pml_ctx {
     // columns
     int C = 0, k = 0, ks = 0, W = 0, G = 0, R = 0;
     int Gf = 0, Rf = 0;  // lane-group shape of the F81-family bottom-up kernels (chunked state ownership)
+    bool bu_wide_lanes = false;  // 32 < k <= 64: most bottom-up levels run with 8 states per lane (see dispatch_sweep)
     int Gt = 0, Rt = 0;  // ... and of the F81-family top-down kernels
     u64 *d_masks = nullptr, *d_masks_init = nullptr;
     bool has_init = false;
@@ -402,7 +403,14 @@ static int dispatch_sweep(pml_ctx* ctx, SweepKind what, const int* level, int n_
     if (ctx->kind == PML_MODEL_F81) {
         if (what == SW_TD) return fail(PML_ERR_INVALID, "the F81 kernels walk descriptor lists: SW_TD has none");
         const bool td = what == SW_TD_FUSED || what == SW_ROOTS;
-        const int g = td ? ctx->Gt : ctx->Gf, r = td ? ctx->Rt : ctx->Rf;
+        int g = td ? ctx->Gt : ctx->Gf, r = td ? ctx->Rt : ctx->Rf;
+        // Fused bottom-up levels, 32 < k <= 64 (measured on cfg4): 8 states per lane (8 units per wavefront share the
+        // per-unit scalar work) wins on the level that rebuilds cherries (1.80 -> 1.58 ms) and on small levels;
+        // 4 states per lane (twice the loads in flight per unit) wins on big levels that stream stored vectors.
+        if (ctx->bu_wide_lanes && (what == SW_BU_MARG_FUSED_NOVEC || (what == SW_BU_MARG_FUSED && n_level <= 65536))) {
+            g = 8;
+            r = 8;
+        }
 #define X(G_, R_)                                                \
     if (g == G_ && r == R_) {                                    \
         launch_sweep_f81<G_, R_>(ctx, what, level, n_level);     \
@@ -786,6 +794,7 @@ int pml_chars_alloc(pml_ctx* ctx, int32_t n_cols, int32_t k) {
             while (G < need) G <<= 1;
         };
         shape("PASTML_HIP_F81_R", 4, ctx->Gf, ctx->Rf);
+        ctx->bu_wide_lanes = k > 32 && k <= 64 && ctx->Rf == 4 && !getenv("PASTML_HIP_F81_R");
         shape("PASTML_HIP_F81_TD_R", (k > 32 && k <= 64) ? 8 : 4, ctx->Gt, ctx->Rt);
         if (k >= 2 && (ctx->ks & 1)) ctx->ks += 1;  // 16-byte lane accesses
     }

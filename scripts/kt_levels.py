@@ -7,7 +7,7 @@ import sys
 path = glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True)[0]
 rows = list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-last_prep = max(i for i, r in enumerate(rows) if 'prep' in r['Kernel_Name'] or 'small' in r['Kernel_Name'])
+last_prep = max(i for i, r in enumerate(rows) if 'prep' in r['Kernel_Name'])
 tot = {}
 for r in rows[last_prep:]:
     us = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
