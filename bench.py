@@ -207,11 +207,14 @@ def main():
         bu_bytes_per_step = BYTES_BU * (N - 1) * k * cpg
         td_gbs = td_bytes_per_step * args.steps / (td_ms * 1e-3) / 1e9 if td_ms > 0 else None
         bu_gbs = bu_bytes_per_step * args.steps / (bu_ms * 1e-3) / 1e9 if bu_ms > 0 else None
+        # HBM bytes per launch from the committed PMC passes (profiles/traffic.json holds bytes per step of the same
+        # workload; null if the workload's shape was changed on the command line or no profile is committed)
         traffic = None
         tpath = os.path.join(REPO, 'profiles', 'traffic.json')
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and cpg == WORKLOADS[args.workload][2] and td_launches > 0:
             try:
-                traffic = json.load(open(tpath)).get(args.workload, {}).get('td_bytes_per_launch')
+                per_step = json.load(open(tpath)).get(args.workload, {}).get('td_bytes_per_step')
+                traffic = per_step / (td_launches / args.steps) if per_step else None
             except Exception:
                 traffic = None
         out = {

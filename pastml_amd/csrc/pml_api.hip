@@ -1196,11 +1196,11 @@ static int enqueue_bottom_up(pml_ctx* ctx, int is_marginal, bool small_path, boo
             PML_TRY(dispatch_sweep(ctx, ctx->bu_level_vec_f[l] ? SW_BU_MARG_FUSED : SW_BU_MARG_FUSED_NOVEC,
                                    ctx->d_bu_order_f + a, b - a));
         }
+        PML_TRY(prof_end(ctx, 0, nl - tail));  // the profile brackets the level kernel's launches only
         if (tail > 0) {  // the levels next to the roots and ln L in one launch
             PML_TRY(dispatch_small_f81(ctx, true, 0, nl - tail, tail));
             loglik_done = true;
         }
-        PML_TRY(prof_end(ctx, 0, nl - tail + (tail > 0 ? 1 : 0)));
     } else {
         for (int l = 0; l < ctx->n_bu_levels; ++l) {
             const int a = ctx->bu_offsets[l], b = ctx->bu_offsets[l + 1];
@@ -1306,13 +1306,11 @@ static int run_top_down(pml_ctx* ctx) {
         const int head = (td_fused && !td_small && ctx->n_roots <= 64)
                              ? narrow_levels(ctx->td_parent_offsets_f, ctx->n_td_levels, true, ctx->C) : 0;
         if (!td_small && head == 0) PML_TRY(dispatch_sweep(ctx, SW_ROOTS, nullptr, ctx->n_roots));
-        PML_TRY(prof_begin(ctx));
+        if (head > 0) PML_TRY(dispatch_small_f81(ctx, false, 0, 0, head));
+        PML_TRY(prof_begin(ctx));  // the profile brackets the level kernel's launches only
         long long n_launch = 0;
         if (td_small) {
             PML_TRY(dispatch_small_f81(ctx, false, 0));
-            n_launch = 1;
-        } else if (head > 0) {
-            PML_TRY(dispatch_small_f81(ctx, false, 0, 0, head));
             n_launch = 1;
         }
         for (int l = head; l < (td_small ? 0 : ctx->n_td_levels); ++l) {

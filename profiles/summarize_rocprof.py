@@ -8,7 +8,7 @@ Condenses rocprofv3 output directories (gpurun_out/...) into the summaries commi
 * <tag>_pmc_traffic.md   : per-kernel HBM traffic from the FETCH_SIZE / WRITE_SIZE passes (separate --pmc runs).
   Units and gfx950 correction as MI355X_MICROARCH.md section HBM prescribes: the counters are in KB; FETCH_SIZE
   reports half of the bytes of wide (16 B/lane) coalesced streaming reads, so bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.
-* traffic.json           : per-launch traffic of the dominant kernel, read by bench.py for roofline.traffic
+* traffic.json           : per-step traffic of the sweeps' kernels, read by bench.py for roofline.traffic
 """
 import collections
 import csv
@@ -59,10 +59,15 @@ def main():
     open(os.path.join(HERE, tag + '_pmc_traffic.md'), 'w').write('\n'.join(lines) + '\n')
     tj = os.path.join(HERE, 'traffic.json')
     data = json.load(open(tj)) if os.path.exists(tj) else {}
-    td = [v for k, v in traffic.items() if k.startswith('td_f81_kernel') or k.startswith('td_matrix_kernel')]
-    bu = [v for k, v in traffic.items() if k.startswith('bu_f81_kernel') or k.startswith('bu_matrix_kernel')]
-    data[workload] = dict(tag=tag, td_bytes_per_launch=td[0]['bytes_per_launch'] if td else None,
-                          bu_bytes_per_launch=bu[0]['bytes_per_launch'] if bu else None, kernels=traffic)
+    # bytes of one bench step over all launches of the sweep's level kernel (every template variant; not the single
+    # launch that walks the narrow end, which bench.py's HIP-event bracket leaves out as well); bench.py divides by
+    # the number of launches it timed
+    def total(prefixes):
+        sel = [v for k, v in traffic.items() if k.startswith(prefixes)]
+        return sum(v['bytes_per_launch'] * v['launches'] for v in sel) if sel else None
+    data[workload] = dict(tag=tag, td_bytes_per_step=total(('td_f81_kernel', 'td_matrix_kernel')),
+                          bu_bytes_per_step=total(('bu_f81_kernel', 'bu_matrix_kernel')),
+                          kernels=traffic)
     json.dump(data, open(tj, 'w'), indent=1)
     print('\n'.join(lines))
 
