@@ -451,3 +451,73 @@ def test_wide_polytomies_vs_oracle(k):
     assert_same_scaled(bu, bu_sf, r['bu'], r['bu_sf'], what='BU')
     np.testing.assert_allclose(post[0], r['posterior'], rtol=POST_RTOL, atol=1e-300)
     np.testing.assert_allclose(np.log10(lh_sum[0]) - lh_sf[0], r['loglik'] / np.log(10), rtol=1e-11)
+
+
+@pytest.mark.parametrize('kind,k', [('HKY', 4), ('EIGEN', 5), ('EIGEN', 20)])
+def test_matrix_models_observed_tips_on_zero_branches(kind, k):
+    """
+    Observed tips take a shortcut in the matrix-model bottom-up kernels (one row of P^T, arg-max in closed form).
+    Zero-length tip branches are its corner: P(0) is the identity up to entries of +-1e-17 (generator.py:54-65 through
+    the eigen-decomposition), so the message holds zeros / negative dust next to one 1 and numpy's first-maximum rule
+    (ml.py:134) decides the arg-max table.  Compared with the oracle entry by entry.
+    """
+    rng = np.random.default_rng(77 + k)
+    flat = FlatForest.random(60, seed=5 + k, max_arity=3)
+    dist = flat.dist.copy()
+    tips = np.flatnonzero(flat.is_tip)
+    zero_tips = tips[::3]
+    dist[zero_tips] = 0.0
+    flat = _with_dist(flat, dist)
+    spec = random_spec(kind, k, rng)
+    masks = np.ones((flat.n_nodes, k), dtype=np.int8)
+    states = rng.integers(0, k, size=flat.n_nodes)
+    states[zero_tips[: len(zero_tips) // 2]] = 0  # state 0 has its own branch in the closed form
+    for n in tips:
+        masks[n] = 0
+        masks[n, states[n]] = 1
+    # two zero-length tips under one parent must agree, or the likelihood is zero (tested elsewhere)
+    for p in np.unique(flat.parent[zero_tips]):
+        kids = [c for c in zero_tips if flat.parent[c] == p]
+        for c in kids[1:]:
+            masks[c] = masks[kids[0]]
+    with hip.Engine(flat, 1, k) as eng:
+        eng.set_models([(spec, (1.0, 0.0, 1.0))])
+        eng.set_masks(masks[None])
+        lnl = eng.bottom_up(True)
+        bu, bu_sf = eng.download(hip.BUF_BU, 0), eng.download(hip.BUF_BU_SF, 0)
+        post, _, _ = eng.top_down_marginals()
+        lnl_j = eng.bottom_up(False)
+        table = eng.download(hip.BUF_JOINT_TABLE, 0)
+        joint = eng.joint_backtrace()
+    r = orc.full_marginal_pass(flat, masks.astype(int), spec, 1.0, 0.0, 1.0)
+    np.testing.assert_allclose(lnl[0], r['loglik'], rtol=LNL_RTOL, atol=1e-12)
+    # entries that are zero in exact arithmetic come out as 0 or +-1e-17 dust, in the reference as here, depending on
+    # how P(0) rounds: compare every vector relative to its largest entry (1e-6 relative is the bar for the rest)
+    la, lb = log_true(bu, bu_sf), log_true(r['bu'], r['bu_sf'])
+    internal = ~flat.is_tip
+    ma, mb = la[internal].max(axis=1), lb[internal].max(axis=1)
+    np.testing.assert_allclose(ma, mb, rtol=0, atol=LOG10_ATOL)
+    np.testing.assert_allclose(10 ** (la[internal] - ma[:, None]), 10 ** (lb[internal] - mb[:, None]), rtol=1e-9,
+                               atol=1e-12)
+    np.testing.assert_allclose(post[0], r['posterior'], rtol=POST_RTOL, atol=1e-12)
+    j = orc.bottom_up(flat, masks.astype(int), spec, 1.0, 0.0, 1.0, is_marginal=False)
+    np.testing.assert_allclose(lnl_j[0], j['loglik'], rtol=LNL_RTOL, atol=1e-12)
+    nonroot = flat.parent >= 0
+    for n, i in np.argwhere(table != j['joint_table']):
+        if not nonroot[n]:
+            continue
+        # the device's P(t) differs from numpy's in the last bits: a flip is allowed only between products that are
+        # equal to 1e-12 of the largest (for t = 0 that includes the +-1e-17 dust around the zeros)
+        prod = orc.pij(spec, flat.dist[n], 1.0, 0.0, 1.0)[i] * j['bu'][n]
+        assert abs(prod[table[n, i]] - prod.max()) <= 1e-12 * max(prod.max(), 1.0), (n, i)
+    ref_states = orc.joint_backtrace(flat, j['bu'], j['joint_table'], spec['pi'])
+    assert np.mean(joint[0] == ref_states) > 0.95  # ties on zero branches may pick the other of two equal states
+    assert np.array_equal(joint[0][flat.is_tip], ref_states[flat.is_tip])
+
+
+def _with_dist(flat, dist):
+    """A copy of a FlatForest with other branch lengths (same topology)."""
+    for node, d in zip(flat.nodes, dist):
+        node.dist = float(d)
+    roots = [n for n in flat.nodes if n.up is None]
+    return FlatForest.from_trees(roots)
