@@ -14,7 +14,7 @@
 #include <string>
 #include <vector>
 
-#include "pml_kernels_pij.h"
+#include "pml_kernels_eigen_mfma.h"
 
 #define PML_VERSION 100
 
@@ -58,6 +58,9 @@ struct pml_ctx {
     int N = 0, n_roots = 0, n_bu_levels = 0, n_td_levels = 0;
     int *d_parent = nullptr, *d_first_child = nullptr, *d_n_children = nullptr, *d_post_rank = nullptr;
     int *d_bu_order = nullptr, *d_td_parents = nullptr;
+    int* d_tips = nullptr;  // ids of the tips (the fused eigen sweeps give them a launch of their own)
+    int n_tips = 0;
+    double* d_msg = nullptr;  // fused eigen sweeps: messages of the bottom-up sweep
     double* d_dist = nullptr;
     std::vector<int> bu_offsets, td_offsets, td_parent_offsets, h_parent, h_n_children;
     // cherry fusion (F81 marginal sweeps): node kinds and level lists over the stored internal nodes only
@@ -221,7 +224,16 @@ static PmlState state_of(const pml_ctx* c) {
     s.J = c->d_J;
     s.js = c->d_js;
     s.err = c->d_err;
+    s.msg = c->d_msg;
     return s;
+}
+
+// Eigen models with 16 <= k <= 32 run the fused matrix-core sweeps (pml_kernels_eigen_mfma.h): P(t) is built and
+// consumed in registers.  PASTML_HIP_NO_MFMA / PASTML_HIP_NO_EIGEN_FUSED fall back to the materialised-P kernels.
+static bool eigen_fused(const pml_ctx* c) {
+    static const bool off = getenv("PASTML_HIP_NO_MFMA") || getenv("PASTML_HIP_NO_EIGEN_FUSED");
+    return !off && c->kind == PML_MODEL_EIGEN && c->k >= 16 && c->k <= 32 && c->W == 1 &&
+           c->ks == 4 * ((c->k + 3) / 4);
 }
 
 static PmlModel model_of(const pml_ctx* c) {
@@ -432,6 +444,41 @@ static int dispatch_sweep(pml_ctx* ctx, SweepKind what, const int* level, int n_
     return fail(PML_ERR_UNSUPPORTED, "no kernel for G=%d R=%d", ctx->G, ctx->R);
 }
 
+// fused eigen sweeps: one launch over a list (nodes) or a contiguous id range (first) of n nodes
+static int launch_eigen_fused(pml_ctx* ctx, int mode, const int* nodes, int first, int n, int tips) {
+    if (n <= 0) return PML_OK;
+    const int k = ctx->k;
+    const int KS = (k + 3) / 4, NT = (k + 15) / 16;
+    const PmlTree t = tree_of(ctx);
+    const PmlCols c = cols_of(ctx);
+    const PmlState st = state_of(ctx);
+    const PmlModel m = model_of(ctx);
+#define PML_EIG_CASE(NT_, KS_, MODE_)                                                                              \
+    if (NT == NT_ && KS == KS_ && mode == MODE_) {                                                                 \
+        typedef EigShape<KS_> S;                                                                                   \
+        const size_t lds = ((size_t)S::KP * k + (size_t)PML_WAVES_PER_BLOCK * S::WAVE_LDS) * sizeof(double);       \
+        int blocks = (n + PML_WAVES_PER_BLOCK * S::NB - 1) / (PML_WAVES_PER_BLOCK * S::NB);                        \
+        const int cap = std::max(8, 8192 / std::max(1, ctx->C));                                                   \
+        if (blocks > cap) blocks = cap;                                                                            \
+        hipLaunchKernelGGL((eigen_fused_kernel<NT_, KS_, MODE_>), dim3(blocks, ctx->C), dim3(PML_BLOCK), lds,      \
+                           ctx->stream, t, c, m, st, nodes, first, n, tips);                                       \
+        HIP_TRY(hipGetLastError());                                                                                \
+        return PML_OK;                                                                                             \
+    }
+#define PML_EIG_MODES(NT_, KS_)               \
+    PML_EIG_CASE(NT_, KS_, PML_EIG_BU_MARG)   \
+    PML_EIG_CASE(NT_, KS_, PML_EIG_BU_JOINT)  \
+    PML_EIG_CASE(NT_, KS_, PML_EIG_TD)
+    PML_EIG_MODES(1, 4)
+    PML_EIG_MODES(2, 5)
+    PML_EIG_MODES(2, 6)
+    PML_EIG_MODES(2, 7)
+    PML_EIG_MODES(2, 8)
+#undef PML_EIG_MODES
+#undef PML_EIG_CASE
+    return fail(PML_ERR_UNSUPPORTED, "no fused eigen kernel for k = %d", k);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 extern "C" {
 
@@ -628,6 +675,16 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
     if (n_internal) {
         PML_TRY(upload(ctx, ctx->d_bu_order, bu_order, n_internal));
         PML_TRY(upload(ctx, ctx->d_td_parents, td_parents, n_internal));
+    }
+    {
+        std::vector<int> tips;
+        tips.reserve(n_nodes - n_internal);
+        for (int i = 0; i < n_nodes; ++i)
+            if (n_children[i] == 0) tips.push_back(i);
+        ctx->n_tips = (int)tips.size();
+        PML_TRY(dev_alloc(ctx, &ctx->d_tips, tips.size()));
+        if (!tips.empty()) PML_TRY(upload(ctx, ctx->d_tips, tips.data(), tips.size()));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));  // the vector goes out of scope
     }
     // ---- cherry fusion tables: kind per node, level lists over the stored internal nodes
     {
@@ -1176,10 +1233,11 @@ static int narrow_levels(const std::vector<int>& off, int n_levels, bool from_fr
 // ---------------------------------------------------------------------------------------------------------------------
 // Everything a bottom-up sweep puts on the stream, without host synchronisation (so that it can be captured).
 static int enqueue_bottom_up(pml_ctx* ctx, int is_marginal, bool small_path, bool force_prep) {
+    const bool eig = eigen_fused(ctx);
     if (!small_path) {  // the single-launch kernel resets the error words itself
         hipLaunchKernelGGL(reset_err_kernel, dim3((ctx->C + 63) / 64), dim3(64), 0, ctx->stream, ctx->d_err, ctx->C);
         HIP_TRY(hipGetLastError());
-        PML_TRY(run_prep(ctx, force_prep));
+        if (!eig) PML_TRY(run_prep(ctx, force_prep));  // the fused eigen sweeps build P(t) themselves
     }
     PML_TRY(prof_begin(ctx));
     const bool fused = is_marginal && ctx->kind == PML_MODEL_F81;
@@ -1201,6 +1259,15 @@ static int enqueue_bottom_up(pml_ctx* ctx, int is_marginal, bool small_path, boo
             PML_TRY(dispatch_small_f81(ctx, true, 0, nl - tail, tail));
             loglik_done = true;
         }
+    } else if (eig) {
+        // every node once, in the launch of its level: the tips first, then the internal nodes by height
+        const int mode = is_marginal ? PML_EIG_BU_MARG : PML_EIG_BU_JOINT;
+        PML_TRY(launch_eigen_fused(ctx, mode, ctx->d_tips, 0, ctx->n_tips, 1));
+        for (int l = 0; l < ctx->n_bu_levels; ++l) {
+            const int a = ctx->bu_offsets[l], b = ctx->bu_offsets[l + 1];
+            PML_TRY(launch_eigen_fused(ctx, mode, ctx->d_bu_order + a, 0, b - a, 0));
+        }
+        PML_TRY(prof_end(ctx, 0, ctx->n_bu_levels + 1));
     } else {
         for (int l = 0; l < ctx->n_bu_levels; ++l) {
             const int a = ctx->bu_offsets[l], b = ctx->bu_offsets[l + 1];
@@ -1253,7 +1320,11 @@ int pml_bottom_up(pml_ctx* ctx, int is_marginal, double* loglik_out, int32_t* er
         PML_TRY(dev_alloc(ctx, &ctx->d_J, CN * ctx->ks));
         PML_TRY(dev_alloc(ctx, &ctx->d_js, CN));
     }
-    PML_TRY(ensure_transition_storage(ctx));
+    if (eigen_fused(ctx)) {
+        if (!ctx->d_msg) PML_TRY(dev_alloc(ctx, &ctx->d_msg, CN * ctx->ks));
+    } else {
+        PML_TRY(ensure_transition_storage(ctx));
+    }
     ctx->bu_mode = -1;
     ctx->td_valid = ctx->js_valid = false;
     // mid-size forests: the level launches are latency-bound, replay them as one hipGraph
@@ -1312,6 +1383,16 @@ static int run_top_down(pml_ctx* ctx) {
         if (td_small) {
             PML_TRY(dispatch_small_f81(ctx, false, 0));
             n_launch = 1;
+        }
+        if (eigen_fused(ctx)) {
+            // child-centric: the nodes of a depth are a contiguous id range (roots are depth 0, done above)
+            for (int d = 1; d < ctx->n_td_levels; ++d) {
+                const int a = ctx->td_offsets[d], b = ctx->td_offsets[d + 1];
+                PML_TRY(launch_eigen_fused(ctx, PML_EIG_TD, nullptr, a, b - a, 0));
+                if (b > a) ++n_launch;
+            }
+            PML_TRY(prof_end(ctx, 1, n_launch));
+            return PML_OK;
         }
         for (int l = head; l < (td_small ? 0 : ctx->n_td_levels); ++l) {
             const std::vector<int>& off = td_fused ? ctx->td_parent_offsets_f : ctx->td_parent_offsets;

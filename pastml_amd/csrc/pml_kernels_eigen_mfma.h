@@ -1,0 +1,296 @@
+// Eigen models (CUSTOM_RATES, JTT), 16 <= k <= 32: sweeps that build P(t) on the FP64 matrix cores and consume it in
+// registers -- P never reaches HBM (the stand-alone batch of pml_kernels_pij.h writes 8 k^2 bytes per branch and the
+// sweeps of pml_kernels_matrix.h read them back: 3.2 KB per branch at k = 20 against 160 B for a state vector).
+//
+// Every sweep of pastml/ml.py applies P(t_n) of the branch above a node n to one vector of that node:
+//   bottom-up  (ml.py:124-148)   msg_n[i] = sum_j / max_j  P[i][j] v_n[j]      v_n = BU vector of n
+//   top-down   (ml.py:273-290)   td_n[i]  = sum_j          P[i][j] x_n[j]      x_n = TD_p o BU_p / msg_n
+// so a node is visited once per sweep, in the launch of its own level: it first forms its vector from what earlier
+// launches left (the messages of its children / the vectors of its parent), then pushes it through its branch.  The
+// messages msg_n are kept (8k bytes per node): the parent multiplies them, and the top-down sweep divides by them
+// instead of recomputing P v (one application of P per node and sweep instead of the reference's two in top-down).
+//
+// One wavefront takes NB nodes at a time.  Their P^T matrices are the rows of a tall GEMM, as in pij_eigen_mfma_kernel:
+//   Pt_b[j][i] = sum_m (Ainv[m][j] exp(d_m t_b)) A[i][m],   rows (b, j) with j padded to KP = 4 ceil(k / 4),
+// NB chosen so that NB * KP is a multiple of the 16 rows of a v_mfma_f64_16x16x4_f64 tile.  In the 16x16 result tile
+// lane (lo, hi) holds column i = lo (+16 nt) of rows hi + 4 reg, so a group of four rows (one reg) lies inside one
+// node (KP is a multiple of 4): which node a (tile, reg) slot belongs to is known at compile time.  Each lane
+// multiplies its entries by v[j], folds them per node (sum, or first maximum with its index as numpy's argmax,
+// ml.py:134) and the four row groups of a column are combined across lanes.  The tile entries are produced by the same
+// MFMA sequence as the stand-alone batch, so P has the same bits as what pml_pij_batch returns.
+//
+// Lane (lo, hi) owns node hi of the pass and its states lo, 16 + lo in all vector steps.
+#pragma once
+#include "pml_kernels_pij.h"
+
+template <int KS>
+struct EigShape {
+    static constexpr int KP = 4 * KS;                                           // padded states per node
+    static constexpr int NB = (KS % 4 == 0) ? 1 : ((KS % 2 == 0) ? 2 : 4);      // nodes per wave pass
+    static constexpr int ROWS = NB * KP;
+    static constexpr int TILES = ROWS / 16;
+    static constexpr int WAVE_LDS = 2 * NB * KP + 4;                            // doubles: exp table, vectors, t'
+};
+
+#define PML_EIG_BU_MARG 0
+#define PML_EIG_BU_JOINT 1
+#define PML_EIG_TD 2
+
+template <int NT, int KS, int MODE>
+__global__ void __launch_bounds__(PML_BLOCK)
+eigen_fused_kernel(PmlTree t, PmlCols c, PmlModel m, PmlState st, const int* __restrict__ nodes, int first,
+                   int n_nodes, int tips) {
+    typedef EigShape<KS> S;
+    constexpr int KP = S::KP, NB = S::NB, TILES = S::TILES;
+    extern __shared__ double smem[];
+    const int k = c.k, ks = c.ks;  // ks == KP (checked on the host)
+    const int col = blockIdx.y;
+    const size_t colN = (size_t)col * t.N;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int lo = lane & 15, hi = lane >> 4;
+    double* sB = smem;                                   // Ainv padded: [KP][k] (rows >= k are zero)
+    double* sE = sB + KP * k + wave * S::WAVE_LDS;       // per wave: exp(d_m t'_q)   [NB][KP]
+    double* sV = sE + NB * KP;                           // per wave: the vectors P is applied to [NB][KP]
+    double* sT = sV + NB * KP;                           // per wave: t' of the NB branches
+    const double* gA = m.A + (size_t)col * k * k;
+    const double* gB = m.Ainv + (size_t)col * k * k;
+    const double* gd = m.d + (size_t)col * k;
+    for (int e = threadIdx.x; e < KP * k; e += blockDim.x) sB[e] = (e / k < k) ? gB[e] : 0.0;
+    // B fragments of A^T: bfrag[nt][s] = A[16 nt + lo][4 s + hi]
+    double bfrag[NT][KS];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int i = 16 * nt + lo, mm = 4 * s + hi;
+            bfrag[nt][s] = (i < k && mm < k) ? gA[i * k + mm] : 0.0;
+        }
+    double pi_r[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) pi_r[nt] = (16 * nt + lo < k) ? c.pi[(size_t)col * ks + 16 * nt + lo] : 0.0;
+    __syncthreads();
+    const double sfc = m.sf[col], tau = m.tau[col], tf = m.tauf[col];
+
+    const int waves_total = gridDim.x * PML_WAVES_PER_BLOCK;
+    for (int b0 = (blockIdx.x * PML_WAVES_PER_BLOCK + wave) * NB; b0 < n_nodes; b0 += waves_total * NB) {
+        const bool act = hi < NB && b0 + hi < n_nodes;
+        const int n = act ? (nodes != nullptr ? nodes[b0 + hi] : first + b0 + hi) : 0;
+        const size_t row = (colN + n) * ks;
+        // ------------------------------------------------------------------ the vector of the node
+        double v[NT];   // what P is applied to
+        double vc[NT];  // top-down: BU vector of the node; mb: its mask
+        double mb[NT];
+        i64 esum = 0;   // bottom-up: exponent of v; top-down: exponent of x
+        i64 bec = 0;
+        bool tipc = false;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) v[nt] = vc[nt] = mb[nt] = 0.0;
+        if (act) {
+            const u64 word = c.masks[colN + n];  // k <= 32: one word
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int i = 16 * nt + lo;
+                mb[nt] = (i < k && ((word >> i) & 1ull)) ? 1.0 : 0.0;
+            }
+            if (MODE != PML_EIG_TD) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) v[nt] = mb[nt];
+                if (!tips) {
+                    // mask o prod of the children's messages (ml.py:126-148), zero check and rescaling per child
+                    const int fc = t.first_child[n], nc = t.n_children[n];
+                    for (int j = 0; j < nc; ++j) {
+                        const int ch = fc + j;
+                        bool nz = false;
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+                            const int i = 16 * nt + lo;
+                            const double mv = i < ks ? st.msg[(colN + ch) * ks + i] : 0.0;
+                            v[nt] *= fmax(mv, 0.0);
+                            nz |= v[nt] != 0.0;
+                        }
+                        if (!group_any<16>(nz)) {
+                            if (lo == 0)
+                                atomicMin(&st.err[col], ((u64)(unsigned)t.post_rank[n] << 32) | (u64)(unsigned)ch);
+                        }
+                        if (t.n_children[ch] != 0) esum += st.be[colN + ch];
+                        esum += lazy_rescale<16, NT>(v);
+                    }
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const int i = 16 * nt + lo;
+                        if (i < ks) st.bu[row + i] = v[nt];
+                    }
+                    if (lo == 0) st.be[colN + n] = esum;
+                }
+            } else {
+                // x = TD_p o BU_p / msg_n (ml.py:279-283); the message is what the bottom-up sweep left
+                const int p = t.parent[n];
+                tipc = t.n_children[n] == 0;
+                if (!tipc) bec = st.be[colN + n];
+                const i64 pe = st.te[colN + p] + st.be[colN + p];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int i = 16 * nt + lo;
+                    vc[nt] = tipc ? mb[nt] : (i < ks ? st.bu[row + i] : 0.0);
+                    const double prod = i < ks ? st.td[(colN + p) * ks + i] * st.bu[(colN + p) * ks + i] : 0.0;
+                    const double mc = i < ks ? st.msg[row + i] : 0.0;
+                    v[nt] = prod / (mc > 0.0 ? mc : 1.0);
+                }
+                esum = pe - bec;
+                esum += lazy_rescale<16, NT>(v);
+            }
+        }
+        // ------------------------------------------------------------------ stage v, t' and exp(d t') in LDS
+        if (hi < NB) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int i = 16 * nt + lo;
+                if (i < KP) sV[hi * KP + i] = v[nt];
+            }
+            if (lo == 0) sT[hi] = act ? (t.dist[n] + tau) * tf * sfc : 0.0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int e = lane; e < NB * KP; e += 64) {
+            const int q = e / KP, mm = e % KP;
+            sE[e] = mm < k ? exp(gd[mm] * sT[q]) : 0.0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ------------------------------------------------------------------ P^T tiles, folded per node
+        double acc_v[NB][NT];
+        int acc_j[NB][NT];
+#pragma unroll
+        for (int q = 0; q < NB; ++q)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                acc_v[q][nt] = MODE == PML_EIG_BU_JOINT ? -INFINITY : 0.0;
+                acc_j[q][nt] = 0x7fffffff;
+            }
+#pragma unroll
+        for (int tile = 0; tile < TILES; ++tile) {
+            const int ra = 16 * tile + lo;  // A operand row of this lane: (node qa, state ja)
+            const int qa = ra / KP, ja = ra % KP;
+            pml_v4f64 acc[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = (pml_v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const int mm = 4 * s + hi;
+                const double a = ja < k ? sB[mm * k + ja] * sE[qa * KP + mm] : 0.0;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bfrag[nt][s], acc[nt], 0, 0, 0);
+            }
+            // D: row = 16 tile + hi + 4 reg, col = lo (+16 nt); the four rows of a reg belong to one node
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                constexpr int dummy = 0;
+                (void)dummy;
+                const int g0 = 16 * tile + 4 * reg;
+                const int q = g0 / KP;          // compile-time after unrolling
+                const int j = g0 % KP + hi;
+                if (j < k) {
+                    const double vj = sV[q * KP + j];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const double w = acc[nt][reg] * vj;
+                        if (MODE == PML_EIG_BU_JOINT) {
+                            if (w > acc_v[q][nt]) {  // j ascends within a lane: the first maximum stays
+                                acc_v[q][nt] = w;
+                                acc_j[q][nt] = j;
+                            }
+                        } else {
+                            acc_v[q][nt] += w;
+                        }
+                    }
+                }
+            }
+        }
+        // the four row groups of a column: lanes lo, lo + 16, lo + 32, lo + 48
+#pragma unroll
+        for (int q = 0; q < NB; ++q)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int o = 16; o <= 32; o <<= 1) {
+                    const double ov = __shfl_xor(acc_v[q][nt], o, 64);
+                    if (MODE == PML_EIG_BU_JOINT) {
+                        const int oj = __shfl_xor(acc_j[q][nt], o, 64);
+                        if (ov > acc_v[q][nt] || (ov == acc_v[q][nt] && oj < acc_j[q][nt])) {
+                            acc_v[q][nt] = ov;
+                            acc_j[q][nt] = oj;
+                        }
+                    } else {
+                        acc_v[q][nt] += ov;
+                    }
+                }
+        double r[NT];
+        int rj[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            r[nt] = acc_v[0][nt];
+            rj[nt] = acc_j[0][nt];
+#pragma unroll
+            for (int q = 1; q < NB; ++q)
+                if (hi == q) {
+                    r[nt] = acc_v[q][nt];
+                    rj[nt] = acc_j[q][nt];
+                }
+        }
+        // ------------------------------------------------------------------ results of the node
+        if (act) {
+            if (MODE != PML_EIG_TD) {
+                if (MODE == PML_EIG_BU_JOINT && c.masks_init != nullptr) {
+                    // altered nodes get their tables rewritten w.r.t. their initial masks (ml.py:408-428)
+                    const u64 mi = c.masks_init[colN + n], mc = c.masks[colN + n];
+                    if (mi != mc) {
+                        const int fa = mi ? __builtin_ctzll(mi) : 0;
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            if (16 * nt + lo < k && !((mi >> rj[nt]) & 1ull)) rj[nt] = fa;
+                    }
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int i = 16 * nt + lo;
+                    if (i < ks) {
+                        st.msg[row + i] = i < k ? r[nt] : 0.0;
+                        if (MODE == PML_EIG_BU_JOINT) st.J[row + i] = i < k ? rj[nt] : 0;
+                    }
+                }
+            } else {
+                // marginal likelihoods pi o mask o BU o TD (ml.py:456-460) and posteriors (ml.py:498-500)
+                double tdc[NT], lh[NT];
+                double lhs = 0.0;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    tdc[nt] = fmax(r[nt], 0.0);
+                    lh[nt] = vc[nt] * tdc[nt] * (pi_r[nt] * mb[nt]);
+                    lhs += lh[nt];
+                }
+                lhs = group_sum<16>(lhs);
+                const int lex = (lhs > 0.0 && !isinf(lhs)) ? exponent_of(lhs) : 0;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int i = 16 * nt + lo;
+                    if (i < ks) {
+                        if (!tipc) st.td[row + i] = i < k ? tdc[nt] : 0.0;
+                        st.post[row + i] = lh[nt] / lhs;
+                    }
+                }
+                if (lo == 0) {
+                    if (!tipc) st.te[colN + n] = esum;
+                    st.lhsum[colN + n] = __builtin_ldexp(lhs, -lex);
+                    st.lhe[colN + n] = esum + bec + lex;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();  // the pass's LDS reads are done before the next pass overwrites the slots
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}

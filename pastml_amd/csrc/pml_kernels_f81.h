@@ -48,6 +48,7 @@ struct PmlState {
     int* J;         // [C][N][ks]  joint argmax tables
     int* js;        // [C][N]      joint states
     u64* err;       // [C]         min over failing (post_rank << 32 | child id)
+    double* msg;    // [C][N][ks]  fused eigen sweeps: message of a node to its parent, P(t) applied to its BU vector
 };
 
 __device__ __forceinline__ int node_kind(const PmlTree& t, int n) {
