@@ -479,6 +479,38 @@ static int launch_eigen_fused(pml_ctx* ctx, int mode, const int* nodes, int firs
     return fail(PML_ERR_UNSUPPORTED, "no fused eigen kernel for k = %d", k);
 }
 
+// bottom-up messages of all tips (observed tips 16 to a tile, see eigen_tips_kernel)
+static int launch_eigen_tips(pml_ctx* ctx, int joint) {
+    if (ctx->n_tips <= 0) return PML_OK;
+    const int k = ctx->k;
+    const int KS = (k + 3) / 4, NT = (k + 15) / 16;
+    const PmlTree t = tree_of(ctx);
+    const PmlCols c = cols_of(ctx);
+    const PmlState st = state_of(ctx);
+    const PmlModel m = model_of(ctx);
+#define PML_EIG_TIPS(NT_, KS_, J_)                                                                                   \
+    if (NT == NT_ && KS == KS_ && joint == J_) {                                                                     \
+        typedef EigShape<KS_> S;                                                                                     \
+        const size_t lds = ((size_t)S::KP * k + (size_t)PML_WAVES_PER_BLOCK * S::WAVE_LDS_TIPS) * sizeof(double);    \
+        int blocks = (ctx->n_tips + PML_WAVES_PER_BLOCK * 16 - 1) / (PML_WAVES_PER_BLOCK * 16);                      \
+        const int cap = std::max(8, 8192 / std::max(1, ctx->C));                                                     \
+        if (blocks > cap) blocks = cap;                                                                              \
+        hipLaunchKernelGGL((eigen_tips_kernel<NT_, KS_, J_>), dim3(blocks, ctx->C), dim3(PML_BLOCK), lds,            \
+                           ctx->stream, t, c, m, st, ctx->d_tips, ctx->n_tips);                                      \
+        HIP_TRY(hipGetLastError());                                                                                  \
+        return PML_OK;                                                                                               \
+    }
+#define PML_EIG_TIPS2(NT_, KS_) PML_EIG_TIPS(NT_, KS_, 0) PML_EIG_TIPS(NT_, KS_, 1)
+    PML_EIG_TIPS2(1, 4)
+    PML_EIG_TIPS2(2, 5)
+    PML_EIG_TIPS2(2, 6)
+    PML_EIG_TIPS2(2, 7)
+    PML_EIG_TIPS2(2, 8)
+#undef PML_EIG_TIPS2
+#undef PML_EIG_TIPS
+    return fail(PML_ERR_UNSUPPORTED, "no fused eigen kernel for k = %d", k);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 extern "C" {
 
@@ -1262,7 +1294,7 @@ static int enqueue_bottom_up(pml_ctx* ctx, int is_marginal, bool small_path, boo
     } else if (eig) {
         // every node once, in the launch of its level: the tips first, then the internal nodes by height
         const int mode = is_marginal ? PML_EIG_BU_MARG : PML_EIG_BU_JOINT;
-        PML_TRY(launch_eigen_fused(ctx, mode, ctx->d_tips, 0, ctx->n_tips, 1));
+        PML_TRY(launch_eigen_tips(ctx, is_marginal ? 0 : 1));
         for (int l = 0; l < ctx->n_bu_levels; ++l) {
             const int a = ctx->bu_offsets[l], b = ctx->bu_offsets[l + 1];
             PML_TRY(launch_eigen_fused(ctx, mode, ctx->d_bu_order + a, 0, b - a, 0));

@@ -30,52 +30,90 @@ struct EigShape {
     static constexpr int ROWS = NB * KP;
     static constexpr int TILES = ROWS / 16;
     static constexpr int WAVE_LDS = 2 * NB * KP + 4;                            // doubles: exp table, vectors, t'
+    // tips kernel: exp table of 16 tips, vectors of a general pass, t', and 16 states + 16 node ids (as ints)
+    static constexpr int WAVE_LDS_TIPS = 16 * KP + NB * KP + 16 + 16;
 };
 
 #define PML_EIG_BU_MARG 0
 #define PML_EIG_BU_JOINT 1
 #define PML_EIG_TD 2
 
-template <int NT, int KS, int MODE>
-__global__ void __launch_bounds__(PML_BLOCK)
-eigen_fused_kernel(PmlTree t, PmlCols c, PmlModel m, PmlState st, const int* __restrict__ nodes, int first,
-                   int n_nodes, int tips) {
+// Per-wave state of the fused kernels: LDS slots, the B fragments of A^T, the column's scalars.
+template <int NT, int KS>
+struct EigWave {
+    int k, ks, col, lo, hi;
+    size_t colN;
+    double* sB;  // Ainv padded: [KP][k] (rows >= k are zero), shared by the block
+    double* sE;  // per wave: exp(d_m t'_q)
+    double* sV;  // per wave: the vectors P is applied to [NB][KP]
+    double* sT;  // per wave: t' of the branches of the pass
+    const double* gd;
+    double bfrag[NT][KS];  // bfrag[nt][s] = A[16 nt + lo][4 s + hi]
+    double pi_r[NT];
+    double sfc, tau, tf;
+};
+
+// wave_lds: doubles of LDS per wave; sE takes n_exp_rows * KP of them, then sV (NB * KP), then sT
+template <int NT, int KS>
+__device__ __forceinline__ void eig_wave_init(EigWave<NT, KS>& w, const PmlCols& c, const PmlModel& m, double* smem,
+                                              int wave_lds, int n_exp_rows) {
     typedef EigShape<KS> S;
-    constexpr int KP = S::KP, NB = S::NB, TILES = S::TILES;
-    extern __shared__ double smem[];
-    const int k = c.k, ks = c.ks;  // ks == KP (checked on the host)
-    const int col = blockIdx.y;
-    const size_t colN = (size_t)col * t.N;
+    constexpr int KP = S::KP, NB = S::NB;
+    const int k = c.k;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int lo = lane & 15, hi = lane >> 4;
-    double* sB = smem;                                   // Ainv padded: [KP][k] (rows >= k are zero)
-    double* sE = sB + KP * k + wave * S::WAVE_LDS;       // per wave: exp(d_m t'_q)   [NB][KP]
-    double* sV = sE + NB * KP;                           // per wave: the vectors P is applied to [NB][KP]
-    double* sT = sV + NB * KP;                           // per wave: t' of the NB branches
-    const double* gA = m.A + (size_t)col * k * k;
-    const double* gB = m.Ainv + (size_t)col * k * k;
-    const double* gd = m.d + (size_t)col * k;
-    for (int e = threadIdx.x; e < KP * k; e += blockDim.x) sB[e] = (e / k < k) ? gB[e] : 0.0;
-    // B fragments of A^T: bfrag[nt][s] = A[16 nt + lo][4 s + hi]
-    double bfrag[NT][KS];
+    w.k = k;
+    w.ks = c.ks;  // == KP (checked on the host)
+    w.col = blockIdx.y;
+    w.colN = 0;
+    w.lo = lane & 15;
+    w.hi = lane >> 4;
+    w.sB = smem;
+    w.sE = smem + KP * k + wave * wave_lds;
+    w.sV = w.sE + n_exp_rows * KP;
+    w.sT = w.sV + NB * KP;
+    const double* gA = m.A + (size_t)w.col * k * k;
+    const double* gB = m.Ainv + (size_t)w.col * k * k;
+    w.gd = m.d + (size_t)w.col * k;
+    for (int e = threadIdx.x; e < KP * k; e += blockDim.x) w.sB[e] = (e / k < k) ? gB[e] : 0.0;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            const int i = 16 * nt + lo, mm = 4 * s + hi;
-            bfrag[nt][s] = (i < k && mm < k) ? gA[i * k + mm] : 0.0;
+            const int i = 16 * nt + w.lo, mm = 4 * s + w.hi;
+            w.bfrag[nt][s] = (i < k && mm < k) ? gA[i * k + mm] : 0.0;
         }
-    double pi_r[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) pi_r[nt] = (16 * nt + lo < k) ? c.pi[(size_t)col * ks + 16 * nt + lo] : 0.0;
+    for (int nt = 0; nt < NT; ++nt)
+        w.pi_r[nt] = (16 * nt + w.lo < k) ? c.pi[(size_t)w.col * c.ks + 16 * nt + w.lo] : 0.0;
+    w.sfc = m.sf[w.col];
+    w.tau = m.tau[w.col];
+    w.tf = m.tauf[w.col];
     __syncthreads();
-    const double sfc = m.sf[col], tau = m.tau[col], tf = m.tauf[col];
+}
 
-    const int waves_total = gridDim.x * PML_WAVES_PER_BLOCK;
-    for (int b0 = (blockIdx.x * PML_WAVES_PER_BLOCK + wave) * NB; b0 < n_nodes; b0 += waves_total * NB) {
-        const bool act = hi < NB && b0 + hi < n_nodes;
-        const int n = act ? (nodes != nullptr ? nodes[b0 + hi] : first + b0 + hi) : 0;
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// One pass of a wave: NB nodes, lane (lo, hi) owns node n of row hi (act: the row has a node).
+template <int NT, int KS, int MODE>
+__device__ __forceinline__ void eig_pass(const EigWave<NT, KS>& W, const PmlTree& t, const PmlCols& c,
+                                         const PmlState& st, bool act, int n, int tips) {
+    typedef EigShape<KS> S;
+    constexpr int KP = S::KP, NB = S::NB, TILES = S::TILES;
+    const int k = W.k, ks = W.ks, col = W.col, lo = W.lo, hi = W.hi;
+    const size_t colN = W.colN;
+    double* sB = W.sB;
+    double* sE = W.sE;
+    double* sV = W.sV;
+    double* sT = W.sT;
+    const double* gd = W.gd;
+    const double sfc = W.sfc, tau = W.tau, tf = W.tf;
+    const int lane = threadIdx.x & 63;
+    {
         const size_t row = (colN + n) * ks;
         // ------------------------------------------------------------------ the vector of the node
         double v[NT];   // what P is applied to
@@ -183,7 +221,7 @@ eigen_fused_kernel(PmlTree t, PmlCols c, PmlModel m, PmlState st, const int* __r
                 const double a = ja < k ? sB[mm * k + ja] * sE[qa * KP + mm] : 0.0;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bfrag[nt][s], acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, W.bfrag[nt][s], acc[nt], 0, 0, 0);
             }
             // D: row = 16 tile + hi + 4 reg, col = lo (+16 nt); the four rows of a reg belong to one node
 #pragma unroll
@@ -269,7 +307,7 @@ eigen_fused_kernel(PmlTree t, PmlCols c, PmlModel m, PmlState st, const int* __r
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     tdc[nt] = fmax(r[nt], 0.0);
-                    lh[nt] = vc[nt] * tdc[nt] * (pi_r[nt] * mb[nt]);
+                    lh[nt] = vc[nt] * tdc[nt] * (W.pi_r[nt] * mb[nt]);
                     lhs += lh[nt];
                 }
                 lhs = group_sum<16>(lhs);
@@ -289,8 +327,126 @@ eigen_fused_kernel(PmlTree t, PmlCols c, PmlModel m, PmlState st, const int* __r
                 }
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();  // the pass's LDS reads are done before the next pass overwrites the slots
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        wave_lds_sync();  // the pass's LDS reads are done before the next pass overwrites the slots
+    }
+}
+
+template <int NT, int KS, int MODE>
+__global__ void __launch_bounds__(PML_BLOCK)
+eigen_fused_kernel(PmlTree t, PmlCols c, PmlModel m, PmlState st, const int* __restrict__ nodes, int first,
+                   int n_nodes, int tips) {
+    typedef EigShape<KS> S;
+    constexpr int NB = S::NB;
+    extern __shared__ double smem[];
+    EigWave<NT, KS> W;
+    eig_wave_init<NT, KS>(W, c, m, smem, S::WAVE_LDS, NB);
+    W.colN = (size_t)W.col * t.N;
+    const int wave = threadIdx.x >> 6;
+    const int waves_total = gridDim.x * PML_WAVES_PER_BLOCK;
+    for (int b0 = (blockIdx.x * PML_WAVES_PER_BLOCK + wave) * NB; b0 < n_nodes; b0 += waves_total * NB) {
+        const bool act = W.hi < NB && b0 + W.hi < n_nodes;
+        const int n = act ? (nodes != nullptr ? nodes[b0 + W.hi] : first + b0 + W.hi) : 0;
+        eig_pass<NT, KS, MODE>(W, t, c, st, act, n, tips);
+    }
+}
+
+// Bottom-up messages of the tips, 16 at a time.  An observed tip (one allowed state s) has the unit vector as its
+// bottom-up vector, so its message is row s of P^T: the 16 tips of a pass are the 16 rows of ONE tile (NT * KS MFMAs
+// for 16 nodes instead of 12.5 per node), and the arg-max table of the joint variant has a closed form (numpy's first
+// maximum of (.., 0, P[i][s], 0, ..)).  A pass that holds a tip with several allowed states runs the general passes.
+template <int NT, int KS, int JOINT>
+__global__ void __launch_bounds__(PML_BLOCK)
+eigen_tips_kernel(PmlTree t, PmlCols c, PmlModel m, PmlState st, const int* __restrict__ tip_ids, int n_tips) {
+    typedef EigShape<KS> S;
+    constexpr int KP = S::KP, NB = S::NB;
+    constexpr int MODE = JOINT ? PML_EIG_BU_JOINT : PML_EIG_BU_MARG;
+    extern __shared__ double smem[];
+    EigWave<NT, KS> W;
+    eig_wave_init<NT, KS>(W, c, m, smem, S::WAVE_LDS_TIPS, 16);
+    W.colN = (size_t)W.col * t.N;
+    const int k = W.k, ks = W.ks, lo = W.lo, hi = W.hi;
+    const size_t colN = W.colN;
+    int* sS = reinterpret_cast<int*>(W.sT + 16);  // states of the 16 tips
+    int* sN = sS + 16;                            // their node ids (-1: no tip in this row)
+    const u64 kbits = state_bits(k);
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int waves_total = gridDim.x * PML_WAVES_PER_BLOCK;
+    for (int b0 = (blockIdx.x * PML_WAVES_PER_BLOCK + wave) * 16; b0 < n_tips; b0 += waves_total * 16) {
+        const bool have = b0 + lo < n_tips;          // lane (lo, .) looks at tip lo of the pass
+        const int tip = tip_ids[have ? b0 + lo : b0];
+        const u64 word = c.masks[colN + tip] & kbits;
+        const bool observed = __popcll(word) == 1;
+        if (!__all(observed || !have)) {
+            for (int g = 0; g < 16; g += NB) {
+                const bool act = hi < NB && b0 + g + hi < n_tips;
+                const int n = act ? tip_ids[b0 + g + hi] : 0;
+                eig_pass<NT, KS, MODE>(W, t, c, st, act, n, 1);
+            }
+            continue;
+        }
+        const int s_own = observed ? __builtin_ctzll(word) : 0;
+        if (hi == 0) {
+            W.sT[lo] = have ? (t.dist[tip] + W.tau) * W.tf * W.sfc : 0.0;
+            sS[lo] = s_own;
+            sN[lo] = have ? tip : -1;
+        }
+        wave_lds_sync();
+        for (int e = lane; e < 16 * KP; e += 64) {
+            const int q = e / KP, mm = e % KP;
+            W.sE[e] = mm < k ? exp(W.gd[mm] * W.sT[q]) : 0.0;
+        }
+        wave_lds_sync();
+        pml_v4f64 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = (pml_v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int mm = 4 * s + hi;
+            const double a = have ? W.sB[mm * k + s_own] * W.sE[lo * KP + mm] : 0.0;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, W.bfrag[nt][s], acc[nt], 0, 0, 0);
+        }
+        // D: row hi + 4 reg = tip of the pass, col lo (+16 nt) = state i:  acc = P[i][s_tip]
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int rr = hi + 4 * reg;
+            const int n = sN[rr];
+            if (n < 0) continue;
+            const int sr = sS[rr];
+            const size_t row = (colN + n) * ks;
+            u64 mi = 0, mc = 0;
+            bool altered = false;
+            if (JOINT && c.masks_init != nullptr) {
+                mi = c.masks_init[colN + n];
+                mc = c.masks[colN + n];
+                altered = mi != mc;
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int i = 16 * nt + lo;
+                if (i >= ks) continue;
+                double pv = i < k ? acc[nt][reg] : 0.0;
+                if (JOINT) {
+                    int arg;
+                    if (pv > 0.0) {
+                        arg = sr;
+                    } else if (sr != 0) {
+                        pv = 0.0;
+                        arg = 0;
+                    } else if (pv == 0.0 || k == 1) {
+                        arg = 0;
+                    } else {
+                        pv = 0.0;
+                        arg = 1;
+                    }
+                    if (altered && !((mi >> arg) & 1ull)) arg = mi ? __builtin_ctzll(mi) : 0;
+                    st.J[row + i] = i < k ? arg : 0;
+                }
+                st.msg[row + i] = pv;
+            }
+        }
+        wave_lds_sync();
     }
 }
