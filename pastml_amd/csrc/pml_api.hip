@@ -59,6 +59,7 @@ struct pml_ctx {
     int *d_parent = nullptr, *d_first_child = nullptr, *d_n_children = nullptr, *d_post_rank = nullptr;
     int *d_bu_order = nullptr, *d_td_parents = nullptr;
     int* d_tips = nullptr;  // ids of the tips (the fused eigen sweeps give them a launch of their own)
+    int *d_bu_offsets = nullptr, *d_td_offsets = nullptr;  // level tables on the device (narrow end in one launch)
     int n_tips = 0;
     double* d_msg = nullptr;  // fused eigen sweeps: messages of the bottom-up sweep
     double* d_dist = nullptr;
@@ -479,6 +480,39 @@ static int launch_eigen_fused(pml_ctx* ctx, int mode, const int* nodes, int firs
     return fail(PML_ERR_UNSUPPORTED, "no fused eigen kernel for k = %d", k);
 }
 
+// fused eigen sweeps: levels [first_level, first_level + n_levels) of a level table in one launch
+static int launch_eigen_narrow(pml_ctx* ctx, int mode, const int* nodes, const int* d_offsets, int first_level,
+                               int n_levels) {
+    if (n_levels <= 0) return PML_OK;
+    const int k = ctx->k;
+    const int KS = (k + 3) / 4, NT = (k + 15) / 16;
+    const PmlTree t = tree_of(ctx);
+    const PmlCols c = cols_of(ctx);
+    const PmlState st = state_of(ctx);
+    const PmlModel m = model_of(ctx);
+#define PML_EIG_CASE(NT_, KS_, MODE_)                                                                              \
+    if (NT == NT_ && KS == KS_ && mode == MODE_) {                                                                 \
+        typedef EigShape<KS_> S;                                                                                   \
+        const size_t lds = ((size_t)S::KP * k + (size_t)PML_WAVES_PER_BLOCK * S::WAVE_LDS) * sizeof(double);       \
+        hipLaunchKernelGGL((eigen_narrow_kernel<NT_, KS_, MODE_>), dim3(1, ctx->C), dim3(PML_BLOCK), lds,          \
+                           ctx->stream, t, c, m, st, nodes, d_offsets + first_level, n_levels);                    \
+        HIP_TRY(hipGetLastError());                                                                                \
+        return PML_OK;                                                                                             \
+    }
+#define PML_EIG_MODES(NT_, KS_)               \
+    PML_EIG_CASE(NT_, KS_, PML_EIG_BU_MARG)   \
+    PML_EIG_CASE(NT_, KS_, PML_EIG_BU_JOINT)  \
+    PML_EIG_CASE(NT_, KS_, PML_EIG_TD)
+    PML_EIG_MODES(1, 4)
+    PML_EIG_MODES(2, 5)
+    PML_EIG_MODES(2, 6)
+    PML_EIG_MODES(2, 7)
+    PML_EIG_MODES(2, 8)
+#undef PML_EIG_MODES
+#undef PML_EIG_CASE
+    return fail(PML_ERR_UNSUPPORTED, "no fused eigen kernel for k = %d", k);
+}
+
 // bottom-up messages of all tips (observed tips 16 to a tile, see eigen_tips_kernel)
 static int launch_eigen_tips(pml_ctx* ctx, int joint) {
     if (ctx->n_tips <= 0) return PML_OK;
@@ -708,6 +742,10 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
         PML_TRY(upload(ctx, ctx->d_bu_order, bu_order, n_internal));
         PML_TRY(upload(ctx, ctx->d_td_parents, td_parents, n_internal));
     }
+    PML_TRY(dev_alloc(ctx, &ctx->d_bu_offsets, n_bu_levels + 1));
+    PML_TRY(dev_alloc(ctx, &ctx->d_td_offsets, n_td_levels + 1));
+    PML_TRY(upload(ctx, ctx->d_bu_offsets, bu_offsets, n_bu_levels + 1));
+    PML_TRY(upload(ctx, ctx->d_td_offsets, td_offsets, n_td_levels + 1));
     {
         std::vector<int> tips;
         tips.reserve(n_nodes - n_internal);
@@ -1250,9 +1288,11 @@ int pml_pij_batch(pml_ctx* ctx, double* P_out) {
 // Measured on MI355X: with one column (cfg2, 65 536 tips) 512 units per level is the best cut (0.205 -> 0.181 ms per
 // marginal pass); one workgroup per column walks the levels, so with many columns the level kernels, which spread a
 // level over the whole chip, win earlier: the limit shrinks with the number of columns.
-static int narrow_levels(const std::vector<int>& off, int n_levels, bool from_front, int C) {
+// The fused eigen sweeps pass their own limit: a pass of theirs is a ~10 us dependent chain, so only levels that one
+// workgroup finishes in a single pass per wave belong to the narrow end.
+static int narrow_levels(const std::vector<int>& off, int n_levels, bool from_front, int C, int fixed_limit = 0) {
     static const int limit_env = getenv("PASTML_HIP_NARROW_UNITS") ? atoi(getenv("PASTML_HIP_NARROW_UNITS")) : 0;
-    const int limit = limit_env > 0 ? limit_env : std::max(8, 512 / std::max(1, C));
+    const int limit = fixed_limit > 0 ? fixed_limit : (limit_env > 0 ? limit_env : std::max(8, 512 / std::max(1, C)));
     int n = 0;
     for (int q = 0; q < n_levels; ++q) {
         const int l = from_front ? q : n_levels - 1 - q;
@@ -1295,11 +1335,14 @@ static int enqueue_bottom_up(pml_ctx* ctx, int is_marginal, bool small_path, boo
         // every node once, in the launch of its level: the tips first, then the internal nodes by height
         const int mode = is_marginal ? PML_EIG_BU_MARG : PML_EIG_BU_JOINT;
         PML_TRY(launch_eigen_tips(ctx, is_marginal ? 0 : 1));
-        for (int l = 0; l < ctx->n_bu_levels; ++l) {
+        const int eig_nb = ((ctx->k + 3) / 4) % 4 == 0 ? 1 : (((ctx->k + 3) / 4) % 2 == 0 ? 2 : 4);  // EigShape::NB
+        const int tail = narrow_levels(ctx->bu_offsets, ctx->n_bu_levels, false, ctx->C, PML_WAVES_PER_BLOCK * eig_nb);
+        for (int l = 0; l < ctx->n_bu_levels - tail; ++l) {
             const int a = ctx->bu_offsets[l], b = ctx->bu_offsets[l + 1];
             PML_TRY(launch_eigen_fused(ctx, mode, ctx->d_bu_order + a, 0, b - a, 0));
         }
-        PML_TRY(prof_end(ctx, 0, ctx->n_bu_levels + 1));
+        PML_TRY(launch_eigen_narrow(ctx, mode, ctx->d_bu_order, ctx->d_bu_offsets, ctx->n_bu_levels - tail, tail));
+        PML_TRY(prof_end(ctx, 0, ctx->n_bu_levels + 1 - tail + (tail > 0 ? 1 : 0)));
     } else {
         for (int l = 0; l < ctx->n_bu_levels; ++l) {
             const int a = ctx->bu_offsets[l], b = ctx->bu_offsets[l + 1];
@@ -1418,7 +1461,19 @@ static int run_top_down(pml_ctx* ctx) {
         }
         if (eigen_fused(ctx)) {
             // child-centric: the nodes of a depth are a contiguous id range (roots are depth 0, done above)
-            for (int d = 1; d < ctx->n_td_levels; ++d) {
+            // td_offsets[d] .. td_offsets[d + 1] = the nodes of depth d: the run of narrow depths below the roots
+            int head = 0;
+            {
+                std::vector<int> off(ctx->td_offsets.begin() + 1, ctx->td_offsets.end());
+                const int ks4 = (ctx->k + 3) / 4;
+                const int eig_nb = ks4 % 4 == 0 ? 1 : (ks4 % 2 == 0 ? 2 : 4);  // EigShape::NB
+                head = narrow_levels(off, ctx->n_td_levels - 1, true, ctx->C, PML_WAVES_PER_BLOCK * eig_nb);
+            }
+            if (head > 0) {
+                PML_TRY(launch_eigen_narrow(ctx, PML_EIG_TD, nullptr, ctx->d_td_offsets, 1, head));
+                ++n_launch;
+            }
+            for (int d = 1 + head; d < ctx->n_td_levels; ++d) {
                 const int a = ctx->td_offsets[d], b = ctx->td_offsets[d + 1];
                 PML_TRY(launch_eigen_fused(ctx, PML_EIG_TD, nullptr, a, b - a, 0));
                 if (b > a) ++n_launch;

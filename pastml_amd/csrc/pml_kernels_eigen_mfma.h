@@ -136,23 +136,41 @@ __device__ __forceinline__ void eig_pass(const EigWave<NT, KS>& W, const PmlTree
                 for (int nt = 0; nt < NT; ++nt) v[nt] = mb[nt];
                 if (!tips) {
                     // mask o prod of the children's messages (ml.py:126-148), zero check and rescaling per child
+                    // The children are taken two at a time: the loads of a pair (messages, exponents) go out
+                    // together, so a binary node waits for memory once, not once per child and array.  A tip's
+                    // exponent word is zero (set when the column arrays are allocated, never written by these
+                    // sweeps), so it is read without asking whether the child is a tip.
                     const int fc = t.first_child[n], nc = t.n_children[n];
-                    for (int j = 0; j < nc; ++j) {
-                        const int ch = fc + j;
-                        bool nz = false;
+                    for (int j0 = 0; j0 < nc; j0 += 2) {
+                        double mv[2][NT];
+                        i64 cbe[2];
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) {
-                            const int i = 16 * nt + lo;
-                            const double mv = i < ks ? st.msg[(colN + ch) * ks + i] : 0.0;
-                            v[nt] *= fmax(mv, 0.0);
-                            nz |= v[nt] != 0.0;
+                        for (int u = 0; u < 2; ++u) {
+                            const int ch = fc + (j0 + u < nc ? j0 + u : j0);
+                            cbe[u] = st.be[colN + ch];
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt) {
+                                const int i = 16 * nt + lo;
+                                mv[u][nt] = i < ks ? st.msg[(colN + ch) * ks + i] : 0.0;
+                            }
                         }
-                        if (!group_any<16>(nz)) {
-                            if (lo == 0)
-                                atomicMin(&st.err[col], ((u64)(unsigned)t.post_rank[n] << 32) | (u64)(unsigned)ch);
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            if (j0 + u >= nc) break;
+                            const int ch = fc + j0 + u;
+                            bool nz = false;
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt) {
+                                v[nt] *= fmax(mv[u][nt], 0.0);
+                                nz |= v[nt] != 0.0;
+                            }
+                            if (!group_any<16>(nz)) {
+                                if (lo == 0)
+                                    atomicMin(&st.err[col], ((u64)(unsigned)t.post_rank[n] << 32) | (u64)(unsigned)ch);
+                            }
+                            esum += cbe[u];
+                            esum += lazy_rescale<16, NT>(v);
                         }
-                        if (t.n_children[ch] != 0) esum += st.be[colN + ch];
-                        esum += lazy_rescale<16, NT>(v);
                     }
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
@@ -347,6 +365,31 @@ eigen_fused_kernel(PmlTree t, PmlCols c, PmlModel m, PmlState st, const int* __r
         const bool act = W.hi < NB && b0 + W.hi < n_nodes;
         const int n = act ? (nodes != nullptr ? nodes[b0 + W.hi] : first + b0 + W.hi) : 0;
         eig_pass<NT, KS, MODE>(W, t, c, st, act, n, tips);
+    }
+}
+
+// The narrow end of a large forest in one launch: one workgroup per column walks the levels [0, n_levels) of a level
+// table (offsets into `nodes`, or node id ranges when nodes == nullptr) with a workgroup barrier between levels.  The
+// prologue of the fused kernels (A, Ainv into registers / LDS) and the launch are paid once instead of once per level.
+template <int NT, int KS, int MODE>
+__global__ void __launch_bounds__(PML_BLOCK)
+eigen_narrow_kernel(PmlTree t, PmlCols c, PmlModel m, PmlState st, const int* __restrict__ nodes,
+                    const int* __restrict__ level_offsets, int n_levels) {
+    typedef EigShape<KS> S;
+    constexpr int NB = S::NB;
+    extern __shared__ double smem[];
+    EigWave<NT, KS> W;
+    eig_wave_init<NT, KS>(W, c, m, smem, S::WAVE_LDS, NB);
+    W.colN = (size_t)W.col * t.N;
+    const int wave = threadIdx.x >> 6;
+    for (int l = 0; l < n_levels; ++l) {
+        const int a = level_offsets[l], n_level = level_offsets[l + 1] - a;
+        for (int b0 = wave * NB; b0 < n_level; b0 += PML_WAVES_PER_BLOCK * NB) {
+            const bool act = W.hi < NB && b0 + W.hi < n_level;
+            const int n = act ? (nodes != nullptr ? nodes[a + b0 + W.hi] : a + b0 + W.hi) : 0;
+            eig_pass<NT, KS, MODE>(W, t, c, st, act, n, 0);
+        }
+        __syncthreads();
     }
 }
 
