@@ -52,12 +52,24 @@ def get_forest_stats(flat):
 
 
 def df2gdf(df):
-    """Groups annotation rows by node name into sets of non-empty states (annotation.py:104-110)."""
+    """
+    One row per node name holding, for every column, the set of its non-empty values over all rows of that name
+    (what annotation.py:104-110 builds with a pandas group-by/apply: one Python call per name and column there, one pass
+    over the column arrays here).  Rows come out sorted by name, as a group-by leaves them; empty cells of ``df`` become
+    '' in place, as in the reference.
+    """
     df.fillna('', inplace=True)
-    gb = df.groupby(df.index)
-    gdf = pd.DataFrame(columns=df.columns)
+    names = df.index.to_numpy()
+    order = sorted(set(names))
+    position = {name: i for i, name in enumerate(order)}
+    rows = np.fromiter((position[name] for name in names), dtype=np.int64, count=len(names))
+    gdf = pd.DataFrame(index=pd.Index(order, name=df.index.name), columns=df.columns)
     for c in df.columns:
-        gdf[c] = gb[c].apply(lambda vs: {v for v in vs if not pd.isnull(v) and v != ''})
+        cells = [set() for _ in order]
+        for r, v in zip(rows, df[c].to_numpy()):
+            if v != '' and not pd.isnull(v):
+                cells[r].add(v)
+        gdf[c] = pd.Series(cells, index=gdf.index, dtype=object)
     return gdf
 
 

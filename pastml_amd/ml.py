@@ -267,23 +267,32 @@ class ForestProblem(object):
             model.set_params_from_optimised(ps)
             specs.append((model.kernel_spec(), model.rate_params()))
             variants.append(0 == model.tau)
-        # masks: altered (tau == 0) or as they are; the alteration does not depend on the other parameters
+        # masks: altered (tau == 0) or as they are; the alteration does not depend on the other parameters, only on
+        # the masks themselves, so it is computed once per state of the masks (the optimiser calls this hundreds of
+        # times between two changes of them) and the columns remember which version they hold
         plain = self.masks
-        altered_masks = None
+        plain_key = hash(plain.tobytes())
+        altered_masks, altered_key = None, None
         if any(variants):
-            keep = (self.masks.copy(), self.init_masks.copy(), self.has_init.copy())
-            altered = self.alter_zero_node_allowed_states()
-            altered_masks = self.masks.copy()
-            # the evaluation itself leaves masks as they were (marginal sweeps un-alter, ml.py:115-117), but the saved
-            # '.initial' masks stay, exactly as after a sequence of single evaluations
-            self.masks = keep[0]
-            if not len(altered):
-                self.init_masks, self.has_init = keep[1], keep[2]
+            memo = self.__dict__.get('_alter_memo')
+            if memo is not None and memo[0] == plain_key:
+                altered_masks, altered_key = memo[1], memo[2]
+            else:
+                keep = (self.masks.copy(), self.init_masks.copy(), self.has_init.copy())
+                altered = self.alter_zero_node_allowed_states()
+                altered_masks = self.masks.copy()
+                altered_key = hash(altered_masks.tobytes())
+                # the evaluation itself leaves masks as they were (marginal sweeps un-alter, ml.py:115-117), but the
+                # saved '.initial' masks stay, exactly as after a sequence of single evaluations
+                self.masks = keep[0]
+                if not len(altered):
+                    self.init_masks, self.has_init = keep[1], keep[2]
+                self._alter_memo = (plain_key, altered_masks, altered_key)
         for col, variant in enumerate(variants):
-            wanted = altered_masks if variant else plain
-            if slot['masks'][col] is None or not np.array_equal(slot['masks'][col], wanted):
+            wanted, wanted_key = (altered_masks, altered_key) if variant else (plain, plain_key)
+            if slot['masks'][col] != wanted_key:
                 engine.set_masks(wanted, col_begin=col)
-                slot['masks'][col] = wanted.copy()
+                slot['masks'][col] = wanted_key
         engine.set_models(specs)
         self.n_sweeps += C
         try:
