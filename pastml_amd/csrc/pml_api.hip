@@ -1543,7 +1543,18 @@ int pml_top_down_marginals(pml_ctx* ctx, double* posterior_out, double* lh_sum_o
 int pml_joint_backtrace(pml_ctx* ctx, int32_t* joint_state_out) {
     PML_TRY(require_model(ctx));
     if (ctx->bu_mode != 0) return fail(PML_ERR_INVALID, "pml_joint_backtrace needs a successful joint pml_bottom_up first");
-    for (int l = 1; l < ctx->n_td_levels; ++l) {
+    // the narrow depths below the roots in one launch, the wide ones one launch each
+    int head = 0;
+    {
+        std::vector<int> off(ctx->td_offsets.begin() + 1, ctx->td_offsets.end());
+        head = narrow_levels(off, ctx->n_td_levels - 1, true, ctx->C, 1024);
+    }
+    if (head > 0) {
+        hipLaunchKernelGGL(joint_backtrace_narrow_kernel, dim3(1, ctx->C), dim3(PML_BLOCK), 0, ctx->stream, tree_of(ctx),
+                           cols_of(ctx), state_of(ctx), ctx->d_td_offsets, 1, head);
+        HIP_TRY(hipGetLastError());
+    }
+    for (int l = 1 + head; l < ctx->n_td_levels; ++l) {
         const int a = ctx->td_offsets[l], b = ctx->td_offsets[l + 1];
         if (b <= a) continue;
         dim3 grid(grid_for(b - a, PML_BLOCK, ctx->C), ctx->C);

@@ -104,6 +104,23 @@ joint_backtrace_kernel(PmlTree t, PmlCols c, PmlState st, int begin, int end) {
     }
 }
 
+// the depth levels right below the roots (a handful of nodes each) in one launch: one workgroup per column, a
+// workgroup barrier between levels; depth_offsets[d] .. depth_offsets[d + 1] are the node ids of depth d
+__global__ void __launch_bounds__(PML_BLOCK)
+joint_backtrace_narrow_kernel(PmlTree t, PmlCols c, PmlState st, const int* __restrict__ depth_offsets, int first_depth,
+                              int n_depths) {
+    const int col = blockIdx.y;
+    const size_t colN = (size_t)col * t.N;
+    for (int d = first_depth; d < first_depth + n_depths; ++d) {
+        const int begin = depth_offsets[d], end = depth_offsets[d + 1];
+        for (int n = begin + threadIdx.x; n < end; n += blockDim.x) {
+            const int ps = st.js[colN + t.parent[n]];
+            st.js[colN + n] = st.J[(colN + n) * c.ks + ps];
+        }
+        __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // State selection from the marginal posteriors: MAP (pastml/ml.py:577-595) and MPPA (pastml/ml.py:505-574).
 // One unit = (node, column), G lanes with R contiguous states each; the unit's vectors live in LDS.
