@@ -15,7 +15,11 @@ struct PmlModel {
 };
 
 // HKY85 closed form (pastml/models/HKYModel.py:55-82); states A, C, G, T = 0..3.  p[i][j].
+// No FMA contraction here: entries such as pc sct - pc ect cancel exactly at t = 0 only when both products are rounded
+// as numpy rounds them, and whether P(0) holds an exact zero or 1e-17 decides if a zero-length branch between
+// conflicting states is a zero likelihood (ml.py:139-145) -- the reference's answer must be ours.
 __device__ __forceinline__ void hky_matrix(const double* __restrict__ pi, double kappa, double tt, double (&p)[4][4]) {
+#pragma clang fp contract(off)
     const double pa = pi[0], pc = pi[1], pg = pi[2], pt = pi[3];
     const double pag = pa + pg, pct = pc + pt;
     const double beta = .5 / (pag * pct + kappa * (pa * pg + pc * pt));
