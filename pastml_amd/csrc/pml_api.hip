@@ -95,7 +95,8 @@ struct pml_ctx {
     double *d_E = nullptr, *d_P = nullptr, *d_bu = nullptr, *d_S = nullptr, *d_td = nullptr, *d_post = nullptr,
            *d_lhsum = nullptr;
     i64 *d_be = nullptr, *d_te = nullptr, *d_lhe = nullptr;
-    int *d_J = nullptr, *d_js = nullptr;
+    pml_jt* d_J = nullptr;  // arg-max tables, one byte per entry
+    int* d_js = nullptr;
     u64* d_err = nullptr;
     int bu_mode = -1;  // -1 invalid, 1 marginal, 0 joint
     bool js_ever = false;  // joint states of some earlier joint sweep are still in d_js
@@ -1708,8 +1709,12 @@ int pml_download(pml_ctx* ctx, int what, int32_t col, void* out) {
             return fetch_exponents(ctx, ctx->d_lhe, col, (double*)out);
         case PML_BUF_JOINT_TABLE: {
             if (ctx->bu_mode != 0) return fail(PML_ERR_INVALID, "no valid joint sweep");
-            HIP_TRY(hipMemcpy2D(out, ctx->k * sizeof(int), ctx->d_J + (size_t)col * N * ctx->ks, ctx->ks * sizeof(int),
-                                ctx->k * sizeof(int), N, hipMemcpyDeviceToHost));
+            // the tables hold one byte per entry on the device; the interface hands out int32
+            std::vector<pml_jt> tmp(N * ctx->ks);
+            HIP_TRY(hipMemcpy(tmp.data(), ctx->d_J + (size_t)col * N * ctx->ks, tmp.size(), hipMemcpyDeviceToHost));
+            int32_t* o = (int32_t*)out;
+            for (size_t n = 0; n < N; ++n)
+                for (int i = 0; i < ctx->k; ++i) o[n * ctx->k + i] = tmp[n * ctx->ks + i];
             return PML_OK;
         }
         case PML_BUF_JOINT_STATE:

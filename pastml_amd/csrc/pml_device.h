@@ -156,6 +156,20 @@ __device__ __forceinline__ void store_vec(double* __restrict__ p, const double (
     }
 }
 
+// R consecutive entries of an arg-max table (one byte each)
+template <int R>
+__device__ __forceinline__ void store_vec_u8(unsigned char* __restrict__ p, const int (&v)[R]) {
+    if (R == 4) {
+        *reinterpret_cast<unsigned*>(p) = (unsigned)((v[0] & 0xff) | ((v[1] & 0xff) << 8) | ((v[2] & 0xff) << 16) |
+                                                     ((unsigned)(v[3] & 0xff) << 24));
+    } else if (R == 2) {
+        *reinterpret_cast<unsigned short*>(p) = (unsigned short)((v[0] & 0xff) | ((v[1] & 0xff) << 8));
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) p[r] = (unsigned char)v[r];
+    }
+}
+
 template <int R>
 __device__ __forceinline__ void store_vec_i32(int* __restrict__ p, const int (&v)[R]) {
     if (R == 1) {

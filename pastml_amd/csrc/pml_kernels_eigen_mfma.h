@@ -315,7 +315,7 @@ __device__ __forceinline__ void eig_pass(const EigWave<NT, KS>& W, const PmlTree
                     const int i = 16 * nt + lo;
                     if (i < ks) {
                         st.msg[row + i] = i < k ? r[nt] : 0.0;
-                        if (MODE == PML_EIG_BU_JOINT) st.J[row + i] = i < k ? rj[nt] : 0;
+                        if (MODE == PML_EIG_BU_JOINT) st.J[row + i] = (pml_jt)(i < k ? rj[nt] : 0);
                     }
                 }
             } else {
@@ -485,7 +485,7 @@ eigen_tips_kernel(PmlTree t, PmlCols c, PmlModel m, PmlState st, const int* __re
                         arg = 1;
                     }
                     if (altered && !((mi >> arg) & 1ull)) arg = mi ? __builtin_ctzll(mi) : 0;
-                    st.J[row + i] = i < k ? arg : 0;
+                    st.J[row + i] = (pml_jt)(i < k ? arg : 0);
                 }
                 st.msg[row + i] = pv;
             }

@@ -17,6 +17,8 @@
 #define PML_KIND_CHERRY 1
 #define PML_KIND_STORED 2
 
+typedef unsigned char pml_jt;  // entry of an arg-max table: a state index, k <= PML_MAX_STATES = 256
+
 struct PmlTree {
     int N;
     int n_roots;
@@ -45,7 +47,7 @@ struct PmlState {
     double* post;   // [C][N][ks]
     double* lhsum;  // [C][N]
     i64* lhe;       // [C][N]
-    int* J;         // [C][N][ks]  joint argmax tables
+    pml_jt* J;      // [C][N][ks]  joint argmax tables (one byte per entry: k <= 256)
     int* js;        // [C][N]      joint states
     u64* err;       // [C]         min over failing (post_rank << 32 | child id)
     double* msg;    // [C][N][ks]  fused eigen sweeps: message of a node to its parent, P(t) applied to its BU vector
@@ -57,7 +59,7 @@ __device__ __forceinline__ int node_kind(const PmlTree& t, int n) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// per-branch e = exp(-mu t') for every (node, column); for tips also S = pi . mask and be = 0
+// per-branch e = exp(-mu t') for every (node, column); for tips also S = pi . mask
 // replaces: transform_t (models/__init__.py:269) + the exp of F81Model.get_Pij_t (F81Model.py:42-45)
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(PML_BLOCK)
@@ -80,8 +82,7 @@ f81_prep_kernel(PmlTree t, PmlCols c, const double* __restrict__ mu, const doubl
                     word &= word - 1ull;
                 }
             }
-            st.S[colN + n] = acc;
-            st.be[colN + n] = 0;
+            st.S[colN + n] = acc;  // a tip's exponent word stays 0 from the allocation of the column arrays
         }
     }
 }
@@ -434,6 +435,22 @@ __device__ __forceinline__ void f81_cherry_from_lanes(const LaneCtx<G, R>& L, co
     if (!(amin >= 0x1p-200)) esum = lazy_rescale<G, R>(v);
 }
 
+// One row of an arg-max table: a byte per state; the two states of a lane's pair go out as one 16-bit store, so the G
+// lanes of a unit write 2G consecutive bytes per pair index.
+template <int G, int R>
+__device__ __forceinline__ void f81_store_table(const LaneCtx<G, R>& L, const PmlCols& c, pml_jt* __restrict__ jp,
+                                                const int (&jj)[R]) {
+    if (R == 1) {
+        if (L.st(0) < c.ks) jp[L.st(0)] = (pml_jt)jj[0];
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; r += 2) {
+            if (L.st(r) < c.ks)
+                *reinterpret_cast<unsigned short*>(jp + L.st(r)) = (unsigned short)((jj[r] & 0xff) | ((jj[r + 1] & 0xff) << 8));
+        }
+    }
+}
+
 // Everything a fast bottom-up unit reads, as issued loads: the gathered scalars, the unit's own mask word and the
 // vectors of its first two children where those are stored nodes.  Filled one unit ahead by the level kernel (software
 // pipeline: the loads of unit i + 1 are in flight while unit i is computed), on the spot elsewhere.
@@ -662,22 +679,7 @@ __device__ __forceinline__ void bu_f81_unit_seq(const LaneCtx<G, R>& L, const Pm
                     }
                 }
             }
-            {
-                int* jp = st.J + ((size_t)L.col * t.N + ch) * c.ks;
-                if (R == 1) {
-                    if (L.st(0) < c.ks) jp[L.st(0)] = jj[0];
-                } else {
-#pragma unroll
-                    for (int r = 0; r < R; r += 2) {
-                        if (L.st(r) < c.ks) {
-                            int2 t2;
-                            t2.x = jj[r];
-                            t2.y = jj[r + 1];
-                            *reinterpret_cast<int2*>(jp + L.st(r)) = t2;
-                        }
-                    }
-                }
-            }
+            f81_store_table<G, R>(L, c, st.J + ((size_t)L.col * t.N + ch) * c.ks, jj);
             if (!group_any<G>(nz)) {
                 if (L.g == 0)
                     atomicMin(&st.err[L.col], ((u64)(unsigned)t.post_rank[n] << 32) | (u64)(unsigned)ch);
@@ -1096,7 +1098,6 @@ bu_f81_small_kernel(PmlTree t, PmlCols c, PmlState st, const double* __restrict_
                     }
                 }
                 st.S[colN + n] = acc;
-                st.be[colN + n] = 0;
             }
         }
         __syncthreads();

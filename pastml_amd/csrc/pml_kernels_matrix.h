@@ -140,7 +140,7 @@ bu_matrix_kernel(PmlTree t, PmlCols c, PmlState st, const double* __restrict__ P
                             }
                         }
                     }
-                    if (lane_valid) store_vec_i32<R>(st.J + (colN + ch) * c.ks + s0, jj);
+                    if (lane_valid) store_vec_u8<R>(st.J + (colN + ch) * c.ks + s0, jj);
                 }
                 bool nz = false;
 #pragma unroll
@@ -224,7 +224,7 @@ bu_matrix_kernel(PmlTree t, PmlCols c, PmlState st, const double* __restrict__ P
                         }
                     }
                 }
-                if (lane_valid) store_vec_i32<R>(st.J + (colN + ch) * c.ks + s0, jj);
+                if (lane_valid) store_vec_u8<R>(st.J + (colN + ch) * c.ks + s0, jj);
             }
             bool nz = false;
 #pragma unroll
