@@ -75,6 +75,7 @@ struct pml_ctx {
     bool small = false;  // forest small enough for the one-launch-per-sweep kernels
     std::vector<int> bu_offsets_f, td_parent_offsets_f;
     std::vector<char> bu_level_vec_f;  // per fused bottom-up level: some unit has a stored node as child 0 or 1
+    std::vector<char> bu_level_vec;    // the same for the plain levels (joint sweep: every internal node is stored)
     int n_cherries = 0;
     bool bu_fused = false;  // the last bottom-up sweep left the cherries unmaterialised
 
@@ -286,7 +287,8 @@ static int prof_end(pml_ctx* ctx, int which, long long launches) {
 
 enum SweepKind {
     SW_BU_MARG, SW_BU_JOINT, SW_TD, SW_ROOTS, SW_BU_MARG_FUSED, SW_TD_FUSED, SW_BU_CHERRIES,
-    SW_BU_MARG_FUSED_NOVEC  // a fused level none of whose units has a stored node among its first two children
+    SW_BU_MARG_FUSED_NOVEC,  // a fused level none of whose units has a stored node among its first two children
+    SW_BU_JOINT_NOVEC        // the same for a level of the joint sweep (the level whose children are all tips)
 };
 
 // matrix-model sweeps: contiguous state ownership (state = g * R + r)
@@ -326,12 +328,13 @@ static void launch_sweep_f81(pml_ctx* ctx, SweepKind what, const int* level, int
     const PmlState st = state_of(ctx);
     const int upb = PML_WAVES_PER_BLOCK * (64 / G);
     const bool pipelined = what == SW_BU_MARG_FUSED || what == SW_BU_MARG_FUSED_NOVEC || what == SW_BU_MARG ||
-                           what == SW_BU_CHERRIES;
+                           what == SW_BU_CHERRIES || what == SW_BU_JOINT || what == SW_BU_JOINT_NOVEC;
     dim3 grid(grid_for(n_level, upb, ctx->C, pipelined), ctx->C), block(PML_BLOCK);
     // the level is given as a position in one of the node lists; the kernels read the descriptor list parallel to it
     const PmlUnit* units = nullptr;
     if (what == SW_BU_MARG_FUSED || what == SW_BU_MARG_FUSED_NOVEC) units = ctx->d_bu_units_f + (level - ctx->d_bu_order_f);
-    if (what == SW_BU_MARG || what == SW_BU_JOINT) units = ctx->d_bu_units + (level - ctx->d_bu_order);
+    if (what == SW_BU_MARG || what == SW_BU_JOINT || what == SW_BU_JOINT_NOVEC)
+        units = ctx->d_bu_units + (level - ctx->d_bu_order);
     if (what == SW_TD_FUSED) units = ctx->d_td_units_f + (level - ctx->d_td_parents_f);
     if (what == SW_BU_CHERRIES) units = ctx->d_cherry_units + (level - ctx->d_cherries);
     switch (what) {
@@ -347,6 +350,10 @@ static void launch_sweep_f81(pml_ctx* ctx, SweepKind what, const int* level, int
             break;
         case SW_BU_JOINT:
             hipLaunchKernelGGL((bu_f81_kernel<G, R, true, true>), grid, block, 0, ctx->stream, t, c, st, units,
+                               n_level);
+            break;
+        case SW_BU_JOINT_NOVEC:
+            hipLaunchKernelGGL((bu_f81_kernel<G, R, true, false>), grid, block, 0, ctx->stream, t, c, st, units,
                                n_level);
             break;
         case SW_TD_FUSED:
@@ -861,6 +868,12 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
                 }
             describe(tdp.data(), n_stored, true, ut_f);
             describe(bu_order, n_internal, false, ub);
+            ctx->bu_level_vec.assign(n_bu_levels > 0 ? n_bu_levels : 1, 0);
+            for (int l = 0; l < n_bu_levels; ++l)
+                for (int q = bu_offsets[l]; q < bu_offsets[l + 1] && !ctx->bu_level_vec[l]; ++q) {
+                    const int pk = ub[q].packed;
+                    if (((pk >> 8) & 7) == 1 || ((pk >> 11) & 7) == 1) ctx->bu_level_vec[l] = 1;
+                }
             PML_TRY(dev_alloc(ctx, &ctx->d_bu_units_f, ub_f.size()));
             PML_TRY(dev_alloc(ctx, &ctx->d_td_units_f, ut_f.size()));
             PML_TRY(dev_alloc(ctx, &ctx->d_bu_units, ub.size()));
@@ -1347,7 +1360,9 @@ static int enqueue_bottom_up(pml_ctx* ctx, int is_marginal, bool small_path, boo
     } else {
         for (int l = 0; l < ctx->n_bu_levels; ++l) {
             const int a = ctx->bu_offsets[l], b = ctx->bu_offsets[l + 1];
-            PML_TRY(dispatch_sweep(ctx, is_marginal ? SW_BU_MARG : SW_BU_JOINT, ctx->d_bu_order + a, b - a));
+            const SweepKind sk = is_marginal ? SW_BU_MARG : (ctx->kind == PML_MODEL_F81 && !ctx->bu_level_vec[l]
+                                                                     ? SW_BU_JOINT_NOVEC : SW_BU_JOINT);
+            PML_TRY(dispatch_sweep(ctx, sk, ctx->d_bu_order + a, b - a));
         }
         PML_TRY(prof_end(ctx, 0, ctx->n_bu_levels));
     }

@@ -101,17 +101,49 @@ __device__ __forceinline__ double group_max(double v) {
     return v;
 }
 
-// (value, index) arg-max with numpy semantics: the first (lowest) index among equal maxima wins
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
+}
+
+__device__ __forceinline__ void argmax_take(double& v, int& idx, double ov, int oi) {
+    if (ov > v || (ov == v && oi < idx)) {
+        v = ov;
+        idx = oi;
+    }
+}
+
+// (value, index) arg-max over the G lanes of a unit with numpy semantics -- the first (lowest) index among equal
+// maxima wins -- result in every lane.  Same lane exchanges as group_sum (DPP inside a row, then the two swaps).
 template <int G>
 __device__ __forceinline__ void group_argmax_first(double& v, int& idx) {
-#pragma unroll
-    for (int o = G / 2; o > 0; o >>= 1) {
-        double ov = __shfl_xor(v, o, 64);
-        int oi = __shfl_xor(idx, o, 64);
-        if (ov > v || (ov == v && oi < idx)) {
-            v = ov;
-            idx = oi;
-        }
+    if (G >= 2) argmax_take(v, idx, dpp_f64<0xB1>(v), dpp_i32<0xB1>(idx));
+    if (G >= 4) argmax_take(v, idx, dpp_f64<0x4E>(v), dpp_i32<0x4E>(idx));
+    if (G >= 8) argmax_take(v, idx, dpp_f64<0x141>(v), dpp_i32<0x141>(idx));
+    if (G >= 16) argmax_take(v, idx, dpp_f64<0x140>(v), dpp_i32<0x140>(idx));
+    if (G >= 32) {
+        const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+        const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        const auto q = __builtin_amdgcn_permlane16_swap((unsigned)idx, (unsigned)idx, false, false);
+        // the two results are this row's and the partner row's values, in an order that depends on the row: taking
+        // the better of the two is symmetric
+        double v0 = __hiloint2double(b[0], a[0]), v1 = __hiloint2double(b[1], a[1]);
+        int i0 = (int)q[0], i1 = (int)q[1];
+        argmax_take(v0, i0, v1, i1);
+        v = v0;
+        idx = i0;
+    }
+    if (G >= 64) {
+        const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+        const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        const auto q = __builtin_amdgcn_permlane32_swap((unsigned)idx, (unsigned)idx, false, false);
+        double v0 = __hiloint2double(b[0], a[0]), v1 = __hiloint2double(b[1], a[1]);
+        int i0 = (int)q[0], i1 = (int)q[1];
+        argmax_take(v0, i0, v1, i1);
+        v = v0;
+        idx = i0;
     }
 }
 

@@ -375,7 +375,7 @@ struct TipLane {  // what lane j * GC + q holds about tip q of cherry child j
     u64 mask;
 };
 
-template <int G, int R>
+template <int G, int R, bool TIPS_OF_CHERRIES = true>
 __device__ __forceinline__ void f81_gather_issue(const LaneCtx<G, R>& L, const UnitRegs& u, ChildLane& cl,
                                                  TipLane& tl) {
     constexpr int GC = Gather<G>::GC;
@@ -386,6 +386,11 @@ __device__ __forceinline__ void f81_gather_issue(const LaneCtx<G, R>& L, const U
     cl.s = L.S[ch];
     cl.mask = L.mask[(unsigned)ch];
     cl.be = L.be[ch];
+    if (!TIPS_OF_CHERRIES) {
+        tl.e = tl.s = 0.0;
+        tl.mask = 0ull;
+        return;
+    }
     const int jj = L.g / GC, q = L.g % GC;
     const int code = unit_code(u.packed, jj & 3);
     const bool has_t = jj < nc && q < code - 1;  // code - 1 = number of tips of a cherry child (<= 0 otherwise)
@@ -435,6 +440,59 @@ __device__ __forceinline__ void f81_cherry_from_lanes(const LaneCtx<G, R>& L, co
     if (!(amin >= 0x1p-200)) esum = lazy_rescale<G, R>(v);
 }
 
+// Message of a child with bottom-up vector v in Pupko's max variant (ml.py:134-136) and the arg-max row that goes
+// with it.  Row i of P * diag(v): off-diagonal entries w_j = ((1-e) pi_j) v_j, diagonal ((1-e) pi_i + e) v_i (same
+// rounding sequence as the reference's P * v broadcast, ml.py:130 with F81Model.py:46), so the row maximum is the larger
+// of the diagonal entry and the best off-diagonal one: the top two of w over the unit's lanes, two butterflies.
+template <int G, int R>
+__device__ __forceinline__ void f81_joint_message(const LaneCtx<G, R>& L, const PmlCols& c, double e,
+                                                  const double (&v)[R], double (&msg)[R], int (&jj)[R]) {
+    const double ome = 1.0 - e;
+    double w[R], dg[R];
+    double m1 = -INFINITY;
+    int j1 = 0x7fffffff;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const double a = ome * L.pi_r[r];
+        const bool ok = L.st(r) < c.k;
+        w[r] = ok ? a * v[r] : -INFINITY;
+        dg[r] = (a + e) * v[r];
+        if (ok && w[r] > m1) {
+            m1 = w[r];
+            j1 = L.st(r);
+        }
+    }
+    group_argmax_first<G>(m1, j1);
+    double m2 = -INFINITY;
+    int j2 = 0x7fffffff;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (L.st(r) < c.k && L.st(r) != j1 && w[r] > m2) {
+            m2 = w[r];
+            j2 = L.st(r);
+        }
+    }
+    group_argmax_first<G>(m2, j2);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int i = L.st(r);
+        const double mo = (i == j1) ? m2 : m1;
+        const int jo = (i == j1) ? j2 : j1;
+        int arg;
+        if (jo >= c.k || dg[r] > mo) {  // no off-diagonal candidate (k == 1) or the diagonal wins
+            msg[r] = dg[r];
+            arg = i;
+        } else if (dg[r] < mo) {
+            msg[r] = mo;
+            arg = jo;
+        } else {  // tie: numpy's argmax returns the first index
+            msg[r] = mo;
+            arg = min(i, jo);
+        }
+        jj[r] = (i < c.k) ? arg : 0;
+    }
+}
+
 // One row of an arg-max table: a byte per state; the two states of a lane's pair go out as one 16-bit store, so the G
 // lanes of a unit write 2G consecutive bytes per pair index.
 template <int G, int R>
@@ -466,10 +524,10 @@ struct BuLoads {
 // same for every unit (VEC: a child that is not a stored node reads the column's frequency vector instead, a cache
 // hit), so that the compiler can wait for exactly the loads of one unit while those of the next stay in flight.
 // VEC = false is for levels without stored children (the level that rebuilds cherries): no vector loads at all.
-template <int G, int R, bool VEC>
+template <int G, int R, bool VEC, bool JOINT = false>
 __device__ __forceinline__ void bu_f81_issue(const LaneCtx<G, R>& L, const PmlCols& c, const UnitRegs& u,
                                              BuLoads<R>& ld) {
-    f81_gather_issue<G, R>(L, u, ld.cl, ld.tl);
+    f81_gather_issue<G, R, !JOINT>(L, u, ld.cl, ld.tl);
     ld.own = L.mask[(unsigned)u.n];
     if (VEC) {
         const bool s0 = unit_code(u.packed, 0) == 1, s1 = unit_nc(u.packed) > 1 && unit_code(u.packed, 1) == 1;
@@ -484,10 +542,13 @@ __device__ __forceinline__ void bu_f81_issue(const LaneCtx<G, R>& L, const PmlCo
 // Makes every value of ld available here: the compiler places ONE s_waitcnt with the right count at this point (the
 // loads issued after ld's -- the next unit's -- stay in flight) instead of conservative vmcnt(0) waits wherever the
 // unit's control flow first touches a value.
-template <int R, bool VEC>
+template <int R, bool VEC, bool JOINT = false>
 __device__ __forceinline__ void bu_loads_arrived(BuLoads<R>& ld) {
-    asm volatile("" : "+v"(ld.cl.e), "+v"(ld.cl.s), "+v"(ld.cl.mask), "+v"(ld.cl.be), "+v"(ld.tl.e), "+v"(ld.tl.s),
-                      "+v"(ld.tl.mask), "+v"(ld.own));
+    if (JOINT)
+        asm volatile("" : "+v"(ld.cl.e), "+v"(ld.cl.s), "+v"(ld.cl.mask), "+v"(ld.cl.be), "+v"(ld.own));
+    else
+        asm volatile("" : "+v"(ld.cl.e), "+v"(ld.cl.s), "+v"(ld.cl.mask), "+v"(ld.cl.be), "+v"(ld.tl.e), "+v"(ld.tl.s),
+                          "+v"(ld.tl.mask), "+v"(ld.own));
     if (VEC) {
 #pragma unroll
         for (int r = 0; r < R; ++r) asm volatile("" : "+v"(ld.v0[r]), "+v"(ld.v1[r]));
@@ -497,12 +558,12 @@ __device__ __forceinline__ void bu_loads_arrived(BuLoads<R>& ld) {
 // Returns false when the unit's vector came out all zero: a product only ever gains zeros, so the zero check of
 // ml.py:139-145 is made once at the end, and the caller repeats the unit on the sequential path, which checks after
 // every child and reports the pair the reference would name.
-template <int G, int R, bool VEC>
+template <int G, int R, bool VEC, bool JOINT = false>
 __device__ __forceinline__ bool bu_f81_unit_fast(const LaneCtx<G, R>& L, const PmlTree& t, const PmlCols& c,
                                                  const PmlState& st, const UnitRegs& u, BuLoads<R>& ld) {
     const int n = u.n, fc = u.fc;
     const int nc = unit_nc(u.packed);
-    bu_loads_arrived<R, VEC>(ld);
+    bu_loads_arrived<R, VEC, JOINT>(ld);
     double acc[R];
     word_to_vec<G, R>(L, c, ld.own, acc);
     ChildLane& cl = ld.cl;
@@ -515,6 +576,38 @@ __device__ __forceinline__ bool bu_f81_unit_fast(const LaneCtx<G, R>& L, const P
         const int code = unit_code(u.packed, jx);
         const double e = __shfl(cl.e, src, 64);
         double v[R];
+        if (JOINT) {
+            // Pupko's max variant (every internal node is a stored node here: codes 0 and 1 only)
+            double msg[R];
+            int jj[R];
+            bool closed = false;
+            if (code == 0) {
+                // An observed tip has one non-zero product per row, so max = sum: its message is the marginal one,
+                // a + e [i == s] with a = (1 - e) pi_s, and every row's arg-max is s (a > 0; else the general scan).
+                const u64 word = __shfl(cl.mask, src, 64);
+                const double a = (1.0 - e) * __shfl(cl.s, src, 64);
+                clean_word_to_vec<G, R>(L, c, word, v);
+                if (__popcll(word) == 1 && a > 0.0) {
+                    const int s = __builtin_ctzll(word);
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        msg[r] = a + e * v[r];
+                        jj[r] = L.st(r) < c.k ? s : 0;
+                    }
+                    closed = true;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < R; ++r) v[r] = jx == 0 ? ld.v0[r] : ld.v1[r];
+                esum += __shfl(cl.be, src, 64);
+            }
+            if (!closed) f81_joint_message<G, R>(L, c, e, v, msg, jj);
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r] *= fmax(msg[r], 0.0);
+            f81_store_table<G, R>(L, c, st.J + ((size_t)L.col * t.N + ch) * c.ks, jj);
+            esum += lazy_rescale<G, R>(acc);
+            continue;
+        }
         double s_child;
         if (code == 0) {
             clean_word_to_vec<G, R>(L, c, __shfl(cl.mask, src, 64), v);
@@ -533,6 +626,15 @@ __device__ __forceinline__ bool bu_f81_unit_fast(const LaneCtx<G, R>& L, const P
         }
         f81_absorb_child<G, R>(L, t, st, n, ch, e, s_child, v, acc, false);
         if ((jx & 1) == 1 || jx == nc - 1) esum += lazy_rescale<G, R>(acc);
+    }
+    if (JOINT) {
+        bool nz = false;
+#pragma unroll
+        for (int r = 0; r < R; ++r) nz |= acc[r] != 0.0 && L.st(r) < c.k;
+        if (!group_any<G>(nz)) return false;
+        if (L.g == 0) L.be[n] = esum;
+        node_store_vec<G, R>(L, c, L.bu, n, acc);
+        return true;
     }
     const double s = pi_dot<G, R>(L, acc);
     if (!(s > 0.0)) {  // pi . acc > 0 already says that acc is not all zero
@@ -612,56 +714,14 @@ __device__ __forceinline__ void bu_f81_unit_seq(const LaneCtx<G, R>& L, const Pm
             // double range, so the band is checked every second child and at the end
             if ((j & 1) == 1 || j == nc - 1) esum += lazy_rescale<G, R>(acc);
         } else {
-            // row i of P * diag(v): off-diagonal entries w_j = ((1-e) pi_j) v_j, diagonal ((1-e) pi_i + e) v_i
-            // (same rounding sequence as the reference's P * v broadcast, ml.py:130 with F81Model.py:46)
-            const double ome = 1.0 - e;
-            double w[R], dg[R];
-            double m1 = -INFINITY;
-            int j1 = 0x7fffffff;
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const double a = ome * L.pi_r[r];
-                const bool ok = L.st(r) < c.k;
-                w[r] = ok ? a * v[r] : -INFINITY;
-                dg[r] = (a + e) * v[r];
-                if (ok && w[r] > m1) {
-                    m1 = w[r];
-                    j1 = L.st(r);
-                }
-            }
-            group_argmax_first<G>(m1, j1);
-            double m2 = -INFINITY;
-            int j2 = 0x7fffffff;
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                if (L.st(r) < c.k && L.st(r) != j1 && w[r] > m2) {
-                    m2 = w[r];
-                    j2 = L.st(r);
-                }
-            }
-            group_argmax_first<G>(m2, j2);
+            double msg[R];
             int jj[R];
+            f81_joint_message<G, R>(L, c, e, v, msg, jj);
             bool nz = false;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                const int i = L.st(r);
-                const double mo = (i == j1) ? m2 : m1;
-                const int jo = (i == j1) ? j2 : j1;
-                double msg;
-                int arg;
-                if (jo >= c.k || dg[r] > mo) {  // no off-diagonal candidate (k == 1) or the diagonal wins
-                    msg = dg[r];
-                    arg = i;
-                } else if (dg[r] < mo) {
-                    msg = mo;
-                    arg = jo;
-                } else {  // tie: numpy's argmax returns the first index
-                    msg = mo;
-                    arg = min(i, jo);
-                }
-                acc[r] *= fmax(msg, 0.0);
+                acc[r] *= fmax(msg[r], 0.0);
                 nz |= acc[r] != 0.0;
-                jj[r] = (i < c.k) ? arg : 0;
             }
             // altered nodes get their tables rewritten w.r.t. their initial masks (ml.py:408-428)
             if (c.masks_init != nullptr) {
@@ -711,19 +771,20 @@ bu_f81_kernel(PmlTree t, PmlCols c, PmlState st, const PmlUnit* __restrict__ uni
     const int stride = gridDim.x * PML_WAVES_PER_BLOCK * UW;
     int idx = (blockIdx.x * PML_WAVES_PER_BLOCK + wave) * UW + sub;
     int base = idx - sub;  // wave-uniform trip count; whole groups drop out together
-    if (!JOINT && Gather<G>::enabled && c.W == 1) {
+    // the joint variant takes the pipeline unless altered nodes need their tables rewritten (masks_init, rare)
+    if (Gather<G>::enabled && c.W == 1 && (!JOINT || c.masks_init == nullptr)) {
         UnitRegs ua = load_unit<G>(units, idx < n_level ? idx : 0, L.g);
         UnitRegs ub = load_unit<G>(units, idx + stride < n_level ? idx + stride : 0, L.g);
         BuLoads<R> la, lb;
-        bu_f81_issue<G, R, VEC>(L, c, ua, la);
+        bu_f81_issue<G, R, VEC, JOINT>(L, c, ua, la);
         while (base < n_level) {
             {  // compute a; loads of b and the descriptor after b in flight
                 const int i2 = idx + 2 * stride;
                 const UnitRegs un = load_unit<G>(units, i2 < n_level ? i2 : 0, L.g);
-                bu_f81_issue<G, R, VEC>(L, c, ub, lb);
+                bu_f81_issue<G, R, VEC, JOINT>(L, c, ub, lb);
                 if (idx < n_level) {
-                    if (!unit_is_fast_bu<G, VEC>(ua.packed) || !bu_f81_unit_fast<G, R, VEC>(L, t, c, st, ua, la))
-                        bu_f81_unit_seq<G, R, false>(L, t, c, st, ua);
+                    if (!unit_is_fast_bu<G, VEC>(ua.packed) || !bu_f81_unit_fast<G, R, VEC, JOINT>(L, t, c, st, ua, la))
+                        bu_f81_unit_seq<G, R, JOINT>(L, t, c, st, ua);
                 }
                 ua = un;
                 idx += stride;
@@ -733,10 +794,10 @@ bu_f81_kernel(PmlTree t, PmlCols c, PmlState st, const PmlUnit* __restrict__ uni
             {  // compute b; loads of a (the unit after b) in flight
                 const int i2 = idx + 2 * stride;
                 const UnitRegs un = load_unit<G>(units, i2 < n_level ? i2 : 0, L.g);
-                bu_f81_issue<G, R, VEC>(L, c, ua, la);
+                bu_f81_issue<G, R, VEC, JOINT>(L, c, ua, la);
                 if (idx < n_level) {
-                    if (!unit_is_fast_bu<G, VEC>(ub.packed) || !bu_f81_unit_fast<G, R, VEC>(L, t, c, st, ub, lb))
-                        bu_f81_unit_seq<G, R, false>(L, t, c, st, ub);
+                    if (!unit_is_fast_bu<G, VEC>(ub.packed) || !bu_f81_unit_fast<G, R, VEC, JOINT>(L, t, c, st, ub, lb))
+                        bu_f81_unit_seq<G, R, JOINT>(L, t, c, st, ub);
                 }
                 ub = un;
                 idx += stride;
