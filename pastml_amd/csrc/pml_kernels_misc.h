@@ -183,8 +183,69 @@ select_states_kernel(int N, int k, int ks, int W, const double* __restrict__ pos
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         int best_k = 1;
-        if (method != 0) {
-            const int ji = force_joint ? js[colN + n] : -1;
+        // A dominant state settles MPPA without sorting: with q the ascending probabilities (joint state last),
+        // T_m the sum of the last m of them, sum_i (u_m[i] - q[i])^2 = sum q^2 + (1 - 2 T_m) / m, and T_m <= 1 gives
+        // corr(m) - corr(1) >= (2 q_last - 1) - 1 / 2 for every m >= 2: with q_last >= 0.76 that is >= 0.02, far
+        // from any rounding, so m = 1 is the first minimiser.  (Observed tips, and most nodes of most trees.)
+        const int ji = (method != 0 && force_joint) ? js[colN + n] : -1;
+        bool general = method != 0;
+        if (general) {
+            double q_last;
+            if (ji >= 0) {
+                q_last = pv[ji < k ? ji : 0];
+            } else {
+                q_last = 0.0;
+#pragma unroll
+                for (int r = 0; r < R; ++r) q_last = fmax(q_last, (s0 + r < k) ? lh[r] / sum : 0.0);
+                q_last = group_max<G>(q_last);
+            }
+            if (q_last >= 0.76) general = false;
+        }
+        // Otherwise the candidates are walked from the top of the sorted order -- the joint state, then the largest
+        // remaining probability (of equal ones the higher index: it has the higher ascending rank), one arg-max
+        // butterfly each -- and compared by f(m) = (1 - 2 T_m) / m, which is the criterion minus the common sum q^2.
+        // T_m <= 1 bounds every later f from below by -1 / m, so the walk stops as soon as the best value so far is
+        // below that: after two or three candidates for a typical node instead of k^2 comparisons plus k sums of k
+        // terms.  A node whose likelihoods do not sum to a positive finite number takes the reference-shaped scan.
+        if (general && sum > 0.0 && !isinf(sum)) {
+            general = false;
+            double cand[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) cand[r] = (s0 + r < k) ? lh[r] / sum : -INFINITY;
+            double T = 0.0, best_f = INFINITY;
+            int best_m = k;
+            for (int m = 1; m <= k; ++m) {
+                double bv = -INFINITY;
+                int bi = -1;
+                if (m == 1 && ji >= 0 && ji < k) {
+                    bv = pv[ji];
+                    bi = ji;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        if (cand[r] >= bv && cand[r] > -INFINITY) {  // r ascends: of equal ones the higher index
+                            bv = cand[r];
+                            bi = s0 + r;
+                        }
+                    }
+                    int nbi = -bi;  // the butterfly keeps the LOWER index among equal values: negate the indices
+                    group_argmax_first<G>(bv, nbi);
+                    bi = -nbi;
+                }
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    if (s0 + r == bi) cand[r] = -INFINITY;
+                T += bv;
+                const double f = (1.0 - 2.0 * T) / (double)m;
+                if (f < best_f) {  // m ascends: strict < keeps the first minimum
+                    best_f = f;
+                    best_m = m;
+                }
+                if (best_f < -(1.0 + 1e-9) / (double)(m + 1)) break;
+            }
+            best_k = best_m;
+        }
+        if (general) {
             // ascending ranks (joint state last)
 #pragma unroll
             for (int r = 0; r < R; ++r) {
@@ -236,16 +297,55 @@ select_states_kernel(int N, int k, int ks, int W, const double* __restrict__ pos
             best_k = (best_m > k) ? k : best_m;
         }
         // keep the best_k states with the largest lh (stable: ties go to the lower index)
+        if (best_k == 1) {
+            // the first maximum of lh: one arg-max butterfly instead of ranking every state
+            double bv = -INFINITY;
+            int bi = 0x7fffffff;
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int i = s0 + r;
-            if (i >= k) continue;
-            int rank = 0;
-            for (int j = 0; j < k; ++j) {
-                const double lj = lhv[j];
-                rank += (lj > lh[r] || (lj == lh[r] && j < i)) ? 1 : 0;
+            for (int r = 0; r < R; ++r) {
+                if (s0 + r < k && lh[r] > bv) {  // a NaN never wins: with all-NaN likelihoods nothing is kept,
+                    bv = lh[r];                  // as ranks computed by comparisons would have it
+                    bi = s0 + r;
+                }
             }
-            if (rank < best_k) atomicOr(&words[i >> 6], 1ull << (i & 63));
+            group_argmax_first<G>(bv, bi);
+            if (g == 0 && bi < k) words[bi >> 6] = 1ull << (bi & 63);
+        } else if (best_k <= 8) {
+            // a few arg-max butterflies: the largest remaining lh, of equal ones the lower index
+            double cand[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) cand[r] = (s0 + r < k) ? lh[r] : -INFINITY;
+            for (int m = 0; m < best_k; ++m) {
+                double bv = -INFINITY;
+                int bi = 0x7fffffff;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    if (cand[r] > bv) {
+                        bv = cand[r];
+                        bi = s0 + r;
+                    }
+                }
+                group_argmax_first<G>(bv, bi);
+                if (bi >= k) break;  // nothing comparable is left (NaN likelihoods)
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    if (s0 + r == bi) {
+                        cand[r] = -INFINITY;
+                        atomicOr(&words[bi >> 6], 1ull << (bi & 63));
+                    }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int i = s0 + r;
+                if (i >= k) continue;
+                int rank = 0;
+                for (int j = 0; j < k; ++j) {
+                    const double lj = lhv[j];
+                    rank += (lj > lh[r] || (lj == lh[r] && j < i)) ? 1 : 0;
+                }
+                if (rank < best_k) atomicOr(&words[i >> 6], 1ull << (i & 63));
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
