@@ -521,3 +521,43 @@ def _with_dist(flat, dist):
         node.dist = float(d)
     roots = [n for n in flat.nodes if n.up is None]
     return FlatForest.from_trees(roots)
+
+
+@pytest.mark.parametrize('k', [4, 20, 64])
+def test_device_state_selection_with_tied_probabilities(k):
+    """
+    JC (equal frequencies) makes posteriors tie exactly: tips without data give uniform posteriors everywhere (every
+    candidate of the MPPA walk ties, the best number of states is k), a tip pair with two different observed states
+    gives a two-way tie at their parent.  The device selection must break the ties as the sort / argmin of
+    ml.py:505-574 do; compared with the host restatement of those rules, with and without the joint state forced.
+    """
+    from pastml_amd import ml
+    rng = np.random.default_rng(11 + k)
+    flat = FlatForest.random(90, seed=k, max_arity=3)
+    spec = dict(kind=0, pi=np.ones(k) / k)
+    tips = np.flatnonzero(flat.is_tip)
+    masks = np.ones((3, flat.n_nodes, k), dtype=np.int8)
+    # column 0: no data at all; column 1: every tip observed with one of two states; column 2: half of the tips observed
+    for col, frac in ((1, 1.0), (2, 0.5)):
+        for n in tips:
+            if rng.random() < frac:
+                masks[col, n] = 0
+                masks[col, n, rng.integers(2) if col == 1 else rng.integers(k)] = 1
+    with hip.Engine(flat, 3, k) as eng:
+        eng.set_models([(spec, (1.0, 0.0, 1.0))] * 3)
+        eng.set_masks(masks)
+        eng.bottom_up(False)
+        js = eng.joint_backtrace()
+        eng.bottom_up(True)
+        post, _, _ = eng.top_down_marginals()
+        assert np.all(post[0] == post[0][:, :1])  # uniform rows, exactly
+        for fj in (False, True):
+            sel, nsel = eng.select_states('MPPA', force_joint=fj)
+            for c in range(3):
+                ref, ref_k = ml.select_mppa(post[c], js[c].astype(np.int64) if fj else None)
+                assert np.array_equal(nsel[c], ref_k), (fj, c)
+                assert np.array_equal(sel[c], ref), (fj, c)
+            assert np.all(nsel[0] == k)
+            eng.set_masks(masks)
+            eng.bottom_up(True)
+            eng.top_down_marginals()
