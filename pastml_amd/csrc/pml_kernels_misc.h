@@ -176,9 +176,12 @@ select_states_kernel(int N, int k, int ks, int W, const double* __restrict__ pos
         for (int w = G; w < W; w += G)
             if (g + w < W) words[g + w] = 0ull;
         sum = group_sum<G>(sum);
+        double pr[R];  // the probabilities of this lane's states: one division each, reused below
 #pragma unroll
-        for (int r = 0; r < R; ++r)
-            if (s0 + r < k) pv[s0 + r] = lh[r] / sum;
+        for (int r = 0; r < R; ++r) {
+            pr[r] = lh[r] / sum;
+            if (s0 + r < k) pv[s0 + r] = pr[r];
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -196,7 +199,7 @@ select_states_kernel(int N, int k, int ks, int W, const double* __restrict__ pos
             } else {
                 q_last = 0.0;
 #pragma unroll
-                for (int r = 0; r < R; ++r) q_last = fmax(q_last, (s0 + r < k) ? lh[r] / sum : 0.0);
+                for (int r = 0; r < R; ++r) q_last = fmax(q_last, (s0 + r < k) ? pr[r] : 0.0);
                 q_last = group_max<G>(q_last);
             }
             if (q_last >= 0.76) general = false;
@@ -211,7 +214,7 @@ select_states_kernel(int N, int k, int ks, int W, const double* __restrict__ pos
             general = false;
             double cand[R];
 #pragma unroll
-            for (int r = 0; r < R; ++r) cand[r] = (s0 + r < k) ? lh[r] / sum : -INFINITY;
+            for (int r = 0; r < R; ++r) cand[r] = (s0 + r < k) ? pr[r] : -INFINITY;
             double T = 0.0, best_f = INFINITY;
             int best_m = k;
             for (int m = 1; m <= k; ++m) {
