@@ -78,6 +78,7 @@ struct pml_ctx {
     std::vector<char> bu_level_vec;    // the same for the plain levels (joint sweep: every internal node is stored)
     int n_cherries = 0;
     bool bu_fused = false;  // the last bottom-up sweep left the cherries unmaterialised
+    bool bu_fused_joint = false;  // ... and it was a joint sweep
 
     // columns
     int C = 0, k = 0, ks = 0, W = 0, G = 0, R = 0;
@@ -288,7 +289,9 @@ static int prof_end(pml_ctx* ctx, int which, long long launches) {
 enum SweepKind {
     SW_BU_MARG, SW_BU_JOINT, SW_TD, SW_ROOTS, SW_BU_MARG_FUSED, SW_TD_FUSED, SW_BU_CHERRIES,
     SW_BU_MARG_FUSED_NOVEC,  // a fused level none of whose units has a stored node among its first two children
-    SW_BU_JOINT_NOVEC        // the same for a level of the joint sweep (the level whose children are all tips)
+    SW_BU_JOINT_NOVEC,       // the same for a level of the joint sweep (the level whose children are all tips)
+    SW_BU_JOINT_FUSED, SW_BU_JOINT_FUSED_NOVEC,  // joint sweep over the cherry-fused level lists
+    SW_BU_CHERRIES_JOINT     // materialises the cherries' vectors after a fused joint sweep
 };
 
 // matrix-model sweeps: contiguous state ownership (state = g * R + r)
@@ -323,20 +326,22 @@ static void launch_sweep(pml_ctx* ctx, SweepKind what, const int* level, int n_l
 // F81-family sweeps: chunked state ownership (pml_kernels_f81.h), their own (G, R)
 template <int G, int R>
 static void launch_sweep_f81(pml_ctx* ctx, SweepKind what, const int* level, int n_level) {
-    const PmlTree t = tree_of(ctx, what == SW_BU_MARG_FUSED || what == SW_BU_MARG_FUSED_NOVEC || what == SW_TD_FUSED);
+    const bool fused_lists = what == SW_BU_MARG_FUSED || what == SW_BU_MARG_FUSED_NOVEC ||
+                             what == SW_BU_JOINT_FUSED || what == SW_BU_JOINT_FUSED_NOVEC;
+    const PmlTree t = tree_of(ctx, fused_lists || what == SW_TD_FUSED);
     const PmlCols c = cols_of(ctx);
     const PmlState st = state_of(ctx);
     const int upb = PML_WAVES_PER_BLOCK * (64 / G);
-    const bool pipelined = what == SW_BU_MARG_FUSED || what == SW_BU_MARG_FUSED_NOVEC || what == SW_BU_MARG ||
-                           what == SW_BU_CHERRIES || what == SW_BU_JOINT || what == SW_BU_JOINT_NOVEC;
+    const bool pipelined = fused_lists || what == SW_BU_MARG || what == SW_BU_CHERRIES || what == SW_BU_JOINT ||
+                           what == SW_BU_JOINT_NOVEC || what == SW_BU_CHERRIES_JOINT;
     dim3 grid(grid_for(n_level, upb, ctx->C, pipelined), ctx->C), block(PML_BLOCK);
     // the level is given as a position in one of the node lists; the kernels read the descriptor list parallel to it
     const PmlUnit* units = nullptr;
-    if (what == SW_BU_MARG_FUSED || what == SW_BU_MARG_FUSED_NOVEC) units = ctx->d_bu_units_f + (level - ctx->d_bu_order_f);
+    if (fused_lists) units = ctx->d_bu_units_f + (level - ctx->d_bu_order_f);
     if (what == SW_BU_MARG || what == SW_BU_JOINT || what == SW_BU_JOINT_NOVEC)
         units = ctx->d_bu_units + (level - ctx->d_bu_order);
     if (what == SW_TD_FUSED) units = ctx->d_td_units_f + (level - ctx->d_td_parents_f);
-    if (what == SW_BU_CHERRIES) units = ctx->d_cherry_units + (level - ctx->d_cherries);
+    if (what == SW_BU_CHERRIES || what == SW_BU_CHERRIES_JOINT) units = ctx->d_cherry_units + (level - ctx->d_cherries);
     switch (what) {
         case SW_BU_MARG_FUSED:
         case SW_BU_MARG:
@@ -349,10 +354,13 @@ static void launch_sweep_f81(pml_ctx* ctx, SweepKind what, const int* level, int
                                n_level);
             break;
         case SW_BU_JOINT:
+        case SW_BU_JOINT_FUSED:
             hipLaunchKernelGGL((bu_f81_kernel<G, R, true, true>), grid, block, 0, ctx->stream, t, c, st, units,
                                n_level);
             break;
         case SW_BU_JOINT_NOVEC:
+        case SW_BU_JOINT_FUSED_NOVEC:
+        case SW_BU_CHERRIES_JOINT:
             hipLaunchKernelGGL((bu_f81_kernel<G, R, true, false>), grid, block, 0, ctx->stream, t, c, st, units,
                                n_level);
             break;
@@ -1328,6 +1336,7 @@ static int enqueue_bottom_up(pml_ctx* ctx, int is_marginal, bool small_path, boo
     PML_TRY(prof_begin(ctx));
     const bool fused = is_marginal && ctx->kind == PML_MODEL_F81;
     bool loglik_done = small_path;
+    bool joint_fused = false;
     if (small_path) {
         // prep + every level + ln L in one launch
         PML_TRY(dispatch_small_f81(ctx, true, (ctx->prep_dirty || force_prep) ? 1 : 0));
@@ -1345,6 +1354,17 @@ static int enqueue_bottom_up(pml_ctx* ctx, int is_marginal, bool small_path, boo
             PML_TRY(dispatch_small_f81(ctx, true, 0, nl - tail, tail));
             loglik_done = true;
         }
+    } else if (!is_marginal && ctx->kind == PML_MODEL_F81 && ctx->fuse && !ctx->has_init && ctx->n_cherries > 0 &&
+               ctx->W == 1) {
+        // joint sweep over the cherry-fused lists (no altered nodes whose tables would need rewriting)
+        const int nl = (int)ctx->bu_offsets_f.size() - 1;
+        for (int l = 0; l < nl; ++l) {
+            const int a = ctx->bu_offsets_f[l], b = ctx->bu_offsets_f[l + 1];
+            PML_TRY(dispatch_sweep(ctx, ctx->bu_level_vec_f[l] ? SW_BU_JOINT_FUSED : SW_BU_JOINT_FUSED_NOVEC,
+                                   ctx->d_bu_order_f + a, b - a));
+        }
+        PML_TRY(prof_end(ctx, 0, nl));
+        joint_fused = true;
     } else if (eig) {
         // every node once, in the launch of its level: the tips first, then the internal nodes by height
         const int mode = is_marginal ? PML_EIG_BU_MARG : PML_EIG_BU_JOINT;
@@ -1372,6 +1392,7 @@ static int enqueue_bottom_up(pml_ctx* ctx, int is_marginal, bool small_path, boo
                            ctx->h_err);
         HIP_TRY(hipGetLastError());
     }
+    ctx->bu_fused_joint = joint_fused;
     return PML_OK;  // ln L and the error words are written straight into pinned host memory by the last kernel
 }
 
@@ -1428,7 +1449,7 @@ int pml_bottom_up(pml_ctx* ctx, int is_marginal, double* loglik_out, int32_t* er
         PML_TRY(enqueue_bottom_up(ctx, is_marginal, small_path, false));
     }
     ctx->prep_dirty = false;
-    ctx->bu_fused = is_marginal && ctx->kind == PML_MODEL_F81 && ctx->n_cherries > 0;
+    ctx->bu_fused = (is_marginal && ctx->kind == PML_MODEL_F81 && ctx->n_cherries > 0) || ctx->bu_fused_joint;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     memcpy(loglik_out, ctx->h_loglik, sizeof(double) * ctx->C);
     const u64* err = ctx->h_err;
@@ -1673,7 +1694,8 @@ static int fetch_exponents(pml_ctx* ctx, const i64* src, int col, double* out) {
 // after a fused sweep the cherries' bottom-up vectors only ever existed in registers: compute them for inspection
 static int materialize_cherries(pml_ctx* ctx) {
     if (!ctx->bu_fused) return PML_OK;
-    PML_TRY(dispatch_sweep(ctx, SW_BU_CHERRIES, ctx->d_cherries, ctx->n_cherries));
+    PML_TRY(dispatch_sweep(ctx, ctx->bu_fused_joint ? SW_BU_CHERRIES_JOINT : SW_BU_CHERRIES, ctx->d_cherries,
+                           ctx->n_cherries));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->bu_fused = false;
     return PML_OK;

@@ -527,7 +527,7 @@ struct BuLoads {
 template <int G, int R, bool VEC, bool JOINT = false>
 __device__ __forceinline__ void bu_f81_issue(const LaneCtx<G, R>& L, const PmlCols& c, const UnitRegs& u,
                                              BuLoads<R>& ld) {
-    f81_gather_issue<G, R, !JOINT>(L, u, ld.cl, ld.tl);
+    f81_gather_issue<G, R>(L, u, ld.cl, ld.tl);
     ld.own = L.mask[(unsigned)u.n];
     if (VEC) {
         const bool s0 = unit_code(u.packed, 0) == 1, s1 = unit_nc(u.packed) > 1 && unit_code(u.packed, 1) == 1;
@@ -544,11 +544,8 @@ __device__ __forceinline__ void bu_f81_issue(const LaneCtx<G, R>& L, const PmlCo
 // unit's control flow first touches a value.
 template <int R, bool VEC, bool JOINT = false>
 __device__ __forceinline__ void bu_loads_arrived(BuLoads<R>& ld) {
-    if (JOINT)
-        asm volatile("" : "+v"(ld.cl.e), "+v"(ld.cl.s), "+v"(ld.cl.mask), "+v"(ld.cl.be), "+v"(ld.own));
-    else
-        asm volatile("" : "+v"(ld.cl.e), "+v"(ld.cl.s), "+v"(ld.cl.mask), "+v"(ld.cl.be), "+v"(ld.tl.e), "+v"(ld.tl.s),
-                          "+v"(ld.tl.mask), "+v"(ld.own));
+    asm volatile("" : "+v"(ld.cl.e), "+v"(ld.cl.s), "+v"(ld.cl.mask), "+v"(ld.cl.be), "+v"(ld.tl.e), "+v"(ld.tl.s),
+                      "+v"(ld.tl.mask), "+v"(ld.own));
     if (VEC) {
 #pragma unroll
         for (int r = 0; r < R; ++r) asm volatile("" : "+v"(ld.v0[r]), "+v"(ld.v1[r]));
@@ -596,10 +593,33 @@ __device__ __forceinline__ bool bu_f81_unit_fast(const LaneCtx<G, R>& L, const P
                     }
                     closed = true;
                 }
-            } else {
+            } else if (code == 1) {
 #pragma unroll
                 for (int r = 0; r < R; ++r) v[r] = jx == 0 ? ld.v0[r] : ld.v1[r];
                 esum += __shfl(cl.be, src, 64);
+            } else {
+                // Cherry child (fused joint sweep): rebuilt from its tips as in the marginal sweep when every tip is
+                // observed with a > 0 -- their max-messages are then the marginal ones and their arg-max rows are
+                // constant; any other tip sends the unit to the sequential path.
+                constexpr int GC = Gather<G>::GC;
+                const int cnc = code - 1;
+                const int cfc = __shfl(u.cfc, L.group_base + jx * GC, 64);
+                bool ok = true;
+                for (int q = 0; q < cnc; ++q) {
+                    const int ts = L.group_base + jx * GC + q;
+                    ok &= __popcll(__shfl(tl.mask, ts, 64)) == 1 && __shfl(tl.a, ts, 64) > 0.0;
+                }
+                if (!ok) return false;
+                i64 ce;
+                f81_cherry_from_lanes<G, R>(L, c, cl, tl, jx, cnc, v, ce);
+                esum += ce;
+                for (int q = 0; q < cnc; ++q) {
+                    const int s = __builtin_ctzll(__shfl(tl.mask, L.group_base + jx * GC + q, 64));
+                    int tj[R];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) tj[r] = L.st(r) < c.k ? s : 0;
+                    f81_store_table<G, R>(L, c, st.J + ((size_t)L.col * t.N + cfc + q) * c.ks, tj);
+                }
             }
             if (!closed) f81_joint_message<G, R>(L, c, e, v, msg, jj);
 #pragma unroll
@@ -701,6 +721,30 @@ __device__ __forceinline__ void bu_f81_unit_seq(const LaneCtx<G, R>& L, const Pm
             node_load_vec<G, R>(L, c, L.bu, ch, v);
             esum += L.be[ch];
             if (!JOINT) s_child = L.S[ch];
+        } else if (JOINT) {
+            // cherry child of the fused joint sweep: the operations of this function for a node whose children are
+            // tips (mask, then per tip: message, product, zero check, rescaling; the tip's arg-max row), in registers
+            node_mask_vec<G, R>(L, c, ch, v);
+            const int fc2 = t.first_child[ch], nc2 = t.n_children[ch];
+            for (int q = 0; q < nc2; ++q) {
+                const int tip = fc2 + q;
+                double tv[R], tmsg[R];
+                int tj[R];
+                node_mask_vec<G, R>(L, c, tip, tv);
+                f81_joint_message<G, R>(L, c, L.E[tip], tv, tmsg, tj);
+                bool tnz = false;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    v[r] *= fmax(tmsg[r], 0.0);
+                    tnz |= v[r] != 0.0;
+                }
+                f81_store_table<G, R>(L, c, st.J + ((size_t)L.col * t.N + tip) * c.ks, tj);
+                if (!group_any<G>(tnz)) {
+                    if (L.g == 0)
+                        atomicMin(&st.err[L.col], ((u64)(unsigned)t.post_rank[ch] << 32) | (u64)(unsigned)tip);
+                }
+                esum += lazy_rescale<G, R>(v);
+            }
         } else {
             i64 ce;
             f81_cherry_vector<G, R>(L, t, c, st, ch, v, ce, true);

@@ -359,11 +359,17 @@ def test_cherry_fusion_is_bit_identical(k):
             bu = eng.download(hip.BUF_BU, 1)
             bu_sf = eng.download(hip.BUF_BU_SF, 1)
             td_sf = eng.download(hip.BUF_TD_SF, 1)
-            out.append((lnl, post, lh_sum, lh_sf, bu, bu_sf, td_sf))
-    for a, b in zip(out[0][:6], out[1][:6]):
+            # the joint sweep fuses cherries too (their tips' arg-max rows are written by the grandparent's unit)
+            lnl_j = eng.bottom_up(False)
+            tables = np.stack([eng.download(hip.BUF_JOINT_TABLE, c) for c in range(2)])[:, flat.parent >= 0]
+            states = eng.joint_backtrace()
+            bu_j = eng.download(hip.BUF_BU, 0)
+            bu_j_sf = eng.download(hip.BUF_BU_SF, 0)
+            out.append((lnl, post, lh_sum, lh_sf, bu, bu_sf, lnl_j, tables, states, bu_j, bu_j_sf, td_sf))
+    for a, b in zip(out[0][:11], out[1][:11]):
         assert np.array_equal(a, b)
     # the fused run never materialised the cherries' top-down vectors
-    assert np.isnan(out[0][6]).sum() > np.isnan(out[1][6]).sum()
+    assert np.isnan(out[0][11]).sum() > np.isnan(out[1][11]).sum()
 
 
 @pytest.mark.parametrize('k', [2, 5, 12, 64])
