@@ -170,83 +170,95 @@ select_states_kernel(int N, int k, int ks, int W, const double* __restrict__ pos
             }
             lh[r] = v;
             sum += v;
-            lhv[s] = v;
         }
         if (g < W) words[g] = 0ull;
         for (int w = G; w < W; w += G)
             if (g + w < W) words[g + w] = 0ull;
         sum = group_sum<G>(sum);
-        double pr[R];  // the probabilities of this lane's states: one division each, reused below
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            pr[r] = lh[r] / sum;
-            if (s0 + r < k) pv[s0 + r] = pr[r];
-        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         int best_k = 1;
-        // A dominant state settles MPPA without sorting: with q the ascending probabilities (joint state last),
-        // T_m the sum of the last m of them, sum_i (u_m[i] - q[i])^2 = sum q^2 + (1 - 2 T_m) / m, and T_m <= 1 gives
-        // corr(m) - corr(1) >= (2 q_last - 1) - 1 / 2 for every m >= 2: with q_last >= 0.76 that is >= 0.02, far
-        // from any rounding, so m = 1 is the first minimiser.  (Observed tips, and most nodes of most trees.)
         const int ji = (method != 0 && force_joint) ? js[colN + n] : -1;
         bool general = method != 0;
-        if (general) {
-            double q_last;
-            if (ji >= 0) {
-                q_last = pv[ji < k ? ji : 0];
-            } else {
-                q_last = 0.0;
-#pragma unroll
-                for (int r = 0; r < R; ++r) q_last = fmax(q_last, (s0 + r < k) ? pr[r] : 0.0);
-                q_last = group_max<G>(q_last);
-            }
-            if (q_last >= 0.76) general = false;
-        }
-        // Otherwise the candidates are walked from the top of the sorted order -- the joint state, then the largest
-        // remaining probability (of equal ones the higher index: it has the higher ascending rank), one arg-max
-        // butterfly each -- and compared by f(m) = (1 - 2 T_m) / m, which is the criterion minus the common sum q^2.
-        // T_m <= 1 bounds every later f from below by -1 / m, so the walk stops as soon as the best value so far is
-        // below that: after two or three candidates for a typical node instead of k^2 comparisons plus k sums of k
-        // terms.  A node whose likelihoods do not sum to a positive finite number takes the reference-shaped scan.
+        bool lds_filled = false;  // lhv / pv are only needed by the reference-shaped scans below
+        // The probabilities are lh / sum; with sum > 0 every comparison below is made on the likelihoods themselves.
+        // With q the ascending probabilities (joint state last) and T_m the sum of the last m of them,
+        //     sum_i (u_m[i] - q[i])^2 = sum q^2 + (1 - 2 T_m) / m,
+        // so the best m is the first minimiser of f(m) = (1 - 2 T_m) / m.
+        //  * A dominant state settles it without sorting: T_m <= 1 gives f(m) - f(1) >= (2 q_last - 1) - 1 / 2 for
+        //    every m >= 2, which is >= 0.02 -- far from any rounding -- once q_last >= 0.76 (observed tips, and most
+        //    nodes of most trees).
+        //  * Otherwise the candidates are walked from the top of the sorted order -- the joint state, then the largest
+        //    remaining likelihood (of equal ones the higher index: it has the higher ascending rank), one arg-max
+        //    butterfly each.  T_m <= 1 bounds every later f from below by -1 / m, so the walk stops as soon as the
+        //    best value so far is below that: after two or three candidates for a typical node instead of k^2
+        //    comparisons plus k sums of k terms.
+        // A node whose likelihoods do not sum to a positive finite number takes the reference-shaped scan.
         if (general && sum > 0.0 && !isinf(sum)) {
             general = false;
-            double cand[R];
-#pragma unroll
-            for (int r = 0; r < R; ++r) cand[r] = (s0 + r < k) ? pr[r] : -INFINITY;
-            double T = 0.0, best_f = INFINITY;
-            int best_m = k;
-            for (int m = 1; m <= k; ++m) {
-                double bv = -INFINITY;
-                int bi = -1;
-                if (m == 1 && ji >= 0 && ji < k) {
-                    bv = pv[ji];
-                    bi = ji;
-                } else {
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        if (cand[r] >= bv && cand[r] > -INFINITY) {  // r ascends: of equal ones the higher index
-                            bv = cand[r];
-                            bi = s0 + r;
-                        }
-                    }
-                    int nbi = -bi;  // the butterfly keeps the LOWER index among equal values: negate the indices
-                    group_argmax_first<G>(bv, nbi);
-                    bi = -nbi;
-                }
+            double l_last;
+            if (ji >= 0) {
+                l_last = -INFINITY;
 #pragma unroll
                 for (int r = 0; r < R; ++r)
-                    if (s0 + r == bi) cand[r] = -INFINITY;
-                T += bv;
-                const double f = (1.0 - 2.0 * T) / (double)m;
-                if (f < best_f) {  // m ascends: strict < keeps the first minimum
-                    best_f = f;
-                    best_m = m;
-                }
-                if (best_f < -(1.0 + 1e-9) / (double)(m + 1)) break;
+                    if (s0 + r == ji) l_last = lh[r];
+                l_last = group_max<G>(l_last);
+            } else {
+                l_last = 0.0;
+#pragma unroll
+                for (int r = 0; r < R; ++r) l_last = fmax(l_last, (s0 + r < k) ? lh[r] : 0.0);
+                l_last = group_max<G>(l_last);
             }
-            best_k = best_m;
+            if (!(l_last >= 0.76 * sum)) {
+                double cand[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) cand[r] = (s0 + r < k) ? lh[r] : -INFINITY;
+                double L2 = 0.0, best_f = INFINITY;  // f scaled by sum: (sum - 2 L_m) / m
+                int best_m = k;
+                for (int m = 1; m <= k; ++m) {
+                    double bv = -INFINITY;
+                    int bi = -1;
+                    if (m == 1 && ji >= 0 && ji < k) {
+                        bv = l_last;
+                        bi = ji;
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < R; ++r) {
+                            if (cand[r] >= bv && cand[r] > -INFINITY) {  // r ascends: of equal ones the higher index
+                                bv = cand[r];
+                                bi = s0 + r;
+                            }
+                        }
+                        int nbi = -bi;  // the butterfly keeps the LOWER index among equal values: negate the indices
+                        group_argmax_first<G>(bv, nbi);
+                        bi = -nbi;
+                    }
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+                        if (s0 + r == bi) cand[r] = -INFINITY;
+                    L2 += bv;
+                    const double f = (sum - 2.0 * L2) / (double)m;
+                    if (f < best_f) {  // m ascends: strict < keeps the first minimum
+                        best_f = f;
+                        best_m = m;
+                    }
+                    if (best_f < -(1.0 + 1e-9) * sum / (double)(m + 1)) break;
+                }
+                best_k = best_m;
+            }
+        }
+        if (general) {
+            // reference-shaped scan: the likelihoods and the probabilities of the unit in LDS
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (s0 + r < KP) lhv[s0 + r] = lh[r];
+                if (s0 + r < k) pv[s0 + r] = lh[r] / sum;
+            }
+            lds_filled = true;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
         if (general) {
             // ascending ranks (joint state last)
@@ -338,6 +350,14 @@ select_states_kernel(int N, int k, int ks, int W, const double* __restrict__ pos
                     }
             }
         } else {
+            if (!lds_filled) {
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    if (s0 + r < KP) lhv[s0 + r] = lh[r];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const int i = s0 + r;
