@@ -43,6 +43,9 @@ def parse_args():
     p.add_argument('--workload', default='cfg4', choices=sorted(WORKLOADS))
     p.add_argument('--chars-per-gpu', type=int, default=None)
     p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--no-kernel-timing', action='store_true',
+                   help='leave the HIP-event brackets off: the sweeps are then replayed as hipGraphs (the library\'s '
+                        'default outside profiling); roofline fields are null')
     p.add_argument('--cpu-baseline-levels', type=int, default=None,
                    help='tree levels of the subtree the CPU baseline is timed on (default: about 15 s of work)')
     p.add_argument('--cpu-baseline-cores', type=int, default=None,
@@ -179,7 +182,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    eng.profile_enable(True)
+    eng.profile_enable(not args.no_kernel_timing)
     for w in (0, 1, 2):
         eng.profile_read(w, reset=True)
     fence()
