@@ -222,14 +222,21 @@ __device__ __forceinline__ void node_load_vec(const LaneCtx<G, R>& L, const PmlC
     }
 }
 
-// streaming (non-temporal) variant for data that is written once and not re-read soon (posteriors)
+// streaming (non-temporal) variant for data that is written once and not re-read soon (posteriors).  Only where a
+// store instruction of a unit covers whole 128-byte lines (G >= 8 lanes x 16 bytes): with fewer lanes per unit the
+// lanes of a wavefront write 16-byte pieces of different rows, and it is the L2 that merges the pieces of a line --
+// streamed past it they reach HBM as partial writes (k = 4, 262 144 tips, 32 characters: last top-down level 1.10 ms
+// non-temporal).
 template <int G, int R>
 __device__ __forceinline__ void node_store_vec_nt(const LaneCtx<G, R>& L, const PmlCols& c, double* base, int n,
                                                   const double (&v)[R]) {
     typedef double dbl2 __attribute__((ext_vector_type(2)));
     double* p = base + (unsigned)n * (unsigned)c.ks;
     if (R == 1) {
-        if (L.st(0) < c.ks) __builtin_nontemporal_store(v[0], p + L.st(0));
+        if (L.st(0) < c.ks) {
+            if (G >= 8) __builtin_nontemporal_store(v[0], p + L.st(0));
+            else p[L.st(0)] = v[0];
+        }
     } else {
 #pragma unroll
         for (int r = 0; r < R; r += 2) {
@@ -237,7 +244,8 @@ __device__ __forceinline__ void node_store_vec_nt(const LaneCtx<G, R>& L, const 
                 dbl2 t2;
                 t2.x = v[r];
                 t2.y = v[r + 1];
-                __builtin_nontemporal_store(t2, reinterpret_cast<dbl2*>(p + L.st(r)));
+                if (G >= 8) __builtin_nontemporal_store(t2, reinterpret_cast<dbl2*>(p + L.st(r)));
+                else *reinterpret_cast<dbl2*>(p + L.st(r)) = t2;
             }
         }
     }
