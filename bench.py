@@ -237,7 +237,7 @@ def main():
                                    '{} characters per GPU ({} in total), marginal (BU+TD+posteriors)'
                                    .format(flat.n_tips, N, k, model, cpg, cpg * world),
                        'tips': int(flat.n_tips), 'nodes': int(N), 'states': k, 'chars_per_gpu': cpg,
-                       'chars_total': cpg * world, 'model': model,
+                       'chars_total': cpg * world, 'substitution_model': model,
                        'sharding': 'characters over ranks, no data-path collective; 1 all-reduce (8 B) per step'},
             'loglik_sum': total,
             'roofline': {
