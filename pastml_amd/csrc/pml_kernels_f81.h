@@ -138,6 +138,10 @@ __device__ __forceinline__ void lane_ctx_init(LaneCtx<G, R>& L, const PmlTree& t
     }
 }
 
+template <int G, int R>
+__device__ __forceinline__ void node_load_vec(const LaneCtx<G, R>& L, const PmlCols& c, const double* base, int n,
+                                              double (&v)[R]);
+
 // prod = TD_p o BU_p of a finished node p, recovered from what the sweep already stored for it: the marginal
 // likelihoods are lh = TD o BU o pi o mask (ml.py:456-460) and the posterior is lh / sum(lh), so
 // TD o BU = posterior * sum(lh) / pi wherever mask and pi are non-zero; elsewhere BU (hence the product) is 0 or the
