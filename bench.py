@@ -69,6 +69,17 @@ def _cpu_baseline_one(job):
     return time.perf_counter() - t0, flat.n_nodes, flat.n_tips, float(r['loglik'])
 
 
+def cpu_model_name():
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
 def cpu_baseline(k, levels, model, cores=None):
     """
     PastML-style numpy CPU path (oracle/pastml_oracle.py, the per-node restatement of pastml/ml.py) timed on this
@@ -86,7 +97,8 @@ def cpu_baseline(k, levels, model, cores=None):
                sample='1 character, balanced {}-tip tree ({} nodes), k={}, full marginal pass (BU+TD+posteriors), '
                       'numpy per-node port of pastml/ml.py, {:.1f} s on 1 of {} host cores'
                       .format(n_tips, n_nodes, k, dt1, os.cpu_count()),
-               seconds=dt1, us_per_node=dt1 / n_nodes * 1e6, loglik=lnl, single_core_value=single)
+               seconds=dt1, us_per_node=dt1 / n_nodes * 1e6, loglik=lnl, single_core_value=single,
+               cpu_model=cpu_model_name(), host_cores=os.cpu_count())
     if cores > 1:
         pl = max(10, levels - 1)  # half the tree per task: the pool leg costs about half the single-thread leg
         ctx = mp.get_context('spawn')  # fresh interpreters: numpy and the oracle only
