@@ -163,6 +163,15 @@ int pml_joint_backtrace(pml_ctx* ctx, int32_t* joint_state_out);
 int pml_select_states(pml_ctx* ctx, int method, int force_joint, const uint64_t* lh_mask, uint64_t* masks_out,
                       int32_t* n_states_out);
 
+/*
+ * Expected numbers of state changes i -> j per scenario, estimated from n_repetitions ancestral scenarios drawn from
+ * the marginal posterior of column col: the sampling scheme of pastml/ml.py:753-862 (marginal_counts) for forests
+ * without nodes altered by the zero-branch handling (ml.py:352-387; the host keeps that case), with a counter-based
+ * generator (Philox-4x32-10 keyed by seed): statistical, not bitwise, parity with the reference's numpy draws.
+ * Needs pml_bottom_up (marginal) and pml_top_down_marginals first.  counts_out[k][k].
+ */
+int pml_marginal_counts(pml_ctx* ctx, int32_t col, int32_t n_repetitions, uint64_t seed, double* counts_out);
+
 /* ---- inspection ------------------------------------------------------------------------------------------------------ */
 int pml_download(pml_ctx* ctx, int what, int32_t col, void* out);
 /* HIP-event timer on the ctx's stream */

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "pml_kernels_eigen_mfma.h"
+#include "pml_kernels_counts.h"
 
 #define PML_VERSION 100
 
@@ -1448,7 +1449,7 @@ int pml_bottom_up(pml_ctx* ctx, int is_marginal, double* loglik_out, int32_t* er
     } else {
         PML_TRY(enqueue_bottom_up(ctx, is_marginal, small_path, false));
     }
-    ctx->prep_dirty = false;
+    if (!eigen_fused(ctx)) ctx->prep_dirty = false;  // the fused eigen sweeps build P(t) in registers: no batch ran
     ctx->bu_fused = (is_marginal && ctx->kind == PML_MODEL_F81 && ctx->n_cherries > 0) || ctx->bu_fused_joint;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     memcpy(loglik_out, ctx->h_loglik, sizeof(double) * ctx->C);
@@ -1605,6 +1606,50 @@ int pml_joint_backtrace(pml_ctx* ctx, int32_t* joint_state_out) {
         HIP_TRY(hipMemcpyAsync(joint_state_out, ctx->d_js, (size_t)ctx->C * ctx->N * sizeof(int), hipMemcpyDeviceToHost,
                                ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PML_OK;
+}
+
+static int materialize_cherries(pml_ctx* ctx);
+
+int pml_marginal_counts(pml_ctx* ctx, int32_t col, int32_t n_repetitions, uint64_t seed, double* counts_out) {
+    PML_TRY(require_model(ctx));
+    if (col < 0 || col >= ctx->C || !counts_out) return fail(PML_ERR_INVALID, "bad column / output");
+    if (n_repetitions <= 0) return fail(PML_ERR_INVALID, "n_repetitions must be positive");
+    if (ctx->bu_mode != 1 || !ctx->td_valid)
+        return fail(PML_ERR_INVALID, "pml_marginal_counts needs a marginal pml_bottom_up and pml_top_down_marginals first");
+    if (ctx->k > PML_COUNTS_MAX_K) return fail(PML_ERR_UNSUPPORTED, "k = %d: at most %d states", ctx->k, PML_COUNTS_MAX_K);
+    PML_TRY(materialize_cherries(ctx));  // the conditional probabilities need every bottom-up vector
+    PML_TRY(run_prep(ctx));  // P(t) of every branch (the fused eigen sweeps never materialise it) / exp(-mu t')
+    const size_t k = ctx->k;
+    int* d_counts = nullptr;
+    long long* d_result = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_counts, (size_t)ctx->N * k * sizeof(int)));
+    hipError_t e = hipMalloc((void**)&d_result, k * k * sizeof(long long));
+    if (e == hipSuccess) e = hipMemsetAsync(d_result, 0, k * k * sizeof(long long), ctx->stream);
+    if (e == hipSuccess) {
+        const PmlTree t = tree_of(ctx);
+        const PmlCols c = cols_of(ctx);
+        const PmlState st = state_of(ctx);
+        const PmlModel m = model_of(ctx);
+        const double* P = ctx->kind == PML_MODEL_F81 ? nullptr : ctx->d_P;
+        hipLaunchKernelGGL(counts_roots_kernel, dim3(std::min(ctx->n_roots, 1024)), dim3(64), 0, ctx->stream, t, c, st, col,
+                           n_repetitions, seed, d_counts);
+        for (int l = 0; l < ctx->n_td_levels; ++l) {
+            const int a = ctx->td_parent_offsets[l], b = ctx->td_parent_offsets[l + 1];
+            if (b <= a) continue;
+            hipLaunchKernelGGL(counts_level_kernel, dim3(std::min(b - a, 65536)), dim3(64), 0, ctx->stream, t, c, st, m, P,
+                               col, n_repetitions, seed, ctx->d_td_parents + a, b - a, d_counts, d_result);
+        }
+        e = hipGetLastError();
+    }
+    std::vector<long long> h(k * k);
+    if (e == hipSuccess) e = hipMemcpyAsync(h.data(), d_result, k * k * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream);
+    const hipError_t e2 = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_counts);
+    if (d_result) (void)hipFree(d_result);
+    if (e != hipSuccess) return fail(PML_ERR_HIP, "pml_marginal_counts failed: %s", hipGetErrorString(e));
+    if (e2 != hipSuccess) return fail(PML_ERR_HIP, "pml_marginal_counts failed: %s", hipGetErrorString(e2));
+    for (size_t i = 0; i < k * k; ++i) counts_out[i] = (double)h[i] / (double)n_repetitions;
     return PML_OK;
 }
 

@@ -77,6 +77,7 @@ SIGNATURES = {
     'pml_top_down_marginals': [_ctx_p, _c_double_p, _c_double_p, _c_double_p],
     'pml_joint_backtrace': [_ctx_p, _c_int32_p],
     'pml_select_states': [_ctx_p, ctypes.c_int, ctypes.c_int, _c_uint64_p, _c_uint64_p, _c_int32_p],
+    'pml_marginal_counts': [_ctx_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_uint64, _c_double_p],
     'pml_download': [_ctx_p, ctypes.c_int, ctypes.c_int32, ctypes.c_void_p],
     'pml_timer_start': [_ctx_p],
     'pml_timer_stop': [_ctx_p, ctypes.POINTER(ctypes.c_float)],
@@ -363,6 +364,16 @@ class Engine(object):
                                            None if lm is None else _ptr(lm, ctypes.c_uint64),
                                            _ptr(words, ctypes.c_uint64), _ptr(nsel, ctypes.c_int32)))
         return unpack_masks(words, self.k), nsel
+
+    def marginal_counts(self, n_repetitions, seed, col=0):
+        """
+        k x k expected numbers of state changes per scenario from n_repetitions scenarios sampled on the device
+        (pastml/ml.py:753-862) after a marginal pass of column col; seed keys the counter-based generator.
+        """
+        out = np.empty((self.k, self.k), dtype=np.float64)
+        _check(self._lib.pml_marginal_counts(self._ctx, col, int(n_repetitions), ctypes.c_uint64(int(seed)),
+                                             _ptr(out, ctypes.c_double)))
+        return out
 
     def download(self, what, col=0):
         N, k = self.n_nodes, self.k

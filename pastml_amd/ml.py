@@ -782,16 +782,19 @@ def ml_acr(forest, character, prediction_method, model, observed_frequencies, fo
 # marginal_counts
 # =====================================================================================================================
 
-def marginal_counts(forest, character, model, n_repetitions=1_000):
+def marginal_counts(forest, character, model, n_repetitions=1_000, device_sampling=True):
     """
     Expected numbers of state changes i -> j along the trees, estimated by drawing ``n_repetitions`` ancestral
     scenarios from the marginal posterior (API and sampling scheme of pastml/ml.py:753-862, used by
     utilities/transition_counter.py).
 
-    The likelihood part -- bottom-up and top-down sweeps, root posteriors, per-branch P(t) -- runs on the GPU; the
-    scenario sampling (multinomial draws of child states given the parent's state counts, ml.py:818-857) stays on the
-    host with numpy's global generator, as in the reference, so only statistical parity is meaningful.
+    The likelihood part -- bottom-up and top-down sweeps, root posteriors, per-branch P(t) -- runs on the GPU, and so
+    does the scenario sampling (draws of child states given the parent's state counts, ml.py:818-857:
+    ``pml_marginal_counts``) unless zero-branch handling altered some nodes: their special rules (ml.py:806-812,
+    840-853) stay on the host with numpy's generator, as in the reference.  Either way only statistical parity with the
+    reference is meaningful.
 
+    :param device_sampling: False forces the host sampler (tests compare the two)
     :return: k x k array, entry [i, j] = average number of i -> j changes per scenario
     """
     if isinstance(forest, TreeNode):
@@ -804,6 +807,10 @@ def marginal_counts(forest, character, model, n_repetitions=1_000):
         altered = problem.alter_zero_node_allowed_states() if 0 == model.tau else np.zeros(0, dtype=np.int64)
         problem.bottom_up_loglikelihood(model, is_marginal=True, alter=False)
         posterior, _, _ = problem.top_down_marginals()
+        if device_sampling and not len(altered):
+            # no node altered by the zero-branch handling: the scenarios are drawn on the device (same scheme, a
+            # counter-based generator seeded from numpy's global one, so np.random.seed still fixes the result)
+            return problem.engine.marginal_counts(n_repetitions, seed=int(np.random.randint(0, 2 ** 62, dtype=np.int64)))
         bu = problem.engine.download(hip.BUF_BU)
         P = problem.engine.pij_batch(copy_out=True)[0]
         frequencies = np.asarray(model.frequencies, dtype=np.float64)

@@ -585,3 +585,50 @@ def test_eigen_models_optimised_match_reference():
     np.testing.assert_allclose(res[LOG_LIKELIHOOD], z['cr_loglik'], rtol=0, atol=2e-5)
     np.testing.assert_allclose(res[MODEL].frequencies, z['cr_frequencies'], atol=2e-4)
     np.testing.assert_allclose(res[MARGINAL_PROBABILITIES].values, z['cr_posterior'], rtol=0, atol=5e-4)
+
+
+@pytest.mark.parametrize('model_name,k', [('F81', 5), ('HKY', 4), ('JTT', 20)])
+def test_marginal_counts_device_sampler_agrees_with_host_sampler(model_name, k):
+    """
+    pml_marginal_counts (scenarios drawn on the device, Philox) against the host sampler that follows ml.py:753-862 line
+    by line with numpy's generator: two independent Monte-Carlo estimates of the same k x k expectation.  F81 uses the
+    closed-form P(t) inside the sampler, HKY the materialised one, JTT (k = 20: fused matrix-core sweeps that never
+    build P) materialises it for the sampler.
+    """
+    from pastml_amd.models.HKYModel import HKYModel
+    from pastml_amd.models.JTTModel import JTTModel, JTT_STATES
+    from pastml_amd.tree import FlatForest
+    rng = np.random.default_rng(5 + k)
+    flat = FlatForest.random(70, seed=17 + k, max_arity=3)
+    roots = flat.to_tree_nodes()
+    if model_name == 'JTT':
+        states = np.array(JTT_STATES)
+    elif model_name == 'HKY':
+        states = np.array(['A', 'C', 'G', 'T'])
+    else:
+        states = np.array(['s{}'.format(i) for i in range(k)])
+    for t in flat.tips:
+        if rng.random() < 0.85:
+            flat.nodes[t].add_feature('c', {states[rng.integers(len(states))]})
+    fs = ForestStats(roots)
+    if model_name == 'F81':
+        model = F81Model(states=states, forest_stats=fs, sf=1.2 / fs.avg_nonzero_brlen,
+                         frequencies=rng.dirichlet(np.ones(k) * 3))
+    elif model_name == 'HKY':
+        model = HKYModel(states=states, forest_stats=fs, sf=1.0 / fs.avg_nonzero_brlen,
+                         frequencies=rng.dirichlet(np.ones(4) * 3), kappa=3.0)
+    else:
+        model = JTTModel(states=states, forest_stats=fs, sf=0.8 / fs.avg_nonzero_brlen)
+    model.freeze()
+    n_rep = 20000
+    np.random.seed(3)
+    dev = ml.marginal_counts(roots, 'c', model, n_repetitions=n_rep)
+    host = ml.marginal_counts(roots, 'c', model, n_repetitions=n_rep, device_sampling=False)
+    assert dev.shape == host.shape == (len(states), len(states))
+    # entries are means of n_rep scenario counts with variance of the order of their value
+    tol = 8 * np.sqrt(np.maximum(host, 0.02) / n_rep) + 0.01
+    assert np.all(np.abs(dev - host) < tol), (np.abs(dev - host).max(), (np.abs(dev - host) / tol).max())
+    assert abs(dev.sum() - host.sum()) < 0.05 * max(1.0, host.sum())
+    # same seed, same result: the generator is counter-based
+    np.random.seed(3)
+    assert np.array_equal(dev, ml.marginal_counts(roots, 'c', model, n_repetitions=n_rep))
