@@ -124,8 +124,34 @@ __device__ __forceinline__ void eig_pass(const EigWave<NT, KS>& W, const PmlTree
         bool tipc = false;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) v[nt] = vc[nt] = mb[nt] = 0.0;
+        // everything that only needs the node id goes out first, together: one wait instead of one per array
+        u64 word = 0ull;
+        int fc = 0, nc = 0, p = 0;
+        double dist_n = 0.0;
+        i64 be_n = 0, te_p = 0, be_p = 0;
+        double own_bu[NT], own_msg[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) own_bu[nt] = own_msg[nt] = 0.0;
         if (act) {
-            const u64 word = c.masks[colN + n];  // k <= 32: one word
+            word = c.masks[colN + n];  // k <= 32: one word
+            nc = t.n_children[n];
+            dist_n = t.dist[n];
+            if (MODE != PML_EIG_TD) {
+                fc = t.first_child[n];
+            } else {
+                p = t.parent[n];
+                be_n = st.be[colN + n];  // a tip's exponent word is 0 (never written by these sweeps)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int i = 16 * nt + lo;
+                    if (i < ks) {
+                        own_bu[nt] = st.bu[row + i];  // a tip's row is allocated but never written: not used below
+                        own_msg[nt] = st.msg[row + i];
+                    }
+                }
+            }
+        }
+        if (act) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int i = 16 * nt + lo;
@@ -140,7 +166,6 @@ __device__ __forceinline__ void eig_pass(const EigWave<NT, KS>& W, const PmlTree
                     // together, so a binary node waits for memory once, not once per child and array.  A tip's
                     // exponent word is zero (set when the column arrays are allocated, never written by these
                     // sweeps), so it is read without asking whether the child is a tip.
-                    const int fc = t.first_child[n], nc = t.n_children[n];
                     for (int j0 = 0; j0 < nc; j0 += 2) {
                         double mv[2][NT];
                         i64 cbe[2];
@@ -181,17 +206,22 @@ __device__ __forceinline__ void eig_pass(const EigWave<NT, KS>& W, const PmlTree
                 }
             } else {
                 // x = TD_p o BU_p / msg_n (ml.py:279-283); the message is what the bottom-up sweep left
-                const int p = t.parent[n];
-                tipc = t.n_children[n] == 0;
-                if (!tipc) bec = st.be[colN + n];
-                const i64 pe = st.te[colN + p] + st.be[colN + p];
+                tipc = nc == 0;
+                bec = tipc ? 0 : be_n;
+                te_p = st.te[colN + p];
+                be_p = st.be[colN + p];
+                double prod[NT];
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     const int i = 16 * nt + lo;
-                    vc[nt] = tipc ? mb[nt] : (i < ks ? st.bu[row + i] : 0.0);
-                    const double prod = i < ks ? st.td[(colN + p) * ks + i] * st.bu[(colN + p) * ks + i] : 0.0;
-                    const double mc = i < ks ? st.msg[row + i] : 0.0;
-                    v[nt] = prod / (mc > 0.0 ? mc : 1.0);
+                    prod[nt] = i < ks ? st.td[(colN + p) * ks + i] * st.bu[(colN + p) * ks + i] : 0.0;
+                }
+                const i64 pe = te_p + be_p;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    vc[nt] = tipc ? mb[nt] : own_bu[nt];
+                    const double mc = own_msg[nt];
+                    v[nt] = prod[nt] / (mc > 0.0 ? mc : 1.0);
                 }
                 esum = pe - bec;
                 esum += lazy_rescale<16, NT>(v);
@@ -204,7 +234,7 @@ __device__ __forceinline__ void eig_pass(const EigWave<NT, KS>& W, const PmlTree
                 const int i = 16 * nt + lo;
                 if (i < KP) sV[hi * KP + i] = v[nt];
             }
-            if (lo == 0) sT[hi] = act ? (t.dist[n] + tau) * tf * sfc : 0.0;
+            if (lo == 0) sT[hi] = act ? (dist_n + tau) * tf * sfc : 0.0;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
