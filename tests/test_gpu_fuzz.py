@@ -98,6 +98,23 @@ def test_random_case(seed):
             states = eng.joint_backtrace()
         except hip.ZeroLikelihoodError:
             joint_ok = False
+        # MAP / MPPA selection on the device against the host restatement of ml.py:505-595, on the device's posteriors
+        if joint_ok and np.all(np.isfinite(post)):
+            from pastml_amd import ml
+            eng.bottom_up(True)
+            eng.top_down_marginals(posterior=False, lh=False)
+            for method, fj in (('MPPA', True), ('MPPA', False), ('MAP', False)):
+                sel, nsel = eng.select_states(method, force_joint=fj)
+                for c in range(C):
+                    if method == 'MAP':
+                        ref_sel, ref_k = ml.select_map(post[c]), np.ones(flat.n_nodes, dtype=int)
+                    else:
+                        ref_sel, ref_k = ml.select_mppa(post[c], states[c].astype(np.int64) if fj else None)
+                    assert np.array_equal(nsel[c], ref_k), (method, fj, c)
+                    assert np.array_equal(sel[c], ref_sel), (method, fj, c)
+                eng.set_masks(masks)
+                eng.bottom_up(True)
+                eng.top_down_marginals(posterior=False, lh=False)
     internal = ~flat.is_tip
     nonroot = flat.parent >= 0
     for c in range(C):
