@@ -1092,7 +1092,13 @@ static int set_common(pml_ctx* ctx, int kind, int cb, int ce, const double* pi, 
                       const double* tauf) {
     PML_TRY(check_cols(ctx, cb, ce));
     if (!pi || !sf || !tau || !tauf) return fail(PML_ERR_INVALID, "NULL parameter array");
-    if (ctx->kind != -1 && ctx->kind != kind) return fail(PML_ERR_INVALID, "all columns of a ctx must use one model kind");
+    if (ctx->kind != -1 && ctx->kind != kind) {
+        // one model kind per ctx; setting ALL columns at once may change it (a pooled ctx serving the next analysis)
+        if (cb != 0 || ce != ctx->C) return fail(PML_ERR_INVALID, "all columns of a ctx must use one model kind");
+        drop_graph(ctx->bu_graph[0]);
+        drop_graph(ctx->bu_graph[1]);
+        drop_graph(ctx->td_graph);
+    }
     if (kind == PML_MODEL_HKY && ctx->k != 4) return fail(PML_ERR_INVALID, "HKY needs k = 4");
     const int nc = ce - cb;
     for (int i = 0; i < nc; ++i)

@@ -157,6 +157,82 @@ def unpack_masks(words, k):
     return np.unpackbits(b, axis=-1, bitorder='little')[..., :k].astype(np.int8)
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# Engine pool.  acr() analyses one character after the other on the same forest (pastml/acr.py:210-231), and every
+# ml_acr needs a context for the single column plus one per width of the batched optimiser: creating and destroying
+# them (device allocations, tree upload, descriptor tables, captured graphs) is a fifth of the wall time of a binary
+# character on a 3 600-tip tree.  Released engines of small problems are kept, keyed by the forest's arrays, the number
+# of columns, k and the device, and handed out again with their per-analysis state reset.
+_POOL = {}
+_POOL_LOCK = threading.Lock()
+_POOL_MAX_BYTES = 1 << 30   # an engine holding more device memory than this is destroyed on release
+_POOL_MAX_ENGINES = 16
+
+
+def _forest_key(flat):
+    key = getattr(flat, '_pool_key', None)
+    if key is None:
+        import hashlib
+        h = hashlib.blake2b(digest_size=16)
+        for a in (flat.parent, flat.first_child, flat.n_children, flat.dist):
+            h.update(np.ascontiguousarray(a).tobytes())
+        key = (flat.n_nodes, h.hexdigest())
+        try:
+            flat._pool_key = key
+        except AttributeError:
+            pass
+    return key
+
+
+def acquire_engine(flat, n_cols, k, device=None):
+    """An Engine for (flat, n_cols, k): a pooled one if there is one (masks, models and '.initial' masks are the
+    caller's to set, as for a new one), else a new one.  Give it back with release_engine()."""
+    dev = default_device() if device is None else device
+    key = (_forest_key(flat), n_cols, k, dev)
+    with _POOL_LOCK:
+        free = _POOL.get(key)
+        if free:
+            eng = free.pop()
+            eng.flat = flat
+            eng.set_initial_masks(None)
+            return eng
+    eng = Engine(flat, n_cols, k, device=device)
+    eng._pool_key = key
+    return eng
+
+
+def release_engine(eng):
+    """Returns an engine of acquire_engine() to the pool (or destroys it: big problems, full pool)."""
+    key = getattr(eng, '_pool_key', None)
+    if key is None or eng._ctx.value is None:
+        eng.close()
+        return
+    try:
+        eng.sync()
+        held, _ = eng.memory()
+    except HipError:
+        eng.close()
+        return
+    with _POOL_LOCK:
+        total = sum(len(v) for v in _POOL.values())
+        if held <= _POOL_MAX_BYTES and total < _POOL_MAX_ENGINES:
+            _POOL.setdefault(key, []).append(eng)
+            return
+    eng.close()
+
+
+def drain_engine_pool():
+    with _POOL_LOCK:
+        engines = [e for v in _POOL.values() for e in v]
+        _POOL.clear()
+    for e in engines:
+        e.close()
+
+
+import atexit  # noqa: E402
+atexit.register(drain_engine_pool)
+
+
 class Engine(object):
     """
     One device context: a flat forest, ``n_cols`` columns with ``k`` states each, one model kind.

@@ -138,15 +138,15 @@ class ForestProblem(object):
     def engine(self):
         """The device context, created on first use (mask bookkeeping alone needs no GPU)."""
         if self._engine is None:
-            self._engine = hip.Engine(self.flat, 1, self.k, device=self._device)
+            self._engine = hip.acquire_engine(self.flat, 1, self.k, device=self._device)
         return self._engine
 
     def close(self):
         if self._engine is not None:
-            self._engine.close()
+            hip.release_engine(self._engine)
             self._engine = None
         for slot in self.__dict__.pop('_batch_engines', {}).values():
-            slot['engine'].close()
+            hip.release_engine(slot['engine'])
 
     # ------------------------------------------------------------------------------------------------ masks
     def initialize_allowed_states(self):
@@ -259,7 +259,7 @@ class ForestProblem(object):
         C = len(parameter_vectors)
         cache = self.__dict__.setdefault('_batch_engines', {})
         if C not in cache:
-            cache[C] = dict(engine=hip.Engine(self.flat, C, self.k, device=self._device), masks=[None] * C)
+            cache[C] = dict(engine=hip.acquire_engine(self.flat, C, self.k, device=self._device), masks=[None] * C)
         slot = cache[C]
         engine = slot['engine']
         specs, variants = [], []
