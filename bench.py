@@ -245,9 +245,11 @@ def main():
             'vs_baseline': None,
             'dtype': 'f64',
             'data': 'synthetic',
-            'config': {'workload': 'BASELINE config 4 shard: balanced tree, {} tips ({} nodes), k={} states, {}, '
+            'config': {'workload': '{}: balanced tree, {} tips ({} nodes), k={} states, {}, '
                                    '{} characters per GPU ({} in total), marginal (BU+TD+posteriors)'
-                                   .format(flat.n_tips, N, k, model, cpg, cpg * world),
+                                   .format({'cfg4': 'BASELINE config 4 shard', 'cfg2': 'BASELINE config 2',
+                                            'cfg4_small': 'reduced config 4 (16 384 tips)'}[args.workload],
+                                           flat.n_tips, N, k, model, cpg, cpg * world),
                        'tips': int(flat.n_tips), 'nodes': int(N), 'states': k, 'chars_per_gpu': cpg,
                        'chars_total': cpg * world, 'substitution_model': model,
                        'sharding': 'characters over ranks, no data-path collective; 1 all-reduce (8 B) per step'},
