@@ -632,3 +632,47 @@ def test_marginal_counts_device_sampler_agrees_with_host_sampler(model_name, k):
     # same seed, same result: the generator is counter-based
     np.random.seed(3)
     assert np.array_equal(dev, ml.marginal_counts(roots, 'c', model, n_repetitions=n_rep))
+
+
+def test_engine_pool_reuse_and_model_kind_switch():
+    """
+    A released engine is handed out again for the same forest / width / k, with no state of the previous analysis
+    leaking into the next one -- including a change of the model kind (F81 -> HKY on four states), which a ctx accepts
+    when all of its columns are set at once.
+    """
+    from pastml_amd import hip
+    from test_gpu_parity import random_masks, random_spec
+    rng = np.random.default_rng(21)
+    flat = FlatForest.random(150, seed=9, max_arity=3)
+    k = 4
+    masks_a, masks_b = random_masks(flat, k, rng)[None], random_masks(flat, k, rng)[None]
+    spec_f81, spec_hky = random_spec('F81', k, rng), random_spec('HKY', k, rng)
+
+    def run(eng, spec, masks):
+        eng.set_models([(spec, (1.3, 0.0, 1.0))])
+        eng.set_masks(masks)
+        lnl = eng.bottom_up(True)
+        post, _, _ = eng.top_down_marginals()
+        lnl_j = eng.bottom_up(False)
+        return lnl.copy(), post.copy(), lnl_j.copy(), eng.joint_backtrace().copy()
+
+    hip.drain_engine_pool()
+    first = hip.acquire_engine(flat, 1, k)
+    a = run(first, spec_f81, masks_a)
+    hip.release_engine(first)
+    again = hip.acquire_engine(flat, 1, k)
+    assert again is first
+    b = run(again, spec_hky, masks_b)      # other kind, other masks, on the pooled ctx
+    c = run(again, spec_f81, masks_a)      # and back
+    hip.release_engine(again)
+    with hip.Engine(flat, 1, k) as fresh:
+        ref_b = run(fresh, spec_hky, masks_b)
+    for x, y in zip(b, ref_b):
+        assert np.array_equal(x, y)
+    for x, y in zip(a, c):
+        assert np.array_equal(x, y)
+    # another forest never gets this engine
+    other = hip.acquire_engine(FlatForest.random(150, seed=10, max_arity=3), 1, k)
+    assert other is not first
+    hip.release_engine(other)
+    hip.drain_engine_pool()
