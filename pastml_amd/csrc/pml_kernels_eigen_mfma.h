@@ -98,6 +98,19 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// combines two partial results of a node: sum, or the larger value with the smaller index among equal ones
+template <int MODE>
+__device__ __forceinline__ void eig_combine(double& v, int& j, double ov, int oj) {
+    if (MODE == PML_EIG_BU_JOINT) {
+        if (ov > v || (ov == v && oj < j)) {
+            v = ov;
+            j = oj;
+        }
+    } else {
+        v += ov;
+    }
+}
+
 // One pass of a wave: NB nodes, lane (lo, hi) owns node n of row hi (act: the row has a node).
 template <int NT, int KS, int MODE>
 __device__ __forceinline__ void eig_pass(const EigWave<NT, KS>& W, const PmlTree& t, const PmlCols& c,
@@ -296,36 +309,53 @@ __device__ __forceinline__ void eig_pass(const EigWave<NT, KS>& W, const PmlTree
                 }
             }
         }
-        // the four row groups of a column: lanes lo, lo + 16, lo + 32, lo + 48
-#pragma unroll
-        for (int q = 0; q < NB; ++q)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int o = 16; o <= 32; o <<= 1) {
-                    const double ov = __shfl_xor(acc_v[q][nt], o, 64);
-                    if (MODE == PML_EIG_BU_JOINT) {
-                        const int oj = __shfl_xor(acc_j[q][nt], o, 64);
-                        if (ov > acc_v[q][nt] || (ov == acc_v[q][nt] && oj < acc_j[q][nt])) {
-                            acc_v[q][nt] = ov;
-                            acc_j[q][nt] = oj;
-                        }
-                    } else {
-                        acc_v[q][nt] += ov;
-                    }
-                }
+        // The four row groups of a column (lanes lo, lo + 16, lo + 32, lo + 48) hold partial results for all NB
+        // nodes; lane (lo, hi) needs the total of node hi only.  Reduce-scatter: across the halves (xor 32) a lane
+        // hands over the partials of the nodes the other half owns, across the rows (xor 16) likewise -- 3 NT
+        // exchanges for NB = 4 instead of the 8 NT of reducing everything everywhere.
         double r[NT];
         int rj[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            r[nt] = acc_v[0][nt];
-            rj[nt] = acc_j[0][nt];
+            double kv[2];
+            int kj[2];
+            if (NB == 4) {
+                const bool upper = (hi & 2) != 0;  // owns nodes 2, 3
 #pragma unroll
-            for (int q = 1; q < NB; ++q)
-                if (hi == q) {
-                    r[nt] = acc_v[q][nt];
-                    rj[nt] = acc_j[q][nt];
+                for (int j = 0; j < 2; ++j) {
+                    const double mine = upper ? acc_v[2 + j][nt] : acc_v[j][nt];
+                    const double give = upper ? acc_v[j][nt] : acc_v[2 + j][nt];
+                    const int minej = upper ? acc_j[2 + j][nt] : acc_j[j][nt];
+                    const int givej = upper ? acc_j[j][nt] : acc_j[2 + j][nt];
+                    kv[j] = mine;
+                    kj[j] = minej;
+                    eig_combine<MODE>(kv[j], kj[j], __shfl_xor(give, 32, 64),
+                                      MODE == PML_EIG_BU_JOINT ? __shfl_xor(givej, 32, 64) : 0);
                 }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int q = j < NB ? j : 0;
+                    kv[j] = acc_v[q][nt];
+                    kj[j] = acc_j[q][nt];
+                    eig_combine<MODE>(kv[j], kj[j], __shfl_xor(acc_v[q][nt], 32, 64),
+                                      MODE == PML_EIG_BU_JOINT ? __shfl_xor(acc_j[q][nt], 32, 64) : 0);
+                }
+            }
+            if (NB >= 2) {
+                const bool odd = (hi & 1) != 0;  // owns the second of the two nodes left
+                r[nt] = odd ? kv[1] : kv[0];
+                rj[nt] = odd ? kj[1] : kj[0];
+                const double give = odd ? kv[0] : kv[1];
+                const int givej = odd ? kj[0] : kj[1];
+                eig_combine<MODE>(r[nt], rj[nt], __shfl_xor(give, 16, 64),
+                                  MODE == PML_EIG_BU_JOINT ? __shfl_xor(givej, 16, 64) : 0);
+            } else {
+                r[nt] = kv[0];
+                rj[nt] = kj[0];
+                eig_combine<MODE>(r[nt], rj[nt], __shfl_xor(kv[0], 16, 64),
+                                  MODE == PML_EIG_BU_JOINT ? __shfl_xor(kj[0], 16, 64) : 0);
+            }
         }
         // ------------------------------------------------------------------ results of the node
         if (act) {
