@@ -4,17 +4,24 @@ Benchmark of the ML-ACR hot path on MI355X (contract: see the task description; 
 
 Workload (BASELINE config 4, weak scaling): synthetic balanced tree with 1 048 576 tips (2 097 151 nodes), k = 64
 states, F81 with independent frequencies per character, 32 characters per GPU (= 256 characters on 8 GPUs).
-One "step" = one full marginal pass over the rank's characters: per-branch transition data, bottom-up sweep
-(log-likelihoods returned to the host), top-down sweep, marginal likelihoods and posteriors for every node, left in HBM.
-With N > 1 GPUs the characters are sharded over the ranks (no data-path collective); the summed log-likelihood is
-all-reduced over RCCL after every step, as the host optimiser would need it.
+One "step" = one full marginal pass over the rank's characters: model parameters to the device, per-branch transition
+data, bottom-up sweep (log-likelihoods returned to the host), top-down sweep, marginal likelihoods and posteriors for
+every node (left in HBM), and -- the one collective of the path -- the all-reduce of the summed log-likelihood over
+RCCL, issued by the library on the sweep's own stream (pml_allreduce_loglik).
 
-Prints ONE JSON line on rank 0.
+N > 1: one process per GPU.  Either the launcher provides RANK / LOCAL_RANK / WORLD_SIZE (torch.distributed.run), or
+`python bench.py --gpus N` starts the N rank processes itself (before anything touches a GPU) and relays rank 0's line.
+
+Prints ONE JSON line on rank 0.  After the timed region the posteriors of EVERY column are validated on a strided
+node sample (rows sum to one, every node sees the column's total likelihood, observed tips keep their state), and,
+on one GPU, the other BASELINE configs are timed in the same process (`secondary`).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -24,8 +31,10 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 TB/s achievable)
-BYTES_BU = 16                    # algorithmic bytes per node.state.char, bottom-up sweep
-BYTES_TD = 32                    # ... top-down + marginals + posterior part of the full pass (48 - 16)
+FP64_MFMA_PEAK_TFLOPS = 78.6     # dense FP64 matrix-core peak (same guide)
+# SURVEY.md 8d's bytes per node.state.char of the REFERENCE's schedule (every vector of every node written and read
+# back): kept only to say how much traffic the schedule below avoids -- never used for `frac`
+REFERENCE_SCHEDULE_BYTES = {'bottom_up': 16, 'top_down': 32}
 
 WORKLOADS = {
     # name: (tree levels, k, characters per GPU)
@@ -43,6 +52,8 @@ def parse_args():
     p.add_argument('--workload', default='cfg4', choices=sorted(WORKLOADS))
     p.add_argument('--chars-per-gpu', type=int, default=None)
     p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--no-secondary', action='store_true', help='skip the cfg2 / cfg3 / cfg5-shaped timings')
+    p.add_argument('--no-validate', action='store_true', help='skip the post-run validation of every column')
     p.add_argument('--no-kernel-timing', action='store_true',
                    help='leave the HIP-event brackets off: the sweeps are then replayed as hipGraphs (the library\'s '
                         'default outside profiling); roofline fields are null')
@@ -53,6 +64,9 @@ def parse_args():
     return p.parse_args()
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU baseline (the oracle as the checker/baseline: never part of the product path)
+# ---------------------------------------------------------------------------------------------------------------------
 def _cpu_baseline_one(job):
     """One character of the workload on a balanced subtree through the oracle (runs in a worker process: numpy only)."""
     k, levels, model, char = job
@@ -78,6 +92,14 @@ def cpu_model_name():
     except OSError:
         pass
     return 'unknown'
+
+
+def under_profiler():
+    """rocprofv3 preloads its tool library, which initialises the GPU before main(): no child processes then."""
+    env = os.environ
+    if any(k.startswith(('ROCPROF', 'ROCPROFILER', 'ROCP_')) for k in env):
+        return True
+    return any(t in env.get('LD_PRELOAD', '') for t in ('rocprof', 'roctracer', 'roctx'))
 
 
 def cpu_baseline(k, levels, model, cores=None):
@@ -117,63 +139,269 @@ def cpu_baseline(k, levels, model, cores=None):
     return out
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# compulsory HBM bytes of THIS schedule, per column and sweep
+# ---------------------------------------------------------------------------------------------------------------------
+def schedule_bytes(flat, k, n_cols, narrow_limit=None):
+    """
+    Bytes the F81-family kernels must move per sweep for one column, from the tree itself: only *stored* internal
+    nodes (internal nodes that are not cherries; roots always) have a bottom-up vector in HBM, tips are 8-byte masks,
+    cherries are rebuilt in registers, top-down vectors are never written, every node's posterior is written once.
+    Returns per-sweep totals and the part moved by the level kernels alone (the launches the HIP-event brackets and
+    rocprofv3 see under the kernel's name; the few levels next to the roots run in one single-workgroup launch).
+    """
+    ks = k + (k & 1) if k >= 2 else k
+    W = (k + 63) // 64
+    vec = 8 * ks
+    N = flat.n_nodes
+    nc = np.asarray(flat.n_children)
+    fc = np.asarray(flat.first_child)
+    parent = np.asarray(flat.parent)
+    internal = nc > 0
+    tip = ~internal
+    # cherry: non-root internal node whose children are all tips
+    n_tip_children = np.zeros(N, dtype=np.int64)
+    np.add.at(n_tip_children, parent[(parent >= 0) & tip], 1)
+    cherry = internal & (n_tip_children == nc) & (parent >= 0)
+    stored = internal & ~cherry
+    nonroot = parent >= 0
+    pmask = np.zeros(N, dtype=bool)
+    pmask[nonroot] = stored[parent[nonroot]]            # node is a child of a stored node
+    cmask = np.zeros(N, dtype=bool)
+    cmask[nonroot] = cherry[parent[nonroot]]            # node is a tip of a cherry
+    n_stored = int(stored.sum())
+    ch_stored = int((pmask & stored).sum())
+    ch_cherry = int((pmask & cherry).sum())
+    ch_tip = int((pmask & tip).sum())
+    tips_of_cherries = int(cmask.sum())
+    n_children_of_stored = ch_stored + ch_cherry + ch_tip
+    # bottom-up, per stored node: descriptor 32; per child E, mask, S, exponent (32); stored child's vector; per tip of
+    # a cherry child E, mask, S (24); writes: vector, S, exponent; S + exponent of every cherry child (16)
+    bu = n_stored * (32 + vec + 16) + n_children_of_stored * 32 + ch_stored * vec + tips_of_cherries * 24 + ch_cherry * 16
+    # top-down, per stored parent: descriptor 32, its posterior + sum + exponent (vec + 16); per child the same gather
+    # (32) + posterior, sum, exponent written (vec + 16); stored child: its bottom-up vector; tips of cherry children:
+    # gather 24 + posterior, sum, exponent written
+    td = n_stored * (32 + vec + 16) + n_children_of_stored * (32 + vec + 16) + ch_stored * vec \
+        + tips_of_cherries * (24 + vec + 16)
+    # per-branch data: dist in (8, shared by the columns through L2: charged once per column all the same), E out (8);
+    # tips: mask in (8 W), S out (8)
+    prep = N * 16 + int(tip.sum()) * (8 * W + 8)
+    return dict(bottom_up=bu, top_down=td, prep=prep, total=bu + td + prep, vec_bytes=vec, n_stored=n_stored,
+                n_cherries=int(cherry.sum()), n_tips=int(tip.sum()),
+                per_unit=dict(bottom_up=bu / (N * k), top_down=td / (N * k), prep=prep / (N * k)))
+
+
+def csrc_digest():
+    """sha256 over the kernel sources: profiles/traffic.json is only valid for the sources it was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(REPO, 'pastml_amd', 'csrc')
+    for name in sorted(os.listdir(d)):
+        if name.endswith(('.h', '.hip')):
+            h.update(name.encode())
+            with open(os.path.join(d, name), 'rb') as f:
+                h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N rank processes (this process never touches a GPU)."""
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    rdzv = tempfile.mkdtemp(prefix='pastml_amd_rdzv_')
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), PASTML_AMD_RDZV_DIR=rdzv, HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    try:
+        os.rmdir(rdzv)
+    except OSError:
+        pass
+    return max(abs(c) for c in codes)
+
+
+def validate_columns(eng, flat, k, tip_states, lnl, stride=4099):
+    """
+    After the timed region: every column's results on a strided node sample + all tips of the sample.  Size-independent
+    properties (no oracle needed at this size): posterior rows sum to 1; log10(sum LH) - LH_SF equals the column's
+    ln L / ln 10 at every sampled node (pastml/ml.py:468-483); an observed tip's posterior is the unit vector of its
+    state.  A wrong column stride or a column left untouched fails here.
+    """
+    from pastml_amd import hip
+    N = flat.n_nodes
+    first_tip = int(flat.tips[0])
+    worst = dict(row_sum=0.0, total_lh=0.0)
+    for c in range(eng.n_cols):
+        post = eng.download_strided(hip.BUF_POSTERIOR, c, 0, stride)
+        lhs = eng.download_strided(hip.BUF_LH_SUM, c, 0, stride)
+        lsf = eng.download_strided(hip.BUF_LH_SF, c, 0, stride)
+        ids = np.arange(0, N, stride)
+        rs = np.abs(post.sum(axis=1) - 1).max()
+        tl = np.abs((np.log10(lhs) - lsf) / (lnl[c] / np.log(10)) - 1).max()
+        worst['row_sum'] = max(worst['row_sum'], float(rs))
+        worst['total_lh'] = max(worst['total_lh'], float(tl))
+        if not (rs < 1e-12 and tl < 1e-11):
+            raise SystemExit('validation failed in column {}: |row sum - 1| = {:.3g}, total-likelihood mismatch {:.3g}'
+                             .format(c, rs, tl))
+        is_tip = ids >= first_tip
+        if np.array_equal(np.asarray(flat.tips), np.arange(first_tip, N)) and is_tip.any():
+            want = tip_states[c][ids[is_tip] - first_tip]
+            got = post[is_tip]
+            if not (np.array_equal(got.argmax(axis=1), want) and np.all(got.max(axis=1) == 1.0)):
+                raise SystemExit('validation failed in column {}: an observed tip lost its state'.format(c))
+    return dict(columns=eng.n_cols, node_stride=stride, max_row_sum_error=worst['row_sum'],
+                max_total_likelihood_rel_error=worst['total_lh'], tips_checked=True)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def secondary_measurements(device):
+    """The other BASELINE configs, timed on the same GPU in the same process (after the main region)."""
+    from pastml_amd import hip, synthetic
+    out = {}
+
+    def timed(fn, reps, eng):
+        fn()
+        eng.sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        eng.sync()
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    # ---- cfg2: 65 536 tips, JC k=4, 1 character, marginal
+    flat = synthetic.balanced_forest(16)
+    k = 4
+    with hip.Engine(flat, 1, k, device=device) as eng:
+        spec = dict(kind=0, pi=np.ones(k) / k)
+        eng.set_tip_states(synthetic.tip_states(flat.n_tips, k, 0))
+
+        def cfg2():
+            eng.set_models([(spec, (1.0, 0.0, 1.0))])
+            eng.bottom_up(True)
+            eng.top_down_marginals(posterior=False, lh=False)
+        ms = timed(cfg2, 50, eng)
+        sb = schedule_bytes(flat, k, 1)
+        out['cfg2'] = dict(workload='BASELINE config 2: balanced 65 536-tip tree, JC k=4, 1 character, marginal '
+                                    '(BU+TD+posteriors), hipGraph replay', ms_per_pass=ms,
+                           value=flat.n_nodes * k / (ms * 1e-3), unit='node*state*char/s',
+                           roofline=dict(bound='hbm (launch-latency-bound in practice: {} level launches)'
+                                         .format(flat.n_bu_levels + flat.n_td_levels),
+                                         model_bytes=sb['total'], achieved=sb['total'] / (ms * 1e-3) / 1e9,
+                                         peak=HBM_PEAK_GBS, unit='GB/s', frac=sb['total'] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS))
+    # ---- cfg3: 262 144 tips, JTT k=20, joint (fused FP64 matrix-core sweep) + back-trace
+    from pastml_amd.models.JTTModel import JTT_FREQUENCIES, JTT_RATE_MATRIX
+    from pastml_amd.models.generator import get_diagonalisation
+    flat = synthetic.balanced_forest(18)
+    k = 20
+    d, A, Ainv = get_diagonalisation(JTT_FREQUENCIES, JTT_RATE_MATRIX)
+    spec = dict(kind=2, pi=JTT_FREQUENCIES, d=d, A=A, Ainv=Ainv)
+    with hip.Engine(flat, 1, k, device=device) as eng:
+        eng.set_models([(spec, (1.0, 0.0, 1.0))])
+        eng.set_tip_states(synthetic.tip_states(flat.n_tips, k, 0))
+
+        def cfg3():
+            eng.bottom_up(False)
+            eng.joint_backtrace(copy_out=False)
+        ms = timed(cfg3, 20, eng)
+        ms_sweep = timed(lambda: eng.bottom_up(False), 20, eng)
+        flops = 2.0 * k ** 3 * (flat.n_nodes - 1)           # P(t) = A diag(exp(d t)) A^-1 per branch (SURVEY 8d)
+        # compulsory bytes of the fused sweep: message (8 k) written + read per non-root node, arg-max row (k bytes),
+        # mask word, branch length, exponent
+        bytes_ = (flat.n_nodes - 1) * (2 * 8 * k + k + 8 + 8 + 8 + 8)
+        out['cfg3'] = dict(workload='BASELINE config 3: balanced 262 144-tip tree, JTT k=20, 1 character, joint (Pupko) '
+                                    'sweep + back-trace, fused FP64 matrix-core sweep', ms_per_pass=ms,
+                           ms_joint_sweep=ms_sweep, value=flat.n_nodes * k / (ms * 1e-3), unit='node*state*char/s',
+                           roofline=dict(bound='mfma', flops=flops, achieved=flops / (ms_sweep * 1e-3) / 1e12,
+                                         peak=FP64_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
+                                         frac=flops / (ms_sweep * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                                         hbm_model_bytes=bytes_,
+                                         hbm_frac=bytes_ / (ms_sweep * 1e-3) / 1e9 / HBM_PEAK_GBS))
+    # ---- cfg5-shaped optimiser gradient: real HIV1C tree (3 619 tips), Loc (k = 12): the 14 likelihoods of one
+    #      L-BFGS-B gradient (13 free parameters + the point itself) in one batched bottom-up sweep
+    nwk = os.path.join(REPO, 'tests', 'golden', 'data', 'hiv1c', 'pastml_phyml_tree.nwk')
+    if os.path.exists(nwk):
+        from pastml_amd.tree import read_tree, get_flat_forest
+        flat = get_flat_forest([read_tree(nwk)])
+        k, cols = 12, 14
+        rng = np.random.default_rng(5)
+        with hip.Engine(flat, cols, k, device=device) as eng:
+            eng.set_tip_states(np.tile(rng.integers(0, k, size=flat.n_tips), (cols, 1)))
+            pis = rng.dirichlet(np.ones(k) * 5, size=cols)
+
+            def grad():
+                eng.set_models([(dict(kind=0, pi=pis[c]), (5.5 + 1e-8 * c, 0.0, 1.0)) for c in range(cols)])
+                eng.bottom_up(True)
+            ms = timed(grad, 200, eng)
+            sb = schedule_bytes(flat, k, cols)
+            b = (sb['bottom_up'] + sb['prep']) * cols
+            out['cfg5_gradient'] = dict(workload='BASELINE config 5 shape: HIV1C tree ({} tips), k=12, one L-BFGS-B '
+                                                 'finite-difference gradient = {} likelihoods in one batched bottom-up '
+                                                 'sweep (model upload included)'.format(flat.n_tips, cols),
+                                        ms_per_gradient=ms, value=flat.n_nodes * k * cols / (ms * 1e-3),
+                                        unit='node*state*char/s',
+                                        roofline=dict(bound='hbm (latency-bound: the tree has {} height levels)'
+                                                      .format(flat.n_bu_levels), model_bytes=b,
+                                                      achieved=b / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit='GB/s',
+                                                      frac=b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS))
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 def main():
     args = parse_args()
+    if 'RANK' not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node {} '
-                             '--master-addr 127.0.0.1 --master-port P bench.py --gpus {} ...'.format(args.gpus, args.gpus))
         raise SystemExit('--gpus {} but WORLD_SIZE={}'.format(args.gpus, world))
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 
     levels, k, cpg = WORKLOADS[args.workload]
     if args.chars_per_gpu:
         cpg = args.chars_per_gpu
     model = 'JC' if args.workload == 'cfg2' else 'F81'
+    profiled = under_profiler()
 
     # CPU baseline first, while this process has not touched the GPU yet (its worker processes are started from a
-    # process without a GPU context)
+    # process without a GPU context); never under a profiler, whose preloaded library has already initialised the GPU
     cpu = None
-    if not args.no_cpu_baseline and world == 1:
+    if not args.no_cpu_baseline and world == 1 and not profiled:
         cl = args.cpu_baseline_levels
         if cl is None:
             cl = min(levels, 17 if k >= 32 else 16)  # 10-20 s of single-thread numpy on the GPU box
         cpu = cpu_baseline(k, cl, model, args.cpu_baseline_cores)
 
-    import torch
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        if os.environ.get('BENCH_ALL_RANKS_ON_GPU0') is None:
-            torch.cuda.set_device(local_rank)
-        backend = os.environ.get('BENCH_DIST_BACKEND', 'nccl')  # 'gloo' only for dry runs of the N > 1 path
-        if backend == 'nccl':
-            dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
-        else:
-            dist.init_process_group(backend=backend)
+    from pastml_amd import hip, synthetic, sharding
 
-    from pastml_amd import hip, synthetic
-    from pastml_amd.sharding import shard_characters, allreduce_sum
-
+    all_on_gpu0 = os.environ.get('BENCH_ALL_RANKS_ON_GPU0') is not None   # dry runs of N > 1 on a one-GPU box (gloo)
+    gpu_index = 0 if all_on_gpu0 else local_rank
     flat = synthetic.balanced_forest(levels)
     N = flat.n_nodes
-    chars = list(shard_characters(cpg * world, rank, world))  # contiguous block of characters per rank
+    chars = list(sharding.shard_characters(cpg * world, rank, world))  # contiguous block of characters per rank
 
-    eng = hip.Engine(flat, cpg, k, device=local_rank if os.environ.get('BENCH_ALL_RANKS_ON_GPU0') is None else 0)
+    eng = hip.Engine(flat, cpg, k, device=gpu_index)
     if model == 'JC':
         specs = [dict(kind=0, pi=np.ones(k) / k) for _ in chars]
     else:
         specs = [dict(kind=0, pi=synthetic.f81_frequencies(k, c)) for c in chars]
     eng.set_models([(s, (1.0, 0.0, 1.0)) for s in specs])
-    eng.set_tip_states(np.stack([synthetic.tip_states(flat.n_tips, k, c) for c in chars]))
+    tip_states = np.stack([synthetic.tip_states(flat.n_tips, k, c) for c in chars])
+    eng.set_tip_states(tip_states)
     eng.sync()
-
-    gpu_index = local_rank if os.environ.get('BENCH_ALL_RANKS_ON_GPU0') is None else 0
-    dev = 'cuda:{}'.format(gpu_index)
-    torch.zeros(1, device=dev)  # initialise torch's context on this GPU before timing
-    red_dev = dev if (dist is None or dist.get_backend() == 'nccl') else 'cpu'
+    # the communicator lives on the engine's own context: the all-reduce is stream-ordered behind the sweep
+    comm = sharding.init(device=gpu_index, engine=eng)
 
     def step():
         # model parameters are re-sent every step, as an optimiser iteration would: forces the per-branch
@@ -182,15 +410,14 @@ def main():
         lnl = eng.bottom_up(True)                       # inputs resident in HBM; returns ln L per character
         eng.top_down_marginals(posterior=False, lh=False)  # TD + marginals + posteriors, outputs stay in HBM
         # the one collective of the path: summed log-likelihood over the ranks (RCCL all-reduce of 8 bytes)
-        total = allreduce_sum(float(lnl.sum()), device=red_dev)
+        total = comm.allreduce_loglik(lnl)
         return total, lnl
 
     def fence():
         eng.sync()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+        hip.device_sync(gpu_index)
+        comm.barrier()
+        hip.device_sync(gpu_index)
 
     for _ in range(args.warmup):
         step()
@@ -199,39 +426,57 @@ def main():
         eng.profile_read(w, reset=True)
     fence()
     t0 = time.perf_counter()
-    total = None
+    total = lnl = None
     for _ in range(args.steps):
         total, lnl = step()
     fence()
     dt = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    dt = float(comm.allreduce([dt], op='max')[0])
 
     bu_ms, bu_launches = eng.profile_read(0)
     td_ms, td_launches = eng.profile_read(1)
     prep_ms, prep_launches = eng.profile_read(2)
+    eng.profile_enable(False)
     held, free = eng.memory()
+    validation = None
+    if not args.no_validate:
+        validation = validate_columns(eng, flat, k, tip_states, lnl)
 
     if rank == 0:
         units_per_step = N * k * cpg * world
         value = units_per_step * args.steps / dt
-        # dominant kernel: the top-down + marginals level kernel (td_f81_kernel): every non-root node is finished once
-        td_bytes_per_step = BYTES_TD * (N - 1) * k * cpg
-        bu_bytes_per_step = BYTES_BU * (N - 1) * k * cpg
-        td_gbs = td_bytes_per_step * args.steps / (td_ms * 1e-3) / 1e9 if td_ms > 0 else None
-        bu_gbs = bu_bytes_per_step * args.steps / (bu_ms * 1e-3) / 1e9 if bu_ms > 0 else None
-        # HBM bytes per launch from the committed PMC passes (profiles/traffic.json holds bytes per step of the same
-        # workload; null if the workload's shape was changed on the command line or no profile is committed)
-        traffic = None
+        # dominant kernel: the top-down + marginals level kernel (td_f81_kernel).  achieved = compulsory bytes of this
+        # schedule (schedule_bytes: DESIGN.md 4b) / the kernel's own time
+        sb = schedule_bytes(flat, k, cpg)
+        per_step = {w: sb[w] * cpg for w in ('bottom_up', 'top_down', 'prep')}
+        def rate(b, ms):
+            return b * args.steps / (ms * 1e-3) / 1e9 if ms > 0 else None
+        td_gbs, bu_gbs, prep_gbs = rate(per_step['top_down'], td_ms), rate(per_step['bottom_up'], bu_ms), \
+            rate(per_step['prep'], prep_ms)
+        # HBM bytes per launch from the committed PMC passes: only if they were measured on these kernel sources and
+        # this workload shape; bench asserts that counters and model agree
+        traffic = traffic_note = None
         tpath = os.path.join(REPO, 'profiles', 'traffic.json')
-        if os.path.exists(tpath) and cpg == WORKLOADS[args.workload][2] and td_launches > 0:
+        if os.path.exists(tpath) and td_launches > 0:
             try:
-                per_step = json.load(open(tpath)).get(args.workload, {}).get('td_bytes_per_step')
-                traffic = per_step / (td_launches / args.steps) if per_step else None
-            except Exception:
-                traffic = None
+                tj = json.load(open(tpath))
+                entry = tj.get(args.workload, {})
+                if entry.get('csrc_sha') != csrc_digest():
+                    traffic_note = 'profiles/traffic.json was measured on other kernel sources ({} != {})'.format(
+                        entry.get('csrc_sha'), csrc_digest())
+                elif entry.get('chars_per_gpu') != cpg:
+                    traffic_note = 'profiles/traffic.json is for {} characters per GPU'.format(entry.get('chars_per_gpu'))
+                else:
+                    traffic = entry['td_bytes_per_step'] / (td_launches / args.steps)
+                    ratio = entry['td_bytes_per_step'] / per_step['top_down']
+                    traffic_note = 'PMC bytes / model bytes = {:.3f}'.format(ratio)
+                    if not 0.85 <= ratio <= 1.15:
+                        raise SystemExit('HBM counters ({:.3g} B per step) and the byte model ({:.3g}) of td_f81_kernel '
+                                         'disagree by more than 15 %'.format(entry['td_bytes_per_step'],
+                                                                             per_step['top_down']))
+            except (OSError, ValueError, KeyError) as e:
+                traffic_note = 'profiles/traffic.json unreadable: {}'.format(e)
+        avg_launch_s = td_ms / max(1, td_launches) * 1e-3
         out = {
             'metric': 'ACR nodes*states*chars/sec (full marginal pass: P(t) + bottom-up + top-down + posteriors)',
             'value': value,
@@ -252,41 +497,62 @@ def main():
                                            flat.n_tips, N, k, model, cpg, cpg * world),
                        'tips': int(flat.n_tips), 'nodes': int(N), 'states': k, 'chars_per_gpu': cpg,
                        'chars_total': cpg * world, 'substitution_model': model,
-                       'sharding': 'characters over ranks, no data-path collective; 1 all-reduce (8 B) per step'},
+                       'sharding': 'characters over ranks, no data-path collective; 1 all-reduce (8 B) per step',
+                       'collective': comm.name},
             'loglik_sum': total,
             'roofline': {
                 'bound': 'hbm', 'kernel': 'td_f81_kernel (top-down + marginals + posteriors, one launch per depth level)',
                 'achieved': td_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': (td_gbs / HBM_PEAK_GBS) if td_gbs else None,
-                'traffic': traffic,
-                # real HBM rate of the kernel = PMC bytes per launch / measured launch time (the cherry-fused schedule
-                # moves fewer bytes than the algorithmic 32 B/unit model, hence achieved can exceed the real rate)
-                'traffic_gbs': (traffic / (td_ms / max(1, td_launches) * 1e-3) / 1e9) if traffic and td_ms > 0 else None,
-                'traffic_frac': (traffic / (td_ms / max(1, td_launches) * 1e-3) / 1e9 / HBM_PEAK_GBS)
-                if traffic and td_ms > 0 else None,
-                'algorithmic_bytes_per_launch': td_bytes_per_step / max(1, td_launches / args.steps),
+                'traffic': traffic, 'traffic_note': traffic_note,
+                'traffic_gbs': (traffic / avg_launch_s / 1e9) if traffic and td_ms > 0 else None,
+                'model_bytes_per_launch': per_step['top_down'] / max(1, td_launches / args.steps),
+                'model_bytes_per_unit': sb['per_unit']['top_down'],
                 'avg_launch_ms': td_ms / max(1, td_launches),
                 'launches': td_launches,
-                'bytes_per_unit': BYTES_TD,
+                'byte_model': 'compulsory bytes of this schedule (DESIGN.md 4b): posterior written for every node, '
+                              'parent posterior + stored child vector read for stored (non-cherry) internal nodes only, '
+                              'per-node scalars; tips are 8-byte masks, cherries live in registers, TD vectors are never stored',
+                'reference_schedule_bytes_avoided': (REFERENCE_SCHEDULE_BYTES['top_down'] * N * k * cpg
+                                                     - per_step['top_down']),
             },
             'roofline_bottom_up': {
                 'kernel': 'bu_f81_kernel (bottom-up, one launch per height level)', 'achieved': bu_gbs,
                 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': (bu_gbs / HBM_PEAK_GBS) if bu_gbs else None,
-                'avg_launch_ms': bu_ms / max(1, bu_launches), 'launches': bu_launches, 'bytes_per_unit': BYTES_BU,
+                'avg_launch_ms': bu_ms / max(1, bu_launches), 'launches': bu_launches,
+                'model_bytes_per_unit': sb['per_unit']['bottom_up'],
+                'reference_schedule_bytes_avoided': (REFERENCE_SCHEDULE_BYTES['bottom_up'] * N * k * cpg
+                                                     - per_step['bottom_up']),
+            },
+            'roofline_step': {
+                'what': 'whole step: all kernels, launch gaps and host round trips of one marginal pass',
+                'model_bytes': sum(per_step.values()),
+                'achieved': sum(per_step.values()) * args.steps / dt / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': sum(per_step.values()) * args.steps / dt / 1e9 / HBM_PEAK_GBS,
             },
             'kernel_ms_per_step': {'bottom_up': bu_ms / args.steps, 'top_down': td_ms / args.steps,
                                    'prep': prep_ms / args.steps},
+            'prep_gbs': prep_gbs,
             'device_memory_gb': held / 1e9,
+            'validation': validation,
         }
         if cpu is not None:
             out['cpu_baseline'] = cpu
             out['speedup_vs_cpu_baseline'] = value / cpu['value']
             out['speedup_vs_cpu_baseline_single_core'] = value / cpu['single_core_value']
-        print(json.dumps(out))
+        elif profiled and world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = None
+            out['cpu_baseline_note'] = 'skipped: a profiler is attached (no worker processes from a GPU-initialised process)'
+    comm.barrier()
+    sharding.shutdown()
     eng.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if rank == 0:
+        if world == 1 and not args.no_secondary and args.workload == 'cfg4':
+            try:
+                out['secondary'] = secondary_measurements(gpu_index)
+            except Exception as e:  # the headline line must survive a failure of the extras
+                out['secondary'] = {'error': repr(e)}
+        print(json.dumps(out))
 
 
 if __name__ == '__main__':

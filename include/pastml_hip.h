@@ -70,8 +70,10 @@ int pml_ctx_sync(pml_ctx* ctx);
  * posteriors of the level above (TD o BU = posterior * sum / pi) and does not write the top-down vectors themselves;
  * with this option it stores them too.  pml_download(PML_BUF_TD / PML_BUF_TD_SF) switches it on and repeats the sweep
  * when they are missing.  The matrix models (HKY, eigen) always store them.
+ * PML_OPT_EIGEN_FUSED (default 1, may be changed at any time): eigen-decomposed models with 16 <= k <= 32 run the fused
+ * matrix-core sweeps (P(t) built and consumed in registers); 0 selects the sweeps that read materialised P(t) from HBM.
  */
-enum { PML_OPT_CHERRY_FUSION = 1, PML_OPT_KEEP_TD = 2 };
+enum { PML_OPT_CHERRY_FUSION = 1, PML_OPT_KEEP_TD = 2, PML_OPT_EIGEN_FUSED = 3 };
 int pml_ctx_set_option(pml_ctx* ctx, int option, int value);
 /* bytes of device memory currently held by the ctx / free on its device */
 int pml_ctx_memory(pml_ctx* ctx, uint64_t* held, uint64_t* device_free);
@@ -172,8 +174,41 @@ int pml_select_states(pml_ctx* ctx, int method, int force_joint, const uint64_t*
  */
 int pml_marginal_counts(pml_ctx* ctx, int32_t col, int32_t n_repetitions, uint64_t seed, double* counts_out);
 
+/* ---- multi-GPU (one process per GPU) ----------------------------------------------------------------------------------- */
+/*
+ * The characters of a run are independent (pastml/acr.py:213-231 hands them to a pool one by one, each with its own
+ * model instance), so they shard over the GPUs of a node with the tree replicated and no exchange on the data path.
+ * The one collective is the sum of the per-rank log-likelihoods (what a caller optimising shared parameters over all
+ * characters, or reporting the total, needs): an all-reduce of 8 bytes over RCCL / xGMI on the ctx's own stream.
+ * librccl is opened with dlopen on first use.  Rank 0 makes the id with pml_comm_unique_id and the host hands it to the
+ * other ranks (file, socket, environment: 128 opaque bytes); every rank then calls pml_comm_init on its ctx (collective).
+ * world == 1 needs neither an id nor librccl.  The communicator survives pml_tree_upload and dies with the ctx.
+ */
+#define PML_COMM_ID_BYTES 128
+enum { PML_COMM_SUM = 0, PML_COMM_MAX = 1 };
+int pml_comm_unique_id(unsigned char* id_out /* [PML_COMM_ID_BYTES] */);
+int pml_comm_init(pml_ctx* ctx, int rank, int world, const unsigned char* id /* [PML_COMM_ID_BYTES] */);
+int pml_comm_destroy(pml_ctx* ctx);
+/* out[i] = sum / max over the ranks of in[i]; in and out are host arrays of count doubles (may alias); collective */
+int pml_comm_allreduce(pml_ctx* ctx, const double* in, double* out, int32_t count, int op);
+/*
+ * total_out[0] = sum over all ranks of (loglik[0] + ... + loglik[n_cols-1]), loglik being this rank's pml_bottom_up
+ * output: the forest-wide, all-character log-likelihood (the sum pastml/ml.py:112-121 forms per character, added up
+ * over the characters of pastml/acr.py:226-231).  Collective.
+ */
+int pml_allreduce_loglik(pml_ctx* ctx, const double* loglik, int32_t n_cols, double* total_out);
+/* hipDeviceSynchronize on the given device (benchmarks bracket their timed region with it) */
+int pml_device_sync(int device);
+
 /* ---- inspection ------------------------------------------------------------------------------------------------------ */
 int pml_download(pml_ctx* ctx, int what, int32_t col, void* out);
+/*
+ * Rows first, first + stride, ... (count of them) of one column's buffer: what a caller that reports a sample of the
+ * nodes needs (the marginal-probability table of named nodes, pastml/ml.py:486-502; validation of full-size runs)
+ * without moving n_nodes * k doubles over PCIe.  what: PML_BUF_POSTERIOR (double[count][k]), PML_BUF_LH_SUM,
+ * PML_BUF_LH_SF (double[count]) or PML_BUF_JOINT_STATE (int32[count]).
+ */
+int pml_download_strided(pml_ctx* ctx, int what, int32_t col, int32_t first, int32_t stride, int32_t count, void* out);
 /* HIP-event timer on the ctx's stream */
 int pml_timer_start(pml_ctx* ctx);
 int pml_timer_stop(pml_ctx* ctx, float* milliseconds);

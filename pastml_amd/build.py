@@ -9,7 +9,7 @@ LIB = os.path.join(HERE, 'libpastml_hip.so')
 SOURCES = ['pml_api.hip']
 HEADERS = ['pml_device.h', 'pml_kernels_f81.h', 'pml_kernels_misc.h', 'pml_kernels_matrix.h', 'pml_kernels_pij.h',
            'pml_kernels_counts.h',
-           'pml_kernels_eigen_mfma.h',
+           'pml_kernels_eigen_mfma.h', 'pml_comm.h',
            os.path.join('..', '..', 'include', 'pastml_hip.h')]
 
 
@@ -30,7 +30,7 @@ def is_stale():
 def build(force=False, verbose=False):
     if not force and not is_stale():
         return LIB
-    cmd = [find_hipcc(), '-O3', '--offload-arch=gfx950', '-std=c++17', '-ffp-contract=on', '-shared', '-fPIC', '-o', LIB] + SOURCES
+    cmd = [find_hipcc(), '-O3', '--offload-arch=gfx950', '-std=c++17', '-ffp-contract=on', '-shared', '-fPIC', '-o', LIB] + SOURCES + ['-ldl']
     if verbose:
         print(' '.join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)

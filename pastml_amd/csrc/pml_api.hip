@@ -16,6 +16,7 @@
 
 #include "pml_kernels_eigen_mfma.h"
 #include "pml_kernels_counts.h"
+#include "pml_comm.h"
 
 #define PML_VERSION 100
 
@@ -122,6 +123,8 @@ struct pml_ctx {
     bool td_valid = false, js_valid = false;
     bool keep_td = false;      // PML_OPT_KEEP_TD (or a pml_download of the TD vectors asked for them)
     bool td_vec_valid = false; // the TD vectors of the last top-down sweep are in d_td
+    bool eig_fused_opt = true; // PML_OPT_EIGEN_FUSED
+    PmlComm* comm = nullptr;   // RCCL communicator attached by pml_comm_init (survives tree uploads)
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -237,7 +240,7 @@ static PmlState state_of(const pml_ctx* c) {
 // consumed in registers.  PASTML_HIP_NO_MFMA / PASTML_HIP_NO_EIGEN_FUSED fall back to the materialised-P kernels.
 static bool eigen_fused(const pml_ctx* c) {
     static const bool off = getenv("PASTML_HIP_NO_MFMA") || getenv("PASTML_HIP_NO_EIGEN_FUSED");
-    return !off && c->kind == PML_MODEL_EIGEN && c->k >= 16 && c->k <= 32 && c->W == 1 &&
+    return !off && c->eig_fused_opt && c->kind == PML_MODEL_EIGEN && c->k >= 16 && c->k <= 32 && c->W == 1 &&
            c->ks == 4 * ((c->k + 3) / 4);
 }
 
@@ -606,6 +609,7 @@ int pml_ctx_destroy(pml_ctx* ctx) {
     if (!ctx) return PML_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    (void)pml_comm_destroy(ctx);
     free_all(ctx);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -626,6 +630,18 @@ int pml_ctx_set_option(pml_ctx* ctx, int option, int value) {
     if (option == PML_OPT_KEEP_TD) {
         if ((value != 0) != ctx->keep_td) drop_graph(ctx->td_graph);
         ctx->keep_td = value != 0;
+        return PML_OK;
+    }
+    if (option == PML_OPT_EIGEN_FUSED) {
+        if ((value != 0) != ctx->eig_fused_opt) {
+            drop_graph(ctx->bu_graph[0]);
+            drop_graph(ctx->bu_graph[1]);
+            drop_graph(ctx->td_graph);
+            ctx->prep_dirty = true;
+            ctx->bu_mode = -1;
+            ctx->td_valid = ctx->js_valid = false;
+        }
+        ctx->eig_fused_opt = value != 0;
         return PML_OK;
     }
     return fail(PML_ERR_INVALID, "unknown option %d", option);
@@ -723,9 +739,13 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
     hipEvent_t e0 = ctx->ev0, e1 = ctx->ev1, p0 = ctx->pev[0], p1 = ctx->pev[1];
     int device = ctx->device;
     const bool profile = ctx->profile;
-    const bool fuse = ctx->fuse;
+    const bool fuse = ctx->fuse, keep_td = ctx->keep_td, eig_fused_opt = ctx->eig_fused_opt;
+    PmlComm* comm = ctx->comm;
     *ctx = pml_ctx();
     ctx->fuse = fuse;
+    ctx->keep_td = keep_td;
+    ctx->eig_fused_opt = eig_fused_opt;
+    ctx->comm = comm;
     ctx->stream = stream;
     ctx->ev0 = e0;
     ctx->ev1 = e1;
@@ -1549,9 +1569,15 @@ static int run_top_down(pml_ctx* ctx) {
 // F81 family: the sweep did not write its TD vectors; repeat it with the stores switched on (same arithmetic)
 static int materialize_td(pml_ctx* ctx) {
     if (ctx->td_vec_valid) return PML_OK;
+    // one sweep with the stores on; the option itself stays as the caller set it (a pooled ctx must not keep paying
+    // for TD stores because somebody once looked at them)
+    const bool was = ctx->keep_td;
     drop_graph(ctx->td_graph);
     ctx->keep_td = true;
-    PML_TRY(run_top_down(ctx));
+    const int status = run_top_down(ctx);
+    ctx->keep_td = was;
+    if (!was) drop_graph(ctx->td_graph);
+    PML_TRY(status);
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return PML_OK;
 }
@@ -1831,6 +1857,155 @@ int pml_download(pml_ctx* ctx, int what, int32_t col, void* out) {
         default:
             return fail(PML_ERR_INVALID, "unknown buffer id %d", what);
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// multi-GPU: one collective, the sum of the per-rank log-likelihoods
+int pml_comm_unique_id(unsigned char* id_out) {
+    if (!id_out) return fail(PML_ERR_INVALID, "id_out is NULL");
+    PmlRccl* r = pml_rccl();
+    if (!r->handle) return fail(PML_ERR_UNSUPPORTED, "librccl could not be loaded: %s", r->error.c_str());
+    ncclUniqueId id;
+    const ncclResult_t e = r->GetUniqueId(&id);
+    if (e != ncclSuccess) return fail(PML_ERR_HIP, "ncclGetUniqueId failed: %s", r->GetErrorString(e));
+    static_assert(sizeof(id.internal) == PML_COMM_ID_BYTES, "unique id size");
+    memcpy(id_out, id.internal, PML_COMM_ID_BYTES);
+    return PML_OK;
+}
+
+int pml_comm_init(pml_ctx* ctx, int rank, int world, const unsigned char* id) {
+    if (!ctx) return fail(PML_ERR_INVALID, "ctx is NULL");
+    if (world < 1 || rank < 0 || rank >= world) return fail(PML_ERR_INVALID, "rank %d out of 0..%d", rank, world - 1);
+    if (ctx->comm) return fail(PML_ERR_INVALID, "the ctx already has a communicator");
+    HIP_TRY(hipSetDevice(ctx->device));
+    PmlComm* c = new PmlComm();
+    c->rank = rank;
+    c->world = world;
+    // PASTML_HIP_COMM_FORCE_RCCL: a world of one still goes through librccl (exercises the whole path on one GPU)
+    if (world > 1 || getenv("PASTML_HIP_COMM_FORCE_RCCL")) {
+        if (!id) {
+            delete c;
+            return fail(PML_ERR_INVALID, "id is NULL");
+        }
+        PmlRccl* r = pml_rccl();
+        if (!r->handle) {
+            delete c;
+            return fail(PML_ERR_UNSUPPORTED, "librccl could not be loaded: %s", r->error.c_str());
+        }
+        ncclUniqueId uid;
+        memcpy(uid.internal, id, PML_COMM_ID_BYTES);
+        const ncclResult_t e = r->CommInitRank(&c->comm, world, uid, rank);
+        if (e != ncclSuccess) {
+            delete c;
+            return fail(PML_ERR_HIP, "ncclCommInitRank failed: %s", r->GetErrorString(e));
+        }
+    }
+    ctx->comm = c;
+    return PML_OK;
+}
+
+int pml_comm_destroy(pml_ctx* ctx) {
+    if (!ctx || !ctx->comm) return PML_OK;
+    PmlComm* c = ctx->comm;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (c->comm) (void)pml_rccl()->CommDestroy(c->comm);
+    if (c->d_buf) (void)hipFree(c->d_buf);
+    if (c->h_buf) (void)hipHostFree(c->h_buf);
+    delete c;
+    ctx->comm = nullptr;
+    return PML_OK;
+}
+
+int pml_comm_allreduce(pml_ctx* ctx, const double* in, double* out, int32_t count, int op) {
+    if (!ctx || !ctx->comm) return fail(PML_ERR_INVALID, "no communicator: call pml_comm_init first");
+    if (!in || !out || count <= 0) return fail(PML_ERR_INVALID, "bad in / out / count");
+    if (op != PML_COMM_SUM && op != PML_COMM_MAX) return fail(PML_ERR_INVALID, "op must be PML_COMM_SUM or PML_COMM_MAX");
+    PmlComm* c = ctx->comm;
+    if (!c->comm) {
+        if (out != in) memmove(out, in, sizeof(double) * count);
+        return PML_OK;
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (c->cap < (size_t)count) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (c->d_buf) (void)hipFree(c->d_buf);
+        if (c->h_buf) (void)hipHostFree(c->h_buf);
+        c->d_buf = c->h_buf = nullptr;
+        c->cap = 0;
+        const size_t cap = std::max<size_t>(64, (size_t)count);
+        HIP_TRY(hipMalloc((void**)&c->d_buf, cap * sizeof(double)));
+        HIP_TRY(hipHostMalloc((void**)&c->h_buf, cap * sizeof(double)));
+        c->cap = cap;
+    }
+    memcpy(c->h_buf, in, sizeof(double) * count);
+    HIP_TRY(hipMemcpyAsync(c->d_buf, c->h_buf, sizeof(double) * count, hipMemcpyHostToDevice, ctx->stream));
+    PmlRccl* r = pml_rccl();
+    const ncclResult_t e = r->AllReduce(c->d_buf, c->d_buf, (size_t)count, ncclDouble, op == PML_COMM_SUM ? ncclSum : ncclMax,
+                                        c->comm, ctx->stream);
+    if (e != ncclSuccess) return fail(PML_ERR_HIP, "ncclAllReduce failed: %s", r->GetErrorString(e));
+    HIP_TRY(hipMemcpyAsync(c->h_buf, c->d_buf, sizeof(double) * count, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    memcpy(out, c->h_buf, sizeof(double) * count);
+    return PML_OK;
+}
+
+int pml_allreduce_loglik(pml_ctx* ctx, const double* loglik, int32_t n_cols, double* total_out) {
+    if (!loglik || !total_out || n_cols <= 0) return fail(PML_ERR_INVALID, "bad loglik / total_out / n_cols");
+    // the local sum in column order (as pastml/acr.py would add the characters' results up), then one 8-byte all-reduce
+    double local = 0.0;
+    for (int i = 0; i < n_cols; ++i) local += loglik[i];
+    return pml_comm_allreduce(ctx, &local, total_out, 1, PML_COMM_SUM);
+}
+
+int pml_device_sync(int device) {
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipDeviceSynchronize());
+    return PML_OK;
+}
+
+int pml_download_strided(pml_ctx* ctx, int what, int32_t col, int32_t first, int32_t stride, int32_t count, void* out) {
+    PML_TRY(require_model(ctx));
+    if (col < 0 || col >= ctx->C || !out) return fail(PML_ERR_INVALID, "bad column / output");
+    if (first < 0 || stride < 1 || count < 1 || (long long)first + (long long)(count - 1) * stride >= ctx->N)
+        return fail(PML_ERR_INVALID, "rows first=%d stride=%d count=%d leave 0..%d", first, stride, count, ctx->N - 1);
+    const size_t N = ctx->N;
+    const void* src = nullptr;
+    size_t row_bytes = 0, src_row_bytes = 0;
+    switch (what) {
+        case PML_BUF_POSTERIOR:
+            if (!ctx->td_valid) return fail(PML_ERR_INVALID, "no valid top-down sweep");
+            src = ctx->d_post + ((size_t)col * N + first) * ctx->ks;
+            row_bytes = ctx->k * sizeof(double);
+            src_row_bytes = ctx->ks * sizeof(double);
+            break;
+        case PML_BUF_LH_SUM:
+            if (!ctx->td_valid) return fail(PML_ERR_INVALID, "no valid top-down sweep");
+            src = ctx->d_lhsum + (size_t)col * N + first;
+            row_bytes = src_row_bytes = sizeof(double);
+            break;
+        case PML_BUF_LH_SF:
+            if (!ctx->td_valid) return fail(PML_ERR_INVALID, "no valid top-down sweep");
+            src = ctx->d_lhe + (size_t)col * N + first;
+            row_bytes = src_row_bytes = sizeof(i64);
+            break;
+        case PML_BUF_JOINT_STATE:
+            if (!ctx->js_valid) return fail(PML_ERR_INVALID, "no valid joint back-trace");
+            src = ctx->d_js + (size_t)col * N + first;
+            row_bytes = src_row_bytes = sizeof(int);
+            break;
+        default:
+            return fail(PML_ERR_INVALID, "pml_download_strided serves PML_BUF_POSTERIOR, _LH_SUM, _LH_SF, _JOINT_STATE");
+    }
+    HIP_TRY(hipMemcpy2DAsync(out, row_bytes, src, src_row_bytes * stride, row_bytes, count, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (what == PML_BUF_LH_SF) {  // base-2 exponents -> the reference's base-10 scale, in place (same width)
+        const double l2 = std::log10(2.0);
+        i64* e = (i64*)out;
+        double* o = (double*)out;
+        for (int i = 0; i < count; ++i) o[i] = -(double)e[i] * l2;
+    }
+    return PML_OK;
 }
 
 int pml_profile_enable(pml_ctx* ctx, int on) {

@@ -5,6 +5,7 @@ context (= one tree + one batch of columns sharing k and the model kind).
 There is no CPU fallback: if the shared library is missing or no MI355X is visible, every entry point raises
 :class:`HipUnavailableError`.
 """
+import collections
 import ctypes
 import os
 import threading
@@ -23,6 +24,9 @@ BUF_BU, BUF_BU_SF, BUF_TD, BUF_TD_SF, BUF_POSTERIOR, BUF_LH_SUM, BUF_LH_SF, BUF_
 MAX_STATES = 256
 OPT_CHERRY_FUSION = 1
 OPT_KEEP_TD = 2
+OPT_EIGEN_FUSED = 3
+COMM_ID_BYTES = 128
+COMM_SUM, COMM_MAX = 0, 1
 
 
 class HipUnavailableError(RuntimeError):
@@ -79,6 +83,14 @@ SIGNATURES = {
     'pml_select_states': [_ctx_p, ctypes.c_int, ctypes.c_int, _c_uint64_p, _c_uint64_p, _c_int32_p],
     'pml_marginal_counts': [_ctx_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_uint64, _c_double_p],
     'pml_download': [_ctx_p, ctypes.c_int, ctypes.c_int32, ctypes.c_void_p],
+    'pml_comm_unique_id': [ctypes.POINTER(ctypes.c_ubyte)],
+    'pml_comm_init': [_ctx_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_ubyte)],
+    'pml_comm_destroy': [_ctx_p],
+    'pml_comm_allreduce': [_ctx_p, _c_double_p, _c_double_p, ctypes.c_int32, ctypes.c_int],
+    'pml_allreduce_loglik': [_ctx_p, _c_double_p, ctypes.c_int32, _c_double_p],
+    'pml_device_sync': [ctypes.c_int],
+    'pml_download_strided': [_ctx_p, ctypes.c_int, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                             ctypes.c_void_p],
     'pml_timer_start': [_ctx_p],
     'pml_timer_stop': [_ctx_p, ctypes.POINTER(ctypes.c_float)],
     'pml_profile_enable': [_ctx_p, ctypes.c_int],
@@ -163,13 +175,18 @@ def unpack_masks(words, k):
 # them (device allocations, tree upload, descriptor tables, captured graphs) is a fifth of the wall time of a binary
 # character on a 3 600-tip tree.  Released engines of small problems are kept, keyed by the forest's arrays, the number
 # of columns, k and the device, and handed out again with their per-analysis state reset.
-_POOL = {}
+_POOL = collections.OrderedDict()   # key -> list of idle engines; least recently used key first
 _POOL_LOCK = threading.Lock()
 _POOL_MAX_BYTES = 1 << 30   # an engine holding more device memory than this is destroyed on release
 _POOL_MAX_ENGINES = 16
 
 
 def _forest_key(flat):
+    """
+    Identity of the forest's arrays.  The digest is cached on the FlatForest together with the arrays' write flags
+    switched off, so an in-place edit of a pooled forest raises in numpy instead of silently reusing a ctx that
+    holds the old tree.
+    """
     key = getattr(flat, '_pool_key', None)
     if key is None:
         import hashlib
@@ -179,7 +196,10 @@ def _forest_key(flat):
         key = (flat.n_nodes, h.hexdigest())
         try:
             flat._pool_key = key
-        except AttributeError:
+            for a in (flat.parent, flat.first_child, flat.n_children, flat.dist):
+                if isinstance(a, np.ndarray):
+                    a.setflags(write=False)
+        except (AttributeError, ValueError):
             pass
     return key
 
@@ -191,18 +211,25 @@ def acquire_engine(flat, n_cols, k, device=None):
     key = (_forest_key(flat), n_cols, k, dev)
     with _POOL_LOCK:
         free = _POOL.get(key)
+        eng = None
         if free:
             eng = free.pop()
-            eng.flat = flat
-            eng.set_initial_masks(None)
-            return eng
+            if free:
+                _POOL.move_to_end(key)
+            else:
+                del _POOL[key]
+    if eng is not None:
+        eng.flat = flat
+        eng.set_initial_masks(None)
+        eng.set_option(OPT_KEEP_TD, 0)
+        return eng
     eng = Engine(flat, n_cols, k, device=device)
     eng._pool_key = key
     return eng
 
 
 def release_engine(eng):
-    """Returns an engine of acquire_engine() to the pool (or destroys it: big problems, full pool)."""
+    """Returns an engine of acquire_engine() to the pool; a full pool evicts its least recently used engine."""
     key = getattr(eng, '_pool_key', None)
     if key is None or eng._ctx.value is None:
         eng.close()
@@ -213,12 +240,20 @@ def release_engine(eng):
     except HipError:
         eng.close()
         return
+    if held > _POOL_MAX_BYTES:
+        eng.close()
+        return
+    evicted = []
     with _POOL_LOCK:
-        total = sum(len(v) for v in _POOL.values())
-        if held <= _POOL_MAX_BYTES and total < _POOL_MAX_ENGINES:
-            _POOL.setdefault(key, []).append(eng)
-            return
-    eng.close()
+        _POOL.setdefault(key, []).append(eng)
+        _POOL.move_to_end(key)
+        while sum(len(v) for v in _POOL.values()) > _POOL_MAX_ENGINES:
+            oldest = next(iter(_POOL))
+            evicted.append(_POOL[oldest].pop(0))
+            if not _POOL[oldest]:
+                del _POOL[oldest]
+    for e in evicted:
+        e.close()
 
 
 def drain_engine_pool():
@@ -233,7 +268,69 @@ import atexit  # noqa: E402
 atexit.register(drain_engine_pool)
 
 
-class Engine(object):
+class BareContext(object):
+    """A device context without a tree: stream, options, communicator (what Engine builds on)."""
+
+    def __init__(self, device=None):
+        lib = load_library()
+        if device_count() < 1:
+            raise HipUnavailableError('no HIP device visible: the likelihood path needs an MI355X (gfx950)')
+        self._lib = lib
+        self._ctx = _ctx_p()
+        self.device = default_device() if device is None else device
+        _check(lib.pml_ctx_create(self.device, ctypes.byref(self._ctx)))
+
+    def close(self):
+        if getattr(self, '_ctx', None) is not None and self._ctx.value is not None:
+            self._lib.pml_ctx_destroy(self._ctx)
+            self._ctx = _ctx_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def sync(self):
+        _check(self._lib.pml_ctx_sync(self._ctx))
+
+    def set_option(self, option, value):
+        _check(self._lib.pml_ctx_set_option(self._ctx, option, 1 if value else 0))
+
+    def comm_init(self, rank, world, unique_id=None):
+        """Attaches a communicator (RCCL for world > 1; unique_id: the 128 bytes of rank 0's comm_unique_id())."""
+        buf = None
+        if unique_id is not None:
+            if len(unique_id) != COMM_ID_BYTES:
+                raise ValueError('unique_id must be {} bytes'.format(COMM_ID_BYTES))
+            buf = (ctypes.c_ubyte * COMM_ID_BYTES).from_buffer_copy(bytes(unique_id))
+        _check(self._lib.pml_comm_init(self._ctx, rank, world, buf))
+
+    def comm_destroy(self):
+        _check(self._lib.pml_comm_destroy(self._ctx))
+
+    def allreduce(self, values, op=COMM_SUM):
+        """Sum (or max) over the ranks of a float array; returns a new array."""
+        a = _as(np.atleast_1d(values), np.float64)
+        out = np.empty_like(a)
+        _check(self._lib.pml_comm_allreduce(self._ctx, _ptr(a, ctypes.c_double), _ptr(out, ctypes.c_double), len(a), op))
+        return out
+
+    def allreduce_loglik(self, loglik):
+        """Sum over all ranks and all of their columns of the log-likelihoods (one 8-byte all-reduce)."""
+        a = _as(np.atleast_1d(loglik), np.float64)
+        total = ctypes.c_double(0)
+        _check(self._lib.pml_allreduce_loglik(self._ctx, _ptr(a, ctypes.c_double), len(a), ctypes.byref(total)))
+        return total.value
+
+
+class Engine(BareContext):
     """
     One device context: a flat forest, ``n_cols`` columns with ``k`` states each, one model kind.
 
@@ -245,17 +342,12 @@ class Engine(object):
     """
 
     def __init__(self, flat, n_cols, k, device=None, cherry_fusion=True, keep_td=False):
-        lib = load_library()
-        if device_count() < 1:
-            raise HipUnavailableError('no HIP device visible: the likelihood path needs an MI355X (gfx950)')
-        self._lib = lib
-        self._ctx = _ctx_p()
-        self.device = default_device() if device is None else device
-        _check(lib.pml_ctx_create(self.device, ctypes.byref(self._ctx)))
+        BareContext.__init__(self, device)
+        lib = self._lib
         if not cherry_fusion:
             _check(lib.pml_ctx_set_option(self._ctx, OPT_CHERRY_FUSION, 0))
         if keep_td:
-            _check(lib.pml_ctx_set_option(self._ctx, OPT_KEEP_TD, 1))
+            _check(lib.pml_ctx_set_option(self._ctx, OPT_KEEP_TD, 1))  # kept across the tree upload below
         self.flat = flat
         self.n_nodes = flat.n_nodes
         self.n_cols = n_cols
@@ -281,26 +373,6 @@ class Engine(object):
             raise
 
     # ------------------------------------------------------------------------------------------------------------------
-    def close(self):
-        if getattr(self, '_ctx', None) is not None and self._ctx.value is not None:
-            self._lib.pml_ctx_destroy(self._ctx)
-            self._ctx = _ctx_p()
-
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
-
-    def __enter__(self):
-        return self
-
-    def __exit__(self, *exc):
-        self.close()
-
-    def sync(self):
-        _check(self._lib.pml_ctx_sync(self._ctx))
-
     def memory(self):
         held, free = ctypes.c_uint64(0), ctypes.c_uint64(0)
         _check(self._lib.pml_ctx_memory(self._ctx, ctypes.byref(held), ctypes.byref(free)))
@@ -464,6 +536,20 @@ class Engine(object):
         _check(self._lib.pml_download(self._ctx, what, col, out.ctypes.data_as(ctypes.c_void_p)))
         return out
 
+    def download_strided(self, what, col=0, first=0, stride=1, count=None):
+        """Rows first, first + stride, ... of one column's posterior / LH_SUM / LH_SF / joint-state buffer."""
+        if count is None:
+            count = (self.n_nodes - first + stride - 1) // stride
+        if what == BUF_POSTERIOR:
+            out = np.empty((count, self.k), dtype=np.float64)
+        elif what == BUF_JOINT_STATE:
+            out = np.empty(count, dtype=np.int32)
+        else:
+            out = np.empty(count, dtype=np.float64)
+        _check(self._lib.pml_download_strided(self._ctx, what, col, first, stride, count,
+                                              out.ctypes.data_as(ctypes.c_void_p)))
+        return out
+
     def profile_enable(self, on=True):
         _check(self._lib.pml_profile_enable(self._ctx, 1 if on else 0))
 
@@ -483,11 +569,30 @@ class Engine(object):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+def comm_unique_id():
+    """128 opaque bytes made by rank 0 and handed to every rank's Engine.comm_init (needs librccl)."""
+    buf = (ctypes.c_ubyte * COMM_ID_BYTES)()
+    _check(load_library().pml_comm_unique_id(buf))
+    return bytes(buf)
+
+
+def device_sync(device=None):
+    _check(load_library().pml_device_sync(default_device() if device is None else device))
+
+
+_PIJ_FOREST = None
+
+
 def pij(model, ts):
-    """P(t) for a Model object and an array of branch lengths, through pml_pij (used by Model.get_Pij_t)."""
+    """P(t) for a Model object and an array of branch lengths, through pml_pij (used by Model.get_Pij_t).  The
+    one-node context it runs on comes from the engine pool: per-branch callers do not pay a context each."""
+    global _PIJ_FOREST
     from pastml_amd.tree import FlatForest
-    k = len(model.states)
-    flat = FlatForest([-1], [0], [1], [0.0], [0])
-    with Engine(flat, 1, k) as eng:
+    if _PIJ_FOREST is None:
+        _PIJ_FOREST = FlatForest([-1], [0], [1], [0.0], [0])
+    eng = acquire_engine(_PIJ_FOREST, 1, len(model.states))
+    try:
         eng.set_models([model])
         return eng.pij(ts)
+    finally:
+        release_engine(eng)

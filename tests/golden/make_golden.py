@@ -689,6 +689,144 @@ def case_eigen_optimised():
 
 CASES['eigen_optimised'] = case_eigen_optimised
 
+
+def case_cfg3_full():
+    """
+    BASELINE config 3 at full size: balanced 262 144-tip tree, JTT (k = 20), one character, joint
+    (Pupko) sweep of the reference (ml.py:82-148 with is_marginal=False) + choose_ancestral_states_joint (:598-622).
+    Stored: lnL_joint, the marginal lnL, and at a strided node sample the joint states, arg-max rows, log10 bottom-up
+    values (bu, sf).  The full joint-state vector is stored as well (one byte per node, compresses well).
+    """
+    import time
+    n_levels = 18
+    flat = synthetic.balanced_forest(n_levels)
+    roots = flat.to_tree_nodes()
+    fs = RForestStats(roots)
+    states = JTT_STATES
+    tips_states = synthetic.tip_states(flat.n_tips, 20, 0)
+    for j, t in enumerate(flat.tips):
+        flat.nodes[t].add_feature('c0', {states[tips_states[j]]})
+    model = RJTT(forest_stats=fs, sf=1.)
+    model.freeze()
+    sys.setrecursionlimit(10000)
+    t0 = time.time()
+    for tree in roots:
+        rml.initialize_allowed_states(tree, 'c0', states)
+    out = dict(forest_stats_arrays(fs))
+    out.update(model_arrays(model))
+    out['loglik'] = sum(rml.get_bottom_up_loglikelihood(tree=t, character='c0', model=model, is_marginal=True,
+                                                        alter=True) for t in roots)
+    t1 = time.time()
+    out['loglik_joint'] = sum(rml.get_bottom_up_loglikelihood(tree=t, character='c0', model=model,
+                                                              is_marginal=False, alter=True) for t in roots)
+    out['reference_seconds_joint_sweep'] = time.time() - t1
+    nodes = flat.nodes
+    for t in roots:
+        rml.choose_ancestral_states_joint(t, 'c0', states, model.frequencies)
+    out['reference_seconds'] = time.time() - t0
+    out['joint_state'] = collect(nodes, feat('c0', rml.JOINT_STATE), dtype=np.int8)
+    sample = np.arange(0, flat.n_nodes, 4099)
+    out['sample'] = sample
+    JS = feat('c0', rml.BU_LH_JOINT_STATES)
+    jt = np.full((len(sample), 20), -1, dtype=np.int64)
+    for r, i in enumerate(sample):
+        if hasattr(nodes[i], JS):
+            jt[r] = getattr(nodes[i], JS)
+    out['joint_table'] = jt
+    out['bu_joint'] = np.array([getattr(nodes[i], feat('c0', rml.BU_LH)) for i in sample])
+    out['bu_joint_sf'] = np.array([getattr(nodes[i], feat('c0', rml.BU_LH_SF)) for i in sample])
+    out['n_levels'] = n_levels
+    save('synthetic_cfg3_full', **out)
+
+
+CASES['cfg3_full'] = case_cfg3_full
+
+
+HIV1C_SRC = os.path.join(REF, 'examples', 'HIV1C', 'data')
+HIV1C_DST = os.path.join(DATA, 'hiv1c')
+HIV1C_SCRATCH = os.path.join(REPO, 'scratch', 'hiv1c_all')
+
+
+def _hiv1c_column_job(col):
+    """One column of BASELINE config 5 through the reference's acr() (optimised); cached per column in scratch/."""
+    import pickle
+    import time
+    import hashlib
+    tag = hashlib.md5(col.encode()).hexdigest()[:12]
+    path = os.path.join(HIV1C_SCRATCH, tag + '.pkl')
+    if os.path.exists(path):
+        return col, path
+    tree = our_tree.read_tree(os.path.join(HIV1C_DST, 'pastml_phyml_tree.nwk'))
+    df = pd.read_csv(os.path.join(HIV1C_DST, 'metadata_all.tab.gz'), sep='\t', index_col=0, header=0)
+    df.index = df.index.map(str)
+    np.random.seed(239)
+    t0 = time.time()
+    res = racr(tree, df[[col]].copy(), prediction_method='MPPA', model='F81', threads=1)[0]
+    dt = time.time() - t0
+    flat = our_tree.FlatForest.from_trees([tree])
+    names = [n.name for n in flat.nodes]
+    states = res['states']
+    s2i = {s: i for i, s in enumerate(states)}
+    sel = np.zeros((flat.n_nodes, len(states)), dtype=np.uint8)
+    for i, n in enumerate(flat.nodes):
+        for s in getattr(n, col):
+            sel[i, s2i[s]] = 1
+    sample = np.arange(0, flat.n_nodes, 37)
+    rec = dict(column=col, states=np.array(states, dtype=str), sf=float(res['model'].sf),
+               frequencies=np.array(res['model'].frequencies), loglik=res['log_likelihood'],
+               loglik_restricted_JOINT=res['log_likelihood_restricted_JOINT'],
+               loglik_restricted_MAP=res['log_likelihood_restricted_MAP'],
+               loglik_restricted_MPPA=res['log_likelihood_restricted_MPPA'],
+               num_unresolved_nodes=res['num_unresolved_nodes'],
+               num_states_per_node_avg=res['num_states_per_node_avg'],
+               posterior_sample=res['marginal_probabilities'].loc[[names[i] for i in sample]].values,
+               selected_bits=np.packbits(sel, axis=1),
+               joint_state=collect(flat.nodes, col + '_JOINT_STATE', dtype=np.int16),
+               reference_seconds=dt)
+    os.makedirs(HIV1C_SCRATCH, exist_ok=True)
+    with open(path + '.tmp', 'wb') as f:
+        pickle.dump(rec, f)
+    os.replace(path + '.tmp', path)
+    print('{} (k={}): {:.1f} s, lnL {:.6f}'.format(col, len(states), dt, rec['loglik']), flush=True)
+    return col, path
+
+
+def case_hiv1c_all():
+    """
+    BASELINE config 5 in full: every usable annotation column of examples/HIV1C/data/metadata.tab (all but `Name`,
+    which has one state per tip) through the reference's acr(MPPA, F81) with parameter optimisation.  The table (minus
+    `Name`) is stored gzipped as a fixture.  Columns run in a pool of worker processes (PASTML_GOLDEN_WORKERS, default
+    5), largest k first, each cached under scratch/hiv1c_all/ so that the run can be resumed; the k = 67 columns take
+    the reference hours.  PASTML_GOLDEN_MAX_K skips columns with more states (they are then absent from the fixture).
+    """
+    import pickle
+    import multiprocessing as mp
+    os.makedirs(HIV1C_DST, exist_ok=True)
+    meta = pd.read_csv(os.path.join(HIV1C_SRC, 'metadata.tab'), sep='\t', index_col=0, header=0)
+    meta = meta[[c for c in meta.columns if c != 'Name']]
+    meta.to_csv(os.path.join(HIV1C_DST, 'metadata_all.tab.gz'), sep='\t', compression={'method': 'gzip', 'mtime': 0})
+    ks = {c: len([_ for _ in meta[c].unique() if not pd.isna(_) and '' != _]) for c in meta.columns}
+    max_k = int(os.environ.get('PASTML_GOLDEN_MAX_K', '1000'))
+    cols = sorted([c for c in meta.columns if ks[c] <= max_k], key=lambda c: -ks[c])
+    workers = int(os.environ.get('PASTML_GOLDEN_WORKERS', '5'))
+    with mp.get_context('fork').Pool(workers) as pool:
+        done = dict(pool.imap_unordered(_hiv1c_column_job, cols, chunksize=1))
+    out = dict(columns=np.array(list(meta.columns), dtype=str), n_states=np.array([ks[c] for c in meta.columns]),
+               sample=np.arange(0, 7237, 37))
+    for ci, c in enumerate(meta.columns):
+        if c not in done:
+            continue
+        with open(done[c], 'rb') as f:
+            rec = pickle.load(f)
+        for key, v in rec.items():
+            if key != 'column':
+                out['c{}_{}'.format(ci, key)] = v
+    out['done'] = np.array([c in done for c in meta.columns])
+    save('hiv1c_all', **out)
+
+
+CASES['hiv1c_all'] = case_hiv1c_all
+
 if __name__ == '__main__':
     np.random.seed(239)
     todo = sys.argv[1:] or list(CASES)

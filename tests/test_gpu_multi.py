@@ -1,0 +1,114 @@
+"""
+GPU tests of the multi-process path: one process per rank, characters sharded, every rank computing its
+shard THROUGH THE HIP PATH, the log-likelihoods reduced by pastml_amd.sharding.
+
+The GPU box has one GPU and RCCL refuses two ranks on one device, so the 2-rank test puts both ranks on GPU 0 and
+reduces over gloo (PASTML_AMD_COMM=gloo); the library's RCCL communicator (dlopen of librccl, ncclCommInitRank,
+ncclAllReduce on the ctx's stream, staging buffers) is exercised for real with a world of one rank
+(PASTML_HIP_COMM_FORCE_RCCL=1).  bench.py --gpus 2 is run the same way.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+from pastml_amd import hip, sharding, synthetic
+
+pytestmark = pytest.mark.gpu
+
+WORKER = os.path.join(REPO, 'tests', '_rank_worker.py')
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _single_process_logliks(n_chars, levels, k):
+    flat = synthetic.balanced_forest(levels)
+    with hip.Engine(flat, n_chars, k) as eng:
+        eng.set_models([(dict(kind=0, pi=synthetic.f81_frequencies(k, c)), (1.0, 0.0, 1.0)) for c in range(n_chars)])
+        eng.set_tip_states(np.stack([synthetic.tip_states(flat.n_tips, k, c) for c in range(n_chars)]))
+        return eng.bottom_up(True)
+
+
+def test_two_ranks_on_one_gpu_through_the_hip_path(tmp_path):
+    n_chars, levels, k = 6, 10, 64
+    port = _free_port()
+    out = str(tmp_path / 'rank0.json')
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), PASTML_AMD_COMM='gloo', PASTML_TEST_DEVICE='0',
+                   HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, WORKER, out, str(n_chars), str(levels), str(k)], env=env))
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    got = json.load(open(out))
+    ref = _single_process_logliks(n_chars, levels, k)
+    # columns are computed independently and deterministically: the sharded run gives the same bits
+    assert got['per_char'] == ref.tolist()
+    # the reduced total: each rank's local sum in column order, then rank 0 + rank 1
+    local = [0.0, 0.0]
+    for r in range(2):
+        for c in sharding.shard_characters(n_chars, r, 2):
+            local[r] += float(ref[c])
+    assert got['total'] == local[0] + local[1]
+    assert got['max_rank'] == 1.0 and got['comm'] == 'gloo'
+
+
+def test_library_rccl_communicator_world_of_one(monkeypatch):
+    """dlopen(librccl) + ncclGetUniqueId + ncclCommInitRank + ncclAllReduce on the engine's stream, one rank."""
+    monkeypatch.setenv('PASTML_HIP_COMM_FORCE_RCCL', '1')
+    flat = synthetic.balanced_forest(6)
+    k = 5
+    with hip.Engine(flat, 3, k) as eng:
+        eng.set_models([(dict(kind=0, pi=synthetic.f81_frequencies(k, c)), (1.0, 0.0, 1.0)) for c in range(3)])
+        eng.set_tip_states(np.stack([synthetic.tip_states(flat.n_tips, k, c) for c in range(3)]))
+        uid = hip.comm_unique_id()
+        assert len(uid) == hip.COMM_ID_BYTES and any(uid)
+        eng.comm_init(0, 1, uid)
+        lnl = eng.bottom_up(True)
+        total = eng.allreduce_loglik(lnl)
+        assert total == float(lnl[0]) + float(lnl[1]) + float(lnl[2])
+        v = np.array([1.5, -2.0, 1e300, 0.0] * 40)   # grows the staging buffer past its first size
+        assert np.array_equal(eng.allreduce(v), v)
+        assert np.array_equal(eng.allreduce(v, hip.COMM_MAX), v)
+        with pytest.raises(hip.HipError):
+            eng.comm_init(0, 1, uid)   # already attached
+        eng.comm_destroy()
+        with pytest.raises(hip.HipError):
+            eng.allreduce([1.0])
+
+
+def test_communicator_survives_tree_upload_and_plain_world_of_one():
+    flat = synthetic.balanced_forest(4)
+    with hip.BareContext() as ctx:
+        ctx.comm_init(0, 1)
+        assert ctx.allreduce_loglik([1.0, 2.0, 3.5]) == 6.5
+    with pytest.raises(hip.HipError):
+        with hip.BareContext() as ctx:
+            ctx.comm_init(2, 2)
+
+
+def test_bench_two_ranks_started_directly(tmp_path):
+    """`python bench.py --gpus 2` with no launcher: the parent starts the ranks itself and relays rank 0's line."""
+    env = dict(os.environ, BENCH_ALL_RANKS_ON_GPU0='1', PASTML_AMD_COMM='gloo')
+    env.pop('RANK', None)
+    env.pop('WORLD_SIZE', None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+                        '--workload', 'cfg4_small', '--chars-per-gpu', '2'], env=env, capture_output=True, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    line = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert line['n_gpus'] == 2 and line['config']['chars_total'] == 4 and line['scaling'] == 'weak'
+    assert line['validation']['columns'] == 2
+    ref = _single_process_logliks(4, 14, 64)
+    np.testing.assert_allclose(line['loglik_sum'], ref.sum(), rtol=1e-13)

@@ -285,6 +285,100 @@ def test_cfg2_full_size_matches_reference_sample():
     np.testing.assert_allclose(np.log10(lh_sum[0]) - lh_sf[0], lnl[0] / np.log(10), rtol=1e-11)
 
 
+def test_cfg3_full_size_matches_reference_sample():
+    """
+    BASELINE config 3 at full size: 262 144 tips, JTT k=20, one character, joint (Pupko) sweep + back-trace
+    (pastml/ml.py:82-148 with is_marginal=False, :598-622) on the fused FP64 matrix-core sweep, and once more on the
+    sweeps that read materialised P(t) (PML_OPT_EIGEN_FUSED = 0).  Reference: lnL (joint and marginal), the joint
+    state of EVERY node, arg-max rows and log10 bottom-up vectors at every 4 099th node.
+    """
+    z = load_golden('synthetic_cfg3_full')
+    flat = synthetic.balanced_forest(int(z['n_levels']))
+    spec, rates = golden_spec(z)
+    s = z['sample']
+    internal = flat.n_children[s] > 0
+    results = []
+    for fused in (True, False):
+        with hip.Engine(flat, 1, 20) as eng:
+            eng.set_option(hip.OPT_EIGEN_FUSED, fused)
+            eng.set_models([(spec, rates)])
+            eng.set_tip_states(synthetic.tip_states(flat.n_tips, 20, 0))
+            lnl = eng.bottom_up(True)
+            lnl_j = eng.bottom_up(False)
+            states = eng.joint_backtrace()
+            table = eng.download(hip.BUF_JOINT_TABLE)
+            bu = eng.download(hip.BUF_BU)
+            bu_sf = eng.download(hip.BUF_BU_SF)
+        np.testing.assert_allclose(lnl[0], z['loglik'], rtol=LNL_RTOL)
+        np.testing.assert_allclose(lnl_j[0], z['loglik_joint'], rtol=LNL_RTOL)
+        assert np.array_equal(states[0], z['joint_state'])
+        nonroot = s > 0
+        assert np.array_equal(table[s][nonroot], z['joint_table'][nonroot])
+        assert_same_scaled(bu[s][internal], bu_sf[s][internal], z['bu_joint'][internal], z['bu_joint_sf'][internal],
+                           what='joint BU, fused={}'.format(fused))
+        results.append((lnl[0], lnl_j[0]))
+    # the two schedules build P(t) differently (accumulators vs HBM): same numbers to rounding
+    np.testing.assert_allclose(results[0], results[1], rtol=1e-12)
+
+
+def test_cfg4_bench_shape_32_columns():
+    """
+    BASELINE config 4 exactly as bench.py runs it: 1 048 576 tips, k=64, F81, 32 characters in one context (72 GB).
+    Columns are independent and every kernel is deterministic, so column c of the 32-column run must equal, bit for bit,
+    the same character run alone: ln L for all 32, posteriors / LH sums on a strided node sample for five of them.
+    Plus, for every column, the invariants of bench.py's validation.
+    """
+    import bench
+    L, C, k = 20, 32, 64
+    flat = synthetic.balanced_forest(L)
+    states = np.stack([synthetic.tip_states(flat.n_tips, k, c) for c in range(C)])
+    specs = [(dict(kind=0, pi=synthetic.f81_frequencies(k, c)), (1.0, 0.0, 1.0)) for c in range(C)]
+    stride = 4099
+    with hip.Engine(flat, C, k) as eng:
+        eng.set_models(specs)
+        eng.set_tip_states(states)
+        lnl = eng.bottom_up(True)
+        eng.top_down_marginals(posterior=False, lh=False)
+        report = bench.validate_columns(eng, flat, k, states, lnl, stride=stride)
+        assert report['columns'] == C and report['max_row_sum_error'] < 1e-12
+        sample = {c: (eng.download_strided(hip.BUF_POSTERIOR, c, 0, stride),
+                      eng.download_strided(hip.BUF_LH_SUM, c, 0, stride),
+                      eng.download_strided(hip.BUF_LH_SF, c, 0, stride)) for c in (0, 1, 13, 30, 31)}
+    with hip.Engine(flat, 1, k) as eng:
+        for c in range(C):
+            eng.set_models([specs[c]])
+            eng.set_tip_states(states[c])
+            alone = eng.bottom_up(True)
+            assert alone[0] == lnl[c], 'column {}'.format(c)
+            if c in sample:
+                eng.top_down_marginals(posterior=False, lh=False)
+                assert np.array_equal(eng.download_strided(hip.BUF_POSTERIOR, 0, 0, stride), sample[c][0])
+                assert np.array_equal(eng.download_strided(hip.BUF_LH_SUM, 0, 0, stride), sample[c][1])
+                assert np.array_equal(eng.download_strided(hip.BUF_LH_SF, 0, 0, stride), sample[c][2])
+
+
+def test_download_strided_matches_full_download():
+    flat = FlatForest.random(300, seed=21, max_arity=4, zero_frac=0.1)
+    k = 7
+    rng = np.random.default_rng(3)
+    with hip.Engine(flat, 2, k) as eng:
+        eng.set_models([(random_spec('F81', k, rng), (1.0, 0.0, 1.0)) for _ in range(2)])
+        eng.set_masks(np.stack([random_masks(flat, k, rng) for _ in range(2)]))
+        eng.bottom_up(True)
+        post, lh_sum, lh_sf = eng.top_down_marginals()
+        for col in (0, 1):
+            for first, stride in ((0, 1), (3, 7), (flat.n_nodes - 1, 5)):
+                rows = np.arange(first, flat.n_nodes, stride)
+                assert np.array_equal(eng.download_strided(hip.BUF_POSTERIOR, col, first, stride), post[col][rows])
+                assert np.array_equal(eng.download_strided(hip.BUF_LH_SUM, col, first, stride), lh_sum[col][rows])
+                assert np.array_equal(eng.download_strided(hip.BUF_LH_SF, col, first, stride), lh_sf[col][rows])
+        with pytest.raises(hip.HipError):
+            eng.download_strided(hip.BUF_POSTERIOR, 0, 0, 1, flat.n_nodes + 1)
+        eng.bottom_up(False)
+        js = eng.joint_backtrace()
+        assert np.array_equal(eng.download_strided(hip.BUF_JOINT_STATE, 1, 2, 3), js[1][2::3])
+
+
 def test_cfg4_shape_matches_reference_sample():
     """BASELINE config 4's shape (F81, k=64, independent parameters per character) on 16 384 tips, 2 characters."""
     zs = [load_golden('synthetic_cfg4_L14_c{}'.format(c)) for c in (0, 1)]
@@ -567,3 +661,31 @@ def test_device_state_selection_with_tied_probabilities(k):
             eng.set_masks(masks)
             eng.bottom_up(True)
             eng.top_down_marginals()
+
+
+def test_keep_td_option_survives_tree_upload_and_is_not_sticky():
+    """Engine(keep_td=True) stores the TD vectors in the first sweep (no second sweep on download); a download on an
+    engine without the option repeats the sweep once and leaves the option off (pooled contexts stay lean)."""
+    flat = synthetic.balanced_forest(12)   # above the single-launch size: level launches are counted
+    k = 6
+    spec = (dict(kind=0, pi=synthetic.f81_frequencies(k, 0)), (1.0, 0.0, 1.0))
+    tds = []
+    for keep in (True, False):
+        with hip.Engine(flat, 1, k, keep_td=keep) as eng:
+            eng.set_models([spec])
+            eng.set_tip_states(synthetic.tip_states(flat.n_tips, k, 0))
+            eng.profile_enable(True)
+            eng.bottom_up(True)
+            eng.top_down_marginals(posterior=False, lh=False)
+            _, launches = eng.profile_read(1)
+            tds.append(eng.download(hip.BUF_TD))
+            _, after = eng.profile_read(1)
+            assert (after == launches) == keep
+            eng.download(hip.BUF_TD_SF)
+            assert eng.profile_read(1)[1] == after          # materialised once
+            eng.bottom_up(True)
+            eng.top_down_marginals(posterior=False, lh=False)
+            _, again = eng.profile_read(1)
+            eng.download(hip.BUF_TD)
+            assert (eng.profile_read(1)[1] == again) == keep  # without the option the next sweep is lean again
+    assert np.array_equal(tds[0], tds[1], equal_nan=True)

@@ -1,7 +1,8 @@
 """
-CPU test of the N > 1 path: characters sharded over 2 ranks (gloo), per-rank log-likelihoods summed with the same
-all-reduce bench.py uses over RCCL.  The per-rank likelihoods come from the oracle (the checker), since there is no
-GPU here; the GPU ranks compute the same numbers (tests/test_gpu_parity.py).
+CPU test of the N > 1 path: characters sharded over 2 ranks, per-rank log-likelihoods reduced through the
+communicator interface of pastml_amd.sharding (here its gloo implementation; on GPUs the library's RCCL one,
+tests/test_gpu_multi.py).  The per-rank likelihoods come from the oracle (the checker), since there is no GPU here;
+the GPU ranks compute the same numbers (tests/test_gpu_parity.py, tests/test_gpu_multi.py).
 """
 import os
 import socket
@@ -35,24 +36,25 @@ def _free_port():
 
 def _worker(rank, world, port, n_chars, out):
     sys.path.insert(0, REPO)
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      PASTML_AMD_COMM='gloo')
     from oracle import pastml_oracle as orc
-    from pastml_amd import synthetic
-    from pastml_amd.sharding import allreduce_sum, gather_floats
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from pastml_amd import synthetic, sharding
+    comm = sharding.init()
+    assert comm.name == 'gloo' and (comm.rank, comm.world) == (rank, world)
     flat = synthetic.balanced_forest(5)
     k = 6
     mine = []
     for c in shard_characters(n_chars, rank, world):
         masks = synthetic.one_hot_masks(flat, k, synthetic.tip_states(flat.n_tips, k, c)).astype(int)
         mine.append(orc.bottom_up(flat, masks, dict(kind=0, pi=synthetic.f81_frequencies(k, c)))['loglik'])
-    total = allreduce_sum(sum(mine))
-    everyone = gather_floats(mine)
+    total = comm.allreduce_loglik(mine)
+    everyone = sharding.gather_floats(mine).tolist()
+    slowest = float(comm.allreduce([float(rank)], op='max')[0])
     if rank == 0:
-        out.put((total, everyone))
-    dist.barrier()
-    dist.destroy_process_group()
+        out.put((total, everyone, slowest))
+    comm.barrier()
+    sharding.shutdown()
 
 
 def test_two_rank_loglik_allreduce():
@@ -65,7 +67,8 @@ def test_two_rank_loglik_allreduce():
     procs = [ctx.Process(target=_worker, args=(r, world, port, n_chars, out)) for r in range(world)]
     for p in procs:
         p.start()
-    total, everyone = out.get(timeout=120)
+    total, everyone, slowest = out.get(timeout=120)
+    assert slowest == world - 1
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -75,3 +78,16 @@ def test_two_rank_loglik_allreduce():
                          dict(kind=0, pi=synthetic.f81_frequencies(k, c)))['loglik'] for c in range(n_chars)]
     np.testing.assert_allclose(everyone, ref, rtol=1e-14)
     np.testing.assert_allclose(total, sum(ref), rtol=1e-14)
+
+
+def test_local_communicator_and_id_exchange(tmp_path, monkeypatch):
+    from pastml_amd import sharding
+    c = sharding.LocalCommunicator()
+    assert c.allreduce_loglik([1.5, 2.5]) == 4.0
+    assert list(sharding.gather_floats([1.0, 2.0], comm=c)) == [1.0, 2.0]
+    monkeypatch.setenv('PASTML_AMD_RDZV_DIR', str(tmp_path / 'rdzv'))
+    monkeypatch.setattr(sharding, '_RDZV_SEQ', [0])
+    data, path = sharding.exchange_unique_id(0, lambda: b'x' * 128)
+    monkeypatch.setattr(sharding, '_RDZV_SEQ', [0])
+    got, path2 = sharding.exchange_unique_id(1, None, timeout=5)
+    assert got == data == b'x' * 128 and path == path2
