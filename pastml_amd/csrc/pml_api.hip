@@ -418,7 +418,12 @@ static void launch_select(pml_ctx* ctx, int method, int force_joint, const u64* 
 }
 
 static int dispatch_small_f81(pml_ctx* ctx, bool bottom_up, int do_prep, int first_level = 0, int n_levels = -1) {
-    const int g = bottom_up ? ctx->Gf : ctx->Gt, r = bottom_up ? ctx->Rf : ctx->Rt;
+    // Bottom-up: the lane shape the level kernels use for levels of this size (dispatch_sweep: 8 states per lane up to
+    // 65 536 units when 32 < k <= 64).  The reductions over a unit's lanes associate differently in different shapes,
+    // so a level must get the same shape whether it runs here or in a level launch: where the narrow end begins
+    // depends on the number of columns, and a column's bits must not.
+    const int g = bottom_up ? (ctx->bu_wide_lanes ? 8 : ctx->Gf) : ctx->Gt;
+    const int r = bottom_up ? (ctx->bu_wide_lanes ? 8 : ctx->Rf) : ctx->Rt;
     if (n_levels < 0) n_levels = bottom_up ? (int)ctx->bu_offsets_f.size() - 1 - first_level : ctx->n_td_levels;
 #define X(G_, R_)                                                                    \
     if (g == G_ && r == R_) {                                                        \

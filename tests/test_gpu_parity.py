@@ -358,7 +358,7 @@ def test_cfg4_bench_shape_32_columns():
 
 
 def test_download_strided_matches_full_download():
-    flat = FlatForest.random(300, seed=21, max_arity=4, zero_frac=0.1)
+    flat = FlatForest.random(300, seed=21, max_arity=4, zero_frac=0.0)
     k = 7
     rng = np.random.default_rng(3)
     with hip.Engine(flat, 2, k) as eng:
