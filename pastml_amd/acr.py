@@ -1,15 +1,22 @@
 """
-``acr()``: the public entry point of the maximum-likelihood ancestral character reconstruction
-(same signature, defaults and result dictionaries as pastml/acr.py:76-279).
+``acr()``: the public entry point of the maximum-likelihood ancestral character reconstruction -- signature, defaults,
+errors and result dictionaries of pastml/acr.py:76-279.
 
-Only the ML path is implemented here (prediction methods MPPA, MAP, JOINT, ML): every likelihood sweep runs on the
-GPU.  The parsimony / COPY methods, polytomy resolution, the pipeline around it (I/O, HTML) are out of scope of this
-package and raise a clear error.
+The reference walks the characters one by one (a thread pool over ``ml_acr`` calls, acr.py:213-231).  Here the
+characters of a call are the columns of the device sweeps: they are turned into :class:`pastml_amd.batch.Task` objects,
+grouped by (number of states, model family, method) and every group is reconstructed as ONE batch -- parameter
+optimisation of all its characters in lock-step, one joint sweep, one marginal pass, one selection per method
+(pastml_amd.batch).  Under a multi-process launch (one process per GPU, pastml_amd.sharding) every rank takes a
+contiguous block of the characters and returns the results of its block; :func:`total_log_likelihood` sums the
+log-likelihoods over all ranks with the library's single RCCL all-reduce.
+
+Only the ML path is implemented (prediction methods MPPA, MAP, JOINT, ML): every likelihood sweep runs on the GPU.
+The parsimony / COPY methods, polytomy resolution and the HTML side of the pipeline are out of scope of this package
+ and raise a clear error; ``pastml_amd.pipeline`` covers the file-to-file part.
 """
 import logging
 import os
 import warnings
-from multiprocessing.pool import ThreadPool
 
 import numpy as np
 import pandas as pd
@@ -24,7 +31,7 @@ from pastml_amd.models.F81Model import F81Model, F81
 from pastml_amd.models.HKYModel import HKYModel, HKY, HKY_STATES
 from pastml_amd.models.JCModel import JCModel, JC
 from pastml_amd.models.JTTModel import JTTModel, JTT, JTT_STATES
-from pastml_amd.tree import TreeNode
+from pastml_amd.tree import TreeNode, get_flat_forest, AnnotationColumn
 
 model2class = {F81: F81Model, JC: JCModel, CUSTOM_RATES: CustomRatesModel, HKY: HKYModel, JTT: JTTModel, EFT: EFTModel}
 
@@ -36,68 +43,121 @@ warnings.filterwarnings("ignore", append=True)
 
 def _serialize_acr(args):
     """
-    Writes the parameter table (and, for marginal methods, the marginal-probability table) of one ACR result into
-    ``work_dir``, in the reference's format (pastml/acr.py:45-73): the parameter file can be fed back through
-    ``column2parameters`` (to PastML or to this package).
+    Writes one reconstruction result into ``work_dir`` in the reference's two table formats (pastml/acr.py:45-73): the
+    parameter table -- statistics and model parameters, readable back through ``column2parameters`` by PastML and by
+    this package -- and, for marginal methods, the marginal-probability table (one row per node).
     """
     from pastml_amd import PASTML_VERSION
     from pastml_amd.file import get_pastml_parameter_file, get_pastml_marginal_prob_file
     from pastml_amd.ml import MODEL
-    acr_result, work_dir = args
-    out_param_file = os.path.join(work_dir, get_pastml_parameter_file(
-        method=acr_result[METHOD], model=acr_result[MODEL].name if MODEL in acr_result else None,
-        column=acr_result[CHARACTER]))
-    with open(out_param_file, 'w+') as f:
-        f.write('parameter\tvalue\n')
-        f.write('pastml_version\t{}\n'.format(PASTML_VERSION))
-        for name in sorted(acr_result.keys()):
-            if name not in [STATES, MARGINAL_PROBABILITIES, METHOD, MODEL]:
-                f.write('{}\t{}\n'.format(name, acr_result[name]))
-        f.write('{}\t{}\n'.format(METHOD, acr_result[METHOD]))
-        if is_ml(acr_result[METHOD]):
-            acr_result[MODEL].save_parameters(f)
-    logging.getLogger('pastml').debug('Serialized ACR parameters and statistics for {} to {}.'
-                                      .format(acr_result[CHARACTER], out_param_file))
-    if is_marginal(acr_result[METHOD]):
-        out_mp_file = os.path.join(work_dir, get_pastml_marginal_prob_file(
-            method=acr_result[METHOD], model=acr_result[MODEL].name, column=acr_result[CHARACTER]))
-        acr_result[MARGINAL_PROBABILITIES].to_csv(out_mp_file, sep='\t', index_label='node')
-        logging.getLogger('pastml').debug('Serialized marginal probabilities for {} to {}.'
-                                          .format(acr_result[CHARACTER], out_mp_file))
+    result, work_dir = args
+    logger = logging.getLogger('pastml')
+    method, character = result[METHOD], result[CHARACTER]
+    model = result.get(MODEL)
+    rows = [('pastml_version', PASTML_VERSION)]
+    rows += [(key, result[key]) for key in sorted(result) if key not in (STATES, MARGINAL_PROBABILITIES, METHOD, MODEL)]
+    rows.append((METHOD, method))
+    path = os.path.join(work_dir, get_pastml_parameter_file(method=method, model=model.name if model is not None else None,
+                                                            column=character))
+    with open(path, 'w+') as out:
+        out.write('parameter\tvalue\n')
+        out.writelines('{}\t{}\n'.format(*row) for row in rows)
+        if is_ml(method):
+            model.save_parameters(out)
+    logger.debug('Serialized ACR parameters and statistics for {} to {}.'.format(character, path))
+    if is_marginal(method):
+        path = os.path.join(work_dir, get_pastml_marginal_prob_file(method=method, model=model.name, column=character))
+        result[MARGINAL_PROBABILITIES].to_csv(path, sep='\t', index_label='node')
+        logger.debug('Serialized marginal probabilities for {} to {}.'.format(character, path))
+
+
+def _tip_state_words(character, forest, states):
+    """Annotation words of the tips in the reference's tip order (tree by tree, left to right)."""
+    from pastml_amd.batch import annotation_words
+    flat = get_flat_forest(forest)
+    words, _ = annotation_words(flat, character, states)
+    tips = flat.tips[np.argsort(flat.post_rank[flat.tips], kind='stable')]
+    return words[tips]
 
 
 def calculate_observed_freqs(character, forest, states):
     """
-    Tip-state frequencies (a tip with several states contributes 1/n to each) and the fraction of tips without a
-    state (pastml/acr.py:282-299).
+    Tip-state frequencies (a tip with n states counts 1/n for each) and the fraction of tips without a state
+    (pastml/acr.py:282-299).  Tips with one state -- nearly all -- are counted in one pass; tips with several are added
+    in the reference's tip order, which matters for the last bits of a sum of thirds.
     """
-    n = len(states)
-    missing_data = 0.
-    state2index = dict(zip(states, range(n)))
-    observed_frequencies = np.zeros(n, np.float64)
-    for tree in forest:
-        for tip in tree:
-            state = getattr(tip, character, set())
-            if state:
-                num_node_states = len(state)
-                for _ in state:
-                    observed_frequencies[state2index[_]] += 1. / num_node_states
-            else:
-                missing_data += 1
-    total_count = observed_frequencies.sum() + missing_data
-    observed_frequencies /= observed_frequencies.sum()
-    missing_data /= total_count
-    return missing_data, observed_frequencies, state2index
+    from pastml_amd.batch import popcount
+    states = np.asarray(states)
+    k = len(states)
+    state2index = dict(zip(states, range(k)))
+    words = _tip_state_words(character, forest, states)
+    per_tip = popcount(words).sum(axis=-1)
+    bits = np.unpackbits(np.ascontiguousarray(words).view(np.uint8), axis=-1, bitorder='little')[:, :k]
+    single = per_tip == 1
+    several = np.flatnonzero(per_tip > 1)
+    if len(several) == 0:
+        observed = bits[single].sum(axis=0).astype(np.float64)
+    else:
+        observed = np.zeros(k, dtype=np.float64)
+        for row in np.flatnonzero(per_tip > 0):
+            share = 1. / per_tip[row]
+            for j in np.flatnonzero(bits[row]):
+                observed[j] += share
+    missing = float((per_tip == 0).sum())
+    total = observed.sum() + missing
+    observed /= observed.sum()
+    return missing / total, observed, state2index
 
 
 def flatten_lists(lists):
-    result = []
-    for _ in lists:
-        if isinstance(_, list):
-            result.extend(_)
-        else:
-            result.append(_)
-    return result
+    out = []
+    for item in lists:
+        out.extend(item) if isinstance(item, list) else out.append(item)
+    return out
+
+
+def _restrict_annotation_to(states, column, forest):
+    """HKY / JTT work on their own alphabets: states of the annotation outside of it are dropped (acr.py:155-163)."""
+    flat = get_flat_forest(forest)
+    col = flat.columns.get(column)
+    allowed = set(states)
+    if isinstance(col, AnnotationColumn) and col.absent is None and \
+            not any(column in n.__dict__ for n in flat.nodes):
+        keep = np.array([v in allowed for v in col.values], dtype=bool)
+        lut = np.concatenate((np.where(keep, np.cumsum(keep) - 1, -1), [-1])).astype(np.int64)
+        codes = col.codes.copy()
+        valued = codes >= 0
+        codes[valued] = lut[codes[valued]]
+        multi = {}
+        for i, vs in col.multi.items():
+            kept = {int(lut[j]) for j in vs if lut[j] >= 0}
+            if len(kept) > 1:
+                multi[i] = kept
+            codes[i] = min(kept) if kept else -1
+        flat.set_column(column, AnnotationColumn(codes, col.values[keep], multi))
+        return
+    for root in forest:
+        for n in root.traverse():
+            if hasattr(n, column):
+                n.add_feature(column, allowed & getattr(n, column))
+
+
+def total_log_likelihood(results):
+    """
+    Sum of the log-likelihoods of all characters of a run.  Under a multi-process launch every rank passes the results
+    of its own block of characters; the sum over the ranks is the library's one collective (an 8-byte RCCL all-reduce,
+    ``pml_allreduce_loglik``).
+    """
+    from pastml_amd import sharding
+    from pastml_amd.ml import LOG_LIKELIHOOD
+    seen, values = set(), []
+    for r in results:
+        base = r[CHARACTER][:-len(r[METHOD]) - 1] if r[CHARACTER].endswith('_' + r[METHOD]) else r[CHARACTER]
+        if base not in seen:   # the meta-method ML reports one character several times
+            seen.add(base)
+            values.append(r[LOG_LIKELIHOOD])
+    comm = sharding.communicator() or sharding.LocalCommunicator()
+    return comm.allreduce_loglik(values if values else [0.0])
 
 
 def acr(forest, df=None, columns=None, column2states=None, prediction_method=MPPA, model=F81,
@@ -115,16 +175,19 @@ def acr(forest, df=None, columns=None, column2states=None, prediction_method=MPP
     :param column2parameters: {column: {param: value}} or {column: path to a parameter file} to preset parameters
     :param column2rates: {column: path to a rate matrix file} for CUSTOM_RATES
     :param force_joint: add the joint state to the MPPA selection even if the Brier score would not
-    :param threads: number of characters processed concurrently (0 = number of CPUs)
+    :param threads: kept for compatibility; characters are batched on the device, not spread over host threads
     :param reoptimise: treat given parameters as starting values
     :param tau: smoothing factor added to the branch lengths (0: zero branches are handled by state alteration)
-    :return: list of ACR result dictionaries
+    :return: list of ACR result dictionaries (of this rank's characters under a multi-process launch)
     """
+    from pastml_amd import sharding
+    from pastml_amd.batch import Task, run_tasks
     if resolve_polytomies:
         raise NotImplementedError('resolve_polytomies (tree editing, pastml/tree.py:344-492) is outside the '
                                   'accelerated likelihood path')
     if isinstance(forest, TreeNode):
         forest = [forest]
+    logger = logging.getLogger('pastml')
 
     if columns is None:
         if df is None:
@@ -137,36 +200,18 @@ def acr(forest, df=None, columns=None, column2states=None, prediction_method=MPP
         preannotate_forest(forest, df=df)
 
     forest_stats = ForestStats(forest)
-    logger = logging.getLogger('pastml')
     logger.debug('\n=============ACR===============================')
+    column2parameters = column2parameters or {}
+    column2rates = column2rates or {}
+    methods = value2list(len(columns), prediction_method, MPPA)
+    model_names = value2list(len(columns), model, F81)
+    optimise_tau = tau is None or reoptimise
+    tau = 0 if tau is None else tau
 
-    column2parameters = column2parameters if column2parameters else {}
-    column2rates = column2rates if column2rates else {}
-
-    prediction_methods = value2list(len(columns), prediction_method, MPPA)
-    models = value2list(len(columns), model, F81)
-
-    def get_states(method, model, column):
-        initial_states = column2states[column]
-        if not is_ml(method) or model not in {HKY, JTT}:
-            return initial_states
-        states = HKY_STATES if HKY == model else JTT_STATES
-        if not set(initial_states) & set(states):
-            raise ValueError('The allowed states for model {} are {}, '
-                             'but your annotation file specifies {} as states in column {}.'
-                             .format(model, ', '.join(states), ', '.join(initial_states), column))
-        state_set = set(states)
-        for root in forest:
-            for n in root.traverse():
-                if hasattr(n, column):
-                    n.add_feature(column, state_set & getattr(n, column))
-        return states
-
-    character2settings = {}
-    for (character, method, model_name) in zip(columns, prediction_methods, models):
+    tasks = []
+    for character, method, model_name in zip(columns, methods, model_names):
         logger.debug('ACR settings for {}:\n\tMethod:\t{}{}.'
-                     .format(character, method, '\n\tModel:\t{}'.format(model_name)
-                             if model_name and is_ml(method) else ''))
+                     .format(character, method, '\n\tModel:\t{}'.format(model_name) if model_name and is_ml(method) else ''))
         if COPY == method or method in MP_METHODS or ALL == method:
             raise NotImplementedError('Method {} is outside the accelerated maximum-likelihood path; '
                                       'supported: {}'.format(method, ', '.join(sorted(ML_METHODS | {ML}))))
@@ -174,37 +219,31 @@ def acr(forest, df=None, columns=None, column2states=None, prediction_method=MPP
             raise ValueError('Method {} is unknown, should be one of ML ({})'.format(method, ', '.join(ML_METHODS)))
         if model_name not in model2class:
             raise ValueError('Model {} is unknown, should be one of {}'.format(model_name, ', '.join(model2class)))
-        params = column2parameters[character] if character in column2parameters else None
-        rate_file = column2rates[character] if character in column2rates else None
-        optimise_tau = tau is None or reoptimise
-        if tau is None:
-            tau = 0
-        states = get_states(method, model_name, character)
-        missing_data, observed_frequencies, state2index = calculate_observed_freqs(character, forest, states)
-        logger.debug('Observed frequencies for {}:{}{}.'
-                     .format(character,
-                             ''.join('\n\tfrequency of {}:\t{:.6f}'.format(state, observed_frequencies[state2index[state]])
-                                     for state in states),
-                             '\n\tfraction of missing data:\t{:.6f}'.format(missing_data) if missing_data else ''))
-        model_instance = model2class[model_name](parameter_file=params, rate_matrix_file=rate_file,
-                                                 reoptimise=reoptimise, frequency_smoothing=frequency_smoothing,
-                                                 tau=tau, optimise_tau=optimise_tau, states=states,
-                                                 forest_stats=forest_stats,
-                                                 observed_frequencies=observed_frequencies, character=character)
-        character2settings[character] = [method, model_instance, observed_frequencies]
+        states = column2states[character]
+        if model_name in (HKY, JTT):
+            alphabet = HKY_STATES if HKY == model_name else JTT_STATES
+            if not set(states) & set(alphabet):
+                raise ValueError('The allowed states for model {} are {}, '
+                                 'but your annotation file specifies {} as states in column {}.'
+                                 .format(model_name, ', '.join(alphabet), ', '.join(states), character))
+            _restrict_annotation_to(alphabet, character, forest)
+            states = alphabet
+        missing, observed, state2index = calculate_observed_freqs(character, forest, states)
+        logger.debug('Observed frequencies for {}:{}{}.'.format(
+            character, ''.join('\n\tfrequency of {}:\t{:.6f}'.format(s, observed[state2index[s]]) for s in states),
+            '\n\tfraction of missing data:\t{:.6f}'.format(missing) if missing else ''))
+        instance = model2class[model_name](parameter_file=column2parameters.get(character),
+                                           rate_matrix_file=column2rates.get(character), reoptimise=reoptimise,
+                                           frequency_smoothing=frequency_smoothing, tau=tau, optimise_tau=optimise_tau,
+                                           states=states, forest_stats=forest_stats, observed_frequencies=observed,
+                                           character=character)
+        tasks.append(Task(character, method, instance, observed))
 
-    if threads < 1:
-        threads = max(os.cpu_count(), 1)
-
-    def _work(character):
-        method, model_instance, observed_frequencies = character2settings[character]
-        return ml_acr(forest=forest, character=character, prediction_method=method, model=model_instance,
-                      force_joint=force_joint, observed_frequencies=observed_frequencies)
-
-    if threads > 1 and len(character2settings) > 1:
-        with ThreadPool(processes=min(threads - 1, len(character2settings))) as pool:
-            acr_results = pool.map(func=_work, iterable=character2settings.keys())
-    else:
-        acr_results = [_work(character) for character in character2settings.keys()]
-
-    return flatten_lists(acr_results)
+    # one process per GPU: this rank's contiguous block of the characters
+    comm = sharding.communicator()
+    if comm is not None and comm.world > 1:
+        mine = sharding.shard_characters(len(tasks), comm.rank, comm.world)
+        tasks = [tasks[i] for i in mine]
+    if not tasks:
+        return []
+    return flatten_lists(run_tasks(forest, tasks, force_joint=force_joint))

@@ -73,10 +73,73 @@ def df2gdf(df):
     return gdf
 
 
+def annotation_columns(flat, df):
+    """
+    The annotation table as columns over the nodes of ``flat``: {column: AnnotationColumn}.  One pass per table column
+    over arrays (codes of the distinct values), no per-node Python objects: a node named in the table gets the set of
+    its non-empty values (several rows of one name: their union), other nodes have no such attribute -- what
+    pastml/annotation.py:104-123 leaves on the tree.  Empty cells of ``df`` become '' in place, as in the reference.
+    """
+    from pastml_amd.tree import AnnotationColumn
+    df.fillna('', inplace=True)
+    N = flat.n_nodes
+    node_names = getattr(flat, '_node_names', None)
+    if node_names is None:
+        node_names = pd.Index([n.name for n in flat.nodes])
+        flat._node_names = node_names
+    if node_names.is_unique and df.index.is_unique:
+        rows_of_node = node_names.get_indexer(df.index)        # df row -> node id (-1: not in the tree)
+        row_ids = np.flatnonzero(rows_of_node >= 0)
+        node_ids = rows_of_node[row_ids]
+        pairs = None
+    else:
+        # names shared by several nodes and / or several rows per name: explicit (row, node) pairs
+        where = {}
+        for i, name in enumerate(node_names):
+            where.setdefault(name, []).append(i)
+        pairs = [(r, i) for r, name in enumerate(df.index) for i in where.get(name, ())]
+        row_ids = np.array([r for r, _ in pairs], dtype=np.int64)
+        node_ids = np.array([i for _, i in pairs], dtype=np.int64)
+    out = {}
+    for c in df.columns:
+        col = df[c].to_numpy()
+        present = np.array([v != '' and not pd.isnull(v) for v in col], dtype=bool) if col.dtype == object \
+            else ~pd.isnull(col)
+        values, inverse = np.unique(col[present].astype(object) if col.dtype != object else col[present],
+                                    return_inverse=True) if present.any() else (np.zeros(0, dtype=object), np.zeros(0, int))
+        code_of_row = np.full(len(col), -1, dtype=np.int64)
+        code_of_row[present] = inverse
+        codes = np.full(N, -2, dtype=np.int64)
+        multi = {}
+        if pairs is None:
+            codes[node_ids] = code_of_row[row_ids]
+        else:
+            for r, i in zip(row_ids, node_ids):
+                cr = code_of_row[r]
+                if cr < 0:                      # a row without a value: the node is in the table, nothing more
+                    if codes[i] == -2:
+                        codes[i] = -1
+                elif codes[i] < 0:
+                    codes[i] = cr
+                elif cr != codes[i]:            # a second, different value for the same node
+                    multi.setdefault(int(i), {int(codes[i])}).add(int(cr))
+        out[c] = AnnotationColumn(codes, values, multi)
+    return out
+
+
 def preannotate_forest(forest, df=None, gdf=None):
-    """Sets ``node.<column> = set(states)`` for annotated nodes, removes the feature elsewhere (annotation.py:113-123)."""
+    """
+    ``node.<column>`` = set of the node's states for the nodes named in the table, no such attribute elsewhere
+    (pastml/annotation.py:113-123).  With ``df`` the annotation becomes columnar features of the flattened forest
+    (pastml_amd.tree, no per-node work); a ready-made ``gdf`` (one row of sets per name) is put on the nodes one by one.
+    """
     if gdf is None:
-        gdf = df2gdf(df)
+        if isinstance(forest, TreeNode):
+            forest = [forest]
+        flat = get_flat_forest(forest)
+        for c, column in annotation_columns(flat, df).items():
+            flat.set_column(c, column)
+        return df.columns, None
     index = set(gdf.index)
     columns = list(gdf.columns)
     records = gdf.to_dict(orient='index')

@@ -1,0 +1,823 @@
+"""
+Characters as columns: the host side of the maximum-likelihood reconstruction for SEVERAL characters of one forest at
+once.
+
+The reference analyses one character at a time (pastml/acr.py:213-231 hands them to a pool one by one; pastml/ml.py
+keeps everything in per-node attributes).  The device sweeps have a column axis with independent masks and parameters
+per column, so here the characters of a run that share the number of states and the model family become the columns
+of ONE device context and every step of ``ml_acr`` (pastml/ml.py:640-750) -- every likelihood evaluation of every
+character's L-BFGS-B run (:174-237), the joint sweep, the marginal pass, the state selections, the restricted
+likelihoods -- is one batched launch sequence for all of them:
+
+* :class:`CharacterBatch` -- allowed-state masks of m characters as packed bit words ``uint64[m, N, W]`` with the
+  zero-branch alteration / restoration rules of ml.py:321-405 as array operations over all characters and zero-branch
+  clusters at once, plus the device context holding the m columns;
+* :class:`SweepServer` -- the optimisers of the m characters run concurrently (one scipy L-BFGS-B instance each, own
+  thread); a likelihood request blocks until every running optimiser has posted one, then a single bottom-up sweep over
+  sum(n_params + 1) columns serves them all.  Columns are computed independently and deterministically, so each
+  character sees exactly the numbers -- and takes exactly the iterates -- of a run on its own;
+* :func:`reconstruct` -- the rest of ``ml_acr`` in lock-step.
+
+Node features the reference leaves on the tree are written as columnar features of the flat forest
+(pastml_amd.tree), O(1) per feature instead of a tree walk.
+"""
+import logging
+import os
+import threading
+
+import numpy as np
+import pandas as pd
+
+from pastml_amd import hip
+from pastml_amd.tree import (TreeNode, get_flat_forest, AnnotationColumn, StateSetColumn, MaskColumn, ArrayColumn,
+                             _DICT_FEATURE_NAMES)
+
+ONE = np.uint64(1)
+
+
+# =====================================================================================================================
+# packed state sets
+# =====================================================================================================================
+def n_words(k):
+    return (k + 63) // 64
+
+
+def full_words(k):
+    """All k states allowed: uint64[W]."""
+    W = n_words(k)
+    w = np.full(W, ~np.uint64(0), dtype=np.uint64)
+    if k % 64:
+        w[-1] = (ONE << np.uint64(k % 64)) - ONE
+    return w
+
+
+def words_from_masks(masks, k):
+    """0/1 array [..., k] -> uint64 [..., W]."""
+    return hip.pack_masks(masks, k)
+
+
+def masks_from_words(words, k):
+    """uint64 [..., W] -> int8 0/1 [..., k]."""
+    return hip.unpack_masks(words, k)
+
+
+def popcount(words):
+    """Number of set bits per entry of a uint64 array."""
+    b = np.ascontiguousarray(words).view(np.uint8)
+    return _POP8[b].reshape(words.shape + (8,)).sum(axis=-1)
+
+
+_POP8 = np.array([bin(i).count('1') for i in range(256)], dtype=np.int64)
+
+
+def one_hot_words(index, k):
+    """State indices [...] -> words [..., W] with that one bit set."""
+    index = np.asarray(index, dtype=np.int64)
+    W = n_words(k)
+    out = np.zeros(index.shape + (W,), dtype=np.uint64)
+    np.put_along_axis(out, (index >> 6)[..., None], (ONE << (index & 63).astype(np.uint64))[..., None], axis=-1)
+    return out
+
+
+# =====================================================================================================================
+# zero-branch clusters (tree level)
+# =====================================================================================================================
+class ZeroClusters(object):
+    """
+    Nodes joined by zero-length branches (pastml/ml.py:321-349), for clusters of at least two nodes: ``nodes`` lists
+    their members cluster by cluster, ``starts`` where each cluster begins in that list, ``cluster_of`` the cluster of
+    every listed member.
+    """
+
+    def __init__(self, flat):
+        N = flat.n_nodes
+        top = np.arange(N, dtype=np.int64)
+        zero = (flat.dist == 0) & (flat.parent >= 0)
+        # parents precede children in id order, level by level
+        for lvl in range(1, flat.n_td_levels):
+            a, b = flat.td_offsets[lvl], flat.td_offsets[lvl + 1]
+            ids = np.arange(a, b)[zero[a:b]]
+            top[ids] = top[flat.parent[ids]]
+        self.top = top
+        size = np.bincount(top, minlength=N)
+        members = np.flatnonzero(size[top] >= 2)
+        order = np.argsort(top[members], kind='stable')
+        self.nodes = members[order]
+        tops = top[self.nodes]
+        self.starts = np.flatnonzero(np.concatenate(([True], tops[1:] != tops[:-1]))) if len(tops) else \
+            np.zeros(0, dtype=np.int64)
+        self.cluster_of = np.cumsum(np.concatenate(([0], (tops[1:] != tops[:-1]).astype(np.int64)))) if len(tops) else \
+            np.zeros(0, dtype=np.int64)
+
+
+def zero_clusters(flat):
+    zc = getattr(flat, '_zero_clusters', None)
+    if zc is None:
+        zc = ZeroClusters(flat)
+        flat._zero_clusters = zc
+    return zc
+
+
+# =====================================================================================================================
+# annotation of a character as packed words
+# =====================================================================================================================
+def annotation_words(flat, character, states):
+    """
+    (words uint64[N, W], annotated bool[N]) of a character: the node's states as given (0 words: none given) and
+    whether the node "has a state" in the sense of pastml/ml.py:329-331 (the attribute exists and is not '': an empty
+    set counts).  Columnar annotations (pastml_amd.annotation.preannotate_forest, an earlier reconstruction) are read as
+    arrays; attributes set node by node are collected with one walk.
+    """
+    states = np.asarray(states)
+    k = len(states)
+    N = flat.n_nodes
+    W = n_words(k)
+    col = flat.columns.get(character)
+    shadowed = character in _DICT_FEATURE_NAMES and flat.nodes is not None and \
+        any(character in n.__dict__ for n in flat.nodes)
+    if col is not None and not shadowed and col.absent is None:
+        if isinstance(col, AnnotationColumn):
+            state2index = {s: i for i, s in enumerate(states)}
+            lut = np.array([state2index.get(v, -1) for v in col.values] + [-1], dtype=np.int64)
+            codes = col.codes
+            annotated = codes > -2
+            idx = lut[np.where(codes >= 0, codes, len(col.values))]
+            words = np.zeros((N, W), dtype=np.uint64)
+            has = idx >= 0
+            words[has] = one_hot_words(idx[has], k)
+            for i, vs in col.multi.items():
+                words[i] = 0
+                for j in vs:
+                    if lut[j] >= 0:
+                        words[i, lut[j] >> 6] |= ONE << np.uint64(lut[j] & 63)
+            return words, annotated
+        if isinstance(col, StateSetColumn) and len(col.states) == k and np.array_equal(col.states, states):
+            return np.array(col.words, dtype=np.uint64, copy=True), np.ones(N, dtype=bool)
+    if flat.nodes is None:
+        return np.zeros((N, W), dtype=np.uint64), np.zeros(N, dtype=bool)
+    state2index = {s: i for i, s in enumerate(states)}
+    words = np.zeros((N, W), dtype=np.uint64)
+    annotated = np.zeros(N, dtype=bool)
+    for i, node in enumerate(flat.nodes):
+        value = getattr(node, character, None)
+        if value is not None and value != '':
+            annotated[i] = True
+        if value:
+            for s in value:
+                j = state2index[s]
+                words[i, j >> 6] |= ONE << np.uint64(j & 63)
+    return words, annotated
+
+
+# =====================================================================================================================
+# the batch
+# =====================================================================================================================
+class LikelihoodError(Exception):
+    """Zero likelihood in a column: (column, parent id, child id); turned into PastMLLikelihoodError by the caller."""
+
+    def __init__(self, column, parent, child):
+        Exception.__init__(self, 'zero likelihood in column {} between nodes {} and {}'.format(column, parent, child))
+        self.column, self.parent, self.child = column, parent, child
+
+
+class CharacterBatch(object):
+    """m characters with k states each on one flat forest: masks on the host, columns on the device."""
+
+    def __init__(self, flat, k, m, device=None):
+        self.flat = flat
+        self.k, self.m = k, m
+        self.N = flat.n_nodes
+        self.W = n_words(k)
+        self.full = full_words(k)
+        self._device = device
+        self._engine = None
+        self._opt = None
+        self.ann = np.zeros((m, self.N, self.W), dtype=np.uint64)
+        self.annotated = np.zeros((m, self.N), dtype=bool)
+        self.masks = np.broadcast_to(self.full, (m, self.N, self.W)).copy()
+        self.init_masks = np.zeros((m, self.N, self.W), dtype=np.uint64)
+        self.has_init = np.zeros((m, self.N), dtype=bool)
+        self._uploaded = None
+        self._uploaded_models = None
+        self.n_sweeps = 0
+
+    # ------------------------------------------------------------------------------------------------ resources
+    @property
+    def engine(self):
+        """The device context of the m columns, created on first use (mask bookkeeping alone needs no GPU)."""
+        if self._engine is None:
+            self._engine = hip.acquire_engine(self.flat, self.m, self.k, device=self._device)
+            self._uploaded = None
+            self._uploaded_models = None
+        return self._engine
+
+    def close(self):
+        if self._engine is not None:
+            hip.release_engine(self._engine)
+            self._engine = None
+        if self._opt is not None:
+            hip.release_engine(self._opt['engine'])
+            self._opt = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ------------------------------------------------------------------------------------------------ masks (host)
+    def set_annotation(self, c, words, annotated):
+        self.ann[c] = words
+        self.annotated[c] = annotated
+
+    def initialize_allowed_states(self, rows=None):
+        """Annotated states where there are any, everything allowed elsewhere (pastml/ml.py:293-318)."""
+        rows = slice(None) if rows is None else rows
+        given = self.ann[rows].any(axis=-1, keepdims=True)
+        self.masks[rows] = np.where(given, self.ann[rows], self.full)
+
+    def alter(self, rows):
+        """
+        Zero-branch alteration (pastml/ml.py:352-387) for the characters whose ``rows`` flag is set: in every cluster of
+        nodes joined by zero-length branches, the annotated members, if they are at least two and share no allowed
+        state, all get the union of their masks; the masks they had are remembered.  All characters and clusters at
+        once.  Returns the altered (character, node) pairs as a bool array [m, N].
+        """
+        altered = np.zeros((self.m, self.N), dtype=bool)
+        zc = zero_clusters(self.flat)
+        rows = np.asarray(rows, dtype=bool)
+        if not len(zc.nodes) or not rows.any():
+            return altered
+        r = np.flatnonzero(rows)
+        a = self.annotated[np.ix_(r, zc.nodes)]                          # [r, n_zc]
+        mk = self.masks[np.ix_(r, zc.nodes)]                             # [r, n_zc, W]
+        count = np.add.reduceat(a.astype(np.int64), zc.starts, axis=1)   # annotated members per cluster
+        common = np.bitwise_and.reduceat(np.where(a[..., None], mk, ~np.uint64(0)), zc.starts, axis=1)
+        union = np.bitwise_or.reduceat(np.where(a[..., None], mk, np.uint64(0)), zc.starts, axis=1)
+        clash = (count >= 2) & ~common.any(axis=-1)                      # [r, n_clusters]
+        hit = clash[:, zc.cluster_of] & a                                # [r, n_zc]
+        if not hit.any():
+            return altered
+        ri, ni = np.nonzero(hit)
+        chars, nodes = r[ri], zc.nodes[ni]
+        self.init_masks[chars, nodes] = mk[ri, ni]
+        self.has_init[chars, nodes] = True
+        self.masks[chars, nodes] = union[ri, zc.cluster_of[ni]]
+        altered[chars, nodes] = True
+        return altered
+
+    def unalter(self, altered):
+        """masks & saved masks, or the saved ones where nothing is left (pastml/ml.py:390-405)."""
+        if not altered.any():
+            return
+        both = self.masks[altered] & self.init_masks[altered]
+        self.masks[altered] = np.where(both.any(axis=-1, keepdims=True), both, self.init_masks[altered])
+
+    # ------------------------------------------------------------------------------------------------ device
+    def _upload_models(self, engine, models, col_begin=0, cache_attr='_uploaded_models'):
+        keys = []
+        for mdl in models:
+            spec = mdl.kernel_spec()
+            keys.append((spec['kind'], mdl.rate_params(),
+                         tuple(np.asarray(v).tobytes() if isinstance(v, np.ndarray) else v
+                               for _, v in sorted(spec.items()))))
+        if getattr(self, cache_attr) != keys:
+            engine.set_models(models, col_begin=col_begin)
+            setattr(self, cache_attr, keys)
+
+    def _upload_masks(self):
+        eng = self.engine
+        if self._uploaded is None:
+            eng.set_mask_words(self.masks)
+            self._uploaded = self.masks.copy()
+            return
+        changed = np.flatnonzero((self.masks != self._uploaded).any(axis=(1, 2)))
+        # contiguous runs of changed columns go up together
+        if len(changed):
+            runs = np.split(changed, np.flatnonzero(np.diff(changed) > 1) + 1)
+            for run in runs:
+                a, b = int(run[0]), int(run[-1]) + 1
+                eng.set_mask_words(self.masks[a:b], col_begin=a)
+                self._uploaded[a:b] = self.masks[a:b]
+
+    def bottom_up(self, models, is_marginal=True, alter=True):
+        """
+        Bottom-up log-likelihood of every character (pastml/ml.py:82-121 summed over the trees): optional alteration of
+        the masks (characters with tau == 0), ONE device sweep over the m columns, restoration of the masks (marginal);
+        after a joint sweep the arg-max tables of the altered nodes are rewritten on the device instead
+        (ml.py:115-119).  Returns ln L [m]; raises LikelihoodError for the first column without likelihood.
+        """
+        rows = np.array([alter and 0 == mdl.tau for mdl in models], dtype=bool)
+        before = self.masks.copy() if (rows.any() and not is_marginal) else None
+        altered = self.alter(rows) if rows.any() else np.zeros((self.m, self.N), dtype=bool)
+        eng = self.engine
+        self._upload_models(eng, models)
+        self._upload_masks()
+        if not is_marginal and altered.any():
+            eng.set_initial_mask_words(before)
+        else:
+            eng.set_initial_masks(None)
+        self.n_sweeps += self.m
+        try:
+            lnl = eng.bottom_up(is_marginal)
+        except hip.ZeroLikelihoodError as e:
+            first = int(np.flatnonzero(e.err_child >= 0)[0])
+            raise LikelihoodError(first, int(e.err_parent[first]), int(e.err_child[first]))
+        if is_marginal and altered.any():
+            self.unalter(altered)
+        return lnl
+
+    def top_down_marginals(self):
+        """After a marginal sweep: (posterior [m, N, k], lh_sum [m, N], lh_sf [m, N]) (ml.py:240-290, 431-502)."""
+        return self.engine.top_down_marginals()
+
+    def joint_states(self):
+        """Joint state of every node after a joint sweep (ml.py:598-622): int64 [m, N]."""
+        return self.engine.joint_backtrace().astype(np.int64)
+
+    def select(self, method, force_joint=False):
+        """
+        MAP / MPPA selection (ml.py:505-595) on the device from the posteriors of the last marginal pass; the marginal
+        likelihoods of nodes with saved ('.initial') masks are restricted to them first.  The selected masks become both
+        the device's and this object's masks.  Returns the number of selected states per node, int64 [m, N].
+        """
+        lh_masks = None
+        if self.has_init.any():
+            lh_masks = np.where(self.has_init[..., None], self.init_masks, self.full)
+        sel, nsel = self.engine.select_states(method, force_joint=force_joint, lh_masks=lh_masks, packed=True)
+        self.masks = sel
+        self._uploaded = sel.copy()
+        return nsel.astype(np.int64)
+
+    # ------------------------------------------------------------------------------------------------ optimiser columns
+    def open_optimiser(self, widths):
+        """
+        A second context whose columns are blocks, one block of widths[c] columns per character: the points of one
+        finite-difference gradient of character c go into block c.  All columns of a block carry the character's masks
+        -- as they are for points with tau > 0, altered (pastml/ml.py:101-103) for points with tau == 0.  The
+        alteration depends on the masks only, not on the parameters, so it is computed once per character, when its
+        first point with tau == 0 comes, for the hundreds of evaluations of an optimisation; the saved '.initial'
+        masks stay, as after a sequence of single evaluations.
+        """
+        offsets = np.concatenate(([0], np.cumsum(widths))).astype(np.int64)
+        total = int(offsets[-1])
+        eng = hip.acquire_engine(self.flat, total, self.k, device=self._device)
+        self._opt = dict(engine=eng, offsets=offsets, total=total, variant=np.full(total, -1, dtype=np.int64),
+                         altered={}, models=[None] * total, all_set=False)
+        return self._opt
+
+    def _altered_variant(self, c):
+        """Masks of character c after alteration, or None if the alteration changes nothing for it."""
+        opt = self._opt
+        if c not in opt['altered']:
+            plain = self.masks[c].copy()
+            rows = np.zeros(self.m, dtype=bool)
+            rows[c] = True
+            changed = self.alter(rows)[c].any()
+            opt['altered'][c] = self.masks[c].copy() if changed else None
+            self.masks[c] = plain   # a marginal evaluation leaves the masks as they were (ml.py:115-117)
+        return opt['altered'][c]
+
+    def evaluate_points(self, requests):
+        """
+        requests: {character: [(spec, rates), ...]} -- kernel descriptions of the parameter vectors to evaluate, at
+        most as many as the character's block is wide.  One bottom-up sweep over all blocks; returns
+        {character: ln L array, or a LikelihoodError if one of its points has no likelihood}.
+        """
+        opt = self._opt
+        eng, offsets, models = opt['engine'], opt['offsets'], opt['models']
+        lo, hi = opt['total'], 0
+        for c, points in requests.items():
+            a = int(offsets[c])
+            if len(points) > int(offsets[c + 1]) - a:
+                raise ValueError('{} points for a block of {} columns'.format(len(points), int(offsets[c + 1]) - a))
+            for j, (spec, rates) in enumerate(points):
+                models[a + j] = (spec, rates)
+                words = self._altered_variant(c) if 0 == rates[1] else None
+                variant = 0 if words is None else 1
+                if opt['variant'][a + j] != variant:
+                    eng.set_mask_words(self.masks[c] if words is None else words, col_begin=a + j)
+                    opt['variant'][a + j] = variant
+            lo, hi = min(lo, a), max(hi, a + len(points))
+        # every column of the context is swept: columns that were never given a model (blocks of characters that have
+        # not asked yet, the unused tail of a block) repeat a valid one; their results are not looked at
+        if not opt['all_set']:
+            filler = next(mm for mm in models if mm is not None)
+            for i in range(opt['total']):
+                if models[i] is None:
+                    models[i] = filler
+                if opt['variant'][i] < 0:
+                    c = int(np.searchsorted(offsets, i, side='right') - 1)
+                    eng.set_mask_words(self.masks[c], col_begin=i)
+                    opt['variant'][i] = 0
+            eng.set_models(models)
+            opt['all_set'] = True
+        else:
+            eng.set_models(models[lo:hi], col_begin=lo)
+        self.n_sweeps += sum(len(p) for p in requests.values())
+        failed = None
+        try:
+            values = eng.bottom_up(True)
+        except hip.ZeroLikelihoodError as e:
+            values, failed = e.loglik, e
+        out = {}
+        for c, points in requests.items():
+            a = int(offsets[c])
+            out[c] = values[a:a + len(points)].copy()
+            if failed is not None:
+                bad = np.flatnonzero(failed.err_child[a:a + len(points)] >= 0)
+                if len(bad):
+                    j = a + int(bad[0])
+                    out[c] = LikelihoodError(c, int(failed.err_parent[j]), int(failed.err_child[j]))
+        return out
+
+
+# =====================================================================================================================
+# lock-step likelihood service for concurrent optimisers
+# =====================================================================================================================
+class SweepServer(object):
+    """
+    Rendezvous of the optimiser threads: ``evaluate(c, points)`` blocks until every *running* client has a request
+    pending, then one of the waiting threads runs the batched sweep for all and wakes the others.  ``finish(c)`` takes a
+    client out of the rendezvous.
+    """
+
+    def __init__(self, batch, clients):
+        self.batch = batch
+        self.cond = threading.Condition()
+        self.running = set(clients)
+        self.pending = {}
+        self.results = {}
+        self.rounds = 0
+
+    def _round_if_complete(self):
+        # caller holds the condition
+        if self.pending and set(self.pending) >= self.running:
+            requests, self.pending = self.pending, {}
+            try:
+                out = self.batch.evaluate_points(requests)
+            except Exception as e:  # a failure of the sweep itself reaches every waiting client
+                out = {c: e for c in requests}
+            self.rounds += 1
+            self.results.update(out)
+            self.cond.notify_all()
+
+    def evaluate(self, c, points):
+        with self.cond:
+            self.pending[c] = points
+            self._round_if_complete()
+            while c not in self.results:
+                self.cond.wait()
+            res = self.results.pop(c)
+        if isinstance(res, Exception):
+            raise res
+        return res
+
+    def finish(self, c):
+        with self.cond:
+            self.running.discard(c)
+            self._round_if_complete()
+
+
+# scipy's finite-difference helper (the one L-BFGS-B itself uses when no gradient is given): with it a whole gradient
+# is evaluated as one batch and the iterates stay those of scipy's own numerical differentiation.  It is a private
+# module: without it the optimisers fall back to letting scipy difference the likelihood point by point (same iterates,
+# one sweep per point).
+try:
+    from scipy.optimize._numdiff import approx_derivative as _approx_derivative
+except Exception:  # pragma: no cover - depends on the SciPy build
+    _approx_derivative = None
+
+
+def batched_gradients_available():
+    return _approx_derivative is not None and os.environ.get('PASTML_AMD_BATCHED_OPTIMISER', '1') != '0'
+
+
+def block_width(model):
+    """Columns a character needs in the optimiser context: one per point of its largest finite-difference gradient."""
+    if not batched_gradients_available():
+        return 1
+    fixed = model.extra_params_fixed()
+    model.unfix_extra_params()
+    n = model.get_num_params()
+    if fixed:
+        model.fix_extra_params()
+    return n + 1
+
+
+def search_parameters(model, observed_frequencies, evaluate, rng):
+    """
+    One L-BFGS-B search over the model's currently free parameters (the procedure of pastml/ml.py:174-237): it starts
+    from the current values, then -- if frequencies are free -- from the observed frequencies, then from up to 98
+    uniform draws inside the bounds, and stops at the first start whose optimum is at least as good as the better of the
+    first two starting likelihoods; if none is, the better starting point is kept.
+    ``evaluate(list of parameter vectors)`` -> list of ln L (one batched sweep); the model is left at the optimum.
+    """
+    from scipy.optimize import minimize
+    from pastml_amd.models import ModelWithFrequencies
+    bounds = model.get_bounds()
+    lower, upper = bounds[:, 0], bounds[:, 1]
+
+    def negative(values):
+        return [np.inf if pd.isnull(v) else -v for v in values]
+
+    def objective(ps):
+        if np.any(pd.isnull(ps)):
+            return np.nan
+        return negative(evaluate([np.asarray(ps, dtype=np.float64)]))[0]
+
+    def objective_and_gradient(ps):
+        # the 2-point scheme scipy would apply itself (absolute step 1e-8, steps mirrored at the bounds): a first pass
+        # of its own helper records the points it asks for, the batch evaluates them together, a second pass runs on
+        # the table of their values -- points and arithmetic are scipy's
+        ps = np.asarray(ps, dtype=np.float64)
+        if np.any(pd.isnull(ps)):
+            return np.nan, np.full(len(ps), np.nan)
+        asked = []
+        _approx_derivative(lambda x: asked.append(np.array(x, dtype=np.float64)) or 0.0, ps, method='2-point',
+                           abs_step=1e-8, f0=0.0, bounds=(lower, upper))
+        values = negative(evaluate([ps] + asked))
+        table = {x.tobytes(): v for x, v in zip(asked, values[1:])}
+        gradient = _approx_derivative(lambda x: table[np.asarray(x, dtype=np.float64).tobytes()], ps,
+                                      method='2-point', abs_step=1e-8, f0=values[0], bounds=(lower, upper))
+        return values[0], gradient
+
+    frequencies_free = isinstance(model, ModelWithFrequencies) and model._optimise_frequencies
+    start_current = model.get_optimised_parameters()
+    start_observed = start_current
+    if frequencies_free:
+        model.frequencies = np.maximum(observed_frequencies, 1e-10) if np.any(observed_frequencies <= 0) \
+            else observed_frequencies
+        start_observed = model.get_optimised_parameters()
+    lnl_current = -objective(start_current)
+    lnl_observed = -objective(start_observed) if frequencies_free else lnl_current
+    to_beat = max(lnl_current, lnl_observed)
+    batched = batched_gradients_available()
+    for attempt in range(100):
+        if attempt == 0:
+            x0 = start_current
+        elif attempt == 1 and frequencies_free:
+            x0 = start_observed
+        else:
+            x0 = rng.uniform(lower, upper)
+        if batched:
+            found = minimize(objective_and_gradient, x0=x0, method='L-BFGS-B', bounds=bounds, jac=True)
+        else:
+            found = minimize(objective, x0=x0, method='L-BFGS-B', bounds=bounds)
+        if found.success and not np.any(np.isnan(found.x)) and -found.fun >= to_beat:
+            model.set_params_from_optimised(found.x)
+            return -found.fun
+    model.set_params_from_optimised(start_current if lnl_current >= lnl_observed else start_observed)
+    return to_beat
+
+
+def fit_parameters(character, model, observed_frequencies, evaluate, rng):
+    """
+    Likelihood at the given parameters, then -- if anything is free -- the scaling / smoothing factors alone, then all
+    free parameters together (the two stages of pastml/ml.py:865-920).  Returns ln L at the optimum.
+    """
+    from pastml_amd.ml import PastMLLikelihoodError
+    logger = logging.getLogger('pastml')
+    trouble = 'Failed to {} the likelihood for your tree, please check that you do not have contradicting {} ' \
+              'states specified for internal tree nodes, ' \
+              'and if not - submit a bug at https://github.com/evolbioinfo/pastml/issues'
+
+    def report(title, text, lnl):
+        logger.debug('{} for {}:\n{}{}'.format(title, character, text, '\tlog likelihood:\t{:.6f}'.format(lnl)))
+
+    def evaluate_vectors(vectors):
+        points = []
+        for ps in vectors:
+            model.set_params_from_optimised(ps)
+            points.append((model.kernel_spec(), model.rate_params()))
+        return evaluate(points)
+
+    lnl = float(evaluate([(model.kernel_spec(), model.rate_params())])[0])
+    if np.isnan(lnl):
+        raise PastMLLikelihoodError(trouble.format('calculate', character))
+    if not model.get_num_params():
+        report('All the parameters are fixed', model._print_parameters(), lnl)
+        return lnl
+    report('Initial values for parameter optimisation', model._print_parameters(), lnl)
+    if not model.basic_params_fixed():
+        model.fix_extra_params()
+        try:
+            lnl = search_parameters(model, observed_frequencies, evaluate_vectors, rng)
+        finally:
+            model.unfix_extra_params()
+        if np.isnan(lnl) or lnl == -np.inf:
+            raise PastMLLikelihoodError(trouble.format('optimise', character))
+        if not model.extra_params_fixed():
+            report('Pre-optimised basic parameters', model._print_basic_parameters(), lnl)
+    if not model.extra_params_fixed():
+        lnl = search_parameters(model, observed_frequencies, evaluate_vectors, rng)
+        if np.isnan(lnl) or lnl == -np.inf:
+            raise PastMLLikelihoodError(trouble.format('calculate', character))
+    report('Optimised parameters', model._print_parameters(), lnl)
+    return lnl
+
+
+# =====================================================================================================================
+# ml_acr for a group of characters
+# =====================================================================================================================
+class Task(object):
+    """One character of a run: what pastml.ml.ml_acr takes as arguments."""
+
+    def __init__(self, character, method, model, observed_frequencies):
+        self.character, self.method, self.model = character, method, model
+        self.observed_frequencies = observed_frequencies
+
+    @property
+    def group_key(self):
+        return len(self.model.states), self.model.kernel_spec()['kind'], self.method
+
+
+def likelihood_error(flat, e):
+    """The reference's message for a zero likelihood (pastml/ml.py:139-145) from the node ids the device reports."""
+    from pastml_amd.ml import PastMLLikelihoodError
+    name = (lambda i: flat.nodes[i].name) if flat.nodes is not None else str
+    return PastMLLikelihoodError("The parent node {} and its child node {} have non-intersecting states, "
+                                 "and are connected by a zero-length ({:g}) branch. "
+                                 "This creates a zero likelihood value. "
+                                 "To avoid this issue check the restrictions on these node states "
+                                 "and/or use a smoothing factor (tau).".format(name(e.parent), name(e.child),
+                                                                               flat.dist[e.child]))
+
+
+def optimise_group(batch, tasks):
+    """Parameters of every character of the batch, all optimisers advancing together (SweepServer).  Returns ln L [m]."""
+    m = len(tasks)
+    batch.open_optimiser([block_width(t.model) for t in tasks])
+    server = SweepServer(batch, range(m))
+    # restart points come from per-character generators seeded, in character order, from numpy's global one: the
+    # optimisers run concurrently, a shared generator would hand its draws out in arrival order
+    seeds = np.random.randint(0, 2 ** 31 - 1, size=m)
+    lnl = np.full(m, np.nan)
+    errors = {}
+
+    def work(c):
+        t = tasks[c]
+        try:
+            lnl[c] = fit_parameters(t.character, t.model, t.observed_frequencies,
+                                    lambda points: server.evaluate(c, points), np.random.RandomState(seeds[c]))
+        except BaseException as e:  # delivered to the caller after all optimisers are done
+            errors[c] = e
+        finally:
+            server.finish(c)
+
+    if m == 1:
+        work(0)
+    else:
+        threads = [threading.Thread(target=work, args=(c,), name='pastml-opt-{}'.format(c)) for c in range(m)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+    hip.release_engine(batch._opt['engine'])
+    batch._opt = None
+    if errors:
+        e = errors[min(errors)]
+        raise likelihood_error(batch.flat, e) if isinstance(e, LikelihoodError) else e
+    return lnl, server.rounds
+
+
+def reconstruct(batch, tasks, lnl, force_joint=True):
+    """
+    Everything of pastml/ml.py:640-750 after the parameters are known, for all characters of the batch at once (they
+    share the prediction method): joint sweep + back-trace, marginal pass, MAP and MPPA selections with their
+    restricted likelihoods; results and node features as the reference leaves them.
+    Returns one list of result dictionaries per character.
+    """
+    from pastml_amd import ml
+    from pastml_amd import get_personalized_feature_name as feature_name, CHARACTER, METHOD, NUM_SCENARIOS, \
+        NUM_UNRESOLVED_NODES, NUM_STATES_PER_NODE, PERC_UNRESOLVED, STATES
+    logger = logging.getLogger('pastml')
+    flat, m, k = batch.flat, batch.m, batch.k
+    method = tasks[0].method
+    models = [t.model for t in tasks]
+    current = [{ml.LOG_LIKELIHOOD: float(lnl[c]), CHARACTER: t.character, METHOD: method, ml.MODEL: t.model,
+                STATES: t.model.states} for c, t in enumerate(tasks)]
+    results = [[] for _ in tasks]
+
+    def emit(which):
+        # the selected states become the character's node feature; a copy of the result as it stands is reported
+        if which != method and not ml.is_meta_ml(method):
+            return
+        for c, t in enumerate(tasks):
+            name = t.character if which == method else feature_name(t.character, which)
+            flat.set_column(name, StateSetColumn(batch.masks[c].copy(), t.model.states))
+            res = current[c].copy()
+            res[CHARACTER], res[METHOD] = name, which
+            results[c].append(res)
+
+    def note_restricted(which, values):
+        for c, t in enumerate(tasks):
+            logger.debug('Log likelihood for {} after {} state selection:\t{:.6f}'.format(t.character, which, values[c]))
+            current[c][ml.RESTRICTED_LOG_LIKELIHOOD_FORMAT_STR.format(which)] = float(values[c])
+
+    try:
+        if method != ml.MAP:
+            note_restricted(ml.JOINT, batch.bottom_up(models, is_marginal=False, alter=True))
+            joint = batch.joint_states()
+            batch.masks = one_hot_words(joint, k)
+            for c, t in enumerate(tasks):
+                flat.set_column(feature_name(t.character, ml.JOINT_STATE), ArrayColumn(joint[c], convert=int))
+            emit(ml.JOINT)
+
+        if ml.is_marginal(method):
+            batch.initialize_allowed_states()
+            altered = batch.alter(np.array([0 == mdl.tau for mdl in models], dtype=bool))
+            batch.bottom_up(models, is_marginal=True, alter=False)
+            posterior, lh_sum, lh_sf = batch.top_down_marginals()
+            order = np.arange(flat.n_nodes) if len(flat.roots) == 1 else \
+                np.lexsort((np.arange(flat.n_nodes), flat.tree_id))   # tree by tree, level order each (ml.py:498-502)
+            names = [flat.nodes[i].name for i in order] if flat.nodes is not None else list(order)
+            for c, t in enumerate(tasks):
+                current[c][ml.MARGINAL_PROBABILITIES] = pd.DataFrame(posterior[c][order], index=names,
+                                                                     columns=t.model.states)
+            batch.unalter(altered)
+            lh = posterior * lh_sum[:, :, None]
+
+            def restrict_saved():
+                # marginal likelihoods of nodes that were ever altered count only inside their own saved masks
+                # (ml.py:541-542, 593-594)
+                if batch.has_init.any():
+                    lh[batch.has_init] *= masks_from_words(batch.init_masks[batch.has_init], k)
+
+            restrict_saved()
+            batch.select('MAP')
+            note_restricted(ml.MAP, batch.bottom_up(models, is_marginal=True, alter=True))
+            emit(ml.MAP)
+
+            if method == ml.MPPA or ml.is_meta_ml(method):
+                restrict_saved()   # the restricted-MAP sweep may have saved new masks (ml.py:675-680 before :541)
+                kept = batch.select('MPPA', force_joint=force_joint)
+                for c, t in enumerate(tasks):
+                    n_nodes = t.model.forest_stats.num_nodes
+                    scenarios = 1
+                    for n_kept in kept[c][kept[c] > 1].tolist():
+                        scenarios *= n_kept
+                    unresolved = int((kept[c] > 1).sum())
+                    per_node = int(kept[c].sum()) / n_nodes
+                    current[c].update({NUM_SCENARIOS: scenarios, NUM_UNRESOLVED_NODES: unresolved,
+                                       NUM_STATES_PER_NODE: per_node, PERC_UNRESOLVED: unresolved * 100 / n_nodes})
+                    logger.debug('{} node{} unresolved ({:.2f}%) for {} by {}, i.e. {:.4f} state{} per node in average.'
+                                 .format(unresolved, 's are' if unresolved != 1 else ' is', unresolved * 100 / n_nodes,
+                                         t.character, ml.MPPA, per_node, 's' if per_node > 1 else ''))
+                note_restricted(ml.MPPA, batch.bottom_up(models, is_marginal=True, alter=True))
+                emit(ml.MPPA)
+
+            for c, t in enumerate(tasks):
+                flat.set_column(feature_name(t.character, ml.LH), ArrayColumn(lh[c]))
+                flat.set_column(feature_name(t.character, ml.LH_SF), ArrayColumn(lh_sf[c], convert=float))
+    except LikelihoodError as e:
+        raise likelihood_error(flat, e)
+
+    for c, t in enumerate(tasks):
+        flat.set_column(feature_name(t.character, ml.ALLOWED_STATES), MaskColumn(batch.masks[c].copy(), k))
+    return results
+
+
+# bytes of device memory per column and node, generously: bottom-up vector, posterior, arg-max rows, scalars
+def _column_bytes(flat, k, widths):
+    ks = k + (k & 1)
+    return flat.n_nodes * ((17 * ks + 96) + sum(widths) / max(1, len(widths)) * (8 * ks + 64))
+
+
+def run_tasks(forest, tasks, force_joint=True, device=None):
+    """
+    ml_acr for a list of Tasks on one forest.  Characters are grouped by (number of states, model family, prediction
+    method); a group becomes one CharacterBatch -- or several, if the device memory does not hold all of its columns
+    at once.  Returns one list of result dictionaries per task, in task order.
+    """
+    if isinstance(forest, TreeNode):
+        forest = [forest]
+    flat = get_flat_forest(forest)
+    groups = {}
+    for i, t in enumerate(tasks):
+        groups.setdefault(t.group_key, []).append(i)
+    out = [None] * len(tasks)
+    stats = dict(groups=0, rounds=0, sweeps=0)
+    for key, members in groups.items():
+        k = key[0]
+        widths = [block_width(tasks[i].model) for i in members]
+        per_char = _column_bytes(flat, k, widths)
+        with hip.BareContext(device) as probe:
+            _, free = probe.memory()
+        chunk = max(1, min(len(members), 4096, int(0.6 * free / max(1.0, per_char))))
+        for a in range(0, len(members), chunk):
+            part = members[a:a + chunk]
+            group = [tasks[i] for i in part]
+            with CharacterBatch(flat, k, len(group), device=device) as batch:
+                for c, t in enumerate(group):
+                    batch.set_annotation(c, *annotation_words(flat, t.character, t.model.states))
+                batch.initialize_allowed_states()
+                lnl, rounds = optimise_group(batch, group)
+                res = reconstruct(batch, group, lnl, force_joint=force_joint)
+                stats['groups'] += 1
+                stats['rounds'] += rounds
+                stats['sweeps'] += batch.n_sweeps
+            for i, r in zip(part, res):
+                out[i] = r
+    run_tasks.last_stats = stats
+    return out

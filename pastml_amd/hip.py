@@ -42,10 +42,11 @@ class HipError(RuntimeError):
 class ZeroLikelihoodError(HipError):
     """PML_ZERO_LIKELIHOOD: carries, per column, the (parent, child) node ids (or -1)."""
 
-    def __init__(self, message, err_parent, err_child):
+    def __init__(self, message, err_parent, err_child, loglik=None):
         HipError.__init__(self, PML_ZERO_LIKELIHOOD, message)
         self.err_parent = err_parent
         self.err_child = err_child
+        self.loglik = loglik   # the log-likelihoods of all columns (the failing ones are not finite)
 
 
 _c_int32_p = ctypes.POINTER(ctypes.c_int32)
@@ -303,6 +304,12 @@ class BareContext(object):
     def set_option(self, option, value):
         _check(self._lib.pml_ctx_set_option(self._ctx, option, 1 if value else 0))
 
+    def memory(self):
+        """(bytes of device memory held by this context, bytes free on its device)."""
+        held, free = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        _check(self._lib.pml_ctx_memory(self._ctx, ctypes.byref(held), ctypes.byref(free)))
+        return held.value, free.value
+
     def comm_init(self, rank, world, unique_id=None):
         """Attaches a communicator (RCCL for world > 1; unique_id: the 128 bytes of rank 0's comm_unique_id())."""
         buf = None
@@ -373,11 +380,6 @@ class Engine(BareContext):
             raise
 
     # ------------------------------------------------------------------------------------------------------------------
-    def memory(self):
-        held, free = ctypes.c_uint64(0), ctypes.c_uint64(0)
-        _check(self._lib.pml_ctx_memory(self._ctx, ctypes.byref(held), ctypes.byref(free)))
-        return held.value, free.value
-
     # ------------------------------------------------------------------------------------------------------------------
     def set_masks(self, masks, col_begin=0):
         """masks: 0/1 array [n, N, k] (or [N, k] for one column)."""
@@ -388,6 +390,23 @@ class Engine(BareContext):
             raise ValueError('masks must be [cols, {}, {}], got {}'.format(self.n_nodes, self.k, masks.shape))
         words = pack_masks(masks, self.k)
         _check(self._lib.pml_masks_upload(self._ctx, col_begin, col_begin + len(masks), _ptr(words, ctypes.c_uint64)))
+
+    def set_mask_words(self, words, col_begin=0):
+        """Packed masks: uint64 [n, N, W] (bit s of word s // 64 = state s)."""
+        words = _as(words, np.uint64)
+        if words.ndim == 2:
+            words = words[None]
+        if words.shape[1:] != (self.n_nodes, (self.k + 63) // 64):
+            raise ValueError('mask words must be [cols, {}, {}], got {}'.format(self.n_nodes, (self.k + 63) // 64,
+                                                                               words.shape))
+        _check(self._lib.pml_masks_upload(self._ctx, col_begin, col_begin + len(words), _ptr(words, ctypes.c_uint64)))
+
+    def set_initial_mask_words(self, words, col_begin=0):
+        words = _as(words, np.uint64)
+        if words.ndim == 2:
+            words = words[None]
+        _check(self._lib.pml_masks_initial_upload(self._ctx, col_begin, col_begin + len(words),
+                                                  _ptr(words, ctypes.c_uint64)))
 
     def set_initial_masks(self, masks, col_begin=0):
         """Masks before zero-branch alteration (joint sweeps only); None clears them."""
@@ -477,7 +496,7 @@ class Engine(BareContext):
         status = self._lib.pml_bottom_up(self._ctx, 1 if is_marginal else 0, _ptr(lnl, ctypes.c_double),
                                          _ptr(ep, ctypes.c_int32), _ptr(ec, ctypes.c_int32))
         if status == PML_ZERO_LIKELIHOOD:
-            raise ZeroLikelihoodError(self._lib.pml_last_error().decode(), ep, ec)
+            raise ZeroLikelihoodError(self._lib.pml_last_error().decode(), ep, ec, lnl)
         _check(status)
         return lnl
 
@@ -497,21 +516,26 @@ class Engine(BareContext):
         _check(self._lib.pml_joint_backtrace(self._ctx, None if out is None else _ptr(out, ctypes.c_int32)))
         return out
 
-    def select_states(self, method, force_joint=False, lh_masks=None):
+    def select_states(self, method, force_joint=False, lh_masks=None, packed=False):
         """
         MAP ('MAP') or MPPA ('MPPA') selection on the device from the last marginals; lh_masks: optional 0/1 array
-        [n_cols, N, k] multiplied into the marginal likelihoods first.  The selected masks become the columns' masks.
-        Returns (masks [n_cols, N, k] int8, n_states [n_cols, N]).
+        [n_cols, N, k] (or, with packed=True, uint64 words [n_cols, N, W]) multiplied into the marginal likelihoods
+        first.  The selected masks become the columns' masks.
+        Returns (masks [n_cols, N, k] int8 -- packed: the words [n_cols, N, W] --, n_states [n_cols, N]).
         """
         W = (self.k + 63) // 64
         words = np.empty((self.n_cols, self.n_nodes, W), dtype=np.uint64)
         nsel = np.empty((self.n_cols, self.n_nodes), dtype=np.int32)
-        lm = None if lh_masks is None else pack_masks(np.asarray(lh_masks).reshape(self.n_cols, self.n_nodes, self.k),
-                                                      self.k)
+        if lh_masks is None:
+            lm = None
+        elif packed:
+            lm = _as(lh_masks, np.uint64).reshape(self.n_cols, self.n_nodes, W)
+        else:
+            lm = pack_masks(np.asarray(lh_masks).reshape(self.n_cols, self.n_nodes, self.k), self.k)
         _check(self._lib.pml_select_states(self._ctx, {'MAP': 0, 'MPPA': 1}[method], 1 if force_joint else 0,
                                            None if lm is None else _ptr(lm, ctypes.c_uint64),
                                            _ptr(words, ctypes.c_uint64), _ptr(nsel, ctypes.c_int32)))
-        return unpack_masks(words, self.k), nsel
+        return (words if packed else unpack_masks(words, self.k)), nsel
 
     def marginal_counts(self, n_repetitions, seed, col=0):
         """

@@ -13,19 +13,12 @@ What stays on the host, as SURVEY.md section 8a prescribes: the allowed-state ma
 (ml.py:293-428), the scipy L-BFGS-B driver (:174-237), the per-node state selection rules (:505-595) and the
 bookkeeping of results.
 """
-import logging
-import os
-
 import numpy as np
 import pandas as pd
-from scipy.optimize import minimize
-from scipy.optimize._numdiff import approx_derivative
 
-from pastml_amd import get_personalized_feature_name, CHARACTER, METHOD, NUM_SCENARIOS, NUM_UNRESOLVED_NODES, \
-    NUM_STATES_PER_NODE, PERC_UNRESOLVED, STATES
+from pastml_amd import get_personalized_feature_name
 from pastml_amd import hip
-from pastml_amd.models import ModelWithFrequencies
-from pastml_amd.tree import TreeNode, FlatForest, get_flat_forest
+from pastml_amd.tree import TreeNode, get_flat_forest
 
 LOG_LIKELIHOOD = 'log_likelihood'
 RESTRICTED_LOG_LIKELIHOOD_FORMAT_STR = '{}_restricted_{{}}'.format(LOG_LIKELIHOOD)
@@ -95,25 +88,22 @@ class PastMLLikelihoodError(Exception):
 def zero_branch_tops(flat):
     """
     top[n] = the highest node reachable from n through zero-length branches (the representative of n's
-    zero-distance cluster, ml.py:321-349).  Parents precede children in id order.
+    zero-distance cluster, ml.py:321-349).
     """
-    top = np.arange(flat.n_nodes, dtype=np.int64)
-    zero = (flat.dist == 0) & (flat.parent >= 0)
-    for lvl in range(1, flat.n_td_levels):
-        a, b = flat.td_offsets[lvl], flat.td_offsets[lvl + 1]
-        ids = np.arange(a, b)[zero[a:b]]
-        top[ids] = top[flat.parent[ids]]
-    return top
+    from pastml_amd.batch import zero_clusters
+    return zero_clusters(flat).top
 
 
 class ForestProblem(object):
     """
-    Host mirror of what the reference keeps in node features for one character: allowed-state masks
-    (``<character>_ALLOWED_STATES``), the masks saved by zero-branch alteration (``...ALLOWED_STATES.initial``),
-    plus the device engine holding the flattened forest.
+    One character on one forest: a single-column view of :class:`pastml_amd.batch.CharacterBatch` (which holds the
+    allowed-state masks of the reference's ``<character>_ALLOWED_STATES`` features as packed words, the masks saved by
+    zero-branch alteration, and the device context) with the masks exposed as 0/1 arrays [N, k].  The stand-alone
+    sweep functions of this module and ``marginal_counts`` work on it; ``ml_acr`` uses the batch directly.
     """
 
     def __init__(self, forest, character, states, flat=None, device=None):
+        from pastml_amd.batch import CharacterBatch
         if isinstance(forest, TreeNode):
             forest = [forest]
         self.forest = forest
@@ -123,203 +113,77 @@ class ForestProblem(object):
         self.flat = flat if flat is not None else get_flat_forest(forest)
         self.nodes = self.flat.nodes
         self.N = self.flat.n_nodes
-        self._device = device
-        self._engine = None
-        self.masks = np.ones((self.N, self.k), dtype=np.int8)
-        self.init_masks = np.zeros((self.N, self.k), dtype=np.int8)
-        self.has_init = np.zeros(self.N, dtype=bool)
-        self.annotated = np.zeros(self.N, dtype=bool)
-        self._top = None
-        self._uploaded_masks = None
-        self._uploaded_model = None
-        self.n_sweeps = 0
+        self.batch = CharacterBatch(self.flat, self.k, 1, device=device)
+
+    # the reference's 0/1 arrays, converted on access
+    @property
+    def masks(self):
+        return hip.unpack_masks(self.batch.masks[0], self.k)
+
+    @masks.setter
+    def masks(self, value):
+        self.batch.masks[0] = hip.pack_masks(value, self.k)
+
+    @property
+    def init_masks(self):
+        return hip.unpack_masks(self.batch.init_masks[0], self.k)
+
+    @property
+    def has_init(self):
+        return self.batch.has_init[0]
+
+    @property
+    def annotated(self):
+        return self.batch.annotated[0]
+
+    @annotated.setter
+    def annotated(self, value):
+        self.batch.annotated[0] = value
+
+    @property
+    def n_sweeps(self):
+        return self.batch.n_sweeps
 
     @property
     def engine(self):
-        """The device context, created on first use (mask bookkeeping alone needs no GPU)."""
-        if self._engine is None:
-            self._engine = hip.acquire_engine(self.flat, 1, self.k, device=self._device)
-        return self._engine
+        return self.batch.engine
 
     def close(self):
-        if self._engine is not None:
-            hip.release_engine(self._engine)
-            self._engine = None
-        for slot in self.__dict__.pop('_batch_engines', {}).values():
-            hip.release_engine(slot['engine'])
+        self.batch.close()
 
     # ------------------------------------------------------------------------------------------------ masks
     def initialize_allowed_states(self):
-        """
-        Masks from the ``character`` feature of the nodes (a set of state names): annotated nodes allow their states,
-        everything else (and empty annotations) allows all states (ml.py:293-318).  Also records which nodes
-        "have a state" in the sense of ml.py:329-331.
-        """
-        state2index = dict(zip(self.states, range(self.k)))
-        masks = np.ones((self.N, self.k), dtype=np.int8)
-        annotated = np.zeros(self.N, dtype=bool)
-        character = self.character
-        for i, node in enumerate(self.nodes):
-            value = getattr(node, character, None)
-            if value is not None and value != '':
-                annotated[i] = True
-            if value:
-                masks[i] = 0
-                for state in value:
-                    masks[i, state2index[state]] = 1
-        self.masks = masks
-        self.annotated = annotated
+        """Masks from the ``character`` feature of the nodes (ml.py:293-318), and which nodes "have a state"."""
+        from pastml_amd.batch import annotation_words
+        self.batch.set_annotation(0, *annotation_words(self.flat, self.character, self.states))
+        self.batch.initialize_allowed_states()
 
     def alter_zero_node_allowed_states(self):
-        """
-        Annotated nodes joined by zero-length branches whose masks have no common state all get the union of
-        their masks; the previous masks are remembered (ml.py:352-387).  Returns the ids of the altered nodes.
-        """
-        if self._top is None:
-            self._top = zero_branch_tops(self.flat)
-        ids = np.flatnonzero(self.annotated)
-        if len(ids) < 2:
-            return np.zeros(0, dtype=np.int64)
-        tops = self._top[ids]
-        order = np.argsort(tops, kind='stable')
-        ids, tops = ids[order], tops[order]
-        bounds = np.flatnonzero(np.concatenate(([True], tops[1:] != tops[:-1], [True])))
-        altered = []
-        for a, b in zip(bounds[:-1], bounds[1:]):
-            if b - a < 2:
-                continue
-            members = ids[a:b]
-            m = self.masks[members]
-            if m.sum(axis=0).max() == len(members):
-                continue
-            union = (m.sum(axis=0) > 0).astype(np.int8)
-            self.init_masks[members] = m
-            self.has_init[members] = True
-            self.masks[members] = union
-            altered.extend(members.tolist())
-        return np.array(altered, dtype=np.int64)
+        """Zero-branch alteration (ml.py:352-387); returns the ids of the altered nodes."""
+        return np.flatnonzero(self.batch.alter(np.ones(1, dtype=bool))[0])
 
     def unalter_zero_node_allowed_states(self, altered):
         """masks & saved masks, or the saved ones if nothing is left (ml.py:390-405)."""
-        for n in altered:
-            both = self.masks[n] & self.init_masks[n]
-            self.masks[n] = both if np.any(both > 0) else self.init_masks[n]
+        flags = np.zeros((1, self.N), dtype=bool)
+        flags[0, np.asarray(altered, dtype=np.int64)] = True
+        self.batch.unalter(flags)
 
     # ------------------------------------------------------------------------------------------------ device
-    def _sync_device(self, model, masks_before_alteration=None):
-        spec = model.kernel_spec()
-        key = (spec['kind'], model.rate_params(), tuple(np.asarray(v).tobytes() if isinstance(v, np.ndarray) else v
-                                                         for k_, v in sorted(spec.items())))
-        if key != self._uploaded_model:
-            self.engine.set_models([model])
-            self._uploaded_model = key
-        if self._uploaded_masks is None or not np.array_equal(self._uploaded_masks, self.masks):
-            self.engine.set_masks(self.masks)
-            self._uploaded_masks = self.masks.copy()
-        self.engine.set_initial_masks(masks_before_alteration)
-
-    def _raise_likelihood_error(self, e):
-        parent, child = int(e.err_parent[0]), int(e.err_child[0])
-        raise PastMLLikelihoodError("The parent node {} and its child node {} have non-intersecting states, "
-                                    "and are connected by a zero-length ({:g}) branch. "
-                                    "This creates a zero likelihood value. "
-                                    "To avoid this issue check the restrictions on these node states "
-                                    "and/or use a smoothing factor (tau)."
-                                    .format(self.nodes[parent].name, self.nodes[child].name, self.flat.dist[child]))
-
     def bottom_up_loglikelihood(self, model, is_marginal=True, alter=True):
-        """
-        Sum over the trees of the forest of get_bottom_up_loglikelihood (ml.py:82-121): optional alteration of the
-        masks, one device sweep, restoration of the masks (marginal) -- for the joint sweep the arg-max tables of the
-        altered nodes are rewritten on the device instead (ml.py:115-119).
-        """
-        altered = np.zeros(0, dtype=np.int64)
-        before = None
-        if 0 == model.tau and alter:
-            before = self.masks.copy()
-            altered = self.alter_zero_node_allowed_states()
-        self._sync_device(model, before if (not is_marginal and len(altered)) else None)
-        self.n_sweeps += 1
+        """Sum over the trees of the forest of get_bottom_up_loglikelihood (ml.py:82-121)."""
+        from pastml_amd.batch import LikelihoodError, likelihood_error
         try:
-            lnl = self.engine.bottom_up(is_marginal)[0]
-        except hip.ZeroLikelihoodError as e:
-            self._raise_likelihood_error(e)
-        if len(altered) and is_marginal:
-            self.unalter_zero_node_allowed_states(altered)
-        return float(lnl)
-
-    def batch_loglikelihoods(self, model, parameter_vectors):
-        """
-        Marginal log-likelihoods (alter=True semantics) for several parameter vectors of the optimiser at once:
-        one device column per vector, ONE bottom-up sweep for all of them.  This is what makes the finite-difference
-        gradient of the optimiser (pastml/ml.py:231, scipy's 2-point scheme: n_params + 1 evaluations) cost one launch
-        sequence instead of n_params + 1.  Every column is computed independently and deterministically, so the values
-        are bit-identical to evaluating the vectors one by one.  The model is left at the last vector.
-        """
-        C = len(parameter_vectors)
-        cache = self.__dict__.setdefault('_batch_engines', {})
-        if C not in cache:
-            cache[C] = dict(engine=hip.acquire_engine(self.flat, C, self.k, device=self._device), masks=[None] * C)
-        slot = cache[C]
-        engine = slot['engine']
-        specs, variants = [], []
-        for ps in parameter_vectors:
-            model.set_params_from_optimised(ps)
-            specs.append((model.kernel_spec(), model.rate_params()))
-            variants.append(0 == model.tau)
-        # masks: altered (tau == 0) or as they are; the alteration does not depend on the other parameters, only on
-        # the masks themselves, so it is computed once per state of the masks (the optimiser calls this hundreds of
-        # times between two changes of them) and the columns remember which version they hold
-        plain = self.masks
-        plain_key = hash(plain.tobytes())
-        altered_masks, altered_key = None, None
-        if any(variants):
-            memo = self.__dict__.get('_alter_memo')
-            if memo is not None and memo[0] == plain_key:
-                altered_masks, altered_key = memo[1], memo[2]
-            else:
-                keep = (self.masks.copy(), self.init_masks.copy(), self.has_init.copy())
-                altered = self.alter_zero_node_allowed_states()
-                altered_masks = self.masks.copy()
-                altered_key = hash(altered_masks.tobytes())
-                # the evaluation itself leaves masks as they were (marginal sweeps un-alter, ml.py:115-117), but the
-                # saved '.initial' masks stay, exactly as after a sequence of single evaluations
-                self.masks = keep[0]
-                if not len(altered):
-                    self.init_masks, self.has_init = keep[1], keep[2]
-                self._alter_memo = (plain_key, altered_masks, altered_key)
-        for col, variant in enumerate(variants):
-            wanted, wanted_key = (altered_masks, altered_key) if variant else (plain, plain_key)
-            if slot['masks'][col] != wanted_key:
-                engine.set_masks(wanted, col_begin=col)
-                slot['masks'][col] = wanted_key
-        engine.set_models(specs)
-        self.n_sweeps += C
-        try:
-            return engine.bottom_up(True)
-        except hip.ZeroLikelihoodError as e:
-            first = int(np.flatnonzero(e.err_child >= 0)[0])
-            e.err_parent, e.err_child = e.err_parent[first:first + 1], e.err_child[first:first + 1]
-            self._raise_likelihood_error(e)
+            return float(self.batch.bottom_up([model], is_marginal=is_marginal, alter=alter)[0])
+        except LikelihoodError as e:
+            raise likelihood_error(self.flat, e)
 
     def select_on_device(self, method, force_joint=False):
-        """
-        MAP / MPPA selection (ml.py:505-595) by ``pml_select_states`` from the posteriors of the last marginal pass;
-        the marginal likelihoods of nodes with saved ('.initial') masks are restricted to them first.  The selected
-        masks become both the device's and this object's masks.  Returns the number of selected states per node.
-        """
-        lh_masks = None
-        if np.any(self.has_init):
-            lh_masks = np.ones((1, self.N, self.k), dtype=np.int8)
-            lh_masks[0, self.has_init] = self.init_masks[self.has_init]
-        sel, nsel = self.engine.select_states(method, force_joint=force_joint, lh_masks=lh_masks)
-        self.masks = sel[0]
-        self._uploaded_masks = self.masks.copy()
-        return nsel[0].astype(np.int64)
+        """MAP / MPPA selection (ml.py:505-595) on the device; returns the number of selected states per node."""
+        return self.batch.select(method, force_joint=force_joint)[0]
 
     def joint_states(self):
         """Joint state of every node after a joint sweep (ml.py:598-622)."""
-        return self.engine.joint_backtrace()[0].astype(np.int64)
+        return self.batch.joint_states()[0]
 
     def top_down_marginals(self):
         """
@@ -327,10 +191,9 @@ class ForestProblem(object):
         Returns (posterior [N, k], lh [N, k], lh_sf [N]) where lh / lh_sf play the role of the reference's
         LIKELIHOOD / LIKELIHOOD_SF features: log10(lh.sum()) - lh_sf is the node's total log10-likelihood.
         """
-        post, lh_sum, lh_sf = self.engine.top_down_marginals()
+        post, lh_sum, lh_sf = self.batch.top_down_marginals()
         return post[0], post[0] * lh_sum[0][:, None], lh_sf[0]
 
-    # ------------------------------------------------------------------------------------------------ row order
     def per_tree_order(self):
         """Node ids tree by tree, each in level order: the row order of the reference's probability table."""
         if len(self.flat.roots) == 1:
@@ -434,22 +297,28 @@ def _pull_masks_from_features(problem, tree, character):
     """Reads the node features into the problem's arrays (stand-alone API path)."""
     A = get_personalized_feature_name(character, ALLOWED_STATES)
     init = A + '.initial'
+    N, k = problem.N, problem.k
+    masks = np.zeros((N, k), dtype=np.int8)
+    saved = np.zeros((N, k), dtype=np.int8)
     for i, node in enumerate(problem.nodes):
-        problem.masks[i] = getattr(node, A)
+        masks[i] = getattr(node, A)
         value = getattr(node, character, None)
-        problem.annotated[i] = value is not None and value != ''
+        problem.batch.annotated[0, i] = value is not None and value != ''
         if hasattr(node, init):
-            problem.has_init[i] = True
-            problem.init_masks[i] = getattr(node, init)
+            problem.batch.has_init[0, i] = True
+            saved[i] = getattr(node, init)
+    problem.masks = masks
+    problem.batch.init_masks[0] = hip.pack_masks(saved, k)
 
 
 def _push_masks_to_features(problem, character):
     A = get_personalized_feature_name(character, ALLOWED_STATES)
     init = A + '.initial'
+    masks, saved, has = problem.masks, problem.init_masks, problem.has_init
     for i, node in enumerate(problem.nodes):
-        node.add_feature(A, problem.masks[i].astype(int))
-        if problem.has_init[i]:
-            node.add_feature(init, problem.init_masks[i].astype(int))
+        node.add_feature(A, masks[i].astype(int))
+        if has[i]:
+            node.add_feature(init, saved[i].astype(int))
 
 
 def get_bottom_up_loglikelihood(tree, character, model, is_marginal=True, alter=True):
@@ -533,132 +402,71 @@ def convert_allowed_states2feature(tree, feature, states, out_feature=None):
 
 
 # =====================================================================================================================
-# parameter optimisation
+# parameter optimisation (API of ml.py:174-237, 865-920; the procedure itself lives in pastml_amd.batch)
 # =====================================================================================================================
+
+def _single_character_evaluator(problem):
+    """evaluate(points) for the optimiser of one character: a bottom-up sweep with one column per point."""
+    from pastml_amd.batch import LikelihoodError, likelihood_error
+    batch = problem.batch
+
+    def evaluate(points):
+        out = batch.evaluate_points({0: points})[0]
+        if isinstance(out, LikelihoodError):
+            raise likelihood_error(problem.flat, out)
+        return out
+    return evaluate
+
 
 def optimize_likelihood_params(forest, character, observed_frequencies, model, problem=None):
     """
-    L-BFGS-B over the free model parameters, two deterministic starting points (current values, observed
-    frequencies), then random restarts (ml.py:174-237).  Every function evaluation is one bottom-up sweep on the GPU.
+    L-BFGS-B over the model's currently free parameters (API of ml.py:174-237); every function evaluation -- every
+    whole finite-difference gradient -- is one bottom-up sweep on the GPU.  The model is left at the optimum.
     """
+    from pastml_amd.batch import search_parameters, block_width
     own = problem is None
     if own:
         problem = ForestProblem(forest, character, model.states)
         problem.initialize_allowed_states()
     try:
-        bounds = model.get_bounds()
+        opened = problem.batch._opt is None
+        if opened:
+            problem.batch.open_optimiser([block_width(model)])
+        evaluate = _single_character_evaluator(problem)
 
-        def get_v(ps):
-            if np.any(pd.isnull(ps)):
-                return np.nan
-            model.set_params_from_optimised(ps)
-            res = problem.bottom_up_loglikelihood(model, is_marginal=True, alter=True)
-            return np.inf if pd.isnull(res) else -res
-
-        if np.any(observed_frequencies <= 0):
-            observed_frequencies = np.maximum(observed_frequencies, 1e-10)
-
-        x0_JC = model.get_optimised_parameters()
-        optimise_frequencies = isinstance(model, ModelWithFrequencies) and model._optimise_frequencies
-        x0_EFT = x0_JC
-        if optimise_frequencies:
-            model.frequencies = observed_frequencies
-            x0_EFT = model.get_optimised_parameters()
-        log_lh_JC = -get_v(x0_JC)
-        log_lh_EFT = log_lh_JC if not optimise_frequencies else -get_v(x0_EFT)
-
-        best_log_lh = max(log_lh_JC, log_lh_EFT)
-
-        lower, upper = bounds[:, 0], bounds[:, 1]
-
-        def get_v_and_gradient(ps):
-            """
-            Value and the 2-point finite-difference gradient scipy's L-BFGS-B would compute itself (abs_step 1e-8,
-            steps flipped at the bounds), with all n_params + 1 likelihoods evaluated in one batched device sweep.
-            scipy's own approx_derivative runs twice -- first to record the points it asks for, then on the table of
-            their values -- so points and arithmetic are scipy's, and the iterates are those of the unbatched run.
-            """
-            ps = np.asarray(ps, dtype=np.float64)
-            if np.any(pd.isnull(ps)):
-                return np.nan, np.full(len(ps), np.nan)
-            asked = []
-
-            def record(x):
-                asked.append(np.array(x, dtype=np.float64))
-                return 0.0
-
-            approx_derivative(record, ps, method='2-point', abs_step=1e-8, f0=0.0, bounds=(lower, upper))
-            values = problem.batch_loglikelihoods(model, [ps] + asked)
-            values = [np.inf if pd.isnull(v) else -v for v in values]
-            table = {x.tobytes(): v for x, v in zip(asked, values[1:])}
-            gradient = approx_derivative(lambda x: table[np.asarray(x, dtype=np.float64).tobytes()], ps,
-                                         method='2-point', abs_step=1e-8, f0=values[0], bounds=(lower, upper))
-            model.set_params_from_optimised(ps)
-            return values[0], gradient
-
-        batched = os.environ.get('PASTML_AMD_BATCHED_OPTIMISER', '1') != '0'
-
-        for i in range(100):
-            if i == 0:
-                vs = x0_JC
-            elif optimise_frequencies and i == 1:
-                vs = x0_EFT
-            else:
-                vs = np.random.uniform(bounds[:, 0], bounds[:, 1])
-            if batched:
-                fres = minimize(get_v_and_gradient, x0=vs, method='L-BFGS-B', bounds=bounds, jac=True)
-            else:
-                fres = minimize(get_v, x0=vs, method='L-BFGS-B', bounds=bounds)
-            if fres.success and not np.any(np.isnan(fres.x)):
-                if -fres.fun >= best_log_lh:
-                    model.set_params_from_optimised(fres.x)
-                    return -fres.fun
-        model.set_params_from_optimised(x0_JC if log_lh_JC >= log_lh_EFT else x0_EFT)
-        return best_log_lh
+        def evaluate_vectors(vectors):
+            points = []
+            for ps in vectors:
+                model.set_params_from_optimised(ps)
+                points.append((model.kernel_spec(), model.rate_params()))
+            return evaluate(points)
+        try:
+            return search_parameters(model, observed_frequencies, evaluate_vectors,
+                                     np.random.RandomState(np.random.randint(0, 2 ** 31 - 1)))
+        finally:
+            if opened:
+                hip.release_engine(problem.batch._opt['engine'])
+                problem.batch._opt = None
     finally:
         if own:
             problem.close()
 
 
 def optimise_likelihood(forest, character, model, observed_frequencies, problem=None):
-    """Initial likelihood, then basic parameters (sf, tau), then all of them (ml.py:865-920)."""
+    """Initial likelihood, then the scaling / smoothing factors, then all free parameters (API of ml.py:865-920)."""
+    from pastml_amd.batch import fit_parameters, block_width
     own = problem is None
     if own:
         problem = ForestProblem(forest, character, model.states)
     try:
         problem.initialize_allowed_states()
-        logger = logging.getLogger('pastml')
-        likelihood = problem.bottom_up_loglikelihood(model, is_marginal=True, alter=True)
-        failure = 'Failed to {} the likelihood for your tree, please check that you do not have contradicting {} ' \
-                  'states specified for internal tree nodes, ' \
-                  'and if not - submit a bug at https://github.com/evolbioinfo/pastml/issues'
-        if np.isnan(likelihood):
-            raise PastMLLikelihoodError(failure.format('calculate', character))
-        if not model.get_num_params():
-            logger.debug('All the parameters are fixed for {}:\n{}{}.'
-                         .format(character, model._print_parameters(), '\tlog likelihood:\t{:.6f}'.format(likelihood)))
-        else:
-            logger.debug('Initial values for {} parameter optimisation:\n{}{}.'
-                         .format(character, model._print_parameters(), '\tlog likelihood:\t{:.6f}'.format(likelihood)))
-            if not model.basic_params_fixed():
-                model.fix_extra_params()
-                likelihood = optimize_likelihood_params(forest=forest, character=character, model=model,
-                                                        observed_frequencies=observed_frequencies, problem=problem)
-                if np.any(np.isnan(likelihood) or likelihood == -np.inf):
-                    raise PastMLLikelihoodError(failure.format('optimise', character))
-                model.unfix_extra_params()
-                if not model.extra_params_fixed():
-                    logger.debug('Pre-optimised basic parameters for {}:\n{}{}.'
-                                 .format(character, model._print_basic_parameters(),
-                                         '\tlog likelihood:\t{:.6f}'.format(likelihood)))
-            if not model.extra_params_fixed():
-                likelihood = optimize_likelihood_params(forest=forest, character=character, model=model,
-                                                        observed_frequencies=observed_frequencies, problem=problem)
-                if np.any(np.isnan(likelihood) or likelihood == -np.inf):
-                    raise PastMLLikelihoodError(failure.format('calculate', character))
-            logger.debug('Optimised parameters for {}:\n{}{}'
-                         .format(character, model._print_parameters(), '\tlog likelihood:\t{:.6f}'.format(likelihood)))
-        return likelihood
+        problem.batch.open_optimiser([block_width(model)])
+        try:
+            return fit_parameters(character, model, observed_frequencies, _single_character_evaluator(problem),
+                                  np.random.RandomState(np.random.randint(0, 2 ** 31 - 1)))
+        finally:
+            hip.release_engine(problem.batch._opt['engine'])
+            problem.batch._opt = None
     finally:
         if own:
             problem.close()
@@ -672,110 +480,18 @@ def ml_acr(forest, character, prediction_method, model, observed_frequencies, fo
     """
     ML states on the trees, stored in node features; returns the list of result dictionaries (ml.py:640-750).
 
-    Node features written (as the reference leaves them): ``<character>`` (set of selected states),
-    ``<character>_ALLOWED_STATES``, ``<character>_JOINT_STATE`` (unless MAP), ``<character>_LIKELIHOOD`` /
-    ``_LIKELIHOOD_SF`` (marginal methods).
+    Node features written (as the reference leaves them, here as columnar features of the flattened forest):
+    ``<character>`` (set of selected states), ``<character>_ALLOWED_STATES``, ``<character>_JOINT_STATE`` (unless
+    MAP), ``<character>_LIKELIHOOD`` / ``_LIKELIHOOD_SF`` (marginal methods).  One character is a batch of one:
+    ``pastml_amd.acr.acr`` hands all characters of a run to :func:`pastml_amd.batch.run_tasks` together.
     """
+    from pastml_amd.batch import Task, run_tasks
     if ALL == prediction_method:
         raise NotImplementedError('The ALL meta-method additionally needs the parsimony methods '
                                   '(pastml/parsimony.py), which are outside the accelerated path; use ML, MPPA, '
                                   'MAP or JOINT.')
-    if isinstance(forest, TreeNode):
-        forest = [forest]
-    logger = logging.getLogger('pastml')
-    problem = ForestProblem(forest, character, model.states)
-    try:
-        likelihood = optimise_likelihood(forest=forest, character=character, model=model,
-                                         observed_frequencies=observed_frequencies, problem=problem)
-        result = {LOG_LIKELIHOOD: likelihood, CHARACTER: character, METHOD: prediction_method, MODEL: model,
-                  STATES: model.states}
-        results = []
-        nodes = problem.nodes
-        states = model.states
-        A = get_personalized_feature_name(character, ALLOWED_STATES)
-
-        def process_reconstructed_states(method):
-            if method == prediction_method or is_meta_ml(prediction_method):
-                method_character = get_personalized_feature_name(character, method) \
-                    if prediction_method != method else character
-                # convert_allowed_states2feature (ml.py:923-928)
-                for i, node in enumerate(nodes):
-                    node.add_feature(method_character, set(states[problem.masks[i].astype(bool)]))
-                res = result.copy()
-                res[CHARACTER] = method_character
-                res[METHOD] = method
-                results.append(res)
-
-        def note_restricted_likelihood(method, restricted_likelihood):
-            logger.debug('Log likelihood for {} after {} state selection:\t{:.6f}'
-                         .format(character, method, restricted_likelihood))
-            result[RESTRICTED_LOG_LIKELIHOOD_FORMAT_STR.format(method)] = restricted_likelihood
-
-        def process_restricted_likelihood_and_states(method):
-            restricted_likelihood = problem.bottom_up_loglikelihood(model, is_marginal=True, alter=True)
-            note_restricted_likelihood(method, restricted_likelihood)
-            process_reconstructed_states(method)
-
-        joint_state = None
-        if prediction_method != MAP:
-            restricted_likelihood = problem.bottom_up_loglikelihood(model, is_marginal=False, alter=True)
-            note_restricted_likelihood(JOINT, restricted_likelihood)
-            joint_state = problem.joint_states()
-            problem.masks = np.zeros((problem.N, problem.k), dtype=np.int8)
-            problem.masks[np.arange(problem.N), joint_state] = 1
-            f = get_personalized_feature_name(character, JOINT_STATE)
-            for i, node in enumerate(nodes):
-                node.add_feature(f, joint_state[i])
-            process_reconstructed_states(JOINT)
-
-        if is_marginal(prediction_method):
-            problem.initialize_allowed_states()
-            altered = np.zeros(0, dtype=np.int64)
-            if 0 == model.tau:
-                altered = problem.alter_zero_node_allowed_states()
-            problem.bottom_up_loglikelihood(model, is_marginal=True, alter=False)
-            posterior, lh, lh_sf = problem.top_down_marginals()
-            order = problem.per_tree_order()
-            result[MARGINAL_PROBABILITIES] = pd.DataFrame(posterior[order], index=[nodes[i].name for i in order],
-                                                          columns=states)
-            if len(altered):
-                problem.unalter_zero_node_allowed_states(altered)
-            # MAP (ml.py:577-595): likelihoods of nodes that were ever altered are masked by their saved masks;
-            # the selection itself runs on the device and leaves the selected masks there for the restricted sweep
-            lh[problem.has_init] *= problem.init_masks[problem.has_init]
-            problem.select_on_device('MAP')
-            process_restricted_likelihood_and_states(MAP)
-
-            if MPPA == prediction_method or is_meta_ml(prediction_method):
-                # the restricted-MAP sweep may have saved new masks (ml.py:541-542 after :675-680)
-                lh[problem.has_init] *= problem.init_masks[problem.has_init]
-                best_k = problem.select_on_device('MPPA', force_joint=force_joint)
-                num_nodes = model.forest_stats.num_nodes
-                num_scenarios = 1
-                for m in best_k[best_k > 1].tolist():
-                    num_scenarios *= m
-                result[NUM_SCENARIOS] = num_scenarios
-                result[NUM_UNRESOLVED_NODES] = int((best_k > 1).sum())
-                result[NUM_STATES_PER_NODE] = int(best_k.sum()) / num_nodes
-                result[PERC_UNRESOLVED] = result[NUM_UNRESOLVED_NODES] * 100 / num_nodes
-                logger.debug('{} node{} unresolved ({:.2f}%) for {} by {}, i.e. {:.4f} state{} per node in average.'
-                             .format(result[NUM_UNRESOLVED_NODES],
-                                     's are' if result[NUM_UNRESOLVED_NODES] != 1 else ' is',
-                                     result[PERC_UNRESOLVED], character, MPPA, result[NUM_STATES_PER_NODE],
-                                     's' if result[NUM_STATES_PER_NODE] > 1 else ''))
-                process_restricted_likelihood_and_states(MPPA)
-
-            lh_feature = get_personalized_feature_name(character, LH)
-            lh_sf_feature = get_personalized_feature_name(character, LH_SF)
-            for i, node in enumerate(nodes):
-                node.add_feature(lh_feature, lh[i])
-                node.add_feature(lh_sf_feature, lh_sf[i])
-
-        for i, node in enumerate(nodes):
-            node.add_feature(A, problem.masks[i].astype(int))
-        return results
-    finally:
-        problem.close()
+    return run_tasks(forest, [Task(character, prediction_method, model, observed_frequencies)],
+                     force_joint=force_joint)[0]
 
 
 # =====================================================================================================================

@@ -27,10 +27,106 @@ class NewickError(ValueError):
     pass
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Columnar node features.  The reference keeps everything it knows about a node in attributes of the ete3 node object
+# (annotations, allowed-state arrays, likelihood vectors, selected states: pastml/ml.py throughout) and walks the tree
+# to read or write them, once per character and feature.  Here a feature of ALL nodes of a forest is one column -- an
+# array (or a packed bit mask per node) owned by the FlatForest -- and a TreeNode only resolves ``node.<feature>`` to
+# its row when somebody asks: writing the results of a character is O(1) per feature, not O(nodes) Python calls.
+# A value set on one node with add_feature() lives in that node's __dict__ and hides the column's row for that node.
+# ---------------------------------------------------------------------------------------------------------------------
+ABSENT = object()
+# names that add_feature() ever put into some node's __dict__: FlatForest.set_column() only has to clear shadowing
+# entries for these
+_DICT_FEATURE_NAMES = set()
+
+
+class NodeColumn(object):
+    """One feature of all nodes.  get(i) returns the value of node i or ABSENT."""
+
+    absent = None  # optional bool array: rows deleted with del_feature()
+
+    def get(self, i):
+        raise NotImplementedError
+
+    def mark_absent(self, i, n_nodes):
+        if self.absent is None:
+            self.absent = np.zeros(n_nodes, dtype=bool)
+        self.absent[i] = True
+
+
+class ArrayColumn(NodeColumn):
+    """values[i] (a scalar or a row of a 2-d array); ``convert`` is applied to what is handed out."""
+
+    def __init__(self, values, convert=None):
+        self.values = values
+        self.convert = convert
+
+    def get(self, i):
+        if self.absent is not None and self.absent[i]:
+            return ABSENT
+        v = self.values[i]
+        return self.convert(v) if self.convert is not None else v
+
+
+class MaskColumn(NodeColumn):
+    """Packed allowed-state words [N, W] handed out as the reference's 0/1 int arrays of length k."""
+
+    def __init__(self, words, k):
+        self.words = words
+        self.k = k
+
+    def get(self, i):
+        if self.absent is not None and self.absent[i]:
+            return ABSENT
+        b = np.ascontiguousarray(self.words[i]).view(np.uint8)
+        return np.unpackbits(b, bitorder='little')[:self.k].astype(int)
+
+
+class StateSetColumn(NodeColumn):
+    """Packed state words [N, W] handed out as sets of state names (pastml/ml.py:923-928)."""
+
+    def __init__(self, words, states):
+        self.words = words
+        self.states = np.asarray(states)
+
+    def get(self, i):
+        if self.absent is not None and self.absent[i]:
+            return ABSENT
+        b = np.ascontiguousarray(self.words[i]).view(np.uint8)
+        bits = np.unpackbits(b, bitorder='little')[:len(self.states)].astype(bool)
+        return set(self.states[bits])
+
+
+class AnnotationColumn(NodeColumn):
+    """
+    A column of the annotation table on the nodes (pastml/annotation.py:113-123): codes[i] = -2 the node is not in the
+    table (no such attribute), -1 it is there without a value (empty set), >= 0 index into ``values``; nodes with
+    several values (several table rows of one name) are in ``multi`` {node: set of value indices}.
+    """
+
+    def __init__(self, codes, values, multi=None):
+        self.codes = codes
+        self.values = values
+        self.multi = multi or {}
+
+    def get(self, i):
+        if self.absent is not None and self.absent[i]:
+            return ABSENT
+        c = self.codes[i]
+        if c == -2:
+            return ABSENT
+        if c == -1:
+            return set()
+        if i in self.multi:
+            return {self.values[j] for j in self.multi[i]}
+        return {self.values[c]}
+
+
 class TreeNode(object):
     """ete3-like tree node. The node *is* the (sub)tree rooted at it."""
 
-    __slots__ = ('children', 'up', 'dist', 'name', 'support', 'features', '__dict__', '_flat_cache')
+    __slots__ = ('children', 'up', 'dist', 'name', 'support', '_features', '__dict__', '_flat_cache', '_cols', '_idx')
 
     def __init__(self, newick=None, format=None, name=None, dist=None, support=None, quoted_node_names=False):
         self.children = []
@@ -38,15 +134,40 @@ class TreeNode(object):
         self.dist = DEFAULT_DIST if dist is None else dist
         self.name = name if name is not None else ''
         self.support = 1.0 if support is None else support
-        self.features = {'dist', 'name', 'support'}
+        self._features = {'dist', 'name', 'support'}
         self._flat_cache = None
+        self._cols = None   # the FlatForest whose columns hold this node's columnar features, and the node's row
+        self._idx = -1
         if newick is not None:
             _parse_newick(newick, self)
 
     # --- features -------------------------------------------------------------------------------------------------
+    def __getattr__(self, name):
+        # reached only when the attribute is neither a slot nor in __dict__: a columnar feature, or nothing
+        if not name.startswith('__'):
+            try:
+                flat = object.__getattribute__(self, '_cols')
+            except AttributeError:
+                flat = None
+            if flat is not None:
+                col = flat.columns.get(name)
+                if col is not None:
+                    v = col.get(object.__getattribute__(self, '_idx'))
+                    if v is not ABSENT:
+                        return v
+        raise AttributeError(name)
+
+    @property
+    def features(self):
+        flat = self._cols
+        if flat is None or not flat.columns:
+            return self._features
+        return self._features | {n for n, c in flat.columns.items() if c.get(self._idx) is not ABSENT}
+
     def add_feature(self, pr_name, pr_value):
         setattr(self, pr_name, pr_value)
-        self.features.add(pr_name)
+        self._features.add(pr_name)
+        _DICT_FEATURE_NAMES.add(pr_name)
 
     def add_features(self, **features):
         for k, v in features.items():
@@ -55,7 +176,12 @@ class TreeNode(object):
     def del_feature(self, pr_name):
         if pr_name in self.__dict__:
             del self.__dict__[pr_name]
-        self.features.discard(pr_name)
+        self._features.discard(pr_name)
+        flat = self._cols
+        if flat is not None:
+            col = flat.columns.get(pr_name)
+            if col is not None:
+                col.mark_absent(self._idx, flat.n_nodes)
 
     # --- topology ---------------------------------------------------------------------------------------------------
     def is_root(self):
@@ -198,7 +324,7 @@ class TreeNode(object):
         mapping = {}
         for n in self._iter_preorder():
             c = TreeNode(name=n.name, dist=n.dist, support=n.support)
-            for f in n.features:
+            for f in sorted(n.features):
                 if f not in ('dist', 'name', 'support'):
                     c.add_feature(f, getattr(n, f))
             mapping[id(n)] = c
@@ -404,7 +530,39 @@ class FlatForest(object):
         self.roots = np.ascontiguousarray(roots, dtype=np.int32)
         self.nodes = nodes
         self.n_nodes = len(self.parent)
+        self.columns = {}   # columnar node features: name -> NodeColumn (see the top of this module)
         self._derive()
+        if nodes is not None:
+            self.adopt_nodes()
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def adopt_nodes(self):
+        """Points the TreeNode objects at this forest: ``node.<feature>`` then resolves through ``self.columns``."""
+        for i, n in enumerate(self.nodes):
+            old = n._cols
+            if old is not None and old is not self and old.columns:
+                # the tree was edited and flattened again: what the old forest's columns held for this node moves onto
+                # the node itself
+                for name, col in old.columns.items():
+                    if name not in n.__dict__:
+                        v = col.get(n._idx)
+                        if v is not ABSENT:
+                            n.add_feature(name, v)
+            n._cols = self
+            n._idx = i
+
+    def set_column(self, name, column):
+        """
+        Sets a columnar feature for all nodes.  Values that add_feature() put on individual nodes under the same name
+        would hide the column: they are removed (only names ever used with add_feature need the walk).
+        """
+        if self.nodes is not None and name in _DICT_FEATURE_NAMES:
+            for n in self.nodes:
+                n.__dict__.pop(name, None)
+        self.columns[name] = column
+
+    def del_column(self, name):
+        self.columns.pop(name, None)
 
     # ------------------------------------------------------------------------------------------------------------------
     def _derive(self):
@@ -506,6 +664,7 @@ class FlatForest(object):
             if self.parent[i] >= 0:
                 nodes[self.parent[i]].add_child(node)
         self.nodes = nodes
+        self.adopt_nodes()
         return [nodes[r] for r in self.roots]
 
     # ------------------------------------------------------------------------------------------------------------------

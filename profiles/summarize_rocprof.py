@@ -65,7 +65,11 @@ def main():
     def total(prefixes):
         sel = [v for k, v in traffic.items() if k.startswith(prefixes)]
         return sum(v['bytes_per_launch'] * v['launches'] for v in sel) if sel else None
-    data[workload] = dict(tag=tag, td_bytes_per_step=total(('td_f81_kernel', 'td_matrix_kernel')),
+    sys.path.insert(0, os.path.dirname(HERE))
+    import bench
+    # the kernel sources these counters were measured on: bench.py reports roofline.traffic only while they are unchanged
+    data[workload] = dict(tag=tag, csrc_sha=bench.csrc_digest(), chars_per_gpu=bench.WORKLOADS[workload][2],
+                          td_bytes_per_step=total(('td_f81_kernel', 'td_matrix_kernel')),
                           bu_bytes_per_step=total(('bu_f81_kernel', 'bu_matrix_kernel')),
                           kernels=traffic)
     json.dump(data, open(tj, 'w'), indent=1)
