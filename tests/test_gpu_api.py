@@ -676,3 +676,88 @@ def test_engine_pool_reuse_and_model_kind_switch():
     assert other is not first
     hip.release_engine(other)
     hip.drain_engine_pool()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# characters as columns (pastml_amd.batch): one acr() call batches all characters of a group on the device
+# ---------------------------------------------------------------------------------------------------------------------
+def _multi_character_table(tree, seed=5):
+    """Six characters on the Albanian tree: Country (k=5) + five synthetic ones with 2, 2, 3, 5 and 5 states, some tips
+    unannotated, so that one call holds three groups (k = 2, 3, 5) of different sizes."""
+    rng = np.random.default_rng(seed)
+    df = albania_df()
+    tips = [t.name for t in tree]
+    for name, k, missing in (('bin_a', 2, 0.0), ('bin_b', 2, 0.2), ('tri', 3, 0.1), ('five_a', 5, 0.0), ('five_b', 5, 0.3)):
+        values = pd.Series(['v{}'.format(i) for i in rng.integers(0, k, size=len(tips))], index=tips)
+        values[rng.random(len(tips)) < missing] = np.nan
+        df[name] = values.reindex(df.index)
+    return df
+
+
+def test_batched_characters_equal_one_by_one():
+    """
+    Every step of ml_acr runs once for all characters of a group (lock-step L-BFGS-B instances served by one sweep of
+    sum(n_params + 1) columns, one joint sweep, one marginal pass, one selection): each character must get exactly the
+    numbers of a run on its own -- optimum, posteriors, selected states, restricted likelihoods -- bit for bit.
+    """
+    from pastml_amd.batch import run_tasks
+    tree = read_tree(TREE_NWK)
+    df = _multi_character_table(tree)
+    models = [F81, JC, F81, EFT, F81, JC]
+    together = acr(tree, df.copy(), prediction_method=MPPA, model=models)
+    stats = dict(run_tasks.last_stats)
+    assert stats['groups'] == 3 and [r['character'] for r in together] == list(df.columns)
+    flat = FlatForest.from_trees([tree])
+    selected = {r['character']: [getattr(n, r['character']) for n in flat.nodes] for r in together}
+    rounds_alone = 0
+    for column, model, batched in zip(df.columns, models, together):
+        tree1 = read_tree(TREE_NWK)
+        alone = acr(tree1, df[[column]].copy(), prediction_method=MPPA, model=model)[0]
+        rounds_alone += run_tasks.last_stats['rounds']
+        assert alone[LOG_LIKELIHOOD] == batched[LOG_LIKELIHOOD], column
+        assert alone[MODEL].sf == batched[MODEL].sf
+        assert np.array_equal(alone[MODEL].frequencies, batched[MODEL].frequencies)
+        assert np.array_equal(alone[MARGINAL_PROBABILITIES].values, batched[MARGINAL_PROBABILITIES].values)
+        for m in (JOINT, MAP, MPPA):
+            key = RESTRICTED_LOG_LIKELIHOOD_FORMAT_STR.format(m)
+            assert alone[key] == batched[key], (column, m)
+        for key in ('num_scenarios', 'num_unresolved_nodes', 'num_states_per_node_avg'):
+            assert alone[key] == batched[key]
+        flat1 = FlatForest.from_trees([tree1])
+        assert [getattr(n, column) for n in flat1.nodes] == selected[column]
+        assert np.array_equal([getattr(n, column + '_JOINT_STATE') for n in flat1.nodes],
+                              [getattr(n, column + '_JOINT_STATE') for n in flat.nodes])
+    # the point of the exercise: the batch needs as many sweep rounds as its slowest character, not the sum
+    assert stats['rounds'] < rounds_alone
+
+
+def test_meta_method_ml_and_mixed_methods_in_one_call():
+    """Characters with different prediction methods go to different groups; ML reports JOINT, MAP and MPPA."""
+    tree = read_tree(TREE_NWK)
+    df = _multi_character_table(tree)[['Country', 'bin_a', 'tri']]
+    res = acr(tree, df.copy(), prediction_method=[ML, MAP, JOINT], model=F81)
+    assert [(r['character'], r['method']) for r in res] == [('Country_JOINT', JOINT), ('Country_MAP', MAP),
+                                                            ('Country_MPPA', MPPA), ('bin_a', MAP), ('tri', JOINT)]
+    ref = albania_result(F81)[1][0]
+    assert res[2][LOG_LIKELIHOOD] == ref[LOG_LIKELIHOOD]
+    assert res[2][RESTRICTED_LOG_LIKELIHOOD_FORMAT_STR.format(MPPA)] == ref[RESTRICTED_LOG_LIKELIHOOD_FORMAT_STR.format(MPPA)]
+    assert MARGINAL_PROBABILITIES in res[3] and MARGINAL_PROBABILITIES not in res[4]
+    assert hasattr(tree, 'Country_MPPA') and hasattr(tree, 'Country_JOINT') and not hasattr(tree, 'bin_a_JOINT_STATE')
+
+
+def test_columnar_node_features_behave_like_attributes():
+    """Results live in columns of the flat forest; per node they read, shadow and delete like ete3 features."""
+    tree, results = albania_result(F81)
+    node = tree.children[0]
+    assert isinstance(getattr(node, feature), set) and feature in node.features
+    allowed = getattr(node, feature + '_ALLOWED_STATES')
+    assert allowed.dtype == int and set(results[0][STATES][allowed.astype(bool)]) == getattr(node, feature)
+    lh = getattr(node, get_personalized_feature_name(feature, LH))
+    assert lh.shape == (5,) and isinstance(getattr(node, get_personalized_feature_name(feature, LH_SF)), float)
+    node.add_feature(feature, {'Mars'})                 # a value set on the node hides the column's row ...
+    assert getattr(node, feature) == {'Mars'} and getattr(tree, feature) != {'Mars'}
+    node.del_feature(feature)                           # ... and deleting removes the feature of that node only
+    assert not hasattr(node, feature) and hasattr(tree, feature)
+    copy = tree.copy()                                  # a copy materialises what its nodes see
+    assert getattr(copy, feature) == getattr(tree, feature)
+    _cache.clear()

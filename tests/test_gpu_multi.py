@@ -112,3 +112,29 @@ def test_bench_two_ranks_started_directly(tmp_path):
     assert line['validation']['columns'] == 2
     ref = _single_process_logliks(4, 14, 64)
     np.testing.assert_allclose(line['loglik_sum'], ref.sum(), rtol=1e-13)
+
+
+def test_acr_shards_characters_over_ranks(tmp_path):
+    """acr() under a 2-process launch: each rank reconstructs its block of the characters (through the HIP path), the
+    total log-likelihood is all-reduced; together the ranks reproduce the single-process run bit for bit."""
+    import pandas as pd  # noqa: F401
+    from test_gpu_api import TREE_NWK, _multi_character_table
+    from pastml_amd.acr import acr
+    from pastml_amd.tree import read_tree
+    port = _free_port()
+    prefix = str(tmp_path / 'rank')
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), PASTML_AMD_COMM='gloo', PASTML_TEST_DEVICE='0', HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, os.path.join(REPO, 'tests', '_acr_rank_worker.py'), prefix], env=env))
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    got = [json.load(open('{}{}.json'.format(prefix, r))) for r in range(2)]
+    tree = read_tree(TREE_NWK)
+    df = _multi_character_table(tree)
+    ref = acr(tree, df, prediction_method='MPPA', model='F81')
+    assert got[0]['characters'] + got[1]['characters'] == [r['character'] for r in ref]
+    assert got[0]['loglik'] + got[1]['loglik'] == [r['log_likelihood'] for r in ref]
+    assert got[0]['total'] == got[1]['total']
+    np.testing.assert_allclose(got[0]['total'], sum(r['log_likelihood'] for r in ref), rtol=1e-14)
