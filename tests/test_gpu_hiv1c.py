@@ -1,0 +1,118 @@
+"""
+BASELINE config 5 in full on the GPU: acr(MPPA, F81) on the HIV1C tree (3 619 tips, 7 237 nodes) for EVERY usable
+column of examples/HIV1C/data/metadata.tab (91: 82 binary drug-resistance columns + k = 5, 10, 11, 12, 30, 36, 67, 67,
+67), all characters of a call batched as device columns (pastml_amd.batch).
+
+Reference: tests/golden/hiv1c_all.npz, one run of the real reference's acr() per column with parameter optimisation
+(tests/golden/make_golden.py hiv1c_all; 3.4 CPU-hours in all -- columns the reference had not finished when the fixture
+was assembled are marked not done and only checked for invariants).
+"""
+import os
+import time
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from conftest import load_golden, GOLDEN
+from pastml_amd.acr import acr
+from pastml_amd.batch import run_tasks
+from pastml_amd.ml import LOG_LIKELIHOOD, RESTRICTED_LOG_LIKELIHOOD_FORMAT_STR, MARGINAL_PROBABILITIES, MODEL, MPPA, MAP, \
+    JOINT
+from pastml_amd.tree import read_tree, FlatForest
+
+pytestmark = pytest.mark.gpu
+
+D = os.path.join(GOLDEN, 'data', 'hiv1c')
+
+
+def inputs():
+    tree = read_tree(os.path.join(D, 'pastml_phyml_tree.nwk'))
+    df = pd.read_csv(os.path.join(D, 'metadata_all.tab.gz'), sep='\t', index_col=0, header=0, dtype=str)
+    df.index = df.index.map(str)
+    return tree, df
+
+
+def test_all_columns_with_parameter_optimisation():
+    """One acr() call over the 91 columns; every optimum against the reference's own optimisation of that column."""
+    z = load_golden('hiv1c_all')
+    tree, df = inputs()
+    assert list(df.columns) == list(z['columns']) and len(df.columns) == 91
+    np.random.seed(239)
+    t0 = time.perf_counter()
+    results = acr(tree, df, prediction_method=MPPA, model='F81')
+    seconds = time.perf_counter() - t0
+    stats = dict(run_tasks.last_stats)
+    assert [r['character'] for r in results] == list(df.columns)
+    # (82 binary columns, k = 67 x 3 and six singletons) -> 8 groups; the reference's 91 runs took 12 000 s
+    assert stats['groups'] == 8
+    reference_seconds = 0.0
+    for ci, (column, res) in enumerate(zip(df.columns, results)):
+        k = int(z['n_states'][ci])
+        assert len(res['states']) == k
+        mp = res[MARGINAL_PROBABILITIES]
+        assert mp.shape == (7237, k)
+        np.testing.assert_allclose(mp.values.sum(axis=1), 1, rtol=1e-12)
+        assert res[LOG_LIKELIHOOD] >= res[RESTRICTED_LOG_LIKELIHOOD_FORMAT_STR.format(MPPA)] - 1e-9
+        assert res[RESTRICTED_LOG_LIKELIHOOD_FORMAT_STR.format(MPPA)] >= \
+            res[RESTRICTED_LOG_LIKELIHOOD_FORMAT_STR.format(JOINT)] - 1e-9
+        if not z['done'][ci]:
+            continue
+        ref = float(z['c{}_loglik'.format(ci)])
+        reference_seconds += float(z['c{}_reference_seconds'.format(ci)])
+        # L-BFGS-B stops where its own tolerances say so: the reference's optima of the three identically partitioned
+        # Country columns differ by 1e-4 among themselves; binary columns agree to 1e-12 relative
+        assert abs(res[LOG_LIKELIHOOD] - ref) <= 2e-5 * max(1.0, abs(ref)), column
+        if k == 2:
+            np.testing.assert_allclose(res[LOG_LIKELIHOOD], ref, rtol=1e-9, atol=1e-9, err_msg=column)
+            np.testing.assert_allclose(res[MODEL].sf, float(z['c{}_sf'.format(ci)]), rtol=1e-4, err_msg=column)
+    print('acr() over 91 HIV1C columns: {:.2f} s ({} sweep rounds); the reference: {:.0f} s for the {} columns it '
+          'finished'.format(seconds, stats['rounds'], reference_seconds, int(z['done'].sum())))
+    assert seconds < 60
+
+
+def test_all_columns_at_the_reference_optima():
+    """
+    No optimiser noise: every column at the parameters the reference found for it (scaling factor + frequencies given
+    through column2parameters), all columns in one batched call.  Log-likelihoods, restricted log-likelihoods, marginal
+    posteriors (strided node sample), joint states and the MPPA selection of every node against the reference.
+    """
+    z = load_golden('hiv1c_all')
+    tree, df = inputs()
+    done = [ci for ci in range(len(df.columns)) if z['done'][ci]]
+    columns = [df.columns[ci] for ci in done]
+    params = {}
+    for ci, column in zip(done, columns):
+        states = np.array(sorted([_ for _ in df[column].unique() if not pd.isna(_) and '' != _]))
+        freqs = z['c{}_frequencies'.format(ci)]
+        assert len(states) == len(freqs) == int(z['n_states'][ci])
+        p = {'scaling_factor': float(z['c{}_sf'.format(ci)])}
+        p.update({s: float(f) for s, f in zip(states, freqs)})
+        params[column] = p
+    results = acr(tree, df[columns].copy(), prediction_method=MPPA, model='F81', column2parameters=params)
+    assert run_tasks.last_stats['rounds'] <= 8   # one likelihood evaluation per group, nothing to optimise
+    flat = FlatForest.from_trees([tree])
+    sample = z['sample']
+    mismatched_nodes = 0
+    for ci, column, res in zip(done, columns, results):
+        g = lambda key: z['c{}_{}'.format(ci, key)]  # noqa: E731
+        k = int(z['n_states'][ci])
+        np.testing.assert_allclose(res[LOG_LIKELIHOOD], float(g('loglik')), rtol=1e-10, atol=1e-9, err_msg=column)
+        for m in (JOINT, MAP, MPPA):
+            np.testing.assert_allclose(res[RESTRICTED_LOG_LIKELIHOOD_FORMAT_STR.format(m)],
+                                       float(g('loglik_restricted_' + m)), rtol=1e-10, atol=1e-9,
+                                       err_msg='{} {}'.format(column, m))
+        np.testing.assert_allclose(res[MARGINAL_PROBABILITIES].values[sample], g('posterior_sample'), rtol=1e-6,
+                                   atol=1e-300, err_msg=column)   # north_star's bar; measured ~1e-10
+        assert res['num_unresolved_nodes'] == int(g('num_unresolved_nodes')), column
+        assert res['num_states_per_node_avg'] == float(g('num_states_per_node_avg')), column
+        joint = np.array([getattr(n, column + '_JOINT_STATE') for n in flat.nodes])
+        assert np.array_equal(joint, g('joint_state')), column
+        selected = np.unpackbits(g('selected_bits'), axis=1)[:, :k].astype(bool)
+        states = res['states']
+        ours = np.zeros_like(selected)
+        for i, n in enumerate(flat.nodes):
+            for s in getattr(n, column):
+                ours[i, np.searchsorted(states, s)] = True
+        mismatched_nodes += int((ours != selected).any(axis=1).sum())
+    assert mismatched_nodes == 0
