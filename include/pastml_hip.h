@@ -44,7 +44,7 @@ enum { PML_MODEL_F81 = 0, PML_MODEL_HKY = 1, PML_MODEL_EIGEN = 2 };
 enum {
     PML_BUF_BU = 0,          /* double[n_nodes][k]  bottom-up vectors of one column (tips: their masks as 0/1)      */
     PML_BUF_BU_SF = 1,       /* double[n_nodes]     their base-10 scale (reference BU_LH_SF convention)              */
-    PML_BUF_TD = 2,          /* double[n_nodes][k]  top-down vectors (stored internal nodes; others: NaN)           */
+    PML_BUF_TD = 2,          /* double[n_nodes][k]  top-down vectors of all nodes (pastml/ml.py:273-290)             */
     PML_BUF_TD_SF = 3,       /* double[n_nodes]                                                                        */
     PML_BUF_POSTERIOR = 4,   /* double[n_nodes][k]  marginal posteriors                                                */
     PML_BUF_LH_SUM = 5,      /* double[n_nodes]     sum of the (scaled) marginal likelihoods, in [1, 2)                */
@@ -64,12 +64,13 @@ int pml_ctx_destroy(pml_ctx* ctx);
 int pml_ctx_sync(pml_ctx* ctx);
 /*
  * Options (set before pml_tree_upload).  PML_OPT_CHERRY_FUSION (default 1): in the F81-family marginal sweeps,
- * internal nodes whose children are all tips are recomputed in registers instead of being stored in HBM; their
- * top-down vectors are then never materialised (pml_download(PML_BUF_TD) reports NaN for them, as for tips).
+ * internal nodes whose children are all tips are recomputed in registers instead of being stored in HBM (their
+ * vectors, like the top-down vectors of tips, are computed when pml_download asks for them).
  * PML_OPT_KEEP_TD (default 0, may be changed at any time): the F81-family top-down sweep works from the stored
  * posteriors of the level above (TD o BU = posterior * sum / pi) and does not write the top-down vectors themselves;
- * with this option it stores them too.  pml_download(PML_BUF_TD / PML_BUF_TD_SF) switches it on and repeats the sweep
- * when they are missing.  The matrix models (HKY, eigen) always store them.
+ * with this option it stores them too.  pml_download(PML_BUF_TD / PML_BUF_TD_SF) repeats the sweep with the stores on
+ * when they are missing and fills in the vectors no sweep stores (tips, fused cherries).  The matrix models (HKY,
+ * eigen) always store the vectors of internal nodes.
  * PML_OPT_EIGEN_FUSED (default 1, may be changed at any time): eigen-decomposed models with 16 <= k <= 32 run the fused
  * matrix-core sweeps (P(t) built and consumed in registers); 0 selects the sweeps that read materialised P(t) from HBM.
  */

@@ -123,6 +123,7 @@ struct pml_ctx {
     bool td_valid = false, js_valid = false;
     bool keep_td = false;      // PML_OPT_KEEP_TD (or a pml_download of the TD vectors asked for them)
     bool td_vec_valid = false; // the TD vectors of the last top-down sweep are in d_td
+    bool td_filled = false;    // ... including those of the nodes the sweeps do not store (td_fill_kernel)
     bool eig_fused_opt = true; // PML_OPT_EIGEN_FUSED
     PmlComm* comm = nullptr;   // RCCL communicator attached by pml_comm_init (survives tree uploads)
 };
@@ -1567,23 +1568,50 @@ static int run_top_down(pml_ctx* ctx) {
     }
     ctx->td_valid = true;
     ctx->td_vec_valid = td_stored;
+    ctx->td_filled = false;
     ctx->post_ever = true;
     return PML_OK;
 }
 
-// F81 family: the sweep did not write its TD vectors; repeat it with the stores switched on (same arithmetic)
+static int materialize_cherries(pml_ctx* ctx);
+
+// For inspection (pml_download of the TD buffers): every non-root node gets its top-down vector.  F81 family: the
+// sweep did not write its TD vectors, it is repeated with the stores switched on (same arithmetic); then the vectors of
+// the nodes no sweep stores (tips; fused cherries) are filled in level by level (td_fill_kernel).
 static int materialize_td(pml_ctx* ctx) {
-    if (ctx->td_vec_valid) return PML_OK;
-    // one sweep with the stores on; the option itself stays as the caller set it (a pooled ctx must not keep paying
-    // for TD stores because somebody once looked at them)
-    const bool was = ctx->keep_td;
-    drop_graph(ctx->td_graph);
-    ctx->keep_td = true;
-    const int status = run_top_down(ctx);
-    ctx->keep_td = was;
-    if (!was) drop_graph(ctx->td_graph);
-    PML_TRY(status);
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (!ctx->td_vec_valid) {
+        // one sweep with the stores on; the option itself stays as the caller set it (a pooled ctx must not keep
+        // paying for TD stores because somebody once looked at them)
+        const bool was = ctx->keep_td;
+        drop_graph(ctx->td_graph);
+        ctx->keep_td = true;
+        const int status = run_top_down(ctx);
+        ctx->keep_td = was;
+        if (!was) drop_graph(ctx->td_graph);
+        PML_TRY(status);
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    if (!ctx->td_filled) {
+        const bool f81 = ctx->kind == PML_MODEL_F81;
+        if (f81) {
+            PML_TRY(materialize_cherries(ctx));  // the cherries' bottom-up vectors
+        } else {
+            PML_TRY(run_prep(ctx, ctx->d_P == nullptr || eigen_fused(ctx)));  // P(t) of every branch in HBM
+        }
+        PmlState st = state_of(ctx);
+        st.td = ctx->d_td;  // state_of hides them when the option is off
+        st.te = ctx->d_te;
+        for (int d = 1; d < ctx->n_td_levels; ++d) {
+            const int a = ctx->td_offsets[d], b = ctx->td_offsets[d + 1];
+            if (b <= a) continue;
+            dim3 grid(grid_for(b - a, PML_WAVES_PER_BLOCK, ctx->C), ctx->C);
+            hipLaunchKernelGGL(td_fill_kernel, grid, dim3(PML_BLOCK), 0, ctx->stream, tree_of(ctx, f81), cols_of(ctx), st,
+                               f81 ? nullptr : ctx->d_P, f81 ? 1 : 0, a, b);
+            HIP_TRY(hipGetLastError());
+        }
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        ctx->td_filled = true;
+    }
     return PML_OK;
 }
 
@@ -1645,8 +1673,6 @@ int pml_joint_backtrace(pml_ctx* ctx, int32_t* joint_state_out) {
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return PML_OK;
 }
-
-static int materialize_cherries(pml_ctx* ctx);
 
 int pml_marginal_counts(pml_ctx* ctx, int32_t col, int32_t n_repetitions, uint64_t seed, double* counts_out) {
     PML_TRY(require_model(ctx));
@@ -1808,27 +1834,14 @@ int pml_download(pml_ctx* ctx, int what, int32_t col, void* out) {
                 if (ctx->h_n_children[n] == 0) ((double*)out)[n] = 0.0;
             return PML_OK;
         }
-        case PML_BUF_TD: {
+        case PML_BUF_TD:
             if (!ctx->td_valid) return fail(PML_ERR_INVALID, "no valid top-down sweep");
             PML_TRY(materialize_td(ctx));
-            double* o = (double*)out;
-            PML_TRY(fetch_vectors(ctx, ctx->d_td, col, o));
-            const bool f81 = ctx->kind == PML_MODEL_F81;
-            for (size_t n = 0; n < N; ++n)
-                if ((ctx->h_n_children[n] == 0 && ctx->h_parent[n] >= 0) || (f81 && ctx->h_kind[n] == PML_KIND_CHERRY))
-                    for (int s = 0; s < ctx->k; ++s) o[n * ctx->k + s] = nan;
-            return PML_OK;
-        }
-        case PML_BUF_TD_SF: {
+            return fetch_vectors(ctx, ctx->d_td, col, (double*)out);
+        case PML_BUF_TD_SF:
             if (!ctx->td_valid) return fail(PML_ERR_INVALID, "no valid top-down sweep");
             PML_TRY(materialize_td(ctx));
-            PML_TRY(fetch_exponents(ctx, ctx->d_te, col, (double*)out));
-            const bool f81 = ctx->kind == PML_MODEL_F81;
-            for (size_t n = 0; n < N; ++n)
-                if ((ctx->h_n_children[n] == 0 && ctx->h_parent[n] >= 0) || (f81 && ctx->h_kind[n] == PML_KIND_CHERRY))
-                    ((double*)out)[n] = nan;
-            return PML_OK;
-        }
+            return fetch_exponents(ctx, ctx->d_te, col, (double*)out);
         case PML_BUF_POSTERIOR:
             if (!ctx->td_valid) return fail(PML_ERR_INVALID, "no valid top-down sweep");
             return fetch_vectors(ctx, ctx->d_post, col, (double*)out);

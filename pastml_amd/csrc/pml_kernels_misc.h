@@ -380,6 +380,104 @@ select_states_kernel(int N, int k, int ks, int W, const double* __restrict__ pos
 }
 
 // err[col] = all ones (a kernel rather than a memset node so that the sweep's launch sequence captures cleanly)
+// ---------------------------------------------------------------------------------------------------------------------
+// Top-down vectors of the nodes the sweeps never store -- tips, and in the F81 family the cherries that only live in
+// registers -- computed on request (pml_download(PML_BUF_TD / PML_BUF_TD_SF)) so that every non-root node has what
+// calc_node_td_likelihood (pastml/ml.py:273-290) leaves on it:
+//     msg[i] = sum_j P[i][j] BU_n[j]   (<= 0 -> 1),   X = TD_p o BU_p / msg,   TD_n[i] = max(sum_j P[i][j] X[j], 0)
+// One wavefront per (node, column), the levels of the tree top-down (a cherry's tips need the cherry's vector).
+// Inspection only, not on the measured path: plain loops, k <= 256 states in up to four registers per lane.
+// P: transposed matrices of the matrix models ([C][N][k][ks], Pt[j][i] = P[i][j]) or nullptr for the F81 family, whose
+// P = (1 - e) 1 pi^T + e I is applied in closed form.
+__global__ void __launch_bounds__(PML_BLOCK)
+td_fill_kernel(PmlTree t, PmlCols c, PmlState st, const double* __restrict__ P, int f81, int begin, int end) {
+    __shared__ double sv[PML_WAVES_PER_BLOCK][PML_MAX_STATES_SEL];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = blockIdx.y;
+    const int k = c.k, ks = c.ks;
+    const size_t colN = (size_t)col * t.N;
+    for (int n = begin + blockIdx.x * PML_WAVES_PER_BLOCK + wave; n < end; n += gridDim.x * PML_WAVES_PER_BLOCK) {
+        const int kind = node_kind(t, n);
+        const bool tip = t.n_children[n] == 0;
+        const bool stored = f81 ? kind == PML_KIND_STORED : !tip;
+        if (stored) continue;  // wave-uniform
+        const int p = t.parent[n];
+        const size_t row = (colN + n) * ks, prow = (colN + p) * ks;
+        const double* Pt = P != nullptr ? P + (colN + n) * (size_t)k * ks : nullptr;
+        const i64 be_n = tip ? 0 : st.be[colN + n];
+        double v[4], x[4];
+        for (int q = 0; q < 4; ++q) {
+            const int i = lane + 64 * q;
+            v[q] = 0.0;
+            if (i < k) v[q] = tip ? (double)((c.masks[(colN + n) * c.W + (i >> 6)] >> (i & 63)) & 1ull) : st.bu[row + i];
+            if (i < k) sv[wave][i] = v[q];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const double e = f81 ? st.E[colN + n] : 0.0;
+        const double s_n = f81 ? st.S[colN + n] : 0.0;
+        double big = 0.0;
+        bool out_of_band = false;
+        for (int q = 0; q < 4; ++q) {
+            const int i = lane + 64 * q;
+            x[q] = 0.0;
+            if (i >= k) continue;
+            double msg;
+            if (f81) {
+                msg = (1.0 - e) * s_n + e * v[q];
+            } else {
+                msg = 0.0;
+                for (int j = 0; j < k; ++j) msg += Pt[(size_t)j * ks + i] * sv[wave][j];
+            }
+            if (!(msg > 0.0)) msg = 1.0;
+            x[q] = st.td[prow + i] * st.bu[prow + i] / msg;
+            big = fmax(big, x[q]);
+            out_of_band |= x[q] != 0.0 && (x[q] < 0x1p-200 || x[q] > 0x1p+200);
+        }
+        i64 xe = st.te[colN + p] + st.be[colN + p] - be_n;
+        if (__any(out_of_band)) {
+            for (int off = 32; off > 0; off >>= 1) big = fmax(big, __shfl_xor(big, off, 64));
+            if (big > 0.0 && !isinf(big)) {
+                const int ex = exponent_of(big);
+                for (int q = 0; q < 4; ++q) x[q] = __builtin_ldexp(x[q], -ex);
+                xe += ex;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int q = 0; q < 4; ++q) {
+            const int i = lane + 64 * q;
+            if (i < k) sv[wave][i] = x[q];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        double dot = 0.0;
+        if (f81) {
+            for (int q = 0; q < 4; ++q) {
+                const int i = lane + 64 * q;
+                if (i < k) dot += c.pi[(size_t)col * ks + i] * x[q];
+            }
+            for (int off = 32; off > 0; off >>= 1) dot += __shfl_xor(dot, off, 64);
+        }
+        for (int q = 0; q < 4; ++q) {
+            const int i = lane + 64 * q;
+            if (i >= ks) continue;
+            double td = 0.0;
+            if (i < k) {
+                if (f81) {
+                    td = (1.0 - e) * dot + e * x[q];
+                } else {
+                    for (int j = 0; j < k; ++j) td += Pt[(size_t)j * ks + i] * sv[wave][j];
+                }
+            }
+            st.td[row + i] = fmax(td, 0.0);
+        }
+        if (lane == 0) st.te[colN + n] = xe;
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 __global__ void reset_err_kernel(u64* __restrict__ err, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) err[i] = ~0ull;

@@ -364,9 +364,10 @@ def _parse_newick(text, root):
     node = root
     root.dist = 0.0
     depth = 0
+    comments = []
 
     def read_label(i):
-        # returns (name, dist or None, next index)
+        # returns (name, dist or None, next index); [...] comments met on the way are kept in `comments`
         name_chars = []
         if i < n and s[i] == "'":
             j = s.index("'", i + 1)
@@ -379,7 +380,9 @@ def _parse_newick(text, root):
         dist = None
         while i < n and s[i] in ':[':
             if s[i] == '[':
-                i = s.index(']', i) + 1
+                j = s.index(']', i)
+                comments.append(s[i + 1:j])
+                i = j + 1
                 continue
             i += 1
             j = i
@@ -419,19 +422,25 @@ def _parse_newick(text, root):
             node = node.up
             depth -= 1
             i += 1
+            comments = []
             name, dist, i = read_label(i)
             # internal labels that are numbers are supports in some formats; we keep them as names only if non-numeric
             node.name = name
             if dist is not None:
                 node.dist = dist
+            if comments:
+                node.__dict__['comment'] = ' '.join(comments)
             expecting_node = False
         elif ch == ';':
             break
         else:
+            comments = []
             name, dist, i = read_label(i)
             node.name = name
             if dist is not None:
                 node.dist = dist
+            if comments:
+                node.__dict__['comment'] = ' '.join(comments)
             expecting_node = False
     if depth != 0:
         raise NewickError('Unbalanced parentheses')

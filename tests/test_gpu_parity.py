@@ -91,10 +91,11 @@ def test_sweeps_match_reference(name, prefix):
         np.testing.assert_allclose(lnl[0], g('loglik'), rtol=LNL_RTOL)
         assert_same_scaled(eng.download(hip.BUF_BU), eng.download(hip.BUF_BU_SF), g('bu'), g('bu_sf'), what='BU')
         post, lh_sum, lh_sf = eng.top_down_marginals()
+        # every node has its top-down vector (ml.py:273-290): those the sweeps do not store (tips; fused cherries) are
+        # filled in when the buffer is asked for
         td, td_sf = eng.download(hip.BUF_TD), eng.download(hip.BUF_TD_SF)
-        stored = ~np.isnan(td_sf)  # tips and (F81 family) fused cherries never materialise their top-down vector
-        assert np.all(stored[internal]) or spec['kind'] == 0
-        assert_same_scaled(td, td_sf, g('td'), g('td_sf'), rows=stored, what='TD')
+        assert not np.isnan(td).any() and not np.isnan(td_sf).any()
+        assert_same_scaled(td, td_sf, g('td'), g('td_sf'), what='TD')
         np.testing.assert_allclose(post[0], g('posterior'), rtol=POST_RTOL, atol=1e-300)
         # LH / LH_SF as the host rebuilds them: posterior * lh_sum with scale lh_sf
         assert_same_scaled(post[0] * lh_sum[0][:, None], lh_sf[0], g('lh'), g('lh_sf'), what='LH')
@@ -452,7 +453,7 @@ def test_cherry_fusion_is_bit_identical(k):
             post, lh_sum, lh_sf = eng.top_down_marginals()
             bu = eng.download(hip.BUF_BU, 1)
             bu_sf = eng.download(hip.BUF_BU_SF, 1)
-            td_sf = eng.download(hip.BUF_TD_SF, 1)
+            td_sf = (eng.download(hip.BUF_TD, 1), eng.download(hip.BUF_TD_SF, 1))
             # the joint sweep fuses cherries too (their tips' arg-max rows are written by the grandparent's unit)
             lnl_j = eng.bottom_up(False)
             tables = np.stack([eng.download(hip.BUF_JOINT_TABLE, c) for c in range(2)])[:, flat.parent >= 0]
@@ -462,8 +463,9 @@ def test_cherry_fusion_is_bit_identical(k):
             out.append((lnl, post, lh_sum, lh_sf, bu, bu_sf, lnl_j, tables, states, bu_j, bu_j_sf, td_sf))
     for a, b in zip(out[0][:11], out[1][:11]):
         assert np.array_equal(a, b)
-    # the fused run never materialised the cherries' top-down vectors
-    assert np.isnan(out[0][11]).sum() > np.isnan(out[1][11]).sum()
+    # the cherries' top-down vectors are filled in on request in the fused run: same scales to rounding
+    assert not np.isnan(out[0][11][0]).any() and not np.isnan(out[0][11][1]).any()
+    assert_same_scaled(out[0][11][0], out[0][11][1], out[1][11][0], out[1][11][1], what='TD, fused vs stored cherries')
 
 
 @pytest.mark.parametrize('k', [2, 5, 12, 64])
