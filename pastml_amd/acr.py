@@ -10,9 +10,11 @@ optimisation of all its characters in lock-step, one joint sweep, one marginal p
 contiguous block of the characters and returns the results of its block; :func:`total_log_likelihood` sums the
 log-likelihoods over all ranks with the library's single RCCL all-reduce.
 
-Only the ML path is implemented (prediction methods MPPA, MAP, JOINT, ML): every likelihood sweep runs on the GPU.
-The parsimony / COPY methods, polytomy resolution and the HTML side of the pipeline are out of scope of this package
- and raise a clear error; ``pastml_amd.pipeline`` covers the file-to-file part.
+Every prediction method of the reference is accepted: the likelihood methods (MPPA, MAP, JOINT, and the meta-methods
+ML and ALL) run their sweeps on the GPU; the parsimony methods (DOWNPASS, ACCTRAN, DELTRAN, MP; integer set work, no
+likelihoods) run on the host as level-wise array passes (pastml_amd.parsimony); COPY reports the annotation as it is.
+Polytomy resolution (tree editing) and the HTML side of the pipeline are out of scope and raise a
+clear error; ``pastml_amd.pipeline`` covers the file-to-file part.
 """
 import logging
 import os
@@ -35,8 +37,9 @@ from pastml_amd.tree import TreeNode, get_flat_forest, AnnotationColumn
 
 model2class = {F81: F81Model, JC: JCModel, CUSTOM_RATES: CustomRatesModel, HKY: HKYModel, JTT: JTTModel, EFT: EFTModel}
 
+from pastml_amd.parsimony import is_parsimonious, parsimonious_acr, MP_METHODS, ACCTRAN, DELTRAN, DOWNPASS, MP  # noqa: E402,F401
+
 COPY = 'COPY'
-MP_METHODS = {'DOWNPASS', 'ACCTRAN', 'DELTRAN', 'MP'}
 
 warnings.filterwarnings("ignore", append=True)
 
@@ -153,7 +156,7 @@ def total_log_likelihood(results):
     seen, values = set(), []
     for r in results:
         base = r[CHARACTER][:-len(r[METHOD]) - 1] if r[CHARACTER].endswith('_' + r[METHOD]) else r[CHARACTER]
-        if base not in seen:   # the meta-method ML reports one character several times
+        if base not in seen and LOG_LIKELIHOOD in r:   # meta-methods report one character several times; parsimony: none
             seen.add(base)
             values.append(r[LOG_LIKELIHOOD])
     comm = sharding.communicator() or sharding.LocalCommunicator()
@@ -208,26 +211,32 @@ def acr(forest, df=None, columns=None, column2states=None, prediction_method=MPP
     optimise_tau = tau is None or reoptimise
     tau = 0 if tau is None else tau
 
-    tasks = []
+    # what to do per column: ('ml', Task) / ('mp', states) / ('copy', states)
+    plan = []
     for character, method, model_name in zip(columns, methods, model_names):
         logger.debug('ACR settings for {}:\n\tMethod:\t{}{}.'
                      .format(character, method, '\n\tModel:\t{}'.format(model_name) if model_name and is_ml(method) else ''))
-        if COPY == method or method in MP_METHODS or ALL == method:
-            raise NotImplementedError('Method {} is outside the accelerated maximum-likelihood path; '
-                                      'supported: {}'.format(method, ', '.join(sorted(ML_METHODS | {ML}))))
-        if not is_ml(method):
-            raise ValueError('Method {} is unknown, should be one of ML ({})'.format(method, ', '.join(ML_METHODS)))
-        if model_name not in model2class:
-            raise ValueError('Model {} is unknown, should be one of {}'.format(model_name, ', '.join(model2class)))
+        if not (COPY == method or is_parsimonious(method) or is_ml(method)):
+            raise ValueError('Method {} is unknown, should be one of ML ({}), one of MP ({}) or {}'
+                             .format(method, ', '.join(ML_METHODS), ', '.join(MP_METHODS), COPY))
         states = column2states[character]
-        if model_name in (HKY, JTT):
-            alphabet = HKY_STATES if HKY == model_name else JTT_STATES
-            if not set(states) & set(alphabet):
-                raise ValueError('The allowed states for model {} are {}, '
-                                 'but your annotation file specifies {} as states in column {}.'
-                                 .format(model_name, ', '.join(alphabet), ', '.join(states), character))
-            _restrict_annotation_to(alphabet, character, forest)
-            states = alphabet
+        if is_ml(method):
+            if model_name not in model2class:
+                raise ValueError('Model {} is unknown, should be one of {}'.format(model_name, ', '.join(model2class)))
+            if model_name in (HKY, JTT):
+                alphabet = HKY_STATES if HKY == model_name else JTT_STATES
+                if not set(states) & set(alphabet):
+                    raise ValueError('The allowed states for model {} are {}, '
+                                     'but your annotation file specifies {} as states in column {}.'
+                                     .format(model_name, ', '.join(alphabet), ', '.join(states), character))
+                _restrict_annotation_to(alphabet, character, forest)
+                states = alphabet
+        if COPY == method:
+            plan.append(('copy', character, method, states))
+            continue
+        if is_parsimonious(method):
+            plan.append(('mp', character, method, states))
+            continue
         missing, observed, state2index = calculate_observed_freqs(character, forest, states)
         logger.debug('Observed frequencies for {}:{}{}.'.format(
             character, ''.join('\n\tfrequency of {}:\t{:.6f}'.format(s, observed[state2index[s]]) for s in states),
@@ -237,13 +246,21 @@ def acr(forest, df=None, columns=None, column2states=None, prediction_method=MPP
                                            frequency_smoothing=frequency_smoothing, tau=tau, optimise_tau=optimise_tau,
                                            states=states, forest_stats=forest_stats, observed_frequencies=observed,
                                            character=character)
-        tasks.append(Task(character, method, instance, observed))
+        plan.append(('ml', character, method, Task(character, method, instance, observed)))
 
     # one process per GPU: this rank's contiguous block of the characters
     comm = sharding.communicator()
     if comm is not None and comm.world > 1:
-        mine = sharding.shard_characters(len(tasks), comm.rank, comm.world)
-        tasks = [tasks[i] for i in mine]
-    if not tasks:
-        return []
-    return flatten_lists(run_tasks(forest, tasks, force_joint=force_joint))
+        plan = [plan[i] for i in sharding.shard_characters(len(plan), comm.rank, comm.world)]
+    tasks = [item[3] for item in plan if item[0] == 'ml']
+    ml_results = iter(run_tasks(forest, tasks, force_joint=force_joint)) if tasks else iter(())
+    results = []
+    for kind, character, method, payload in plan:
+        if kind == 'ml':
+            results.append(next(ml_results))
+        elif kind == 'mp':
+            results.append(parsimonious_acr(forest, character, method, payload, forest_stats.num_nodes,
+                                            forest_stats.num_tips))
+        else:
+            results.append({CHARACTER: character, STATES: payload, METHOD: method})
+    return flatten_lists(results)

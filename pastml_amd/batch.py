@@ -300,12 +300,13 @@ class CharacterBatch(object):
                 eng.set_mask_words(self.masks[a:b], col_begin=a)
                 self._uploaded[a:b] = self.masks[a:b]
 
-    def bottom_up(self, models, is_marginal=True, alter=True):
+    def bottom_up(self, models, is_marginal=True, alter=True, errors=None):
         """
         Bottom-up log-likelihood of every character (pastml/ml.py:82-121 summed over the trees): optional alteration of
         the masks (characters with tau == 0), ONE device sweep over the m columns, restoration of the masks (marginal);
         after a joint sweep the arg-max tables of the altered nodes are rewritten on the device instead
-        (ml.py:115-119).  Returns ln L [m]; raises LikelihoodError for the first column without likelihood.
+        (ml.py:115-119).  Returns ln L [m]; raises LikelihoodError for the first column without likelihood -- or, if a
+        dict is given as ``errors``, records the failing columns there ({column: LikelihoodError}) and goes on.
         """
         rows = np.array([alter and 0 == mdl.tau for mdl in models], dtype=bool)
         before = self.masks.copy() if (rows.any() and not is_marginal) else None
@@ -321,8 +322,13 @@ class CharacterBatch(object):
         try:
             lnl = eng.bottom_up(is_marginal)
         except hip.ZeroLikelihoodError as e:
-            first = int(np.flatnonzero(e.err_child >= 0)[0])
-            raise LikelihoodError(first, int(e.err_parent[first]), int(e.err_child[first]))
+            failed = np.flatnonzero(e.err_child >= 0)
+            if errors is None:
+                first = int(failed[0])
+                raise LikelihoodError(first, int(e.err_parent[first]), int(e.err_child[first]))
+            for c in failed.tolist():
+                errors[c] = LikelihoodError(c, int(e.err_parent[c]), int(e.err_child[c]))
+            lnl = e.loglik
         if is_marginal and altered.any():
             self.unalter(altered)
         return lnl
@@ -748,6 +754,28 @@ def reconstruct(batch, tasks, lnl, force_joint=True):
             batch.select('MAP')
             note_restricted(ml.MAP, batch.bottom_up(models, is_marginal=True, alter=True))
             emit(ml.MAP)
+
+            if method == ml.ALL:
+                # the parsimonious reconstructions of the annotation, and the likelihood restricted to each of them
+                # (ml.py:718-733); a selection that leaves some zero-length branch without a common state has none
+                from pastml_amd.parsimony import parsimonious_acr, MP
+                mp_results = [parsimonious_acr(batch.flat.nodes[:len(flat.roots)], t.character, MP, t.model.states,
+                                               t.model.forest_stats.num_nodes, t.model.forest_stats.num_tips)
+                              for t in tasks]
+                for c in range(m):
+                    results[c].extend(mp_results[c])
+                for which in range(len(mp_results[0])):
+                    for c, t in enumerate(tasks):
+                        batch.masks[c] = flat.columns[mp_results[c][which][CHARACTER]].words
+                    failures = {}
+                    values = batch.bottom_up(models, is_marginal=True, alter=True, errors=failures)
+                    name = mp_results[0][which][METHOD]
+                    for c, t in enumerate(tasks):
+                        if c in failures:
+                            logger.error('{}\n{} parsimonious state selection is inconsistent in terms of ML.'
+                                         .format(likelihood_error(flat, failures[c]).message, name))
+                        else:
+                            current[c][ml.RESTRICTED_LOG_LIKELIHOOD_FORMAT_STR.format(name)] = float(values[c])
 
             if method == ml.MPPA or ml.is_meta_ml(method):
                 restrict_saved()   # the restricted-MAP sweep may have saved new masks (ml.py:675-680 before :541)

@@ -486,10 +486,6 @@ def ml_acr(forest, character, prediction_method, model, observed_frequencies, fo
     ``pastml_amd.acr.acr`` hands all characters of a run to :func:`pastml_amd.batch.run_tasks` together.
     """
     from pastml_amd.batch import Task, run_tasks
-    if ALL == prediction_method:
-        raise NotImplementedError('The ALL meta-method additionally needs the parsimony methods '
-                                  '(pastml/parsimony.py), which are outside the accelerated path; use ML, MPPA, '
-                                  'MAP or JOINT.')
     return run_tasks(forest, [Task(character, prediction_method, model, observed_frequencies)],
                      force_joint=force_joint)[0]
 

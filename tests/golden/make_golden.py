@@ -836,6 +836,89 @@ def case_hiv1c_all():
 
 CASES['hiv1c_all'] = case_hiv1c_all
 
+
+def case_parsimony():
+    """
+    pastml/parsimony.py on the Albanian tree (Country) and on random trees with polytomies, missing and multi-state
+    tips: the three reconstructions of the meta-method MP (selected states per node, steps, statistics), each method on
+    its own (DELTRAN alone reports other steps than inside MP), and the ALL meta-method of ml_acr on Albania / F81
+    (order of the results, likelihoods restricted to the parsimonious reconstructions).
+    """
+    from pastml.annotation import preannotate_forest
+    from pastml.parsimony import parsimonious_acr as rpars, STEPS
+    out = {}
+
+    def capture(prefix, roots, character, states, num_nodes, num_tips):
+        flat = our_tree.FlatForest.from_trees(roots)
+        s2i = {s: i for i, s in enumerate(states)}
+        ann = np.zeros((flat.n_nodes, len(states)), dtype=np.int8)
+        for i, n in enumerate(flat.nodes):
+            for s in getattr(n, character, set()):
+                ann[i, s2i[s]] = 1
+        out[prefix + 'annotation'] = ann
+        out[prefix + 'states'] = np.array(states, dtype=str)
+        out.update({prefix + k_: v for k_, v in tree_arrays(flat).items()})
+        for method in ('MP', 'DOWNPASS', 'ACCTRAN', 'DELTRAN'):
+            # every run starts from the annotation (a run overwrites the character feature when the method is not meta)
+            for i, n in enumerate(flat.nodes):
+                if ann[i].any():
+                    n.add_feature(character, set(np.array(states)[ann[i].astype(bool)]))
+                else:
+                    n.del_feature(character)
+            for res in rpars(roots, character, method, np.array(states), num_nodes, num_tips):
+                tag = '{}{}_{}_'.format(prefix, method, res['method'])
+                sel = np.zeros((flat.n_nodes, len(states)), dtype=np.int8)
+                for i, n in enumerate(flat.nodes):
+                    for s in getattr(n, res['character']):
+                        sel[i, s2i[s]] = 1
+                out[tag + 'selected'] = sel
+                out[tag + 'character'] = res['character']
+                out[tag + 'steps'] = res[STEPS]
+                out[tag + 'num_scenarios'] = float(res['num_scenarios'])
+                out[tag + 'num_unresolved_nodes'] = res['num_unresolved_nodes']
+                out[tag + 'num_states_per_node_avg'] = res['num_states_per_node_avg']
+
+    tree, df = albania_inputs()
+    preannotate_forest([tree], df=df)
+    fs = RForestStats([tree])
+    states = sorted(df['Country'].unique())
+    capture('alb_', [tree], 'Country', states, fs.num_nodes, fs.num_tips)
+    rng = np.random.default_rng(17)
+    for tag, kwargs, k in (('poly_', dict(n_tips=70, seed=13, max_arity=5, zero_frac=0.1), 4),
+                           ('forest_', dict(n_tips=60, seed=14, max_arity=3, zero_frac=0.0, n_trees=2), 3)):
+        flat = our_tree.FlatForest.random(**kwargs)
+        roots = [flat.nodes[r] for r in flat.roots]
+        states = list(synthetic.state_names(k))
+        for n in flat.nodes:
+            u = rng.random()
+            if n.is_leaf():
+                if u < 0.1:
+                    continue
+                n.add_feature('ch', set(rng.choice(states, size=2, replace=False)) if u < 0.2
+                              else {states[int(rng.integers(k))]})
+            elif u < 0.05:
+                n.add_feature('ch', {states[int(rng.integers(k))]})
+        fs = RForestStats(roots)
+        capture(tag, roots, 'ch', states, fs.num_nodes, fs.num_tips)
+
+    # ALL on Albania, F81
+    tree, df = albania_inputs()
+    res = racr(tree, df, prediction_method='ALL', model='F81', threads=1)
+    out['all_methods'] = np.array([r['method'] for r in res], dtype=str)
+    out['all_characters'] = np.array([r['character'] for r in res], dtype=str)
+    last = res[-1]
+    for key in ('log_likelihood', 'log_likelihood_restricted_JOINT', 'log_likelihood_restricted_MAP',
+                'log_likelihood_restricted_MPPA', 'log_likelihood_restricted_ACCTRAN',
+                'log_likelihood_restricted_DOWNPASS', 'log_likelihood_restricted_DELTRAN'):
+        if key in last:
+            out['all_' + key] = last[key]
+    out['all_mppa_keys'] = np.array(sorted(k_ for k_ in last.keys()), dtype=str)
+    out['all_sf'] = float(last['model'].sf)
+    save('parsimony', **out)
+
+
+CASES['parsimony'] = case_parsimony
+
 if __name__ == '__main__':
     np.random.seed(239)
     todo = sys.argv[1:] or list(CASES)
