@@ -74,26 +74,28 @@ def _serialize_acr(args):
         logger.debug('Serialized marginal probabilities for {} to {}.'.format(character, path))
 
 
-def _tip_state_words(character, forest, states):
+def _tip_state_words(character, forest, states, flat=None):
     """Annotation words of the tips in the reference's tip order (tree by tree, left to right)."""
     from pastml_amd.batch import annotation_words
-    flat = get_flat_forest(forest)
+    if flat is None:
+        flat = get_flat_forest(forest)
     words, _ = annotation_words(flat, character, states)
     tips = flat.tips[np.argsort(flat.post_rank[flat.tips], kind='stable')]
     return words[tips]
 
 
-def calculate_observed_freqs(character, forest, states):
+def calculate_observed_freqs(character, forest, states, flat=None):
     """
     Tip-state frequencies (a tip with n states counts 1/n for each) and the fraction of tips without a state
     (pastml/acr.py:282-299).  Tips with one state -- nearly all -- are counted in one pass; tips with several are added
-    in the reference's tip order, which matters for the last bits of a sum of thirds.
+    in the reference's tip order, which matters for the last bits of a sum of thirds.  ``flat``: the flattened forest
+    if the caller already has it (flattening re-validates the cached arrays against the tree, a walk per call).
     """
     from pastml_amd.batch import popcount
     states = np.asarray(states)
     k = len(states)
     state2index = dict(zip(states, range(k)))
-    words = _tip_state_words(character, forest, states)
+    words = _tip_state_words(character, forest, states, flat)
     per_tip = popcount(words).sum(axis=-1)
     bits = np.unpackbits(np.ascontiguousarray(words).view(np.uint8), axis=-1, bitorder='little')[:, :k]
     single = per_tip == 1
@@ -119,9 +121,10 @@ def flatten_lists(lists):
     return out
 
 
-def _restrict_annotation_to(states, column, forest):
+def _restrict_annotation_to(states, column, forest, flat=None):
     """HKY / JTT work on their own alphabets: states of the annotation outside of it are dropped (acr.py:155-163)."""
-    flat = get_flat_forest(forest)
+    if flat is None:
+        flat = get_flat_forest(forest)
     col = flat.columns.get(column)
     allowed = set(states)
     if isinstance(col, AnnotationColumn) and col.absent is None and \
@@ -203,6 +206,7 @@ def acr(forest, df=None, columns=None, column2states=None, prediction_method=MPP
         preannotate_forest(forest, df=df)
 
     forest_stats = ForestStats(forest)
+    flat = get_flat_forest(forest)   # once per call: the characters below all work on these arrays
     logger.debug('\n=============ACR===============================')
     column2parameters = column2parameters or {}
     column2rates = column2rates or {}
@@ -229,7 +233,7 @@ def acr(forest, df=None, columns=None, column2states=None, prediction_method=MPP
                     raise ValueError('The allowed states for model {} are {}, '
                                      'but your annotation file specifies {} as states in column {}.'
                                      .format(model_name, ', '.join(alphabet), ', '.join(states), character))
-                _restrict_annotation_to(alphabet, character, forest)
+                _restrict_annotation_to(alphabet, character, forest, flat)
                 states = alphabet
         if COPY == method:
             plan.append(('copy', character, method, states))
@@ -237,7 +241,7 @@ def acr(forest, df=None, columns=None, column2states=None, prediction_method=MPP
         if is_parsimonious(method):
             plan.append(('mp', character, method, states))
             continue
-        missing, observed, state2index = calculate_observed_freqs(character, forest, states)
+        missing, observed, state2index = calculate_observed_freqs(character, forest, states, flat)
         logger.debug('Observed frequencies for {}:{}{}.'.format(
             character, ''.join('\n\tfrequency of {}:\t{:.6f}'.format(s, observed[state2index[s]]) for s in states),
             '\n\tfraction of missing data:\t{:.6f}'.format(missing) if missing else ''))
@@ -253,7 +257,7 @@ def acr(forest, df=None, columns=None, column2states=None, prediction_method=MPP
     if comm is not None and comm.world > 1:
         plan = [plan[i] for i in sharding.shard_characters(len(plan), comm.rank, comm.world)]
     tasks = [item[3] for item in plan if item[0] == 'ml']
-    ml_results = iter(run_tasks(forest, tasks, force_joint=force_joint)) if tasks else iter(())
+    ml_results = iter(run_tasks(forest, tasks, force_joint=force_joint, flat=flat)) if tasks else iter(())
     results = []
     for kind, character, method, payload in plan:
         if kind == 'ml':

@@ -650,14 +650,15 @@ def likelihood_error(flat, e):
                                                                                flat.dist[e.child]))
 
 
-def optimise_group(batch, tasks):
+def optimise_group(batch, tasks, seeds=None):
     """Parameters of every character of the batch, all optimisers advancing together (SweepServer).  Returns ln L [m]."""
     m = len(tasks)
     batch.open_optimiser([block_width(t.model) for t in tasks])
     server = SweepServer(batch, range(m))
     # restart points come from per-character generators seeded, in character order, from numpy's global one: the
     # optimisers run concurrently, a shared generator would hand its draws out in arrival order
-    seeds = np.random.randint(0, 2 ** 31 - 1, size=m)
+    if seeds is None:
+        seeds = np.random.randint(0, 2 ** 31 - 1, size=m)
     lnl = np.full(m, np.nan)
     errors = {}
 
@@ -812,7 +813,7 @@ def _column_bytes(flat, k, widths):
     return flat.n_nodes * ((17 * ks + 96) + sum(widths) / max(1, len(widths)) * (8 * ks + 64))
 
 
-def run_tasks(forest, tasks, force_joint=True, device=None):
+def run_tasks(forest, tasks, force_joint=True, device=None, flat=None):
     """
     ml_acr for a list of Tasks on one forest.  Characters are grouped by (number of states, model family, prediction
     method); a group becomes one CharacterBatch -- or several, if the device memory does not hold all of its columns
@@ -820,32 +821,67 @@ def run_tasks(forest, tasks, force_joint=True, device=None):
     """
     if isinstance(forest, TreeNode):
         forest = [forest]
-    flat = get_flat_forest(forest)
+    if flat is None:
+        flat = get_flat_forest(forest)
     groups = {}
     for i, t in enumerate(tasks):
         groups.setdefault(t.group_key, []).append(i)
     out = [None] * len(tasks)
     stats = dict(groups=0, rounds=0, sweeps=0)
+    with hip.BareContext(device) as probe:
+        _, free = probe.memory()
+    jobs, total_bytes = [], 0.0
     for key, members in groups.items():
         k = key[0]
-        widths = [block_width(tasks[i].model) for i in members]
-        per_char = _column_bytes(flat, k, widths)
-        with hip.BareContext(device) as probe:
-            _, free = probe.memory()
+        per_char = _column_bytes(flat, k, [block_width(tasks[i].model) for i in members])
         chunk = max(1, min(len(members), 4096, int(0.6 * free / max(1.0, per_char))))
         for a in range(0, len(members), chunk):
-            part = members[a:a + chunk]
-            group = [tasks[i] for i in part]
-            with CharacterBatch(flat, k, len(group), device=device) as batch:
-                for c, t in enumerate(group):
-                    batch.set_annotation(c, *annotation_words(flat, t.character, t.model.states))
-                batch.initialize_allowed_states()
-                lnl, rounds = optimise_group(batch, group)
-                res = reconstruct(batch, group, lnl, force_joint=force_joint)
-                stats['groups'] += 1
-                stats['rounds'] += rounds
-                stats['sweeps'] += batch.n_sweeps
-            for i, r in zip(part, res):
-                out[i] = r
+            jobs.append((k, members[a:a + chunk]))
+            total_bytes += per_char * len(members[a:a + chunk])
+
+    # restart seeds of all characters, drawn here in task order (the groups may run concurrently)
+    seeds = np.random.randint(0, 2 ** 31 - 1, size=len(tasks))
+
+    def run(job):
+        k, part = job
+        group = [tasks[i] for i in part]
+        with CharacterBatch(flat, k, len(group), device=device) as batch:
+            for c, t in enumerate(group):
+                batch.set_annotation(c, *annotation_words(flat, t.character, t.model.states))
+            batch.initialize_allowed_states()
+            lnl, rounds = optimise_group(batch, group, seeds[part])
+            res = reconstruct(batch, group, lnl, force_joint=force_joint)
+            return part, res, rounds, batch.n_sweeps
+
+    # Groups are independent: when all of them fit the device together they run concurrently, each on its own contexts
+    # (= streams).  On small trees a sweep is a chain of latency-bound launches, so the sweeps of different groups
+    # overlap on the GPU and a run costs the rounds of its slowest group, not the sum over the groups.
+    concurrent = len(jobs) > 1 and total_bytes < 0.3 * free and os.environ.get('PASTML_AMD_CONCURRENT_GROUPS', '1') != '0'
+    done = []
+    if concurrent:
+        failures = []
+
+        def work(job):
+            try:
+                done.append(run(job))
+            except BaseException as e:
+                failures.append((job[1][0], e))
+        threads = [threading.Thread(target=work, args=(job,), name='pastml-group-{}'.format(j))
+                   for j, job in enumerate(jobs)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        if failures:
+            raise min(failures, key=lambda f: f[0])[1]
+    else:
+        for job in jobs:
+            done.append(run(job))
+    for part, res, rounds, sweeps in done:
+        stats['groups'] += 1
+        stats['rounds'] += rounds
+        stats['sweeps'] += sweeps
+        for i, r in zip(part, res):
+            out[i] = r
     run_tasks.last_stats = stats
     return out

@@ -9,9 +9,11 @@ Launch: one process per GPU with RANK / WORLD_SIZE / LOCAL_RANK in the environme
 them, so does ``bench.py --gpus N`` for the processes it starts).  ``init()`` picks the communicator:
 
 * world == 1                       -> :class:`LocalCommunicator` (no library, no GPU needed)
-* PASTML_AMD_COMM=gloo             -> :class:`GlooCommunicator` (torch.distributed on the CPU: tests and dry runs of the
-                                      N > 1 path on boxes with fewer GPUs than ranks -- RCCL refuses two ranks per device)
-* otherwise                        -> :class:`RcclCommunicator`
+* PASTML_AMD_COMM=gloo             -> :class:`TorchCommunicator` on gloo (CPU: tests and dry runs of the N > 1 path on
+                                      boxes with fewer GPUs than ranks -- RCCL refuses two ranks per device)
+* otherwise                        -> :class:`RcclCommunicator`; if it cannot be set up (no librccl, ...) a warning and
+                                      torch.distributed's nccl backend behind the same interface (PASTML_AMD_COMM=torch-nccl
+                                      asks for it directly)
 """
 import os
 import time
@@ -81,7 +83,12 @@ def exchange_unique_id(rank, make_id, timeout=300.0):
     path = os.path.join(d, 'rccl_id_{}.bin'.format(seq))
     if rank == 0:
         os.makedirs(d, exist_ok=True)
-        data = make_id()
+        try:
+            data = make_id()
+        except Exception:
+            with open(path + '.failed', 'w') as f:   # the other ranks must not wait for an id that will not come
+                f.write('rank 0 could not create the RCCL id')
+            raise
         tmp = path + '.tmp{}'.format(os.getpid())
         with open(tmp, 'wb') as f:
             f.write(data)
@@ -96,6 +103,8 @@ def exchange_unique_id(rank, make_id, timeout=300.0):
                 return data, path
         except OSError:
             pass
+        if os.path.exists(path + '.failed'):
+            raise RuntimeError('rank 0 could not create the RCCL id')
         if time.time() - t0 > timeout:
             raise TimeoutError('rank {}: no RCCL id from rank 0 at {} after {:.0f} s'.format(rank, path, timeout))
         time.sleep(0.01)
@@ -142,33 +151,48 @@ class RcclCommunicator(object):
             self._eng = None
 
 
-class GlooCommunicator(object):
-    """torch.distributed (gloo) on the CPU: the same interface for tests / dry runs; never used for measurements."""
-    name = 'gloo'
+class TorchCommunicator(object):
+    """
+    torch.distributed behind the same interface.  'gloo' (CPU): tests / dry runs of the N > 1 path on boxes with fewer
+    GPUs than ranks.  'nccl' (= RCCL through torch): the fallback if the library's own communicator cannot be set up.
+    """
 
-    def __init__(self, rank, world):
+    def __init__(self, rank, world, backend='gloo', device=None):
+        import torch
         import torch.distributed as dist
         self._dist = dist
+        self.name = backend if backend == 'gloo' else 'torch-' + backend
+        self._device = 'cpu'
         self._own = not dist.is_initialized()
-        if self._own:
-            dist.init_process_group('gloo', rank=rank, world_size=world)
+        if backend == 'nccl':
+            local = rank_world()[2] if device is None else device
+            torch.cuda.set_device(local)
+            self._device = 'cuda:{}'.format(local)
+            if self._own:
+                dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(self._device))
+        elif self._own:
+            dist.init_process_group(backend, rank=rank, world_size=world)
         self.rank, self.world = rank, world
 
     def allreduce(self, values, op='sum'):
         import torch
-        t = torch.tensor(np.atleast_1d(values), dtype=torch.float64)
+        t = torch.tensor(np.atleast_1d(values), dtype=torch.float64, device=self._device)
         self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM if op == 'sum' else self._dist.ReduceOp.MAX)
-        return t.numpy().copy()
+        return t.cpu().numpy().copy()
 
     def allreduce_loglik(self, loglik):
         return float(self.allreduce([LocalCommunicator().allreduce_loglik(loglik)])[0])
 
     def barrier(self):
-        self._dist.barrier()
+        self.allreduce([0.0])
 
     def close(self):
         if self._own and self._dist.is_initialized():
             self._dist.destroy_process_group()
+
+
+def GlooCommunicator(rank, world):
+    return TorchCommunicator(rank, world, 'gloo')
 
 
 _COMM = None
@@ -185,8 +209,16 @@ def init(device=None, engine=None, kind=None):
         _COMM = LocalCommunicator()
     elif kind == 'gloo':
         _COMM = GlooCommunicator(rank, world)
+    elif kind == 'torch-nccl':
+        _COMM = TorchCommunicator(rank, world, 'nccl', device=device)
     else:
-        _COMM = RcclCommunicator(rank, world, device=local_rank if device is None else device, engine=engine)
+        try:
+            _COMM = RcclCommunicator(rank, world, device=local_rank if device is None else device, engine=engine)
+        except Exception as e:   # librccl missing, no id from rank 0, ...: the same failure on every rank of the node
+            import sys
+            sys.stderr.write('pastml_amd.sharding: the library\'s RCCL communicator failed ({}); falling back to '
+                             'torch.distributed (nccl)\n'.format(e))
+            _COMM = TorchCommunicator(rank, world, 'nccl', device=device)
     return _COMM
 
 
