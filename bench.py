@@ -287,8 +287,7 @@ def secondary_measurements(device):
 
         def cfg2():
             eng.set_models([(spec, (1.0, 0.0, 1.0))])
-            eng.bottom_up(True)
-            eng.top_down_marginals(posterior=False, lh=False)
+            eng.marginal_pass(posterior=False, lh=False)
         ms = timed(cfg2, 50, eng)
         sb = schedule_bytes(flat, k, 1)
         out['cfg2'] = dict(workload='BASELINE config 2: balanced 65 536-tip tree, JC k=4, 1 character, marginal '
@@ -407,8 +406,9 @@ def main():
         # model parameters are re-sent every step, as an optimiser iteration would: forces the per-branch
         # transition data to be recomputed inside the step
         eng.set_models([(s, (1.0, 0.0, 1.0)) for s in specs])
-        lnl = eng.bottom_up(True)                       # inputs resident in HBM; returns ln L per character
-        eng.top_down_marginals(posterior=False, lh=False)  # TD + marginals + posteriors, outputs stay in HBM
+        # bottom-up sweep (ln L per character back to the host) + top-down sweep, marginals and posteriors (outputs stay
+        # in HBM): one call, one host round trip (pml_marginal_pass)
+        lnl = eng.marginal_pass(posterior=False, lh=False)[0]
         # the one collective of the path: summed log-likelihood over the ranks (RCCL all-reduce of 8 bytes)
         total = comm.allreduce_loglik(lnl)
         return total, lnl

@@ -150,6 +150,13 @@ int pml_bottom_up(pml_ctx* ctx, int is_marginal, double* loglik_out, int32_t* er
  */
 int pml_top_down_marginals(pml_ctx* ctx, double* posterior_out, double* lh_sum_out, double* lh_sf_out);
 /*
+ * pml_bottom_up(marginal) + pml_top_down_marginals in one call: both sweeps are submitted before the host waits, so a
+ * marginal pass costs one host round trip instead of two (what pastml/ml.py:700-707 does per tree in ml_acr).  Same
+ * outputs and statuses as the two calls; on PML_ZERO_LIKELIHOOD the top-down results are invalid.
+ */
+int pml_marginal_pass(pml_ctx* ctx, double* loglik_out, int32_t* err_parent, int32_t* err_child,
+                      double* posterior_out, double* lh_sum_out, double* lh_sf_out);
+/*
  * Joint reconstruction after a joint pml_bottom_up: pastml/ml.py:598-622 (choose_ancestral_states_joint).
  * joint_state_out[n_cols][n_nodes].
  */

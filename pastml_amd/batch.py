@@ -337,6 +337,23 @@ class CharacterBatch(object):
         """After a marginal sweep: (posterior [m, N, k], lh_sum [m, N], lh_sf [m, N]) (ml.py:240-290, 431-502)."""
         return self.engine.top_down_marginals()
 
+    def marginal_pass(self, models):
+        """
+        Bottom-up sweep with the masks as they are (no alteration: the caller has done it, ml.py:700-703) and the
+        top-down sweep + marginals + posteriors behind it, one host round trip (``pml_marginal_pass``).
+        Returns (ln L [m], posterior [m, N, k], lh_sum [m, N], lh_sf [m, N]).
+        """
+        eng = self.engine
+        self._upload_models(eng, models)
+        self._upload_masks()
+        eng.set_initial_masks(None)
+        self.n_sweeps += self.m
+        try:
+            return eng.marginal_pass()
+        except hip.ZeroLikelihoodError as e:
+            first = int(np.flatnonzero(e.err_child >= 0)[0])
+            raise LikelihoodError(first, int(e.err_parent[first]), int(e.err_child[first]))
+
     def joint_states(self):
         """Joint state of every node after a joint sweep (ml.py:598-622): int64 [m, N]."""
         return self.engine.joint_backtrace().astype(np.int64)
@@ -734,8 +751,7 @@ def reconstruct(batch, tasks, lnl, force_joint=True):
         if ml.is_marginal(method):
             batch.initialize_allowed_states()
             altered = batch.alter(np.array([0 == mdl.tau for mdl in models], dtype=bool))
-            batch.bottom_up(models, is_marginal=True, alter=False)
-            posterior, lh_sum, lh_sf = batch.top_down_marginals()
+            _, posterior, lh_sum, lh_sf = batch.marginal_pass(models)
             order = np.arange(flat.n_nodes) if len(flat.roots) == 1 else \
                 np.lexsort((np.arange(flat.n_nodes), flat.tree_id))   # tree by tree, level order each (ml.py:498-502)
             names = [flat.nodes[i].name for i in order] if flat.nodes is not None else list(order)

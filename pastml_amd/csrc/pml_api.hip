@@ -1456,9 +1456,8 @@ static int run_captured(pml_ctx* ctx, pml_ctx::GraphSlot& slot, const std::funct
     return PML_OK;
 }
 
-int pml_bottom_up(pml_ctx* ctx, int is_marginal, double* loglik_out, int32_t* err_parent, int32_t* err_child) {
-    PML_TRY(require_model(ctx));
-    if (!loglik_out) return fail(PML_ERR_INVALID, "loglik_out is NULL");
+// puts a bottom-up sweep on the stream (no host synchronisation)
+static int submit_bottom_up(pml_ctx* ctx, int is_marginal) {
     const bool small_path = ctx->small && is_marginal && ctx->kind == PML_MODEL_F81;
     const size_t CN = (size_t)ctx->C * ctx->N;
     if (!is_marginal && !ctx->d_J) {
@@ -1483,7 +1482,11 @@ int pml_bottom_up(pml_ctx* ctx, int is_marginal, double* loglik_out, int32_t* er
     }
     if (!eigen_fused(ctx)) ctx->prep_dirty = false;  // the fused eigen sweeps build P(t) in registers: no batch ran
     ctx->bu_fused = (is_marginal && ctx->kind == PML_MODEL_F81 && ctx->n_cherries > 0) || ctx->bu_fused_joint;
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PML_OK;
+}
+
+// after the stream has been synchronised: log-likelihoods and zero-likelihood reports of the last sweep
+static int collect_bottom_up(pml_ctx* ctx, int is_marginal, double* loglik_out, int32_t* err_parent, int32_t* err_child) {
     memcpy(loglik_out, ctx->h_loglik, sizeof(double) * ctx->C);
     const u64* err = ctx->h_err;
     int status = PML_OK;
@@ -1500,6 +1503,14 @@ int pml_bottom_up(pml_ctx* ctx, int is_marginal, double* loglik_out, int32_t* er
     }
     if (status == PML_OK) ctx->bu_mode = is_marginal ? 1 : 0;
     return status;
+}
+
+int pml_bottom_up(pml_ctx* ctx, int is_marginal, double* loglik_out, int32_t* err_parent, int32_t* err_child) {
+    PML_TRY(require_model(ctx));
+    if (!loglik_out) return fail(PML_ERR_INVALID, "loglik_out is NULL");
+    PML_TRY(submit_bottom_up(ctx, is_marginal));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return collect_bottom_up(ctx, is_marginal, loglik_out, err_parent, err_child);
 }
 
 // the top-down launches (shared by pml_top_down_marginals and the lazy TD materialisation of pml_download)
@@ -1615,11 +1626,9 @@ static int materialize_td(pml_ctx* ctx) {
     return PML_OK;
 }
 
-int pml_top_down_marginals(pml_ctx* ctx, double* posterior_out, double* lh_sum_out, double* lh_sf_out) {
-    PML_TRY(require_model(ctx));
-    if (ctx->bu_mode != 1) return fail(PML_ERR_INVALID, "pml_top_down_marginals needs a successful marginal pml_bottom_up first");
+// copies of the marginal results the caller asked for (stream-ordered behind the sweep), then one synchronisation
+static int fetch_marginals(pml_ctx* ctx, double* posterior_out, double* lh_sum_out, double* lh_sf_out) {
     const size_t CN = (size_t)ctx->C * ctx->N;
-    PML_TRY(run_top_down(ctx));
     if (posterior_out) {
         if (ctx->ks == ctx->k) {
             HIP_TRY(hipMemcpyAsync(posterior_out, ctx->d_post, CN * ctx->k * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -1641,6 +1650,31 @@ int pml_top_down_marginals(pml_ctx* ctx, double* posterior_out, double* lh_sum_o
         for (size_t i = 0; i < CN; ++i) lh_sf_out[i] = -(double)lhe[i] * l2;
     }
     return PML_OK;
+}
+
+int pml_top_down_marginals(pml_ctx* ctx, double* posterior_out, double* lh_sum_out, double* lh_sf_out) {
+    PML_TRY(require_model(ctx));
+    if (ctx->bu_mode != 1) return fail(PML_ERR_INVALID, "pml_top_down_marginals needs a successful marginal pml_bottom_up first");
+    PML_TRY(run_top_down(ctx));
+    return fetch_marginals(ctx, posterior_out, lh_sum_out, lh_sf_out);
+}
+
+int pml_marginal_pass(pml_ctx* ctx, double* loglik_out, int32_t* err_parent, int32_t* err_child, double* posterior_out,
+                      double* lh_sum_out, double* lh_sf_out) {
+    PML_TRY(require_model(ctx));
+    if (!loglik_out) return fail(PML_ERR_INVALID, "loglik_out is NULL");
+    // both sweeps go on the stream before the host looks at anything: the top-down sweep does not wait for a round trip
+    PML_TRY(submit_bottom_up(ctx, 1));
+    ctx->bu_mode = 1;  // provisional, for run_top_down's bookkeeping; collect_bottom_up has the last word
+    PML_TRY(run_top_down(ctx));
+    const int fetched = fetch_marginals(ctx, posterior_out, lh_sum_out, lh_sf_out);  // synchronises
+    ctx->bu_mode = -1;
+    const int status = collect_bottom_up(ctx, 1, loglik_out, err_parent, err_child);
+    if (status != PML_OK) {
+        ctx->td_valid = false;  // a column without likelihood: its top-down results mean nothing
+        return status;
+    }
+    return fetched;
 }
 
 int pml_joint_backtrace(pml_ctx* ctx, int32_t* joint_state_out) {

@@ -80,6 +80,7 @@ SIGNATURES = {
     'pml_pij_batch': [_ctx_p, _c_double_p],
     'pml_bottom_up': [_ctx_p, ctypes.c_int, _c_double_p, _c_int32_p, _c_int32_p],
     'pml_top_down_marginals': [_ctx_p, _c_double_p, _c_double_p, _c_double_p],
+    'pml_marginal_pass': [_ctx_p, _c_double_p, _c_int32_p, _c_int32_p, _c_double_p, _c_double_p, _c_double_p],
     'pml_joint_backtrace': [_ctx_p, _c_int32_p],
     'pml_select_states': [_ctx_p, ctypes.c_int, ctypes.c_int, _c_uint64_p, _c_uint64_p, _c_int32_p],
     'pml_marginal_counts': [_ctx_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_uint64, _c_double_p],
@@ -510,6 +511,25 @@ class Engine(BareContext):
                                                 None if lh_sum is None else _ptr(lh_sum, dbl),
                                                 None if lh_sf is None else _ptr(lh_sf, dbl)))
         return post, lh_sum, lh_sf
+
+    def marginal_pass(self, posterior=True, lh=True):
+        """bottom_up(True) + top_down_marginals() with one host round trip: (lnl, posterior, lh_sum, lh_sf)."""
+        CN = (self.n_cols, self.n_nodes)
+        lnl = np.empty(self.n_cols, dtype=np.float64)
+        ep = np.empty(self.n_cols, dtype=np.int32)
+        ec = np.empty(self.n_cols, dtype=np.int32)
+        post = np.empty(CN + (self.k,), dtype=np.float64) if posterior else None
+        lh_sum = np.empty(CN, dtype=np.float64) if lh else None
+        lh_sf = np.empty(CN, dtype=np.float64) if lh else None
+        dbl, i32 = ctypes.c_double, ctypes.c_int32
+        status = self._lib.pml_marginal_pass(self._ctx, _ptr(lnl, dbl), _ptr(ep, i32), _ptr(ec, i32),
+                                             None if post is None else _ptr(post, dbl),
+                                             None if lh_sum is None else _ptr(lh_sum, dbl),
+                                             None if lh_sf is None else _ptr(lh_sf, dbl))
+        if status == PML_ZERO_LIKELIHOOD:
+            raise ZeroLikelihoodError(self._lib.pml_last_error().decode(), ep, ec, lnl)
+        _check(status)
+        return lnl, post, lh_sum, lh_sf
 
     def joint_backtrace(self, copy_out=True):
         out = np.empty((self.n_cols, self.n_nodes), dtype=np.int32) if copy_out else None

@@ -691,3 +691,33 @@ def test_keep_td_option_survives_tree_upload_and_is_not_sticky():
             eng.download(hip.BUF_TD)
             assert (eng.profile_read(1)[1] == again) == keep  # without the option the next sweep is lean again
     assert np.array_equal(tds[0], tds[1], equal_nan=True)
+
+
+def test_marginal_pass_equals_the_two_calls():
+    """pml_marginal_pass = pml_bottom_up + pml_top_down_marginals with one host round trip: same bits, same errors."""
+    rng = np.random.default_rng(11)
+    for kind, k, tips in (('F81', 5, 300), ('F81', 64, 3000), ('HKY', 4, 200), ('EIGEN', 20, 500)):
+        flat = FlatForest.random(tips, seed=k, max_arity=3, zero_frac=0.0)
+        specs = [(random_spec(kind, k, rng), (1.2, 0.0, 1.0)) for _ in range(2)]
+        masks = np.stack([random_masks(flat, k, rng) for _ in range(2)])
+        with hip.Engine(flat, 2, k) as eng:
+            eng.set_models(specs)
+            eng.set_masks(masks)
+            lnl = eng.bottom_up(True)
+            post, lh_sum, lh_sf = eng.top_down_marginals()
+            lnl2, post2, lh_sum2, lh_sf2 = eng.marginal_pass()
+            assert np.array_equal(lnl, lnl2) and np.array_equal(post, post2)
+            assert np.array_equal(lh_sum, lh_sum2) and np.array_equal(lh_sf, lh_sf2)
+            # results stay valid for what follows a marginal pass
+            assert eng.download(hip.BUF_POSTERIOR, 1).shape == (flat.n_nodes, k)
+    # a column without likelihood: the error of pml_bottom_up, and no top-down results
+    z = load_golden('edge_zero_likelihood')
+    flat = golden_forest(z)
+    spec, rates = golden_spec(z)
+    with hip.Engine(flat, 1, 3) as eng:
+        eng.set_models([(spec, rates)])
+        eng.set_masks(z['masks'])
+        with pytest.raises(hip.ZeroLikelihoodError):
+            eng.marginal_pass()
+        with pytest.raises(hip.HipError):
+            eng.download(hip.BUF_POSTERIOR)
