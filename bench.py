@@ -309,8 +309,7 @@ def secondary_measurements(device):
         eng.set_tip_states(synthetic.tip_states(flat.n_tips, k, 0))
 
         def cfg3():
-            eng.bottom_up(False)
-            eng.joint_backtrace(copy_out=False)
+            eng.joint_pass(copy_out=False)
         ms = timed(cfg3, 20, eng)
         ms_sweep = timed(lambda: eng.bottom_up(False), 20, eng)
         flops = 2.0 * k ** 3 * (flat.n_nodes - 1)           # P(t) = A diag(exp(d t)) A^-1 per branch

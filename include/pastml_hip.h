@@ -161,6 +161,8 @@ int pml_marginal_pass(pml_ctx* ctx, double* loglik_out, int32_t* err_parent, int
  * joint_state_out[n_cols][n_nodes].
  */
 int pml_joint_backtrace(pml_ctx* ctx, int32_t* joint_state_out);
+/* pml_bottom_up(joint) + pml_joint_backtrace in one call (one host round trip); outputs and statuses of the two */
+int pml_joint_pass(pml_ctx* ctx, double* loglik_out, int32_t* err_parent, int32_t* err_child, int32_t* joint_state_out);
 
 /*
  * State selection on the device after pml_top_down_marginals: method 0 = MAP (pastml/ml.py:577-595), 1 = MPPA

@@ -300,7 +300,12 @@ class CharacterBatch(object):
                 eng.set_mask_words(self.masks[a:b], col_begin=a)
                 self._uploaded[a:b] = self.masks[a:b]
 
-    def bottom_up(self, models, is_marginal=True, alter=True, errors=None):
+    def joint_pass(self, models):
+        """Joint sweep (with alteration, ml.py:688-691) and the back-trace behind it, one host round trip
+        (``pml_joint_pass``): (ln L [m], joint states int64 [m, N])."""
+        return self.bottom_up(models, is_marginal=False, alter=True, backtrace=True)
+
+    def bottom_up(self, models, is_marginal=True, alter=True, errors=None, backtrace=False):
         """
         Bottom-up log-likelihood of every character (pastml/ml.py:82-121 summed over the trees): optional alteration of
         the masks (characters with tau == 0), ONE device sweep over the m columns, restoration of the masks (marginal);
@@ -319,8 +324,12 @@ class CharacterBatch(object):
         else:
             eng.set_initial_masks(None)
         self.n_sweeps += self.m
+        joint = None
         try:
-            lnl = eng.bottom_up(is_marginal)
+            if backtrace:
+                lnl, joint = eng.joint_pass()
+            else:
+                lnl = eng.bottom_up(is_marginal)
         except hip.ZeroLikelihoodError as e:
             failed = np.flatnonzero(e.err_child >= 0)
             if errors is None:
@@ -331,7 +340,7 @@ class CharacterBatch(object):
             lnl = e.loglik
         if is_marginal and altered.any():
             self.unalter(altered)
-        return lnl
+        return (lnl, joint.astype(np.int64)) if backtrace else lnl
 
     def top_down_marginals(self):
         """After a marginal sweep: (posterior [m, N, k], lh_sum [m, N], lh_sf [m, N]) (ml.py:240-290, 431-502)."""
@@ -741,8 +750,8 @@ def reconstruct(batch, tasks, lnl, force_joint=True):
 
     try:
         if method != ml.MAP:
-            note_restricted(ml.JOINT, batch.bottom_up(models, is_marginal=False, alter=True))
-            joint = batch.joint_states()
+            lnl_joint, joint = batch.joint_pass(models)
+            note_restricted(ml.JOINT, lnl_joint)
             batch.masks = one_hot_words(joint, k)
             for c, t in enumerate(tasks):
                 flat.set_column(feature_name(t.character, ml.JOINT_STATE), ArrayColumn(joint[c], convert=int))

@@ -112,7 +112,7 @@ struct pml_ctx {
         hipGraphExec_t exec = nullptr;
         bool has_init = false;
     };
-    GraphSlot bu_graph[2], td_graph;
+    GraphSlot bu_graph[2], td_graph, bt_graph;
     bool graphs = true;
     double* h_loglik = nullptr;  // pinned staging of the per-column results
     // pi, sf, tau, tau factor, mu, kappa of all columns live in ONE device block with a pinned host mirror of the same
@@ -154,6 +154,7 @@ static void free_all(pml_ctx* ctx) {
     drop_graph(ctx->bu_graph[0]);
     drop_graph(ctx->bu_graph[1]);
     drop_graph(ctx->td_graph);
+    drop_graph(ctx->bt_graph);
     if (ctx->h_loglik) (void)hipHostFree(ctx->h_loglik);
     if (ctx->h_err) (void)hipHostFree(ctx->h_err);
     if (ctx->h_params) (void)hipHostFree(ctx->h_params);
@@ -1677,28 +1678,39 @@ int pml_marginal_pass(pml_ctx* ctx, double* loglik_out, int32_t* err_parent, int
     return fetched;
 }
 
-int pml_joint_backtrace(pml_ctx* ctx, int32_t* joint_state_out) {
-    PML_TRY(require_model(ctx));
-    if (ctx->bu_mode != 0) return fail(PML_ERR_INVALID, "pml_joint_backtrace needs a successful joint pml_bottom_up first");
-    // the narrow depths below the roots in one launch, the wide ones one launch each
+// the back-trace launches (no host synchronisation): the narrow depths below the roots in one launch, the wide ones one
+// launch each
+static int submit_joint_backtrace(pml_ctx* ctx) {
     int head = 0;
     {
         std::vector<int> off(ctx->td_offsets.begin() + 1, ctx->td_offsets.end());
         head = narrow_levels(off, ctx->n_td_levels - 1, true, ctx->C, 1024);
     }
-    if (head > 0) {
-        hipLaunchKernelGGL(joint_backtrace_narrow_kernel, dim3(1, ctx->C), dim3(PML_BLOCK), 0, ctx->stream, tree_of(ctx),
-                           cols_of(ctx), state_of(ctx), ctx->d_td_offsets, 1, head);
-        HIP_TRY(hipGetLastError());
+    auto enqueue = [&]() -> int {
+        if (head > 0) {
+            hipLaunchKernelGGL(joint_backtrace_narrow_kernel, dim3(1, ctx->C), dim3(PML_BLOCK), 0, ctx->stream,
+                               tree_of(ctx), cols_of(ctx), state_of(ctx), ctx->d_td_offsets, 1, head);
+            HIP_TRY(hipGetLastError());
+        }
+        for (int l = 1 + head; l < ctx->n_td_levels; ++l) {
+            const int a = ctx->td_offsets[l], b = ctx->td_offsets[l + 1];
+            if (b <= a) continue;
+            dim3 grid(grid_for(b - a, PML_BLOCK, ctx->C), ctx->C);
+            hipLaunchKernelGGL(joint_backtrace_kernel, grid, dim3(PML_BLOCK), 0, ctx->stream, tree_of(ctx), cols_of(ctx),
+                               state_of(ctx), a, b);
+            HIP_TRY(hipGetLastError());
+        }
+        return PML_OK;
+    };
+    if (ctx->graphs && !ctx->profile && ctx->n_td_levels - head >= 4) {
+        PML_TRY(run_captured(ctx, ctx->bt_graph, enqueue));
+    } else {
+        PML_TRY(enqueue());
     }
-    for (int l = 1 + head; l < ctx->n_td_levels; ++l) {
-        const int a = ctx->td_offsets[l], b = ctx->td_offsets[l + 1];
-        if (b <= a) continue;
-        dim3 grid(grid_for(b - a, PML_BLOCK, ctx->C), ctx->C);
-        hipLaunchKernelGGL(joint_backtrace_kernel, grid, dim3(PML_BLOCK), 0, ctx->stream, tree_of(ctx), cols_of(ctx),
-                           state_of(ctx), a, b);
-        HIP_TRY(hipGetLastError());
-    }
+    return PML_OK;
+}
+
+static int fetch_joint_states(pml_ctx* ctx, int32_t* joint_state_out) {
     ctx->js_valid = true;
     ctx->js_ever = true;
     if (joint_state_out)
@@ -1706,6 +1718,28 @@ int pml_joint_backtrace(pml_ctx* ctx, int32_t* joint_state_out) {
                                ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return PML_OK;
+}
+
+int pml_joint_backtrace(pml_ctx* ctx, int32_t* joint_state_out) {
+    PML_TRY(require_model(ctx));
+    if (ctx->bu_mode != 0) return fail(PML_ERR_INVALID, "pml_joint_backtrace needs a successful joint pml_bottom_up first");
+    PML_TRY(submit_joint_backtrace(ctx));
+    return fetch_joint_states(ctx, joint_state_out);
+}
+
+int pml_joint_pass(pml_ctx* ctx, double* loglik_out, int32_t* err_parent, int32_t* err_child, int32_t* joint_state_out) {
+    PML_TRY(require_model(ctx));
+    if (!loglik_out) return fail(PML_ERR_INVALID, "loglik_out is NULL");
+    // joint sweep and back-trace submitted together: one host round trip
+    PML_TRY(submit_bottom_up(ctx, 0));
+    PML_TRY(submit_joint_backtrace(ctx));
+    const int fetched = fetch_joint_states(ctx, joint_state_out);  // synchronises
+    const int status = collect_bottom_up(ctx, 0, loglik_out, err_parent, err_child);
+    if (status != PML_OK) {
+        ctx->js_valid = false;
+        return status;
+    }
+    return fetched;
 }
 
 int pml_marginal_counts(pml_ctx* ctx, int32_t col, int32_t n_repetitions, uint64_t seed, double* counts_out) {

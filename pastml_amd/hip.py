@@ -82,6 +82,7 @@ SIGNATURES = {
     'pml_top_down_marginals': [_ctx_p, _c_double_p, _c_double_p, _c_double_p],
     'pml_marginal_pass': [_ctx_p, _c_double_p, _c_int32_p, _c_int32_p, _c_double_p, _c_double_p, _c_double_p],
     'pml_joint_backtrace': [_ctx_p, _c_int32_p],
+    'pml_joint_pass': [_ctx_p, _c_double_p, _c_int32_p, _c_int32_p, _c_int32_p],
     'pml_select_states': [_ctx_p, ctypes.c_int, ctypes.c_int, _c_uint64_p, _c_uint64_p, _c_int32_p],
     'pml_marginal_counts': [_ctx_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_uint64, _c_double_p],
     'pml_download': [_ctx_p, ctypes.c_int, ctypes.c_int32, ctypes.c_void_p],
@@ -535,6 +536,20 @@ class Engine(BareContext):
         out = np.empty((self.n_cols, self.n_nodes), dtype=np.int32) if copy_out else None
         _check(self._lib.pml_joint_backtrace(self._ctx, None if out is None else _ptr(out, ctypes.c_int32)))
         return out
+
+    def joint_pass(self, copy_out=True):
+        """bottom_up(False) + joint_backtrace() with one host round trip: (lnl, joint states or None)."""
+        lnl = np.empty(self.n_cols, dtype=np.float64)
+        ep = np.empty(self.n_cols, dtype=np.int32)
+        ec = np.empty(self.n_cols, dtype=np.int32)
+        out = np.empty((self.n_cols, self.n_nodes), dtype=np.int32) if copy_out else None
+        i32 = ctypes.c_int32
+        status = self._lib.pml_joint_pass(self._ctx, _ptr(lnl, ctypes.c_double), _ptr(ep, i32), _ptr(ec, i32),
+                                          None if out is None else _ptr(out, i32))
+        if status == PML_ZERO_LIKELIHOOD:
+            raise ZeroLikelihoodError(self._lib.pml_last_error().decode(), ep, ec, lnl)
+        _check(status)
+        return lnl, out
 
     def select_states(self, method, force_joint=False, lh_masks=None, packed=False):
         """

@@ -721,3 +721,32 @@ def test_marginal_pass_equals_the_two_calls():
             eng.marginal_pass()
         with pytest.raises(hip.HipError):
             eng.download(hip.BUF_POSTERIOR)
+
+
+def test_joint_pass_equals_the_two_calls():
+    """pml_joint_pass = joint pml_bottom_up + pml_joint_backtrace with one host round trip (back-trace replayed as a
+    graph): same bits; on altered forests too."""
+    rng = np.random.default_rng(12)
+    for kind, k, tips, zero in (('F81', 5, 3000, 0.0), ('F81', 64, 3000, 0.0), ('EIGEN', 20, 3000, 0.0), ('HKY', 4, 500, 0.0)):
+        flat = FlatForest.random(tips, seed=k + 3, max_arity=3, zero_frac=zero)
+        specs = [(random_spec(kind, k, rng), (1.2, 0.0, 1.0)) for _ in range(2)]
+        masks = np.stack([random_masks(flat, k, rng) for _ in range(2)])
+        with hip.Engine(flat, 2, k) as eng:
+            eng.set_models(specs)
+            eng.set_masks(masks)
+            lnl = eng.bottom_up(False)
+            states = eng.joint_backtrace()
+            for _ in range(2):   # the second call replays the captured graphs
+                lnl2, states2 = eng.joint_pass()
+                assert np.array_equal(lnl, lnl2) and np.array_equal(states, states2)
+            assert np.array_equal(eng.download(hip.BUF_JOINT_STATE, 1), states[1])
+    z = load_golden('edge_zero')
+    flat = golden_forest(z)
+    spec, rates = golden_spec(z)
+    with hip.Engine(flat, 1, len(spec['pi'])) as eng:
+        eng.set_models([(spec, rates)])
+        eng.set_masks(z['masks_altered'])
+        eng.set_initial_masks(z['masks_initial'])
+        lnl, states = eng.joint_pass()
+        np.testing.assert_allclose(lnl[0], z['loglik_joint'], rtol=LNL_RTOL)
+        assert np.array_equal(states[0], z['joint_state'])
