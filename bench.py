@@ -312,13 +312,16 @@ def secondary_measurements(device):
             eng.joint_pass(copy_out=False)
         ms = timed(cfg3, 20, eng)
         ms_sweep = timed(lambda: eng.bottom_up(False), 20, eng)
+        # the marginal pass of the same problem: no P(t) is formed, msg = A (e o (A^-1 v)) as two small GEMMs per 16 nodes
+        ms_marginal = timed(lambda: eng.marginal_pass(posterior=False, lh=False), 20, eng)
         flops = 2.0 * k ** 3 * (flat.n_nodes - 1)           # P(t) = A diag(exp(d t)) A^-1 per branch
         # compulsory bytes of the fused sweep: message (8 k) written + read per non-root node, arg-max row (k bytes),
         # mask word, branch length, exponent
         bytes_ = (flat.n_nodes - 1) * (2 * 8 * k + k + 8 + 8 + 8 + 8)
         out['cfg3'] = dict(workload='BASELINE config 3: balanced 262 144-tip tree, JTT k=20, 1 character, joint (Pupko) '
                                     'sweep + back-trace, fused FP64 matrix-core sweep', ms_per_pass=ms,
-                           ms_joint_sweep=ms_sweep, value=flat.n_nodes * k / (ms * 1e-3), unit='node*state*char/s',
+                           ms_joint_sweep=ms_sweep, ms_marginal_pass=ms_marginal,
+                           value=flat.n_nodes * k / (ms * 1e-3), unit='node*state*char/s',
                            roofline=dict(bound='mfma', flops=flops, achieved=flops / (ms_sweep * 1e-3) / 1e12,
                                          peak=FP64_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
                                          frac=flops / (ms_sweep * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,

@@ -14,7 +14,7 @@
 #include <string>
 #include <vector>
 
-#include "pml_kernels_eigen_mfma.h"
+#include "pml_kernels_eigen_gemm.h"
 #include "pml_kernels_counts.h"
 #include "pml_comm.h"
 
@@ -505,6 +505,67 @@ static int launch_eigen_fused(pml_ctx* ctx, int mode, const int* nodes, int firs
 #undef PML_EIG_MODES
 #undef PML_EIG_CASE
     return fail(PML_ERR_UNSUPPORTED, "no fused eigen kernel for k = %d", k);
+}
+
+// sum sweeps of the eigen models without forming P(t) (pml_kernels_eigen_gemm.h): one launch over a list (nodes) or a
+// contiguous id range (first) of n nodes
+static bool eigen_gemm(const pml_ctx* c) {
+    static const bool off = getenv("PASTML_HIP_NO_EIGEN_GEMM") != nullptr;
+    return !off && eigen_fused(c);
+}
+
+static int launch_eigen_gemm(pml_ctx* ctx, int mode, const int* nodes, int first, int n) {
+    if (n <= 0) return PML_OK;
+    const int KS = (ctx->k + 3) / 4;
+    const PmlTree t = tree_of(ctx);
+    const PmlCols c = cols_of(ctx);
+    const PmlState st = state_of(ctx);
+    const PmlModel m = model_of(ctx);
+    int blocks = (n + PML_WAVES_PER_BLOCK * 16 - 1) / (PML_WAVES_PER_BLOCK * 16);
+    const int cap = std::max(8, 16384 / std::max(1, ctx->C));
+    if (blocks > cap) blocks = cap;
+#define PML_EIGG_CASE(KS_, MODE_)                                                                                   \
+    if (KS == KS_ && mode == MODE_) {                                                                               \
+        hipLaunchKernelGGL((eigen_gemm_kernel<KS_, MODE_>), dim3(blocks, ctx->C), dim3(PML_BLOCK), 0, ctx->stream, \
+                           t, c, m, st, nodes, first, n);                                                           \
+        HIP_TRY(hipGetLastError());                                                                                 \
+        return PML_OK;                                                                                              \
+    }
+#define PML_EIGG_MODES(KS_) PML_EIGG_CASE(KS_, PML_EIGG_BU) PML_EIGG_CASE(KS_, PML_EIGG_TIPS) PML_EIGG_CASE(KS_, PML_EIGG_TD)
+    PML_EIGG_MODES(4)
+    PML_EIGG_MODES(5)
+    PML_EIGG_MODES(6)
+    PML_EIGG_MODES(7)
+    PML_EIGG_MODES(8)
+#undef PML_EIGG_MODES
+#undef PML_EIGG_CASE
+    return fail(PML_ERR_UNSUPPORTED, "no eigen kernel for k = %d", ctx->k);
+}
+
+static int launch_eigen_gemm_narrow(pml_ctx* ctx, int mode, const int* nodes, const int* d_offsets, int first_level,
+                                    int n_levels) {
+    if (n_levels <= 0) return PML_OK;
+    const int KS = (ctx->k + 3) / 4;
+    const PmlTree t = tree_of(ctx);
+    const PmlCols c = cols_of(ctx);
+    const PmlState st = state_of(ctx);
+    const PmlModel m = model_of(ctx);
+#define PML_EIGG_CASE(KS_, MODE_)                                                                                      \
+    if (KS == KS_ && mode == MODE_) {                                                                                  \
+        hipLaunchKernelGGL((eigen_gemm_narrow_kernel<KS_, MODE_>), dim3(1, ctx->C), dim3(PML_BLOCK), 0, ctx->stream, \
+                           t, c, m, st, nodes, d_offsets + first_level, n_levels);                                     \
+        HIP_TRY(hipGetLastError());                                                                                    \
+        return PML_OK;                                                                                                 \
+    }
+#define PML_EIGG_MODES(KS_) PML_EIGG_CASE(KS_, PML_EIGG_BU) PML_EIGG_CASE(KS_, PML_EIGG_TD)
+    PML_EIGG_MODES(4)
+    PML_EIGG_MODES(5)
+    PML_EIGG_MODES(6)
+    PML_EIGG_MODES(7)
+    PML_EIGG_MODES(8)
+#undef PML_EIGG_MODES
+#undef PML_EIGG_CASE
+    return fail(PML_ERR_UNSUPPORTED, "no eigen kernel for k = %d", ctx->k);
 }
 
 // fused eigen sweeps: levels [first_level, first_level + n_levels) of a level table in one launch
@@ -1399,6 +1460,17 @@ static int enqueue_bottom_up(pml_ctx* ctx, int is_marginal, bool small_path, boo
         }
         PML_TRY(prof_end(ctx, 0, nl));
         joint_fused = true;
+    } else if (eig && is_marginal && eigen_gemm(ctx)) {
+        // marginal sweep: P(t) is never formed, msg = A (e o (A^-1 v)) as two small GEMMs per 16 nodes
+        PML_TRY(launch_eigen_gemm(ctx, PML_EIGG_TIPS, ctx->d_tips, 0, ctx->n_tips));
+        // levels one workgroup finishes in a pass or two per wave (4 waves x 16 nodes) share one launch
+        const int tail = narrow_levels(ctx->bu_offsets, ctx->n_bu_levels, false, ctx->C, 2 * PML_WAVES_PER_BLOCK * 16);
+        for (int l = 0; l < ctx->n_bu_levels - tail; ++l) {
+            const int a = ctx->bu_offsets[l], b = ctx->bu_offsets[l + 1];
+            PML_TRY(launch_eigen_gemm(ctx, PML_EIGG_BU, ctx->d_bu_order + a, 0, b - a));
+        }
+        PML_TRY(launch_eigen_gemm_narrow(ctx, PML_EIGG_BU, ctx->d_bu_order, ctx->d_bu_offsets, ctx->n_bu_levels - tail, tail));
+        PML_TRY(prof_end(ctx, 0, ctx->n_bu_levels + 1 - tail + (tail > 0 ? 1 : 0)));
     } else if (eig) {
         // every node once, in the launch of its level: the tips first, then the internal nodes by height
         const int mode = is_marginal ? PML_EIG_BU_MARG : PML_EIG_BU_JOINT;
@@ -1540,6 +1612,24 @@ static int run_top_down(pml_ctx* ctx) {
         if (td_small) {
             PML_TRY(dispatch_small_f81(ctx, false, 0));
             n_launch = 1;
+        }
+        if (eigen_gemm(ctx)) {
+            int head = 0;
+            {
+                std::vector<int> off(ctx->td_offsets.begin() + 1, ctx->td_offsets.end());
+                head = narrow_levels(off, ctx->n_td_levels - 1, true, ctx->C, 2 * PML_WAVES_PER_BLOCK * 16);
+            }
+            if (head > 0) {
+                PML_TRY(launch_eigen_gemm_narrow(ctx, PML_EIGG_TD, nullptr, ctx->d_td_offsets, 1, head));
+                ++n_launch;
+            }
+            for (int d = 1 + head; d < ctx->n_td_levels; ++d) {
+                const int a = ctx->td_offsets[d], b = ctx->td_offsets[d + 1];
+                PML_TRY(launch_eigen_gemm(ctx, PML_EIGG_TD, nullptr, a, b - a));
+                if (b > a) ++n_launch;
+            }
+            PML_TRY(prof_end(ctx, 1, n_launch));
+            return PML_OK;
         }
         if (eigen_fused(ctx)) {
             // child-centric: the nodes of a depth are a contiguous id range (roots are depth 0, done above)

@@ -1,0 +1,286 @@
+// Eigen models (CUSTOM_RATES, JTT), 16 <= k <= 32: the SUM sweeps (marginal bottom-up, top-down) without ever forming
+// P(t).  Both apply P(t_n) = A diag(exp(d t_n)) A^-1 of the branch above a node n to ONE vector of that node
+//   bottom-up  (ml.py:124-148)   msg_n = P v_n        v_n = mask o prod of the children's messages
+//   top-down   (ml.py:273-290)   td_n  = P x_n        x_n = TD_p o BU_p / msg_n
+// so  P v = A (e o (A^-1 v)),  e_m = exp(d_m t_n):  two k x k matrix-vector products and k exponentials per node -- 4 k^2
+// flops instead of the 2 k^3 of building the matrix first (pml_kernels_eigen_mfma.h, which the joint sweep keeps: a
+// maximum over j of P[i][j] v[j] needs the entries of P).  Sixteen nodes of a level are the sixteen columns of the
+// right-hand operand, so the products are two small GEMMs on the FP64 matrix cores with the constant matrices A^-1, A as
+// the left operands held in registers:
+//   Y[m][node] = sum_j Ainv[m][j] V[j][node],   Z = Y o E,   MSG[i][node] = sum_m A[i][m] Z[m][node].
+// In v_mfma_f64_16x16x4_f64 the right operand of k-step s is held by lane (lo, hi) as element [4 s + hi][column lo] and
+// the result tile hands lane (lo, hi) the rows hi + 4 reg of column lo: a lane that owns the states {hi, 4 + hi, 8 + hi,
+// ..} of node lo gets exactly those states of Y, and then of MSG, back -- both GEMMs, the exponentials and everything
+// per node stay in the lane; only per-node reductions (zero check, rescaling, likelihood sum) cross the four lanes
+// (lo, lo + 16, lo + 32, lo + 48) of a node.  20 MFMAs per 16 nodes at k = 20 (the matrix-building sweep: 200).
+//
+// Rounding: P v is evaluated in a different order than the reference's (P built, then applied).  Both carry an
+// absolute error of a few ulps of |A| |A^-1| |v| (cond(A) = 2 for JTT); messages are bounded below by
+// min_j P[i][j] max v, so relative errors stay ~1e-11 (tests: 1e-9 on posteriors, 1e-11 on ln L).
+#pragma once
+#include "pml_kernels_eigen_mfma.h"
+
+#define PML_EIGG_BU 0    // marginal bottom-up, internal nodes
+#define PML_EIGG_TIPS 1  // marginal bottom-up, tips (no children)
+#define PML_EIGG_TD 2    // top-down + marginal likelihoods + posteriors
+
+template <int KS>
+struct EigGemm {
+    static constexpr int KP = 4 * KS;             // padded states
+    static constexpr int MT = (KP + 15) / 16;     // row tiles of the constant matrices
+};
+
+// per-node reductions over the four lanes (lo, lo + 16 q) that share a node
+__device__ __forceinline__ bool node_any(bool p, int lo) {
+    const u64 b = __ballot(p);
+    return (((b | (b >> 16) | (b >> 32) | (b >> 48)) >> lo) & 1ull) != 0ull;
+}
+
+__device__ __forceinline__ double node_max(double v) {
+    v = fmax(v, __shfl_xor(v, 16, 64));
+    return fmax(v, __shfl_xor(v, 32, 64));
+}
+
+__device__ __forceinline__ double node_sum(double v) {  // fixed order: bit-reproducible
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+}
+
+// exact lazy rescaling of a node's vector spread over its four lanes (same rule as lazy_rescale in pml_device.h)
+template <int KS>
+__device__ __forceinline__ int node_lazy_rescale(double (&v)[KS], int lo) {
+    bool out_of_band = false;
+    double m = 0.0;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        m = fmax(m, v[s]);
+        out_of_band |= (v[s] != 0.0) && (v[s] < 0x1p-200 || v[s] > 0x1p+200);
+    }
+    if (!__any(out_of_band)) return 0;           // wave-uniform early out (the common case)
+    const bool mine = node_any(out_of_band, lo);
+    m = node_max(m);
+    if (!mine || !(m > 0.0) || isinf(m)) return 0;
+    const int ex = exponent_of(m);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) v[s] = __builtin_ldexp(v[s], -ex);
+    return ex;
+}
+
+// per-wave constants of a column: the left operands of the two products in registers
+template <int KS>
+struct EigGemmWave {
+    int k, ks, col, lo, hi;
+    size_t colN;
+    double a1[EigGemm<KS>::MT][KS], a2[EigGemm<KS>::MT][KS], dl[KS], pil[KS];
+    double sfc, tau, tf;
+};
+
+template <int KS>
+__device__ __forceinline__ void eig_gemm_init(EigGemmWave<KS>& W, const PmlTree& t, const PmlCols& c, const PmlModel& m) {
+    constexpr int MT = EigGemm<KS>::MT;
+    const int k = c.k, ks = c.ks;  // ks == 4 KS (checked on the host)
+    const int col = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int lo = lane & 15, hi = lane >> 4;
+    W.k = k;
+    W.ks = ks;
+    W.col = col;
+    W.lo = lo;
+    W.hi = hi;
+    W.colN = (size_t)col * t.N;
+    // constant operands: rows 16 mt + lo of A^-1 (first product) and of A (second), k-step s: column 4 s + hi
+    const double* gA = m.A + (size_t)col * k * k;
+    const double* gB = m.Ainv + (size_t)col * k * k;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int row = 16 * mt + lo, cc = 4 * s + hi;
+            const bool in = row < k && cc < k;
+            W.a1[mt][s] = in ? gB[row * k + cc] : 0.0;
+            W.a2[mt][s] = in ? gA[row * k + cc] : 0.0;
+        }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int j = 4 * s + hi;
+        W.dl[s] = j < k ? m.d[(size_t)col * k + j] : 0.0;
+        W.pil[s] = j < k ? c.pi[(size_t)col * ks + j] : 0.0;
+    }
+    W.sfc = m.sf[col];
+    W.tau = m.tau[col];
+    W.tf = m.tauf[col];
+}
+
+// One pass of a wave: 16 nodes, lane (lo, hi) owns the states {4 s + hi} of node n (act: slot lo holds a node).
+template <int KS, int MODE>
+__device__ __forceinline__ void eig_gemm_pass(const EigGemmWave<KS>& W, const PmlTree& t, const PmlCols& c,
+                                              const PmlState& st, bool act, int n) {
+    constexpr int MT = EigGemm<KS>::MT;
+    const int k = W.k, ks = W.ks, col = W.col, lo = W.lo, hi = W.hi;
+    const size_t colN = W.colN;
+    const double sfc = W.sfc, tau = W.tau, tf = W.tf;
+    {
+        const size_t row = (colN + n) * ks;
+        const u64 word = c.masks[colN + n];  // k <= 32: one word
+        const int nc = t.n_children[n];
+        const double tt = (t.dist[n] + tau) * tf * sfc;
+        double v[KS], mb[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int j = 4 * s + hi;
+            mb[s] = (j < k && ((word >> j) & 1ull)) ? 1.0 : 0.0;
+        }
+        i64 esum = 0;
+        // ------------------------------------------------------------------ the vector P is applied to
+        double vc[KS];  // top-down: the node's own bottom-up vector
+        i64 bec = 0;
+        bool tipc = false;
+        if (MODE != PML_EIGG_TD) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) v[s] = mb[s];
+            if (MODE == PML_EIGG_BU) {
+                // mask o prod of the children's messages (ml.py:126-148), zero check and rescaling per child; a tip's
+                // exponent word is zero (never written by these sweeps)
+                const int fc = t.first_child[n];
+                int most = nc;
+                most = max(most, __shfl_xor(most, 1, 64));
+                most = max(most, __shfl_xor(most, 2, 64));
+                most = max(most, __shfl_xor(most, 4, 64));
+                most = max(most, __shfl_xor(most, 8, 64));
+                for (int j0 = 0; j0 < most; ++j0) {   // wave-uniform trip count (ballots inside)
+                    const bool has = act && j0 < nc;
+                    const int ch = has ? fc + j0 : n;
+                    double mv[KS];
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) mv[s] = st.msg[(colN + ch) * ks + 4 * s + hi];
+                    const i64 cbe = st.be[colN + ch];
+                    bool nz = false;
+                    if (has) {
+#pragma unroll
+                        for (int s = 0; s < KS; ++s) {
+                            v[s] *= fmax(mv[s], 0.0);
+                            nz |= v[s] != 0.0;
+                        }
+                        esum += cbe;
+                    }
+                    const bool alive = node_any(nz, lo);
+                    if (has && !alive && hi == 0)
+                        atomicMin(&st.err[col], ((u64)(unsigned)t.post_rank[n] << 32) | (u64)(unsigned)ch);
+                    const int ex = node_lazy_rescale<KS>(v, lo);
+                    if (has) esum += ex;
+                }
+                if (act) {
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) st.bu[row + 4 * s + hi] = v[s];
+                    if (hi == 0) st.be[colN + n] = esum;
+                }
+            }
+        } else {
+            // x = TD_p o BU_p / msg_n (ml.py:279-283); the message is what the bottom-up sweep left
+            const int p = act ? t.parent[n] : 0;
+            const size_t prow = (colN + (p < 0 ? 0 : p)) * ks;
+            tipc = nc == 0;
+            bec = tipc ? 0 : st.be[colN + n];
+            const i64 pe = st.te[colN + (p < 0 ? 0 : p)] + st.be[colN + (p < 0 ? 0 : p)];
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const int j = 4 * s + hi;
+                const double prod = st.td[prow + j] * st.bu[prow + j];
+                const double mc = st.msg[row + j];
+                vc[s] = tipc ? mb[s] : st.bu[row + j];  // a tip's row is allocated but never written
+                v[s] = prod / (mc > 0.0 ? mc : 1.0);
+            }
+            esum = pe - bec;
+            esum += node_lazy_rescale<KS>(v, lo);
+        }
+        // ------------------------------------------------------------------ Y = A^-1 V, Z = Y o exp(d t), OUT = A Z
+        pml_v4f64 acc[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            acc[mt] = (pml_v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+                acc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(W.a1[mt][s], act ? v[s] : 0.0, acc[mt], 0, 0, 0);
+        }
+        double z[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) z[s] = acc[s / 4][s % 4] * exp(W.dl[s] * tt);  // rows 4 s + hi of Y: the lane's own
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            acc[mt] = (pml_v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s = 0; s < KS; ++s) acc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(W.a2[mt][s], z[s], acc[mt], 0, 0, 0);
+        }
+        double out[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) out[s] = (4 * s + hi < k) ? acc[s / 4][s % 4] : 0.0;
+        // ------------------------------------------------------------------ results of the node
+        if (MODE != PML_EIGG_TD) {
+            if (act) {
+#pragma unroll
+                for (int s = 0; s < KS; ++s) st.msg[row + 4 * s + hi] = out[s];
+            }
+        } else {
+            // marginal likelihoods pi o mask o BU o TD (ml.py:456-460) and posteriors (ml.py:498-500)
+            double tdc[KS], lh[KS];
+            double lhs = 0.0;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                tdc[s] = fmax(out[s], 0.0);
+                lh[s] = vc[s] * tdc[s] * (W.pil[s] * mb[s]);
+                lhs += lh[s];
+            }
+            lhs = node_sum(lhs);
+            const int lex = (lhs > 0.0 && !isinf(lhs)) ? exponent_of(lhs) : 0;
+            if (act) {
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    if (!tipc) st.td[row + 4 * s + hi] = tdc[s];
+                    st.post[row + 4 * s + hi] = lh[s] / lhs;
+                }
+                if (hi == 0) {
+                    if (!tipc) st.te[colN + n] = esum;
+                    st.lhsum[colN + n] = __builtin_ldexp(lhs, -lex);
+                    st.lhe[colN + n] = esum + bec + lex;
+                }
+            }
+        }
+    }
+}
+
+// one level of a sweep
+template <int KS, int MODE>
+__global__ void __launch_bounds__(PML_BLOCK)
+eigen_gemm_kernel(PmlTree t, PmlCols c, PmlModel m, PmlState st, const int* __restrict__ nodes, int first, int n_nodes) {
+    EigGemmWave<KS> W;
+    eig_gemm_init<KS>(W, t, c, m);
+    const int wave = threadIdx.x >> 6;
+    const int stride = gridDim.x * PML_WAVES_PER_BLOCK * 16;
+    for (int b0 = (blockIdx.x * PML_WAVES_PER_BLOCK + wave) * 16; b0 < n_nodes; b0 += stride) {
+        const bool act = b0 + W.lo < n_nodes;
+        const int n = act ? (nodes != nullptr ? nodes[b0 + W.lo] : first + b0 + W.lo) : 0;
+        eig_gemm_pass<KS, MODE>(W, t, c, st, act, n);
+    }
+}
+
+// The narrow end of a large forest in one launch: one workgroup per column walks the levels [0, n_levels) of a level
+// table (offsets into `nodes`, or node id ranges when nodes == nullptr) with a workgroup barrier between levels: the
+// launch and the loading of the constant operands are paid once instead of once per level.
+template <int KS, int MODE>
+__global__ void __launch_bounds__(PML_BLOCK)
+eigen_gemm_narrow_kernel(PmlTree t, PmlCols c, PmlModel m, PmlState st, const int* __restrict__ nodes,
+                         const int* __restrict__ level_offsets, int n_levels) {
+    EigGemmWave<KS> W;
+    eig_gemm_init<KS>(W, t, c, m);
+    const int wave = threadIdx.x >> 6;
+    for (int l = 0; l < n_levels; ++l) {
+        const int a = level_offsets[l], n_level = level_offsets[l + 1] - a;
+        for (int b0 = wave * 16; b0 < n_level; b0 += PML_WAVES_PER_BLOCK * 16) {
+            const bool act = b0 + W.lo < n_level;
+            const int n = act ? (nodes != nullptr ? nodes[a + b0 + W.lo] : a + b0 + W.lo) : 0;
+            eig_gemm_pass<KS, MODE>(W, t, c, st, act, n);
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
