@@ -761,3 +761,21 @@ def test_columnar_node_features_behave_like_attributes():
     copy = tree.copy()                                  # a copy materialises what its nodes see
     assert getattr(copy, feature) == getattr(tree, feature)
     _cache.clear()
+
+
+def test_groups_are_cut_to_fit_the_device(monkeypatch):
+    """A group whose columns would not fit the free device memory is reconstructed in chunks (characters
+    were one unbounded engine each): same results, more batches."""
+    from pastml_amd.batch import run_tasks
+    tree = read_tree(TREE_NWK)
+    df = _multi_character_table(tree)[['bin_a', 'bin_b', 'five_a', 'five_b', 'Country']]
+    whole = acr(tree, df.copy(), prediction_method=MPPA, model=F81)
+    assert run_tasks.last_stats['groups'] == 2
+    monkeypatch.setenv('PASTML_AMD_DEVICE_BYTES', '400000')     # room for one character of this tree at a time
+    tree2 = read_tree(TREE_NWK)
+    chunked = acr(tree2, df.copy(), prediction_method=MPPA, model=F81)
+    assert run_tasks.last_stats['groups'] > 2
+    for a, b in zip(whole, chunked):
+        assert a['character'] == b['character'] and a[LOG_LIKELIHOOD] == b[LOG_LIKELIHOOD]
+        assert np.array_equal(a[MARGINAL_PROBABILITIES].values, b[MARGINAL_PROBABILITIES].values)
+        assert a[RESTRICTED_LOG_LIKELIHOOD_FORMAT_STR.format(MPPA)] == b[RESTRICTED_LOG_LIKELIHOOD_FORMAT_STR.format(MPPA)]

@@ -138,3 +138,21 @@ def test_acr_shards_characters_over_ranks(tmp_path):
     assert got[0]['loglik'] + got[1]['loglik'] == [r['log_likelihood'] for r in ref]
     assert got[0]['total'] == got[1]['total']
     np.testing.assert_allclose(got[0]['total'], sum(r['log_likelihood'] for r in ref), rtol=1e-14)
+
+
+def test_bench_two_ranks_under_torchrun(tmp_path):
+    """The driver's way of starting N > 1: torch.distributed.run provides RANK / LOCAL_RANK / WORLD_SIZE; the ranks find
+    each other's RCCL id (here: gloo, both ranks on GPU 0) through the launcher-scoped rendezvous directory."""
+    env = dict(os.environ, BENCH_ALL_RANKS_ON_GPU0='1', PASTML_AMD_COMM='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for key in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'PASTML_AMD_RDZV_DIR'):
+        env.pop(key, None)
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                        '--master-addr', '127.0.0.1', '--master-port', str(_free_port()),
+                        os.path.join(REPO, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+                        '--workload', 'cfg4_small', '--chars-per-gpu', '2'], env=env, capture_output=True, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith('{')]
+    assert len(lines) == 1                      # rank 0 only
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['config']['chars_total'] == 4 and line['config']['collective'] == 'gloo'
+    np.testing.assert_allclose(line['loglik_sum'], _single_process_logliks(4, 14, 64).sum(), rtol=1e-13)
