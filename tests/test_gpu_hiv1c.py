@@ -4,8 +4,7 @@ column of examples/HIV1C/data/metadata.tab (91: 82 binary drug-resistance column
 67), all characters of a call batched as device columns (pastml_amd.batch).
 
 Reference: tests/golden/hiv1c_all.npz, one run of the real reference's acr() per column with parameter optimisation
-(tests/golden/make_golden.py hiv1c_all; 3.4 CPU-hours in all -- columns the reference had not finished when the fixture
-was assembled are marked not done and only checked for invariants).
+(tests/golden/make_golden.py hiv1c_all; 4.6 CPU-hours in all).
 """
 import os
 import time
@@ -44,7 +43,7 @@ def test_all_columns_with_parameter_optimisation():
     seconds = time.perf_counter() - t0
     stats = dict(run_tasks.last_stats)
     assert [r['character'] for r in results] == list(df.columns)
-    # (82 binary columns, k = 67 x 3 and six singletons) -> 8 groups; the reference's 91 runs took 12 000 s
+    # (82 binary columns, k = 67 x 3 and six singletons) -> 8 groups; the reference's 91 runs took 16 669 s
     assert stats['groups'] == 8
     reference_seconds = 0.0
     for ci, (column, res) in enumerate(zip(df.columns, results)):
