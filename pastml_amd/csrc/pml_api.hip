@@ -509,9 +509,11 @@ static int launch_eigen_fused(pml_ctx* ctx, int mode, const int* nodes, int firs
 
 // sum sweeps of the eigen models without forming P(t) (pml_kernels_eigen_gemm.h): one launch over a list (nodes) or a
 // contiguous id range (first) of n nodes
+// (any eigen model with up to 32 states: below 16 the joint sweep still reads materialised P(t), see eigen_fused)
 static bool eigen_gemm(const pml_ctx* c) {
-    static const bool off = getenv("PASTML_HIP_NO_EIGEN_GEMM") != nullptr;
-    return !off && eigen_fused(c);
+    static const bool off = getenv("PASTML_HIP_NO_EIGEN_GEMM") || getenv("PASTML_HIP_NO_MFMA") ||
+                            getenv("PASTML_HIP_NO_EIGEN_FUSED");
+    return !off && c->eig_fused_opt && c->kind == PML_MODEL_EIGEN && c->k >= 2 && c->k <= 32 && c->W == 1;
 }
 
 static int launch_eigen_gemm(pml_ctx* ctx, int mode, const int* nodes, int first, int n) {
@@ -532,6 +534,9 @@ static int launch_eigen_gemm(pml_ctx* ctx, int mode, const int* nodes, int first
         return PML_OK;                                                                                              \
     }
 #define PML_EIGG_MODES(KS_) PML_EIGG_CASE(KS_, PML_EIGG_BU) PML_EIGG_CASE(KS_, PML_EIGG_TIPS) PML_EIGG_CASE(KS_, PML_EIGG_TD)
+    PML_EIGG_MODES(1)
+    PML_EIGG_MODES(2)
+    PML_EIGG_MODES(3)
     PML_EIGG_MODES(4)
     PML_EIGG_MODES(5)
     PML_EIGG_MODES(6)
@@ -558,6 +563,9 @@ static int launch_eigen_gemm_narrow(pml_ctx* ctx, int mode, const int* nodes, co
         return PML_OK;                                                                                                 \
     }
 #define PML_EIGG_MODES(KS_) PML_EIGG_CASE(KS_, PML_EIGG_BU) PML_EIGG_CASE(KS_, PML_EIGG_TD)
+    PML_EIGG_MODES(1)
+    PML_EIGG_MODES(2)
+    PML_EIGG_MODES(3)
     PML_EIGG_MODES(4)
     PML_EIGG_MODES(5)
     PML_EIGG_MODES(6)
@@ -1423,10 +1431,12 @@ static int narrow_levels(const std::vector<int>& off, int n_levels, bool from_fr
 // Everything a bottom-up sweep puts on the stream, without host synchronisation (so that it can be captured).
 static int enqueue_bottom_up(pml_ctx* ctx, int is_marginal, bool small_path, bool force_prep) {
     const bool eig = eigen_fused(ctx);
+    const bool gemm = is_marginal && eigen_gemm(ctx);
     if (!small_path) {  // the single-launch kernel resets the error words itself
         hipLaunchKernelGGL(reset_err_kernel, dim3((ctx->C + 63) / 64), dim3(64), 0, ctx->stream, ctx->d_err, ctx->C);
         HIP_TRY(hipGetLastError());
-        if (!eig) PML_TRY(run_prep(ctx, force_prep));  // the fused eigen sweeps build P(t) themselves
+        // the fused eigen sweeps build P(t) themselves, the two-GEMM sweeps never need it
+        if (!eig && !gemm) PML_TRY(run_prep(ctx, force_prep));
     }
     PML_TRY(prof_begin(ctx));
     const bool fused = is_marginal && ctx->kind == PML_MODEL_F81;
@@ -1460,7 +1470,7 @@ static int enqueue_bottom_up(pml_ctx* ctx, int is_marginal, bool small_path, boo
         }
         PML_TRY(prof_end(ctx, 0, nl));
         joint_fused = true;
-    } else if (eig && is_marginal && eigen_gemm(ctx)) {
+    } else if (gemm) {
         // marginal sweep: P(t) is never formed, msg = A (e o (A^-1 v)) as two small GEMMs per 16 nodes
         PML_TRY(launch_eigen_gemm(ctx, PML_EIGG_TIPS, ctx->d_tips, 0, ctx->n_tips));
         // levels one workgroup finishes in a pass or two per wave (4 waves x 16 nodes) share one launch
@@ -1537,11 +1547,10 @@ static int submit_bottom_up(pml_ctx* ctx, int is_marginal) {
         PML_TRY(dev_alloc(ctx, &ctx->d_J, CN * ctx->ks));
         PML_TRY(dev_alloc(ctx, &ctx->d_js, CN));
     }
-    if (eigen_fused(ctx)) {
+    if (eigen_fused(ctx) || eigen_gemm(ctx)) {
         if (!ctx->d_msg) PML_TRY(dev_alloc(ctx, &ctx->d_msg, CN * ctx->ks));
-    } else {
-        PML_TRY(ensure_transition_storage(ctx));
     }
+    if (!eigen_fused(ctx) && !(is_marginal && eigen_gemm(ctx))) PML_TRY(ensure_transition_storage(ctx));
     ctx->bu_mode = -1;
     ctx->td_valid = ctx->js_valid = false;
     // mid-size forests: the level launches are latency-bound, replay them as one hipGraph
@@ -1553,7 +1562,8 @@ static int submit_bottom_up(pml_ctx* ctx, int is_marginal) {
     } else {
         PML_TRY(enqueue_bottom_up(ctx, is_marginal, small_path, false));
     }
-    if (!eigen_fused(ctx)) ctx->prep_dirty = false;  // the fused eigen sweeps build P(t) in registers: no batch ran
+    // the fused eigen sweeps build P(t) in registers, the two-GEMM sweeps never form it: no batch ran
+    if (!eigen_fused(ctx) && !(is_marginal && eigen_gemm(ctx))) ctx->prep_dirty = false;
     ctx->bu_fused = (is_marginal && ctx->kind == PML_MODEL_F81 && ctx->n_cherries > 0) || ctx->bu_fused_joint;
     return PML_OK;
 }
@@ -1698,7 +1708,7 @@ static int materialize_td(pml_ctx* ctx) {
         if (f81) {
             PML_TRY(materialize_cherries(ctx));  // the cherries' bottom-up vectors
         } else {
-            PML_TRY(run_prep(ctx, ctx->d_P == nullptr || eigen_fused(ctx)));  // P(t) of every branch in HBM
+            PML_TRY(run_prep(ctx, ctx->d_P == nullptr || eigen_fused(ctx) || eigen_gemm(ctx)));  // P(t) of every branch in HBM
         }
         PmlState st = state_of(ctx);
         st.td = ctx->d_td;  // state_of hides them when the option is off

@@ -1,4 +1,4 @@
-// Eigen models (CUSTOM_RATES, JTT), 16 <= k <= 32: the SUM sweeps (marginal bottom-up, top-down) without ever forming
+// Eigen models (CUSTOM_RATES, JTT), 2 <= k <= 32: the SUM sweeps (marginal bottom-up, top-down) without ever forming
 // P(t).  Both apply P(t_n) = A diag(exp(d t_n)) A^-1 of the branch above a node n to ONE vector of that node
 //   bottom-up  (ml.py:124-148)   msg_n = P v_n        v_n = mask o prod of the children's messages
 //   top-down   (ml.py:273-290)   td_n  = P x_n        x_n = TD_p o BU_p / msg_n
@@ -78,7 +78,7 @@ struct EigGemmWave {
 template <int KS>
 __device__ __forceinline__ void eig_gemm_init(EigGemmWave<KS>& W, const PmlTree& t, const PmlCols& c, const PmlModel& m) {
     constexpr int MT = EigGemm<KS>::MT;
-    const int k = c.k, ks = c.ks;  // ks == 4 KS (checked on the host)
+    const int k = c.k, ks = c.ks;  // k <= ks <= 4 KS: states 4 s + hi >= ks do not exist in memory
     const int col = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int lo = lane & 15, hi = lane >> 4;
@@ -152,7 +152,7 @@ __device__ __forceinline__ void eig_gemm_pass(const EigGemmWave<KS>& W, const Pm
                     const int ch = has ? fc + j0 : n;
                     double mv[KS];
 #pragma unroll
-                    for (int s = 0; s < KS; ++s) mv[s] = st.msg[(colN + ch) * ks + 4 * s + hi];
+                    for (int s = 0; s < KS; ++s) mv[s] = 4 * s + hi < ks ? st.msg[(colN + ch) * ks + 4 * s + hi] : 0.0;
                     const i64 cbe = st.be[colN + ch];
                     bool nz = false;
                     if (has) {
@@ -171,7 +171,8 @@ __device__ __forceinline__ void eig_gemm_pass(const EigGemmWave<KS>& W, const Pm
                 }
                 if (act) {
 #pragma unroll
-                    for (int s = 0; s < KS; ++s) st.bu[row + 4 * s + hi] = v[s];
+                    for (int s = 0; s < KS; ++s)
+                        if (4 * s + hi < ks) st.bu[row + 4 * s + hi] = v[s];
                     if (hi == 0) st.be[colN + n] = esum;
                 }
             }
@@ -184,7 +185,7 @@ __device__ __forceinline__ void eig_gemm_pass(const EigGemmWave<KS>& W, const Pm
             const i64 pe = st.te[colN + (p < 0 ? 0 : p)] + st.be[colN + (p < 0 ? 0 : p)];
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
-                const int j = 4 * s + hi;
+                const int j = 4 * s + hi < ks ? 4 * s + hi : 0;  // padding lanes read (and ignore) state 0
                 const double prod = st.td[prow + j] * st.bu[prow + j];
                 const double mc = st.msg[row + j];
                 vc[s] = tipc ? mb[s] : st.bu[row + j];  // a tip's row is allocated but never written
@@ -218,7 +219,8 @@ __device__ __forceinline__ void eig_gemm_pass(const EigGemmWave<KS>& W, const Pm
         if (MODE != PML_EIGG_TD) {
             if (act) {
 #pragma unroll
-                for (int s = 0; s < KS; ++s) st.msg[row + 4 * s + hi] = out[s];
+                for (int s = 0; s < KS; ++s)
+                    if (4 * s + hi < ks) st.msg[row + 4 * s + hi] = out[s];
             }
         } else {
             // marginal likelihoods pi o mask o BU o TD (ml.py:456-460) and posteriors (ml.py:498-500)
@@ -235,6 +237,7 @@ __device__ __forceinline__ void eig_gemm_pass(const EigGemmWave<KS>& W, const Pm
             if (act) {
 #pragma unroll
                 for (int s = 0; s < KS; ++s) {
+                    if (4 * s + hi >= ks) continue;
                     if (!tipc) st.td[row + 4 * s + hi] = tdc[s];
                     st.post[row + 4 * s + hi] = lh[s] / lhs;
                 }
