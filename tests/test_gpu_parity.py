@@ -750,3 +750,27 @@ def test_joint_pass_equals_the_two_calls():
         lnl, states = eng.joint_pass()
         np.testing.assert_allclose(lnl[0], z['loglik_joint'], rtol=LNL_RTOL)
         assert np.array_equal(states[0], z['joint_state'])
+
+
+def test_many_columns_take_the_single_launch_kernels_with_the_same_bits():
+    """Contexts of 64+ columns on forests of up to 16 384 nodes sweep in one launch (one workgroup per column walks all
+    levels); a one-column context on the same forest (above the 2 048-node limit) takes the level kernels: same bits."""
+    rng = np.random.default_rng(31)
+    flat = FlatForest.random(1500, seed=9, max_arity=3, zero_frac=0.0)
+    assert flat.n_nodes > 2048
+    for k in (2, 12, 40):
+        C = 66
+        specs = [(random_spec('F81', k, rng), (float(rng.uniform(0.5, 3)), 0.0, 1.0)) for _ in range(C)]
+        masks = np.stack([random_masks(flat, k, rng) for _ in range(C)])
+        with hip.Engine(flat, C, k) as eng:
+            eng.set_models(specs)
+            eng.set_masks(masks)
+            lnl, post, lh_sum, lh_sf = eng.marginal_pass()
+        with hip.Engine(flat, 1, k) as eng:
+            for c in (0, 17, 65):
+                eng.set_models([specs[c]])
+                eng.set_masks(masks[c])
+                lnl1, post1, lh_sum1, lh_sf1 = eng.marginal_pass()
+                assert lnl1[0] == lnl[c]
+                assert np.array_equal(post1[0], post[c]) and np.array_equal(lh_sum1[0], lh_sum[c])
+                assert np.array_equal(lh_sf1[0], lh_sf[c])
