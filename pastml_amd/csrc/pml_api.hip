@@ -74,6 +74,19 @@ struct pml_ctx {
     // unit descriptors of the F81 kernels, parallel to d_bu_order_f / d_td_parents_f / d_bu_order
     PmlUnit *d_bu_units_f = nullptr, *d_td_units_f = nullptr, *d_bu_units = nullptr, *d_cherry_units = nullptr;
     int *d_bu_offsets_f = nullptr, *d_td_parent_offsets_f = nullptr;  // level tables for the single-launch kernels
+    // subtree blocks (pml_kernels_f81.h, bottom): the stored nodes cut into subtrees of at most PML_BLOCK_NODES stored
+    // nodes, walked by one workgroup each, and the "top" above the cuts with level tables of its own
+    struct BlockSchedule {
+        bool ok = false;
+        int n_blocks = 0;
+        PmlUnit *d_bu_units = nullptr, *d_td_units = nullptr;          // units of the blocks, block by block
+        int *d_bu_start = nullptr, *d_bu_levels = nullptr, *d_bu_lv = nullptr;
+        int *d_td_start = nullptr, *d_td_levels = nullptr, *d_td_lv = nullptr;
+        PmlUnit *d_top_bu_units = nullptr, *d_top_td_units = nullptr;  // units of the top part, level by level
+        int *d_top_bu_offsets = nullptr, *d_top_td_offsets = nullptr;
+        std::vector<int> top_bu_offsets, top_td_offsets;               // host copies (launch geometry)
+        std::vector<char> top_bu_vec;                                   // per top level: stored node among children 0, 1
+    } blocks;
     bool small = false;  // forest small enough for the one-launch-per-sweep kernels
     std::vector<int> bu_offsets_f, td_parent_offsets_f;
     std::vector<char> bu_level_vec_f;  // per fused bottom-up level: some unit has a stored node as child 0 or 1
@@ -125,6 +138,7 @@ struct pml_ctx {
     bool td_vec_valid = false; // the TD vectors of the last top-down sweep are in d_td
     bool td_filled = false;    // ... including those of the nodes the sweeps do not store (td_fill_kernel)
     bool eig_fused_opt = true; // PML_OPT_EIGEN_FUSED
+    const PmlUnit* units_override = nullptr;  // set around a dispatch_sweep on the block schedule's top lists
     PmlComm* comm = nullptr;   // RCCL communicator attached by pml_comm_init (survives tree uploads)
 };
 
@@ -358,6 +372,7 @@ static void launch_sweep_f81(pml_ctx* ctx, SweepKind what, const int* level, int
         units = ctx->d_bu_units + (level - ctx->d_bu_order);
     if (what == SW_TD_FUSED) units = ctx->d_td_units_f + (level - ctx->d_td_parents_f);
     if (what == SW_BU_CHERRIES || what == SW_BU_CHERRIES_JOINT) units = ctx->d_cherry_units + (level - ctx->d_cherries);
+    if (ctx->units_override != nullptr) units = ctx->units_override;  // a level of the block schedule's top part
     switch (what) {
         case SW_BU_MARG_FUSED:
         case SW_BU_MARG:
@@ -394,18 +409,35 @@ static void launch_sweep_f81(pml_ctx* ctx, SweepKind what, const int* level, int
 // Single-workgroup-per-column launch over a range of levels: the whole sweep of a small forest, or the narrow end of
 // a large one (bottom-up: levels first_level .. end, then ln L; top-down: roots, then levels 0 .. n_levels - 1).
 template <int G, int R>
-static void launch_small_f81(pml_ctx* ctx, bool bottom_up, int do_prep, int first_level, int n_levels) {
+static void launch_small_f81(pml_ctx* ctx, bool bottom_up, int do_prep, const PmlUnit* units, const int* d_offsets,
+                             int n_levels, int reset_err) {
     const PmlTree t = tree_of(ctx, true);
     const PmlCols c = cols_of(ctx);
     const PmlState st = state_of(ctx);
     dim3 grid(1, ctx->C), block(PML_SMALL_BLOCK);
     if (bottom_up)
         hipLaunchKernelGGL((bu_f81_small_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, ctx->d_mu, ctx->d_sf,
-                           ctx->d_tau, ctx->d_tauf, do_prep, ctx->d_bu_units_f, ctx->d_bu_offsets_f + first_level,
-                           n_levels, ctx->h_loglik, ctx->h_err, first_level == 0 ? 1 : 0);
+                           ctx->d_tau, ctx->d_tauf, do_prep, units, d_offsets, n_levels, ctx->h_loglik, ctx->h_err,
+                           reset_err);
     else
-        hipLaunchKernelGGL((td_f81_small_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, ctx->d_td_units_f,
-                           ctx->d_td_parent_offsets_f, n_levels);
+        hipLaunchKernelGGL((td_f81_small_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, units, d_offsets,
+                           n_levels);
+}
+
+// one workgroup per (subtree block, column) walks the block's levels (pml_kernels_f81.h, bottom)
+template <int G, int R>
+static void launch_blocks_f81(pml_ctx* ctx, bool bottom_up) {
+    const PmlTree t = tree_of(ctx, true);
+    const PmlCols c = cols_of(ctx);
+    const PmlState st = state_of(ctx);
+    const pml_ctx::BlockSchedule& B = ctx->blocks;
+    dim3 grid(B.n_blocks, ctx->C), block(PML_SMALL_BLOCK);
+    if (bottom_up)
+        hipLaunchKernelGGL((bu_f81_blocks_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, B.d_bu_units, B.d_bu_start,
+                           B.d_bu_levels, B.d_bu_lv);
+    else
+        hipLaunchKernelGGL((td_f81_blocks_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, B.d_td_units, B.d_td_start,
+                           B.d_td_levels, B.d_td_lv);
 }
 
 #define PML_F81_CASES(X) \
@@ -429,19 +461,45 @@ static void launch_select(pml_ctx* ctx, int method, int force_joint, const u64* 
                        ctx->d_post, d_lh_mask, ctx->d_js, method, force_joint, ctx->d_masks, ctx->d_nsel);
 }
 
-static int dispatch_small_f81(pml_ctx* ctx, bool bottom_up, int do_prep, int first_level = 0, int n_levels = -1) {
-    // Bottom-up: the lane shape the level kernels use for levels of this size (dispatch_sweep: 8 states per lane up to
-    // 65 536 units when 32 < k <= 64).  The reductions over a unit's lanes associate differently in different shapes,
-    // so a level must get the same shape whether it runs here or in a level launch: where the narrow end begins
-    // depends on the number of columns, and a column's bits must not.
-    const int g = bottom_up ? (ctx->bu_wide_lanes ? 8 : ctx->Gf) : ctx->Gt;
-    const int r = bottom_up ? (ctx->bu_wide_lanes ? 8 : ctx->Rf) : ctx->Rt;
+// lane shape of the kernels that walk several levels in one launch.  Bottom-up: the shape the level kernels use for
+// levels of this size (dispatch_sweep: 8 states per lane up to 65 536 units when 32 < k <= 64).  The reductions over a
+// unit's lanes associate differently in different shapes, so a level must get the same shape whether it runs here or in
+// a level launch: where the narrow end begins depends on the number of columns, and a column's bits must not.
+static void multi_level_shape(const pml_ctx* ctx, bool bottom_up, int& g, int& r) {
+    g = bottom_up ? (ctx->bu_wide_lanes ? 8 : ctx->Gf) : ctx->Gt;
+    r = bottom_up ? (ctx->bu_wide_lanes ? 8 : ctx->Rf) : ctx->Rt;
+}
+
+// units / d_offsets: the level table to walk (default: the fused lists of the whole forest from first_level on)
+static int dispatch_small_f81(pml_ctx* ctx, bool bottom_up, int do_prep, int first_level = 0, int n_levels = -1,
+                              const PmlUnit* units = nullptr, const int* d_offsets = nullptr) {
+    int g, r;
+    multi_level_shape(ctx, bottom_up, g, r);
     if (n_levels < 0) n_levels = bottom_up ? (int)ctx->bu_offsets_f.size() - 1 - first_level : ctx->n_td_levels;
-#define X(G_, R_)                                                                    \
-    if (g == G_ && r == R_) {                                                        \
-        launch_small_f81<G_, R_>(ctx, bottom_up, do_prep, first_level, n_levels);    \
-        HIP_TRY(hipGetLastError());                                                  \
-        return PML_OK;                                                               \
+    const int reset_err = (units == nullptr && first_level == 0) ? 1 : 0;
+    if (units == nullptr) {
+        units = bottom_up ? ctx->d_bu_units_f : ctx->d_td_units_f;
+        d_offsets = bottom_up ? ctx->d_bu_offsets_f + first_level : ctx->d_td_parent_offsets_f;
+    }
+#define X(G_, R_)                                                                                   \
+    if (g == G_ && r == R_) {                                                                       \
+        launch_small_f81<G_, R_>(ctx, bottom_up, do_prep, units, d_offsets, n_levels, reset_err);   \
+        HIP_TRY(hipGetLastError());                                                                 \
+        return PML_OK;                                                                              \
+    }
+    PML_F81_CASES(X)
+#undef X
+    return fail(PML_ERR_UNSUPPORTED, "no F81 kernel for G=%d R=%d", g, r);
+}
+
+static int dispatch_blocks_f81(pml_ctx* ctx, bool bottom_up) {
+    int g, r;
+    multi_level_shape(ctx, bottom_up, g, r);
+#define X(G_, R_)                                    \
+    if (g == G_ && r == R_) {                        \
+        launch_blocks_f81<G_, R_>(ctx, bottom_up);   \
+        HIP_TRY(hipGetLastError());                  \
+        return PML_OK;                               \
     }
     PML_F81_CASES(X)
 #undef X
@@ -996,6 +1054,108 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
             PML_TRY(upload(ctx, ctx->d_td_units_f, ut_f.data(), ut_f.size()));
             PML_TRY(upload(ctx, ctx->d_bu_units, ub.data(), ub.size()));
             HIP_TRY(hipStreamSynchronize(ctx->stream));  // the vectors go out of scope
+        // ---- subtree blocks: stored nodes -> blocks (maximal subtrees of <= S stored nodes) + top
+        {
+            const char* env = getenv("PASTML_HIP_BLOCK_NODES");
+            const int S = env ? atoi(env) : 256;  // measured: 128-512 are within a few per cent, 1024+ loses at k >= 16
+            pml_ctx::BlockSchedule& B = ctx->blocks;
+            B = pml_ctx::BlockSchedule();
+            if (S > 0 && n_stored > S && n_stored <= (1 << 17)) {
+                std::vector<int> ssz(n_nodes, 0), blk(n_nodes, -1), depth(n_nodes, 0);
+                for (int l = 0; l < n_td_levels; ++l)
+                    for (int i = td_offsets[l]; i < td_offsets[l + 1]; ++i) depth[i] = l;
+                for (int i = n_nodes - 1; i >= 0; --i) {
+                    if (kind[i] != PML_KIND_STORED) continue;
+                    ssz[i] += 1;
+                    if (parent[i] >= 0) ssz[parent[i]] += ssz[i];
+                }
+                int nb = 0;
+                for (int i = 0; i < n_nodes; ++i) {  // parents have smaller ids
+                    if (kind[i] != PML_KIND_STORED || ssz[i] > S) continue;
+                    const int p = parent[i];
+                    blk[i] = (p >= 0 && blk[p] >= 0) ? blk[p] : nb++;
+                }
+                // per block: its nodes by fused height (bottom-up) and by depth (top-down), each as consecutive levels
+                std::vector<std::vector<int>> members(nb);
+                for (int i = 0; i < n_nodes; ++i)
+                    if (blk[i] >= 0) members[blk[i]].push_back(i);
+                std::vector<int> bu_list, td_list, bu_start(nb), bu_levels(nb), bu_lv, td_start(nb), td_levels(nb), td_lv;
+                for (int b = 0; b < nb; ++b) {
+                    std::vector<int>& mem = members[b];  // ascending ids = non-decreasing depth
+                    td_start[b] = (int)td_lv.size();
+                    int nl = 0;
+                    for (size_t q = 0; q < mem.size(); ++q) {
+                        if (q == 0 || depth[mem[q]] != depth[mem[q - 1]]) {
+                            td_lv.push_back((int)td_list.size());
+                            ++nl;
+                        }
+                        td_list.push_back(mem[q]);
+                    }
+                    td_lv.push_back((int)td_list.size());
+                    td_levels[b] = nl;
+                    std::stable_sort(mem.begin(), mem.end(), [&](int x, int y) { return fh[x] < fh[y]; });
+                    bu_start[b] = (int)bu_lv.size();
+                    nl = 0;
+                    for (size_t q = 0; q < mem.size(); ++q) {
+                        if (q == 0 || fh[mem[q]] != fh[mem[q - 1]]) {
+                            bu_lv.push_back((int)bu_list.size());
+                            ++nl;
+                        }
+                        bu_list.push_back(mem[q]);
+                    }
+                    bu_lv.push_back((int)bu_list.size());
+                    bu_levels[b] = nl;
+                }
+                // the top: stored nodes outside the blocks, by fused height / by depth
+                std::vector<int> top_bu, top_td;
+                B.top_bu_offsets.assign(1, 0);
+                for (int l = 0; l < max_h; ++l) {
+                    for (int q = off[l]; q < off[l + 1]; ++q)
+                        if (blk[order[q]] < 0) top_bu.push_back(order[q]);
+                    if ((int)top_bu.size() > B.top_bu_offsets.back()) B.top_bu_offsets.push_back((int)top_bu.size());
+                }
+                B.top_td_offsets.assign(n_td_levels + 1, 0);
+                for (int l = 0; l < n_td_levels; ++l) {
+                    for (int q = ctx->td_parent_offsets_f[l]; q < ctx->td_parent_offsets_f[l + 1]; ++q)
+                        if (blk[tdp[q]] < 0) top_td.push_back(tdp[q]);
+                    B.top_td_offsets[l + 1] = (int)top_td.size();
+                }
+                const int n_top_levels = (int)B.top_bu_offsets.size() - 1;
+                if (nb > 0 && n_top_levels + 1 < max_h) {  // fewer dependent launches than the level schedule
+                    std::vector<PmlUnit> u1, u2, u3, u4;
+                    describe(bu_list.data(), (int)bu_list.size(), true, u1);
+                    describe(td_list.data(), (int)td_list.size(), true, u2);
+                    describe(top_bu.data(), (int)top_bu.size(), true, u3);
+                    describe(top_td.data(), (int)top_td.size(), true, u4);
+                    B.top_bu_vec.assign(n_top_levels > 0 ? n_top_levels : 1, 0);
+                    for (int l = 0; l < n_top_levels; ++l)
+                        for (int q = B.top_bu_offsets[l]; q < B.top_bu_offsets[l + 1] && !B.top_bu_vec[l]; ++q) {
+                            const int pk = u3[q].packed;
+                            if (((pk >> 8) & 7) == 1 || ((pk >> 11) & 7) == 1) B.top_bu_vec[l] = 1;
+                        }
+                    auto put = [&](auto** dst, const auto& v) -> int {
+                        PML_TRY(dev_alloc(ctx, dst, v.size()));
+                        if (!v.empty()) PML_TRY(upload(ctx, *dst, v.data(), v.size()));
+                        return PML_OK;
+                    };
+                    PML_TRY(put(&B.d_bu_units, u1));
+                    PML_TRY(put(&B.d_td_units, u2));
+                    PML_TRY(put(&B.d_top_bu_units, u3));
+                    PML_TRY(put(&B.d_top_td_units, u4));
+                    PML_TRY(put(&B.d_bu_start, bu_start));
+                    PML_TRY(put(&B.d_bu_levels, bu_levels));
+                    PML_TRY(put(&B.d_bu_lv, bu_lv));
+                    PML_TRY(put(&B.d_td_start, td_start));
+                    PML_TRY(put(&B.d_td_levels, td_levels));
+                    PML_TRY(put(&B.d_td_lv, td_lv));
+                    PML_TRY(put(&B.d_top_bu_offsets, B.top_bu_offsets));
+                    PML_TRY(put(&B.d_top_td_offsets, B.top_td_offsets));
+                    HIP_TRY(hipStreamSynchronize(ctx->stream));  // the vectors go out of scope
+                    B.n_blocks = nb;
+                    B.ok = true;
+                }
+            }
+        }
         }
         PML_TRY(dev_alloc(ctx, &ctx->d_kind, n_nodes));
         PML_TRY(dev_alloc(ctx, &ctx->d_bu_order_f, n_stored));
@@ -1456,6 +1616,25 @@ static int enqueue_bottom_up(pml_ctx* ctx, int is_marginal, bool small_path, boo
         // prep + every level + ln L in one launch
         PML_TRY(dispatch_small_f81(ctx, true, (ctx->prep_dirty || force_prep) ? 1 : 0));
         PML_TRY(prof_end(ctx, 0, 1));
+    } else if (fused && ctx->blocks.ok) {
+        // subtree blocks in one launch, then the top part: level launches, its narrow end (and ln L) in one launch
+        const pml_ctx::BlockSchedule& B = ctx->blocks;
+        PML_TRY(dispatch_blocks_f81(ctx, true));
+        const int nl = (int)B.top_bu_offsets.size() - 1;
+        const int tail = narrow_levels(B.top_bu_offsets, nl, false, ctx->C);
+        for (int l = 0; l < nl - tail; ++l) {
+            const int a = B.top_bu_offsets[l], b = B.top_bu_offsets[l + 1];
+            ctx->units_override = B.d_top_bu_units + a;
+            const int status = dispatch_sweep(ctx, B.top_bu_vec[l] ? SW_BU_MARG_FUSED : SW_BU_MARG_FUSED_NOVEC,
+                                              ctx->d_bu_order_f, b - a);
+            ctx->units_override = nullptr;
+            PML_TRY(status);
+        }
+        PML_TRY(prof_end(ctx, 0, 1 + nl - tail));
+        if (tail > 0) {
+            PML_TRY(dispatch_small_f81(ctx, true, 0, 0, tail, B.d_top_bu_units, B.d_top_bu_offsets + (nl - tail)));
+            loglik_done = true;
+        }
     } else if (fused) {
         const int nl = (int)ctx->bu_offsets_f.size() - 1;
         const int tail = narrow_levels(ctx->bu_offsets_f, nl, false, ctx->C);
@@ -1566,7 +1745,7 @@ static int submit_bottom_up(pml_ctx* ctx, int is_marginal) {
     // mid-size forests: the level launches are latency-bound, replay them as one hipGraph
     const int n_launches = small_path ? 1 : (is_marginal && ctx->kind == PML_MODEL_F81 ? (int)ctx->bu_offsets_f.size() - 1
                                                                                           : ctx->n_bu_levels);
-    if (ctx->graphs && !ctx->profile && n_launches >= 4) {
+    if (ctx->graphs && !ctx->profile && n_launches >= 4) {  // (the block schedule's few launches replay as a graph too)
         PML_TRY(run_captured(ctx, ctx->bu_graph[is_marginal ? 1 : 0],
                              [&]() { return enqueue_bottom_up(ctx, is_marginal, small_path, true); }));
     } else {
@@ -1622,6 +1801,28 @@ static int run_top_down(pml_ctx* ctx) {
     const bool td_small = single_launch_sweeps(ctx) && ctx->kind == PML_MODEL_F81;
     const bool td_fused = ctx->kind == PML_MODEL_F81;
     auto enqueue = [&]() -> int {
+        if (td_fused && !td_small && ctx->blocks.ok) {
+            // block schedule: the top part (roots, its narrow end in one launch, its wide levels one launch each),
+            // then all subtree blocks in one launch
+            const pml_ctx::BlockSchedule& B = ctx->blocks;
+            const int head = ctx->n_roots <= 64 ? narrow_levels(B.top_td_offsets, ctx->n_td_levels, true, ctx->C) : 0;
+            if (head == 0) PML_TRY(dispatch_sweep(ctx, SW_ROOTS, nullptr, ctx->n_roots));
+            if (head > 0) PML_TRY(dispatch_small_f81(ctx, false, 0, 0, head, B.d_top_td_units, B.d_top_td_offsets));
+            PML_TRY(prof_begin(ctx));
+            long long n_launch = 0;
+            for (int l = head; l < ctx->n_td_levels; ++l) {
+                const int a = B.top_td_offsets[l], b = B.top_td_offsets[l + 1];
+                if (b <= a) continue;
+                ctx->units_override = B.d_top_td_units + a;
+                const int status = dispatch_sweep(ctx, SW_TD_FUSED, ctx->d_td_parents_f, b - a);
+                ctx->units_override = nullptr;
+                PML_TRY(status);
+                ++n_launch;
+            }
+            PML_TRY(dispatch_blocks_f81(ctx, false));
+            PML_TRY(prof_end(ctx, 1, n_launch + 1));
+            return PML_OK;
+        }
         // F81 family: the roots and the levels right below them in one launch
         const int head = (td_fused && !td_small && ctx->n_roots <= 64)
                              ? narrow_levels(ctx->td_parent_offsets_f, ctx->n_td_levels, true, ctx->C) : 0;

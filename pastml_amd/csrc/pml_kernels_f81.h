@@ -1312,3 +1312,56 @@ td_f81_small_kernel(PmlTree t, PmlCols c, PmlState st, const PmlUnit* __restrict
         __syncthreads();
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Subtree blocks: mid-size forests in a handful of launches.  The stored nodes are cut into blocks -- maximal subtrees
+// of at most PASTML_HIP_BLOCK_NODES (256) stored nodes (pml_tree_upload) -- and the nodes above the cuts (the "top").  A block
+// depends on nothing outside itself in the bottom-up sweep, and only on its root's parent (a top node) in the top-down
+// sweep, so ONE launch walks all blocks, one workgroup per (block, column) stepping through the block's levels with a
+// workgroup barrier (~2 us per level) instead of one launch per level of the forest (~4.6 us each, and the levels of a
+// 65 536-tip tree are 16): the bottom-up sweep is blocks + top, the top-down sweep top + blocks.  Same unit functions
+// and lane shapes as the level kernels, hence the same bits.
+// units: the blocks' units, block by block, each block level by level; level j of block b is
+// units[lv[start[b] + j] .. lv[start[b] + j + 1]).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int G, int R>
+__global__ void __launch_bounds__(PML_SMALL_BLOCK)
+bu_f81_blocks_kernel(PmlTree t, PmlCols c, PmlState st, const PmlUnit* __restrict__ units,
+                     const int* __restrict__ blk_start, const int* __restrict__ blk_levels, const int* __restrict__ lv) {
+    constexpr int UW = 64 / G;
+    const int wave = threadIdx.x >> 6;
+    const int n_waves = blockDim.x >> 6;
+    const int sub = (threadIdx.x & 63) / G;
+    LaneCtx<G, R> L;
+    lane_ctx_init<G, R>(L, t, c, st);
+    const int p = blk_start[blockIdx.x], nl = blk_levels[blockIdx.x];
+    for (int l = 0; l < nl; ++l) {
+        const int a = lv[p + l], n_level = lv[p + l + 1] - a;
+        for (int base = wave * UW; base < n_level; base += n_waves * UW) {
+            const int idx = base + sub;
+            if (idx < n_level) bu_f81_unit<G, R, false>(L, t, c, st, load_unit<G>(units, a + idx, L.g));
+        }
+        __syncthreads();
+    }
+}
+
+template <int G, int R>
+__global__ void __launch_bounds__(PML_SMALL_BLOCK)
+td_f81_blocks_kernel(PmlTree t, PmlCols c, PmlState st, const PmlUnit* __restrict__ units,
+                     const int* __restrict__ blk_start, const int* __restrict__ blk_levels, const int* __restrict__ lv) {
+    constexpr int UW = 64 / G;
+    const int wave = threadIdx.x >> 6;
+    const int n_waves = blockDim.x >> 6;
+    const int sub = (threadIdx.x & 63) / G;
+    LaneCtx<G, R> L;
+    lane_ctx_init<G, R>(L, t, c, st);
+    const int p = blk_start[blockIdx.x], nl = blk_levels[blockIdx.x];
+    for (int l = 0; l < nl; ++l) {
+        const int a = lv[p + l], n_level = lv[p + l + 1] - a;
+        for (int base = wave * UW; base < n_level; base += n_waves * UW) {
+            const int idx = base + sub;
+            if (idx < n_level) td_f81_unit<G, R>(L, t, c, st, load_unit<G>(units, a + idx, L.g));
+        }
+        __syncthreads();
+    }
+}

@@ -774,3 +774,30 @@ def test_many_columns_take_the_single_launch_kernels_with_the_same_bits():
                 assert lnl1[0] == lnl[c]
                 assert np.array_equal(post1[0], post[c]) and np.array_equal(lh_sum1[0], lh_sum[c])
                 assert np.array_equal(lh_sf1[0], lh_sf[c])
+
+
+@pytest.mark.parametrize('k', [2, 4, 12, 64])
+def test_block_schedule_gives_the_bits_of_the_level_schedule(k, monkeypatch):
+    """Mid-size forests: subtree blocks walked by one workgroup each + the top above the cuts (a handful of launches)
+    against one launch per level; blocks of 256 (default), 1024, 64 and 7 stored nodes; balanced and ragged forests."""
+    rng = np.random.default_rng(40 + k)
+    forests = [synthetic.balanced_forest(13),
+               FlatForest.random(6000, seed=k + 2, max_arity=4, zero_frac=0.0, n_trees=3)]
+    for flat in forests:
+        C = 3
+        specs = [(random_spec('F81', k, rng), (float(rng.uniform(0.5, 3)), 0.0, 1.0)) for _ in range(C)]
+        masks = np.stack([random_masks(flat, k, rng, internal=0.0) for _ in range(C)])
+        results = []
+        for block_nodes in ('0', '256', '1024', '64', '7'):
+            monkeypatch.setenv('PASTML_HIP_BLOCK_NODES', block_nodes)
+            with hip.Engine(flat, C, k) as eng:
+                eng.set_models(specs)
+                eng.set_masks(masks)
+                lnl, post, lh_sum, lh_sf = eng.marginal_pass()
+                again = eng.bottom_up(True)            # graph replay of the same schedule
+                bu = eng.download(hip.BUF_BU, 1)
+                assert np.array_equal(lnl, again)
+            results.append((lnl, post, lh_sum, lh_sf, bu))
+        for other in results[1:]:
+            for a, b in zip(results[0], other):
+                assert np.array_equal(a, b)
