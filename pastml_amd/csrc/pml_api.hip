@@ -1060,7 +1060,9 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
             const int S = env ? atoi(env) : 256;  // measured: 128-512 are within a few per cent, 1024+ loses at k >= 16
             pml_ctx::BlockSchedule& B = ctx->blocks;
             B = pml_ctx::BlockSchedule();
-            if (S > 0 && n_stored > S && n_stored <= (1 << 17)) {
+            const char* env_cap = getenv("PASTML_HIP_BLOCK_MAX_STORED");
+            const int cap_stored = env_cap ? atoi(env_cap) : (1 << 17);  // beyond: the streaming level kernels
+            if (S > 0 && n_stored > S && n_stored <= cap_stored) {
                 std::vector<int> ssz(n_nodes, 0), blk(n_nodes, -1), depth(n_nodes, 0);
                 for (int l = 0; l < n_td_levels; ++l)
                     for (int i = td_offsets[l]; i < td_offsets[l + 1]; ++i) depth[i] = l;

@@ -1186,13 +1186,54 @@ __device__ __forceinline__ double column_loglik(const PmlTree& t, const PmlCols&
     return total;
 }
 
+// Walks the levels [0, nl) of a level table inside one workgroup (barrier between levels).  A level's units depend on
+// the previous level's results, its DESCRIPTORS do not: the descriptor a lane needs first in the next level (and that
+// level's bounds) are fetched before the current level is computed, which takes one round trip out of the dependent
+// chain descriptor -> gathered scalars -> vectors of every level.
+template <int G, int R, bool BU>
+__device__ __forceinline__ void walk_levels(const LaneCtx<G, R>& L, const PmlTree& t, const PmlCols& c, const PmlState& st,
+                                            const PmlUnit* __restrict__ units, const int* __restrict__ lv, int nl) {
+    constexpr int UW = 64 / G;
+    const int wave = threadIdx.x >> 6;
+    const int n_waves = blockDim.x >> 6;
+    const int sub = (threadIdx.x & 63) / G;
+    const int first = wave * UW + sub;  // the unit of a level this lane's group takes first
+    if (nl <= 0) return;
+    int a = lv[0], b = lv[1];
+    UnitRegs nxt = load_unit<G>(units, first < b - a ? a + first : a, L.g);
+    for (int l = 0; l < nl; ++l) {
+        const int n_level = b - a;
+        const UnitRegs cur = nxt;
+        int a2 = a, b2 = a;
+        if (l + 1 < nl) {
+            a2 = lv[l + 1];
+            b2 = lv[l + 2];
+            nxt = load_unit<G>(units, first < b2 - a2 ? a2 + first : a2, L.g);
+        }
+        if (first < n_level) {
+            if (BU) bu_f81_unit<G, R, false>(L, t, c, st, cur);
+            else td_f81_unit<G, R>(L, t, c, st, cur);
+        }
+        for (int base = wave * UW + n_waves * UW; base < n_level; base += n_waves * UW) {
+            const int idx = base + sub;
+            if (idx < n_level) {
+                if (BU) bu_f81_unit<G, R, false>(L, t, c, st, load_unit<G>(units, a + idx, L.g));
+                else td_f81_unit<G, R>(L, t, c, st, load_unit<G>(units, a + idx, L.g));
+            }
+        }
+        __syncthreads();
+        a = a2;
+        b = b2;
+    }
+}
+
+
 template <int G, int R>
 __global__ void __launch_bounds__(PML_SMALL_BLOCK)
 bu_f81_small_kernel(PmlTree t, PmlCols c, PmlState st, const double* __restrict__ mu, const double* __restrict__ sf,
                     const double* __restrict__ tau, const double* __restrict__ tauf, int do_prep,
                     const PmlUnit* __restrict__ units, const int* __restrict__ level_offsets, int n_levels,
                     double* __restrict__ loglik, u64* __restrict__ err_out, int reset_err) {
-    constexpr int UW = 64 / G;
     const int col = blockIdx.y;
     if (reset_err) {  // whole sweep in this launch: the column's error word is reset here, not by a launch of its own
         if (threadIdx.x == 0) st.err[col] = ~0ull;
@@ -1219,19 +1260,9 @@ bu_f81_small_kernel(PmlTree t, PmlCols c, PmlState st, const double* __restrict_
         }
         __syncthreads();
     }
-    const int wave = threadIdx.x >> 6;
-    const int n_waves = blockDim.x >> 6;
-    const int sub = (threadIdx.x & 63) / G;
     LaneCtx<G, R> L;
     lane_ctx_init<G, R>(L, t, c, st);
-    for (int l = 0; l < n_levels; ++l) {
-        const int a = level_offsets[l], n_level = level_offsets[l + 1] - a;
-        for (int base = wave * UW; base < n_level; base += n_waves * UW) {
-            const int idx = base + sub;
-            if (idx < n_level) bu_f81_unit<G, R, false>(L, t, c, st, load_unit<G>(units, a + idx, L.g));
-        }
-        __syncthreads();
-    }
+    walk_levels<G, R, true>(L, t, c, st, units, level_offsets, n_levels);
     if (threadIdx.x == 0) {
         // pinned host memory: the results land where the caller reads them
         loglik[col] = column_loglik(t, c, st, col, 1);
@@ -1303,15 +1334,9 @@ td_f81_small_kernel(PmlTree t, PmlCols c, PmlState st, const PmlUnit* __restrict
         if (idx < t.n_roots) f81_root_unit<G, R>(L, t, c, st, idx);
     }
     __syncthreads();
-    for (int l = 0; l < n_levels; ++l) {
-        const int a = level_offsets[l], n_level = level_offsets[l + 1] - a;
-        for (int base = wave * UW; base < n_level; base += n_waves * UW) {
-            const int idx = base + sub;
-            if (idx < n_level) td_f81_unit<G, R>(L, t, c, st, load_unit<G>(units, a + idx, L.g));
-        }
-        __syncthreads();
-    }
+    walk_levels<G, R, false>(L, t, c, st, units, level_offsets, n_levels);
 }
+
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Subtree blocks: mid-size forests in a handful of launches.  The stored nodes are cut into blocks -- maximal subtrees
@@ -1328,40 +1353,16 @@ template <int G, int R>
 __global__ void __launch_bounds__(PML_SMALL_BLOCK)
 bu_f81_blocks_kernel(PmlTree t, PmlCols c, PmlState st, const PmlUnit* __restrict__ units,
                      const int* __restrict__ blk_start, const int* __restrict__ blk_levels, const int* __restrict__ lv) {
-    constexpr int UW = 64 / G;
-    const int wave = threadIdx.x >> 6;
-    const int n_waves = blockDim.x >> 6;
-    const int sub = (threadIdx.x & 63) / G;
     LaneCtx<G, R> L;
     lane_ctx_init<G, R>(L, t, c, st);
-    const int p = blk_start[blockIdx.x], nl = blk_levels[blockIdx.x];
-    for (int l = 0; l < nl; ++l) {
-        const int a = lv[p + l], n_level = lv[p + l + 1] - a;
-        for (int base = wave * UW; base < n_level; base += n_waves * UW) {
-            const int idx = base + sub;
-            if (idx < n_level) bu_f81_unit<G, R, false>(L, t, c, st, load_unit<G>(units, a + idx, L.g));
-        }
-        __syncthreads();
-    }
+    walk_levels<G, R, true>(L, t, c, st, units, lv + blk_start[blockIdx.x], blk_levels[blockIdx.x]);
 }
 
 template <int G, int R>
 __global__ void __launch_bounds__(PML_SMALL_BLOCK)
 td_f81_blocks_kernel(PmlTree t, PmlCols c, PmlState st, const PmlUnit* __restrict__ units,
                      const int* __restrict__ blk_start, const int* __restrict__ blk_levels, const int* __restrict__ lv) {
-    constexpr int UW = 64 / G;
-    const int wave = threadIdx.x >> 6;
-    const int n_waves = blockDim.x >> 6;
-    const int sub = (threadIdx.x & 63) / G;
     LaneCtx<G, R> L;
     lane_ctx_init<G, R>(L, t, c, st);
-    const int p = blk_start[blockIdx.x], nl = blk_levels[blockIdx.x];
-    for (int l = 0; l < nl; ++l) {
-        const int a = lv[p + l], n_level = lv[p + l + 1] - a;
-        for (int base = wave * UW; base < n_level; base += n_waves * UW) {
-            const int idx = base + sub;
-            if (idx < n_level) td_f81_unit<G, R>(L, t, c, st, load_unit<G>(units, a + idx, L.g));
-        }
-        __syncthreads();
-    }
+    walk_levels<G, R, false>(L, t, c, st, units, lv + blk_start[blockIdx.x], blk_levels[blockIdx.x]);
 }
