@@ -779,3 +779,30 @@ def test_groups_are_cut_to_fit_the_device(monkeypatch):
         assert a['character'] == b['character'] and a[LOG_LIKELIHOOD] == b[LOG_LIKELIHOOD]
         assert np.array_equal(a[MARGINAL_PROBABILITIES].values, b[MARGINAL_PROBABILITIES].values)
         assert a[RESTRICTED_LOG_LIKELIHOOD_FORMAT_STR.format(MPPA)] == b[RESTRICTED_LOG_LIKELIHOOD_FORMAT_STR.format(MPPA)]
+
+
+def test_zero_likelihood_of_one_character_fails_the_batch_cleanly():
+    """One character of a batch has no likelihood (masks in conflict across a zero-length branch, the reference's
+    edge case of ml.py:139-145) while the optimisers of the others are running: the batch raises the reference's error
+    for that character, every optimiser thread ends, and the engine pool serves the next call."""
+    import threading
+    from pastml_amd import batch as B
+    z = load_golden('edge_zero_likelihood')
+    flat = FlatForest(z['parent'], z['n_children'], z['first_child'], z['dist'], np.arange(int(z['n_roots'])))
+    flat.to_tree_nodes(names=list(z['node_names']))
+    states = z['states']
+    fs = ForestStats(flat)
+    tasks = [B.Task('c{}'.format(i), MPPA, F81Model(states=states, forest_stats=fs, character='c{}'.format(i)),
+                    np.ones(len(states)) / len(states)) for i in range(3)]
+    with B.CharacterBatch(flat, len(states), 3) as cb:
+        cb.initialize_allowed_states()
+        cb.masks[1] = B.words_from_masks(z['masks'], len(states))      # the conflicting masks, for the middle character
+        tip_masks = z['masks'].copy()
+        tip_masks[flat.n_children > 0] = 1                              # the same tips without the conflict
+        cb.masks[0] = cb.masks[2] = B.words_from_masks(tip_masks, len(states))
+        with pytest.raises(PastMLLikelihoodError) as e:
+            B.optimise_group(cb, tasks)
+        assert str(e.value) == str(z['error_message'])
+    assert not [th for th in threading.enumerate() if th.name.startswith('pastml-opt')]
+    tree, results = albania_result(JC)
+    assert results[0][LOG_LIKELIHOOD] < 0
