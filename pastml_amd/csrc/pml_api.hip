@@ -218,6 +218,14 @@ static bool single_launch_sweeps(const pml_ctx* c) {
     return c->small || (c->C >= 64 && c->N <= many);
 }
 
+// The subtree-block schedule pays where a sweep is a chain of latency-bound launches; once the levels carry enough work
+// to fill the chip (stored nodes x columns beyond ~1.6e5: measured on 16 384 - 131 072-tip trees with 1 - 32 columns)
+// the level kernels, which spread every level over all compute units, win again.
+static bool block_schedule(const pml_ctx* c) {
+    static const long long limit = getenv("PASTML_HIP_BLOCK_MAX_WORK") ? atoll(getenv("PASTML_HIP_BLOCK_MAX_WORK")) : 160000;
+    return c->blocks.ok && !c->bu_offsets_f.empty() && (long long)c->bu_offsets_f.back() * c->C <= limit;
+}
+
 static PmlTree tree_of(const pml_ctx* c, bool fused = false) {
     PmlTree t;
     t.kind = fused ? c->d_kind : nullptr;
@@ -1618,7 +1626,7 @@ static int enqueue_bottom_up(pml_ctx* ctx, int is_marginal, bool small_path, boo
         // prep + every level + ln L in one launch
         PML_TRY(dispatch_small_f81(ctx, true, (ctx->prep_dirty || force_prep) ? 1 : 0));
         PML_TRY(prof_end(ctx, 0, 1));
-    } else if (fused && ctx->blocks.ok) {
+    } else if (fused && block_schedule(ctx)) {
         // subtree blocks in one launch, then the top part: level launches, its narrow end (and ln L) in one launch
         const pml_ctx::BlockSchedule& B = ctx->blocks;
         PML_TRY(dispatch_blocks_f81(ctx, true));
@@ -1803,7 +1811,7 @@ static int run_top_down(pml_ctx* ctx) {
     const bool td_small = single_launch_sweeps(ctx) && ctx->kind == PML_MODEL_F81;
     const bool td_fused = ctx->kind == PML_MODEL_F81;
     auto enqueue = [&]() -> int {
-        if (td_fused && !td_small && ctx->blocks.ok) {
+        if (td_fused && !td_small && block_schedule(ctx)) {
             // block schedule: the top part (roots, its narrow end in one launch, its wide levels one launch each),
             // then all subtree blocks in one launch
             const pml_ctx::BlockSchedule& B = ctx->blocks;
