@@ -88,6 +88,7 @@ struct pml_ctx {
         std::vector<char> top_bu_vec;                                   // per top level: stored node among children 0, 1
     } blocks;
     bool small = false;  // forest small enough for the one-launch-per-sweep kernels
+    bool levels_fit_workgroup = false;  // (nearly) every fused level is one pass of a 512-thread workgroup
     std::vector<int> bu_offsets_f, td_parent_offsets_f;
     std::vector<char> bu_level_vec_f;  // per fused bottom-up level: some unit has a stored node as child 0 or 1
     std::vector<char> bu_level_vec;    // the same for the plain levels (joint sweep: every internal node is stored)
@@ -211,11 +212,13 @@ static int grid_for(int n_units, int units_per_block, int C, bool pipelined = fa
 // Whole F81 sweeps in ONE launch (one workgroup per column walks every level): forests of up to
 // PASTML_HIP_SMALL_MAX_NODES (2048) nodes, where a sweep is otherwise a chain of latency-bound launches -- and, when
 // there are many columns (the optimiser's batches: one workgroup per column already fills the chip), forests of up to
-// PASTML_HIP_SMALL_MANY_NODES (16384) nodes: HIV1C-sized sweeps (7 237 nodes, 57 height levels) of 246 columns 0.34 ->
-// 0.27 ms.  Same unit functions and lane shapes as the level kernels: identical bits.
+// PASTML_HIP_SMALL_MANY_NODES (16384) nodes whose levels each fit one pass of a workgroup (deep, ragged trees:
+// HIV1C-sized sweeps -- 7 237 nodes, 57 height levels -- of 246 binary columns 0.34 -> 0.27 ms; a balanced 4 096-tip
+// tree with 20 states has levels of 16 passes and stays with the level kernels: 0.12 against 0.27 ms).  Same unit
+// functions and lane shapes as the level kernels: identical bits.
 static bool single_launch_sweeps(const pml_ctx* c) {
     static const int many = getenv("PASTML_HIP_SMALL_MANY_NODES") ? atoi(getenv("PASTML_HIP_SMALL_MANY_NODES")) : 16384;
-    return c->small || (c->C >= 64 && c->N <= many);
+    return c->small || (c->C >= 64 && c->N <= many && c->levels_fit_workgroup);
 }
 
 // The subtree-block schedule pays where a sweep is a chain of latency-bound launches; once the levels carry enough work
@@ -1223,6 +1226,14 @@ int pml_chars_alloc(pml_ctx* ctx, int32_t n_cols, int32_t k) {
         ctx->bu_wide_lanes = k > 32 && k <= 64 && ctx->Rf == 4 && !getenv("PASTML_HIP_F81_R");
         shape("PASTML_HIP_F81_TD_R", (k > 32 && k <= 64) ? 8 : 4, ctx->Gt, ctx->Rt);
         if (k >= 2 && (ctx->ks & 1)) ctx->ks += 1;  // 16-byte lane accesses
+        {
+            const int g = ctx->bu_wide_lanes ? 8 : ctx->Gf;
+            const int nl = (int)ctx->bu_offsets_f.size() - 1;
+            long long passes = 0;
+            for (int l = 0; l < nl; ++l)
+                passes += ((long long)(ctx->bu_offsets_f[l + 1] - ctx->bu_offsets_f[l]) * g + PML_SMALL_BLOCK - 1) / PML_SMALL_BLOCK;
+            ctx->levels_fit_workgroup = nl > 0 && passes * 4 <= (long long)nl * 5;
+        }
     }
     ctx->W = (k + 63) / 64;
     if ((size_t)ctx->N * ctx->ks >= (1ull << 31)) {
