@@ -79,6 +79,7 @@ struct pml_ctx {
     struct BlockSchedule {
         bool ok = false;
         int n_blocks = 0;
+        long long steps = 0;  // sum over the blocks of their levels: workgroup steps of one column's sweep
         PmlUnit *d_bu_units = nullptr, *d_td_units = nullptr;          // units of the blocks, block by block
         int *d_bu_start = nullptr, *d_bu_levels = nullptr, *d_bu_lv = nullptr;
         int *d_td_start = nullptr, *d_td_levels = nullptr, *d_td_lv = nullptr;
@@ -226,7 +227,13 @@ static bool single_launch_sweeps(const pml_ctx* c) {
 // the level kernels, which spread every level over all compute units, win again.
 static bool block_schedule(const pml_ctx* c) {
     static const long long limit = getenv("PASTML_HIP_BLOCK_MAX_WORK") ? atoll(getenv("PASTML_HIP_BLOCK_MAX_WORK")) : 160000;
-    return c->blocks.ok && !c->bu_offsets_f.empty() && (long long)c->bu_offsets_f.back() * c->C <= limit;
+    // ragged trees give many shallow-filled blocks (HIV1C: 45 blocks of 505 levels for 2 455 stored nodes, a balanced tree
+    // 8 levels per 255 nodes): each (block, level, column) is a workgroup step of a few microseconds whatever it holds,
+    // so with many columns the level kernels, which pack a level of all columns densely, are ahead (HIV1C, k = 64:
+    // 16 columns 0.68 against 0.71 ms for a marginal pass, 64 columns 1.46 against 0.81)
+    static const long long steps = getenv("PASTML_HIP_BLOCK_MAX_STEPS") ? atoll(getenv("PASTML_HIP_BLOCK_MAX_STEPS")) : 8192;
+    return c->blocks.ok && !c->bu_offsets_f.empty() && (long long)c->bu_offsets_f.back() * c->C <= limit &&
+           c->blocks.steps * c->C <= steps;
 }
 
 static PmlTree tree_of(const pml_ctx* c, bool fused = false) {
@@ -1165,6 +1172,10 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
                     PML_TRY(put(&B.d_top_td_offsets, B.top_td_offsets));
                     HIP_TRY(hipStreamSynchronize(ctx->stream));  // the vectors go out of scope
                     B.n_blocks = nb;
+                    for (int b = 0; b < nb; ++b) B.steps += bu_levels[b];
+                    if (getenv("PASTML_HIP_DEBUG"))
+                        fprintf(stderr, "pastml_hip: %d stored nodes, %d subtree blocks, %lld block levels, %d top levels of %d\n",
+                                n_stored, nb, B.steps, n_top_levels, max_h);
                     B.ok = true;
                 }
             }
@@ -1232,7 +1243,9 @@ int pml_chars_alloc(pml_ctx* ctx, int32_t n_cols, int32_t k) {
             long long passes = 0;
             for (int l = 0; l < nl; ++l)
                 passes += ((long long)(ctx->bu_offsets_f[l + 1] - ctx->bu_offsets_f[l]) * g + PML_SMALL_BLOCK - 1) / PML_SMALL_BLOCK;
-            ctx->levels_fit_workgroup = nl > 0 && passes * 4 <= (long long)nl * 5;
+            // (up to 4 lanes per unit, k <= 16: with wider units one workgroup per column is too little parallelism --
+            // HIV1C tree, 64 columns: k = 12 0.28 against 0.32 ms with level launches, k = 20 0.27 against 0.22)
+            ctx->levels_fit_workgroup = nl > 0 && g <= 4 && passes * 4 <= (long long)nl * 5;
         }
     }
     ctx->W = (k + 63) / 64;
