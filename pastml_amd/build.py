@@ -9,7 +9,7 @@ LIB = os.path.join(HERE, 'libpastml_hip.so')
 SOURCES = ['pml_api.hip']
 HEADERS = ['pml_device.h', 'pml_kernels_f81.h', 'pml_kernels_misc.h', 'pml_kernels_matrix.h', 'pml_kernels_pij.h',
            'pml_kernels_counts.h',
-           'pml_kernels_eigen_mfma.h', 'pml_kernels_eigen_gemm.h', 'pml_comm.h',
+           'pml_kernels_eigen_mfma.h', 'pml_kernels_eigen_gemm.h', 'pml_kernels_eigen_joint.h', 'pml_comm.h',
            os.path.join('..', '..', 'include', 'pastml_hip.h')]
 
 

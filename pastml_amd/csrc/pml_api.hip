@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "pml_kernels_eigen_gemm.h"
+#include "pml_kernels_eigen_joint.h"
 #include "pml_kernels_counts.h"
 #include "pml_comm.h"
 
@@ -106,6 +107,7 @@ struct pml_ctx {
     bool has_init = false;
     int kind = -1;
     double *d_pi = nullptr, *d_mu = nullptr, *d_kappa = nullptr, *d_d = nullptr, *d_A = nullptr, *d_Ainv = nullptr;
+    double* d_AinvT = nullptr;  // [C][32][32]: Ainv transposed and zero-padded (k <= 32), for eigen_joint_kernel
     double *d_sf = nullptr, *d_tau = nullptr, *d_tauf = nullptr;
     std::vector<char> model_set;  // per column
     bool prep_dirty = true;
@@ -572,7 +574,8 @@ static int launch_eigen_fused(pml_ctx* ctx, int mode, const int* nodes, int firs
         typedef EigShape<KS_> S;                                                                                   \
         const size_t lds = ((size_t)S::KP * k + (size_t)PML_WAVES_PER_BLOCK * S::WAVE_LDS) * sizeof(double);       \
         int blocks = (n + PML_WAVES_PER_BLOCK * S::NB - 1) / (PML_WAVES_PER_BLOCK * S::NB);                        \
-        const int cap = std::max(8, 8192 / std::max(1, ctx->C));                                                   \
+        static const int cap_all = getenv("PASTML_HIP_EIG_BLOCKS") ? atoi(getenv("PASTML_HIP_EIG_BLOCKS")) : 8192;   \
+        const int cap = std::max(8, cap_all / std::max(1, ctx->C));                                                \
         if (blocks > cap) blocks = cap;                                                                            \
         hipLaunchKernelGGL((eigen_fused_kernel<NT_, KS_, MODE_>), dim3(blocks, ctx->C), dim3(PML_BLOCK), lds,      \
                            ctx->stream, t, c, m, st, nodes, first, n, tips);                                       \
@@ -693,6 +696,52 @@ static int launch_eigen_narrow(pml_ctx* ctx, int mode, const int* nodes, const i
 #undef PML_EIG_MODES
 #undef PML_EIG_CASE
     return fail(PML_ERR_UNSUPPORTED, "no fused eigen kernel for k = %d", k);
+}
+
+// The joint sweep of the eigen models on the vector units (pml_kernels_eigen_joint.h) for 2 <= k <= 32;
+// PASTML_HIP_NO_EIGEN_JOINT_VALU keeps the matrix-core kernels (pml_kernels_eigen_mfma.h).
+static bool eigen_joint_valu(const pml_ctx* c) {
+    static const bool off = getenv("PASTML_HIP_NO_EIGEN_JOINT_VALU") != nullptr;
+    return !off && c->kind == PML_MODEL_EIGEN && c->k >= 2 && c->k <= PML_EIGJ_STRIDE && c->W == 1 &&
+           c->ks == 4 * ((c->k + 3) / 4) && c->d_AinvT != nullptr;
+}
+
+// levels == nullptr: one launch over a list (nodes) or a contiguous id range (first) of n nodes; otherwise the levels
+// [first, first + n) of the level table in one launch (one workgroup per column)
+static int launch_eigen_joint(pml_ctx* ctx, const int* nodes, const int* d_offsets, int first, int n) {
+    if (n <= 0) return PML_OK;
+    const int KU = 4 * ((ctx->k + 3) / 4);
+    const PmlTree t = tree_of(ctx);
+    const PmlCols c = cols_of(ctx);
+    const PmlState st = state_of(ctx);
+    const PmlModel m = model_of(ctx);
+    const int per_block = PML_WAVES_PER_BLOCK * (64 / ctx->k);
+    static const int cap_all = getenv("PASTML_HIP_EIGJ_BLOCKS") ? atoi(getenv("PASTML_HIP_EIGJ_BLOCKS")) : 1024;
+#define PML_EIGJ_CASE(KU_)                                                                                          \
+    if (KU == KU_) {                                                                                                \
+        if (d_offsets) {                                                                                            \
+            hipLaunchKernelGGL((eigen_joint_narrow_kernel<KU_>), dim3(1, ctx->C), dim3(PML_BLOCK), 0, ctx->stream,  \
+                               t, c, m, st, ctx->d_AinvT, nodes, d_offsets + first, n);                             \
+        } else {                                                                                                    \
+            int blocks = (n + per_block - 1) / per_block;                                                           \
+            const int cap = std::max(8, cap_all / std::max(1, ctx->C));                                             \
+            if (blocks > cap) blocks = cap;                                                                         \
+            hipLaunchKernelGGL((eigen_joint_kernel<KU_>), dim3(blocks, ctx->C), dim3(PML_BLOCK), 0, ctx->stream,    \
+                               t, c, m, st, ctx->d_AinvT, nodes, first, n);                                         \
+        }                                                                                                           \
+        HIP_TRY(hipGetLastError());                                                                                 \
+        return PML_OK;                                                                                              \
+    }
+    PML_EIGJ_CASE(4)
+    PML_EIGJ_CASE(8)
+    PML_EIGJ_CASE(12)
+    PML_EIGJ_CASE(16)
+    PML_EIGJ_CASE(20)
+    PML_EIGJ_CASE(24)
+    PML_EIGJ_CASE(28)
+    PML_EIGJ_CASE(32)
+#undef PML_EIGJ_CASE
+    return fail(PML_ERR_UNSUPPORTED, "no joint eigen kernel for k = %d", ctx->k);
 }
 
 // bottom-up messages of all tips (observed tips 16 to a tile, see eigen_tips_kernel)
@@ -1467,6 +1516,17 @@ int pml_model_set_eigen(pml_ctx* ctx, int32_t col_begin, int32_t col_end, const 
     PML_TRY(upload(ctx, ctx->d_d + col_begin * k, d, nc * k));
     PML_TRY(upload(ctx, ctx->d_A + col_begin * k * k, A, nc * k * k));
     PML_TRY(upload(ctx, ctx->d_Ainv + col_begin * k * k, Ainv, nc * k * k));
+    std::vector<double> at;
+    if (k <= PML_EIGJ_STRIDE) {
+        const size_t sq = (size_t)PML_EIGJ_STRIDE * PML_EIGJ_STRIDE;
+        if (!ctx->d_AinvT) PML_TRY(dev_alloc(ctx, &ctx->d_AinvT, (size_t)ctx->C * sq));
+        at.assign((size_t)nc * sq, 0.0);
+        for (int c = 0; c < nc; ++c)
+            for (size_t mm = 0; mm < k; ++mm)
+                for (size_t j = 0; j < k; ++j)
+                    at[c * sq + j * PML_EIGJ_STRIDE + mm] = Ainv[(size_t)c * k * k + mm * k + j];
+        PML_TRY(upload(ctx, ctx->d_AinvT + (size_t)col_begin * sq, at.data(), at.size()));
+    }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return PML_OK;
 }
@@ -1708,6 +1768,16 @@ static int enqueue_bottom_up(pml_ctx* ctx, int is_marginal, bool small_path, boo
         // every node once, in the launch of its level: the tips first, then the internal nodes by height
         const int mode = is_marginal ? PML_EIG_BU_MARG : PML_EIG_BU_JOINT;
         PML_TRY(launch_eigen_tips(ctx, is_marginal ? 0 : 1));
+        if (!is_marginal && eigen_joint_valu(ctx)) {
+            const int tail = narrow_levels(ctx->bu_offsets, ctx->n_bu_levels, false, ctx->C,
+                                           PML_WAVES_PER_BLOCK * (64 / ctx->k));
+            for (int l = 0; l < ctx->n_bu_levels - tail; ++l) {
+                const int a = ctx->bu_offsets[l], b = ctx->bu_offsets[l + 1];
+                PML_TRY(launch_eigen_joint(ctx, ctx->d_bu_order + a, nullptr, 0, b - a));
+            }
+            PML_TRY(launch_eigen_joint(ctx, ctx->d_bu_order, ctx->d_bu_offsets, ctx->n_bu_levels - tail, tail));
+            PML_TRY(prof_end(ctx, 0, ctx->n_bu_levels + 1 - tail + (tail > 0 ? 1 : 0)));
+        } else {
         const int eig_nb = ((ctx->k + 3) / 4) % 4 == 0 ? 1 : (((ctx->k + 3) / 4) % 2 == 0 ? 2 : 4);  // EigShape::NB
         const int tail = narrow_levels(ctx->bu_offsets, ctx->n_bu_levels, false, ctx->C, PML_WAVES_PER_BLOCK * eig_nb);
         for (int l = 0; l < ctx->n_bu_levels - tail; ++l) {
@@ -1716,6 +1786,7 @@ static int enqueue_bottom_up(pml_ctx* ctx, int is_marginal, bool small_path, boo
         }
         PML_TRY(launch_eigen_narrow(ctx, mode, ctx->d_bu_order, ctx->d_bu_offsets, ctx->n_bu_levels - tail, tail));
         PML_TRY(prof_end(ctx, 0, ctx->n_bu_levels + 1 - tail + (tail > 0 ? 1 : 0)));
+        }
     } else {
         for (int l = 0; l < ctx->n_bu_levels; ++l) {
             const int a = ctx->bu_offsets[l], b = ctx->bu_offsets[l + 1];

@@ -1,0 +1,222 @@
+// Eigen models (CUSTOM_RATES, JTT), 2 <= k <= 32: the joint (max-product) bottom-up sweep, ml.py:124-148 with
+// is_marginal=False, on the vector FP64 units.
+//
+// The joint sweep needs every entry of P(t_n) -- msg_n[i] = max_j P[i][j] v_n[j] and its arg-max -- so P cannot be
+// avoided the way the sum sweeps avoid it (pml_kernels_eigen_gemm.h).  What can be chosen is where its 2 k^3 flops per
+// node run.  Measured on MI355X (scratch/ub/overlap.hip): v_mfma_f64_16x16x4_f64 and v_fma_f64
+// deliver the same 32 flop / clock / SIMD, and they do not overlap -- a wave's FP64 MFMAs and the vector instructions
+// of every wave of the SIMD add up.  The matrix cores therefore buy nothing for FP64 but their tile shape, and the
+// tile shape costs: k = 20 pads to 32 columns (62 % useful), the products of a tile land spread over lanes and
+// registers, and folding them per node took 21 vector instructions per MFMA (pml_kernels_eigen_mfma.h: 0.24 of peak).
+//
+// Here a lane stands for (node, parent state i) -- floor(64 / k) nodes per wavefront, no padding but the idle tail
+// lanes -- and holds row i of A in registers.  Per node it forms u[m] = A[i][m] exp(d_m t) once (k multiplications)
+// and then, for j = 0 .. k-1 in order, P[i][j] = sum_m u[m] Ainv[m][j] as a chain of k FMAs whose second operand is
+// the same for every lane: it comes from a transposed, zero-padded copy of Ainv through the scalar cache into SGPRs
+// (s_load_dwordx16, one SGPR operand per v_fma_f64), so the inner loop is FMAs only.  P[i][j] v[j] is folded into the
+// running maximum in the lane itself (j ascends: the first maximum stays, as numpy's argmax) -- no cross-lane
+// reduction at all.  v and exp(d t) are shared between the lanes of a node through 1 KB of LDS per wavefront.
+#pragma once
+#include "pml_kernels_eigen_mfma.h"
+
+typedef const __attribute__((address_space(4))) double* pml_const_f64;
+#define PML_EIGJ_STRIDE 32                     // row stride (and rows) of the transposed padded copy of Ainv
+#define PML_EIGJ_WAVE_LDS 128                  // doubles per wave and array: (64 / k) * KU <= 128
+// rows of A in LDS: 16-byte aligned, and a stride that is not a multiple of 64 bytes so that the rows of the states
+// of a node start in different banks
+#define PML_EIGJ_ASTRIDE(KU) ((KU) + 2)
+#define PML_EIGJ_LDS(KU) (PML_WAVES_PER_BLOCK * 2 * PML_EIGJ_WAVE_LDS + 32 * PML_EIGJ_ASTRIDE(KU))
+
+template <int KU>
+struct EigJWave {
+    int k, ks, col, b, i, npw;
+    bool lane_ok;   // the lane stands for a (node slot, state) pair
+    u64 gmask;      // the lanes of the lane's node slot
+    size_t colN;
+    const double* sA;  // row i of A in LDS (shared by the block), zero for m >= k; rows PML_EIGJ_ASTRIDE(KU) apart
+    double d_i;
+    double sfc, tau, tf;
+    pml_const_f64 ainvT;
+    double* sE;     // per wave: exp(d_m t') of the slot's node, [npw][KU]
+    double* sV;     // per wave: the vectors P is applied to, [npw][KU]
+};
+
+template <int KU>
+__device__ __forceinline__ void eigj_wave_init(EigJWave<KU>& w, const PmlTree& t, const PmlCols& c, const PmlModel& m,
+                                               const double* ainvT, double* smem) {
+    const int k = c.k;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    w.k = k;
+    w.ks = c.ks;
+    w.col = blockIdx.y;
+    w.colN = (size_t)w.col * t.N;
+    w.npw = 64 / k;
+    const int b = lane / k;
+    w.lane_ok = b < w.npw;
+    w.b = w.lane_ok ? b : w.npw - 1;  // idle lanes read the last slot's LDS entries and write nothing
+    w.i = w.lane_ok ? lane - b * k : 0;
+    w.gmask = (k >= 64 ? ~0ull : ((1ull << k) - 1ull)) << (w.b * k);
+    w.sE = smem + (size_t)wave * 2 * PML_EIGJ_WAVE_LDS;
+    w.sV = w.sE + PML_EIGJ_WAVE_LDS;
+    for (int e = lane; e < 2 * PML_EIGJ_WAVE_LDS; e += 64) w.sE[e] = 0.0;  // the padding entries stay zero
+    double* sA = smem + PML_WAVES_PER_BLOCK * 2 * PML_EIGJ_WAVE_LDS;
+    const double* gA = m.A + (size_t)w.col * k * k;
+    for (int e = threadIdx.x; e < k * PML_EIGJ_ASTRIDE(KU); e += blockDim.x) {
+        const int r = e / PML_EIGJ_ASTRIDE(KU), q = e % PML_EIGJ_ASTRIDE(KU);
+        sA[e] = q < k ? gA[r * k + q] : 0.0;
+    }
+    w.sA = sA + w.i * PML_EIGJ_ASTRIDE(KU);
+    w.d_i = m.d[(size_t)w.col * k + w.i];
+    w.sfc = m.sf[w.col];
+    w.tau = m.tau[w.col];
+    w.tf = m.tauf[w.col];
+    w.ainvT = (pml_const_f64)(ainvT + (size_t)w.col * PML_EIGJ_STRIDE * PML_EIGJ_STRIDE);
+    __syncthreads();
+}
+
+// any() over the lanes of the lane's node slot (all of them are in the same control flow: they share the node)
+template <int KU>
+__device__ __forceinline__ bool eigj_node_any(const EigJWave<KU>& W, bool p) {
+    return (__ballot(p) & W.gmask) != 0ull;
+}
+
+// One pass of a wave: npw nodes, lane (b, i) owns state i of the node n of slot b (act: the slot has a node).
+template <int KU>
+__device__ __forceinline__ void eigj_pass(const EigJWave<KU>& W, const PmlTree& t, const PmlCols& c,
+                                          const PmlState& st, bool act, int n) {
+    const int k = W.k, ks = W.ks, i = W.i;
+    const size_t colN = W.colN;
+    const size_t row = (colN + n) * ks;
+    // ------------------------------------------------------------------ the vector of the node (ml.py:126-148)
+    double v = 0.0;
+    double tq = 0.0;
+    if (act) {
+        const u64 word = c.masks[colN + n];  // k <= 32: one word
+        const int nc = t.n_children[n];
+        const int fc = t.first_child[n];
+        tq = (t.dist[n] + W.tau) * W.tf * W.sfc;
+        v = ((word >> i) & 1ull) ? 1.0 : 0.0;
+        i64 esum = 0;
+        // the children two at a time: the loads of a pair go out together (a tip's exponent word is zero)
+        for (int j0 = 0; j0 < nc; j0 += 2) {
+            double mv[2];
+            i64 cbe[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int ch = fc + (j0 + u < nc ? j0 + u : j0);
+                cbe[u] = st.be[colN + ch];
+                mv[u] = st.msg[(colN + ch) * ks + i];
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (j0 + u >= nc) break;
+                v *= fmax(mv[u], 0.0);
+                if (!eigj_node_any<KU>(W, v != 0.0)) {
+                    if (i == 0)
+                        atomicMin(&st.err[W.col], ((u64)(unsigned)t.post_rank[n] << 32) | (u64)(unsigned)(fc + j0 + u));
+                }
+                esum += cbe[u];
+                // lazy_rescale of pml_device.h over the k lanes of the node: out of the band [2^-200, 2^200] is rare
+                if (eigj_node_any<KU>(W, v != 0.0 && (v < 0x1p-200 || v > 0x1p+200))) {
+                    double mx = 0.0;
+                    for (int q = 0; q < k; ++q) mx = fmax(mx, __shfl(v, (W.b * k + q) & 63, 64));
+                    if (mx > 0.0 && !isinf(mx)) {
+                        const int ex = exponent_of(mx);
+                        v = __builtin_ldexp(v, -ex);
+                        esum += ex;
+                    }
+                }
+            }
+        }
+        st.bu[row + i] = v;
+        if (i == 0) st.be[colN + n] = esum;
+        if (i == k - 1)
+            for (int q = k; q < ks; ++q) st.bu[row + q] = 0.0;
+    }
+    // ------------------------------------------------------------------ v and exp(d t') of the node, for its lanes
+    const int slot = W.b * KU;
+    if (W.lane_ok) {
+        W.sE[slot + i] = exp(W.d_i * tq);
+        W.sV[slot + i] = v;
+    }
+    wave_lds_sync();
+    double u[KU];
+#pragma unroll
+    for (int mm = 0; mm < KU; ++mm) u[mm] = W.sA[mm] * W.sE[slot + mm];
+    // ------------------------------------------------------------------ P[i][j] v[j], folded as it is produced
+    double best = -INFINITY;
+    int bj = 0;
+    // the matrix is the same in every pass, and the compiler would keep all of it in (spilled) SGPRs across the loop
+    // over the passes: hide the pointer from it so that the rows are streamed through the scalar cache pass by pass
+    pml_const_f64 at = W.ainvT;
+    asm volatile("" : "+s"(at));
+#pragma unroll
+    for (int j = 0; j < KU; ++j) {
+        double p = u[0] * at[j * PML_EIGJ_STRIDE];
+#pragma unroll
+        for (int mm = 1; mm < KU; ++mm) p = __builtin_fma(u[mm], at[j * PML_EIGJ_STRIDE + mm], p);
+        double w = p * W.sV[slot + j];
+        if (j >= KU - 3 && j >= k) w = -INFINITY;  // padding columns (k > KU - 4) must not win
+        if (w > best) {  // j ascends: the first maximum stays
+            best = w;
+            bj = j;
+        }
+    }
+    // ------------------------------------------------------------------ results of the node
+    if (act) {
+        if (c.masks_init != nullptr) {
+            // altered nodes get their tables rewritten w.r.t. their initial masks (ml.py:408-428)
+            const u64 mi = c.masks_init[colN + n], mc = c.masks[colN + n];
+            if (mi != mc && !((mi >> bj) & 1ull)) bj = mi ? __builtin_ctzll(mi) : 0;
+        }
+        st.msg[row + i] = best;
+        st.J[row + i] = (pml_jt)bj;
+        if (i == k - 1)
+            for (int q = k; q < ks; ++q) {
+                st.msg[row + q] = 0.0;
+                st.J[row + q] = (pml_jt)0;
+            }
+    }
+    wave_lds_sync();  // the pass's LDS reads are done before the next pass overwrites the slots
+}
+
+#define PML_EIGJ_ATTR __launch_bounds__(PML_BLOCK)
+
+// one launch over a list (nodes) or a contiguous id range (first) of n internal nodes of one height level
+template <int KU>
+__global__ void PML_EIGJ_ATTR eigen_joint_kernel(PmlTree t, PmlCols c, PmlModel m, PmlState st,
+                                                 const double* __restrict__ ainvT, const int* __restrict__ nodes,
+                                                 int first, int n_nodes) {
+    __shared__ double smem[PML_EIGJ_LDS(KU)];
+    EigJWave<KU> W;
+    eigj_wave_init<KU>(W, t, c, m, ainvT, smem);
+    const int wave = threadIdx.x >> 6;
+    const int waves_total = gridDim.x * PML_WAVES_PER_BLOCK;
+    for (int b0 = (blockIdx.x * PML_WAVES_PER_BLOCK + wave) * W.npw; b0 < n_nodes; b0 += waves_total * W.npw) {
+        const bool act = W.lane_ok && b0 + W.b < n_nodes;
+        const int n = act ? (nodes != nullptr ? nodes[b0 + W.b] : first + b0 + W.b) : 0;
+        eigj_pass<KU>(W, t, c, st, act, n);
+    }
+}
+
+// the narrow end of a forest in one launch: one workgroup per column walks the levels [0, n_levels) of a level table
+template <int KU>
+__global__ void PML_EIGJ_ATTR eigen_joint_narrow_kernel(PmlTree t, PmlCols c, PmlModel m, PmlState st,
+                                                        const double* __restrict__ ainvT,
+                                                        const int* __restrict__ nodes,
+                                                        const int* __restrict__ level_offsets, int n_levels) {
+    __shared__ double smem[PML_EIGJ_LDS(KU)];
+    EigJWave<KU> W;
+    eigj_wave_init<KU>(W, t, c, m, ainvT, smem);
+    const int wave = threadIdx.x >> 6;
+    for (int l = 0; l < n_levels; ++l) {
+        const int a = level_offsets[l], n_level = level_offsets[l + 1] - a;
+        for (int b0 = wave * W.npw; b0 < n_level; b0 += PML_WAVES_PER_BLOCK * W.npw) {
+            const bool act = W.lane_ok && b0 + W.b < n_level;
+            const int n = act ? (nodes != nullptr ? nodes[a + b0 + W.b] : a + b0 + W.b) : 0;
+            eigj_pass<KU>(W, t, c, st, act, n);
+        }
+        __syncthreads();
+    }
+}
