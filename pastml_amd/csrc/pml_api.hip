@@ -703,12 +703,12 @@ static int launch_eigen_narrow(pml_ctx* ctx, int mode, const int* nodes, const i
 static bool eigen_joint_valu(const pml_ctx* c) {
     static const bool off = getenv("PASTML_HIP_NO_EIGEN_JOINT_VALU") != nullptr;
     return !off && c->kind == PML_MODEL_EIGEN && c->k >= 2 && c->k <= PML_EIGJ_STRIDE && c->W == 1 &&
-           c->ks == 4 * ((c->k + 3) / 4) && c->d_AinvT != nullptr;
+           c->d_AinvT != nullptr;
 }
 
-// levels == nullptr: one launch over a list (nodes) or a contiguous id range (first) of n nodes; otherwise the levels
+// d_offsets == nullptr: one launch over the n nodes of a level (their unit descriptors); otherwise the levels
 // [first, first + n) of the level table in one launch (one workgroup per column)
-static int launch_eigen_joint(pml_ctx* ctx, const int* nodes, const int* d_offsets, int first, int n) {
+static int launch_eigen_joint(pml_ctx* ctx, const PmlUnit* units, const int* d_offsets, int first, int n) {
     if (n <= 0) return PML_OK;
     const int KU = 4 * ((ctx->k + 3) / 4);
     const PmlTree t = tree_of(ctx);
@@ -721,13 +721,13 @@ static int launch_eigen_joint(pml_ctx* ctx, const int* nodes, const int* d_offse
     if (KU == KU_) {                                                                                                \
         if (d_offsets) {                                                                                            \
             hipLaunchKernelGGL((eigen_joint_narrow_kernel<KU_>), dim3(1, ctx->C), dim3(PML_BLOCK), 0, ctx->stream,  \
-                               t, c, m, st, ctx->d_AinvT, nodes, d_offsets + first, n);                             \
+                               t, c, m, st, ctx->d_AinvT, units, d_offsets + first, n);                                \
         } else {                                                                                                    \
             int blocks = (n + per_block - 1) / per_block;                                                           \
             const int cap = std::max(8, cap_all / std::max(1, ctx->C));                                             \
             if (blocks > cap) blocks = cap;                                                                         \
             hipLaunchKernelGGL((eigen_joint_kernel<KU_>), dim3(blocks, ctx->C), dim3(PML_BLOCK), 0, ctx->stream,    \
-                               t, c, m, st, ctx->d_AinvT, nodes, first, n);                                         \
+                               t, c, m, st, ctx->d_AinvT, units, n);                                                \
         }                                                                                                           \
         HIP_TRY(hipGetLastError());                                                                                 \
         return PML_OK;                                                                                              \
@@ -741,6 +741,37 @@ static int launch_eigen_joint(pml_ctx* ctx, const int* nodes, const int* d_offse
     PML_EIGJ_CASE(28)
     PML_EIGJ_CASE(32)
 #undef PML_EIGJ_CASE
+    return fail(PML_ERR_UNSUPPORTED, "no joint eigen kernel for k = %d", ctx->k);
+}
+
+static int launch_eigen_joint_tips(pml_ctx* ctx) {
+    if (ctx->n_tips <= 0) return PML_OK;
+    const int KU = 4 * ((ctx->k + 3) / 4);
+    const PmlTree t = tree_of(ctx);
+    const PmlCols c = cols_of(ctx);
+    const PmlState st = state_of(ctx);
+    const PmlModel m = model_of(ctx);
+    const int per_block = PML_WAVES_PER_BLOCK * (64 / ctx->k);
+    int blocks = (ctx->n_tips + per_block - 1) / per_block;
+    static const int cap_all = getenv("PASTML_HIP_EIGJ_TIP_BLOCKS") ? atoi(getenv("PASTML_HIP_EIGJ_TIP_BLOCKS")) : 2048;
+    const int cap = std::max(8, cap_all / std::max(1, ctx->C));
+    if (blocks > cap) blocks = cap;
+#define PML_EIGJ_TIPS(KU_)                                                                                          \
+    if (KU == KU_) {                                                                                                \
+        hipLaunchKernelGGL((eigen_joint_tips_kernel<KU_>), dim3(blocks, ctx->C), dim3(PML_BLOCK), 0, ctx->stream,   \
+                           t, c, m, st, ctx->d_AinvT, ctx->d_tips, ctx->n_tips);                                    \
+        HIP_TRY(hipGetLastError());                                                                                 \
+        return PML_OK;                                                                                              \
+    }
+    PML_EIGJ_TIPS(4)
+    PML_EIGJ_TIPS(8)
+    PML_EIGJ_TIPS(12)
+    PML_EIGJ_TIPS(16)
+    PML_EIGJ_TIPS(20)
+    PML_EIGJ_TIPS(24)
+    PML_EIGJ_TIPS(28)
+    PML_EIGJ_TIPS(32)
+#undef PML_EIGJ_TIPS
     return fail(PML_ERR_UNSUPPORTED, "no joint eigen kernel for k = %d", ctx->k);
 }
 
@@ -1696,11 +1727,12 @@ static int narrow_levels(const std::vector<int>& off, int n_levels, bool from_fr
 static int enqueue_bottom_up(pml_ctx* ctx, int is_marginal, bool small_path, bool force_prep) {
     const bool eig = eigen_fused(ctx);
     const bool gemm = is_marginal && eigen_gemm(ctx);
+    const bool eigj = !is_marginal && eigen_joint_valu(ctx);
     if (!small_path) {  // the single-launch kernel resets the error words itself
         hipLaunchKernelGGL(reset_err_kernel, dim3((ctx->C + 63) / 64), dim3(64), 0, ctx->stream, ctx->d_err, ctx->C);
         HIP_TRY(hipGetLastError());
         // the fused eigen sweeps build P(t) themselves, the two-GEMM sweeps never need it
-        if (!eig && !gemm) PML_TRY(run_prep(ctx, force_prep));
+        if (!eig && !gemm && !eigj) PML_TRY(run_prep(ctx, force_prep));
     }
     PML_TRY(prof_begin(ctx));
     const bool fused = is_marginal && ctx->kind == PML_MODEL_F81;
@@ -1753,6 +1785,17 @@ static int enqueue_bottom_up(pml_ctx* ctx, int is_marginal, bool small_path, boo
         }
         PML_TRY(prof_end(ctx, 0, nl));
         joint_fused = true;
+    } else if (eigj) {
+        // joint sweep of an eigen model on the vector units (pml_kernels_eigen_joint.h): the tips, then the levels
+        PML_TRY(launch_eigen_joint_tips(ctx));
+        const int tail = narrow_levels(ctx->bu_offsets, ctx->n_bu_levels, false, ctx->C,
+                                       PML_WAVES_PER_BLOCK * (64 / ctx->k));
+        for (int l = 0; l < ctx->n_bu_levels - tail; ++l) {
+            const int a = ctx->bu_offsets[l], b = ctx->bu_offsets[l + 1];
+            PML_TRY(launch_eigen_joint(ctx, ctx->d_bu_units + a, nullptr, 0, b - a));
+        }
+        PML_TRY(launch_eigen_joint(ctx, ctx->d_bu_units, ctx->d_bu_offsets, ctx->n_bu_levels - tail, tail));
+        PML_TRY(prof_end(ctx, 0, ctx->n_bu_levels + 1 - tail + (tail > 0 ? 1 : 0)));
     } else if (gemm) {
         // marginal sweep: P(t) is never formed, msg = A (e o (A^-1 v)) as two small GEMMs per 16 nodes
         PML_TRY(launch_eigen_gemm(ctx, PML_EIGG_TIPS, ctx->d_tips, 0, ctx->n_tips));
@@ -1768,16 +1811,7 @@ static int enqueue_bottom_up(pml_ctx* ctx, int is_marginal, bool small_path, boo
         // every node once, in the launch of its level: the tips first, then the internal nodes by height
         const int mode = is_marginal ? PML_EIG_BU_MARG : PML_EIG_BU_JOINT;
         PML_TRY(launch_eigen_tips(ctx, is_marginal ? 0 : 1));
-        if (!is_marginal && eigen_joint_valu(ctx)) {
-            const int tail = narrow_levels(ctx->bu_offsets, ctx->n_bu_levels, false, ctx->C,
-                                           PML_WAVES_PER_BLOCK * (64 / ctx->k));
-            for (int l = 0; l < ctx->n_bu_levels - tail; ++l) {
-                const int a = ctx->bu_offsets[l], b = ctx->bu_offsets[l + 1];
-                PML_TRY(launch_eigen_joint(ctx, ctx->d_bu_order + a, nullptr, 0, b - a));
-            }
-            PML_TRY(launch_eigen_joint(ctx, ctx->d_bu_order, ctx->d_bu_offsets, ctx->n_bu_levels - tail, tail));
-            PML_TRY(prof_end(ctx, 0, ctx->n_bu_levels + 1 - tail + (tail > 0 ? 1 : 0)));
-        } else {
+        {
         const int eig_nb = ((ctx->k + 3) / 4) % 4 == 0 ? 1 : (((ctx->k + 3) / 4) % 2 == 0 ? 2 : 4);  // EigShape::NB
         const int tail = narrow_levels(ctx->bu_offsets, ctx->n_bu_levels, false, ctx->C, PML_WAVES_PER_BLOCK * eig_nb);
         for (int l = 0; l < ctx->n_bu_levels - tail; ++l) {
@@ -1841,10 +1875,11 @@ static int submit_bottom_up(pml_ctx* ctx, int is_marginal) {
         PML_TRY(dev_alloc(ctx, &ctx->d_J, CN * ctx->ks));
         PML_TRY(dev_alloc(ctx, &ctx->d_js, CN));
     }
-    if (eigen_fused(ctx) || eigen_gemm(ctx)) {
+    const bool no_p = eigen_fused(ctx) || (is_marginal && eigen_gemm(ctx)) || (!is_marginal && eigen_joint_valu(ctx));
+    if (eigen_fused(ctx) || eigen_gemm(ctx) || eigen_joint_valu(ctx)) {
         if (!ctx->d_msg) PML_TRY(dev_alloc(ctx, &ctx->d_msg, CN * ctx->ks));
     }
-    if (!eigen_fused(ctx) && !(is_marginal && eigen_gemm(ctx))) PML_TRY(ensure_transition_storage(ctx));
+    if (!no_p) PML_TRY(ensure_transition_storage(ctx));
     ctx->bu_mode = -1;
     ctx->td_valid = ctx->js_valid = false;
     // mid-size forests: the level launches are latency-bound, replay them as one hipGraph
@@ -1857,7 +1892,7 @@ static int submit_bottom_up(pml_ctx* ctx, int is_marginal) {
         PML_TRY(enqueue_bottom_up(ctx, is_marginal, small_path, false));
     }
     // the fused eigen sweeps build P(t) in registers, the two-GEMM sweeps never form it: no batch ran
-    if (!eigen_fused(ctx) && !(is_marginal && eigen_gemm(ctx))) ctx->prep_dirty = false;
+    if (!no_p) ctx->prep_dirty = false;
     ctx->bu_fused = (is_marginal && ctx->kind == PML_MODEL_F81 && ctx->n_cherries > 0) || ctx->bu_fused_joint;
     return PML_OK;
 }

@@ -84,7 +84,7 @@ __device__ __forceinline__ bool eigj_node_any(const EigJWave<KU>& W, bool p) {
 // One pass of a wave: npw nodes, lane (b, i) owns state i of the node n of slot b (act: the slot has a node).
 template <int KU>
 __device__ __forceinline__ void eigj_pass(const EigJWave<KU>& W, const PmlTree& t, const PmlCols& c,
-                                          const PmlState& st, bool act, int n) {
+                                          const PmlState& st, bool act, int n, int fc, int nc) {
     const int k = W.k, ks = W.ks, i = W.i;
     const size_t colN = W.colN;
     const size_t row = (colN + n) * ks;
@@ -93,8 +93,6 @@ __device__ __forceinline__ void eigj_pass(const EigJWave<KU>& W, const PmlTree& 
     double tq = 0.0;
     if (act) {
         const u64 word = c.masks[colN + n];  // k <= 32: one word
-        const int nc = t.n_children[n];
-        const int fc = t.first_child[n];
         tq = (t.dist[n] + W.tau) * W.tf * W.sfc;
         v = ((word >> i) & 1ull) ? 1.0 : 0.0;
         i64 esum = 0;
@@ -129,10 +127,12 @@ __device__ __forceinline__ void eigj_pass(const EigJWave<KU>& W, const PmlTree& 
                 }
             }
         }
-        st.bu[row + i] = v;
-        if (i == 0) st.be[colN + n] = esum;
-        if (i == k - 1)
-            for (int q = k; q < ks; ++q) st.bu[row + q] = 0.0;
+        if (nc > 0) {  // a tip's bottom-up vector is its mask and its exponent word stays zero: nothing is stored
+            st.bu[row + i] = v;
+            if (i == 0) st.be[colN + n] = esum;
+            if (i == k - 1)
+                for (int q = k; q < ks; ++q) st.bu[row + q] = 0.0;
+        }
     }
     // ------------------------------------------------------------------ v and exp(d t') of the node, for its lanes
     const int slot = W.b * KU;
@@ -183,11 +183,26 @@ __device__ __forceinline__ void eigj_pass(const EigJWave<KU>& W, const PmlTree& 
 
 #define PML_EIGJ_ATTR __launch_bounds__(PML_BLOCK)
 
-// one launch over a list (nodes) or a contiguous id range (first) of n internal nodes of one height level
+// The node, its first child and its number of children come from the unit descriptors of the bottom-up order
+// (PmlUnit, pml_kernels_f81.h): one load instead of the chain node list -> first_child / n_children.
+struct EigJUnit {
+    int n, fc, nc;
+};
+__device__ __forceinline__ EigJUnit eigj_load_unit(const PmlTree& t, const PmlUnit* __restrict__ units, int idx) {
+    const int4 h = *reinterpret_cast<const int4*>(units + idx);
+    EigJUnit u;
+    u.n = h.x;
+    u.fc = h.y;
+    u.nc = unit_nc(h.z);
+    if (u.nc == 15) u.nc = t.n_children[u.n];  // the descriptor counts up to 14
+    return u;
+}
+
+// one launch over the n_nodes internal nodes of one height level (their unit descriptors)
 template <int KU>
 __global__ void PML_EIGJ_ATTR eigen_joint_kernel(PmlTree t, PmlCols c, PmlModel m, PmlState st,
-                                                 const double* __restrict__ ainvT, const int* __restrict__ nodes,
-                                                 int first, int n_nodes) {
+                                                 const double* __restrict__ ainvT,
+                                                 const PmlUnit* __restrict__ units, int n_nodes) {
     __shared__ double smem[PML_EIGJ_LDS(KU)];
     EigJWave<KU> W;
     eigj_wave_init<KU>(W, t, c, m, ainvT, smem);
@@ -195,16 +210,18 @@ __global__ void PML_EIGJ_ATTR eigen_joint_kernel(PmlTree t, PmlCols c, PmlModel 
     const int waves_total = gridDim.x * PML_WAVES_PER_BLOCK;
     for (int b0 = (blockIdx.x * PML_WAVES_PER_BLOCK + wave) * W.npw; b0 < n_nodes; b0 += waves_total * W.npw) {
         const bool act = W.lane_ok && b0 + W.b < n_nodes;
-        const int n = act ? (nodes != nullptr ? nodes[b0 + W.b] : first + b0 + W.b) : 0;
-        eigj_pass<KU>(W, t, c, st, act, n);
+        EigJUnit u = {0, 0, 0};
+        if (act) u = eigj_load_unit(t, units, b0 + W.b);
+        eigj_pass<KU>(W, t, c, st, act, u.n, u.fc, u.nc);
     }
 }
 
 // the narrow end of a forest in one launch: one workgroup per column walks the levels [0, n_levels) of a level table
+// (offsets into the unit descriptors)
 template <int KU>
 __global__ void PML_EIGJ_ATTR eigen_joint_narrow_kernel(PmlTree t, PmlCols c, PmlModel m, PmlState st,
                                                         const double* __restrict__ ainvT,
-                                                        const int* __restrict__ nodes,
+                                                        const PmlUnit* __restrict__ units,
                                                         const int* __restrict__ level_offsets, int n_levels) {
     __shared__ double smem[PML_EIGJ_LDS(KU)];
     EigJWave<KU> W;
@@ -214,9 +231,107 @@ __global__ void PML_EIGJ_ATTR eigen_joint_narrow_kernel(PmlTree t, PmlCols c, Pm
         const int a = level_offsets[l], n_level = level_offsets[l + 1] - a;
         for (int b0 = wave * W.npw; b0 < n_level; b0 += PML_WAVES_PER_BLOCK * W.npw) {
             const bool act = W.lane_ok && b0 + W.b < n_level;
-            const int n = act ? (nodes != nullptr ? nodes[a + b0 + W.b] : a + b0 + W.b) : 0;
-            eigj_pass<KU>(W, t, c, st, act, n);
+            EigJUnit u = {0, 0, 0};
+            if (act) u = eigj_load_unit(t, units, a + b0 + W.b);
+            eigj_pass<KU>(W, t, c, st, act, u.n, u.fc, u.nc);
         }
         __syncthreads();
+    }
+}
+
+// Messages of the tips.  An observed tip (one allowed state s) has the unit vector as its bottom-up vector, so its
+// message is column s of P -- k FMAs per lane instead of k^2, against row s of the transposed Ainv in LDS (the tips of
+// a wave differ in s, so this operand cannot come through SGPRs) -- and the arg-max table has a closed form (numpy's
+// first maximum of (.., 0, P[i][s], 0, ..)).  A pass that holds a tip with several allowed states runs the general pass.
+template <int KU>
+__global__ void PML_EIGJ_ATTR eigen_joint_tips_kernel(PmlTree t, PmlCols c, PmlModel m, PmlState st,
+                                                      const double* __restrict__ ainvT,
+                                                      const int* __restrict__ tip_ids, int n_tips) {
+    constexpr int AS = PML_EIGJ_ASTRIDE(KU);
+    __shared__ double smem[PML_EIGJ_LDS(KU) + 32 * AS];
+    EigJWave<KU> W;
+    eigj_wave_init<KU>(W, t, c, m, ainvT, smem);
+    const int k = W.k, ks = W.ks, i = W.i;
+    const size_t colN = W.colN;
+    double* sT = smem + PML_EIGJ_LDS(KU);  // sT[j * AS + m] = Ainv[m][j]
+    {
+        const double* g = ainvT + (size_t)W.col * PML_EIGJ_STRIDE * PML_EIGJ_STRIDE;
+        for (int e = threadIdx.x; e < k * AS; e += blockDim.x) {
+            const int r = e / AS, q = e % AS;
+            sT[e] = q < KU ? g[r * PML_EIGJ_STRIDE + q] : 0.0;
+        }
+    }
+    __syncthreads();
+    const u64 kbits = k >= 64 ? ~0ull : (1ull << k) - 1ull;
+    const int wave = threadIdx.x >> 6;
+    const int waves_total = gridDim.x * PML_WAVES_PER_BLOCK;
+    const int slot = W.b * KU;
+    // software pipeline over the passes of the wave: the tip id is requested two passes ahead, its mask word and
+    // branch length one pass ahead -- a pass never waits for the two dependent round trips to memory
+    const int stride = waves_total * W.npw;
+    const int first = (blockIdx.x * PML_WAVES_PER_BLOCK + wave) * W.npw;
+    auto tip_of = [&](int b0) { return (W.lane_ok && b0 + W.b < n_tips) ? tip_ids[b0 + W.b] : -1; };
+    int tip_n1 = tip_of(first), tip_n2 = tip_of(first + stride);
+    u64 word_n1 = 0ull;
+    double dist_n1 = 0.0;
+    if (tip_n1 >= 0) {
+        word_n1 = c.masks[colN + tip_n1];
+        dist_n1 = t.dist[tip_n1];
+    }
+    for (int b0 = first; b0 < n_tips; b0 += stride) {
+        const int tip_c = tip_n1;
+        const u64 word_c = word_n1;
+        const double dist_c = dist_n1;
+        tip_n1 = tip_n2;
+        tip_n2 = tip_of(b0 + 2 * stride);
+        word_n1 = 0ull;
+        dist_n1 = 0.0;
+        if (tip_n1 >= 0) {
+            word_n1 = c.masks[colN + tip_n1];
+            dist_n1 = t.dist[tip_n1];
+        }
+        const bool act = tip_c >= 0;
+        const int tip = act ? tip_c : 0;
+        const u64 word = word_c & kbits;
+        const double tq = act ? (dist_c + W.tau) * W.tf * W.sfc : 0.0;
+        if (!__all(!act || __popcll(word) == 1)) {
+            eigj_pass<KU>(W, t, c, st, act, tip, 0, 0);
+            continue;
+        }
+        const int s_own = act ? __builtin_ctzll(word) : 0;
+        if (W.lane_ok) W.sE[slot + i] = exp(W.d_i * tq);
+        wave_lds_sync();
+        const double* row_s = sT + s_own * AS;
+        double p = (W.sA[0] * W.sE[slot]) * row_s[0];
+#pragma unroll
+        for (int mm = 1; mm < KU; ++mm) p = __builtin_fma(W.sA[mm] * W.sE[slot + mm], row_s[mm], p);
+        if (act) {
+            const size_t row = (colN + tip) * ks;
+            double pv = p;
+            int arg;
+            if (pv > 0.0) {
+                arg = s_own;
+            } else if (s_own != 0) {
+                pv = 0.0;
+                arg = 0;
+            } else if (pv == 0.0 || k == 1) {
+                arg = 0;
+            } else {
+                pv = 0.0;
+                arg = 1;
+            }
+            if (c.masks_init != nullptr) {
+                const u64 mi = c.masks_init[colN + tip], mc = c.masks[colN + tip];
+                if (mi != mc && !((mi >> arg) & 1ull)) arg = mi ? __builtin_ctzll(mi) : 0;
+            }
+            st.msg[row + i] = pv;
+            st.J[row + i] = (pml_jt)arg;
+            if (i == k - 1)
+                for (int q = k; q < ks; ++q) {
+                    st.msg[row + q] = 0.0;
+                    st.J[row + q] = (pml_jt)0;
+                }
+        }
+        wave_lds_sync();
     }
 }
