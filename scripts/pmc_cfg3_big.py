@@ -30,7 +30,14 @@ for part in 'abc':
     out['grid_' + part] = best['grid']
 for k, v in out.items():
     print('%-28s %14.4g' % (k, v))
-if 'SQ_INSTS_MFMA' in out:
+if out.get('SQ_INSTS_MFMA'):
     print('VALU per MFMA %.1f, SALU per MFMA %.1f, LDS per MFMA %.2f' % (
         out['SQ_INSTS_VALU'] / out['SQ_INSTS_MFMA'], out['SQ_INSTS_SALU'] / out['SQ_INSTS_MFMA'],
         out['SQ_INSTS_LDS'] / out['SQ_INSTS_MFMA']))
+
+if 'SQ_ACTIVE_INST_VALU' in out and 'SQ_BUSY_CYCLES' in out:
+    # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the SIMDs (1024); SQ_BUSY_CYCLES cycles summed over 32 SEs
+    cycles = out['SQ_BUSY_CYCLES'] / 32
+    print('kernel cycles %.0f (%.2f GHz); VALU busy %.3f of the SIMD cycles; MFMA busy %.3f; waves per SIMD %.2f' % (
+        cycles, cycles / out['duration_us_max'] / 1e3, out['SQ_ACTIVE_INST_VALU'] * 4 / 1024 / cycles,
+        out.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / 1024 / cycles, out['SQ_WAVE_CYCLES'] * 4 / 1024 / cycles))
