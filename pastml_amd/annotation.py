@@ -103,10 +103,15 @@ def annotation_columns(flat, df):
     out = {}
     for c in df.columns:
         col = df[c].to_numpy()
-        present = np.array([v != '' and not pd.isnull(v) for v in col], dtype=bool) if col.dtype == object \
-            else ~pd.isnull(col)
-        values, inverse = np.unique(col[present].astype(object) if col.dtype != object else col[present],
-                                    return_inverse=True) if present.any() else (np.zeros(0, dtype=object), np.zeros(0, int))
+        present = ~pd.isnull(col)
+        if col.dtype == object:
+            present &= np.asarray(col != '', dtype=bool)
+        if present.any():
+            # hash-based codes, distinct values in sorted order (what np.unique gives, without sorting every cell)
+            inverse, values = pd.factorize(col[present], sort=True)
+            values = np.asarray(values, dtype=object)
+        else:
+            values, inverse = np.zeros(0, dtype=object), np.zeros(0, int)
         code_of_row = np.full(len(col), -1, dtype=np.int64)
         code_of_row[present] = inverse
         codes = np.full(N, -2, dtype=np.int64)

@@ -714,6 +714,18 @@ def optimise_group(batch, tasks, seeds=None):
     return lnl, server.rounds
 
 
+def count_scenarios(sizes):
+    """
+    Product of the numbers of states kept per node (ml.py:567-568), as an exact integer.  As powers per distinct size:
+    the node-by-node product of the reference multiplies an ever longer integer N times (seconds at 10^5 nodes).
+    """
+    values, counts = np.unique(np.asarray(sizes)[np.asarray(sizes) > 1], return_counts=True)
+    scenarios = 1
+    for value, count in zip(values.tolist(), counts.tolist()):
+        scenarios *= value ** count
+    return scenarios
+
+
 def reconstruct(batch, tasks, lnl, force_joint=True):
     """
     Everything of pastml/ml.py:640-750 after the parameters are known, for all characters of the batch at once (they
@@ -808,9 +820,7 @@ def reconstruct(batch, tasks, lnl, force_joint=True):
                 kept = batch.select('MPPA', force_joint=force_joint)
                 for c, t in enumerate(tasks):
                     n_nodes = t.model.forest_stats.num_nodes
-                    scenarios = 1
-                    for n_kept in kept[c][kept[c] > 1].tolist():
-                        scenarios *= n_kept
+                    scenarios = count_scenarios(kept[c])
                     unresolved = int((kept[c] > 1).sum())
                     per_node = int(kept[c].sum()) / n_nodes
                     current[c].update({NUM_SCENARIOS: scenarios, NUM_UNRESOLVED_NODES: unresolved,

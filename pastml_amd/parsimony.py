@@ -164,7 +164,7 @@ def parsimonious_acr(forest, character, prediction_method, states, num_nodes, nu
     Parsimonious states on the trees, stored as the node feature ``character`` (``character_<METHOD>`` for the
     meta-method MP); returns the list of result dictionaries (pastml/parsimony.py:249-333).
     """
-    from pastml_amd.batch import annotation_words, masks_from_words, words_from_masks
+    from pastml_amd.batch import annotation_words, masks_from_words, words_from_masks, count_scenarios
     from pastml_amd.tree import TreeNode, get_flat_forest, StateSetColumn
     if isinstance(forest, TreeNode):
         forest = [forest]
@@ -184,9 +184,7 @@ def parsimonious_acr(forest, character, prediction_method, states, num_nodes, nu
         name = character if prediction_method == method else get_personalized_feature_name(character, method)
         flat.set_column(name, StateSetColumn(words_from_masks(sets, k), states))
         sizes = sets.sum(axis=1)
-        scenarios = 1
-        for n_states in sizes[sizes > 1].tolist():
-            scenarios *= n_states
+        scenarios = count_scenarios(sizes)
         res = result.copy()
         res[NUM_SCENARIOS] = scenarios
         res[NUM_UNRESOLVED_NODES] = int((sizes > 1).sum())
