@@ -25,6 +25,7 @@ typedef const __attribute__((address_space(4))) double* pml_const_f64;
 // rows of A in LDS: 16-byte aligned, and a stride that is not a multiple of 64 bytes so that the rows of the states
 // of a node start in different banks
 #define PML_EIGJ_ASTRIDE(KU) ((KU) + 2)
+#define PML_EIGJ_CHUNK_LDS 160                 // doubles per wave: 64 x (branch length, mask word, node id)
 #define PML_EIGJ_LDS(KU) (PML_WAVES_PER_BLOCK * 2 * PML_EIGJ_WAVE_LDS + 32 * PML_EIGJ_ASTRIDE(KU))
 
 template <int KU>
@@ -248,7 +249,7 @@ __global__ void PML_EIGJ_ATTR eigen_joint_tips_kernel(PmlTree t, PmlCols c, PmlM
                                                       const double* __restrict__ ainvT,
                                                       const int* __restrict__ tip_ids, int n_tips) {
     constexpr int AS = PML_EIGJ_ASTRIDE(KU);
-    __shared__ double smem[PML_EIGJ_LDS(KU) + 32 * AS];
+    __shared__ double smem[PML_EIGJ_LDS(KU) + 32 * AS + PML_WAVES_PER_BLOCK * PML_EIGJ_CHUNK_LDS];
     EigJWave<KU> W;
     eigj_wave_init<KU>(W, t, c, m, ainvT, smem);
     const int k = W.k, ks = W.ks, i = W.i;
@@ -266,34 +267,41 @@ __global__ void PML_EIGJ_ATTR eigen_joint_tips_kernel(PmlTree t, PmlCols c, PmlM
     const int wave = threadIdx.x >> 6;
     const int waves_total = gridDim.x * PML_WAVES_PER_BLOCK;
     const int slot = W.b * KU;
-    // software pipeline over the passes of the wave: the tip id is requested two passes ahead, its mask word and
-    // branch length one pass ahead -- a pass never waits for the two dependent round trips to memory
-    const int stride = waves_total * W.npw;
-    const int first = (blockIdx.x * PML_WAVES_PER_BLOCK + wave) * W.npw;
-    auto tip_of = [&](int b0) { return (W.lane_ok && b0 + W.b < n_tips) ? tip_ids[b0 + W.b] : -1; };
-    int tip_n1 = tip_of(first), tip_n2 = tip_of(first + stride);
-    u64 word_n1 = 0ull;
-    double dist_n1 = 0.0;
-    if (tip_n1 >= 0) {
-        word_n1 = c.masks[colN + tip_n1];
-        dist_n1 = t.dist[tip_n1];
-    }
-    for (int b0 = first; b0 < n_tips; b0 += stride) {
-        const int tip_c = tip_n1;
-        const u64 word_c = word_n1;
-        const double dist_c = dist_n1;
-        tip_n1 = tip_n2;
-        tip_n2 = tip_of(b0 + 2 * stride);
-        word_n1 = 0ull;
-        dist_n1 = 0.0;
-        if (tip_n1 >= 0) {
-            word_n1 = c.masks[colN + tip_n1];
-            dist_n1 = t.dist[tip_n1];
+    // The tips of a wave come in chunks: lane L fetches the id, mask word and branch length of tip c0 + L -- up to 64
+    // tips per round trip to memory instead of the 64 / k of one pass -- and leaves them in LDS, from where the
+    // passes over the chunk read them.  A chunk holds the passes a wave has to make anyway when the tips are spread
+    // over all waves (at most 64 / npw of them).
+    const int lane = threadIdx.x & 63;
+    const int npw = W.npw;
+    const int passes_total = (n_tips + npw - 1) / npw;
+    int cp = (passes_total + waves_total - 1) / waves_total;
+    if (cp > 64 / npw) cp = 64 / npw;
+    const int chunk = cp * npw;
+    double* sTq = smem + PML_EIGJ_LDS(KU) + 32 * AS + wave * PML_EIGJ_CHUNK_LDS;
+    u64* sWord = reinterpret_cast<u64*>(sTq + 64);
+    int* sTip = reinterpret_cast<int*>(sWord + 64);
+    for (int c0 = (blockIdx.x * PML_WAVES_PER_BLOCK + wave) * chunk; c0 < n_tips; c0 += waves_total * chunk) {
+        {
+            int tip_l = -1;
+            u64 word_l = 0ull;
+            double tq_l = 0.0;
+            if (lane < chunk && c0 + lane < n_tips) {
+                tip_l = tip_ids[c0 + lane];
+                word_l = c.masks[colN + tip_l] & kbits;
+                tq_l = (t.dist[tip_l] + W.tau) * W.tf * W.sfc;
+            }
+            sTip[lane] = tip_l;
+            sWord[lane] = word_l;
+            sTq[lane] = tq_l;
         }
+        wave_lds_sync();
+        for (int ps = 0; ps < cp && c0 + ps * npw < n_tips; ++ps) {
+        const int sq = ps * npw + W.b;
+        const int tip_c = W.lane_ok ? sTip[sq] : -1;
         const bool act = tip_c >= 0;
         const int tip = act ? tip_c : 0;
-        const u64 word = word_c & kbits;
-        const double tq = act ? (dist_c + W.tau) * W.tf * W.sfc : 0.0;
+        const u64 word = act ? sWord[sq] : 0ull;
+        const double tq = act ? sTq[sq] : 0.0;
         if (!__all(!act || __popcll(word) == 1)) {
             eigj_pass<KU>(W, t, c, st, act, tip, 0, 0);
             continue;
@@ -333,5 +341,7 @@ __global__ void PML_EIGJ_ATTR eigen_joint_tips_kernel(PmlTree t, PmlCols c, PmlM
                 }
         }
         wave_lds_sync();
+        }
+        wave_lds_sync();  // the chunk has been consumed before the next one overwrites it
     }
 }
