@@ -3,7 +3,7 @@
 //
 // The joint sweep needs every entry of P(t_n) -- msg_n[i] = max_j P[i][j] v_n[j] and its arg-max -- so P cannot be
 // avoided the way the sum sweeps avoid it (pml_kernels_eigen_gemm.h).  What can be chosen is where its 2 k^3 flops per
-// node run.  Measured on MI355X (scratch/ub/overlap.hip): v_mfma_f64_16x16x4_f64 and v_fma_f64
+// node run.  Measured on MI355X (scripts/ub/overlap.hip): v_mfma_f64_16x16x4_f64 and v_fma_f64
 // deliver the same 32 flop / clock / SIMD, and they do not overlap -- a wave's FP64 MFMAs and the vector instructions
 // of every wave of the SIMD add up.  The matrix cores therefore buy nothing for FP64 but their tile shape, and the
 // tile shape costs: k = 20 pads to 32 columns (62 % useful), the products of a tile land spread over lanes and
