@@ -320,7 +320,7 @@ def secondary_measurements(device):
         ms_marginal = timed(lambda: eng.marginal_pass(posterior=False, lh=False), 20, eng)
         # P(t) = A diag(exp(d t)) A^-1 per branch.  The kernels execute less: an observed tip needs one
         # column of P (2 k^2 flops).  FP64 peak: 78.6 TFLOP/s on the matrix cores AND on the vector units (measured
-        # equal, and not additive: scripts/ub/overlap.hip) -- the joint sweep runs on the vector units.
+        # equal, and the two do not run concurrently: scripts/ub/overlap.hip) -- the joint sweep runs on the vector units.
         flops = 2.0 * k ** 3 * (flat.n_nodes - 1)
         # compulsory bytes of the fused sweep: message (8 k) written + read per non-root node, arg-max row (k bytes),
         # mask word, branch length, exponent
