@@ -7,6 +7,8 @@ Tolerances.  north_star asks for 1e-6 relative on posteriors and log-likelihoods
 1e-9 relative on posteriors, 2e-10 in log10 units (5e-10 relative) on every likelihood vector entry and 1e-11 relative
 on log-likelihoods.  Integer outputs (arg-max tables, joint states, selected states) must be identical.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -17,6 +19,7 @@ from pastml_amd.tree import FlatForest
 
 pytestmark = pytest.mark.gpu
 
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LOG10_ATOL = 2e-10
 POST_RTOL = 1e-9
 LNL_RTOL = 1e-11
@@ -801,3 +804,87 @@ def test_block_schedule_gives_the_bits_of_the_level_schedule(k, monkeypatch):
         for other in results[1:]:
             for a, b in zip(results[0], other):
                 assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize('k', [3, 11, 20, 32])
+def test_eigen_joint_sweep_wide_polytomies_and_deep_trees(k):
+    """
+    The vector-unit joint sweep of the eigen models (pml_kernels_eigen_joint.h) where its shortcuts end: nodes with
+    more than 14 children (the unit descriptor counts up to 14, the kernel reads the true number), unobserved and
+    ambiguous tips (the general pass instead of the one-column closed form), several columns, and a caterpillar deep
+    enough to drive the products out of the rescaling band.  ln L, tables and states against the oracle.
+    """
+    rng = np.random.default_rng(300 + k)
+    wide = FlatForest.random(150, seed=70 + k, max_arity=24)
+    assert wide.n_children.max() > 14
+    from pastml_amd.tree import TreeNode
+    root = TreeNode(name='r', dist=0.0)
+    cur = root
+    for d in range(700):   # every level multiplies by a tip's message (<= max P ~ 0.1-0.5): far below 2^-200 in total
+        cur.add_child(name='t{}'.format(d), dist=0.8)
+        cur = cur.add_child(name='i{}'.format(d), dist=0.05)
+    cur.add_child(name='ta', dist=0.1)
+    cur.add_child(name='tb', dist=0.1)
+    deep = FlatForest.from_trees([root])
+    for flat in (wide, deep):
+        C = 2
+        specs = [random_spec('EIGEN', k, rng) for _ in range(C)]
+        rates = [(float(rng.uniform(0.5, 3)), 0.0, 1.0), (1.0, 0.02, 0.9)]
+        masks = np.stack([random_masks(flat, k, rng, missing=0.1, multi=0.1, internal=0.03) for _ in range(C)])
+        with hip.Engine(flat, C, k) as eng:
+            eng.set_models(list(zip(specs, rates)))
+            eng.set_masks(masks)
+            lnl_j = eng.bottom_up(False)
+            tables = [eng.download(hip.BUF_JOINT_TABLE, c) for c in range(C)]
+            states = eng.joint_backtrace()
+        nonroot = flat.parent >= 0
+        for c in range(C):
+            j = orc.bottom_up(flat, masks[c].astype(int), specs[c], *rates[c], is_marginal=False)
+            np.testing.assert_allclose(lnl_j[c], j['loglik'], rtol=LNL_RTOL, atol=1e-12)
+            flips = 0
+            for n, i in np.argwhere(tables[c] != j['joint_table']):
+                if not nonroot[n]:
+                    continue
+                prod = orc.pij(specs[c], flat.dist[n], *rates[c])[i] * j['bu'][n]
+                assert abs(prod[tables[c][n, i]] - prod.max()) <= 1e-12 * prod.max()
+                flips += 1
+            if flips == 0:
+                assert np.array_equal(states[c], orc.joint_backtrace(flat, j['bu'], j['joint_table'], specs[c]['pi']))
+
+
+@pytest.mark.parametrize('k', [5, 20])
+def test_eigen_joint_vector_and_matrix_core_sweeps_agree(k, monkeypatch):
+    """Both joint sweeps of the eigen models (vector FMAs; materialised / matrix-core P) give the same ln L to rounding
+    and the same reconstruction on a random forest."""
+    import subprocess
+    import sys
+    import json
+    code = '''
+import json, sys
+import numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})
+from pastml_amd import hip
+from pastml_amd.tree import FlatForest
+from test_gpu_parity import random_spec, random_masks
+k = {k}
+rng = np.random.default_rng(77)
+flat = FlatForest.random(300, seed=9, max_arity=5, n_trees=2)
+spec = random_spec('EIGEN', k, rng)
+masks = random_masks(flat, k, rng)
+with hip.Engine(flat, 1, k) as eng:
+    eng.set_models([(spec, (1.3, 0.0, 1.0))])
+    eng.set_masks(masks[None])
+    lnl = eng.bottom_up(False)
+    states = eng.joint_backtrace()
+print(json.dumps(dict(lnl=float(lnl[0]), states=states[0].tolist())))
+'''.format(root=REPO, tests=os.path.dirname(os.path.abspath(__file__)), k=k)
+    out = []
+    for off in (False, True):
+        env = dict(os.environ)
+        if off:
+            env['PASTML_HIP_NO_EIGEN_JOINT_VALU'] = '1'
+        res = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stderr[-2000:]
+        out.append(json.loads(res.stdout.strip().splitlines()[-1]))
+    np.testing.assert_allclose(out[0]['lnl'], out[1]['lnl'], rtol=1e-12)
+    assert out[0]['states'] == out[1]['states']
