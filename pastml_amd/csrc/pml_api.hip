@@ -93,6 +93,7 @@ struct pml_ctx {
     bool levels_fit_workgroup = false;  // (nearly) every fused level is one pass of a 512-thread workgroup
     std::vector<int> bu_offsets_f, td_parent_offsets_f;
     std::vector<char> bu_level_vec_f;  // per fused bottom-up level: some unit has a stored node as child 0 or 1
+    std::vector<int> td_cherry_prefix; // over the fused top-down units: how many before it have a cherry as child 0 or 1
     std::vector<char> bu_level_vec;    // the same for the plain levels (joint sweep: every internal node is stored)
     int n_cherries = 0;
     bool bu_fused = false;  // the last bottom-up sweep left the cherries unmaterialised
@@ -415,9 +416,23 @@ static void launch_sweep_f81(pml_ctx* ctx, SweepKind what, const int* level, int
             hipLaunchKernelGGL((bu_f81_kernel<G, R, true, false>), grid, block, 0, ctx->stream, t, c, st, units,
                                n_level);
             break;
-        case SW_TD_FUSED:
-            hipLaunchKernelGGL((td_f81_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, units, n_level);
+        case SW_TD_FUSED: {
+            // units narrower than 8 lanes stage their posterior rows in LDS (pml_kernels_f81.h, post_row): 2 rows per
+            // unit, 6 on levels with cherry children (their tips)
+            static const bool no_stage = getenv("PASTML_HIP_NO_TD_STAGE") != nullptr;
+            int rows = 0;
+            if (G < 8 && !no_stage && (c.ks & 1) == 0) {
+                rows = 6;
+                if (ctx->units_override == nullptr && !ctx->td_cherry_prefix.empty()) {
+                    const size_t a = (size_t)(level - ctx->d_td_parents_f), b = a + (size_t)n_level;
+                    if (b < ctx->td_cherry_prefix.size() && ctx->td_cherry_prefix[b] == ctx->td_cherry_prefix[a]) rows = 2;
+                }
+            }
+            const int n_slots = (64 / G) * rows;
+            const size_t lds = (size_t)PML_WAVES_PER_BLOCK * ((size_t)n_slots * c.ks + ((n_slots + 1) >> 1)) * sizeof(double);
+            hipLaunchKernelGGL((td_f81_kernel<G, R>), grid, block, lds, ctx->stream, t, c, st, units, n_level, rows);
             break;
+        }
         case SW_ROOTS:
             hipLaunchKernelGGL((td_f81_roots_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st);
             break;
@@ -1138,6 +1153,11 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
                     if (((pk >> 8) & 7) == 1 || ((pk >> 11) & 7) == 1) ctx->bu_level_vec_f[l] = 1;
                 }
             describe(tdp.data(), n_stored, true, ut_f);
+            ctx->td_cherry_prefix.assign(n_stored + 1, 0);
+            for (int q = 0; q < n_stored; ++q) {
+                const int pk = ut_f[q].packed;
+                ctx->td_cherry_prefix[q + 1] = ctx->td_cherry_prefix[q] + ((((pk >> 8) & 7) >= 2 || ((pk >> 11) & 7) >= 2) ? 1 : 0);
+            }
             describe(bu_order, n_internal, false, ub);
             ctx->bu_level_vec.assign(n_bu_levels > 0 ? n_bu_levels : 1, 0);
             for (int l = 0; l < n_bu_levels; ++l)

@@ -92,6 +92,13 @@ f81_prep_kernel(PmlTree t, PmlCols c, const double* __restrict__ mu, const doubl
 //
 // State ownership ("chunked"): a lane owns R states, in R/2 pairs; pair q of lane g is states q*2G + 2g, +1.  So for
 // every q the G lanes of a unit read one contiguous run of 2G doubles with 16-byte lane loads (R = 1: state g).
+// orders a wave's LDS traffic (write by some lanes, read by others) without a workgroup barrier
+__device__ __forceinline__ void wave_sync_lds() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <int G, int R>
 struct LaneCtx {
     int col, g, group_base, k;
@@ -108,6 +115,11 @@ struct LaneCtx {
     double* post;
     double* lhsum;
     i64* lhe;
+    // top-down level kernel, units narrower than 8 lanes: posterior rows of the unit are staged in LDS (slots of
+    // c.ks doubles, node ids beside them) and written out by the whole wave in address order (td_stage_flush)
+    double* srow;
+    int* sid;
+    int srows;
     __device__ __forceinline__ int st(int r) const { return R == 1 ? g : ((r >> 1) * 2 * G + 2 * g + (r & 1)); }
 };
 
@@ -131,6 +143,9 @@ __device__ __forceinline__ void lane_ctx_init(LaneCtx<G, R>& L, const PmlTree& t
     L.post = st.post + colN * c.ks;
     L.lhsum = st.lhsum + colN;
     L.lhe = st.lhe + colN;
+    L.srow = nullptr;
+    L.sid = nullptr;
+    L.srows = 0;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         L.pi_r[r] = (L.st(r) < c.k) ? c.pi[(size_t)L.col * c.ks + L.st(r)] : 0.0;
@@ -271,6 +286,34 @@ __device__ __forceinline__ void node_store_vec(const LaneCtx<G, R>& L, const Pml
                 *reinterpret_cast<double2*>(p + L.st(r)) = t2;
             }
         }
+    }
+}
+
+// Posterior row of `node`: into the unit's staging slot when the kernel stages (slot >= 0 and within the unit's
+// slots), straight to memory otherwise.  Why staged: one lane per unit writes 16-byte pieces of different rows per
+// store instruction (64 - 128 bytes apart) and reaches 3.5 TB/s; the same bytes written by the wave in address order,
+// every instruction covering 1 KB, reach 6.7 (scratch/ub/wr2.hip).
+template <int G, int R>
+__device__ __forceinline__ void post_row(const LaneCtx<G, R>& L, const PmlCols& c, int slot, int node,
+                                         const double (&v)[R]) {
+    if (G < 8 && L.srow != nullptr && slot >= 0 && slot < L.srows) {
+        double* p = L.srow + slot * c.ks;
+        if (R == 1) {
+            if (L.st(0) < c.ks) p[L.st(0)] = v[0];
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; r += 2) {
+                if (L.st(r) < c.ks) {
+                    double2 t2;
+                    t2.x = v[r];
+                    t2.y = v[r + 1];
+                    *reinterpret_cast<double2*>(p + L.st(r)) = t2;
+                }
+            }
+        }
+        if (L.g == 0) L.sid[slot] = node;
+    } else {
+        node_store_vec_nt<G, R>(L, c, L.post, node, v);
     }
 }
 
@@ -885,7 +928,8 @@ template <int G, int R>
 __device__ __forceinline__ void f81_finish_child(const LaneCtx<G, R>& L, const PmlCols& c, const double (&prod)[R],
                                                  i64 pe, int ch, double e, double s_child, i64 bec,
                                                  const double (&v)[R], bool full_mask, const double (&mb)[R],
-                                                 double (&tdc)[R], i64& xe, double (&lh)[R], double& lsum, i64& le) {
+                                                 double (&tdc)[R], i64& xe, double (&lh)[R], double& lsum, i64& le,
+                                                 int slot = -1) {
     const double a = (1.0 - e) * s_child;
     double x[R];
 #pragma unroll
@@ -921,7 +965,7 @@ __device__ __forceinline__ void f81_finish_child(const LaneCtx<G, R>& L, const P
         const double q = lh[r] * inv;
         lh[r] = fma(fma(-lhs, q, lh[r]), inv, q);
     }
-    node_store_vec_nt<G, R>(L, c, L.post, ch, lh);
+    post_row<G, R>(L, c, slot, ch, lh);
     lsum = __builtin_ldexp(lhs, -lex);
     le = xe + bec + lex;
     if (L.g == 0) {
@@ -939,7 +983,7 @@ __device__ __forceinline__ void f81_finish_child(const LaneCtx<G, R>& L, const P
 template <int G, int R>
 __device__ __forceinline__ void f81_finish_tip_word(const LaneCtx<G, R>& L, const PmlCols& c, const double (&prod)[R],
                                                     i64 pe, double& P, bool& have_P, int tip, u64 word, double e,
-                                                    double pis) {
+                                                    double pis, int slot = -1) {
     if (__popcll(word) == 1) {
         if (!have_P) {
             P = pi_dot<G, R>(L, prod);
@@ -966,7 +1010,7 @@ __device__ __forceinline__ void f81_finish_tip_word(const LaneCtx<G, R>& L, cons
 #pragma unroll
             for (int r = 0; r < R; ++r) oh[r] = __builtin_nan("");
         }
-        node_store_vec_nt<G, R>(L, c, L.post, tip, oh);
+        post_row<G, R>(L, c, slot, tip, oh);
         if (L.g == 0) {
             L.lhsum[tip] = __builtin_ldexp(lhs, -lex);
             L.lhe[tip] = pe + lex;
@@ -975,7 +1019,7 @@ __device__ __forceinline__ void f81_finish_tip_word(const LaneCtx<G, R>& L, cons
         double mt[R], tdt[R], pt[R], lt;
         clean_word_to_vec<G, R>(L, c, word, mt);
         i64 xt, et;
-        f81_finish_child<G, R>(L, c, prod, pe, tip, e, pis, 0, mt, false, mt, tdt, xt, pt, lt, et);
+        f81_finish_child<G, R>(L, c, prod, pe, tip, e, pis, 0, mt, false, mt, tdt, xt, pt, lt, et, slot);
     }
 }
 
@@ -986,17 +1030,18 @@ __device__ __forceinline__ void f81_finish_tip_word(const LaneCtx<G, R>& L, cons
 // posterior is exactly the unit vector (what lh / lh.sum() gives in the reference, ml.py:500).
 template <int G, int R>
 __device__ __forceinline__ void f81_finish_tip(const LaneCtx<G, R>& L, const PmlCols& c, const double (&prod)[R], i64 pe,
-                                               double& P, bool& have_P, int tip) {
+                                               double& P, bool& have_P, int tip, int slot = -1) {
     const double e = L.E[tip];
     const double pis = L.S[tip];
     if (c.W == 1) {
-        f81_finish_tip_word<G, R>(L, c, prod, pe, P, have_P, tip, L.mask[(unsigned)tip] & state_bits(c.k), e, pis);
+        f81_finish_tip_word<G, R>(L, c, prod, pe, P, have_P, tip, L.mask[(unsigned)tip] & state_bits(c.k), e, pis,
+                                  slot);
     } else {
         // k > 64: general path (the closed form above would need the state's word; not worth a special case)
         double mt[R], tdt[R], pt[R], lt;
         node_mask_vec<G, R>(L, c, tip, mt);
         i64 xt, et;
-        f81_finish_child<G, R>(L, c, prod, pe, tip, e, pis, 0, mt, false, mt, tdt, xt, pt, lt, et);
+        f81_finish_child<G, R>(L, c, prod, pe, tip, e, pis, 0, mt, false, mt, tdt, xt, pt, lt, et, slot);
     }
 }
 
@@ -1090,8 +1135,9 @@ __device__ __forceinline__ void td_f81_unit(const LaneCtx<G, R>& L, const PmlTre
     for (int j = 0; j < nc; ++j) {
         const int ch = fc + j;
         const int kd = node_kind(t, ch);
+        const int slot = j < 2 ? j : -1;  // staging slots: children 0 and 1, then two tips of each if it is a cherry
         if (kd == PML_KIND_TIP) {
-            f81_finish_tip<G, R>(L, c, prod, pe, P, have_P, ch);
+            f81_finish_tip<G, R>(L, c, prod, pe, P, have_P, ch, slot);
             continue;
         }
         const double e = L.E[ch];
@@ -1100,7 +1146,7 @@ __device__ __forceinline__ void td_f81_unit(const LaneCtx<G, R>& L, const PmlTre
         i64 xe, le;
         if (kd == PML_KIND_STORED) {
             node_load_vec<G, R>(L, c, L.bu, ch, v);
-            f81_finish_child<G, R>(L, c, prod, pe, ch, e, L.S[ch], L.be[ch], v, false, mb, tdc, xe, po, ls, le);
+            f81_finish_child<G, R>(L, c, prod, pe, ch, e, L.S[ch], L.be[ch], v, false, mb, tdc, xe, po, ls, le, slot);
             if (st.td != nullptr) {
                 node_store_vec<G, R>(L, c, L.td, ch, tdc);
                 if (L.g == 0) L.te[ch] = xe;
@@ -1110,7 +1156,7 @@ __device__ __forceinline__ void td_f81_unit(const LaneCtx<G, R>& L, const PmlTre
             i64 bec;
             f81_cherry_vector<G, R>(L, t, c, st, ch, v, bec, false);
             const double s_child = L.S[ch];  // pi . v, stored by the bottom-up sweep
-            f81_finish_child<G, R>(L, c, prod, pe, ch, e, s_child, bec, v, false, mb, tdc, xe, po, ls, le);
+            f81_finish_child<G, R>(L, c, prod, pe, ch, e, s_child, bec, v, false, mb, tdc, xe, po, ls, le, slot);
             double prod2[R];
 #pragma unroll
             for (int r = 0; r < R; ++r) prod2[r] = po[r] * (ls * L.ipi_r[r]);
@@ -1119,19 +1165,58 @@ __device__ __forceinline__ void td_f81_unit(const LaneCtx<G, R>& L, const PmlTre
             bool have_P2 = false;
             const int fc2 = t.first_child[ch];
             const int nc2 = t.n_children[ch];
-            for (int q = 0; q < nc2; ++q) f81_finish_tip<G, R>(L, c, prod2, pe2, P2, have_P2, fc2 + q);
+            for (int q = 0; q < nc2; ++q)
+                f81_finish_tip<G, R>(L, c, prod2, pe2, P2, have_P2, fc2 + q, (j < 2 && q < 2) ? 2 + 2 * j + q : -1);
         }
     }
 }
 
+// The wave writes out the posterior rows its units staged: piece p of the wave's slots (16 bytes) by lane p mod 64, so
+// that consecutive lanes write consecutive memory wherever consecutive units have consecutive children.
+template <int G, int R>
+__device__ __forceinline__ void td_stage_flush(const LaneCtx<G, R>& L, const PmlCols& c, double* wrow, int* wid,
+                                               int n_slots) {
+    typedef double dbl2 __attribute__((ext_vector_type(2)));
+    wave_sync_lds();
+    const int lane = threadIdx.x & 63;
+    const int ppr = c.ks >> 1;  // 16-byte pieces per row (ks is even for k >= 2)
+    const int total = n_slots * ppr;
+    for (int p = lane; p < total; p += 64) {
+        const int slot = p / ppr, piece = p - slot * ppr;
+        const int node = wid[slot];
+        if (node >= 0) {
+            const dbl2 v = *reinterpret_cast<const dbl2*>(wrow + slot * c.ks + 2 * piece);
+            __builtin_nontemporal_store(v, reinterpret_cast<dbl2*>(L.post + (size_t)(unsigned)node * c.ks + 2 * piece));
+        }
+    }
+    wave_sync_lds();
+    for (int e = lane; e < n_slots; e += 64) wid[e] = -1;
+    wave_sync_lds();
+}
+
 template <int G, int R>
 __global__ void __launch_bounds__(PML_BLOCK)
-td_f81_kernel(PmlTree t, PmlCols c, PmlState st, const PmlUnit* __restrict__ units, int n_level) {
+td_f81_kernel(PmlTree t, PmlCols c, PmlState st, const PmlUnit* __restrict__ units, int n_level, int stage_rows) {
+    extern __shared__ double td_stage[];
     constexpr int UW = 64 / G;
     const int wave = threadIdx.x >> 6;
     const int sub = (threadIdx.x & 63) / G;
     LaneCtx<G, R> L;
     lane_ctx_init<G, R>(L, t, c, st);
+    const int n_slots = UW * stage_rows;  // per wave
+    double* wrow = nullptr;
+    int* wid = nullptr;
+    const bool staged = G < 8 && stage_rows > 0 && (c.ks & 1) == 0;
+    if (staged) {
+        const int wave_doubles = n_slots * c.ks + ((n_slots + 1) >> 1);
+        wrow = td_stage + wave * wave_doubles;
+        wid = reinterpret_cast<int*>(wrow + n_slots * c.ks);
+        L.srow = wrow + sub * stage_rows * c.ks;
+        L.sid = wid + sub * stage_rows;
+        L.srows = stage_rows;
+        for (int e = threadIdx.x & 63; e < n_slots; e += 64) wid[e] = -1;
+        wave_sync_lds();
+    }
     const int stride = gridDim.x * PML_WAVES_PER_BLOCK * UW;
     int idx = (blockIdx.x * PML_WAVES_PER_BLOCK + wave) * UW + sub;
     UnitRegs cur = load_unit<G>(units, idx < n_level ? idx : 0, L.g);
@@ -1139,6 +1224,7 @@ td_f81_kernel(PmlTree t, PmlCols c, PmlState st, const PmlUnit* __restrict__ uni
         const int nxt_idx = idx + stride;
         const UnitRegs nxt = load_unit<G>(units, nxt_idx < n_level ? nxt_idx : 0, L.g);
         if (idx < n_level) td_f81_unit<G, R>(L, t, c, st, cur);
+        if (staged) td_stage_flush<G, R>(L, c, wrow, wid, n_slots);
         cur = nxt;
         idx = nxt_idx;
     }
