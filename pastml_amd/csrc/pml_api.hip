@@ -429,7 +429,7 @@ static void launch_sweep_f81(pml_ctx* ctx, SweepKind what, const int* level, int
                 }
             }
             const int n_slots = (64 / G) * rows;
-            const size_t lds = (size_t)PML_WAVES_PER_BLOCK * ((size_t)n_slots * c.ks + ((n_slots + 1) >> 1)) * sizeof(double);
+            const size_t lds = (size_t)PML_WAVES_PER_BLOCK * ((size_t)n_slots * (c.ks + (G == 1 ? 2 : 0)) + ((n_slots + 1) >> 1)) * sizeof(double);
             hipLaunchKernelGGL((td_f81_kernel<G, R>), grid, block, lds, ctx->stream, t, c, st, units, n_level, rows);
             break;
         }

@@ -119,6 +119,8 @@ struct LaneCtx {
     // c.ks doubles, node ids beside them) and written out by the whole wave in address order (td_stage_flush)
     double* srow;
     int* sid;
+    double* ssum;  // staged lhsum / lhe of the same slots
+    i64* sexp;
     int srows;
     __device__ __forceinline__ int st(int r) const { return R == 1 ? g : ((r >> 1) * 2 * G + 2 * g + (r & 1)); }
 };
@@ -145,6 +147,8 @@ __device__ __forceinline__ void lane_ctx_init(LaneCtx<G, R>& L, const PmlTree& t
     L.lhe = st.lhe + colN;
     L.srow = nullptr;
     L.sid = nullptr;
+    L.ssum = nullptr;
+    L.sexp = nullptr;
     L.srows = 0;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -314,6 +318,19 @@ __device__ __forceinline__ void post_row(const LaneCtx<G, R>& L, const PmlCols& 
         if (L.g == 0) L.sid[slot] = node;
     } else {
         node_store_vec_nt<G, R>(L, c, L.post, node, v);
+    }
+}
+
+// the two scalars that go with a posterior row (sum of the marginal likelihoods and its exponent), same staging
+template <int G, int R>
+__device__ __forceinline__ void post_scalars(const LaneCtx<G, R>& L, int slot, int node, double lsum, i64 le) {
+    if (L.g != 0) return;
+    if (G == 1 && L.srow != nullptr && slot >= 0 && slot < L.srows) {  // (measured: a loss with 2 or 4 lanes per unit)
+        L.ssum[slot] = lsum;
+        L.sexp[slot] = le;
+    } else {
+        L.lhsum[node] = lsum;
+        L.lhe[node] = le;
     }
 }
 
@@ -968,10 +985,7 @@ __device__ __forceinline__ void f81_finish_child(const LaneCtx<G, R>& L, const P
     post_row<G, R>(L, c, slot, ch, lh);
     lsum = __builtin_ldexp(lhs, -lex);
     le = xe + bec + lex;
-    if (L.g == 0) {
-        L.lhsum[ch] = lsum;
-        L.lhe[ch] = le;
-    }
+    post_scalars<G, R>(L, slot, ch, lsum, le);
 }
 
 // A tip below a parent with prod = TD_parent o BU_parent.  Observed tips (one allowed state s) in closed form:
@@ -1011,10 +1025,7 @@ __device__ __forceinline__ void f81_finish_tip_word(const LaneCtx<G, R>& L, cons
             for (int r = 0; r < R; ++r) oh[r] = __builtin_nan("");
         }
         post_row<G, R>(L, c, slot, tip, oh);
-        if (L.g == 0) {
-            L.lhsum[tip] = __builtin_ldexp(lhs, -lex);
-            L.lhe[tip] = pe + lex;
-        }
+        post_scalars<G, R>(L, slot, tip, __builtin_ldexp(lhs, -lex), pe + lex);
     } else {
         double mt[R], tdt[R], pt[R], lt;
         clean_word_to_vec<G, R>(L, c, word, mt);
@@ -1175,7 +1186,7 @@ __device__ __forceinline__ void td_f81_unit(const LaneCtx<G, R>& L, const PmlTre
 // that consecutive lanes write consecutive memory wherever consecutive units have consecutive children.
 template <int G, int R>
 __device__ __forceinline__ void td_stage_flush(const LaneCtx<G, R>& L, const PmlCols& c, double* wrow, int* wid,
-                                               int n_slots) {
+                                               double* wsum, i64* wexp, int n_slots) {
     typedef double dbl2 __attribute__((ext_vector_type(2)));
     wave_sync_lds();
     const int lane = threadIdx.x & 63;
@@ -1187,6 +1198,15 @@ __device__ __forceinline__ void td_stage_flush(const LaneCtx<G, R>& L, const Pml
         if (node >= 0) {
             const dbl2 v = *reinterpret_cast<const dbl2*>(wrow + slot * c.ks + 2 * piece);
             __builtin_nontemporal_store(v, reinterpret_cast<dbl2*>(L.post + (size_t)(unsigned)node * c.ks + 2 * piece));
+        }
+    }
+    if (G == 1) {
+        for (int e = lane; e < n_slots; e += 64) {
+            const int node = wid[e];
+            if (node >= 0) {
+                L.lhsum[node] = wsum[e];
+                L.lhe[node] = wexp[e];
+            }
         }
     }
     wave_sync_lds();
@@ -1205,14 +1225,20 @@ td_f81_kernel(PmlTree t, PmlCols c, PmlState st, const PmlUnit* __restrict__ uni
     lane_ctx_init<G, R>(L, t, c, st);
     const int n_slots = UW * stage_rows;  // per wave
     double* wrow = nullptr;
+    double* wsum = nullptr;
+    i64* wexp = nullptr;
     int* wid = nullptr;
     const bool staged = G < 8 && stage_rows > 0 && (c.ks & 1) == 0;
     if (staged) {
-        const int wave_doubles = n_slots * c.ks + ((n_slots + 1) >> 1);
+        const int wave_doubles = n_slots * (c.ks + (G == 1 ? 2 : 0)) + ((n_slots + 1) >> 1);
         wrow = td_stage + wave * wave_doubles;
-        wid = reinterpret_cast<int*>(wrow + n_slots * c.ks);
+        wsum = wrow + n_slots * c.ks;
+        wexp = reinterpret_cast<i64*>(wsum + n_slots);
+        wid = reinterpret_cast<int*>(wsum + (G == 1 ? 2 : 0) * n_slots);
         L.srow = wrow + sub * stage_rows * c.ks;
         L.sid = wid + sub * stage_rows;
+        L.ssum = wsum + sub * stage_rows;
+        L.sexp = wexp + sub * stage_rows;
         L.srows = stage_rows;
         for (int e = threadIdx.x & 63; e < n_slots; e += 64) wid[e] = -1;
         wave_sync_lds();
@@ -1224,7 +1250,7 @@ td_f81_kernel(PmlTree t, PmlCols c, PmlState st, const PmlUnit* __restrict__ uni
         const int nxt_idx = idx + stride;
         const UnitRegs nxt = load_unit<G>(units, nxt_idx < n_level ? nxt_idx : 0, L.g);
         if (idx < n_level) td_f81_unit<G, R>(L, t, c, st, cur);
-        if (staged) td_stage_flush<G, R>(L, c, wrow, wid, n_slots);
+        if (staged) td_stage_flush<G, R>(L, c, wrow, wid, wsum, wexp, n_slots);
         cur = nxt;
         idx = nxt_idx;
     }
