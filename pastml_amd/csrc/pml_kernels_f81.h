@@ -296,7 +296,7 @@ __device__ __forceinline__ void node_store_vec(const LaneCtx<G, R>& L, const Pml
 // Posterior row of `node`: into the unit's staging slot when the kernel stages (slot >= 0 and within the unit's
 // slots), straight to memory otherwise.  Why staged: one lane per unit writes 16-byte pieces of different rows per
 // store instruction (64 - 128 bytes apart) and reaches 3.5 TB/s; the same bytes written by the wave in address order,
-// every instruction covering 1 KB, reach 6.7 (scratch/ub/wr2.hip).
+// every instruction covering 1 KB, reach 6.7 (scripts/ub/wr2.hip).
 template <int G, int R>
 __device__ __forceinline__ void post_row(const LaneCtx<G, R>& L, const PmlCols& c, int slot, int node,
                                          const double (&v)[R]) {
