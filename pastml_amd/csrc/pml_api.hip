@@ -417,20 +417,26 @@ static void launch_sweep_f81(pml_ctx* ctx, SweepKind what, const int* level, int
                                n_level);
             break;
         case SW_TD_FUSED: {
-            // units narrower than 8 lanes stage their posterior rows in LDS (pml_kernels_f81.h, post_row): 2 rows per
-            // unit, 6 on levels with cherry children (their tips)
+            // units narrower than 8 lanes stage their posterior rows in LDS (pml_kernels_f81.h, post_row / post_onehot)
             static const bool no_stage = getenv("PASTML_HIP_NO_TD_STAGE") != nullptr;
-            int rows = 0;
-            if (G < 8 && !no_stage && (c.ks & 1) == 0) {
-                rows = 6;
+            static const int scal_env = getenv("PASTML_HIP_TD_STAGE_SCALARS") ? atoi(getenv("PASTML_HIP_TD_STAGE_SCALARS")) : -1;
+            int stage = 0;
+            size_t lds = 0;
+            // (measured, 262 144 tips x 32 columns: k = 2 0.59 -> 0.39 ms, k = 4 0.68 -> 0.45, k = 8 0.83 -> 0.71; with four
+            // lanes per unit, k = 12 / 16, a loss of 5 - 10 %)
+            if (G <= PML_TD_STAGE_MAX_G && !no_stage && (c.ks & 1) == 0) {
+                const bool scalars = scal_env >= 0 ? scal_env != 0 : true;
+                stage = scalars ? 3 : 1;
+                // bit 2: some unit of the level has a cherry among its first two children (tip slots in use)
+                bool cherries = true;
                 if (ctx->units_override == nullptr && !ctx->td_cherry_prefix.empty()) {
                     const size_t a = (size_t)(level - ctx->d_td_parents_f), b = a + (size_t)n_level;
-                    if (b < ctx->td_cherry_prefix.size() && ctx->td_cherry_prefix[b] == ctx->td_cherry_prefix[a]) rows = 2;
+                    if (b < ctx->td_cherry_prefix.size()) cherries = ctx->td_cherry_prefix[b] != ctx->td_cherry_prefix[a];
                 }
+                if (cherries) stage |= 4;
+                lds = (size_t)PML_WAVES_PER_BLOCK * td_stage_doubles(64 / G, c.ks, scalars) * sizeof(double);
             }
-            const int n_slots = (64 / G) * rows;
-            const size_t lds = (size_t)PML_WAVES_PER_BLOCK * ((size_t)n_slots * (c.ks + (G == 1 ? 2 : 0)) + ((n_slots + 1) >> 1)) * sizeof(double);
-            hipLaunchKernelGGL((td_f81_kernel<G, R>), grid, block, lds, ctx->stream, t, c, st, units, n_level, rows);
+            hipLaunchKernelGGL((td_f81_kernel<G, R>), grid, block, lds, ctx->stream, t, c, st, units, n_level, stage);
             break;
         }
         case SW_ROOTS:

@@ -92,6 +92,10 @@ f81_prep_kernel(PmlTree t, PmlCols c, const double* __restrict__ mu, const doubl
 //
 // State ownership ("chunked"): a lane owns R states, in R/2 pairs; pair q of lane g is states q*2G + 2g, +1.  So for
 // every q the G lanes of a unit read one contiguous run of 2G doubles with 16-byte lane loads (R = 1: state g).
+// widest unit (lanes) whose top-down level kernel stages its posterior rows in LDS (compile-time: the kernels of wider
+// units carry none of that code; four lanes per unit measured 5 - 10 % slower staged, and slower unstaged with the code in)
+#define PML_TD_STAGE_MAX_G 2
+
 // orders a wave's LDS traffic (write by some lanes, read by others) without a workgroup barrier
 __device__ __forceinline__ void wave_sync_lds() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -117,11 +121,14 @@ struct LaneCtx {
     i64* lhe;
     // top-down level kernel, units narrower than 8 lanes: posterior rows of the unit are staged in LDS (slots of
     // c.ks doubles, node ids beside them) and written out by the whole wave in address order (td_stage_flush)
+    // Slots of a unit: 0, 1 = its first two children (rows of c.ks doubles, ids beside them); 2 + 2 j + q = tip q < 2 of
+    // child j < 2 when that is a cherry: an observed tip's posterior is a unit vector, so (id, state) stands for the row.
     double* srow;
     int* sid;
-    double* ssum;  // staged lhsum / lhe of the same slots
+    int* stid;
+    int* stst;
+    double* ssum;  // staged lhsum / lhe of the six slots (null: not staged)
     i64* sexp;
-    int srows;
     __device__ __forceinline__ int st(int r) const { return R == 1 ? g : ((r >> 1) * 2 * G + 2 * g + (r & 1)); }
 };
 
@@ -147,9 +154,10 @@ __device__ __forceinline__ void lane_ctx_init(LaneCtx<G, R>& L, const PmlTree& t
     L.lhe = st.lhe + colN;
     L.srow = nullptr;
     L.sid = nullptr;
+    L.stid = nullptr;
+    L.stst = nullptr;
     L.ssum = nullptr;
     L.sexp = nullptr;
-    L.srows = 0;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         L.pi_r[r] = (L.st(r) < c.k) ? c.pi[(size_t)L.col * c.ks + L.st(r)] : 0.0;
@@ -298,9 +306,9 @@ __device__ __forceinline__ void node_store_vec(const LaneCtx<G, R>& L, const Pml
 // store instruction (64 - 128 bytes apart) and reaches 3.5 TB/s; the same bytes written by the wave in address order,
 // every instruction covering 1 KB, reach 6.7 (scripts/ub/wr2.hip).
 template <int G, int R>
-__device__ __forceinline__ void post_row(const LaneCtx<G, R>& L, const PmlCols& c, int slot, int node,
+__device__ __forceinline__ bool post_row(const LaneCtx<G, R>& L, const PmlCols& c, int slot, int node,
                                          const double (&v)[R]) {
-    if (G < 8 && L.srow != nullptr && slot >= 0 && slot < L.srows) {
+    if (G <= PML_TD_STAGE_MAX_G && L.srow != nullptr && slot >= 0 && slot < 2) {
         double* p = L.srow + slot * c.ks;
         if (R == 1) {
             if (L.st(0) < c.ks) p[L.st(0)] = v[0];
@@ -316,16 +324,34 @@ __device__ __forceinline__ void post_row(const LaneCtx<G, R>& L, const PmlCols& 
             }
         }
         if (L.g == 0) L.sid[slot] = node;
-    } else {
-        node_store_vec_nt<G, R>(L, c, L.post, node, v);
+        return true;
     }
+    node_store_vec_nt<G, R>(L, c, L.post, node, v);
+    return false;
 }
 
-// the two scalars that go with a posterior row (sum of the marginal likelihoods and its exponent), same staging
+// Posterior of an observed tip with state s (the unit vector oh; ok = its likelihood is a positive finite number,
+// otherwise oh holds NaNs and is written as it is): staged as (id, state) in a tip slot.
+template <int G, int R>
+__device__ __forceinline__ bool post_onehot(const LaneCtx<G, R>& L, const PmlCols& c, int slot, int tip, int s,
+                                            const double (&oh)[R], bool ok) {
+    if (G <= PML_TD_STAGE_MAX_G && L.srow != nullptr && slot >= 2 && slot < 6 && ok) {
+        if (L.g == 0) {
+            L.stid[slot - 2] = tip;
+            L.stst[slot - 2] = s;
+        }
+        return true;
+    }
+    node_store_vec_nt<G, R>(L, c, L.post, tip, oh);
+    return false;
+}
+
+// the two scalars that go with a posterior row (sum of the marginal likelihoods and its exponent): staged with it
+// (slot = the row's slot if the row was staged, -1 otherwise)
 template <int G, int R>
 __device__ __forceinline__ void post_scalars(const LaneCtx<G, R>& L, int slot, int node, double lsum, i64 le) {
     if (L.g != 0) return;
-    if (G == 1 && L.srow != nullptr && slot >= 0 && slot < L.srows) {  // (measured: a loss with 2 or 4 lanes per unit)
+    if (G <= PML_TD_STAGE_MAX_G && L.ssum != nullptr && slot >= 0 && slot < 6) {
         L.ssum[slot] = lsum;
         L.sexp[slot] = le;
     } else {
@@ -982,10 +1008,10 @@ __device__ __forceinline__ void f81_finish_child(const LaneCtx<G, R>& L, const P
         const double q = lh[r] * inv;
         lh[r] = fma(fma(-lhs, q, lh[r]), inv, q);
     }
-    post_row<G, R>(L, c, slot, ch, lh);
+    const bool staged = post_row<G, R>(L, c, slot, ch, lh);
     lsum = __builtin_ldexp(lhs, -lex);
     le = xe + bec + lex;
-    post_scalars<G, R>(L, slot, ch, lsum, le);
+    post_scalars<G, R>(L, staged ? slot : -1, ch, lsum, le);
 }
 
 // A tip below a parent with prod = TD_parent o BU_parent.  Observed tips (one allowed state s) in closed form:
@@ -1024,8 +1050,8 @@ __device__ __forceinline__ void f81_finish_tip_word(const LaneCtx<G, R>& L, cons
 #pragma unroll
             for (int r = 0; r < R; ++r) oh[r] = __builtin_nan("");
         }
-        post_row<G, R>(L, c, slot, tip, oh);
-        post_scalars<G, R>(L, slot, tip, __builtin_ldexp(lhs, -lex), pe + lex);
+        const bool staged = post_onehot<G, R>(L, c, slot, tip, (int)__builtin_ctzll(word), oh, ok);
+        post_scalars<G, R>(L, staged ? slot : -1, tip, __builtin_ldexp(lhs, -lex), pe + lex);
     } else {
         double mt[R], tdt[R], pt[R], lt;
         clean_word_to_vec<G, R>(L, c, word, mt);
@@ -1182,65 +1208,101 @@ __device__ __forceinline__ void td_f81_unit(const LaneCtx<G, R>& L, const PmlTre
     }
 }
 
-// The wave writes out the posterior rows its units staged: piece p of the wave's slots (16 bytes) by lane p mod 64, so
-// that consecutive lanes write consecutive memory wherever consecutive units have consecutive children.
+// Staging area of a wave (UW units): rows [UW][2][ks], then (optional) lhsum [UW][6], lhe [UW][6], then the ints: row
+// ids [UW][2], tip ids [UW][4], tip states [UW][4].
+struct TdStage {
+    double* rows;
+    double* sum;
+    i64* exp;
+    int* id;
+    int* tid;
+    int* tst;
+};
+__host__ __device__ __forceinline__ int td_stage_doubles(int uw, int ks, bool scalars) {
+    return uw * 2 * ks + (scalars ? uw * 12 : 0) + uw * 5;  // 10 ints per unit
+}
+
+// The wave writes out what its units staged: piece p (16 bytes) of the wave's slots by lane p mod 64, so that
+// consecutive lanes write consecutive memory wherever consecutive units have consecutive children / tips.
 template <int G, int R>
-__device__ __forceinline__ void td_stage_flush(const LaneCtx<G, R>& L, const PmlCols& c, double* wrow, int* wid,
-                                               double* wsum, i64* wexp, int n_slots) {
+__device__ __forceinline__ void td_stage_flush(const LaneCtx<G, R>& L, const PmlCols& c, const TdStage& S, bool tips) {
     typedef double dbl2 __attribute__((ext_vector_type(2)));
+    constexpr int UW = 64 / G;
     wave_sync_lds();
     const int lane = threadIdx.x & 63;
     const int ppr = c.ks >> 1;  // 16-byte pieces per row (ks is even for k >= 2)
-    const int total = n_slots * ppr;
-    for (int p = lane; p < total; p += 64) {
+    for (int p = lane; p < UW * 2 * ppr; p += 64) {
         const int slot = p / ppr, piece = p - slot * ppr;
-        const int node = wid[slot];
+        const int node = S.id[slot];
         if (node >= 0) {
-            const dbl2 v = *reinterpret_cast<const dbl2*>(wrow + slot * c.ks + 2 * piece);
+            const dbl2 v = *reinterpret_cast<const dbl2*>(S.rows + slot * c.ks + 2 * piece);
             __builtin_nontemporal_store(v, reinterpret_cast<dbl2*>(L.post + (size_t)(unsigned)node * c.ks + 2 * piece));
         }
     }
-    if (G == 1) {
-        for (int e = lane; e < n_slots; e += 64) {
-            const int node = wid[e];
+    for (int p = lane; tips && p < UW * 4 * ppr; p += 64) {
+        const int slot = p / ppr, piece = p - slot * ppr;
+        const int node = S.tid[slot];
+        if (node >= 0) {
+            const int s = S.tst[slot];
+            dbl2 v;
+            v.x = s == 2 * piece ? 1.0 : 0.0;
+            v.y = s == 2 * piece + 1 ? 1.0 : 0.0;
+            __builtin_nontemporal_store(v, reinterpret_cast<dbl2*>(L.post + (size_t)(unsigned)node * c.ks + 2 * piece));
+        }
+    }
+    if (S.sum != nullptr) {
+        for (int e = lane; e < UW * 6; e += 64) {
+            const int u = e / 6, j = e - u * 6;
+            if (j >= 2 && !tips) continue;
+            const int node = j < 2 ? S.id[u * 2 + j] : S.tid[u * 4 + j - 2];
             if (node >= 0) {
-                L.lhsum[node] = wsum[e];
-                L.lhe[node] = wexp[e];
+                L.lhsum[node] = S.sum[e];
+                L.lhe[node] = S.exp[e];
             }
         }
     }
     wave_sync_lds();
-    for (int e = lane; e < n_slots; e += 64) wid[e] = -1;
+    for (int e = lane; e < UW * 2; e += 64) S.id[e] = -1;
+    for (int e = lane; tips && e < UW * 4; e += 64) S.tid[e] = -1;
     wave_sync_lds();
 }
 
+// stage: 0 = posteriors straight to memory; bit 0 = rows through the LDS slots, bit 1 = also the two scalars per row,
+// bit 2 = the level has cherries among the first two children of its units (tip slots in use)
 template <int G, int R>
 __global__ void __launch_bounds__(PML_BLOCK)
-td_f81_kernel(PmlTree t, PmlCols c, PmlState st, const PmlUnit* __restrict__ units, int n_level, int stage_rows) {
+td_f81_kernel(PmlTree t, PmlCols c, PmlState st, const PmlUnit* __restrict__ units, int n_level, int stage) {
     extern __shared__ double td_stage[];
     constexpr int UW = 64 / G;
     const int wave = threadIdx.x >> 6;
     const int sub = (threadIdx.x & 63) / G;
     LaneCtx<G, R> L;
     lane_ctx_init<G, R>(L, t, c, st);
-    const int n_slots = UW * stage_rows;  // per wave
-    double* wrow = nullptr;
-    double* wsum = nullptr;
-    i64* wexp = nullptr;
-    int* wid = nullptr;
-    const bool staged = G < 8 && stage_rows > 0 && (c.ks & 1) == 0;
+    TdStage S = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const bool staged = G <= PML_TD_STAGE_MAX_G && (stage & 1) && (c.ks & 1) == 0;
     if (staged) {
-        const int wave_doubles = n_slots * (c.ks + (G == 1 ? 2 : 0)) + ((n_slots + 1) >> 1);
-        wrow = td_stage + wave * wave_doubles;
-        wsum = wrow + n_slots * c.ks;
-        wexp = reinterpret_cast<i64*>(wsum + n_slots);
-        wid = reinterpret_cast<int*>(wsum + (G == 1 ? 2 : 0) * n_slots);
-        L.srow = wrow + sub * stage_rows * c.ks;
-        L.sid = wid + sub * stage_rows;
-        L.ssum = wsum + sub * stage_rows;
-        L.sexp = wexp + sub * stage_rows;
-        L.srows = stage_rows;
-        for (int e = threadIdx.x & 63; e < n_slots; e += 64) wid[e] = -1;
+        const bool scalars = (stage & 2) != 0;
+        double* base = td_stage + wave * td_stage_doubles(UW, c.ks, scalars);
+        S.rows = base;
+        base += UW * 2 * c.ks;
+        if (scalars) {
+            S.sum = base;
+            S.exp = reinterpret_cast<i64*>(base + UW * 6);
+            base += UW * 12;
+        }
+        S.id = reinterpret_cast<int*>(base);
+        S.tid = S.id + UW * 2;
+        S.tst = S.tid + UW * 4;
+        L.srow = S.rows + sub * 2 * c.ks;
+        L.sid = S.id + sub * 2;
+        L.stid = S.tid + sub * 4;
+        L.stst = S.tst + sub * 4;
+        if (scalars) {
+            L.ssum = S.sum + sub * 6;
+            L.sexp = S.exp + sub * 6;
+        }
+        for (int e = threadIdx.x & 63; e < UW * 2; e += 64) S.id[e] = -1;
+        for (int e = threadIdx.x & 63; e < UW * 4; e += 64) S.tid[e] = -1;
         wave_sync_lds();
     }
     const int stride = gridDim.x * PML_WAVES_PER_BLOCK * UW;
@@ -1250,7 +1312,7 @@ td_f81_kernel(PmlTree t, PmlCols c, PmlState st, const PmlUnit* __restrict__ uni
         const int nxt_idx = idx + stride;
         const UnitRegs nxt = load_unit<G>(units, nxt_idx < n_level ? nxt_idx : 0, L.g);
         if (idx < n_level) td_f81_unit<G, R>(L, t, c, st, cur);
-        if (staged) td_stage_flush<G, R>(L, c, wrow, wid, wsum, wexp, n_slots);
+        if (staged) td_stage_flush<G, R>(L, c, S, (stage & 4) != 0);
         cur = nxt;
         idx = nxt_idx;
     }
