@@ -888,3 +888,45 @@ print(json.dumps(dict(lnl=float(lnl[0]), states=states[0].tolist())))
         out.append(json.loads(res.stdout.strip().splitlines()[-1]))
     np.testing.assert_allclose(out[0]['lnl'], out[1]['lnl'], rtol=1e-12)
     assert out[0]['states'] == out[1]['states']
+
+
+@pytest.mark.parametrize('k', [2, 4, 7])
+def test_staged_posterior_stores_give_the_same_bits(k):
+    """Top-down level kernels of narrow units (k <= 8) write their posteriors through LDS slots (observed tips as
+    (id, state) pairs); PASTML_HIP_NO_TD_STAGE=1 writes them straight from the units.  Same tables, bit for bit -- on a
+    forest with polytomies, unobserved and ambiguous tips and restricted internal nodes, big enough for level launches."""
+    import json
+    import subprocess
+    import sys
+    code = '''
+import hashlib, json, sys
+import numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})
+from pastml_amd import hip
+from pastml_amd.tree import FlatForest
+from test_gpu_parity import random_spec, random_masks
+k = {k}
+rng = np.random.default_rng(11)
+flat = FlatForest.random(40000, seed=4, max_arity=5, n_trees=2)
+C = 2
+specs = [(random_spec('F81', k, rng), (1.3, 0.0, 1.0)) for _ in range(C)]
+masks = np.stack([random_masks(flat, k, rng) for _ in range(C)])
+with hip.Engine(flat, C, k) as eng:
+    eng.set_models(specs)
+    eng.set_masks(masks)
+    lnl, post, lh_sum, lh_sf = eng.marginal_pass()
+h = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+print(json.dumps(dict(lnl=h(lnl), post=h(post), lh_sum=h(lh_sum), lh_sf=h(lh_sf), finite=bool(np.isfinite(post).all()))))
+'''.format(root=REPO, tests=os.path.dirname(os.path.abspath(__file__)), k=k)
+    out = []
+    for off in (False, True):
+        env = dict(os.environ)
+        env['PASTML_HIP_BLOCK_NODES'] = '0'      # level launches, not subtree blocks
+        env['PASTML_HIP_SMALL_MANY_NODES'] = '0'
+        if off:
+            env['PASTML_HIP_NO_TD_STAGE'] = '1'
+        res = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stderr[-2000:]
+        out.append(json.loads(res.stdout.strip().splitlines()[-1]))
+    assert out[0]['finite']
+    assert out[0] == out[1]
