@@ -879,15 +879,22 @@ def run_tasks(forest, tasks, force_joint=True, device=None, flat=None):
     # restart seeds of all characters, drawn here in task order (the groups may run concurrently)
     seeds = np.random.randint(0, 2 ** 31 - 1, size=len(tasks))
 
+    per_group = []   # (diagnostics) where the time of a run goes: one entry per group of characters
+
     def run(job):
+        import time
         k, part = job
         group = [tasks[i] for i in part]
+        t0 = time.perf_counter()
         with CharacterBatch(flat, k, len(group), device=device) as batch:
             for c, t in enumerate(group):
                 batch.set_annotation(c, *annotation_words(flat, t.character, t.model.states))
             batch.initialize_allowed_states()
             lnl, rounds = optimise_group(batch, group, seeds[part])
+            t1 = time.perf_counter()
             res = reconstruct(batch, group, lnl, force_joint=force_joint)
+            per_group.append(dict(k=k, characters=len(group), rounds=rounds, sweeps=batch.n_sweeps,
+                                  optimise_s=round(t1 - t0, 3), reconstruct_s=round(time.perf_counter() - t1, 3)))
             return part, res, rounds, batch.n_sweeps
 
     # Groups are independent: when all of them fit the device together they run concurrently, each on its own contexts
@@ -920,5 +927,6 @@ def run_tasks(forest, tasks, force_joint=True, device=None, flat=None):
         stats['sweeps'] += sweeps
         for i, r in zip(part, res):
             out[i] = r
+    stats['per_group'] = per_group
     run_tasks.last_stats = stats
     return out
