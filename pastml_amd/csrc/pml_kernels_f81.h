@@ -391,11 +391,12 @@ __device__ __forceinline__ void f81_absorb_child(const LaneCtx<G, R>& L, const P
 template <int G, int R>
 __device__ __forceinline__ void f81_cherry_vector(const LaneCtx<G, R>& L, const PmlTree& t, const PmlCols& c,
                                                   const PmlState& st, int n, double (&acc)[R], i64& esum,
-                                                  bool report) {
+                                                  bool report, bool tips_known = false, int fc_known = 0,
+                                                  int nc_known = 0) {
     node_mask_vec<G, R>(L, c, n, acc);
     esum = 0;
-    const int fc = t.first_child[n];
-    const int nc = t.n_children[n];
+    const int fc = tips_known ? fc_known : t.first_child[n];
+    const int nc = tips_known ? nc_known : t.n_children[n];
     for (int j = 0; j < nc; ++j) {
         const int ch = fc + j;
         double v[R];
@@ -433,8 +434,14 @@ struct __attribute__((aligned(32))) PmlUnit {
     int cfc[4];
 };
 
-struct UnitRegs {  // per lane: the descriptor's header and the cfc entry of the child this lane gathers tips for
+__device__ __forceinline__ int unit_nc(int packed) { return packed & 15; }
+__device__ __forceinline__ int unit_code(int packed, int j) { return (packed >> (8 + 3 * j)) & 7; }
+
+// per lane: the descriptor's header and the cfc entry of the child this lane gathers tips for (units of 8 lanes and
+// more); units of fewer lanes walk their children one after the other and keep all four entries (cfc = cfc[0])
+struct UnitRegs {
     int n, fc, packed, cfc;
+    int cfc1, cfc2, cfc3;
 };
 
 template <int G>
@@ -444,12 +451,46 @@ __device__ __forceinline__ UnitRegs load_unit(const PmlUnit* __restrict__ units,
     u.n = h.x;
     u.fc = h.y;
     u.packed = h.z;
-    u.cfc = units[idx].cfc[(g / Gather<G>::GC) & 3];
+    if (G < 8) {
+        const int4 f = *reinterpret_cast<const int4*>(units[idx].cfc);
+        u.cfc = f.x;
+        u.cfc1 = f.y;
+        u.cfc2 = f.z;
+        u.cfc3 = f.w;
+    } else {
+        u.cfc = units[idx].cfc[(g / Gather<G>::GC) & 3];
+        u.cfc1 = u.cfc2 = u.cfc3 = 0;
+    }
     return u;
 }
 
-__device__ __forceinline__ int unit_nc(int packed) { return packed & 15; }
-__device__ __forceinline__ int unit_code(int packed, int j) { return (packed >> (8 + 3 * j)) & 7; }
+// What the sequential paths know about child j of a unit without touching the tree arrays: its kind from the
+// descriptor's codes (children 0 - 3), and for a cherry of a narrow unit where its tips start and how many they are
+// (bit 4 of packed: every cherry among the first four children has 1 - 4 tips, so code - 1 is the number).
+struct ChildDesc {
+    int kind;
+    bool tips_known;
+    int fc2, nc2;
+};
+template <int G>
+__device__ __forceinline__ ChildDesc unit_child(const PmlTree& t, const UnitRegs& u, int j, int ch) {
+    ChildDesc d;
+    d.tips_known = false;
+    d.fc2 = d.nc2 = 0;
+    if (j < 4) {
+        const int code = unit_code(u.packed, j);
+        d.kind = code == 0 ? PML_KIND_TIP : (code == 1 ? PML_KIND_STORED : PML_KIND_CHERRY);
+        if (G < 8 && code >= 2 && ((u.packed >> 4) & 1)) {
+            d.tips_known = true;
+            d.fc2 = j == 0 ? u.cfc : (j == 1 ? u.cfc1 : (j == 2 ? u.cfc2 : u.cfc3));
+            d.nc2 = code - 1;
+        }
+    } else {
+        d.kind = node_kind(t, ch);
+    }
+    return d;
+}
+
 template <int G>
 __device__ __forceinline__ bool unit_is_fast(int packed) {
     return unit_nc(packed) <= Gather<G>::CH && ((packed >> 4) & 1);
@@ -804,12 +845,15 @@ __device__ __forceinline__ void bu_f81_unit_seq(const LaneCtx<G, R>& L, const Pm
     double acc[R];
     node_mask_vec<G, R>(L, c, n, acc);
     i64 esum = 0;
-    const int fc = t.first_child[n];
-    const int nc = t.n_children[n];
+    // topology from the descriptor (no chain node -> first_child -> kind -> the cherry's children through memory)
+    const int fc = u.fc;
+    int nc = unit_nc(u.packed);
+    if (nc == 15) nc = t.n_children[n];  // the descriptor counts up to 14
     for (int j = 0; j < nc; ++j) {
         const int ch = fc + j;
         const double e = L.E[ch];
-        const int kd = node_kind(t, ch);
+        const ChildDesc cd = unit_child<G>(t, u, j, ch);
+        const int kd = cd.kind;
         double v[R];
         double s_child = 0.0;
         if (kd == PML_KIND_TIP) {
@@ -823,7 +867,8 @@ __device__ __forceinline__ void bu_f81_unit_seq(const LaneCtx<G, R>& L, const Pm
             // cherry child of the fused joint sweep: the operations of this function for a node whose children are
             // tips (mask, then per tip: message, product, zero check, rescaling; the tip's arg-max row), in registers
             node_mask_vec<G, R>(L, c, ch, v);
-            const int fc2 = t.first_child[ch], nc2 = t.n_children[ch];
+            const int fc2 = cd.tips_known ? cd.fc2 : t.first_child[ch];
+            const int nc2 = cd.tips_known ? cd.nc2 : t.n_children[ch];
             for (int q = 0; q < nc2; ++q) {
                 const int tip = fc2 + q;
                 double tv[R], tmsg[R];
@@ -845,7 +890,7 @@ __device__ __forceinline__ void bu_f81_unit_seq(const LaneCtx<G, R>& L, const Pm
             }
         } else {
             i64 ce;
-            f81_cherry_vector<G, R>(L, t, c, st, ch, v, ce, true);
+            f81_cherry_vector<G, R>(L, t, c, st, ch, v, ce, true, cd.tips_known, cd.fc2, cd.nc2);
             esum += ce;
             s_child = pi_dot<G, R>(L, v);
             if (L.g == 0) L.S[ch] = s_child;
@@ -1167,11 +1212,13 @@ __device__ __forceinline__ void td_f81_unit(const LaneCtx<G, R>& L, const PmlTre
     f81_parent_prod<G, R>(L, c, p, prod, pe);
     double P = 0.0;
     bool have_P = false;
-    const int fc = t.first_child[p];
-    const int nc = t.n_children[p];
+    const int fc = u.fc;
+    int nc = unit_nc(u.packed);
+    if (nc == 15) nc = t.n_children[p];  // the descriptor counts up to 14
     for (int j = 0; j < nc; ++j) {
         const int ch = fc + j;
-        const int kd = node_kind(t, ch);
+        const ChildDesc cd = unit_child<G>(t, u, j, ch);
+        const int kd = cd.kind;
         const int slot = j < 2 ? j : -1;  // staging slots: children 0 and 1, then two tips of each if it is a cherry
         if (kd == PML_KIND_TIP) {
             f81_finish_tip<G, R>(L, c, prod, pe, P, have_P, ch, slot);
@@ -1191,7 +1238,7 @@ __device__ __forceinline__ void td_f81_unit(const LaneCtx<G, R>& L, const PmlTre
         } else {
             // cherry: rebuild its bottom-up vector, finish it, then finish its tips from registers
             i64 bec;
-            f81_cherry_vector<G, R>(L, t, c, st, ch, v, bec, false);
+            f81_cherry_vector<G, R>(L, t, c, st, ch, v, bec, false, cd.tips_known, cd.fc2, cd.nc2);
             const double s_child = L.S[ch];  // pi . v, stored by the bottom-up sweep
             f81_finish_child<G, R>(L, c, prod, pe, ch, e, s_child, bec, v, false, mb, tdc, xe, po, ls, le, slot);
             double prod2[R];
@@ -1200,8 +1247,8 @@ __device__ __forceinline__ void td_f81_unit(const LaneCtx<G, R>& L, const PmlTre
             const i64 pe2 = le;
             double P2 = 0.0;
             bool have_P2 = false;
-            const int fc2 = t.first_child[ch];
-            const int nc2 = t.n_children[ch];
+            const int fc2 = cd.tips_known ? cd.fc2 : t.first_child[ch];
+            const int nc2 = cd.tips_known ? cd.nc2 : t.n_children[ch];
             for (int q = 0; q < nc2; ++q)
                 f81_finish_tip<G, R>(L, c, prod2, pe2, P2, have_P2, fc2 + q, (j < 2 && q < 2) ? 2 + 2 * j + q : -1);
         }
