@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libpastml_hip.so')
 SOURCES = ['pml_api.hip']
-HEADERS = ['pml_device.h', 'pml_kernels_f81.h', 'pml_kernels_misc.h', 'pml_kernels_matrix.h', 'pml_kernels_pij.h',
+HEADERS = ['pml_device.h', 'pml_kernels_f81.h', 'pml_kernels_misc.h', 'pml_model.h', 'pml_kernels_matrix.h', 'pml_kernels_pij.h',
            'pml_kernels_counts.h',
            'pml_kernels_eigen_mfma.h', 'pml_kernels_eigen_gemm.h', 'pml_kernels_eigen_joint.h', 'pml_comm.h',
            os.path.join('..', '..', 'include', 'pastml_hip.h')]

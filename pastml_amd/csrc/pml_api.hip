@@ -291,6 +291,12 @@ static bool eigen_fused(const pml_ctx* c) {
            c->ks == 4 * ((c->k + 3) / 4);
 }
 
+// HKY sweeps build P(t) in registers (pml_kernels_matrix.h, PML_P_HKY); PASTML_HIP_NO_HKY_FUSED reads the batch.
+static bool hky_fused(const pml_ctx* c) {
+    static const bool off = getenv("PASTML_HIP_NO_HKY_FUSED") != nullptr;
+    return !off && c->kind == PML_MODEL_HKY && c->k == 4 && c->ks == 4 && c->G == 4 && c->R == 1 && c->W == 1;
+}
+
 static PmlModel model_of(const pml_ctx* c) {
     PmlModel m;
     m.kind = c->kind;
@@ -353,17 +359,37 @@ static void launch_sweep(pml_ctx* ctx, SweepKind what, const int* level, int n_l
     const PmlState st = state_of(ctx);
     const int upb = PML_WAVES_PER_BLOCK * (64 / G);
     dim3 grid(grid_for(n_level, upb, ctx->C), ctx->C), block(PML_BLOCK);
+    const PmlModel m = model_of(ctx);
+    if (G == 4 && R == 1 && hky_fused(ctx)) {  // HKY: P(t) from the closed form, in registers (no batch in HBM)
+        constexpr int GG = G == 4 ? 4 : 4, RR = R == 1 ? 1 : 1;  // (keeps the other shapes from instantiating it)
+        switch (what) {
+            case SW_BU_MARG:
+                hipLaunchKernelGGL((bu_matrix_kernel<GG, RR, false, PML_P_HKY>), grid, block, 0, ctx->stream, t, c, st,
+                                   nullptr, m, level, n_level);
+                return;
+            case SW_BU_JOINT:
+                hipLaunchKernelGGL((bu_matrix_kernel<GG, RR, true, PML_P_HKY>), grid, block, 0, ctx->stream, t, c, st,
+                                   nullptr, m, level, n_level);
+                return;
+            case SW_TD:
+                hipLaunchKernelGGL((td_matrix_kernel<GG, RR, PML_P_HKY>), grid, block, 0, ctx->stream, t, c, st, nullptr,
+                                   m, level, n_level);
+                return;
+            default:
+                break;
+        }
+    }
     switch (what) {
         case SW_BU_MARG:
-            hipLaunchKernelGGL((bu_matrix_kernel<G, R, false>), grid, block, 0, ctx->stream, t, c, st, ctx->d_P, level,
+            hipLaunchKernelGGL((bu_matrix_kernel<G, R, false>), grid, block, 0, ctx->stream, t, c, st, ctx->d_P, m, level,
                                n_level);
             break;
         case SW_BU_JOINT:
-            hipLaunchKernelGGL((bu_matrix_kernel<G, R, true>), grid, block, 0, ctx->stream, t, c, st, ctx->d_P, level,
+            hipLaunchKernelGGL((bu_matrix_kernel<G, R, true>), grid, block, 0, ctx->stream, t, c, st, ctx->d_P, m, level,
                                n_level);
             break;
         case SW_TD:
-            hipLaunchKernelGGL((td_matrix_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, ctx->d_P, level,
+            hipLaunchKernelGGL((td_matrix_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, ctx->d_P, m, level,
                                n_level);
             break;
         case SW_ROOTS:
@@ -1758,7 +1784,7 @@ static int enqueue_bottom_up(pml_ctx* ctx, int is_marginal, bool small_path, boo
         hipLaunchKernelGGL(reset_err_kernel, dim3((ctx->C + 63) / 64), dim3(64), 0, ctx->stream, ctx->d_err, ctx->C);
         HIP_TRY(hipGetLastError());
         // the fused eigen sweeps build P(t) themselves, the two-GEMM sweeps never need it
-        if (!eig && !gemm && !eigj) PML_TRY(run_prep(ctx, force_prep));
+        if (!eig && !gemm && !eigj && !hky_fused(ctx)) PML_TRY(run_prep(ctx, force_prep));
     }
     PML_TRY(prof_begin(ctx));
     const bool fused = is_marginal && ctx->kind == PML_MODEL_F81;
@@ -1901,7 +1927,8 @@ static int submit_bottom_up(pml_ctx* ctx, int is_marginal) {
         PML_TRY(dev_alloc(ctx, &ctx->d_J, CN * ctx->ks));
         PML_TRY(dev_alloc(ctx, &ctx->d_js, CN));
     }
-    const bool no_p = eigen_fused(ctx) || (is_marginal && eigen_gemm(ctx)) || (!is_marginal && eigen_joint_valu(ctx));
+    const bool no_p = eigen_fused(ctx) || (is_marginal && eigen_gemm(ctx)) || (!is_marginal && eigen_joint_valu(ctx)) ||
+                      hky_fused(ctx);
     if (eigen_fused(ctx) || eigen_gemm(ctx) || eigen_joint_valu(ctx)) {
         if (!ctx->d_msg) PML_TRY(dev_alloc(ctx, &ctx->d_msg, CN * ctx->ks));
     }

@@ -2,7 +2,7 @@
 // P is stored transposed per branch: Pt[branch][j][i] = P[i][j] (row stride ks), so that for a fixed source state j
 // the lanes of a unit (which own the target rows i) read consecutive doubles.
 #pragma once
-#include "pml_kernels_misc.h"
+#include "pml_model.h"
 
 #define PML_MAX_STATES 256
 
@@ -21,6 +21,33 @@ __device__ __forceinline__ void stage_vec(double* __restrict__ slot, int s0, con
 // a unit waits for memory k / PML_ROWS_AT_ONCE times per child instead of k times.  The order of the arithmetic is
 // unchanged (j ascending), so the results are the bits of the one-row-at-a-time loop.
 #define PML_ROWS_AT_ONCE 8
+
+// HKY (k = 4, one state per lane): the sweeps build P(t) in registers instead of reading the materialised batch -- a
+// branch's 4x4 matrix is 128 bytes against the 32 bytes of a state vector, four fifths of what these sweeps read.
+// A lane keeps row i of P (its own state): PRow4.  Same closed form (hky_matrix), hence the same bits as the batch.
+struct PRow4 {
+    double e[4];  // P[i][j], j = 0 .. 3
+};
+__device__ __forceinline__ PRow4 hky_row(const double* __restrict__ pi, double kappa, double tt, int i) {
+    double p[4][4];
+    hky_matrix(pi, kappa, tt, p);
+    PRow4 r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r.e[j] = i == 0 ? p[0][j] : (i == 1 ? p[1][j] : (i == 2 ? p[2][j] : p[3][j]));
+    return r;
+}
+__device__ __forceinline__ double prow_pick(const PRow4& r, int j) {
+    return j == 0 ? r.e[0] : (j == 1 ? r.e[1] : (j == 2 ? r.e[2] : r.e[3]));
+}
+// out = sum_j P[i][j] v[j], j ascending as matvec_rows (the same additions in the same order)
+__device__ __forceinline__ void matvec_prow(const PRow4& r, const double* __restrict__ slot, double (&out)[1]) {
+    out[0] = 0.0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) out[0] += r.e[j] * slot[j];
+}
+
+#define PML_P_MATERIALISED 0
+#define PML_P_HKY 1
 
 // out[i] = sum_j P[i][j] v[j]  (rows i = s0 .. s0+R-1 of this lane), v staged in LDS
 template <int R>
@@ -48,10 +75,12 @@ __device__ __forceinline__ void matvec_rows(const double* __restrict__ Pt, int k
 }
 
 // replaces calc_node_bu_likelihood (pastml/ml.py:124-148) for materialised P
-template <int G, int R, bool JOINT>
+// SRC = PML_P_HKY (only G = 4, R = 1, k = 4): P(t) of a child's branch from the closed form, in registers.
+template <int G, int R, bool JOINT, int SRC = PML_P_MATERIALISED>
 __global__ void __launch_bounds__(PML_BLOCK)
-bu_matrix_kernel(PmlTree t, PmlCols c, PmlState st, const double* __restrict__ P,
+bu_matrix_kernel(PmlTree t, PmlCols c, PmlState st, const double* __restrict__ P, PmlModel m,
                  const int* __restrict__ level_nodes, int n_level) {
+    static_assert(SRC == PML_P_MATERIALISED || (G == 4 && R == 1), "the HKY source is for one state per lane, k = 4");
     constexpr int UW = 64 / G;
     __shared__ double lds[PML_WAVES_PER_BLOCK * UW][G * R];
     const int lane = threadIdx.x & 63;
@@ -82,6 +111,10 @@ bu_matrix_kernel(PmlTree t, PmlCols c, PmlState st, const double* __restrict__ P
         for (int j = 0; j < nc; ++j) {
             const int ch = fc + j;
             const bool tip = t.n_children[ch] == 0;
+            PRow4 prow;
+            if (SRC == PML_P_HKY)
+                prow = hky_row(c.pi + (size_t)col * c.ks, m.kappa[col],
+                               (t.dist[ch] + m.tau[col]) * m.tauf[col] * m.sf[col], s0);
             double v[R];
             int observed = -1;  // state of an observed tip (exactly one allowed state)
             if (tip) {
@@ -98,7 +131,9 @@ bu_matrix_kernel(PmlTree t, PmlCols c, PmlState st, const double* __restrict__ P
                 // arg-max scan has a closed form, so one 8k-byte row of Pt is read instead of the whole matrix
                 const double* Pt = P + (colN + ch) * pstride;
                 double msg[R];
-                if (lane_valid) {
+                if (SRC == PML_P_HKY) {
+                    msg[0] = prow_pick(prow, observed);
+                } else if (lane_valid) {
                     load_vec<R>(Pt + (size_t)observed * c.ks + s0, msg);
                 } else {
 #pragma unroll
@@ -170,7 +205,13 @@ bu_matrix_kernel(PmlTree t, PmlCols c, PmlState st, const double* __restrict__ P
             const double* Pt = P + (colN + ch) * pstride;
             double msg[R];
             if (!JOINT) {
-                matvec_rows<R>(Pt, c.k, c.ks, s0, lane_valid, slot, msg);
+                if (SRC == PML_P_HKY) {
+                    double m1[1];
+                    matvec_prow(prow, slot, m1);
+                    msg[0] = m1[0];
+                } else {
+                    matvec_rows<R>(Pt, c.k, c.ks, s0, lane_valid, slot, msg);
+                }
             } else {
                 int jj[R];
 #pragma unroll
@@ -178,7 +219,16 @@ bu_matrix_kernel(PmlTree t, PmlCols c, PmlState st, const double* __restrict__ P
                     msg[r] = -INFINITY;
                     jj[r] = 0;
                 }
-                if (lane_valid) {
+                if (SRC == PML_P_HKY) {
+#pragma unroll
+                    for (int jc = 0; jc < 4; ++jc) {
+                        const double pr = prow.e[jc] * slot[jc];
+                        if (pr > msg[0]) {
+                            msg[0] = pr;
+                            jj[0] = jc;
+                        }
+                    }
+                } else if (lane_valid) {
                     // sequential scan over j keeps numpy's first-maximum semantics (ml.py:134)
                     for (int j0 = 0; j0 < c.k; j0 += PML_ROWS_AT_ONCE) {
                         double p[PML_ROWS_AT_ONCE][R];
@@ -244,10 +294,11 @@ bu_matrix_kernel(PmlTree t, PmlCols c, PmlState st, const double* __restrict__ P
 }
 
 // replaces calc_node_td_likelihood (ml.py:273-290) + marginals (:454-460, :498-500) for materialised P
-template <int G, int R>
+template <int G, int R, int SRC = PML_P_MATERIALISED>
 __global__ void __launch_bounds__(PML_BLOCK)
-td_matrix_kernel(PmlTree t, PmlCols c, PmlState st, const double* __restrict__ P,
+td_matrix_kernel(PmlTree t, PmlCols c, PmlState st, const double* __restrict__ P, PmlModel m,
                  const int* __restrict__ level_parents, int n_level) {
+    static_assert(SRC == PML_P_MATERIALISED || (G == 4 && R == 1), "the HKY source is for one state per lane, k = 4");
     constexpr int UW = 64 / G;
     __shared__ double lds[PML_WAVES_PER_BLOCK * UW][G * R];
     const int lane = threadIdx.x & 63;
@@ -307,9 +358,19 @@ td_matrix_kernel(PmlTree t, PmlCols c, PmlState st, const double* __restrict__ P
                 bec = st.be[colN + ch];
             }
             const double* Pt = P + (colN + ch) * pstride;
+            PRow4 prow;
+            if (SRC == PML_P_HKY)
+                prow = hky_row(c.pi + (size_t)col * c.ks, m.kappa[col],
+                               (t.dist[ch] + m.tau[col]) * m.tauf[col] * m.sf[col], s0);
             stage_vec<R>(slot, s0, v);
             double cn[R], x[R];
-            matvec_rows<R>(Pt, c.k, c.ks, s0, lane_valid, slot, cn);
+            if (SRC == PML_P_HKY) {
+                double m1[1];
+                matvec_prow(prow, slot, m1);
+                cn[0] = m1[0];
+            } else {
+                matvec_rows<R>(Pt, c.k, c.ks, s0, lane_valid, slot, cn);
+            }
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const double d = (cn[r] > 0.0) ? cn[r] : 1.0;
@@ -320,7 +381,13 @@ td_matrix_kernel(PmlTree t, PmlCols c, PmlState st, const double* __restrict__ P
             __builtin_amdgcn_wave_barrier();
             stage_vec<R>(slot, s0, x);
             double tdc[R], lh[R];
-            matvec_rows<R>(Pt, c.k, c.ks, s0, lane_valid, slot, tdc);
+            if (SRC == PML_P_HKY) {
+                double m1[1];
+                matvec_prow(prow, slot, m1);
+                tdc[0] = m1[0];
+            } else {
+                matvec_rows<R>(Pt, c.k, c.ks, s0, lane_valid, slot, tdc);
+            }
             double lhs = 0.0;
 #pragma unroll
             for (int r = 0; r < R; ++r) {

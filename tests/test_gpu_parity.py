@@ -930,3 +930,43 @@ print(json.dumps(dict(lnl=h(lnl), post=h(post), lh_sum=h(lh_sum), lh_sf=h(lh_sf)
         out.append(json.loads(res.stdout.strip().splitlines()[-1]))
     assert out[0]['finite']
     assert out[0] == out[1]
+
+
+def test_hky_sweeps_with_p_in_registers_give_the_bits_of_the_materialised_batch():
+    """HKY: the sweeps build P(t) of a branch from the closed form in registers (PML_P_HKY); PASTML_HIP_NO_HKY_FUSED=1
+    reads the materialised batch.  Same closed form, same order of additions: identical posteriors, ln L, tables."""
+    import json
+    import subprocess
+    import sys
+    code = '''
+import hashlib, json, sys
+import numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})
+from pastml_amd import hip
+from pastml_amd.tree import FlatForest
+from test_gpu_parity import random_spec, random_masks
+rng = np.random.default_rng(21)
+flat = FlatForest.random(5000, seed=8, max_arity=4, n_trees=2)
+C = 3
+specs = [(random_spec('HKY', 4, rng), (float(rng.uniform(0.5, 2)), 0.0, 1.0)) for _ in range(C)]
+masks = np.stack([random_masks(flat, 4, rng) for _ in range(C)])
+with hip.Engine(flat, C, 4) as eng:
+    eng.set_models(specs)
+    eng.set_masks(masks)
+    lnl, post, lh_sum, lh_sf = eng.marginal_pass()
+    lnl_j, states = eng.joint_pass()
+    tables = [eng.download(hip.BUF_JOINT_TABLE, c) for c in range(C)]
+h = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+print(json.dumps(dict(lnl=h(lnl), post=h(post), lh_sum=h(lh_sum), lh_sf=h(lh_sf), lnl_j=h(lnl_j), states=h(states),
+                      tables=h(np.stack(tables)), finite=bool(np.isfinite(post).all()))))
+'''.format(root=REPO, tests=os.path.dirname(os.path.abspath(__file__)))
+    out = []
+    for off in (False, True):
+        env = dict(os.environ)
+        if off:
+            env['PASTML_HIP_NO_HKY_FUSED'] = '1'
+        res = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stderr[-2000:]
+        out.append(json.loads(res.stdout.strip().splitlines()[-1]))
+    assert out[0]['finite']
+    assert out[0] == out[1]
