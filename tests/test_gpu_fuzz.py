@@ -17,7 +17,7 @@ from test_gpu_parity import LNL_RTOL, LOG10_ATOL, log_true, random_masks, random
 
 pytestmark = pytest.mark.gpu
 
-N_CASES = 120
+N_CASES = int(__import__('os').environ.get('PASTML_FUZZ_CASES', '120'))
 
 
 def draw_case(seed):
