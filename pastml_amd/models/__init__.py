@@ -47,6 +47,57 @@ def _read_param_table(params):
     return {str(k.encode('ASCII', 'replace').decode()): v for (k, v) in table.items()}
 
 
+class ScalarParameter(object):
+    """
+    One scalar of a model's optimiser vector, described once: the attribute that holds it, the flag that frees it, its
+    bounds, and how it is read from / written to a parameter file.  ``Model`` walks tables of these instead of spelling
+    out sf, tau (and, for HKY, kappa) in every method that touches the vector -- pastml/models/__init__.py:145-258 and
+    HKYModel.py:84-189 do the latter.
+    """
+
+    def __init__(self, attr, flag, bounds, key, label, lowest_ok, strictly, pins_on_read=True, typo=False):
+        self.attr = attr                # property through which optimised values are assigned (setters guard frozen ones)
+        self.flag = flag                # name of the boolean attribute: is the scalar a free parameter?
+        self.bounds = bounds            # model -> (low, high)
+        self.key = key                  # row name in parameter files / dicts
+        self.label = label              # how log messages call it
+        self.lowest_ok = lowest_ok      # values at or below (strictly) / below this are rejected when read
+        self.strictly = strictly
+        self.pins_on_read = pins_on_read  # a value read from a file fixes the scalar unless reoptimise
+        self.typo = typo                # the reference's kappa message says 'paramaters'; kept for log parity
+
+    def is_free(self, model):
+        return bool(getattr(model, self.flag))
+
+    def read(self, model, params, reoptimise):
+        if self.key not in params:
+            return
+        logger = logging.getLogger('pastml')
+        raw = params[self.key]
+        try:
+            value = np.float64(raw)
+        except (TypeError, ValueError):
+            logger.error('{} ({}) given in parameters is not float, ignoring it.'.format(self.label, raw))
+            return
+        if value < self.lowest_ok or (self.strictly and value == self.lowest_ok):
+            logger.error('{} cannot be negative, ignoring the value given in {} ({}).'
+                         .format(self.label, 'paramaters' if self.typo else 'parameters', raw))
+            return
+        setattr(model, '_' + self.attr, value)
+        if self.pins_on_read:
+            setattr(model, self.flag, reoptimise)
+
+
+def _brlen_scaled(low, high):
+    return lambda model: (low / model.forest_stats.avg_nonzero_brlen, high / model.forest_stats.avg_nonzero_brlen)
+
+
+SF_PARAMETER = ScalarParameter('sf', '_optimise_sf', _brlen_scaled(0.001, 10.), SCALING_FACTOR, 'Scaling factor',
+                               0, True)
+TAU_PARAMETER = ScalarParameter('tau', '_optimise_tau', lambda model: (0, model.forest_stats.avg_nonzero_brlen),
+                                SMOOTHING_FACTOR, 'Smoothing factor', 0, False, pins_on_read=False)
+
+
 class Model(object):
     """
     Base model: scaling factor ``sf``, smoothing factor ``tau`` (reference: pastml/models/__init__.py:17-273).
@@ -128,36 +179,29 @@ class Model(object):
         return (t + self.tau) * self._tau_factor * self.sf
 
     # ------------------------------------------------------------------ optimiser interface (models/__init__.py:145-189)
-    def _basic_flags(self):
-        return [self._optimise_sf, self._optimise_tau]
+    # x = [leading scalars that are free] [subclass block] [trailing scalars that are free]
+    LEADING = (SF_PARAMETER, TAU_PARAMETER)
+    TRAILING = ()
+
+    def _free(self, table):
+        return [p for p in table if p.is_free(self)]
 
     def get_num_params(self):
-        return sum(1 for _ in self._basic_flags() if _)
+        return len(self._free(self.LEADING))
 
     def get_optimised_parameters(self):
-        return np.array([v for v, flag in zip((self.sf, self.tau), self._basic_flags()) if flag], dtype=np.float64) \
-            if self.get_num_params() else np.hstack(([], []))
+        return np.array([getattr(self, p.attr) for p in self._free(self.LEADING)], dtype=np.float64)
 
     def set_params_from_optimised(self, ps, **kwargs):
-        i = 0
-        if self._optimise_sf:
-            self.sf = ps[i]
-            i += 1
-        if self._optimise_tau:
-            self.tau = ps[i]
+        for value, p in zip(ps, self._free(self.LEADING)):
+            setattr(self, p.attr, value)
 
     def get_bounds(self):
-        avg = self.forest_stats.avg_nonzero_brlen
-        bounds = []
-        if self._optimise_sf:
-            bounds.append([0.001 / avg, 10. / avg])
-        if self._optimise_tau:
-            bounds.append([0, avg])
-        return np.array(bounds, np.float64)
+        return np.array([p.bounds(self) for p in self._free(self.LEADING)], np.float64)
 
     def freeze(self):
-        self._optimise_sf = False
-        self._optimise_tau = False
+        for p in self.LEADING + self.TRAILING:
+            setattr(self, p.flag, False)
 
     def basic_params_fixed(self):
         return not self._optimise_tau and not self._optimise_sf
@@ -174,36 +218,14 @@ class Model(object):
     # ------------------------------------------------------------------ parameters in / out
     def parse_parameters(self, params, reoptimise=False):
         """
-        Reads 'scaling_factor' / 'smoothing_factor' from a dict or a parameter file; given values are fixed unless
-        ``reoptimise`` (reference: models/__init__.py:191-258).
+        Reads the scalars of the model's tables ('scaling_factor', 'smoothing_factor', ...) from a dict or a parameter
+        file; given values are fixed unless ``reoptimise`` (reference: models/__init__.py:191-258).
         """
-        logger = logging.getLogger('pastml')
         params = _read_param_table(params)
         if params is None:
             return {}
-        if SCALING_FACTOR in params:
-            raw = params[SCALING_FACTOR]
-            try:
-                value = np.float64(raw)
-                if value <= 0:
-                    logger.error('Scaling factor cannot be negative, ignoring the value given in parameters ({}).'
-                                 .format(raw))
-                else:
-                    self._sf = value
-                    self._optimise_sf = reoptimise
-            except (TypeError, ValueError):
-                logger.error('Scaling factor ({}) given in parameters is not float, ignoring it.'.format(raw))
-        if SMOOTHING_FACTOR in params:
-            raw = params[SMOOTHING_FACTOR]
-            try:
-                value = np.float64(raw)
-                if value < 0:
-                    logger.error('Smoothing factor cannot be negative, ignoring the value given in parameters ({}).'
-                                 .format(raw))
-                else:
-                    self._tau = value
-            except (TypeError, ValueError):
-                logger.error('Smoothing factor ({}) given in parameters is not float, ignoring it.'.format(raw))
+        for p in self.LEADING:
+            p.read(self, params, reoptimise)
         return params
 
     def save_parameters(self, filehandle):
@@ -279,7 +301,7 @@ class ModelWithFrequencies(Model):
         return 1 if self._frequency_smoothing else 0
 
     def get_num_params(self):
-        return Model.get_num_params(self) + self._n_frequency_params()
+        return Model.get_num_params(self) + self._n_frequency_params() + len(self._free(self.TRAILING))
 
     def extra_params_fixed(self):
         return self._extra_params_fixed or Model.get_num_params(self) == self.get_num_params()
@@ -291,35 +313,37 @@ class ModelWithFrequencies(Model):
         Model.set_params_from_optimised(self, ps, **kwargs)
         if self.extra_params_fixed():
             return
-        first = Model.get_num_params(self)
+        at = Model.get_num_params(self)
         if self._optimise_frequencies:
-            freqs = np.hstack((ps[first: first + len(self.frequencies) - 1], [1.]))
+            freqs = np.hstack((ps[at: at + len(self.frequencies) - 1], [1.]))
             self.frequencies = freqs / freqs.sum()
         elif self._frequency_smoothing:
             # NB (reference behaviour, models/__init__.py:331-335): smoothing is applied to the *current* frequencies
-            freqs = self.frequencies * self.forest_stats.num_tips + ps[first]
+            freqs = self.frequencies * self.forest_stats.num_tips + ps[at]
             self.frequencies = freqs / freqs.sum()
+        at += self._n_frequency_params()
+        for value, p in zip(ps[at:], self._free(self.TRAILING)):
+            setattr(self, p.attr, value)
 
     def get_optimised_parameters(self):
         basic = Model.get_optimised_parameters(self)
         if self.extra_params_fixed():
             return basic
         if self._optimise_frequencies:
-            extra = self.frequencies[:-1] / self.frequencies[-1]
+            block = self.frequencies[:-1] / self.frequencies[-1]
         else:
-            extra = [0] if self._frequency_smoothing else []
-        return np.hstack((basic, extra))
+            block = [0] if self._frequency_smoothing else []
+        return np.hstack((basic, block, [getattr(self, p.attr) for p in self._free(self.TRAILING)]))
 
     def get_bounds(self):
         basic = Model.get_bounds(self)
         if self.extra_params_fixed():
             return basic
-        extras = []
-        if self._optimise_frequencies:
-            extras += [np.array([1e-6, 10e6], np.float64)] * (len(self.frequencies) - 1)
+        rows = [np.array([1e-6, 10e6], np.float64)] * (len(self.frequencies) - 1 if self._optimise_frequencies else 0)
         if self._frequency_smoothing:
-            extras.append(np.array([0, self.forest_stats.num_nodes]))
-        return np.array((*basic, *extras))
+            rows.append(np.array([0, self.forest_stats.num_nodes]))
+        rows += [np.array(p.bounds(self), np.float64) for p in self._free(self.TRAILING)]
+        return np.array((*basic, *rows))
 
     def freeze(self):
         Model.freeze(self)
@@ -332,7 +356,12 @@ class ModelWithFrequencies(Model):
         (reference: models/__init__.py:365-414).  As in the reference, accepted frequencies are stored as given
         (the floor-and-renormalise step of ``:398-408`` computes a local value that is never assigned).
         """
-        params = Model.parse_parameters(self, params, reoptimise)
+        params = self._parse_frequencies(Model.parse_parameters(self, params, reoptimise), reoptimise)
+        for p in self.TRAILING:
+            p.read(self, params, reoptimise)
+        return params
+
+    def _parse_frequencies(self, params, reoptimise):
         logger = logging.getLogger('pastml')
         known = set(self.states) & set(params.keys())
         if not known:
@@ -371,12 +400,18 @@ class ModelWithFrequencies(Model):
         return params
 
     def _print_parameters(self):
-        return '{}\tfrequencies\t{}\n{}\n'.format(
+        text = '{}\tfrequencies\t{}\n{}\n'.format(
             Model._print_parameters(self),
             '(optimised)' if self._optimise_frequencies else '(smoothed)' if self._frequency_smoothing else '(fixed)',
             '\n'.join('\t\t{}:\t{:g}'.format(state, freq) for (state, freq) in zip(self.states, self.frequencies)))
+        for p in self.TRAILING:
+            text += '\t{}\t{:.6f}\t{}\n'.format(p.key, getattr(self, p.attr),
+                                                 '(optimised)' if p.is_free(self) else '(fixed)')
+        return text
 
     def save_parameters(self, filehandle):
         Model.save_parameters(self, filehandle)
         for state, frequency in zip(self.states, self.frequencies):
             filehandle.write('{}\t{}\n'.format(state, frequency))
+        for p in self.TRAILING:
+            filehandle.write('{}\t{:g}\n'.format(p.key, getattr(self, p.attr)))

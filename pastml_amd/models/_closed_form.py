@@ -3,11 +3,9 @@ Closed-form model families: F81 / JC / EFT (one exponential per branch, pastml/m
 EFTModel.py) and HKY85 (pastml/models/HKYModel.py).  The classes carry parameters, bounds and (de)serialisation; the
 per-branch arithmetic runs on the device (kernel_spec() describes the model to libpastml_hip).
 """
-import logging
-
 import numpy as np
 
-from pastml_amd.models import Model, ModelWithFrequencies, KIND_F81, KIND_HKY
+from pastml_amd.models import Model, ModelWithFrequencies, ScalarParameter, KIND_F81, KIND_HKY
 
 
 F81 = 'F81'
@@ -89,16 +87,23 @@ HKY_STATES = np.array(['A', 'C', 'G', 'T'])
 A, C, G, T = 0, 1, 2, 3
 KAPPA = 'kappa'
 
+# kappa rides behind the frequency block of the optimiser vector; bounds HKYModel.py:121-130
+KAPPA_PARAMETER = ScalarParameter('kappa', '_optimise_kappa', lambda model: (1e-6, 20.), KAPPA, 'Kappa', 0, True,
+                                  typo=True)
+
 
 class HKYModel(ModelWithFrequencies):
     """
-    Four states A, C, G, T; parameters: frequencies and the transition/transversion ratio kappa (bounds [1e-6, 20],
-    HKYModel.py:121-130).  The closed-form P(t) (HKYModel.py:44-82) is evaluated per branch by the HIP library.
+    Four states A, C, G, T; parameters: frequencies and the transition/transversion ratio kappa.  The closed-form P(t)
+    (HKYModel.py:44-82) is evaluated per branch by the HIP library.  Everything the reference spells out per method for
+    kappa (HKYModel.py:84-189: vector length, packing / unpacking, bounds, file row, freezing, printing) follows from
+    one entry in the model's table of trailing scalars (pastml_amd/models/__init__.py, ScalarParameter).
     """
+    TRAILING = (KAPPA_PARAMETER,)
 
     def __init__(self, forest_stats, sf=None, frequencies=None, kappa=4, tau=0,
                  frequency_smoothing=False, optimise_tau=False, parameter_file=None, reoptimise=False, **kwargs):
-        self._kappa = None
+        self._kappa = None           # a parameter file read by the base constructor may set both
         self._optimise_kappa = True
         kwargs['states'] = HKY_STATES
         ModelWithFrequencies.__init__(self, forest_stats=forest_stats, sf=sf, tau=tau, optimise_tau=optimise_tau,
@@ -122,58 +127,6 @@ class HKYModel(ModelWithFrequencies):
     def states(self, states):
         raise NotImplementedError("The HKY model is only implemented for nucleotides: "
                                   "the states are A, C, G, T and cannot be reset")
-
-    # ---- optimiser vector: [basic..., frequency params..., kappa] (HKYModel.py:84-130)
-    def get_num_params(self):
-        return ModelWithFrequencies.get_num_params(self) + (1 if self._optimise_kappa else 0)
-
-    def set_params_from_optimised(self, ps, **kwargs):
-        if self.extra_params_fixed():
-            Model.set_params_from_optimised(self, ps, **kwargs)
-            return
-        ModelWithFrequencies.set_params_from_optimised(self, ps, **kwargs)
-        if self._optimise_kappa:
-            self.kappa = ps[ModelWithFrequencies.get_num_params(self)]
-
-    def get_optimised_parameters(self):
-        if self.extra_params_fixed():
-            return Model.get_optimised_parameters(self)
-        return np.hstack((ModelWithFrequencies.get_optimised_parameters(self),
-                          [self.kappa] if self._optimise_kappa else []))
-
-    def get_bounds(self):
-        if self.extra_params_fixed():
-            return Model.get_bounds(self)
-        return np.array((*ModelWithFrequencies.get_bounds(self),
-                         *([np.array([1e-6, 20.])] if self._optimise_kappa else [])))
-
-    def parse_parameters(self, params, reoptimise=False):
-        params = ModelWithFrequencies.parse_parameters(self, params, reoptimise)
-        if KAPPA in params:
-            logger = logging.getLogger('pastml')
-            raw = params[KAPPA]
-            try:
-                value = np.float64(raw)
-                if value <= 0:
-                    logger.error('Kappa cannot be negative, ignoring the value given in paramaters ({}).'.format(raw))
-                else:
-                    self._kappa = value
-                    self._optimise_kappa = reoptimise
-            except (TypeError, ValueError):
-                logger.error('Kappa ({}) given in parameters is not float, ignoring it.'.format(raw))
-        return params
-
-    def _print_parameters(self):
-        return '{}\tkappa\t{:.6f}\t{}\n'.format(ModelWithFrequencies._print_parameters(self), self.kappa,
-                                              '(optimised)' if self._optimise_kappa else '(fixed)')
-
-    def freeze(self):
-        ModelWithFrequencies.freeze(self)
-        self._optimise_kappa = False
-
-    def save_parameters(self, filehandle):
-        ModelWithFrequencies.save_parameters(self, filehandle)
-        filehandle.write('{}\t{:g}\n'.format(KAPPA, self.kappa))
 
     def kernel_spec(self):
         return dict(kind=KIND_HKY, pi=np.ascontiguousarray(self.frequencies, dtype=np.float64),

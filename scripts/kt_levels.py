@@ -7,7 +7,9 @@ import sys
 path = glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True)[0]
 rows = list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-last_prep = max(i for i, r in enumerate(rows) if 'prep' in r['Kernel_Name'])
+starts = [i for i, r in enumerate(rows) if 'prep' in r['Kernel_Name']] or \
+    [i for i, r in enumerate(rows) if 'reset_err' in r['Kernel_Name']]  # (a folded sweep has no per-branch pass)
+last_prep = max(starts)
 tot = {}
 for r in rows[last_prep:]:
     us = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
