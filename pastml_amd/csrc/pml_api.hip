@@ -50,7 +50,16 @@ struct pml_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    hipEvent_t pev[2] = {nullptr, nullptr};
+    // kernel timing (pml_profile_*): event pairs around the level launches, read back when the profile is read -- a
+    // bracket never makes the host wait inside a sweep
+    struct ProfBracket {
+        hipEvent_t a, b;
+        int which;
+        long long launches;
+    };
+    std::vector<ProfBracket> prof_pending;
+    std::vector<hipEvent_t> prof_pool;
+    hipEvent_t prof_open = nullptr;
     bool profile = false;
     double prof_ms[3] = {0, 0, 0};
     long long prof_launches[3] = {0, 0, 0};
@@ -327,19 +336,60 @@ static PmlModel model_of(const pml_ctx* c) {
     return m;
 }
 
+static int prof_event(pml_ctx* ctx, hipEvent_t* out) {
+    if (!ctx->prof_pool.empty()) {
+        *out = ctx->prof_pool.back();
+        ctx->prof_pool.pop_back();
+        return PML_OK;
+    }
+    HIP_TRY(hipEventCreate(out));
+    return PML_OK;
+}
+
+// adds up the brackets recorded so far (waits for the stream) and returns their events to the pool
+static int prof_drain(pml_ctx* ctx) {
+    if (ctx->prof_pending.empty()) return PML_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipEventSynchronize(ctx->prof_pending.back().b));
+    for (const pml_ctx::ProfBracket& br : ctx->prof_pending) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, br.a, br.b));
+        ctx->prof_ms[br.which] += ms;
+        ctx->prof_launches[br.which] += br.launches;
+        ctx->prof_pool.push_back(br.a);
+        ctx->prof_pool.push_back(br.b);
+    }
+    ctx->prof_pending.clear();
+    return PML_OK;
+}
+
+static void prof_release(pml_ctx* ctx) {
+    for (const pml_ctx::ProfBracket& br : ctx->prof_pending) {
+        (void)hipEventDestroy(br.a);
+        (void)hipEventDestroy(br.b);
+    }
+    for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
+    if (ctx->prof_open) (void)hipEventDestroy(ctx->prof_open);
+    ctx->prof_pending.clear();
+    ctx->prof_pool.clear();
+    ctx->prof_open = nullptr;
+}
+
 static int prof_begin(pml_ctx* ctx) {
-    if (ctx->profile) HIP_TRY(hipEventRecord(ctx->pev[0], ctx->stream));
+    if (!ctx->profile) return PML_OK;
+    if (!ctx->prof_open) PML_TRY(prof_event(ctx, &ctx->prof_open));
+    HIP_TRY(hipEventRecord(ctx->prof_open, ctx->stream));
     return PML_OK;
 }
 
 static int prof_end(pml_ctx* ctx, int which, long long launches) {
-    if (!ctx->profile) return PML_OK;
-    HIP_TRY(hipEventRecord(ctx->pev[1], ctx->stream));
-    HIP_TRY(hipEventSynchronize(ctx->pev[1]));
-    float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, ctx->pev[0], ctx->pev[1]));
-    ctx->prof_ms[which] += ms;
-    ctx->prof_launches[which] += launches;
+    if (!ctx->profile || !ctx->prof_open) return PML_OK;
+    hipEvent_t b = nullptr;
+    PML_TRY(prof_event(ctx, &b));
+    HIP_TRY(hipEventRecord(b, ctx->stream));
+    ctx->prof_pending.push_back({ctx->prof_open, b, which, launches});
+    ctx->prof_open = nullptr;
+    if (ctx->prof_pending.size() >= 4096) PML_TRY(prof_drain(ctx));  // (bounds the number of live events)
     return PML_OK;
 }
 
@@ -918,8 +968,6 @@ int pml_ctx_create(int device, pml_ctx** out) {
     hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
-    if (e == hipSuccess) e = hipEventCreate(&ctx->pev[0]);
-    if (e == hipSuccess) e = hipEventCreate(&ctx->pev[1]);
     if (e != hipSuccess) {
         delete ctx;
         return fail(PML_ERR_HIP, "stream/event creation failed: %s", hipGetErrorString(e));
@@ -936,8 +984,7 @@ int pml_ctx_destroy(pml_ctx* ctx) {
     free_all(ctx);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
-    for (int i = 0; i < 2; ++i)
-        if (ctx->pev[i]) (void)hipEventDestroy(ctx->pev[i]);
+    prof_release(ctx);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return PML_OK;
@@ -1059,7 +1106,12 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
     // a new tree resets everything the ctx holds
     free_all(ctx);
     hipStream_t stream = ctx->stream;
-    hipEvent_t e0 = ctx->ev0, e1 = ctx->ev1, p0 = ctx->pev[0], p1 = ctx->pev[1];
+    hipEvent_t e0 = ctx->ev0, e1 = ctx->ev1;
+    (void)prof_drain(ctx);
+    std::vector<hipEvent_t> prof_pool;
+    prof_pool.swap(ctx->prof_pool);
+    if (ctx->prof_open) prof_pool.push_back(ctx->prof_open);
+
     int device = ctx->device;
     const bool profile = ctx->profile;
     const bool fuse = ctx->fuse, keep_td = ctx->keep_td, eig_fused_opt = ctx->eig_fused_opt;
@@ -1072,8 +1124,7 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
     ctx->stream = stream;
     ctx->ev0 = e0;
     ctx->ev1 = e1;
-    ctx->pev[0] = p0;
-    ctx->pev[1] = p1;
+    ctx->prof_pool.swap(prof_pool);
     ctx->profile = profile;
     ctx->device = device;
 
@@ -1678,9 +1729,14 @@ static int run_prep(pml_ctx* ctx, bool force = false) {
     PML_TRY(ensure_transition_storage(ctx));
     PML_TRY(prof_begin(ctx));
     if (ctx->kind == PML_MODEL_F81) {
-        dim3 grid(grid_for(ctx->N, PML_BLOCK, ctx->C), ctx->C);
+        // columns per thread: as many as still leave a few thousand blocks (the branch length is read once per chunk)
+        int cpy = 1;
+        const int bx = (ctx->N + PML_BLOCK - 1) / PML_BLOCK;
+        while (cpy < 8 && cpy * 2 <= ctx->C && (long long)bx * ((ctx->C + 2 * cpy - 1) / (2 * cpy)) >= 4096) cpy *= 2;
+        const int ny = (ctx->C + cpy - 1) / cpy;
+        dim3 grid(grid_for(ctx->N, PML_BLOCK, ny), ny);
         hipLaunchKernelGGL(f81_prep_kernel, grid, dim3(PML_BLOCK), 0, ctx->stream, t, c, ctx->d_mu, ctx->d_sf,
-                           ctx->d_tau, ctx->d_tauf, state_of(ctx));
+                           ctx->d_tau, ctx->d_tauf, state_of(ctx), ctx->C, cpy);
         HIP_TRY(hipGetLastError());
     } else {
         if (ctx->kind == PML_MODEL_HKY) {
@@ -2662,6 +2718,7 @@ int pml_profile_enable(pml_ctx* ctx, int on) {
 
 int pml_profile_read(pml_ctx* ctx, int which, double* total_ms, int64_t* launches, int reset) {
     if (!ctx || which < 0 || which > 2) return fail(PML_ERR_INVALID, "bad profile slot");
+    PML_TRY(prof_drain(ctx));
     if (total_ms) *total_ms = ctx->prof_ms[which];
     if (launches) *launches = ctx->prof_launches[which];
     if (reset) {

@@ -65,27 +65,34 @@ __device__ __forceinline__ int node_kind(const PmlTree& t, int n) {
 // per-branch e = exp(-mu t') for every (node, column); for tips also S = pi . mask
 // replaces: transform_t (models/__init__.py:269) + the exp of F81Model.get_Pij_t (F81Model.py:42-45)
 // ---------------------------------------------------------------------------------------------------------------------
+// A thread takes node n for `cpy` consecutive columns (blockIdx.y = column chunk): the branch length is read once per
+// chunk instead of once per column (a third of this pass's traffic on a wide batch).
 __global__ void __launch_bounds__(PML_BLOCK)
 f81_prep_kernel(PmlTree t, PmlCols c, const double* __restrict__ mu, const double* __restrict__ sf,
-                const double* __restrict__ tau, const double* __restrict__ tauf, PmlState st) {
-    const int col = blockIdx.y;
-    const size_t colN = (size_t)col * t.N;
-    const double m = mu[col], s = sf[col], ta = tau[col], tf = tauf[col];
+                const double* __restrict__ tau, const double* __restrict__ tauf, PmlState st, int n_cols, int cpy) {
+    const int col0 = blockIdx.y * cpy;
+    const int col1 = min(n_cols, col0 + cpy);
     for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < t.N; n += gridDim.x * blockDim.x) {
-        const double tt = (t.dist[n] + ta) * tf * s;
-        // if mu == inf (a single state) it wins over t == 0 (F81Model.py:44-45)
-        st.E[colN + n] = isinf(m) ? 0.0 : exp(-m * tt);
-        if (t.n_children[n] == 0) {
-            double acc = 0.0;
-            for (int w = 0; w < c.W; ++w) {
-                u64 word = c.masks[(colN + n) * c.W + w];
-                while (word) {
-                    const int b = __builtin_ctzll(word);
-                    acc += c.pi[(size_t)col * c.ks + w * 64 + b];
-                    word &= word - 1ull;
+        const double d = t.dist[n];
+        const bool tip = t.n_children[n] == 0;
+        for (int col = col0; col < col1; ++col) {
+            const size_t colN = (size_t)col * t.N;
+            const double m = mu[col];
+            const double tt = (d + tau[col]) * tauf[col] * sf[col];
+            // if mu == inf (a single state) it wins over t == 0 (F81Model.py:44-45)
+            st.E[colN + n] = isinf(m) ? 0.0 : exp(-m * tt);
+            if (tip) {
+                double acc = 0.0;
+                for (int w = 0; w < c.W; ++w) {
+                    u64 word = c.masks[(colN + n) * c.W + w];
+                    while (word) {
+                        const int b = __builtin_ctzll(word);
+                        acc += c.pi[(size_t)col * c.ks + w * 64 + b];
+                        word &= word - 1ull;
+                    }
                 }
+                st.S[colN + n] = acc;  // a tip's exponent word stays 0 from the allocation of the column arrays
             }
-            st.S[colN + n] = acc;  // a tip's exponent word stays 0 from the allocation of the column arrays
         }
     }
 }
@@ -814,11 +821,14 @@ __device__ __forceinline__ void bu_loads_arrived(BuLoads<R>& ld) {
 // contributes to a non-zero entry is fma(e, v, a) >= a = (1 - e) S, and <= 1 for tips and cherries (v <= 1), so after
 // children that are not stored nodes the non-zero entries lie in [prod a, 1]: while that product stays above 2^-190 no
 // entry can have left the band [2^-200, 2^200] and lazy_rescale -- 24 compares per call -- would have returned 0.
-template <int G, int R, bool VEC, bool FULL>
+// PAIR (wave-uniform, decided by the caller): every unit of the wave has two children, both cherries of two tips -- the
+// shape of a whole level of a balanced binary tree.  Child and tip counts are then compile-time constants: the loops
+// unroll into straight-line code (no per-child exec masks, the lane exchanges of all four tips issued together).
+template <int G, int R, bool VEC, bool FULL, bool PAIR = false>
 __device__ __forceinline__ bool bu_f81_marg_body(const LaneCtx<G, R>& L, const PmlTree& t, const PmlCols& c,
                                                  const PmlState& st, const UnitRegs& u, BuLoads<R>& ld) {
     const int n = u.n, fc = u.fc;
-    const int nc = unit_nc(u.packed);
+    const int nc = PAIR ? 2 : unit_nc(u.packed);
     ChildLane& cl = ld.cl;
     TipLane& tl = ld.tl;
     double acc[R];
@@ -826,10 +836,10 @@ __device__ __forceinline__ bool bu_f81_marg_body(const LaneCtx<G, R>& L, const P
     i64 esum = 0;
     double lob = 1.0;     // lower bound of the non-zero entries of acc
     bool bounded = true;  // ... valid (no stored child so far, no rescaling so far)
-    for (int jx = 0; jx < nc; ++jx) {
+    auto child = [&](const int jx) {
         const int src = L.group_base + jx;
         const int ch = fc + jx;
-        const int code = unit_code(u.packed, jx);
+        const int code = PAIR ? 3 : unit_code(u.packed, jx);
         const double e = __shfl(cl.e, src, 64);
         double msg[R];
         double a;
@@ -871,6 +881,12 @@ __device__ __forceinline__ bool bu_f81_marg_body(const LaneCtx<G, R>& L, const P
                 if (ex != 0) bounded = false;
             }
         }
+    };
+    if (PAIR) {
+        child(0);
+        child(1);
+    } else {
+        for (int jx = 0; jx < nc; ++jx) child(jx);
     }
     if (FULL && nc == 0) {  // (no descriptor of a level has no children; keeps acc defined)
 #pragma unroll
@@ -914,7 +930,12 @@ __device__ __forceinline__ bool bu_f81_unit_fast(const LaneCtx<G, R>& L, const P
         const bool ones = c.k == G * R && (ld.own & kbits) == kbits && (unit_code(u.packed, cj & 3) < 2 || cl.mask == kbits);
         // (specialised only where it pays: the level that rebuilds cherries is bound by its instruction stream, the
         // levels that stream stored vectors by memory -- there the second body only costs registers: spills at R = 4)
-        if (!VEC && __all(ones)) return bu_f81_marg_body<G, R, VEC, true>(L, t, c, st, u, ld);
+        if (!VEC && __all(ones)) {
+            // nc = 2, both children cherries of two tips (codes 3, 3; bits 4, 5 of packed are set for fast units)
+            const bool pair = (u.packed & 0x3f0f) == ((3 << 11) | (3 << 8) | 2);
+            if (__all(pair)) return bu_f81_marg_body<G, R, VEC, true, true>(L, t, c, st, u, ld);
+            return bu_f81_marg_body<G, R, VEC, true>(L, t, c, st, u, ld);
+        }
         return bu_f81_marg_body<G, R, VEC, false>(L, t, c, st, u, ld);
     }
     i64 esum = 0;
