@@ -153,8 +153,7 @@ struct pml_ctx {
     bool td_filled = false;    // ... including those of the nodes the sweeps do not store (td_fill_kernel)
     bool eig_fused_opt = true; // PML_OPT_EIGEN_FUSED
     const PmlUnit* units_override = nullptr;  // set around a dispatch_sweep on the block schedule's top lists
-    bool fold_launch = false;  // set around the launches of a sweep that folds the per-branch pass into its gathers
-    double* d_sumpi = nullptr;
+
     PmlComm* comm = nullptr;   // RCCL communicator attached by pml_comm_init (survives tree uploads)
 };
 
@@ -271,11 +270,6 @@ static PmlCols cols_of(const pml_ctx* c) {
     s.masks = c->d_masks;
     s.masks_init = c->has_init ? c->d_masks_init : nullptr;
     s.pi = c->d_pi;
-    s.mu = c->d_mu;
-    s.sf = c->d_sf;
-    s.tau = c->d_tau;
-    s.tauf = c->d_tauf;
-    s.sumpi = c->d_sumpi;
     return s;
 }
 
@@ -311,15 +305,6 @@ static bool eigen_fused(const pml_ctx* c) {
 static bool hky_fused(const pml_ctx* c) {
     static const bool off = getenv("PASTML_HIP_NO_HKY_FUSED") != nullptr;
     return !off && c->kind == PML_MODEL_HKY && c->k == 4 && c->ks == 4 && c->G == 4 && c->R == 1 && c->W == 1;
-}
-
-// F81 family, level schedule of large forests, single-word masks: the sweeps form e = exp(-mu t') and the tips'
-// S = pi . mask in their gathers (LaneCtx::fold) -- f81_prep_kernel does not run and E is not in memory while
-// prep_dirty says so; whoever else needs E (joint sweeps, subtree blocks, inspection) calls run_prep.
-// Opt-in (PASTML_HIP_FOLD=1): measured slower than the separate pass so far.
-static bool f81_fold(const pml_ctx* c) {
-    static const bool on = getenv("PASTML_HIP_FOLD") != nullptr;
-    return on && c->kind == PML_MODEL_F81 && c->W == 1 && c->k >= 2;
 }
 
 static PmlModel model_of(const pml_ctx* c) {
@@ -489,21 +474,13 @@ static void launch_sweep_f81(pml_ctx* ctx, SweepKind what, const int* level, int
     switch (what) {
         case SW_BU_MARG_FUSED:
         case SW_BU_MARG:
-            if (ctx->fold_launch)
-                hipLaunchKernelGGL((bu_f81_kernel<G, R, false, true, true>), grid, block, 0, ctx->stream, t, c, st, units,
-                                   n_level);
-            else
-                hipLaunchKernelGGL((bu_f81_kernel<G, R, false, true>), grid, block, 0, ctx->stream, t, c, st, units,
-                                   n_level);
+            hipLaunchKernelGGL((bu_f81_kernel<G, R, false, true>), grid, block, 0, ctx->stream, t, c, st, units,
+                               n_level);
             break;
         case SW_BU_MARG_FUSED_NOVEC:
         case SW_BU_CHERRIES:
-            if (ctx->fold_launch)
-                hipLaunchKernelGGL((bu_f81_kernel<G, R, false, false, true>), grid, block, 0, ctx->stream, t, c, st, units,
-                                   n_level);
-            else
-                hipLaunchKernelGGL((bu_f81_kernel<G, R, false, false>), grid, block, 0, ctx->stream, t, c, st, units,
-                                   n_level);
+            hipLaunchKernelGGL((bu_f81_kernel<G, R, false, false>), grid, block, 0, ctx->stream, t, c, st, units,
+                               n_level);
             break;
         case SW_BU_JOINT:
         case SW_BU_JOINT_FUSED:
@@ -536,11 +513,7 @@ static void launch_sweep_f81(pml_ctx* ctx, SweepKind what, const int* level, int
                 if (cherries) stage |= 4;
                 lds = (size_t)PML_WAVES_PER_BLOCK * td_stage_doubles(64 / G, c.ks, scalars) * sizeof(double);
             }
-            if (ctx->fold_launch)
-                hipLaunchKernelGGL((td_f81_kernel<G, R, true>), grid, block, lds, ctx->stream, t, c, st, units, n_level,
-                                   stage);
-            else
-                hipLaunchKernelGGL((td_f81_kernel<G, R>), grid, block, lds, ctx->stream, t, c, st, units, n_level, stage);
+            hipLaunchKernelGGL((td_f81_kernel<G, R>), grid, block, lds, ctx->stream, t, c, st, units, n_level, stage);
             break;
         }
         case SW_ROOTS:
@@ -560,16 +533,10 @@ static void launch_small_f81(pml_ctx* ctx, bool bottom_up, int do_prep, const Pm
     const PmlCols c = cols_of(ctx);
     const PmlState st = state_of(ctx);
     dim3 grid(1, ctx->C), block(PML_SMALL_BLOCK);
-    if (bottom_up && ctx->fold_launch)
-        hipLaunchKernelGGL((bu_f81_small_kernel<G, R, true>), grid, block, 0, ctx->stream, t, c, st, ctx->d_mu, ctx->d_sf,
-                           ctx->d_tau, ctx->d_tauf, 0, units, d_offsets, n_levels, ctx->h_loglik, ctx->h_err, reset_err);
-    else if (bottom_up)
+    if (bottom_up)
         hipLaunchKernelGGL((bu_f81_small_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, ctx->d_mu, ctx->d_sf,
                            ctx->d_tau, ctx->d_tauf, do_prep, units, d_offsets, n_levels, ctx->h_loglik, ctx->h_err,
                            reset_err);
-    else if (ctx->fold_launch)
-        hipLaunchKernelGGL((td_f81_small_kernel<G, R, true>), grid, block, 0, ctx->stream, t, c, st, units, d_offsets,
-                           n_levels);
     else
         hipLaunchKernelGGL((td_f81_small_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, units, d_offsets,
                            n_levels);
@@ -1473,7 +1440,7 @@ int pml_chars_alloc(pml_ctx* ctx, int32_t n_cols, int32_t k) {
     }
     const size_t CN = (size_t)n_cols * ctx->N;
     PML_TRY(dev_alloc(ctx, &ctx->d_masks, CN * ctx->W));
-    ctx->n_params = (size_t)n_cols * (ctx->ks + 6);
+    ctx->n_params = (size_t)n_cols * (ctx->ks + 5);
     PML_TRY(dev_alloc(ctx, &ctx->d_params, ctx->n_params));
     HIP_TRY(hipHostMalloc((void**)&ctx->h_params, sizeof(double) * ctx->n_params));
     memset(ctx->h_params, 0, sizeof(double) * ctx->n_params);
@@ -1483,7 +1450,6 @@ int pml_chars_alloc(pml_ctx* ctx, int32_t n_cols, int32_t k) {
     ctx->d_tauf = ctx->d_tau + n_cols;
     ctx->d_mu = ctx->d_tauf + n_cols;
     ctx->d_kappa = ctx->d_mu + n_cols;
-    ctx->d_sumpi = ctx->d_kappa + n_cols;
     PML_TRY(dev_alloc(ctx, &ctx->d_err, n_cols));
     HIP_TRY(hipHostMalloc((void**)&ctx->h_loglik, sizeof(double) * n_cols));
     HIP_TRY(hipHostMalloc((void**)&ctx->h_err, sizeof(u64) * n_cols));
@@ -1634,12 +1600,6 @@ static int set_common(pml_ctx* ctx, int kind, int cb, int ce, const double* pi, 
     memcpy(h + C * ks + cb, sf, nc * sizeof(double));
     memcpy(h + C * ks + C + cb, tau, nc * sizeof(double));
     memcpy(h + C * ks + 2 * C + cb, tauf, nc * sizeof(double));
-    for (int i = 0; i < nc; ++i) {
-        // sum(pi) in ascending state order from 0.0: S = pi . mask of a tip without data, as f81_prep_kernel forms it
-        double acc = 0.0;
-        for (size_t q = 0; q < k; ++q) acc += pi[(size_t)i * k + q];
-        h[C * ks + 5 * C + cb + i] = acc;
-    }
     for (int i = cb; i < ce; ++i) ctx->model_set[i] = 1;
     invalidate(ctx);
     return PML_OK;
@@ -1880,10 +1840,8 @@ static int enqueue_bottom_up(pml_ctx* ctx, int is_marginal, bool small_path, boo
     if (!small_path) {  // the single-launch kernel resets the error words itself
         hipLaunchKernelGGL(reset_err_kernel, dim3((ctx->C + 63) / 64), dim3(64), 0, ctx->stream, ctx->d_err, ctx->C);
         HIP_TRY(hipGetLastError());
-        // the fused eigen sweeps build P(t) themselves, the two-GEMM sweeps never need it; the level schedule of the
-        // F81 marginal sweep forms its per-branch data in the gathers
-        const bool folds = is_marginal && f81_fold(ctx) && !block_schedule(ctx);
-        if (!eig && !gemm && !eigj && !hky_fused(ctx) && !folds) PML_TRY(run_prep(ctx, force_prep));
+        // the fused eigen sweeps build P(t) themselves, the two-GEMM sweeps never need it
+        if (!eig && !gemm && !eigj && !hky_fused(ctx)) PML_TRY(run_prep(ctx, force_prep));
     }
     PML_TRY(prof_begin(ctx));
     const bool fused = is_marginal && ctx->kind == PML_MODEL_F81;
@@ -1915,20 +1873,16 @@ static int enqueue_bottom_up(pml_ctx* ctx, int is_marginal, bool small_path, boo
     } else if (fused) {
         const int nl = (int)ctx->bu_offsets_f.size() - 1;
         const int tail = narrow_levels(ctx->bu_offsets_f, nl, false, ctx->C);
-        ctx->fold_launch = f81_fold(ctx);
-        int status = PML_OK;
-        for (int l = 0; l < nl - tail && status == PML_OK; ++l) {
+        for (int l = 0; l < nl - tail; ++l) {
             const int a = ctx->bu_offsets_f[l], b = ctx->bu_offsets_f[l + 1];
-            status = dispatch_sweep(ctx, ctx->bu_level_vec_f[l] ? SW_BU_MARG_FUSED : SW_BU_MARG_FUSED_NOVEC,
-                                    ctx->d_bu_order_f + a, b - a);
+            PML_TRY(dispatch_sweep(ctx, ctx->bu_level_vec_f[l] ? SW_BU_MARG_FUSED : SW_BU_MARG_FUSED_NOVEC,
+                                   ctx->d_bu_order_f + a, b - a));
         }
-        if (status == PML_OK) status = prof_end(ctx, 0, nl - tail);  // the profile brackets the level kernel's launches only
-        if (status == PML_OK && tail > 0) {  // the levels next to the roots and ln L in one launch
-            status = dispatch_small_f81(ctx, true, 0, nl - tail, tail);
+        PML_TRY(prof_end(ctx, 0, nl - tail));  // the profile brackets the level kernel's launches only
+        if (tail > 0) {  // the levels next to the roots and ln L in one launch
+            PML_TRY(dispatch_small_f81(ctx, true, 0, nl - tail, tail));
             loglik_done = true;
         }
-        ctx->fold_launch = false;
-        PML_TRY(status);
     } else if (!is_marginal && ctx->kind == PML_MODEL_F81 && ctx->fuse && !ctx->has_init && ctx->n_cherries > 0 &&
                ctx->W == 1) {
         // joint sweep over the cherry-fused lists (no altered nodes whose tables would need rewriting)
@@ -2031,7 +1985,7 @@ static int submit_bottom_up(pml_ctx* ctx, int is_marginal) {
         PML_TRY(dev_alloc(ctx, &ctx->d_js, CN));
     }
     const bool no_p = eigen_fused(ctx) || (is_marginal && eigen_gemm(ctx)) || (!is_marginal && eigen_joint_valu(ctx)) ||
-                      hky_fused(ctx) || (is_marginal && !small_path && f81_fold(ctx) && !block_schedule(ctx));
+                      hky_fused(ctx);
     if (eigen_fused(ctx) || eigen_gemm(ctx) || eigen_joint_valu(ctx)) {
         if (!ctx->d_msg) PML_TRY(dev_alloc(ctx, &ctx->d_msg, CN * ctx->ks));
     }
@@ -2119,13 +2073,6 @@ static int run_top_down(pml_ctx* ctx) {
             PML_TRY(prof_end(ctx, 1, n_launch + 1));
             return PML_OK;
         }
-        // F81 family, level schedule: per-branch data formed in the gathers, as in the bottom-up sweep of this schedule
-        // (always: the launches may be replayed from a captured graph, whatever is in E by then)
-        struct FoldScope {
-            pml_ctx* c;
-            ~FoldScope() { c->fold_launch = false; }
-        } fold_scope{ctx};
-        ctx->fold_launch = td_fused && !td_small && f81_fold(ctx);
         // F81 family: the roots and the levels right below them in one launch
         const int head = (td_fused && !td_small && ctx->n_roots <= 64)
                              ? narrow_levels(ctx->td_parent_offsets_f, ctx->n_td_levels, true, ctx->C) : 0;
@@ -2220,7 +2167,6 @@ static int materialize_td(pml_ctx* ctx) {
     if (!ctx->td_filled) {
         const bool f81 = ctx->kind == PML_MODEL_F81;
         if (f81) {
-            PML_TRY(run_prep(ctx));              // E and the tips' S (a folded sweep left none in memory)
             PML_TRY(materialize_cherries(ctx));  // the cherries' bottom-up vectors
         } else {
             PML_TRY(run_prep(ctx, ctx->d_P == nullptr || eigen_fused(ctx) || eigen_gemm(ctx)));  // P(t) of every branch in HBM
@@ -2485,7 +2431,6 @@ static int fetch_exponents(pml_ctx* ctx, const i64* src, int col, double* out) {
 // after a fused sweep the cherries' bottom-up vectors only ever existed in registers: compute them for inspection
 static int materialize_cherries(pml_ctx* ctx) {
     if (!ctx->bu_fused) return PML_OK;
-    if (ctx->kind == PML_MODEL_F81) PML_TRY(run_prep(ctx));  // (a folded sweep left no E in memory)
     PML_TRY(dispatch_sweep(ctx, ctx->bu_fused_joint ? SW_BU_CHERRIES_JOINT : SW_BU_CHERRIES, ctx->d_cherries,
                            ctx->n_cherries));
     HIP_TRY(hipStreamSynchronize(ctx->stream));

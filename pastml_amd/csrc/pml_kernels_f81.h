@@ -35,9 +35,6 @@ struct PmlCols {
     const u64* masks;       // [C][N][W]
     const u64* masks_init;  // [C][N][W] or nullptr
     const double* pi;       // [C][ks]
-    // F81 family, per column: mu, scaling factor, tau, tau factor and sum(pi) in ascending state order -- what the sweeps
-    // need to form e = exp(-mu t') and a tip's S = pi . mask themselves when the per-branch pass is folded into them
-    const double *mu, *sf, *tau, *tauf, *sumpi;
 };
 
 struct PmlState {
@@ -139,15 +136,6 @@ struct LaneCtx {
     int* stst;
     double* ssum;  // staged lhsum / lhe of the six slots (null: not staged)
     i64* sexp;
-    // Folded per-branch data (level kernels of large forests, single-word masks): no f81_prep_kernel pass, E and the
-    // tips' S are never in memory -- the lane that gathers a child / tip loads its branch length instead of E (same
-    // load, other array) and forms e = exp(-mu t') itself, one exp for 64 different branches per wave instruction;
-    // a tip's S = pi . mask comes from the mask word and a copy of pi in LDS.  Same expressions as f81_prep_kernel:
-    // the bits of the stored arrays.
-    bool fold;
-    const double* esrc;  // what a branch's "E" load reads: E, or the branch lengths when folded
-    double c_mu, c_sf, c_tau, c_tauf, sumpi;
-    const double* lpi;   // the column's pi in LDS (folded) or in global memory
     __device__ __forceinline__ int st(int r) const { return R == 1 ? g : ((r >> 1) * 2 * G + 2 * g + (r & 1)); }
 };
 
@@ -177,10 +165,6 @@ __device__ __forceinline__ void lane_ctx_init(LaneCtx<G, R>& L, const PmlTree& t
     L.stst = nullptr;
     L.ssum = nullptr;
     L.sexp = nullptr;
-    L.fold = false;
-    L.esrc = L.E;
-    L.c_mu = L.c_sf = L.c_tau = L.c_tauf = L.sumpi = 0.0;
-    L.lpi = L.pi;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         L.pi_r[r] = (L.st(r) < c.k) ? c.pi[(size_t)L.col * c.ks + L.st(r)] : 0.0;
@@ -189,57 +173,6 @@ __device__ __forceinline__ void lane_ctx_init(LaneCtx<G, R>& L, const PmlTree& t
 }
 
 __device__ __forceinline__ u64 state_bits(int k) { return k >= 64 ? ~0ull : (1ull << k) - 1ull; }
-
-// Switches a lane context to folded per-branch data.  lds_pi: PML_FOLD_PI doubles of LDS of the workgroup, filled here
-// (the caller's workgroup must reach this call as a whole: it contains a barrier).
-#define PML_FOLD_PI 64
-template <int G, int R>
-__device__ __forceinline__ void lane_ctx_fold(LaneCtx<G, R>& L, const PmlTree& t, const PmlCols& c, double* lds_pi) {
-    for (int i = threadIdx.x; i < PML_FOLD_PI; i += blockDim.x) lds_pi[i] = i < c.ks ? L.pi[i] : 0.0;
-    __syncthreads();
-    L.fold = true;
-    L.esrc = t.dist;
-    L.c_mu = c.mu[L.col];
-    L.c_sf = c.sf[L.col];
-    L.c_tau = c.tau[L.col];
-    L.c_tauf = c.tauf[L.col];
-    L.sumpi = c.sumpi[L.col];
-    L.lpi = lds_pi;
-}
-
-// e of a branch from what the "E" load returned: E itself, or the branch length (folded; the expression of
-// f81_prep_kernel, models/__init__.py:269 + F81Model.py:42-45)
-template <int G, int R>
-__device__ __forceinline__ double branch_e(const LaneCtx<G, R>& L, double x) {
-    if (!L.fold) return x;
-    const double tt = (x + L.c_tau) * L.c_tauf * L.c_sf;
-    return isinf(L.c_mu) ? 0.0 : exp(-L.c_mu * tt);
-}
-
-// S = pi . mask of a tip from its mask word (bits >= k clear; folded contexts have single-word masks): the sum of
-// f81_prep_kernel in its order -- ascending states from 0.0 -- so one allowed state gives pi_s and a tip without data
-// the column's sum(pi), both without a loop
-template <int G, int R>
-__device__ __forceinline__ double tip_s_word(const LaneCtx<G, R>& L, u64 word) {
-    if (__popcll(word) == 1) return L.lpi[__builtin_ctzll(word)];
-    if (word == state_bits(L.k)) return L.sumpi;
-    double acc = 0.0;
-    while (word) {
-        acc += L.lpi[__builtin_ctzll(word)];
-        word &= word - 1ull;
-    }
-    return acc;
-}
-
-// e of node n's branch / S of tip n, whatever the context (sequential paths)
-template <int G, int R>
-__device__ __forceinline__ double node_e(const LaneCtx<G, R>& L, int n) {
-    return branch_e<G, R>(L, L.esrc[n]);
-}
-template <int G, int R>
-__device__ __forceinline__ double tip_s(const LaneCtx<G, R>& L, int n) {
-    return L.fold ? tip_s_word<G, R>(L, L.mask[(unsigned)n] & state_bits(L.k)) : L.S[n];
-}
 
 template <int G, int R>
 __device__ __forceinline__ void node_load_vec(const LaneCtx<G, R>& L, const PmlCols& c, const double* base, int n,
@@ -475,7 +408,7 @@ __device__ __forceinline__ void f81_cherry_vector(const LaneCtx<G, R>& L, const 
         const int ch = fc + j;
         double v[R];
         node_mask_vec<G, R>(L, c, ch, v);
-        f81_absorb_child<G, R>(L, t, st, n, ch, node_e<G, R>(L, ch), tip_s<G, R>(L, ch), v, acc, report);
+        f81_absorb_child<G, R>(L, t, st, n, ch, L.E[ch], L.S[ch], v, acc, report);
         if ((j & 3) == 3 || j == nc - 1) esum += lazy_rescale<G, R>(acc);
     }
 }
@@ -595,7 +528,7 @@ __device__ __forceinline__ void f81_gather_issue(const LaneCtx<G, R>& L, const U
     const int nc = unit_nc(u.packed);
     const int j = L.g;
     const int ch = u.fc + (j < nc ? j : 0);
-    cl.e = L.esrc[ch];
+    cl.e = L.E[ch];
     cl.s = L.S[ch];
     cl.mask = L.mask[(unsigned)ch];
     cl.be = L.be[ch];
@@ -608,36 +541,24 @@ __device__ __forceinline__ void f81_gather_issue(const LaneCtx<G, R>& L, const U
     const int code = unit_code(u.packed, jj & 3);
     const bool has_t = jj < nc && q < code - 1;  // code - 1 = number of tips of a cherry child (<= 0 otherwise)
     const int tip = has_t ? u.cfc + q : u.fc;
-    tl.e = L.esrc[tip];
-    tl.s = L.fold ? 0.0 : L.S[tip];
+    tl.e = L.E[tip];
+    tl.s = L.S[tip];
     tl.mask = L.mask[(unsigned)tip];
 }
 
 // the part of the gather that needs the loaded values (kept apart so that the loads can be issued one unit ahead)
-template <int G, int R, bool TIPS_OF_CHERRIES = true>
-__device__ __forceinline__ void f81_gather_finish(const LaneCtx<G, R>& L, const UnitRegs& u, ChildLane& cl,
-                                                  TipLane& tl) {
+template <int G, int R>
+__device__ __forceinline__ void f81_gather_finish(const LaneCtx<G, R>& L, ChildLane& cl, TipLane& tl) {
     const u64 kbits = state_bits(L.k);
     cl.mask &= kbits;
-    tl.mask &= kbits;
-    if (L.fold) {
-        // the loads brought branch lengths: every lane turns the one of its child and the one of its tip into e (the
-        // lanes of a wave hold up to 64 different branches per exp), and forms S = pi . mask of its tip (and of its
-        // child where that is a tip; stored children have theirs in memory, cherries get theirs from the unit)
-        cl.e = branch_e<G, R>(L, cl.e);
-        if (unit_code(u.packed, L.g & 3) == 0 && L.g < 4) cl.s = tip_s_word<G, R>(L, cl.mask);
-        if (TIPS_OF_CHERRIES) {
-            tl.e = branch_e<G, R>(L, tl.e);
-            tl.s = tip_s_word<G, R>(L, tl.mask);
-        }
-    }
     tl.a = (1.0 - tl.e) * tl.s;
+    tl.mask &= kbits;
 }
 
 template <int G, int R>
 __device__ __forceinline__ void f81_gather(const LaneCtx<G, R>& L, const UnitRegs& u, ChildLane& cl, TipLane& tl) {
     f81_gather_issue<G, R>(L, u, cl, tl);
-    f81_gather_finish<G, R>(L, u, cl, tl);
+    f81_gather_finish<G, R>(L, cl, tl);
 }
 
 // out[r] = a + e * [state st(r) allowed by word] without forming the 0/1 vector: the two possible values are a (the fused
@@ -920,7 +841,7 @@ __device__ __forceinline__ bool bu_f81_unit_fast(const LaneCtx<G, R>& L, const P
     word_to_vec<G, R>(L, c, ld.own, acc);
     ChildLane& cl = ld.cl;
     TipLane& tl = ld.tl;
-    f81_gather_finish<G, R>(L, u, cl, tl);
+    f81_gather_finish<G, R>(L, cl, tl);
     if (!JOINT) {
         // every mask that would only contribute a vector of ones?  (own mask; masks of the cherry children.  Lanes
         // beyond the children hold child 0's data again.)  Wave-uniform over the units that take this path.
@@ -1084,14 +1005,14 @@ __device__ __forceinline__ void bu_f81_unit_seq(const LaneCtx<G, R>& L, const Pm
     if (nc == 15) nc = t.n_children[n];  // the descriptor counts up to 14
     for (int j = 0; j < nc; ++j) {
         const int ch = fc + j;
-        const double e = node_e<G, R>(L, ch);
+        const double e = L.E[ch];
         const ChildDesc cd = unit_child<G>(t, u, j, ch);
         const int kd = cd.kind;
         double v[R];
         double s_child = 0.0;
         if (kd == PML_KIND_TIP) {
             node_mask_vec<G, R>(L, c, ch, v);
-            if (!JOINT) s_child = tip_s<G, R>(L, ch);
+            if (!JOINT) s_child = L.S[ch];
         } else if (kd == PML_KIND_STORED) {
             node_load_vec<G, R>(L, c, L.bu, ch, v);
             esum += L.be[ch];
@@ -1107,7 +1028,7 @@ __device__ __forceinline__ void bu_f81_unit_seq(const LaneCtx<G, R>& L, const Pm
                 double tv[R], tmsg[R];
                 int tj[R];
                 node_mask_vec<G, R>(L, c, tip, tv);
-                f81_joint_message<G, R>(L, c, node_e<G, R>(L, tip), tv, tmsg, tj);
+                f81_joint_message<G, R>(L, c, L.E[tip], tv, tmsg, tj);
                 bool tnz = false;
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
@@ -1180,17 +1101,14 @@ __device__ __forceinline__ void bu_f81_unit_seq(const LaneCtx<G, R>& L, const Pm
 // i + 2 are in flight, so a wave waits for memory once per sweep of its units instead of once per unit (the level that
 // rebuilds cherries spent 65 % of its wave cycles in s_waitcnt before).  The two halves of the loop body ping-pong
 // between two register sets instead of copying one into the other.
-// FOLD: no f81_prep_kernel pass ran -- the gathers form e = exp(-mu t') and the tips' S themselves (LaneCtx::fold).
-template <int G, int R, bool JOINT, bool VEC, bool FOLD = false>
+template <int G, int R, bool JOINT, bool VEC>
 __global__ void __launch_bounds__(PML_BLOCK) __attribute__((amdgpu_waves_per_eu(R >= 8 ? 2 : 3, R >= 8 ? 2 : 4)))
 bu_f81_kernel(PmlTree t, PmlCols c, PmlState st, const PmlUnit* __restrict__ units, int n_level) {
-    __shared__ double fold_pi[FOLD ? PML_FOLD_PI : 1];
     constexpr int UW = 64 / G;  // units per wave
     const int wave = threadIdx.x >> 6;
     const int sub = (threadIdx.x & 63) / G;
     LaneCtx<G, R> L;
     lane_ctx_init<G, R>(L, t, c, st);
-    if (FOLD) lane_ctx_fold<G, R>(L, t, c, fold_pi);
     const int stride = gridDim.x * PML_WAVES_PER_BLOCK * UW;
     int idx = (blockIdx.x * PML_WAVES_PER_BLOCK + wave) * UW + sub;
     int base = idx - sub;  // wave-uniform trip count; whole groups drop out together
@@ -1349,8 +1267,8 @@ __device__ __forceinline__ void f81_finish_tip_word(const LaneCtx<G, R>& L, cons
 template <int G, int R>
 __device__ __forceinline__ void f81_finish_tip(const LaneCtx<G, R>& L, const PmlCols& c, const double (&prod)[R], i64 pe,
                                                double& P, bool& have_P, int tip, int slot = -1) {
-    const double e = node_e<G, R>(L, tip);
-    const double pis = tip_s<G, R>(L, tip);
+    const double e = L.E[tip];
+    const double pis = L.S[tip];
     if (c.W == 1) {
         f81_finish_tip_word<G, R>(L, c, prod, pe, P, have_P, tip, L.mask[(unsigned)tip] & state_bits(c.k), e, pis,
                                   slot);
@@ -1377,7 +1295,7 @@ __device__ __forceinline__ void td_f81_unit_fast(const LaneCtx<G, R>& L, const P
     f81_gather_issue<G, R>(L, u, cl, tl);
     double vn[R];
     if (unit_code(u.packed, 0) == 1) node_load_vec<G, R>(L, c, L.bu, fc, vn);
-    f81_gather_finish<G, R>(L, u, cl, tl);  // (after the last load is out: folded, it waits for the gathered values)
+    f81_gather_finish<G, R>(L, cl, tl);
     double P = 0.0;
     bool have_P = false;
     for (int jx = 0; jx < nc; ++jx) {
@@ -1461,7 +1379,7 @@ __device__ __forceinline__ void td_f81_unit(const LaneCtx<G, R>& L, const PmlTre
             f81_finish_tip<G, R>(L, c, prod, pe, P, have_P, ch, slot);
             continue;
         }
-        const double e = node_e<G, R>(L, ch);
+        const double e = L.E[ch];
         double mb[R], v[R], tdc[R], po[R], ls;
         node_mask_vec<G, R>(L, c, ch, mb);
         i64 xe, le;
@@ -1553,17 +1471,15 @@ __device__ __forceinline__ void td_stage_flush(const LaneCtx<G, R>& L, const Pml
 
 // stage: 0 = posteriors straight to memory; bit 0 = rows through the LDS slots, bit 1 = also the two scalars per row,
 // bit 2 = the level has cherries among the first two children of its units (tip slots in use)
-template <int G, int R, bool FOLD = false>
+template <int G, int R>
 __global__ void __launch_bounds__(PML_BLOCK)
 td_f81_kernel(PmlTree t, PmlCols c, PmlState st, const PmlUnit* __restrict__ units, int n_level, int stage) {
     extern __shared__ double td_stage[];
-    __shared__ double fold_pi[FOLD ? PML_FOLD_PI : 1];
     constexpr int UW = 64 / G;
     const int wave = threadIdx.x >> 6;
     const int sub = (threadIdx.x & 63) / G;
     LaneCtx<G, R> L;
     lane_ctx_init<G, R>(L, t, c, st);
-    if (FOLD) lane_ctx_fold<G, R>(L, t, c, fold_pi);
     TdStage S = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     const bool staged = G <= PML_TD_STAGE_MAX_G && (stage & 1) && (c.ks & 1) == 0;
     if (staged) {
@@ -1688,13 +1604,12 @@ __device__ __forceinline__ void walk_levels(const LaneCtx<G, R>& L, const PmlTre
 }
 
 
-template <int G, int R, bool FOLD = false>
+template <int G, int R>
 __global__ void __launch_bounds__(PML_SMALL_BLOCK)
 bu_f81_small_kernel(PmlTree t, PmlCols c, PmlState st, const double* __restrict__ mu, const double* __restrict__ sf,
                     const double* __restrict__ tau, const double* __restrict__ tauf, int do_prep,
                     const PmlUnit* __restrict__ units, const int* __restrict__ level_offsets, int n_levels,
                     double* __restrict__ loglik, u64* __restrict__ err_out, int reset_err) {
-    __shared__ double fold_pi[FOLD ? PML_FOLD_PI : 1];
     const int col = blockIdx.y;
     if (reset_err) {  // whole sweep in this launch: the column's error word is reset here, not by a launch of its own
         if (threadIdx.x == 0) st.err[col] = ~0ull;
@@ -1723,7 +1638,6 @@ bu_f81_small_kernel(PmlTree t, PmlCols c, PmlState st, const double* __restrict_
     }
     LaneCtx<G, R> L;
     lane_ctx_init<G, R>(L, t, c, st);
-    if (FOLD) lane_ctx_fold<G, R>(L, t, c, fold_pi);  // the narrow end of a forest whose level kernels fold
     walk_levels<G, R, true>(L, t, c, st, units, level_offsets, n_levels);
     if (threadIdx.x == 0) {
         // pinned host memory: the results land where the caller reads them
@@ -1781,18 +1695,16 @@ td_f81_roots_kernel(PmlTree t, PmlCols c, PmlState st) {
     }
 }
 
-template <int G, int R, bool FOLD = false>
+template <int G, int R>
 __global__ void __launch_bounds__(PML_SMALL_BLOCK)
 td_f81_small_kernel(PmlTree t, PmlCols c, PmlState st, const PmlUnit* __restrict__ units,
                     const int* __restrict__ level_offsets, int n_levels) {
-    __shared__ double fold_pi[FOLD ? PML_FOLD_PI : 1];
     constexpr int UW = 64 / G;
     const int wave = threadIdx.x >> 6;
     const int n_waves = blockDim.x >> 6;
     const int sub = (threadIdx.x & 63) / G;
     LaneCtx<G, R> L;
     lane_ctx_init<G, R>(L, t, c, st);
-    if (FOLD) lane_ctx_fold<G, R>(L, t, c, fold_pi);
     for (int base = wave * UW; base < t.n_roots; base += n_waves * UW) {
         const int idx = base + sub;
         if (idx < t.n_roots) f81_root_unit<G, R>(L, t, c, st, idx);
