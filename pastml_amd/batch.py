@@ -537,14 +537,193 @@ def block_width(model):
     return n + 1
 
 
-def search_parameters(model, observed_frequencies, evaluate, rng):
+# ---------------------------------------------------------------------------------------------------------------------
+# L-BFGS-B by reverse communication.  scipy.optimize.minimize(method='L-BFGS-B') is a Python loop around the routine
+# ``setulb``, which returns to its caller whenever it wants the function and gradient at a point
+# (scipy/optimize/_lbfgsb_py.py, _minimize_lbfgsb).  Calling ``setulb`` from a *generator* that yields those points gives
+# the same iterates -- same routine, same workspace, same options -- without scipy's callback holding the thread: all
+# characters of a group then advance in ONE loop (optimise_group), a sweep round per step, no thread per character and
+# no hand-offs through the interpreter lock.  The routine is private to scipy; its argument list is checked once and the
+# thread-per-character driver (scipy's own minimize) stays as the fallback.
+# ---------------------------------------------------------------------------------------------------------------------
+def _probe_setulb():
+    if os.environ.get('PASTML_AMD_LBFGSB_THREADS'):
+        return None
+    try:
+        from scipy.optimize import _lbfgsb
+        doc = (_lbfgsb.setulb.__doc__ or '').replace(' ', '')
+        if 'setulb(m,x,l,u,nbd,f,g,factr,pgtol,wa,iwa,task,lsave,isave,dsave,maxls,ln_task)' in doc:
+            return _lbfgsb.setulb
+    except Exception:  # pragma: no cover - depends on the SciPy build
+        pass
+    return None
+
+
+_setulb = _probe_setulb()
+
+
+def single_loop_optimiser_available():
+    return _setulb is not None and batched_gradients_available()
+
+
+class _Found(object):
+    """What the search looks at in scipy's OptimizeResult."""
+    __slots__ = ('x', 'fun', 'success', 'nit', 'nfev')
+
+    def __init__(self, x, fun, success, nit, nfev):
+        self.x, self.fun, self.success, self.nit, self.nfev = x, fun, success, nit, nfev
+
+
+def lbfgsb_steps(x0, bounds):
+    """
+    Generator form of ``minimize(fun, x0, method='L-BFGS-B', bounds=bounds, jac=True)`` with scipy's default options
+    (maxcor 10, ftol 2.22e-9, gtol 1e-5, maxfun = maxiter = 15000, maxls 20): yields the points at which it needs
+    (f, gradient) and is sent the pair; its return value (StopIteration.value) carries x, fun, success.
+    As in scipy, the function is evaluated once at the (clipped) starting point before the routine is entered, and a
+    request for the point evaluated last is served from memory (ScalarFunction / MemoizeJac).
+    """
+    m, factr, pgtol, maxfun, maxiter, maxls = 10, 2.220446049250313e-09 / np.finfo(float).eps, 1e-5, 15000, 15000, 20
+    bounds = np.asarray(bounds, dtype=np.float64)
+    low, up = bounds[:, 0], bounds[:, 1]
+    x0 = np.clip(np.asarray(x0, dtype=np.float64).ravel(), low, up)
+    n = len(x0)
+    nbd = np.zeros(n, np.int32)
+    low_bnd = np.zeros(n, np.float64)
+    upper_bnd = np.zeros(n, np.float64)
+    for i in range(n):
+        has_low, has_up = not np.isinf(low[i]), not np.isinf(up[i])
+        if has_low:
+            low_bnd[i] = low[i]
+        if has_up:
+            upper_bnd[i] = up[i]
+        nbd[i] = 2 if (has_low and has_up) else 1 if has_low else 3 if has_up else 0
+    at = np.array(x0, dtype=np.float64)            # the point whose values are in f, g
+    f, g = yield at.copy()
+    nfev = 1
+    g = np.asarray(g, dtype=np.float64)
+    x = np.array(x0, dtype=np.float64)
+    wa = np.zeros(2 * m * n + 5 * n + 11 * m * m + 8 * m, np.float64)
+    iwa = np.zeros(3 * n, dtype=np.int32)
+    task = np.zeros(2, dtype=np.int32)
+    ln_task = np.zeros(2, dtype=np.int32)
+    lsave = np.zeros(4, dtype=np.int32)
+    isave = np.zeros(44, dtype=np.int32)
+    dsave = np.zeros(29, dtype=np.float64)
+    fx, gx = np.array(0.0, dtype=np.int32), np.zeros((n,), dtype=np.int32)   # (scipy enters with these placeholders)
+    n_iterations = 0
+    while True:
+        gx = np.asarray(gx).astype(np.float64)
+        _setulb(m, x, low_bnd, upper_bnd, nbd, fx, gx, factr, pgtol, wa, iwa, task, lsave, isave, dsave, maxls, ln_task)
+        if task[0] == 3:
+            if not np.array_equal(x, at):
+                at = np.array(x, dtype=np.float64)
+                f, g = yield at.copy()
+                g = np.asarray(g, dtype=np.float64)
+                nfev += 1
+            fx, gx = f, g
+        elif task[0] == 1:
+            n_iterations += 1
+            if n_iterations >= maxiter:
+                task[0], task[1] = 5, 504
+            elif nfev > maxfun:
+                task[0], task[1] = 5, 502
+        else:
+            break
+    return _Found(x, fx, task[0] == 4, n_iterations, nfev)
+
+
+def _drive(steps, evaluate):
+    """Runs a generator of likelihood requests to its end against a synchronous evaluator; returns its value."""
+    try:
+        request = next(steps)
+        while True:
+            request = steps.send(evaluate(request))
+    except StopIteration as stop:
+        return stop.value
+
+
+def search_parameters_steps(model, observed_frequencies, rng):
     """
     One L-BFGS-B search over the model's currently free parameters (the procedure of pastml/ml.py:174-237): it starts
     from the current values, then -- if frequencies are free -- from the observed frequencies, then from up to 98
     uniform draws inside the bounds, and stops at the first start whose optimum is at least as good as the better of the
     first two starting likelihoods; if none is, the better starting point is kept.
-    ``evaluate(list of parameter vectors)`` -> list of ln L (one batched sweep); the model is left at the optimum.
+    Generator: yields lists of parameter vectors, is sent their ln L (one batched sweep each); returns ln L at the
+    optimum, where the model is left.
     """
+    bounds = model.get_bounds()
+    lower, upper = bounds[:, 0], bounds[:, 1]
+
+    def negative(values):
+        return [np.inf if pd.isnull(v) else -v for v in values]
+
+    def objective(ps):
+        if np.any(pd.isnull(ps)):
+            return np.nan
+        values = yield [np.asarray(ps, dtype=np.float64)]
+        return negative(values)[0]
+
+    def objective_and_gradient(ps):
+        # the 2-point scheme scipy would apply itself (absolute step 1e-8, steps mirrored at the bounds): a first pass
+        # of its own helper records the points it asks for, the batch evaluates them together, a second pass runs on
+        # the table of their values -- points and arithmetic are scipy's
+        ps = np.asarray(ps, dtype=np.float64)
+        if np.any(pd.isnull(ps)):
+            return np.nan, np.full(len(ps), np.nan)
+        asked = []
+        _approx_derivative(lambda x: asked.append(np.array(x, dtype=np.float64)) or 0.0, ps, method='2-point',
+                           abs_step=1e-8, f0=0.0, bounds=(lower, upper))
+        values = yield [ps] + asked
+        values = negative(values)
+        table = {x.tobytes(): v for x, v in zip(asked, values[1:])}
+        gradient = _approx_derivative(lambda x: table[np.asarray(x, dtype=np.float64).tobytes()], ps,
+                                      method='2-point', abs_step=1e-8, f0=values[0], bounds=(lower, upper))
+        return values[0], gradient
+
+    from pastml_amd.models import ModelWithFrequencies
+    frequencies_free = isinstance(model, ModelWithFrequencies) and model._optimise_frequencies
+    start_current = model.get_optimised_parameters()
+    start_observed = start_current
+    if frequencies_free:
+        model.frequencies = np.maximum(observed_frequencies, 1e-10) if np.any(observed_frequencies <= 0) \
+            else observed_frequencies
+        start_observed = model.get_optimised_parameters()
+    lnl_current = -(yield from objective(start_current))
+    lnl_observed = -(yield from objective(start_observed)) if frequencies_free else lnl_current
+    to_beat = max(lnl_current, lnl_observed)
+    for attempt in range(100):
+        if attempt == 0:
+            x0 = start_current
+        elif attempt == 1 and frequencies_free:
+            x0 = start_observed
+        else:
+            x0 = rng.uniform(lower, upper)
+        search = lbfgsb_steps(x0, bounds)
+        try:
+            point = next(search)
+            while True:
+                point = search.send((yield from objective_and_gradient(point)))
+        except StopIteration as stop:
+            found = stop.value
+        if found.success and not np.any(np.isnan(found.x)) and -found.fun >= to_beat:
+            model.set_params_from_optimised(found.x)
+            return -found.fun
+    model.set_params_from_optimised(start_current if lnl_current >= lnl_observed else start_observed)
+    return to_beat
+
+
+def search_parameters(model, observed_frequencies, evaluate, rng):
+    """
+    Synchronous form of search_parameters_steps: ``evaluate(list of parameter vectors)`` -> list of ln L.  Without the
+    reverse-communication routine (other SciPy builds) the search runs through scipy's own minimize.
+    """
+    if single_loop_optimiser_available():
+        return _drive(search_parameters_steps(model, observed_frequencies, rng), evaluate)
+    return _search_parameters_scipy(model, observed_frequencies, evaluate, rng)
+
+
+def _search_parameters_scipy(model, observed_frequencies, evaluate, rng):
+    """The search of search_parameters_steps with scipy.optimize.minimize as the inner loop (fallback)."""
     from scipy.optimize import minimize
     from pastml_amd.models import ModelWithFrequencies
     bounds = model.get_bounds()
@@ -559,9 +738,6 @@ def search_parameters(model, observed_frequencies, evaluate, rng):
         return negative(evaluate([np.asarray(ps, dtype=np.float64)]))[0]
 
     def objective_and_gradient(ps):
-        # the 2-point scheme scipy would apply itself (absolute step 1e-8, steps mirrored at the bounds): a first pass
-        # of its own helper records the points it asks for, the batch evaluates them together, a second pass runs on
-        # the table of their values -- points and arithmetic are scipy's
         ps = np.asarray(ps, dtype=np.float64)
         if np.any(pd.isnull(ps)):
             return np.nan, np.full(len(ps), np.nan)
@@ -603,10 +779,12 @@ def search_parameters(model, observed_frequencies, evaluate, rng):
     return to_beat
 
 
-def fit_parameters(character, model, observed_frequencies, evaluate, rng):
+def fit_parameters_steps(character, model, observed_frequencies, rng, search=None):
     """
     Likelihood at the given parameters, then -- if anything is free -- the scaling / smoothing factors alone, then all
-    free parameters together (the two stages of pastml/ml.py:865-920).  Returns ln L at the optimum.
+    free parameters together (the two stages of pastml/ml.py:865-920).  Generator: yields lists of
+    (kernel description, rate parameters), is sent their ln L; returns ln L at the optimum.
+    ``search``: a synchronous replacement for the inner search (the fallback driver), given the point evaluator.
     """
     from pastml_amd.ml import PastMLLikelihoodError
     logger = logging.getLogger('pastml')
@@ -617,14 +795,25 @@ def fit_parameters(character, model, observed_frequencies, evaluate, rng):
     def report(title, text, lnl):
         logger.debug('{} for {}:\n{}{}'.format(title, character, text, '\tlog likelihood:\t{:.6f}'.format(lnl)))
 
-    def evaluate_vectors(vectors):
+    def points_of(vectors):
         points = []
         for ps in vectors:
             model.set_params_from_optimised(ps)
             points.append((model.kernel_spec(), model.rate_params()))
-        return evaluate(points)
+        return points
 
-    lnl = float(evaluate([(model.kernel_spec(), model.rate_params())])[0])
+    def run_search():
+        if search is not None:
+            return search(points_of)
+        steps = search_parameters_steps(model, observed_frequencies, rng)
+        try:
+            vectors = next(steps)
+            while True:
+                vectors = steps.send((yield points_of(vectors)))
+        except StopIteration as stop:
+            return stop.value
+
+    lnl = float((yield [(model.kernel_spec(), model.rate_params())])[0])
     if np.isnan(lnl):
         raise PastMLLikelihoodError(trouble.format('calculate', character))
     if not model.get_num_params():
@@ -634,7 +823,7 @@ def fit_parameters(character, model, observed_frequencies, evaluate, rng):
     if not model.basic_params_fixed():
         model.fix_extra_params()
         try:
-            lnl = search_parameters(model, observed_frequencies, evaluate_vectors, rng)
+            lnl = yield from run_search()
         finally:
             model.unfix_extra_params()
         if np.isnan(lnl) or lnl == -np.inf:
@@ -642,11 +831,20 @@ def fit_parameters(character, model, observed_frequencies, evaluate, rng):
         if not model.extra_params_fixed():
             report('Pre-optimised basic parameters', model._print_basic_parameters(), lnl)
     if not model.extra_params_fixed():
-        lnl = search_parameters(model, observed_frequencies, evaluate_vectors, rng)
+        lnl = yield from run_search()
         if np.isnan(lnl) or lnl == -np.inf:
             raise PastMLLikelihoodError(trouble.format('calculate', character))
     report('Optimised parameters', model._print_parameters(), lnl)
     return lnl
+
+
+def fit_parameters(character, model, observed_frequencies, evaluate, rng):
+    """Synchronous form of fit_parameters_steps: ``evaluate(list of (kernel description, rates))`` -> ln L array."""
+    search = None
+    if not single_loop_optimiser_available():
+        def search(points_of):
+            return _search_parameters_scipy(model, observed_frequencies, lambda vectors: evaluate(points_of(vectors)), rng)
+    return _drive(fit_parameters_steps(character, model, observed_frequencies, rng, search), evaluate)
 
 
 # =====================================================================================================================
@@ -677,14 +875,63 @@ def likelihood_error(flat, e):
 
 
 def optimise_group(batch, tasks, seeds=None):
-    """Parameters of every character of the batch, all optimisers advancing together (SweepServer).  Returns ln L [m]."""
+    """
+    Parameters of every character of the batch, all optimisers advancing together: ONE loop steps every character's
+    search (fit_parameters_steps) to its next likelihood request, a single batched sweep serves them all, and so on until
+    the last search has ended -- a run costs the rounds of its slowest character, and no interpreter thread per
+    character.  Returns (ln L [m], sweep rounds).
+    """
+    m = len(tasks)
+    # restart points come from per-character generators seeded, in character order, from numpy's global one: the
+    # optimisers advance together, a shared generator would hand its draws out in an order that depends on the batch
+    if seeds is None:
+        seeds = np.random.randint(0, 2 ** 31 - 1, size=m)
+    if not single_loop_optimiser_available():
+        return _optimise_group_threads(batch, tasks, seeds)
+    batch.open_optimiser([block_width(t.model) for t in tasks])
+    lnl = np.full(m, np.nan)
+    errors = {}
+    searches = [fit_parameters_steps(t.character, t.model, t.observed_frequencies, np.random.RandomState(seeds[c]))
+                for c, t in enumerate(tasks)]
+    pending = {}
+
+    def advance(c, step):
+        # runs character c's search up to its next request (or its end / failure)
+        try:
+            pending[c] = step()
+        except StopIteration as stop:
+            lnl[c] = stop.value
+        except BaseException as e:  # delivered to the caller after all searches are done
+            errors[c] = e
+
+    for c in range(m):
+        advance(c, lambda: next(searches[c]))
+    rounds = 0
+    while pending:
+        requests, pending = pending, {}
+        try:
+            out = batch.evaluate_points(requests)
+        except Exception as e:  # a failure of the sweep itself reaches every character that asked
+            out = {c: e for c in requests}
+        rounds += 1
+        for c, res in out.items():
+            if isinstance(res, Exception):
+                advance(c, lambda: searches[c].throw(res))
+            else:
+                advance(c, lambda: searches[c].send(res))
+    hip.release_engine(batch._opt['engine'])
+    batch._opt = None
+    if errors:
+        e = errors[min(errors)]
+        raise likelihood_error(batch.flat, e) if isinstance(e, LikelihoodError) else e
+    return lnl, rounds
+
+
+def _optimise_group_threads(batch, tasks, seeds):
+    """Fallback driver (scipy's own minimize, which holds its thread): one thread per character, met in SweepServer."""
     m = len(tasks)
     batch.open_optimiser([block_width(t.model) for t in tasks])
     server = SweepServer(batch, range(m))
-    # restart points come from per-character generators seeded, in character order, from numpy's global one: the
-    # optimisers run concurrently, a shared generator would hand its draws out in arrival order
-    if seeds is None:
-        seeds = np.random.randint(0, 2 ** 31 - 1, size=m)
     lnl = np.full(m, np.nan)
     errors = {}
 

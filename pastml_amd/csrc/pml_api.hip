@@ -140,6 +140,8 @@ struct pml_ctx {
         bool has_init = false;
     };
     GraphSlot bu_graph[2], td_graph, bt_graph;
+    GraphSlot mp_graph;            // bottom-up + top-down of pml_marginal_pass as ONE graph
+    bool in_outer_capture = false; // the sweeps are being captured into mp_graph: no graphs of their own
     bool graphs = true;
     double* h_loglik = nullptr;  // pinned staging of the per-column results
     // pi, sf, tau, tau factor, mu, kappa of all columns live in ONE device block with a pinned host mirror of the same
@@ -183,6 +185,7 @@ static void free_all(pml_ctx* ctx) {
     drop_graph(ctx->bu_graph[0]);
     drop_graph(ctx->bu_graph[1]);
     drop_graph(ctx->td_graph);
+    drop_graph(ctx->mp_graph);
     drop_graph(ctx->bt_graph);
     if (ctx->h_loglik) (void)hipHostFree(ctx->h_loglik);
     if (ctx->h_err) (void)hipHostFree(ctx->h_err);
@@ -240,11 +243,12 @@ static bool single_launch_sweeps(const pml_ctx* c) {
 // the level kernels, which spread every level over all compute units, win again.
 static bool block_schedule(const pml_ctx* c) {
     static const long long limit = getenv("PASTML_HIP_BLOCK_MAX_WORK") ? atoll(getenv("PASTML_HIP_BLOCK_MAX_WORK")) : 160000;
-    // ragged trees give many shallow-filled blocks (HIV1C: 45 blocks of 505 levels for 2 455 stored nodes, a balanced tree
-    // 8 levels per 255 nodes): each (block, level, column) is a workgroup step of a few microseconds whatever it holds,
-    // so with many columns the level kernels, which pack a level of all columns densely, are ahead (HIV1C, k = 64:
-    // 16 columns 0.68 against 0.71 ms for a marginal pass, 64 columns 1.46 against 0.81)
-    static const long long steps = getenv("PASTML_HIP_BLOCK_MAX_STEPS") ? atoll(getenv("PASTML_HIP_BLOCK_MAX_STEPS")) : 8192;
+    // (Round 2 also capped the number of (block, level, column) workgroup steps: with 512-thread workgroups a ragged tree
+    // times many columns ran in rounds of long-lived workgroups and lost to the level kernels.  The workgroups now
+    // shrink until all are resident (launch_blocks_f81) and the blocks end below the top's lowest level
+    // (pml_tree_upload): over scripts/schedule_sweep.py's grid the blocks never lose -- profiles/r03c_schedule_sweep.txt.
+    // PASTML_HIP_BLOCK_MAX_STEPS is kept as a switch.)
+    static const long long steps = getenv("PASTML_HIP_BLOCK_MAX_STEPS") ? atoll(getenv("PASTML_HIP_BLOCK_MAX_STEPS")) : (1ll << 40);
     return c->blocks.ok && !c->bu_offsets_f.empty() && (long long)c->bu_offsets_f.back() * c->C <= limit &&
            c->blocks.steps * c->C <= steps;
 }
@@ -549,7 +553,29 @@ static void launch_blocks_f81(pml_ctx* ctx, bool bottom_up) {
     const PmlCols c = cols_of(ctx);
     const PmlState st = state_of(ctx);
     const pml_ctx::BlockSchedule& B = ctx->blocks;
-    dim3 grid(B.n_blocks, ctx->C), block(PML_SMALL_BLOCK);
+    // Workgroup size: 512 threads while every (block, column) workgroup is resident at once; with more workgroups than
+    // the chip holds the launch runs in rounds of long-lived workgroups (HIV1C x 14 columns: 980 workgroups of 8 waves,
+    // one per CU at 3 waves per SIMD -> four rounds, 97 us for blocks of <= 24 level steps), so the workgroups shrink
+    // until they all fit: a thin level needs one or two waves, wider ones take more passes (walk_levels).
+    static int waves_per_cu[2] = {0, 0}, n_cus = 0;
+    if (n_cus == 0) {
+        hipDeviceProp_t prop;
+        n_cus = hipGetDeviceProperties(&prop, ctx->device) == hipSuccess ? prop.multiProcessorCount : 256;
+    }
+    int& wpc = waves_per_cu[bottom_up ? 1 : 0];
+    if (wpc == 0) {
+        int nb = 0;
+        const hipError_t e = bottom_up
+            ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, bu_f81_blocks_kernel<G, R>, 64, 0)
+            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, td_f81_blocks_kernel<G, R>, 64, 0);
+        wpc = (e == hipSuccess && nb > 0) ? nb : 8;
+    }
+    static const int forced = getenv("PASTML_HIP_BLOCK_THREADS") ? atoi(getenv("PASTML_HIP_BLOCK_THREADS")) : 0;
+    int threads = PML_SMALL_BLOCK;
+    const long long n_wg = (long long)B.n_blocks * ctx->C;
+    while (threads > 64 && n_wg * (threads / 64) > (long long)n_cus * wpc) threads /= 2;
+    if (forced >= 64 && forced <= PML_SMALL_BLOCK) threads = forced;
+    dim3 grid(B.n_blocks, ctx->C), block(threads);
     if (bottom_up)
         hipLaunchKernelGGL((bu_f81_blocks_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, B.d_bu_units, B.d_bu_start,
                            B.d_bu_levels, B.d_bu_lv);
@@ -965,7 +991,10 @@ int pml_ctx_set_option(pml_ctx* ctx, int option, int value) {
         return PML_OK;
     }
     if (option == PML_OPT_KEEP_TD) {
-        if ((value != 0) != ctx->keep_td) drop_graph(ctx->td_graph);
+        if ((value != 0) != ctx->keep_td) {
+            drop_graph(ctx->td_graph);
+            drop_graph(ctx->mp_graph);
+        }
         ctx->keep_td = value != 0;
         return PML_OK;
     }
@@ -974,6 +1003,7 @@ int pml_ctx_set_option(pml_ctx* ctx, int option, int value) {
             drop_graph(ctx->bu_graph[0]);
             drop_graph(ctx->bu_graph[1]);
             drop_graph(ctx->td_graph);
+            drop_graph(ctx->mp_graph);
             ctx->prep_dirty = true;
             ctx->bu_mode = -1;
             ctx->td_valid = ctx->js_valid = false;
@@ -1273,9 +1303,22 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
                     ssz[i] += 1;
                     if (parent[i] >= 0) ssz[parent[i]] += ssz[i];
                 }
+                // Height cap.  All blocks run in one launch and the top starts after it: a sweep costs (levels of the
+                // tallest block) + (levels of the top).  Ragged trees have thin subtrees of few nodes and many levels;
+                // uncapped, such a block outlasts all others while the top's lowest levels wait for it (HIV1C: 47 + 27
+                // level steps for a tree of 57 levels).  Blocks therefore end below the lowest level of the top: what
+                // sticks out joins levels the top walks anyway, and blocks + top together are as many level steps as
+                // the forest has levels.  (PASTML_HIP_BLOCK_HEIGHT_CAP: 0 = no cap, n = cap at fused height n.)
+                int h_cap = max_h;
+                for (int q = 0; q < n_stored; ++q)
+                    if (ssz[order[q]] > S) h_cap = std::min(h_cap, fh[order[q]]);
+                if (const char* env_h = getenv("PASTML_HIP_BLOCK_HEIGHT_CAP")) {
+                    const int v = atoi(env_h);
+                    h_cap = v > 0 ? v : max_h + 1;
+                }
                 int nb = 0;
                 for (int i = 0; i < n_nodes; ++i) {  // parents have smaller ids
-                    if (kind[i] != PML_KIND_STORED || ssz[i] > S) continue;
+                    if (kind[i] != PML_KIND_STORED || ssz[i] > S || fh[i] >= h_cap) continue;
                     const int p = parent[i];
                     blk[i] = (p >= 0 && blk[p] >= 0) ? blk[p] : nb++;
                 }
@@ -1582,6 +1625,7 @@ static int set_common(pml_ctx* ctx, int kind, int cb, int ce, const double* pi, 
         drop_graph(ctx->bu_graph[0]);
         drop_graph(ctx->bu_graph[1]);
         drop_graph(ctx->td_graph);
+        drop_graph(ctx->mp_graph);
     }
     if (kind == PML_MODEL_HKY && ctx->k != 4) return fail(PML_ERR_INVALID, "HKY needs k = 4");
     const int nc = ce - cb;
@@ -1951,6 +1995,7 @@ static int enqueue_bottom_up(pml_ctx* ctx, int is_marginal, bool small_path, boo
 
 // Captures fn's stream work once and replays it afterwards; falls back to direct submission if capture fails.
 static int run_captured(pml_ctx* ctx, pml_ctx::GraphSlot& slot, const std::function<int()>& enqueue) {
+    if (ctx->in_outer_capture) return enqueue();  // part of a larger capture (pml_marginal_pass)
     if (slot.exec && slot.has_init != ctx->has_init) drop_graph(slot);
     if (!slot.exec) {
         HIP_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
@@ -1999,7 +2044,8 @@ static int submit_bottom_up(pml_ctx* ctx, int is_marginal) {
         PML_TRY(run_captured(ctx, ctx->bu_graph[is_marginal ? 1 : 0],
                              [&]() { return enqueue_bottom_up(ctx, is_marginal, small_path, true); }));
     } else {
-        PML_TRY(enqueue_bottom_up(ctx, is_marginal, small_path, false));
+        // (inside the capture of a whole marginal pass the per-branch pass must be part of the graph)
+        PML_TRY(enqueue_bottom_up(ctx, is_marginal, small_path, ctx->in_outer_capture));
     }
     // the fused eigen sweeps build P(t) in registers, the two-GEMM sweeps never form it: no batch ran
     if (!no_p) ctx->prep_dirty = false;
@@ -2157,10 +2203,14 @@ static int materialize_td(pml_ctx* ctx) {
         // paying for TD stores because somebody once looked at them)
         const bool was = ctx->keep_td;
         drop_graph(ctx->td_graph);
+        drop_graph(ctx->mp_graph);
         ctx->keep_td = true;
         const int status = run_top_down(ctx);
         ctx->keep_td = was;
-        if (!was) drop_graph(ctx->td_graph);
+        if (!was) {
+            drop_graph(ctx->td_graph);
+            drop_graph(ctx->mp_graph);
+        }
         PML_TRY(status);
         HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
@@ -2225,10 +2275,44 @@ int pml_marginal_pass(pml_ctx* ctx, double* loglik_out, int32_t* err_parent, int
                       double* lh_sum_out, double* lh_sf_out) {
     PML_TRY(require_model(ctx));
     if (!loglik_out) return fail(PML_ERR_INVALID, "loglik_out is NULL");
-    // both sweeps go on the stream before the host looks at anything: the top-down sweep does not wait for a round trip
-    PML_TRY(submit_bottom_up(ctx, 1));
-    ctx->bu_mode = 1;  // provisional, for run_top_down's bookkeeping; collect_bottom_up has the last word
-    PML_TRY(run_top_down(ctx));
+    // both sweeps go on the stream before the host looks at anything: the top-down sweep does not wait for a round trip.
+    // Latency-bound forests (the sweeps replay as hipGraphs): ONE graph holds both sweeps -- one launch call, no gap
+    // between the last bottom-up kernel and the first top-down one.  (F81 family, once the buffers of a top-down sweep
+    // exist: nothing may be allocated while a stream is captured.)
+    const bool td_small = single_launch_sweeps(ctx) && ctx->kind == PML_MODEL_F81;
+    const int bu_launches = td_small ? 1 : (int)ctx->bu_offsets_f.size() - 1;
+    const bool one_graph = ctx->graphs && !ctx->profile && ctx->kind == PML_MODEL_F81 && ctx->d_post != nullptr &&
+                           (!ctx->keep_td || ctx->d_td != nullptr) &&
+                           (bu_launches >= 4 || (!td_small && ctx->n_td_levels >= 4));
+    if (one_graph) {
+        if (ctx->mp_graph.exec && ctx->mp_graph.has_init == ctx->has_init) {
+            HIP_TRY(hipGraphLaunch(ctx->mp_graph.exec, ctx->stream));
+        } else {
+            PML_TRY(run_captured(ctx, ctx->mp_graph, [&]() {
+                ctx->in_outer_capture = true;
+                int status = submit_bottom_up(ctx, 1);
+                if (status == PML_OK) {
+                    ctx->bu_mode = 1;
+                    status = run_top_down(ctx);
+                }
+                ctx->in_outer_capture = false;
+                return status;
+            }));
+        }
+        // the bookkeeping of submit_bottom_up / run_top_down (a replay runs neither)
+        ctx->js_valid = false;
+        ctx->prep_dirty = false;
+        ctx->bu_fused = ctx->n_cherries > 0;
+        ctx->bu_fused_joint = false;
+        ctx->td_valid = true;
+        ctx->td_vec_valid = ctx->keep_td;
+        ctx->td_filled = false;
+        ctx->post_ever = true;
+    } else {
+        PML_TRY(submit_bottom_up(ctx, 1));
+        ctx->bu_mode = 1;  // provisional, for run_top_down's bookkeeping; collect_bottom_up has the last word
+        PML_TRY(run_top_down(ctx));
+    }
     const int fetched = fetch_marginals(ctx, posterior_out, lh_sum_out, lh_sf_out);  // synchronises
     ctx->bu_mode = -1;
     const int status = collect_bottom_up(ctx, 1, loglik_out, err_parent, err_child);

@@ -964,6 +964,137 @@ __device__ __forceinline__ bool bu_f81_unit_fast(const LaneCtx<G, R>& L, const P
     return true;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Lean unit for the kernels that walk several levels in one launch (walk_levels: small forests, subtree blocks, the
+// narrow end of large forests), units of fewer than 8 lanes.  There a level holds a handful of units and a level step
+// is the latency of ONE unit, which on the sequential path is a chain of dependent round trips to L2 (child -> its
+// kind -> its scalars -> the cherry's tips -> their scalars; ~45 s_waitcnt in the unit's code).  The descriptor says
+// where everything lives, so this unit issues every load it can need -- own mask, both children's scalars and vectors,
+// the scalars of up to two tips under each -- before it touches any value: one round trip.  Arithmetic: the operations
+// of the sequential path in its order (tip messages picked by the mask bit, word_select_vec; band checks skipped where
+// the product of the message floors proves them void, as in bu_f81_marg_body): the same bits.
+// Units it takes: single-word masks, at most two children, cherries of at most two tips.  Returns false for an all-zero
+// result: the caller repeats the unit on the sequential path, which reports the pair the reference would name.
+// (In the level kernels of large forests the sequential path stays: there the loads of 16 - 64 units per wavefront
+// overlap by themselves and the extra load slots cost more than they save -- DESIGN.md 4a.)
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool unit_is_lean(int packed) {
+    if (unit_nc(packed) > 2 || !((packed >> 4) & 1)) return false;
+    return unit_code(packed, 0) <= 3 && unit_code(packed, 1) <= 3;
+}
+
+template <int G, int R>
+__device__ __forceinline__ bool bu_f81_unit_lean(const LaneCtx<G, R>& L, const PmlTree& t, const PmlCols& c,
+                                                 const PmlState& st, const UnitRegs& u) {
+    const int n = u.n, fc = u.fc;
+    const int nc = unit_nc(u.packed);
+    const u64 kbits = state_bits(c.k);
+    // ---- loads
+    const u64 own = L.mask[(unsigned)n];
+    double ce[2], cs[2], vv[2][R];
+    u64 cm[2];
+    i64 cbe[2];
+    double te[2][2], ts[2][2];
+    u64 tm[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int ch = fc + (j < nc ? j : 0);
+        const int code = j < nc ? unit_code(u.packed, j) : 0;
+        ce[j] = L.E[ch];
+        cm[j] = L.mask[(unsigned)ch];
+        cs[j] = code <= 1 ? L.S[ch] : 0.0;
+        cbe[j] = code == 1 ? L.be[ch] : 0;
+        if (code == 1) {
+            node_load_vec<G, R>(L, c, L.bu, ch, vv[j]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) vv[j][r] = 0.0;
+        }
+        const int cfc = j == 0 ? u.cfc : u.cfc1;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const bool has = code >= 2 && q < code - 1;
+            const int tip = has ? cfc + q : ch;
+            te[j][q] = L.E[tip];
+            ts[j][q] = has ? L.S[tip] : 0.0;
+            tm[j][q] = L.mask[(unsigned)tip];
+        }
+    }
+    // ---- arithmetic (bu_f81_unit_seq's operations)
+    double acc[R];
+    clean_word_to_vec<G, R>(L, c, own & kbits, acc);
+    i64 esum = 0;
+    double lob = 1.0;
+    bool bounded = true;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        if (j < nc) {
+            const int code = unit_code(u.packed, j);
+            const double e = ce[j];
+            double msg[R];
+            double a;
+            if (code == 0) {
+                a = (1.0 - e) * cs[j];
+                word_select_vec<G, R>(L, c, cm[j] & kbits, a, e, msg);
+            } else {
+                double v[R];
+                double s_child;
+                if (code == 1) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) v[r] = vv[j][r];
+                    esum += cbe[j];
+                    s_child = cs[j];
+                    bounded = false;
+                } else {
+                    // cherry: mask, then per tip its message and the product; band check after the last tip
+                    clean_word_to_vec<G, R>(L, c, cm[j] & kbits, v);
+                    double amin = 1.0;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        if (q < code - 1) {
+                            const double ta = (1.0 - te[j][q]) * ts[j][q];
+                            double tmsg[R];
+                            word_select_vec<G, R>(L, c, tm[j][q] & kbits, ta, te[j][q], tmsg);
+                            amin *= ta;
+#pragma unroll
+                            for (int r = 0; r < R; ++r) v[r] *= tmsg[r];
+                        }
+                    }
+                    if (!(amin >= 0x1p-190)) esum += lazy_rescale<G, R>(v);
+                    s_child = pi_dot<G, R>(L, v);
+                    if (L.g == 0) L.S[fc + j] = s_child;
+                }
+                a = (1.0 - e) * s_child;
+#pragma unroll
+                for (int r = 0; r < R; ++r) msg[r] = a + e * v[r];
+            }
+            lob *= a;
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r] *= msg[r];
+            if (j == 1 || j == nc - 1) {
+                if (!bounded || !(lob >= 0x1p-190)) {
+                    const int ex = lazy_rescale<G, R>(acc);
+                    esum += ex;
+                    if (ex != 0) bounded = false;
+                }
+            }
+        }
+    }
+    const double s = pi_dot<G, R>(L, acc);
+    if (!(s > 0.0)) {
+        bool nz = false;
+#pragma unroll
+        for (int r = 0; r < R; ++r) nz |= acc[r] != 0.0 && L.st(r) < c.k;
+        if (!group_any<G>(nz)) return false;
+    }
+    if (L.g == 0) {
+        L.S[n] = s;
+        L.be[n] = esum;
+    }
+    node_store_vec<G, R>(L, c, L.bu, n, acc);
+    return true;
+}
+
 template <int G, int R, bool JOINT>
 __device__ __forceinline__ bool bu_f81_unit_is_fast(const PmlCols& c, const UnitRegs& u) {
     return !JOINT && Gather<G>::enabled && c.W == 1 && unit_is_fast_bu<G, true>(u.packed);
@@ -979,9 +1110,12 @@ template <int G, int R, bool JOINT>
 __device__ __forceinline__ void bu_f81_unit_seq(const LaneCtx<G, R>& L, const PmlTree& t, const PmlCols& c,
                                                 const PmlState& st, const UnitRegs& u);
 
-template <int G, int R, bool JOINT>
+template <int G, int R, bool JOINT, bool LEAN = false>
 __device__ __forceinline__ void bu_f81_unit(const LaneCtx<G, R>& L, const PmlTree& t, const PmlCols& c,
                                             const PmlState& st, const UnitRegs& u) {
+    if (LEAN && !JOINT && G < 8 && c.W == 1 && unit_is_lean(u.packed)) {
+        if (bu_f81_unit_lean<G, R>(L, t, c, st, u)) return;
+    }
     if (bu_f81_unit_is_fast<G, R, JOINT>(c, u)) {
         BuLoads<R> ld;
         bu_f81_issue<G, R, true>(L, c, u, ld);
@@ -1348,14 +1482,124 @@ __device__ __forceinline__ void td_f81_unit_fast(const LaneCtx<G, R>& L, const P
     }
 }
 
+// Lean top-down unit for the kernels that walk several levels in one launch (see bu_f81_unit_lean): every load the unit
+// can need -- the parent's posterior row and scalars, both children's scalars and vectors, the scalars of up to two tips
+// under each -- is issued before any value is used; then the operations of td_f81_unit's sequential path in its order.
+template <int G, int R>
+__device__ __forceinline__ void td_f81_unit_lean(const LaneCtx<G, R>& L, const PmlTree& t, const PmlCols& c,
+                                                 const PmlState& st, const UnitRegs& u) {
+    const int p = u.n, fc = u.fc;
+    const int nc = unit_nc(u.packed);
+    const u64 kbits = state_bits(c.k);
+    // ---- loads
+    double po[R];
+    node_load_vec<G, R>(L, c, L.post, p, po);
+    const double ls = L.lhsum[p];
+    const i64 pe = L.lhe[p];
+    double ce[2], cs[2], vv[2][R];
+    u64 cm[2];
+    i64 cbe[2];
+    double te[2][2], ts[2][2];
+    u64 tm[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int ch = fc + (j < nc ? j : 0);
+        const int code = j < nc ? unit_code(u.packed, j) : 0;
+        ce[j] = L.E[ch];
+        cm[j] = L.mask[(unsigned)ch];
+        cs[j] = L.S[ch];
+        cbe[j] = code == 1 ? L.be[ch] : 0;
+        if (code == 1) {
+            node_load_vec<G, R>(L, c, L.bu, ch, vv[j]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) vv[j][r] = 0.0;
+        }
+        const int cfc = j == 0 ? u.cfc : u.cfc1;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const bool has = code >= 2 && q < code - 1;
+            const int tip = has ? cfc + q : ch;
+            te[j][q] = L.E[tip];
+            ts[j][q] = has ? L.S[tip] : 0.0;
+            tm[j][q] = L.mask[(unsigned)tip];
+        }
+    }
+    // ---- arithmetic
+    double prod[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) prod[r] = po[r] * (ls * L.ipi_r[r]);  // f81_parent_prod
+    double P = 0.0;
+    bool have_P = false;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        if (j < nc) {
+            const int ch = fc + j;
+            const int code = unit_code(u.packed, j);
+            const double e = ce[j];
+            if (code == 0) {
+                f81_finish_tip_word<G, R>(L, c, prod, pe, P, have_P, ch, cm[j] & kbits, e, cs[j], j);
+            } else {
+                double mb[R], v[R], tdc[R], pc[R], lsc;
+                clean_word_to_vec<G, R>(L, c, cm[j] & kbits, mb);
+                i64 xe, le;
+                if (code == 1) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) v[r] = vv[j][r];
+                    f81_finish_child<G, R>(L, c, prod, pe, ch, e, cs[j], cbe[j], v, false, mb, tdc, xe, pc, lsc, le, j);
+                    if (st.td != nullptr) {
+                        node_store_vec<G, R>(L, c, L.td, ch, tdc);
+                        if (L.g == 0) L.te[ch] = xe;
+                    }
+                } else {
+                    // cherry: its bottom-up vector again (f81_cherry_vector's operations), finished, then its tips
+#pragma unroll
+                    for (int r = 0; r < R; ++r) v[r] = mb[r];
+                    double amin = 1.0;
+                    i64 bec = 0;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        if (q < code - 1) {
+                            const double ta = (1.0 - te[j][q]) * ts[j][q];
+                            double tmsg[R];
+                            word_select_vec<G, R>(L, c, tm[j][q] & kbits, ta, te[j][q], tmsg);
+                            amin *= ta;
+#pragma unroll
+                            for (int r = 0; r < R; ++r) v[r] *= tmsg[r];
+                        }
+                    }
+                    if (!(amin >= 0x1p-190)) bec = lazy_rescale<G, R>(v);
+                    f81_finish_child<G, R>(L, c, prod, pe, ch, e, cs[j], bec, v, false, mb, tdc, xe, pc, lsc, le, j);
+                    double prod2[R];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) prod2[r] = pc[r] * (lsc * L.ipi_r[r]);
+                    double P2 = 0.0;
+                    bool have_P2 = false;
+                    const int cfc = j == 0 ? u.cfc : u.cfc1;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        if (q < code - 1)
+                            f81_finish_tip_word<G, R>(L, c, prod2, le, P2, have_P2, cfc + q, tm[j][q] & kbits, te[j][q],
+                                                      ts[j][q], 2 + 2 * j + q);
+                    }
+                }
+            }
+        }
+    }
+}
+
 // One unit = (stored internal node of the depth level, column): the parent's BU and TD vectors are loaded once and
 // every child is finished from them; cherry children are recomputed and their tips finished in the same unit.
 // replaces calc_node_td_likelihood (ml.py:273-290), calc_node_marginal_likelihood (:454-460) and the normalisation
 // of convert_likelihoods_to_probabilities (:498-500) for the F81 family.
 // One top-down unit: stored internal node p of the current depth level.
-template <int G, int R>
+template <int G, int R, bool LEAN = false>
 __device__ __forceinline__ void td_f81_unit(const LaneCtx<G, R>& L, const PmlTree& t, const PmlCols& c,
                                             const PmlState& st, const UnitRegs& u) {
+    if (LEAN && G < 8 && c.W == 1 && unit_is_lean(u.packed)) {
+        td_f81_unit_lean<G, R>(L, t, c, st, u);
+        return;
+    }
     if (Gather<G>::enabled && c.W == 1 && unit_is_fast<G>(u.packed)) {
         td_f81_unit_fast<G, R>(L, t, c, st, u);
         return;
@@ -1587,14 +1831,14 @@ __device__ __forceinline__ void walk_levels(const LaneCtx<G, R>& L, const PmlTre
             nxt = load_unit<G>(units, first < b2 - a2 ? a2 + first : a2, L.g);
         }
         if (first < n_level) {
-            if (BU) bu_f81_unit<G, R, false>(L, t, c, st, cur);
-            else td_f81_unit<G, R>(L, t, c, st, cur);
+            if (BU) bu_f81_unit<G, R, false, true>(L, t, c, st, cur);
+            else td_f81_unit<G, R, true>(L, t, c, st, cur);
         }
         for (int base = wave * UW + n_waves * UW; base < n_level; base += n_waves * UW) {
             const int idx = base + sub;
             if (idx < n_level) {
-                if (BU) bu_f81_unit<G, R, false>(L, t, c, st, load_unit<G>(units, a + idx, L.g));
-                else td_f81_unit<G, R>(L, t, c, st, load_unit<G>(units, a + idx, L.g));
+                if (BU) bu_f81_unit<G, R, false, true>(L, t, c, st, load_unit<G>(units, a + idx, L.g));
+                else td_f81_unit<G, R, true>(L, t, c, st, load_unit<G>(units, a + idx, L.g));
             }
         }
         __syncthreads();

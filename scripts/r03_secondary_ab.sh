@@ -1,0 +1,15 @@
+#!/bin/bash
+# the secondary configs (cfg2, cfg3, cfg5-shaped gradient) with two builds of the library: A = in-tree, B = scratch/$1
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+cd /tmp && export TMPDIR=/tmp
+cp $R/pastml_amd/libpastml_hip.so /tmp/libA.so
+for v in A B A2 B2; do
+  case $v in A*) cp /tmp/libA.so $R/pastml_amd/libpastml_hip.so;; B*) [ -f "$R/scratch/$1" ] || continue; cp $R/scratch/$1 $R/pastml_amd/libpastml_hip.so;; esac
+  timeout -k 10 300 python3 -c "
+import sys, json; sys.path.insert(0, '$R')
+import bench
+o = bench.secondary_measurements(0)
+print('$v', {k: round(v.get('ms_per_pass', v.get('ms_per_gradient')), 4) for k, v in o.items()}, 'cfg3 sweep', round(o['cfg3']['ms_joint_sweep'], 4), 'marg', round(o['cfg3']['ms_marginal_pass'], 4))
+" || exit 1
+done
+cp /tmp/libA.so $R/pastml_amd/libpastml_hip.so

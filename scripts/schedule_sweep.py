@@ -3,7 +3,7 @@
 Sanity sweep of the schedule heuristics (subtree blocks, single-launch sweeps for many columns): marginal pass and
 bottom-up sweep times of the default schedule against the plain level schedule over a grid of tree shapes, state counts
 and column counts.  Prints every case and flags those where the default loses more than 10 %.
-    python scripts/schedule_sweep.py            # the whole grid (spawns one process per case and schedule)
+    python scripts/schedule_sweep.py [TREES]    # the whole grid (spawns one process per case and schedule); TREES e.g. 14,hiv1c
     python scripts/schedule_sweep.py one TREE K C
 """
 import json
@@ -46,7 +46,8 @@ def main():
         return one(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]))
     level = dict(os.environ, PASTML_HIP_BLOCK_NODES='0', PASTML_HIP_SMALL_MANY_NODES='0')
     worst = []
-    for tree in ('10', '12', '14', '16', 'hiv1c'):
+    trees = sys.argv[1].split(',') if len(sys.argv) > 1 else ('10', '12', '14', '16', 'hiv1c')
+    for tree in trees:
         for k in (2, 4, 12, 20, 64):
             for C in (1, 4, 16, 64, 256):
                 n = 7237 if tree == 'hiv1c' else 2 ** (int(tree) + 1)

@@ -224,3 +224,46 @@ def test_set_outgroup_keeps_the_unrooted_tree(seed):
     for key, d in before.items():
         assert after[key] == pytest.approx(d, abs=1e-12)
     assert sum(n.dist for n in tree.traverse() if n.up is not None) == pytest.approx(total, abs=1e-12)
+
+
+def test_generator_lbfgsb_reproduces_scipy_minimize():
+    """
+    batch.lbfgsb_steps (scipy's reverse-communication routine driven from a generator, so that all characters of a
+    group advance in one loop) asks for the points scipy.optimize.minimize(method='L-BFGS-B', jac=True) asks for, in
+    its order, and ends at its result.
+    """
+    from scipy.optimize import minimize
+    from pastml_amd import batch as B
+    if B._setulb is None:
+        pytest.skip('this SciPy build has another reverse-communication routine: the thread driver is used')
+
+    def fg(x):
+        f = np.sum(100.0 * (x[1:] - x[:-1] ** 2) ** 2 + (1 - x[:-1]) ** 2) + 0.1 * np.sum(np.sin(3 * x))
+        g = 0.3 * np.cos(3 * x)
+        g[:-1] += -400 * x[:-1] * (x[1:] - x[:-1] ** 2) - 2 * (1 - x[:-1])
+        g[1:] += 200 * (x[1:] - x[:-1] ** 2)
+        return f, g
+
+    rng = np.random.default_rng(0)
+    for trial in range(12):
+        n = int(rng.integers(2, 9))
+        bounds = np.stack([rng.uniform(-2, 0, n), rng.uniform(0.5, 3, n)], axis=1)
+        x0 = rng.uniform(-3, 3, n)   # (also outside the bounds: both clip it)
+        asked_scipy = []
+
+        def recorded(x):
+            asked_scipy.append(x.copy())
+            return fg(x)
+        ref = minimize(recorded, x0, method='L-BFGS-B', bounds=bounds, jac=True)
+        asked = []
+        steps = B.lbfgsb_steps(x0, bounds)
+        try:
+            point = next(steps)
+            while True:
+                asked.append(point.copy())
+                point = steps.send(fg(point))
+        except StopIteration as stop:
+            found = stop.value
+        assert len(asked) == len(asked_scipy) and all(np.array_equal(a, b) for a, b in zip(asked, asked_scipy))
+        assert np.array_equal(found.x, ref.x) and found.fun == ref.fun and found.success == ref.success
+        assert found.nit == ref.nit and found.nfev == ref.nfev
