@@ -142,6 +142,15 @@ int pml_pij_batch(pml_ctx* ctx, double* P_out);
  */
 int pml_bottom_up(pml_ctx* ctx, int is_marginal, double* loglik_out, int32_t* err_parent, int32_t* err_child);
 /*
+ * pml_bottom_up in two halves: submit puts the sweep on the context's stream and returns at once, collect waits for it
+ * and hands out what pml_bottom_up would have.  A host loop that serves several contexts (groups of characters with
+ * different numbers of states, each with its own optimisers: the reference runs them one after the other,
+ * pastml/acr.py:213-231) submits all their sweeps before it waits for any: the sweeps overlap on the device and with
+ * the host work between them.  Between the two calls nothing else may be called on the context.
+ */
+int pml_bottom_up_submit(pml_ctx* ctx, int is_marginal);
+int pml_bottom_up_collect(pml_ctx* ctx, int is_marginal, double* loglik_out, int32_t* err_parent, int32_t* err_child);
+/*
  * Top-down sweep + marginal likelihoods + posteriors, fused: pastml/ml.py:240-290 (calculate_top_down_likelihood),
  * :431-465 (calculate_marginal_likelihoods), :486-502 (convert_likelihoods_to_probabilities).  Needs a preceding
  * marginal pml_bottom_up with the same masks.  Outputs are optional (NULL = keep on the device only):

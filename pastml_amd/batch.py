@@ -416,6 +416,11 @@ class CharacterBatch(object):
         most as many as the character's block is wide.  One bottom-up sweep over all blocks; returns
         {character: ln L array, or a LikelihoodError if one of its points has no likelihood}.
         """
+        self.submit_points(requests)
+        return self.collect_points()
+
+    def submit_points(self, requests):
+        """First half of evaluate_points: parameters and masks to the device, the sweep on the stream; no waiting."""
         opt = self._opt
         eng, offsets, models = opt['engine'], opt['offsets'], opt['models']
         lo, hi = opt['total'], 0
@@ -447,9 +452,17 @@ class CharacterBatch(object):
         else:
             eng.set_models(models[lo:hi], col_begin=lo)
         self.n_sweeps += sum(len(p) for p in requests.values())
+        eng.bottom_up_submit(True)
+        opt['in_flight'] = requests
+
+    def collect_points(self):
+        """Second half of evaluate_points: waits for the sweep of submit_points and sorts its results by character."""
+        opt = self._opt
+        eng, offsets = opt['engine'], opt['offsets']
+        requests = opt.pop('in_flight')
         failed = None
         try:
-            values = eng.bottom_up(True)
+            values = eng.bottom_up_collect(True)
         except hip.ZeroLikelihoodError as e:
             values, failed = e.loglik, e
         out = {}
@@ -519,6 +532,31 @@ try:
     from scipy.optimize._numdiff import approx_derivative as _approx_derivative
 except Exception:  # pragma: no cover - depends on the SciPy build
     _approx_derivative = None
+try:
+    from scipy.optimize._numdiff import _adjust_scheme_to_bounds
+except Exception:  # pragma: no cover - depends on the SciPy build
+    _adjust_scheme_to_bounds = None
+
+
+def two_point_scheme(x0, lower, upper):
+    """
+    The points of scipy's forward-difference gradient at x0 -- approx_derivative(method='2-point', abs_step=1e-8,
+    bounds=...), the scheme L-BFGS-B applies when it is given no gradient -- and the steps to divide by:
+    rows x0 + h_i e_i with the step mirrored where it would leave the bounds, steps recomputed as (x0_i + h_i) - x0_i.
+    The gradient is then (f(row_i) - f(x0)) / step_i: scipy's _dense_difference, without calling its function wrapper
+    per coordinate (a third of the host time of an optimiser round went there).
+    """
+    x0 = np.asarray(x0, dtype=np.float64)
+    h = np.full(x0.shape, 1e-8)
+    zero = ((x0 + h) - x0) == 0
+    if zero.any():   # (a step below the spacing of x0: scipy falls back to a relative one)
+        sign = (x0 >= 0).astype(float) * 2 - 1
+        h = np.where(zero, np.finfo(np.float64).eps ** 0.5 * sign * np.maximum(1.0, np.abs(x0)), h)
+    h, _ = _adjust_scheme_to_bounds(x0, h, 1, '1-sided', lower, upper)
+    points = np.repeat(x0[None, :], len(x0), axis=0)
+    idx = np.arange(len(x0))
+    points[idx, idx] += h
+    return points, points[idx, idx] - x0
 
 
 def batched_gradients_available():
@@ -670,6 +708,13 @@ def search_parameters_steps(model, observed_frequencies, rng):
         ps = np.asarray(ps, dtype=np.float64)
         if np.any(pd.isnull(ps)):
             return np.nan, np.full(len(ps), np.nan)
+        if _adjust_scheme_to_bounds is not None:
+            if np.any((ps < lower) | (ps > upper)):
+                raise ValueError("`x0` violates bound constraints.")
+            points, steps = two_point_scheme(ps, lower, upper)
+            values = yield [ps] + list(points)
+            values = np.array(negative(values), dtype=np.float64)
+            return values[0], (values[1:] - values[0]) / steps
         asked = []
         _approx_derivative(lambda x: asked.append(np.array(x, dtype=np.float64)) or 0.0, ps, method='2-point',
                            abs_step=1e-8, f0=0.0, bounds=(lower, upper))
@@ -796,11 +841,7 @@ def fit_parameters_steps(character, model, observed_frequencies, rng, search=Non
         logger.debug('{} for {}:\n{}{}'.format(title, character, text, '\tlog likelihood:\t{:.6f}'.format(lnl)))
 
     def points_of(vectors):
-        points = []
-        for ps in vectors:
-            model.set_params_from_optimised(ps)
-            points.append((model.kernel_spec(), model.rate_params()))
-        return points
+        return model.kernel_points(vectors)
 
     def run_search():
         if search is not None:
@@ -874,6 +915,89 @@ def likelihood_error(flat, e):
                                                                                flat.dist[e.child]))
 
 
+class GroupSearch(object):
+    """
+    The parameter searches of one group of characters (one CharacterBatch): every character's fit_parameters_steps
+    generator, the requests they are waiting on, and the two halves of a sweep round -- ``submit`` sends the pending
+    requests of all characters to the device in one batched sweep without waiting, ``collect`` waits for it and steps
+    every character to its next request.
+    """
+
+    def __init__(self, batch, tasks, seeds):
+        self.batch, self.tasks = batch, tasks
+        m = len(tasks)
+        self.lnl = np.full(m, np.nan)
+        self.errors = {}
+        self.pending = {}
+        self.rounds = 0
+        batch.open_optimiser([block_width(t.model) for t in tasks])
+        self.searches = [fit_parameters_steps(t.character, t.model, t.observed_frequencies,
+                                              np.random.RandomState(seeds[c])) for c, t in enumerate(tasks)]
+        for c in range(m):
+            self._advance(c, lambda: next(self.searches[c]))
+
+    def _advance(self, c, step):
+        # runs character c's search up to its next request (or its end / failure)
+        try:
+            self.pending[c] = step()
+        except StopIteration as stop:
+            self.lnl[c] = stop.value
+        except BaseException as e:  # delivered to the caller after all searches are done
+            self.errors[c] = e
+
+    def submit(self):
+        self._failed = None
+        try:
+            self.batch.submit_points(self.pending)
+        except Exception as e:  # a failure of the sweep itself reaches every character that asked
+            self._failed = e
+
+    def collect(self):
+        requests, self.pending = self.pending, {}
+        if self._failed is None:
+            try:
+                out = self.batch.collect_points()
+            except Exception as e:
+                self._failed = e
+        if self._failed is not None:
+            out = {c: self._failed for c in requests}
+        self.rounds += 1
+        for c, res in out.items():
+            if isinstance(res, Exception):
+                self._advance(c, lambda: self.searches[c].throw(res))
+            else:
+                self._advance(c, lambda: self.searches[c].send(res))
+
+    def close(self):
+        hip.release_engine(self.batch._opt['engine'])
+        self.batch._opt = None
+
+    def error(self):
+        if not self.errors:
+            return None
+        e = self.errors[min(self.errors)]
+        return likelihood_error(self.batch.flat, e) if isinstance(e, LikelihoodError) else e
+
+
+def optimise_groups(groups):
+    """
+    ONE loop for all searches of all groups: every round submits the pending sweep of every group (each on its own
+    context = stream) before it waits for any, then steps the characters of each group to their next requests.  The
+    sweeps of the groups overlap on the device and with the host work of the other groups; no interpreter threads, so
+    the groups do not take the interpreter lock from each other (with a thread per group an acr() over the 91 HIV1C
+    columns took as long as its groups one after the other).
+    """
+    live = [g for g in groups if g.pending]
+    while live:
+        for g in live:
+            g.submit()
+        for g in live:
+            g.collect()
+        live = [g for g in live if g.pending]
+    for g in groups:
+        g.close()
+
+
 def optimise_group(batch, tasks, seeds=None):
     """
     Parameters of every character of the batch, all optimisers advancing together: ONE loop steps every character's
@@ -888,43 +1012,11 @@ def optimise_group(batch, tasks, seeds=None):
         seeds = np.random.randint(0, 2 ** 31 - 1, size=m)
     if not single_loop_optimiser_available():
         return _optimise_group_threads(batch, tasks, seeds)
-    batch.open_optimiser([block_width(t.model) for t in tasks])
-    lnl = np.full(m, np.nan)
-    errors = {}
-    searches = [fit_parameters_steps(t.character, t.model, t.observed_frequencies, np.random.RandomState(seeds[c]))
-                for c, t in enumerate(tasks)]
-    pending = {}
-
-    def advance(c, step):
-        # runs character c's search up to its next request (or its end / failure)
-        try:
-            pending[c] = step()
-        except StopIteration as stop:
-            lnl[c] = stop.value
-        except BaseException as e:  # delivered to the caller after all searches are done
-            errors[c] = e
-
-    for c in range(m):
-        advance(c, lambda: next(searches[c]))
-    rounds = 0
-    while pending:
-        requests, pending = pending, {}
-        try:
-            out = batch.evaluate_points(requests)
-        except Exception as e:  # a failure of the sweep itself reaches every character that asked
-            out = {c: e for c in requests}
-        rounds += 1
-        for c, res in out.items():
-            if isinstance(res, Exception):
-                advance(c, lambda: searches[c].throw(res))
-            else:
-                advance(c, lambda: searches[c].send(res))
-    hip.release_engine(batch._opt['engine'])
-    batch._opt = None
-    if errors:
-        e = errors[min(errors)]
-        raise likelihood_error(batch.flat, e) if isinstance(e, LikelihoodError) else e
-    return lnl, rounds
+    group = GroupSearch(batch, tasks, seeds)
+    optimise_groups([group])
+    if group.error() is not None:
+        raise group.error()
+    return group.lnl, group.rounds
 
 
 def _optimise_group_threads(batch, tasks, seeds):
@@ -1128,15 +1220,22 @@ def run_tasks(forest, tasks, force_joint=True, device=None, flat=None):
 
     per_group = []   # (diagnostics) where the time of a run goes: one entry per group of characters
 
-    def run(job):
-        import time
+    import time
+
+    def prepare(job):
         k, part = job
         group = [tasks[i] for i in part]
+        batch = CharacterBatch(flat, k, len(group), device=device)
+        for c, t in enumerate(group):
+            batch.set_annotation(c, *annotation_words(flat, t.character, t.model.states))
+        batch.initialize_allowed_states()
+        return batch, group
+
+    def run(job):
+        k, part = job
         t0 = time.perf_counter()
-        with CharacterBatch(flat, k, len(group), device=device) as batch:
-            for c, t in enumerate(group):
-                batch.set_annotation(c, *annotation_words(flat, t.character, t.model.states))
-            batch.initialize_allowed_states()
+        batch, group = prepare(job)
+        with batch:
             lnl, rounds = optimise_group(batch, group, seeds[part])
             t1 = time.perf_counter()
             res = reconstruct(batch, group, lnl, force_joint=force_joint)
@@ -1144,27 +1243,35 @@ def run_tasks(forest, tasks, force_joint=True, device=None, flat=None):
                                   optimise_s=round(t1 - t0, 3), reconstruct_s=round(time.perf_counter() - t1, 3)))
             return part, res, rounds, batch.n_sweeps
 
-    # Groups are independent: when all of them fit the device together they run concurrently, each on its own contexts
-    # (= streams).  On small trees a sweep is a chain of latency-bound launches, so the sweeps of different groups
-    # overlap on the GPU and a run costs the rounds of its slowest group, not the sum over the groups.
-    concurrent = len(jobs) > 1 and total_bytes < 0.3 * free and os.environ.get('PASTML_AMD_CONCURRENT_GROUPS', '1') != '0'
+    # Groups are independent: when all of them fit the device together their searches advance in ONE loop
+    # (optimise_groups), each group on its own contexts (= streams).  On small trees a sweep is a chain of latency-bound
+    # launches, so the sweeps of different groups overlap on the GPU and with the host work of the other groups, and a
+    # run costs about the host work of all groups, not the sum of their sweep latencies on top.
+    concurrent = len(jobs) > 1 and total_bytes < 0.3 * free and os.environ.get('PASTML_AMD_CONCURRENT_GROUPS', '1') != '0' \
+        and single_loop_optimiser_available()
     done = []
     if concurrent:
-        failures = []
-
-        def work(job):
-            try:
-                done.append(run(job))
-            except BaseException as e:
-                failures.append((job[1][0], e))
-        threads = [threading.Thread(target=work, args=(job,), name='pastml-group-{}'.format(j))
-                   for j, job in enumerate(jobs)]
-        for th in threads:
-            th.start()
-        for th in threads:
-            th.join()
-        if failures:
-            raise min(failures, key=lambda f: f[0])[1]
+        t0 = time.perf_counter()
+        prepared, searches = [], []
+        try:
+            for job in jobs:
+                prepared.append(prepare(job))
+            searches = [GroupSearch(batch, group, seeds[job[1]]) for job, (batch, group) in zip(jobs, prepared)]
+            optimise_groups(searches)
+            t1 = time.perf_counter()
+            failures = [(job[1][0], g.error()) for job, g in zip(jobs, searches) if g.error() is not None]
+            if failures:
+                raise min(failures, key=lambda f: f[0])[1]
+            for job, (batch, group), g in zip(jobs, prepared, searches):
+                t2 = time.perf_counter()
+                res = reconstruct(batch, group, g.lnl, force_joint=force_joint)
+                per_group.append(dict(k=job[0], characters=len(group), rounds=g.rounds, sweeps=batch.n_sweeps,
+                                      optimise_s=None, reconstruct_s=round(time.perf_counter() - t2, 3)))
+                done.append((job[1], res, g.rounds, batch.n_sweeps))
+            stats['optimise_all_groups_s'] = round(t1 - t0, 3)
+        finally:
+            for batch, _ in prepared:
+                batch.__exit__(None, None, None)
     else:
         for job in jobs:
             done.append(run(job))

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <functional>
 #include <limits>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -947,15 +948,30 @@ int pml_device_count(int* count) {
 int pml_ctx_create(int device, pml_ctx** out) {
     if (!out) return fail(PML_ERR_INVALID, "out is NULL");
     *out = nullptr;
-    int n = 0;
-    HIP_TRY(hipGetDeviceCount(&n));
+    // (the device list and the architecture names are asked for once per process: hipGetDeviceProperties costs ~10 ms,
+    // and an analysis opens a context per group of characters)
+    static std::mutex arch_lock;
+    static std::vector<std::string> arch;
+    {
+        std::lock_guard<std::mutex> guard(arch_lock);
+        if (arch.empty()) {
+            int n = 0;
+            HIP_TRY(hipGetDeviceCount(&n));
+            std::vector<std::string> names;
+            for (int d = 0; d < n; ++d) {
+                hipDeviceProp_t prop;
+                HIP_TRY(hipGetDeviceProperties(&prop, d));
+                names.push_back(prop.gcnArchName);
+            }
+            arch.swap(names);
+        }
+    }
+    const int n = (int)arch.size();
     if (device < 0 || device >= n) return fail(PML_ERR_INVALID, "device %d out of range (0..%d)", device, n - 1);
     HIP_TRY(hipSetDevice(device));
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, device));
-    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    if (strncmp(arch[device].c_str(), "gfx950", 6) != 0)
         return fail(PML_ERR_UNSUPPORTED, "device %d is %s; this library is built for gfx950 (MI355X) only", device,
-                    prop.gcnArchName);
+                    arch[device].c_str());
     pml_ctx* ctx = new pml_ctx();
     ctx->device = device;
     hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
@@ -2077,6 +2093,19 @@ int pml_bottom_up(pml_ctx* ctx, int is_marginal, double* loglik_out, int32_t* er
     PML_TRY(require_model(ctx));
     if (!loglik_out) return fail(PML_ERR_INVALID, "loglik_out is NULL");
     PML_TRY(submit_bottom_up(ctx, is_marginal));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return collect_bottom_up(ctx, is_marginal, loglik_out, err_parent, err_child);
+}
+
+int pml_bottom_up_submit(pml_ctx* ctx, int is_marginal) {
+    PML_TRY(require_model(ctx));
+    return submit_bottom_up(ctx, is_marginal);
+}
+
+int pml_bottom_up_collect(pml_ctx* ctx, int is_marginal, double* loglik_out, int32_t* err_parent, int32_t* err_child) {
+    if (!ctx || ctx->C == 0) return fail(PML_ERR_INVALID, "allocate the columns first");
+    if (!loglik_out) return fail(PML_ERR_INVALID, "loglik_out is NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return collect_bottom_up(ctx, is_marginal, loglik_out, err_parent, err_child);
 }

@@ -79,6 +79,8 @@ SIGNATURES = {
     'pml_pij': [_ctx_p, ctypes.c_int32, ctypes.c_int32, _c_double_p, _c_double_p],
     'pml_pij_batch': [_ctx_p, _c_double_p],
     'pml_bottom_up': [_ctx_p, ctypes.c_int, _c_double_p, _c_int32_p, _c_int32_p],
+    'pml_bottom_up_submit': [_ctx_p, ctypes.c_int],
+    'pml_bottom_up_collect': [_ctx_p, ctypes.c_int, _c_double_p, _c_int32_p, _c_int32_p],
     'pml_top_down_marginals': [_ctx_p, _c_double_p, _c_double_p, _c_double_p],
     'pml_marginal_pass': [_ctx_p, _c_double_p, _c_int32_p, _c_int32_p, _c_double_p, _c_double_p, _c_double_p],
     'pml_joint_backtrace': [_ctx_p, _c_int32_p],
@@ -132,12 +134,19 @@ def _check(status):
         raise HipError(status, load_library().pml_last_error().decode())
 
 
+_device_count = None
+
+
 def device_count():
-    n = ctypes.c_int(0)
-    lib = load_library()
-    if lib.pml_device_count(ctypes.byref(n)) != PML_OK:
-        return 0
-    return n.value
+    """Visible HIP devices (asked once per process: the runtime's answer costs milliseconds)."""
+    global _device_count
+    if _device_count is None:
+        n = ctypes.c_int(0)
+        lib = load_library()
+        if lib.pml_device_count(ctypes.byref(n)) != PML_OK:
+            return 0
+        _device_count = n.value
+    return _device_count
 
 
 def default_device():
@@ -497,6 +506,22 @@ class Engine(BareContext):
         ec = np.empty(self.n_cols, dtype=np.int32)
         status = self._lib.pml_bottom_up(self._ctx, 1 if is_marginal else 0, _ptr(lnl, ctypes.c_double),
                                          _ptr(ep, ctypes.c_int32), _ptr(ec, ctypes.c_int32))
+        if status == PML_ZERO_LIKELIHOOD:
+            raise ZeroLikelihoodError(self._lib.pml_last_error().decode(), ep, ec, lnl)
+        _check(status)
+        return lnl
+
+    def bottom_up_submit(self, is_marginal=True):
+        """Puts a bottom-up sweep on the context's stream and returns at once (see bottom_up_collect)."""
+        _check(self._lib.pml_bottom_up_submit(self._ctx, 1 if is_marginal else 0))
+
+    def bottom_up_collect(self, is_marginal=True):
+        """Waits for the sweep of bottom_up_submit; returns / raises what bottom_up would have."""
+        lnl = np.empty(self.n_cols, dtype=np.float64)
+        ep = np.empty(self.n_cols, dtype=np.int32)
+        ec = np.empty(self.n_cols, dtype=np.int32)
+        status = self._lib.pml_bottom_up_collect(self._ctx, 1 if is_marginal else 0, _ptr(lnl, ctypes.c_double),
+                                                 _ptr(ep, ctypes.c_int32), _ptr(ec, ctypes.c_int32))
         if status == PML_ZERO_LIKELIHOOD:
             raise ZeroLikelihoodError(self._lib.pml_last_error().decode(), ep, ec, lnl)
         _check(status)

@@ -259,6 +259,17 @@ class Model(object):
         """Description of P(t) for the HIP library: dict(kind=..., arrays...)."""
         raise NotImplementedError('Please implement this method in the Model subclass')
 
+    def kernel_points(self, vectors):
+        """
+        (kernel description, rate parameters) of every optimiser vector of a batch -- the points of one finite-difference
+        gradient go to the device together.  The model is left at the last vector, as after evaluating them in turn.
+        """
+        points = []
+        for ps in vectors:
+            self.set_params_from_optimised(ps)
+            points.append((self.kernel_spec(), self.rate_params()))
+        return points
+
     def get_Pij_t(self, t, *args, **kwargs):
         """
         Probability matrix of substitutions i->j over time t (k x k ndarray), computed by the HIP library

@@ -36,6 +36,35 @@ class F81Model(ModelWithFrequencies):
             mu = np.float64(1.) / (np.float64(1.) - pi.dot(pi))
         return dict(kind=KIND_F81, pi=pi, mu=float(mu))
 
+    def kernel_points(self, vectors):
+        # All vectors of a batch decoded at once (the arithmetic of set_params_from_optimised, row by row: scalars
+        # first, then pi = (ratios, 1) / their sum): a character's gradient is k + 1 points per optimiser step, and
+        # decoding them one by one through the property setters was a quarter of the host time of a sweep round.
+        X = np.asarray(vectors, dtype=np.float64)
+        if X.ndim != 2 or not len(X) or self.TRAILING or (self._frequency_smoothing and not self.extra_params_fixed()):
+            return ModelWithFrequencies.kernel_points(self, vectors)
+        n = len(X)
+        at = 0
+        sf = np.full(n, self.sf, dtype=np.float64)
+        tau = np.full(n, self.tau, dtype=np.float64)
+        if self._optimise_sf:
+            sf, at = X[:, at], at + 1
+        if self._optimise_tau:
+            tau, at = X[:, at], at + 1
+        if self.extra_params_fixed() or not self._optimise_frequencies:
+            pi = np.repeat(np.ascontiguousarray(self.frequencies, dtype=np.float64)[None, :], n, axis=0)
+        else:
+            ratios = np.hstack((X[:, at: at + len(self.frequencies) - 1], np.ones((n, 1))))
+            pi = ratios / ratios.sum(axis=1)[:, None]
+        fs = self._forest_stats
+        points = []
+        for i in range(n):
+            t = tau[i]
+            factor = fs.forest_length / (fs.forest_length + t * (fs.num_nodes - 1)) if t else 1
+            points.append((dict(kind=KIND_F81, pi=pi[i]), (float(sf[i]), float(t), float(factor))))
+        self.set_params_from_optimised(X[-1])
+        return points
+
 
 JC = 'JC'
 
