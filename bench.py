@@ -217,20 +217,54 @@ def spawn_ranks(args):
     s.close()
     rdzv = tempfile.mkdtemp(prefix='pastml_amd_rdzv_')
     procs = []
-    for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR='127.0.0.1',
-                   MASTER_PORT=str(port), PASTML_AMD_RDZV_DIR=rdzv, HSA_ENABLE_IPC_MODE_LEGACY='0')
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode())
+    fd, out_path = tempfile.mkstemp(prefix='pastml_amd_rank0_', suffix='.stdout')
+    with os.fdopen(fd, 'wb') as out0:
+        for r in range(args.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR='127.0.0.1',
+                       MASTER_PORT=str(port), PASTML_AMD_RDZV_DIR=rdzv, HSA_ENABLE_IPC_MODE_LEGACY='0')
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=out0 if r == 0 else subprocess.DEVNULL))
+        # All ranks are watched: the first one to exit non-zero ends the job -- the others may be waiting for it inside a
+        # collective, where nothing will ever wake them -- and so does the job's time limit.  (Fresh child processes
+        # only; this parent never touches a GPU.)
+        limit = float(os.environ.get('BENCH_RANKS_TIMEOUT', '1800'))
+        t0 = time.time()
+        codes = [None] * len(procs)
+        failed = None
+        while any(c is None for c in codes) and failed is None:
+            for i, p in enumerate(procs):
+                if codes[i] is None:
+                    codes[i] = p.poll()
+                    if codes[i] not in (None, 0):
+                        failed = 'rank {} exited with code {}'.format(i, codes[i])
+            if failed is None and time.time() - t0 > limit:
+                failed = 'no result after {:.0f} s'.format(limit)
+            if failed is None:
+                time.sleep(0.05)
+        if failed is not None:
+            sys.stderr.write('bench.py: {}; stopping the other ranks\n'.format(failed))
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            t1 = time.time()
+            while any(p.poll() is None for p in procs) and time.time() - t1 < 10:
+                time.sleep(0.05)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            codes = [p.wait() for p in procs]
+    with open(out_path, 'rb') as f:
+        sys.stdout.write(f.read().decode())
     sys.stdout.flush()
+    import shutil
+    shutil.rmtree(rdzv, ignore_errors=True)
     try:
-        os.rmdir(rdzv)
+        os.remove(out_path)
     except OSError:
         pass
-    return max(abs(c) for c in codes)
+    if failed is not None:
+        return max(1, max(abs(c) for c in codes if c is not None) % 256 or 1)
+    return 0
 
 
 def validate_columns(eng, flat, k, tip_states, lnl, stride=4099):
@@ -322,18 +356,26 @@ def secondary_measurements(device):
         # column of P (2 k^2 flops).  FP64 peak: 78.6 TFLOP/s on the matrix cores AND on the vector units (measured
         # equal, and the two do not run concurrently: scripts/ub/overlap.hip) -- the joint sweep runs on the vector units.
         flops = 2.0 * k ** 3 * (flat.n_nodes - 1)
+        # executed: an observed tip needs one column of P (2 k^2 flops), an internal node all of it (2 k^3)
+        flops_executed = 2.0 * k ** 3 * (flat.n_nodes - flat.n_tips - 1) + 2.0 * k ** 2 * flat.n_tips
         # compulsory bytes of the fused sweep: message (8 k) written + read per non-root node, arg-max row (k bytes),
         # mask word, branch length, exponent
         bytes_ = (flat.n_nodes - 1) * (2 * 8 * k + k + 8 + 8 + 8 + 8)
         out['cfg3'] = dict(workload='BASELINE config 3: balanced 262 144-tip tree, JTT k=20, 1 character, joint (Pupko) '
-                                    'sweep + back-trace; P(t) built and folded in registers (FP64 vector FMAs)',
+                                    'sweep + back-trace; P(t) built and folded in registers on the FP64 VECTOR units: '
+                                    'BASELINE\'s "MFMA tile path" was measured and replaced -- FP64 matrix cores and vector '
+                                    'units share one issue port at the same 12.8 FMA/clk/SIMD and do not overlap '
+                                    '(profiles/r02e_fp64_mfma_valu_overlap.txt), and the 16x16 tiles pad k=20 to 32',
                            ms_per_pass=ms,
                            ms_joint_sweep=ms_sweep, ms_marginal_pass=ms_marginal,
                            value=flat.n_nodes * k / (ms * 1e-3), unit='node*state*char/s',
-                           roofline=dict(bound='mfma', units='v_fma_f64 (same FP64 peak as the matrix cores)',
-                                         flops=flops, achieved=flops / (ms_sweep * 1e-3) / 1e12,
+                           roofline=dict(bound='fp64-valu', units='v_fma_f64 (same FP64 peak as the matrix cores)',
+                                         flops=flops, flops_executed=flops_executed,
+                                         achieved=flops / (ms_sweep * 1e-3) / 1e12,
+                                         achieved_executed=flops_executed / (ms_sweep * 1e-3) / 1e12,
                                          peak=FP64_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
                                          frac=flops / (ms_sweep * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                                         frac_executed=flops_executed / (ms_sweep * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
                                          hbm_model_bytes=bytes_,
                                          hbm_frac=bytes_ / (ms_sweep * 1e-3) / 1e9 / HBM_PEAK_GBS))
     # ---- cfg5-shaped optimiser gradient: real HIV1C tree (3 619 tips), Loc (k = 12): the 14 likelihoods of one
@@ -363,6 +405,52 @@ def secondary_measurements(device):
                                                       .format(flat.n_bu_levels), model_bytes=b,
                                                       achieved=b / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit='GB/s',
                                                       frac=b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS))
+    # ---- cfg5 end to end: ONE acr() over the 91 usable columns of the HIV1C annotation table (MPPA + F81, parameter
+    #      optimisation of every character, 3 619 tips), against the reference's own time for the same columns
+    #      (tests/golden/hiv1c_all.npz: measured when the fixtures were made, 1 CPU thread)
+    meta = os.path.join(REPO, 'tests', 'golden', 'data', 'hiv1c', 'metadata_all.tab.gz')
+    gold = os.path.join(REPO, 'tests', 'golden', 'hiv1c_all.npz')
+    if os.path.exists(nwk) and os.path.exists(meta):
+        import pandas as pd
+        from pastml_amd.acr import acr
+        from pastml_amd.batch import run_tasks
+        from pastml_amd.tree import read_tree
+        df = pd.read_csv(meta, sep='\t', index_col=0, header=0)
+        df.index = df.index.map(str)
+        best = None
+        for _ in range(2):   # (the first call also pays for the library's first launches of these shapes)
+            tree = read_tree(nwk)
+            np.random.seed(239)
+            t0 = time.perf_counter()
+            res = acr(tree, df.copy(), prediction_method='MPPA', model='F81')
+            dt = time.perf_counter() - t0
+            if best is None or dt < best[0]:
+                best = (dt, dict(run_tasks.last_stats), res)
+        dt, st, res = best
+        ref_s = ref_cols = None
+        worst = None
+        if os.path.exists(gold):
+            z = np.load(gold)
+            names = list(z['columns']) if 'columns' in z.files else []
+            secs = [float(z[k]) for k in z.files if k.endswith('_reference_seconds')]
+            ref_s, ref_cols = float(np.sum(secs)), len(secs)
+            for r in res:
+                if r['character'] in names:
+                    key = 'c{}_loglik'.format(names.index(r['character']))
+                    if key in z.files:
+                        d = abs(r['log_likelihood'] - float(z[key])) / abs(float(z[key]))
+                        worst = d if worst is None else max(worst, d)
+        out['cfg5_acr'] = dict(workload='BASELINE config 5: HIV1C tree (3 619 tips), all {} usable annotation columns, '
+                                        'MPPA + F81 with parameter optimisation, one acr() call, 1 GPU'.format(len(res)),
+                               seconds=dt, characters=len(res), groups=st.get('groups'), sweep_rounds=st.get('rounds'),
+                               likelihood_evaluations=st.get('sweeps'),
+                               optimise_seconds=st.get('optimise_all_groups_s'),
+                               cpu_baseline=dict(kind='reference', seconds=ref_s, columns=ref_cols, cores=1,
+                                                 sample='pastml.acr.acr() of the reference itself, column by column, '
+                                                        'timed when tests/golden/hiv1c_all.npz was generated '
+                                                        '(tests/golden/make_golden.py)'),
+                               speedup_vs_reference=(ref_s / dt) if ref_s else None,
+                               max_rel_loglik_difference_to_reference=worst)
     return out
 
 
@@ -410,6 +498,8 @@ def main():
     tip_states = np.stack([synthetic.tip_states(flat.n_tips, k, c) for c in chars])
     eng.set_tip_states(tip_states)
     eng.sync()
+    if os.environ.get('BENCH_TEST_DIE_RANK') == str(rank):   # (tests: a rank that dies before it joins the communicator)
+        os._exit(7)
     # the communicator lives on the engine's own context: the all-reduce is stream-ordered behind the sweep
     comm = sharding.init(device=gpu_index, engine=eng)
 
@@ -449,9 +539,15 @@ def main():
     prep_ms, prep_launches = eng.profile_read(2)
     eng.profile_enable(False)
     held, free = eng.memory()
+    # A check that fails on one rank must not leave the others waiting in the closing collective: failures are collected,
+    # agreed on by all ranks (all-reduce of a flag), and every rank leaves through the same barrier before it exits.
+    failure = None
     validation = None
     if not args.no_validate:
-        validation = validate_columns(eng, flat, k, tip_states, lnl)
+        try:
+            validation = validate_columns(eng, flat, k, tip_states, lnl)
+        except SystemExit as e:
+            failure = str(e)
 
     if rank == 0:
         units_per_step = N * k * cpg * world
@@ -482,9 +578,9 @@ def main():
                     ratio = entry['td_bytes_per_step'] / per_step['top_down']
                     traffic_note = 'PMC bytes / model bytes = {:.3f}'.format(ratio)
                     if not 0.85 <= ratio <= 1.15:
-                        raise SystemExit('HBM counters ({:.3g} B per step) and the byte model ({:.3g}) of td_f81_kernel '
-                                         'disagree by more than 15 %'.format(entry['td_bytes_per_step'],
-                                                                             per_step['top_down']))
+                        failure = failure or ('HBM counters ({:.3g} B per step) and the byte model ({:.3g}) of '
+                                              'td_f81_kernel disagree by more than 15 %'
+                                              .format(entry['td_bytes_per_step'], per_step['top_down']))
             except (OSError, ValueError, KeyError) as e:
                 traffic_note = 'profiles/traffic.json unreadable: {}'.format(e)
         avg_launch_s = td_ms / max(1, td_launches) * 1e-3
@@ -554,9 +650,14 @@ def main():
         elif profiled and world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = None
             out['cpu_baseline_note'] = 'skipped: a profiler is attached (no worker processes from a GPU-initialised process)'
+    any_failure = float(comm.allreduce([1.0 if failure else 0.0], op='max')[0]) > 0
     comm.barrier()
     sharding.shutdown()
     eng.close()
+    if any_failure:
+        if failure:
+            sys.stderr.write('bench.py, rank {}: {}\n'.format(rank, failure))
+        sys.exit(3)
     if rank == 0:
         if world == 1 and not args.no_secondary and args.workload == 'cfg4':
             try:

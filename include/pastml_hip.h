@@ -216,6 +216,13 @@ int pml_comm_allreduce(pml_ctx* ctx, const double* in, double* out, int32_t coun
  * over the characters of pastml/acr.py:226-231).  Collective.
  */
 int pml_allreduce_loglik(pml_ctx* ctx, const double* loglik, int32_t n_cols, double* total_out);
+/*
+ * The same total without a host round trip of its own: when a communicator is attached, pml_marginal_pass forms the sum
+ * of its columns' log-likelihoods on the device (column order), all-reduces it on the sweep's stream behind the sweeps
+ * and copies it back before its one wait; pml_loglik_total hands that value out (once per pml_marginal_pass; every rank
+ * must use the same route).
+ */
+int pml_loglik_total(pml_ctx* ctx, double* total_out);
 /* hipDeviceSynchronize on the given device (benchmarks bracket their timed region with it) */
 int pml_device_sync(int device);
 

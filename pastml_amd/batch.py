@@ -1187,11 +1187,30 @@ def _column_bytes(flat, k, widths):
     return flat.n_nodes * ((17 * ks + 96) + sum(widths) / max(1, len(widths)) * (8 * ks + 64))
 
 
+def visible_devices(device=None):
+    """
+    The GPUs one process spreads its groups of characters over.  A process that is one rank of a multi-process launch
+    (RANK / LOCAL_RANK / PASTML_HIP_DEVICE set: one process per GPU, pastml_amd.sharding) keeps to its own device; a
+    plain call -- what pastml.acr.acr() with threads is in the reference (acr.py:226-231) -- takes every visible
+    device.  PASTML_AMD_DEVICES="0,1,..." picks them explicitly (a device may be named twice: tests on one GPU).
+    """
+    if device is not None:
+        return [int(device)]
+    env = os.environ.get('PASTML_AMD_DEVICES')
+    if env:
+        return [int(x) for x in env.split(',') if x.strip() != '']
+    if any(v in os.environ for v in ('LOCAL_RANK', 'PASTML_HIP_DEVICE')) or int(os.environ.get('WORLD_SIZE', 1)) > 1:
+        return [hip.default_device()]
+    return list(range(max(1, hip.device_count())))
+
+
 def run_tasks(forest, tasks, force_joint=True, device=None, flat=None):
     """
     ml_acr for a list of Tasks on one forest.  Characters are grouped by (number of states, model family, prediction
     method); a group becomes one CharacterBatch -- or several, if the device memory does not hold all of its columns
-    at once.  Returns one list of result dictionaries per task, in task order.
+    at once, or if there are several GPUs to spread a large group over (visible_devices).  Results do not depend on
+    the placement: a column's bits depend on nothing but the column.  Returns one list of result dictionaries per
+    task, in task order.
     """
     if isinstance(forest, TreeNode):
         forest = [forest]
@@ -1202,18 +1221,37 @@ def run_tasks(forest, tasks, force_joint=True, device=None, flat=None):
         groups.setdefault(t.group_key, []).append(i)
     out = [None] * len(tasks)
     stats = dict(groups=0, rounds=0, sweeps=0)
-    with hip.BareContext(device) as probe:
-        _, free = probe.memory()
+    devices = visible_devices(device)
+    free = None
+    for dev in sorted(set(devices)):
+        with hip.BareContext(dev) as probe:
+            _, f = probe.memory()
+        free = f if free is None else min(free, f)
     if os.environ.get('PASTML_AMD_DEVICE_BYTES'):   # plan as if the device had this much free memory (tests)
         free = min(free, int(float(os.environ['PASTML_AMD_DEVICE_BYTES'])))
-    jobs, total_bytes = [], 0.0
+    # a group is split over the devices when it is worth a second context (nodes x characters; small forests are bound
+    # by the host loop, which does not get shorter)
+    split_min = float(os.environ.get('PASTML_AMD_SPLIT_MIN_WORK', 2e5))
+    jobs, job_bytes = [], []
     for key, members in groups.items():
         k = key[0]
         per_char = _column_bytes(flat, k, [block_width(tasks[i].model) for i in members])
         chunk = max(1, min(len(members), 4096, int(0.6 * free / max(1.0, per_char))))
+        if len(devices) > 1 and len(members) >= 2 and flat.n_nodes * len(members) >= split_min:
+            chunk = min(chunk, -(-len(members) // len(devices)))
         for a in range(0, len(members), chunk):
             jobs.append((k, members[a:a + chunk]))
-            total_bytes += per_char * len(members[a:a + chunk])
+            job_bytes.append(per_char * len(members[a:a + chunk]))
+    # placement: largest job first, each on the device that holds the least so far (deterministic)
+    load = [0.0] * len(devices)
+    job_device = [devices[0]] * len(jobs)
+    for j in sorted(range(len(jobs)), key=lambda q: (-job_bytes[q], q)):
+        d = min(range(len(devices)), key=lambda q: (load[q], q))
+        job_device[j] = devices[d]
+        load[d] += job_bytes[j]
+    jobs = [(k, part, job_device[j]) for j, (k, part) in enumerate(jobs)]
+    total_bytes = max(load) if load else 0.0
+    stats['devices'] = sorted(set(job_device)) if jobs else []
 
     # restart seeds of all characters, drawn here in task order (the groups may run concurrently)
     seeds = np.random.randint(0, 2 ** 31 - 1, size=len(tasks))
@@ -1223,16 +1261,16 @@ def run_tasks(forest, tasks, force_joint=True, device=None, flat=None):
     import time
 
     def prepare(job):
-        k, part = job
+        k, part, dev = job
         group = [tasks[i] for i in part]
-        batch = CharacterBatch(flat, k, len(group), device=device)
+        batch = CharacterBatch(flat, k, len(group), device=dev)
         for c, t in enumerate(group):
             batch.set_annotation(c, *annotation_words(flat, t.character, t.model.states))
         batch.initialize_allowed_states()
         return batch, group
 
     def run(job):
-        k, part = job
+        k, part = job[:2]
         t0 = time.perf_counter()
         batch, group = prepare(job)
         with batch:

@@ -2342,6 +2342,21 @@ int pml_marginal_pass(pml_ctx* ctx, double* loglik_out, int32_t* err_parent, int
         ctx->bu_mode = 1;  // provisional, for run_top_down's bookkeeping; collect_bottom_up has the last word
         PML_TRY(run_top_down(ctx));
     }
+    // a communicator is attached: the one collective of the path goes on the stream right here, behind the sweeps --
+    // the rank's sum formed on the device from the values the sweep left in pinned memory, all-reduced over RCCL, copied
+    // back; the single wait of this call (fetch_marginals) covers it.  pml_loglik_total hands the result out.
+    if (ctx->comm != nullptr) {
+        PmlComm* cm = ctx->comm;
+        hipLaunchKernelGGL(sum_loglik_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->h_loglik, ctx->C, cm->d_total);
+        HIP_TRY(hipGetLastError());
+        if (cm->comm) {
+            PmlRccl* r = pml_rccl();
+            const ncclResult_t e = r->AllReduce(cm->d_total, cm->d_total, 1, ncclDouble, ncclSum, cm->comm, ctx->stream);
+            if (e != ncclSuccess) return fail(PML_ERR_HIP, "ncclAllReduce failed: %s", r->GetErrorString(e));
+        }
+        HIP_TRY(hipMemcpyAsync(cm->h_total, cm->d_total, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        cm->total_fresh = true;
+    }
     const int fetched = fetch_marginals(ctx, posterior_out, lh_sum_out, lh_sf_out);  // synchronises
     ctx->bu_mode = -1;
     const int status = collect_bottom_up(ctx, 1, loglik_out, err_parent, err_child);
@@ -2660,6 +2675,13 @@ int pml_comm_init(pml_ctx* ctx, int rank, int world, const unsigned char* id) {
             return fail(PML_ERR_HIP, "ncclCommInitRank failed: %s", r->GetErrorString(e));
         }
     }
+    if (hipMalloc((void**)&c->d_total, sizeof(double)) != hipSuccess ||
+        hipHostMalloc((void**)&c->h_total, sizeof(double)) != hipSuccess) {
+        if (c->comm) (void)pml_rccl()->CommDestroy(c->comm);
+        if (c->d_total) (void)hipFree(c->d_total);
+        delete c;
+        return fail(PML_ERR_HIP, "allocation of the communicator's buffers failed");
+    }
     ctx->comm = c;
     return PML_OK;
 }
@@ -2672,6 +2694,8 @@ int pml_comm_destroy(pml_ctx* ctx) {
     if (c->comm) (void)pml_rccl()->CommDestroy(c->comm);
     if (c->d_buf) (void)hipFree(c->d_buf);
     if (c->h_buf) (void)hipHostFree(c->h_buf);
+    if (c->d_total) (void)hipFree(c->d_total);
+    if (c->h_total) (void)hipHostFree(c->h_total);
     delete c;
     ctx->comm = nullptr;
     return PML_OK;
@@ -2716,6 +2740,15 @@ int pml_allreduce_loglik(pml_ctx* ctx, const double* loglik, int32_t n_cols, dou
     double local = 0.0;
     for (int i = 0; i < n_cols; ++i) local += loglik[i];
     return pml_comm_allreduce(ctx, &local, total_out, 1, PML_COMM_SUM);
+}
+
+int pml_loglik_total(pml_ctx* ctx, double* total_out) {
+    if (!ctx || !ctx->comm) return fail(PML_ERR_INVALID, "no communicator: call pml_comm_init first");
+    if (!total_out) return fail(PML_ERR_INVALID, "total_out is NULL");
+    if (!ctx->comm->total_fresh) return fail(PML_ERR_INVALID, "no pml_marginal_pass since the last pml_loglik_total");
+    *total_out = ctx->comm->h_total[0];  // (pml_marginal_pass has waited for the stream)
+    ctx->comm->total_fresh = false;
+    return PML_OK;
 }
 
 int pml_device_sync(int device) {

@@ -50,4 +50,9 @@ struct PmlComm {
     double* d_buf = nullptr;  // device staging of the reduced values
     double* h_buf = nullptr;  // pinned
     size_t cap = 0;
+    // pml_marginal_pass with a communicator: sum of the rank's log-likelihoods formed on the device and all-reduced on
+    // the sweep's stream; the result waits here for pml_loglik_total
+    double* d_total = nullptr;
+    double* h_total = nullptr;  // pinned
+    bool total_fresh = false;
 };

@@ -478,6 +478,16 @@ td_fill_kernel(PmlTree t, PmlCols c, PmlState st, const double* __restrict__ P, 
     }
 }
 
+// sum of the columns' log-likelihoods in column order (as a host loop over the characters would add them), on the device:
+// the values are where the last kernel of the sweep put them (pinned host memory, visible to the device)
+__global__ void sum_loglik_kernel(const double* __restrict__ loglik, int n, double* __restrict__ total) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        double acc = 0.0;
+        for (int i = 0; i < n; ++i) acc += loglik[i];
+        total[0] = acc;
+    }
+}
+
 __global__ void reset_err_kernel(u64* __restrict__ err, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) err[i] = ~0ull;

@@ -80,6 +80,7 @@ SIGNATURES = {
     'pml_pij_batch': [_ctx_p, _c_double_p],
     'pml_bottom_up': [_ctx_p, ctypes.c_int, _c_double_p, _c_int32_p, _c_int32_p],
     'pml_bottom_up_submit': [_ctx_p, ctypes.c_int],
+    'pml_loglik_total': [_ctx_p, _c_double_p],
     'pml_bottom_up_collect': [_ctx_p, ctypes.c_int, _c_double_p, _c_int32_p, _c_int32_p],
     'pml_top_down_marginals': [_ctx_p, _c_double_p, _c_double_p, _c_double_p],
     'pml_marginal_pass': [_ctx_p, _c_double_p, _c_int32_p, _c_int32_p, _c_double_p, _c_double_p, _c_double_p],
@@ -329,9 +330,25 @@ class BareContext(object):
                 raise ValueError('unique_id must be {} bytes'.format(COMM_ID_BYTES))
             buf = (ctypes.c_ubyte * COMM_ID_BYTES).from_buffer_copy(bytes(unique_id))
         _check(self._lib.pml_comm_init(self._ctx, rank, world, buf))
+        self._comm_attached = True
+        self._total_fresh = False
 
     def comm_destroy(self):
         _check(self._lib.pml_comm_destroy(self._ctx))
+        self._comm_attached = False
+        self._total_fresh = False
+
+    def loglik_total(self):
+        """
+        Sum over all ranks of the log-likelihoods of the last marginal_pass, reduced on the device behind the sweeps
+        (pml_loglik_total); None if no marginal pass has run on this context since the last call.
+        """
+        if not getattr(self, '_total_fresh', False):
+            return None
+        total = ctypes.c_double(0)
+        _check(self._lib.pml_loglik_total(self._ctx, ctypes.byref(total)))
+        self._total_fresh = False
+        return total.value
 
     def allreduce(self, values, op=COMM_SUM):
         """Sum (or max) over the ranks of a float array; returns a new array."""
@@ -552,6 +569,7 @@ class Engine(BareContext):
                                              None if post is None else _ptr(post, dbl),
                                              None if lh_sum is None else _ptr(lh_sum, dbl),
                                              None if lh_sf is None else _ptr(lh_sf, dbl))
+        self._total_fresh = getattr(self, '_comm_attached', False)   # (the collective is on the stream whatever the status)
         if status == PML_ZERO_LIKELIHOOD:
             raise ZeroLikelihoodError(self._lib.pml_last_error().decode(), ep, ec, lnl)
         _check(status)

@@ -11,9 +11,13 @@ them, so does ``bench.py --gpus N`` for the processes it starts).  ``init()`` pi
 * world == 1                       -> :class:`LocalCommunicator` (no library, no GPU needed)
 * PASTML_AMD_COMM=gloo             -> :class:`TorchCommunicator` on gloo (CPU: tests and dry runs of the N > 1 path on
                                       boxes with fewer GPUs than ranks -- RCCL refuses two ranks per device)
-* otherwise                        -> :class:`RcclCommunicator`; if it cannot be set up (no librccl, ...) a warning and
-                                      torch.distributed's nccl backend behind the same interface (PASTML_AMD_COMM=torch-nccl
-                                      asks for it directly)
+* PASTML_AMD_COMM=torch-nccl       -> :class:`TorchCommunicator` on torch.distributed's nccl backend (RCCL through torch)
+* otherwise                        -> :class:`RcclCommunicator`.  Whether it can be set up is decided by ALL ranks together
+                                      (``agree``): every rank reports "ready" or its failure in the job's rendezvous
+                                      directory before anyone enters the collective initialisation; if one rank failed, or
+                                      did not report in time, every rank raises -- no rank is left waiting inside
+                                      ncclCommInitRank, and there is no per-rank fallback that would split the job over two
+                                      communicators.
 """
 import os
 import time
@@ -110,6 +114,47 @@ def exchange_unique_id(rank, make_id, timeout=300.0):
         time.sleep(0.01)
 
 
+def agree(rank, world, ok, reason='', stage='ready', timeout=None):
+    """
+    All-or-none decision through the rendezvous directory (no collective is available yet): every rank writes its
+    verdict, then waits -- for a bounded time, rank 0 included -- until all verdicts are there.  Raises RuntimeError on
+    every rank if any rank reported a failure or is missing after ``timeout`` seconds (PASTML_AMD_RDZV_TIMEOUT, 120).
+    """
+    if timeout is None:
+        timeout = float(os.environ.get('PASTML_AMD_RDZV_TIMEOUT', '120'))
+    d = _rendezvous_dir()
+    os.makedirs(d, exist_ok=True)
+    mine = os.path.join(d, '{}_{}'.format(stage, rank))
+    tmp = mine + '.tmp{}'.format(os.getpid())
+    with open(tmp, 'w') as f:
+        f.write('ok' if ok else 'failed: {}'.format(reason))
+    os.replace(tmp, mine)
+    t0 = time.time()
+    verdicts = {}
+    while len(verdicts) < world:
+        for r in range(world):
+            if r not in verdicts:
+                try:
+                    with open(os.path.join(d, '{}_{}'.format(stage, r))) as f:
+                        text = f.read()
+                    if text:
+                        verdicts[r] = text
+                except OSError:
+                    pass
+        if any(v != 'ok' for v in verdicts.values()):
+            break   # no need to wait for the rest
+        if len(verdicts) < world:
+            if time.time() - t0 > timeout:
+                missing = sorted(set(range(world)) - set(verdicts))
+                raise RuntimeError('rank {}: ranks {} did not report "{}" within {:.0f} s'.format(rank, missing, stage,
+                                                                                                   timeout))
+            time.sleep(0.01)
+    bad = {r: v for r, v in verdicts.items() if v != 'ok'}
+    if bad:
+        raise RuntimeError('rank {}: the communicator cannot be set up on every rank: {}'.format(
+            rank, '; '.join('rank {} {}'.format(r, v) for r, v in sorted(bad.items()))))
+
+
 class RcclCommunicator(object):
     """
     The library's communicator on a bare device context of this rank's GPU (``pml_comm_*``, RCCL over xGMI).
@@ -122,23 +167,35 @@ class RcclCommunicator(object):
         from pastml_amd import hip
         self.rank, self.world = rank, world
         self._own = engine is None
-        self._eng = engine if engine is not None else hip.BareContext(device)
         forced = bool(os.environ.get('PASTML_HIP_COMM_FORCE_RCCL'))
-        uid, path = exchange_unique_id(rank, hip.comm_unique_id) if (world > 1 or forced) else (None, None)
-        self._eng.comm_init(rank, world, uid)   # collective: returns once every rank has read the id
-        if rank == 0 and path:
-            try:
-                os.remove(path)
-                os.rmdir(os.path.dirname(path))
-            except OSError:
-                pass
+        self._eng = None
+        uid = path = None
+        problem = None
+        seq = _RDZV_SEQ[0]   # successive communicators of one job use successive file names
+        self._rdzv = _rendezvous_dir() if world > 1 else None
+        try:
+            self._eng = engine if engine is not None else hip.BareContext(device)
+            if world > 1 or forced:
+                uid, path = exchange_unique_id(rank, hip.comm_unique_id,
+                                               timeout=float(os.environ.get('PASTML_AMD_RDZV_TIMEOUT', '120')))
+        except Exception as e:   # no device, no librccl, no id from rank 0, ...
+            problem = e
+        if world > 1:
+            # everybody, or nobody, enters the collective initialisation
+            agree(rank, world, problem is None, reason=repr(problem), stage='ready{}'.format(seq))
+        elif problem is not None:
+            raise problem
+        self._eng.comm_init(rank, world, uid)   # collective: returns once every rank has joined
 
     def allreduce(self, values, op='sum'):
         from pastml_amd import hip
         return self._eng.allreduce(values, hip.COMM_SUM if op == 'sum' else hip.COMM_MAX)
 
     def allreduce_loglik(self, loglik):
-        return self._eng.allreduce_loglik(loglik)
+        # after a marginal pass on the engine this communicator is attached to, the total is already there: the library
+        # reduced it on the device, on the sweep's stream (no host round trip of its own)
+        total = self._eng.loglik_total() if not self._own else None
+        return total if total is not None else self._eng.allreduce_loglik(loglik)
 
     def barrier(self):
         self._eng.allreduce([0.0])
@@ -149,6 +206,15 @@ class RcclCommunicator(object):
             if self._own:
                 self._eng.close()
             self._eng = None
+        if self.rank == 0 and self._rdzv:
+            # (callers close after a barrier: every rank is past the rendezvous) the job's files can go
+            try:
+                for name in os.listdir(self._rdzv):
+                    os.remove(os.path.join(self._rdzv, name))
+                os.rmdir(self._rdzv)
+            except OSError:
+                pass
+            self._rdzv = None
 
 
 class TorchCommunicator(object):
@@ -212,13 +278,9 @@ def init(device=None, engine=None, kind=None):
     elif kind == 'torch-nccl':
         _COMM = TorchCommunicator(rank, world, 'nccl', device=device)
     else:
-        try:
-            _COMM = RcclCommunicator(rank, world, device=local_rank if device is None else device, engine=engine)
-        except Exception as e:   # librccl missing, no id from rank 0, ...: the same failure on every rank of the node
-            import sys
-            sys.stderr.write('pastml_amd.sharding: the library\'s RCCL communicator failed ({}); falling back to '
-                             'torch.distributed (nccl)\n'.format(e))
-            _COMM = TorchCommunicator(rank, world, 'nccl', device=device)
+        # no automatic fallback: a failure is a failure of the job, on every rank (RcclCommunicator / agree);
+        # PASTML_AMD_COMM=torch-nccl is there for whoever wants torch's communicator
+        _COMM = RcclCommunicator(rank, world, device=local_rank if device is None else device, engine=engine)
     return _COMM
 
 

@@ -806,3 +806,33 @@ def test_zero_likelihood_of_one_character_fails_the_batch_cleanly():
     assert not [th for th in threading.enumerate() if th.name.startswith('pastml-opt')]
     tree, results = albania_result(JC)
     assert results[0][LOG_LIKELIHOOD] < 0
+
+
+def test_groups_spread_over_devices_with_the_same_bits(monkeypatch):
+    """
+    A plain acr() call takes every visible GPU: groups of characters are cut into one chunk per device and placed
+    largest first (batch.run_tasks, visible_devices); all chunks advance in the one optimiser loop, each on its own
+    device context.  Here the "devices" are GPU 0 twice: same placement logic, and every character must come out with
+    exactly the numbers of the single-device run.
+    """
+    from pastml_amd.batch import run_tasks
+    tree = read_tree(TREE_NWK)
+    df = _multi_character_table(tree)
+    models = [F81, JC, F81, EFT, F81, JC]
+    one = acr(tree, df.copy(), prediction_method=MPPA, model=models)
+    assert run_tasks.last_stats['devices'] == [0] and run_tasks.last_stats['groups'] == 3
+    monkeypatch.setenv('PASTML_AMD_DEVICES', '0,0')
+    monkeypatch.setenv('PASTML_AMD_SPLIT_MIN_WORK', '0')
+    tree2 = read_tree(TREE_NWK)
+    two = acr(tree2, df.copy(), prediction_method=MPPA, model=models)
+    assert run_tasks.last_stats['groups'] == 5     # k = 2: 2 + 1 characters -> 2 chunks, k = 5: 3 -> 2 chunks, k = 3: 1
+    for a, b in zip(one, two):
+        assert a['character'] == b['character'] and a[LOG_LIKELIHOOD] == b[LOG_LIKELIHOOD]
+        assert np.array_equal(a[MARGINAL_PROBABILITIES].values, b[MARGINAL_PROBABILITIES].values)
+        for m in (JOINT, MAP, MPPA):
+            key = RESTRICTED_LOG_LIKELIHOOD_FORMAT_STR.format(m)
+            assert a[key] == b[key]
+        assert a[MODEL].sf == b[MODEL].sf and np.array_equal(a[MODEL].frequencies, b[MODEL].frequencies)
+    f1, f2 = FlatForest.from_trees([tree]), FlatForest.from_trees([tree2])
+    for column in df.columns:
+        assert [getattr(n, column) for n in f1.nodes] == [getattr(n, column) for n in f2.nodes]

@@ -156,3 +156,51 @@ def test_bench_two_ranks_under_torchrun(tmp_path):
     line = json.loads(lines[0])
     assert line['n_gpus'] == 2 and line['config']['chars_total'] == 4 and line['config']['collective'] == 'gloo'
     np.testing.assert_allclose(line['loglik_sum'], _single_process_logliks(4, 14, 64).sum(), rtol=1e-13)
+
+
+def test_bench_ends_when_a_rank_dies_before_joining(tmp_path):
+    """
+    A rank that dies mid-initialisation must not leave the job hanging: `bench.py --gpus 2` watches all its ranks, stops
+    the survivor (which waits for the dead rank in the communicator's rendezvous) and exits non-zero -- within seconds,
+    not at a collective's timeout.
+    """
+    import time
+    env = dict(os.environ, BENCH_ALL_RANKS_ON_GPU0='1', PASTML_AMD_COMM='gloo', BENCH_TEST_DIE_RANK='1')
+    for key in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'PASTML_AMD_RDZV_DIR'):
+        env.pop(key, None)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0',
+                        '--workload', 'cfg4_small', '--chars-per-gpu', '1', '--no-cpu-baseline'], env=env,
+                       capture_output=True, timeout=120)
+    assert r.returncode != 0
+    assert time.time() - t0 < 30
+    assert b'rank 1 exited with code 7' in r.stderr
+
+
+def test_marginal_pass_reduces_the_total_on_the_device(monkeypatch):
+    """
+    With a communicator attached pml_marginal_pass puts the one collective of the path on the sweep's stream itself: the
+    rank's sum formed on the device (column order), ncclAllReduce, the copy back -- all behind the sweeps and before the
+    call's single wait; pml_loglik_total hands the value out.  One rank through librccl (PASTML_HIP_COMM_FORCE_RCCL).
+    """
+    monkeypatch.setenv('PASTML_HIP_COMM_FORCE_RCCL', '1')
+    flat = synthetic.balanced_forest(9)
+    k, C = 12, 5
+    with hip.Engine(flat, C, k) as eng:
+        eng.set_models([(dict(kind=0, pi=synthetic.f81_frequencies(k, c)), (1.0, 0.0, 1.0)) for c in range(C)])
+        eng.set_tip_states(np.stack([synthetic.tip_states(flat.n_tips, k, c) for c in range(C)]))
+        assert eng.loglik_total() is None                       # no communicator yet
+        eng.comm_init(0, 1, hip.comm_unique_id())
+        for _ in range(3):                                      # (the third pass replays the captured graph)
+            lnl = eng.marginal_pass(posterior=False, lh=False)[0]
+            want = 0.0
+            for v in lnl:
+                want += float(v)
+            assert eng.loglik_total() == want
+            assert eng.loglik_total() is None                   # handed out once per pass
+        comm = sharding.RcclCommunicator.__new__(sharding.RcclCommunicator)
+        comm._eng, comm._own, comm.rank, comm.world, comm._rdzv = eng, False, 0, 1, None
+        lnl = eng.marginal_pass(posterior=False, lh=False)[0]
+        assert comm.allreduce_loglik(lnl) == want               # the communicator takes the device's total
+        assert comm.allreduce_loglik(lnl) == want               # ... or reduces the values it is given
+        eng.comm_destroy()

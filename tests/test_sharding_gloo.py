@@ -91,3 +91,37 @@ def test_local_communicator_and_id_exchange(tmp_path, monkeypatch):
     monkeypatch.setattr(sharding, '_RDZV_SEQ', [0])
     got, path2 = sharding.exchange_unique_id(1, None, timeout=5)
     assert got == data == b'x' * 128 and path == path2
+
+
+def test_communicator_setup_is_all_or_none(tmp_path, monkeypatch):
+    """
+    sharding.agree: before any rank enters the collective initialisation every rank reports "ready" or its failure in
+    the rendezvous directory.  One failing rank makes EVERY rank raise (no rank waits inside ncclCommInitRank, no rank
+    falls back to another communicator on its own); a rank that never reports makes the others raise after the bound.
+    """
+    import threading
+    from pastml_amd import sharding
+    monkeypatch.setenv('PASTML_AMD_RDZV_DIR', str(tmp_path / 'a'))
+    outcome = {}
+
+    def rank(r, ok, stage, timeout=20):
+        try:
+            sharding.agree(r, 3, ok, reason='no librccl here', stage=stage, timeout=timeout)
+            outcome[r] = 'went on'
+        except RuntimeError as e:
+            outcome[r] = str(e)
+
+    def run(verdicts, stage, ranks=(0, 1, 2), timeout=20):
+        outcome.clear()
+        threads = [threading.Thread(target=rank, args=(r, verdicts[r], stage, timeout)) for r in ranks]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        return dict(outcome)
+
+    assert run({0: True, 1: True, 2: True}, 'ready0') == {0: 'went on', 1: 'went on', 2: 'went on'}
+    got = run({0: True, 1: False, 2: True}, 'ready1')
+    assert all('rank 1 failed: no librccl here' in got[r] for r in (0, 1, 2))
+    got = run({0: True, 1: True, 2: True}, 'ready2', ranks=(0, 2), timeout=0.5)   # rank 1 never shows up
+    assert all('ranks [1] did not report' in got[r] for r in (0, 2))
