@@ -73,8 +73,11 @@ int pml_ctx_sync(pml_ctx* ctx);
  * eigen) always store the vectors of internal nodes.
  * PML_OPT_EIGEN_FUSED (default 1, may be changed at any time): eigen-decomposed models with 16 <= k <= 32 run the fused
  * matrix-core sweeps (P(t) built and consumed in registers); 0 selects the sweeps that read materialised P(t) from HBM.
+ * PML_OPT_EIGEN_JOINT_VALU (default 1, may be changed at any time): the JOINT sweep of eigen-decomposed models with
+ * k <= 32 runs on the FP64 vector units (the default: faster than the matrix cores for this sweep);
+ * 0 sends it to the kernels PML_OPT_EIGEN_FUSED selects -- kept as the cross-check of the default path.
  */
-enum { PML_OPT_CHERRY_FUSION = 1, PML_OPT_KEEP_TD = 2, PML_OPT_EIGEN_FUSED = 3 };
+enum { PML_OPT_CHERRY_FUSION = 1, PML_OPT_KEEP_TD = 2, PML_OPT_EIGEN_FUSED = 3, PML_OPT_EIGEN_JOINT_VALU = 4 };
 int pml_ctx_set_option(pml_ctx* ctx, int option, int value);
 /* bytes of device memory currently held by the ctx / free on its device */
 int pml_ctx_memory(pml_ctx* ctx, uint64_t* held, uint64_t* device_free);

@@ -44,6 +44,21 @@ COPY = 'COPY'
 warnings.filterwarnings("ignore", append=True)
 
 
+def _table_value(value):
+    """
+    A result value as it goes into the parameter table.  The number of scenarios is a product over all nodes and can have
+    tens of thousands of digits at 10^5 tips; Python refuses to print integers of more than 4 300 digits (and the
+    reference's own writer fails there): beyond that the value is written as mantissa and decimal exponent.
+    """
+    if isinstance(value, int) and not isinstance(value, bool) and value.bit_length() > 14000:
+        import math
+        shift = value.bit_length() - 64
+        log10 = math.log10(value >> shift) + shift * math.log10(2.0)
+        exponent = int(math.floor(log10))
+        return '{:.6f}e+{}'.format(10.0 ** (log10 - exponent), exponent)
+    return value
+
+
 def _serialize_acr(args):
     """
     Writes one reconstruction result into ``work_dir`` in the reference's two table formats (pastml/acr.py:45-73): the
@@ -64,7 +79,7 @@ def _serialize_acr(args):
                                                             column=character))
     with open(path, 'w+') as out:
         out.write('parameter\tvalue\n')
-        out.writelines('{}\t{}\n'.format(*row) for row in rows)
+        out.writelines('{}\t{}\n'.format(key, _table_value(value)) for key, value in rows)
         if is_ml(method):
             model.save_parameters(out)
     logger.debug('Serialized ACR parameters and statistics for {} to {}.'.format(character, path))
@@ -212,8 +227,6 @@ def acr(forest, df=None, columns=None, column2states=None, prediction_method=MPP
     column2rates = column2rates or {}
     methods = value2list(len(columns), prediction_method, MPPA)
     model_names = value2list(len(columns), model, F81)
-    optimise_tau = tau is None or reoptimise
-    tau = 0 if tau is None else tau
 
     # what to do per column: ('ml', Task) / ('mp', states) / ('copy', states)
     plan = []
@@ -241,6 +254,13 @@ def acr(forest, df=None, columns=None, column2states=None, prediction_method=MPP
         if is_parsimonious(method):
             plan.append(('mp', character, method, states))
             continue
+        # As in the reference (acr.py:185-187, inside its loop over the characters): with tau=None -- "smoothing" of the
+        # pipeline -- the FIRST maximum-likelihood character optimises tau and resets the argument to 0, so the later
+        # characters get tau = 0, fixed (unless reoptimise).  Probably unintended there; reproduced, because the results
+        # of columns 2..n depend on it (tests/test_host_logic.py pins it).
+        optimise_tau = tau is None or reoptimise
+        if tau is None:
+            tau = 0
         missing, observed, state2index = calculate_observed_freqs(character, forest, states, flat)
         logger.debug('Observed frequencies for {}:{}{}.'.format(
             character, ''.join('\n\tfrequency of {}:\t{:.6f}'.format(s, observed[state2index[s]]) for s in states),
@@ -252,12 +272,20 @@ def acr(forest, df=None, columns=None, column2states=None, prediction_method=MPP
                                            character=character)
         plan.append(('ml', character, method, Task(character, method, instance, observed)))
 
+    # restart seeds of the optimisers: one per maximum-likelihood character of the CALL, drawn before the characters are
+    # dealt out to the ranks, so that a character restarts from the same points however many processes share the work
+    n_ml = sum(1 for item in plan if item[0] == 'ml')
+    seeds_all = np.random.randint(0, 2 ** 31 - 1, size=n_ml) if n_ml else np.zeros(0, dtype=np.int64)
+    ml_rank = np.cumsum([item[0] == 'ml' for item in plan]) - 1
     # one process per GPU: this rank's contiguous block of the characters
     comm = sharding.communicator()
+    mine = range(len(plan))
     if comm is not None and comm.world > 1:
-        plan = [plan[i] for i in sharding.shard_characters(len(plan), comm.rank, comm.world)]
+        mine = sharding.shard_characters(len(plan), comm.rank, comm.world)
+    seeds = np.array([seeds_all[ml_rank[i]] for i in mine if plan[i][0] == 'ml'], dtype=np.int64)
+    plan = [plan[i] for i in mine]
     tasks = [item[3] for item in plan if item[0] == 'ml']
-    ml_results = iter(run_tasks(forest, tasks, force_joint=force_joint, flat=flat)) if tasks else iter(())
+    ml_results = iter(run_tasks(forest, tasks, force_joint=force_joint, flat=flat, seeds=seeds)) if tasks else iter(())
     results = []
     for kind, character, method, payload in plan:
         if kind == 'ml':

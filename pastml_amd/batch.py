@@ -1204,7 +1204,7 @@ def visible_devices(device=None):
     return list(range(max(1, hip.device_count())))
 
 
-def run_tasks(forest, tasks, force_joint=True, device=None, flat=None):
+def run_tasks(forest, tasks, force_joint=True, device=None, flat=None, seeds=None):
     """
     ml_acr for a list of Tasks on one forest.  Characters are grouped by (number of states, model family, prediction
     method); a group becomes one CharacterBatch -- or several, if the device memory does not hold all of its columns
@@ -1253,8 +1253,11 @@ def run_tasks(forest, tasks, force_joint=True, device=None, flat=None):
     total_bytes = max(load) if load else 0.0
     stats['devices'] = sorted(set(job_device)) if jobs else []
 
-    # restart seeds of all characters, drawn here in task order (the groups may run concurrently)
-    seeds = np.random.randint(0, 2 ** 31 - 1, size=len(tasks))
+    # restart seeds of all characters, in task order (the groups advance together); acr() hands in the ones it drew for
+    # the whole call when the characters are shared out over several processes
+    if seeds is None:
+        seeds = np.random.randint(0, 2 ** 31 - 1, size=len(tasks))
+    seeds = np.asarray(seeds)
 
     per_group = []   # (diagnostics) where the time of a run goes: one entry per group of characters
 

@@ -155,6 +155,7 @@ struct pml_ctx {
     bool td_vec_valid = false; // the TD vectors of the last top-down sweep are in d_td
     bool td_filled = false;    // ... including those of the nodes the sweeps do not store (td_fill_kernel)
     bool eig_fused_opt = true; // PML_OPT_EIGEN_FUSED
+    bool eigj_valu_opt = true; // PML_OPT_EIGEN_JOINT_VALU
     const PmlUnit* units_override = nullptr;  // set around a dispatch_sweep on the block schedule's top lists
 
     PmlComm* comm = nullptr;   // RCCL communicator attached by pml_comm_init (survives tree uploads)
@@ -827,7 +828,7 @@ static int launch_eigen_narrow(pml_ctx* ctx, int mode, const int* nodes, const i
 // PASTML_HIP_NO_EIGEN_JOINT_VALU keeps the matrix-core kernels (pml_kernels_eigen_mfma.h).
 static bool eigen_joint_valu(const pml_ctx* c) {
     static const bool off = getenv("PASTML_HIP_NO_EIGEN_JOINT_VALU") != nullptr;
-    return !off && c->kind == PML_MODEL_EIGEN && c->k >= 2 && c->k <= PML_EIGJ_STRIDE && c->W == 1 &&
+    return !off && c->eigj_valu_opt && c->kind == PML_MODEL_EIGEN && c->k >= 2 && c->k <= PML_EIGJ_STRIDE && c->W == 1 &&
            c->d_AinvT != nullptr;
 }
 
@@ -1027,6 +1028,16 @@ int pml_ctx_set_option(pml_ctx* ctx, int option, int value) {
         ctx->eig_fused_opt = value != 0;
         return PML_OK;
     }
+    if (option == PML_OPT_EIGEN_JOINT_VALU) {
+        if ((value != 0) != ctx->eigj_valu_opt) {
+            drop_graph(ctx->bu_graph[0]);
+            ctx->prep_dirty = true;
+            ctx->bu_mode = -1;
+            ctx->td_valid = ctx->js_valid = false;
+        }
+        ctx->eigj_valu_opt = value != 0;
+        return PML_OK;
+    }
     return fail(PML_ERR_INVALID, "unknown option %d", option);
 }
 
@@ -1127,12 +1138,13 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
 
     int device = ctx->device;
     const bool profile = ctx->profile;
-    const bool fuse = ctx->fuse, keep_td = ctx->keep_td, eig_fused_opt = ctx->eig_fused_opt;
+    const bool fuse = ctx->fuse, keep_td = ctx->keep_td, eig_fused_opt = ctx->eig_fused_opt, eigj_valu_opt = ctx->eigj_valu_opt;
     PmlComm* comm = ctx->comm;
     *ctx = pml_ctx();
     ctx->fuse = fuse;
     ctx->keep_td = keep_td;
     ctx->eig_fused_opt = eig_fused_opt;
+    ctx->eigj_valu_opt = eigj_valu_opt;
     ctx->comm = comm;
     ctx->stream = stream;
     ctx->ev0 = e0;

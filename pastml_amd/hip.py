@@ -25,6 +25,7 @@ MAX_STATES = 256
 OPT_CHERRY_FUSION = 1
 OPT_KEEP_TD = 2
 OPT_EIGEN_FUSED = 3
+OPT_EIGEN_JOINT_VALU = 4
 COMM_ID_BYTES = 128
 COMM_SUM, COMM_MAX = 0, 1
 

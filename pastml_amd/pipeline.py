@@ -9,8 +9,9 @@ formats and under the reference's file names, so that the outputs are interchang
 * ``combined_ancestral_states.tab``                          the selected states of every node, all characters
 * ``named.tree_<tree>.nwk``                                  the input tree(s) with every node named
 
-HTML maps, iTOL upload, dates / timelines, polytomy resolution and the parsimony / COPY methods belong to PastML's
-visualisation and tree-editing layers (out of scope): asking for them raises NotImplementedError.
+HTML maps, iTOL upload, dates / timelines and polytomy resolution belong to PastML's visualisation and tree-editing
+layers (out of scope): asking for them raises NotImplementedError.  (The parsimony methods and COPY
+are host-side array passes of acr(); they run here too.)
 """
 import logging
 import os
@@ -25,7 +26,7 @@ from pastml_amd.annotation import preannotate_forest
 from pastml_amd.file import col_name2cat
 from pastml_amd.ml import MPPA
 from pastml_amd.models.F81Model import F81
-from pastml_amd.tree import read_tree, name_tree, get_flat_forest
+from pastml_amd.tree import StateSetColumn, _DICT_FEATURE_NAMES, read_tree, name_tree, get_flat_forest
 
 PASTML_WORK_DIR = '{tree}_pastml'
 COMBINED_ANCESTRAL_STATE_TAB = 'combined_ancestral_states.tab'
@@ -205,10 +206,14 @@ def validate_input(tree_nwk, columns=None, data=None, data_sep='\t', id_index=0,
         states = np.array(sorted(column2states[c]))
         words, _ = annotation_words(flat, c, states)
         given = words.any(axis=-1)
-        annotated_tips[c] = int(given[flat.tips].sum())
+        # annotated nodes of any kind count (acr.py:747-754), against the number of tips
+        annotated_tips[c] = int(given.sum())
         present = np.bitwise_or.reduce(words[given], axis=0) if given.any() else np.zeros(words.shape[1], np.uint64)
         annotated_states[c] = int(popcount(present).sum())
-    c = min(columns, key=lambda _: annotated_tips[_])
+    # the least annotated column among those with any annotation (acr.py:758-761: columns without one are not in the
+    # reference's counter); the first column, with none, if no column has any
+    some = [_ for _ in columns if annotated_tips[_] > 0]
+    c = min(some, key=lambda _: annotated_tips[_]) if some else columns[0]
     unknown = (n_tips - annotated_tips[c]) / n_tips
     if unknown >= (.9 if not copy_only else 1):
         raise ValueError('{:.1f}% of tip annotations for character "{}" are unknown, '
@@ -255,16 +260,58 @@ def serialize_predicted_states(columns, out_data, roots):
     ``combined_ancestral_states.tab`` (pastml/acr.py:831-858): one line per node with its state in every column; a node
     with several states in some column takes several lines, the columns' states listed in ascending order and the
     exhausted columns left empty.  Rows follow the trees one after another, each in level order.
+    Columns that live in the flat forest as packed state sets (what acr() leaves) are expanded array-wise: at 10^5 tips
+    the per-node attribute loop of the reference is the longest stage of the pipeline.
     """
+    from pastml_amd.hip import unpack_masks
     flat = get_flat_forest(roots)
-    order = np.arange(flat.n_nodes) if len(flat.roots) == 1 else np.lexsort((np.arange(flat.n_nodes), flat.tree_id))
+    N = flat.n_nodes
+    order = np.arange(N) if len(flat.roots) == 1 else np.lexsort((np.arange(N), flat.tree_id))
+    names = np.array([n.name for n in flat.nodes], dtype=object)
+    # per column: number of states of every node and, line by line, the state names
+    counts = np.zeros((len(columns), N), dtype=np.int64)
+    cells = []   # per column: function line -> object array [N] of the line's entries ('' where exhausted)
+    for ci, c in enumerate(columns):
+        col = flat.columns.get(c) if hasattr(flat, 'columns') else None
+        # (a value put on a single node with add_feature hides the column there: such names take the per-node path)
+        if isinstance(col, StateSetColumn) and c not in _DICT_FEATURE_NAMES and col.absent is None:
+            states = np.array([str(x) for x in col.states], dtype=object)
+            ascending = np.argsort(states, kind='stable')           # lines list a node's states in ascending order
+            bits = unpack_masks(col.words, len(states))[:, ascending].astype(bool)
+            rank = np.cumsum(bits, axis=1)
+            counts[ci] = rank[:, -1]
+            sorted_states = states[ascending]
+
+            def line_cells(line, bits=bits, rank=rank, sorted_states=sorted_states):
+                hit = bits & (rank == line + 1)
+                out = np.full(N, '', dtype=object)
+                has = hit.any(axis=1)
+                out[has] = sorted_states[hit[has].argmax(axis=1)]
+                return out
+        else:
+            values = [sorted(getattr(node, c, set())) for node in flat.nodes]
+            counts[ci] = [len(v) for v in values]
+
+            def line_cells(line, values=values):
+                return np.array([str(v[line]) if line < len(v) else '' for v in values], dtype=object)
+        cells.append(line_cells)
+    lines = counts.max(axis=0) if len(columns) else np.zeros(N, dtype=np.int64)
+    per_line = [[fn(line) for fn in cells] for line in range(int(lines.max()) if N else 0)]
     with open(out_data, 'w+') as f:
         f.write('node\t{}\n'.format('\t'.join(columns)))
-        for i in order:
-            node = flat.nodes[i]
-            values = [sorted(getattr(node, c, set())) for c in columns]
-            for line in range(max([len(v) for v in values] + [0])):
-                f.write('{}\t{}\n'.format(node.name, '\t'.join(str(v[line]) if line < len(v) else '' for v in values)))
+        if N and per_line:
+            ordered_lines = lines[order]
+            node_of_row = np.repeat(order, ordered_lines)
+            starts = np.cumsum(ordered_lines) - ordered_lines
+            line_of_row = np.arange(len(node_of_row)) - np.repeat(starts, ordered_lines)
+            table = np.empty((len(node_of_row), len(columns) + 1), dtype=object)
+            table[:, 0] = names[node_of_row]
+            for line, row_cells in enumerate(per_line):
+                sel = line_of_row == line
+                for ci, values in enumerate(row_cells):
+                    table[sel, ci + 1] = values[node_of_row[sel]]
+            f.write('\n'.join('\t'.join(row) for row in table.tolist()))
+            f.write('\n')
     logging.getLogger('pastml').debug('Serialized reconstructed states to {}.'.format(out_data))
 
 
@@ -304,9 +351,21 @@ def pastml_pipeline(tree, data=None, data_sep='\t', id_index=0, columns=None, pr
                   threads=threads, reoptimise=reoptimise, tau=None if smoothing else 0,
                   frequency_smoothing=frequency_smoothing)
     characters = sorted({r[CHARACTER]: r[STATES] for r in results}.keys())
-    serialize_predicted_states(characters, out_data or os.path.join(work_dir, get_combined_ancestral_state_file()), roots)
-    with open(os.path.join(work_dir, get_named_tree_file(tree)), 'w+') as f:
-        f.write('\n'.join(root.write() for root in roots))
+    # Several processes (one per GPU, pastml_amd.sharding): acr() returned this rank's block of the characters.  The
+    # per-character tables are one file each and do not meet; the combined table holds this rank's columns and carries
+    # the rank in its name (joining them is a column-wise paste: every rank writes the same nodes in the same order);
+    # the named tree is the same everywhere and written by rank 0.
+    from pastml_amd import sharding
+    comm = sharding.communicator()
+    rank, world = (comm.rank, comm.world) if comm is not None else (0, 1)
+    combined = out_data or os.path.join(work_dir, get_combined_ancestral_state_file())
+    if world > 1:
+        stem, ext = os.path.splitext(combined)
+        combined = '{}.rank{}of{}{}'.format(stem, rank, world, ext)
+    serialize_predicted_states(characters, combined, roots)
+    if rank == 0:
+        with open(os.path.join(work_dir, get_named_tree_file(tree)), 'w+') as f:
+            f.write('\n'.join(root.write() for root in roots))
     for r in results:
         _serialize_acr((r, work_dir))
     return results

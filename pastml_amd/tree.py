@@ -18,6 +18,8 @@ Two representations live here:
 """
 from collections import deque, Counter
 
+import re
+
 import numpy as np
 
 DEFAULT_DIST = 1.0
@@ -39,6 +41,7 @@ ABSENT = object()
 # names that add_feature() ever put into some node's __dict__: FlatForest.set_column() only has to clear shadowing
 # entries for these
 _DICT_FEATURE_NAMES = set()
+_BASE_FEATURES = frozenset(('dist', 'name', 'support'))
 
 
 class NodeColumn(object):
@@ -134,7 +137,7 @@ class TreeNode(object):
         self.dist = DEFAULT_DIST if dist is None else dist
         self.name = name if name is not None else ''
         self.support = 1.0 if support is None else support
-        self._features = {'dist', 'name', 'support'}
+        self._features = _BASE_FEATURES   # shared until the node gets a feature of its own (add_feature)
         self._flat_cache = None
         self._cols = None   # the FlatForest whose columns hold this node's columnar features, and the node's row
         self._idx = -1
@@ -166,6 +169,8 @@ class TreeNode(object):
 
     def add_feature(self, pr_name, pr_value):
         setattr(self, pr_name, pr_value)
+        if self._features is _BASE_FEATURES:
+            self._features = set(_BASE_FEATURES)
         self._features.add(pr_name)
         _DICT_FEATURE_NAMES.add(pr_name)
 
@@ -176,7 +181,10 @@ class TreeNode(object):
     def del_feature(self, pr_name):
         if pr_name in self.__dict__:
             del self.__dict__[pr_name]
-        self._features.discard(pr_name)
+        if pr_name in self._features:
+            if self._features is _BASE_FEATURES:
+                self._features = set(_BASE_FEATURES)
+            self._features.discard(pr_name)
         flat = self._cols
         if flat is not None:
             col = flat.columns.get(pr_name)
@@ -347,11 +355,31 @@ class TreeNode(object):
 Tree = TreeNode
 
 
+# one token of a newick string: a structural character, a [comment], a :length, or a label (an optional quoted part
+# followed by anything up to the next delimiter; it starts at a non-blank)
+_NEWICK_TOKEN = re.compile(r"""\s*(?:(?P<p>[(),;])|\[(?P<c>[^\]]*)\]|:(?P<d>[^,();\[]*)|(?P<l>(?:'[^']*')?[^:,();\[\s]?[^:,();\[]*))""")
+
+
+def _bare_node():
+    # TreeNode() without the argument handling of __init__ (a million-tip tree is two million of these)
+    node = TreeNode.__new__(TreeNode)
+    node.children = []
+    node.up = None
+    node.dist = DEFAULT_DIST
+    node.name = ''
+    node.support = 1.0
+    node._features = _BASE_FEATURES
+    node._flat_cache = None
+    node._cols = None
+    node._idx = -1
+    return node
+
+
 def _parse_newick(text, root):
     """
-    Iterative newick reader (no recursion, so million-tip trees are fine).
-    Labels may be quoted with single quotes; ``[...]`` comments are skipped; missing branch lengths get ete3's default
-    (1.0), a missing root length is 0.
+    Iterative newick reader (no recursion, so million-tip trees are fine), one regular-expression token at a time.
+    Labels may be quoted with single quotes; ``[...]`` comments are kept on the node they follow; missing branch lengths
+    get ete3's default (1.0), a missing root length is 0.
     """
     if '\n' not in text and not text.lstrip().startswith('(') and not text.rstrip().endswith(';'):
         # a path
@@ -360,88 +388,63 @@ def _parse_newick(text, root):
     s = text.strip()
     if not s.endswith(';'):
         raise NewickError('Newick string must end with ";"')
-    i, n = 0, len(s)
     node = root
     root.dist = 0.0
     depth = 0
-    comments = []
-
-    def read_label(i):
-        # returns (name, dist or None, next index); [...] comments met on the way are kept in `comments`
-        name_chars = []
-        if i < n and s[i] == "'":
-            j = s.index("'", i + 1)
-            name_chars.append(s[i + 1:j])
-            i = j + 1
-        while i < n and s[i] not in ':,();[':
-            name_chars.append(s[i])
-            i += 1
-        name = ''.join(name_chars).strip()
-        dist = None
-        while i < n and s[i] in ':[':
-            if s[i] == '[':
-                j = s.index(']', i)
-                comments.append(s[i + 1:j])
-                i = j + 1
-                continue
-            i += 1
-            j = i
-            while j < n and s[j] not in ',();[':
-                j += 1
-            try:
-                dist = float(s[i:j])
-            except ValueError:
-                raise NewickError('Bad branch length "{}"'.format(s[i:j]))
-            i = j
-        return name, dist, i
-
     expecting_node = True
-    while i < n:
-        ch = s[i]
-        if ch.isspace():
-            i += 1
-        elif ch == '(':
-            if not expecting_node:
-                raise NewickError('Unexpected "(" at position {}'.format(i))
-            child = TreeNode()
-            node.add_child(child)
-            node = child
-            depth += 1
-            i += 1
-        elif ch == ',':
-            if depth == 0:
-                raise NewickError('Unexpected "," at top level')
-            child = TreeNode()
-            node.up.add_child(child)
-            node = child
-            expecting_node = True
-            i += 1
-        elif ch == ')':
-            if depth == 0:
-                raise NewickError('Unbalanced ")"')
-            node = node.up
-            depth -= 1
-            i += 1
-            comments = []
-            name, dist, i = read_label(i)
-            # internal labels that are numbers are supports in some formats; we keep them as names only if non-numeric
-            node.name = name
-            if dist is not None:
-                node.dist = dist
-            if comments:
-                node.__dict__['comment'] = ' '.join(comments)
+    pos, n = 0, len(s)
+    match = _NEWICK_TOKEN.match
+    while pos < n:
+        m = match(s, pos)
+        if m is None or m.end() == pos:
+            if s[pos:].strip() == '':
+                break
+            raise NewickError('Unexpected "{}" at position {}'.format(s[pos], pos))
+        pos = m.end()
+        kind = m.lastgroup
+        if kind == 'p':
+            ch = m.group('p')
+            if ch == '(':
+                if not expecting_node:
+                    raise NewickError('Unexpected "(" at position {}'.format(m.start('p')))
+                child = _bare_node()
+                node.children.append(child)
+                child.up = node
+                node = child
+                depth += 1
+            elif ch == ',':
+                if depth == 0:
+                    raise NewickError('Unexpected "," at top level')
+                child = _bare_node()
+                parent = node.up
+                parent.children.append(child)
+                child.up = parent
+                node = child
+                expecting_node = True
+            elif ch == ')':
+                if depth == 0:
+                    raise NewickError('Unbalanced ")"')
+                node = node.up
+                depth -= 1
+                expecting_node = False
+            else:  # ';'
+                break
+        elif kind == 'l':
+            label = m.group('l')
+            if label[:1] == "'":
+                close = label.index("'", 1)
+                label = label[1:close] + label[close + 1:]
+            node.name = label.strip()
             expecting_node = False
-        elif ch == ';':
-            break
-        else:
-            comments = []
-            name, dist, i = read_label(i)
-            node.name = name
-            if dist is not None:
-                node.dist = dist
-            if comments:
-                node.__dict__['comment'] = ' '.join(comments)
+        elif kind == 'd':
+            try:
+                node.dist = float(m.group('d'))
+            except ValueError:
+                raise NewickError('Bad branch length "{}"'.format(m.group('d')))
             expecting_node = False
+        else:  # a comment: kept on the node whose label / length it sits next to
+            previous = node.__dict__.get('comment')
+            node.__dict__['comment'] = m.group('c') if previous is None else previous + ' ' + m.group('c')
     if depth != 0:
         raise NewickError('Unbalanced parentheses')
     return root

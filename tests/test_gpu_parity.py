@@ -292,9 +292,10 @@ def test_cfg2_full_size_matches_reference_sample():
 def test_cfg3_full_size_matches_reference_sample():
     """
     BASELINE config 3 at full size: 262 144 tips, JTT k=20, one character, joint (Pupko) sweep + back-trace
-    (pastml/ml.py:82-148 with is_marginal=False, :598-622) on the fused FP64 matrix-core sweep, and once more on the
-    sweeps that read materialised P(t) (PML_OPT_EIGEN_FUSED = 0).  Reference: lnL (joint and marginal), the joint
-    state of EVERY node, arg-max rows and log10 bottom-up vectors at every 4 099th node.
+    (pastml/ml.py:82-148 with is_marginal=False, :598-622) on every joint sweep the library has for it: the default on
+    the FP64 vector units (eigen_joint_kernel), the fused FP64 matrix-core sweep (PML_OPT_EIGEN_JOINT_VALU = 0) and the
+    sweeps that read materialised P(t) (additionally PML_OPT_EIGEN_FUSED = 0).  Reference: lnL (joint and marginal), the
+    joint state of EVERY node, arg-max rows and log10 bottom-up vectors at every 4 099th node.
     """
     z = load_golden('synthetic_cfg3_full')
     flat = synthetic.balanced_forest(int(z['n_levels']))
@@ -302,8 +303,9 @@ def test_cfg3_full_size_matches_reference_sample():
     s = z['sample']
     internal = flat.n_children[s] > 0
     results = []
-    for fused in (True, False):
+    for valu, fused in ((True, True), (False, True), (False, False)):
         with hip.Engine(flat, 1, 20) as eng:
+            eng.set_option(hip.OPT_EIGEN_JOINT_VALU, valu)
             eng.set_option(hip.OPT_EIGEN_FUSED, fused)
             eng.set_models([(spec, rates)])
             eng.set_tip_states(synthetic.tip_states(flat.n_tips, 20, 0))
@@ -319,10 +321,11 @@ def test_cfg3_full_size_matches_reference_sample():
         nonroot = s > 0
         assert np.array_equal(table[s][nonroot], z['joint_table'][nonroot])
         assert_same_scaled(bu[s][internal], bu_sf[s][internal], z['bu_joint'][internal], z['bu_joint_sf'][internal],
-                           what='joint BU, fused={}'.format(fused))
+                           what='joint BU, vector units={}, fused={}'.format(valu, fused))
         results.append((lnl[0], lnl_j[0]))
-    # the two schedules build P(t) differently (accumulators vs HBM): same numbers to rounding
+    # the three schedules build P(t) differently (FMA chains, accumulators, HBM): same numbers to rounding
     np.testing.assert_allclose(results[0], results[1], rtol=1e-12)
+    np.testing.assert_allclose(results[0], results[2], rtol=1e-12)
 
 
 def test_cfg4_bench_shape_32_columns():

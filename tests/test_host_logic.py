@@ -267,3 +267,34 @@ def test_generator_lbfgsb_reproduces_scipy_minimize():
         assert len(asked) == len(asked_scipy) and all(np.array_equal(a, b) for a, b in zip(asked, asked_scipy))
         assert np.array_equal(found.x, ref.x) and found.fun == ref.fun and found.success == ref.success
         assert found.nit == ref.nit and found.nfev == ref.nfev
+
+
+def test_tau_none_frees_tau_for_the_first_ml_character_only(monkeypatch):
+    """
+    acr(tau=None) -- the pipeline's smoothing=True -- as in the reference (pastml/acr.py:185-187, inside its loop over
+    the characters): the first maximum-likelihood character optimises tau, the argument is then 0 for the later ones.
+    """
+    from pastml_amd import acr as acr_module
+
+    class Planned(Exception):
+        pass
+
+    seen = {}
+
+    def fake_run_tasks(forest, tasks, **kwargs):
+        seen['tau_free'] = [bool(t.model._optimise_tau) for t in tasks]
+        seen['tau'] = [t.model.tau for t in tasks]
+        raise Planned()
+
+    from pastml_amd import batch as batch_module
+    monkeypatch.setattr(batch_module, 'run_tasks', fake_run_tasks)   # (acr imports it when called)
+    tree = read_tree(os.path.join(GOLDEN, 'data', 'Albanian.tree.152tax.tre'))
+    tips = [t.name for t in tree]
+    df = pd.DataFrame({c: ['x' if i % 3 else 'y' for i in range(len(tips))] for c in ('a', 'b', 'c')}, index=tips)
+    for tau, reoptimise, expect in ((None, False, [True, False, False]), (0, False, [False] * 3),
+                                    (None, True, [True] * 3), (0.01, False, [False] * 3)):
+        with pytest.raises(Planned):
+            acr_module.acr(read_tree(os.path.join(GOLDEN, 'data', 'Albanian.tree.152tax.tre')), df.copy(),
+                           prediction_method=[ml.MPPA, ml.MAP, ml.JOINT], model='F81', tau=tau, reoptimise=reoptimise)
+        assert seen['tau_free'] == expect, (tau, reoptimise)
+        assert seen['tau'] == [0 if tau is None else tau] * 3

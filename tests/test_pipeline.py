@@ -128,3 +128,80 @@ def test_pipeline_reproduces_the_stored_reference_run(tmp_path):
                                      parameters={'Country': str(work / files[3])})
     assert again[0]['model'].get_num_params() == 0
     np.testing.assert_allclose(again[0]['log_likelihood'], results[0]['log_likelihood'], rtol=1e-12)
+
+
+def test_combined_states_table_array_writer_equals_the_per_node_loop(tmp_path):
+    """
+    serialize_predicted_states expands packed state-set columns array-wise; the rows must be those of the reference's
+    per-node loop (pastml/acr.py:831-858): a node with several states takes several lines, every column's states in
+    ascending order, exhausted columns empty -- also with multi-state nodes in several columns and unsorted state lists.
+    """
+    from pastml_amd.tree import FlatForest, StateSetColumn, get_flat_forest
+    from pastml_amd.hip import pack_masks
+    flat0 = FlatForest.random(40, seed=3, max_arity=3, n_trees=2)
+    roots = flat0.to_tree_nodes(names=['n{}'.format(i) for i in range(flat0.n_nodes)])
+    flat = get_flat_forest(roots)
+    rng = np.random.default_rng(1)
+    spec = {'x': np.array(['b', 'a', 'c']), 'y': np.array(['s10', 's2', 's1', 's3', 's0'])}
+    expect = {}
+    for c, states in spec.items():
+        masks = (rng.random((flat.n_nodes, len(states))) < 0.4).astype(np.int8)
+        masks[masks.sum(axis=1) == 0, 0] = 1
+        flat.set_column(c, StateSetColumn(pack_masks(masks, len(states)), states))
+        expect[c] = [sorted(states[m.astype(bool)]) for m in masks]
+    out = tmp_path / 'combined.tab'
+    pipeline.serialize_predicted_states(['x', 'y'], str(out), roots)
+    order = np.lexsort((np.arange(flat.n_nodes), flat.tree_id))
+    lines = ['node\tx\ty']
+    for i in order:
+        values = [expect[c][i] for c in ('x', 'y')]
+        for line in range(max(len(v) for v in values)):
+            lines.append('{}\t{}'.format(flat.nodes[i].name, '\t'.join(v[line] if line < len(v) else '' for v in values)))
+    assert out.read_text() == '\n'.join(lines) + '\n'
+
+
+@pytest.mark.gpu
+def test_pipeline_at_size(tmp_path):
+    """
+    SURVEY 8f-4 at the size it names: pastml_pipeline -- newick and table readers, validation, naming, one batched acr()
+    (F81 + MPPA with parameter optimisation), the result writers -- on a 262 144-tip tree with two characters, inside a
+    time budget; outputs complete and consistent with each other.  (At this size the number of scenarios has tens of
+    thousands of digits: the parameter table writes it as mantissa and exponent.)
+    """
+    import time
+    L, C, k = 18, 2, 4
+    rng = np.random.default_rng(3)
+    level = ['t%d:%.4f' % (i, rng.uniform(0.01, 0.2)) for i in range(2 ** L)]
+    while len(level) > 1:
+        level = ['(%s,%s):%.4f' % (level[i], level[i + 1], rng.uniform(0.01, 0.2)) for i in range(0, len(level), 2)]
+    nwk, tab = tmp_path / 'tree.nwk', tmp_path / 'data.tab'
+    nwk.write_text(level[0] + ';')
+    states = np.array(['s%d' % s for s in range(k)])
+    table = pd.DataFrame({'char%d' % c: states[rng.integers(0, k, size=2 ** L)] for c in range(C)},
+                         index=['t%d' % i for i in range(2 ** L)])
+    table.to_csv(tab, sep='\t', index_label='id')
+    t0 = time.perf_counter()
+    results = pipeline.pastml_pipeline(str(nwk), data=str(tab), work_dir=str(tmp_path / 'out'))
+    seconds = time.perf_counter() - t0
+    print('pastml_pipeline on {} tips x {} characters: {:.1f} s'.format(2 ** L, C, seconds))
+    assert seconds < 60
+    n_nodes = 2 ** (L + 1) - 1
+    assert [r['character'] for r in results] == ['char0', 'char1']
+    combined = pd.read_csv(tmp_path / 'out' / 'combined_ancestral_states.tab', sep='\t', index_col=0, dtype=str,
+                           keep_default_na=False)
+    assert combined.index.nunique() == n_nodes and len(combined) >= n_nodes
+    tips = combined.loc[['t0', 't77', 't{}'.format(2 ** L - 1)]]
+    assert tips['char0'].tolist() == table.loc[tips.index, 'char0'].tolist()       # observed tips keep their states
+    for r in results:
+        mp = pd.read_csv(tmp_path / 'out' / 'marginal_probabilities.character_{}.model_F81.tab'.format(r['character']),
+                         sep='\t', index_col=0, nrows=2000)
+        np.testing.assert_allclose(mp.values.sum(axis=1), 1, rtol=1e-9)
+        params = pd.read_csv(tmp_path / 'out' / 'params.character_{}.method_MPPA.model_F81.tab'.format(r['character']),
+                             sep='\t', index_col=0)['value']
+        assert abs(float(params['log_likelihood']) - r['log_likelihood']) < 1e-6 * abs(r['log_likelihood'])
+        assert 'e+' in params['num_scenarios'] and int(params['num_tips']) == 2 ** L
+        # the nodes MPPA left unresolved are the ones that take more than one line
+        multi = combined[r['character']].replace('', np.nan).groupby(level=0).count()
+        assert int((multi > 1).sum()) == int(params['num_unresolved_nodes'])
+    named = read_tree(str(tmp_path / 'out' / 'named.tree_tree.nwk'))
+    assert len(named) == 2 ** L
