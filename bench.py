@@ -183,9 +183,12 @@ def schedule_bytes(flat, k, n_cols, narrow_limit=None):
     # gather 24 + posterior, sum, exponent written
     td = n_stored * (32 + vec + 16) + n_children_of_stored * (32 + vec + 16) + ch_stored * vec \
         + tips_of_cherries * (24 + vec + 16)
-    # per-branch data: dist in (8, shared by the columns through L2: charged once per column all the same), E out (8);
-    # tips: mask in (8 W), S out (8)
-    prep = N * 16 + int(tip.sum()) * (8 * W + 8)
+    # per-branch data: dist in (8, read once per chunk of columns a thread walks: run_prep's cpy), E out (8); tips: mask
+    # in (8 W), S out (8)
+    cpy, bx = 1, (N + 255) // 256
+    while cpy < 8 and cpy * 2 <= n_cols and bx * ((n_cols + 2 * cpy - 1) // (2 * cpy)) >= 4096:
+        cpy *= 2
+    prep = N * (8 + 8.0 / cpy) + int(tip.sum()) * (8 * W + 8)
     return dict(bottom_up=bu, top_down=td, prep=prep, total=bu + td + prep, vec_bytes=vec, n_stored=n_stored,
                 n_cherries=int(cherry.sum()), n_tips=int(tip.sum()),
                 per_unit=dict(bottom_up=bu / (N * k), top_down=td / (N * k), prep=prep / (N * k)))
