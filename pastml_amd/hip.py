@@ -72,19 +72,23 @@ SIGNATURES = {
     'pml_masks_upload': [_ctx_p, ctypes.c_int32, ctypes.c_int32, _c_uint64_p],
     'pml_masks_from_tip_states': [_ctx_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _c_int32_p, _c_int32_p],
     'pml_masks_initial_upload': [_ctx_p, ctypes.c_int32, ctypes.c_int32, _c_uint64_p],
-    'pml_model_set_f81': [_ctx_p, ctypes.c_int32, ctypes.c_int32, _c_double_p, _c_double_p, _c_double_p, _c_double_p],
+    # (the hot calls take plain addresses -- c_void_p accepts an int -- of buffers the Engine keeps: building a ctypes
+    # pointer object costs ~2 us, and an optimiser round is a handful of such calls)
+    'pml_model_set_f81': [_ctx_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                          ctypes.c_void_p],
     'pml_model_set_hky': [_ctx_p, ctypes.c_int32, ctypes.c_int32, _c_double_p, _c_double_p, _c_double_p, _c_double_p,
                           _c_double_p],
     'pml_model_set_eigen': [_ctx_p, ctypes.c_int32, ctypes.c_int32, _c_double_p, _c_double_p, _c_double_p,
                             _c_double_p, _c_double_p, _c_double_p, _c_double_p],
     'pml_pij': [_ctx_p, ctypes.c_int32, ctypes.c_int32, _c_double_p, _c_double_p],
     'pml_pij_batch': [_ctx_p, _c_double_p],
-    'pml_bottom_up': [_ctx_p, ctypes.c_int, _c_double_p, _c_int32_p, _c_int32_p],
+    'pml_bottom_up': [_ctx_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p],
     'pml_bottom_up_submit': [_ctx_p, ctypes.c_int],
     'pml_loglik_total': [_ctx_p, _c_double_p],
-    'pml_bottom_up_collect': [_ctx_p, ctypes.c_int, _c_double_p, _c_int32_p, _c_int32_p],
+    'pml_bottom_up_collect': [_ctx_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p],
     'pml_top_down_marginals': [_ctx_p, _c_double_p, _c_double_p, _c_double_p],
-    'pml_marginal_pass': [_ctx_p, _c_double_p, _c_int32_p, _c_int32_p, _c_double_p, _c_double_p, _c_double_p],
+    'pml_marginal_pass': [_ctx_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _c_double_p, _c_double_p,
+                          _c_double_p],
     'pml_joint_backtrace': [_ctx_p, _c_int32_p],
     'pml_joint_pass': [_ctx_p, _c_double_p, _c_int32_p, _c_int32_p, _c_int32_p],
     'pml_select_states': [_ctx_p, ctypes.c_int, ctypes.c_int, _c_uint64_p, _c_uint64_p, _c_int32_p],
@@ -389,6 +393,15 @@ class Engine(BareContext):
         self.n_cols = n_cols
         self.k = k
         self.kind = None
+        # buffers (and their addresses) of the calls an optimiser repeats hundreds of times
+        self._lnl = np.empty(n_cols, dtype=np.float64)
+        self._ep = np.empty(n_cols, dtype=np.int32)
+        self._ec = np.empty(n_cols, dtype=np.int32)
+        self._out_addr = (self._lnl.ctypes.data, self._ep.ctypes.data, self._ec.ctypes.data)
+        self._par_pi = np.empty((n_cols, k), dtype=np.float64)
+        self._par = np.empty((3, n_cols), dtype=np.float64)   # sf, tau, tau factor
+        self._par_addr = (self._par_pi.ctypes.data, self._par[0].ctypes.data, self._par[1].ctypes.data,
+                          self._par[2].ctypes.data)
         i32 = ctypes.c_int32
         arrays = dict(parent=_as(flat.parent, np.int32), first_child=_as(flat.first_child, np.int32),
                       n_children=_as(flat.n_children, np.int32), dist=_as(flat.dist, np.float64),
@@ -476,6 +489,19 @@ class Engine(BareContext):
             raise ValueError('all columns of an Engine must use the same model kind')
         kind = kinds.pop()
         n = len(specs)
+        if kind == KIND_F81 and 0 <= col_begin and col_begin + n <= self.n_cols:
+            # straight into the engine's own staging arrays (the library copies them into its pinned mirror)
+            cb, ce = col_begin, col_begin + n
+            try:
+                self._par_pi[cb:ce] = [s['pi'] for s in specs]
+            except ValueError:
+                raise ValueError('frequencies must have {} entries'.format(self.k))
+            self._par[:, cb:ce] = np.array(rates, dtype=np.float64).T
+            a_pi, a_sf, a_tau, a_tf = self._par_addr
+            _check(self._lib.pml_model_set_f81(self._ctx, cb, ce, a_pi + cb * self.k * 8, a_sf + cb * 8, a_tau + cb * 8,
+                                               a_tf + cb * 8))
+            self.kind = kind
+            return
         dbl = ctypes.c_double
         pi = _as(np.stack([s['pi'] for s in specs]), np.float64)
         if pi.shape != (n, self.k):
@@ -485,8 +511,8 @@ class Engine(BareContext):
         tf = _as([r[2] for r in rates], np.float64)
         cb, ce = col_begin, col_begin + n
         if kind == KIND_F81:
-            _check(self._lib.pml_model_set_f81(self._ctx, cb, ce, _ptr(pi, dbl), _ptr(sf, dbl), _ptr(tau, dbl),
-                                               _ptr(tf, dbl)))
+            _check(self._lib.pml_model_set_f81(self._ctx, cb, ce, pi.ctypes.data, sf.ctypes.data, tau.ctypes.data,
+                                               tf.ctypes.data))
         elif kind == KIND_HKY:
             kappa = _as([s['kappa'] for s in specs], np.float64)
             _check(self._lib.pml_model_set_hky(self._ctx, cb, ce, _ptr(pi, dbl), _ptr(kappa, dbl), _ptr(sf, dbl),
@@ -518,16 +544,16 @@ class Engine(BareContext):
         _check(self._lib.pml_pij_batch(self._ctx, None if out is None else _ptr(out, ctypes.c_double)))
         return out
 
-    def bottom_up(self, is_marginal=True):
-        lnl = np.empty(self.n_cols, dtype=np.float64)
-        ep = np.empty(self.n_cols, dtype=np.int32)
-        ec = np.empty(self.n_cols, dtype=np.int32)
-        status = self._lib.pml_bottom_up(self._ctx, 1 if is_marginal else 0, _ptr(lnl, ctypes.c_double),
-                                         _ptr(ep, ctypes.c_int32), _ptr(ec, ctypes.c_int32))
+    def _sweep_results(self, status):
+        # copies of the engine's own result buffers (callers keep what they get)
         if status == PML_ZERO_LIKELIHOOD:
-            raise ZeroLikelihoodError(self._lib.pml_last_error().decode(), ep, ec, lnl)
+            raise ZeroLikelihoodError(self._lib.pml_last_error().decode(), self._ep.copy(), self._ec.copy(),
+                                      self._lnl.copy())
         _check(status)
-        return lnl
+        return self._lnl.copy()
+
+    def bottom_up(self, is_marginal=True):
+        return self._sweep_results(self._lib.pml_bottom_up(self._ctx, 1 if is_marginal else 0, *self._out_addr))
 
     def bottom_up_submit(self, is_marginal=True):
         """Puts a bottom-up sweep on the context's stream and returns at once (see bottom_up_collect)."""
@@ -535,15 +561,7 @@ class Engine(BareContext):
 
     def bottom_up_collect(self, is_marginal=True):
         """Waits for the sweep of bottom_up_submit; returns / raises what bottom_up would have."""
-        lnl = np.empty(self.n_cols, dtype=np.float64)
-        ep = np.empty(self.n_cols, dtype=np.int32)
-        ec = np.empty(self.n_cols, dtype=np.int32)
-        status = self._lib.pml_bottom_up_collect(self._ctx, 1 if is_marginal else 0, _ptr(lnl, ctypes.c_double),
-                                                 _ptr(ep, ctypes.c_int32), _ptr(ec, ctypes.c_int32))
-        if status == PML_ZERO_LIKELIHOOD:
-            raise ZeroLikelihoodError(self._lib.pml_last_error().decode(), ep, ec, lnl)
-        _check(status)
-        return lnl
+        return self._sweep_results(self._lib.pml_bottom_up_collect(self._ctx, 1 if is_marginal else 0, *self._out_addr))
 
     def top_down_marginals(self, posterior=True, lh=True):
         CN = (self.n_cols, self.n_nodes)
@@ -559,22 +577,16 @@ class Engine(BareContext):
     def marginal_pass(self, posterior=True, lh=True):
         """bottom_up(True) + top_down_marginals() with one host round trip: (lnl, posterior, lh_sum, lh_sf)."""
         CN = (self.n_cols, self.n_nodes)
-        lnl = np.empty(self.n_cols, dtype=np.float64)
-        ep = np.empty(self.n_cols, dtype=np.int32)
-        ec = np.empty(self.n_cols, dtype=np.int32)
         post = np.empty(CN + (self.k,), dtype=np.float64) if posterior else None
         lh_sum = np.empty(CN, dtype=np.float64) if lh else None
         lh_sf = np.empty(CN, dtype=np.float64) if lh else None
-        dbl, i32 = ctypes.c_double, ctypes.c_int32
-        status = self._lib.pml_marginal_pass(self._ctx, _ptr(lnl, dbl), _ptr(ep, i32), _ptr(ec, i32),
+        dbl = ctypes.c_double
+        status = self._lib.pml_marginal_pass(self._ctx, *self._out_addr,
                                              None if post is None else _ptr(post, dbl),
                                              None if lh_sum is None else _ptr(lh_sum, dbl),
                                              None if lh_sf is None else _ptr(lh_sf, dbl))
         self._total_fresh = getattr(self, '_comm_attached', False)   # (the collective is on the stream whatever the status)
-        if status == PML_ZERO_LIKELIHOOD:
-            raise ZeroLikelihoodError(self._lib.pml_last_error().decode(), ep, ec, lnl)
-        _check(status)
-        return lnl, post, lh_sum, lh_sf
+        return self._sweep_results(status), post, lh_sum, lh_sf
 
     def joint_backtrace(self, copy_out=True):
         out = np.empty((self.n_cols, self.n_nodes), dtype=np.int32) if copy_out else None
