@@ -408,6 +408,36 @@ def secondary_measurements(device):
                                                       .format(flat.n_bu_levels), model_bytes=b,
                                                       achieved=b / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit='GB/s',
                                                       frac=b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS))
+    # ---- cfg4 with the observed tips' posteriors left implicit (PML_OPT_IMPLICIT_TIP_POSTERIORS): NOT the headline --
+    #      the headline step writes the posterior row of every node; here the unit-vector rows of observed tips (half
+    #      of all nodes of a binary tree) are not written by the sweep but when somebody reads the table.  Own byte model.
+    levels, k, cpg = WORKLOADS['cfg4']
+    flat = synthetic.balanced_forest(levels)
+    with hip.Engine(flat, cpg, k, device=device) as eng:
+        eng.set_option(hip.OPT_IMPLICIT_TIP_POSTERIORS, 1)
+        specs = [(dict(kind=0, pi=synthetic.f81_frequencies(k, c)), (1.0, 0.0, 1.0)) for c in range(cpg)]
+        tip_states = np.stack([synthetic.tip_states(flat.n_tips, k, c) for c in range(cpg)])
+        eng.set_tip_states(tip_states)
+        last = {}
+
+        def implicit_step():
+            eng.set_models(specs)
+            last['lnl'] = eng.marginal_pass(posterior=False, lh=False)[0]
+        ms = timed(implicit_step, 10, eng)
+        sb = schedule_bytes(flat, k, cpg)
+        # every tip of this workload is observed: its posterior row (vec bytes) is not written
+        model_bytes = (sb['total'] - flat.n_tips * sb['vec_bytes']) * cpg
+        # the readers still see the full table: the strided sample of every column, tips included, as after the headline
+        validation = validate_columns(eng, flat, k, tip_states, last['lnl'])
+        out['cfg4_implicit_tip_posteriors'] = dict(
+            workload='BASELINE config 4 shard with PML_OPT_IMPLICIT_TIP_POSTERIORS: as the headline step, but the unit-vector '
+                     'posterior rows of the {} observed tips per character are written on request, not by the sweep '
+                     '(separate entry: the headline value always includes them)'.format(flat.n_tips),
+            ms_per_step=ms, value=flat.n_nodes * k * cpg / (ms * 1e-3), unit='node*state*char/s',
+            roofline=dict(bound='hbm', model_bytes=model_bytes, achieved=model_bytes / (ms * 1e-3) / 1e9,
+                          peak=HBM_PEAK_GBS, unit='GB/s', frac=model_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                          byte_model='compulsory bytes of the headline schedule minus one posterior row per observed tip'),
+            validation=validation)
     # ---- cfg5 end to end: ONE acr() over the 91 usable columns of the HIV1C annotation table (MPPA + F81, parameter
     #      optimisation of every character, 3 619 tips), against the reference's own time for the same columns
     #      (tests/golden/hiv1c_all.npz: measured when the fixtures were made, 1 CPU thread)

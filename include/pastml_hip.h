@@ -76,8 +76,13 @@ int pml_ctx_sync(pml_ctx* ctx);
  * PML_OPT_EIGEN_JOINT_VALU (default 1, may be changed at any time): the JOINT sweep of eigen-decomposed models with
  * k <= 32 runs on the FP64 vector units (the default: faster than the matrix cores for this sweep);
  * 0 sends it to the kernels PML_OPT_EIGEN_FUSED selects -- kept as the cross-check of the default path.
+ * PML_OPT_IMPLICIT_TIP_POSTERIORS (default 0, may be changed at any time; F81 family, k <= 64): the top-down sweep does
+ * not write the posterior rows of observed tips -- unit vectors, a third of the sweep's traffic on a binary tree; they
+ * are written when the table is read (pml_download*, posterior_out, pml_select_states, pml_marginal_counts) or before
+ * the masks that define them change.  The sums / exponents of every node are written as always.
  */
-enum { PML_OPT_CHERRY_FUSION = 1, PML_OPT_KEEP_TD = 2, PML_OPT_EIGEN_FUSED = 3, PML_OPT_EIGEN_JOINT_VALU = 4 };
+enum { PML_OPT_CHERRY_FUSION = 1, PML_OPT_KEEP_TD = 2, PML_OPT_EIGEN_FUSED = 3, PML_OPT_EIGEN_JOINT_VALU = 4,
+       PML_OPT_IMPLICIT_TIP_POSTERIORS = 5 };
 int pml_ctx_set_option(pml_ctx* ctx, int option, int value);
 /* bytes of device memory currently held by the ctx / free on its device */
 int pml_ctx_memory(pml_ctx* ctx, uint64_t* held, uint64_t* device_free);

@@ -156,6 +156,8 @@ struct pml_ctx {
     bool td_filled = false;    // ... including those of the nodes the sweeps do not store (td_fill_kernel)
     bool eig_fused_opt = true; // PML_OPT_EIGEN_FUSED
     bool eigj_valu_opt = true; // PML_OPT_EIGEN_JOINT_VALU
+    bool implicit_tips = false;    // PML_OPT_IMPLICIT_TIP_POSTERIORS
+    bool tip_post_missing = false; // the last top-down sweep left the observed tips' posteriors implicit
     const PmlUnit* units_override = nullptr;  // set around a dispatch_sweep on the block schedule's top lists
 
     PmlComm* comm = nullptr;   // RCCL communicator attached by pml_comm_init (survives tree uploads)
@@ -290,6 +292,7 @@ static PmlState state_of(const pml_ctx* c) {
     s.td = td_stored ? c->d_td : nullptr;
     s.te = td_stored ? c->d_te : nullptr;
     s.post = c->d_post;
+    s.implicit_tips = c->implicit_tips && c->kind == PML_MODEL_F81 && c->W == 1;
     s.lhsum = c->d_lhsum;
     s.lhe = c->d_lhe;
     s.J = c->d_J;
@@ -1038,6 +1041,14 @@ int pml_ctx_set_option(pml_ctx* ctx, int option, int value) {
         ctx->eigj_valu_opt = value != 0;
         return PML_OK;
     }
+    if (option == PML_OPT_IMPLICIT_TIP_POSTERIORS) {
+        if ((value != 0) != ctx->implicit_tips) {
+            drop_graph(ctx->td_graph);
+            drop_graph(ctx->mp_graph);
+        }
+        ctx->implicit_tips = value != 0;
+        return PML_OK;
+    }
     return fail(PML_ERR_INVALID, "unknown option %d", option);
 }
 
@@ -1138,13 +1149,15 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
 
     int device = ctx->device;
     const bool profile = ctx->profile;
-    const bool fuse = ctx->fuse, keep_td = ctx->keep_td, eig_fused_opt = ctx->eig_fused_opt, eigj_valu_opt = ctx->eigj_valu_opt;
+    const bool fuse = ctx->fuse, keep_td = ctx->keep_td, eig_fused_opt = ctx->eig_fused_opt, eigj_valu_opt = ctx->eigj_valu_opt,
+               implicit_tips = ctx->implicit_tips;
     PmlComm* comm = ctx->comm;
     *ctx = pml_ctx();
     ctx->fuse = fuse;
     ctx->keep_td = keep_td;
     ctx->eig_fused_opt = eig_fused_opt;
     ctx->eigj_valu_opt = eigj_valu_opt;
+    ctx->implicit_tips = implicit_tips;
     ctx->comm = comm;
     ctx->stream = stream;
     ctx->ev0 = e0;
@@ -1552,6 +1565,8 @@ static int check_cols(pml_ctx* ctx, int cb, int ce) {
     return PML_OK;
 }
 
+static int materialize_tip_posteriors(pml_ctx* ctx);
+
 static void invalidate(pml_ctx* ctx) {
     ctx->prep_dirty = true;
     ctx->bu_mode = -1;
@@ -1560,6 +1575,7 @@ static void invalidate(pml_ctx* ctx) {
 
 int pml_masks_upload(pml_ctx* ctx, int32_t col_begin, int32_t col_end, const uint64_t* masks) {
     PML_TRY(check_cols(ctx, col_begin, col_end));
+    PML_TRY(materialize_tip_posteriors(ctx));  // (rows left implicit are defined by the masks about to change)
     if (!masks) return fail(PML_ERR_INVALID, "masks is NULL");
     const size_t per_col = (size_t)ctx->N * ctx->W;
     // bits beyond k must be clear: the kernels trust the words
@@ -1578,6 +1594,7 @@ int pml_masks_upload(pml_ctx* ctx, int32_t col_begin, int32_t col_end, const uin
 int pml_masks_from_tip_states(pml_ctx* ctx, int32_t col_begin, int32_t col_end, int32_t n_tips,
                               const int32_t* tip_ids, const int32_t* states) {
     PML_TRY(check_cols(ctx, col_begin, col_end));
+    PML_TRY(materialize_tip_posteriors(ctx));
     if (n_tips < 0 || (n_tips > 0 && (!tip_ids || !states))) return fail(PML_ERR_INVALID, "bad tip arrays");
     const int nc = col_end - col_begin;
     for (int j = 0; j < n_tips; ++j)
@@ -2230,6 +2247,18 @@ static int run_top_down(pml_ctx* ctx) {
     ctx->td_vec_valid = td_stored;
     ctx->td_filled = false;
     ctx->post_ever = true;
+    ctx->tip_post_missing = state_of(ctx).implicit_tips;
+    return PML_OK;
+}
+
+// PML_OPT_IMPLICIT_TIP_POSTERIORS: whoever reads the posterior table gets the rows the sweep left implicit first
+static int materialize_tip_posteriors(pml_ctx* ctx) {
+    if (!ctx->tip_post_missing || !ctx->d_post || ctx->n_tips == 0) return PML_OK;
+    dim3 grid(grid_for(ctx->n_tips, PML_BLOCK, ctx->C), ctx->C);
+    hipLaunchKernelGGL(tip_posteriors_kernel, grid, dim3(PML_BLOCK), 0, ctx->stream, cols_of(ctx), state_of(ctx), ctx->N,
+                       ctx->d_tips, ctx->n_tips);
+    HIP_TRY(hipGetLastError());
+    ctx->tip_post_missing = false;
     return PML_OK;
 }
 
@@ -2283,6 +2312,7 @@ static int materialize_td(pml_ctx* ctx) {
 static int fetch_marginals(pml_ctx* ctx, double* posterior_out, double* lh_sum_out, double* lh_sf_out) {
     const size_t CN = (size_t)ctx->C * ctx->N;
     if (posterior_out) {
+        PML_TRY(materialize_tip_posteriors(ctx));
         if (ctx->ks == ctx->k) {
             HIP_TRY(hipMemcpyAsync(posterior_out, ctx->d_post, CN * ctx->k * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         } else {
@@ -2349,6 +2379,7 @@ int pml_marginal_pass(pml_ctx* ctx, double* loglik_out, int32_t* err_parent, int
         ctx->td_vec_valid = ctx->keep_td;
         ctx->td_filled = false;
         ctx->post_ever = true;
+        ctx->tip_post_missing = state_of(ctx).implicit_tips;
     } else {
         PML_TRY(submit_bottom_up(ctx, 1));
         ctx->bu_mode = 1;  // provisional, for run_top_down's bookkeeping; collect_bottom_up has the last word
@@ -2451,6 +2482,7 @@ int pml_marginal_counts(pml_ctx* ctx, int32_t col, int32_t n_repetitions, uint64
         return fail(PML_ERR_INVALID, "pml_marginal_counts needs a marginal pml_bottom_up and pml_top_down_marginals first");
     if (ctx->k > PML_COUNTS_MAX_K) return fail(PML_ERR_UNSUPPORTED, "k = %d: at most %d states", ctx->k, PML_COUNTS_MAX_K);
     PML_TRY(materialize_cherries(ctx));  // the conditional probabilities need every bottom-up vector
+    PML_TRY(materialize_tip_posteriors(ctx));
     PML_TRY(run_prep(ctx));  // P(t) of every branch (the fused eigen sweeps never materialise it) / exp(-mu t')
     const size_t k = ctx->k;
     int* d_counts = nullptr;
@@ -2492,6 +2524,7 @@ int pml_select_states(pml_ctx* ctx, int method, int force_joint, const uint64_t*
     if (method != 0 && method != 1) return fail(PML_ERR_INVALID, "method must be 0 (MAP) or 1 (MPPA)");
     if (method == 1 && force_joint && !ctx->js_ever)
         return fail(PML_ERR_INVALID, "force_joint needs the joint states of a pml_joint_backtrace");
+    PML_TRY(materialize_tip_posteriors(ctx));  // the selection reads every row, and rewrites the masks
     const size_t CN = (size_t)ctx->C * ctx->N;
     if (!ctx->d_nsel) PML_TRY(dev_alloc(ctx, &ctx->d_nsel, CN));
     u64* d_lh_mask = nullptr;
@@ -2613,6 +2646,7 @@ int pml_download(pml_ctx* ctx, int what, int32_t col, void* out) {
             return fetch_exponents(ctx, ctx->d_te, col, (double*)out);
         case PML_BUF_POSTERIOR:
             if (!ctx->td_valid) return fail(PML_ERR_INVALID, "no valid top-down sweep");
+            PML_TRY(materialize_tip_posteriors(ctx));
             return fetch_vectors(ctx, ctx->d_post, col, (double*)out);
         case PML_BUF_LH_SUM:
             if (!ctx->td_valid) return fail(PML_ERR_INVALID, "no valid top-down sweep");
@@ -2780,6 +2814,7 @@ int pml_download_strided(pml_ctx* ctx, int what, int32_t col, int32_t first, int
     switch (what) {
         case PML_BUF_POSTERIOR:
             if (!ctx->td_valid) return fail(PML_ERR_INVALID, "no valid top-down sweep");
+            PML_TRY(materialize_tip_posteriors(ctx));
             src = ctx->d_post + ((size_t)col * N + first) * ctx->ks;
             row_bytes = ctx->k * sizeof(double);
             src_row_bytes = ctx->ks * sizeof(double);

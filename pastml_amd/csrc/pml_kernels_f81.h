@@ -47,6 +47,7 @@ struct PmlState {
     double* post;   // [C][N][ks]
     double* lhsum;  // [C][N]
     i64* lhe;       // [C][N]
+    bool implicit_tips;  // top-down sweep: the unit-vector posteriors of observed tips are not written (PML_OPT_IMPLICIT_TIP_POSTERIORS)
     pml_jt* J;      // [C][N][ks]  joint argmax tables (one byte per entry: k <= 256)
     int* js;        // [C][N]      joint states
     u64* err;       // [C]         min over failing (post_rank << 32 | child id)
@@ -136,6 +137,7 @@ struct LaneCtx {
     int* stst;
     double* ssum;  // staged lhsum / lhe of the six slots (null: not staged)
     i64* sexp;
+    bool implicit_tips;  // observed tips' posteriors stay implicit (their mask says which unit vector it is)
     __device__ __forceinline__ int st(int r) const { return R == 1 ? g : ((r >> 1) * 2 * G + 2 * g + (r & 1)); }
 };
 
@@ -165,6 +167,7 @@ __device__ __forceinline__ void lane_ctx_init(LaneCtx<G, R>& L, const PmlTree& t
     L.stst = nullptr;
     L.ssum = nullptr;
     L.sexp = nullptr;
+    L.implicit_tips = st.implicit_tips;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         L.pi_r[r] = (L.st(r) < c.k) ? c.pi[(size_t)L.col * c.ks + L.st(r)] : 0.0;
@@ -342,6 +345,7 @@ __device__ __forceinline__ bool post_row(const LaneCtx<G, R>& L, const PmlCols& 
 template <int G, int R>
 __device__ __forceinline__ bool post_onehot(const LaneCtx<G, R>& L, const PmlCols& c, int slot, int tip, int s,
                                             const double (&oh)[R], bool ok) {
+    if (L.implicit_tips && ok) return false;  // the row is the unit vector of the tip's one allowed state: not written
     if (G <= PML_TD_STAGE_MAX_G && L.srow != nullptr && slot >= 2 && slot < 6 && ok) {
         if (L.g == 0) {
             L.stid[slot - 2] = tip;

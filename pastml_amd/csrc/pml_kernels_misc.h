@@ -488,6 +488,24 @@ __global__ void sum_loglik_kernel(const double* __restrict__ loglik, int n, doub
     }
 }
 
+// PML_OPT_IMPLICIT_TIP_POSTERIORS: the rows the top-down sweep left implicit -- an observed tip (one allowed state) with a
+// positive finite likelihood has the unit vector of its state as its posterior (pastml/ml.py:498-500 gives exactly that)
+// -- written out when somebody reads the table.  One thread per (tip, column).
+__global__ void __launch_bounds__(PML_BLOCK)
+tip_posteriors_kernel(PmlCols c, PmlState st, int N, const int* __restrict__ tips, int n_tips) {
+    const int col = blockIdx.y;
+    const size_t colN = (size_t)col * N;
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < n_tips; q += gridDim.x * blockDim.x) {
+        const int tip = tips[q];
+        const u64 word = c.masks[colN + tip] & (c.k >= 64 ? ~0ull : (1ull << c.k) - 1ull);
+        const double ls = st.lhsum[colN + tip];
+        if (__popcll(word) != 1 || !(ls > 0.0) || isinf(ls)) continue;  // (such rows were written by the sweep)
+        const int s = __builtin_ctzll(word);
+        double* row = st.post + (colN + tip) * c.ks;
+        for (int i = 0; i < c.ks; ++i) row[i] = i == s ? 1.0 : 0.0;
+    }
+}
+
 __global__ void reset_err_kernel(u64* __restrict__ err, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) err[i] = ~0ull;

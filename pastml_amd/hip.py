@@ -26,6 +26,7 @@ OPT_CHERRY_FUSION = 1
 OPT_KEEP_TD = 2
 OPT_EIGEN_FUSED = 3
 OPT_EIGEN_JOINT_VALU = 4
+OPT_IMPLICIT_TIP_POSTERIORS = 5
 COMM_ID_BYTES = 128
 COMM_SUM, COMM_MAX = 0, 1
 

