@@ -479,25 +479,31 @@ class Engine(BareContext):
         """models: list (one per column) of Model objects or (spec dict, (sf, tau, tau_factor)) tuples."""
         specs, rates = [], []
         for m in models:
-            if isinstance(m, tuple):
+            if type(m) is tuple:
                 spec, r = m
             else:
                 spec, r = m.kernel_spec(), m.rate_params()
             specs.append(spec)
             rates.append(r)
-        kinds = {s['kind'] for s in specs}
-        if len(kinds) != 1:
-            raise ValueError('all columns of an Engine must use the same model kind')
-        kind = kinds.pop()
+        kind = specs[0]['kind']
+        for s in specs:
+            if s['kind'] != kind:
+                raise ValueError('all columns of an Engine must use the same model kind')
         n = len(specs)
         if kind == KIND_F81 and 0 <= col_begin and col_begin + n <= self.n_cols:
             # straight into the engine's own staging arrays (the library copies them into its pinned mirror)
             cb, ce = col_begin, col_begin + n
             try:
-                self._par_pi[cb:ce] = [s['pi'] for s in specs]
+                if n == 1:
+                    self._par_pi[cb] = specs[0]['pi']
+                else:
+                    self._par_pi[cb:ce] = [s['pi'] for s in specs]
             except ValueError:
                 raise ValueError('frequencies must have {} entries'.format(self.k))
-            self._par[:, cb:ce] = np.array(rates, dtype=np.float64).T
+            if n == 1:
+                self._par[0, cb], self._par[1, cb], self._par[2, cb] = rates[0]
+            else:
+                self._par[:, cb:ce] = np.array(rates, dtype=np.float64).T
             a_pi, a_sf, a_tau, a_tf = self._par_addr
             _check(self._lib.pml_model_set_f81(self._ctx, cb, ce, a_pi + cb * self.k * 8, a_sf + cb * 8, a_tau + cb * 8,
                                                a_tf + cb * 8))

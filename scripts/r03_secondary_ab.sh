@@ -9,7 +9,7 @@ for v in A B A2 B2; do
 import sys, json; sys.path.insert(0, '$R')
 import bench
 o = bench.secondary_measurements(0)
-print('$v', {k: round(v.get('ms_per_pass', v.get('ms_per_gradient', v.get('seconds'))), 4) for k, v in o.items()}, 'cfg3 sweep', round(o['cfg3']['ms_joint_sweep'], 4), 'marg', round(o['cfg3']['ms_marginal_pass'], 4))
+print('$v', {k: round(v.get('ms_per_pass') or v.get('ms_per_gradient') or v.get('seconds') or v.get('ms_per_step'), 4) for k, v in o.items()}, 'cfg3 sweep', round(o['cfg3']['ms_joint_sweep'], 4), 'marg', round(o['cfg3']['ms_marginal_pass'], 4))
 " || exit 1
 done
 cp /tmp/libA.so $R/pastml_amd/libpastml_hip.so
