@@ -1239,6 +1239,9 @@ __device__ __forceinline__ void bu_f81_unit_seq(const LaneCtx<G, R>& L, const Pm
 // i + 2 are in flight, so a wave waits for memory once per sweep of its units instead of once per unit (the level that
 // rebuilds cherries spent 65 % of its wave cycles in s_waitcnt before).  The two halves of the loop body ping-pong
 // between two register sets instead of copying one into the other.
+// (Occupancy: three waves per SIMD at four states per lane.  The joint variants that stream vectors then spill 12 bytes
+// per lane -- the only scratch in a level kernel; without the spill, at two waves, the cfg4-size joint sweep takes
+// 8.9 instead of 7.85 ms: measured in round 3, kept.)
 template <int G, int R, bool JOINT, bool VEC>
 __global__ void __launch_bounds__(PML_BLOCK) __attribute__((amdgpu_waves_per_eu(R >= 8 ? 2 : 3, R >= 8 ? 2 : 4)))
 bu_f81_kernel(PmlTree t, PmlCols c, PmlState st, const PmlUnit* __restrict__ units, int n_level) {
