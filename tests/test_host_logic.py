@@ -298,3 +298,83 @@ def test_tau_none_frees_tau_for_the_first_ml_character_only(monkeypatch):
                            prediction_method=[ml.MPPA, ml.MAP, ml.JOINT], model='F81', tau=tau, reoptimise=reoptimise)
         assert seen['tau_free'] == expect, (tau, reoptimise)
         assert seen['tau'] == [0 if tau is None else tau] * 3
+
+
+def test_two_point_scheme_is_scipys_forward_difference():
+    """
+    batch.two_point_scheme: the points of scipy's 2-point gradient (absolute step 1e-8, mirrored at the bounds, relative
+    fall-back where the step vanishes) and the steps to divide by -- (f(point_i) - f(x0)) / step_i must be
+    approx_derivative's gradient bit for bit, or the batched optimiser would not walk scipy's iterates.
+    """
+    from scipy.optimize._numdiff import approx_derivative
+    from pastml_amd import batch as B
+    if B._adjust_scheme_to_bounds is None:
+        pytest.skip('this SciPy build has no _adjust_scheme_to_bounds: the helper is called twice instead')
+    rng = np.random.default_rng(1)
+    for t in range(200):
+        n = int(rng.integers(1, 14))
+        lo = rng.uniform(-1, 0.5, n)
+        up = lo + rng.uniform(1e-9, 2, n)
+        x0 = lo + (up - lo) * rng.uniform(0, 1, n)
+        if t % 4 == 0:
+            x0[0] = up[0]            # the step is mirrored at an upper bound
+        if t % 5 == 0:
+            x0[-1] = lo[-1]
+        if t % 7 == 0:               # 1e-8 is below the spacing of x0: scipy's relative fall-back
+            x0, lo, up = x0 * 1e9, lo * 1e9 - 1, up * 1e9 + 1
+        w = rng.normal(size=n)
+
+        def f(x):
+            return float(np.sin(x @ w) + np.sum(x ** 2))
+        ref = approx_derivative(f, x0, method='2-point', abs_step=1e-8, f0=f(x0), bounds=(lo, up))
+        points, steps = B.two_point_scheme(x0, lo, up)
+        mine = (np.array([f(p) for p in points]) - f(x0)) / steps
+        assert np.array_equal(np.atleast_1d(ref), mine), t
+
+
+def test_kernel_points_decodes_a_batch_like_one_vector_at_a_time():
+    """F81Model.kernel_points (all optimiser vectors of a batch decoded array-wise) == set_params_from_optimised +
+    kernel_spec + rate_params per vector, bit for bit, and leaves the model at the last vector."""
+    from pastml_amd.models import Model, ModelWithFrequencies
+    from pastml_amd.models._closed_form import F81Model, JCModel
+    fs = ForestStats([read_tree(os.path.join(GOLDEN, 'data', 'Albanian.tree.152tax.tre'))])
+    rng = np.random.default_rng(0)
+    for k in (2, 3, 5, 12, 36, 67):
+        for optimise_tau in (False, True):
+            for fixed in (False, True):
+                states = ['s%02d' % i for i in range(k)]
+                freqs = np.random.default_rng(k).dirichlet(np.ones(k))
+                a, b = (F81Model(states=states, forest_stats=fs, optimise_tau=optimise_tau, frequencies=freqs.copy())
+                        for _ in range(2))
+                if fixed:
+                    a.fix_extra_params()
+                    b.fix_extra_params()
+                bounds = a.get_bounds()
+                lo, up = bounds[:, 0], bounds[:, 1]
+                vectors = [lo + (up - lo) * rng.uniform(0, 1, len(lo)) ** 3 for _ in range(k + 2)]
+                if optimise_tau:
+                    vectors[1][1] = 0.0
+                pa, pb = a.kernel_points(vectors), ModelWithFrequencies.kernel_points(b, vectors)
+                for (sa, ra), (sb, rb) in zip(pa, pb):
+                    assert np.array_equal(sa['pi'], sb['pi']) and ra == rb
+                assert np.array_equal(a.frequencies, b.frequencies) and (a.sf, a.tau, a._tau_factor) == (b.sf, b.tau, b._tau_factor)
+    jc = JCModel(states=['a', 'b', 'c'], forest_stats=fs)
+    assert [p[1][0] for p in jc.kernel_points([np.array([v]) for v in (1., 2., 3.)])] == [1., 2., 3.] and jc.sf == 3.
+
+
+def test_visible_devices(monkeypatch):
+    """Which GPUs one process uses: its own as a rank of a multi-process launch, an explicit list, else all visible."""
+    from pastml_amd import batch as B, hip
+    for var in ('PASTML_AMD_DEVICES', 'LOCAL_RANK', 'PASTML_HIP_DEVICE', 'WORLD_SIZE'):
+        monkeypatch.delenv(var, raising=False)
+    monkeypatch.setattr(hip, 'device_count', lambda: 4)
+    assert B.visible_devices() == [0, 1, 2, 3]
+    assert B.visible_devices(2) == [2]
+    monkeypatch.setenv('PASTML_AMD_DEVICES', '1,3,3')
+    assert B.visible_devices() == [1, 3, 3]
+    monkeypatch.delenv('PASTML_AMD_DEVICES')
+    monkeypatch.setenv('LOCAL_RANK', '2')
+    assert B.visible_devices() == [2]
+    monkeypatch.delenv('LOCAL_RANK')
+    monkeypatch.setattr(hip, 'device_count', lambda: 0)
+    assert B.visible_devices() == [0]
