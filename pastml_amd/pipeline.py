@@ -26,7 +26,7 @@ from pastml_amd.annotation import preannotate_forest
 from pastml_amd.file import col_name2cat
 from pastml_amd.ml import MPPA
 from pastml_amd.models.F81Model import F81
-from pastml_amd.tree import StateSetColumn, _DICT_FEATURE_NAMES, read_tree, name_tree, get_flat_forest
+from pastml_amd.tree import StateSetColumn, _DICT_FEATURE_NAMES, read_tree, name_tree, get_flat_forest, trusted_flat_cache
 
 PASTML_WORK_DIR = '{tree}_pastml'
 COMBINED_ANCESTRAL_STATE_TAB = 'combined_ancestral_states.tab'
@@ -340,6 +340,13 @@ def pastml_pipeline(tree, data=None, data_sep='\t', id_index=0, columns=None, pr
                                   'covers tree + table -> reconstruction -> result tables'.format(', '.join(asked)))
     copy_only = COPY == prediction_method or (isinstance(prediction_method, list)
                                               and all(COPY == _ for _ in prediction_method))
+    with trusted_flat_cache():   # the trees are this function's own from reading to writing
+        return _pipeline(tree, data, data_sep, id_index, columns, prediction_method, model, parameters, rate_matrix,
+                         out_data, work_dir, forced_joint, threads, reoptimise, smoothing, frequency_smoothing, copy_only)
+
+
+def _pipeline(tree, data, data_sep, id_index, columns, prediction_method, model, parameters, rate_matrix, out_data,
+              work_dir, forced_joint, threads, reoptimise, smoothing, frequency_smoothing, copy_only):
     roots, columns, column2states, parameters, rates = \
         validate_input(tree, columns, data, data_sep, id_index, copy_only=copy_only, parameters=parameters,
                        rates=rate_matrix)
