@@ -969,9 +969,9 @@ __device__ __forceinline__ bool bu_f81_unit_fast(const LaneCtx<G, R>& L, const P
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Lean unit for the kernels that walk several levels in one launch (walk_levels: small forests, subtree blocks, the
-// narrow end of large forests), units of fewer than 8 lanes.  There a level holds a handful of units and a level step
-// is the latency of ONE unit, which on the sequential path is a chain of dependent round trips to L2 (child -> its
+// Lean unit for units of fewer than 8 lanes.  In the kernels that walk several levels in one launch (walk_levels: small
+// forests, subtree blocks, the narrow end of large forests) a level holds a handful of units and a level step is the
+// latency of ONE unit, which on the sequential path is a chain of dependent round trips to L2 (child -> its
 // kind -> its scalars -> the cherry's tips -> their scalars; ~45 s_waitcnt in the unit's code).  The descriptor says
 // where everything lives, so this unit issues every load it can need -- own mask, both children's scalars and vectors,
 // the scalars of up to two tips under each -- before it touches any value: one round trip.  Arithmetic: the operations
@@ -979,8 +979,10 @@ __device__ __forceinline__ bool bu_f81_unit_fast(const LaneCtx<G, R>& L, const P
 // the product of the message floors proves them void, as in bu_f81_marg_body): the same bits.
 // Units it takes: single-word masks, at most two children, cherries of at most two tips.  Returns false for an all-zero
 // result: the caller repeats the unit on the sequential path, which reports the pair the reference would name.
-// (In the level kernels of large forests the sequential path stays: there the loads of 16 - 64 units per wavefront
-// overlap by themselves and the extra load slots cost more than they save -- DESIGN.md 4a.)
+// The level kernels of large forests take it too (units of fewer than 8 lanes, k <= 28): 262 144 tips x 32 characters,
+// marginal pass k = 2 0.66 -> 0.56 ms, k = 4 0.76 -> 0.68, k = 8 1.11 -> 1.00, k = 12 1.76 -> 1.39 (round 2's
+// descriptor-driven path for these units, which lost 2x, had every lane load every child / tip slot of up to four
+// children; this one keeps to two children and two tips and to the loads the codes ask for).
 // ---------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool unit_is_lean(int packed) {
     if (unit_nc(packed) > 2 || !((packed >> 4) & 1)) return false;
@@ -1292,7 +1294,7 @@ bu_f81_kernel(PmlTree t, PmlCols c, PmlState st, const PmlUnit* __restrict__ uni
     for (; base < n_level; base += stride) {  // the next descriptor is in flight during the unit
         const int nxt_idx = idx + stride;
         const UnitRegs nxt = load_unit<G>(units, nxt_idx < n_level ? nxt_idx : 0, L.g);
-        if (idx < n_level) bu_f81_unit<G, R, JOINT>(L, t, c, st, cur);
+        if (idx < n_level) bu_f81_unit<G, R, JOINT, true>(L, t, c, st, cur);
         cur = nxt;
         idx = nxt_idx;
     }
@@ -1764,7 +1766,7 @@ td_f81_kernel(PmlTree t, PmlCols c, PmlState st, const PmlUnit* __restrict__ uni
     for (int base = idx - sub; base < n_level; base += stride) {
         const int nxt_idx = idx + stride;
         const UnitRegs nxt = load_unit<G>(units, nxt_idx < n_level ? nxt_idx : 0, L.g);
-        if (idx < n_level) td_f81_unit<G, R>(L, t, c, st, cur);
+        if (idx < n_level) td_f81_unit<G, R, true>(L, t, c, st, cur);
         if (staged) td_stage_flush<G, R>(L, c, S, (stage & 4) != 0);
         cur = nxt;
         idx = nxt_idx;
