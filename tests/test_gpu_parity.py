@@ -442,7 +442,7 @@ def test_cfg4_full_tree_invariants():
     assert_same_scaled(bu[ids], bu_sf[ids], r['bu'], r['bu_sf'], what='subtree BU')
 
 
-@pytest.mark.parametrize('k', [4, 20, 64, 130])
+@pytest.mark.parametrize('k', [4, 20, 32, 64, 130])
 def test_cherry_fusion_is_bit_identical(k):
     """Recomputing cherries in registers (default) gives exactly the bits of the store-everything schedule."""
     rng = np.random.default_rng(k)
@@ -1008,3 +1008,38 @@ def test_implicit_tip_posteriors_give_the_same_table(k):
     for a, b in zip(out[0], out[1]):
         assert np.array_equal(a, b, equal_nan=True)
     assert np.array_equal(out[0][4][1][3::7], out[0][3])
+
+
+@pytest.mark.parametrize('k', [32, 64])
+def test_full_mask_pair_waves_match_the_oracle(k):
+    """
+    The cherry level's specialised bodies (bu_f81_marg_body FULL / PAIR: k = lanes x states per lane, every mask of the
+    wave's units and cherries full, every unit two cherries of two tips) run on whole waves of a balanced tree with
+    observed tips -- and must not run when one unit of the wave has a restricted internal node or a tip without data.
+    Both against the oracle, and the second forest against itself with the restrictions lifted one at a time.
+    """
+    flat = synthetic.balanced_forest(9)
+    rng = np.random.default_rng(k)
+    spec = random_spec('F81', k, rng)
+    states = synthetic.tip_states(flat.n_tips, k, 3)
+    plain = synthetic.one_hot_masks(flat, k, states).astype(int)
+    mixed = plain.copy()
+    tips = np.flatnonzero(flat.is_tip)
+    internal = np.flatnonzero(~flat.is_tip)
+    mixed[tips[5]] = 1                                  # a tip without data
+    mixed[tips[40], :] = 0
+    mixed[tips[40], [1, 3]] = 1                         # an ambiguous tip
+    mixed[internal[-7], : k // 2] = 0                   # a restricted cherry
+    mixed[internal[len(internal) // 2], 1::2] = 0       # a restricted node higher up
+    for masks in (plain, mixed):
+        with hip.Engine(flat, 1, k) as eng:
+            eng.set_models([(spec, (1.4, 0.0, 1.0))])
+            eng.set_masks(masks[None])
+            lnl = eng.bottom_up(True)
+            post, lh_sum, lh_sf = eng.top_down_marginals()
+            bu = eng.download(hip.BUF_BU, 0)
+            bu_sf = eng.download(hip.BUF_BU_SF, 0)
+        ref = orc.full_marginal_pass(flat, masks, spec, sf=1.4)
+        np.testing.assert_allclose(lnl[0], ref['loglik'], rtol=LNL_RTOL)
+        np.testing.assert_allclose(post[0], ref['posterior'], rtol=1e-9, atol=1e-300)
+        assert_same_scaled(bu[internal], bu_sf[internal], ref['bu'][internal], ref['bu_sf'][internal], what='BU')
