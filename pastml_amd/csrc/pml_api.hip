@@ -62,8 +62,8 @@ struct pml_ctx {
     std::vector<hipEvent_t> prof_pool;
     hipEvent_t prof_open = nullptr;
     bool profile = false;
-    double prof_ms[3] = {0, 0, 0};
-    long long prof_launches[3] = {0, 0, 0};
+    double prof_ms[5] = {0, 0, 0, 0, 0};  // bottom-up levels, top-down levels, per-branch pass, two-level launch TD / BU
+    long long prof_launches[5] = {0, 0, 0, 0, 0};
     std::vector<void*> allocs;
     size_t held = 0;
 
@@ -99,6 +99,17 @@ struct pml_ctx {
         std::vector<int> top_bu_offsets, top_td_offsets;               // host copies (launch geometry)
         std::vector<char> top_bu_vec;                                   // per top level: stored node among children 0, 1
     } blocks;
+    // two-level units (pml_kernels_f81.h): nodes with two stored children that each carry two cherries of two tips run
+    // both levels in one unit; they and their children leave the level lists ("rest" lists, same level structure)
+    struct SuperSchedule {
+        bool ok = false;
+        int n = 0;
+        PmlUnit* d_units = nullptr;
+        PmlUnit *d_bu_units_r = nullptr, *d_td_units_r = nullptr;
+        int *d_bu_offsets_r = nullptr, *d_td_offsets_r = nullptr;
+        std::vector<int> bu_offsets_r, td_offsets_r;
+        std::vector<char> bu_level_vec_r;
+    } sup;
     bool small = false;  // forest small enough for the one-launch-per-sweep kernels
     bool levels_fit_workgroup = false;  // (nearly) every fused level is one pass of a 512-thread workgroup
     std::vector<int> bu_offsets_f, td_parent_offsets_f;
@@ -687,6 +698,54 @@ static int dispatch_sweep(pml_ctx* ctx, SweepKind what, const int* level, int n_
     PML_GR_CASES(X)
 #undef X
     return fail(PML_ERR_UNSUPPORTED, "no kernel for G=%d R=%d", ctx->G, ctx->R);
+}
+
+// Two-level units run in the lane shape the level kernels give the levels they replace where those do not stream stored
+// vectors (bottom-up: 8 states per lane for 32 < k <= 64) -- units of 8 lanes and more, single-word masks.
+static void super_shape(const pml_ctx* ctx, bool bottom_up, int& g, int& r) {
+    g = bottom_up ? (ctx->bu_wide_lanes ? 8 : ctx->Gf) : ctx->Gt;
+    r = bottom_up ? (ctx->bu_wide_lanes ? 8 : ctx->Rf) : ctx->Rt;
+}
+
+static bool super_units(const pml_ctx* ctx) {
+    if (!ctx->sup.ok || ctx->kind != PML_MODEL_F81 || ctx->W != 1) return false;
+    int g, r;
+    super_shape(ctx, true, g, r);
+    if (g < 8) return false;
+    super_shape(ctx, false, g, r);
+    return g >= 8;
+}
+
+template <int G, int R>
+static void launch_super_f81(pml_ctx* ctx, bool bottom_up) {
+    const PmlTree t = tree_of(ctx, true);
+    const PmlCols c = cols_of(ctx);
+    const PmlState st = state_of(ctx);
+    const int upb = PML_WAVES_PER_BLOCK * (64 / G);
+    dim3 grid(grid_for(ctx->sup.n, upb, ctx->C, bottom_up), ctx->C), block(PML_BLOCK);
+    if (bottom_up)
+        hipLaunchKernelGGL((bu_f81_super_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, ctx->sup.d_units, ctx->sup.n);
+    else
+        hipLaunchKernelGGL((td_f81_super_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, ctx->sup.d_units, ctx->sup.n);
+}
+
+#define PML_SUPER_CASES(X) \
+    X(8, 4)                \
+    X(16, 4)               \
+    X(8, 8)
+
+static int dispatch_super_f81(pml_ctx* ctx, bool bottom_up) {
+    int g, r;
+    super_shape(ctx, bottom_up, g, r);
+#define X(G_, R_)                                   \
+    if (g == G_ && r == R_) {                       \
+        launch_super_f81<G_, R_>(ctx, bottom_up);   \
+        HIP_TRY(hipGetLastError());                 \
+        return PML_OK;                              \
+    }
+    PML_SUPER_CASES(X)
+#undef X
+    return fail(PML_ERR_UNSUPPORTED, "no two-level F81 kernel for G=%d R=%d", g, r);
 }
 
 // fused eigen sweeps: one launch over a list (nodes) or a contiguous id range (first) of n nodes
@@ -1327,6 +1386,93 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
             PML_TRY(upload(ctx, ctx->d_td_units_f, ut_f.data(), ut_f.size()));
             PML_TRY(upload(ctx, ctx->d_bu_units, ub.data(), ub.size()));
             HIP_TRY(hipStreamSynchronize(ctx->stream));  // the vectors go out of scope
+        // ---- two-level units: stored nodes with two stored children that are each the parent of two cherries of two
+        // tips (ids of the four cherries and of the eight tips consecutive, as breadth-first numbering makes them)
+        {
+            pml_ctx::SuperSchedule& U = ctx->sup;
+            U = pml_ctx::SuperSchedule();
+            std::vector<char> pair(n_nodes, 0), sup(n_nodes, 0), gone(n_nodes, 0);
+            std::vector<int> sup_list;
+            if (ctx->fuse && !getenv("PASTML_HIP_NO_SUPER")) {
+                auto two = [&](int i) { return kind[i] == PML_KIND_STORED && n_children[i] == 2; };
+                for (int i = 0; i < n_nodes; ++i) {
+                    if (!two(i)) continue;
+                    const int a = first_child[i], b = a + 1;
+                    pair[i] = kind[a] == PML_KIND_CHERRY && kind[b] == PML_KIND_CHERRY && n_children[a] == 2 &&
+                              n_children[b] == 2 && first_child[b] == first_child[a] + 2;
+                }
+                for (int i = 0; i < n_nodes; ++i) {
+                    if (!two(i)) continue;
+                    const int a = first_child[i], b = a + 1;
+                    if (pair[a] && pair[b] && first_child[b] == first_child[a] + 2 &&
+                        first_child[first_child[b]] == first_child[first_child[a]] + 4) {
+                        sup[i] = 1;
+                        gone[i] = gone[a] = gone[b] = 1;
+                        sup_list.push_back(i);
+                    }
+                }
+            }
+            const char* env_min = getenv("PASTML_HIP_SUPER_MIN");
+            const int min_units = env_min ? atoi(env_min) : 64;
+            // (a launch of its own per sweep: only where it carries a share of the work)
+            if ((int)sup_list.size() >= min_units && (long long)sup_list.size() * 16 >= n_stored) {
+                std::vector<PmlUnit> us(sup_list.size());
+                for (size_t q = 0; q < sup_list.size(); ++q) {
+                    const int n = sup_list[q];
+                    PmlUnit u;
+                    u.n = n;
+                    u.fc = first_child[n];
+                    u.packed = PML_PACKED_TWO_STORED;
+                    u.cfc[0] = first_child[u.fc];
+                    u.cfc[1] = first_child[u.fc + 1];
+                    u.cfc[2] = u.cfc[3] = 0;
+                    u.pad = first_child[u.cfc[0]];
+                    us[q] = u;
+                }
+                // rest lists: the level structure of the fused lists, without the nodes the two-level units take over
+                std::vector<int> bu_r, td_r;
+                U.bu_offsets_r.assign(1, 0);
+                for (int l = 0; l < max_h; ++l) {
+                    for (int q = off[l]; q < off[l + 1]; ++q)
+                        if (!gone[order[q]]) bu_r.push_back(order[q]);
+                    U.bu_offsets_r.push_back((int)bu_r.size());
+                }
+                U.td_offsets_r.assign(1, 0);
+                for (int l = 0; l < n_td_levels; ++l) {
+                    for (int q = ctx->td_parent_offsets_f[l]; q < ctx->td_parent_offsets_f[l + 1]; ++q)
+                        if (!gone[tdp[q]]) td_r.push_back(tdp[q]);
+                    U.td_offsets_r.push_back((int)td_r.size());
+                }
+                std::vector<PmlUnit> ubr, utr;
+                describe(bu_r.data(), (int)bu_r.size(), true, ubr);
+                describe(td_r.data(), (int)td_r.size(), true, utr);
+                U.bu_level_vec_r.assign(max_h > 0 ? max_h : 1, 0);
+                for (int l = 0; l < max_h; ++l)
+                    for (int q = U.bu_offsets_r[l]; q < U.bu_offsets_r[l + 1] && !U.bu_level_vec_r[l]; ++q) {
+                        const int pk = ubr[q].packed;
+                        if (((pk >> 8) & 7) == 1 || ((pk >> 11) & 7) == 1) U.bu_level_vec_r[l] = 1;
+                    }
+                // (one element of slack: the walk over a level table reads the descriptor at a level's start even when
+                // the level is empty)
+                ubr.resize(bu_r.size() + 1, us[0]);
+                utr.resize(td_r.size() + 1, us[0]);
+                PML_TRY(dev_alloc(ctx, &U.d_units, us.size()));
+                PML_TRY(dev_alloc(ctx, &U.d_bu_units_r, ubr.size()));
+                PML_TRY(dev_alloc(ctx, &U.d_td_units_r, utr.size()));
+                PML_TRY(dev_alloc(ctx, &U.d_bu_offsets_r, U.bu_offsets_r.size()));
+                PML_TRY(dev_alloc(ctx, &U.d_td_offsets_r, U.td_offsets_r.size()));
+                PML_TRY(upload(ctx, U.d_units, us.data(), us.size()));
+                PML_TRY(upload(ctx, U.d_bu_units_r, ubr.data(), ubr.size()));
+                PML_TRY(upload(ctx, U.d_td_units_r, utr.data(), utr.size()));
+                PML_TRY(upload(ctx, U.d_bu_offsets_r, U.bu_offsets_r.data(), U.bu_offsets_r.size()));
+                PML_TRY(upload(ctx, U.d_td_offsets_r, U.td_offsets_r.data(), U.td_offsets_r.size()));
+                HIP_TRY(hipStreamSynchronize(ctx->stream));  // the vectors go out of scope
+                U.n = (int)us.size();
+                U.ok = true;
+                if (getenv("PASTML_HIP_DEBUG"))
+                    fprintf(stderr, "pastml_hip: %d two-level units (%d of %d stored nodes)\n", U.n, 3 * U.n, n_stored);
+            }
+        }
         // ---- subtree blocks: stored nodes -> blocks (maximal subtrees of <= S stored nodes) + top
         {
             const char* env = getenv("PASTML_HIP_BLOCK_NODES");
@@ -1959,6 +2105,30 @@ static int enqueue_bottom_up(pml_ctx* ctx, int is_marginal, bool small_path, boo
             PML_TRY(dispatch_small_f81(ctx, true, 0, 0, tail, B.d_top_bu_units, B.d_top_bu_offsets + (nl - tail)));
             loglik_done = true;
         }
+    } else if (fused && super_units(ctx)) {
+        // the two-level units first (they depend on tips only), then the levels of what is left
+        const pml_ctx::SuperSchedule& U = ctx->sup;
+        PML_TRY(dispatch_super_f81(ctx, true));
+        PML_TRY(prof_end(ctx, 4, 1));
+        PML_TRY(prof_begin(ctx));
+        const int nl = (int)U.bu_offsets_r.size() - 1;
+        const int tail = narrow_levels(U.bu_offsets_r, nl, false, ctx->C);
+        long long n_launch = 0;
+        for (int l = 0; l < nl - tail; ++l) {
+            const int a = U.bu_offsets_r[l], b = U.bu_offsets_r[l + 1];
+            if (b <= a) continue;
+            ctx->units_override = U.d_bu_units_r + a;
+            const int status = dispatch_sweep(ctx, U.bu_level_vec_r[l] ? SW_BU_MARG_FUSED : SW_BU_MARG_FUSED_NOVEC,
+                                              ctx->d_bu_order_f, b - a);
+            ctx->units_override = nullptr;
+            PML_TRY(status);
+            ++n_launch;
+        }
+        PML_TRY(prof_end(ctx, 0, n_launch));
+        if (tail > 0) {
+            PML_TRY(dispatch_small_f81(ctx, true, 0, 0, tail, U.d_bu_units_r, U.d_bu_offsets_r + (nl - tail)));
+            loglik_done = true;
+        }
     } else if (fused) {
         const int nl = (int)ctx->bu_offsets_f.size() - 1;
         const int tail = narrow_levels(ctx->bu_offsets_f, nl, false, ctx->C);
@@ -2175,6 +2345,30 @@ static int run_top_down(pml_ctx* ctx) {
             }
             PML_TRY(dispatch_blocks_f81(ctx, false));
             PML_TRY(prof_end(ctx, 1, n_launch + 1));
+            return PML_OK;
+        }
+        if (td_fused && !td_small && super_units(ctx)) {
+            // the levels of the rest lists, then every two-level unit in one launch (it needs its node's row only, and
+            // that comes from a unit of the rest lists or from the roots)
+            const pml_ctx::SuperSchedule& U = ctx->sup;
+            const int head = ctx->n_roots <= 64 ? narrow_levels(U.td_offsets_r, ctx->n_td_levels, true, ctx->C) : 0;
+            if (head == 0) PML_TRY(dispatch_sweep(ctx, SW_ROOTS, nullptr, ctx->n_roots));
+            if (head > 0) PML_TRY(dispatch_small_f81(ctx, false, 0, 0, head, U.d_td_units_r, U.d_td_offsets_r));
+            PML_TRY(prof_begin(ctx));
+            long long n_launch = 0;
+            for (int l = head; l < ctx->n_td_levels; ++l) {
+                const int a = U.td_offsets_r[l], b = U.td_offsets_r[l + 1];
+                if (b <= a) continue;
+                ctx->units_override = U.d_td_units_r + a;
+                const int status = dispatch_sweep(ctx, SW_TD_FUSED, ctx->d_td_parents_f, b - a);
+                ctx->units_override = nullptr;
+                PML_TRY(status);
+                ++n_launch;
+            }
+            PML_TRY(prof_end(ctx, 1, n_launch));
+            PML_TRY(prof_begin(ctx));
+            PML_TRY(dispatch_super_f81(ctx, false));
+            PML_TRY(prof_end(ctx, 3, 1));
             return PML_OK;
         }
         // F81 family: the roots and the levels right below them in one launch
@@ -2855,7 +3049,7 @@ int pml_profile_enable(pml_ctx* ctx, int on) {
 }
 
 int pml_profile_read(pml_ctx* ctx, int which, double* total_ms, int64_t* launches, int reset) {
-    if (!ctx || which < 0 || which > 2) return fail(PML_ERR_INVALID, "bad profile slot");
+    if (!ctx || which < 0 || which > 4) return fail(PML_ERR_INVALID, "bad profile slot");
     PML_TRY(prof_drain(ctx));
     if (total_ms) *total_ms = ctx->prof_ms[which];
     if (launches) *launches = ctx->prof_launches[which];

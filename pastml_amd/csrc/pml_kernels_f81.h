@@ -749,9 +749,18 @@ __device__ __forceinline__ void bu_loads_arrived(BuLoads<R>& ld) {
 // PAIR (wave-uniform, decided by the caller): every unit of the wave has two children, both cherries of two tips -- the
 // shape of a whole level of a balanced binary tree.  Child and tip counts are then compile-time constants: the loops
 // unroll into straight-line code (no per-child exec masks, the lane exchanges of all four tips issued together).
+// What a unit's body leaves in registers for a caller that goes on with the node's parent (two-level units below).
+template <int R>
+struct BuResult {
+    double v[R];
+    double s;
+    i64 e;
+};
+
 template <int G, int R, bool VEC, bool FULL, bool PAIR = false>
 __device__ __forceinline__ bool bu_f81_marg_body(const LaneCtx<G, R>& L, const PmlTree& t, const PmlCols& c,
-                                                 const PmlState& st, const UnitRegs& u, BuLoads<R>& ld) {
+                                                 const PmlState& st, const UnitRegs& u, BuLoads<R>& ld,
+                                                 BuResult<R>* keep = nullptr) {
     const int n = u.n, fc = u.fc;
     const int nc = PAIR ? 2 : unit_nc(u.packed);
     ChildLane& cl = ld.cl;
@@ -829,6 +838,12 @@ __device__ __forceinline__ bool bu_f81_marg_body(const LaneCtx<G, R>& L, const P
         L.be[n] = esum;
     }
     node_store_vec<G, R>(L, c, L.bu, n, acc);
+    if (keep != nullptr) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) keep->v[r] = acc[r];
+        keep->s = s;
+        keep->e = esum;
+    }
     return true;
 }
 
@@ -1301,6 +1316,179 @@ bu_f81_kernel(PmlTree t, PmlCols c, PmlState st, const PmlUnit* __restrict__ uni
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Two-level units (round 3).  Where a tree is locally balanced -- a stored node n with two stored children, each of
+// them the parent of two cherries of two tips -- the level schedule writes the children's vectors in one launch and
+// reads them straight back in the next (bottom-up), and writes the children's posterior rows in one launch and reads
+// them back as "parent" rows in the next (top-down): on a balanced binary tree that is a fifth of the bottom-up bytes
+// and a twelfth of the top-down bytes.  A two-level unit is (n, column): it runs the units of both children and then
+// n's own unit on what they left in registers.  The three units are the level kernels' bodies, called with the same
+// arguments in the same lane shape: the same bits.  The children of such nodes ("absorbed") and the nodes themselves
+// leave the level lists (pml_tree_upload: rest lists); everything still lands in memory where the other sweeps,
+// the downloads and the other schedules expect it.
+// Descriptor of a two-level unit: n, fc (children fc, fc + 1), cfc[0] = g0 (the four cherries g0 .. g0 + 3),
+// pad = t0 (the eight tips t0 .. t0 + 7).
+// ---------------------------------------------------------------------------------------------------------------------
+#define PML_PACKED_PAIR ((3 << 11) | (3 << 8) | (3 << 4) | 2)        // two children, both cherries of two tips
+#define PML_PACKED_TWO_STORED ((1 << 11) | (1 << 8) | (3 << 4) | 2)  // two children, both stored nodes
+
+struct SuperRegs {
+    int n, fc, g0, t0;
+};
+
+__device__ __forceinline__ SuperRegs load_super(const PmlUnit* __restrict__ units, int idx) {
+    const int4 h = *reinterpret_cast<const int4*>(units + idx);
+    SuperRegs s;
+    s.n = h.x;
+    s.fc = h.y;
+    s.t0 = h.w;
+    s.g0 = units[idx].cfc[0];
+    return s;
+}
+
+// the descriptor registers child j of a two-level unit would get from load_unit (G >= 8)
+template <int G>
+__device__ __forceinline__ UnitRegs super_child(const SuperRegs& s, int j, int g) {
+    UnitRegs u;
+    u.n = s.fc + j;
+    u.fc = s.g0 + 2 * j;
+    u.packed = PML_PACKED_PAIR;
+    u.cfc = s.t0 + 4 * j + 2 * ((g / Gather<G>::GC) & 1);
+    u.cfc1 = u.cfc2 = u.cfc3 = 0;
+    return u;
+}
+
+__device__ __forceinline__ UnitRegs super_own(const SuperRegs& s) {
+    UnitRegs u;
+    u.n = s.n;
+    u.fc = s.fc;
+    u.packed = PML_PACKED_TWO_STORED;
+    u.cfc = u.cfc1 = u.cfc2 = u.cfc3 = 0;
+    return u;
+}
+
+template <int R>
+struct SuperLoads {
+    BuLoads<R> c[2];  // what the two children's own units read
+    double e;         // lane j < 2: E of child j
+    u64 own;          // the node's own mask word
+};
+
+template <int G, int R>
+__device__ __forceinline__ void bu_f81_super_issue(const LaneCtx<G, R>& L, const SuperRegs& s, SuperLoads<R>& ld) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const UnitRegs u = super_child<G>(s, j, L.g);
+        f81_gather_issue<G, R>(L, u, ld.c[j].cl, ld.c[j].tl);
+        ld.c[j].own = L.mask[(unsigned)u.n];
+    }
+    ld.e = L.E[s.fc + (L.g & 1)];
+    ld.own = L.mask[(unsigned)s.n];
+}
+
+// one wait for exactly this unit's loads (see bu_loads_arrived); S and the exponent word of a cherry are not read
+template <int R>
+__device__ __forceinline__ void super_loads_arrived(SuperLoads<R>& ld) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+        asm volatile("" : "+v"(ld.c[j].cl.e), "+v"(ld.c[j].cl.mask), "+v"(ld.c[j].tl.e), "+v"(ld.c[j].tl.s),
+                          "+v"(ld.c[j].tl.mask), "+v"(ld.c[j].own));
+    asm volatile("" : "+v"(ld.e), "+v"(ld.own));
+}
+
+// false: some vector came out all zero (nothing of the failing unit was stored); the caller repeats the three units
+// on the sequential path, which names the pair the reference would.
+template <int G, int R>
+__device__ __forceinline__ bool bu_f81_super_unit(const LaneCtx<G, R>& L, const PmlTree& t, const PmlCols& c,
+                                                  const PmlState& st, const SuperRegs& s, SuperLoads<R>& ld) {
+    super_loads_arrived<R>(ld);
+    const u64 kbits = state_bits(c.k);
+    bool ones = c.k == G * R;  // (a padding entry must stay 0, and only a mask makes it so)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        f81_gather_finish<G, R>(L, ld.c[j].cl, ld.c[j].tl);
+        ones = ones && (ld.c[j].own & kbits) == kbits && ld.c[j].cl.mask == kbits;
+    }
+    const bool full = __all(ones);  // wave-uniform choice of the body, as in bu_f81_unit_fast
+    BuResult<R> res[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const UnitRegs u = super_child<G>(s, j, L.g);
+        const bool ok = full ? bu_f81_marg_body<G, R, false, true, true>(L, t, c, st, u, ld.c[j], &res[j])
+                             : bu_f81_marg_body<G, R, false, false, true>(L, t, c, st, u, ld.c[j], &res[j]);
+        if (!ok) return false;
+    }
+    // the node's own unit, as the level above would run it (bu_f81_unit_fast, streaming level): the children's vectors,
+    // pi . v and exponents from registers instead of from memory
+    BuLoads<R> top;
+    top.cl.e = ld.e;
+    top.cl.s = (L.g & 1) ? res[1].s : res[0].s;
+    top.cl.be = (L.g & 1) ? res[1].e : res[0].e;
+    top.cl.mask = kbits;
+    top.tl.e = top.tl.s = top.tl.a = 0.0;
+    top.tl.mask = 0ull;
+    top.own = ld.own;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        top.v0[r] = res[0].v[r];
+        top.v1[r] = res[1].v[r];
+    }
+    return bu_f81_marg_body<G, R, true, false>(L, t, c, st, super_own(s), top);
+}
+
+template <int G, int R>
+__device__ __forceinline__ void bu_f81_super_seq(const LaneCtx<G, R>& L, const PmlTree& t, const PmlCols& c,
+                                                 const PmlState& st, const SuperRegs& s) {
+    bu_f81_unit_seq<G, R, false>(L, t, c, st, super_child<G>(s, 0, L.g));
+    bu_f81_unit_seq<G, R, false>(L, t, c, st, super_child<G>(s, 1, L.g));
+    __threadfence();  // the node's unit reads what the wave has just stored
+    bu_f81_unit_seq<G, R, false>(L, t, c, st, super_own(s));
+}
+
+// The same two-stage software pipeline as bu_f81_kernel: the loads of unit i + 1 and the descriptor of unit i + 2 are
+// in flight while unit i is computed.
+template <int G, int R>
+__global__ void __launch_bounds__(PML_BLOCK) __attribute__((amdgpu_waves_per_eu(R >= 8 ? 2 : 3, R >= 8 ? 2 : 4)))
+bu_f81_super_kernel(PmlTree t, PmlCols c, PmlState st, const PmlUnit* __restrict__ units, int n_level) {
+    constexpr int UW = 64 / G;
+    const int wave = threadIdx.x >> 6;
+    const int sub = (threadIdx.x & 63) / G;
+    LaneCtx<G, R> L;
+    lane_ctx_init<G, R>(L, t, c, st);
+    const int stride = gridDim.x * PML_WAVES_PER_BLOCK * UW;
+    int idx = (blockIdx.x * PML_WAVES_PER_BLOCK + wave) * UW + sub;
+    int base = idx - sub;
+    SuperRegs ua = load_super(units, idx < n_level ? idx : 0);
+    SuperRegs ub = load_super(units, idx + stride < n_level ? idx + stride : 0);
+    SuperLoads<R> la, lb;
+    bu_f81_super_issue<G, R>(L, ua, la);
+    while (base < n_level) {
+        {
+            const int i2 = idx + 2 * stride;
+            const SuperRegs un = load_super(units, i2 < n_level ? i2 : 0);
+            bu_f81_super_issue<G, R>(L, ub, lb);
+            if (idx < n_level) {
+                if (!bu_f81_super_unit<G, R>(L, t, c, st, ua, la)) bu_f81_super_seq<G, R>(L, t, c, st, ua);
+            }
+            ua = un;
+            idx += stride;
+            base += stride;
+        }
+        if (base >= n_level) break;
+        {
+            const int i2 = idx + 2 * stride;
+            const SuperRegs un = load_super(units, i2 < n_level ? i2 : 0);
+            bu_f81_super_issue<G, R>(L, ua, la);
+            if (idx < n_level) {
+                if (!bu_f81_super_unit<G, R>(L, t, c, st, ub, lb)) bu_f81_super_seq<G, R>(L, t, c, st, ub);
+            }
+            ub = un;
+            idx += stride;
+            base += stride;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // top-down + marginal likelihoods + posteriors.
 //
 // f81_finish_child: given prod = TD_parent o BU_parent (exponent pe) and the child's own data, divides the child's
@@ -1425,11 +1613,14 @@ __device__ __forceinline__ void f81_finish_tip(const LaneCtx<G, R>& L, const Pml
 }
 
 template <int G, int R>
+__device__ __forceinline__ void td_f81_fast_children(const LaneCtx<G, R>& L, const PmlTree& t, const PmlCols& c,
+                                                     const PmlState& st, const UnitRegs& u, const double (&prod)[R],
+                                                     i64 pe, const ChildLane& cl, const TipLane& tl, double (&vn)[R]);
+
+template <int G, int R>
 __device__ __forceinline__ void td_f81_unit_fast(const LaneCtx<G, R>& L, const PmlTree& t, const PmlCols& c,
                                                  const PmlState& st, const UnitRegs& u) {
-    constexpr int GC = Gather<G>::GC;
     const int p = u.n, fc = u.fc;
-    const int nc = unit_nc(u.packed);
     double prod[R];
     i64 pe;
     f81_parent_prod<G, R>(L, c, p, prod, pe);
@@ -1439,6 +1630,18 @@ __device__ __forceinline__ void td_f81_unit_fast(const LaneCtx<G, R>& L, const P
     double vn[R];
     if (unit_code(u.packed, 0) == 1) node_load_vec<G, R>(L, c, L.bu, fc, vn);
     f81_gather_finish<G, R>(L, cl, tl);
+    td_f81_fast_children<G, R>(L, t, c, st, u, prod, pe, cl, tl, vn);
+}
+
+// The children of a fast unit's node, given prod = TD o BU of the node (exponent pe), the gathered scalars and -- if
+// child 0 is a stored node -- its bottom-up vector in vn.
+template <int G, int R>
+__device__ __forceinline__ void td_f81_fast_children(const LaneCtx<G, R>& L, const PmlTree& t, const PmlCols& c,
+                                                     const PmlState& st, const UnitRegs& u, const double (&prod)[R],
+                                                     i64 pe, const ChildLane& cl, const TipLane& tl, double (&vn)[R]) {
+    constexpr int GC = Gather<G>::GC;
+    const int fc = u.fc;
+    const int nc = unit_nc(u.packed);
     double P = 0.0;
     bool have_P = false;
     for (int jx = 0; jx < nc; ++jx) {
@@ -1768,6 +1971,88 @@ td_f81_kernel(PmlTree t, PmlCols c, PmlState st, const PmlUnit* __restrict__ uni
         const UnitRegs nxt = load_unit<G>(units, nxt_idx < n_level ? nxt_idx : 0, L.g);
         if (idx < n_level) td_f81_unit<G, R, true>(L, t, c, st, cur);
         if (staged) td_stage_flush<G, R>(L, c, S, (stage & 4) != 0);
+        cur = nxt;
+        idx = nxt_idx;
+    }
+}
+
+// Top-down two-level unit (see bu_f81_super_unit): the node's own unit finishes its two stored children from the node's
+// posterior row; each child's finished row, sum and exponent then serve, from registers, as the "parent" data of the
+// child's own unit (two cherries of two tips) -- what the next level launch would have read back.  Same functions,
+// same arguments, same lane shape as the level kernel: the same bits.  Order: both children are finished first (the
+// node's row and the children's vectors are dead after that), then the children's units one after the other; the
+// gather of the second child's unit goes out while the first one's is computed.
+template <int G, int R>
+__device__ __forceinline__ void td_f81_super_unit(const LaneCtx<G, R>& L, const PmlTree& t, const PmlCols& c,
+                                                  const PmlState& st, const SuperRegs& s) {
+    const u64 kbits = state_bits(c.k);
+    double prod2[2][R];
+    i64 pe2[2];
+    ChildLane cl0;
+    TipLane tl0;
+    {
+        double prod[R];
+        i64 pe;
+        f81_parent_prod<G, R>(L, c, s.n, prod, pe);
+        ChildLane top;  // lane j < 2: child j
+        {
+            const int ch = s.fc + (L.g & 1);
+            top.e = L.E[ch];
+            top.s = L.S[ch];
+            top.mask = L.mask[(unsigned)ch];
+            top.be = L.be[ch];
+        }
+        double v[2][R];
+        node_load_vec<G, R>(L, c, L.bu, s.fc, v[0]);
+        node_load_vec<G, R>(L, c, L.bu, s.fc + 1, v[1]);
+        f81_gather_issue<G, R>(L, super_child<G>(s, 0, L.g), cl0, tl0);
+        top.mask &= kbits;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int src = L.group_base + j;
+            const int ch = s.fc + j;
+            const double e = __shfl(top.e, src, 64);
+            const u64 word = __shfl(top.mask, src, 64);
+            double mb[R], tdc[R], po[R], ls;
+            const bool full = word == kbits;
+            if (!full) clean_word_to_vec<G, R>(L, c, word, mb);
+            i64 xe;
+            f81_finish_child<G, R>(L, c, prod, pe, ch, e, __shfl(top.s, src, 64), __shfl(top.be, src, 64), v[j], full, mb,
+                                   tdc, xe, po, ls, pe2[j]);
+            if (st.td != nullptr) {
+                node_store_vec<G, R>(L, c, L.td, ch, tdc);
+                if (L.g == 0) L.te[ch] = xe;
+            }
+            // f81_parent_prod on the row, sum and exponent just stored
+#pragma unroll
+            for (int r = 0; r < R; ++r) prod2[j][r] = po[r] * (ls * L.ipi_r[r]);
+        }
+    }
+    ChildLane cl1;
+    TipLane tl1;
+    f81_gather_issue<G, R>(L, super_child<G>(s, 1, L.g), cl1, tl1);
+    double none[R];
+    f81_gather_finish<G, R>(L, cl0, tl0);
+    td_f81_fast_children<G, R>(L, t, c, st, super_child<G>(s, 0, L.g), prod2[0], pe2[0], cl0, tl0, none);
+    f81_gather_finish<G, R>(L, cl1, tl1);
+    td_f81_fast_children<G, R>(L, t, c, st, super_child<G>(s, 1, L.g), prod2[1], pe2[1], cl1, tl1, none);
+}
+
+template <int G, int R>
+__global__ void __launch_bounds__(PML_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
+td_f81_super_kernel(PmlTree t, PmlCols c, PmlState st, const PmlUnit* __restrict__ units, int n_level) {
+    constexpr int UW = 64 / G;
+    const int wave = threadIdx.x >> 6;
+    const int sub = (threadIdx.x & 63) / G;
+    LaneCtx<G, R> L;
+    lane_ctx_init<G, R>(L, t, c, st);
+    const int stride = gridDim.x * PML_WAVES_PER_BLOCK * UW;
+    int idx = (blockIdx.x * PML_WAVES_PER_BLOCK + wave) * UW + sub;
+    SuperRegs cur = load_super(units, idx < n_level ? idx : 0);
+    for (int base = idx - sub; base < n_level; base += stride) {
+        const int nxt_idx = idx + stride;
+        const SuperRegs nxt = load_super(units, nxt_idx < n_level ? nxt_idx : 0);
+        if (idx < n_level) td_f81_super_unit<G, R>(L, t, c, st, cur);
         cur = nxt;
         idx = nxt_idx;
     }
