@@ -105,6 +105,7 @@ struct pml_ctx {
         bool ok = false;
         int n = 0;
         PmlUnit* d_units = nullptr;
+        PmlUnit* d_child_units = nullptr;  // the 2 n children of the two-level units, as units of their own (downloads)
         PmlUnit *d_bu_units_r = nullptr, *d_td_units_r = nullptr;
         int *d_bu_offsets_r = nullptr, *d_td_offsets_r = nullptr;
         std::vector<int> bu_offsets_r, td_offsets_r;
@@ -118,6 +119,7 @@ struct pml_ctx {
     std::vector<char> bu_level_vec;    // the same for the plain levels (joint sweep: every internal node is stored)
     int n_cherries = 0;
     bool bu_fused = false;  // the last bottom-up sweep left the cherries unmaterialised
+    bool bu_absorbed = false;  // ... and the children of the two-level units
     bool bu_fused_joint = false;  // ... and it was a joint sweep
 
     // columns
@@ -716,13 +718,19 @@ static bool super_units(const pml_ctx* ctx) {
     return g >= 8;
 }
 
+// the sweeps of this context run the level schedule with two-level units (not one launch per sweep, not subtree blocks)
+static bool super_sweeps(const pml_ctx* ctx) {
+    return super_units(ctx) && !single_launch_sweeps(ctx) && !block_schedule(ctx);
+}
+
 template <int G, int R>
 static void launch_super_f81(pml_ctx* ctx, bool bottom_up) {
     const PmlTree t = tree_of(ctx, true);
     const PmlCols c = cols_of(ctx);
     const PmlState st = state_of(ctx);
     const int upb = PML_WAVES_PER_BLOCK * (64 / G);
-    dim3 grid(grid_for(ctx->sup.n, upb, ctx->C, bottom_up), ctx->C), block(PML_BLOCK);
+    // (top-down: one unit per child of a two-level node)
+    dim3 grid(grid_for(bottom_up ? ctx->sup.n : 2 * ctx->sup.n, upb, ctx->C, bottom_up), ctx->C), block(PML_BLOCK);
     if (bottom_up)
         hipLaunchKernelGGL((bu_f81_super_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, ctx->sup.d_units, ctx->sup.n);
     else
@@ -1443,7 +1451,17 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
                         if (!gone[tdp[q]]) td_r.push_back(tdp[q]);
                     U.td_offsets_r.push_back((int)td_r.size());
                 }
-                std::vector<PmlUnit> ubr, utr;
+                std::vector<PmlUnit> ubr, utr, uch;
+                {
+                    std::vector<int> ch_list;
+                    for (int n : sup_list) {
+                        ch_list.push_back(first_child[n]);
+                        ch_list.push_back(first_child[n] + 1);
+                    }
+                    describe(ch_list.data(), (int)ch_list.size(), true, uch);
+                    PML_TRY(dev_alloc(ctx, &U.d_child_units, uch.size()));
+                    PML_TRY(upload(ctx, U.d_child_units, uch.data(), uch.size()));
+                }
                 describe(bu_r.data(), (int)bu_r.size(), true, ubr);
                 describe(td_r.data(), (int)td_r.size(), true, utr);
                 U.bu_level_vec_r.assign(max_h > 0 ? max_h : 1, 0);
@@ -2105,7 +2123,7 @@ static int enqueue_bottom_up(pml_ctx* ctx, int is_marginal, bool small_path, boo
             PML_TRY(dispatch_small_f81(ctx, true, 0, 0, tail, B.d_top_bu_units, B.d_top_bu_offsets + (nl - tail)));
             loglik_done = true;
         }
-    } else if (fused && super_units(ctx)) {
+    } else if (fused && super_sweeps(ctx)) {
         // the two-level units first (they depend on tips only), then the levels of what is left
         const pml_ctx::SuperSchedule& U = ctx->sup;
         PML_TRY(dispatch_super_f81(ctx, true));
@@ -2265,6 +2283,7 @@ static int submit_bottom_up(pml_ctx* ctx, int is_marginal) {
     // the fused eigen sweeps build P(t) in registers, the two-GEMM sweeps never form it: no batch ran
     if (!no_p) ctx->prep_dirty = false;
     ctx->bu_fused = (is_marginal && ctx->kind == PML_MODEL_F81 && ctx->n_cherries > 0) || ctx->bu_fused_joint;
+    ctx->bu_absorbed = is_marginal && ctx->kind == PML_MODEL_F81 && !small_path && super_sweeps(ctx);
     return PML_OK;
 }
 
@@ -2347,7 +2366,7 @@ static int run_top_down(pml_ctx* ctx) {
             PML_TRY(prof_end(ctx, 1, n_launch + 1));
             return PML_OK;
         }
-        if (td_fused && !td_small && super_units(ctx)) {
+        if (td_fused && !td_small && super_sweeps(ctx)) {
             // the levels of the rest lists, then every two-level unit in one launch (it needs its node's row only, and
             // that comes from a unit of the rest lists or from the roots)
             const pml_ctx::SuperSchedule& U = ctx->sup;
@@ -2569,6 +2588,7 @@ int pml_marginal_pass(pml_ctx* ctx, double* loglik_out, int32_t* err_parent, int
         ctx->prep_dirty = false;
         ctx->bu_fused = ctx->n_cherries > 0;
         ctx->bu_fused_joint = false;
+        ctx->bu_absorbed = super_sweeps(ctx);
         ctx->td_valid = true;
         ctx->td_vec_valid = ctx->keep_td;
         ctx->td_filled = false;
@@ -2797,6 +2817,15 @@ static int fetch_exponents(pml_ctx* ctx, const i64* src, int col, double* out) {
 
 // after a fused sweep the cherries' bottom-up vectors only ever existed in registers: compute them for inspection
 static int materialize_cherries(pml_ctx* ctx) {
+    if (ctx->bu_absorbed) {
+        // the children of the two-level units: their own units (two cherries of two tips), from the tips
+        ctx->units_override = ctx->sup.d_child_units;
+        const int status = dispatch_sweep(ctx, SW_BU_MARG_FUSED_NOVEC, ctx->d_bu_order_f, 2 * ctx->sup.n);
+        ctx->units_override = nullptr;
+        PML_TRY(status);
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        ctx->bu_absorbed = false;
+    }
     if (!ctx->bu_fused) return PML_OK;
     PML_TRY(dispatch_sweep(ctx, ctx->bu_fused_joint ? SW_BU_CHERRIES_JOINT : SW_BU_CHERRIES, ctx->d_cherries,
                            ctx->n_cherries));

@@ -760,7 +760,8 @@ struct BuResult {
 template <int G, int R, bool VEC, bool FULL, bool PAIR = false>
 __device__ __forceinline__ bool bu_f81_marg_body(const LaneCtx<G, R>& L, const PmlTree& t, const PmlCols& c,
                                                  const PmlState& st, const UnitRegs& u, BuLoads<R>& ld,
-                                                 BuResult<R>* keep = nullptr) {
+                                                 BuResult<R>* keep = nullptr, bool store_vec = true,
+                                                 bool vec_only = false) {
     const int n = u.n, fc = u.fc;
     const int nc = PAIR ? 2 : unit_nc(u.packed);
     ChildLane& cl = ld.cl;
@@ -793,8 +794,12 @@ __device__ __forceinline__ bool bu_f81_marg_body(const LaneCtx<G, R>& L, const P
                 i64 ce;
                 f81_cherry_from_lanes<G, R>(L, c, cl, tl, jx, code - 1, v, ce, FULL);
                 esum += ce;
-                s_child = pi_dot<G, R>(L, v);
-                if (L.g == 0) L.S[ch] = s_child;  // 8 bytes kept for the top-down sweep (saves its reduction there)
+                if (vec_only) {
+                    s_child = __shfl(cl.s, src, 64);  // as the bottom-up sweep stored it
+                } else {
+                    s_child = pi_dot<G, R>(L, v);
+                    if (L.g == 0) L.S[ch] = s_child;  // 8 bytes kept for the top-down sweep (saves its reduction there)
+                }
             }
             a = (1.0 - e) * s_child;
 #pragma unroll
@@ -826,6 +831,13 @@ __device__ __forceinline__ bool bu_f81_marg_body(const LaneCtx<G, R>& L, const P
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = L.st(r) < c.k ? 1.0 : 0.0;
     }
+    if (vec_only) {  // (the top-down two-level unit: the vector again, nothing stored)
+#pragma unroll
+        for (int r = 0; r < R; ++r) keep->v[r] = acc[r];
+        keep->s = 0.0;
+        keep->e = esum;
+        return true;
+    }
     const double s = pi_dot<G, R>(L, acc);
     if (!(s > 0.0)) {  // pi . acc > 0 already says that acc is not all zero
         bool nz = false;
@@ -837,7 +849,7 @@ __device__ __forceinline__ bool bu_f81_marg_body(const LaneCtx<G, R>& L, const P
         L.S[n] = s;
         L.be[n] = esum;
     }
-    node_store_vec<G, R>(L, c, L.bu, n, acc);
+    if (store_vec) node_store_vec<G, R>(L, c, L.bu, n, acc);
     if (keep != nullptr) {
 #pragma unroll
         for (int r = 0; r < R; ++r) keep->v[r] = acc[r];
@@ -1413,8 +1425,10 @@ __device__ __forceinline__ bool bu_f81_super_unit(const LaneCtx<G, R>& L, const 
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const UnitRegs u = super_child<G>(s, j, L.g);
-        const bool ok = full ? bu_f81_marg_body<G, R, false, true, true>(L, t, c, st, u, ld.c[j], &res[j])
-                             : bu_f81_marg_body<G, R, false, false, true>(L, t, c, st, u, ld.c[j], &res[j]);
+        // (the children's vectors are not written: the top-down two-level unit rebuilds them from the tips, as both
+        // sweeps rebuild cherries; pi . v and the exponent are -- 16 bytes instead of 8 ks + 16)
+        const bool ok = full ? bu_f81_marg_body<G, R, false, true, true>(L, t, c, st, u, ld.c[j], &res[j], false)
+                             : bu_f81_marg_body<G, R, false, false, true>(L, t, c, st, u, ld.c[j], &res[j], false);
         if (!ok) return false;
     }
     // the node's own unit, as the level above would run it (bu_f81_unit_fast, streaming level): the children's vectors,
@@ -1976,83 +1990,71 @@ td_f81_kernel(PmlTree t, PmlCols c, PmlState st, const PmlUnit* __restrict__ uni
     }
 }
 
-// Top-down two-level unit (see bu_f81_super_unit): the node's own unit finishes its two stored children from the node's
-// posterior row; each child's finished row, sum and exponent then serve, from registers, as the "parent" data of the
-// child's own unit (two cherries of two tips) -- what the next level launch would have read back.  Same functions,
-// same arguments, same lane shape as the level kernel: the same bits.  Order: both children are finished first (the
-// node's row and the children's vectors are dead after that), then the children's units one after the other; the
-// gather of the second child's unit goes out while the first one's is computed.
+// Top-down side of the two-level units (see bu_f81_super_unit): one unit per CHILD j of a two-level node p.  The unit
+// rebuilds the child's bottom-up vector from the tips (the bottom-up body again, with pi . v of the cherries as that
+// sweep stored it: the vector was never written), finishes the child from p's posterior row -- the step of p's own unit
+// that concerns this child -- and goes on with the child's own unit (two cherries of two tips) on the row, sum and
+// exponent it has just produced: what the next level launch would have read back.  The two children of p are adjacent
+// units of one wavefront, so p's row comes from memory once.  Same functions, same arguments, same lane shape as the
+// level kernels: the same bits.
 template <int G, int R>
 __device__ __forceinline__ void td_f81_super_unit(const LaneCtx<G, R>& L, const PmlTree& t, const PmlCols& c,
-                                                  const PmlState& st, const SuperRegs& s) {
+                                                  const PmlState& st, const SuperRegs& s, int j) {
     const u64 kbits = state_bits(c.k);
-    double prod2[2][R];
-    i64 pe2[2];
-    ChildLane cl0;
-    TipLane tl0;
+    const int ch = s.fc + j;
+    const UnitRegs u = super_child<G>(s, j, L.g);
+    double prod[R];
+    i64 pe;
+    f81_parent_prod<G, R>(L, c, s.n, prod, pe);
+    const double e = L.E[ch];
+    const double s_child = L.S[ch];
+    const i64 bec = L.be[ch];
+    BuLoads<R> ld;
+    ld.own = L.mask[(unsigned)ch];
+    f81_gather_issue<G, R>(L, u, ld.cl, ld.tl);
+    f81_gather_finish<G, R>(L, ld.cl, ld.tl);
+    ld.own &= kbits;
+    const bool all_ones = __all(c.k == G * R && ld.own == kbits && ld.cl.mask == kbits);
+    BuResult<R> v;
+    if (all_ones) bu_f81_marg_body<G, R, false, true, true>(L, t, c, st, u, ld, &v, false, true);
+    else bu_f81_marg_body<G, R, false, false, true>(L, t, c, st, u, ld, &v, false, true);
+    double prod2[R];
+    i64 pe2;
     {
-        double prod[R];
-        i64 pe;
-        f81_parent_prod<G, R>(L, c, s.n, prod, pe);
-        ChildLane top;  // lane j < 2: child j
-        {
-            const int ch = s.fc + (L.g & 1);
-            top.e = L.E[ch];
-            top.s = L.S[ch];
-            top.mask = L.mask[(unsigned)ch];
-            top.be = L.be[ch];
+        double mb[R], tdc[R], po[R], ls;
+        const bool full = ld.own == kbits;
+        if (!full) clean_word_to_vec<G, R>(L, c, ld.own, mb);
+        i64 xe;
+        f81_finish_child<G, R>(L, c, prod, pe, ch, e, s_child, bec, v.v, full, mb, tdc, xe, po, ls, pe2);
+        if (st.td != nullptr) {
+            node_store_vec<G, R>(L, c, L.td, ch, tdc);
+            if (L.g == 0) L.te[ch] = xe;
         }
-        double v[2][R];
-        node_load_vec<G, R>(L, c, L.bu, s.fc, v[0]);
-        node_load_vec<G, R>(L, c, L.bu, s.fc + 1, v[1]);
-        f81_gather_issue<G, R>(L, super_child<G>(s, 0, L.g), cl0, tl0);
-        top.mask &= kbits;
+        // f81_parent_prod on the row, sum and exponent just stored
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int src = L.group_base + j;
-            const int ch = s.fc + j;
-            const double e = __shfl(top.e, src, 64);
-            const u64 word = __shfl(top.mask, src, 64);
-            double mb[R], tdc[R], po[R], ls;
-            const bool full = word == kbits;
-            if (!full) clean_word_to_vec<G, R>(L, c, word, mb);
-            i64 xe;
-            f81_finish_child<G, R>(L, c, prod, pe, ch, e, __shfl(top.s, src, 64), __shfl(top.be, src, 64), v[j], full, mb,
-                                   tdc, xe, po, ls, pe2[j]);
-            if (st.td != nullptr) {
-                node_store_vec<G, R>(L, c, L.td, ch, tdc);
-                if (L.g == 0) L.te[ch] = xe;
-            }
-            // f81_parent_prod on the row, sum and exponent just stored
-#pragma unroll
-            for (int r = 0; r < R; ++r) prod2[j][r] = po[r] * (ls * L.ipi_r[r]);
-        }
+        for (int r = 0; r < R; ++r) prod2[r] = po[r] * (ls * L.ipi_r[r]);
     }
-    ChildLane cl1;
-    TipLane tl1;
-    f81_gather_issue<G, R>(L, super_child<G>(s, 1, L.g), cl1, tl1);
     double none[R];
-    f81_gather_finish<G, R>(L, cl0, tl0);
-    td_f81_fast_children<G, R>(L, t, c, st, super_child<G>(s, 0, L.g), prod2[0], pe2[0], cl0, tl0, none);
-    f81_gather_finish<G, R>(L, cl1, tl1);
-    td_f81_fast_children<G, R>(L, t, c, st, super_child<G>(s, 1, L.g), prod2[1], pe2[1], cl1, tl1, none);
+    td_f81_fast_children<G, R>(L, t, c, st, u, prod2, pe2, ld.cl, ld.tl, none);
 }
 
+// n_level = number of two-level nodes; unit i is child i & 1 of node i >> 1
 template <int G, int R>
-__global__ void __launch_bounds__(PML_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ void __launch_bounds__(PML_BLOCK)
 td_f81_super_kernel(PmlTree t, PmlCols c, PmlState st, const PmlUnit* __restrict__ units, int n_level) {
     constexpr int UW = 64 / G;
     const int wave = threadIdx.x >> 6;
     const int sub = (threadIdx.x & 63) / G;
     LaneCtx<G, R> L;
     lane_ctx_init<G, R>(L, t, c, st);
+    const int n_units = 2 * n_level;
     const int stride = gridDim.x * PML_WAVES_PER_BLOCK * UW;
     int idx = (blockIdx.x * PML_WAVES_PER_BLOCK + wave) * UW + sub;
-    SuperRegs cur = load_super(units, idx < n_level ? idx : 0);
-    for (int base = idx - sub; base < n_level; base += stride) {
+    SuperRegs cur = load_super(units, idx < n_units ? idx >> 1 : 0);
+    for (int base = idx - sub; base < n_units; base += stride) {
         const int nxt_idx = idx + stride;
-        const SuperRegs nxt = load_super(units, nxt_idx < n_level ? nxt_idx : 0);
-        if (idx < n_level) td_f81_super_unit<G, R>(L, t, c, st, cur);
+        const SuperRegs nxt = load_super(units, nxt_idx < n_units ? nxt_idx >> 1 : 0);
+        if (idx < n_units) td_f81_super_unit<G, R>(L, t, c, st, cur, idx & 1);
         cur = nxt;
         idx = nxt_idx;
     }
