@@ -142,13 +142,52 @@ def cpu_baseline(k, levels, model, cores=None):
 # ---------------------------------------------------------------------------------------------------------------------
 # compulsory HBM bytes of THIS schedule, per column and sweep
 # ---------------------------------------------------------------------------------------------------------------------
+def two_level_nodes(flat, k, n_cols):
+    """
+    The nodes the library's level schedule runs as two-level units (pml_tree_upload): stored nodes with two
+    stored children that each carry two cherries of two tips, ids of the four cherries and of the eight tips consecutive;
+    only for lane groups of 8 and more (29 <= k <= 64), where they are at least 64 and a sixteenth of the stored nodes,
+    and only where the sweeps run level launches (not one launch per sweep, not subtree blocks).  Returns a boolean
+    array over the nodes (empty selection if the schedule does not apply).
+    """
+    N = flat.n_nodes
+    nc = np.asarray(flat.n_children)
+    fc = np.asarray(flat.first_child)
+    parent = np.asarray(flat.parent)
+    sup = np.zeros(N, dtype=bool)
+    if not 29 <= k <= 64 or os.environ.get('PASTML_HIP_NO_SUPER'):
+        return sup
+    internal = nc > 0
+    tip = ~internal
+    n_tip_children = np.zeros(N, dtype=np.int64)
+    np.add.at(n_tip_children, parent[(parent >= 0) & tip], 1)
+    cherry = internal & (n_tip_children == nc) & (parent >= 0)
+    stored = internal & ~cherry
+    n_stored = int(stored.sum())
+    if N <= 2048 or (256 < n_stored <= 131072 and n_stored * n_cols <= 160000):
+        return sup
+    two = np.flatnonzero(stored & (nc == 2))
+    a = fc[two]
+    ok = cherry[a] & cherry[a + 1] & (nc[a] == 2) & (nc[a + 1] == 2) & (fc[a + 1] == fc[a] + 2)
+    pair = np.zeros(N, dtype=bool)
+    pair[two[ok]] = True
+    ok = pair[a] & pair[a + 1]
+    cand, a = two[ok], a[ok]
+    ok = (fc[a + 1] == fc[a] + 2) & (fc[fc[a + 1]] == fc[fc[a]] + 4)
+    sup[cand[ok]] = True
+    if sup.sum() < 64 or sup.sum() * 16 < n_stored:
+        sup[:] = False
+    return sup
+
+
 def schedule_bytes(flat, k, n_cols, narrow_limit=None):
     """
     Bytes the F81-family kernels must move per sweep for one column, from the tree itself: only *stored* internal
     nodes (internal nodes that are not cherries; roots always) have a bottom-up vector in HBM, tips are 8-byte masks,
     cherries are rebuilt in registers, top-down vectors are never written, every node's posterior is written once.
-    Returns per-sweep totals and the part moved by the level kernels alone (the launches the HIP-event brackets and
-    rocprofv3 see under the kernel's name; the few levels next to the roots run in one single-workgroup launch).
+    Two-level units (two_level_nodes): the two children of such a node have no bottom-up vector in HBM either, and their
+    posterior rows are not read back.  Returns per-sweep totals and the parts of the level kernels and of the two-level
+    launches.
     """
     ks = k + (k & 1) if k >= 2 else k
     W = (k + 63) // 64
@@ -164,33 +203,51 @@ def schedule_bytes(flat, k, n_cols, narrow_limit=None):
     np.add.at(n_tip_children, parent[(parent >= 0) & tip], 1)
     cherry = internal & (n_tip_children == nc) & (parent >= 0)
     stored = internal & ~cherry
+    sup = two_level_nodes(flat, k, n_cols)
+    n_sup = int(sup.sum())
+    gone = sup.copy()                                   # nodes that are not units of the level lists any more
+    gone[fc[sup]] = True
+    gone[fc[sup] + 1] = True
+    unit = stored & ~gone                               # units of the level kernels
     nonroot = parent >= 0
     pmask = np.zeros(N, dtype=bool)
-    pmask[nonroot] = stored[parent[nonroot]]            # node is a child of a stored node
+    pmask[nonroot] = unit[parent[nonroot]]              # node is a child of a level-kernel unit
+    gp = np.where(nonroot, parent, 0)
     cmask = np.zeros(N, dtype=bool)
-    cmask[nonroot] = cherry[parent[nonroot]]            # node is a tip of a cherry
-    n_stored = int(stored.sum())
+    cmask[nonroot] = cherry[parent[nonroot]] & pmask[gp[nonroot]]   # tip of a cherry child of a level-kernel unit
+    n_units = int(unit.sum())
     ch_stored = int((pmask & stored).sum())
     ch_cherry = int((pmask & cherry).sum())
     ch_tip = int((pmask & tip).sum())
     tips_of_cherries = int(cmask.sum())
-    n_children_of_stored = ch_stored + ch_cherry + ch_tip
-    # bottom-up, per stored node: descriptor 32; per child E, mask, S, exponent (32); stored child's vector; per tip of
+    n_children_of_units = ch_stored + ch_cherry + ch_tip
+    # bottom-up, per unit: descriptor 32; per child E, mask, S, exponent (32); stored child's vector; per tip of
     # a cherry child E, mask, S (24); writes: vector, S, exponent; S + exponent of every cherry child (16)
-    bu = n_stored * (32 + vec + 16) + n_children_of_stored * 32 + ch_stored * vec + tips_of_cherries * 24 + ch_cherry * 16
-    # top-down, per stored parent: descriptor 32, its posterior + sum + exponent (vec + 16); per child the same gather
+    bu_levels = n_units * (32 + vec + 16) + n_children_of_units * 32 + ch_stored * vec + tips_of_cherries * 24 + ch_cherry * 16
+    # top-down, per unit: descriptor 32, its posterior + sum + exponent (vec + 16); per child the same gather
     # (32) + posterior, sum, exponent written (vec + 16); stored child: its bottom-up vector; tips of cherry children:
     # gather 24 + posterior, sum, exponent written
-    td = n_stored * (32 + vec + 16) + n_children_of_stored * (32 + vec + 16) + ch_stored * vec \
+    td_levels = n_units * (32 + vec + 16) + n_children_of_units * (32 + vec + 16) + ch_stored * vec \
         + tips_of_cherries * (24 + vec + 16)
+    # two-level unit, bottom-up: descriptor 32; E + mask of the two children (32), own mask (8); per child its two
+    # cherries' E and mask (32) and its four tips' E, mask, S (96); writes: pi . v of the four cherries (32), pi . v +
+    # exponent of the two children (32), the node's vector, pi . v, exponent (vec + 16)
+    bu_two = n_sup * (32 + 32 + 8 + 2 * (32 + 96) + 32 + 32 + vec + 16)
+    # top-down: one unit per child.  Shared by the two: descriptor 32, the node's row, sum, exponent (vec + 16); per
+    # child: E, S, mask, exponent (32), its cherries' E, S, mask (48), its tips' E, S, mask (96); writes 7 rows with sum
+    # and exponent (the child, two cherries, four tips)
+    td_two = n_sup * (32 + vec + 16) + 2 * n_sup * (32 + 48 + 96 + 7 * (vec + 16))
+    bu, td = bu_levels + bu_two, td_levels + td_two
     # per-branch data: dist in (8, read once per chunk of columns a thread walks: run_prep's cpy), E out (8); tips: mask
     # in (8 W), S out (8)
     cpy, bx = 1, (N + 255) // 256
     while cpy < 8 and cpy * 2 <= n_cols and bx * ((n_cols + 2 * cpy - 1) // (2 * cpy)) >= 4096:
         cpy *= 2
     prep = N * (8 + 8.0 / cpy) + int(tip.sum()) * (8 * W + 8)
-    return dict(bottom_up=bu, top_down=td, prep=prep, total=bu + td + prep, vec_bytes=vec, n_stored=n_stored,
-                n_cherries=int(cherry.sum()), n_tips=int(tip.sum()),
+    return dict(bottom_up=bu, top_down=td, prep=prep, total=bu + td + prep, vec_bytes=vec, n_stored=int(stored.sum()),
+                n_cherries=int(cherry.sum()), n_tips=int(tip.sum()), n_two_level=n_sup,
+                bottom_up_levels=bu_levels, bottom_up_two_level=bu_two, top_down_levels=td_levels,
+                top_down_two_level=td_two,
                 per_unit=dict(bottom_up=bu / (N * k), top_down=td / (N * k), prep=prep / (N * k)))
 
 
@@ -556,7 +613,7 @@ def main():
     for _ in range(args.warmup):
         step()
     eng.profile_enable(not args.no_kernel_timing)
-    for w in (0, 1, 2):
+    for w in range(5):
         eng.profile_read(w, reset=True)
     fence()
     t0 = time.perf_counter()
@@ -567,9 +624,15 @@ def main():
     dt = time.perf_counter() - t0
     dt = float(comm.allreduce([dt], op='max')[0])
 
-    bu_ms, bu_launches = eng.profile_read(0)
-    td_ms, td_launches = eng.profile_read(1)
+    # kernel time by HIP events on the library's stream: the level kernels' launches of the two sweeps (0, 1), the
+    # per-branch pass (2), the launches of the two-level units (3 top-down, 4 bottom-up)
+    bul_ms, bul_launches = eng.profile_read(0)
+    tdl_ms, tdl_launches = eng.profile_read(1)
     prep_ms, prep_launches = eng.profile_read(2)
+    td2_ms, td2_launches = eng.profile_read(3)
+    bu2_ms, bu2_launches = eng.profile_read(4)
+    bu_ms, bu_launches = bul_ms + bu2_ms, bul_launches + bu2_launches
+    td_ms, td_launches = tdl_ms + td2_ms, tdl_launches + td2_launches
     eng.profile_enable(False)
     held, free = eng.memory()
     # A check that fails on one rank must not leave the others waiting in the closing collective: failures are collected,
@@ -593,11 +656,24 @@ def main():
             return b * args.steps / (ms * 1e-3) / 1e9 if ms > 0 else None
         td_gbs, bu_gbs, prep_gbs = rate(per_step['top_down'], td_ms), rate(per_step['bottom_up'], bu_ms), \
             rate(per_step['prep'], prep_ms)
+        # The dominant kernel.  With two-level units (the balanced tree of this workload) it is td_f81_super_kernel: ONE
+        # launch per step that finishes the children of every two-level node, their cherries and their tips -- 7 of every
+        # 8 posterior rows of the table.  Without them: the level kernel td_f81_kernel, averaged over its launches.
+        two_level = td2_launches > 0
+        if two_level:
+            dom = dict(name='td_f81_super_kernel (top-down + marginals + posteriors below the two-level nodes: their '
+                            'children, those children\'s cherries and tips -- one launch per step)',
+                       key='td_two_level_bytes_per_step', model=sb['top_down_two_level'] * cpg, ms=td2_ms,
+                       launches=td2_launches)
+        else:
+            dom = dict(name='td_f81_kernel (top-down + marginals + posteriors, one launch per depth level)',
+                       key='td_bytes_per_step', model=per_step['top_down'], ms=td_ms, launches=td_launches)
+        dom_gbs = rate(dom['model'], dom['ms'])
         # HBM bytes per launch from the committed PMC passes: only if they were measured on these kernel sources and
         # this workload shape; bench asserts that counters and model agree
         traffic = traffic_note = None
         tpath = os.path.join(REPO, 'profiles', 'traffic.json')
-        if os.path.exists(tpath) and td_launches > 0:
+        if os.path.exists(tpath) and dom['launches'] > 0:
             try:
                 tj = json.load(open(tpath))
                 entry = tj.get(args.workload, {})
@@ -607,16 +683,16 @@ def main():
                 elif entry.get('chars_per_gpu') != cpg:
                     traffic_note = 'profiles/traffic.json is for {} characters per GPU'.format(entry.get('chars_per_gpu'))
                 else:
-                    traffic = entry['td_bytes_per_step'] / (td_launches / args.steps)
-                    ratio = entry['td_bytes_per_step'] / per_step['top_down']
+                    traffic = entry[dom['key']] / (dom['launches'] / args.steps)
+                    ratio = entry[dom['key']] / dom['model']
                     traffic_note = 'PMC bytes / model bytes = {:.3f}'.format(ratio)
                     if not 0.85 <= ratio <= 1.15:
-                        failure = failure or ('HBM counters ({:.3g} B per step) and the byte model ({:.3g}) of '
-                                              'td_f81_kernel disagree by more than 15 %'
-                                              .format(entry['td_bytes_per_step'], per_step['top_down']))
-            except (OSError, ValueError, KeyError) as e:
+                        failure = failure or ('HBM counters ({:.3g} B per step) and the byte model ({:.3g}) of the '
+                                              'dominant kernel disagree by more than 15 %'
+                                              .format(entry[dom['key']], dom['model']))
+            except (OSError, ValueError, KeyError, TypeError) as e:
                 traffic_note = 'profiles/traffic.json unreadable: {}'.format(e)
-        avg_launch_s = td_ms / max(1, td_launches) * 1e-3
+        avg_launch_s = dom['ms'] / max(1, dom['launches']) * 1e-3
         out = {
             'metric': 'ACR nodes*states*chars/sec (full marginal pass: P(t) + bottom-up + top-down + posteriors)',
             'value': value,
@@ -641,26 +717,39 @@ def main():
                        'collective': comm.name},
             'loglik_sum': total,
             'roofline': {
-                'bound': 'hbm', 'kernel': 'td_f81_kernel (top-down + marginals + posteriors, one launch per depth level)',
-                'achieved': td_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': (td_gbs / HBM_PEAK_GBS) if td_gbs else None,
+                'bound': 'hbm', 'kernel': dom['name'],
+                'achieved': dom_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': (dom_gbs / HBM_PEAK_GBS) if dom_gbs else None,
                 'traffic': traffic, 'traffic_note': traffic_note,
-                'traffic_gbs': (traffic / avg_launch_s / 1e9) if traffic and td_ms > 0 else None,
-                'model_bytes_per_launch': per_step['top_down'] / max(1, td_launches / args.steps),
-                'model_bytes_per_unit': sb['per_unit']['top_down'],
-                'avg_launch_ms': td_ms / max(1, td_launches),
-                'launches': td_launches,
+                'traffic_gbs': (traffic / avg_launch_s / 1e9) if traffic and dom['ms'] > 0 else None,
+                'model_bytes_per_launch': dom['model'] / max(1, dom['launches'] / args.steps),
+                'model_bytes_per_unit': dom['model'] / cpg / (N * k),
+                'avg_launch_ms': dom['ms'] / max(1, dom['launches']),
+                'launches': dom['launches'],
                 'byte_model': 'compulsory bytes of this schedule (DESIGN.md 4b): posterior written for every node, '
                               'parent posterior + stored child vector read for stored (non-cherry) internal nodes only, '
-                              'per-node scalars; tips are 8-byte masks, cherries live in registers, TD vectors are never stored',
+                              'per-node scalars; tips are 8-byte masks, cherries and the children of two-level nodes live '
+                              'in registers, TD vectors are never stored',
                 'reference_schedule_bytes_avoided': (REFERENCE_SCHEDULE_BYTES['top_down'] * N * k * cpg
                                                      - per_step['top_down']),
             },
+            'roofline_top_down': {
+                'kernel': 'whole top-down sweep: td_f81_kernel (one launch per depth level)'
+                          + (' + td_f81_super_kernel (one launch)' if two_level else ''),
+                'achieved': td_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': (td_gbs / HBM_PEAK_GBS) if td_gbs else None, 'launches': td_launches,
+                'model_bytes_per_unit': sb['per_unit']['top_down'],
+                'level_kernel_ms_per_step': tdl_ms / args.steps, 'two_level_ms_per_step': td2_ms / args.steps,
+            },
             'roofline_bottom_up': {
-                'kernel': 'bu_f81_kernel (bottom-up, one launch per height level)', 'achieved': bu_gbs,
+                'kernel': 'whole bottom-up sweep: bu_f81_kernel (one launch per height level)'
+                          + (' + bu_f81_super_kernel (one launch)' if two_level else ''),
+                'achieved': bu_gbs,
                 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': (bu_gbs / HBM_PEAK_GBS) if bu_gbs else None,
                 'avg_launch_ms': bu_ms / max(1, bu_launches), 'launches': bu_launches,
                 'model_bytes_per_unit': sb['per_unit']['bottom_up'],
+                'level_kernel_ms_per_step': bul_ms / args.steps, 'two_level_ms_per_step': bu2_ms / args.steps,
+                'two_level_gbs': rate(sb['bottom_up_two_level'] * cpg, bu2_ms),
                 'reference_schedule_bytes_avoided': (REFERENCE_SCHEDULE_BYTES['bottom_up'] * N * k * cpg
                                                      - per_step['bottom_up']),
             },
