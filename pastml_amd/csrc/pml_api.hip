@@ -677,7 +677,10 @@ static int dispatch_sweep(pml_ctx* ctx, SweepKind what, const int* level, int n_
         // Fused bottom-up levels, 32 < k <= 64 (measured on cfg4): 8 states per lane (8 units per wavefront share the
         // per-unit scalar work) wins on the level that rebuilds cherries (1.80 -> 1.58 ms) and on small levels;
         // 4 states per lane (twice the loads in flight per unit) wins on big levels that stream stored vectors.
-        if (ctx->bu_wide_lanes && (what == SW_BU_MARG_FUSED_NOVEC || (what == SW_BU_MARG_FUSED && n_level <= 65536))) {
+        // (SW_BU_CHERRIES rewrites pi . v of the cherries, which the level that rebuilds them has stored: same shape, or
+        // a download of the bottom-up vectors would change the last bit of what a later top-down sweep reads)
+        if (ctx->bu_wide_lanes && (what == SW_BU_MARG_FUSED_NOVEC || what == SW_BU_CHERRIES ||
+                                   (what == SW_BU_MARG_FUSED && n_level <= 65536))) {
             g = 8;
             r = 8;
         }
@@ -1423,7 +1426,9 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
             const char* env_min = getenv("PASTML_HIP_SUPER_MIN");
             const int min_units = env_min ? atoi(env_min) : 64;
             // (a launch of its own per sweep: only where it carries a share of the work)
-            if ((int)sup_list.size() >= min_units && (long long)sup_list.size() * 16 >= n_stored) {
+            // (PASTML_HIP_SUPER_MIN given: whatever their share, for tests on ragged forests)
+            if (!sup_list.empty() && (int)sup_list.size() >= min_units &&
+                (env_min != nullptr || (long long)sup_list.size() * 16 >= n_stored)) {
                 std::vector<PmlUnit> us(sup_list.size());
                 for (size_t q = 0; q < sup_list.size(); ++q) {
                     const int n = sup_list[q];

@@ -1043,3 +1043,111 @@ def test_full_mask_pair_waves_match_the_oracle(k):
         np.testing.assert_allclose(lnl[0], ref['loglik'], rtol=LNL_RTOL)
         np.testing.assert_allclose(post[0], ref['posterior'], rtol=1e-9, atol=1e-300)
         assert_same_scaled(bu[internal], bu_sf[internal], ref['bu'][internal], ref['bu_sf'][internal], what='BU')
+
+
+def _forest_with_balanced_clumps(n_leaves, seed, clump_frac=0.5):
+    """A random binary forest where a share of the leaves is replaced by perfectly balanced 8-tip subtrees (the shape
+    the two-level units take: a node with two children that each carry two cherries of two tips)."""
+    from pastml_amd.tree import TreeNode
+    rng = np.random.default_rng(seed)
+    roots = []
+    for _ in range(2):
+        root = TreeNode(name='', dist=0.0)
+        leaves = [root]
+        while len(leaves) < n_leaves // 2:
+            leaf = leaves.pop(int(rng.integers(len(leaves))))
+            for _c in range(2 if rng.random() < 0.9 else 3):
+                leaves.append(leaf.add_child(dist=float(rng.uniform(0.001, 0.3))))
+        for leaf in leaves:
+            if rng.random() < clump_frac:
+                level = [leaf]
+                for _d in range(3):
+                    level = [n.add_child(dist=float(rng.uniform(0.001, 0.3))) for n in level for _c in range(2)]
+        roots.append(root)
+    for ti, root in enumerate(roots):
+        for i, n in enumerate(root.traverse('preorder')):
+            n.name = 't{}_{}'.format(ti, i) if n.is_leaf() else 'n{}_{}'.format(ti, i)
+    return FlatForest.from_trees(roots)
+
+
+@pytest.mark.parametrize('k', [29, 32, 40, 64])
+def test_two_level_units_give_the_bits_of_the_level_schedule(k, monkeypatch):
+    """
+    Level schedule of large forests, lane groups of 8 and more: nodes with two stored children that each carry two
+    cherries of two tips run as two-level units (their children's bottom-up vectors are never written, their posterior
+    rows are not read back).  Against the same library with PASTML_HIP_NO_SUPER=1 -- bit for bit: ln L, posteriors,
+    sums, scales, the bottom-up vectors a download materialises, the top-down vectors of PML_OPT_KEEP_TD -- on a
+    balanced tree (every node of the two levels is taken over) and on a ragged forest with balanced clumps (both kinds
+    of units, thin rest levels), with unobserved and ambiguous tips and restricted internal nodes (the bodies with masks)
+    and with every state allowed (the straight-line bodies); k = 40 has padding states.
+    """
+    monkeypatch.setenv('PASTML_HIP_BLOCK_NODES', '0')       # level launches, not subtree blocks
+    monkeypatch.setenv('PASTML_HIP_SMALL_MANY_NODES', '0')
+    monkeypatch.setenv('PASTML_HIP_SUPER_MIN', '1')
+    rng = np.random.default_rng(900 + k)
+    forests = [synthetic.balanced_forest(12), _forest_with_balanced_clumps(700, seed=k)]
+    for fi, flat in enumerate(forests):
+        C = 3
+        specs = [(random_spec('F81', k, rng), (float(rng.uniform(0.5, 3)), 0.0, 1.0)) for _ in range(C)]
+        masks = np.stack([random_masks(flat, k, rng, missing=0.05, multi=0.05, internal=0.02) for _ in range(C)])
+        # column 0: observed tips, every internal state allowed (the full-mask bodies wherever a wave is uniform)
+        masks[0] = synthetic.one_hot_masks(flat, k, rng.integers(0, k, size=flat.n_tips))
+        results = []
+        for no_super in (True, False):
+            if no_super:
+                monkeypatch.setenv('PASTML_HIP_NO_SUPER', '1')
+            else:
+                monkeypatch.delenv('PASTML_HIP_NO_SUPER', raising=False)
+            with hip.Engine(flat, C, k) as eng:
+                eng.set_models(specs)
+                eng.set_masks(masks)
+                lnl, post, lh_sum, lh_sf = eng.marginal_pass()
+                again = eng.bottom_up(True)
+                assert np.array_equal(lnl, again)
+                bu = [eng.download(hip.BUF_BU, c) for c in range(C)]
+                bu_sf = [eng.download(hip.BUF_BU_SF, c) for c in range(C)]
+                post2, lh_sum2, lh_sf2 = eng.top_down_marginals()    # after the download's materialisation
+                assert np.array_equal(post, post2) and np.array_equal(lh_sum, lh_sum2)
+                td = eng.download(hip.BUF_TD, 1)
+                td_sf = eng.download(hip.BUF_TD_SF, 1)
+            results.append((lnl, post, lh_sum, lh_sf, np.stack(bu), np.stack(bu_sf), td, td_sf))
+        assert np.isfinite(results[0][1]).all()
+        for a, b in zip(results[0], results[1]):
+            assert np.array_equal(a, b), 'forest {}'.format(fi)
+        # and the numbers are right: column 1 against the oracle
+        ref = orc.bottom_up(flat, masks[1].astype(int), specs[1][0], *specs[1][1])
+        np.testing.assert_allclose(results[1][0][1], ref['loglik'], rtol=LNL_RTOL)
+
+
+def test_two_level_units_report_the_reference_pair_on_zero_likelihood(monkeypatch):
+    """A child of a two-level node whose vector comes out all zero: the unit falls back to the sequential path, which
+    names the pair the reference would (the same pair as without two-level units)."""
+    monkeypatch.setenv('PASTML_HIP_BLOCK_NODES', '0')
+    monkeypatch.setenv('PASTML_HIP_SMALL_MANY_NODES', '0')
+    monkeypatch.setenv('PASTML_HIP_SUPER_MIN', '1')
+    k = 64
+    flat = synthetic.balanced_forest(12)
+    rng = np.random.default_rng(5)
+    spec = (random_spec('F81', k, rng), (1.0, 0.0, 1.0))
+    masks = synthetic.one_hot_masks(flat, k, rng.integers(0, k, size=flat.n_tips))
+    bad = masks.copy()
+    # an internal node two levels above the tips that allows a single state none of whose ... no: make it impossible
+    # outright: its mask is empty
+    node = int(flat.parent[flat.parent[flat.tips[777]]])
+    bad[node] = 0
+    out = []
+    for no_super in (True, False):
+        if no_super:
+            monkeypatch.setenv('PASTML_HIP_NO_SUPER', '1')
+        else:
+            monkeypatch.delenv('PASTML_HIP_NO_SUPER', raising=False)
+        with hip.Engine(flat, 2, k) as eng:
+            eng.set_models([spec, spec])
+            eng.set_masks(np.stack([masks, bad]))
+            with pytest.raises(hip.ZeroLikelihoodError) as e:
+                eng.bottom_up(True)
+            out.append((int(e.value.err_parent[0]), int(e.value.err_child[0]), int(e.value.err_parent[1]),
+                        int(e.value.err_child[1])))
+    assert out[0][:2] == (-1, -1)
+    assert out[0][2] == node
+    assert out[0] == out[1]
