@@ -65,7 +65,9 @@ int pml_ctx_sync(pml_ctx* ctx);
 /*
  * Options (set before pml_tree_upload).  PML_OPT_CHERRY_FUSION (default 1): in the F81-family marginal sweeps,
  * internal nodes whose children are all tips are recomputed in registers instead of being stored in HBM (their
- * vectors, like the top-down vectors of tips, are computed when pml_download asks for them).
+ * vectors, like the top-down vectors of tips, are computed when pml_download asks for them).  With it, on large
+ * forests and 29 <= k <= 64, nodes with two stored children that each carry two cherries of two tips run as two-level
+ * units: their children's bottom-up vectors are not stored either, same rule for downloads.
  * PML_OPT_KEEP_TD (default 0, may be changed at any time): the F81-family top-down sweep works from the stored
  * posteriors of the level above (TD o BU = posterior * sum / pi) and does not write the top-down vectors themselves;
  * with this option it stores them too.  pml_download(PML_BUF_TD / PML_BUF_TD_SF) repeats the sweep with the stores on
@@ -250,7 +252,8 @@ int pml_timer_stop(pml_ctx* ctx, float* milliseconds);
  * Kernel-time accounting with HIP events on the ctx's stream (the stream the kernels are launched on).
  * While enabled, every pml_bottom_up / pml_top_down_marginals / pml_pij_batch call brackets its level-kernel
  * launches with an event pair and adds the elapsed time to an accumulator.
- * which: 0 = bottom-up level kernels, 1 = top-down level kernels, 2 = P(t) / prep kernels.
+ * which: 0 = bottom-up level kernels, 1 = top-down level kernels, 2 = P(t) / prep kernels, 3 = the top-down launch of
+ * the two-level units, 4 = their bottom-up launch (F81 family, level schedule of large forests; zero elsewhere).
  * launches counts kernel launches.  reset != 0 clears the accumulator after reading.
  */
 int pml_profile_enable(pml_ctx* ctx, int on);
