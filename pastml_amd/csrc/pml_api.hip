@@ -75,6 +75,7 @@ struct pml_ctx {
     int *d_bu_offsets = nullptr, *d_td_offsets = nullptr;  // level tables on the device (narrow end in one launch)
     int n_tips = 0;
     double* d_msg = nullptr;  // fused eigen sweeps: messages of the bottom-up sweep
+    int *d_tip_rest = nullptr, *d_tip_rest_count = nullptr;  // eigen joint sweep: [C][n_tips] tips that are not observed, [C]
     double* d_dist = nullptr;
     std::vector<int> bu_offsets, td_offsets, td_parent_offsets, h_parent, h_n_children;
     // cherry fusion (F81 marginal sweeps): node kinds and level lists over the stored internal nodes only
@@ -955,10 +956,23 @@ static int launch_eigen_joint_tips(pml_ctx* ctx) {
     static const int cap_all = getenv("PASTML_HIP_EIGJ_TIP_BLOCKS") ? atoi(getenv("PASTML_HIP_EIGJ_TIP_BLOCKS")) : 2048;
     const int cap = std::max(8, cap_all / std::max(1, ctx->C));
     if (blocks > cap) blocks = cap;
+    // observed tips in the lean kernel; what it leaves on the columns' lists (tips with several or all states allowed)
+    // in one launch of the general kernel -- PASTML_HIP_EIGJ_ONE_TIPS_KERNEL: everything in the general kernel (round 2)
+    static const bool one_kernel = getenv("PASTML_HIP_EIGJ_ONE_TIPS_KERNEL") != nullptr;
+    const int rest_blocks = std::min(blocks, std::max(8, 1024 / std::max(1, ctx->C)));
 #define PML_EIGJ_TIPS(KU_)                                                                                          \
     if (KU == KU_) {                                                                                                \
-        hipLaunchKernelGGL((eigen_joint_tips_kernel<KU_>), dim3(blocks, ctx->C), dim3(PML_BLOCK), 0, ctx->stream,   \
-                           t, c, m, st, ctx->d_AinvT, ctx->d_tips, ctx->n_tips);                                    \
+        if (one_kernel) {                                                                                           \
+            hipLaunchKernelGGL((eigen_joint_tips_kernel<KU_>), dim3(blocks, ctx->C), dim3(PML_BLOCK), 0,            \
+                               ctx->stream, t, c, m, st, ctx->d_AinvT, ctx->d_tips, ctx->n_tips, nullptr);          \
+        } else {                                                                                                    \
+            hipLaunchKernelGGL((eigen_joint_obs_tips_kernel<KU_>), dim3(blocks, ctx->C), dim3(PML_BLOCK), 0,        \
+                               ctx->stream, t, c, m, st, ctx->d_AinvT, ctx->d_tips, ctx->n_tips, ctx->d_tip_rest,   \
+                               ctx->d_tip_rest_count);                                                              \
+            hipLaunchKernelGGL((eigen_joint_tips_kernel<KU_>), dim3(rest_blocks, ctx->C), dim3(PML_BLOCK), 0,       \
+                               ctx->stream, t, c, m, st, ctx->d_AinvT, ctx->d_tip_rest, ctx->n_tips,                \
+                               ctx->d_tip_rest_count);                                                              \
+        }                                                                                                           \
         HIP_TRY(hipGetLastError());                                                                                 \
         return PML_OK;                                                                                              \
     }
@@ -2096,7 +2110,8 @@ static int enqueue_bottom_up(pml_ctx* ctx, int is_marginal, bool small_path, boo
     const bool gemm = is_marginal && eigen_gemm(ctx);
     const bool eigj = !is_marginal && eigen_joint_valu(ctx);
     if (!small_path) {  // the single-launch kernel resets the error words itself
-        hipLaunchKernelGGL(reset_err_kernel, dim3((ctx->C + 63) / 64), dim3(64), 0, ctx->stream, ctx->d_err, ctx->C);
+        hipLaunchKernelGGL(reset_err_kernel, dim3((ctx->C + 63) / 64), dim3(64), 0, ctx->stream, ctx->d_err, ctx->C,
+                           eigj ? ctx->d_tip_rest_count : nullptr);
         HIP_TRY(hipGetLastError());
         // the fused eigen sweeps build P(t) themselves, the two-GEMM sweeps never need it
         if (!eig && !gemm && !eigj && !hky_fused(ctx)) PML_TRY(run_prep(ctx, force_prep));
@@ -2271,6 +2286,10 @@ static int submit_bottom_up(pml_ctx* ctx, int is_marginal) {
                       hky_fused(ctx);
     if (eigen_fused(ctx) || eigen_gemm(ctx) || eigen_joint_valu(ctx)) {
         if (!ctx->d_msg) PML_TRY(dev_alloc(ctx, &ctx->d_msg, CN * ctx->ks));
+    }
+    if (!is_marginal && eigen_joint_valu(ctx) && !ctx->d_tip_rest) {
+        PML_TRY(dev_alloc(ctx, &ctx->d_tip_rest, (size_t)ctx->C * std::max(1, ctx->n_tips)));
+        PML_TRY(dev_alloc(ctx, &ctx->d_tip_rest_count, (size_t)ctx->C));
     }
     if (!no_p) PML_TRY(ensure_transition_storage(ctx));
     ctx->bu_mode = -1;

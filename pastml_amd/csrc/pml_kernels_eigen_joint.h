@@ -247,7 +247,15 @@ __global__ void PML_EIGJ_ATTR eigen_joint_narrow_kernel(PmlTree t, PmlCols c, Pm
 template <int KU>
 __global__ void PML_EIGJ_ATTR eigen_joint_tips_kernel(PmlTree t, PmlCols c, PmlModel m, PmlState st,
                                                       const double* __restrict__ ainvT,
-                                                      const int* __restrict__ tip_ids, int n_tips) {
+                                                      const int* __restrict__ tip_ids, int n_tips,
+                                                      const int* __restrict__ n_listed) {
+    // (n_listed: the launch serves the list eigen_joint_obs_tips_kernel left for this column -- tip_ids is that list,
+    // n_tips its stride -- and most of the time there is nothing on it)
+    if (n_listed != nullptr) {
+        tip_ids += (size_t)blockIdx.y * n_tips;
+        n_tips = min(n_tips, n_listed[blockIdx.y]);
+        if (n_tips <= 0) return;
+    }
     constexpr int AS = PML_EIGJ_ASTRIDE(KU);
     __shared__ double smem[PML_EIGJ_LDS(KU) + 32 * AS + PML_WAVES_PER_BLOCK * PML_EIGJ_CHUNK_LDS];
     EigJWave<KU> W;
@@ -341,6 +349,127 @@ __global__ void PML_EIGJ_ATTR eigen_joint_tips_kernel(PmlTree t, PmlCols c, PmlM
                 }
         }
         wave_lds_sync();
+        }
+        wave_lds_sync();  // the chunk has been consumed before the next one overwrites it
+    }
+}
+
+// Observed tips only, lean (round 3).  The kernel above carries the general pass inline (its registers: 4 waves per
+// SIMD) and reads three LDS operands per FMA -- A[i][m], exp(d_m t), Ainv[m][s] -- which is what bounded it (44 us for
+// cfg3's 262 144 tips: the LDS pipe, not the FMAs).  Here row i of A sits in the lane's registers and the other two
+// operands are folded before the sum: lane m forms w[m] = exp(d_m t) Ainv[m][s] (one exponential and one
+// multiplication per lane, as before) and leaves it in LDS; the lane's P[i][s] = sum_m A[i][m] w[m] is then k FMAs
+// against k / 2 16-byte LDS reads that all lanes of a tip share.  (Rounding: A (e Ainv) instead of (A e) Ainv -- the
+// reference's own P(t) is numpy's A.dot(diag).dot(Ainv), neither order; ln L of cfg3 agrees to 1e-13.)  Tips that are
+// not observed go on a list (per column; order irrelevant, every tip is independent) that one launch of the general
+// kernel serves afterwards.
+template <int KU>
+__global__ void __launch_bounds__(PML_BLOCK) eigen_joint_obs_tips_kernel(PmlTree t, PmlCols c, PmlModel m, PmlState st,
+                                                                          const double* __restrict__ ainvT,
+                                                                          const int* __restrict__ tip_ids, int n_tips,
+                                                                          int* __restrict__ rest_list,
+                                                                          int* __restrict__ rest_count) {
+    constexpr int AS = PML_EIGJ_ASTRIDE(KU);
+    __shared__ double smem[32 * AS + PML_WAVES_PER_BLOCK * (128 + PML_EIGJ_CHUNK_LDS)];
+    const int k = c.k, ks = c.ks;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = blockIdx.y;
+    const size_t colN = (size_t)col * t.N;
+    const int npw = 64 / k;
+    const int b0 = lane / k;
+    const bool lane_ok = b0 < npw;
+    const int b = lane_ok ? b0 : npw - 1;
+    const int i = lane_ok ? lane - b0 * k : 0;
+    double a[KU];
+    {
+        const double* gA = m.A + (size_t)col * k * k + (size_t)i * k;
+#pragma unroll
+        for (int mm = 0; mm < KU; ++mm) a[mm] = (lane_ok && mm < k) ? gA[mm] : 0.0;
+    }
+    const double d_i = m.d[(size_t)col * k + i];
+    const double sfc = m.sf[col], tau = m.tau[col], tf = m.tauf[col];
+    double* sT = smem;  // sT[j * AS + m] = Ainv[m][j]
+    {
+        const double* g = ainvT + (size_t)col * PML_EIGJ_STRIDE * PML_EIGJ_STRIDE;
+        for (int e = threadIdx.x; e < k * AS; e += blockDim.x) {
+            const int r = e / AS, q = e % AS;
+            sT[e] = q < KU ? g[r * PML_EIGJ_STRIDE + q] : 0.0;
+        }
+    }
+    double* sW = smem + 32 * AS + wave * (128 + PML_EIGJ_CHUNK_LDS);
+    for (int e = lane; e < 128; e += 64) sW[e] = 0.0;  // the padding entries (m >= k) stay zero
+    double* sTq = sW + 128;
+    u64* sWord = reinterpret_cast<u64*>(sTq + 64);
+    int* sTip = reinterpret_cast<int*>(sWord + 64);
+    __syncthreads();
+    const u64 kbits = k >= 64 ? ~0ull : (1ull << k) - 1ull;
+    const int waves_total = gridDim.x * PML_WAVES_PER_BLOCK;
+    const int slot = b * KU;
+    const int passes_total = (n_tips + npw - 1) / npw;
+    int cp = (passes_total + waves_total - 1) / waves_total;
+    if (cp > 64 / npw) cp = 64 / npw;
+    const int chunk = cp * npw;
+    for (int c0 = (blockIdx.x * PML_WAVES_PER_BLOCK + wave) * chunk; c0 < n_tips; c0 += waves_total * chunk) {
+        {
+            int tip_l = -1;
+            u64 word_l = 0ull;
+            double tq_l = 0.0;
+            if (lane < chunk && c0 + lane < n_tips) {
+                tip_l = tip_ids[c0 + lane];
+                word_l = c.masks[colN + tip_l] & kbits;
+                tq_l = (t.dist[tip_l] + tau) * tf * sfc;
+                if (__popcll(word_l) != 1) {  // not observed: for the general kernel
+                    rest_list[(size_t)col * n_tips + atomicAdd(&rest_count[col], 1)] = tip_l;
+                    tip_l = -1;
+                }
+            }
+            sTip[lane] = tip_l;
+            sWord[lane] = word_l;
+            sTq[lane] = tq_l;
+        }
+        wave_lds_sync();
+        for (int ps = 0; ps < cp && c0 + ps * npw < n_tips; ++ps) {
+            const int sq = ps * npw + b;
+            const int tip_c = lane_ok ? sTip[sq] : -1;
+            const bool act = tip_c >= 0;
+            const int tip = act ? tip_c : 0;
+            const int s_own = act ? __builtin_ctzll(sWord[sq]) : 0;
+            const double tq = act ? sTq[sq] : 0.0;
+            if (lane_ok) sW[slot + i] = exp(d_i * tq) * sT[s_own * AS + i];
+            wave_lds_sync();
+            const double* w = sW + slot;
+            double p = a[0] * w[0];
+#pragma unroll
+            for (int mm = 1; mm < KU; ++mm) p = __builtin_fma(a[mm], w[mm], p);
+            if (act) {
+                // numpy's first maximum of (.., 0, P[i][s], 0, ..) with the reference's clamp of negative entries
+                const size_t row = (colN + tip) * ks;
+                double pv = p;
+                int arg;
+                if (pv > 0.0) {
+                    arg = s_own;
+                } else if (s_own != 0) {
+                    pv = 0.0;
+                    arg = 0;
+                } else if (pv == 0.0 || k == 1) {
+                    arg = 0;
+                } else {
+                    pv = 0.0;
+                    arg = 1;
+                }
+                if (c.masks_init != nullptr) {
+                    const u64 mi = c.masks_init[colN + tip], mc = c.masks[colN + tip];
+                    if (mi != mc && !((mi >> arg) & 1ull)) arg = mi ? __builtin_ctzll(mi) : 0;
+                }
+                st.msg[row + i] = pv;
+                st.J[row + i] = (pml_jt)arg;
+                if (i == k - 1)
+                    for (int q = k; q < ks; ++q) {
+                        st.msg[row + q] = 0.0;
+                        st.J[row + q] = (pml_jt)0;
+                    }
+            }
+            wave_lds_sync();
         }
         wave_lds_sync();  // the chunk has been consumed before the next one overwrites it
     }

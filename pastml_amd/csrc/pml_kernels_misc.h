@@ -506,7 +506,12 @@ tip_posteriors_kernel(PmlCols c, PmlState st, int N, const int* __restrict__ tip
     }
 }
 
-__global__ void reset_err_kernel(u64* __restrict__ err, int n) {
+// start of a bottom-up sweep: the columns' error words, and (if given) the counters of the tips the lean tips kernel of
+// the eigen joint sweep hands on
+__global__ void reset_err_kernel(u64* __restrict__ err, int n, int* __restrict__ counters = nullptr) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) err[i] = ~0ull;
+    if (i < n) {
+        err[i] = ~0ull;
+        if (counters != nullptr) counters[i] = 0;
+    }
 }
