@@ -676,7 +676,8 @@ class Engine(BareContext):
         _check(self._lib.pml_profile_enable(self._ctx, 1 if on else 0))
 
     def profile_read(self, which, reset=False):
-        """(total milliseconds, launches) of slot which: 0 bottom-up, 1 top-down, 2 P(t)/prep kernels."""
+        """(total milliseconds, launches) of slot which: 0 bottom-up / 1 top-down level kernels, 2 P(t)/prep kernels,
+        3 / 4 the top-down / bottom-up launch of the two-level units."""
         ms, n = ctypes.c_double(0), ctypes.c_int64(0)
         _check(self._lib.pml_profile_read(self._ctx, which, ctypes.byref(ms), ctypes.byref(n), 1 if reset else 0))
         return ms.value, n.value

@@ -836,3 +836,24 @@ def test_groups_spread_over_devices_with_the_same_bits(monkeypatch):
     f1, f2 = FlatForest.from_trees([tree]), FlatForest.from_trees([tree2])
     for column in df.columns:
         assert [getattr(n, column) for n in f1.nodes] == [getattr(n, column) for n in f2.nodes]
+
+
+def test_two_level_launches_where_the_byte_model_expects_them(monkeypatch):
+    """bench.schedule_bytes decides from the tree which sweeps run two-level units; the library decides at upload.  The
+    profile slots say what ran: slots 3 / 4 (the two-level launches) are used exactly where the model counts such nodes."""
+    import bench
+    from pastml_amd import hip, synthetic
+    flat = synthetic.balanced_forest(12)
+    for k, n_cols in ((64, 64), (64, 2), (32, 64), (20, 64)):
+        C = n_cols
+        expect = bench.schedule_bytes(flat, k, C)['n_two_level'] > 0
+        with hip.Engine(flat, C, k) as eng:
+            eng.set_models([(dict(kind=0, pi=synthetic.f81_frequencies(k, c)), (1.0, 0.0, 1.0)) for c in range(C)])
+            eng.set_tip_states(np.stack([synthetic.tip_states(flat.n_tips, k, c) for c in range(C)]))
+            eng.profile_enable(True)
+            for w in range(5):
+                eng.profile_read(w, reset=True)
+            eng.marginal_pass(posterior=False, lh=False)
+            ran = [eng.profile_read(w)[1] for w in range(5)]
+            eng.profile_enable(False)
+        assert (ran[3] > 0) == expect and (ran[4] > 0) == expect, (k, C, ran)

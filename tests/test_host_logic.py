@@ -378,3 +378,37 @@ def test_visible_devices(monkeypatch):
     monkeypatch.delenv('LOCAL_RANK')
     monkeypatch.setattr(hip, 'device_count', lambda: 0)
     assert B.visible_devices() == [0]
+
+
+def test_bench_byte_model_knows_the_two_level_schedule():
+    """bench.schedule_bytes restates, from the tree, which nodes the library's level schedule runs as two-level units
+    (pml_tree_upload) and what the sweeps then move; the GPU side of this is test_gpu_api's profile-slot check."""
+    import bench
+    from pastml_amd import synthetic
+    flat = synthetic.balanced_forest(12)
+    # level launches (stored nodes x columns beyond the subtree blocks' reach): every node of height 3 is a two-level node
+    sb = bench.schedule_bytes(flat, 64, 128)
+    assert sb['n_two_level'] == flat.n_tips // 8
+    plain = bench.schedule_bytes(flat, 64, 3)          # subtree blocks: no two-level units
+    assert plain['n_two_level'] == 0 and plain['bottom_up_two_level'] == 0
+    vec = 8 * 64
+    n2 = sb['n_two_level']
+    # bottom-up, per two-level node.  Plain: its two children as units (descriptor 32, vector + pi.v + exponent written
+    # 528, two cherries gathered 64 and their pi.v + exponent written 32, four tips gathered 96 = 752 each) and its own unit
+    # (32 + 528 + two children gathered 64 + their vectors read 1024 = 1648).  Two-level: 920 (DESIGN.md 4b).
+    assert plain['bottom_up'] - sb['bottom_up'] == n2 * (2 * 752 + 1648 - 920)
+    # top-down.  Plain: its own unit (descriptor 32, own row 528, two children: gather 32 + row written 528 each, their
+    # vectors read 1024 = 2704) and its children's units (32 + 528 + two cherries (32 + 528) + four tips (24 + 528) = 3888
+    # each).  Two-level: descriptor and own row once (560), per child 32 + 48 + 96 + 7 rows of 528.
+    assert plain['top_down'] - sb['top_down'] == n2 * (2704 + 2 * 3888 - 560 - 2 * (176 + 7 * 528))
+    assert vec == 512
+    assert bench.schedule_bytes(flat, 20, 128)['n_two_level'] == 0      # units of fewer than 8 lanes
+    # a caterpillar has no such nodes
+    root = TreeNode(name='r', dist=0.0)
+    cur = root
+    for d in range(3000):
+        cur.add_child(name='t{}'.format(d), dist=0.1)
+        cur = cur.add_child(name='i{}'.format(d), dist=0.1)
+    cur.add_child(name='ta', dist=0.1)
+    cur.add_child(name='tb', dist=0.1)
+    assert bench.schedule_bytes(FlatForest.from_trees([root]), 64, 128)['n_two_level'] == 0
