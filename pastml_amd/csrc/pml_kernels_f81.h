@@ -1460,8 +1460,9 @@ __device__ __forceinline__ void bu_f81_super_seq(const LaneCtx<G, R>& L, const P
 
 // The same two-stage software pipeline as bu_f81_kernel: the loads of unit i + 1 and the descriptor of unit i + 2 are
 // in flight while unit i is computed.
+// (two waves per SIMD in every shape: at three, four states per lane spill 64 - 72 bytes)
 template <int G, int R>
-__global__ void __launch_bounds__(PML_BLOCK) __attribute__((amdgpu_waves_per_eu(R >= 8 ? 2 : 3, R >= 8 ? 2 : 4)))
+__global__ void __launch_bounds__(PML_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
 bu_f81_super_kernel(PmlTree t, PmlCols c, PmlState st, const PmlUnit* __restrict__ units, int n_level) {
     constexpr int UW = 64 / G;
     const int wave = threadIdx.x >> 6;
