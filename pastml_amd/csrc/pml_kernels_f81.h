@@ -757,11 +757,18 @@ struct BuResult {
     i64 e;
 };
 
+// the vectors (and rescaling exponents) of a PAIR unit's two cherries, for a caller that goes on with them
+template <int R>
+struct CherryKeep {
+    double v[2][R];
+    i64 e[2];
+};
+
 template <int G, int R, bool VEC, bool FULL, bool PAIR = false>
 __device__ __forceinline__ bool bu_f81_marg_body(const LaneCtx<G, R>& L, const PmlTree& t, const PmlCols& c,
                                                  const PmlState& st, const UnitRegs& u, BuLoads<R>& ld,
                                                  BuResult<R>* keep = nullptr, bool store_vec = true,
-                                                 bool vec_only = false) {
+                                                 bool vec_only = false, CherryKeep<R>* cherries = nullptr) {
     const int n = u.n, fc = u.fc;
     const int nc = PAIR ? 2 : unit_nc(u.packed);
     ChildLane& cl = ld.cl;
@@ -794,6 +801,11 @@ __device__ __forceinline__ bool bu_f81_marg_body(const LaneCtx<G, R>& L, const P
                 i64 ce;
                 f81_cherry_from_lanes<G, R>(L, c, cl, tl, jx, code - 1, v, ce, FULL);
                 esum += ce;
+                if (PAIR && cherries != nullptr) {  // (jx is a constant in the straight-line body)
+#pragma unroll
+                    for (int r = 0; r < R; ++r) cherries->v[jx & 1][r] = v[r];
+                    cherries->e[jx & 1] = ce;
+                }
                 if (vec_only) {
                     s_child = __shfl(cl.s, src, 64);  // as the bottom-up sweep stored it
                 } else {
@@ -2017,8 +2029,9 @@ __device__ __forceinline__ void td_f81_super_unit(const LaneCtx<G, R>& L, const 
     ld.own &= kbits;
     const bool all_ones = __all(c.k == G * R && ld.own == kbits && ld.cl.mask == kbits);
     BuResult<R> v;
-    if (all_ones) bu_f81_marg_body<G, R, false, true, true>(L, t, c, st, u, ld, &v, false, true);
-    else bu_f81_marg_body<G, R, false, false, true>(L, t, c, st, u, ld, &v, false, true);
+    CherryKeep<R> ck;  // the two cherries' vectors: the child's own unit below needs them again
+    if (all_ones) bu_f81_marg_body<G, R, false, true, true>(L, t, c, st, u, ld, &v, false, true, &ck);
+    else bu_f81_marg_body<G, R, false, false, true>(L, t, c, st, u, ld, &v, false, true, &ck);
     double prod2[R];
     i64 pe2;
     {
@@ -2035,8 +2048,33 @@ __device__ __forceinline__ void td_f81_super_unit(const LaneCtx<G, R>& L, const 
 #pragma unroll
         for (int r = 0; r < R; ++r) prod2[r] = po[r] * (ls * L.ipi_r[r]);
     }
-    double none[R];
-    td_f81_fast_children<G, R>(L, t, c, st, u, prod2, pe2, ld.cl, ld.tl, none);
+    // the child's own unit: td_f81_fast_children for two cherries of two tips, with the cherries' vectors at hand
+    constexpr int GC = Gather<G>::GC;
+#pragma unroll
+    for (int jx = 0; jx < 2; ++jx) {
+        const int src = L.group_base + jx;
+        const int cch = u.fc + jx;
+        const double ce = __shfl(ld.cl.e, src, 64);
+        const u64 word = __shfl(ld.cl.mask, src, 64);
+        double mb[R], tdc[R], po[R], ls;
+        const bool full = word == kbits;
+        if (!full) clean_word_to_vec<G, R>(L, c, word, mb);
+        i64 xe, le;
+        const int cfc = __shfl(u.cfc, L.group_base + jx * GC, 64);
+        f81_finish_child<G, R>(L, c, prod2, pe2, cch, ce, __shfl(ld.cl.s, src, 64), ck.e[jx], ck.v[jx], full, mb, tdc, xe, po,
+                               ls, le);
+        double prod3[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) prod3[r] = po[r] * (ls * L.ipi_r[r]);
+        double P3 = 0.0;
+        bool have_P3 = false;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int ts = L.group_base + jx * GC + q;
+            f81_finish_tip_word<G, R>(L, c, prod3, le, P3, have_P3, cfc + q, __shfl(ld.tl.mask, ts, 64),
+                                      __shfl(ld.tl.e, ts, 64), __shfl(ld.tl.s, ts, 64));
+        }
+    }
 }
 
 // n_level = number of two-level nodes; unit i is child i & 1 of node i >> 1

@@ -12,7 +12,7 @@ for d in sys.argv[1:]:
                                                      'grid': int(r['Grid_Size'])})
         dd[r['Counter_Name']] = dd.get(r['Counter_Name'], 0) + float(r['Counter_Value'])
     for k, v in disp.items():
-        if 'f81_kernel' in v['name'] and v.get('SQ_WAVES', v.get('SQ_WAVE_CYCLES', 0)) > 0:
+        if ('f81_kernel' in v['name'] or 'super_kernel' in v['name']) and v.get('SQ_WAVES', v.get('SQ_WAVE_CYCLES', 0)) > 0:
             big = {a: round(b / 1e6, 1) for a, b in v.items() if a not in ('name', 'grid')}
             if max(big.values()) > 100:
                 print(k, v['name'], v['grid'], big)
