@@ -139,3 +139,61 @@ def test_random_case(seed):
             for n, i in diff:
                 prod = orc.pij(specs[c], flat.dist[n], *rates[c])[i] * j['bu'][n]
                 assert abs(prod[tables[c][n, i]] - prod.max()) <= 1e-12 * max(prod.max(), 1e-300), (n, i)
+
+
+@pytest.mark.parametrize('seed', range(max(8, N_CASES // 5)))
+def test_random_case_with_two_level_units(seed, monkeypatch):
+    """The level schedule with two-level units (forced on a small forest: no subtree blocks, no single-launch sweeps, any
+    number of such nodes) against the oracle: ragged forests with balanced clumps, 29 <= k <= 64, masks of every kind,
+    several columns; ln L, bottom-up vectors (the clumps' inner nodes come from the download's materialisation),
+    posteriors, totals; a zero likelihood names the reference's pair."""
+    from test_gpu_parity import _forest_with_balanced_clumps
+    monkeypatch.setenv('PASTML_HIP_BLOCK_NODES', '0')
+    monkeypatch.setenv('PASTML_HIP_SMALL_MANY_NODES', '0')
+    monkeypatch.setenv('PASTML_HIP_SMALL_MAX_NODES', '0')
+    monkeypatch.setenv('PASTML_HIP_SUPER_MIN', '1')
+    rng = np.random.default_rng(70_000 + seed)
+    k = int(rng.choice([29, 31, 32, 33, 40, 48, 63, 64]))
+    flat = _forest_with_balanced_clumps(int(rng.integers(20, 120)), seed=seed, clump_frac=float(rng.uniform(0.3, 0.9)))
+    C = int(rng.integers(1, 4))
+    specs = [random_spec('F81', k, rng) for _ in range(C)]
+    rates = [(float(rng.uniform(0.3, 4)), float(rng.choice([0.0, 0.0, 0.02])), float(rng.uniform(0.7, 1.0)))
+             for _ in range(C)]
+    masks = np.stack([random_masks(flat, k, rng, missing=float(rng.choice([0.0, 0.1, 0.3])),
+                                   multi=float(rng.choice([0.0, 0.1])), internal=float(rng.choice([0.0, 0.0, 0.05])))
+                      for _ in range(C)])
+    refs, ref_errors = [], []
+    for c in range(C):
+        try:
+            refs.append(orc.full_marginal_pass(flat, masks[c].astype(int), specs[c], *rates[c]))
+            ref_errors.append(None)
+        except orc.OracleLikelihoodError as e:
+            refs.append(None)
+            ref_errors.append(e)
+        except ValueError:
+            pytest.skip('the reference fails on this input (all-zero marginal likelihoods)')
+    with hip.Engine(flat, C, k) as eng:
+        eng.set_models(list(zip(specs, rates)))
+        eng.set_masks(masks)
+        eng.profile_enable(True)
+        if any(e is not None for e in ref_errors):
+            with pytest.raises(hip.ZeroLikelihoodError) as err:
+                eng.bottom_up(True)
+            for c in range(C):
+                if ref_errors[c] is None:
+                    assert err.value.err_child[c] == -1
+                else:
+                    assert (err.value.err_parent[c], err.value.err_child[c]) == (ref_errors[c].parent, ref_errors[c].child)
+            return
+        lnl = eng.bottom_up(True)
+        post, lh_sum, lh_sf = eng.top_down_marginals()
+        assert eng.profile_read(3)[1] > 0 and eng.profile_read(4)[1] > 0     # the two-level launches did run
+        bus = [(eng.download(hip.BUF_BU, c), eng.download(hip.BUF_BU_SF, c)) for c in range(C)]
+    internal = ~flat.is_tip
+    for c in range(C):
+        r = refs[c]
+        np.testing.assert_allclose(lnl[c], r['loglik'], rtol=LNL_RTOL, atol=1e-11)
+        compare_vectors(bus[c][0], bus[c][1], r['bu'], r['bu_sf'], internal, 'BU col {}'.format(c))
+        np.testing.assert_allclose(post[c], r['posterior'], rtol=1e-8, atol=1e-12)
+        tot = np.log10(lh_sum[c]) - lh_sf[c]
+        np.testing.assert_allclose(tot, r['loglik_per_tree'][flat.tree_id] / np.log(10), rtol=1e-10, atol=1e-11)
