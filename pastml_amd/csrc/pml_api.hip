@@ -112,6 +112,19 @@ struct pml_ctx {
         std::vector<int> bu_offsets_r, td_offsets_r;
         std::vector<char> bu_level_vec_r;
     } sup;
+    // Joint sweep of the eigen models: the thin levels of a large forest (runs of levels of at most 4 096 nodes) in tiers
+    // of four levels; a tier is cut into subtree blocks and ONE launch walks them, a workgroup per (block, column) with a
+    // workgroup barrier between its levels -- a level costs a ~3.5 us pass instead of a ~7.5 us dependent launch.
+    struct EigenTiers {
+        bool ok = false;
+        int first_level = 0;   // plain bottom-up level the first tier starts at
+        int top_level = 0;     // ... and the level from which the single-workgroup launch takes over
+        struct Tier { int first_block, n_blocks, depth; };
+        std::vector<Tier> tiers;
+        PmlUnit* d_units = nullptr;
+        int *d_lv = nullptr, *d_start = nullptr;
+        int widest = 0;        // nodes of the widest level inside the tiers
+    } eig_tiers;
     bool small = false;  // forest small enough for the one-launch-per-sweep kernels
     bool levels_fit_workgroup = false;  // (nearly) every fused level is one pass of a 512-thread workgroup
     std::vector<int> bu_offsets_f, td_parent_offsets_f;
@@ -908,7 +921,8 @@ static bool eigen_joint_valu(const pml_ctx* c) {
 
 // d_offsets == nullptr: one launch over the n nodes of a level (their unit descriptors); otherwise the levels
 // [first, first + n) of the level table in one launch (one workgroup per column)
-static int launch_eigen_joint(pml_ctx* ctx, const PmlUnit* units, const int* d_offsets, int first, int n) {
+static int launch_eigen_joint(pml_ctx* ctx, const PmlUnit* units, const int* d_offsets, int first, int n,
+                              const int* d_blk_start = nullptr, int n_blocks = 1) {
     if (n <= 0) return PML_OK;
     const int KU = 4 * ((ctx->k + 3) / 4);
     const PmlTree t = tree_of(ctx);
@@ -920,8 +934,8 @@ static int launch_eigen_joint(pml_ctx* ctx, const PmlUnit* units, const int* d_o
 #define PML_EIGJ_CASE(KU_)                                                                                          \
     if (KU == KU_) {                                                                                                \
         if (d_offsets) {                                                                                            \
-            hipLaunchKernelGGL((eigen_joint_narrow_kernel<KU_>), dim3(1, ctx->C), dim3(PML_BLOCK), 0, ctx->stream,  \
-                               t, c, m, st, ctx->d_AinvT, units, d_offsets + first, n);                                \
+            hipLaunchKernelGGL((eigen_joint_narrow_kernel<KU_>), dim3(n_blocks, ctx->C), dim3(PML_BLOCK), 0,        \
+                               ctx->stream, t, c, m, st, ctx->d_AinvT, units, d_offsets + first, n, d_blk_start);   \
         } else {                                                                                                    \
             int blocks = (n + per_block - 1) / per_block;                                                           \
             const int cap = std::max(8, cap_all / std::max(1, ctx->C));                                             \
@@ -1398,6 +1412,79 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
                 ctx->td_cherry_prefix[q + 1] = ctx->td_cherry_prefix[q] + ((((pk >> 8) & 7) >= 2 || ((pk >> 11) & 7) >= 2) ? 1 : 0);
             }
             describe(bu_order, n_internal, false, ub);
+            {
+                pml_ctx::EigenTiers& E = ctx->eig_tiers;
+                E = pml_ctx::EigenTiers();
+                const int thin = getenv("PASTML_HIP_EIGJ_TIER_THIN") ? atoi(getenv("PASTML_HIP_EIGJ_TIER_THIN")) : 4096;
+                const int depth = getenv("PASTML_HIP_EIGJ_TIER_DEPTH") ? std::max(2, atoi(getenv("PASTML_HIP_EIGJ_TIER_DEPTH"))) : 4;
+                const int top_nodes = 48;
+                int L0 = n_bu_levels;
+                while (L0 > 0 && bu_offsets[L0] - bu_offsets[L0 - 1] <= thin) --L0;
+                if (!getenv("PASTML_HIP_NO_EIGJ_TIERS") && n_bu_levels - L0 >= depth + 2) {
+                    std::vector<int> level_of(n_nodes, -1);
+                    for (int l = 0; l < n_bu_levels; ++l)
+                        for (int q = bu_offsets[l]; q < bu_offsets[l + 1]; ++q) level_of[bu_order[q]] = l;
+                    std::vector<PmlUnit> tu;
+                    std::vector<int> lv, start;
+                    int a = L0;
+                    while (a + depth <= n_bu_levels && bu_offsets[a + 1] - bu_offsets[a] > top_nodes) {
+                        const int b = a + depth;
+                        // block of a node: its highest ancestor below level b
+                        std::vector<int> nodes(bu_order + bu_offsets[a], bu_order + bu_offsets[b]);
+                        std::vector<int> root(nodes.size());
+                        std::vector<int> roots;
+                        std::vector<int> block_of(n_nodes, -1);
+                        for (size_t q = nodes.size(); q-- > 0;) {  // higher levels last in the list: roots first
+                            const int n = nodes[q];
+                            const int p = parent[n];
+                            if (p >= 0 && level_of[p] >= 0 && level_of[p] < b) {
+                                block_of[n] = block_of[p];
+                            } else {
+                                block_of[n] = (int)roots.size();
+                                roots.push_back(n);
+                            }
+                        }
+                        const int nb = (int)roots.size();
+                        // per block and level: its nodes, in list order
+                        std::vector<std::vector<int>> cell((size_t)nb * depth);
+                        for (int n : nodes) cell[(size_t)block_of[n] * depth + (level_of[n] - a)].push_back(n);
+                        pml_ctx::EigenTiers::Tier T;
+                        T.first_block = (int)start.size();
+                        T.n_blocks = nb;
+                        T.depth = depth;
+                        std::vector<int> flat_nodes;
+                        const int base = (int)tu.size();
+                        for (int bl = 0; bl < nb; ++bl) {
+                            start.push_back((int)lv.size());
+                            for (int d = 0; d < depth; ++d) {
+                                lv.push_back(base + (int)flat_nodes.size());
+                                for (int n : cell[(size_t)bl * depth + d]) flat_nodes.push_back(n);
+                            }
+                            lv.push_back(base + (int)flat_nodes.size());
+                        }
+                        std::vector<PmlUnit> part;
+                        describe(flat_nodes.data(), (int)flat_nodes.size(), false, part);
+                        part.resize(flat_nodes.size());
+                        tu.insert(tu.end(), part.begin(), part.end());
+                        E.tiers.push_back(T);
+                        for (int l = a; l < b; ++l) E.widest = std::max(E.widest, bu_offsets[l + 1] - bu_offsets[l]);
+                        a = b;
+                    }
+                    if (!E.tiers.empty()) {
+                        tu.push_back(ub[0]);  // (slack: an empty level at the end of the table is still addressed)
+                        PML_TRY(dev_alloc(ctx, &E.d_units, tu.size()));
+                        PML_TRY(dev_alloc(ctx, &E.d_lv, lv.size()));
+                        PML_TRY(dev_alloc(ctx, &E.d_start, start.size()));
+                        PML_TRY(upload(ctx, E.d_units, tu.data(), tu.size()));
+                        PML_TRY(upload(ctx, E.d_lv, lv.data(), lv.size()));
+                        PML_TRY(upload(ctx, E.d_start, start.data(), start.size()));
+                        HIP_TRY(hipStreamSynchronize(ctx->stream));
+                        E.first_level = L0;
+                        E.top_level = a;
+                        E.ok = true;
+                    }
+                }
+            }
             ctx->bu_level_vec.assign(n_bu_levels > 0 ? n_bu_levels : 1, 0);
             for (int l = 0; l < n_bu_levels; ++l)
                 for (int q = bu_offsets[l]; q < bu_offsets[l + 1] && !ctx->bu_level_vec[l]; ++q) {
@@ -2194,6 +2281,26 @@ static int enqueue_bottom_up(pml_ctx* ctx, int is_marginal, bool small_path, boo
     } else if (eigj) {
         // joint sweep of an eigen model on the vector units (pml_kernels_eigen_joint.h): the tips, then the levels
         PML_TRY(launch_eigen_joint_tips(ctx));
+        const pml_ctx::EigenTiers& E = ctx->eig_tiers;
+        // (tiers only while their levels are thin for the whole batch: with many columns a level fills the chip)
+        if (E.ok && (long long)E.widest * ctx->C <= 16384) {
+            for (int l = 0; l < E.first_level; ++l) {
+                const int a = ctx->bu_offsets[l], b = ctx->bu_offsets[l + 1];
+                PML_TRY(launch_eigen_joint(ctx, ctx->d_bu_units + a, nullptr, 0, b - a));
+            }
+            for (const pml_ctx::EigenTiers::Tier& T : E.tiers)
+                PML_TRY(launch_eigen_joint(ctx, E.d_units, E.d_lv, 0, T.depth, E.d_start + T.first_block, T.n_blocks));
+            // what is left above the tiers: levels of a launch each while they are wide (a forest of many trees), then
+            // the narrow end in one launch
+            int l = E.top_level;
+            long long extra = 0;
+            for (; l < ctx->n_bu_levels && ctx->bu_offsets[l + 1] - ctx->bu_offsets[l] > 48; ++l, ++extra) {
+                const int a = ctx->bu_offsets[l], b = ctx->bu_offsets[l + 1];
+                PML_TRY(launch_eigen_joint(ctx, ctx->d_bu_units + a, nullptr, 0, b - a));
+            }
+            PML_TRY(launch_eigen_joint(ctx, ctx->d_bu_units, ctx->d_bu_offsets, l, ctx->n_bu_levels - l));
+            PML_TRY(prof_end(ctx, 0, E.first_level + 2 + extra + (long long)E.tiers.size()));
+        } else {
         const int tail = narrow_levels(ctx->bu_offsets, ctx->n_bu_levels, false, ctx->C,
                                        PML_WAVES_PER_BLOCK * (64 / ctx->k));
         for (int l = 0; l < ctx->n_bu_levels - tail; ++l) {
@@ -2202,6 +2309,7 @@ static int enqueue_bottom_up(pml_ctx* ctx, int is_marginal, bool small_path, boo
         }
         PML_TRY(launch_eigen_joint(ctx, ctx->d_bu_units, ctx->d_bu_offsets, ctx->n_bu_levels - tail, tail));
         PML_TRY(prof_end(ctx, 0, ctx->n_bu_levels + 1 - tail + (tail > 0 ? 1 : 0)));
+        }
     } else if (gemm) {
         // marginal sweep: P(t) is never formed, msg = A (e o (A^-1 v)) as two small GEMMs per 16 nodes
         PML_TRY(launch_eigen_gemm(ctx, PML_EIGG_TIPS, ctx->d_tips, 0, ctx->n_tips));

@@ -223,7 +223,11 @@ template <int KU>
 __global__ void PML_EIGJ_ATTR eigen_joint_narrow_kernel(PmlTree t, PmlCols c, PmlModel m, PmlState st,
                                                         const double* __restrict__ ainvT,
                                                         const PmlUnit* __restrict__ units,
-                                                        const int* __restrict__ level_offsets, int n_levels) {
+                                                        const int* __restrict__ level_offsets, int n_levels,
+                                                        const int* __restrict__ blk_start) {
+    // (blk_start: the launch walks the subtree blocks of a tier of thin levels, one workgroup per (block, column);
+    // block b's level table starts at level_offsets[blk_start[b]], n_levels + 1 entries)
+    if (blk_start != nullptr) level_offsets += blk_start[blockIdx.x];
     __shared__ double smem[PML_EIGJ_LDS(KU)];
     EigJWave<KU> W;
     eigj_wave_init<KU>(W, t, c, m, ainvT, smem);

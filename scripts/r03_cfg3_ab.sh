@@ -25,7 +25,7 @@ print(os.environ.get('TAG', ''), 'joint sweep %.4f ms, + backtrace %.4f ms lnL %
 PY
 for i in 1 2; do
 TAG=new python /tmp/t.py
-TAG=old PASTML_HIP_EIGJ_ONE_TIPS_KERNEL=1 python /tmp/t.py
+TAG=old PASTML_HIP_NO_EIGJ_TIERS=1 python /tmp/t.py
 done
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/q/kt -o run -- python3 $GRAFT_REPO_ROOT/scripts/cfg3_run.py j 10 > /dev/null 2>&1
