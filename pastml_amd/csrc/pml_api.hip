@@ -123,6 +123,7 @@ struct pml_ctx {
         std::vector<Tier> tiers;
         PmlUnit* d_units = nullptr;
         int *d_lv = nullptr, *d_start = nullptr;
+        int* d_nodes = nullptr;  // the node ids parallel to d_units (the sum sweeps walk node lists)
         int widest = 0;        // nodes of the widest level inside the tiers
     } eig_tiers;
     bool small = false;  // forest small enough for the one-launch-per-sweep kernels
@@ -850,7 +851,7 @@ static int launch_eigen_gemm(pml_ctx* ctx, int mode, const int* nodes, int first
 }
 
 static int launch_eigen_gemm_narrow(pml_ctx* ctx, int mode, const int* nodes, const int* d_offsets, int first_level,
-                                    int n_levels) {
+                                    int n_levels, const int* d_blk_start = nullptr, int n_blocks = 1) {
     if (n_levels <= 0) return PML_OK;
     const int KS = (ctx->k + 3) / 4;
     const PmlTree t = tree_of(ctx);
@@ -859,8 +860,8 @@ static int launch_eigen_gemm_narrow(pml_ctx* ctx, int mode, const int* nodes, co
     const PmlModel m = model_of(ctx);
 #define PML_EIGG_CASE(KS_, MODE_)                                                                                      \
     if (KS == KS_ && mode == MODE_) {                                                                                  \
-        hipLaunchKernelGGL((eigen_gemm_narrow_kernel<KS_, MODE_>), dim3(1, ctx->C), dim3(PML_BLOCK), 0, ctx->stream, \
-                           t, c, m, st, nodes, d_offsets + first_level, n_levels);                                     \
+        hipLaunchKernelGGL((eigen_gemm_narrow_kernel<KS_, MODE_>), dim3(n_blocks, ctx->C), dim3(PML_BLOCK), 0,         \
+                           ctx->stream, t, c, m, st, nodes, d_offsets + first_level, n_levels, d_blk_start);           \
         HIP_TRY(hipGetLastError());                                                                                    \
         return PML_OK;                                                                                                 \
     }
@@ -1420,45 +1421,63 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
                 const int top_nodes = 48;
                 int L0 = n_bu_levels;
                 while (L0 > 0 && bu_offsets[L0] - bu_offsets[L0 - 1] <= thin) --L0;
-                if (!getenv("PASTML_HIP_NO_EIGJ_TIERS") && n_bu_levels - L0 >= depth + 2) {
+                if (!getenv("PASTML_HIP_NO_EIGJ_TIERS") && n_bu_levels - L0 >= 6) {
                     std::vector<int> level_of(n_nodes, -1);
                     for (int l = 0; l < n_bu_levels; ++l)
                         for (int q = bu_offsets[l]; q < bu_offsets[l + 1]; ++q) level_of[bu_order[q]] = l;
                     std::vector<PmlUnit> tu;
-                    std::vector<int> lv, start;
+                    std::vector<int> lv, start, tnodes;
                     int a = L0;
-                    while (a + depth <= n_bu_levels && bu_offsets[a + 1] - bu_offsets[a] > top_nodes) {
-                        const int b = a + depth;
-                        // block of a node: its highest ancestor below level b
-                        std::vector<int> nodes(bu_order + bu_offsets[a], bu_order + bu_offsets[b]);
-                        std::vector<int> root(nodes.size());
-                        std::vector<int> roots;
-                        std::vector<int> block_of(n_nodes, -1);
-                        for (size_t q = nodes.size(); q-- > 0;) {  // higher levels last in the list: roots first
-                            const int n = nodes[q];
-                            const int p = parent[n];
-                            if (p >= 0 && level_of[p] >= 0 && level_of[p] < b) {
-                                block_of[n] = block_of[p];
-                            } else {
-                                block_of[n] = (int)roots.size();
-                                roots.push_back(n);
+                    std::vector<int> block_of(n_nodes, -1);
+                    // The depth of a tier is the largest (up to 12 levels) whose blocks still have at most 12 nodes per
+                    // level -- one pass of a workgroup per level step at k = 20 (three nodes per wavefront).  A
+                    // balanced binary tree gets tiers of four levels, ragged trees deeper ones (measured: HIV1C-shaped
+                    // and random 40 000-tip trees are 10 - 20 % faster with 6 - 8 levels than with 4, cfg3 slower).
+                    // PASTML_HIP_EIGJ_TIER_DEPTH fixes the depth.
+                    const bool fixed_depth = getenv("PASTML_HIP_EIGJ_TIER_DEPTH") != nullptr;
+                    while (a + 2 <= n_bu_levels && bu_offsets[a + 1] - bu_offsets[a] > top_nodes) {
+                        int use = 0, nb = 0;
+                        std::vector<std::vector<int>> cell;
+                        for (int dep = fixed_depth ? depth : 12; dep >= 2; --dep) {
+                            if (a + dep > n_bu_levels) {
+                                if (fixed_depth) break;
+                                continue;
+                            }
+                            const int b = a + dep;
+                            // block of a node: its highest ancestor below level b (higher levels come last in the list,
+                            // so walking it backwards meets parents before children)
+                            nb = 0;
+                            for (int q = bu_offsets[b]; q-- > bu_offsets[a];) {
+                                const int n = bu_order[q];
+                                const int p = parent[n];
+                                block_of[n] = (p >= 0 && level_of[p] >= 0 && level_of[p] < b) ? block_of[p] : nb++;
+                            }
+                            cell.assign((size_t)nb * dep, std::vector<int>());
+                            size_t widest_cell = 0;
+                            for (int q = bu_offsets[a]; q < bu_offsets[b]; ++q) {
+                                const int n = bu_order[q];
+                                std::vector<int>& cl = cell[(size_t)block_of[n] * dep + (level_of[n] - a)];
+                                cl.push_back(n);
+                                widest_cell = std::max(widest_cell, cl.size());
+                            }
+                            if (widest_cell <= 12 || dep == 2 || fixed_depth) {
+                                use = dep;
+                                break;
                             }
                         }
-                        const int nb = (int)roots.size();
-                        // per block and level: its nodes, in list order
-                        std::vector<std::vector<int>> cell((size_t)nb * depth);
-                        for (int n : nodes) cell[(size_t)block_of[n] * depth + (level_of[n] - a)].push_back(n);
+                        if (use == 0) break;
+                        const int b = a + use;
                         pml_ctx::EigenTiers::Tier T;
                         T.first_block = (int)start.size();
                         T.n_blocks = nb;
-                        T.depth = depth;
+                        T.depth = use;
                         std::vector<int> flat_nodes;
                         const int base = (int)tu.size();
                         for (int bl = 0; bl < nb; ++bl) {
                             start.push_back((int)lv.size());
-                            for (int d = 0; d < depth; ++d) {
+                            for (int d = 0; d < use; ++d) {
                                 lv.push_back(base + (int)flat_nodes.size());
-                                for (int n : cell[(size_t)bl * depth + d]) flat_nodes.push_back(n);
+                                for (int n : cell[(size_t)bl * use + d]) flat_nodes.push_back(n);
                             }
                             lv.push_back(base + (int)flat_nodes.size());
                         }
@@ -1466,12 +1485,16 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
                         describe(flat_nodes.data(), (int)flat_nodes.size(), false, part);
                         part.resize(flat_nodes.size());
                         tu.insert(tu.end(), part.begin(), part.end());
+                        tnodes.insert(tnodes.end(), flat_nodes.begin(), flat_nodes.end());
                         E.tiers.push_back(T);
                         for (int l = a; l < b; ++l) E.widest = std::max(E.widest, bu_offsets[l + 1] - bu_offsets[l]);
                         a = b;
                     }
                     if (!E.tiers.empty()) {
                         tu.push_back(ub[0]);  // (slack: an empty level at the end of the table is still addressed)
+                        tnodes.push_back(ub[0].n);
+                        PML_TRY(dev_alloc(ctx, &E.d_nodes, tnodes.size()));
+                        PML_TRY(upload(ctx, E.d_nodes, tnodes.data(), tnodes.size()));
                         PML_TRY(dev_alloc(ctx, &E.d_units, tu.size()));
                         PML_TRY(dev_alloc(ctx, &E.d_lv, lv.size()));
                         PML_TRY(dev_alloc(ctx, &E.d_start, start.size()));
@@ -2313,6 +2336,26 @@ static int enqueue_bottom_up(pml_ctx* ctx, int is_marginal, bool small_path, boo
     } else if (gemm) {
         // marginal sweep: P(t) is never formed, msg = A (e o (A^-1 v)) as two small GEMMs per 16 nodes
         PML_TRY(launch_eigen_gemm(ctx, PML_EIGG_TIPS, ctx->d_tips, 0, ctx->n_tips));
+        const pml_ctx::EigenTiers& E = ctx->eig_tiers;
+        static const bool gemm_tiers = getenv("PASTML_HIP_NO_EIGG_TIERS") == nullptr;
+        if (gemm_tiers && E.ok && (long long)E.widest * ctx->C <= 16384) {
+            // thin levels in tiers of subtree blocks, as in the joint sweep (pml_ctx::EigenTiers)
+            for (int l = 0; l < E.first_level; ++l) {
+                const int a = ctx->bu_offsets[l], b = ctx->bu_offsets[l + 1];
+                PML_TRY(launch_eigen_gemm(ctx, PML_EIGG_BU, ctx->d_bu_order + a, 0, b - a));
+            }
+            for (const pml_ctx::EigenTiers::Tier& T : E.tiers)
+                PML_TRY(launch_eigen_gemm_narrow(ctx, PML_EIGG_BU, E.d_nodes, E.d_lv, 0, T.depth, E.d_start + T.first_block,
+                                                 T.n_blocks));
+            int l = E.top_level;
+            long long extra = 0;
+            for (; l < ctx->n_bu_levels && ctx->bu_offsets[l + 1] - ctx->bu_offsets[l] > 2 * PML_WAVES_PER_BLOCK * 16; ++l, ++extra) {
+                const int a = ctx->bu_offsets[l], b = ctx->bu_offsets[l + 1];
+                PML_TRY(launch_eigen_gemm(ctx, PML_EIGG_BU, ctx->d_bu_order + a, 0, b - a));
+            }
+            PML_TRY(launch_eigen_gemm_narrow(ctx, PML_EIGG_BU, ctx->d_bu_order, ctx->d_bu_offsets, l, ctx->n_bu_levels - l));
+            PML_TRY(prof_end(ctx, 0, E.first_level + 2 + extra + (long long)E.tiers.size()));
+        } else {
         // levels one workgroup finishes in a pass or two per wave (4 waves x 16 nodes) share one launch
         const int tail = narrow_levels(ctx->bu_offsets, ctx->n_bu_levels, false, ctx->C, 2 * PML_WAVES_PER_BLOCK * 16);
         for (int l = 0; l < ctx->n_bu_levels - tail; ++l) {
@@ -2321,6 +2364,7 @@ static int enqueue_bottom_up(pml_ctx* ctx, int is_marginal, bool small_path, boo
         }
         PML_TRY(launch_eigen_gemm_narrow(ctx, PML_EIGG_BU, ctx->d_bu_order, ctx->d_bu_offsets, ctx->n_bu_levels - tail, tail));
         PML_TRY(prof_end(ctx, 0, ctx->n_bu_levels + 1 - tail + (tail > 0 ? 1 : 0)));
+        }
     } else if (eig) {
         // every node once, in the launch of its level: the tips first, then the internal nodes by height
         const int mode = is_marginal ? PML_EIG_BU_MARG : PML_EIG_BU_JOINT;

@@ -272,7 +272,9 @@ eigen_gemm_kernel(PmlTree t, PmlCols c, PmlModel m, PmlState st, const int* __re
 template <int KS, int MODE>
 __global__ void __launch_bounds__(PML_BLOCK)
 eigen_gemm_narrow_kernel(PmlTree t, PmlCols c, PmlModel m, PmlState st, const int* __restrict__ nodes,
-                         const int* __restrict__ level_offsets, int n_levels) {
+                         const int* __restrict__ level_offsets, int n_levels, const int* __restrict__ blk_start) {
+    // (blk_start: the subtree blocks of a tier of thin levels, one workgroup per (block, column) -- pml_ctx::EigenTiers)
+    if (blk_start != nullptr) level_offsets += blk_start[blockIdx.x];
     EigGemmWave<KS> W;
     eig_gemm_init<KS>(W, t, c, m);
     const int wave = threadIdx.x >> 6;
