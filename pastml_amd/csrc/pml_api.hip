@@ -149,6 +149,7 @@ struct pml_ctx {
     double* d_AinvT = nullptr;  // [C][32][32]: Ainv transposed and zero-padded (k <= 32), for eigen_joint_kernel
     double *d_sf = nullptr, *d_tau = nullptr, *d_tauf = nullptr;
     std::vector<char> model_set;  // per column
+    std::vector<char> tips_observed;  // per column: every tip has exactly one allowed state (known from pml_masks_from_tip_states)
     bool prep_dirty = true;
 
     // state
@@ -975,6 +976,10 @@ static int launch_eigen_joint_tips(pml_ctx* ctx) {
     // in one launch of the general kernel -- PASTML_HIP_EIGJ_ONE_TIPS_KERNEL: everything in the general kernel (round 2)
     static const bool one_kernel = getenv("PASTML_HIP_EIGJ_ONE_TIPS_KERNEL") != nullptr;
     const int rest_blocks = std::min(blocks, std::max(8, 1024 / std::max(1, ctx->C)));
+    // (every tip of every column known to be observed -- the masks came from pml_masks_from_tip_states: nothing can be
+    // on the lists, their launch is left out)
+    bool all_observed = !ctx->tips_observed.empty();
+    for (char f : ctx->tips_observed) all_observed = all_observed && f != 0;
 #define PML_EIGJ_TIPS(KU_)                                                                                          \
     if (KU == KU_) {                                                                                                \
         if (one_kernel) {                                                                                           \
@@ -984,9 +989,10 @@ static int launch_eigen_joint_tips(pml_ctx* ctx) {
             hipLaunchKernelGGL((eigen_joint_obs_tips_kernel<KU_>), dim3(blocks, ctx->C), dim3(PML_BLOCK), 0,        \
                                ctx->stream, t, c, m, st, ctx->d_AinvT, ctx->d_tips, ctx->n_tips, ctx->d_tip_rest,   \
                                ctx->d_tip_rest_count);                                                              \
-            hipLaunchKernelGGL((eigen_joint_tips_kernel<KU_>), dim3(rest_blocks, ctx->C), dim3(PML_BLOCK), 0,       \
-                               ctx->stream, t, c, m, st, ctx->d_AinvT, ctx->d_tip_rest, ctx->n_tips,                \
-                               ctx->d_tip_rest_count);                                                              \
+            if (!all_observed)                                                                                      \
+                hipLaunchKernelGGL((eigen_joint_tips_kernel<KU_>), dim3(rest_blocks, ctx->C), dim3(PML_BLOCK), 0,   \
+                                   ctx->stream, t, c, m, st, ctx->d_AinvT, ctx->d_tip_rest, ctx->n_tips,            \
+                                   ctx->d_tip_rest_count);                                                          \
         }                                                                                                           \
         HIP_TRY(hipGetLastError());                                                                                 \
         return PML_OK;                                                                                              \
@@ -1845,6 +1851,7 @@ int pml_chars_alloc(pml_ctx* ctx, int32_t n_cols, int32_t k) {
         HIP_TRY(hipGetLastError());
     }
     ctx->model_set.assign(n_cols, 0);
+    ctx->tips_observed.assign(n_cols, 0);
     ctx->prep_dirty = true;
     ctx->bu_mode = -1;
     ctx->td_valid = ctx->js_valid = false;
@@ -1866,6 +1873,19 @@ static void invalidate(pml_ctx* ctx) {
     ctx->td_valid = ctx->js_valid = false;
 }
 
+// what is known about the tips of columns [col_begin, col_end); the captured launch sequence of the joint sweep depends
+// on whether ALL columns' tips are observed (launch_eigen_joint_tips), so a change of that drops the graph
+static void note_tips_observed(pml_ctx* ctx, int col_begin, int col_end, bool observed) {
+    auto all = [&]() {
+        bool a = !ctx->tips_observed.empty();
+        for (char f : ctx->tips_observed) a = a && f != 0;
+        return a;
+    };
+    const bool before = all();
+    for (int col = col_begin; col < col_end; ++col) ctx->tips_observed[col] = observed ? 1 : 0;
+    if (all() != before) drop_graph(ctx->bu_graph[0]);
+}
+
 int pml_masks_upload(pml_ctx* ctx, int32_t col_begin, int32_t col_end, const uint64_t* masks) {
     PML_TRY(check_cols(ctx, col_begin, col_end));
     PML_TRY(materialize_tip_posteriors(ctx));  // (rows left implicit are defined by the masks about to change)
@@ -1880,6 +1900,7 @@ int pml_masks_upload(pml_ctx* ctx, int32_t col_begin, int32_t col_end, const uin
     }
     PML_TRY(upload(ctx, ctx->d_masks + col_begin * per_col, (const u64*)masks, per_col * (col_end - col_begin)));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    note_tips_observed(ctx, col_begin, col_end, false);
     invalidate(ctx);
     return PML_OK;
 }
@@ -1921,6 +1942,11 @@ int pml_masks_from_tip_states(pml_ctx* ctx, int32_t col_begin, int32_t col_end, 
         (void)hipFree(d_states);
         if (e != hipSuccess) return fail(PML_ERR_HIP, "tip mask upload failed: %s", hipGetErrorString(e));
         if (e2 != hipSuccess) return fail(PML_ERR_HIP, "tip mask upload failed: %s", hipGetErrorString(e2));
+    }
+    for (int col = col_begin; col < col_end; ++col) {
+        bool all = n_tips == ctx->n_tips;   // (the ids are distinct tips or the masks would not be what the caller meant)
+        for (int j = 0; all && j < n_tips; ++j) all = states[(size_t)(col - col_begin) * n_tips + j] >= 0;
+        note_tips_observed(ctx, col, col + 1, all);
     }
     invalidate(ctx);
     return PML_OK;
@@ -2915,6 +2941,7 @@ int pml_select_states(pml_ctx* ctx, int method, int force_joint, const uint64_t*
     if (method == 1 && force_joint && !ctx->js_ever)
         return fail(PML_ERR_INVALID, "force_joint needs the joint states of a pml_joint_backtrace");
     PML_TRY(materialize_tip_posteriors(ctx));  // the selection reads every row, and rewrites the masks
+    note_tips_observed(ctx, 0, ctx->C, false);  // (masks from now on: whatever was selected)
     const size_t CN = (size_t)ctx->C * ctx->N;
     if (!ctx->d_nsel) PML_TRY(dev_alloc(ctx, &ctx->d_nsel, CN));
     u64* d_lh_mask = nullptr;

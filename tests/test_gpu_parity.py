@@ -1151,3 +1151,36 @@ def test_two_level_units_report_the_reference_pair_on_zero_likelihood(monkeypatc
     assert out[0][:2] == (-1, -1)
     assert out[0][2] == node
     assert out[0] == out[1]
+
+
+def test_eigen_joint_sweep_follows_the_masks_through_graph_replay():
+    """The joint sweep of the eigen models leaves out the launch for unobserved tips when every column's masks came from
+    tip states; its launch sequence is replayed as a graph.  Masks that change between calls -- observed tips, then some
+    unobserved and ambiguous ones, then observed again -- must change the sequence with them: every result equals a fresh
+    engine's."""
+    k = 20
+    rng = np.random.default_rng(77)
+    flat = FlatForest.random(3000, seed=5, max_arity=3, n_trees=2)
+    spec = (random_spec('EIGEN', k, rng), (1.2, 0.0, 1.0))
+    states = rng.integers(0, k, size=flat.n_tips).astype(np.int32)
+    loose = random_masks(flat, k, rng, missing=0.2, multi=0.2, internal=0.0)
+
+    def fresh(setter):
+        with hip.Engine(flat, 1, k) as e:
+            e.set_models([spec])
+            setter(e)
+            lnl = e.bottom_up(False)
+            return lnl, e.download(hip.BUF_JOINT_TABLE, 0), e.joint_backtrace()
+
+    ref_obs = fresh(lambda e: e.set_tip_states(states))
+    ref_loose = fresh(lambda e: e.set_masks(loose[None]))
+    with hip.Engine(flat, 1, k) as eng:
+        eng.set_models([spec])
+        for setter, ref in ((lambda: eng.set_tip_states(states), ref_obs), (lambda: eng.set_masks(loose[None]), ref_loose),
+                            (lambda: eng.set_tip_states(states), ref_obs)):
+            setter()
+            for _ in range(3):   # capture, then replays
+                lnl = eng.bottom_up(False)
+                assert np.array_equal(lnl, ref[0])
+                assert np.array_equal(eng.download(hip.BUF_JOINT_TABLE, 0), ref[1])
+                assert np.array_equal(eng.joint_backtrace(), ref[2])
