@@ -1184,3 +1184,32 @@ def test_eigen_joint_sweep_follows_the_masks_through_graph_replay():
                 assert np.array_equal(lnl, ref[0])
                 assert np.array_equal(eng.download(hip.BUF_JOINT_TABLE, 0), ref[1])
                 assert np.array_equal(eng.joint_backtrace(), ref[2])
+
+
+@pytest.mark.parametrize('k', [5, 20, 32])
+def test_eigen_tiers_give_the_bits_of_one_launch_per_level(k, monkeypatch):
+    """Eigen models: the thin levels of the joint sweep and of the marginal bottom-up sweep run in tiers of subtree blocks
+    (one launch per tier); PASTML_HIP_NO_EIGJ_TIERS=1 gives every level its own launch.  Same passes over the same nodes:
+    ln L, arg-max tables, joint states, posteriors bit for bit -- balanced tree, ragged forest, several columns, tips of
+    every kind."""
+    rng = np.random.default_rng(600 + k)
+    for flat in (synthetic.balanced_forest(11), FlatForest.random(5000, seed=k, max_arity=4, n_trees=3)):
+        C = 2
+        specs = [(random_spec('EIGEN', k, rng), (float(rng.uniform(0.5, 2)), 0.0, 1.0)) for _ in range(C)]
+        masks = np.stack([random_masks(flat, k, rng, missing=0.1, multi=0.1, internal=0.02) for _ in range(C)])
+        out = []
+        for off in (True, False):
+            if off:
+                monkeypatch.setenv('PASTML_HIP_NO_EIGJ_TIERS', '1')
+            else:
+                monkeypatch.delenv('PASTML_HIP_NO_EIGJ_TIERS', raising=False)
+            with hip.Engine(flat, C, k) as eng:
+                eng.set_models(specs)
+                eng.set_masks(masks)
+                lnl_j = eng.bottom_up(False)
+                tables = [eng.download(hip.BUF_JOINT_TABLE, c) for c in range(C)]
+                states = eng.joint_backtrace()
+                lnl, post, lh_sum, lh_sf = eng.marginal_pass()
+            out.append((lnl_j, np.stack(tables), states, lnl, post, lh_sum, lh_sf))
+        for a, b in zip(out[0], out[1]):
+            assert np.array_equal(a, b)
