@@ -129,6 +129,14 @@ struct pml_ctx {
         int* d_nodes = nullptr;  // the node ids parallel to d_units (the sum sweeps walk node lists)
         int widest = 0;        // nodes of the widest level inside the tiers
     } eig_tiers;
+    // joint back-trace: the depths beyond its single-workgroup launch in tiers of subtrees (joint_backtrace_blocks_kernel)
+    struct BacktraceTiers {
+        bool ok = false;
+        int first_depth = 0;  // depths 1 .. first_depth - 1 stay with the single-workgroup launch
+        struct Tier { int first_block, n_blocks, depth; };
+        std::vector<Tier> tiers;
+        int *d_nodes = nullptr, *d_lv = nullptr, *d_start = nullptr;
+    } bt_tiers;
     bool small = false;  // forest small enough for the one-launch-per-sweep kernels
     bool levels_fit_workgroup = false;  // (nearly) every fused level is one pass of a 512-thread workgroup
     std::vector<int> bu_offsets_f, td_parent_offsets_f;
@@ -1527,6 +1535,68 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
                     const int pk = ub[q].packed;
                     if (((pk >> 8) & 7) == 1 || ((pk >> 11) & 7) == 1) ctx->bu_level_vec[l] = 1;
                 }
+            {
+                // joint back-trace tiers: from the first depth of more than 1 024 nodes on, tiers of up to 10 depths whose
+                // subtrees keep at most 256 nodes per depth (one pass of a workgroup per step)
+                pml_ctx::BacktraceTiers& B = ctx->bt_tiers;
+                B = pml_ctx::BacktraceTiers();
+                int d1 = 1;
+                while (d1 < n_td_levels && td_offsets[d1 + 1] - td_offsets[d1] <= 1024) ++d1;
+                if (!getenv("PASTML_HIP_NO_BT_TIERS") && n_td_levels - d1 >= 2) {
+                    std::vector<int> depth_of(n_nodes, 0), anc(n_nodes, 0), tn, lv, start;
+                    for (int l = 0; l < n_td_levels; ++l)
+                        for (int i = td_offsets[l]; i < td_offsets[l + 1]; ++i) depth_of[i] = l;
+                    int da = d1;
+                    while (da < n_td_levels) {
+                        int use = 0, nb = 0;
+                        std::vector<int> cnt;
+                        for (int dep = std::min(10, n_td_levels - da); dep >= 1; --dep) {
+                            const int db = da + dep;
+                            nb = td_offsets[da + 1] - td_offsets[da];
+                            cnt.assign((size_t)nb * dep, 0);
+                            int widest = 0;
+                            for (int i = td_offsets[da]; i < td_offsets[db]; ++i) {
+                                anc[i] = depth_of[i] == da ? i - td_offsets[da] : anc[parent[i]];
+                                widest = std::max(widest, ++cnt[(size_t)anc[i] * dep + (depth_of[i] - da)]);
+                            }
+                            if (widest <= 256 || dep == 1) {
+                                use = dep;
+                                break;
+                            }
+                        }
+                        // tables of the tier: per subtree its depth offsets into the node list
+                        pml_ctx::BacktraceTiers::Tier T;
+                        T.first_block = (int)start.size();
+                        T.n_blocks = nb;
+                        T.depth = use;
+                        const int base = (int)tn.size();
+                        std::vector<int> cell_start((size_t)nb * use + 1, 0);
+                        for (size_t q = 0; q < (size_t)nb * use; ++q) cell_start[q + 1] = cell_start[q] + cnt[q];
+                        tn.resize(base + cell_start.back());
+                        std::vector<int> cursor(cell_start.begin(), cell_start.end() - 1);
+                        for (int i = td_offsets[da]; i < td_offsets[da + use]; ++i)
+                            tn[base + cursor[(size_t)anc[i] * use + (depth_of[i] - da)]++] = i;
+                        for (int b = 0; b < nb; ++b) {
+                            start.push_back((int)lv.size());
+                            for (int d = 0; d <= use; ++d) lv.push_back(base + cell_start[(size_t)b * use + d]);
+                        }
+                        B.tiers.push_back(T);
+                        da += use;
+                    }
+                    if (!B.tiers.empty()) {
+                        tn.push_back(0);
+                        PML_TRY(dev_alloc(ctx, &B.d_nodes, tn.size()));
+                        PML_TRY(dev_alloc(ctx, &B.d_lv, lv.size()));
+                        PML_TRY(dev_alloc(ctx, &B.d_start, start.size()));
+                        PML_TRY(upload(ctx, B.d_nodes, tn.data(), tn.size()));
+                        PML_TRY(upload(ctx, B.d_lv, lv.data(), lv.size()));
+                        PML_TRY(upload(ctx, B.d_start, start.data(), start.size()));
+                        HIP_TRY(hipStreamSynchronize(ctx->stream));
+                        B.first_depth = d1;
+                        B.ok = true;
+                    }
+                }
+            }
             // Units of one shape next to each other.  Within a level the order of the units is free, and a wavefront runs
             // the union of its units' control flow: on a balanced tree every unit of a level has the same kinds of children
             // (tip / stored node / cherry of m tips), on a ragged one a wave of 8 units met most combinations and ran them
@@ -2878,11 +2948,27 @@ static int submit_joint_backtrace(pml_ctx* ctx) {
         std::vector<int> off(ctx->td_offsets.begin() + 1, ctx->td_offsets.end());
         head = narrow_levels(off, ctx->n_td_levels - 1, true, ctx->C, 1024);
     }
+    const pml_ctx::BacktraceTiers& B = ctx->bt_tiers;
+    // (tiers while one column's narrow end is the limit they were cut for: with many columns the narrow end is shorter
+    // and the depths in between keep their launches)
+    bool tiers = B.ok && 1 + head >= B.first_depth;
+    for (const pml_ctx::BacktraceTiers::Tier& T : B.tiers)
+        tiers = tiers && (long long)T.n_blocks * ctx->C <= 8192;  // (a workgroup per subtree and column: only while few)
     auto enqueue = [&]() -> int {
         if (head > 0) {
             hipLaunchKernelGGL(joint_backtrace_narrow_kernel, dim3(1, ctx->C), dim3(PML_BLOCK), 0, ctx->stream,
-                               tree_of(ctx), cols_of(ctx), state_of(ctx), ctx->d_td_offsets, 1, head);
+                               tree_of(ctx), cols_of(ctx), state_of(ctx), ctx->d_td_offsets, 1,
+                               tiers ? B.first_depth - 1 : head);
             HIP_TRY(hipGetLastError());
+        }
+        if (tiers) {
+            for (const pml_ctx::BacktraceTiers::Tier& T : B.tiers) {
+                hipLaunchKernelGGL(joint_backtrace_blocks_kernel, dim3(T.n_blocks, ctx->C), dim3(PML_BLOCK), 0, ctx->stream,
+                                   tree_of(ctx), cols_of(ctx), state_of(ctx), B.d_nodes, B.d_lv, B.d_start + T.first_block,
+                                   T.depth);
+                HIP_TRY(hipGetLastError());
+            }
+            return PML_OK;
         }
         for (int l = 1 + head; l < ctx->n_td_levels; ++l) {
             const int a = ctx->td_offsets[l], b = ctx->td_offsets[l + 1];

@@ -121,6 +121,27 @@ joint_backtrace_narrow_kernel(PmlTree t, PmlCols c, PmlState st, const int* __re
     }
 }
 
+// The depths below the narrow end in tiers: a tier of depths is cut into the subtrees hanging off its first depth, one
+// workgroup per (subtree, column) walks its depths with a workgroup barrier between them -- one launch per tier instead
+// of one per depth (the work is one table look-up per node: a depth is pure launch latency).  nodes: the tier's nodes,
+// subtree by subtree, depth by depth; subtree b's depth table starts at lv[blk_start[b]], n_depths + 1 entries.
+__global__ void __launch_bounds__(PML_BLOCK)
+joint_backtrace_blocks_kernel(PmlTree t, PmlCols c, PmlState st, const int* __restrict__ nodes,
+                              const int* __restrict__ lv, const int* __restrict__ blk_start, int n_depths) {
+    const int col = blockIdx.y;
+    const size_t colN = (size_t)col * t.N;
+    const int* off = lv + blk_start[blockIdx.x];
+    for (int d = 0; d < n_depths; ++d) {
+        const int begin = off[d], end = off[d + 1];
+        for (int q = begin + threadIdx.x; q < end; q += blockDim.x) {
+            const int n = nodes[q];
+            const int ps = st.js[colN + t.parent[n]];
+            st.js[colN + n] = st.J[(colN + n) * c.ks + ps];
+        }
+        __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // State selection from the marginal posteriors: MAP (pastml/ml.py:577-595) and MPPA (pastml/ml.py:505-574).
 // One unit = (node, column), G lanes with R contiguous states each; the unit's vectors live in LDS.
