@@ -1213,3 +1213,44 @@ def test_eigen_tiers_give_the_bits_of_one_launch_per_level(k, monkeypatch):
             out.append((lnl_j, np.stack(tables), states, lnl, post, lh_sum, lh_sf))
         for a, b in zip(out[0], out[1]):
             assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize('k', [29, 33, 64])
+def test_two_level_units_when_roots_are_two_level_nodes(k, monkeypatch):
+    """Forests of tiny balanced trees: a root with two children of two cherries each IS a two-level node -- its row comes from
+    the roots' launch, its own vector from the two-level launch, and the rest lists are empty or nearly so.  Against the
+    oracle."""
+    from pastml_amd.tree import TreeNode
+    for var, val in (('PASTML_HIP_BLOCK_NODES', '0'), ('PASTML_HIP_SMALL_MANY_NODES', '0'), ('PASTML_HIP_SMALL_MAX_NODES', '0'),
+                     ('PASTML_HIP_SUPER_MIN', '1')):
+        monkeypatch.setenv(var, val)
+    rng = np.random.default_rng(k)
+
+    def forest_of(levels):
+        roots = []
+        for n_levels in levels:
+            root = TreeNode(name='', dist=0.0)
+            level = [root]
+            for _ in range(n_levels):
+                level = [n.add_child(dist=float(rng.uniform(0.01, 0.3))) for n in level for _c in range(2)]
+            roots.append(root)
+        for ti, root in enumerate(roots):
+            for i, n in enumerate(root.traverse('preorder')):
+                n.name = 't{}_{}'.format(ti, i) if n.is_leaf() else 'n{}_{}'.format(ti, i)
+        return FlatForest.from_trees(roots)
+
+    for levels in ([3], [3, 3, 3], [3, 4, 2], [5]):
+        flat = forest_of(levels)
+        C = 2
+        specs = [(random_spec('F81', k, rng), (1.3, 0.0, 1.0)) for _ in range(C)]
+        masks = np.stack([random_masks(flat, k, rng, missing=0.1, multi=0.1, internal=0.0) for _ in range(C)])
+        with hip.Engine(flat, C, k) as eng:
+            eng.set_models(specs)
+            eng.set_masks(masks)
+            eng.profile_enable(True)
+            lnl, post, lh_sum, lh_sf = eng.marginal_pass()
+            assert eng.profile_read(3)[1] > 0 and eng.profile_read(4)[1] > 0
+        for c in range(C):
+            r = orc.full_marginal_pass(flat, masks[c].astype(int), specs[c][0], *specs[c][1])
+            np.testing.assert_allclose(lnl[c], r['loglik'], rtol=LNL_RTOL)
+            np.testing.assert_allclose(post[c], r['posterior'], rtol=1e-8, atol=1e-12)
