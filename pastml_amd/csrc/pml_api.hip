@@ -1552,22 +1552,21 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
                         for (int i = td_offsets[l]; i < td_offsets[l + 1]; ++i) depth_of[i] = l;
                     int da = d1;
                     while (da < n_td_levels) {
-                        int use = 0, nb = 0;
-                        std::vector<int> cnt;
-                        for (int dep = std::min(10, n_td_levels - da); dep >= 1; --dep) {
-                            const int db = da + dep;
-                            nb = td_offsets[da + 1] - td_offsets[da];
-                            cnt.assign((size_t)nb * dep, 0);
-                            int widest = 0;
-                            for (int i = td_offsets[da]; i < td_offsets[db]; ++i) {
-                                anc[i] = depth_of[i] == da ? i - td_offsets[da] : anc[parent[i]];
-                                widest = std::max(widest, ++cnt[(size_t)anc[i] * dep + (depth_of[i] - da)]);
-                            }
-                            if (widest <= 256 || dep == 1) {
-                                use = dep;
-                                break;
-                            }
+                        // one counting pass over up to 10 depths: nodes per (subtree, depth), the widest cell of every
+                        // depth; the tier takes the depths before the first one that is too wide
+                        const int dmax = std::min(10, n_td_levels - da);
+                        const int nb = td_offsets[da + 1] - td_offsets[da];
+                        std::vector<int> cnt10((size_t)nb * dmax, 0), widest(dmax, 0);
+                        for (int i = td_offsets[da]; i < td_offsets[da + dmax]; ++i) {
+                            const int dd = depth_of[i] - da;
+                            anc[i] = dd == 0 ? i - td_offsets[da] : anc[parent[i]];
+                            widest[dd] = std::max(widest[dd], ++cnt10[(size_t)anc[i] * dmax + dd]);
                         }
+                        int use = 1;
+                        while (use < dmax && widest[use] <= 256) ++use;
+                        std::vector<int> cnt((size_t)nb * use);
+                        for (int b = 0; b < nb; ++b)
+                            for (int d = 0; d < use; ++d) cnt[(size_t)b * use + d] = cnt10[(size_t)b * dmax + d];
                         // tables of the tier: per subtree its depth offsets into the node list
                         pml_ctx::BacktraceTiers::Tier T;
                         T.first_block = (int)start.size();
@@ -1609,17 +1608,26 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
             // neighbouring memory.  262 144-tip random binary tree x 32 characters, k = 64: marginal pass 6.5 -> 5.7 ms;
             // 100 000 tips with polytomies: 2.86 -> 2.13 ms; narrow units (k = 4: 64 units per wave, every lane its own
             // rows) lose 20 % to the scattered rows and keep id order.  PASTML_HIP_NO_SHAPE_SORT: id order everywhere.
+            auto shape_less = [](const PmlUnit& x, const PmlUnit& y) { return x.packed < y.packed; };
+            auto in_shape_order = [&](const std::vector<PmlUnit>& in, const std::vector<int>& offs, size_t count) {
+                for (size_t l = 0; l + 1 < offs.size(); ++l) {
+                    const size_t a = (size_t)offs[l], b = std::min((size_t)offs[l + 1], count);
+                    if (b > a + 1 && !std::is_sorted(in.begin() + a, in.begin() + b, shape_less)) return false;
+                }
+                return true;
+            };
             auto by_shape = [&](const std::vector<PmlUnit>& in, const std::vector<int>& offs, size_t count) {
                 std::vector<PmlUnit> out(in);
                 for (size_t l = 0; l + 1 < offs.size(); ++l) {
                     const size_t a = (size_t)offs[l], b = std::min((size_t)offs[l + 1], count);
-                    if (b > a + 1)
-                        std::stable_sort(out.begin() + a, out.begin() + b,
-                                         [](const PmlUnit& x, const PmlUnit& y) { return x.packed < y.packed; });
+                    if (b > a + 1) std::stable_sort(out.begin() + a, out.begin() + b, shape_less);
                 }
                 return out;
             };
-            const bool shape_sort = !getenv("PASTML_HIP_NO_SHAPE_SORT") && n_stored > 0;
+            // (a balanced tree is in shape order as it is: no second copy, the launches walk the id-ordered lists)
+            const bool shape_sort = !getenv("PASTML_HIP_NO_SHAPE_SORT") && n_stored > 0 &&
+                                    !(in_shape_order(ub_f, off, (size_t)n_stored) &&
+                                      in_shape_order(ut_f, ctx->td_parent_offsets_f, (size_t)n_stored));
             if (shape_sort) {
                 const std::vector<PmlUnit> sb = by_shape(ub_f, off, (size_t)n_stored);
                 const std::vector<PmlUnit> st_ = by_shape(ut_f, ctx->td_parent_offsets_f, (size_t)n_stored);
