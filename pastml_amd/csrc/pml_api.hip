@@ -111,6 +111,11 @@ struct pml_ctx {
         PmlUnit* d_child_units = nullptr;  // the 2 n children of the two-level units, as units of their own (downloads)
         PmlUnit *d_bu_units_r = nullptr, *d_td_units_r = nullptr;
         PmlUnit *d_bu_units_rs = nullptr, *d_td_units_rs = nullptr;  // ... sorted by shape inside every level
+        // stacked units (pml_kernels_f81.h): nodes with two plain stored children of two stored children each, by
+        // bottom-up level and by depth; their children as units of their own for downloads
+        int n_stack = 0;
+        PmlUnit *d_stack_bu = nullptr, *d_stack_td = nullptr, *d_stack_children = nullptr;
+        std::vector<int> stack_bu_offsets, stack_td_offsets;
         int *d_bu_offsets_r = nullptr, *d_td_offsets_r = nullptr;
         std::vector<int> bu_offsets_r, td_offsets_r;
         std::vector<char> bu_level_vec_r;
@@ -775,6 +780,20 @@ static void launch_super_f81(pml_ctx* ctx, bool bottom_up) {
         hipLaunchKernelGGL((td_f81_super_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, ctx->sup.d_units, ctx->sup.n);
 }
 
+// stacked units of bottom-up level / depth `level` (pml_kernels_f81.h)
+template <int G, int R>
+static void launch_stack_f81(pml_ctx* ctx, bool bottom_up, int a, int n) {
+    const PmlTree t = tree_of(ctx, true);
+    const PmlCols c = cols_of(ctx);
+    const PmlState st = state_of(ctx);
+    const int upb = PML_WAVES_PER_BLOCK * (64 / G);
+    dim3 grid(grid_for(bottom_up ? n : 2 * n, upb, ctx->C), ctx->C), block(PML_BLOCK);
+    if (bottom_up)
+        hipLaunchKernelGGL((bu_f81_stack_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, ctx->sup.d_stack_bu + a, n);
+    else
+        hipLaunchKernelGGL((td_f81_stack_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, ctx->sup.d_stack_td + a, n);
+}
+
 #define PML_SUPER_CASES(X) \
     X(8, 4)                \
     X(16, 4)               \
@@ -792,6 +811,24 @@ static int dispatch_super_f81(pml_ctx* ctx, bool bottom_up) {
     PML_SUPER_CASES(X)
 #undef X
     return fail(PML_ERR_UNSUPPORTED, "no two-level F81 kernel for G=%d R=%d", g, r);
+}
+
+static int dispatch_stack_f81(pml_ctx* ctx, bool bottom_up, int level) {
+    const std::vector<int>& off = bottom_up ? ctx->sup.stack_bu_offsets : ctx->sup.stack_td_offsets;
+    if (ctx->sup.n_stack == 0 || level + 1 >= (int)off.size()) return PML_OK;
+    const int a = off[level], n = off[level + 1] - a;
+    if (n <= 0) return PML_OK;
+    int g, r;
+    super_shape(ctx, bottom_up, g, r);
+#define X(G_, R_)                                         \
+    if (g == G_ && r == R_) {                             \
+        launch_stack_f81<G_, R_>(ctx, bottom_up, a, n);   \
+        HIP_TRY(hipGetLastError());                       \
+        return PML_OK;                                    \
+    }
+    PML_SUPER_CASES(X)
+#undef X
+    return fail(PML_ERR_UNSUPPORTED, "no stacked F81 kernel for G=%d R=%d", g, r);
 }
 
 // fused eigen sweeps: one launch over a list (nodes) or a contiguous id range (first) of n nodes
@@ -1689,6 +1726,65 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
                     u.pad = first_child[u.cfc[0]];
                     us[q] = u;
                 }
+                // stacked units: ascending height, a node takes its two children over when both are plain units (not
+                // two-level nodes, not taken over, not stacked themselves) with two stored children whose vectors are in
+                // memory; only on levels of 1 024 .. 65 536 nodes (below: the narrow end's single launch; above: the
+                // streaming levels' other lane shape)
+                std::vector<char> stacked(n_nodes, 0), taken(n_nodes, 0), novec(n_nodes, 0);
+                std::vector<int> stack_list;
+                // (PASTML_HIP_STACK_MIN: smallest level that gets stacked units -- tests on small forests)
+                const int stack_min = getenv("PASTML_HIP_STACK_MIN") ? atoi(getenv("PASTML_HIP_STACK_MIN")) : 1024;
+                if (!getenv("PASTML_HIP_NO_STACK")) {
+                    for (int n : sup_list) novec[first_child[n]] = novec[first_child[n] + 1] = 1;
+                    auto level_size = [&](int node) { return off[fh[node]] - off[fh[node] - 1]; };
+                    auto has_vec = [&](int g) { return kind[g] == PML_KIND_STORED && !novec[g]; };
+                    auto plain2 = [&](int ch) {
+                        return kind[ch] == PML_KIND_STORED && !gone[ch] && !stacked[ch] && !taken[ch] && n_children[ch] == 2 &&
+                               has_vec(first_child[ch]) && has_vec(first_child[ch] + 1) && level_size(ch) <= 65536;
+                    };
+                    for (int q = 0; q < n_stored; ++q) {
+                        const int n = order[q];
+                        if (gone[n] || taken[n] || n_children[n] != 2 || level_size(n) < stack_min || level_size(n) > 65536) continue;
+                        const int a = first_child[n], b = a + 1;
+                        if (!plain2(a) || !plain2(b)) continue;
+                        stacked[n] = 1;
+                        taken[a] = taken[b] = novec[a] = novec[b] = 1;
+                        stack_list.push_back(n);
+                    }
+                }
+                for (int n : stack_list) gone[n] = gone[first_child[n]] = gone[first_child[n] + 1] = 1;
+                if (!stack_list.empty()) {
+                    std::vector<int> depth_of(n_nodes, 0);
+                    for (int l = 0; l < n_td_levels; ++l)
+                        for (int i = td_offsets[l]; i < td_offsets[l + 1]; ++i) depth_of[i] = l;
+                    // by bottom-up level (stack_list is in that order already) and by depth
+                    U.stack_bu_offsets.assign(max_h + 1, 0);
+                    for (int n : stack_list) ++U.stack_bu_offsets[fh[n]];
+                    for (int l = 0; l < max_h; ++l) U.stack_bu_offsets[l + 1] += U.stack_bu_offsets[l];
+                    std::vector<int> by_depth(stack_list);
+                    std::stable_sort(by_depth.begin(), by_depth.end(), [&](int x, int y) { return depth_of[x] < depth_of[y]; });
+                    U.stack_td_offsets.assign(n_td_levels + 1, 0);
+                    for (int n : by_depth) ++U.stack_td_offsets[depth_of[n] + 1];
+                    for (int l = 0; l < n_td_levels; ++l) U.stack_td_offsets[l + 1] += U.stack_td_offsets[l];
+                    std::vector<PmlUnit> sb, sd, sc;
+                    describe(stack_list.data(), (int)stack_list.size(), true, sb);
+                    describe(by_depth.data(), (int)by_depth.size(), true, sd);
+                    std::vector<int> ch_list;
+                    for (int n : stack_list) {
+                        ch_list.push_back(first_child[n]);
+                        ch_list.push_back(first_child[n] + 1);
+                    }
+                    describe(ch_list.data(), (int)ch_list.size(), true, sc);
+                    PML_TRY(dev_alloc(ctx, &U.d_stack_bu, sb.size()));
+                    PML_TRY(dev_alloc(ctx, &U.d_stack_td, sd.size()));
+                    PML_TRY(dev_alloc(ctx, &U.d_stack_children, sc.size()));
+                    PML_TRY(upload(ctx, U.d_stack_bu, sb.data(), sb.size()));
+                    PML_TRY(upload(ctx, U.d_stack_td, sd.data(), sd.size()));
+                    PML_TRY(upload(ctx, U.d_stack_children, sc.data(), sc.size()));
+                    HIP_TRY(hipStreamSynchronize(ctx->stream));
+                    U.n_stack = (int)stack_list.size();
+                    if (getenv("PASTML_HIP_DEBUG")) fprintf(stderr, "pastml_hip: %d stacked units\n", U.n_stack);
+                }
                 // rest lists: the level structure of the fused lists, without the nodes the two-level units take over
                 std::vector<int> bu_r, td_r;
                 U.bu_offsets_r.assign(1, 0);
@@ -2427,17 +2523,30 @@ static int enqueue_bottom_up(pml_ctx* ctx, int is_marginal, bool small_path, boo
         PML_TRY(prof_end(ctx, 4, 1));
         PML_TRY(prof_begin(ctx));
         const int nl = (int)U.bu_offsets_r.size() - 1;
-        const int tail = narrow_levels(U.bu_offsets_r, nl, false, ctx->C);
+        int tail = narrow_levels(U.bu_offsets_r, nl, false, ctx->C);
+        // (the narrow end's single launch walks the rest lists only: it starts above the last level with stacked units)
+        for (int l = nl - 1; l >= 0 && U.n_stack > 0; --l)
+            if (U.stack_bu_offsets[l + 1] > U.stack_bu_offsets[l]) {
+                tail = std::min(tail, nl - 1 - l);
+                break;
+            }
+        if (tail < 2) tail = 0;
         long long n_launch = 0;
         for (int l = 0; l < nl - tail; ++l) {
             const int a = U.bu_offsets_r[l], b = U.bu_offsets_r[l + 1];
-            if (b <= a) continue;
-            ctx->units_override = (ctx->bu_wide_lanes && U.d_bu_units_rs ? U.d_bu_units_rs : U.d_bu_units_r) + a;
-            const int status = dispatch_sweep(ctx, U.bu_level_vec_r[l] ? SW_BU_MARG_FUSED : SW_BU_MARG_FUSED_NOVEC,
-                                              ctx->d_bu_order_f, b - a);
-            ctx->units_override = nullptr;
-            PML_TRY(status);
-            ++n_launch;
+            if (b > a) {
+                ctx->units_override = (ctx->bu_wide_lanes && U.d_bu_units_rs ? U.d_bu_units_rs : U.d_bu_units_r) + a;
+                const int status = dispatch_sweep(ctx, U.bu_level_vec_r[l] ? SW_BU_MARG_FUSED : SW_BU_MARG_FUSED_NOVEC,
+                                                  ctx->d_bu_order_f, b - a);
+                ctx->units_override = nullptr;
+                PML_TRY(status);
+                ++n_launch;
+            }
+            // the level's stacked units (they read vectors of two levels down: independent of the launch above)
+            if (U.n_stack > 0 && U.stack_bu_offsets[l + 1] > U.stack_bu_offsets[l]) {
+                PML_TRY(dispatch_stack_f81(ctx, true, l));
+                ++n_launch;
+            }
         }
         PML_TRY(prof_end(ctx, 0, n_launch));
         if (tail > 0) {
@@ -2718,19 +2827,32 @@ static int run_top_down(pml_ctx* ctx) {
             // the levels of the rest lists, then every two-level unit in one launch (it needs its node's row only, and
             // that comes from a unit of the rest lists or from the roots)
             const pml_ctx::SuperSchedule& U = ctx->sup;
-            const int head = ctx->n_roots <= 64 ? narrow_levels(U.td_offsets_r, ctx->n_td_levels, true, ctx->C) : 0;
+            int head = ctx->n_roots <= 64 ? narrow_levels(U.td_offsets_r, ctx->n_td_levels, true, ctx->C) : 0;
+            // (... and the single launch below the roots ends above the first depth with stacked nodes)
+            for (int l = 0; l < ctx->n_td_levels && U.n_stack > 0; ++l)
+                if (U.stack_td_offsets[l + 1] > U.stack_td_offsets[l]) {
+                    head = std::min(head, l);
+                    break;
+                }
+            if (head < 2) head = 0;
             if (head == 0) PML_TRY(dispatch_sweep(ctx, SW_ROOTS, nullptr, ctx->n_roots));
             if (head > 0) PML_TRY(dispatch_small_f81(ctx, false, 0, 0, head, U.d_td_units_r, U.d_td_offsets_r));
             PML_TRY(prof_begin(ctx));
             long long n_launch = 0;
             for (int l = head; l < ctx->n_td_levels; ++l) {
                 const int a = U.td_offsets_r[l], b = U.td_offsets_r[l + 1];
-                if (b <= a) continue;
-                ctx->units_override = (ctx->bu_wide_lanes && U.d_td_units_rs ? U.d_td_units_rs : U.d_td_units_r) + a;
-                const int status = dispatch_sweep(ctx, SW_TD_FUSED, ctx->d_td_parents_f, b - a);
-                ctx->units_override = nullptr;
-                PML_TRY(status);
-                ++n_launch;
+                if (b > a) {
+                    ctx->units_override = (ctx->bu_wide_lanes && U.d_td_units_rs ? U.d_td_units_rs : U.d_td_units_r) + a;
+                    const int status = dispatch_sweep(ctx, SW_TD_FUSED, ctx->d_td_parents_f, b - a);
+                    ctx->units_override = nullptr;
+                    PML_TRY(status);
+                    ++n_launch;
+                }
+                // the children of the stacked nodes of this depth (their rows come from the depth above)
+                if (U.n_stack > 0 && U.stack_td_offsets[l + 1] > U.stack_td_offsets[l]) {
+                    PML_TRY(dispatch_stack_f81(ctx, false, l));
+                    ++n_launch;
+                }
             }
             PML_TRY(prof_end(ctx, 1, n_launch));
             PML_TRY(prof_begin(ctx));
@@ -3189,6 +3311,14 @@ static int materialize_cherries(pml_ctx* ctx) {
         const int status = dispatch_sweep(ctx, SW_BU_MARG_FUSED_NOVEC, ctx->d_bu_order_f, 2 * ctx->sup.n);
         ctx->units_override = nullptr;
         PML_TRY(status);
+        // ... and the children of the stacked units (two stored children each; in chunks of at most 65 536 units: the
+        // lane shape, hence the rounding of pi . v, of the levels they were taken from)
+        for (int a = 0; a < 2 * ctx->sup.n_stack; a += 65536) {
+            ctx->units_override = ctx->sup.d_stack_children + a;
+            const int st2 = dispatch_sweep(ctx, SW_BU_MARG_FUSED, ctx->d_bu_order_f, std::min(65536, 2 * ctx->sup.n_stack - a));
+            ctx->units_override = nullptr;
+            PML_TRY(st2);
+        }
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         ctx->bu_absorbed = false;
     }

@@ -2100,6 +2100,197 @@ td_f81_super_kernel(PmlTree t, PmlCols c, PmlState st, const PmlUnit* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Stacked units (round 3): the two-level idea above the tips.  A stored node n with two plain stored children that each
+// have two stored children (whose vectors are in memory) runs, bottom-up, its children's units and its own in one unit:
+// four vectors in, one out -- the children's vectors are not written (pi . v and the exponent are), nor read back.
+// Top-down there is one unit per child c: it rebuilds c's vector from its two children's vectors (which it needs anyway),
+// finishes c from n's row, then c's two children from the row it has just formed.  The level kernels' bodies with their
+// arguments, in their lane shape: the same bits.  Descriptor: the standard one of n (cfc[j] = first child of child j).
+// ---------------------------------------------------------------------------------------------------------------------
+struct StackRegs {
+    int n, fc, g0, g1;
+};
+
+__device__ __forceinline__ StackRegs load_stack(const PmlUnit* __restrict__ units, int idx) {
+    const int4 h = *reinterpret_cast<const int4*>(units + idx);
+    const int4 f = *reinterpret_cast<const int4*>(units[idx].cfc);
+    StackRegs s;
+    s.n = h.x;
+    s.fc = h.y;
+    s.g0 = f.x;
+    s.g1 = f.y;
+    return s;
+}
+
+__device__ __forceinline__ UnitRegs stack_child(const StackRegs& s, int j) {
+    UnitRegs u;
+    u.n = s.fc + j;
+    u.fc = j ? s.g1 : s.g0;
+    u.packed = PML_PACKED_TWO_STORED;
+    u.cfc = u.cfc1 = u.cfc2 = u.cfc3 = 0;
+    return u;
+}
+
+// what a unit with two stored children reads about them: lane j < 2 holds child j's scalars, the vectors in v0 / v1
+template <int G, int R>
+__device__ __forceinline__ void stack_child_loads(const LaneCtx<G, R>& L, const PmlCols& c, int node, int first,
+                                                  BuLoads<R>& ld) {
+    const int ch = first + (L.g & 1);
+    ld.cl.e = L.E[ch];
+    ld.cl.s = L.S[ch];
+    ld.cl.be = L.be[ch];
+    ld.cl.mask = 0ull;
+    ld.tl.e = ld.tl.s = ld.tl.a = 0.0;
+    ld.tl.mask = 0ull;
+    ld.own = L.mask[(unsigned)node];
+    node_load_vec<G, R>(L, c, L.bu, first, ld.v0);
+    node_load_vec<G, R>(L, c, L.bu, first + 1, ld.v1);
+}
+
+template <int G, int R>
+__device__ __forceinline__ bool bu_f81_stack_unit(const LaneCtx<G, R>& L, const PmlTree& t, const PmlCols& c,
+                                                  const PmlState& st, const StackRegs& s) {
+    BuLoads<R> ld[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) stack_child_loads<G, R>(L, c, s.fc + j, j ? s.g1 : s.g0, ld[j]);
+    const double e_top = L.E[s.fc + (L.g & 1)];
+    const u64 own = L.mask[(unsigned)s.n];
+    BuResult<R> res[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+        if (!bu_f81_marg_body<G, R, true, false>(L, t, c, st, stack_child(s, j), ld[j], &res[j], false)) return false;
+    BuLoads<R> top;
+    top.cl.e = e_top;
+    top.cl.s = (L.g & 1) ? res[1].s : res[0].s;
+    top.cl.be = (L.g & 1) ? res[1].e : res[0].e;
+    top.cl.mask = 0ull;
+    top.tl.e = top.tl.s = top.tl.a = 0.0;
+    top.tl.mask = 0ull;
+    top.own = own;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        top.v0[r] = res[0].v[r];
+        top.v1[r] = res[1].v[r];
+    }
+    UnitRegs un;
+    un.n = s.n;
+    un.fc = s.fc;
+    un.packed = PML_PACKED_TWO_STORED;
+    un.cfc = un.cfc1 = un.cfc2 = un.cfc3 = 0;
+    return bu_f81_marg_body<G, R, true, false>(L, t, c, st, un, top);
+}
+
+template <int G, int R>
+__global__ void __launch_bounds__(PML_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
+bu_f81_stack_kernel(PmlTree t, PmlCols c, PmlState st, const PmlUnit* __restrict__ units, int n_level) {
+    constexpr int UW = 64 / G;
+    const int wave = threadIdx.x >> 6;
+    const int sub = (threadIdx.x & 63) / G;
+    LaneCtx<G, R> L;
+    lane_ctx_init<G, R>(L, t, c, st);
+    const int stride = gridDim.x * PML_WAVES_PER_BLOCK * UW;
+    int idx = (blockIdx.x * PML_WAVES_PER_BLOCK + wave) * UW + sub;
+    StackRegs cur = load_stack(units, idx < n_level ? idx : 0);
+    for (int base = idx - sub; base < n_level; base += stride) {
+        const int nxt_idx = idx + stride;
+        const StackRegs nxt = load_stack(units, nxt_idx < n_level ? nxt_idx : 0);
+        if (idx < n_level) {
+            if (!bu_f81_stack_unit<G, R>(L, t, c, st, cur)) {
+                // an all-zero vector: the three units on the sequential path, which names the pair the reference would
+                bu_f81_unit_seq<G, R, false>(L, t, c, st, stack_child(cur, 0));
+                bu_f81_unit_seq<G, R, false>(L, t, c, st, stack_child(cur, 1));
+                __threadfence();
+                UnitRegs un = stack_child(cur, 0);
+                un.n = cur.n;
+                un.fc = cur.fc;
+                bu_f81_unit_seq<G, R, false>(L, t, c, st, un);
+            }
+        }
+        cur = nxt;
+        idx = nxt_idx;
+    }
+}
+
+// top-down: unit i is child i & 1 of stacked node i >> 1
+template <int G, int R>
+__device__ __forceinline__ void td_f81_stack_unit(const LaneCtx<G, R>& L, const PmlTree& t, const PmlCols& c,
+                                                  const PmlState& st, const StackRegs& s, int j) {
+    const u64 kbits = state_bits(c.k);
+    const int ch = s.fc + j;
+    const int first = j ? s.g1 : s.g0;
+    double prod[R];
+    i64 pe;
+    f81_parent_prod<G, R>(L, c, s.n, prod, pe);
+    const double e = L.E[ch];
+    const double s_child = L.S[ch];
+    const i64 bec = L.be[ch];
+    BuLoads<R> ld;
+    stack_child_loads<G, R>(L, c, ch, first, ld);
+    // the grandchildren's masks (for their own rows): lane j < 2
+    const u64 gmask = L.mask[(unsigned)(first + (L.g & 1))] & kbits;
+    ld.own &= kbits;
+    BuResult<R> v;
+    double g0v[R], g1v[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        g0v[r] = ld.v0[r];
+        g1v[r] = ld.v1[r];
+    }
+    bu_f81_marg_body<G, R, true, false>(L, t, c, st, stack_child(s, j), ld, &v, false, true);
+    double prod2[R];
+    i64 pe2;
+    {
+        double mb[R], tdc[R], po[R], ls;
+        const bool full = ld.own == kbits;
+        if (!full) clean_word_to_vec<G, R>(L, c, ld.own, mb);
+        i64 xe;
+        f81_finish_child<G, R>(L, c, prod, pe, ch, e, s_child, bec, v.v, full, mb, tdc, xe, po, ls, pe2);
+        if (st.td != nullptr) {
+            node_store_vec<G, R>(L, c, L.td, ch, tdc);
+            if (L.g == 0) L.te[ch] = xe;
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) prod2[r] = po[r] * (ls * L.ipi_r[r]);  // f81_parent_prod on the row just stored
+    }
+#pragma unroll
+    for (int jx = 0; jx < 2; ++jx) {
+        const int src = L.group_base + jx;
+        const u64 word = __shfl(gmask, src, 64);
+        double mb[R], tdc[R], po[R], ls;
+        const bool full = word == kbits;
+        if (!full) clean_word_to_vec<G, R>(L, c, word, mb);
+        i64 xe, le;
+        f81_finish_child<G, R>(L, c, prod2, pe2, first + jx, __shfl(ld.cl.e, src, 64), __shfl(ld.cl.s, src, 64),
+                               __shfl(ld.cl.be, src, 64), jx ? g1v : g0v, full, mb, tdc, xe, po, ls, le);
+        if (st.td != nullptr) {
+            node_store_vec<G, R>(L, c, L.td, first + jx, tdc);
+            if (L.g == 0) L.te[first + jx] = xe;
+        }
+    }
+}
+
+template <int G, int R>
+__global__ void __launch_bounds__(PML_BLOCK)
+td_f81_stack_kernel(PmlTree t, PmlCols c, PmlState st, const PmlUnit* __restrict__ units, int n_level) {
+    constexpr int UW = 64 / G;
+    const int wave = threadIdx.x >> 6;
+    const int sub = (threadIdx.x & 63) / G;
+    LaneCtx<G, R> L;
+    lane_ctx_init<G, R>(L, t, c, st);
+    const int n_units = 2 * n_level;
+    const int stride = gridDim.x * PML_WAVES_PER_BLOCK * UW;
+    int idx = (blockIdx.x * PML_WAVES_PER_BLOCK + wave) * UW + sub;
+    StackRegs cur = load_stack(units, idx < n_units ? idx >> 1 : 0);
+    for (int base = idx - sub; base < n_units; base += stride) {
+        const int nxt_idx = idx + stride;
+        const StackRegs nxt = load_stack(units, nxt_idx < n_units ? nxt_idx >> 1 : 0);
+        if (idx < n_units) td_f81_stack_unit<G, R>(L, t, c, st, cur, idx & 1);
+        cur = nxt;
+        idx = nxt_idx;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Small forests: the whole sweep in ONE launch.  One workgroup per column walks the levels with a workgroup barrier
 // between them, so a sweep costs one kernel launch instead of one per level (a 150-tip tree has ~16 levels of a few
 // nodes each: the level-per-launch schedule is pure launch latency there, and the optimiser repeats the bottom-up

@@ -152,6 +152,7 @@ def test_random_case_with_two_level_units(seed, monkeypatch):
     monkeypatch.setenv('PASTML_HIP_SMALL_MANY_NODES', '0')
     monkeypatch.setenv('PASTML_HIP_SMALL_MAX_NODES', '0')
     monkeypatch.setenv('PASTML_HIP_SUPER_MIN', '1')
+    monkeypatch.setenv('PASTML_HIP_STACK_MIN', '1')
     rng = np.random.default_rng(70_000 + seed)
     k = int(rng.choice([29, 31, 32, 33, 40, 48, 63, 64]))
     flat = _forest_with_balanced_clumps(int(rng.integers(20, 120)), seed=seed, clump_frac=float(rng.uniform(0.3, 0.9)))

@@ -1084,6 +1084,7 @@ def test_two_level_units_give_the_bits_of_the_level_schedule(k, monkeypatch):
     monkeypatch.setenv('PASTML_HIP_BLOCK_NODES', '0')       # level launches, not subtree blocks
     monkeypatch.setenv('PASTML_HIP_SMALL_MANY_NODES', '0')
     monkeypatch.setenv('PASTML_HIP_SUPER_MIN', '1')
+    monkeypatch.setenv('PASTML_HIP_STACK_MIN', '1')
     rng = np.random.default_rng(900 + k)
     forests = [synthetic.balanced_forest(12), _forest_with_balanced_clumps(700, seed=k)]
     for fi, flat in enumerate(forests):
@@ -1125,6 +1126,7 @@ def test_two_level_units_report_the_reference_pair_on_zero_likelihood(monkeypatc
     monkeypatch.setenv('PASTML_HIP_BLOCK_NODES', '0')
     monkeypatch.setenv('PASTML_HIP_SMALL_MANY_NODES', '0')
     monkeypatch.setenv('PASTML_HIP_SUPER_MIN', '1')
+    monkeypatch.setenv('PASTML_HIP_STACK_MIN', '1')
     k = 64
     flat = synthetic.balanced_forest(12)
     rng = np.random.default_rng(5)
@@ -1222,7 +1224,7 @@ def test_two_level_units_when_roots_are_two_level_nodes(k, monkeypatch):
     oracle."""
     from pastml_amd.tree import TreeNode
     for var, val in (('PASTML_HIP_BLOCK_NODES', '0'), ('PASTML_HIP_SMALL_MANY_NODES', '0'), ('PASTML_HIP_SMALL_MAX_NODES', '0'),
-                     ('PASTML_HIP_SUPER_MIN', '1')):
+                     ('PASTML_HIP_SUPER_MIN', '1'), ('PASTML_HIP_STACK_MIN', '1')):
         monkeypatch.setenv(var, val)
     rng = np.random.default_rng(k)
 
