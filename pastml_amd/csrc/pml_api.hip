@@ -800,6 +800,7 @@ static void launch_stack_f81(pml_ctx* ctx, bool bottom_up, int a, int n) {
     X(8, 8)
 
 static int dispatch_super_f81(pml_ctx* ctx, bool bottom_up) {
+    if (ctx->sup.n <= 0) return PML_OK;  // (a schedule of stacked units only)
     int g, r;
     super_shape(ctx, bottom_up, g, r);
 #define X(G_, R_)                                   \
@@ -1711,9 +1712,25 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
             const int min_units = env_min ? atoi(env_min) : 64;
             // (a launch of its own per sweep: only where it carries a share of the work)
             // (PASTML_HIP_SUPER_MIN given: whatever their share, for tests on ragged forests)
-            if (!sup_list.empty() && (int)sup_list.size() >= min_units &&
-                (env_min != nullptr || (long long)sup_list.size() * 16 >= n_stored)) {
-                std::vector<PmlUnit> us(sup_list.size());
+            const bool use_sup = !sup_list.empty() && (int)sup_list.size() >= min_units &&
+                                 (env_min != nullptr || (long long)sup_list.size() * 16 >= n_stored);
+            if (!use_sup) {  // (too few: no launch of their own; the stacked units below may still pay)
+                for (int n : sup_list) gone[n] = gone[first_child[n]] = gone[first_child[n] + 1] = 0;
+                sup_list.clear();
+            }
+            // (the rest-list schedule needs wide units and a forest beyond the subtree blocks' reach to be used at all:
+            // super_sweeps; here only the tree is known)
+            if (ctx->fuse && !getenv("PASTML_HIP_NO_SUPER") && n_stored > 0) {
+                std::vector<PmlUnit> us(std::max<size_t>(1, sup_list.size()));
+                {
+                    PmlUnit u;   // (padding element of the lists below when there are no two-level units)
+                    u.n = order[0];
+                    u.fc = first_child[order[0]];
+                    u.packed = 0;
+                    u.pad = 0;
+                    u.cfc[0] = u.cfc[1] = u.cfc[2] = u.cfc[3] = 0;
+                    us[0] = u;
+                }
                 for (size_t q = 0; q < sup_list.size(); ++q) {
                     const int n = sup_list[q];
                     PmlUnit u;
@@ -1752,6 +1769,13 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
                         stack_list.push_back(n);
                     }
                 }
+                // (A level with stacked units costs a launch more per sweep: they pay where they take most of what the
+                // two-level units leave -- the balanced part of a tree -- and not at a tenth of the nodes: a random binary
+                // tree of 262 144 tips had 6 132 of them, 10 % of its stored nodes, and was 3 % slower with them.
+                // PASTML_HIP_STACK_MIN given: whatever their share.)
+                if (getenv("PASTML_HIP_STACK_MIN") == nullptr &&
+                    (long long)stack_list.size() * 3 * 2 < (long long)n_stored - 3 * (long long)sup_list.size())
+                    stack_list.clear();
                 for (int n : stack_list) gone[n] = gone[first_child[n]] = gone[first_child[n] + 1] = 1;
                 if (!stack_list.empty()) {
                     std::vector<int> depth_of(n_nodes, 0);
@@ -1785,6 +1809,7 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
                     U.n_stack = (int)stack_list.size();
                     if (getenv("PASTML_HIP_DEBUG")) fprintf(stderr, "pastml_hip: %d stacked units\n", U.n_stack);
                 }
+                if (!sup_list.empty() || !stack_list.empty()) {  // (else: the plain level lists, nothing to build)
                 // rest lists: the level structure of the fused lists, without the nodes the two-level units take over
                 std::vector<int> bu_r, td_r;
                 U.bu_offsets_r.assign(1, 0);
@@ -1806,7 +1831,7 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
                         ch_list.push_back(first_child[n]);
                         ch_list.push_back(first_child[n] + 1);
                     }
-                    describe(ch_list.data(), (int)ch_list.size(), true, uch);
+                    describe(ch_list.data(), (int)ch_list.size(), true, uch);  // (at least one element)
                     PML_TRY(dev_alloc(ctx, &U.d_child_units, uch.size()));
                     PML_TRY(upload(ctx, U.d_child_units, uch.data(), uch.size()));
                 }
@@ -1842,10 +1867,13 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
                 PML_TRY(upload(ctx, U.d_bu_offsets_r, U.bu_offsets_r.data(), U.bu_offsets_r.size()));
                 PML_TRY(upload(ctx, U.d_td_offsets_r, U.td_offsets_r.data(), U.td_offsets_r.size()));
                 HIP_TRY(hipStreamSynchronize(ctx->stream));  // the vectors go out of scope
-                U.n = (int)us.size();
-                U.ok = true;
+                U.n = (int)sup_list.size();
+                // worth its lists: two-level units, or stacked units that take a sixteenth of the stored nodes over
+                U.ok = U.n > 0 || U.n_stack >= 64 || (U.n_stack > 0 && getenv("PASTML_HIP_STACK_MIN") != nullptr);
                 if (getenv("PASTML_HIP_DEBUG"))
-                    fprintf(stderr, "pastml_hip: %d two-level units (%d of %d stored nodes)\n", U.n, 3 * U.n, n_stored);
+                    fprintf(stderr, "pastml_hip: %d two-level units (%d of %d stored nodes)%s\n", U.n, 3 * U.n, n_stored,
+                            U.ok ? "" : " -- plain level lists");
+                }
             }
         }
         // ---- subtree blocks: stored nodes -> blocks (maximal subtrees of <= S stored nodes) + top
@@ -2520,7 +2548,7 @@ static int enqueue_bottom_up(pml_ctx* ctx, int is_marginal, bool small_path, boo
         // the two-level units first (they depend on tips only), then the levels of what is left
         const pml_ctx::SuperSchedule& U = ctx->sup;
         PML_TRY(dispatch_super_f81(ctx, true));
-        PML_TRY(prof_end(ctx, 4, 1));
+        PML_TRY(prof_end(ctx, 4, U.n > 0 ? 1 : 0));
         PML_TRY(prof_begin(ctx));
         const int nl = (int)U.bu_offsets_r.size() - 1;
         int tail = narrow_levels(U.bu_offsets_r, nl, false, ctx->C);
@@ -2857,7 +2885,7 @@ static int run_top_down(pml_ctx* ctx) {
             PML_TRY(prof_end(ctx, 1, n_launch));
             PML_TRY(prof_begin(ctx));
             PML_TRY(dispatch_super_f81(ctx, false));
-            PML_TRY(prof_end(ctx, 3, 1));
+            PML_TRY(prof_end(ctx, 3, U.n > 0 ? 1 : 0));
             return PML_OK;
         }
         // F81 family: the roots and the levels right below them in one launch
@@ -3308,7 +3336,7 @@ static int materialize_cherries(pml_ctx* ctx) {
     if (ctx->bu_absorbed) {
         // the children of the two-level units: their own units (two cherries of two tips), from the tips
         ctx->units_override = ctx->sup.d_child_units;
-        const int status = dispatch_sweep(ctx, SW_BU_MARG_FUSED_NOVEC, ctx->d_bu_order_f, 2 * ctx->sup.n);
+        const int status = dispatch_sweep(ctx, SW_BU_MARG_FUSED_NOVEC, ctx->d_bu_order_f, 2 * ctx->sup.n);  // (nothing if n == 0)
         ctx->units_override = nullptr;
         PML_TRY(status);
         // ... and the children of the stacked units (two stored children each; in chunks of at most 65 536 units: the
