@@ -180,6 +180,63 @@ def two_level_nodes(flat, k, n_cols):
     return sup
 
 
+def stacked_nodes(flat, stored, sup, absorbed):
+    """
+    The nodes the library runs as stacked units (pml_tree_upload) once the two-level nodes `sup` (whose
+    children `absorbed` have no vector in memory) are known: in ascending fused height, a node with two children that are
+    plain units with two stored children each (vectors in memory) takes its children over -- on levels of 1 024 to
+    65 536 nodes, and only where the stacked units take over at least half of what the two-level units leave.
+    Returns (stacked, taken) boolean arrays.
+    """
+    N = flat.n_nodes
+    nc = np.asarray(flat.n_children)
+    fc = np.asarray(flat.first_child)
+    depth = np.asarray(flat.depth)
+    stacked = np.zeros(N, dtype=bool)
+    taken = np.zeros(N, dtype=bool)
+    if os.environ.get('PASTML_HIP_NO_STACK') or not stored.any():
+        return stacked, taken
+    # fused height of the stored nodes: 1 + the largest height among stored children (deepest nodes first)
+    fh = np.zeros(N, dtype=np.int64)
+    for d in range(int(depth.max()), -1, -1):
+        idx = np.flatnonzero(stored & (depth == d))
+        if not len(idx):
+            continue
+        h = np.zeros(len(idx), dtype=np.int64)
+        for j in range(int(nc[idx].max())):
+            has = nc[idx] > j
+            ch = fc[idx[has]] + j
+            h[has] = np.maximum(h[has], np.where(stored[ch], fh[ch], 0))
+        fh[idx] = h + 1
+    level_size = np.bincount(fh[stored], minlength=int(fh.max()) + 1)
+    novec = absorbed.copy()
+    gone = sup | absorbed
+    lo = int(os.environ.get('PASTML_HIP_STACK_MIN', 1024))
+    for h in range(2, int(fh.max()) + 1):
+        if not lo <= level_size[h] <= 65536:
+            continue
+        cand = np.flatnonzero(stored & (fh == h) & ~gone & ~taken & (nc == 2))
+        if not len(cand):
+            continue
+        ok = np.ones(len(cand), dtype=bool)
+        for j in (0, 1):
+            ch = fc[cand] + j
+            plain = stored[ch] & ~gone[ch] & ~stacked[ch] & ~taken[ch] & (nc[ch] == 2) & (level_size[fh[ch]] <= 65536)
+            g = fc[ch]
+            g0 = np.where(plain, g, 0)
+            plain &= stored[g0] & ~novec[g0] & stored[g0 + 1] & ~novec[g0 + 1]
+            ok &= plain
+        n = cand[ok]
+        stacked[n] = True
+        for j in (0, 1):
+            taken[fc[n] + j] = True
+            novec[fc[n] + j] = True
+    if 'PASTML_HIP_STACK_MIN' not in os.environ and int(stacked.sum()) * 6 < int(stored.sum()) - 3 * int(sup.sum()):
+        stacked[:] = False
+        taken[:] = False
+    return stacked, taken
+
+
 def schedule_bytes(flat, k, n_cols, narrow_limit=None):
     """
     Bytes the F81-family kernels must move per sweep for one column, from the tree itself: only *stored* internal
@@ -208,6 +265,14 @@ def schedule_bytes(flat, k, n_cols, narrow_limit=None):
     gone = sup.copy()                                   # nodes that are not units of the level lists any more
     gone[fc[sup]] = True
     gone[fc[sup] + 1] = True
+    absorbed = gone & ~sup
+    stacked, taken = (stacked_nodes(flat, stored, sup, absorbed) if 29 <= k <= 64 and not os.environ.get('PASTML_HIP_NO_SUPER')
+                      else (np.zeros(N, dtype=bool), np.zeros(N, dtype=bool)))
+    if n_sup == 0 and stacked.any() and (N <= 2048 or (256 < int(stored.sum()) <= 131072 and int(stored.sum()) * n_cols <= 160000)):
+        stacked[:] = False                              # (the level schedule is not used at all: two_level_nodes' rule)
+        taken[:] = False
+    n_stack = int(stacked.sum())
+    gone = gone | stacked | taken
     unit = stored & ~gone                               # units of the level kernels
     nonroot = parent >= 0
     pmask = np.zeros(N, dtype=bool)
@@ -237,6 +302,16 @@ def schedule_bytes(flat, k, n_cols, narrow_limit=None):
     # child: E, S, mask, exponent (32), its cherries' E, S, mask (48), its tips' E, S, mask (96); writes 7 rows with sum
     # and exponent (the child, two cherries, four tips)
     td_two = n_sup * (32 + vec + 16) + 2 * n_sup * (32 + 48 + 96 + 7 * (vec + 16))
+    # stacked unit, bottom-up: descriptor 32; E, S, exponent of the four grandchildren (96) and their vectors (4 vec), E of
+    # the two children and the three own masks (40); written: pi . v + exponent of the children (32), the node's vector,
+    # pi . v, exponent (vec + 16)
+    bu_stack = n_stack * (32 + 96 + 4 * vec + 40 + 32 + vec + 16)
+    # top-down, one unit per child: descriptor 32 and the node's row (vec + 16) once per node; per child E, S, mask,
+    # exponent (32), the grandchildren's E, S, mask, exponent (64) and vectors (2 vec); written: 3 rows with sums and
+    # exponents (the child and its two children)
+    td_stack = n_stack * (32 + vec + 16) + 2 * n_stack * (32 + 64 + 2 * vec + 3 * (vec + 16))
+    bu_levels += bu_stack                               # (they run between the level launches, in the same HIP-event slots)
+    td_levels += td_stack
     bu, td = bu_levels + bu_two, td_levels + td_two
     # per-branch data: dist in (8, read once per chunk of columns a thread walks: run_prep's cpy), E out (8); tips: mask
     # in (8 W), S out (8)
@@ -245,7 +320,7 @@ def schedule_bytes(flat, k, n_cols, narrow_limit=None):
         cpy *= 2
     prep = N * (8 + 8.0 / cpy) + int(tip.sum()) * (8 * W + 8)
     return dict(bottom_up=bu, top_down=td, prep=prep, total=bu + td + prep, vec_bytes=vec, n_stored=int(stored.sum()),
-                n_cherries=int(cherry.sum()), n_tips=int(tip.sum()), n_two_level=n_sup,
+                n_cherries=int(cherry.sum()), n_tips=int(tip.sum()), n_two_level=n_sup, n_stacked=n_stack,
                 bottom_up_levels=bu_levels, bottom_up_two_level=bu_two, top_down_levels=td_levels,
                 top_down_two_level=td_two,
                 per_unit=dict(bottom_up=bu / (N * k), top_down=td / (N * k), prep=prep / (N * k)))

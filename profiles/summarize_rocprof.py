@@ -69,8 +69,8 @@ def main():
     import bench
     # the kernel sources these counters were measured on: bench.py reports roofline.traffic only while they are unchanged
     data[workload] = dict(tag=tag, csrc_sha=bench.csrc_digest(), chars_per_gpu=bench.WORKLOADS[workload][2],
-                          td_bytes_per_step=total(('td_f81_kernel', 'td_matrix_kernel', 'td_f81_super_kernel')),
-                          bu_bytes_per_step=total(('bu_f81_kernel', 'bu_matrix_kernel', 'bu_f81_super_kernel')),
+                          td_bytes_per_step=total(('td_f81_kernel', 'td_matrix_kernel', 'td_f81_super_kernel', 'td_f81_stack_kernel')),
+                          bu_bytes_per_step=total(('bu_f81_kernel', 'bu_matrix_kernel', 'bu_f81_super_kernel', 'bu_f81_stack_kernel')),
                           td_two_level_bytes_per_step=total(('td_f81_super_kernel',)),
                           bu_two_level_bytes_per_step=total(('bu_f81_super_kernel',)),
                           kernels=traffic)
