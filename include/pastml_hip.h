@@ -67,7 +67,8 @@ int pml_ctx_sync(pml_ctx* ctx);
  * internal nodes whose children are all tips are recomputed in registers instead of being stored in HBM (their
  * vectors, like the top-down vectors of tips, are computed when pml_download asks for them).  With it, on large
  * forests and 29 <= k <= 64, nodes with two stored children that each carry two cherries of two tips run as two-level
- * units: their children's bottom-up vectors are not stored either, same rule for downloads.
+ * units, and above them nodes take pairs of plain children over as stacked units: those children's
+ * bottom-up vectors are not stored either, same rule for downloads.
  * PML_OPT_KEEP_TD (default 0, may be changed at any time): the F81-family top-down sweep works from the stored
  * posteriors of the level above (TD o BU = posterior * sum / pi) and does not write the top-down vectors themselves;
  * with this option it stores them too.  pml_download(PML_BUF_TD / PML_BUF_TD_SF) repeats the sweep with the stores on
