@@ -146,7 +146,7 @@ def two_level_nodes(flat, k, n_cols):
     """
     The nodes the library's level schedule runs as two-level units (pml_tree_upload): stored nodes with two
     stored children that each carry two cherries of two tips, ids of the four cherries and of the eight tips consecutive;
-    only for lane groups of 8 and more (29 <= k <= 64), where they are at least 64 and a sixteenth of the stored nodes,
+    only for lane groups of 8 and more (17 <= k <= 64), where they are at least 64 and a sixteenth of the stored nodes,
     and only where the sweeps run level launches (not one launch per sweep, not subtree blocks).  Returns a boolean
     array over the nodes (empty selection if the schedule does not apply).
     """
@@ -155,7 +155,7 @@ def two_level_nodes(flat, k, n_cols):
     fc = np.asarray(flat.first_child)
     parent = np.asarray(flat.parent)
     sup = np.zeros(N, dtype=bool)
-    if not 29 <= k <= 64 or os.environ.get('PASTML_HIP_NO_SUPER'):
+    if not 17 <= k <= 64 or os.environ.get('PASTML_HIP_NO_SUPER'):
         return sup
     internal = nc > 0
     tip = ~internal
@@ -266,7 +266,7 @@ def schedule_bytes(flat, k, n_cols, narrow_limit=None):
     gone[fc[sup]] = True
     gone[fc[sup] + 1] = True
     absorbed = gone & ~sup
-    stacked, taken = (stacked_nodes(flat, stored, sup, absorbed) if 29 <= k <= 64 and not os.environ.get('PASTML_HIP_NO_SUPER')
+    stacked, taken = (stacked_nodes(flat, stored, sup, absorbed) if 17 <= k <= 64 and not os.environ.get('PASTML_HIP_NO_SUPER')
                       else (np.zeros(N, dtype=bool), np.zeros(N, dtype=bool)))
     if n_sup == 0 and stacked.any() and (N <= 2048 or (256 < int(stored.sum()) <= 131072 and int(stored.sum()) * n_cols <= 160000)):
         stacked[:] = False                              # (the level schedule is not used at all: two_level_nodes' rule)

@@ -66,7 +66,7 @@ int pml_ctx_sync(pml_ctx* ctx);
  * Options (set before pml_tree_upload).  PML_OPT_CHERRY_FUSION (default 1): in the F81-family marginal sweeps,
  * internal nodes whose children are all tips are recomputed in registers instead of being stored in HBM (their
  * vectors, like the top-down vectors of tips, are computed when pml_download asks for them).  With it, on large
- * forests and 29 <= k <= 64, nodes with two stored children that each carry two cherries of two tips run as two-level
+ * forests and 17 <= k <= 64, nodes with two stored children that each carry two cherries of two tips run as two-level
  * units, and above them nodes take pairs of plain children over as stacked units: those children's
  * bottom-up vectors are not stored either, same rule for downloads.
  * PML_OPT_KEEP_TD (default 0, may be changed at any time): the F81-family top-down sweep works from the stored
@@ -89,6 +89,13 @@ enum { PML_OPT_CHERRY_FUSION = 1, PML_OPT_KEEP_TD = 2, PML_OPT_EIGEN_FUSED = 3, 
 int pml_ctx_set_option(pml_ctx* ctx, int option, int value);
 /* bytes of device memory currently held by the ctx / free on its device */
 int pml_ctx_memory(pml_ctx* ctx, uint64_t* held, uint64_t* device_free);
+/*
+ * What the F81-family sweeps of this context (tree uploaded, columns allocated) will run: *level_schedule = 1 if they
+ * take the level schedule with two-level / stacked units (0: single launch, subtree blocks, plain levels, other models),
+ * and the numbers of two-level and of stacked nodes in it.  For tools that model the sweeps' traffic (bench.py's byte
+ * model is checked against this); the reference has no counterpart.
+ */
+int pml_schedule_info(pml_ctx* ctx, int32_t* level_schedule, int32_t* n_two_level, int32_t* n_stacked);
 
 /* ---- tree (replaces the ete3 traversals of pastml/ml.py:109,269,449) ------------------------------------------ */
 /*

@@ -1230,6 +1230,21 @@ int pml_ctx_memory(pml_ctx* ctx, uint64_t* held, uint64_t* device_free) {
     return PML_OK;
 }
 
+static bool super_sweeps(const pml_ctx* ctx);
+
+int pml_schedule_info(pml_ctx* ctx, int32_t* level_schedule, int32_t* n_two_level, int32_t* n_stacked) {
+    if (!ctx || ctx->C == 0) return fail(PML_ERR_INVALID, "allocate the columns first");
+    // (the model kind is set with the first model; until then the F81 family is assumed)
+    const int kind = ctx->kind;
+    if (kind < 0) ctx->kind = PML_MODEL_F81;
+    const bool on = super_sweeps(ctx);
+    ctx->kind = kind;
+    if (level_schedule) *level_schedule = on ? 1 : 0;
+    if (n_two_level) *n_two_level = on ? ctx->sup.n : 0;
+    if (n_stacked) *n_stacked = on ? ctx->sup.n_stack : 0;
+    return PML_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_t* parent, const int32_t* first_child,
                     const int32_t* n_children, const double* dist, int32_t n_bu_levels, const int32_t* bu_offsets,

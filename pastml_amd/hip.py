@@ -66,6 +66,7 @@ SIGNATURES = {
     'pml_ctx_sync': [_ctx_p],
     'pml_ctx_set_option': [_ctx_p, ctypes.c_int, ctypes.c_int],
     'pml_ctx_memory': [_ctx_p, _c_uint64_p, _c_uint64_p],
+    'pml_schedule_info': [_ctx_p, _c_int32_p, _c_int32_p, _c_int32_p],
     'pml_tree_upload': [_ctx_p, ctypes.c_int32, ctypes.c_int32, _c_int32_p, _c_int32_p, _c_int32_p, _c_double_p,
                         ctypes.c_int32, _c_int32_p, _c_int32_p, ctypes.c_int32, _c_int32_p, _c_int32_p, _c_int32_p,
                         _c_int32_p],
@@ -327,6 +328,12 @@ class BareContext(object):
         held, free = ctypes.c_uint64(0), ctypes.c_uint64(0)
         _check(self._lib.pml_ctx_memory(self._ctx, ctypes.byref(held), ctypes.byref(free)))
         return held.value, free.value
+
+    def schedule_info(self):
+        """(level schedule with two-level / stacked units in use, two-level nodes, stacked nodes) of the F81-family sweeps."""
+        a, b, c = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0)
+        _check(self._lib.pml_schedule_info(self._ctx, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return bool(a.value), b.value, c.value
 
     def comm_init(self, rank, world, unique_id=None):
         """Attaches a communicator (RCCL for world > 1; unique_id: the 128 bytes of rank 0's comm_unique_id())."""

@@ -838,6 +838,31 @@ def test_groups_spread_over_devices_with_the_same_bits(monkeypatch):
         assert [getattr(n, column) for n in f1.nodes] == [getattr(n, column) for n in f2.nodes]
 
 
+def test_byte_model_counts_the_units_the_library_schedules(monkeypatch):
+    """bench.schedule_bytes restates from the tree which nodes run as two-level and as stacked units; pml_schedule_info
+    says what pml_tree_upload made of it: the same numbers -- balanced trees of several sizes, ragged forests with balanced
+    clumps and without, the thresholds at their defaults and forced (tests' switches)."""
+    import bench
+    from pastml_amd import hip, synthetic
+    from test_gpu_parity import _forest_with_balanced_clumps
+    forests = [synthetic.balanced_forest(12), synthetic.balanced_forest(16), synthetic.balanced_forest(18),
+               _forest_with_balanced_clumps(3000, seed=2, clump_frac=0.7), FlatForest.random(30000, seed=1, max_arity=3)]
+    for forced in (False, True):
+        for var in ('PASTML_HIP_SUPER_MIN', 'PASTML_HIP_STACK_MIN'):
+            if forced:
+                monkeypatch.setenv(var, '1')
+            else:
+                monkeypatch.delenv(var, raising=False)
+        for flat in forests:
+            for k, n_cols in ((64, 64), (64, 1), (33, 16), (20, 64)):
+                sb = bench.schedule_bytes(flat, k, n_cols)
+                with hip.Engine(flat, n_cols, k) as eng:
+                    on, n2, ns = eng.schedule_info()
+                if forced and not on:
+                    continue    # (forced thresholds only matter where the level schedule runs at all)
+                assert (n2, ns) == (sb['n_two_level'], sb['n_stacked']), (flat.n_tips, k, n_cols, forced, on, n2, ns)
+
+
 def test_two_level_launches_where_the_byte_model_expects_them(monkeypatch):
     """bench.schedule_bytes decides from the tree which sweeps run two-level units; the library decides at upload.  The
     profile slots say what ran: slots 3 / 4 (the two-level launches) are used exactly where the model counts such nodes."""

@@ -1070,7 +1070,7 @@ def _forest_with_balanced_clumps(n_leaves, seed, clump_frac=0.5):
     return FlatForest.from_trees(roots)
 
 
-@pytest.mark.parametrize('k', [29, 32, 40, 64])
+@pytest.mark.parametrize('k', [17, 20, 29, 32, 40, 64])
 def test_two_level_units_give_the_bits_of_the_level_schedule(k, monkeypatch):
     """
     Level schedule of large forests, lane groups of 8 and more: nodes with two stored children that each carry two
@@ -1079,7 +1079,7 @@ def test_two_level_units_give_the_bits_of_the_level_schedule(k, monkeypatch):
     sums, scales, the bottom-up vectors a download materialises, the top-down vectors of PML_OPT_KEEP_TD -- on a
     balanced tree (every node of the two levels is taken over) and on a ragged forest with balanced clumps (both kinds
     of units, thin rest levels), with unobserved and ambiguous tips and restricted internal nodes (the bodies with masks)
-    and with every state allowed (the straight-line bodies); k = 40 has padding states.
+    and with every state allowed (the straight-line bodies); k = 17, 20, 29, 40 have padding states.
     """
     monkeypatch.setenv('PASTML_HIP_BLOCK_NODES', '0')       # level launches, not subtree blocks
     monkeypatch.setenv('PASTML_HIP_SMALL_MANY_NODES', '0')

@@ -402,7 +402,8 @@ def test_bench_byte_model_knows_the_two_level_schedule():
     # each).  Two-level: descriptor and own row once (560), per child 32 + 48 + 96 + 7 rows of 528.
     assert plain['top_down'] - sb['top_down'] == n2 * (2704 + 2 * 3888 - 560 - 2 * (176 + 7 * 528))
     assert vec == 512
-    assert bench.schedule_bytes(flat, 20, 128)['n_two_level'] == 0      # units of fewer than 8 lanes
+    assert bench.schedule_bytes(flat, 16, 128)['n_two_level'] == 0      # units of fewer than 8 lanes (k <= 16)
+    assert bench.schedule_bytes(flat, 20, 128)['n_two_level'] == flat.n_tips // 8
     # a caterpillar has no such nodes
     root = TreeNode(name='r', dist=0.0)
     cur = root
