@@ -981,19 +981,26 @@ class GroupSearch(object):
 
 def optimise_groups(groups):
     """
-    ONE loop for all searches of all groups: every round submits the pending sweep of every group (each on its own
-    context = stream) before it waits for any, then steps the characters of each group to their next requests.  The
-    sweeps of the groups overlap on the device and with the host work of the other groups; no interpreter threads, so
-    the groups do not take the interpreter lock from each other (with a thread per group an acr() over the 91 HIV1C
-    columns took as long as its groups one after the other).
+    ONE loop for all searches of all groups, each group on its own context (= stream).  Every group's first sweep is
+    submitted before any is waited for; from then on a group's next sweep goes out as soon as its last one has been
+    collected and its characters stepped to their next requests -- while the loop does that for one group the sweeps of
+    all the others are in flight, so the device is not idle during the host's share of a round (round 3; before, every
+    round submitted all groups, then collected all: the device waited while the points of the next round were made).
+    A group's sequence of sweeps is what it would be alone.  No interpreter threads, so the groups do not take the
+    interpreter lock from each other (with a thread per group an acr() over the 91 HIV1C columns took as long as its
+    groups one after the other).
     """
     live = [g for g in groups if g.pending]
+    for g in live:
+        g.submit()
     while live:
-        for g in live:
-            g.submit()
+        still = []
         for g in live:
             g.collect()
-        live = [g for g in live if g.pending]
+            if g.pending:
+                g.submit()
+                still.append(g)
+        live = still
     for g in groups:
         g.close()
 
