@@ -313,12 +313,13 @@ def schedule_bytes(flat, k, n_cols, narrow_limit=None):
     bu_levels += bu_stack                               # (they run between the level launches, in the same HIP-event slots)
     td_levels += td_stack
     bu, td = bu_levels + bu_two, td_levels + td_two
-    # per-branch data: dist in (8, read once per chunk of columns a thread walks: run_prep's cpy), E out (8); tips: mask
-    # in (8 W), S out (8)
+    # per-branch data: dist in (8, read once per chunk of columns a thread walks: run_prep's cpy), the node's record out
+    # (32: e, mask word, S, exponent -- PmlRec, round 4); mask words in: every node's for k <= 64 (the record's copy), the
+    # tips' otherwise (S = pi . mask)
     cpy, bx = 1, (N + 255) // 256
     while cpy < 8 and cpy * 2 <= n_cols and bx * ((n_cols + 2 * cpy - 1) // (2 * cpy)) >= 4096:
         cpy *= 2
-    prep = N * (8 + 8.0 / cpy) + int(tip.sum()) * (8 * W + 8)
+    prep = N * (32 + 8.0 / cpy) + (N * 8 if W == 1 else int(tip.sum()) * 8 * W)
     return dict(bottom_up=bu, top_down=td, prep=prep, total=bu + td + prep, vec_bytes=vec, n_stored=int(stored.sum()),
                 n_cherries=int(cherry.sum()), n_tips=int(tip.sum()), n_two_level=n_sup, n_stacked=n_stack,
                 bottom_up_levels=bu_levels, bottom_up_two_level=bu_two, top_down_levels=td_levels,
@@ -329,13 +330,13 @@ def schedule_bytes(flat, k, n_cols, narrow_limit=None):
 def csrc_digest():
     """
     sha256 over the sources of the profiled kernels (the F81-family sweeps and the device helpers they are made of):
-    profiles/traffic.json is only valid for the sources it was measured on.  Launch geometry lives in pml_api.hip, which
-    changes for unrelated reasons; a change of grid caps moves the traffic by well under the 15 % the check allows.
+    profiles/traffic.json is only valid for the sources it was measured on -- pml_api.hip (schedules, launch geometry)
+    included since round 4.
     """
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(REPO, 'pastml_amd', 'csrc')
-    for name in ('pml_device.h', 'pml_kernels_f81.h'):
+    for name in ('pml_device.h', 'pml_kernels_f81.h', 'pml_api.hip'):
         h.update(name.encode())
         with open(os.path.join(d, name), 'rb') as f:
             h.update(f.read())
@@ -402,17 +403,33 @@ def spawn_ranks(args):
     return 0
 
 
-def validate_columns(eng, flat, k, tip_states, lnl, stride=4099):
+def reference_fixture(flat, k):
+    """
+    The reference's own numbers for characters 0 and 1 of config 4 at full size (tests/golden/synthetic_cfg4_full.npz,
+    written by tests/golden/make_golden.py::case_cfg4_full from the real PastML: ln L and posteriors at every 4 099th
+    node), or None when this run is not that tree.
+    """
+    path = os.path.join(REPO, 'tests', 'golden', 'synthetic_cfg4_full.npz')
+    if k != 64 or flat.n_tips != (1 << 20) or not os.path.exists(path):
+        return None
+    return np.load(path, allow_pickle=False)
+
+
+def validate_columns(eng, flat, k, tip_states, lnl, stride=4099, chars=None):
     """
     After the timed region: every column's results on a strided node sample + all tips of the sample.  Size-independent
     properties (no oracle needed at this size): posterior rows sum to 1; log10(sum LH) - LH_SF equals the column's
     ln L / ln 10 at every sampled node (pastml/ml.py:468-483); an observed tip's posterior is the unit vector of its
-    state.  A wrong column stride or a column left untouched fails here.
+    state.  A wrong column stride or a column left untouched fails here.  Columns that hold character 0 or 1 of the
+    full-size workload (chars: the character of every column) are also compared with what the reference itself computed
+    (reference_fixture): ln L to 1e-11, the sampled posteriors to 1e-9 relative.
     """
     from pastml_amd import hip
     N = flat.n_nodes
     first_tip = int(flat.tips[0])
     worst = dict(row_sum=0.0, total_lh=0.0)
+    ref = reference_fixture(flat, k) if chars is not None and stride == 4099 else None
+    ref_seen = dict(characters=[], max_rel_loglik_error=0.0, max_rel_posterior_error=0.0)
     for c in range(eng.n_cols):
         post = eng.download_strided(hip.BUF_POSTERIOR, c, 0, stride)
         lhs = eng.download_strided(hip.BUF_LH_SUM, c, 0, stride)
@@ -425,14 +442,29 @@ def validate_columns(eng, flat, k, tip_states, lnl, stride=4099):
         if not (rs < 1e-12 and tl < 1e-11):
             raise SystemExit('validation failed in column {}: |row sum - 1| = {:.3g}, total-likelihood mismatch {:.3g}'
                              .format(c, rs, tl))
+        if ref is not None and int(chars[c]) in (0, 1):
+            ch = int(chars[c])
+            want_l, want_p = float(ref['c{}_loglik'.format(ch)]), ref['c{}_posterior'.format(ch)]
+            el = abs(lnl[c] / want_l - 1)
+            nz = want_p > 0
+            ep = float(np.abs(post[nz] / want_p[nz] - 1).max()) if post.shape == want_p.shape else np.inf
+            if not (el < 1e-11 and ep < 1e-9 and np.array_equal(post == 0, ~nz)):
+                raise SystemExit('validation failed in column {}: character {} differs from the reference run: ln L rel {:.3g}, '
+                                 'posteriors rel {:.3g}'.format(c, ch, el, ep))
+            ref_seen['characters'].append(ch)
+            ref_seen['max_rel_loglik_error'] = max(ref_seen['max_rel_loglik_error'], float(el))
+            ref_seen['max_rel_posterior_error'] = max(ref_seen['max_rel_posterior_error'], ep)
         is_tip = ids >= first_tip
         if np.array_equal(np.asarray(flat.tips), np.arange(first_tip, N)) and is_tip.any():
             want = tip_states[c][ids[is_tip] - first_tip]
             got = post[is_tip]
             if not (np.array_equal(got.argmax(axis=1), want) and np.all(got.max(axis=1) == 1.0)):
                 raise SystemExit('validation failed in column {}: an observed tip lost its state'.format(c))
-    return dict(columns=eng.n_cols, node_stride=stride, max_row_sum_error=worst['row_sum'],
-                max_total_likelihood_rel_error=worst['total_lh'], tips_checked=True)
+    out = dict(columns=eng.n_cols, node_stride=stride, max_row_sum_error=worst['row_sum'],
+               max_total_likelihood_rel_error=worst['total_lh'], tips_checked=True)
+    if ref is not None:
+        out['against_reference_run'] = ref_seen  # (empty on ranks whose shard holds neither character)
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -716,7 +748,7 @@ def main():
     validation = None
     if not args.no_validate:
         try:
-            validation = validate_columns(eng, flat, k, tip_states, lnl)
+            validation = validate_columns(eng, flat, k, tip_states, lnl, chars=chars)
         except SystemExit as e:
             failure = str(e)
 

@@ -919,6 +919,79 @@ def case_parsimony():
 
 CASES['parsimony'] = case_parsimony
 
+
+def _cfg4_marginal_job(job):
+    """
+    One character of BASELINE config 4 through the reference's marginal path with fixed parameters (sf = 1, tau = 0,
+    the character's own frequencies): initialize_allowed_states (ml.py:293-318), get_bottom_up_loglikelihood
+    (:82-148), calculate_top_down_likelihood (:240-290), calculate_marginal_likelihoods (:431-465) and the
+    normalisation of convert_likelihoods_to_probabilities (:498-500) at a strided node sample.
+    """
+    import time
+    n_levels, c, stride, keep_vectors = job
+    k = 64
+    flat = synthetic.balanced_forest(n_levels)
+    roots = flat.to_tree_nodes()
+    fs = RForestStats(roots)
+    states, tips_states = annotate_synthetic(flat, roots, 'c', k, c)
+    model = RF81(states=states, forest_stats=fs, sf=1., frequencies=synthetic.f81_frequencies(k, c))
+    model.freeze()
+    t0 = time.time()
+    for t in roots:
+        rml.initialize_allowed_states(t, 'c', states)
+    lnl = sum(rml.get_bottom_up_loglikelihood(tree=t, character='c', model=model, is_marginal=True, alter=False)
+              for t in roots)
+    for t in roots:
+        rml.calculate_top_down_likelihood(t, 'c', model=model)
+        rml.calculate_marginal_likelihoods(t, 'c', model.frequencies, clean_up=False)
+    seconds = time.time() - t0
+    nodes = flat.nodes
+    sample = np.arange(0, flat.n_nodes, stride)
+    lh = np.array([getattr(nodes[i], feat('c', rml.LH)) for i in sample])
+    out = dict(loglik=lnl, sample=sample, reference_seconds=seconds,
+               posterior=np.array([row / row.sum() for row in lh]),
+               lh_sf=np.array([getattr(nodes[i], feat('c', rml.LH_SF)) for i in sample], dtype=np.float64))
+    if keep_vectors:
+        out['lh'] = lh
+        for key, name, sf_name in (('bu', rml.BU_LH, rml.BU_LH_SF), ('td', rml.TD_LH, rml.TD_LH_SF)):
+            out[key] = np.array([getattr(nodes[i], feat('c', name)) for i in sample])
+            out[key + '_sf'] = np.array([getattr(nodes[i], feat('c', sf_name)) for i in sample], dtype=np.float64)
+    print('cfg4 character {} on 2^{} tips: lnL {:.6f}, {:.0f} s of reference time'.format(c, n_levels, lnl, seconds),
+          flush=True)
+    return c, out
+
+
+def case_cfg4_full():
+    """
+    BASELINE config 4 at full size: (i) the 1 048 576-tip tree, k = 64, F81 with per-character
+    frequencies, characters 0 and 1 (= columns 0 and 1 of rank 0's shard in bench.py): lnL and, at every 4 099th node,
+    posteriors, marginal likelihoods, bottom-up and top-down vectors with their scaling factors; (ii) all 32
+    characters of the bench shard on a 4 096-tip tree: lnL and posteriors at every 37th node.
+    ~4 minutes of reference time per sweep-triple of the full tree; the three jobs run as separate processes.
+    """
+    import multiprocessing as mp
+    sys.setrecursionlimit(10000)
+    jobs = [(20, 0, 4099, True), (20, 1, 4099, True)]
+    small = [(12, c, 37, False) for c in range(32)]
+    with mp.get_context('fork').Pool(3) as pool:
+        big = pool.map_async(_cfg4_marginal_job, jobs, chunksize=1)
+        small_res = dict(pool.map(_cfg4_marginal_job, small, chunksize=32))
+        big_res = dict(big.get())
+    out = dict(n_levels=20, k=64, characters=np.array([0, 1]))
+    for c, res in big_res.items():
+        for key, v in res.items():
+            out['c{}_{}'.format(c, key)] = v
+        out['c{}_frequencies'.format(c)] = synthetic.f81_frequencies(64, c)
+    out['small_n_levels'] = 12
+    out['small_sample'] = small_res[0]['sample']
+    out['small_loglik'] = np.array([small_res[c]['loglik'] for c in range(32)])
+    out['small_posterior'] = np.stack([small_res[c]['posterior'] for c in range(32)])
+    out['small_lh_sf'] = np.stack([small_res[c]['lh_sf'] for c in range(32)])
+    save('synthetic_cfg4_full', **out)
+
+
+CASES['cfg4_full'] = case_cfg4_full
+
 if __name__ == '__main__':
     np.random.seed(239)
     todo = sys.argv[1:] or list(CASES)

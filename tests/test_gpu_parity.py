@@ -418,6 +418,7 @@ def test_cfg4_full_tree_invariants():
         eng.set_tip_states(states)
         lnl = eng.bottom_up(True)
         post, lh_sum, lh_sf = eng.top_down_marginals()
+        sched = eng.schedule_info()
         # subtree rooted at the first node of depth 8 (id 255): its 4 096 tips
         sub_root = 255
         bu = eng.download(hip.BUF_BU, 0)
@@ -440,6 +441,38 @@ def test_cfg4_full_tree_invariants():
     masks[sub.tips, states[0][tip_pos]] = 1
     r = orc.bottom_up(sub, masks, specs[0])
     assert_same_scaled(bu[ids], bu_sf[ids], r['bu'], r['bu_sf'], what='subtree BU')
+    # ... and the numbers the REFERENCE produced for this very run (tests/golden/make_golden.py::case_cfg4_full: ml.py:82-148,
+    # 240-290, 431-502 on the 1 048 576-tip tree, characters 0 and 1): ln L, and at every 4 099th node the posteriors, the
+    # marginal likelihoods and the bottom-up vectors.  Default dispatch: the two-level and stacked units are what runs here.
+    z = load_golden('synthetic_cfg4_full')
+    assert sched[0] == 1 and sched[1] > 0 and sched[2] > 0, 'the two-level / stacked schedule was expected here: {}'.format(sched)
+    for c in range(C):
+        s = z['c{}_sample'.format(c)]
+        np.testing.assert_allclose(lnl[c], z['c{}_loglik'.format(c)], rtol=LNL_RTOL)
+        np.testing.assert_allclose(post[c][s], z['c{}_posterior'.format(c)], rtol=POST_RTOL, atol=1e-300)
+        with np.errstate(divide='ignore'):
+            np.testing.assert_allclose(np.log10(lh_sum[c][s]) - lh_sf[c][s],
+                                       np.log10(z['c{}_lh'.format(c)].sum(axis=1)) - z['c{}_lh_sf'.format(c)],
+                                       rtol=LNL_RTOL)  # (values of -2.7e6: an ulp is 4.7e-10)
+    s = z['c0_sample']
+    assert_same_scaled(bu[s], bu_sf[s], z['c0_bu'], z['c0_bu_sf'], what='BU at the sample, reference')
+
+
+def test_cfg4_bench_characters_match_reference_on_4096_tips():
+    """All 32 characters of the bench shard on a 4 096-tip tree against the reference's own run (synthetic_cfg4_full)."""
+    z = load_golden('synthetic_cfg4_full')
+    flat = synthetic.balanced_forest(int(z['small_n_levels']))
+    C, k = 32, 64
+    states = np.stack([synthetic.tip_states(flat.n_tips, k, c) for c in range(C)])
+    with hip.Engine(flat, C, k) as eng:
+        eng.set_models([(dict(kind=0, pi=synthetic.f81_frequencies(k, c)), (1.0, 0.0, 1.0)) for c in range(C)])
+        eng.set_tip_states(states)
+        lnl = eng.bottom_up(True)
+        post, lh_sum, lh_sf = eng.top_down_marginals()
+    s = z['small_sample']
+    np.testing.assert_allclose(lnl, z['small_loglik'], rtol=LNL_RTOL)
+    np.testing.assert_allclose(post[:, s], z['small_posterior'], rtol=POST_RTOL, atol=1e-300)
+    np.testing.assert_allclose(np.log10(lh_sum) - lh_sf, (lnl / np.log(10))[:, None] * np.ones(flat.n_nodes), rtol=1e-11)
 
 
 @pytest.mark.parametrize('k', [4, 20, 32, 64, 130])

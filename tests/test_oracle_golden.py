@@ -2,6 +2,8 @@
 Pins the oracle (oracle/pastml_oracle.py) against the golden vectors produced by the real reference
 (tests/golden/make_golden.py).  CPU only.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -139,3 +141,47 @@ def test_large_samples():
     r = orc.bottom_up(flat, masks.astype(int), spec, sf, tau, tf, True)
     np.testing.assert_allclose(r['loglik'], z['loglik'], rtol=1e-12)
     np.testing.assert_allclose(r['bu'][z['sample']], z['bu'], rtol=1e-10, atol=1e-300)
+
+
+def _cfg4_character(levels, c):
+    from pastml_amd import synthetic
+    flat = synthetic.balanced_forest(levels)
+    masks = synthetic.one_hot_masks(flat, 64, synthetic.tip_states(flat.n_tips, 64, c)).astype(int)
+    return flat, masks, dict(kind=0, pi=synthetic.f81_frequencies(64, c))
+
+
+def test_cfg4_full_fixture_small_tree():
+    """
+    synthetic_cfg4_full (the real reference on BASELINE config 4, tests/golden/make_golden.py::case_cfg4_full): the
+    bench shard's characters on the 4 096-tip tree -- ln L and posteriors at every 37th node.  Four of the 32 characters
+    by default (a second each), all of them with PASTML_GOLDEN_FULL=1.
+    """
+    z = load_golden('synthetic_cfg4_full')
+    sample = z['small_sample']
+    chars = range(32) if os.environ.get('PASTML_GOLDEN_FULL') else (0, 1, 13, 31)
+    for c in chars:
+        flat, masks, spec = _cfg4_character(int(z['small_n_levels']), c)
+        r = orc.full_marginal_pass(flat, masks, spec)
+        np.testing.assert_allclose(r['loglik'], z['small_loglik'][c], rtol=1e-12)
+        np.testing.assert_allclose(r['posterior'][sample], z['small_posterior'][c], rtol=1e-10, atol=1e-300)
+        np.testing.assert_allclose(r['lh_sf'][sample], z['small_lh_sf'][c], rtol=0, atol=1e-9)
+
+
+@pytest.mark.skipif(not os.environ.get('PASTML_GOLDEN_FULL'), reason='5 minutes per character: PASTML_GOLDEN_FULL=1')
+@pytest.mark.parametrize('c', [0, 1])
+def test_cfg4_full_fixture_full_tree(c):
+    """The 1 048 576-tip tree, characters 0 and 1: the oracle against the reference's strided sample."""
+    z = load_golden('synthetic_cfg4_full')
+    flat, masks, spec = _cfg4_character(int(z['n_levels']), c)
+    np.testing.assert_array_equal(spec['pi'], z['c{}_frequencies'.format(c)])
+    r = orc.full_marginal_pass(flat, masks, spec)
+    s = z['c{}_sample'.format(c)]
+    np.testing.assert_allclose(r['loglik'], z['c{}_loglik'.format(c)], rtol=1e-12)
+    np.testing.assert_allclose(r['posterior'][s], z['c{}_posterior'.format(c)], rtol=1e-10, atol=1e-300)
+    with np.errstate(divide='ignore'):
+        for key in ('bu', 'td', 'lh'):
+            a = np.log10(r[key][s]) - r[key + '_sf'][s][:, None]
+            b = np.log10(z['c{}_{}'.format(c, key)]) - z['c{}_{}_sf'.format(c, key)][:, None]
+            fin = np.isfinite(b)
+            assert np.array_equal(np.isfinite(a), fin)
+            np.testing.assert_allclose(a[fin], b[fin], rtol=0, atol=1e-9, err_msg=key)
