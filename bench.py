@@ -180,7 +180,73 @@ def two_level_nodes(flat, k, n_cols):
     return sup
 
 
-def stacked_nodes(flat, stored, sup, absorbed):
+def fused_height(flat, stored):
+    """Fused height of the stored nodes: 1 + the largest height among stored children (deepest nodes first)."""
+    N = flat.n_nodes
+    nc = np.asarray(flat.n_children)
+    fc = np.asarray(flat.first_child)
+    depth = np.asarray(flat.depth)
+    fh = np.zeros(N, dtype=np.int64)
+    for d in range(int(depth.max()), -1, -1):
+        idx = np.flatnonzero(stored & (depth == d))
+        if not len(idx):
+            continue
+        h = np.zeros(len(idx), dtype=np.int64)
+        for j in range(int(nc[idx].max())):
+            has = nc[idx] > j
+            ch = fc[idx[has]] + j
+            h[has] = np.maximum(h[has], np.where(stored[ch], fh[ch], 0))
+        fh[idx] = h + 1
+    return fh
+
+
+def general_two_level_nodes(flat, stored, cherry, gone, fh):
+    """
+    The general two-level units of the library (pml_tree_upload, round 4), restated: a stored node of fused height 1 --
+    its children are tips and cherries -- with at most two children and cherries of at most four tips is ABSORBED by its
+    parent when the parent has at most two children (cherries of at most four tips), sits on a level of at most 65 536
+    nodes, is not taken by a two-level unit of the balanced kind (`gone`) and ALL its stored children can be absorbed.
+    Off unless PASTML_HIP_ABSORB_MIN = n is given (then: from n absorbed nodes on) -- they do not pay, profiles/r04c_*.
+    Returns (absorbing, absorbed) boolean arrays.
+    """
+    N = flat.n_nodes
+    nc = np.asarray(flat.n_children)
+    fc = np.asarray(flat.first_child)
+    absorbing = np.zeros(N, dtype=bool)
+    absorbed = np.zeros(N, dtype=bool)
+    if os.environ.get('PASTML_HIP_NO_ABSORB') or os.environ.get('PASTML_HIP_NO_SUPER') or not stored.any() \
+            or 'PASTML_HIP_ABSORB_MIN' not in os.environ:
+        return absorbing, absorbed
+    level_size = np.bincount(fh[stored], minlength=int(fh.max()) + 1)
+    big_cherry = np.zeros(N, dtype=bool)      # some cherry among the first two children has more than four tips
+    for j in (0, 1):
+        idx = np.flatnonzero(nc > j)
+        ch = fc[idx] + j
+        big_cherry[idx] |= cherry[ch] & (nc[ch] > 4)
+    small = (nc <= 2) & ~big_cherry
+    cand = np.flatnonzero(stored & (fh >= 2) & ~gone & small & (level_size[fh] <= 65536))
+    some = np.zeros(len(cand), dtype=bool)
+    every = np.ones(len(cand), dtype=bool)
+    for j in (0, 1):
+        has = nc[cand] > j
+        ch = np.where(has, fc[cand] + j, 0)
+        is_stored = has & stored[ch]
+        ok = is_stored & (fh[ch] == 1) & ~gone[ch] & small[ch]
+        some |= ok
+        every &= ~is_stored | ok
+    parents = cand[some & every]
+    absorbing[parents] = True
+    for j in (0, 1):
+        has = nc[parents] > j
+        ch = fc[parents[has]] + j
+        absorbed[ch[stored[ch]]] = True
+    if int(absorbed.sum()) < int(os.environ['PASTML_HIP_ABSORB_MIN']):
+        absorbing[:] = False
+        absorbed[:] = False
+    return absorbing, absorbed
+
+
+def stacked_nodes(flat, stored, sup, absorbed, fh=None):
     """
     The nodes the library runs as stacked units (pml_tree_upload) once the two-level nodes `sup` (whose
     children `absorbed` have no vector in memory) are known: in ascending fused height, a node with two children that are
@@ -196,18 +262,8 @@ def stacked_nodes(flat, stored, sup, absorbed):
     taken = np.zeros(N, dtype=bool)
     if os.environ.get('PASTML_HIP_NO_STACK') or not stored.any():
         return stacked, taken
-    # fused height of the stored nodes: 1 + the largest height among stored children (deepest nodes first)
-    fh = np.zeros(N, dtype=np.int64)
-    for d in range(int(depth.max()), -1, -1):
-        idx = np.flatnonzero(stored & (depth == d))
-        if not len(idx):
-            continue
-        h = np.zeros(len(idx), dtype=np.int64)
-        for j in range(int(nc[idx].max())):
-            has = nc[idx] > j
-            ch = fc[idx[has]] + j
-            h[has] = np.maximum(h[has], np.where(stored[ch], fh[ch], 0))
-        fh[idx] = h + 1
+    if fh is None:
+        fh = fused_height(flat, stored)
     level_size = np.bincount(fh[stored], minlength=int(fh.max()) + 1)
     novec = absorbed.copy()
     gone = sup | absorbed
@@ -266,13 +322,19 @@ def schedule_bytes(flat, k, n_cols, narrow_limit=None):
     gone[fc[sup]] = True
     gone[fc[sup] + 1] = True
     absorbed = gone & ~sup
-    stacked, taken = (stacked_nodes(flat, stored, sup, absorbed) if 17 <= k <= 64 and not os.environ.get('PASTML_HIP_NO_SUPER')
+    wide = 17 <= k <= 64 and not os.environ.get('PASTML_HIP_NO_SUPER')
+    level_schedule = not (N <= 2048 or (256 < int(stored.sum()) <= 131072 and int(stored.sum()) * n_cols <= 160000))
+    fh = fused_height(flat, stored) if wide else None
+    # general two-level units (round 4): stored nodes without stored children absorbed by their parents
+    g_absorbing, g_absorbed = (general_two_level_nodes(flat, stored, cherry, gone, fh) if wide and level_schedule
+                               else (np.zeros(N, dtype=bool), np.zeros(N, dtype=bool)))
+    stacked, taken = (stacked_nodes(flat, stored, sup, absorbed | g_absorbed | g_absorbing, fh) if wide
                       else (np.zeros(N, dtype=bool), np.zeros(N, dtype=bool)))
-    if n_sup == 0 and stacked.any() and (N <= 2048 or (256 < int(stored.sum()) <= 131072 and int(stored.sum()) * n_cols <= 160000)):
+    if n_sup == 0 and not g_absorbed.any() and stacked.any() and not level_schedule:
         stacked[:] = False                              # (the level schedule is not used at all: two_level_nodes' rule)
         taken[:] = False
     n_stack = int(stacked.sum())
-    gone = gone | stacked | taken
+    gone = gone | stacked | taken | g_absorbing | g_absorbed
     unit = stored & ~gone                               # units of the level kernels
     nonroot = parent >= 0
     pmask = np.zeros(N, dtype=bool)
@@ -312,16 +374,47 @@ def schedule_bytes(flat, k, n_cols, narrow_limit=None):
     td_stack = n_stack * (32 + vec + 16) + 2 * n_stack * (32 + 64 + 2 * vec + 3 * (vec + 16))
     bu_levels += bu_stack                               # (they run between the level launches, in the same HIP-event slots)
     td_levels += td_stack
+    # general two-level units.  Children of the absorbing nodes / of the absorbed nodes by kind, tips of their cherries:
+    def family(mask):
+        kid = np.zeros(N, dtype=bool)
+        kid[nonroot] = mask[parent[nonroot]]
+        grand = np.zeros(N, dtype=bool)
+        grand[nonroot] = cherry[parent[nonroot]] & kid[gp[nonroot]]
+        return int(kid.sum()), int((kid & cherry).sum()), int(grand.sum())
+    n_gp, n_gc = int(g_absorbing.sum()), int(g_absorbed.sum())
+    p_kids, p_cherries, p_tips = family(g_absorbing)     # (the absorbed nodes are among p_kids)
+    c_kids, c_cherries, c_tips = family(g_absorbed)
+    own_td = g_absorbing.copy()                          # absorbing nodes with tips / cherries of their own to finish
+    own_td[g_absorbing] = nc[g_absorbing] > np.array([int(g_absorbed[fc[n]:fc[n] + nc[n]].sum()) for n in np.flatnonzero(g_absorbing)],
+                                                      dtype=np.int64) if n_gp else False
+    o_kids, o_cherries, o_tips = family(own_td)
+    o_kids -= int((g_absorbed & own_td[gp]).sum())       # (its absorbed children are skipped)
+    # bottom-up, per absorbing node: three descriptors (96), own mask (8), every child's E, mask, S, exponent (32), the tips
+    # of its cherries (24); per absorbed child: own mask (8), its children's scalars (32 each), the tips of its cherries
+    # (24); written: pi . v + exponent of the absorbed children (16) and of all cherries (16), the node's vector, pi . v,
+    # exponent (vec + 16)
+    bu_general = n_gp * (96 + 8 + vec + 16) + p_kids * 32 + p_tips * 24 + p_cherries * 16 \
+        + n_gc * (8 + 16) + c_kids * 32 + c_tips * 24 + c_cherries * 16
+    # top-down, per absorbed child: descriptor 32, its E, S, mask, exponent (32), its children's scalars (32 each), the tips
+    # of its cherries (24); the parent's row, sum, exponent (vec + 16) once per absorbing node; written: the rows, sums and
+    # exponents of the child, of its children and of the tips of its cherries.  The absorbing nodes' own units (those with
+    # tips / cherries of their own): descriptor 32, all children's scalars (32 each), the tips of their cherries (24);
+    # written: the rows of those children and tips
+    td_general = n_gc * (32 + 32 + vec + 16) + c_kids * (32 + vec + 16) + c_tips * (24 + vec + 16) + n_gp * (vec + 16) \
+        + int(own_td.sum()) * 32 + (o_kids + int((g_absorbed & own_td[gp]).sum())) * 32 + o_kids * (vec + 16) \
+        + o_tips * (24 + vec + 16)
+    bu_levels += bu_general
+    td_levels += td_general
     bu, td = bu_levels + bu_two, td_levels + td_two
-    # per-branch data: dist in (8, read once per chunk of columns a thread walks: run_prep's cpy), the node's record out
-    # (32: e, mask word, S, exponent -- PmlRec, round 4); mask words in: every node's for k <= 64 (the record's copy), the
-    # tips' otherwise (S = pi . mask)
+    # per-branch data: dist in (8, read once per chunk of columns a thread walks: run_prep's cpy), E out (8); tips: mask
+    # in (8 W), S out (8)
     cpy, bx = 1, (N + 255) // 256
     while cpy < 8 and cpy * 2 <= n_cols and bx * ((n_cols + 2 * cpy - 1) // (2 * cpy)) >= 4096:
         cpy *= 2
-    prep = N * (32 + 8.0 / cpy) + (N * 8 if W == 1 else int(tip.sum()) * 8 * W)
+    prep = N * (8 + 8.0 / cpy) + int(tip.sum()) * (8 * W + 8)
     return dict(bottom_up=bu, top_down=td, prep=prep, total=bu + td + prep, vec_bytes=vec, n_stored=int(stored.sum()),
                 n_cherries=int(cherry.sum()), n_tips=int(tip.sum()), n_two_level=n_sup, n_stacked=n_stack,
+                n_absorbed=n_gc, n_absorbing=n_gp,
                 bottom_up_levels=bu_levels, bottom_up_two_level=bu_two, top_down_levels=td_levels,
                 top_down_two_level=td_two,
                 per_unit=dict(bottom_up=bu / (N * k), top_down=td / (N * k), prep=prep / (N * k)))
@@ -501,6 +594,38 @@ def secondary_measurements(device):
                                          .format(flat.n_bu_levels + flat.n_td_levels),
                                          model_bytes=sb['total'], achieved=sb['total'] / (ms * 1e-3) / 1e9,
                                          peak=HBM_PEAK_GBS, unit='GB/s', frac=sb['total'] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS))
+    # ---- a ragged tree: random binary tree of 262 144 tips, 32 characters -- what real inputs look like next
+    #      to the balanced benchmark tree; k = 64 (the headline's lane shape) and k = 4
+    from pastml_amd.tree import FlatForest
+    flat = FlatForest.random(262144, seed=3, max_arity=2, n_trees=1)
+    ragged = {}
+    for k in (64, 4):
+        C = 32
+        with hip.Engine(flat, C, k, device=device) as eng:
+            specs = [(dict(kind=0, pi=synthetic.f81_frequencies(k, c)), (1.0, 0.0, 1.0)) for c in range(C)]
+            eng.set_tip_states(np.stack([synthetic.tip_states(flat.n_tips, k, c) for c in range(C)]))
+
+            def ragged_pass():
+                eng.set_models(specs)
+                eng.marginal_pass(posterior=False, lh=False)
+            ms = timed(ragged_pass, 20, eng)
+            eng.set_models(specs)
+            ms_bu = timed(lambda: eng.bottom_up(True), 20, eng)
+            sb = schedule_bytes(flat, k, C)
+            gb = sb['total'] * C / 1e9
+            ragged['k{}'.format(k)] = dict(
+                ms_per_pass=ms, ms_bottom_up=ms_bu, value=flat.n_nodes * k * C / (ms * 1e-3), unit='node*state*char/s',
+                schedule=dict(zip(('level_schedule', 'n_two_level', 'n_stacked'), eng.schedule_info())),
+                roofline=dict(bound='hbm', model_gb=gb, achieved=gb / (ms * 1e-3), peak=HBM_PEAK_GBS, unit='GB/s',
+                              frac=gb / (ms * 1e-3) / HBM_PEAK_GBS,
+                              bottom_up=dict(model_gb=sb['bottom_up'] * C / 1e9,
+                                             achieved=sb['bottom_up'] * C / 1e9 / (ms_bu * 1e-3))))
+    # (HBM counters of the k = 64 pass, profiles/r04b_ragged_tree_memory_counters.md: 28.8 GB moved for the 22.2 GB of this
+    # model -- the gathered 8-byte scalars cost 128-byte lines -- at 5.1 TB/s, the same rate as on the balanced tree)
+    ragged['k64']['roofline']['traffic_note'] = ('rocprofv3 TCC_EA0_RDREQ / WRREQ, round 4: 28.8 GB per pass at 5.1 TB/s '
+                                                 '(profiles/r04b_ragged_tree_memory_counters.md)')
+    out['ragged262k'] = dict(workload='random binary tree, 262 144 tips (FlatForest.random seed 3), 32 characters, F81 with '
+                                      'per-character frequencies, marginal pass (model upload + BU + TD + posteriors)', **ragged)
     # ---- cfg3: 262 144 tips, JTT k=20, joint sweep (P(t) built and folded in registers on the FP64 vector units,
     #      pml_kernels_eigen_joint.h) + back-trace
     from pastml_amd.models.JTTModel import JTT_FREQUENCIES, JTT_RATE_MATRIX
@@ -626,6 +751,7 @@ def secondary_measurements(device):
         dt, st, res = best
         ref_s = ref_cols = None
         worst = None
+        signed = []
         if os.path.exists(gold):
             z = np.load(gold)
             names = list(z['columns']) if 'columns' in z.files else []
@@ -635,8 +761,9 @@ def secondary_measurements(device):
                 if r['character'] in names:
                     key = 'c{}_loglik'.format(names.index(r['character']))
                     if key in z.files:
-                        d = abs(r['log_likelihood'] - float(z[key])) / abs(float(z[key]))
-                        worst = d if worst is None else max(worst, d)
+                        sd = (r['log_likelihood'] - float(z[key])) / abs(float(z[key]))   # signed: > 0 = ours is the better optimum
+                        worst = abs(sd) if worst is None else max(worst, abs(sd))
+                        signed.append((sd, str(r['character'])))
         out['cfg5_acr'] = dict(workload='BASELINE config 5: HIV1C tree (3 619 tips), all {} usable annotation columns, '
                                         'MPPA + F81 with parameter optimisation, one acr() call, 1 GPU'.format(len(res)),
                                seconds=dt, characters=len(res), groups=st.get('groups'), sweep_rounds=st.get('rounds'),
@@ -647,7 +774,12 @@ def secondary_measurements(device):
                                                         'timed when tests/golden/hiv1c_all.npz was generated '
                                                         '(tests/golden/make_golden.py)'),
                                speedup_vs_reference=(ref_s / dt) if ref_s else None,
-                               max_rel_loglik_difference_to_reference=worst)
+                               max_rel_loglik_difference_to_reference=worst,
+                               # signed (ours - reference) / |reference|: a positive value is a better optimum than the
+                               # reference's own; every column more than 1e-6 away is named
+                               worst_rel_loglik_shortfall=min([d for d, _ in signed] + [0.0]) if signed else None,
+                               best_rel_loglik_gain=max([d for d, _ in signed] + [0.0]) if signed else None,
+                               columns_beyond_1e6={c: d for d, c in signed if abs(d) > 1e-6})
     return out
 
 

@@ -87,6 +87,17 @@ int pml_ctx_sync(pml_ctx* ctx);
 enum { PML_OPT_CHERRY_FUSION = 1, PML_OPT_KEEP_TD = 2, PML_OPT_EIGEN_FUSED = 3, PML_OPT_EIGEN_JOINT_VALU = 4,
        PML_OPT_IMPLICIT_TIP_POSTERIORS = 5 };
 int pml_ctx_set_option(pml_ctx* ctx, int option, int value);
+/*
+ * The switches of the schedules (tuning and test variants; DESIGN.md section 6a lists them).  Every ctx has its own set:
+ * the defaults are the environment variables PASTML_HIP_<NAME> as they stand when the ctx is created, and this call
+ * overrides one of them for this ctx -- name with or without the PASTML_HIP_ prefix; is_set = 0 returns the switch to
+ * "not given" (the built-in default), otherwise value is what the environment variable would have held (for the NO_* /
+ * on-off switches: value != 0 = on).  Switches that shape what pml_tree_upload / pml_chars_alloc build (NO_SUPER,
+ * SUPER_MIN, STACK_MIN, NO_STACK, BLOCK_NODES, SMALL_MAX_NODES, NO_SHAPE_SORT, F81_R, ...) must be set before the tree
+ * is uploaded (PML_ERR_INVALID afterwards); the others take effect with the next sweep (captured launch sequences are
+ * dropped).  Unknown names are PML_ERR_INVALID.  There is no process-wide state: two contexts may run different schedules.
+ */
+int pml_ctx_set_tunable(pml_ctx* ctx, const char* name, int64_t value, int is_set);
 /* bytes of device memory currently held by the ctx / free on its device */
 int pml_ctx_memory(pml_ctx* ctx, uint64_t* held, uint64_t* device_free);
 /*
@@ -96,6 +107,17 @@ int pml_ctx_memory(pml_ctx* ctx, uint64_t* held, uint64_t* device_free);
  * model is checked against this); the reference has no counterpart.
  */
 int pml_schedule_info(pml_ctx* ctx, int32_t* level_schedule, int32_t* n_two_level, int32_t* n_stacked);
+/*
+ * Which of the schedules the marginal sweeps of the F81 family will take on this context (tree uploaded, columns
+ * allocated; enqueue_bottom_up's own decision): the whole sweep in one launch (small forests), subtree blocks + the top
+ * above them (mid-size forests; *n_blocks = their number), the level schedule with two-level / stacked units
+ * (*n_absorbed = the stored nodes that the general two-level units keep out of memory, beside those pml_schedule_info
+ * counts), plain level launches; PML_SCHEDULE_OTHER_MODEL for the matrix / eigen models.  For tests that compare schedules bit for bit: they
+ * assert that the schedule under test is the one that runs.
+ */
+enum { PML_SCHEDULE_SINGLE_LAUNCH = 0, PML_SCHEDULE_BLOCKS = 1, PML_SCHEDULE_TWO_LEVEL = 2, PML_SCHEDULE_LEVELS = 3,
+       PML_SCHEDULE_OTHER_MODEL = 4 };
+int pml_sweep_schedule(pml_ctx* ctx, int32_t* kind, int32_t* n_blocks, int32_t* n_absorbed);
 
 /* ---- tree (replaces the ete3 traversals of pastml/ml.py:109,269,449) ------------------------------------------ */
 /*

@@ -29,6 +29,7 @@ import numpy as np
 import pandas as pd
 
 from pastml_amd import hip
+from pastml_amd.models import PointBlock
 from pastml_amd.tree import (TreeNode, get_flat_forest, AnnotationColumn, StateSetColumn, MaskColumn, ArrayColumn,
                              _DICT_FEATURE_NAMES)
 
@@ -424,6 +425,26 @@ class CharacterBatch(object):
         opt = self._opt
         eng, offsets, models = opt['engine'], opt['offsets'], opt['models']
         lo, hi = opt['total'], 0
+        if opt['all_set'] and opt.get('staged') and all(type(p) is PointBlock for p in requests.values()):
+            # the array path (F81 family, every column staged before): a character's points go into the engine's staging
+            # arrays as slices, the masks are looked at once per block
+            for c, block in requests.items():
+                a, n = int(offsets[c]), len(block)
+                if n > int(offsets[c + 1]) - a:
+                    raise ValueError('{} points for a block of {} columns'.format(n, int(offsets[c + 1]) - a))
+                eng.stage_f81(a, block.pi, block.sf, block.tau, block.tf)
+                plain = block.tau != 0
+                words = None if plain.all() else self._altered_variant(c)
+                want = np.zeros(n, dtype=np.int64) if words is None else (~plain).astype(np.int64)
+                for j in np.flatnonzero(opt['variant'][a:a + n] != want):
+                    eng.set_mask_words(self.masks[c] if want[j] == 0 else words, col_begin=a + int(j))
+                    opt['variant'][a + j] = want[j]
+                lo, hi = min(lo, a), max(hi, a + n)
+            eng.commit_f81(lo, hi)
+            self.n_sweeps += sum(len(p) for p in requests.values())
+            eng.bottom_up_submit(True)
+            opt['in_flight'] = requests
+            return
         for c, points in requests.items():
             a = int(offsets[c])
             if len(points) > int(offsets[c + 1]) - a:
@@ -449,6 +470,7 @@ class CharacterBatch(object):
                     opt['variant'][i] = 0
             eng.set_models(models)
             opt['all_set'] = True
+            opt['staged'] = eng.kind == hip.KIND_F81   # (every column's parameters are in the engine's staging arrays now)
         else:
             eng.set_models(models[lo:hi], col_begin=lo)
         self.n_sweeps += sum(len(p) for p in requests.values())
@@ -552,7 +574,9 @@ def two_point_scheme(x0, lower, upper):
     if zero.any():   # (a step below the spacing of x0: scipy falls back to a relative one)
         sign = (x0 >= 0).astype(float) * 2 - 1
         h = np.where(zero, np.finfo(np.float64).eps ** 0.5 * sign * np.maximum(1.0, np.abs(x0)), h)
-    h, _ = _adjust_scheme_to_bounds(x0, h, 1, '1-sided', lower, upper)
+    x = x0 + h
+    if ((x < lower) | (x > upper)).any():   # (otherwise scipy's helper returns h as it is)
+        h, _ = _adjust_scheme_to_bounds(x0, h, 1, '1-sided', lower, upper)
     points = np.repeat(x0[None, :], len(x0), axis=0)
     idx = np.arange(len(x0))
     points[idx, idx] += h
@@ -612,7 +636,12 @@ class _Found(object):
         self.x, self.fun, self.success, self.nit, self.nfev = x, fun, success, nit, nfev
 
 
-def lbfgsb_steps(x0, bounds):
+# tests / diagnostics: a dict {character: [one record per L-BFGS-B run: start, iterates (x_k, f(x_k)), end, counts]} that
+# the searches fill in when it is not None (tests/test_gpu_hiv1c.py compares them with the reference's own runs)
+TRACE = None
+
+
+def lbfgsb_steps(x0, bounds, iterates=None):
     """
     Generator form of ``minimize(fun, x0, method='L-BFGS-B', bounds=bounds, jac=True)`` with scipy's default options
     (maxcor 10, ftol 2.22e-9, gtol 1e-5, maxfun = maxiter = 15000, maxls 20): yields the points at which it needs
@@ -661,6 +690,8 @@ def lbfgsb_steps(x0, bounds):
             fx, gx = f, g
         elif task[0] == 1:
             n_iterations += 1
+            if iterates is not None:
+                iterates.append((np.array(x, dtype=np.float64), float(fx)))
             if n_iterations >= maxiter:
                 task[0], task[1] = 5, 504
             elif nfev > maxfun:
@@ -680,7 +711,7 @@ def _drive(steps, evaluate):
         return stop.value
 
 
-def search_parameters_steps(model, observed_frequencies, rng):
+def search_parameters_steps(model, observed_frequencies, rng, trace=None):
     """
     One L-BFGS-B search over the model's currently free parameters (the procedure of pastml/ml.py:174-237): it starts
     from the current values, then -- if frequencies are free -- from the observed frequencies, then from up to 98
@@ -693,10 +724,11 @@ def search_parameters_steps(model, observed_frequencies, rng):
     lower, upper = bounds[:, 0], bounds[:, 1]
 
     def negative(values):
-        return [np.inf if pd.isnull(v) else -v for v in values]
+        values = np.asarray(values, dtype=np.float64)   # (ln L values or NaN: what pd.isnull would flag)
+        return np.where(np.isnan(values), np.inf, -values)
 
     def objective(ps):
-        if np.any(pd.isnull(ps)):
+        if np.isnan(np.asarray(ps, dtype=np.float64)).any():
             return np.nan
         values = yield [np.asarray(ps, dtype=np.float64)]
         return negative(values)[0]
@@ -706,14 +738,13 @@ def search_parameters_steps(model, observed_frequencies, rng):
         # of its own helper records the points it asks for, the batch evaluates them together, a second pass runs on
         # the table of their values -- points and arithmetic are scipy's
         ps = np.asarray(ps, dtype=np.float64)
-        if np.any(pd.isnull(ps)):
+        if np.isnan(ps).any():
             return np.nan, np.full(len(ps), np.nan)
         if _adjust_scheme_to_bounds is not None:
-            if np.any((ps < lower) | (ps > upper)):
+            if ((ps < lower) | (ps > upper)).any():
                 raise ValueError("`x0` violates bound constraints.")
             points, steps = two_point_scheme(ps, lower, upper)
-            values = yield [ps] + list(points)
-            values = np.array(negative(values), dtype=np.float64)
+            values = negative((yield np.vstack((ps[None, :], points))))
             return values[0], (values[1:] - values[0]) / steps
         asked = []
         _approx_derivative(lambda x: asked.append(np.array(x, dtype=np.float64)) or 0.0, ps, method='2-point',
@@ -743,13 +774,18 @@ def search_parameters_steps(model, observed_frequencies, rng):
             x0 = start_observed
         else:
             x0 = rng.uniform(lower, upper)
-        search = lbfgsb_steps(x0, bounds)
+        iterates = [] if trace is not None else None
+        search = lbfgsb_steps(x0, bounds, iterates)
         try:
             point = next(search)
             while True:
                 point = search.send((yield from objective_and_gradient(point)))
         except StopIteration as stop:
             found = stop.value
+        if trace is not None:
+            trace.append(dict(x0=np.array(x0, dtype=np.float64), x=np.array(found.x), fun=float(found.fun),
+                              success=bool(found.success), nit=found.nit, nfev=found.nfev,
+                              iterates=np.array([it[0] for it in iterates]), values=np.array([it[1] for it in iterates])))
         if found.success and not np.any(np.isnan(found.x)) and -found.fun >= to_beat:
             model.set_params_from_optimised(found.x)
             return -found.fun
@@ -846,7 +882,8 @@ def fit_parameters_steps(character, model, observed_frequencies, rng, search=Non
     def run_search():
         if search is not None:
             return search(points_of)
-        steps = search_parameters_steps(model, observed_frequencies, rng)
+        steps = search_parameters_steps(model, observed_frequencies, rng,
+                                        None if TRACE is None else TRACE.setdefault(character, []))
         try:
             vectors = next(steps)
             while True:

@@ -47,8 +47,61 @@ static int fail(int code, const char* fmt, ...) {
         if (_s != PML_OK) return _s; \
     } while (0)
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Every switch of the schedules in one table per context.  The defaults come from the environment (PASTML_HIP_<NAME>) when
+// the ctx is created, pml_ctx_set_tunable overrides them for that ctx -- there are no function-local statics: two contexts
+// of one process can run different schedules, and a test that sets a switch gets it (round 3 latched several of them at
+// their first use in the process).  FLAG: on when present (environment: whatever the value; set_tunable: value != 0).
+// TREE: read by pml_tree_upload / pml_chars_alloc, so it must be set before the tree is uploaded.
+// ---------------------------------------------------------------------------------------------------------------------
+#define PML_TUNABLES(X)                                                                                              \
+    X(MATRIX_R1, 1, 1) X(GRID_CAP, 0, 0) X(SMALL_MANY_NODES, 0, 0) X(BLOCK_MAX_WORK, 0, 0) X(BLOCK_MAX_STEPS, 0, 0)    \
+    X(NO_MFMA, 1, 0) X(NO_EIGEN_FUSED, 1, 0) X(NO_HKY_FUSED, 1, 0) X(NO_TD_STAGE, 1, 0) X(TD_STAGE_SCALARS, 0, 0)      \
+    X(BLOCK_THREADS, 0, 0) X(EIG_BLOCKS, 0, 0) X(NO_EIGEN_GEMM, 1, 0) X(NO_EIGEN_JOINT_VALU, 1, 0) X(EIGJ_BLOCKS, 0, 0) \
+    X(EIGJ_TIP_BLOCKS, 0, 0) X(EIGJ_ONE_TIPS_KERNEL, 1, 0) X(EIGJ_TIER_THIN, 0, 1) X(EIGJ_TIER_DEPTH, 0, 1)            \
+    X(NO_EIGJ_TIERS, 1, 1) X(NO_BT_TIERS, 1, 1) X(NO_SHAPE_SORT, 1, 1) X(NO_SUPER, 1, 1) X(SUPER_MIN, 0, 1)            \
+    X(STACK_MIN, 0, 1) X(NO_STACK, 1, 1) X(DEBUG, 1, 0) X(BLOCK_NODES, 0, 1) X(BLOCK_MAX_STORED, 0, 1)                 \
+    X(BLOCK_HEIGHT_CAP, 0, 1) X(SMALL_MAX_NODES, 0, 1) X(F81_R, 0, 1) X(F81_TD_R, 0, 1) X(NO_GRAPH, 1, 1)              \
+    X(NARROW_UNITS, 0, 0) X(NO_EIGG_TIERS, 1, 0) X(NO_ABSORB, 1, 1) X(ABSORB_MIN, 0, 1)
+enum PmlTunable {
+#define X(name, flag, tree) T_##name,
+    PML_TUNABLES(X)
+#undef X
+    T_COUNT
+};
+static const char* const kTunableName[T_COUNT] = {
+#define X(name, flag, tree) #name,
+    PML_TUNABLES(X)
+#undef X
+};
+static const bool kTunableFlag[T_COUNT] = {
+#define X(name, flag, tree) flag != 0,
+    PML_TUNABLES(X)
+#undef X
+};
+static const bool kTunableTree[T_COUNT] = {
+#define X(name, flag, tree) tree != 0,
+    PML_TUNABLES(X)
+#undef X
+};
+struct PmlTune {
+    long long val[T_COUNT];
+    bool has[T_COUNT];
+    PmlTune() {
+        for (int i = 0; i < T_COUNT; ++i) {
+            const std::string var = std::string("PASTML_HIP_") + kTunableName[i];
+            const char* e = getenv(var.c_str());
+            has[i] = e != nullptr;
+            val[i] = e ? atoll(e) : 0;
+        }
+    }
+    bool on(int i) const { return has[i]; }
+    long long get(int i, long long dflt) const { return has[i] ? val[i] : dflt; }
+};
+
 struct pml_ctx {
     int device = 0;
+    PmlTune tune;  // the schedules' switches (environment at creation, pml_ctx_set_tunable)
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // kernel timing (pml_profile_*): event pairs around the level launches, read back when the profile is read -- a
@@ -113,6 +166,15 @@ struct pml_ctx {
         PmlUnit *d_bu_units_rs = nullptr, *d_td_units_rs = nullptr;  // ... sorted by shape inside every level
         // stacked units (pml_kernels_f81.h): nodes with two plain stored children of two stored children each, by
         // bottom-up level and by depth; their children as units of their own for downloads
+        int n_child_units = 0;  // entries of d_child_units: the children of the two-level units + the absorbed nodes below
+        // general two-level units (pml_kernels_f81.h, round 4): stored nodes whose children are tips and cherries are
+        // absorbed by their parents, whatever the shapes.  Bottom-up: the absorbing nodes by level, three records each;
+        // top-down: one record per absorbed node (pad = the parent), all in one launch
+        int n_absorbing = 0, n_absorbed = 0;
+        PmlUnit *d_absorb_bu = nullptr, *d_absorb_td = nullptr;
+        PmlUnit* d_absorbing_td = nullptr;  // the absorbing nodes' own top-down records (those with tips / cherries to finish)
+        int n_absorbing_td = 0;
+        std::vector<int> absorb_bu_offsets;
         int n_stack = 0;
         PmlUnit *d_stack_bu = nullptr, *d_stack_td = nullptr, *d_stack_children = nullptr;
         std::vector<int> stack_bu_offsets, stack_td_offsets;
@@ -257,9 +319,9 @@ static int upload(pml_ctx* ctx, T* dst, const T* src, size_t count) {
     return PML_OK;
 }
 
-static void pick_group(int k, int& G, int& R) {
+static void pick_group(const pml_ctx* ctx, int k, int& G, int& R) {
     R = k <= 32 ? 1 : (k <= 128 ? 2 : 4);
-    if (k > 16 && k <= 32 && !getenv("PASTML_HIP_MATRIX_R1")) R = 4;  // 8 lanes per unit: 8 units per wavefront
+    if (k > 16 && k <= 32 && !ctx->tune.on(T_MATRIX_R1)) R = 4;  // 8 lanes per unit: 8 units per wavefront
     const int need = (k + R - 1) / R;
     G = 1;
     while (G < need) G <<= 1;
@@ -268,9 +330,9 @@ static void pick_group(int k, int& G, int& R) {
 // Blocks along x for a level of n_units units per column (grid-stride loops take the rest).  The cap on the total
 // number of blocks was measured on cfg4 (MI355X): the pipelined bottom-up kernels like ~8192 (a wave then walks several
 // units and its prefetch stage pays off), everything else 32768; persistent-size grids (768-2048) were 5-15 % slower.
-static int grid_for(int n_units, int units_per_block, int C, bool pipelined = false) {
+static int grid_for(const pml_ctx* ctx, int n_units, int units_per_block, int C, bool pipelined = false) {
     int blocks = (n_units + units_per_block - 1) / units_per_block;
-    static const int cap_env = getenv("PASTML_HIP_GRID_CAP") ? atoi(getenv("PASTML_HIP_GRID_CAP")) : 0;
+    const int cap_env = (int)ctx->tune.get(T_GRID_CAP, 0);
     const int total_cap = cap_env > 0 ? cap_env : (pipelined ? 8192 : 32768);
     int cap = total_cap / (C < 1 ? 1 : C);
     if (cap < 8) cap = 8;
@@ -287,7 +349,7 @@ static int grid_for(int n_units, int units_per_block, int C, bool pipelined = fa
 // tree with 20 states has levels of 16 passes and stays with the level kernels: 0.12 against 0.27 ms).  Same unit
 // functions and lane shapes as the level kernels: identical bits.
 static bool single_launch_sweeps(const pml_ctx* c) {
-    static const int many = getenv("PASTML_HIP_SMALL_MANY_NODES") ? atoi(getenv("PASTML_HIP_SMALL_MANY_NODES")) : 16384;
+    const int many = (int)c->tune.get(T_SMALL_MANY_NODES, 16384);
     return c->small || (c->C >= 64 && c->N <= many && c->levels_fit_workgroup);
 }
 
@@ -295,13 +357,13 @@ static bool single_launch_sweeps(const pml_ctx* c) {
 // to fill the chip (stored nodes x columns beyond ~1.6e5: measured on 16 384 - 131 072-tip trees with 1 - 32 columns)
 // the level kernels, which spread every level over all compute units, win again.
 static bool block_schedule(const pml_ctx* c) {
-    static const long long limit = getenv("PASTML_HIP_BLOCK_MAX_WORK") ? atoll(getenv("PASTML_HIP_BLOCK_MAX_WORK")) : 160000;
+    const long long limit = c->tune.get(T_BLOCK_MAX_WORK, 160000);
     // (Round 2 also capped the number of (block, level, column) workgroup steps: with 512-thread workgroups a ragged tree
     // times many columns ran in rounds of long-lived workgroups and lost to the level kernels.  The workgroups now
     // shrink until all are resident (launch_blocks_f81) and the blocks end below the top's lowest level
     // (pml_tree_upload): over scripts/schedule_sweep.py's grid the blocks never lose -- profiles/r03c_schedule_sweep.txt.
     // PASTML_HIP_BLOCK_MAX_STEPS is kept as a switch.)
-    static const long long steps = getenv("PASTML_HIP_BLOCK_MAX_STEPS") ? atoll(getenv("PASTML_HIP_BLOCK_MAX_STEPS")) : (1ll << 40);
+    const long long steps = c->tune.get(T_BLOCK_MAX_STEPS, 1ll << 40);
     return c->blocks.ok && !c->bu_offsets_f.empty() && (long long)c->bu_offsets_f.back() * c->C <= limit &&
            c->blocks.steps * c->C <= steps;
 }
@@ -354,14 +416,14 @@ static PmlState state_of(const pml_ctx* c) {
 // Eigen models with 16 <= k <= 32 run the fused matrix-core sweeps (pml_kernels_eigen_mfma.h): P(t) is built and
 // consumed in registers.  PASTML_HIP_NO_MFMA / PASTML_HIP_NO_EIGEN_FUSED fall back to the materialised-P kernels.
 static bool eigen_fused(const pml_ctx* c) {
-    static const bool off = getenv("PASTML_HIP_NO_MFMA") || getenv("PASTML_HIP_NO_EIGEN_FUSED");
+    const bool off = c->tune.on(T_NO_MFMA) || c->tune.on(T_NO_EIGEN_FUSED);
     return !off && c->eig_fused_opt && c->kind == PML_MODEL_EIGEN && c->k >= 16 && c->k <= 32 && c->W == 1 &&
            c->ks == 4 * ((c->k + 3) / 4);
 }
 
 // HKY sweeps build P(t) in registers (pml_kernels_matrix.h, PML_P_HKY); PASTML_HIP_NO_HKY_FUSED reads the batch.
 static bool hky_fused(const pml_ctx* c) {
-    static const bool off = getenv("PASTML_HIP_NO_HKY_FUSED") != nullptr;
+    const bool off = c->tune.on(T_NO_HKY_FUSED);
     return !off && c->kind == PML_MODEL_HKY && c->k == 4 && c->ks == 4 && c->G == 4 && c->R == 1 && c->W == 1;
 }
 
@@ -467,7 +529,7 @@ static void launch_sweep(pml_ctx* ctx, SweepKind what, const int* level, int n_l
     const PmlCols c = cols_of(ctx);
     const PmlState st = state_of(ctx);
     const int upb = PML_WAVES_PER_BLOCK * (64 / G);
-    dim3 grid(grid_for(n_level, upb, ctx->C), ctx->C), block(PML_BLOCK);
+    dim3 grid(grid_for(ctx, n_level, upb, ctx->C), ctx->C), block(PML_BLOCK);
     const PmlModel m = model_of(ctx);
     if (G == 4 && R == 1 && hky_fused(ctx)) {  // HKY: P(t) from the closed form, in registers (no batch in HBM)
         constexpr int GG = G == 4 ? 4 : 4, RR = R == 1 ? 1 : 1;  // (keeps the other shapes from instantiating it)
@@ -520,7 +582,7 @@ static void launch_sweep_f81(pml_ctx* ctx, SweepKind what, const int* level, int
     const int upb = PML_WAVES_PER_BLOCK * (64 / G);
     const bool pipelined = fused_lists || what == SW_BU_MARG || what == SW_BU_CHERRIES || what == SW_BU_JOINT ||
                            what == SW_BU_JOINT_NOVEC || what == SW_BU_CHERRIES_JOINT;
-    dim3 grid(grid_for(n_level, upb, ctx->C, pipelined), ctx->C), block(PML_BLOCK);
+    dim3 grid(grid_for(ctx, n_level, upb, ctx->C, pipelined), ctx->C), block(PML_BLOCK);
     // the level is given as a position in one of the node lists; the kernels read the descriptor list parallel to it
     const PmlUnit* units = nullptr;
     // (level launches of wide units walk the lists sorted by shape, pml_tree_upload)
@@ -557,8 +619,8 @@ static void launch_sweep_f81(pml_ctx* ctx, SweepKind what, const int* level, int
             break;
         case SW_TD_FUSED: {
             // units narrower than 8 lanes stage their posterior rows in LDS (pml_kernels_f81.h, post_row / post_onehot)
-            static const bool no_stage = getenv("PASTML_HIP_NO_TD_STAGE") != nullptr;
-            static const int scal_env = getenv("PASTML_HIP_TD_STAGE_SCALARS") ? atoi(getenv("PASTML_HIP_TD_STAGE_SCALARS")) : -1;
+            const bool no_stage = ctx->tune.on(T_NO_TD_STAGE);
+            const int scal_env = (int)ctx->tune.get(T_TD_STAGE_SCALARS, -1);
             int stage = 0;
             size_t lds = 0;
             // (measured, 262 144 tips x 32 columns: k = 2 0.59 -> 0.39 ms, k = 4 0.68 -> 0.45, k = 8 0.83 -> 0.71; with four
@@ -628,7 +690,7 @@ static void launch_blocks_f81(pml_ctx* ctx, bool bottom_up) {
             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, td_f81_blocks_kernel<G, R>, 64, 0);
         wpc = (e == hipSuccess && nb > 0) ? nb : 8;
     }
-    static const int forced = getenv("PASTML_HIP_BLOCK_THREADS") ? atoi(getenv("PASTML_HIP_BLOCK_THREADS")) : 0;
+    const int forced = (int)ctx->tune.get(T_BLOCK_THREADS, 0);
     int threads = PML_SMALL_BLOCK;
     const long long n_wg = (long long)B.n_blocks * ctx->C;
     while (threads > 64 && n_wg * (threads / 64) > (long long)n_cus * wpc) threads /= 2;
@@ -658,7 +720,7 @@ static void launch_blocks_f81(pml_ctx* ctx, bool bottom_up) {
 template <int G, int R>
 static void launch_select(pml_ctx* ctx, int method, int force_joint, const u64* d_lh_mask) {
     const int upb = PML_WAVES_PER_BLOCK * (64 / G);
-    dim3 grid(grid_for(ctx->N, upb, ctx->C), ctx->C), block(PML_BLOCK);
+    dim3 grid(grid_for(ctx, ctx->N, upb, ctx->C), ctx->C), block(PML_BLOCK);
     hipLaunchKernelGGL((select_states_kernel<G, R>), grid, block, 0, ctx->stream, ctx->N, ctx->k, ctx->ks, ctx->W,
                        ctx->d_post, d_lh_mask, ctx->d_js, method, force_joint, ctx->d_masks, ctx->d_nsel);
 }
@@ -773,7 +835,7 @@ static void launch_super_f81(pml_ctx* ctx, bool bottom_up) {
     const PmlState st = state_of(ctx);
     const int upb = PML_WAVES_PER_BLOCK * (64 / G);
     // (top-down: one unit per child of a two-level node)
-    dim3 grid(grid_for(bottom_up ? ctx->sup.n : 2 * ctx->sup.n, upb, ctx->C, bottom_up), ctx->C), block(PML_BLOCK);
+    dim3 grid(grid_for(ctx, bottom_up ? ctx->sup.n : 2 * ctx->sup.n, upb, ctx->C, bottom_up), ctx->C), block(PML_BLOCK);
     if (bottom_up)
         hipLaunchKernelGGL((bu_f81_super_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, ctx->sup.d_units, ctx->sup.n);
     else
@@ -787,11 +849,32 @@ static void launch_stack_f81(pml_ctx* ctx, bool bottom_up, int a, int n) {
     const PmlCols c = cols_of(ctx);
     const PmlState st = state_of(ctx);
     const int upb = PML_WAVES_PER_BLOCK * (64 / G);
-    dim3 grid(grid_for(bottom_up ? n : 2 * n, upb, ctx->C), ctx->C), block(PML_BLOCK);
+    dim3 grid(grid_for(ctx, bottom_up ? n : 2 * n, upb, ctx->C), ctx->C), block(PML_BLOCK);
     if (bottom_up)
         hipLaunchKernelGGL((bu_f81_stack_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, ctx->sup.d_stack_bu + a, n);
     else
         hipLaunchKernelGGL((td_f81_stack_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, ctx->sup.d_stack_td + a, n);
+}
+
+// general two-level units: the absorbing nodes of bottom-up level `level` (a launch next to the level's plain units), or
+// every absorbed node's top-down unit (one launch behind the depth launches)
+template <int G, int R>
+static void launch_absorb_f81(pml_ctx* ctx, bool bottom_up, int a, int n) {
+    const PmlTree t = tree_of(ctx, true);
+    const PmlCols c = cols_of(ctx);
+    const PmlState st = state_of(ctx);
+    const int upb = PML_WAVES_PER_BLOCK * (64 / G);
+    dim3 grid(grid_for(ctx, n, upb, ctx->C), ctx->C), block(PML_BLOCK);
+    if (bottom_up) {
+        hipLaunchKernelGGL((bu_f81_absorb_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, ctx->sup.d_absorb_bu + 3 * (size_t)a, n);
+    } else {
+        hipLaunchKernelGGL((td_f81_absorb_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, ctx->sup.d_absorb_td + a, n);
+        if (ctx->sup.n_absorbing_td > 0) {
+            dim3 g2(grid_for(ctx, ctx->sup.n_absorbing_td, upb, ctx->C), ctx->C);
+            hipLaunchKernelGGL((td_f81_absorbing_kernel<G, R>), g2, block, 0, ctx->stream, t, c, st, ctx->sup.d_absorbing_td,
+                               ctx->sup.n_absorbing_td);
+        }
+    }
 }
 
 #define PML_SUPER_CASES(X) \
@@ -812,6 +895,29 @@ static int dispatch_super_f81(pml_ctx* ctx, bool bottom_up) {
     PML_SUPER_CASES(X)
 #undef X
     return fail(PML_ERR_UNSUPPORTED, "no two-level F81 kernel for G=%d R=%d", g, r);
+}
+
+static int dispatch_absorb_f81(pml_ctx* ctx, bool bottom_up, int level) {
+    const pml_ctx::SuperSchedule& U = ctx->sup;
+    if (U.n_absorbed == 0) return PML_OK;
+    int a = 0, n = U.n_absorbed;
+    if (bottom_up) {
+        if (level + 1 >= (int)U.absorb_bu_offsets.size()) return PML_OK;
+        a = U.absorb_bu_offsets[level];
+        n = U.absorb_bu_offsets[level + 1] - a;
+    }
+    if (n <= 0) return PML_OK;
+    int g, r;
+    super_shape(ctx, bottom_up, g, r);
+#define X(G_, R_)                                          \
+    if (g == G_ && r == R_) {                              \
+        launch_absorb_f81<G_, R_>(ctx, bottom_up, a, n);   \
+        HIP_TRY(hipGetLastError());                        \
+        return PML_OK;                                     \
+    }
+    PML_SUPER_CASES(X)
+#undef X
+    return fail(PML_ERR_UNSUPPORTED, "no general two-level F81 kernel for G=%d R=%d", g, r);
 }
 
 static int dispatch_stack_f81(pml_ctx* ctx, bool bottom_up, int level) {
@@ -846,7 +952,7 @@ static int launch_eigen_fused(pml_ctx* ctx, int mode, const int* nodes, int firs
         typedef EigShape<KS_> S;                                                                                   \
         const size_t lds = ((size_t)S::KP * k + (size_t)PML_WAVES_PER_BLOCK * S::WAVE_LDS) * sizeof(double);       \
         int blocks = (n + PML_WAVES_PER_BLOCK * S::NB - 1) / (PML_WAVES_PER_BLOCK * S::NB);                        \
-        static const int cap_all = getenv("PASTML_HIP_EIG_BLOCKS") ? atoi(getenv("PASTML_HIP_EIG_BLOCKS")) : 8192;   \
+        const int cap_all = (int)ctx->tune.get(T_EIG_BLOCKS, 8192);                                                  \
         const int cap = std::max(8, cap_all / std::max(1, ctx->C));                                                \
         if (blocks > cap) blocks = cap;                                                                            \
         hipLaunchKernelGGL((eigen_fused_kernel<NT_, KS_, MODE_>), dim3(blocks, ctx->C), dim3(PML_BLOCK), lds,      \
@@ -872,8 +978,7 @@ static int launch_eigen_fused(pml_ctx* ctx, int mode, const int* nodes, int firs
 // contiguous id range (first) of n nodes
 // (any eigen model with up to 32 states: below 16 the joint sweep still reads materialised P(t), see eigen_fused)
 static bool eigen_gemm(const pml_ctx* c) {
-    static const bool off = getenv("PASTML_HIP_NO_EIGEN_GEMM") || getenv("PASTML_HIP_NO_MFMA") ||
-                            getenv("PASTML_HIP_NO_EIGEN_FUSED");
+    const bool off = c->tune.on(T_NO_EIGEN_GEMM) || c->tune.on(T_NO_MFMA) || c->tune.on(T_NO_EIGEN_FUSED);
     return !off && c->eig_fused_opt && c->kind == PML_MODEL_EIGEN && c->k >= 2 && c->k <= 32 && c->W == 1;
 }
 
@@ -973,7 +1078,7 @@ static int launch_eigen_narrow(pml_ctx* ctx, int mode, const int* nodes, const i
 // The joint sweep of the eigen models on the vector units (pml_kernels_eigen_joint.h) for 2 <= k <= 32;
 // PASTML_HIP_NO_EIGEN_JOINT_VALU keeps the matrix-core kernels (pml_kernels_eigen_mfma.h).
 static bool eigen_joint_valu(const pml_ctx* c) {
-    static const bool off = getenv("PASTML_HIP_NO_EIGEN_JOINT_VALU") != nullptr;
+    const bool off = c->tune.on(T_NO_EIGEN_JOINT_VALU);
     return !off && c->eigj_valu_opt && c->kind == PML_MODEL_EIGEN && c->k >= 2 && c->k <= PML_EIGJ_STRIDE && c->W == 1 &&
            c->d_AinvT != nullptr;
 }
@@ -989,7 +1094,7 @@ static int launch_eigen_joint(pml_ctx* ctx, const PmlUnit* units, const int* d_o
     const PmlState st = state_of(ctx);
     const PmlModel m = model_of(ctx);
     const int per_block = PML_WAVES_PER_BLOCK * (64 / ctx->k);
-    static const int cap_all = getenv("PASTML_HIP_EIGJ_BLOCKS") ? atoi(getenv("PASTML_HIP_EIGJ_BLOCKS")) : 1024;
+    const int cap_all = (int)ctx->tune.get(T_EIGJ_BLOCKS, 1024);
 #define PML_EIGJ_CASE(KU_)                                                                                          \
     if (KU == KU_) {                                                                                                \
         if (d_offsets) {                                                                                            \
@@ -1026,12 +1131,12 @@ static int launch_eigen_joint_tips(pml_ctx* ctx) {
     const PmlModel m = model_of(ctx);
     const int per_block = PML_WAVES_PER_BLOCK * (64 / ctx->k);
     int blocks = (ctx->n_tips + per_block - 1) / per_block;
-    static const int cap_all = getenv("PASTML_HIP_EIGJ_TIP_BLOCKS") ? atoi(getenv("PASTML_HIP_EIGJ_TIP_BLOCKS")) : 2048;
+    const int cap_all = (int)ctx->tune.get(T_EIGJ_TIP_BLOCKS, 2048);
     const int cap = std::max(8, cap_all / std::max(1, ctx->C));
     if (blocks > cap) blocks = cap;
     // observed tips in the lean kernel; what it leaves on the columns' lists (tips with several or all states allowed)
     // in one launch of the general kernel -- PASTML_HIP_EIGJ_ONE_TIPS_KERNEL: everything in the general kernel (round 2)
-    static const bool one_kernel = getenv("PASTML_HIP_EIGJ_ONE_TIPS_KERNEL") != nullptr;
+    const bool one_kernel = ctx->tune.on(T_EIGJ_ONE_TIPS_KERNEL);
     const int rest_blocks = std::min(blocks, std::max(8, 1024 / std::max(1, ctx->C)));
     // (every tip of every column known to be observed -- the masks came from pml_masks_from_tip_states: nothing can be
     // on the lists, their launch is left out)
@@ -1214,6 +1319,30 @@ int pml_ctx_set_option(pml_ctx* ctx, int option, int value) {
     return fail(PML_ERR_INVALID, "unknown option %d", option);
 }
 
+int pml_ctx_set_tunable(pml_ctx* ctx, const char* name, int64_t value, int is_set) {
+    if (!ctx || !name) return fail(PML_ERR_INVALID, "ctx / name is NULL");
+    if (strncmp(name, "PASTML_HIP_", 11) == 0) name += 11;
+    for (int i = 0; i < T_COUNT; ++i) {
+        if (strcmp(name, kTunableName[i]) != 0) continue;
+        if (kTunableTree[i] && ctx->N != 0)
+            return fail(PML_ERR_INVALID, "%s is read when the tree is uploaded: set it before pml_tree_upload", name);
+        const bool on = is_set != 0 && (!kTunableFlag[i] || value != 0);
+        ctx->tune.has[i] = on;
+        ctx->tune.val[i] = on ? (long long)value : 0;
+        // a captured launch sequence was made under the old setting
+        drop_graph(ctx->bu_graph[0]);
+        drop_graph(ctx->bu_graph[1]);
+        drop_graph(ctx->td_graph);
+        drop_graph(ctx->mp_graph);
+        drop_graph(ctx->bt_graph);
+        ctx->prep_dirty = true;
+        ctx->bu_mode = -1;
+        ctx->td_valid = ctx->js_valid = false;
+        return PML_OK;
+    }
+    return fail(PML_ERR_INVALID, "unknown tunable %s", name);
+}
+
 int pml_ctx_sync(pml_ctx* ctx) {
     if (!ctx) return fail(PML_ERR_INVALID, "ctx is NULL");
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -1242,6 +1371,22 @@ int pml_schedule_info(pml_ctx* ctx, int32_t* level_schedule, int32_t* n_two_leve
     if (level_schedule) *level_schedule = on ? 1 : 0;
     if (n_two_level) *n_two_level = on ? ctx->sup.n : 0;
     if (n_stacked) *n_stacked = on ? ctx->sup.n_stack : 0;
+    return PML_OK;
+}
+
+int pml_sweep_schedule(pml_ctx* ctx, int32_t* kind, int32_t* n_blocks, int32_t* n_absorbed) {
+    if (!ctx || ctx->C == 0) return fail(PML_ERR_INVALID, "allocate the columns first");
+    const int model = ctx->kind;
+    if (model < 0) ctx->kind = PML_MODEL_F81;  // (until the first model is set the F81 family is assumed)
+    int k = PML_SCHEDULE_LEVELS;
+    if (ctx->kind != PML_MODEL_F81) k = PML_SCHEDULE_OTHER_MODEL;
+    else if (single_launch_sweeps(ctx)) k = PML_SCHEDULE_SINGLE_LAUNCH;
+    else if (block_schedule(ctx)) k = PML_SCHEDULE_BLOCKS;
+    else if (super_sweeps(ctx)) k = PML_SCHEDULE_TWO_LEVEL;
+    ctx->kind = model;
+    if (kind) *kind = k;
+    if (n_blocks) *n_blocks = k == PML_SCHEDULE_BLOCKS ? ctx->blocks.n_blocks : 0;
+    if (n_absorbed) *n_absorbed = k == PML_SCHEDULE_TWO_LEVEL ? ctx->sup.n_absorbed : 0;
     return PML_OK;
 }
 
@@ -1329,7 +1474,9 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
     const bool fuse = ctx->fuse, keep_td = ctx->keep_td, eig_fused_opt = ctx->eig_fused_opt, eigj_valu_opt = ctx->eigj_valu_opt,
                implicit_tips = ctx->implicit_tips;
     PmlComm* comm = ctx->comm;
+    const PmlTune tune = ctx->tune;
     *ctx = pml_ctx();
+    ctx->tune = tune;
     ctx->fuse = fuse;
     ctx->keep_td = keep_td;
     ctx->eig_fused_opt = eig_fused_opt;
@@ -1494,12 +1641,12 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
             {
                 pml_ctx::EigenTiers& E = ctx->eig_tiers;
                 E = pml_ctx::EigenTiers();
-                const int thin = getenv("PASTML_HIP_EIGJ_TIER_THIN") ? atoi(getenv("PASTML_HIP_EIGJ_TIER_THIN")) : 4096;
-                const int depth = getenv("PASTML_HIP_EIGJ_TIER_DEPTH") ? std::max(2, atoi(getenv("PASTML_HIP_EIGJ_TIER_DEPTH"))) : 4;
+                const int thin = (int)ctx->tune.get(T_EIGJ_TIER_THIN, 4096);
+                const int depth = std::max(2, (int)ctx->tune.get(T_EIGJ_TIER_DEPTH, 4));
                 const int top_nodes = 48;
                 int L0 = n_bu_levels;
                 while (L0 > 0 && bu_offsets[L0] - bu_offsets[L0 - 1] <= thin) --L0;
-                if (!getenv("PASTML_HIP_NO_EIGJ_TIERS") && n_bu_levels - L0 >= 6) {
+                if (!ctx->tune.on(T_NO_EIGJ_TIERS) && n_bu_levels - L0 >= 6) {
                     std::vector<int> level_of(n_nodes, -1);
                     for (int l = 0; l < n_bu_levels; ++l)
                         for (int q = bu_offsets[l]; q < bu_offsets[l + 1]; ++q) level_of[bu_order[q]] = l;
@@ -1512,7 +1659,7 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
                     // balanced binary tree gets tiers of four levels, ragged trees deeper ones (measured: HIV1C-shaped
                     // and random 40 000-tip trees are 10 - 20 % faster with 6 - 8 levels than with 4, cfg3 slower).
                     // PASTML_HIP_EIGJ_TIER_DEPTH fixes the depth.
-                    const bool fixed_depth = getenv("PASTML_HIP_EIGJ_TIER_DEPTH") != nullptr;
+                    const bool fixed_depth = ctx->tune.on(T_EIGJ_TIER_DEPTH);
                     while (a + 2 <= n_bu_levels && bu_offsets[a + 1] - bu_offsets[a] > top_nodes) {
                         int use = 0, nb = 0;
                         std::vector<std::vector<int>> cell;
@@ -1599,7 +1746,7 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
                 B = pml_ctx::BacktraceTiers();
                 int d1 = 1;
                 while (d1 < n_td_levels && td_offsets[d1 + 1] - td_offsets[d1] <= 1024) ++d1;
-                if (!getenv("PASTML_HIP_NO_BT_TIERS") && n_td_levels - d1 >= 2) {
+                if (!ctx->tune.on(T_NO_BT_TIERS) && n_td_levels - d1 >= 2) {
                     std::vector<int> depth_of(n_nodes, 0), anc(n_nodes, 0), tn, lv, start;
                     for (int l = 0; l < n_td_levels; ++l)
                         for (int i = td_offsets[l]; i < td_offsets[l + 1]; ++i) depth_of[i] = l;
@@ -1678,7 +1825,7 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
                 return out;
             };
             // (a balanced tree is in shape order as it is: no second copy, the launches walk the id-ordered lists)
-            const bool shape_sort = !getenv("PASTML_HIP_NO_SHAPE_SORT") && n_stored > 0 &&
+            const bool shape_sort = !ctx->tune.on(T_NO_SHAPE_SORT) && n_stored > 0 &&
                                     !(in_shape_order(ub_f, off, (size_t)n_stored) &&
                                       in_shape_order(ut_f, ctx->td_parent_offsets_f, (size_t)n_stored));
             if (shape_sort) {
@@ -1704,7 +1851,7 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
             U = pml_ctx::SuperSchedule();
             std::vector<char> pair(n_nodes, 0), sup(n_nodes, 0), gone(n_nodes, 0);
             std::vector<int> sup_list;
-            if (ctx->fuse && !getenv("PASTML_HIP_NO_SUPER")) {
+            if (ctx->fuse && !ctx->tune.on(T_NO_SUPER)) {
                 auto two = [&](int i) { return kind[i] == PML_KIND_STORED && n_children[i] == 2; };
                 for (int i = 0; i < n_nodes; ++i) {
                     if (!two(i)) continue;
@@ -1723,19 +1870,19 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
                     }
                 }
             }
-            const char* env_min = getenv("PASTML_HIP_SUPER_MIN");
-            const int min_units = env_min ? atoi(env_min) : 64;
+            const bool env_min = ctx->tune.on(T_SUPER_MIN);
+            const int min_units = (int)ctx->tune.get(T_SUPER_MIN, 64);
             // (a launch of its own per sweep: only where it carries a share of the work)
             // (PASTML_HIP_SUPER_MIN given: whatever their share, for tests on ragged forests)
             const bool use_sup = !sup_list.empty() && (int)sup_list.size() >= min_units &&
-                                 (env_min != nullptr || (long long)sup_list.size() * 16 >= n_stored);
+                                 (env_min || (long long)sup_list.size() * 16 >= n_stored);
             if (!use_sup) {  // (too few: no launch of their own; the stacked units below may still pay)
                 for (int n : sup_list) gone[n] = gone[first_child[n]] = gone[first_child[n] + 1] = 0;
                 sup_list.clear();
             }
             // (the rest-list schedule needs wide units and a forest beyond the subtree blocks' reach to be used at all:
             // super_sweeps; here only the tree is known)
-            if (ctx->fuse && !getenv("PASTML_HIP_NO_SUPER") && n_stored > 0) {
+            if (ctx->fuse && !ctx->tune.on(T_NO_SUPER) && n_stored > 0) {
                 std::vector<PmlUnit> us(std::max<size_t>(1, sup_list.size()));
                 {
                     PmlUnit u;   // (padding element of the lists below when there are no two-level units)
@@ -1758,6 +1905,58 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
                     u.pad = first_child[u.cfc[0]];
                     us[q] = u;
                 }
+                // General two-level units (round 4; pml_kernels_f81.h): what is left of the lowest fused level -- stored nodes
+                // whose children are tips and cherries, at most two of them, cherries of at most four tips -- is absorbed by
+                // the parents, whatever their level and shape (at most two children, stored ones among them in memory or
+                // absorbed; on levels of at most 65 536 nodes: the lane shape of the levels they leave).
+                // OFF unless PASTML_HIP_ABSORB_MIN = n is given (then: from n absorbed nodes on): measured on the random
+                // 262 144-tip tree x 32 characters, k = 64, they take 22 % of the stored nodes and 11 % of the modelled bytes
+                // out of the sweeps -- and the marginal pass takes the same 5.8 ms (profiles/r04c_*): bottom-up -5 %, top-down
+                // +2 %; the units that rebuild a node and go on with its children are bound by their dependent instruction
+                // chain (0.84 ns per unit and column against 0.63 for the plain units they replace), not by the bytes.
+                std::vector<char> absorbed(n_nodes, 0), absorbing(n_nodes, 0);
+                std::vector<int> absorbing_list, absorbed_list;
+                if (!ctx->tune.on(T_NO_ABSORB) && ctx->tune.on(T_ABSORB_MIN)) {
+                    auto level_size_of = [&](int node) { return off[fh[node]] - off[fh[node] - 1]; };
+                    auto small_unit = [&](int i) {   // what the lane-parallel gather of an 8-lane unit takes
+                        if (n_children[i] > 2) return false;
+                        for (int j = 0; j < n_children[i]; ++j) {
+                            const int ch = first_child[i] + j;
+                            if (kind[ch] == PML_KIND_CHERRY && n_children[ch] > 4) return false;
+                        }
+                        return true;
+                    };
+                    for (int q = 0; q < n_stored; ++q) {
+                        const int n = order[q];
+                        if (fh[n] < 2 || gone[n] || !small_unit(n) || level_size_of(n) > 65536) continue;
+                        // (every stored child must go: the node's own top-down unit then finishes tips and cherries only, and
+                        // nothing below depends on it -- it runs behind the depth launches, like its children's units)
+                        bool any = false, all = true;
+                        for (int j = 0; j < n_children[n]; ++j) {
+                            const int ch = first_child[n] + j;
+                            if (kind[ch] != PML_KIND_STORED) continue;
+                            const bool ok = fh[ch] == 1 && !gone[ch] && small_unit(ch);
+                            any |= ok;
+                            all &= ok;
+                        }
+                        if (!any || !all) continue;
+                        absorbing[n] = 1;
+                        for (int j = 0; j < n_children[n]; ++j)
+                            if (kind[first_child[n] + j] == PML_KIND_STORED) absorbed[first_child[n] + j] = 1;
+                    }
+                    int n_abs = 0;
+                    for (int i = 0; i < n_nodes; ++i) n_abs += absorbed[i];
+                    if (n_abs < (int)ctx->tune.get(T_ABSORB_MIN, 64)) {
+                        std::fill(absorbed.begin(), absorbed.end(), 0);
+                        std::fill(absorbing.begin(), absorbing.end(), 0);
+                    }
+                    for (int q = 0; q < n_stored; ++q) {
+                        if (absorbing[order[q]]) absorbing_list.push_back(order[q]);   // (bottom-up level order)
+                        if (absorbed[order[q]]) absorbed_list.push_back(order[q]);
+                    }
+                    for (int c2 : absorbed_list) gone[c2] = 1;   // (neither sweep's lists hold them)
+                    for (int n2 : absorbing_list) gone[n2] = 1;  // (... nor the absorbing nodes: launches of their own)
+                }
                 // stacked units: ascending height, a node takes its two children over when both are plain units (not
                 // two-level nodes, not taken over, not stacked themselves) with two stored children whose vectors are in
                 // memory; only on levels of 1 024 .. 65 536 nodes (below: the narrow end's single launch; above: the
@@ -1765,18 +1964,19 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
                 std::vector<char> stacked(n_nodes, 0), taken(n_nodes, 0), novec(n_nodes, 0);
                 std::vector<int> stack_list;
                 // (PASTML_HIP_STACK_MIN: smallest level that gets stacked units -- tests on small forests)
-                const int stack_min = getenv("PASTML_HIP_STACK_MIN") ? atoi(getenv("PASTML_HIP_STACK_MIN")) : 1024;
-                if (!getenv("PASTML_HIP_NO_STACK")) {
+                const int stack_min = (int)ctx->tune.get(T_STACK_MIN, 1024);
+                if (!ctx->tune.on(T_NO_STACK)) {
                     for (int n : sup_list) novec[first_child[n]] = novec[first_child[n] + 1] = 1;
+                    for (int c2 : absorbed_list) novec[c2] = 1;
                     auto level_size = [&](int node) { return off[fh[node]] - off[fh[node] - 1]; };
                     auto has_vec = [&](int g) { return kind[g] == PML_KIND_STORED && !novec[g]; };
                     auto plain2 = [&](int ch) {
-                        return kind[ch] == PML_KIND_STORED && !gone[ch] && !stacked[ch] && !taken[ch] && n_children[ch] == 2 &&
+                        return kind[ch] == PML_KIND_STORED && !gone[ch] && !absorbing[ch] && !stacked[ch] && !taken[ch] && n_children[ch] == 2 &&
                                has_vec(first_child[ch]) && has_vec(first_child[ch] + 1) && level_size(ch) <= 65536;
                     };
                     for (int q = 0; q < n_stored; ++q) {
                         const int n = order[q];
-                        if (gone[n] || taken[n] || n_children[n] != 2 || level_size(n) < stack_min || level_size(n) > 65536) continue;
+                        if (gone[n] || absorbing[n] || taken[n] || n_children[n] != 2 || level_size(n) < stack_min || level_size(n) > 65536) continue;
                         const int a = first_child[n], b = a + 1;
                         if (!plain2(a) || !plain2(b)) continue;
                         stacked[n] = 1;
@@ -1788,7 +1988,7 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
                 // two-level units leave -- the balanced part of a tree -- and not at a tenth of the nodes: a random binary
                 // tree of 262 144 tips had 6 132 of them, 10 % of its stored nodes, and was 3 % slower with them.
                 // PASTML_HIP_STACK_MIN given: whatever their share.)
-                if (getenv("PASTML_HIP_STACK_MIN") == nullptr &&
+                if (!ctx->tune.on(T_STACK_MIN) &&
                     (long long)stack_list.size() * 3 * 2 < (long long)n_stored - 3 * (long long)sup_list.size())
                     stack_list.clear();
                 for (int n : stack_list) gone[n] = gone[first_child[n]] = gone[first_child[n] + 1] = 1;
@@ -1822,9 +2022,9 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
                     PML_TRY(upload(ctx, U.d_stack_children, sc.data(), sc.size()));
                     HIP_TRY(hipStreamSynchronize(ctx->stream));
                     U.n_stack = (int)stack_list.size();
-                    if (getenv("PASTML_HIP_DEBUG")) fprintf(stderr, "pastml_hip: %d stacked units\n", U.n_stack);
+                    if (ctx->tune.on(T_DEBUG)) fprintf(stderr, "pastml_hip: %d stacked units\n", U.n_stack);
                 }
-                if (!sup_list.empty() || !stack_list.empty()) {  // (else: the plain level lists, nothing to build)
+                if (!sup_list.empty() || !stack_list.empty() || !absorbed_list.empty()) {  // (else: the plain level lists, nothing to build)
                 // rest lists: the level structure of the fused lists, without the nodes the two-level units take over
                 std::vector<int> bu_r, td_r;
                 U.bu_offsets_r.assign(1, 0);
@@ -1846,12 +2046,95 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
                         ch_list.push_back(first_child[n]);
                         ch_list.push_back(first_child[n] + 1);
                     }
+                    for (int c2 : absorbed_list) ch_list.push_back(c2);
+                    U.n_child_units = (int)ch_list.size();
                     describe(ch_list.data(), (int)ch_list.size(), true, uch);  // (at least one element)
                     PML_TRY(dev_alloc(ctx, &U.d_child_units, uch.size()));
                     PML_TRY(upload(ctx, U.d_child_units, uch.data(), uch.size()));
                 }
                 describe(bu_r.data(), (int)bu_r.size(), true, ubr);
                 describe(td_r.data(), (int)td_r.size(), true, utr);
+                if (!absorbed_list.empty()) {
+                    // top-down records of the absorbing nodes that have tips or cherries of their own to finish: an absorbed
+                    // child is skipped there (PML_CODE_ABSORBED; its slot of cfc points at the node itself, so that the gather
+                    // of "its tips" reads valid addresses: an absorbed child has at least three descendants after the node in
+                    // the numbering)
+                    std::vector<int> own_td;
+                    for (int n : absorbing_list) {
+                        bool other = false;
+                        for (int j = 0; j < n_children[n]; ++j) other |= !absorbed[first_child[n] + j];
+                        if (other) own_td.push_back(n);
+                    }
+                    std::vector<PmlUnit> uown;
+                    describe(own_td.data(), (int)own_td.size(), true, uown);
+                    for (size_t q = 0; q < own_td.size(); ++q) {
+                        const int n = own_td[q];
+                        for (int j = 0; j < n_children[n] && j < 4; ++j)
+                            if (absorbed[first_child[n] + j]) {
+                                uown[q].packed = (uown[q].packed & ~(7 << (8 + 3 * j))) | (PML_CODE_ABSORBED << (8 + 3 * j));
+                                uown[q].cfc[j] = n;
+                            }
+                    }
+                    std::stable_sort(uown.begin(), uown.begin() + own_td.size(), shape_less);
+                    PML_TRY(dev_alloc(ctx, &U.d_absorbing_td, uown.size()));
+                    PML_TRY(upload(ctx, U.d_absorbing_td, uown.data(), uown.size()));
+                    U.n_absorbing_td = (int)own_td.size();
+                    // bottom-up: the absorbing nodes by level, three records each, one shape next to the other
+                    std::vector<PmlUnit> own, kids;
+                    describe(absorbing_list.data(), (int)absorbing_list.size(), true, own);
+                    struct Triple { PmlUnit r[3]; };
+                    std::vector<Triple> triples(absorbing_list.size());
+                    U.absorb_bu_offsets.assign(max_h + 1, 0);
+                    for (size_t q = 0; q < absorbing_list.size(); ++q) {
+                        const int n = absorbing_list[q];
+                        ++U.absorb_bu_offsets[fh[n]];
+                        Triple& T = triples[q];
+                        T.r[0] = own[q];
+                        T.r[0].pad = 0;
+                        for (int j = 0; j < 2; ++j) {
+                            T.r[1 + j] = own[q];
+                            if (j < n_children[n] && absorbed[first_child[n] + j]) {
+                                const int c2 = first_child[n] + j;
+                                std::vector<PmlUnit> one;
+                                describe(&c2, 1, true, one);
+                                T.r[1 + j] = one[0];
+                                T.r[0].pad |= 1 << j;
+                            }
+                        }
+                    }
+                    for (int l = 0; l < max_h; ++l) U.absorb_bu_offsets[l + 1] += U.absorb_bu_offsets[l];
+                    // (absorb_bu_offsets[l] .. [l + 1]: the units of bottom-up level l = fused height l + 1; the counts above
+                    // were filed under the height)
+                    for (int l = 0; l < max_h; ++l) {
+                        const size_t a = (size_t)U.absorb_bu_offsets[l], b = (size_t)U.absorb_bu_offsets[l + 1];
+                        std::stable_sort(triples.begin() + a, triples.begin() + b, [](const Triple& x, const Triple& y) {
+                            if (x.r[0].pad != y.r[0].pad) return x.r[0].pad < y.r[0].pad;
+                            if (x.r[0].packed != y.r[0].packed) return x.r[0].packed < y.r[0].packed;
+                            if (x.r[1].packed != y.r[1].packed) return x.r[1].packed < y.r[1].packed;
+                            return x.r[2].packed < y.r[2].packed;
+                        });
+                    }
+                    std::vector<PmlUnit> flat3;
+                    flat3.reserve(3 * triples.size() + 3);
+                    for (const Triple& T : triples)
+                        for (int j = 0; j < 3; ++j) flat3.push_back(T.r[j]);
+                    // top-down: one record per absorbed node, pad = the parent, one shape next to the other
+                    std::vector<PmlUnit> down;
+                    describe(absorbed_list.data(), (int)absorbed_list.size(), true, down);
+                    down.resize(absorbed_list.size());
+                    for (size_t q = 0; q < absorbed_list.size(); ++q) down[q].pad = parent[absorbed_list[q]];
+                    std::stable_sort(down.begin(), down.end(), shape_less);
+                    PML_TRY(dev_alloc(ctx, &U.d_absorb_bu, flat3.size()));
+                    PML_TRY(dev_alloc(ctx, &U.d_absorb_td, down.size()));
+                    PML_TRY(upload(ctx, U.d_absorb_bu, flat3.data(), flat3.size()));
+                    PML_TRY(upload(ctx, U.d_absorb_td, down.data(), down.size()));
+                    HIP_TRY(hipStreamSynchronize(ctx->stream));
+                    U.n_absorbing = (int)absorbing_list.size();
+                    U.n_absorbed = (int)absorbed_list.size();
+                    if (ctx->tune.on(T_DEBUG))
+                        fprintf(stderr, "pastml_hip: %d of %d stored nodes absorbed by %d parents\n", U.n_absorbed, n_stored,
+                                U.n_absorbing);
+                }
                 U.bu_level_vec_r.assign(max_h > 0 ? max_h : 1, 0);
                 for (int l = 0; l < max_h; ++l)
                     for (int q = U.bu_offsets_r[l]; q < U.bu_offsets_r[l + 1] && !U.bu_level_vec_r[l]; ++q) {
@@ -1884,8 +2167,8 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
                 HIP_TRY(hipStreamSynchronize(ctx->stream));  // the vectors go out of scope
                 U.n = (int)sup_list.size();
                 // worth its lists: two-level units, or stacked units that take a sixteenth of the stored nodes over
-                U.ok = U.n > 0 || U.n_stack >= 64 || (U.n_stack > 0 && getenv("PASTML_HIP_STACK_MIN") != nullptr);
-                if (getenv("PASTML_HIP_DEBUG"))
+                U.ok = U.n > 0 || U.n_absorbed > 0 || U.n_stack >= 64 || (U.n_stack > 0 && ctx->tune.on(T_STACK_MIN));
+                if (ctx->tune.on(T_DEBUG))
                     fprintf(stderr, "pastml_hip: %d two-level units (%d of %d stored nodes)%s\n", U.n, 3 * U.n, n_stored,
                             U.ok ? "" : " -- plain level lists");
                 }
@@ -1893,12 +2176,10 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
         }
         // ---- subtree blocks: stored nodes -> blocks (maximal subtrees of <= S stored nodes) + top
         {
-            const char* env = getenv("PASTML_HIP_BLOCK_NODES");
-            const int S = env ? atoi(env) : 256;  // measured: 128-512 are within a few per cent, 1024+ loses at k >= 16
+            const int S = (int)ctx->tune.get(T_BLOCK_NODES, 256);  // measured: 128-512 are within a few per cent, 1024+ loses at k >= 16
             pml_ctx::BlockSchedule& B = ctx->blocks;
             B = pml_ctx::BlockSchedule();
-            const char* env_cap = getenv("PASTML_HIP_BLOCK_MAX_STORED");
-            const int cap_stored = env_cap ? atoi(env_cap) : (1 << 17);  // beyond: the streaming level kernels
+            const int cap_stored = (int)ctx->tune.get(T_BLOCK_MAX_STORED, 1 << 17);  // beyond: the streaming level kernels
             if (S > 0 && n_stored > S && n_stored <= cap_stored) {
                 std::vector<int> ssz(n_nodes, 0), blk(n_nodes, -1), depth(n_nodes, 0);
                 for (int l = 0; l < n_td_levels; ++l)
@@ -1917,8 +2198,8 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
                 int h_cap = max_h;
                 for (int q = 0; q < n_stored; ++q)
                     if (ssz[order[q]] > S) h_cap = std::min(h_cap, fh[order[q]]);
-                if (const char* env_h = getenv("PASTML_HIP_BLOCK_HEIGHT_CAP")) {
-                    const int v = atoi(env_h);
+                if (ctx->tune.on(T_BLOCK_HEIGHT_CAP)) {
+                    const int v = (int)ctx->tune.get(T_BLOCK_HEIGHT_CAP, 0);
                     h_cap = v > 0 ? v : max_h + 1;
                 }
                 int nb = 0;
@@ -2005,7 +2286,7 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
                     HIP_TRY(hipStreamSynchronize(ctx->stream));  // the vectors go out of scope
                     B.n_blocks = nb;
                     for (int b = 0; b < nb; ++b) B.steps += bu_levels[b];
-                    if (getenv("PASTML_HIP_DEBUG"))
+                    if (ctx->tune.on(T_DEBUG))
                         fprintf(stderr, "pastml_hip: %d stored nodes, %d subtree blocks, %lld block levels, %d top levels of %d\n",
                                 n_stored, nb, B.steps, n_top_levels, max_h);
                     B.ok = true;
@@ -2028,8 +2309,7 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
         PML_TRY(upload(ctx, ctx->d_bu_offsets_f, ctx->bu_offsets_f.data(), ctx->bu_offsets_f.size()));
         PML_TRY(upload(ctx, ctx->d_td_parent_offsets_f, ctx->td_parent_offsets_f.data(), ctx->td_parent_offsets_f.size()));
         {
-            const char* env = getenv("PASTML_HIP_SMALL_MAX_NODES");
-            const int limit = env ? atoi(env) : 2048;
+            const int limit = (int)ctx->tune.get(T_SMALL_MAX_NODES, 2048);
             ctx->small = n_nodes <= limit;
         }
         HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -2048,16 +2328,16 @@ int pml_chars_alloc(pml_ctx* ctx, int32_t n_cols, int32_t k) {
     HIP_TRY(hipSetDevice(ctx->device));
     ctx->C = n_cols;
     ctx->k = k;
-    pick_group(k, ctx->G, ctx->R);
+    pick_group(ctx, k, ctx->G, ctx->R);
     ctx->ks = (k + ctx->R - 1) / ctx->R * ctx->R;
     {
         // F81 family: 4 states per lane (two 16-byte pairs).  Most of a unit's work is scalar (per child, per tip), so
         // the top-down kernels, which have the most of it, take 8 states per lane for 32 < k <= 64: 8 units per
         // wavefront share each scalar instruction.  PASTML_HIP_F81_R / PASTML_HIP_F81_TD_R = 2 / 4 / 8: tuning variants
-        auto shape = [&](const char* var, int dflt, int& G, int& R) {
+        auto shape = [&](int var, int dflt, int& G, int& R) {
             int rf = k >= 3 ? dflt : k;
-            if (const char* env = getenv(var)) {
-                const int v = atoi(env);
+            if (ctx->tune.on(var)) {
+                const int v = (int)ctx->tune.get(var, 0);
                 if ((v == 2 || v == 4 || v == 8) && k > 32 && k <= 64) rf = v;
             }
             R = rf;
@@ -2065,9 +2345,9 @@ int pml_chars_alloc(pml_ctx* ctx, int32_t n_cols, int32_t k) {
             G = 1;
             while (G < need) G <<= 1;
         };
-        shape("PASTML_HIP_F81_R", 4, ctx->Gf, ctx->Rf);
-        ctx->bu_wide_lanes = k > 32 && k <= 64 && ctx->Rf == 4 && !getenv("PASTML_HIP_F81_R");
-        shape("PASTML_HIP_F81_TD_R", (k > 32 && k <= 64) ? 8 : 4, ctx->Gt, ctx->Rt);
+        shape(T_F81_R, 4, ctx->Gf, ctx->Rf);
+        ctx->bu_wide_lanes = k > 32 && k <= 64 && ctx->Rf == 4 && !ctx->tune.on(T_F81_R);
+        shape(T_F81_TD_R, (k > 32 && k <= 64) ? 8 : 4, ctx->Gt, ctx->Rt);
         if (k >= 2 && (ctx->ks & 1)) ctx->ks += 1;  // 16-byte lane accesses
         {
             const int g = ctx->bu_wide_lanes ? 8 : ctx->Gf;
@@ -2101,7 +2381,7 @@ int pml_chars_alloc(pml_ctx* ctx, int32_t n_cols, int32_t k) {
     PML_TRY(dev_alloc(ctx, &ctx->d_err, n_cols));
     HIP_TRY(hipHostMalloc((void**)&ctx->h_loglik, sizeof(double) * n_cols));
     HIP_TRY(hipHostMalloc((void**)&ctx->h_err, sizeof(u64) * n_cols));
-    ctx->graphs = !(getenv("PASTML_HIP_NO_GRAPH"));
+    ctx->graphs = !ctx->tune.on(T_NO_GRAPH);
     PML_TRY(dev_alloc(ctx, &ctx->d_bu, CN * ctx->ks));
     PML_TRY(dev_alloc(ctx, &ctx->d_S, CN));
     PML_TRY(dev_alloc(ctx, &ctx->d_be, CN));
@@ -2110,7 +2390,7 @@ int pml_chars_alloc(pml_ctx* ctx, int32_t n_cols, int32_t k) {
     HIP_TRY(hipMemsetAsync(ctx->d_be, 0, CN * sizeof(i64), ctx->stream));
     // default masks: everything allowed
     {
-        dim3 grid(grid_for((int)std::min<size_t>((size_t)ctx->N * ctx->W, 1u << 30), PML_BLOCK, n_cols), n_cols);
+        dim3 grid(grid_for(ctx, (int)std::min<size_t>((size_t)ctx->N * ctx->W, 1u << 30), PML_BLOCK, n_cols), n_cols);
         hipLaunchKernelGGL(masks_fill_kernel, grid, dim3(PML_BLOCK), 0, ctx->stream, ctx->N, ctx->W, ctx->k,
                            ctx->d_masks, 0);
         HIP_TRY(hipGetLastError());
@@ -2181,7 +2461,7 @@ int pml_masks_from_tip_states(pml_ctx* ctx, int32_t col_begin, int32_t col_end, 
             return fail(PML_ERR_INVALID, "tip_ids[%d] = %d is not a tip", j, tip_ids[j]);
     for (size_t i = 0; i < (size_t)nc * n_tips; ++i)
         if (states[i] >= ctx->k) return fail(PML_ERR_INVALID, "state %d out of range (k = %d)", states[i], ctx->k);
-    dim3 grid(grid_for((int)std::min<size_t>((size_t)ctx->N * ctx->W, 1u << 30), PML_BLOCK, nc), nc);
+    dim3 grid(grid_for(ctx, (int)std::min<size_t>((size_t)ctx->N * ctx->W, 1u << 30), PML_BLOCK, nc), nc);
     hipLaunchKernelGGL(masks_fill_kernel, grid, dim3(PML_BLOCK), 0, ctx->stream, ctx->N, ctx->W, ctx->k, ctx->d_masks,
                        col_begin);
     HIP_TRY(hipGetLastError());
@@ -2197,7 +2477,7 @@ int pml_masks_from_tip_states(pml_ctx* ctx, int32_t col_begin, int32_t col_end, 
         if (e == hipSuccess)
             e = hipMemcpyAsync(d_states, states, sizeof(int) * (size_t)nc * n_tips, hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) {
-            dim3 g2(grid_for(n_tips, PML_BLOCK, nc), nc);
+            dim3 g2(grid_for(ctx, n_tips, PML_BLOCK, nc), nc);
             hipLaunchKernelGGL(masks_tips_kernel, g2, dim3(PML_BLOCK), 0, ctx->stream, ctx->N, ctx->W, ctx->k,
                                ctx->d_masks, col_begin, n_tips, d_ids, d_states);
             e = hipGetLastError();
@@ -2380,15 +2660,15 @@ static int run_prep(pml_ctx* ctx, bool force = false) {
         const int bx = (ctx->N + PML_BLOCK - 1) / PML_BLOCK;
         while (cpy < 8 && cpy * 2 <= ctx->C && (long long)bx * ((ctx->C + 2 * cpy - 1) / (2 * cpy)) >= 4096) cpy *= 2;
         const int ny = (ctx->C + cpy - 1) / cpy;
-        dim3 grid(grid_for(ctx->N, PML_BLOCK, ny), ny);
+        dim3 grid(grid_for(ctx, ctx->N, PML_BLOCK, ny), ny);
         hipLaunchKernelGGL(f81_prep_kernel, grid, dim3(PML_BLOCK), 0, ctx->stream, t, c, ctx->d_mu, ctx->d_sf,
                            ctx->d_tau, ctx->d_tauf, state_of(ctx), ctx->C, cpy);
         HIP_TRY(hipGetLastError());
     } else {
         if (ctx->kind == PML_MODEL_HKY) {
-            dim3 grid(grid_for(ctx->N, PML_BLOCK, ctx->C), ctx->C);
+            dim3 grid(grid_for(ctx, ctx->N, PML_BLOCK, ctx->C), ctx->C);
             hipLaunchKernelGGL(pij_hky_kernel, grid, dim3(PML_BLOCK), 0, ctx->stream, t, c, m, ctx->d_P);
-        } else if (ctx->k >= 16 && ctx->k <= 32 && !getenv("PASTML_HIP_NO_MFMA")) {
+        } else if (ctx->k >= 16 && ctx->k <= 32 && !ctx->tune.on(T_NO_MFMA)) {
             // FP64 matrix-core path (BASELINE config 3: JTT, k = 20)
             const int k = ctx->k;
             const int KS = (k + 3) / 4, NT = (k + 15) / 16;
@@ -2506,8 +2786,8 @@ int pml_pij_batch(pml_ctx* ctx, double* P_out) {
 // level over the whole chip, win earlier: the limit shrinks with the number of columns.
 // The fused eigen sweeps pass their own limit: a pass of theirs is a ~10 us dependent chain, so only levels that one
 // workgroup finishes in a single pass per wave belong to the narrow end.
-static int narrow_levels(const std::vector<int>& off, int n_levels, bool from_front, int C, int fixed_limit = 0) {
-    static const int limit_env = getenv("PASTML_HIP_NARROW_UNITS") ? atoi(getenv("PASTML_HIP_NARROW_UNITS")) : 0;
+static int narrow_levels(const pml_ctx* ctx, const std::vector<int>& off, int n_levels, bool from_front, int C, int fixed_limit = 0) {
+    const int limit_env = (int)ctx->tune.get(T_NARROW_UNITS, 0);
     const int limit = fixed_limit > 0 ? fixed_limit : (limit_env > 0 ? limit_env : std::max(8, 512 / std::max(1, C)));
     int n = 0;
     for (int q = 0; q < n_levels; ++q) {
@@ -2545,7 +2825,7 @@ static int enqueue_bottom_up(pml_ctx* ctx, int is_marginal, bool small_path, boo
         const pml_ctx::BlockSchedule& B = ctx->blocks;
         PML_TRY(dispatch_blocks_f81(ctx, true));
         const int nl = (int)B.top_bu_offsets.size() - 1;
-        const int tail = narrow_levels(B.top_bu_offsets, nl, false, ctx->C);
+        const int tail = narrow_levels(ctx, B.top_bu_offsets, nl, false, ctx->C);
         for (int l = 0; l < nl - tail; ++l) {
             const int a = B.top_bu_offsets[l], b = B.top_bu_offsets[l + 1];
             ctx->units_override = B.d_top_bu_units + a;
@@ -2566,10 +2846,15 @@ static int enqueue_bottom_up(pml_ctx* ctx, int is_marginal, bool small_path, boo
         PML_TRY(prof_end(ctx, 4, U.n > 0 ? 1 : 0));
         PML_TRY(prof_begin(ctx));
         const int nl = (int)U.bu_offsets_r.size() - 1;
-        int tail = narrow_levels(U.bu_offsets_r, nl, false, ctx->C);
+        int tail = narrow_levels(ctx, U.bu_offsets_r, nl, false, ctx->C);
         // (the narrow end's single launch walks the rest lists only: it starts above the last level with stacked units)
         for (int l = nl - 1; l >= 0 && U.n_stack > 0; --l)
             if (U.stack_bu_offsets[l + 1] > U.stack_bu_offsets[l]) {
+                tail = std::min(tail, nl - 1 - l);
+                break;
+            }
+        for (int l = nl - 1; l >= 0 && U.n_absorbed > 0; --l)   // (... and above the last level with absorbing nodes)
+            if (U.absorb_bu_offsets[l + 1] > U.absorb_bu_offsets[l]) {
                 tail = std::min(tail, nl - 1 - l);
                 break;
             }
@@ -2590,6 +2875,11 @@ static int enqueue_bottom_up(pml_ctx* ctx, int is_marginal, bool small_path, boo
                 PML_TRY(dispatch_stack_f81(ctx, true, l));
                 ++n_launch;
             }
+            // the level's absorbing nodes (what they read of stored nodes is of lower levels: independent as well)
+            if (U.n_absorbed > 0 && U.absorb_bu_offsets[l + 1] > U.absorb_bu_offsets[l]) {
+                PML_TRY(dispatch_absorb_f81(ctx, true, l));
+                ++n_launch;
+            }
         }
         PML_TRY(prof_end(ctx, 0, n_launch));
         if (tail > 0) {
@@ -2598,7 +2888,7 @@ static int enqueue_bottom_up(pml_ctx* ctx, int is_marginal, bool small_path, boo
         }
     } else if (fused) {
         const int nl = (int)ctx->bu_offsets_f.size() - 1;
-        const int tail = narrow_levels(ctx->bu_offsets_f, nl, false, ctx->C);
+        const int tail = narrow_levels(ctx, ctx->bu_offsets_f, nl, false, ctx->C);
         for (int l = 0; l < nl - tail; ++l) {
             const int a = ctx->bu_offsets_f[l], b = ctx->bu_offsets_f[l + 1];
             PML_TRY(dispatch_sweep(ctx, ctx->bu_level_vec_f[l] ? SW_BU_MARG_FUSED : SW_BU_MARG_FUSED_NOVEC,
@@ -2643,7 +2933,7 @@ static int enqueue_bottom_up(pml_ctx* ctx, int is_marginal, bool small_path, boo
             PML_TRY(launch_eigen_joint(ctx, ctx->d_bu_units, ctx->d_bu_offsets, l, ctx->n_bu_levels - l));
             PML_TRY(prof_end(ctx, 0, E.first_level + 2 + extra + (long long)E.tiers.size()));
         } else {
-        const int tail = narrow_levels(ctx->bu_offsets, ctx->n_bu_levels, false, ctx->C,
+        const int tail = narrow_levels(ctx, ctx->bu_offsets, ctx->n_bu_levels, false, ctx->C,
                                        PML_WAVES_PER_BLOCK * (64 / ctx->k));
         for (int l = 0; l < ctx->n_bu_levels - tail; ++l) {
             const int a = ctx->bu_offsets[l], b = ctx->bu_offsets[l + 1];
@@ -2656,7 +2946,7 @@ static int enqueue_bottom_up(pml_ctx* ctx, int is_marginal, bool small_path, boo
         // marginal sweep: P(t) is never formed, msg = A (e o (A^-1 v)) as two small GEMMs per 16 nodes
         PML_TRY(launch_eigen_gemm(ctx, PML_EIGG_TIPS, ctx->d_tips, 0, ctx->n_tips));
         const pml_ctx::EigenTiers& E = ctx->eig_tiers;
-        static const bool gemm_tiers = getenv("PASTML_HIP_NO_EIGG_TIERS") == nullptr;
+        const bool gemm_tiers = !ctx->tune.on(T_NO_EIGG_TIERS);
         if (gemm_tiers && E.ok && (long long)E.widest * ctx->C <= 16384) {
             // thin levels in tiers of subtree blocks, as in the joint sweep (pml_ctx::EigenTiers)
             for (int l = 0; l < E.first_level; ++l) {
@@ -2676,7 +2966,7 @@ static int enqueue_bottom_up(pml_ctx* ctx, int is_marginal, bool small_path, boo
             PML_TRY(prof_end(ctx, 0, E.first_level + 2 + extra + (long long)E.tiers.size()));
         } else {
         // levels one workgroup finishes in a pass or two per wave (4 waves x 16 nodes) share one launch
-        const int tail = narrow_levels(ctx->bu_offsets, ctx->n_bu_levels, false, ctx->C, 2 * PML_WAVES_PER_BLOCK * 16);
+        const int tail = narrow_levels(ctx, ctx->bu_offsets, ctx->n_bu_levels, false, ctx->C, 2 * PML_WAVES_PER_BLOCK * 16);
         for (int l = 0; l < ctx->n_bu_levels - tail; ++l) {
             const int a = ctx->bu_offsets[l], b = ctx->bu_offsets[l + 1];
             PML_TRY(launch_eigen_gemm(ctx, PML_EIGG_BU, ctx->d_bu_order + a, 0, b - a));
@@ -2690,7 +2980,7 @@ static int enqueue_bottom_up(pml_ctx* ctx, int is_marginal, bool small_path, boo
         PML_TRY(launch_eigen_tips(ctx, is_marginal ? 0 : 1));
         {
         const int eig_nb = ((ctx->k + 3) / 4) % 4 == 0 ? 1 : (((ctx->k + 3) / 4) % 2 == 0 ? 2 : 4);  // EigShape::NB
-        const int tail = narrow_levels(ctx->bu_offsets, ctx->n_bu_levels, false, ctx->C, PML_WAVES_PER_BLOCK * eig_nb);
+        const int tail = narrow_levels(ctx, ctx->bu_offsets, ctx->n_bu_levels, false, ctx->C, PML_WAVES_PER_BLOCK * eig_nb);
         for (int l = 0; l < ctx->n_bu_levels - tail; ++l) {
             const int a = ctx->bu_offsets[l], b = ctx->bu_offsets[l + 1];
             PML_TRY(launch_eigen_fused(ctx, mode, ctx->d_bu_order + a, 0, b - a, 0));
@@ -2848,7 +3138,7 @@ static int run_top_down(pml_ctx* ctx) {
             // block schedule: the top part (roots, its narrow end in one launch, its wide levels one launch each),
             // then all subtree blocks in one launch
             const pml_ctx::BlockSchedule& B = ctx->blocks;
-            const int head = ctx->n_roots <= 64 ? narrow_levels(B.top_td_offsets, ctx->n_td_levels, true, ctx->C) : 0;
+            const int head = ctx->n_roots <= 64 ? narrow_levels(ctx, B.top_td_offsets, ctx->n_td_levels, true, ctx->C) : 0;
             if (head == 0) PML_TRY(dispatch_sweep(ctx, SW_ROOTS, nullptr, ctx->n_roots));
             if (head > 0) PML_TRY(dispatch_small_f81(ctx, false, 0, 0, head, B.d_top_td_units, B.d_top_td_offsets));
             PML_TRY(prof_begin(ctx));
@@ -2870,7 +3160,7 @@ static int run_top_down(pml_ctx* ctx) {
             // the levels of the rest lists, then every two-level unit in one launch (it needs its node's row only, and
             // that comes from a unit of the rest lists or from the roots)
             const pml_ctx::SuperSchedule& U = ctx->sup;
-            int head = ctx->n_roots <= 64 ? narrow_levels(U.td_offsets_r, ctx->n_td_levels, true, ctx->C) : 0;
+            int head = ctx->n_roots <= 64 ? narrow_levels(ctx, U.td_offsets_r, ctx->n_td_levels, true, ctx->C) : 0;
             // (... and the single launch below the roots ends above the first depth with stacked nodes)
             for (int l = 0; l < ctx->n_td_levels && U.n_stack > 0; ++l)
                 if (U.stack_td_offsets[l + 1] > U.stack_td_offsets[l]) {
@@ -2900,12 +3190,15 @@ static int run_top_down(pml_ctx* ctx) {
             PML_TRY(prof_end(ctx, 1, n_launch));
             PML_TRY(prof_begin(ctx));
             PML_TRY(dispatch_super_f81(ctx, false));
-            PML_TRY(prof_end(ctx, 3, U.n > 0 ? 1 : 0));
+            // the absorbed nodes' units: each needs its parent's row only (a unit of the rest lists, a two-level unit is
+            // never its parent)
+            PML_TRY(dispatch_absorb_f81(ctx, false, 0));
+            PML_TRY(prof_end(ctx, 3, (U.n > 0 ? 1 : 0) + (U.n_absorbed > 0 ? 1 : 0) + (U.n_absorbed > 0 && U.n_absorbing_td > 0 ? 1 : 0)));
             return PML_OK;
         }
         // F81 family: the roots and the levels right below them in one launch
         const int head = (td_fused && !td_small && ctx->n_roots <= 64)
-                             ? narrow_levels(ctx->td_parent_offsets_f, ctx->n_td_levels, true, ctx->C) : 0;
+                             ? narrow_levels(ctx, ctx->td_parent_offsets_f, ctx->n_td_levels, true, ctx->C) : 0;
         if (!td_small && head == 0) PML_TRY(dispatch_sweep(ctx, SW_ROOTS, nullptr, ctx->n_roots));
         if (head > 0) PML_TRY(dispatch_small_f81(ctx, false, 0, 0, head));
         PML_TRY(prof_begin(ctx));  // the profile brackets the level kernel's launches only
@@ -2918,7 +3211,7 @@ static int run_top_down(pml_ctx* ctx) {
             int head = 0;
             {
                 std::vector<int> off(ctx->td_offsets.begin() + 1, ctx->td_offsets.end());
-                head = narrow_levels(off, ctx->n_td_levels - 1, true, ctx->C, 2 * PML_WAVES_PER_BLOCK * 16);
+                head = narrow_levels(ctx, off, ctx->n_td_levels - 1, true, ctx->C, 2 * PML_WAVES_PER_BLOCK * 16);
             }
             if (head > 0) {
                 PML_TRY(launch_eigen_gemm_narrow(ctx, PML_EIGG_TD, nullptr, ctx->d_td_offsets, 1, head));
@@ -2940,7 +3233,7 @@ static int run_top_down(pml_ctx* ctx) {
                 std::vector<int> off(ctx->td_offsets.begin() + 1, ctx->td_offsets.end());
                 const int ks4 = (ctx->k + 3) / 4;
                 const int eig_nb = ks4 % 4 == 0 ? 1 : (ks4 % 2 == 0 ? 2 : 4);  // EigShape::NB
-                head = narrow_levels(off, ctx->n_td_levels - 1, true, ctx->C, PML_WAVES_PER_BLOCK * eig_nb);
+                head = narrow_levels(ctx, off, ctx->n_td_levels - 1, true, ctx->C, PML_WAVES_PER_BLOCK * eig_nb);
             }
             if (head > 0) {
                 PML_TRY(launch_eigen_narrow(ctx, PML_EIG_TD, nullptr, ctx->d_td_offsets, 1, head));
@@ -2980,7 +3273,7 @@ static int run_top_down(pml_ctx* ctx) {
 // PML_OPT_IMPLICIT_TIP_POSTERIORS: whoever reads the posterior table gets the rows the sweep left implicit first
 static int materialize_tip_posteriors(pml_ctx* ctx) {
     if (!ctx->tip_post_missing || !ctx->d_post || ctx->n_tips == 0) return PML_OK;
-    dim3 grid(grid_for(ctx->n_tips, PML_BLOCK, ctx->C), ctx->C);
+    dim3 grid(grid_for(ctx, ctx->n_tips, PML_BLOCK, ctx->C), ctx->C);
     hipLaunchKernelGGL(tip_posteriors_kernel, grid, dim3(PML_BLOCK), 0, ctx->stream, cols_of(ctx), state_of(ctx), ctx->N,
                        ctx->d_tips, ctx->n_tips);
     HIP_TRY(hipGetLastError());
@@ -3023,7 +3316,7 @@ static int materialize_td(pml_ctx* ctx) {
         for (int d = 1; d < ctx->n_td_levels; ++d) {
             const int a = ctx->td_offsets[d], b = ctx->td_offsets[d + 1];
             if (b <= a) continue;
-            dim3 grid(grid_for(b - a, PML_WAVES_PER_BLOCK, ctx->C), ctx->C);
+            dim3 grid(grid_for(ctx, b - a, PML_WAVES_PER_BLOCK, ctx->C), ctx->C);
             hipLaunchKernelGGL(td_fill_kernel, grid, dim3(PML_BLOCK), 0, ctx->stream, tree_of(ctx, f81), cols_of(ctx), st,
                                f81 ? nullptr : ctx->d_P, f81 ? 1 : 0, a, b);
             HIP_TRY(hipGetLastError());
@@ -3144,7 +3437,7 @@ static int submit_joint_backtrace(pml_ctx* ctx) {
     int head = 0;
     {
         std::vector<int> off(ctx->td_offsets.begin() + 1, ctx->td_offsets.end());
-        head = narrow_levels(off, ctx->n_td_levels - 1, true, ctx->C, 1024);
+        head = narrow_levels(ctx, off, ctx->n_td_levels - 1, true, ctx->C, 1024);
     }
     const pml_ctx::BacktraceTiers& B = ctx->bt_tiers;
     // (tiers while one column's narrow end is the limit they were cut for: with many columns the narrow end is shorter
@@ -3171,7 +3464,7 @@ static int submit_joint_backtrace(pml_ctx* ctx) {
         for (int l = 1 + head; l < ctx->n_td_levels; ++l) {
             const int a = ctx->td_offsets[l], b = ctx->td_offsets[l + 1];
             if (b <= a) continue;
-            dim3 grid(grid_for(b - a, PML_BLOCK, ctx->C), ctx->C);
+            dim3 grid(grid_for(ctx, b - a, PML_BLOCK, ctx->C), ctx->C);
             hipLaunchKernelGGL(joint_backtrace_kernel, grid, dim3(PML_BLOCK), 0, ctx->stream, tree_of(ctx), cols_of(ctx),
                                state_of(ctx), a, b);
             HIP_TRY(hipGetLastError());
@@ -3351,7 +3644,7 @@ static int materialize_cherries(pml_ctx* ctx) {
     if (ctx->bu_absorbed) {
         // the children of the two-level units: their own units (two cherries of two tips), from the tips
         ctx->units_override = ctx->sup.d_child_units;
-        const int status = dispatch_sweep(ctx, SW_BU_MARG_FUSED_NOVEC, ctx->d_bu_order_f, 2 * ctx->sup.n);  // (nothing if n == 0)
+        const int status = dispatch_sweep(ctx, SW_BU_MARG_FUSED_NOVEC, ctx->d_bu_order_f, ctx->sup.n_child_units);  // (nothing if 0)
         ctx->units_override = nullptr;
         PML_TRY(status);
         // ... and the children of the stacked units (two stored children each; in chunks of at most 65 536 units: the

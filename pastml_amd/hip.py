@@ -22,6 +22,7 @@ BUF_BU, BUF_BU_SF, BUF_TD, BUF_TD_SF, BUF_POSTERIOR, BUF_LH_SUM, BUF_LH_SF, BUF_
     BUF_BRANCH_EXP = range(10)
 
 MAX_STATES = 256
+SCHEDULE_SINGLE_LAUNCH, SCHEDULE_BLOCKS, SCHEDULE_TWO_LEVEL, SCHEDULE_LEVELS, SCHEDULE_OTHER_MODEL = 0, 1, 2, 3, 4
 OPT_CHERRY_FUSION = 1
 OPT_KEEP_TD = 2
 OPT_EIGEN_FUSED = 3
@@ -65,8 +66,10 @@ SIGNATURES = {
     'pml_ctx_destroy': [_ctx_p],
     'pml_ctx_sync': [_ctx_p],
     'pml_ctx_set_option': [_ctx_p, ctypes.c_int, ctypes.c_int],
+    'pml_ctx_set_tunable': [_ctx_p, ctypes.c_char_p, ctypes.c_int64, ctypes.c_int],
     'pml_ctx_memory': [_ctx_p, _c_uint64_p, _c_uint64_p],
     'pml_schedule_info': [_ctx_p, _c_int32_p, _c_int32_p, _c_int32_p],
+    'pml_sweep_schedule': [_ctx_p, _c_int32_p, _c_int32_p, _c_int32_p],
     'pml_tree_upload': [_ctx_p, ctypes.c_int32, ctypes.c_int32, _c_int32_p, _c_int32_p, _c_int32_p, _c_double_p,
                         ctypes.c_int32, _c_int32_p, _c_int32_p, ctypes.c_int32, _c_int32_p, _c_int32_p, _c_int32_p,
                         _c_int32_p],
@@ -323,6 +326,11 @@ class BareContext(object):
     def set_option(self, option, value):
         _check(self._lib.pml_ctx_set_option(self._ctx, option, 1 if value else 0))
 
+    def set_tunable(self, name, value):
+        """One switch of the schedules for this context (value None: not given; see pml_ctx_set_tunable)."""
+        _check(self._lib.pml_ctx_set_tunable(self._ctx, str(name).encode(), 0 if value is None else int(value),
+                                             0 if value is None else 1))
+
     def memory(self):
         """(bytes of device memory held by this context, bytes free on its device)."""
         held, free = ctypes.c_uint64(0), ctypes.c_uint64(0)
@@ -334,6 +342,13 @@ class BareContext(object):
         a, b, c = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0)
         _check(self._lib.pml_schedule_info(self._ctx, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
         return bool(a.value), b.value, c.value
+
+    def sweep_schedule(self):
+        """(schedule of the F81 marginal sweeps -- SCHEDULE_SINGLE_LAUNCH / _BLOCKS / _TWO_LEVEL / _LEVELS / _OTHER_MODEL,
+        number of subtree blocks, stored nodes absorbed by the general two-level units)."""
+        a, b, c = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0)
+        _check(self._lib.pml_sweep_schedule(self._ctx, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return a.value, b.value, c.value
 
     def comm_init(self, rank, world, unique_id=None):
         """Attaches a communicator (RCCL for world > 1; unique_id: the 128 bytes of rank 0's comm_unique_id())."""
@@ -389,9 +404,16 @@ class Engine(BareContext):
     >>> post, lh_sum, lh_sf = eng.top_down_marginals()
     """
 
-    def __init__(self, flat, n_cols, k, device=None, cherry_fusion=True, keep_td=False):
+    def __init__(self, flat, n_cols, k, device=None, cherry_fusion=True, keep_td=False, tune=None):
+        """
+        tune: {switch name: value or None} -- the schedules' switches for THIS engine (pml_ctx_set_tunable; names as the
+        PASTML_HIP_* environment variables, with or without the prefix; None = back to the built-in default whatever the
+        environment says).  Set before the tree is uploaded, so the switches that shape the schedules take effect.
+        """
         BareContext.__init__(self, device)
         lib = self._lib
+        for name, value in (tune or {}).items():
+            self.set_tunable(name, value)
         if not cherry_fusion:
             _check(lib.pml_ctx_set_option(self._ctx, OPT_CHERRY_FUSION, 0))
         if keep_td:
@@ -482,6 +504,24 @@ class Engine(BareContext):
                                                    _ptr(tips, ctypes.c_int32), _ptr(states, ctypes.c_int32)))
 
     # ------------------------------------------------------------------------------------------------------------------
+    def stage_f81(self, col_begin, pi, sf, tau, tf):
+        """F81 family: parameters of columns col_begin .. into the staging arrays (arrays [n, k], [n], [n], [n]); commit_f81
+        hands a range of them to the library."""
+        ce = col_begin + len(sf)
+        if col_begin < 0 or ce > self.n_cols or pi.shape != (len(sf), self.k):
+            raise ValueError('parameter block of {} columns x {} states does not fit at column {}'.format(len(sf), pi.shape[-1],
+                                                                                                         col_begin))
+        self._par_pi[col_begin:ce] = pi
+        self._par[0, col_begin:ce] = sf
+        self._par[1, col_begin:ce] = tau
+        self._par[2, col_begin:ce] = tf
+
+    def commit_f81(self, col_begin, col_end):
+        a_pi, a_sf, a_tau, a_tf = self._par_addr
+        _check(self._lib.pml_model_set_f81(self._ctx, col_begin, col_end, a_pi + col_begin * self.k * 8, a_sf + col_begin * 8,
+                                           a_tau + col_begin * 8, a_tf + col_begin * 8))
+        self.kind = KIND_F81
+
     def set_models(self, models, col_begin=0):
         """models: list (one per column) of Model objects or (spec dict, (sf, tau, tau_factor)) tuples."""
         specs, rates = [], []

@@ -98,6 +98,28 @@ TAU_PARAMETER = ScalarParameter('tau', '_optimise_tau', lambda model: (0, model.
                                 SMOOTHING_FACTOR, 'Smoothing factor', 0, False, pins_on_read=False)
 
 
+class PointBlock(object):
+    """
+    The points of one batch as arrays -- frequencies [n, k], scaling factors, smoothing factors and their tau factors [n]
+    -- for the models whose kernel description is (kind, pi): the batch goes to the engine's staging arrays as slices
+    instead of n dictionaries and tuples (57 000 points per acr() over the HIV1C columns).  Reads like the list of
+    (kernel description, rate parameters) it replaces: len(), indexing, iteration.
+    """
+    __slots__ = ('kind', 'pi', 'sf', 'tau', 'tf')
+
+    def __init__(self, kind, pi, sf, tau, tf):
+        self.kind, self.pi, self.sf, self.tau, self.tf = kind, pi, sf, tau, tf
+
+    def __len__(self):
+        return len(self.sf)
+
+    def __getitem__(self, i):
+        return dict(kind=self.kind, pi=self.pi[i]), (float(self.sf[i]), float(self.tau[i]), float(self.tf[i]))
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+
 class Model(object):
     """
     Base model: scaling factor ``sf``, smoothing factor ``tau`` (reference: pastml/models/__init__.py:17-273).

@@ -5,7 +5,7 @@ per-branch arithmetic runs on the device (kernel_spec() describes the model to l
 """
 import numpy as np
 
-from pastml_amd.models import Model, ModelWithFrequencies, ScalarParameter, KIND_F81, KIND_HKY
+from pastml_amd.models import Model, ModelWithFrequencies, PointBlock, ScalarParameter, KIND_F81, KIND_HKY
 
 
 F81 = 'F81'
@@ -41,7 +41,8 @@ class F81Model(ModelWithFrequencies):
         # first, then pi = (ratios, 1) / their sum): a character's gradient is k + 1 points per optimiser step, and
         # decoding them one by one through the property setters was a quarter of the host time of a sweep round.
         X = np.asarray(vectors, dtype=np.float64)
-        if X.ndim != 2 or not len(X) or self.TRAILING or (self._frequency_smoothing and not self.extra_params_fixed()):
+        extra_fixed = self.extra_params_fixed()
+        if X.ndim != 2 or not len(X) or self.TRAILING or (self._frequency_smoothing and not extra_fixed):
             return ModelWithFrequencies.kernel_points(self, vectors)
         n = len(X)
         at = 0
@@ -51,19 +52,28 @@ class F81Model(ModelWithFrequencies):
             sf, at = X[:, at], at + 1
         if self._optimise_tau:
             tau, at = X[:, at], at + 1
-        if self.extra_params_fixed() or not self._optimise_frequencies:
+        free_pi = not extra_fixed and self._optimise_frequencies
+        if not free_pi:
             pi = np.repeat(np.ascontiguousarray(self.frequencies, dtype=np.float64)[None, :], n, axis=0)
         else:
             ratios = np.hstack((X[:, at: at + len(self.frequencies) - 1], np.ones((n, 1))))
             pi = ratios / ratios.sum(axis=1)[:, None]
         fs = self._forest_stats
-        points = []
-        for i in range(n):
-            t = tau[i]
-            factor = fs.forest_length / (fs.forest_length + t * (fs.num_nodes - 1)) if t else 1
-            points.append((dict(kind=KIND_F81, pi=pi[i]), (float(sf[i]), float(t), float(factor))))
-        self.set_params_from_optimised(X[-1])
-        return points
+        tau = np.asarray(tau, dtype=np.float64)
+        factor = np.ones(n, dtype=np.float64)
+        smoothed = tau != 0
+        if smoothed.any():
+            factor[smoothed] = fs.forest_length / (fs.forest_length + tau[smoothed] * (fs.num_nodes - 1))
+        # the model is left at the last vector, as set_params_from_optimised(X[-1]) would leave it (the same values: the
+        # rows above are its arithmetic)
+        if self._optimise_sf:
+            self._sf = X[-1, 0]
+        if self._optimise_tau:
+            self._tau = tau[-1]
+            self.calc_tau_factor()
+        if free_pi:
+            self._frequencies = pi[-1].copy()
+        return PointBlock(KIND_F81, np.ascontiguousarray(pi), np.array(sf, dtype=np.float64), tau, factor)
 
 
 JC = 'JC'

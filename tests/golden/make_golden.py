@@ -992,6 +992,54 @@ def case_cfg4_full():
 
 CASES['cfg4_full'] = case_cfg4_full
 
+
+def case_hiv1c_year_trace(perturb=0.0):
+    """
+    The reference's optimiser path for the one HIV1C column whose optimum ours misses by more than 1e-6 relative ('Year',
+    k = 30): pastml.acr.acr() as in hiv1c_all, with the `minimize` that pastml/ml.py:231 calls wrapped (module attribute,
+    the reference's files untouched) so that every L-BFGS-B run leaves its start, its iterates (x_k, f(x_k)), its end and
+    scipy's message.  ~25 minutes of reference time.
+    """
+    import time
+    import scipy.optimize
+    col = 'Year'
+    tree = our_tree.read_tree(os.path.join(HIV1C_DST, 'pastml_phyml_tree.nwk'))
+    df = pd.read_csv(os.path.join(HIV1C_DST, 'metadata_all.tab.gz'), sep='\t', index_col=0, header=0)
+    df.index = df.index.map(str)
+    runs = []
+    real = scipy.optimize.minimize
+
+    def traced(fun, x0, **kw):
+        its = []
+        if perturb:   # (the sensitivity run: every start point moved by a relative `perturb`, the size of a rounding error)
+            x0 = np.array(x0, dtype=np.float64) * (1.0 + perturb)
+        res = real(fun, x0=x0, callback=lambda xk: its.append(np.array(xk, dtype=np.float64)), **kw)
+        runs.append(dict(x0=np.array(x0, dtype=np.float64), x=np.array(res.x), fun=float(res.fun), success=bool(res.success),
+                         nit=int(res.nit), nfev=int(res.nfev), message=str(res.message), iterates=np.array(its)))
+        return res
+
+    rml.minimize = traced
+    try:
+        np.random.seed(239)
+        t0 = time.time()
+        res = racr(tree, df[[col]].copy(), prediction_method='MPPA', model='F81', threads=1)[0]
+        dt = time.time() - t0
+    finally:
+        rml.minimize = real
+    out = dict(column=col, loglik=res['log_likelihood'], sf=float(res['model'].sf),
+               frequencies=np.array(res['model'].frequencies), reference_seconds=dt, n_runs=len(runs))
+    for i, r in enumerate(runs):
+        for key, v in r.items():
+            out['run{}_{}'.format(i, key)] = v
+    out['start_points_moved_by'] = perturb
+    save('hiv1c_year_trace' if not perturb else 'hiv1c_year_trace_perturbed', **out)
+
+
+CASES['hiv1c_year_trace'] = case_hiv1c_year_trace
+# the same run with every L-BFGS-B start point moved by 1e-12 relative: how far the REFERENCE's own optimum moves when its
+# input moves by a rounding error (the fixture keeps the run summaries and the final values)
+CASES['hiv1c_year_trace_perturbed'] = lambda: case_hiv1c_year_trace(1e-12)
+
 if __name__ == '__main__':
     np.random.seed(239)
     todo = sys.argv[1:] or list(CASES)

@@ -142,17 +142,12 @@ def test_random_case(seed):
 
 
 @pytest.mark.parametrize('seed', range(max(8, N_CASES // 5)))
-def test_random_case_with_two_level_units(seed, monkeypatch):
+def test_random_case_with_two_level_units(seed):
     """The level schedule with two-level units (forced on a small forest: no subtree blocks, no single-launch sweeps, any
     number of such nodes) against the oracle: ragged forests with balanced clumps, 17 <= k <= 64, masks of every kind,
     several columns; ln L, bottom-up vectors (the clumps' inner nodes come from the download's materialisation),
     posteriors, totals; a zero likelihood names the reference's pair."""
     from test_gpu_parity import _forest_with_balanced_clumps
-    monkeypatch.setenv('PASTML_HIP_BLOCK_NODES', '0')
-    monkeypatch.setenv('PASTML_HIP_SMALL_MANY_NODES', '0')
-    monkeypatch.setenv('PASTML_HIP_SMALL_MAX_NODES', '0')
-    monkeypatch.setenv('PASTML_HIP_SUPER_MIN', '1')
-    monkeypatch.setenv('PASTML_HIP_STACK_MIN', '1')
     rng = np.random.default_rng(70_000 + seed)
     k = int(rng.choice([17, 20, 24, 29, 31, 32, 33, 40, 48, 63, 64]))
     flat = _forest_with_balanced_clumps(int(rng.integers(20, 120)), seed=seed, clump_frac=float(rng.uniform(0.3, 0.9)))
@@ -173,7 +168,8 @@ def test_random_case_with_two_level_units(seed, monkeypatch):
             ref_errors.append(e)
         except ValueError:
             pytest.skip('the reference fails on this input (all-zero marginal likelihoods)')
-    with hip.Engine(flat, C, k) as eng:
+    with hip.Engine(flat, C, k, tune=dict(BLOCK_NODES=0, SMALL_MANY_NODES=0, SMALL_MAX_NODES=0, SUPER_MIN=1,
+                                          STACK_MIN=1)) as eng:
         eng.set_models(list(zip(specs, rates)))
         eng.set_masks(masks)
         eng.profile_enable(True)

@@ -114,6 +114,27 @@ def test_bench_two_ranks_started_directly(tmp_path):
     np.testing.assert_allclose(line['loglik_sum'], ref.sum(), rtol=1e-13)
 
 
+def test_bench_four_ranks_of_32_characters(tmp_path):
+    """
+    The shard of BASELINE config 4 -- 32 characters per rank -- end to end through `bench.py --gpus N` on a reduced tree
+    (16 384 tips): N = 4 ranks on GPU 0 over gloo, 128 characters, every rank validating its 32 columns, the reduced total
+    against one process that computes all 128.  (N = 8 x 32 = 256 is what the driver launches on a node; a GPU box admits
+    six processes on its card, so the 8-way partition itself is covered on the CPU, tests/test_sharding_gloo.py.)
+    """
+    env = dict(os.environ, BENCH_ALL_RANKS_ON_GPU0='1', PASTML_AMD_COMM='gloo')
+    for key in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'PASTML_AMD_RDZV_DIR'):
+        env.pop(key, None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '4', '--steps', '2', '--warmup', '1',
+                        '--workload', 'cfg4_small', '--chars-per-gpu', '32', '--no-secondary'], env=env,
+                       capture_output=True, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    line = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert line['n_gpus'] == 4 and line['config']['chars_total'] == 128 and line['scaling'] == 'weak'
+    assert line['validation']['columns'] == 32
+    ref = _single_process_logliks(128, 14, 64)
+    np.testing.assert_allclose(line['loglik_sum'], ref.sum(), rtol=1e-13)
+
+
 def test_acr_shards_characters_over_ranks(tmp_path):
     """acr() under a 2-process launch: each rank reconstructs its block of the characters (through the HIP path), the
     total log-likelihood is all-reduced; together the ranks reproduce the single-process run bit for bit."""

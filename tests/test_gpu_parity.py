@@ -31,13 +31,23 @@ def log_true(vec, sf):
         return np.log10(vec) - sf[:, None]
 
 
-def assert_same_scaled(ours, ours_sf, ref, ref_sf, rows=None, what=''):
+def assert_same_scaled(ours, ours_sf, ref, ref_sf, rows=None, what='', ulps=0):
+    """ulps: slack in units of the spacing of the compared numbers (log10 values of -1e6 have a spacing of 2.3e-10)."""
     a, b = log_true(ours, ours_sf), log_true(ref, ref_sf)
     if rows is not None:
         a, b = a[rows], b[rows]
     assert np.array_equal(np.isneginf(a), np.isneginf(b)), what + ': zero patterns differ'
     fin = np.isfinite(b)
-    np.testing.assert_allclose(a[fin], b[fin], rtol=0, atol=LOG10_ATOL, err_msg=what)
+    if ulps:
+        assert np.all(np.abs(a[fin] - b[fin]) <= LOG10_ATOL + ulps * np.spacing(np.abs(b[fin]))), what
+    else:
+        np.testing.assert_allclose(a[fin], b[fin], rtol=0, atol=LOG10_ATOL, err_msg=what)
+
+
+# the level schedule on forests that would otherwise take the single-launch kernels or the subtree blocks, with two-level
+# and stacked units from the first one on (per-engine switches: pml_ctx_set_tunable -- nothing is read from the
+# environment here, and nothing is latched in the process)
+LEVEL_SCHEDULE = dict(BLOCK_NODES=0, SMALL_MANY_NODES=0, SUPER_MIN=1, STACK_MIN=1)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -455,7 +465,7 @@ def test_cfg4_full_tree_invariants():
                                        np.log10(z['c{}_lh'.format(c)].sum(axis=1)) - z['c{}_lh_sf'.format(c)],
                                        rtol=LNL_RTOL)  # (values of -2.7e6: an ulp is 4.7e-10)
     s = z['c0_sample']
-    assert_same_scaled(bu[s], bu_sf[s], z['c0_bu'], z['c0_bu_sf'], what='BU at the sample, reference')
+    assert_same_scaled(bu[s], bu_sf[s], z['c0_bu'], z['c0_bu_sf'], what='BU at the sample, reference', ulps=4)
 
 
 def test_cfg4_bench_characters_match_reference_on_4096_tips():
@@ -508,7 +518,7 @@ def test_cherry_fusion_is_bit_identical(k):
 
 
 @pytest.mark.parametrize('k', [2, 5, 12, 64])
-def test_single_launch_path_matches_level_path(k, monkeypatch):
+def test_single_launch_path_matches_level_path(k):
     """Small forests run a whole sweep in one launch; the level-per-launch schedule must give the same bits."""
     rng = np.random.default_rng(100 + k)
     flat = FlatForest.random(400, seed=k + 7, max_arity=4, zero_frac=0.0, n_trees=2)
@@ -516,11 +526,12 @@ def test_single_launch_path_matches_level_path(k, monkeypatch):
     rates = [(1.1, 0.0, 1.0), (0.7, 0.03, 0.9), (2.0, 0.0, 1.0)]
     masks = np.stack([random_masks(flat, k, rng) for _ in range(3)])
     out = []
-    for limit in ('1000000', '0'):
-        monkeypatch.setenv('PASTML_HIP_SMALL_MAX_NODES', limit)
-        with hip.Engine(flat, 3, k) as eng:
+    for limit in (1000000, 0):
+        with hip.Engine(flat, 3, k, tune=dict(SMALL_MAX_NODES=limit, BLOCK_NODES=0)) as eng:
             eng.set_models(list(zip(specs, rates)))
             eng.set_masks(masks)
+            # the path under test is the one that runs: the whole sweep in one launch / level launches
+            assert (eng.sweep_schedule()[0] == hip.SCHEDULE_SINGLE_LAUNCH) == bool(limit)
             lnl = eng.bottom_up(True)
             post, lh_sum, lh_sf = eng.top_down_marginals()
             # a second sweep with new parameters re-runs the fused prep
@@ -816,7 +827,7 @@ def test_many_columns_take_the_single_launch_kernels_with_the_same_bits():
 
 
 @pytest.mark.parametrize('k', [2, 4, 12, 64])
-def test_block_schedule_gives_the_bits_of_the_level_schedule(k, monkeypatch):
+def test_block_schedule_gives_the_bits_of_the_level_schedule(k):
     """Mid-size forests: subtree blocks walked by one workgroup each + the top above the cuts (a handful of launches)
     against one launch per level; blocks of 256 (default), 1024, 64 and 7 stored nodes; balanced and ragged forests."""
     rng = np.random.default_rng(40 + k)
@@ -827,16 +838,20 @@ def test_block_schedule_gives_the_bits_of_the_level_schedule(k, monkeypatch):
         specs = [(random_spec('F81', k, rng), (float(rng.uniform(0.5, 3)), 0.0, 1.0)) for _ in range(C)]
         masks = np.stack([random_masks(flat, k, rng, internal=0.0) for _ in range(C)])
         results = []
-        for block_nodes in ('0', '256', '1024', '64', '7'):
-            monkeypatch.setenv('PASTML_HIP_BLOCK_NODES', block_nodes)
-            with hip.Engine(flat, C, k) as eng:
+        n_blocks = []
+        for block_nodes in (0, 256, 1024, 64, 7):
+            with hip.Engine(flat, C, k, tune=dict(BLOCK_NODES=block_nodes, BLOCK_MAX_WORK=1 << 40)) as eng:
                 eng.set_models(specs)
                 eng.set_masks(masks)
+                kind, nb, _ = eng.sweep_schedule()   # the schedule under test is the one that runs
+                assert (kind == hip.SCHEDULE_BLOCKS) == (block_nodes != 0), (block_nodes, kind)
+                n_blocks.append(nb)
                 lnl, post, lh_sum, lh_sf = eng.marginal_pass()
                 again = eng.bottom_up(True)            # graph replay of the same schedule
                 bu = eng.download(hip.BUF_BU, 1)
                 assert np.array_equal(lnl, again)
             results.append((lnl, post, lh_sum, lh_sf, bu))
+        assert n_blocks[0] == 0 and n_blocks[4] > n_blocks[3] > n_blocks[1] >= n_blocks[2] > 0, n_blocks
         for other in results[1:]:
             for a, b in zip(results[0], other):
                 assert np.array_equal(a, b)
@@ -1104,7 +1119,7 @@ def _forest_with_balanced_clumps(n_leaves, seed, clump_frac=0.5):
 
 
 @pytest.mark.parametrize('k', [17, 20, 29, 32, 40, 64])
-def test_two_level_units_give_the_bits_of_the_level_schedule(k, monkeypatch):
+def test_two_level_units_give_the_bits_of_the_level_schedule(k):
     """
     Level schedule of large forests, lane groups of 8 and more: nodes with two stored children that each carry two
     cherries of two tips run as two-level units (their children's bottom-up vectors are never written, their posterior
@@ -1114,10 +1129,6 @@ def test_two_level_units_give_the_bits_of_the_level_schedule(k, monkeypatch):
     of units, thin rest levels), with unobserved and ambiguous tips and restricted internal nodes (the bodies with masks)
     and with every state allowed (the straight-line bodies); k = 17, 20, 29, 40 have padding states.
     """
-    monkeypatch.setenv('PASTML_HIP_BLOCK_NODES', '0')       # level launches, not subtree blocks
-    monkeypatch.setenv('PASTML_HIP_SMALL_MANY_NODES', '0')
-    monkeypatch.setenv('PASTML_HIP_SUPER_MIN', '1')
-    monkeypatch.setenv('PASTML_HIP_STACK_MIN', '1')
     rng = np.random.default_rng(900 + k)
     forests = [synthetic.balanced_forest(12), _forest_with_balanced_clumps(700, seed=k)]
     for fi, flat in enumerate(forests):
@@ -1128,14 +1139,16 @@ def test_two_level_units_give_the_bits_of_the_level_schedule(k, monkeypatch):
         masks[0] = synthetic.one_hot_masks(flat, k, rng.integers(0, k, size=flat.n_tips))
         results = []
         for no_super in (True, False):
-            if no_super:
-                monkeypatch.setenv('PASTML_HIP_NO_SUPER', '1')
-            else:
-                monkeypatch.delenv('PASTML_HIP_NO_SUPER', raising=False)
-            with hip.Engine(flat, C, k) as eng:
+            with hip.Engine(flat, C, k, tune=dict(LEVEL_SCHEDULE, NO_SUPER=1 if no_super else None)) as eng:
                 eng.set_models(specs)
                 eng.set_masks(masks)
+                # the schedule under test is the one that runs: two-level / stacked units scheduled and launched, or none
+                on, n_two, n_stack = eng.schedule_info()
+                assert on == (not no_super) and (n_two > 0 and n_stack > 0) == (not no_super), (no_super, on, n_two, n_stack)
+                eng.profile_enable(True)
                 lnl, post, lh_sum, lh_sf = eng.marginal_pass()
+                assert (eng.profile_read(3)[1] > 0) == (not no_super) and (eng.profile_read(4)[1] > 0) == (not no_super)
+                eng.profile_enable(False)
                 again = eng.bottom_up(True)
                 assert np.array_equal(lnl, again)
                 bu = [eng.download(hip.BUF_BU, c) for c in range(C)]
@@ -1153,13 +1166,89 @@ def test_two_level_units_give_the_bits_of_the_level_schedule(k, monkeypatch):
         np.testing.assert_allclose(results[1][0][1], ref['loglik'], rtol=LNL_RTOL)
 
 
-def test_two_level_units_report_the_reference_pair_on_zero_likelihood(monkeypatch):
+@pytest.mark.parametrize('k', [17, 24, 32, 33, 64])
+def test_general_two_level_units_give_the_bits_of_the_level_schedule(k):
+    """
+    Ragged forests (random binary trees, trees with polytomies and one-child nodes, several roots): the stored nodes whose
+    children are tips and cherries are absorbed by their parents, whatever the shapes (pml_kernels_f81.h, general two-level
+    units: the absorbed node's vector is never written, its parent does not gather its scalars, its top-down unit reads
+    the parent's row).  Against the plain level schedule (NO_SUPER) bit for bit: ln L, posteriors, sums, scales, the
+    bottom-up vectors a download materialises, the top-down vectors of PML_OPT_KEEP_TD; and against the oracle.
+    """
+    rng = np.random.default_rng(1700 + k)
+    forests = [FlatForest.random(3000, seed=k, max_arity=2, n_trees=1), FlatForest.random(2500, seed=k + 1, max_arity=4, n_trees=3),
+               _forest_with_balanced_clumps(400, seed=k + 2)]
+    base = dict(LEVEL_SCHEDULE, SMALL_MAX_NODES=0, ABSORB_MIN=1)
+    for fi, flat in enumerate(forests):
+        C = 3
+        specs = [(random_spec('F81', k, rng), (float(rng.uniform(0.5, 3)), 0.0, 1.0)) for _ in range(C)]
+        masks = np.stack([random_masks(flat, k, rng, missing=0.05, multi=0.05, internal=0.02) for _ in range(C)])
+        masks[0] = synthetic.one_hot_masks(flat, k, rng.integers(0, k, size=flat.n_tips))
+        results = []
+        for variant in ('plain', 'absorb'):
+            tune = dict(base, NO_SUPER=1) if variant == 'plain' else base
+            with hip.Engine(flat, C, k, tune=tune, keep_td=True) as eng:
+                eng.set_models(specs)
+                eng.set_masks(masks)
+                kind, _, n_absorbed = eng.sweep_schedule()
+                if variant == 'plain':
+                    assert kind == hip.SCHEDULE_LEVELS and n_absorbed == 0
+                else:
+                    assert kind == hip.SCHEDULE_TWO_LEVEL and n_absorbed > 0, (fi, kind, n_absorbed)
+                lnl, post, lh_sum, lh_sf = eng.marginal_pass()
+                again = eng.bottom_up(True)
+                assert np.array_equal(lnl, again)
+                bu = [eng.download(hip.BUF_BU, c) for c in range(C)]
+                bu_sf = [eng.download(hip.BUF_BU_SF, c) for c in range(C)]
+                post2, lh_sum2, lh_sf2 = eng.top_down_marginals()    # after the download's materialisation
+                assert np.array_equal(post, post2) and np.array_equal(lh_sum, lh_sum2)
+                td = eng.download(hip.BUF_TD, 1)
+                td_sf = eng.download(hip.BUF_TD_SF, 1)
+            results.append((lnl, post, lh_sum, lh_sf, np.stack(bu), np.stack(bu_sf), td, td_sf))
+        assert np.isfinite(results[0][1]).all()
+        for a, b in zip(results[0], results[1]):
+            assert np.array_equal(a, b), 'forest {}'.format(fi)
+        ref = orc.full_marginal_pass(flat, masks[1].astype(int), specs[1][0], *specs[1][1])
+        np.testing.assert_allclose(results[1][0][1], ref['loglik'], rtol=LNL_RTOL)
+        np.testing.assert_allclose(results[1][1][1], ref['posterior'], rtol=POST_RTOL, atol=1e-300)
+
+
+def test_general_two_level_units_report_the_reference_pair_on_zero_likelihood():
+    """An absorbed node whose vector comes out all zero (its own mask is empty): the unit falls back to the sequential
+    path, which names the pair the reference would -- the same pair as the plain level schedule."""
+    k = 40
+    flat = FlatForest.random(2000, seed=11, max_arity=2, n_trees=1)
+    rng = np.random.default_rng(6)
+    spec = (random_spec('F81', k, rng), (1.0, 0.0, 1.0))
+    masks = synthetic.one_hot_masks(flat, k, rng.integers(0, k, size=flat.n_tips))
+    # a stored node without stored children: every child a tip or a cherry, not all of them tips
+    kid_tip = np.zeros(flat.n_nodes, dtype=bool)
+    cherry = np.zeros(flat.n_nodes, dtype=bool)
+    for n in range(flat.n_nodes):
+        ch = range(flat.first_child[n], flat.first_child[n] + flat.n_children[n])
+        cherry[n] = flat.n_children[n] > 0 and all(flat.n_children[c] == 0 for c in ch) and flat.parent[n] >= 0
+    node = next(n for n in range(flat.n_nodes) if flat.n_children[n] > 0 and not cherry[n] and flat.parent[n] >= 0 and
+                all(flat.n_children[c] == 0 or cherry[c] for c in range(flat.first_child[n], flat.first_child[n] + flat.n_children[n])))
+    bad = masks.copy()
+    bad[node] = 0
+    out = []
+    base = dict(LEVEL_SCHEDULE, SMALL_MAX_NODES=0, ABSORB_MIN=1)
+    for variant in ('plain', 'absorb'):
+        with hip.Engine(flat, 2, k, tune=dict(base, NO_SUPER=1) if variant == 'plain' else base) as eng:
+            eng.set_models([spec, spec])
+            eng.set_masks(np.stack([masks, bad]))
+            assert (eng.sweep_schedule()[2] > 0) == (variant == 'absorb')
+            with pytest.raises(hip.ZeroLikelihoodError) as e:
+                eng.bottom_up(True)
+            out.append((int(e.value.err_parent[0]), int(e.value.err_child[0]), int(e.value.err_parent[1]),
+                        int(e.value.err_child[1])))
+    assert out[0][:2] == (-1, -1) and out[0][2] == node
+    assert out[0] == out[1]
+
+
+def test_two_level_units_report_the_reference_pair_on_zero_likelihood():
     """A child of a two-level node whose vector comes out all zero: the unit falls back to the sequential path, which
     names the pair the reference would (the same pair as without two-level units)."""
-    monkeypatch.setenv('PASTML_HIP_BLOCK_NODES', '0')
-    monkeypatch.setenv('PASTML_HIP_SMALL_MANY_NODES', '0')
-    monkeypatch.setenv('PASTML_HIP_SUPER_MIN', '1')
-    monkeypatch.setenv('PASTML_HIP_STACK_MIN', '1')
     k = 64
     flat = synthetic.balanced_forest(12)
     rng = np.random.default_rng(5)
@@ -1172,13 +1261,10 @@ def test_two_level_units_report_the_reference_pair_on_zero_likelihood(monkeypatc
     bad[node] = 0
     out = []
     for no_super in (True, False):
-        if no_super:
-            monkeypatch.setenv('PASTML_HIP_NO_SUPER', '1')
-        else:
-            monkeypatch.delenv('PASTML_HIP_NO_SUPER', raising=False)
-        with hip.Engine(flat, 2, k) as eng:
+        with hip.Engine(flat, 2, k, tune=dict(LEVEL_SCHEDULE, NO_SUPER=1 if no_super else None)) as eng:
             eng.set_models([spec, spec])
             eng.set_masks(np.stack([masks, bad]))
+            assert eng.schedule_info()[0] == (not no_super)
             with pytest.raises(hip.ZeroLikelihoodError) as e:
                 eng.bottom_up(True)
             out.append((int(e.value.err_parent[0]), int(e.value.err_child[0]), int(e.value.err_parent[1]),
@@ -1222,7 +1308,7 @@ def test_eigen_joint_sweep_follows_the_masks_through_graph_replay():
 
 
 @pytest.mark.parametrize('k', [5, 20, 32])
-def test_eigen_tiers_give_the_bits_of_one_launch_per_level(k, monkeypatch):
+def test_eigen_tiers_give_the_bits_of_one_launch_per_level(k):
     """Eigen models: the thin levels of the joint sweep and of the marginal bottom-up sweep run in tiers of subtree blocks
     (one launch per tier); PASTML_HIP_NO_EIGJ_TIERS=1 gives every level its own launch.  Same passes over the same nodes:
     ln L, arg-max tables, joint states, posteriors bit for bit -- balanced tree, ragged forest, several columns, tips of
@@ -1233,32 +1319,31 @@ def test_eigen_tiers_give_the_bits_of_one_launch_per_level(k, monkeypatch):
         specs = [(random_spec('EIGEN', k, rng), (float(rng.uniform(0.5, 2)), 0.0, 1.0)) for _ in range(C)]
         masks = np.stack([random_masks(flat, k, rng, missing=0.1, multi=0.1, internal=0.02) for _ in range(C)])
         out = []
+        launches = []
         for off in (True, False):
-            if off:
-                monkeypatch.setenv('PASTML_HIP_NO_EIGJ_TIERS', '1')
-            else:
-                monkeypatch.delenv('PASTML_HIP_NO_EIGJ_TIERS', raising=False)
-            with hip.Engine(flat, C, k) as eng:
+            with hip.Engine(flat, C, k, tune=dict(NO_EIGJ_TIERS=1 if off else None)) as eng:
                 eng.set_models(specs)
                 eng.set_masks(masks)
+                eng.profile_enable(True)
+                eng.bottom_up(False)
+                launches.append(eng.profile_read(0)[1])
+                eng.profile_enable(False)
                 lnl_j = eng.bottom_up(False)
                 tables = [eng.download(hip.BUF_JOINT_TABLE, c) for c in range(C)]
                 states = eng.joint_backtrace()
                 lnl, post, lh_sum, lh_sf = eng.marginal_pass()
             out.append((lnl_j, np.stack(tables), states, lnl, post, lh_sum, lh_sf))
+        assert launches[1] < launches[0], launches   # the tiers ran: fewer launches than one per level
         for a, b in zip(out[0], out[1]):
             assert np.array_equal(a, b)
 
 
 @pytest.mark.parametrize('k', [29, 33, 64])
-def test_two_level_units_when_roots_are_two_level_nodes(k, monkeypatch):
+def test_two_level_units_when_roots_are_two_level_nodes(k):
     """Forests of tiny balanced trees: a root with two children of two cherries each IS a two-level node -- its row comes from
     the roots' launch, its own vector from the two-level launch, and the rest lists are empty or nearly so.  Against the
     oracle."""
     from pastml_amd.tree import TreeNode
-    for var, val in (('PASTML_HIP_BLOCK_NODES', '0'), ('PASTML_HIP_SMALL_MANY_NODES', '0'), ('PASTML_HIP_SMALL_MAX_NODES', '0'),
-                     ('PASTML_HIP_SUPER_MIN', '1'), ('PASTML_HIP_STACK_MIN', '1')):
-        monkeypatch.setenv(var, val)
     rng = np.random.default_rng(k)
 
     def forest_of(levels):
@@ -1279,7 +1364,7 @@ def test_two_level_units_when_roots_are_two_level_nodes(k, monkeypatch):
         C = 2
         specs = [(random_spec('F81', k, rng), (1.3, 0.0, 1.0)) for _ in range(C)]
         masks = np.stack([random_masks(flat, k, rng, missing=0.1, multi=0.1, internal=0.0) for _ in range(C)])
-        with hip.Engine(flat, C, k) as eng:
+        with hip.Engine(flat, C, k, tune=dict(LEVEL_SCHEDULE, SMALL_MAX_NODES=0)) as eng:
             eng.set_models(specs)
             eng.set_masks(masks)
             eng.profile_enable(True)

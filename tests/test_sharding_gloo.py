@@ -57,10 +57,12 @@ def _worker(rank, world, port, n_chars, out):
     sharding.shutdown()
 
 
-def test_two_rank_loglik_allreduce():
+@pytest.mark.parametrize('n_chars,world', [(4, 2), (256, 8)])
+def test_loglik_allreduce_over_ranks(n_chars, world):
+    """world 2: the smallest split; world 8 x 32 characters: BASELINE config 4's partition (256 characters over the 8 GPUs
+    of a node) over gloo on the CPU -- every rank its contiguous block, one all-reduce of the summed ln L."""
     from oracle import pastml_oracle as orc
     from pastml_amd import synthetic
-    n_chars, world = 4, 2
     ctx = mp.get_context('spawn')
     out = ctx.Queue()
     port = _free_port()
