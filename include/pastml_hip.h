@@ -266,6 +266,24 @@ int pml_loglik_total(pml_ctx* ctx, double* total_out);
 /* hipDeviceSynchronize on the given device (benchmarks bracket their timed region with it) */
 int pml_device_sync(int device);
 
+/* ---- host-side helper of the optimiser loop (no GPU involved) -------------------------------------------------------- */
+/*
+ * The points of ONE forward-difference gradient of an F81-family character, decoded for the device, in one call: what
+ * scipy's approx_derivative(method='2-point', abs_step=1e-8, bounds=...) evaluates around x -- x itself, then x + h_i e_i
+ * with h_i = 1e-8 (the default L-BFGS-B differencing of pastml/ml.py:231) -- pushed through the model's parameter layout
+ * (pastml/models/__init__.py:159-181, :328-330: x = [sf?] [tau?] [pi_0/pi_{k-1} .. pi_{k-2}/pi_{k-1}]?,
+ * pi = (ratios, 1) / their sum with numpy's pairwise summation; tau factor of models/__init__.py:39-42).  Between two
+ * sweeps of an optimiser round this arithmetic was a third of the host's time when done in numpy, a few small arrays at a
+ * time.  n = len(x) = opt_sf + opt_tau + (free_pi ? k - 1 : 0); outputs: rows 0 .. n of pi_out[(n + 1) * k], sf_out,
+ * tau_out, tf_out [n + 1] (row 0 = x itself) and steps_out[n] = (x_i + h_i) - x_i, the divisors of the differences.
+ * Returns PML_OK, or PML_ERR_UNSUPPORTED when some x_i + h_i leaves [lower_i, upper_i] or equals x_i (scipy then mirrors
+ * or rescales the step: the caller takes its general path) -- nothing is written in that case.
+ */
+int pml_host_f81_fd_points(int32_t n, int32_t k, const double* x, const double* lower, const double* upper, int32_t opt_sf,
+                           int32_t opt_tau, int32_t free_pi, double sf_fixed, double tau_fixed, const double* pi_fixed,
+                           double forest_length, double num_nodes, double* pi_out, double* sf_out, double* tau_out,
+                           double* tf_out, double* steps_out);
+
 /* ---- inspection ------------------------------------------------------------------------------------------------------ */
 int pml_download(pml_ctx* ctx, int what, int32_t col, void* out);
 /*

@@ -636,6 +636,10 @@ class _Found(object):
         self.x, self.fun, self.success, self.nit, self.nfev = x, fun, success, nit, nfev
 
 
+# PASTML_AMD_FD_IN_LIBRARY=0: the finite-difference points of the F81 family through numpy (two_point_scheme + kernel_points)
+# instead of the library's helper -- the same numbers; tests compare the two
+FD_IN_LIBRARY = os.environ.get('PASTML_AMD_FD_IN_LIBRARY', '1') != '0'
+
 # tests / diagnostics: a dict {character: [one record per L-BFGS-B run: start, iterates (x_k, f(x_k)), end, counts]} that
 # the searches fill in when it is not None (tests/test_gpu_hiv1c.py compares them with the reference's own runs)
 TRACE = None
@@ -722,6 +726,8 @@ def search_parameters_steps(model, observed_frequencies, rng, trace=None):
     """
     bounds = model.get_bounds()
     lower, upper = bounds[:, 0], bounds[:, 1]
+    lower_c, upper_c = np.ascontiguousarray(lower, dtype=np.float64), np.ascontiguousarray(upper, dtype=np.float64)
+    fd_block = getattr(model, 'fd_block', None) if _adjust_scheme_to_bounds is not None and FD_IN_LIBRARY else None
 
     def negative(values):
         values = np.asarray(values, dtype=np.float64)   # (ln L values or NaN: what pd.isnull would flag)
@@ -740,6 +746,14 @@ def search_parameters_steps(model, observed_frequencies, rng, trace=None):
         ps = np.asarray(ps, dtype=np.float64)
         if np.isnan(ps).any():
             return np.nan, np.full(len(ps), np.nan)
+        if fd_block is not None:
+            # F81 family: the points of the gradient, decoded, in one call into the library (host arithmetic; the numbers of
+            # two_point_scheme + kernel_points)
+            made = fd_block(ps, lower_c, upper_c)
+            if made is not None:
+                block, steps = made
+                values = negative((yield block))
+                return values[0], (values[1:] - values[0]) / steps
         if _adjust_scheme_to_bounds is not None:
             if ((ps < lower) | (ps > upper)).any():
                 raise ValueError("`x0` violates bound constraints.")
@@ -877,7 +891,7 @@ def fit_parameters_steps(character, model, observed_frequencies, rng, search=Non
         logger.debug('{} for {}:\n{}{}'.format(title, character, text, '\tlog likelihood:\t{:.6f}'.format(lnl)))
 
     def points_of(vectors):
-        return model.kernel_points(vectors)
+        return vectors if type(vectors) is PointBlock else model.kernel_points(vectors)
 
     def run_search():
         if search is not None:
@@ -1156,12 +1170,15 @@ def reconstruct(batch, tasks, lnl, force_joint=True):
             batch.initialize_allowed_states()
             altered = batch.alter(np.array([0 == mdl.tau for mdl in models], dtype=bool))
             _, posterior, lh_sum, lh_sf = batch.marginal_pass(models)
-            order = np.arange(flat.n_nodes) if len(flat.roots) == 1 else \
+            # (row order and row names: ONE index object for the tables of all characters of the group -- an index of 7 237
+            # names built per table was a sixth of the time outside the optimiser on the HIV1C columns)
+            order = None if len(flat.roots) == 1 else \
                 np.lexsort((np.arange(flat.n_nodes), flat.tree_id))   # tree by tree, level order each (ml.py:498-502)
-            names = [flat.nodes[i].name for i in order] if flat.nodes is not None else list(order)
+            ids = range(flat.n_nodes) if order is None else order
+            names = pd.Index([flat.nodes[i].name for i in ids] if flat.nodes is not None else list(ids))
             for c, t in enumerate(tasks):
-                current[c][ml.MARGINAL_PROBABILITIES] = pd.DataFrame(posterior[c][order], index=names,
-                                                                     columns=t.model.states)
+                current[c][ml.MARGINAL_PROBABILITIES] = pd.DataFrame(posterior[c] if order is None else posterior[c][order],
+                                                                     index=names, columns=t.model.states)
             batch.unalter(altered)
             lh = posterior * lh_sum[:, :, None]
 

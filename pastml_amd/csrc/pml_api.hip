@@ -3852,6 +3852,70 @@ int pml_loglik_total(pml_ctx* ctx, double* total_out) {
     return PML_OK;
 }
 
+// numpy's pairwise summation of a contiguous run (numpy/_core/src/umath/loops_utils.h.src, pairwise_sum: what
+// ndarray.sum() does along a contiguous axis): the frequencies must come out with numpy's bits, because the decoded
+// points are what the reference-side arithmetic (models/__init__.py:328-330) would hand to the sweeps
+static double np_pairwise_sum(const double* a, int n) {
+    if (n < 8) {
+        double res = 0.0;
+        for (int i = 0; i < n; ++i) res += a[i];
+        return res;
+    }
+    if (n <= 128) {
+        double r[8];
+        for (int j = 0; j < 8; ++j) r[j] = a[j];
+        int i = 8;
+        for (; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += a[i];
+        return res;
+    }
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_pairwise_sum(a, n2) + np_pairwise_sum(a + n2, n - n2);
+}
+
+int pml_host_f81_fd_points(int32_t n, int32_t k, const double* x, const double* lower, const double* upper, int32_t opt_sf,
+                           int32_t opt_tau, int32_t free_pi, double sf_fixed, double tau_fixed, const double* pi_fixed,
+                           double forest_length, double num_nodes, double* pi_out, double* sf_out, double* tau_out,
+                           double* tf_out, double* steps_out) {
+    if (n < 0 || k < 1 || !x || !lower || !upper || !pi_out || !sf_out || !tau_out || !tf_out || (n > 0 && !steps_out))
+        return fail(PML_ERR_INVALID, "NULL array / bad sizes");
+    if (n != (opt_sf ? 1 : 0) + (opt_tau ? 1 : 0) + (free_pi ? k - 1 : 0))
+        return fail(PML_ERR_INVALID, "n = %d does not match the parameter layout", n);
+    if (!free_pi && !pi_fixed) return fail(PML_ERR_INVALID, "pi_fixed is NULL");
+    const double h = 1e-8;
+    for (int i = 0; i < n; ++i) {
+        const volatile double moved = x[i] + h;   // (scipy: the step as the floating-point numbers see it)
+        const double step = moved - x[i];
+        if (step == 0.0 || moved < lower[i] || moved > upper[i] || !(x[i] >= lower[i] && x[i] <= upper[i]))
+            return PML_ERR_UNSUPPORTED;
+    }
+    std::vector<double> ratios((size_t)k);
+    for (int row = 0; row <= n; ++row) {
+        const int moved = row - 1;   // row 0 is x itself
+        auto at = [&](int i) { return i == moved ? x[i] + h : x[i]; };
+        int pos = 0;
+        const double sf = opt_sf ? at(pos++) : sf_fixed;
+        const double tau = opt_tau ? at(pos++) : tau_fixed;
+        sf_out[row] = sf;
+        tau_out[row] = tau;
+        tf_out[row] = tau != 0.0 ? forest_length / (forest_length + tau * (num_nodes - 1.0)) : 1.0;
+        double* pi = pi_out + (size_t)row * k;
+        if (free_pi) {
+            for (int j = 0; j < k - 1; ++j) ratios[j] = at(pos + j);
+            ratios[k - 1] = 1.0;
+            const double total = np_pairwise_sum(ratios.data(), k);
+            for (int j = 0; j < k; ++j) pi[j] = ratios[j] / total;
+        } else {
+            memcpy(pi, pi_fixed, sizeof(double) * k);
+        }
+        if (moved >= 0) steps_out[moved] = (x[moved] + h) - x[moved];
+    }
+    return PML_OK;
+}
+
 int pml_device_sync(int device) {
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipDeviceSynchronize());

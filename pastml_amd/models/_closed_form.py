@@ -76,6 +76,55 @@ class F81Model(ModelWithFrequencies):
         return PointBlock(KIND_F81, np.ascontiguousarray(pi), np.array(sf, dtype=np.float64), tau, factor)
 
 
+    def fd_block(self, ps, lower, upper):
+        """
+        The points of one forward-difference gradient around the optimiser vector ``ps`` (scipy's 2-point scheme with the
+        absolute step 1e-8), decoded: (PointBlock of len(ps) + 1 points -- ps itself first --, steps to divide by), or None
+        when the library's helper does not take the case (a step that leaves the bounds, smoothed frequencies, ...) and the
+        caller goes through two_point_scheme + kernel_points.  One call into libpastml_hip (pml_host_f81_fd_points, host
+        arithmetic only) instead of two dozen small numpy operations per optimiser round; the same numbers, bit for bit
+        (tests/test_host_logic.py).  The model is left at the last point, as kernel_points leaves it.
+        """
+        n = len(ps)
+        work = self.__dict__.get('_fd_work')
+        key = (n, self._extra_params_fixed, self._optimise_sf, self._optimise_tau, self._optimise_frequencies,
+               self._frequency_smoothing)
+        if work is None or work[0] != key:
+            # (per search stage: the layout, the buffers and the call's constant arguments)
+            extra_fixed = self.extra_params_fixed()
+            if self.TRAILING or (self._frequency_smoothing and not extra_fixed):
+                return None
+            from pastml_amd import hip
+            k = len(self._frequencies)
+            free_pi = not extra_fixed and self._optimise_frequencies
+            pi = np.empty((n + 1, k), dtype=np.float64)
+            rows = np.empty((3, n + 1), dtype=np.float64)
+            steps = np.empty(max(n, 1), dtype=np.float64)
+            fs = self._forest_stats
+            work = self.__dict__['_fd_work'] = (key, pi, rows, steps[:n], free_pi, hip.load_library().pml_host_f81_fd_points,
+                                                (1 if self._optimise_sf else 0, 1 if self._optimise_tau else 0,
+                                                 1 if free_pi else 0),
+                                                (float(fs.forest_length), float(fs.num_nodes), pi.ctypes.data,
+                                                 rows[0].ctypes.data, rows[1].ctypes.data, rows[2].ctypes.data, steps.ctypes.data),
+                                                PointBlock(KIND_F81, pi, rows[0], rows[1], rows[2]))
+        _, pi, rows, steps, free_pi, call, flags, tail, block = work
+        x = ps if ps.dtype == np.float64 and ps.flags.c_contiguous else np.ascontiguousarray(ps, dtype=np.float64)
+        fixed = self._frequencies
+        if fixed.dtype != np.float64 or not fixed.flags.c_contiguous:
+            fixed = np.ascontiguousarray(fixed, dtype=np.float64)
+        if call(n, pi.shape[1], x.ctypes.data, lower.ctypes.data, upper.ctypes.data, *flags, float(self._sf), float(self._tau),
+                fixed.ctypes.data, *tail) != 0:
+            return None
+        if flags[0]:
+            self._sf = rows[0, -1]
+        if flags[1]:
+            self._tau = rows[1, -1]
+            self.calc_tau_factor()
+        if free_pi:
+            self._frequencies = pi[-1].copy()
+        return block, steps
+
+
 JC = 'JC'
 
 

@@ -413,3 +413,53 @@ def test_bench_byte_model_knows_the_two_level_schedule():
     cur.add_child(name='ta', dist=0.1)
     cur.add_child(name='tb', dist=0.1)
     assert bench.schedule_bytes(FlatForest.from_trees([root]), 64, 128)['n_two_level'] == 0
+
+
+def test_library_fd_points_are_numpys():
+    """
+    pml_host_f81_fd_points (the points of one forward-difference gradient, decoded, in one call into the library) ==
+    two_point_scheme + F81Model.kernel_points bit for bit -- frequencies (numpy's pairwise summation, k beyond 128 included),
+    scaling and smoothing factors, tau factors, steps -- and the model is left where kernel_points leaves it; a step that
+    would leave the bounds is handed back to the numpy path.
+    """
+    from pastml_amd.batch import two_point_scheme
+    from pastml_amd.models._closed_form import F81Model, JCModel
+    fs = ForestStats([read_tree(os.path.join(GOLDEN, 'data', 'Albanian.tree.152tax.tre'))])
+    rng = np.random.default_rng(3)
+    checked = 0
+    for k in (2, 3, 5, 9, 12, 30, 67, 130, 200):
+        for optimise_tau in (False, True):
+            for fixed in (False, True):
+                states = ['s%03d' % i for i in range(k)]
+                freqs = np.random.default_rng(k).dirichlet(np.ones(k))
+                a, b = (F81Model(states=states, forest_stats=fs, optimise_tau=optimise_tau, frequencies=freqs.copy())
+                        for _ in range(2))
+                if fixed:
+                    a.fix_extra_params()
+                    b.fix_extra_params()
+                bounds = a.get_bounds()
+                lo, up = np.ascontiguousarray(bounds[:, 0]), np.ascontiguousarray(bounds[:, 1])
+                for trial in range(4):
+                    x = lo + (up - lo) * rng.uniform(0, 1, len(lo)) ** 3
+                    if optimise_tau and trial == 1:
+                        x[1] = 0.0
+                    made = a.fd_block(x, lo, up)
+                    assert made is not None
+                    block, steps = made
+                    points, steps_np = two_point_scheme(x, lo, up)
+                    ref = b.kernel_points(np.vstack((x[None, :], points)))
+                    assert np.array_equal(steps, steps_np)
+                    assert len(block) == len(ref) == len(x) + 1
+                    for name in ('pi', 'sf', 'tau', 'tf'):
+                        assert np.array_equal(getattr(block, name), getattr(ref, name)), (k, optimise_tau, fixed, name)
+                    assert np.array_equal(a.frequencies, b.frequencies)
+                    assert (a.sf, a.tau, a._tau_factor) == (b.sf, b.tau, b._tau_factor)
+                    checked += 1
+                # at the upper bound the step must be mirrored: scipy's helper, not the library
+                x = up.copy()
+                assert a.fd_block(x, lo, up) is None
+    assert checked == 9 * 2 * 2 * 4
+    jc = JCModel(states=['a', 'b', 'c'], forest_stats=fs)
+    b0 = jc.get_bounds()
+    block, steps = jc.fd_block(np.array([1.5]), np.ascontiguousarray(b0[:, 0]), np.ascontiguousarray(b0[:, 1]))
+    assert len(block) == 2 and np.array_equal(block.pi, np.full((2, 3), 1 / 3)) and block.sf[0] == 1.5
