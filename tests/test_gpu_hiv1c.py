@@ -33,13 +33,15 @@ def inputs():
 
 
 # The one column whose optimum ours misses by more than 1e-6 relative (round 4: signed differences, all 91 columns): 'Year',
-# k = 30, -4.2e-6 (0.033 in ln L).  Both searches end on the relative-reduction test of L-BFGS-B (ftol 2.2e-9) in a flat valley
-# -- forward differences of step 1e-8 on a function of 8 000 carry an error of the size of the slope there -- after 139 (ours)
-# and 153 (reference) iterations of the 30-parameter stage; the paths part at the first iterate, because the stage starts at
-# the optimum of the one-parameter stage, which the two arithmetics find 1e-11 apart (test_year_optimiser_path below, fixture
-# hiv1c_year_trace.npz).  The REFERENCE moves just as far when its own start points move by a rounding error
-# (hiv1c_year_trace_perturbed.npz).  Not an arithmetic difference: at the reference's parameters ln L agrees to 1e-10
-# (test_all_columns_at_the_reference_optima).
+# k = 30, -4.2e-6 (0.033 in ln L).  Both searches end on the relative-reduction test of L-BFGS-B (ftol 2.2e-9) in a flat valley,
+# after 139 (ours) and 153 (reference) iterations of the 30-parameter stage; the paths part at the first iterate, because the
+# stage starts at the optimum of the one-parameter stage, which the two arithmetics find 1e-11 apart (fixture
+# hiv1c_year_trace.npz: the reference's own iterates; scripts/r04_year_trace.py).  Where such a search ends is a heavy-tailed
+# random variable: of 16 runs of ours whose start points are moved by j * 1e-12, 13 end within 1.4e-6 of the reference's optimum
+# (median 1.5e-7) and three stop early on a plateau -- the unperturbed run is one of those (profiles/r04e_year_optimiser_path.txt;
+# the reference's own two runs, hiv1c_year_trace_perturbed.npz, are 3e-9 apart: two typical ones).  Not an arithmetic difference:
+# at the reference's parameters ln L agrees to 1e-10 (test_all_columns_at_the_reference_optima), and along a line through the
+# optimum our ln L is as smooth as the numpy restatement's or smoother (scripts/r04_noise.py).
 KNOWN_SHORTFALL = {'Year': 1e-5}
 
 
