@@ -1049,7 +1049,7 @@ __device__ __forceinline__ bool bu_f81_unit_lean(const LaneCtx<G, R>& L, const P
         const int ch = fc + (j < nc ? j : 0);
         const int code = j < nc ? unit_code(u.packed, j) : 0;
         ce[j] = L.E[ch];
-        cm[j] = L.mask[(unsigned)ch];
+        cm[j] = code != 1 ? L.mask[(unsigned)ch] : 0ull;
         cs[j] = code <= 1 ? L.S[ch] : 0.0;
         cbe[j] = code == 1 ? L.be[ch] : 0;
         if (code == 1) {
@@ -1061,11 +1061,16 @@ __device__ __forceinline__ bool bu_f81_unit_lean(const LaneCtx<G, R>& L, const P
         const int cfc = j == 0 ? u.cfc : u.cfc1;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const bool has = code >= 2 && q < code - 1;
-            const int tip = has ? cfc + q : ch;
-            te[j][q] = L.E[tip];
-            ts[j][q] = has ? L.S[tip] : 0.0;
-            tm[j][q] = L.mask[(unsigned)tip];
+            // (only what the codes ask for: in the thin levels a wave holds a unit or two and the loads it issues,
+            // address arithmetic included, are a third of the level step)
+            te[j][q] = 0.0;
+            ts[j][q] = 0.0;
+            tm[j][q] = 0ull;
+            if (code >= 2 && q < code - 1) {
+                te[j][q] = L.E[cfc + q];
+                ts[j][q] = L.S[cfc + q];
+                tm[j][q] = L.mask[(unsigned)(cfc + q)];
+            }
         }
     }
     // ---- arithmetic (bu_f81_unit_seq's operations)

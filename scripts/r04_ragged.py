@@ -10,7 +10,10 @@ cases = dict(ragged64=('ragged262k k64 C32', lambda: FlatForest.random(262144, s
              ragged4=('ragged262k k4 C32', lambda: FlatForest.random(262144, seed=3, max_arity=2, n_trees=1), 4, 32),
              ragged20=('ragged262k k20 C16', lambda: FlatForest.random(262144, seed=3, max_arity=2, n_trees=1), 20, 16),
              poly64=('polytomies100k k64 C16', lambda: FlatForest.random(100000, seed=5, max_arity=5, n_trees=2), 64, 16),
-             balanced64=('balanced2^18 k64 C32', lambda: synthetic.balanced_forest(18), 64, 32))
+             balanced64=('balanced2^18 k64 C32', lambda: synthetic.balanced_forest(18), 64, 32),
+             balanced4=('balanced2^18 k4 C32', lambda: synthetic.balanced_forest(18), 4, 32),
+             balanced12=('balanced2^18 k12 C32', lambda: synthetic.balanced_forest(18), 12, 32),
+             ragged12=('ragged262k k12 C32', lambda: FlatForest.random(262144, seed=3, max_arity=2, n_trees=1), 12, 32))
 for key in which:
     name, make, k, C = cases[key]
     f = make()
