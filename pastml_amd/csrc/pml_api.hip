@@ -742,7 +742,10 @@ static int dispatch_small_f81(pml_ctx* ctx, bool bottom_up, int do_prep, int fir
     if (n_levels < 0) n_levels = bottom_up ? (int)ctx->bu_offsets_f.size() - 1 - first_level : ctx->n_td_levels;
     const int reset_err = (units == nullptr && first_level == 0) ? 1 : 0;
     if (units == nullptr) {
-        units = bottom_up ? ctx->d_bu_units_f : ctx->d_td_units_f;
+        // (the lists sorted by shape inside every level where the forest has them: a wave of one shape runs that shape's
+        // code -- walk_levels; a forest this small sits in the L2, where its rows lie does not matter)
+        const bool sorted = ctx->d_bu_units_fs != nullptr && g < 8 && !ctx->tune.on(T_NO_SHAPE_SORT);
+        units = bottom_up ? (sorted ? ctx->d_bu_units_fs : ctx->d_bu_units_f) : (sorted ? ctx->d_td_units_fs : ctx->d_td_units_f);
         d_offsets = bottom_up ? ctx->d_bu_offsets_f + first_level : ctx->d_td_parent_offsets_f;
     }
 #define X(G_, R_)                                                                                   \
@@ -2260,6 +2263,14 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
                     describe(td_list.data(), (int)td_list.size(), true, u2);
                     describe(top_bu.data(), (int)top_bu.size(), true, u3);
                     describe(top_td.data(), (int)top_td.size(), true, u4);
+                    if (!ctx->tune.on(T_NO_SHAPE_SORT)) {
+                        // inside every level by shape (a wave of one shape runs that shape's code only: walk_levels); the
+                        // blocks' level tables lie one behind the other, so the whole array delimits the segments
+                        u1 = by_shape(u1, bu_lv, bu_list.size());
+                        u2 = by_shape(u2, td_lv, td_list.size());
+                        u3 = by_shape(u3, B.top_bu_offsets, top_bu.size());
+                        u4 = by_shape(u4, B.top_td_offsets, top_td.size());
+                    }
                     B.top_bu_vec.assign(n_top_levels > 0 ? n_top_levels : 1, 0);
                     for (int l = 0; l < n_top_levels; ++l)
                         for (int q = B.top_bu_offsets[l]; q < B.top_bu_offsets[l + 1] && !B.top_bu_vec[l]; ++q) {

@@ -1031,11 +1031,19 @@ __device__ __forceinline__ bool unit_is_lean(int packed) {
     return unit_code(packed, 0) <= 3 && unit_code(packed, 1) <= 3;
 }
 
-template <int G, int R>
+// SC0, SC1: the codes of the two children when the caller knows them at compile time (SC1 = -1: one child; walk_levels
+// dispatches the common shapes: the unit's decoding, the loads and the branches of the other shapes fall away -- where a
+// level is a unit or two, the wave's instruction count is the level's time); PML_SHAPE_ANY: read from the descriptor.
+#define PML_SHAPE_ANY (-9)
+#ifndef PML_SPREAD_LEVELS
+#define PML_SPREAD_LEVELS 0
+#endif
+template <int G, int R, int SC0 = PML_SHAPE_ANY, int SC1 = PML_SHAPE_ANY>
 __device__ __forceinline__ bool bu_f81_unit_lean(const LaneCtx<G, R>& L, const PmlTree& t, const PmlCols& c,
                                                  const PmlState& st, const UnitRegs& u) {
+    constexpr bool ANY = SC0 == PML_SHAPE_ANY;
     const int n = u.n, fc = u.fc;
-    const int nc = unit_nc(u.packed);
+    const int nc = ANY ? unit_nc(u.packed) : (SC1 < 0 ? 1 : 2);
     const u64 kbits = state_bits(c.k);
     // ---- loads
     const u64 own = L.mask[(unsigned)n];
@@ -1047,7 +1055,7 @@ __device__ __forceinline__ bool bu_f81_unit_lean(const LaneCtx<G, R>& L, const P
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int ch = fc + (j < nc ? j : 0);
-        const int code = j < nc ? unit_code(u.packed, j) : 0;
+        const int code = j < nc ? (ANY ? unit_code(u.packed, j) : (j == 0 ? SC0 : SC1)) : 0;
         ce[j] = L.E[ch];
         cm[j] = code != 1 ? L.mask[(unsigned)ch] : 0ull;
         cs[j] = code <= 1 ? L.S[ch] : 0.0;
@@ -1082,7 +1090,7 @@ __device__ __forceinline__ bool bu_f81_unit_lean(const LaneCtx<G, R>& L, const P
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         if (j < nc) {
-            const int code = unit_code(u.packed, j);
+            const int code = ANY ? unit_code(u.packed, j) : (j == 0 ? SC0 : SC1);
             const double e = ce[j];
             double msg[R];
             double a;
@@ -1163,11 +1171,31 @@ template <int G, int R, bool JOINT>
 __device__ __forceinline__ void bu_f81_unit_seq(const LaneCtx<G, R>& L, const PmlTree& t, const PmlCols& c,
                                                 const PmlState& st, const UnitRegs& u);
 
-template <int G, int R, bool JOINT, bool LEAN = false>
+#define PML_SHAPE_KEY(nc, c0, c1) ((nc) | ((c0) << 8) | ((c1) << 11))
+template <int G, int R, bool JOINT, bool LEAN = false, bool SHAPES = false>
 __device__ __forceinline__ void bu_f81_unit(const LaneCtx<G, R>& L, const PmlTree& t, const PmlCols& c,
                                             const PmlState& st, const UnitRegs& u) {
     if (LEAN && !JOINT && G < 8 && c.W == 1 && unit_is_lean(u.packed)) {
-        if (bu_f81_unit_lean<G, R>(L, t, c, st, u)) return;
+        bool ok;
+        const int key = u.packed & (15 | (63 << 8));
+        const int key0 = __builtin_amdgcn_readfirstlane(key);
+        // (only where every unit of the wave has the shape: a wave of mixed shapes would run one variant after the other)
+        if (SHAPES && __ballot(key != key0) == 0ull) {
+            switch (key0) {
+                case PML_SHAPE_KEY(2, 1, 1): ok = bu_f81_unit_lean<G, R, 1, 1>(L, t, c, st, u); break;
+                case PML_SHAPE_KEY(2, 3, 3): ok = bu_f81_unit_lean<G, R, 3, 3>(L, t, c, st, u); break;
+                case PML_SHAPE_KEY(2, 1, 0): ok = bu_f81_unit_lean<G, R, 1, 0>(L, t, c, st, u); break;
+                case PML_SHAPE_KEY(2, 0, 1): ok = bu_f81_unit_lean<G, R, 0, 1>(L, t, c, st, u); break;
+                case PML_SHAPE_KEY(2, 1, 3): ok = bu_f81_unit_lean<G, R, 1, 3>(L, t, c, st, u); break;
+                case PML_SHAPE_KEY(2, 3, 1): ok = bu_f81_unit_lean<G, R, 3, 1>(L, t, c, st, u); break;
+                case PML_SHAPE_KEY(2, 0, 3): ok = bu_f81_unit_lean<G, R, 0, 3>(L, t, c, st, u); break;
+                case PML_SHAPE_KEY(2, 3, 0): ok = bu_f81_unit_lean<G, R, 3, 0>(L, t, c, st, u); break;
+                default: ok = bu_f81_unit_lean<G, R>(L, t, c, st, u); break;
+            }
+        } else {
+            ok = bu_f81_unit_lean<G, R>(L, t, c, st, u);
+        }
+        if (ok) return;
     }
     if (bu_f81_unit_is_fast<G, R, JOINT>(c, u)) {
         BuLoads<R> ld;
@@ -1735,11 +1763,12 @@ __device__ __forceinline__ void td_f81_fast_children(const LaneCtx<G, R>& L, con
 // Lean top-down unit for the kernels that walk several levels in one launch (see bu_f81_unit_lean): every load the unit
 // can need -- the parent's posterior row and scalars, both children's scalars and vectors, the scalars of up to two tips
 // under each -- is issued before any value is used; then the operations of td_f81_unit's sequential path in its order.
-template <int G, int R>
+template <int G, int R, int SC0 = PML_SHAPE_ANY, int SC1 = PML_SHAPE_ANY>
 __device__ __forceinline__ void td_f81_unit_lean(const LaneCtx<G, R>& L, const PmlTree& t, const PmlCols& c,
                                                  const PmlState& st, const UnitRegs& u) {
+    constexpr bool ANY = SC0 == PML_SHAPE_ANY;  // (compile-time shapes: see bu_f81_unit_lean)
     const int p = u.n, fc = u.fc;
-    const int nc = unit_nc(u.packed);
+    const int nc = ANY ? unit_nc(u.packed) : (SC1 < 0 ? 1 : 2);
     const u64 kbits = state_bits(c.k);
     // ---- loads
     double po[R];
@@ -1754,7 +1783,7 @@ __device__ __forceinline__ void td_f81_unit_lean(const LaneCtx<G, R>& L, const P
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int ch = fc + (j < nc ? j : 0);
-        const int code = j < nc ? unit_code(u.packed, j) : 0;
+        const int code = j < nc ? (ANY ? unit_code(u.packed, j) : (j == 0 ? SC0 : SC1)) : 0;
         ce[j] = L.E[ch];
         cm[j] = L.mask[(unsigned)ch];
         cs[j] = L.S[ch];
@@ -1785,7 +1814,7 @@ __device__ __forceinline__ void td_f81_unit_lean(const LaneCtx<G, R>& L, const P
     for (int j = 0; j < 2; ++j) {
         if (j < nc) {
             const int ch = fc + j;
-            const int code = unit_code(u.packed, j);
+            const int code = ANY ? unit_code(u.packed, j) : (j == 0 ? SC0 : SC1);
             const double e = ce[j];
             if (code == 0) {
                 f81_finish_tip_word<G, R>(L, c, prod, pe, P, have_P, ch, cm[j] & kbits, e, cs[j], j);
@@ -1843,11 +1872,27 @@ __device__ __forceinline__ void td_f81_unit_lean(const LaneCtx<G, R>& L, const P
 // replaces calc_node_td_likelihood (ml.py:273-290), calc_node_marginal_likelihood (:454-460) and the normalisation
 // of convert_likelihoods_to_probabilities (:498-500) for the F81 family.
 // One top-down unit: stored internal node p of the current depth level.
-template <int G, int R, bool LEAN = false>
+template <int G, int R, bool LEAN = false, bool SHAPES = false>
 __device__ __forceinline__ void td_f81_unit(const LaneCtx<G, R>& L, const PmlTree& t, const PmlCols& c,
                                             const PmlState& st, const UnitRegs& u) {
     if (LEAN && G < 8 && c.W == 1 && unit_is_lean(u.packed)) {
-        td_f81_unit_lean<G, R>(L, t, c, st, u);
+        const int key = u.packed & (15 | (63 << 8));
+        const int key0 = __builtin_amdgcn_readfirstlane(key);
+        if (SHAPES && __ballot(key != key0) == 0ull) {  // (a wave of one shape: bu_f81_unit)
+            switch (key0) {
+                case PML_SHAPE_KEY(2, 1, 1): td_f81_unit_lean<G, R, 1, 1>(L, t, c, st, u); break;
+                case PML_SHAPE_KEY(2, 3, 3): td_f81_unit_lean<G, R, 3, 3>(L, t, c, st, u); break;
+                case PML_SHAPE_KEY(2, 1, 0): td_f81_unit_lean<G, R, 1, 0>(L, t, c, st, u); break;
+                case PML_SHAPE_KEY(2, 0, 1): td_f81_unit_lean<G, R, 0, 1>(L, t, c, st, u); break;
+                case PML_SHAPE_KEY(2, 1, 3): td_f81_unit_lean<G, R, 1, 3>(L, t, c, st, u); break;
+                case PML_SHAPE_KEY(2, 3, 1): td_f81_unit_lean<G, R, 3, 1>(L, t, c, st, u); break;
+                case PML_SHAPE_KEY(2, 0, 3): td_f81_unit_lean<G, R, 0, 3>(L, t, c, st, u); break;
+                case PML_SHAPE_KEY(2, 3, 0): td_f81_unit_lean<G, R, 3, 0>(L, t, c, st, u); break;
+                default: td_f81_unit_lean<G, R>(L, t, c, st, u); break;
+            }
+        } else {
+            td_f81_unit_lean<G, R>(L, t, c, st, u);
+        }
         return;
     }
     if (Gather<G>::enabled && c.W == 1 && unit_is_fast<G>(u.packed)) {
@@ -2584,28 +2629,36 @@ __device__ __forceinline__ void walk_levels(const LaneCtx<G, R>& L, const PmlTre
     const int wave = threadIdx.x >> 6;
     const int n_waves = blockDim.x >> 6;
     const int sub = (threadIdx.x & 63) / G;
-    const int first = wave * UW + sub;  // the unit of a level this lane's group takes first
     if (nl <= 0) return;
+    // The unit of a level this lane's group takes first.  A level of no more units than the workgroup has waves is spread
+    // over the waves, one unit each, instead of filling the first wave: a wave whose units all have one shape runs
+    // that shape's code only (bu_f81_unit, SHAPES).
+    auto first_of = [&](int n_level) { return PML_SPREAD_LEVELS && n_level <= n_waves ? (sub == 0 ? wave : n_level) : wave * UW + sub; };
     int a = lv[0], b = lv[1];
+    int first = first_of(b - a);
     UnitRegs nxt = load_unit<G>(units, first < b - a ? a + first : a, L.g);
     for (int l = 0; l < nl; ++l) {
         const int n_level = b - a;
         const UnitRegs cur = nxt;
+        const int cur_first = first;
         int a2 = a, b2 = a;
         if (l + 1 < nl) {
             a2 = lv[l + 1];
             b2 = lv[l + 2];
+            first = first_of(b2 - a2);
             nxt = load_unit<G>(units, first < b2 - a2 ? a2 + first : a2, L.g);
         }
-        if (first < n_level) {
-            if (BU) bu_f81_unit<G, R, false, true>(L, t, c, st, cur);
-            else td_f81_unit<G, R, true>(L, t, c, st, cur);
+        if (cur_first < n_level) {
+            if (BU) bu_f81_unit<G, R, false, true, true>(L, t, c, st, cur);
+            else td_f81_unit<G, R, true, true>(L, t, c, st, cur);
         }
-        for (int base = wave * UW + n_waves * UW; base < n_level; base += n_waves * UW) {
-            const int idx = base + sub;
-            if (idx < n_level) {
-                if (BU) bu_f81_unit<G, R, false, true>(L, t, c, st, load_unit<G>(units, a + idx, L.g));
-                else td_f81_unit<G, R, true>(L, t, c, st, load_unit<G>(units, a + idx, L.g));
+        if (!PML_SPREAD_LEVELS || n_level > n_waves) {
+            for (int base = wave * UW + n_waves * UW; base < n_level; base += n_waves * UW) {
+                const int idx = base + sub;
+                if (idx < n_level) {
+                    if (BU) bu_f81_unit<G, R, false, true, true>(L, t, c, st, load_unit<G>(units, a + idx, L.g));
+                    else td_f81_unit<G, R, true, true>(L, t, c, st, load_unit<G>(units, a + idx, L.g));
+                }
             }
         }
         __syncthreads();
