@@ -13,6 +13,7 @@
 #include <limits>
 #include <mutex>
 #include <string>
+#include <chrono>
 #include <vector>
 
 #include "pml_kernels_eigen_gemm.h"
@@ -62,7 +63,7 @@ static int fail(int code, const char* fmt, ...) {
     X(NO_EIGJ_TIERS, 1, 1) X(NO_BT_TIERS, 1, 1) X(NO_SHAPE_SORT, 1, 1) X(NO_SUPER, 1, 1) X(SUPER_MIN, 0, 1)            \
     X(STACK_MIN, 0, 1) X(NO_STACK, 1, 1) X(DEBUG, 1, 0) X(BLOCK_NODES, 0, 1) X(BLOCK_MAX_STORED, 0, 1)                 \
     X(BLOCK_HEIGHT_CAP, 0, 1) X(SMALL_MAX_NODES, 0, 1) X(F81_R, 0, 1) X(F81_TD_R, 0, 1) X(NO_GRAPH, 1, 1)              \
-    X(NARROW_UNITS, 0, 0) X(NO_EIGG_TIERS, 1, 0) X(NO_ABSORB, 1, 1) X(ABSORB_MIN, 0, 1)
+    X(NARROW_UNITS, 0, 0) X(NO_EIGG_TIERS, 1, 0) X(NO_ABSORB, 1, 1) X(ABSORB_MIN, 0, 1) X(NO_SPIN_WAIT, 1, 0)
 enum PmlTunable {
 #define X(name, flag, tree) T_##name,
     PML_TUNABLES(X)
@@ -261,6 +262,14 @@ struct pml_ctx {
     bool capturing = false;     // a sweep's launch sequence is being captured into a graph
     size_t n_params = 0;
     u64* h_err = nullptr;
+    // completion of a bottom-up sweep whose last launch is the single-workgroup-per-column kernel: that kernel raises a
+    // word in pinned memory when its last column is done (bu_f81_small_kernel), and the collect spins on it
+    u64* h_done = nullptr;      // pinned: generation of the last finished launch
+    u64* d_done = nullptr;      // device: [0] columns done in the running launch, [1] generation
+    u64 done_expect = 0;        // what *h_done shows when the sweep submitted last has finished
+    bool enqueue_signals = false;          // set by the launcher while a sweep is enqueued
+    bool bu_signals[2] = {false, false};   // per captured sweep (joint / marginal): its last launch signals
+    bool wait_signal = false;              // the sweep submitted last signals
     bool td_valid = false, js_valid = false;
     bool keep_td = false;      // PML_OPT_KEEP_TD (or a pml_download of the TD vectors asked for them)
     bool td_vec_valid = false; // the TD vectors of the last top-down sweep are in d_td
@@ -304,6 +313,8 @@ static void free_all(pml_ctx* ctx) {
     drop_graph(ctx->bt_graph);
     if (ctx->h_loglik) (void)hipHostFree(ctx->h_loglik);
     if (ctx->h_err) (void)hipHostFree(ctx->h_err);
+    if (ctx->h_done) (void)hipHostFree(ctx->h_done);
+    ctx->h_done = nullptr;
     if (ctx->h_params) (void)hipHostFree(ctx->h_params);
     ctx->h_params = nullptr;
     ctx->h_loglik = nullptr;
@@ -657,11 +668,16 @@ static void launch_small_f81(pml_ctx* ctx, bool bottom_up, int do_prep, const Pm
     const PmlCols c = cols_of(ctx);
     const PmlState st = state_of(ctx);
     dim3 grid(1, ctx->C), block(PML_SMALL_BLOCK);
-    if (bottom_up)
+    if (bottom_up) {
+        // The completion word (bu_f81_small_kernel, wait_bottom_up) for sweeps of few columns, where the host's wait is
+        // a tenth of the sweep (HIV1C tree, k = 12: 14 columns 0.1265 -> 0.1127 ms per sweep; at 128 columns the
+        // system-scope fences in 128 workgroups cost what the spin saves: 0.203 against 0.207 ms)
+        const bool signal = ctx->C <= 64 && !ctx->tune.on(T_NO_SPIN_WAIT);
         hipLaunchKernelGGL((bu_f81_small_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, ctx->d_mu, ctx->d_sf,
                            ctx->d_tau, ctx->d_tauf, do_prep, units, d_offsets, n_levels, ctx->h_loglik, ctx->h_err,
-                           reset_err);
-    else
+                           reset_err, signal ? ctx->d_done : nullptr, signal ? ctx->h_done : nullptr);
+        ctx->enqueue_signals = signal;  // (the last launch of a bottom-up sweep whenever it is part of one)
+    } else
         hipLaunchKernelGGL((td_f81_small_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, units, d_offsets,
                            n_levels);
 }
@@ -2392,6 +2408,12 @@ int pml_chars_alloc(pml_ctx* ctx, int32_t n_cols, int32_t k) {
     PML_TRY(dev_alloc(ctx, &ctx->d_err, n_cols));
     HIP_TRY(hipHostMalloc((void**)&ctx->h_loglik, sizeof(double) * n_cols));
     HIP_TRY(hipHostMalloc((void**)&ctx->h_err, sizeof(u64) * n_cols));
+    HIP_TRY(hipHostMalloc((void**)&ctx->h_done, 64));
+    *ctx->h_done = 0;
+    PML_TRY(dev_alloc(ctx, &ctx->d_done, 2));
+    HIP_TRY(hipMemsetAsync(ctx->d_done, 0, 2 * sizeof(u64), ctx->stream));
+    ctx->done_expect = 0;
+    ctx->wait_signal = false;
     ctx->graphs = !ctx->tune.on(T_NO_GRAPH);
     PML_TRY(dev_alloc(ctx, &ctx->d_bu, CN * ctx->ks));
     PML_TRY(dev_alloc(ctx, &ctx->d_S, CN));
@@ -2812,6 +2834,7 @@ static int narrow_levels(const pml_ctx* ctx, const std::vector<int>& off, int n_
 // ---------------------------------------------------------------------------------------------------------------------
 // Everything a bottom-up sweep puts on the stream, without host synchronisation (so that it can be captured).
 static int enqueue_bottom_up(pml_ctx* ctx, int is_marginal, bool small_path, bool force_prep) {
+    ctx->enqueue_signals = false;
     const bool eig = eigen_fused(ctx);
     const bool gemm = is_marginal && eigen_gemm(ctx);
     const bool eigj = !is_marginal && eigen_joint_valu(ctx);
@@ -3053,6 +3076,10 @@ static int run_captured(pml_ctx* ctx, pml_ctx::GraphSlot& slot, const std::funct
 
 // puts a bottom-up sweep on the stream (no host synchronisation)
 static int submit_bottom_up(pml_ctx* ctx, int is_marginal) {
+    if (ctx->wait_signal) {  // a sweep was submitted and never collected: the generation below must be read on an idle stream
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        ctx->wait_signal = false;
+    }
     const bool small_path = single_launch_sweeps(ctx) && is_marginal && ctx->kind == PML_MODEL_F81;
     const size_t CN = (size_t)ctx->C * ctx->N;
     if (!is_marginal && !ctx->d_J) {
@@ -3074,17 +3101,45 @@ static int submit_bottom_up(pml_ctx* ctx, int is_marginal) {
     // mid-size forests: the level launches are latency-bound, replay them as one hipGraph
     const int n_launches = small_path ? 1 : (is_marginal && ctx->kind == PML_MODEL_F81 ? (int)ctx->bu_offsets_f.size() - 1
                                                                                           : ctx->n_bu_levels);
+    const u64 generation_before = ctx->h_done ? *reinterpret_cast<volatile u64*>(ctx->h_done) : 0;  // (the stream is idle)
     if (ctx->graphs && !ctx->profile && n_launches >= 4) {  // (the block schedule's few launches replay as a graph too)
-        PML_TRY(run_captured(ctx, ctx->bu_graph[is_marginal ? 1 : 0],
+        const int slot = is_marginal ? 1 : 0;
+        const bool replay = ctx->bu_graph[slot].exec != nullptr;
+        PML_TRY(run_captured(ctx, ctx->bu_graph[slot],
                              [&]() { return enqueue_bottom_up(ctx, is_marginal, small_path, true); }));
+        if (!replay) ctx->bu_signals[slot] = ctx->enqueue_signals;  // (a replay runs what was captured)
+        ctx->wait_signal = ctx->bu_signals[slot];
     } else {
         // (inside the capture of a whole marginal pass the per-branch pass must be part of the graph)
         PML_TRY(enqueue_bottom_up(ctx, is_marginal, small_path, ctx->in_outer_capture));
+        ctx->wait_signal = ctx->enqueue_signals;
     }
+    ctx->done_expect = generation_before + 1;
+    if (ctx->in_outer_capture || ctx->tune.on(T_NO_SPIN_WAIT)) ctx->wait_signal = false;
     // the fused eigen sweeps build P(t) in registers, the two-GEMM sweeps never form it: no batch ran
     if (!no_p) ctx->prep_dirty = false;
     ctx->bu_fused = (is_marginal && ctx->kind == PML_MODEL_F81 && ctx->n_cherries > 0) || ctx->bu_fused_joint;
     ctx->bu_absorbed = is_marginal && ctx->kind == PML_MODEL_F81 && !small_path && super_sweeps(ctx);
+    return PML_OK;
+}
+
+// Waits for the bottom-up sweep submitted last.  Where its last launch raises the pinned word (bu_f81_small_kernel) the
+// host spins on that word -- the results lie in pinned memory behind it -- instead of asking the runtime, which notices
+// the end of a short launch sequence ~4 us later (scripts/ub/syncwait.hip); after 2 ms, or for any other sweep, it is
+// hipStreamSynchronize.  Everything queued afterwards is ordered behind the sweep by the stream as before.
+static int wait_bottom_up(pml_ctx* ctx) {
+    if (ctx->wait_signal && ctx->h_done) {
+        ctx->wait_signal = false;
+        const volatile u64* flag = reinterpret_cast<volatile u64*>(ctx->h_done);
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spins = 0;; ++spins) {
+            if (*flag >= ctx->done_expect) return PML_OK;
+            if ((spins & 1023u) == 1023u &&
+                std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2))
+                break;
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
     return PML_OK;
 }
 
@@ -3112,7 +3167,7 @@ int pml_bottom_up(pml_ctx* ctx, int is_marginal, double* loglik_out, int32_t* er
     PML_TRY(require_model(ctx));
     if (!loglik_out) return fail(PML_ERR_INVALID, "loglik_out is NULL");
     PML_TRY(submit_bottom_up(ctx, is_marginal));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    PML_TRY(wait_bottom_up(ctx));
     return collect_bottom_up(ctx, is_marginal, loglik_out, err_parent, err_child);
 }
 
@@ -3125,7 +3180,7 @@ int pml_bottom_up_collect(pml_ctx* ctx, int is_marginal, double* loglik_out, int
     if (!ctx || ctx->C == 0) return fail(PML_ERR_INVALID, "allocate the columns first");
     if (!loglik_out) return fail(PML_ERR_INVALID, "loglik_out is NULL");
     HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    PML_TRY(wait_bottom_up(ctx));
     return collect_bottom_up(ctx, is_marginal, loglik_out, err_parent, err_child);
 }
 
@@ -3414,6 +3469,7 @@ int pml_marginal_pass(pml_ctx* ctx, double* loglik_out, int32_t* err_parent, int
         ctx->tip_post_missing = state_of(ctx).implicit_tips;
     } else {
         PML_TRY(submit_bottom_up(ctx, 1));
+        ctx->wait_signal = false;  // (this call waits for the whole pass: fetch_marginals)
         ctx->bu_mode = 1;  // provisional, for run_top_down's bookkeeping; collect_bottom_up has the last word
         PML_TRY(run_top_down(ctx));
     }
@@ -3512,6 +3568,7 @@ int pml_joint_pass(pml_ctx* ctx, double* loglik_out, int32_t* err_parent, int32_
     if (!loglik_out) return fail(PML_ERR_INVALID, "loglik_out is NULL");
     // joint sweep and back-trace submitted together: one host round trip
     PML_TRY(submit_bottom_up(ctx, 0));
+    ctx->wait_signal = false;  // (fetch_joint_states waits for both)
     PML_TRY(submit_joint_backtrace(ctx));
     const int fetched = fetch_joint_states(ctx, joint_state_out);  // synchronises
     const int status = collect_bottom_up(ctx, 0, loglik_out, err_parent, err_child);

@@ -2673,7 +2673,8 @@ __global__ void __launch_bounds__(PML_SMALL_BLOCK)
 bu_f81_small_kernel(PmlTree t, PmlCols c, PmlState st, const double* __restrict__ mu, const double* __restrict__ sf,
                     const double* __restrict__ tau, const double* __restrict__ tauf, int do_prep,
                     const PmlUnit* __restrict__ units, const int* __restrict__ level_offsets, int n_levels,
-                    double* __restrict__ loglik, u64* __restrict__ err_out, int reset_err) {
+                    double* __restrict__ loglik, u64* __restrict__ err_out, int reset_err,
+                    u64* __restrict__ done_state, u64* done_flag) {
     const int col = blockIdx.y;
     if (reset_err) {  // whole sweep in this launch: the column's error word is reset here, not by a launch of its own
         if (threadIdx.x == 0) st.err[col] = ~0ull;
@@ -2707,6 +2708,19 @@ bu_f81_small_kernel(PmlTree t, PmlCols c, PmlState st, const double* __restrict_
         // pinned host memory: the results land where the caller reads them
         loglik[col] = column_loglik(t, c, st, col, 1);
         err_out[col] = atomicMin(&st.err[col], ~0ull);  // the value in L2, whatever this CU's L1 holds
+        // The host need not wait for the stream to drain: the workgroup that finishes last says so in pinned memory
+        // (done_state[0] counts the columns of this launch, done_state[1] the launches; pml_bottom_up_collect spins on
+        // *done_flag, which saves the ~4 us a stream synchronisation takes to notice -- scripts/ub/syncwait.hip).
+        if (done_flag != nullptr) {
+            __threadfence_system();
+            if (atomicAdd(&done_state[0], 1ull) == (u64)gridDim.y - 1ull) {
+                done_state[0] = 0ull;
+                const u64 generation = done_state[1] + 1ull;
+                done_state[1] = generation;
+                __threadfence_system();
+                *reinterpret_cast<volatile u64*>(done_flag) = generation;
+            }
+        }
     }
 }
 
