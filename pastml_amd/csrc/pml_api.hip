@@ -270,6 +270,11 @@ struct pml_ctx {
     bool enqueue_signals = false;          // set by the launcher while a sweep is enqueued
     bool bu_signals[2] = {false, false};   // per captured sweep (joint / marginal): its last launch signals
     bool wait_signal = false;              // the sweep submitted last signals
+    // the same for a whole marginal pass: its last top-down launch signals where the schedule ends in a multi-level
+    // kernel (single-launch sweeps, subtree blocks); signals_enqueued counts the signalling launches of what is being
+    // enqueued (the bottom-up sweep's and the top-down sweep's), mp_signals / mp_final keep them for the captured pass
+    bool signal_next_td = false, td_final_signals = false, mp_final = false, mp_wants_signal = false;
+    int signals_enqueued = 0, mp_signals = 0;
     bool td_valid = false, js_valid = false;
     bool keep_td = false;      // PML_OPT_KEEP_TD (or a pml_download of the TD vectors asked for them)
     bool td_vec_valid = false; // the TD vectors of the last top-down sweep are in d_td
@@ -677,9 +682,15 @@ static void launch_small_f81(pml_ctx* ctx, bool bottom_up, int do_prep, const Pm
                            ctx->d_tau, ctx->d_tauf, do_prep, units, d_offsets, n_levels, ctx->h_loglik, ctx->h_err,
                            reset_err, signal ? ctx->d_done : nullptr, signal ? ctx->h_done : nullptr);
         ctx->enqueue_signals = signal;  // (the last launch of a bottom-up sweep whenever it is part of one)
-    } else
+        if (signal) ++ctx->signals_enqueued;
+    } else {
+        const bool signal = ctx->signal_next_td && ctx->C <= 64 && !ctx->tune.on(T_NO_SPIN_WAIT);
+        ctx->signal_next_td = false;
         hipLaunchKernelGGL((td_f81_small_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, units, d_offsets,
-                           n_levels);
+                           n_levels, signal ? ctx->d_done : nullptr, signal ? ctx->h_done : nullptr);
+        ctx->td_final_signals = signal;
+        if (signal) ++ctx->signals_enqueued;
+    }
 }
 
 // one workgroup per (subtree block, column) walks the block's levels (pml_kernels_f81.h, bottom)
@@ -715,9 +726,14 @@ static void launch_blocks_f81(pml_ctx* ctx, bool bottom_up) {
     if (bottom_up)
         hipLaunchKernelGGL((bu_f81_blocks_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, B.d_bu_units, B.d_bu_start,
                            B.d_bu_levels, B.d_bu_lv);
-    else
+    else {
+        const bool signal = ctx->signal_next_td && ctx->C <= 64 && !ctx->tune.on(T_NO_SPIN_WAIT);
+        ctx->signal_next_td = false;
         hipLaunchKernelGGL((td_f81_blocks_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, B.d_td_units, B.d_td_start,
-                           B.d_td_levels, B.d_td_lv);
+                           B.d_td_levels, B.d_td_lv, signal ? ctx->d_done : nullptr, signal ? ctx->h_done : nullptr);
+        ctx->td_final_signals = signal;
+        if (signal) ++ctx->signals_enqueued;
+    }
 }
 
 #define PML_F81_CASES(X) \
@@ -3218,6 +3234,7 @@ static int run_top_down(pml_ctx* ctx) {
                 PML_TRY(status);
                 ++n_launch;
             }
+            ctx->signal_next_td = ctx->mp_wants_signal;  // (the last launch of the pass)
             PML_TRY(dispatch_blocks_f81(ctx, false));
             PML_TRY(prof_end(ctx, 1, n_launch + 1));
             return PML_OK;
@@ -3270,6 +3287,7 @@ static int run_top_down(pml_ctx* ctx) {
         PML_TRY(prof_begin(ctx));  // the profile brackets the level kernel's launches only
         long long n_launch = 0;
         if (td_small) {
+            ctx->signal_next_td = ctx->mp_wants_signal;  // (the last launch of the pass)
             PML_TRY(dispatch_small_f81(ctx, false, 0));
             n_launch = 1;
         }
@@ -3440,22 +3458,40 @@ int pml_marginal_pass(pml_ctx* ctx, double* loglik_out, int32_t* err_parent, int
     const bool one_graph = ctx->graphs && !ctx->profile && ctx->kind == PML_MODEL_F81 && ctx->d_post != nullptr &&
                            (!ctx->keep_td || ctx->d_td != nullptr) &&
                            (bu_launches >= 4 || (!td_small && ctx->n_td_levels >= 4));
+    // Where the pass ends in a multi-level kernel and has few columns, that kernel says when it is done (pml_signal_done)
+    // and the wait at the end of this call is a spin on the word it raises (wait_signals) -- as for a bottom-up sweep.
+    // The word counts the signalling launches (the bottom-up sweep's last one may be one too).
+    if (ctx->wait_signal) {  // (a sweep submitted and never collected: the count below is read on an idle stream)
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        ctx->wait_signal = false;
+    }
+    const u64 generation_before = ctx->h_done ? *reinterpret_cast<volatile u64*>(ctx->h_done) : 0;
+    int n_signals = 0;
+    bool final_signals = false;
     if (one_graph) {
         if (ctx->mp_graph.exec && ctx->mp_graph.has_init == ctx->has_init) {
             HIP_TRY(hipGraphLaunch(ctx->mp_graph.exec, ctx->stream));
             if (ctx->mp_graph.has_params) ctx->params_dirty = false;
         } else {
+            ctx->signals_enqueued = 0;
+            ctx->td_final_signals = false;
             PML_TRY(run_captured(ctx, ctx->mp_graph, [&]() {
                 ctx->in_outer_capture = true;
+                ctx->mp_wants_signal = true;
                 int status = submit_bottom_up(ctx, 1);
                 if (status == PML_OK) {
                     ctx->bu_mode = 1;
                     status = run_top_down(ctx);
                 }
+                ctx->mp_wants_signal = false;
                 ctx->in_outer_capture = false;
                 return status;
             }));
+            ctx->mp_signals = ctx->signals_enqueued;
+            ctx->mp_final = ctx->td_final_signals;
         }
+        n_signals = ctx->mp_signals;
+        final_signals = ctx->mp_final;
         // the bookkeeping of submit_bottom_up / run_top_down (a replay runs neither)
         ctx->js_valid = false;
         ctx->prep_dirty = false;
@@ -3469,10 +3505,21 @@ int pml_marginal_pass(pml_ctx* ctx, double* loglik_out, int32_t* err_parent, int
         ctx->tip_post_missing = state_of(ctx).implicit_tips;
     } else {
         PML_TRY(submit_bottom_up(ctx, 1));
+        n_signals = ctx->wait_signal ? 1 : 0;  // (its last launch signals)
         ctx->wait_signal = false;  // (this call waits for the whole pass: fetch_marginals)
         ctx->bu_mode = 1;  // provisional, for run_top_down's bookkeeping; collect_bottom_up has the last word
-        PML_TRY(run_top_down(ctx));
+        ctx->signals_enqueued = 0;
+        ctx->td_final_signals = false;
+        ctx->mp_wants_signal = td_small;  // (the single launch is enqueued afresh every time; level sweeps may replay a graph)
+        const int td_status = run_top_down(ctx);
+        ctx->mp_wants_signal = false;
+        PML_TRY(td_status);
+        n_signals += ctx->signals_enqueued;
+        final_signals = ctx->td_final_signals;
     }
+    const bool spin = final_signals && ctx->comm == nullptr && !posterior_out && !lh_sum_out && !lh_sf_out &&
+                      !ctx->tune.on(T_NO_SPIN_WAIT);
+    ctx->done_expect = generation_before + (u64)n_signals;
     // a communicator is attached: the one collective of the path goes on the stream right here, behind the sweeps --
     // the rank's sum formed on the device from the values the sweep left in pinned memory, all-reduced over RCCL, copied
     // back; the single wait of this call (fetch_marginals) covers it.  pml_loglik_total hands the result out.
@@ -3488,7 +3535,13 @@ int pml_marginal_pass(pml_ctx* ctx, double* loglik_out, int32_t* err_parent, int
         HIP_TRY(hipMemcpyAsync(cm->h_total, cm->d_total, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         cm->total_fresh = true;
     }
-    const int fetched = fetch_marginals(ctx, posterior_out, lh_sum_out, lh_sf_out);  // synchronises
+    int fetched = PML_OK;
+    if (spin) {
+        ctx->wait_signal = true;
+        fetched = wait_bottom_up(ctx);  // (nothing to copy: the spin on the last launch's word, or the stream)
+    } else {
+        fetched = fetch_marginals(ctx, posterior_out, lh_sum_out, lh_sf_out);  // synchronises
+    }
     ctx->bu_mode = -1;
     const int status = collect_bottom_up(ctx, 1, loglik_out, err_parent, err_child);
     if (status != PML_OK) {

@@ -2773,10 +2773,25 @@ td_f81_roots_kernel(PmlTree t, PmlCols c, PmlState st) {
     }
 }
 
+// The last launch of a short marginal pass tells the host that it is done (see bu_f81_small_kernel; what the pass leaves in
+// device memory is read by later work on the stream, what it left in pinned memory was written by earlier launches):
+// called by thread 0 of every workgroup behind the barrier that ends its walk.
+__device__ __forceinline__ void pml_signal_done(u64* __restrict__ done_state, u64* done_flag) {
+    if (done_flag == nullptr) return;
+    __threadfence();
+    if (atomicAdd(&done_state[0], 1ull) == (u64)gridDim.x * gridDim.y - 1ull) {
+        done_state[0] = 0ull;
+        const u64 generation = done_state[1] + 1ull;
+        done_state[1] = generation;
+        __threadfence_system();
+        *reinterpret_cast<volatile u64*>(done_flag) = generation;
+    }
+}
+
 template <int G, int R>
 __global__ void __launch_bounds__(PML_SMALL_BLOCK)
 td_f81_small_kernel(PmlTree t, PmlCols c, PmlState st, const PmlUnit* __restrict__ units,
-                    const int* __restrict__ level_offsets, int n_levels) {
+                    const int* __restrict__ level_offsets, int n_levels, u64* __restrict__ done_state, u64* done_flag) {
     constexpr int UW = 64 / G;
     const int wave = threadIdx.x >> 6;
     const int n_waves = blockDim.x >> 6;
@@ -2789,6 +2804,7 @@ td_f81_small_kernel(PmlTree t, PmlCols c, PmlState st, const PmlUnit* __restrict
     }
     __syncthreads();
     walk_levels<G, R, false>(L, t, c, st, units, level_offsets, n_levels);
+    if (threadIdx.x == 0) pml_signal_done(done_state, done_flag);
 }
 
 
@@ -2815,8 +2831,10 @@ bu_f81_blocks_kernel(PmlTree t, PmlCols c, PmlState st, const PmlUnit* __restric
 template <int G, int R>
 __global__ void __launch_bounds__(PML_SMALL_BLOCK)
 td_f81_blocks_kernel(PmlTree t, PmlCols c, PmlState st, const PmlUnit* __restrict__ units,
-                     const int* __restrict__ blk_start, const int* __restrict__ blk_levels, const int* __restrict__ lv) {
+                     const int* __restrict__ blk_start, const int* __restrict__ blk_levels, const int* __restrict__ lv,
+                     u64* __restrict__ done_state, u64* done_flag) {
     LaneCtx<G, R> L;
     lane_ctx_init<G, R>(L, t, c, st);
     walk_levels<G, R, false>(L, t, c, st, units, lv + blk_start[blockIdx.x], blk_levels[blockIdx.x]);
+    if (threadIdx.x == 0) pml_signal_done(done_state, done_flag);
 }

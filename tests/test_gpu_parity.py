@@ -826,6 +826,45 @@ def test_many_columns_take_the_single_launch_kernels_with_the_same_bits():
                 assert np.array_equal(lh_sf1[0], lh_sf[c])
 
 
+@pytest.mark.parametrize('n_tips,cols', [(300, 3), (6000, 2), (300, 70)])
+def test_completion_word_wait_returns_what_the_stream_wait_returns(n_tips, cols):
+    """Short sweeps of few columns end in a kernel that raises a word in pinned memory, and the host spins on it instead of
+    synchronising the stream (pml_bottom_up / _collect, pml_marginal_pass without copies; NO_SPIN_WAIT = the stream): the
+    results of a series of sweeps with changing models, of a sweep submitted twice before it is collected, and of passes
+    with and without copies are the same either way (70 columns: no word, the stream)."""
+    k = 4
+    rng = np.random.default_rng(n_tips + cols)
+    flat = FlatForest.random(n_tips, seed=n_tips, max_arity=3, zero_frac=0.0, n_trees=2)
+    masks = np.stack([random_masks(flat, k, rng, internal=0.0) for _ in range(cols)])
+    series = [[(random_spec('F81', k, rng), (float(rng.uniform(0.5, 3)), 0.0, 1.0)) for _ in range(cols)] for _ in range(6)]
+    results = {}
+    for name, tune in (('word', {}), ('stream', dict(NO_SPIN_WAIT=1))):
+        out = []
+        with hip.Engine(flat, cols, k, tune=tune) as eng:
+            eng.set_masks(masks)
+            for specs in series:
+                eng.set_models(specs)
+                out.append(eng.bottom_up(True))
+                out.append(eng.marginal_pass(posterior=False, lh=False)[0])
+                lnl, post, lh_sum, lh_sf = eng.marginal_pass()
+                out += [lnl, post, lh_sum]
+            # submitted twice, collected once: the second sweep's results
+            eng.set_models(series[0])
+            eng.bottom_up_submit(True)
+            eng.set_models(series[1])
+            eng.bottom_up_submit(True)
+            out.append(eng.bottom_up_collect(True))
+            eng.set_models(series[1])
+            assert np.array_equal(out[-1], eng.bottom_up(True))
+            # a pass without copies leaves the table where a later download finds it
+            eng.set_models(series[2])
+            eng.marginal_pass(posterior=False, lh=False)
+            out.append(eng.download(hip.BUF_POSTERIOR, cols - 1))
+        results[name] = out
+    for x, y in zip(results['word'], results['stream']):
+        assert np.array_equal(x, y)
+
+
 @pytest.mark.parametrize('k', [2, 4, 12, 64])
 def test_block_schedule_gives_the_bits_of_the_level_schedule(k):
     """Mid-size forests: subtree blocks walked by one workgroup each + the top above the cuts (a handful of launches)
