@@ -187,6 +187,9 @@ int pml_bottom_up(pml_ctx* ctx, int is_marginal, double* loglik_out, int32_t* er
  * different numbers of states, each with its own optimisers: the reference runs them one after the other,
  * pastml/acr.py:213-231) submits all their sweeps before it waits for any: the sweeps overlap on the device and with
  * the host work between them.  Between the two calls nothing else may be called on the context.
+ * How the wait is done is the library's business: for short sweeps of at most 64 columns the last kernel raises a word in
+ * pinned memory and the host spins on it (the runtime reports the end of a replayed launch sequence 10 - 14 us late);
+ * everything else synchronises the stream (always with the switch NO_SPIN_WAIT).  The results are the same.
  */
 int pml_bottom_up_submit(pml_ctx* ctx, int is_marginal);
 int pml_bottom_up_collect(pml_ctx* ctx, int is_marginal, double* loglik_out, int32_t* err_parent, int32_t* err_child);
