@@ -737,6 +737,8 @@ static void launch_blocks_f81(pml_ctx* ctx, bool bottom_up) {
 }
 
 #define PML_F81_CASES(X) \
+    X(2, 2)              \
+    X(4, 2)              \
     X(1, 1)              \
     X(1, 2)              \
     X(1, 4)              \
@@ -2379,9 +2381,17 @@ int pml_chars_alloc(pml_ctx* ctx, int32_t n_cols, int32_t k) {
         // wavefront share each scalar instruction.  PASTML_HIP_F81_R / PASTML_HIP_F81_TD_R = 2 / 4 / 8: tuning variants
         auto shape = [&](int var, int dflt, int& G, int& R) {
             int rf = k >= 3 ? dflt : k;
+            // Up to 8 states: two per lane (2 or 4 lanes per unit).  In the latency-bound schedules -- small and mid-size
+            // forests -- a level is one wavefront's instruction stream, and half the states per lane are a shorter one
+            // (HIV1C tree, 14 columns: bottom-up sweep k = 4 0.111 -> 0.094 ms, k = 8 0.107 -> 0.095; marginal pass
+            // 0.290 -> 0.262, 0.319 -> 0.262; cfg2 0.0765 -> 0.0713 ms); the level kernels of large forests are
+            // indifferent (262 144 tips x 32 characters, k = 4: balanced 0.73 -> 0.77 ms, ragged 2.46 -> 2.34).  One state
+            // per lane is another 3 - 5 % on the small forests and costs the large balanced one a third: not taken.
+            if (k >= 3 && k <= 8 && dflt == 4) rf = 2;
             if (ctx->tune.on(var)) {
                 const int v = (int)ctx->tune.get(var, 0);
                 if ((v == 2 || v == 4 || v == 8) && k > 32 && k <= 64) rf = v;
+                if ((v == 2 || v == 4) && k >= 3 && k <= 8) rf = v;
             }
             R = rf;
             const int need = (k + rf - 1) / rf;

@@ -11,6 +11,8 @@ cases = dict(ragged64=('ragged262k k64 C32', lambda: FlatForest.random(262144, s
              ragged20=('ragged262k k20 C16', lambda: FlatForest.random(262144, seed=3, max_arity=2, n_trees=1), 20, 16),
              poly64=('polytomies100k k64 C16', lambda: FlatForest.random(100000, seed=5, max_arity=5, n_trees=2), 64, 16),
              balanced64=('balanced2^18 k64 C32', lambda: synthetic.balanced_forest(18), 64, 32),
+             balanced8=('balanced2^18 k8 C32', lambda: synthetic.balanced_forest(18), 8, 32),
+             ragged8=('ragged262k k8 C32', lambda: FlatForest.random(262144, seed=3, max_arity=2, n_trees=1), 8, 32),
              balanced4=('balanced2^18 k4 C32', lambda: synthetic.balanced_forest(18), 4, 32),
              balanced12=('balanced2^18 k12 C32', lambda: synthetic.balanced_forest(18), 12, 32),
              ragged12=('ragged262k k12 C32', lambda: FlatForest.random(262144, seed=3, max_arity=2, n_trees=1), 12, 32))
