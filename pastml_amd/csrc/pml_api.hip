@@ -3160,6 +3160,9 @@ static int wait_bottom_up(pml_ctx* ctx) {
         const auto t0 = std::chrono::steady_clock::now();
         for (unsigned spins = 0;; ++spins) {
             if (*flag >= ctx->done_expect) return PML_OK;
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
             if ((spins & 1023u) == 1023u &&
                 std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2))
                 break;
