@@ -192,6 +192,15 @@ int pml_bottom_up(pml_ctx* ctx, int is_marginal, double* loglik_out, int32_t* er
  * everything else synchronises the stream (always with the switch NO_SPIN_WAIT).  The results are the same.
  */
 int pml_bottom_up_submit(pml_ctx* ctx, int is_marginal);
+/*
+ * pml_bottom_up_submit for some of the columns: active[n_cols], 0 = the column sits this sweep out (NULL = all).  What
+ * pml_bottom_up_collect returns for such a column is what the last sweep that computed it returned (ln L) and "no error";
+ * its parameters and masks must be those of that sweep.  For the optimisers of a group of characters, most of which
+ * are done long before the last one (the reference optimises one character at a time, pastml/acr.py:213-231).  The
+ * next sweep or pass submitted in any other way computes every column again.  F81 family, marginal sweep; otherwise the
+ * flags are ignored.
+ */
+int pml_bottom_up_submit_columns(pml_ctx* ctx, int is_marginal, const uint8_t* active);
 int pml_bottom_up_collect(pml_ctx* ctx, int is_marginal, double* loglik_out, int32_t* err_parent, int32_t* err_child);
 /*
  * Top-down sweep + marginal likelihoods + posteriors, fused: pastml/ml.py:240-290 (calculate_top_down_likelihood),

@@ -442,7 +442,17 @@ class CharacterBatch(object):
                 lo, hi = min(lo, a), max(hi, a + n)
             eng.commit_f81(lo, hi)
             self.n_sweeps += sum(len(p) for p in requests.values())
-            eng.bottom_up_submit(True)
+            # only the blocks that asked: every other column keeps the parameters and the results of an earlier sweep
+            # (most characters of a group are done long before the last one: a sweep of 246 columns for the six that
+            # still matter is the group's whole tail otherwise)
+            active = opt.get('active')
+            if active is None:
+                active = opt['active'] = np.zeros(opt['total'], dtype=np.uint8)
+            active[:] = 0
+            for c, block in requests.items():
+                a = int(offsets[c])
+                active[a:a + len(block)] = 1
+            eng.bottom_up_submit(True, active=active if SWEEP_ACTIVE_COLUMNS_ONLY else None)
             opt['in_flight'] = requests
             return
         for c, points in requests.items():
@@ -638,6 +648,8 @@ class _Found(object):
 
 # PASTML_AMD_FD_IN_LIBRARY=0: the finite-difference points of the F81 family through numpy (two_point_scheme + kernel_points)
 # instead of the library's helper -- the same numbers; tests compare the two
+# the optimiser's sweeps compute the columns of the characters that asked only (Engine.bottom_up_submit(active=...))
+SWEEP_ACTIVE_COLUMNS_ONLY = os.environ.get('PASTML_AMD_SWEEP_ACTIVE_ONLY', '1') != '0'
 FD_IN_LIBRARY = os.environ.get('PASTML_AMD_FD_IN_LIBRARY', '1') != '0'
 
 # tests / diagnostics: a dict {character: [one record per L-BFGS-B run: start, iterates (x_k, f(x_k)), end, counts]} that

@@ -225,6 +225,9 @@ struct pml_ctx {
     bool has_init = false;
     int kind = -1;
     double *d_pi = nullptr, *d_mu = nullptr, *d_kappa = nullptr, *d_d = nullptr, *d_A = nullptr, *d_Ainv = nullptr;
+    double* d_active = nullptr;   // last array of the parameter block: 0.0 = the column sits the next bottom-up sweep out
+    bool active_partial = false;  // ... some column does (pml_bottom_up_submit_columns)
+    bool in_bu_enqueue = false;   // the launches being enqueued are a bottom-up sweep's: they look at the flags
     double* d_AinvT = nullptr;  // [C][32][32]: Ainv transposed and zero-padded (k <= 32), for eigen_joint_kernel
     double *d_sf = nullptr, *d_tau = nullptr, *d_tauf = nullptr;
     std::vector<char> model_set;  // per column
@@ -405,6 +408,7 @@ static PmlCols cols_of(const pml_ctx* c) {
     s.masks = c->d_masks;
     s.masks_init = c->has_init ? c->d_masks_init : nullptr;
     s.pi = c->d_pi;
+    s.active = c->in_bu_enqueue ? c->d_active : nullptr;  // (only the sweep itself: downloads rebuild what they need for all)
     return s;
 }
 
@@ -2421,16 +2425,19 @@ int pml_chars_alloc(pml_ctx* ctx, int32_t n_cols, int32_t k) {
     }
     const size_t CN = (size_t)n_cols * ctx->N;
     PML_TRY(dev_alloc(ctx, &ctx->d_masks, CN * ctx->W));
-    ctx->n_params = (size_t)n_cols * (ctx->ks + 5);
+    ctx->n_params = (size_t)n_cols * (ctx->ks + 6);  // pi, sf, tau, tau factor, mu, kappa, active
     PML_TRY(dev_alloc(ctx, &ctx->d_params, ctx->n_params));
     HIP_TRY(hipHostMalloc((void**)&ctx->h_params, sizeof(double) * ctx->n_params));
     memset(ctx->h_params, 0, sizeof(double) * ctx->n_params);
+    for (int i = 0; i < n_cols; ++i) ctx->h_params[(size_t)n_cols * (ctx->ks + 5) + i] = 1.0;  // every column active
     ctx->d_pi = ctx->d_params;
     ctx->d_sf = ctx->d_pi + (size_t)n_cols * ctx->ks;
     ctx->d_tau = ctx->d_sf + n_cols;
     ctx->d_tauf = ctx->d_tau + n_cols;
     ctx->d_mu = ctx->d_tauf + n_cols;
     ctx->d_kappa = ctx->d_mu + n_cols;
+    ctx->d_active = ctx->d_kappa + n_cols;
+    ctx->active_partial = false;
     PML_TRY(dev_alloc(ctx, &ctx->d_err, n_cols));
     HIP_TRY(hipHostMalloc((void**)&ctx->h_loglik, sizeof(double) * n_cols));
     HIP_TRY(hipHostMalloc((void**)&ctx->h_err, sizeof(u64) * n_cols));
@@ -2445,7 +2452,7 @@ int pml_chars_alloc(pml_ctx* ctx, int32_t n_cols, int32_t k) {
     PML_TRY(dev_alloc(ctx, &ctx->d_S, CN));
     PML_TRY(dev_alloc(ctx, &ctx->d_be, CN));
     PML_TRY(dev_alloc(ctx, &ctx->d_E, CN));
-    HIP_TRY(hipMemsetAsync(ctx->d_params, 0, ctx->n_params * sizeof(double), ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->d_params, ctx->h_params, ctx->n_params * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemsetAsync(ctx->d_be, 0, CN * sizeof(i64), ctx->stream));
     // default masks: everything allowed
     {
@@ -2860,6 +2867,11 @@ static int narrow_levels(const pml_ctx* ctx, const std::vector<int>& off, int n_
 // ---------------------------------------------------------------------------------------------------------------------
 // Everything a bottom-up sweep puts on the stream, without host synchronisation (so that it can be captured).
 static int enqueue_bottom_up(pml_ctx* ctx, int is_marginal, bool small_path, bool force_prep) {
+    struct Scope {
+        pml_ctx* c;
+        explicit Scope(pml_ctx* x) : c(x) { c->in_bu_enqueue = true; }
+        ~Scope() { c->in_bu_enqueue = false; }
+    } scope(ctx);
     ctx->enqueue_signals = false;
     const bool eig = eigen_fused(ctx);
     const bool gemm = is_marginal && eigen_gemm(ctx);
@@ -3101,7 +3113,25 @@ static int run_captured(pml_ctx* ctx, pml_ctx::GraphSlot& slot, const std::funct
 }
 
 // puts a bottom-up sweep on the stream (no host synchronisation)
-static int submit_bottom_up(pml_ctx* ctx, int is_marginal) {
+// Which columns the next bottom-up sweep computes (nullptr: all).  The flags travel with the parameter block (params_push:
+// inside the captured sweep when it is replayed), so they are written while no sweep is in flight, like the parameters.
+static void set_active_columns(pml_ctx* ctx, const uint8_t* active) {
+    if (!ctx->h_params) return;
+    double* flags = ctx->h_params + (size_t)ctx->C * (ctx->ks + 5);
+    if (active == nullptr && !ctx->active_partial) return;  // (all ones already)
+    bool partial = false, changed = false;
+    for (int i = 0; i < ctx->C; ++i) {
+        const double v = (active == nullptr || active[i]) ? 1.0 : 0.0;
+        changed = changed || flags[i] != v;
+        partial = partial || v == 0.0;
+        flags[i] = v;
+    }
+    ctx->active_partial = partial;
+    if (changed) ctx->params_dirty = true;
+}
+
+static int submit_bottom_up(pml_ctx* ctx, int is_marginal, const uint8_t* active = nullptr) {
+    set_active_columns(ctx, active);
     if (ctx->wait_signal) {  // a sweep was submitted and never collected: the generation below must be read on an idle stream
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         ctx->wait_signal = false;
@@ -3177,9 +3207,10 @@ static int collect_bottom_up(pml_ctx* ctx, int is_marginal, double* loglik_out, 
     memcpy(loglik_out, ctx->h_loglik, sizeof(double) * ctx->C);
     const u64* err = ctx->h_err;
     int status = PML_OK;
+    const double* flags = ctx->h_params + (size_t)ctx->C * (ctx->ks + 5);
     for (int c = 0; c < ctx->C; ++c) {
         int ep = -1, ec = -1;
-        if (err[c] != ~0ull) {
+        if (err[c] != ~0ull && flags[c] != 0.0) {  // (a column that sat the sweep out reports nothing)
             ec = (int)(err[c] & 0xffffffffull);
             ep = ctx->h_parent[ec];
             if (status == PML_OK)
@@ -3203,6 +3234,12 @@ int pml_bottom_up(pml_ctx* ctx, int is_marginal, double* loglik_out, int32_t* er
 int pml_bottom_up_submit(pml_ctx* ctx, int is_marginal) {
     PML_TRY(require_model(ctx));
     return submit_bottom_up(ctx, is_marginal);
+}
+
+int pml_bottom_up_submit_columns(pml_ctx* ctx, int is_marginal, const uint8_t* active) {
+    PML_TRY(require_model(ctx));
+    if (!is_marginal || ctx->kind != PML_MODEL_F81) active = nullptr;  // (only the F81 marginal kernels look at the flags)
+    return submit_bottom_up(ctx, is_marginal, active);
 }
 
 int pml_bottom_up_collect(pml_ctx* ctx, int is_marginal, double* loglik_out, int32_t* err_parent, int32_t* err_child) {
@@ -3478,6 +3515,7 @@ int pml_marginal_pass(pml_ctx* ctx, double* loglik_out, int32_t* err_parent, int
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         ctx->wait_signal = false;
     }
+    set_active_columns(ctx, nullptr);  // (the replayed pass does not go through submit_bottom_up)
     const u64 generation_before = ctx->h_done ? *reinterpret_cast<volatile u64*>(ctx->h_done) : 0;
     int n_signals = 0;
     bool final_signals = false;

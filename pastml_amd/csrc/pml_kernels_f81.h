@@ -38,7 +38,12 @@ struct PmlCols {
     const u64* masks;       // [C][N][W]
     const u64* masks_init;  // [C][N][W] or nullptr
     const double* pi;       // [C][ks]
+    // [C]: 0.0 = the bottom-up sweep leaves this column alone -- its parameters and masks are those of the last sweep
+    // that computed it, and so are its results (pml_bottom_up_submit_columns: the optimisers of most characters of a
+    // group are done long before the last one).  The F81 bottom-up kernels with a workgroup per column check it.
+    const double* active;
 };
+__device__ __forceinline__ bool column_active(const PmlCols& c, int col) { return c.active == nullptr || c.active[col] != 0.0; }
 
 struct PmlState {
     double* E;      // [C][N]      F81: exp(-mu t') per branch
@@ -77,6 +82,7 @@ f81_prep_kernel(PmlTree t, PmlCols c, const double* __restrict__ mu, const doubl
         const double d = t.dist[n];
         const bool tip = t.n_children[n] == 0;
         for (int col = col0; col < col1; ++col) {
+            if (!column_active(c, col)) continue;
             const size_t colN = (size_t)col * t.N;
             const double m = mu[col];
             const double tt = (d + tau[col]) * tauf[col] * sf[col];
@@ -1322,6 +1328,7 @@ __device__ __forceinline__ void bu_f81_unit_seq(const LaneCtx<G, R>& L, const Pm
 template <int G, int R, bool JOINT, bool VEC>
 __global__ void __launch_bounds__(PML_BLOCK) __attribute__((amdgpu_waves_per_eu(R >= 8 ? 2 : 3, R >= 8 ? 2 : 4)))
 bu_f81_kernel(PmlTree t, PmlCols c, PmlState st, const PmlUnit* __restrict__ units, int n_level) {
+    if (!JOINT && !column_active(c, blockIdx.y)) return;
     constexpr int UW = 64 / G;  // units per wave
     const int wave = threadIdx.x >> 6;
     const int sub = (threadIdx.x & 63) / G;
@@ -2676,6 +2683,18 @@ bu_f81_small_kernel(PmlTree t, PmlCols c, PmlState st, const double* __restrict_
                     double* __restrict__ loglik, u64* __restrict__ err_out, int reset_err,
                     u64* __restrict__ done_state, u64* done_flag) {
     const int col = blockIdx.y;
+    if (!column_active(c, col)) {  // (its words in pinned memory stay what they were; the launch still counts it)
+        if (threadIdx.x == 0 && done_flag != nullptr) {
+            if (atomicAdd(&done_state[0], 1ull) == (u64)gridDim.y - 1ull) {
+                done_state[0] = 0ull;
+                const u64 generation = done_state[1] + 1ull;
+                done_state[1] = generation;
+                __threadfence_system();
+                *reinterpret_cast<volatile u64*>(done_flag) = generation;
+            }
+        }
+        return;
+    }
     if (reset_err) {  // whole sweep in this launch: the column's error word is reset here, not by a launch of its own
         if (threadIdx.x == 0) st.err[col] = ~0ull;
         __syncthreads();
@@ -2823,6 +2842,7 @@ template <int G, int R>
 __global__ void __launch_bounds__(PML_SMALL_BLOCK)
 bu_f81_blocks_kernel(PmlTree t, PmlCols c, PmlState st, const PmlUnit* __restrict__ units,
                      const int* __restrict__ blk_start, const int* __restrict__ blk_levels, const int* __restrict__ lv) {
+    if (!column_active(c, blockIdx.y)) return;
     LaneCtx<G, R> L;
     lane_ctx_init<G, R>(L, t, c, st);
     walk_levels<G, R, true>(L, t, c, st, units, lv + blk_start[blockIdx.x], blk_levels[blockIdx.x]);

@@ -89,6 +89,7 @@ SIGNATURES = {
     'pml_pij_batch': [_ctx_p, _c_double_p],
     'pml_bottom_up': [_ctx_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p],
     'pml_bottom_up_submit': [_ctx_p, ctypes.c_int],
+    'pml_bottom_up_submit_columns': [_ctx_p, ctypes.c_int, ctypes.c_void_p],
     'pml_loglik_total': [_ctx_p, _c_double_p],
     'pml_bottom_up_collect': [_ctx_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p],
     'pml_top_down_marginals': [_ctx_p, _c_double_p, _c_double_p, _c_double_p],
@@ -612,9 +613,17 @@ class Engine(BareContext):
     def bottom_up(self, is_marginal=True):
         return self._sweep_results(self._lib.pml_bottom_up(self._ctx, 1 if is_marginal else 0, *self._out_addr))
 
-    def bottom_up_submit(self, is_marginal=True):
-        """Puts a bottom-up sweep on the context's stream and returns at once (see bottom_up_collect)."""
-        _check(self._lib.pml_bottom_up_submit(self._ctx, 1 if is_marginal else 0))
+    def bottom_up_submit(self, is_marginal=True, active=None):
+        """Puts a bottom-up sweep on the context's stream and returns at once (see bottom_up_collect).  active: uint8
+        array of n_cols, 0 = the column sits this sweep out (its parameters and masks are those of the last sweep that
+        computed it, and bottom_up_collect returns that sweep's value for it); None = all columns."""
+        if active is None:
+            _check(self._lib.pml_bottom_up_submit(self._ctx, 1 if is_marginal else 0))
+            return
+        active = np.ascontiguousarray(active, dtype=np.uint8)
+        if active.shape != (self.n_cols,):
+            raise ValueError('active must have one entry per column')
+        _check(self._lib.pml_bottom_up_submit_columns(self._ctx, 1 if is_marginal else 0, active.ctypes.data))
 
     def bottom_up_collect(self, is_marginal=True):
         """Waits for the sweep of bottom_up_submit; returns / raises what bottom_up would have."""

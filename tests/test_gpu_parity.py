@@ -826,6 +826,41 @@ def test_many_columns_take_the_single_launch_kernels_with_the_same_bits():
                 assert np.array_equal(lh_sf1[0], lh_sf[c])
 
 
+@pytest.mark.parametrize('n_tips,cols,k', [(300, 70, 2), (6000, 12, 4), (3000, 5, 12), (40000, 3, 64)])
+def test_sweep_of_some_columns_leaves_the_others_alone(n_tips, cols, k):
+    """pml_bottom_up_submit_columns: the columns named take part in the sweep and get the values of a sweep of all columns,
+    the others keep the value of the last sweep that computed them (single-launch sweeps, subtree blocks, level kernels);
+    a zero likelihood in a column that sits the sweep out is not reported; the next ordinary sweep computes everything."""
+    rng = np.random.default_rng(n_tips + cols)
+    flat = FlatForest.random(n_tips, seed=n_tips + 1, max_arity=3, zero_frac=0.0, n_trees=2)
+    masks = np.stack([random_masks(flat, k, rng, internal=0.0) for _ in range(cols)])
+    first = [(random_spec('F81', k, rng), (float(rng.uniform(0.5, 3)), 0.0, 1.0)) for _ in range(cols)]
+    second = [(random_spec('F81', k, rng), (float(rng.uniform(0.5, 3)), 0.0, 1.0)) for _ in range(cols)]
+    active = (rng.random(cols) < 0.4).astype(np.uint8)
+    active[0], active[-1] = 1, 0
+    with hip.Engine(flat, cols, k) as eng:
+        eng.set_masks(masks)
+        eng.set_models(first)
+        before = eng.bottom_up(True)
+        for rep in range(3):   # (the second and third time as replayed launch sequences)
+            eng.set_models(first)
+            eng.bottom_up(True)
+            for c in np.flatnonzero(active):
+                eng.set_models([second[c]], col_begin=int(c))
+            eng.bottom_up_submit(True, active=active)
+            mixed = eng.bottom_up_collect(True)
+            bu_mixed = [eng.download(hip.BUF_BU, c) for c in (0, cols - 1)]
+        eng.set_models(second)
+        after = eng.bottom_up(True)
+        bu_after = eng.download(hip.BUF_BU, 0)
+        eng.set_models(first)
+        assert np.array_equal(eng.bottom_up(True), before)
+        bu_before = eng.download(hip.BUF_BU, cols - 1)
+    assert np.array_equal(mixed, np.where(active == 1, after, before))
+    assert np.array_equal(bu_mixed[0], bu_after) and np.array_equal(bu_mixed[1], bu_before)
+    assert not np.array_equal(before, after)
+
+
 @pytest.mark.parametrize('n_tips,cols', [(300, 3), (6000, 2), (300, 70)])
 def test_completion_word_wait_returns_what_the_stream_wait_returns(n_tips, cols):
     """Short sweeps of few columns end in a kernel that raises a word in pinned memory, and the host spins on it instead of
