@@ -228,6 +228,9 @@ struct pml_ctx {
     double* d_active = nullptr;   // last array of the parameter block: 0.0 = the column sits the next bottom-up sweep out
     bool active_partial = false;  // ... some column does (pml_bottom_up_submit_columns)
     bool in_bu_enqueue = false;   // the launches being enqueued are a bottom-up sweep's: they look at the flags
+    int n_active = 0;             // columns that take part in the next sweep
+    int sched_cols = 0;           // the number of columns the schedule of a sweep is chosen for (C; 32 for a few active ones)
+    bool bu_signals_few = false;
     double* d_AinvT = nullptr;  // [C][32][32]: Ainv transposed and zero-padded (k <= 32), for eigen_joint_kernel
     double *d_sf = nullptr, *d_tau = nullptr, *d_tauf = nullptr;
     std::vector<char> model_set;  // per column
@@ -254,6 +257,7 @@ struct pml_ctx {
     };
     bool capture_saw_params = false;
     GraphSlot bu_graph[2], td_graph, bt_graph;
+    GraphSlot bu_graph_few;        // the marginal sweep as scheduled for a few active columns (submit_bottom_up)
     GraphSlot mp_graph;            // bottom-up + top-down of pml_marginal_pass as ONE graph
     bool in_outer_capture = false; // the sweeps are being captured into mp_graph: no graphs of their own
     bool graphs = true;
@@ -316,6 +320,7 @@ static void drop_graph(pml_ctx::GraphSlot& g) {
 static void free_all(pml_ctx* ctx) {
     drop_graph(ctx->bu_graph[0]);
     drop_graph(ctx->bu_graph[1]);
+    drop_graph(ctx->bu_graph_few);
     drop_graph(ctx->td_graph);
     drop_graph(ctx->mp_graph);
     drop_graph(ctx->bt_graph);
@@ -369,7 +374,7 @@ static int grid_for(const pml_ctx* ctx, int n_units, int units_per_block, int C,
 // functions and lane shapes as the level kernels: identical bits.
 static bool single_launch_sweeps(const pml_ctx* c) {
     const int many = (int)c->tune.get(T_SMALL_MANY_NODES, 16384);
-    return c->small || (c->C >= 64 && c->N <= many && c->levels_fit_workgroup);
+    return c->small || (c->sched_cols >= 64 && c->N <= many && c->levels_fit_workgroup);
 }
 
 // The subtree-block schedule pays where a sweep is a chain of latency-bound launches; once the levels carry enough work
@@ -383,8 +388,8 @@ static bool block_schedule(const pml_ctx* c) {
     // (pml_tree_upload): over scripts/schedule_sweep.py's grid the blocks never lose -- profiles/r03c_schedule_sweep.txt.
     // PASTML_HIP_BLOCK_MAX_STEPS is kept as a switch.)
     const long long steps = c->tune.get(T_BLOCK_MAX_STEPS, 1ll << 40);
-    return c->blocks.ok && !c->bu_offsets_f.empty() && (long long)c->bu_offsets_f.back() * c->C <= limit &&
-           c->blocks.steps * c->C <= steps;
+    return c->blocks.ok && !c->bu_offsets_f.empty() && (long long)c->bu_offsets_f.back() * c->sched_cols <= limit &&
+           c->blocks.steps * c->sched_cols <= steps;
 }
 
 static PmlTree tree_of(const pml_ctx* c, bool fused = false) {
@@ -681,7 +686,7 @@ static void launch_small_f81(pml_ctx* ctx, bool bottom_up, int do_prep, const Pm
         // The completion word (bu_f81_small_kernel, wait_bottom_up) for sweeps of few columns, where the host's wait is
         // a tenth of the sweep (HIV1C tree, k = 12: 14 columns 0.1265 -> 0.1127 ms per sweep; at 128 columns the
         // system-scope fences in 128 workgroups cost what the spin saves: 0.203 against 0.207 ms)
-        const bool signal = ctx->C <= 64 && !ctx->tune.on(T_NO_SPIN_WAIT);
+        const bool signal = ctx->sched_cols <= 64 && !ctx->tune.on(T_NO_SPIN_WAIT);
         hipLaunchKernelGGL((bu_f81_small_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, ctx->d_mu, ctx->d_sf,
                            ctx->d_tau, ctx->d_tauf, do_prep, units, d_offsets, n_levels, ctx->h_loglik, ctx->h_err,
                            reset_err, signal ? ctx->d_done : nullptr, signal ? ctx->h_done : nullptr);
@@ -723,7 +728,7 @@ static void launch_blocks_f81(pml_ctx* ctx, bool bottom_up) {
     }
     const int forced = (int)ctx->tune.get(T_BLOCK_THREADS, 0);
     int threads = PML_SMALL_BLOCK;
-    const long long n_wg = (long long)B.n_blocks * ctx->C;
+    const long long n_wg = (long long)B.n_blocks * (bottom_up ? ctx->sched_cols : ctx->C);  // (the workgroups that work)
     while (threads > 64 && n_wg * (threads / 64) > (long long)n_cus * wpc) threads /= 2;
     if (forced >= 64 && forced <= PML_SMALL_BLOCK) threads = forced;
     dim3 grid(B.n_blocks, ctx->C), block(threads);
@@ -1330,6 +1335,9 @@ int pml_ctx_set_option(pml_ctx* ctx, int option, int value) {
         if ((value != 0) != ctx->eig_fused_opt) {
             drop_graph(ctx->bu_graph[0]);
             drop_graph(ctx->bu_graph[1]);
+        drop_graph(ctx->bu_graph_few);
+            drop_graph(ctx->bu_graph_few);
+    drop_graph(ctx->bu_graph_few);
             drop_graph(ctx->td_graph);
             drop_graph(ctx->mp_graph);
             ctx->prep_dirty = true;
@@ -1373,6 +1381,8 @@ int pml_ctx_set_tunable(pml_ctx* ctx, const char* name, int64_t value, int is_se
         // a captured launch sequence was made under the old setting
         drop_graph(ctx->bu_graph[0]);
         drop_graph(ctx->bu_graph[1]);
+        drop_graph(ctx->bu_graph_few);
+    drop_graph(ctx->bu_graph_few);
         drop_graph(ctx->td_graph);
         drop_graph(ctx->mp_graph);
         drop_graph(ctx->bt_graph);
@@ -2438,6 +2448,7 @@ int pml_chars_alloc(pml_ctx* ctx, int32_t n_cols, int32_t k) {
     ctx->d_kappa = ctx->d_mu + n_cols;
     ctx->d_active = ctx->d_kappa + n_cols;
     ctx->active_partial = false;
+    ctx->n_active = ctx->sched_cols = n_cols;
     PML_TRY(dev_alloc(ctx, &ctx->d_err, n_cols));
     HIP_TRY(hipHostMalloc((void**)&ctx->h_loglik, sizeof(double) * n_cols));
     HIP_TRY(hipHostMalloc((void**)&ctx->h_err, sizeof(u64) * n_cols));
@@ -2599,6 +2610,8 @@ static int set_common(pml_ctx* ctx, int kind, int cb, int ce, const double* pi, 
         if (cb != 0 || ce != ctx->C) return fail(PML_ERR_INVALID, "all columns of a ctx must use one model kind");
         drop_graph(ctx->bu_graph[0]);
         drop_graph(ctx->bu_graph[1]);
+        drop_graph(ctx->bu_graph_few);
+    drop_graph(ctx->bu_graph_few);
         drop_graph(ctx->td_graph);
         drop_graph(ctx->mp_graph);
     }
@@ -2897,7 +2910,7 @@ static int enqueue_bottom_up(pml_ctx* ctx, int is_marginal, bool small_path, boo
         const pml_ctx::BlockSchedule& B = ctx->blocks;
         PML_TRY(dispatch_blocks_f81(ctx, true));
         const int nl = (int)B.top_bu_offsets.size() - 1;
-        const int tail = narrow_levels(ctx, B.top_bu_offsets, nl, false, ctx->C);
+        const int tail = narrow_levels(ctx, B.top_bu_offsets, nl, false, ctx->sched_cols);
         for (int l = 0; l < nl - tail; ++l) {
             const int a = B.top_bu_offsets[l], b = B.top_bu_offsets[l + 1];
             ctx->units_override = B.d_top_bu_units + a;
@@ -2918,7 +2931,7 @@ static int enqueue_bottom_up(pml_ctx* ctx, int is_marginal, bool small_path, boo
         PML_TRY(prof_end(ctx, 4, U.n > 0 ? 1 : 0));
         PML_TRY(prof_begin(ctx));
         const int nl = (int)U.bu_offsets_r.size() - 1;
-        int tail = narrow_levels(ctx, U.bu_offsets_r, nl, false, ctx->C);
+        int tail = narrow_levels(ctx, U.bu_offsets_r, nl, false, ctx->sched_cols);
         // (the narrow end's single launch walks the rest lists only: it starts above the last level with stacked units)
         for (int l = nl - 1; l >= 0 && U.n_stack > 0; --l)
             if (U.stack_bu_offsets[l + 1] > U.stack_bu_offsets[l]) {
@@ -2960,7 +2973,7 @@ static int enqueue_bottom_up(pml_ctx* ctx, int is_marginal, bool small_path, boo
         }
     } else if (fused) {
         const int nl = (int)ctx->bu_offsets_f.size() - 1;
-        const int tail = narrow_levels(ctx, ctx->bu_offsets_f, nl, false, ctx->C);
+        const int tail = narrow_levels(ctx, ctx->bu_offsets_f, nl, false, ctx->sched_cols);
         for (int l = 0; l < nl - tail; ++l) {
             const int a = ctx->bu_offsets_f[l], b = ctx->bu_offsets_f[l + 1];
             PML_TRY(dispatch_sweep(ctx, ctx->bu_level_vec_f[l] ? SW_BU_MARG_FUSED : SW_BU_MARG_FUSED_NOVEC,
@@ -3118,15 +3131,21 @@ static int run_captured(pml_ctx* ctx, pml_ctx::GraphSlot& slot, const std::funct
 static void set_active_columns(pml_ctx* ctx, const uint8_t* active) {
     if (!ctx->h_params) return;
     double* flags = ctx->h_params + (size_t)ctx->C * (ctx->ks + 5);
-    if (active == nullptr && !ctx->active_partial) return;  // (all ones already)
+    if (active == nullptr && !ctx->active_partial) {  // (all ones already)
+        ctx->n_active = ctx->C;
+        return;
+    }
     bool partial = false, changed = false;
+    int n = 0;
     for (int i = 0; i < ctx->C; ++i) {
         const double v = (active == nullptr || active[i]) ? 1.0 : 0.0;
         changed = changed || flags[i] != v;
         partial = partial || v == 0.0;
+        n += v != 0.0;
         flags[i] = v;
     }
     ctx->active_partial = partial;
+    ctx->n_active = n;
     if (changed) ctx->params_dirty = true;
 }
 
@@ -3136,6 +3155,16 @@ static int submit_bottom_up(pml_ctx* ctx, int is_marginal, const uint8_t* active
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         ctx->wait_signal = false;
     }
+    // A sweep of a few columns of a context of many is scheduled as a context of few would be (the workgroups of the
+    // other columns return at once): subtree blocks instead of one workgroup per column walking every level, the
+    // completion word -- HIV1C tree, 6 of 246 binary columns: 0.15 -> 0.10 ms per sweep.  Two schedules, two captured
+    // sequences: all the columns' (sched_cols = C) and a few columns' (sched_cols = 32).
+    const bool few = ctx->active_partial && ctx->n_active <= 32 && ctx->C > 32 && is_marginal && ctx->kind == PML_MODEL_F81;
+    struct Sched {
+        pml_ctx* c;
+        Sched(pml_ctx* x, int cols) : c(x) { c->sched_cols = cols; }
+        ~Sched() { c->sched_cols = c->C; }
+    } sched(ctx, few ? 32 : ctx->C);
     const bool small_path = single_launch_sweeps(ctx) && is_marginal && ctx->kind == PML_MODEL_F81;
     const size_t CN = (size_t)ctx->C * ctx->N;
     if (!is_marginal && !ctx->d_J) {
@@ -3160,11 +3189,12 @@ static int submit_bottom_up(pml_ctx* ctx, int is_marginal, const uint8_t* active
     const u64 generation_before = ctx->h_done ? *reinterpret_cast<volatile u64*>(ctx->h_done) : 0;  // (the stream is idle)
     if (ctx->graphs && !ctx->profile && n_launches >= 4) {  // (the block schedule's few launches replay as a graph too)
         const int slot = is_marginal ? 1 : 0;
-        const bool replay = ctx->bu_graph[slot].exec != nullptr;
-        PML_TRY(run_captured(ctx, ctx->bu_graph[slot],
-                             [&]() { return enqueue_bottom_up(ctx, is_marginal, small_path, true); }));
-        if (!replay) ctx->bu_signals[slot] = ctx->enqueue_signals;  // (a replay runs what was captured)
-        ctx->wait_signal = ctx->bu_signals[slot];
+        pml_ctx::GraphSlot& graph = few ? ctx->bu_graph_few : ctx->bu_graph[slot];
+        bool& signals = few ? ctx->bu_signals_few : ctx->bu_signals[slot];
+        const bool replay = graph.exec != nullptr;
+        PML_TRY(run_captured(ctx, graph, [&]() { return enqueue_bottom_up(ctx, is_marginal, small_path, true); }));
+        if (!replay) signals = ctx->enqueue_signals;  // (a replay runs what was captured)
+        ctx->wait_signal = signals;
     } else {
         // (inside the capture of a whole marginal pass the per-branch pass must be part of the graph)
         PML_TRY(enqueue_bottom_up(ctx, is_marginal, small_path, ctx->in_outer_capture));
