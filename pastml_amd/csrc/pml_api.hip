@@ -3159,7 +3159,12 @@ static int submit_bottom_up(pml_ctx* ctx, int is_marginal, const uint8_t* active
     // other columns return at once): subtree blocks instead of one workgroup per column walking every level, the
     // completion word -- HIV1C tree, 6 of 246 binary columns: 0.15 -> 0.10 ms per sweep.  Two schedules, two captured
     // sequences: all the columns' (sched_cols = C) and a few columns' (sched_cols = 32).
-    const bool few = ctx->active_partial && ctx->n_active <= 32 && ctx->C > 32 && is_marginal && ctx->kind == PML_MODEL_F81;
+    bool few = ctx->active_partial && ctx->n_active <= 32 && ctx->C > 32 && is_marginal && ctx->kind == PML_MODEL_F81;
+    if (few) {  // (only where the few-column schedule is the subtree blocks: never from one launch to one per level)
+        ctx->sched_cols = 32;
+        few = !single_launch_sweeps(ctx) && block_schedule(ctx);
+        ctx->sched_cols = ctx->C;
+    }
     struct Sched {
         pml_ctx* c;
         Sched(pml_ctx* x, int cols) : c(x) { c->sched_cols = cols; }
