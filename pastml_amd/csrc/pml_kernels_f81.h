@@ -1041,9 +1041,6 @@ __device__ __forceinline__ bool unit_is_lean(int packed) {
 // dispatches the common shapes: the unit's decoding, the loads and the branches of the other shapes fall away -- where a
 // level is a unit or two, the wave's instruction count is the level's time); PML_SHAPE_ANY: read from the descriptor.
 #define PML_SHAPE_ANY (-9)
-#ifndef PML_SPREAD_LEVELS
-#define PML_SPREAD_LEVELS 0
-#endif
 template <int G, int R, int SC0 = PML_SHAPE_ANY, int SC1 = PML_SHAPE_ANY>
 __device__ __forceinline__ bool bu_f81_unit_lean(const LaneCtx<G, R>& L, const PmlTree& t, const PmlCols& c,
                                                  const PmlState& st, const UnitRegs& u) {
@@ -2628,7 +2625,9 @@ __device__ __forceinline__ double column_loglik(const PmlTree& t, const PmlCols&
 // Walks the levels [0, nl) of a level table inside one workgroup (barrier between levels).  A level's units depend on
 // the previous level's results, its DESCRIPTORS do not: the descriptor a lane needs first in the next level (and that
 // level's bounds) are fetched before the current level is computed, which takes one round trip out of the dependent
-// chain descriptor -> gathered scalars -> vectors of every level.
+// chain descriptor -> gathered scalars -> vectors of every level.  The units run with SHAPES: a wave whose units all have
+// one of the common shapes takes that shape's variant of the lean unit (a level here is one wavefront's instruction
+// stream: profiles/r04h_thin_level_step_breakdown.txt).
 template <int G, int R, bool BU>
 __device__ __forceinline__ void walk_levels(const LaneCtx<G, R>& L, const PmlTree& t, const PmlCols& c, const PmlState& st,
                                             const PmlUnit* __restrict__ units, const int* __restrict__ lv, int nl) {
@@ -2636,36 +2635,28 @@ __device__ __forceinline__ void walk_levels(const LaneCtx<G, R>& L, const PmlTre
     const int wave = threadIdx.x >> 6;
     const int n_waves = blockDim.x >> 6;
     const int sub = (threadIdx.x & 63) / G;
+    const int first = wave * UW + sub;  // the unit of a level this lane's group takes first
     if (nl <= 0) return;
-    // The unit of a level this lane's group takes first.  A level of no more units than the workgroup has waves is spread
-    // over the waves, one unit each, instead of filling the first wave: a wave whose units all have one shape runs
-    // that shape's code only (bu_f81_unit, SHAPES).
-    auto first_of = [&](int n_level) { return PML_SPREAD_LEVELS && n_level <= n_waves ? (sub == 0 ? wave : n_level) : wave * UW + sub; };
     int a = lv[0], b = lv[1];
-    int first = first_of(b - a);
     UnitRegs nxt = load_unit<G>(units, first < b - a ? a + first : a, L.g);
     for (int l = 0; l < nl; ++l) {
         const int n_level = b - a;
         const UnitRegs cur = nxt;
-        const int cur_first = first;
         int a2 = a, b2 = a;
         if (l + 1 < nl) {
             a2 = lv[l + 1];
             b2 = lv[l + 2];
-            first = first_of(b2 - a2);
             nxt = load_unit<G>(units, first < b2 - a2 ? a2 + first : a2, L.g);
         }
-        if (cur_first < n_level) {
+        if (first < n_level) {
             if (BU) bu_f81_unit<G, R, false, true, true>(L, t, c, st, cur);
             else td_f81_unit<G, R, true, true>(L, t, c, st, cur);
         }
-        if (!PML_SPREAD_LEVELS || n_level > n_waves) {
-            for (int base = wave * UW + n_waves * UW; base < n_level; base += n_waves * UW) {
-                const int idx = base + sub;
-                if (idx < n_level) {
-                    if (BU) bu_f81_unit<G, R, false, true, true>(L, t, c, st, load_unit<G>(units, a + idx, L.g));
-                    else td_f81_unit<G, R, true, true>(L, t, c, st, load_unit<G>(units, a + idx, L.g));
-                }
+        for (int base = wave * UW + n_waves * UW; base < n_level; base += n_waves * UW) {
+            const int idx = base + sub;
+            if (idx < n_level) {
+                if (BU) bu_f81_unit<G, R, false, true, true>(L, t, c, st, load_unit<G>(units, a + idx, L.g));
+                else td_f81_unit<G, R, true, true>(L, t, c, st, load_unit<G>(units, a + idx, L.g));
             }
         }
         __syncthreads();
