@@ -863,6 +863,26 @@ def test_sweep_of_some_columns_leaves_the_others_alone(n_tips, cols, k):
     assert not np.array_equal(before, after)
 
 
+@pytest.mark.parametrize('kind,k,marginal', [('HKY', 4, True), ('EIG', 6, True), ('F81', 5, False)])
+def test_column_flags_are_ignored_where_no_kernel_reads_them(kind, k, marginal):
+    """pml_bottom_up_submit_columns outside the F81 marginal sweep (matrix / eigen models, the joint sweep): every column is
+    computed, as the header says."""
+    rng = np.random.default_rng(k)
+    flat = FlatForest.random(500, seed=k, max_arity=3, zero_frac=0.0, n_trees=1)
+    cols = 3
+    masks = np.stack([random_masks(flat, k, rng, internal=0.0) for _ in range(cols)])
+    first = [(random_spec(kind, k, rng), (float(rng.uniform(0.5, 3)), 0.0, 1.0)) for _ in range(cols)]
+    second = [(random_spec(kind, k, rng), (float(rng.uniform(0.5, 3)), 0.0, 1.0)) for _ in range(cols)]
+    with hip.Engine(flat, cols, k) as eng:
+        eng.set_masks(masks)
+        eng.set_models(first)
+        eng.bottom_up(marginal)
+        eng.set_models(second)
+        eng.bottom_up_submit(marginal, active=np.array([1, 0, 0], dtype=np.uint8))
+        flagged = eng.bottom_up_collect(marginal)
+        assert np.array_equal(flagged, eng.bottom_up(marginal))
+
+
 @pytest.mark.parametrize('n_tips,cols', [(300, 3), (6000, 2), (300, 70)])
 def test_completion_word_wait_returns_what_the_stream_wait_returns(n_tips, cols):
     """Short sweeps of few columns end in a kernel that raises a word in pinned memory, and the host spins on it instead of
