@@ -136,6 +136,11 @@ def cpu_baseline(k, levels, model, cores=None):
                           '(pool wall {:.1f} s); single thread on a {}-tip tree: {:.3g} units/s in {:.1f} s; host '
                           'reports {} cores'.format(cores, cores, res[0][2], res[0][1], k, work, wall, n_tips, single,
                                                     dt1, os.cpu_count()))
+    # BASELINE.md section 3 asks for 2 x cores characters at FULL tree size: the reference needs 359 s per character there
+    # (tests/golden/make_golden.py, 1 048 576 tips: 171 us per node against the ~40 us per node of this sample), so this
+    # bounded sample flatters the CPU by about 4x and the speed-up computed from it is a lower bound
+    out['sample'] += ('; NOT the full-size tree: the reference itself took 359 s per character at 1 048 576 tips '
+                      '(171 us/node, tests/golden/make_golden.py), so this sample overstates the CPU rate about fourfold')
     return out
 
 
@@ -437,9 +442,30 @@ def csrc_digest():
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+def run_cpu_baseline(args, levels, k, model):
+    """The CPU baseline of this run (None if switched off): called from a process that has not touched a GPU."""
+    if args.no_cpu_baseline or under_profiler():
+        return None
+    cl = args.cpu_baseline_levels
+    if cl is None:
+        cl = min(levels, 17 if k >= 32 else 16)  # 10-20 s of single-thread numpy on the GPU box
+    return cpu_baseline(k, cl, model, args.cpu_baseline_cores)
+
+
 def spawn_ranks(args):
-    """`python bench.py --gpus N` without a launcher: start the N rank processes (this process never touches a GPU)."""
+    """
+    `python bench.py --gpus N` without a launcher: start the N rank processes (this process never touches a GPU).  The CPU
+    baseline is timed HERE, once, before the ranks exist -- no rank competes with it for the host cores -- and handed to
+    rank 0 through a file (PASTML_BENCH_CPU_BASELINE), so the N > 1 line carries it like the N = 1 line does.
+    """
     import socket
+    levels, k, _ = WORKLOADS[args.workload]
+    cpu = run_cpu_baseline(args, levels, k, 'JC' if args.workload == 'cfg2' else 'F81')
+    cpu_path = None
+    if cpu is not None:
+        fd, cpu_path = tempfile.mkstemp(prefix='pastml_amd_cpu_baseline_', suffix='.json')
+        with os.fdopen(fd, 'w') as f:
+            json.dump(cpu, f)
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
     port = s.getsockname()[1]
@@ -451,6 +477,8 @@ def spawn_ranks(args):
         for r in range(args.gpus):
             env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR='127.0.0.1',
                        MASTER_PORT=str(port), PASTML_AMD_RDZV_DIR=rdzv, HSA_ENABLE_IPC_MODE_LEGACY='0')
+            if cpu_path is not None:
+                env['PASTML_BENCH_CPU_BASELINE'] = cpu_path
             procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                           stdout=out0 if r == 0 else subprocess.DEVNULL))
         # All ranks are watched: the first one to exit non-zero ends the job -- the others may be waiting for it inside a
@@ -487,10 +515,12 @@ def spawn_ranks(args):
     sys.stdout.flush()
     import shutil
     shutil.rmtree(rdzv, ignore_errors=True)
-    try:
-        os.remove(out_path)
-    except OSError:
-        pass
+    for path in (out_path, cpu_path):
+        try:
+            if path:
+                os.remove(path)
+        except OSError:
+            pass
     if failed is not None:
         return max(1, max(abs(c) for c in codes if c is not None) % 256 or 1)
     return 0
@@ -670,6 +700,49 @@ def secondary_measurements(device):
                                          frac_executed=flops_executed / (ms_sweep * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
                                          hbm_model_bytes=bytes_,
                                          hbm_frac=bytes_ / (ms_sweep * 1e-3) / 1e9 / HBM_PEAK_GBS))
+    # ---- the P(t) batch north_star names: P(t) = A diag(exp(d t')) A^-1 materialised for every branch (reference:
+    #      pastml/models/generator.py:54-65, CustomRatesModel.py:70-79), on cfg3's shape (JTT, k = 20) and on k = 32.  The
+    #      kernel's own time by HIP events (profile slot 2); bytes out = 8 k ks per branch ("P(t) kernel on its
+    #      own: 8 B in, 8 k^2 B out"), which a write stream cannot push beyond ~0.70 of the HBM peak
+    #      (profiles/r02g_write_stream_ceiling.txt)
+    flat = synthetic.balanced_forest(18)
+    pij = {}
+    rng = np.random.default_rng(11)
+    for name, k in (('jtt_k20', 20), ('custom_k32', 32)):
+        if k == 20:
+            pi_, (d_, A_, Ainv_) = JTT_FREQUENCIES, get_diagonalisation(JTT_FREQUENCIES, JTT_RATE_MATRIX)
+        else:
+            pi_ = rng.dirichlet(np.ones(k) * 4)
+            r_ = np.triu(rng.uniform(0.1, 2.0, size=(k, k)), 1)
+            d_, A_, Ainv_ = get_diagonalisation(pi_, r_ + r_.T)
+        spec = dict(kind=2, pi=pi_, d=d_, A=A_, Ainv=Ainv_)
+        with hip.Engine(flat, 1, k, device=device) as eng:
+            reps = 20
+            eng.set_models([(spec, (1.0, 0.0, 1.0))])
+            eng.pij_batch()
+            eng.sync()
+            eng.profile_enable(True)
+            eng.profile_read(2, reset=True)
+            for _ in range(reps):
+                eng.set_models([(spec, (1.0, 0.0, 1.0))])   # (marks the batch stale: the next call recomputes it)
+                eng.pij_batch()
+            eng.sync()
+            ms_total, launches = eng.profile_read(2, reset=True)
+            eng.profile_enable(False)
+            ms = ms_total / max(1, launches)
+            ks = 4 * ((k + 3) // 4)
+            bytes_out = flat.n_nodes * 8.0 * k * ks
+            flops = 2.0 * k ** 3 * flat.n_nodes
+            pij[name] = dict(k=k, branches=flat.n_nodes - 1, launches=int(launches), ms_per_batch=ms,
+                             kernel='pij_eigen_mfma_kernel (v_mfma_f64_16x16x4_f64; one launch per batch)',
+                             value=flat.n_nodes / (ms * 1e-3), unit='branch/s',
+                             roofline=dict(bound='hbm', bytes_per_branch=8 * k * ks, model_bytes=bytes_out,
+                                           achieved=bytes_out / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit='GB/s',
+                                           frac=bytes_out / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                           mfma_tflops=flops / (ms * 1e-3) / 1e12,
+                                           mfma_frac=flops / (ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS))
+    out['pij_batch'] = dict(workload='P(t) of every branch of a balanced 262 144-tip tree ({} nodes) for one column, eigen '
+                                     'models: pml_pij_batch, results left in HBM'.format(flat.n_nodes), **pij)
     # ---- cfg5-shaped optimiser gradient: real HIV1C tree (3 619 tips), Loc (k = 12): the 14 likelihoods of one
     #      L-BFGS-B gradient (13 free parameters + the point itself) in one batched bottom-up sweep
     nwk = os.path.join(REPO, 'tests', 'golden', 'data', 'hiv1c', 'pastml_phyml_tree.nwk')
@@ -803,12 +876,18 @@ def main():
 
     # CPU baseline first, while this process has not touched the GPU yet (its worker processes are started from a
     # process without a GPU context); never under a profiler, whose preloaded library has already initialised the GPU
+    # N > 1: bench.py's own parent has timed it already (spawn_ranks) and says where; under a launcher of somebody else's
+    # (torch.distributed.run) rank 0 times it now, before it touches its GPU, while the other ranks build their engines and
+    # then wait for it at the communicator's rendezvous (whose time limit is raised for that).
     cpu = None
-    if not args.no_cpu_baseline and world == 1 and not profiled:
-        cl = args.cpu_baseline_levels
-        if cl is None:
-            cl = min(levels, 17 if k >= 32 else 16)  # 10-20 s of single-thread numpy on the GPU box
-        cpu = cpu_baseline(k, cl, model, args.cpu_baseline_cores)
+    handed = os.environ.get('PASTML_BENCH_CPU_BASELINE')
+    if rank == 0 and handed and os.path.exists(handed):
+        with open(handed) as f:
+            cpu = json.load(f)
+    elif rank == 0:
+        cpu = run_cpu_baseline(args, levels, k, model)
+    if world > 1:
+        os.environ.setdefault('PASTML_AMD_RDZV_TIMEOUT', '900')
 
     from pastml_amd import hip, synthetic, sharding
 
@@ -870,6 +949,9 @@ def main():
     prep_ms, prep_launches = eng.profile_read(2)
     td2_ms, td2_launches = eng.profile_read(3)
     bu2_ms, bu2_launches = eng.profile_read(4)
+    if world > 1:   # the roofline of an N > 1 line is the slowest rank's: every rank runs the same launches on its own shard
+        bul_ms, tdl_ms, prep_ms, td2_ms, bu2_ms = (float(v) for v in
+                                                   comm.allreduce([bul_ms, tdl_ms, prep_ms, td2_ms, bu2_ms], op='max'))
     bu_ms, bu_launches = bul_ms + bu2_ms, bul_launches + bu2_launches
     td_ms, td_launches = tdl_ms + td2_ms, tdl_launches + td2_launches
     eng.profile_enable(False)
@@ -910,12 +992,13 @@ def main():
         dom_gbs = rate(dom['model'], dom['ms'])
         # HBM bytes per launch from the committed PMC passes: only if they were measured on these kernel sources and
         # this workload shape; bench asserts that counters and model agree
-        traffic = traffic_note = None
+        traffic = traffic_note = traffic_stamp = None
         tpath = os.path.join(REPO, 'profiles', 'traffic.json')
         if os.path.exists(tpath) and dom['launches'] > 0:
             try:
                 tj = json.load(open(tpath))
                 entry = tj.get(args.workload, {})
+                traffic_stamp = entry.get('csrc_sha')
                 if entry.get('csrc_sha') != csrc_digest():
                     traffic_note = 'profiles/traffic.json was measured on other kernel sources ({} != {})'.format(
                         entry.get('csrc_sha'), csrc_digest())
@@ -1003,12 +1086,16 @@ def main():
             'prep_gbs': prep_gbs,
             'device_memory_gb': held / 1e9,
             'validation': validation,
+            # which sources the library that ran was compiled from (pml_build_digest) next to what the tree holds now and
+            # the stamp of the committed HBM counters
+            'library': {'build_digest': hip.build_digest(), 'source_digest': library_source_digest(),
+                        'traffic_stamp': traffic_stamp, 'kernel_sources_digest': csrc_digest()},
         }
         if cpu is not None:
             out['cpu_baseline'] = cpu
             out['speedup_vs_cpu_baseline'] = value / cpu['value']
             out['speedup_vs_cpu_baseline_single_core'] = value / cpu['single_core_value']
-        elif profiled and world == 1 and not args.no_cpu_baseline:
+        elif profiled and not args.no_cpu_baseline:
             out['cpu_baseline'] = None
             out['cpu_baseline_note'] = 'skipped: a profiler is attached (no worker processes from a GPU-initialised process)'
     any_failure = float(comm.allreduce([1.0 if failure else 0.0], op='max')[0]) > 0

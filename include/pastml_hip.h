@@ -56,6 +56,10 @@ enum {
 
 const char* pml_last_error(void);
 int pml_version(void);
+/* first 16 hex digits of the sha256 over the sources (everything under pastml_amd/csrc and this header) the library was compiled from --
+ * pastml_amd/build.py hands it to the compiler and rebuilds when the sources in the tree give another one;
+ * "unknown" for a build made by hand without -DPML_BUILD_DIGEST */
+const char* pml_build_digest(void);
 int pml_device_count(int* count);
 
 /* ---- context ------------------------------------------------------------------------------------------------- */

@@ -5,10 +5,9 @@ Only the path named in BASELINE.json's north_star is implemented: per-branch P(t
 likelihood sweeps of ``pastml/ml.py``, behind PastML's own Python API (``acr()`` / ``ml_acr()``).
 
 The constants and helpers below are the part of the reference's ``pastml/__init__.py`` that belongs to the
-boundary (result-dict keys ``pastml/__init__.py:6-15``, feature naming ``:69-78``, ``value2list`` ``:81-94``).
+boundary (result-dict keys ``pastml/__init__.py:6-15``, feature naming ``:69-78``, ``value2list`` ``:81-94``); the reference's
+logger set-up is not on the path: modules ask for ``logging.getLogger('pastml')`` themselves.
 """
-import logging
-
 PASTML_VERSION = '1.9.50'
 
 METHOD = 'method'
@@ -29,25 +28,12 @@ def get_personalized_feature_name(character, feature):
 
 
 def value2list(n, value, default_value):
-    """Broadcasts a per-column setting to n columns (reference: pastml/__init__.py:81-94)."""
-    if value is None:
-        value = default_value
-    if not isinstance(value, list):
-        value = [value] * n
-    elif len(value) == 1:
-        value = value * n
-    else:
-        value += [default_value] * (n - len(value))
-    return value
-
-
-def _set_up_pastml_logger(verbose):
-    logger = logging.getLogger('pastml')
-    logger.setLevel(level=logging.DEBUG if verbose else logging.ERROR)
-    logger.propagate = False
-    if not logger.hasHandlers():
-        ch = logging.StreamHandler()
-        formatter = logging.Formatter('%(name)s:%(levelname)s:%(asctime)s %(message)s', datefmt="%H:%M:%S")
-        ch.setFormatter(formatter)
-        logger.addHandler(ch)
-    return logger
+    """
+    A per-column setting of ``acr()`` as a list of n entries (same results as the reference's helper,
+    pastml/__init__.py:81-94): a scalar or a one-element list is repeated, ``None`` stands for the default, a shorter list
+    is completed with the default.  The caller's list is never modified.
+    """
+    given = [] if value is None else (list(value) if isinstance(value, list) else [value])
+    if len(given) <= 1:
+        return (given or [default_value]) * n
+    return given + [default_value] * max(0, n - len(given))

@@ -35,6 +35,8 @@ from pastml_amd.models.JCModel import JCModel, JC
 from pastml_amd.models.JTTModel import JTTModel, JTT, JTT_STATES
 from pastml_amd.tree import TreeNode, get_flat_forest, AnnotationColumn
 
+MAX_STATES = 256   # = pastml_amd.hip.MAX_STATES = PML_MAX_STATES of include/pastml_hip.h (tests/test_host_logic.py checks)
+
 model2class = {F81: F81Model, JC: JCModel, CUSTOM_RATES: CustomRatesModel, HKY: HKYModel, JTT: JTTModel, EFT: EFTModel}
 
 from pastml_amd.parsimony import is_parsimonious, parsimonious_acr, MP_METHODS, ACCTRAN, DELTRAN, DOWNPASS, MP  # noqa: E402,F401
@@ -240,6 +242,14 @@ def acr(forest, df=None, columns=None, column2states=None, prediction_method=MPP
         if is_ml(method):
             if model_name not in model2class:
                 raise ValueError('Model {} is unknown, should be one of {}'.format(model_name, ', '.join(model2class)))
+            # A boundary difference to the reference, which has no bound on k (int64 arg-max tables, pastml/ml.py:134; its
+            # pipeline only drops columns whose values are mostly unique, acr.py:774): the device path keeps arg-max tables
+            # in bytes and state masks in four words -- pml_chars_alloc answers PML_ERR_UNSUPPORTED beyond 256 states.  Said
+            # here, before any work is done, by name ("Limits").
+            if len(states) > MAX_STATES:
+                raise ValueError('Character {} has {} states: the MI355X likelihood path supports at most {} states per '
+                                 'character (PML_ERR_UNSUPPORTED); reconstruct it with a parsimonious method or merge rare '
+                                 'states.'.format(character, len(states), MAX_STATES))
             if model_name in (HKY, JTT):
                 alphabet = HKY_STATES if HKY == model_name else JTT_STATES
                 if not set(states) & set(alphabet):

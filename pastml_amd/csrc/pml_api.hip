@@ -21,7 +21,14 @@
 #include "pml_kernels_counts.h"
 #include "pml_comm.h"
 
-#define PML_VERSION 100
+#define PML_VERSION 101
+
+// sha256 (first 16 hex digits) over the sources this library was compiled from, handed in by pastml_amd/build.py; the
+// marker in front lets build.py read it out of the file without loading it
+#ifndef PML_BUILD_DIGEST
+#define PML_BUILD_DIGEST "unknown"
+#endif
+static const char kBuildDigest[] = "PML_BUILD_DIGEST=" PML_BUILD_DIGEST;
 
 static thread_local std::string g_last_error;
 
@@ -63,7 +70,8 @@ static int fail(int code, const char* fmt, ...) {
     X(NO_EIGJ_TIERS, 1, 1) X(NO_BT_TIERS, 1, 1) X(NO_SHAPE_SORT, 1, 1) X(NO_SUPER, 1, 1) X(SUPER_MIN, 0, 1)            \
     X(STACK_MIN, 0, 1) X(NO_STACK, 1, 1) X(DEBUG, 1, 0) X(BLOCK_NODES, 0, 1) X(BLOCK_MAX_STORED, 0, 1)                 \
     X(BLOCK_HEIGHT_CAP, 0, 1) X(SMALL_MAX_NODES, 0, 1) X(F81_R, 0, 1) X(F81_TD_R, 0, 1) X(NO_GRAPH, 1, 1)              \
-    X(NARROW_UNITS, 0, 0) X(NO_EIGG_TIERS, 1, 0) X(NO_ABSORB, 1, 1) X(ABSORB_MIN, 0, 1) X(NO_SPIN_WAIT, 1, 0)
+    X(NARROW_UNITS, 0, 0) X(NO_EIGG_TIERS, 1, 0) X(NO_ABSORB, 1, 1) X(ABSORB_MIN, 0, 1) X(NO_SPIN_WAIT, 1, 0)   \
+    X(SPLIT_PARTS, 0, 0)
 enum PmlTunable {
 #define X(name, flag, tree) T_##name,
     PML_TUNABLES(X)
@@ -293,6 +301,12 @@ struct pml_ctx {
     const PmlUnit* units_override = nullptr;  // set around a dispatch_sweep on the block schedule's top lists
 
     PmlComm* comm = nullptr;   // RCCL communicator attached by pml_comm_init (survives tree uploads)
+
+    // marginal pass of a large forest in parts of its columns on two streams (split_marginal_pass): the second stream, the
+    // events that chain the parts, and the flag that says the launches being enqueued see a window of the columns
+    hipStream_t stream2 = nullptr;
+    std::vector<hipEvent_t> split_ev;
+    bool windowed = false;
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -317,12 +331,17 @@ static void drop_graph(pml_ctx::GraphSlot& g) {
     g.graph = nullptr;
 }
 
-static void free_all(pml_ctx* ctx) {
+// every captured launch sequence of the two sweeps (the back-trace's graph depends on the tree and the tunables only)
+static void drop_sweep_graphs(pml_ctx* ctx) {
     drop_graph(ctx->bu_graph[0]);
     drop_graph(ctx->bu_graph[1]);
     drop_graph(ctx->bu_graph_few);
     drop_graph(ctx->td_graph);
     drop_graph(ctx->mp_graph);
+}
+
+static void free_all(pml_ctx* ctx) {
+    drop_sweep_graphs(ctx);
     drop_graph(ctx->bt_graph);
     if (ctx->h_loglik) (void)hipHostFree(ctx->h_loglik);
     if (ctx->h_err) (void)hipHostFree(ctx->h_err);
@@ -480,9 +499,9 @@ static int prof_event(pml_ctx* ctx, hipEvent_t* out) {
 static int prof_drain(pml_ctx* ctx) {
     if (ctx->prof_pending.empty()) return PML_OK;
     HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipEventSynchronize(ctx->prof_pending.back().b));
     for (const pml_ctx::ProfBracket& br : ctx->prof_pending) {
         float ms = 0.f;
+        HIP_TRY(hipEventSynchronize(br.b));  // (the brackets of a split pass lie on two streams)
         HIP_TRY(hipEventElapsedTime(&ms, br.a, br.b));
         ctx->prof_ms[br.which] += ms;
         ctx->prof_launches[br.which] += br.launches;
@@ -686,14 +705,14 @@ static void launch_small_f81(pml_ctx* ctx, bool bottom_up, int do_prep, const Pm
         // The completion word (bu_f81_small_kernel, wait_bottom_up) for sweeps of few columns, where the host's wait is
         // a tenth of the sweep (HIV1C tree, k = 12: 14 columns 0.1265 -> 0.1127 ms per sweep; at 128 columns the
         // system-scope fences in 128 workgroups cost what the spin saves: 0.203 against 0.207 ms)
-        const bool signal = ctx->sched_cols <= 64 && !ctx->tune.on(T_NO_SPIN_WAIT);
+        const bool signal = ctx->sched_cols <= 64 && !ctx->windowed && !ctx->tune.on(T_NO_SPIN_WAIT);
         hipLaunchKernelGGL((bu_f81_small_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, ctx->d_mu, ctx->d_sf,
                            ctx->d_tau, ctx->d_tauf, do_prep, units, d_offsets, n_levels, ctx->h_loglik, ctx->h_err,
                            reset_err, signal ? ctx->d_done : nullptr, signal ? ctx->h_done : nullptr);
         ctx->enqueue_signals = signal;  // (the last launch of a bottom-up sweep whenever it is part of one)
         if (signal) ++ctx->signals_enqueued;
     } else {
-        const bool signal = ctx->signal_next_td && ctx->C <= 64 && !ctx->tune.on(T_NO_SPIN_WAIT);
+        const bool signal = ctx->signal_next_td && ctx->C <= 64 && !ctx->windowed && !ctx->tune.on(T_NO_SPIN_WAIT);
         ctx->signal_next_td = false;
         hipLaunchKernelGGL((td_f81_small_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, units, d_offsets,
                            n_levels, signal ? ctx->d_done : nullptr, signal ? ctx->h_done : nullptr);
@@ -736,7 +755,7 @@ static void launch_blocks_f81(pml_ctx* ctx, bool bottom_up) {
         hipLaunchKernelGGL((bu_f81_blocks_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, B.d_bu_units, B.d_bu_start,
                            B.d_bu_levels, B.d_bu_lv);
     else {
-        const bool signal = ctx->signal_next_td && ctx->C <= 64 && !ctx->tune.on(T_NO_SPIN_WAIT);
+        const bool signal = ctx->signal_next_td && ctx->C <= 64 && !ctx->windowed && !ctx->tune.on(T_NO_SPIN_WAIT);
         ctx->signal_next_td = false;
         hipLaunchKernelGGL((td_f81_blocks_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, B.d_td_units, B.d_td_start,
                            B.d_td_levels, B.d_td_lv, signal ? ctx->d_done : nullptr, signal ? ctx->h_done : nullptr);
@@ -1256,6 +1275,8 @@ const char* pml_last_error(void) { return g_last_error.c_str(); }
 
 int pml_version(void) { return PML_VERSION; }
 
+const char* pml_build_digest(void) { return kBuildDigest + sizeof("PML_BUILD_DIGEST=") - 1; }
+
 int pml_device_count(int* count) {
     if (!count) return fail(PML_ERR_INVALID, "count is NULL");
     HIP_TRY(hipGetDeviceCount(count));
@@ -1311,6 +1332,8 @@ int pml_ctx_destroy(pml_ctx* ctx) {
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     prof_release(ctx);
+    for (hipEvent_t e : ctx->split_ev) (void)hipEventDestroy(e);
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return PML_OK;
@@ -1333,13 +1356,7 @@ int pml_ctx_set_option(pml_ctx* ctx, int option, int value) {
     }
     if (option == PML_OPT_EIGEN_FUSED) {
         if ((value != 0) != ctx->eig_fused_opt) {
-            drop_graph(ctx->bu_graph[0]);
-            drop_graph(ctx->bu_graph[1]);
-        drop_graph(ctx->bu_graph_few);
-            drop_graph(ctx->bu_graph_few);
-    drop_graph(ctx->bu_graph_few);
-            drop_graph(ctx->td_graph);
-            drop_graph(ctx->mp_graph);
+            drop_sweep_graphs(ctx);
             ctx->prep_dirty = true;
             ctx->bu_mode = -1;
             ctx->td_valid = ctx->js_valid = false;
@@ -1379,12 +1396,7 @@ int pml_ctx_set_tunable(pml_ctx* ctx, const char* name, int64_t value, int is_se
         ctx->tune.has[i] = on;
         ctx->tune.val[i] = on ? (long long)value : 0;
         // a captured launch sequence was made under the old setting
-        drop_graph(ctx->bu_graph[0]);
-        drop_graph(ctx->bu_graph[1]);
-        drop_graph(ctx->bu_graph_few);
-    drop_graph(ctx->bu_graph_few);
-        drop_graph(ctx->td_graph);
-        drop_graph(ctx->mp_graph);
+        drop_sweep_graphs(ctx);
         drop_graph(ctx->bt_graph);
         ctx->prep_dirty = true;
         ctx->bu_mode = -1;
@@ -1526,7 +1538,12 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
                implicit_tips = ctx->implicit_tips;
     PmlComm* comm = ctx->comm;
     const PmlTune tune = ctx->tune;
+    hipStream_t stream2 = ctx->stream2;
+    std::vector<hipEvent_t> split_ev;
+    split_ev.swap(ctx->split_ev);
     *ctx = pml_ctx();
+    ctx->stream2 = stream2;
+    ctx->split_ev.swap(split_ev);
     ctx->tune = tune;
     ctx->fuse = fuse;
     ctx->keep_td = keep_td;
@@ -2608,12 +2625,7 @@ static int set_common(pml_ctx* ctx, int kind, int cb, int ce, const double* pi, 
     if (ctx->kind != -1 && ctx->kind != kind) {
         // one model kind per ctx; setting ALL columns at once may change it (a pooled ctx serving the next analysis)
         if (cb != 0 || ce != ctx->C) return fail(PML_ERR_INVALID, "all columns of a ctx must use one model kind");
-        drop_graph(ctx->bu_graph[0]);
-        drop_graph(ctx->bu_graph[1]);
-        drop_graph(ctx->bu_graph_few);
-    drop_graph(ctx->bu_graph_few);
-        drop_graph(ctx->td_graph);
-        drop_graph(ctx->mp_graph);
+        drop_sweep_graphs(ctx);
     }
     if (kind == PML_MODEL_HKY && ctx->k != 4) return fail(PML_ERR_INVALID, "HKY needs k = 4");
     const int nc = ce - cb;
@@ -3094,7 +3106,7 @@ static int enqueue_bottom_up(pml_ctx* ctx, int is_marginal, bool small_path, boo
 
 // Captures fn's stream work once and replays it afterwards; falls back to direct submission if capture fails.
 static int run_captured(pml_ctx* ctx, pml_ctx::GraphSlot& slot, const std::function<int()>& enqueue) {
-    if (ctx->in_outer_capture) return enqueue();  // part of a larger capture (pml_marginal_pass)
+    if (ctx->in_outer_capture || ctx->windowed) return enqueue();  // part of a larger capture / of a split pass
     if (slot.exec && slot.has_init != ctx->has_init) drop_graph(slot);
     if (!slot.exec) {
         HIP_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
@@ -3210,7 +3222,10 @@ static int submit_bottom_up(pml_ctx* ctx, int is_marginal, const uint8_t* active
     // the fused eigen sweeps build P(t) in registers, the two-GEMM sweeps never form it: no batch ran
     if (!no_p) ctx->prep_dirty = false;
     ctx->bu_fused = (is_marginal && ctx->kind == PML_MODEL_F81 && ctx->n_cherries > 0) || ctx->bu_fused_joint;
-    ctx->bu_absorbed = is_marginal && ctx->kind == PML_MODEL_F81 && !small_path && super_sweeps(ctx);
+    // (a sweep of some of the columns says nothing about the others: where an earlier sweep of the level schedule left the
+    // children of their two-level units out of memory they still are -- rebuilding rows that are in memory is harmless)
+    ctx->bu_absorbed = (is_marginal && ctx->kind == PML_MODEL_F81 && !small_path && super_sweeps(ctx)) ||
+                       (ctx->active_partial && ctx->bu_absorbed);
     return PML_OK;
 }
 
@@ -3221,10 +3236,11 @@ static int submit_bottom_up(pml_ctx* ctx, int is_marginal, const uint8_t* active
 static int wait_bottom_up(pml_ctx* ctx) {
     if (ctx->wait_signal && ctx->h_done) {
         ctx->wait_signal = false;
-        const volatile u64* flag = reinterpret_cast<volatile u64*>(ctx->h_done);
+        const u64* flag = ctx->h_done;
         const auto t0 = std::chrono::steady_clock::now();
         for (unsigned spins = 0;; ++spins) {
-            if (*flag >= ctx->done_expect) return PML_OK;
+            // (acquire: the results the host reads next were written before the word was raised)
+            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) >= ctx->done_expect) return PML_OK;
 #if defined(__x86_64__)
             __builtin_ia32_pause();
 #endif
@@ -3530,6 +3546,150 @@ int pml_top_down_marginals(pml_ctx* ctx, double* posterior_out, double* lh_sum_o
     return fetch_marginals(ctx, posterior_out, lh_sum_out, lh_sf_out);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Marginal pass of a large forest in PARTS of its columns, on two streams.  Columns are independent, and on a large forest
+// the two sweeps are bound by different things -- the bottom-up launches by their instruction stream, the top-down ones
+// by the rate at which posterior rows can be written -- so part i + 1's bottom-up sweep runs while part i's top-down
+// sweep does: every part's bottom-up sweep waits for the one before it (an event), its top-down sweep follows it on the
+// part's own stream (parts alternate between the ctx's stream and a second one), and the ctx's stream waits for all of
+// them at the end.  A part sees a WINDOW of the columns: every per-column base pointer moved to its first column, C = its
+// width -- the kernels are the same, and a column's bits do not depend on how many columns share its launches (the lane
+// shapes follow k and the level sizes, multi_level_shape).  PASTML_HIP_SPLIT_PARTS = n: n parts (0 / 1: off).
+// ---------------------------------------------------------------------------------------------------------------------
+struct ColumnWindow {
+    pml_ctx* c;
+    u64 *masks, *masks_init, *err, *h_err;
+    double *pi, *sf, *tau, *tauf, *mu, *kappa, *active, *E, *bu, *S, *td, *post, *lhsum, *h_loglik;
+    i64 *be, *te, *lhe;
+    int C, sched_cols;
+    hipStream_t stream;
+    ColumnWindow(pml_ctx* ctx, int col0, int ncol, hipStream_t s)
+        : c(ctx), masks(ctx->d_masks), masks_init(ctx->d_masks_init), err(ctx->d_err), h_err(ctx->h_err), pi(ctx->d_pi),
+          sf(ctx->d_sf), tau(ctx->d_tau), tauf(ctx->d_tauf), mu(ctx->d_mu), kappa(ctx->d_kappa), active(ctx->d_active),
+          E(ctx->d_E), bu(ctx->d_bu), S(ctx->d_S), td(ctx->d_td), post(ctx->d_post), lhsum(ctx->d_lhsum),
+          h_loglik(ctx->h_loglik), be(ctx->d_be), te(ctx->d_te), lhe(ctx->d_lhe), C(ctx->C), sched_cols(ctx->sched_cols),
+          stream(ctx->stream) {
+        const size_t N = (size_t)ctx->N, ks = (size_t)ctx->ks, W = (size_t)ctx->W, o = (size_t)col0;
+        ctx->d_masks += o * N * W;
+        if (ctx->d_masks_init) ctx->d_masks_init += o * N * W;
+        ctx->d_pi += o * ks;
+        ctx->d_sf += o;
+        ctx->d_tau += o;
+        ctx->d_tauf += o;
+        ctx->d_mu += o;
+        ctx->d_kappa += o;
+        ctx->d_active += o;
+        ctx->d_E += o * N;
+        ctx->d_bu += o * N * ks;
+        ctx->d_S += o * N;
+        ctx->d_be += o * N;
+        if (ctx->d_td) ctx->d_td += o * N * ks;
+        if (ctx->d_te) ctx->d_te += o * N;
+        ctx->d_post += o * N * ks;
+        ctx->d_lhsum += o * N;
+        ctx->d_lhe += o * N;
+        ctx->d_err += o;
+        ctx->h_loglik += o;
+        ctx->h_err += o;
+        ctx->C = ncol;
+        ctx->sched_cols = ncol;
+        ctx->stream = s;
+        ctx->windowed = true;
+    }
+    ~ColumnWindow() {
+        c->d_masks = masks;
+        c->d_masks_init = masks_init;
+        c->d_pi = pi;
+        c->d_sf = sf;
+        c->d_tau = tau;
+        c->d_tauf = tauf;
+        c->d_mu = mu;
+        c->d_kappa = kappa;
+        c->d_active = active;
+        c->d_E = E;
+        c->d_bu = bu;
+        c->d_S = S;
+        c->d_be = be;
+        c->d_td = td;
+        c->d_te = te;
+        c->d_post = post;
+        c->d_lhsum = lhsum;
+        c->d_lhe = lhe;
+        c->d_err = err;
+        c->h_loglik = h_loglik;
+        c->h_err = h_err;
+        c->C = C;
+        c->sched_cols = sched_cols;
+        c->stream = stream;
+        c->windowed = false;
+    }
+};
+
+// how many parts the marginal pass of this context runs in (1: the plain pass)
+static int split_parts(pml_ctx* ctx) {
+    const int parts = (int)ctx->tune.get(T_SPLIT_PARTS, 2);
+    if (parts < 2 || ctx->kind != PML_MODEL_F81 || ctx->W != 1 ) return 1;
+    // only where the sweeps are the streaming level launches with enough work per part to fill the chip on their own
+    if (ctx->C < 4 * parts || (long long)ctx->N * (ctx->C / parts) < (4ll << 20)) return 1;
+    if (ctx->small || ctx->blocks.ok || single_launch_sweeps(ctx)) return 1;
+    return parts;
+}
+
+static int split_marginal_pass(pml_ctx* ctx, int parts) {
+    if (!ctx->stream2) HIP_TRY(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+    while ((int)ctx->split_ev.size() < parts + 1) {
+        hipEvent_t e = nullptr;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ctx->split_ev.push_back(e);
+    }
+    const size_t CN = (size_t)ctx->C * ctx->N;
+    if (ctx->keep_td && !ctx->d_td) {
+        PML_TRY(dev_alloc(ctx, &ctx->d_td, CN * ctx->ks));
+        PML_TRY(dev_alloc(ctx, &ctx->d_te, CN));
+    }
+    if (!ctx->d_post) {
+        PML_TRY(dev_alloc(ctx, &ctx->d_post, CN * ctx->ks));
+        PML_TRY(dev_alloc(ctx, &ctx->d_lhsum, CN));
+        PML_TRY(dev_alloc(ctx, &ctx->d_lhe, CN));
+    }
+    PML_TRY(params_push(ctx));  // the whole parameter block, once, ahead of every part
+    hipStream_t streams[2] = {ctx->stream, ctx->stream2};
+    const int C = ctx->C;
+    int status = PML_OK;
+    bool td_stored = false, implicit = false;
+    for (int i = 0; i < parts && status == PML_OK; ++i) {
+        const int c0 = (int)((long long)C * i / parts), c1 = (int)((long long)C * (i + 1) / parts);
+        hipStream_t s = streams[i & 1];
+        // (part 0 follows the parameter copy in stream order; every later part through the event of the part before it)
+        if (i > 0) HIP_TRY(hipStreamWaitEvent(s, ctx->split_ev[i - 1], 0));
+        ColumnWindow win(ctx, c0, c1 - c0, s);
+        status = enqueue_bottom_up(ctx, 1, false, true);
+        if (status == PML_OK && hipEventRecord(ctx->split_ev[i], s) != hipSuccess)
+            status = fail(PML_ERR_HIP, "hipEventRecord failed in the split pass");
+        if (status == PML_OK) {
+            ctx->bu_mode = 1;  // (provisional, as in the plain pass)
+            status = run_top_down(ctx);
+            td_stored = ctx->td_vec_valid;
+            implicit = ctx->tip_post_missing;
+        }
+    }
+    // the ctx's stream waits for what ran on the other one (also after a failure: nothing may be left running behind it)
+    if (hipEventRecord(ctx->split_ev[parts], ctx->stream2) == hipSuccess)
+        (void)hipStreamWaitEvent(ctx->stream, ctx->split_ev[parts], 0);
+    PML_TRY(status);
+    ctx->js_valid = false;
+    ctx->prep_dirty = false;
+    ctx->bu_fused = ctx->n_cherries > 0;
+    ctx->bu_fused_joint = false;
+    ctx->bu_absorbed = super_sweeps(ctx);
+    ctx->td_valid = true;
+    ctx->td_vec_valid = td_stored;
+    ctx->td_filled = false;
+    ctx->post_ever = true;
+    ctx->tip_post_missing = implicit;
+    return PML_OK;
+}
+
 int pml_marginal_pass(pml_ctx* ctx, double* loglik_out, int32_t* err_parent, int32_t* err_child, double* posterior_out,
                       double* lh_sum_out, double* lh_sf_out) {
     PML_TRY(require_model(ctx));
@@ -3554,7 +3714,10 @@ int pml_marginal_pass(pml_ctx* ctx, double* loglik_out, int32_t* err_parent, int
     const u64 generation_before = ctx->h_done ? *reinterpret_cast<volatile u64*>(ctx->h_done) : 0;
     int n_signals = 0;
     bool final_signals = false;
-    if (one_graph) {
+    const int parts = split_parts(ctx);
+    if (parts > 1) {
+        PML_TRY(split_marginal_pass(ctx, parts));
+    } else if (one_graph) {
         if (ctx->mp_graph.exec && ctx->mp_graph.has_init == ctx->has_init) {
             HIP_TRY(hipGraphLaunch(ctx->mp_graph.exec, ctx->stream));
             if (ctx->mp_graph.has_params) ctx->params_dirty = false;
@@ -3876,6 +4039,10 @@ static int materialize_cherries(pml_ctx* ctx) {
 int pml_download(pml_ctx* ctx, int what, int32_t col, void* out) {
     PML_TRY(require_model(ctx));
     if (col < 0 || col >= ctx->C || !out) return fail(PML_ERR_INVALID, "bad column / output");
+    // (a pass that ended in a spin on the completion word may have left the stream busy, and the blocking copies below run
+    // on the NULL stream, which a non-blocking stream is not ordered with)
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->wait_signal = false;
     if (what == PML_BUF_BU || what == PML_BUF_BU_SF) PML_TRY(materialize_cherries(ctx));
     const size_t N = ctx->N;
     const double nan = std::numeric_limits<double>::quiet_NaN();

@@ -91,6 +91,9 @@ loglik_kernel(PmlTree t, PmlCols c, PmlState st, int n_cols, int is_marginal, do
     // loglik / err_out are pinned host memory: the results land where the caller reads them, no copy is queued
     loglik[col] = column_loglik(t, c, st, col, is_marginal);
     err_out[col] = st.err[col];
+    // (a later launch of the pass may raise the completion word the host spins on: these writes must be visible to the
+    // host before anything that launch publishes)
+    __threadfence_system();
 }
 
 // joint back-trace, one depth level per launch: state[n] = table[n][state[parent]] (ml.py:615-620)

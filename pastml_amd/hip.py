@@ -61,6 +61,7 @@ _ctx_p = ctypes.c_void_p
 SIGNATURES = {
     'pml_last_error': [],
     'pml_version': [],
+    'pml_build_digest': [],
     'pml_device_count': [ctypes.POINTER(ctypes.c_int)],
     'pml_ctx_create': [ctypes.c_int, ctypes.POINTER(_ctx_p)],
     'pml_ctx_destroy': [_ctx_p],
@@ -116,7 +117,7 @@ SIGNATURES = {
     'pml_profile_enable': [_ctx_p, ctypes.c_int],
     'pml_profile_read': [_ctx_p, ctypes.c_int, _c_double_p, ctypes.POINTER(ctypes.c_int64), ctypes.c_int],
 }
-_RESTYPES = {'pml_last_error': ctypes.c_char_p}
+_RESTYPES = {'pml_last_error': ctypes.c_char_p, 'pml_build_digest': ctypes.c_char_p}
 
 _lib = None
 _lib_lock = threading.Lock()
@@ -142,6 +143,11 @@ def load_library():
                 fn.restype = _RESTYPES.get(name, ctypes.c_int)
             _lib = lib
     return _lib
+
+
+def build_digest():
+    """Digest of the sources the loaded library was compiled from (pml_build_digest; pastml_amd/build.py makes it)."""
+    return load_library().pml_build_digest().decode()
 
 
 def _check(status):

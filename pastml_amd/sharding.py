@@ -11,7 +11,6 @@ them, so does ``bench.py --gpus N`` for the processes it starts).  ``init()`` pi
 * world == 1                       -> :class:`LocalCommunicator` (no library, no GPU needed)
 * PASTML_AMD_COMM=gloo             -> :class:`TorchCommunicator` on gloo (CPU: tests and dry runs of the N > 1 path on
                                       boxes with fewer GPUs than ranks -- RCCL refuses two ranks per device)
-* PASTML_AMD_COMM=torch-nccl       -> :class:`TorchCommunicator` on torch.distributed's nccl backend (RCCL through torch)
 * otherwise                        -> :class:`RcclCommunicator`.  Whether it can be set up is decided by ALL ranks together
                                       (``agree``): every rank reports "ready" or its failure in the job's rendezvous
                                       directory before anyone enters the collective initialisation; if one rank failed, or
@@ -219,32 +218,25 @@ class RcclCommunicator(object):
 
 class TorchCommunicator(object):
     """
-    torch.distributed behind the same interface.  'gloo' (CPU): tests / dry runs of the N > 1 path on boxes with fewer
-    GPUs than ranks.  'nccl' (= RCCL through torch): the fallback if the library's own communicator cannot be set up.
+    torch.distributed's gloo backend (CPU) behind the same interface: tests and dry runs of the N > 1 path on boxes with
+    fewer GPUs than ranks.  GPUs talk through the library's own RCCL communicator (:class:`RcclCommunicator`) -- there is
+    no second GPU backend.
     """
+    name = 'gloo'
 
-    def __init__(self, rank, world, backend='gloo', device=None):
-        import torch
+    def __init__(self, rank, world):
         import torch.distributed as dist
         self._dist = dist
-        self.name = backend if backend == 'gloo' else 'torch-' + backend
-        self._device = 'cpu'
         self._own = not dist.is_initialized()
-        if backend == 'nccl':
-            local = rank_world()[2] if device is None else device
-            torch.cuda.set_device(local)
-            self._device = 'cuda:{}'.format(local)
-            if self._own:
-                dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(self._device))
-        elif self._own:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        if self._own:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
         self.rank, self.world = rank, world
 
     def allreduce(self, values, op='sum'):
         import torch
-        t = torch.tensor(np.atleast_1d(values), dtype=torch.float64, device=self._device)
+        t = torch.tensor(np.atleast_1d(values), dtype=torch.float64)
         self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM if op == 'sum' else self._dist.ReduceOp.MAX)
-        return t.cpu().numpy().copy()
+        return t.numpy().copy()
 
     def allreduce_loglik(self, loglik):
         return float(self.allreduce([LocalCommunicator().allreduce_loglik(loglik)])[0])
@@ -257,8 +249,7 @@ class TorchCommunicator(object):
             self._dist.destroy_process_group()
 
 
-def GlooCommunicator(rank, world):
-    return TorchCommunicator(rank, world, 'gloo')
+GlooCommunicator = TorchCommunicator
 
 
 _COMM = None
@@ -275,11 +266,10 @@ def init(device=None, engine=None, kind=None):
         _COMM = LocalCommunicator()
     elif kind == 'gloo':
         _COMM = GlooCommunicator(rank, world)
-    elif kind == 'torch-nccl':
-        _COMM = TorchCommunicator(rank, world, 'nccl', device=device)
+    elif kind != 'rccl':
+        raise ValueError('PASTML_AMD_COMM={!r}: the communicators are "rccl" (GPUs) and "gloo" (CPU dry runs)'.format(kind))
     else:
-        # no automatic fallback: a failure is a failure of the job, on every rank (RcclCommunicator / agree);
-        # PASTML_AMD_COMM=torch-nccl is there for whoever wants torch's communicator
+        # no automatic fallback: a failure is a failure of the job, on every rank (RcclCommunicator / agree)
         _COMM = RcclCommunicator(rank, world, device=local_rank if device is None else device, engine=engine)
     return _COMM
 

@@ -40,6 +40,17 @@ def _single_process_logliks(n_chars, levels, k):
         return eng.bottom_up(True)
 
 
+def _assert_complete_line(line):
+    """An N > 1 line carries what the N = 1 line does (north_star: the CPU path timed in the same run, the roofline)."""
+    cpu = line['cpu_baseline']
+    assert cpu['value'] > 0 and cpu['cores'] >= 1 and cpu['kind'] == 'port' and cpu['unit'] == line['unit']
+    assert line['speedup_vs_cpu_baseline'] == pytest.approx(line['value'] / cpu['value'])
+    roof = line['roofline']
+    assert roof['bound'] == 'hbm' and roof['unit'] == 'GB/s' and roof['peak'] == 8000.0
+    assert roof['achieved'] > 0 and roof['frac'] == pytest.approx(roof['achieved'] / roof['peak'])
+    assert len(line['library']['build_digest']) == 16 and line['library']['build_digest'] == line['library']['source_digest']
+
+
 def test_two_ranks_on_one_gpu_through_the_hip_path(tmp_path):
     n_chars, levels, k = 6, 10, 64
     port = _free_port()
@@ -105,10 +116,12 @@ def test_bench_two_ranks_started_directly(tmp_path):
     env.pop('RANK', None)
     env.pop('WORLD_SIZE', None)
     r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
-                        '--workload', 'cfg4_small', '--chars-per-gpu', '2'], env=env, capture_output=True, timeout=600)
+                        '--workload', 'cfg4_small', '--chars-per-gpu', '2', '--cpu-baseline-levels', '11',
+                        '--cpu-baseline-cores', '2'], env=env, capture_output=True, timeout=600)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     line = json.loads(r.stdout.decode().strip().splitlines()[-1])
     assert line['n_gpus'] == 2 and line['config']['chars_total'] == 4 and line['scaling'] == 'weak'
+    _assert_complete_line(line)
     assert line['validation']['columns'] == 2
     ref = _single_process_logliks(4, 14, 64)
     np.testing.assert_allclose(line['loglik_sum'], ref.sum(), rtol=1e-13)
@@ -125,12 +138,14 @@ def test_bench_four_ranks_of_32_characters(tmp_path):
     for key in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'PASTML_AMD_RDZV_DIR'):
         env.pop(key, None)
     r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '4', '--steps', '2', '--warmup', '1',
-                        '--workload', 'cfg4_small', '--chars-per-gpu', '32', '--no-secondary'], env=env,
+                        '--workload', 'cfg4_small', '--chars-per-gpu', '32', '--no-secondary', '--cpu-baseline-levels', '11',
+                        '--cpu-baseline-cores', '2'], env=env,
                        capture_output=True, timeout=900)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     line = json.loads(r.stdout.decode().strip().splitlines()[-1])
     assert line['n_gpus'] == 4 and line['config']['chars_total'] == 128 and line['scaling'] == 'weak'
     assert line['validation']['columns'] == 32
+    _assert_complete_line(line)
     ref = _single_process_logliks(128, 14, 64)
     np.testing.assert_allclose(line['loglik_sum'], ref.sum(), rtol=1e-13)
 
@@ -170,12 +185,14 @@ def test_bench_two_ranks_under_torchrun(tmp_path):
     r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
                         '--master-addr', '127.0.0.1', '--master-port', str(_free_port()),
                         os.path.join(REPO, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
-                        '--workload', 'cfg4_small', '--chars-per-gpu', '2'], env=env, capture_output=True, timeout=900)
+                        '--workload', 'cfg4_small', '--chars-per-gpu', '2', '--cpu-baseline-levels', '11',
+                        '--cpu-baseline-cores', '2'], env=env, capture_output=True, timeout=900)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     lines = [l for l in r.stdout.decode().splitlines() if l.startswith('{')]
     assert len(lines) == 1                      # rank 0 only
     line = json.loads(lines[0])
     assert line['n_gpus'] == 2 and line['config']['chars_total'] == 4 and line['config']['collective'] == 'gloo'
+    _assert_complete_line(line)   # (no parent of ours under a launcher: rank 0 timed the CPU path before touching the GPU)
     np.testing.assert_allclose(line['loglik_sum'], _single_process_logliks(4, 14, 64).sum(), rtol=1e-13)
 
 

@@ -863,6 +863,48 @@ def test_sweep_of_some_columns_leaves_the_others_alone(n_tips, cols, k):
     assert not np.array_equal(before, after)
 
 
+@pytest.mark.parametrize('k,cols', [(20, 48), (64, 40)])
+def test_partial_sweep_keeps_the_idle_columns_downloadable(k, cols):
+    """
+    A context whose full sweeps run the level schedule with two-level units (their children's vectors are never written)
+    and whose few-column sweeps run the subtree blocks: after a sweep of a few columns, the bottom-up vectors of a column
+    that sat it out must still be rebuilt for a download -- what the last FULL sweep left out of memory is still missing
+    for that column (the "children absorbed" flag is sticky across partial sweeps).
+    """
+    flat = synthetic.balanced_forest(13)   # 8 192 tips: 4 095 stored nodes x 48 columns > 160 000 >= 4 095 x 32
+    rng = np.random.default_rng(k)
+    specs = [(dict(kind=0, pi=synthetic.f81_frequencies(k, c)), (1.0 + 0.01 * c, 0.0, 1.0)) for c in range(cols)]
+    other = [(dict(kind=0, pi=synthetic.f81_frequencies(k, 100 + c)), (1.3, 0.0, 1.0)) for c in range(cols)]
+    states = np.stack([synthetic.tip_states(flat.n_tips, k, c) for c in range(cols)])
+    active = np.zeros(cols, dtype=np.uint8)
+    active[rng.choice(cols - 1, size=5, replace=False)] = 1
+    idle = cols - 1
+    with hip.Engine(flat, cols, k) as eng:
+        eng.set_tip_states(states)
+        eng.set_models(specs)
+        assert eng.sweep_schedule()[0] == hip.SCHEDULE_TWO_LEVEL
+        before = eng.bottom_up(True)                    # a full sweep: the units' children are not in memory
+        for c in np.flatnonzero(active):
+            eng.set_models([other[c]], col_begin=int(c))
+        eng.bottom_up_submit(True, active=active)
+        mixed = eng.bottom_up_collect(True)
+        got = eng.download(hip.BUF_BU, idle)            # (nothing has ever materialised the idle column's rows)
+        got_sf = eng.download(hip.BUF_BU_SF, idle)
+        first_active = int(np.flatnonzero(active)[0])
+        got_active = eng.download(hip.BUF_BU, first_active)
+        eng.set_models(other)
+        after = eng.bottom_up(True)
+        want_active = eng.download(hip.BUF_BU, first_active)
+        eng.set_models(specs)
+        assert np.array_equal(eng.bottom_up(True), before)
+        want = eng.download(hip.BUF_BU, idle)
+        want_sf = eng.download(hip.BUF_BU_SF, idle)
+    assert np.array_equal(mixed, np.where(active == 1, after, before))
+    assert np.array_equal(got, want) and np.array_equal(got_sf, want_sf)
+    assert np.array_equal(got_active, want_active)
+    assert np.isfinite(got).all() and (got.max(axis=1) > 0).all()
+
+
 @pytest.mark.parametrize('kind,k,marginal', [('HKY', 4, True), ('EIG', 6, True), ('F81', 5, False)])
 def test_column_flags_are_ignored_where_no_kernel_reads_them(kind, k, marginal):
     """pml_bottom_up_submit_columns outside the F81 marginal sweep (matrix / eigen models, the joint sweep): every column is

@@ -463,3 +463,26 @@ def test_library_fd_points_are_numpys():
     b0 = jc.get_bounds()
     block, steps = jc.fd_block(np.array([1.5]), np.ascontiguousarray(b0[:, 0]), np.ascontiguousarray(b0[:, 1]))
     assert len(block) == 2 and np.array_equal(block.pi, np.full((2, 3), 1 / 3)) and block.sf[0] == 1.5
+
+
+def test_acr_names_a_character_with_more_than_256_states():
+    """Boundary difference to the reference (no bound on k there): said up front, by name, before any device work."""
+    import pandas as pd
+    from pastml_amd import acr as acr_module, hip
+    from pastml_amd.tree import read_tree as read_newick
+    assert acr_module.MAX_STATES == hip.MAX_STATES == 256
+    n = 300
+    tree = read_newick('(' + ','.join('t{}:1'.format(i) for i in range(n)) + ');')
+    df = pd.DataFrame({'wide': ['s{:03d}'.format(i) for i in range(n)], 'ok': ['a', 'b'] * (n // 2)},
+                      index=['t{}'.format(i) for i in range(n)])
+    with pytest.raises(ValueError, match='wide has 300 states.*at most 256'):
+        acr_module.acr(tree, df, prediction_method='MPPA', model='F81')
+
+
+def test_value2list_broadcasts_like_the_reference():
+    from pastml_amd import value2list
+    given = ['a', 'b']
+    assert value2list(4, given, 'D') == ['a', 'b', 'D', 'D'] and given == ['a', 'b']   # (the caller's list is left alone)
+    assert value2list(3, None, 'D') == ['D'] * 3 and value2list(3, 'x', 'D') == ['x'] * 3
+    assert value2list(3, ['x'], 'D') == ['x'] * 3 and value2list(2, [], 'D') == ['D'] * 2
+    assert value2list(2, ['a', 'b', 'c'], 'D') == ['a', 'b', 'c']
