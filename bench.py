@@ -442,6 +442,12 @@ def csrc_digest():
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+def library_source_digest():
+    """Digest of the library's sources as the tree holds them now (what pastml_amd/build.py compiles in)."""
+    from pastml_amd import build
+    return build.source_digest()
+
+
 def run_cpu_baseline(args, levels, k, model):
     """The CPU baseline of this run (None if switched off): called from a process that has not touched a GPU."""
     if args.no_cpu_baseline or under_profiler():
