@@ -570,7 +570,7 @@ except Exception:  # pragma: no cover - depends on the SciPy build
     _adjust_scheme_to_bounds = None
 
 
-def two_point_scheme(x0, lower, upper):
+def two_point_scheme(x0, lower, upper, step=1e-8):
     """
     The points of scipy's forward-difference gradient at x0 -- approx_derivative(method='2-point', abs_step=1e-8,
     bounds=...), the scheme L-BFGS-B applies when it is given no gradient -- and the steps to divide by:
@@ -579,7 +579,7 @@ def two_point_scheme(x0, lower, upper):
     per coordinate (a third of the host time of an optimiser round went there).
     """
     x0 = np.asarray(x0, dtype=np.float64)
-    h = np.full(x0.shape, 1e-8)
+    h = np.full(x0.shape, float(step))   # (1e-8: scipy's; the polish of search_parameters_steps takes a larger one)
     zero = ((x0 + h) - x0) == 0
     if zero.any():   # (a step below the spacing of x0: scipy falls back to a relative one)
         sign = (x0 >= 0).astype(float) * 2 - 1
@@ -640,21 +640,33 @@ def single_loop_optimiser_available():
 
 class _Found(object):
     """What the search looks at in scipy's OptimizeResult."""
-    __slots__ = ('x', 'fun', 'success', 'nit', 'nfev', 'reason')
+    __slots__ = ('x', 'fun', 'success', 'nit', 'nfev', 'reason', 'continued_at')
 
-    def __init__(self, x, fun, success, nit, nfev, reason=0):
+    def __init__(self, x, fun, success, nit, nfev, reason=0, continued_at=None):
         self.x, self.fun, self.success, self.nit, self.nfev, self.reason = x, fun, success, nit, nfev, reason
+        self.continued_at = continued_at   # (iteration count, f) where a continued run would have stopped, or None
 
 
 # L-BFGS-B's second convergence test, "RELATIVE REDUCTION OF F <= FACTR*EPSMCH" (scipy/optimize/_lbfgsb_py.py,
-# task_messages[402]): the search stopped because a step gained too little, not because the gradient vanished.  In a flat
-# valley of many parameters that happens on plateaus well short of the optimum (HIV1C 'Year', k = 30: 3 of 16
-# rounding-perturbed runs, profiles/r04e_year_optimiser_path.txt).  A search of at least RESTART_MIN_PARAMETERS free
-# parameters that ends this way is therefore run once more from its end point, with a fresh limited-memory matrix, and the
-# better of the two ends is kept -- it can only raise ln L, and the reference's acceptance rule is untouched (first successful
-# run at least as good as the better start, pastml/ml.py:217-233).  INTEGRATION.md, "Differences".
+# task_messages[402]): the search stopped because ONE step gained too little, not because the gradient vanished.  In a flat
+# valley of many parameters that happens on plateaus well short of the optimum (HIV1C 'Year', k = 30: the run ends 0.033 in
+# ln L short after a step that gained 6e-6 where its neighbours gained 3e-4; 3 of 16 rounding-perturbed runs do,
+# profiles/r04e_year_optimiser_path.txt).  A search of at least CONTINUE_MIN_PARAMETERS free parameters that ends this way
+# is therefore CONTINUED once -- same routine, same limited-memory matrix, same iterates as if the run had been started
+# with a tenfold tighter ftol (the routine keeps its tolerance in its own workspace; round 5 measured that a fresh run from
+# the end point, without the matrix, stalls on the same plateau) -- until the test fires again at the tighter level.  A
+# continued run can only end at a higher ln L, and the reference's acceptance rule is untouched (first successful run at
+# least as good as the better start, pastml/ml.py:217-233).  INTEGRATION.md, "Differences".
 RELATIVE_REDUCTION = 402
-RESTART_MIN_PARAMETERS = int(os.environ.get('PASTML_AMD_RESTART_MIN_PARAMETERS', '20'))
+CONTINUE_FTOL_FACTOR = 0.1
+CONTINUE = os.environ.get('PASTML_AMD_CONTINUE', '1') != '0'
+# ... and the accepted optimum of such a search is POLISHED: one more L-BFGS-B run from it whose forward differences take a
+# step of 1e-6 instead of scipy's 1e-8.  At 1e-8 the gradient of ln L ~ -8e3 is mostly rounding noise near an optimum
+# (ln L is computed to ~2e-10: 2e-2 of noise in a slope that goes to zero, profiles/r04e_year_optimiser_path.txt -- the
+# reference's own numpy arithmetic has the same), which is what makes the end of a many-parameter search a matter of luck;
+# at 1e-6 the noise is 2e-4.  The better of the two ends is kept.
+POLISH_STEP = float(os.environ.get('PASTML_AMD_POLISH_STEP', '1e-6'))
+CONTINUE_MIN_PARAMETERS = int(os.environ.get('PASTML_AMD_CONTINUE_MIN_PARAMETERS', '20'))
 
 
 # PASTML_AMD_FD_IN_LIBRARY=0: the finite-difference points of the F81 family through numpy (two_point_scheme + kernel_points)
@@ -668,13 +680,14 @@ FD_IN_LIBRARY = os.environ.get('PASTML_AMD_FD_IN_LIBRARY', '1') != '0'
 TRACE = None
 
 
-def lbfgsb_steps(x0, bounds, iterates=None):
+def lbfgsb_steps(x0, bounds, iterates=None, continue_factor=None):
     """
     Generator form of ``minimize(fun, x0, method='L-BFGS-B', bounds=bounds, jac=True)`` with scipy's default options
     (maxcor 10, ftol 2.22e-9, gtol 1e-5, maxfun = maxiter = 15000, maxls 20): yields the points at which it needs
     (f, gradient) and is sent the pair; its return value (StopIteration.value) carries x, fun, success.
     As in scipy, the function is evaluated once at the (clipped) starting point before the routine is entered, and a
     request for the point evaluated last is served from memory (ScalarFunction / MemoizeJac).
+    continue_factor: a run that ends on the relative-reduction test goes on, once, with its tolerance multiplied by this.
     """
     m, factr, pgtol, maxfun, maxiter, maxls = 10, 2.220446049250313e-09 / np.finfo(float).eps, 1e-5, 15000, 15000, 20
     bounds = np.asarray(bounds, dtype=np.float64)
@@ -705,6 +718,7 @@ def lbfgsb_steps(x0, bounds, iterates=None):
     dsave = np.zeros(29, dtype=np.float64)
     fx, gx = np.array(0.0, dtype=np.int32), np.zeros((n,), dtype=np.int32)   # (scipy enters with these placeholders)
     n_iterations = 0
+    continued = False
     while True:
         gx = np.asarray(gx).astype(np.float64)
         _setulb(m, x, low_bnd, upper_bnd, nbd, fx, gx, factr, pgtol, wa, iwa, task, lsave, isave, dsave, maxls, ln_task)
@@ -723,9 +737,16 @@ def lbfgsb_steps(x0, bounds, iterates=None):
                 task[0], task[1] = 5, 504
             elif nfev > maxfun:
                 task[0], task[1] = 5, 502
+        elif task[0] == 4 and task[1] == RELATIVE_REDUCTION and continue_factor and not continued \
+                and dsave[2] == factr * np.finfo(float).eps:
+            # the routine computes its tolerance (factr * epsmch) when it starts and keeps it in dsave[2] (checked above);
+            # entering again with NEW_X repeats the test that just fired, now at the tighter level, and goes on from there
+            continued = (n_iterations, float(fx))
+            dsave[2] *= continue_factor
+            task[0], task[1] = 1, 0
         else:
             break
-    return _Found(x, fx, task[0] == 4, n_iterations, nfev, int(task[1]))
+    return _Found(x, fx, task[0] == 4, n_iterations, nfev, int(task[1]), continued or None)
 
 
 def _drive(steps, evaluate):
@@ -762,14 +783,14 @@ def search_parameters_steps(model, observed_frequencies, rng, trace=None):
         values = yield [np.asarray(ps, dtype=np.float64)]
         return negative(values)[0]
 
-    def objective_and_gradient(ps):
+    def objective_and_gradient(ps, step=1e-8):
         # the 2-point scheme scipy would apply itself (absolute step 1e-8, steps mirrored at the bounds): a first pass
         # of its own helper records the points it asks for, the batch evaluates them together, a second pass runs on
         # the table of their values -- points and arithmetic are scipy's
         ps = np.asarray(ps, dtype=np.float64)
         if np.isnan(ps).any():
             return np.nan, np.full(len(ps), np.nan)
-        if fd_block is not None:
+        if fd_block is not None and step == 1e-8:
             # F81 family: the points of the gradient, decoded, in one call into the library (host arithmetic; the numbers of
             # two_point_scheme + kernel_points)
             made = fd_block(ps, lower_c, upper_c)
@@ -780,17 +801,17 @@ def search_parameters_steps(model, observed_frequencies, rng, trace=None):
         if _adjust_scheme_to_bounds is not None:
             if ((ps < lower) | (ps > upper)).any():
                 raise ValueError("`x0` violates bound constraints.")
-            points, steps = two_point_scheme(ps, lower, upper)
+            points, steps = two_point_scheme(ps, lower, upper, step)
             values = negative((yield np.vstack((ps[None, :], points))))
             return values[0], (values[1:] - values[0]) / steps
         asked = []
         _approx_derivative(lambda x: asked.append(np.array(x, dtype=np.float64)) or 0.0, ps, method='2-point',
-                           abs_step=1e-8, f0=0.0, bounds=(lower, upper))
+                           abs_step=step, f0=0.0, bounds=(lower, upper))
         values = yield [ps] + asked
         values = negative(values)
         table = {x.tobytes(): v for x, v in zip(asked, values[1:])}
         gradient = _approx_derivative(lambda x: table[np.asarray(x, dtype=np.float64).tobytes()], ps,
-                                      method='2-point', abs_step=1e-8, f0=values[0], bounds=(lower, upper))
+                                      method='2-point', abs_step=step, f0=values[0], bounds=(lower, upper))
         return values[0], gradient
 
     from pastml_amd.models import ModelWithFrequencies
@@ -801,20 +822,22 @@ def search_parameters_steps(model, observed_frequencies, rng, trace=None):
         model.frequencies = np.maximum(observed_frequencies, 1e-10) if np.any(observed_frequencies <= 0) \
             else observed_frequencies
         start_observed = model.get_optimised_parameters()
-    def minimise(x0):
+    def minimise(x0, step=1e-8):
         # one L-BFGS-B run from x0: (what it found, its trace record or None)
         iterates = [] if trace is not None else None
-        search = lbfgsb_steps(x0, bounds, iterates)
+        search = lbfgsb_steps(x0, bounds, iterates,
+                              CONTINUE_FTOL_FACTOR if CONTINUE and len(x0) >= CONTINUE_MIN_PARAMETERS else None)
         try:
             point = next(search)
             while True:
-                point = search.send((yield from objective_and_gradient(point)))
+                point = search.send((yield from objective_and_gradient(point, step)))
         except StopIteration as stop:
             found = stop.value
         record = None
         if trace is not None:
             record = dict(x0=np.array(x0, dtype=np.float64), x=np.array(found.x), fun=float(found.fun),
                           success=bool(found.success), nit=found.nit, nfev=found.nfev, reason=found.reason,
+                          continued_at=found.continued_at,
                           iterates=np.array([it[0] for it in iterates]), values=np.array([it[1] for it in iterates]))
         return found, record
 
@@ -831,14 +854,13 @@ def search_parameters_steps(model, observed_frequencies, rng, trace=None):
         found, record = yield from minimise(x0)
         if trace is not None:
             trace.append(record)
-        if found.success and found.reason == RELATIVE_REDUCTION and len(found.x) >= RESTART_MIN_PARAMETERS \
-                and not np.any(np.isnan(found.x)):
-            again, record2 = yield from minimise(found.x)
-            if record is not None:
-                record['restart'] = record2
-            if not np.any(np.isnan(again.x)) and again.fun < found.fun:
-                found = _Found(again.x, again.fun, True, found.nit + again.nit, found.nfev + again.nfev, again.reason)
         if found.success and not np.any(np.isnan(found.x)) and -found.fun >= to_beat:
+            if POLISH_STEP and len(found.x) >= CONTINUE_MIN_PARAMETERS:
+                polished, record2 = yield from minimise(found.x, POLISH_STEP)
+                if record is not None:
+                    record['polish'] = record2
+                if not np.any(np.isnan(polished.x)) and polished.fun < found.fun:
+                    found = polished
             model.set_params_from_optimised(found.x)
             return -found.fun
     model.set_params_from_optimised(start_current if lnl_current >= lnl_observed else start_observed)
@@ -901,18 +923,15 @@ def _search_parameters_scipy(model, observed_frequencies, evaluate, rng):
             x0 = start_observed
         else:
             x0 = rng.uniform(lower, upper)
-        def run(start):
+        def run(options=None):
             if batched:
-                return minimize(objective_and_gradient, x0=start, method='L-BFGS-B', bounds=bounds, jac=True)
-            return minimize(objective, x0=start, method='L-BFGS-B', bounds=bounds)
-        found = run(x0)
-        # (the restart of search_parameters_steps: same rule, so both drivers end at the same optima)
-        if found.success and 'RELATIVE REDUCTION OF F' in str(found.message) and len(found.x) >= RESTART_MIN_PARAMETERS \
-                and not np.any(np.isnan(found.x)):
-            again = run(found.x)
-            if not np.any(np.isnan(again.x)) and again.fun < found.fun:
-                again.success = True
-                found = again
+                return minimize(objective_and_gradient, x0=x0, method='L-BFGS-B', bounds=bounds, jac=True, options=options)
+            return minimize(objective, x0=x0, method='L-BFGS-B', bounds=bounds, options=options)
+        found = run()
+        # (the continuation of lbfgsb_steps, in the only form scipy's own driver offers: the run again from its start with
+        # the tighter ftol -- the same iterates up to where the first run stopped, then the ones the continuation makes)
+        if found.success and 'RELATIVE REDUCTION OF F' in str(found.message) and len(found.x) >= CONTINUE_MIN_PARAMETERS:
+            found = run(dict(ftol=2.220446049250313e-09 * CONTINUE_FTOL_FACTOR))
         if found.success and not np.any(np.isnan(found.x)) and -found.fun >= to_beat:
             model.set_params_from_optimised(found.x)
             return -found.fun

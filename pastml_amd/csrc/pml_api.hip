@@ -71,7 +71,7 @@ static int fail(int code, const char* fmt, ...) {
     X(STACK_MIN, 0, 1) X(NO_STACK, 1, 1) X(DEBUG, 1, 0) X(BLOCK_NODES, 0, 1) X(BLOCK_MAX_STORED, 0, 1)                 \
     X(BLOCK_HEIGHT_CAP, 0, 1) X(SMALL_MAX_NODES, 0, 1) X(F81_R, 0, 1) X(F81_TD_R, 0, 1) X(NO_GRAPH, 1, 1)              \
     X(NARROW_UNITS, 0, 0) X(NO_EIGG_TIERS, 1, 0) X(NO_ABSORB, 1, 1) X(ABSORB_MIN, 0, 1) X(NO_SPIN_WAIT, 1, 0)   \
-    X(SPLIT_PARTS, 0, 0)
+    X(SPLIT_PARTS, 0, 0) X(PIJ_STAGE_ROWS, 0, 0) X(PIJ_ABLATE, 0, 0)
 enum PmlTunable {
 #define X(name, flag, tree) T_##name,
     PML_TUNABLES(X)
@@ -2763,19 +2763,32 @@ static int run_prep(pml_ctx* ctx, bool force = false) {
             // FP64 matrix-core path (BASELINE config 3: JTT, k = 20)
             const int k = ctx->k;
             const int KS = (k + 3) / 4, NT = (k + 15) / 16;
-            const size_t lds = ((size_t)KS * 4 * k + (size_t)PML_WAVES_PER_BLOCK * PML_MFMA_CHUNK * KS * 4) * sizeof(double);
+            // rows of the result a wave stages in LDS per flush (pml_kernels_pij.h)
+            int srows = (int)ctx->tune.get(T_PIJ_STAGE_ROWS, 32);
+            if (srows != 16 && srows != 64) srows = 32;
+            if (srows == 64 && ((size_t)KS * 4 * k + (size_t)PML_WAVES_PER_BLOCK * (PML_MFMA_CHUNK + 64) * KS * 4) * sizeof(double) > 64 * 1024)
+                srows = 32;  // (the default limit of dynamic LDS)
+            const size_t lds = ((size_t)KS * 4 * k + (size_t)PML_WAVES_PER_BLOCK * (PML_MFMA_CHUNK + srows) * KS * 4) * sizeof(double);
             int blocks = (ctx->N + PML_WAVES_PER_BLOCK * PML_MFMA_CHUNK - 1) / (PML_WAVES_PER_BLOCK * PML_MFMA_CHUNK);
             if (blocks > 4096) blocks = 4096;
             dim3 grid(blocks, ctx->C);
-#define PML_MFMA_CASE(NT_, KS_)                                                                                  \
-    if (NT == NT_ && KS == KS_)                                                                                  \
-        hipLaunchKernelGGL((pij_eigen_mfma_kernel<NT_, KS_>), grid, dim3(PML_BLOCK), lds, ctx->stream, t, c, m, \
-                           ctx->d_P);
+            const int ablate = (int)ctx->tune.get(T_PIJ_ABLATE, 0);   // (measurements: 1 = no stores, 2 = no matrix instructions)
+#define PML_MFMA_CASE_R(NT_, KS_, SR_)                                                                             \
+    if (NT == NT_ && KS == KS_ && srows == SR_) {                                                                  \
+        if (ablate == 1 && KS_ == 5 && SR_ == 32)                                                                  \
+            hipLaunchKernelGGL((pij_eigen_mfma_kernel<NT_, KS_, SR_, 1>), grid, dim3(PML_BLOCK), lds, ctx->stream, t, c, m, ctx->d_P); \
+        else if (ablate == 2 && KS_ == 5 && SR_ == 32)                                                             \
+            hipLaunchKernelGGL((pij_eigen_mfma_kernel<NT_, KS_, SR_, 2>), grid, dim3(PML_BLOCK), lds, ctx->stream, t, c, m, ctx->d_P); \
+        else                                                                                                       \
+            hipLaunchKernelGGL((pij_eigen_mfma_kernel<NT_, KS_, SR_>), grid, dim3(PML_BLOCK), lds, ctx->stream, t, c, m, ctx->d_P);    \
+    }
+#define PML_MFMA_CASE(NT_, KS_) PML_MFMA_CASE_R(NT_, KS_, 16) PML_MFMA_CASE_R(NT_, KS_, 32) PML_MFMA_CASE_R(NT_, KS_, 64)
             PML_MFMA_CASE(1, 4)
             PML_MFMA_CASE(2, 5)
             PML_MFMA_CASE(2, 6)
             PML_MFMA_CASE(2, 7)
             PML_MFMA_CASE(2, 8)
+#undef PML_MFMA_CASE_R
 #undef PML_MFMA_CASE
         } else {
             const int k = ctx->k;
@@ -3627,7 +3640,7 @@ struct ColumnWindow {
 
 // how many parts the marginal pass of this context runs in (1: the plain pass)
 static int split_parts(pml_ctx* ctx) {
-    const int parts = (int)ctx->tune.get(T_SPLIT_PARTS, 2);
+    const int parts = (int)ctx->tune.get(T_SPLIT_PARTS, 1);   // (off unless asked for: measured, profiles/r05a_split_pass_ab.txt)
     if (parts < 2 || ctx->kind != PML_MODEL_F81 || ctx->W != 1 ) return 1;
     // only where the sweeps are the streaming level launches with enough work per part to fill the chip on their own
     if (ctx->C < 4 * parts || (long long)ctx->N * (ctx->C / parts) < (4ll << 20)) return 1;

@@ -120,7 +120,20 @@ pij_explicit_kernel(PmlCols c, PmlModel m, int col, int n_t, const double* __res
 
 typedef double pml_v4f64 __attribute__((ext_vector_type(4)));
 
-template <int NT, int KS>
+// Rows of the result a wave collects in LDS before it writes them out.  In the 16x16 result tile a store instruction
+// would cover four row pieces of 128 bytes (and, for the second column tile of k = 20, of 32 bytes): the L2 has to merge
+// partial lines and the batch ran at 3.3 TB/s (k = 20).  The rows (b, j) of a chunk are contiguous in memory (row stride
+// ks doubles), so the wave stages SROWS of them in LDS in memory order and writes them with 16 bytes per lane
+// in address order -- every store instruction covers 1 KB of consecutive bytes.
+// SROWS: 16 (one result tile), 32 or 64 -- LDS per wave against bytes per flush (PASTML_HIP_PIJ_STAGE_ROWS).
+template <int KS, int SROWS>
+struct PijStage {
+    static constexpr int KP = 4 * KS;
+    static constexpr int ROWS = SROWS;
+    static constexpr int DOUBLES = ROWS * KP;
+};
+
+template <int NT, int KS, int SROWS, int ABLATE = 0>
 __global__ void __launch_bounds__(PML_BLOCK)
 pij_eigen_mfma_kernel(PmlTree t, PmlCols c, PmlModel m, double* __restrict__ P) {
     extern __shared__ double smem[];
@@ -131,8 +144,11 @@ pij_eigen_mfma_kernel(PmlTree t, PmlCols c, PmlModel m, double* __restrict__ P) 
     const int wave = threadIdx.x >> 6;
     const int lo = lane & 15, hi = lane >> 4;
     constexpr int KP = KS * 4;
+    typedef PijStage<KS, SROWS> ST;
+    typedef double dbl2 __attribute__((ext_vector_type(2)));
     double* sB = smem;                                  // Ainv padded: [KP][k]   (rows >= k are zero)
-    double* sE = sB + KP * k + wave * PML_MFMA_CHUNK * KP;  // per wave: exp(d_m t_b)  [CHUNK][KP]
+    double* sE = sB + KP * k + wave * (PML_MFMA_CHUNK * KP + ST::DOUBLES);  // per wave: exp(d_m t_b)  [CHUNK][KP]
+    double* sO = sE + PML_MFMA_CHUNK * KP;              // per wave: staged rows of the result [ROWS][ks]
     const double* gA = m.A + (size_t)col * k * k;
     const double* gB = m.Ainv + (size_t)col * k * k;
     const double* gd = m.d + (size_t)col * k;
@@ -163,37 +179,62 @@ pij_eigen_mfma_kernel(PmlTree t, PmlCols c, PmlModel m, double* __restrict__ P) 
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const int rows = nb * k;
-        for (int r0 = 0; r0 < rows; r0 += 16) {
-            // A operand row of this lane: (branch q, state j)
-            const int ra = r0 + lo;
-            const bool va = ra < rows;
-            const int qa = va ? ra / k : 0, ja = va ? ra % k : 0;
-            pml_v4f64 acc[NT];
+        double* const chunk_out = P + (colN + b0) * (size_t)k * ks;   // rows (b, j) of the chunk, ks doubles each
+        for (int g0 = 0; g0 < rows; g0 += ST::ROWS) {
+            const int grows = min(ST::ROWS, rows - g0);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[nt] = (pml_v4f64){0.0, 0.0, 0.0, 0.0};
+            for (int tt = 0; tt < ST::ROWS / 16; ++tt) {
+                const int r0 = g0 + 16 * tt;
+                if (r0 >= rows) break;
+                // A operand row of this lane: (branch q, state j)
+                const int ra = r0 + lo;
+                const bool va = ra < rows;
+                const int qa = va ? ra / k : 0, ja = va ? ra % k : 0;
+                pml_v4f64 acc[NT];
 #pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                const int mm = 4 * s + hi;
-                const double a = va ? sB[mm * k + ja] * sE[qa * KP + mm] : 0.0;
+                for (int nt = 0; nt < NT; ++nt) acc[nt] = (pml_v4f64){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bfrag[nt][s], acc[nt], 0, 0, 0);
-            }
-            // D: row = hi + 4 * reg, col = lo  ->  Pt[b0 + q][j][16nt + lo]
+                for (int s = 0; s < KS; ++s) {
+                    const int mm = 4 * s + hi;
+                    const double a = va ? sB[mm * k + ja] * sE[qa * KP + mm] : 0.0;
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const int rr = r0 + hi + 4 * reg;
-                if (rr < rows) {
-                    const int q = rr / k, j = rr % k;
-                    double* out = P + ((colN + b0 + q) * (size_t)k + j) * ks;
+                    for (int nt = 0; nt < NT; ++nt) {
+                        if (ABLATE == 2) acc[nt][0] += a * bfrag[nt][s];   // (measurement only: no matrix instructions)
+                        else acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bfrag[nt][s], acc[nt], 0, 0, 0);
+                    }
+                }
+                // D: row = hi + 4 * reg, col = lo  ->  staged row (r0 - g0) + hi + 4 reg, columns 16 nt + lo
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    double* srow = sO + (16 * tt + hi + 4 * reg) * ks;
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
                         const int i = 16 * nt + lo;
-                        if (i < ks) out[i] = acc[nt][reg];  // columns k..ks-1 are exact zeros (zero B fragments)
+                        if (i < ks) srow[i] = acc[nt][reg];  // columns k..ks-1 are exact zeros (zero B fragments)
                     }
                 }
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // the staged rows in address order, 16 bytes per lane (ks is even: whole pairs)
+            double* const gout = chunk_out + (size_t)g0 * ks;
+            if ((ks & 1) == 0) {
+                const int pairs = grows * ks / 2;
+                for (int e = lane; e < pairs; e += 64) {
+                    const dbl2 v = *reinterpret_cast<const dbl2*>(sO + 2 * e);
+                    if (ABLATE == 1) {   // (measurement only: one lane in 2^20 stores, the rest of the work stays)
+                        if (v.x == 0x1p-1000) __builtin_nontemporal_store(v, reinterpret_cast<dbl2*>(gout + 2 * e));
+                    } else {
+                        __builtin_nontemporal_store(v, reinterpret_cast<dbl2*>(gout + 2 * e));
+                    }
+                }
+            } else {  // (odd row stride -- PASTML_HIP_MATRIX_R1 with an odd k: no 16-byte alignment)
+                for (int e = lane; e < grows * ks; e += 64) gout[e] = sO[e];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-        __builtin_amdgcn_wave_barrier();
     }
 }

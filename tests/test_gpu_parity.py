@@ -863,6 +863,35 @@ def test_sweep_of_some_columns_leaves_the_others_alone(n_tips, cols, k):
     assert not np.array_equal(before, after)
 
 
+@pytest.mark.parametrize('parts', [2, 3])
+def test_split_marginal_pass_has_the_same_bits(parts):
+    """
+    PASTML_HIP_SPLIT_PARTS: the marginal pass of a large forest in parts of its columns on two streams (windows of the
+    columns, part i + 1's bottom-up sweep beside part i's top-down sweep).  Off by default (profiles/r05a_split_pass_ab.txt);
+    the results -- ln L, posteriors, the sums, a download of bottom-up vectors afterwards -- are those of the plain pass.
+    """
+    flat = synthetic.balanced_forest(17)   # 131 072 tips x 48 columns: every part is past the 4 M node-column threshold
+    k, cols = 64, 48
+    specs = [(dict(kind=0, pi=synthetic.f81_frequencies(k, c)), (1.0 + 0.02 * c, 0.0, 1.0)) for c in range(cols)]
+    states = np.stack([synthetic.tip_states(flat.n_tips, k, c) for c in range(cols)])
+    out = {}
+    for name, tune in (('plain', dict(SPLIT_PARTS=1)), ('split', dict(SPLIT_PARTS=parts))):
+        with hip.Engine(flat, cols, k, tune=tune) as eng:
+            eng.set_tip_states(states)
+            eng.set_models(specs)
+            for _ in range(2):   # (the second pass reuses what the first allocated)
+                eng.set_models(specs)
+                lnl = eng.marginal_pass(posterior=False, lh=False)[0]
+            sample = [(eng.download_strided(hip.BUF_POSTERIOR, c, 0, 997), eng.download_strided(hip.BUF_LH_SUM, c, 0, 997),
+                       eng.download_strided(hip.BUF_LH_SF, c, 0, 997)) for c in (0, cols // parts, cols - 1)]
+            bu = eng.download(hip.BUF_BU, cols - 1)[::1013]
+            out[name] = (lnl, sample, bu)
+    assert np.array_equal(out['plain'][0], out['split'][0])
+    for a, b in zip(out['plain'][1], out['split'][1]):
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    assert np.array_equal(out['plain'][2], out['split'][2])
+
+
 @pytest.mark.parametrize('k,cols', [(20, 48), (64, 40)])
 def test_partial_sweep_keeps_the_idle_columns_downloadable(k, cols):
     """

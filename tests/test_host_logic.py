@@ -269,6 +269,57 @@ def test_generator_lbfgsb_reproduces_scipy_minimize():
         assert found.nit == ref.nit and found.nfev == ref.nfev
 
 
+def test_continued_lbfgsb_run_is_the_run_with_the_tighter_tolerance():
+    """
+    A search that ends on L-BFGS-B's relative-reduction test is continued once at a tenfold tighter ftol
+    (batch.CONTINUE_FTOL_FACTOR; searches of at least batch.CONTINUE_MIN_PARAMETERS parameters): the continued run asks for
+    the points scipy's minimize asks for when it is given the tighter ftol from the start, and ends where that run ends --
+    never above where the default run ends.
+    """
+    from scipy.optimize import minimize
+    from pastml_amd import batch as B
+    if B._setulb is None:
+        pytest.skip('this SciPy build has another reverse-communication routine')
+
+    def fg(x):
+        f = np.sum(100.0 * (x[1:] - x[:-1] ** 2) ** 2 + (1 - x[:-1]) ** 2)
+        g = np.zeros_like(x)
+        g[:-1] += -400 * x[:-1] * (x[1:] - x[:-1] ** 2) - 2 * (1 - x[:-1])
+        g[1:] += 200 * (x[1:] - x[:-1] ** 2)
+        return f, g
+
+    n = 30
+    bounds = np.stack([np.full(n, -5.0), np.full(n, 5.0)], axis=1)
+    seen = 0
+    for seed in range(6):
+        x0 = np.random.default_rng(seed).uniform(-2, 2, n)
+        plain = minimize(fg, x0, method='L-BFGS-B', bounds=bounds, jac=True)
+        asked_tight = []
+
+        def recorded(x):
+            asked_tight.append(x.copy())
+            return fg(x)
+        tight = minimize(recorded, x0, method='L-BFGS-B', bounds=bounds, jac=True,
+                         options=dict(ftol=2.220446049250313e-09 * B.CONTINUE_FTOL_FACTOR))
+        asked = []
+        steps = B.lbfgsb_steps(x0, bounds, continue_factor=B.CONTINUE_FTOL_FACTOR)
+        try:
+            point = next(steps)
+            while True:
+                asked.append(point.copy())
+                point = steps.send(fg(point))
+        except StopIteration as stop:
+            found = stop.value
+        if 'RELATIVE REDUCTION' not in plain.message:
+            assert found.continued_at is None and np.array_equal(found.x, plain.x)
+            continue
+        seen += 1
+        assert found.continued_at == (plain.nit, plain.fun)
+        assert len(asked) == len(asked_tight) and all(np.array_equal(a, b) for a, b in zip(asked, asked_tight))
+        assert np.array_equal(found.x, tight.x) and found.fun == tight.fun and found.fun <= plain.fun
+    assert seen >= 2
+
+
 def test_tau_none_frees_tau_for_the_first_ml_character_only(monkeypatch):
     """
     acr(tau=None) -- the pipeline's smoothing=True -- as in the reference (pastml/acr.py:185-187, inside its loop over
