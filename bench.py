@@ -425,6 +425,13 @@ def schedule_bytes(flat, k, n_cols, narrow_limit=None):
                 per_unit=dict(bottom_up=bu / (N * k), top_down=td / (N * k), prep=prep / (N * k)))
 
 
+def library_forest(eng, flat):
+    """The forest in the numbering the library works in (pml_tree_order): what the byte model of its schedules must look at
+    -- which nodes form two-level or stacked units depends on which sibling groups are neighbours."""
+    order = eng.node_order()
+    return flat if np.array_equal(order, np.arange(flat.n_nodes)) else flat.renumbered(order)
+
+
 def csrc_digest():
     """
     sha256 over the sources of the profiled kernels (the F81-family sweeps and the device helpers they are made of):
@@ -647,7 +654,7 @@ def secondary_measurements(device):
             ms = timed(ragged_pass, 20, eng)
             eng.set_models(specs)
             ms_bu = timed(lambda: eng.bottom_up(True), 20, eng)
-            sb = schedule_bytes(flat, k, C)
+            sb = schedule_bytes(library_forest(eng, flat), k, C)
             gb = sb['total'] * C / 1e9
             ragged['k{}'.format(k)] = dict(
                 ms_per_pass=ms, ms_bottom_up=ms_bu, value=flat.n_nodes * k * C / (ms * 1e-3), unit='node*state*char/s',
@@ -765,7 +772,7 @@ def secondary_measurements(device):
                 eng.set_models([(dict(kind=0, pi=pis[c]), (5.5 + 1e-8 * c, 0.0, 1.0)) for c in range(cols)])
                 eng.bottom_up(True)
             ms = timed(grad, 200, eng)
-            sb = schedule_bytes(flat, k, cols)
+            sb = schedule_bytes(library_forest(eng, flat), k, cols)
             b = (sb['bottom_up'] + sb['prep']) * cols
             out['cfg5_gradient'] = dict(workload='BASELINE config 5 shape: HIV1C tree ({} tips), k=12, one L-BFGS-B '
                                                  'finite-difference gradient = {} likelihoods in one batched bottom-up '

@@ -122,6 +122,18 @@ int pml_schedule_info(pml_ctx* ctx, int32_t* level_schedule, int32_t* n_two_leve
 enum { PML_SCHEDULE_SINGLE_LAUNCH = 0, PML_SCHEDULE_BLOCKS = 1, PML_SCHEDULE_TWO_LEVEL = 2, PML_SCHEDULE_LEVELS = 3,
        PML_SCHEDULE_OTHER_MODEL = 4 };
 int pml_sweep_schedule(pml_ctx* ctx, int32_t* kind, int32_t* n_blocks, int32_t* n_absorbed);
+/*
+ * The library's own node numbering.  The layout rules above leave the order of the sibling groups inside a depth to the
+ * caller; pml_tree_upload renumbers the nodes of a ragged forest so that the sibling groups a level's units gather lie
+ * next to each other in memory ("height order", pml_api.hip: the children of stored nodes by the nodes' fused height, the tips
+ * of cherries by the height of the cherry's parent).  Every per-node array of this interface -- masks, tip ids, posteriors,
+ * downloads, joint states, selections, the ids of a zero-likelihood report -- stays in the CALLER's numbering: the library
+ * permutes rows on the way in and out (host side; whole-table outputs of a renumbered forest cost that pass).  This call
+ * reports the numbering in use: new_of_old[caller's id] = the library's id (int32[n_nodes]; the identity for forests that are
+ * in height order as given -- balanced trees are).  For tools that model the schedules (bench.py); PASTML_HIP_NO_HEIGHT_ORDER
+ * keeps the caller's numbering.
+ */
+int pml_tree_order(pml_ctx* ctx, int32_t* new_of_old);
 
 /* ---- tree (replaces the ete3 traversals of pastml/ml.py:109,269,449) ------------------------------------------ */
 /*

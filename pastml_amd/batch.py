@@ -647,24 +647,27 @@ class _Found(object):
         self.continued_at = continued_at   # (iteration count, f) where a continued run would have stopped, or None
 
 
-# L-BFGS-B's second convergence test, "RELATIVE REDUCTION OF F <= FACTR*EPSMCH" (scipy/optimize/_lbfgsb_py.py,
-# task_messages[402]): the search stopped because ONE step gained too little, not because the gradient vanished.  In a flat
-# valley of many parameters that happens on plateaus well short of the optimum (HIV1C 'Year', k = 30: the run ends 0.033 in
-# ln L short after a step that gained 6e-6 where its neighbours gained 3e-4; 3 of 16 rounding-perturbed runs do,
-# profiles/r04e_year_optimiser_path.txt).  A search of at least CONTINUE_MIN_PARAMETERS free parameters that ends this way
-# is therefore CONTINUED once -- same routine, same limited-memory matrix, same iterates as if the run had been started
-# with a tenfold tighter ftol (the routine keeps its tolerance in its own workspace; round 5 measured that a fresh run from
-# the end point, without the matrix, stalls on the same plateau) -- until the test fires again at the tighter level.  A
-# continued run can only end at a higher ln L, and the reference's acceptance rule is untouched (first successful run at
-# least as good as the better start, pastml/ml.py:217-233).  INTEGRATION.md, "Differences".
+# The end of a many-parameter search (round 5; HIV1C 'Year', k = 30, was the one column of 91 whose optimum fell short of the
+# reference's by more than 1e-6 relative: 0.033 in ln L).  Two things make where such a search ends a matter of luck
+# (profiles/r04e_year_optimiser_path.txt, profiles/r05b_year_polish.txt):
+#   * scipy's forward differences take a step of 1e-8, and ln L ~ -8e3 is computed to ~2e-10 -- 2e-2 of rounding noise in a
+#     slope that goes to zero at the optimum (the reference's own numpy arithmetic has the same);
+#   * L-BFGS-B's second convergence test, "RELATIVE REDUCTION OF F <= FACTR*EPSMCH" (task_messages[402] of
+#     scipy/optimize/_lbfgsb_py.py), fires when ONE step gains less than 1.8e-5 -- in a flat valley that happens on
+#     plateaus well short of the optimum.
+# The reference's procedure is kept as it is (same routine, options, differencing, acceptance rule: pastml/ml.py:174-237).
+# What is added, for searches of at least CONTINUE_MIN_PARAMETERS free parameters only: the ACCEPTED optimum is polished by
+# one more L-BFGS-B run from it whose differences take a step of POLISH_STEP = 1e-6 (noise 2e-4 instead of 2e-2) and which,
+# when it ends on the relative-reduction test, is continued once with a tenfold tighter tolerance (the routine keeps its
+# tolerance in its workspace: the continued run makes the iterates of a run started with ftol / 10; a FRESH run from the end
+# point, without the limited-memory matrix, stalls on the same plateau -- measured).  The better of the two ends is kept: ln L
+# can only rise.  Measured on the five HIV1C columns with k >= 30: Year -4.2e-6 -> +1.6e-8 relative to the reference's
+# optimum, the others +4e-9 .. +5e-8; the step alone or the continuation alone leave Year at -3.9e-6.  INTEGRATION.md,
+# "Differences".  PASTML_AMD_CONTINUE: 0 never continue, 1 continue every run of such a search, 2 (default) its polish only;
+# PASTML_AMD_POLISH_STEP=0: no polish.
 RELATIVE_REDUCTION = 402
 CONTINUE_FTOL_FACTOR = 0.1
-CONTINUE = os.environ.get('PASTML_AMD_CONTINUE', '1') != '0'
-# ... and the accepted optimum of such a search is POLISHED: one more L-BFGS-B run from it whose forward differences take a
-# step of 1e-6 instead of scipy's 1e-8.  At 1e-8 the gradient of ln L ~ -8e3 is mostly rounding noise near an optimum
-# (ln L is computed to ~2e-10: 2e-2 of noise in a slope that goes to zero, profiles/r04e_year_optimiser_path.txt -- the
-# reference's own numpy arithmetic has the same), which is what makes the end of a many-parameter search a matter of luck;
-# at 1e-6 the noise is 2e-4.  The better of the two ends is kept.
+CONTINUE = int(os.environ.get('PASTML_AMD_CONTINUE', '2'))
 POLISH_STEP = float(os.environ.get('PASTML_AMD_POLISH_STEP', '1e-6'))
 CONTINUE_MIN_PARAMETERS = int(os.environ.get('PASTML_AMD_CONTINUE_MIN_PARAMETERS', '20'))
 
@@ -826,7 +829,8 @@ def search_parameters_steps(model, observed_frequencies, rng, trace=None):
         # one L-BFGS-B run from x0: (what it found, its trace record or None)
         iterates = [] if trace is not None else None
         search = lbfgsb_steps(x0, bounds, iterates,
-                              CONTINUE_FTOL_FACTOR if CONTINUE and len(x0) >= CONTINUE_MIN_PARAMETERS else None)
+                              CONTINUE_FTOL_FACTOR if len(x0) >= CONTINUE_MIN_PARAMETERS
+                              and (CONTINUE == 1 or (CONTINUE == 2 and step != 1e-8)) else None)
         try:
             point = next(search)
             while True:

@@ -71,7 +71,7 @@ static int fail(int code, const char* fmt, ...) {
     X(STACK_MIN, 0, 1) X(NO_STACK, 1, 1) X(DEBUG, 1, 0) X(BLOCK_NODES, 0, 1) X(BLOCK_MAX_STORED, 0, 1)                 \
     X(BLOCK_HEIGHT_CAP, 0, 1) X(SMALL_MAX_NODES, 0, 1) X(F81_R, 0, 1) X(F81_TD_R, 0, 1) X(NO_GRAPH, 1, 1)              \
     X(NARROW_UNITS, 0, 0) X(NO_EIGG_TIERS, 1, 0) X(NO_ABSORB, 1, 1) X(ABSORB_MIN, 0, 1) X(NO_SPIN_WAIT, 1, 0)   \
-    X(SPLIT_PARTS, 0, 0) X(PIJ_STAGE_ROWS, 0, 0) X(PIJ_ABLATE, 0, 0)
+    X(SPLIT_PARTS, 0, 0) X(PIJ_STAGE_ROWS, 0, 0) X(PIJ_ABLATE, 0, 0) X(PIJ_BLOCKS, 0, 0) X(NO_HEIGHT_ORDER, 1, 1)
 enum PmlTunable {
 #define X(name, flag, tree) T_##name,
     PML_TUNABLES(X)
@@ -140,6 +140,10 @@ struct pml_ctx {
     int *d_tip_rest = nullptr, *d_tip_rest_count = nullptr;  // eigen joint sweep: [C][n_tips] tips that are not observed, [C]
     double* d_dist = nullptr;
     std::vector<int> bu_offsets, td_offsets, td_parent_offsets, h_parent, h_n_children;
+    // Internal node numbering (height_order below): the library numbers the nodes of a ragged forest so that the sibling
+    // groups a level's units gather lie next to each other; every per-node array that crosses the C-ABI is in the CALLER's
+    // numbering and is permuted on the way in / out.  Both empty when the caller's numbering is kept (balanced trees, ...).
+    std::vector<int> new_of_old, old_of_new;
     // cherry fusion (F81 marginal sweeps): node kinds and level lists over the stored internal nodes only
     bool fuse = true;
     unsigned char* d_kind = nullptr;
@@ -1268,6 +1272,101 @@ static int launch_eigen_tips(pml_ctx* ctx, int joint) {
     return fail(PML_ERR_UNSUPPORTED, "no fused eigen kernel for k = %d", k);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Height-ordered numbering (round 5).  The C-ABI asks for breadth-first ids -- roots first, the children of a node
+// contiguous, every depth a contiguous id range -- which leaves the ORDER OF THE SIBLING GROUPS INSIDE A DEPTH free.  The
+// sweeps walk the nodes by fused height (bottom-up) and gather, per unit, 8-byte scalars of the unit's children (E, S, mask,
+// exponent) and of the tips under its cherry children; in plain breadth-first order the children of the units of ONE height
+// are scattered over their depth, so every gathered scalar costs a 128-byte line of its own (a random 262 144-tip tree moved
+// 28.8 GB per marginal pass where the schedule needs 22.2, profiles/r04b_*).  Here the sibling groups of a depth are ordered
+// by the height class of the unit that gathers them -- a stored node's children by its fused height, the tips of a cherry by
+// the fused height of the cherry's parent -- and, inside a class, in the order of their parents: the children of consecutive
+// units of a level are then consecutive in memory.  Same tree, same arithmetic per node, same bits (the order of a node's own
+// children is kept); k = 64: marginal pass 5.8 -> 5.2 ms, k = 12: 3.25 -> 2.48, k = 4: 2.39 -> 1.68 (262 144 random tips x 32
+// characters, profiles/r05e_height_order.txt).  A balanced tree is in this order already.
+// Returns false (and leaves the vectors empty) when the caller's numbering is the height order.
+// ---------------------------------------------------------------------------------------------------------------------
+static bool height_order(int N, int R, const int* parent, const int* first_child, const int* n_children,
+                         const int* td_offsets, int n_td_levels, bool fuse, std::vector<int>& old_of_new,
+                         std::vector<int>& new_of_old) {
+    old_of_new.clear();
+    new_of_old.clear();
+    std::vector<int> cls(N, 0), fh(N, 0);
+    std::vector<char> stored(N, 0);
+    for (int i = 0; i < N; ++i) {
+        if (n_children[i] == 0) continue;
+        bool all_tips = true;
+        for (int j = 0; j < n_children[i]; ++j) all_tips &= n_children[first_child[i] + j] == 0;
+        stored[i] = !(fuse && all_tips && parent[i] >= 0);
+    }
+    for (int i = N - 1; i >= 0; --i) {  // children have larger ids than their parent
+        if (!stored[i]) continue;
+        int h = 0;
+        for (int j = 0; j < n_children[i]; ++j) {
+            const int ch = first_child[i] + j;
+            if (stored[ch] && fh[ch] > h) h = fh[ch];
+        }
+        fh[i] = h + 1;
+    }
+    for (int i = 0; i < N; ++i)
+        if (n_children[i] > 0) cls[i] = stored[i] ? fh[i] : fh[parent[i]];   // (a cherry is never a root)
+    std::vector<int> order;
+    order.reserve(N);
+    for (int i = 0; i < R; ++i) order.push_back(i);
+    size_t lo = 0;
+    bool identity = true;
+    std::vector<int> par;
+    for (int d = 0; d + 1 < n_td_levels; ++d) {
+        const size_t hi = order.size();
+        par.clear();
+        for (size_t q = lo; q < hi; ++q)
+            if (n_children[order[q]] > 0) par.push_back(order[q]);
+        std::stable_sort(par.begin(), par.end(), [&](int x, int y) { return cls[x] < cls[y]; });
+        for (int p : par)
+            for (int j = 0; j < n_children[p]; ++j) {
+                identity = identity && first_child[p] + j == (int)order.size();
+                order.push_back(first_child[p] + j);
+            }
+        lo = hi;
+    }
+    (void)td_offsets;
+    if (identity || (int)order.size() != N) return false;
+    old_of_new.swap(order);
+    new_of_old.assign(N, 0);
+    for (int q = 0; q < N; ++q) new_of_old[old_of_new[q]] = q;
+    return true;
+}
+
+// rows of `width` elements between the caller's numbering and the library's, for n_cols columns of N rows each
+template <typename T>
+static void rows_to_internal(const pml_ctx* ctx, const T* api, T* internal, size_t width, size_t n_cols) {
+    const size_t N = (size_t)ctx->N;
+    for (size_t c = 0; c < n_cols; ++c)
+        for (size_t q = 0; q < N; ++q)
+            memcpy(internal + (c * N + q) * width, api + (c * N + (size_t)ctx->old_of_new[q]) * width, width * sizeof(T));
+}
+
+template <typename T>
+static void rows_to_api(const pml_ctx* ctx, const T* internal, T* api, size_t width, size_t n_cols) {
+    const size_t N = (size_t)ctx->N;
+    for (size_t c = 0; c < n_cols; ++c)
+        for (size_t q = 0; q < N; ++q)
+            memcpy(api + (c * N + (size_t)ctx->old_of_new[q]) * width, internal + (c * N + q) * width, width * sizeof(T));
+}
+
+static inline bool permuted(const pml_ctx* ctx) { return !ctx->old_of_new.empty(); }
+
+// an output that was fetched in the library's numbering, put into the caller's in place (after the copy has been waited for)
+template <typename T>
+static void rows_to_api_inplace(const pml_ctx* ctx, T* buf, size_t width, size_t n_cols) {
+    if (!permuted(ctx) || buf == nullptr) return;
+    const std::vector<T> tmp(buf, buf + n_cols * (size_t)ctx->N * width);
+    rows_to_api(ctx, tmp.data(), buf, width, n_cols);
+}
+static inline int api_id(const pml_ctx* ctx, int internal) { return permuted(ctx) && internal >= 0 ? ctx->old_of_new[internal] : internal; }
+static inline int internal_id(const pml_ctx* ctx, int api) { return permuted(ctx) && api >= 0 ? ctx->new_of_old[api] : api; }
+
 // ---------------------------------------------------------------------------------------------------------------------
 extern "C" {
 
@@ -1437,6 +1536,13 @@ int pml_schedule_info(pml_ctx* ctx, int32_t* level_schedule, int32_t* n_two_leve
     return PML_OK;
 }
 
+int pml_tree_order(pml_ctx* ctx, int32_t* new_of_old) {
+    if (!ctx || ctx->N == 0) return fail(PML_ERR_INVALID, "upload the tree first");
+    if (!new_of_old) return fail(PML_ERR_INVALID, "new_of_old is NULL");
+    for (int i = 0; i < ctx->N; ++i) new_of_old[i] = permuted(ctx) ? ctx->new_of_old[i] : i;
+    return PML_OK;
+}
+
 int pml_sweep_schedule(pml_ctx* ctx, int32_t* kind, int32_t* n_blocks, int32_t* n_absorbed) {
     if (!ctx || ctx->C == 0) return fail(PML_ERR_INVALID, "allocate the columns first");
     const int model = ctx->kind;
@@ -1521,6 +1627,48 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
         }
     }
 
+    // ---- the library's own numbering (height_order): from here on every array is in it
+    std::vector<int> perm_old_of_new, perm_new_of_old;
+    std::vector<int32_t> p_parent, p_first_child, p_n_children, p_bu_order, p_td_parents, p_post_rank;
+    std::vector<double> p_dist;
+    if (!ctx->tune.on(T_NO_HEIGHT_ORDER) &&
+        height_order(n_nodes, n_roots, parent, first_child, n_children, td_offsets, n_td_levels, ctx->fuse, perm_old_of_new,
+                     perm_new_of_old)) {
+        const std::vector<int>& o = perm_old_of_new;
+        const std::vector<int>& nw = perm_new_of_old;
+        p_parent.resize(n_nodes);
+        p_first_child.resize(n_nodes);
+        p_n_children.resize(n_nodes);
+        p_post_rank.resize(n_nodes);
+        p_dist.resize(n_nodes);
+        for (int q = 0; q < n_nodes; ++q) {
+            const int old = o[q];
+            p_parent[q] = parent[old] >= 0 ? nw[parent[old]] : -1;
+            p_n_children[q] = n_children[old];
+            // (a tip's entry is never read; it only has to pass for an id)
+            p_first_child[q] = n_children[old] > 0 ? nw[first_child[old]] : 0;
+            p_post_rank[q] = post_rank[old];
+            p_dist[q] = dist[old];
+        }
+        p_bu_order.assign(n_internal > 0 ? n_internal : 1, 0);
+        p_td_parents.assign(n_internal > 0 ? n_internal : 1, 0);
+        for (int l = 0; l < n_bu_levels; ++l) {
+            for (int q = bu_offsets[l]; q < bu_offsets[l + 1]; ++q) p_bu_order[q] = nw[bu_order[q]];
+            std::sort(p_bu_order.begin() + bu_offsets[l], p_bu_order.begin() + bu_offsets[l + 1]);
+        }
+        for (int l = 0; l < n_td_levels; ++l) {
+            for (int q = td_parent_offsets[l]; q < td_parent_offsets[l + 1]; ++q) p_td_parents[q] = nw[td_parents[q]];
+            std::sort(p_td_parents.begin() + td_parent_offsets[l], p_td_parents.begin() + td_parent_offsets[l + 1]);
+        }
+        parent = p_parent.data();
+        first_child = p_first_child.data();
+        n_children = p_n_children.data();
+        post_rank = p_post_rank.data();
+        dist = p_dist.data();
+        bu_order = p_bu_order.data();
+        td_parents = p_td_parents.data();
+    }
+
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     // a new tree resets everything the ctx holds
@@ -1557,6 +1705,8 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
     ctx->prof_pool.swap(prof_pool);
     ctx->profile = profile;
     ctx->device = device;
+    ctx->old_of_new.swap(perm_old_of_new);
+    ctx->new_of_old.swap(perm_new_of_old);
 
     ctx->N = n_nodes;
     ctx->n_roots = n_roots;
@@ -2537,7 +2687,14 @@ int pml_masks_upload(pml_ctx* ctx, int32_t col_begin, int32_t col_end, const uin
         for (size_t i = ctx->W - 1; i < n; i += ctx->W)
             if (masks[i] & ~valid) return fail(PML_ERR_INVALID, "mask word %zu has bits beyond k = %d", i, ctx->k);
     }
-    PML_TRY(upload(ctx, ctx->d_masks + col_begin * per_col, (const u64*)masks, per_col * (col_end - col_begin)));
+    std::vector<u64> reordered;   // (the caller's rows in the library's numbering; alive until the copy below has been waited for)
+    const u64* src = (const u64*)masks;
+    if (permuted(ctx)) {
+        reordered.resize(per_col * (col_end - col_begin));
+        rows_to_internal(ctx, src, reordered.data(), (size_t)ctx->W, (size_t)(col_end - col_begin));
+        src = reordered.data();
+    }
+    PML_TRY(upload(ctx, ctx->d_masks + col_begin * per_col, src, per_col * (col_end - col_begin)));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     note_tips_observed(ctx, col_begin, col_end, false);
     invalidate(ctx);
@@ -2550,9 +2707,15 @@ int pml_masks_from_tip_states(pml_ctx* ctx, int32_t col_begin, int32_t col_end, 
     PML_TRY(materialize_tip_posteriors(ctx));
     if (n_tips < 0 || (n_tips > 0 && (!tip_ids || !states))) return fail(PML_ERR_INVALID, "bad tip arrays");
     const int nc = col_end - col_begin;
+    std::vector<int32_t> own_ids;   // the caller's tip ids in the library's numbering
     for (int j = 0; j < n_tips; ++j)
-        if (tip_ids[j] < 0 || tip_ids[j] >= ctx->N || ctx->h_n_children[tip_ids[j]] != 0)
+        if (tip_ids[j] < 0 || tip_ids[j] >= ctx->N || ctx->h_n_children[internal_id(ctx, tip_ids[j])] != 0)
             return fail(PML_ERR_INVALID, "tip_ids[%d] = %d is not a tip", j, tip_ids[j]);
+    if (permuted(ctx) && n_tips > 0) {
+        own_ids.resize(n_tips);
+        for (int j = 0; j < n_tips; ++j) own_ids[j] = ctx->new_of_old[tip_ids[j]];
+        tip_ids = own_ids.data();
+    }
     for (size_t i = 0; i < (size_t)nc * n_tips; ++i)
         if (states[i] >= ctx->k) return fail(PML_ERR_INVALID, "state %d out of range (k = %d)", states[i], ctx->k);
     dim3 grid(grid_for(ctx, (int)std::min<size_t>((size_t)ctx->N * ctx->W, 1u << 30), PML_BLOCK, nc), nc);
@@ -2610,7 +2773,14 @@ int pml_masks_initial_upload(pml_ctx* ctx, int32_t col_begin, int32_t col_end, c
         for (size_t i = ctx->W - 1; i < n; i += ctx->W)
             if (masks[i] & ~valid) return fail(PML_ERR_INVALID, "mask word %zu has bits beyond k = %d", i, ctx->k);
     }
-    PML_TRY(upload(ctx, ctx->d_masks_init + col_begin * per_col, (const u64*)masks, per_col * (col_end - col_begin)));
+    std::vector<u64> reordered;
+    const u64* src = (const u64*)masks;
+    if (permuted(ctx)) {
+        reordered.resize(per_col * (col_end - col_begin));
+        rows_to_internal(ctx, src, reordered.data(), (size_t)ctx->W, (size_t)(col_end - col_begin));
+        src = reordered.data();
+    }
+    PML_TRY(upload(ctx, ctx->d_masks_init + col_begin * per_col, src, per_col * (col_end - col_begin)));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->has_init = true;
     ctx->bu_mode = -1;
@@ -2766,11 +2936,15 @@ static int run_prep(pml_ctx* ctx, bool force = false) {
             // rows of the result a wave stages in LDS per flush (pml_kernels_pij.h)
             int srows = (int)ctx->tune.get(T_PIJ_STAGE_ROWS, 32);
             if (srows != 16 && srows != 64) srows = 32;
-            if (srows == 64 && ((size_t)KS * 4 * k + (size_t)PML_WAVES_PER_BLOCK * (PML_MFMA_CHUNK + 64) * KS * 4) * sizeof(double) > 64 * 1024)
-                srows = 32;  // (the default limit of dynamic LDS)
-            const size_t lds = ((size_t)KS * 4 * k + (size_t)PML_WAVES_PER_BLOCK * (PML_MFMA_CHUNK + srows) * KS * 4) * sizeof(double);
+            auto lds_of = [&](int sr) {
+                return ((size_t)KS * 4 * k + (size_t)PML_WAVES_PER_BLOCK * ((size_t)(PML_MFMA_CHUNK + sr) * KS * 4 + 64)) * sizeof(double);
+            };
+            if (srows == 64 && lds_of(64) > 64 * 1024) srows = 32;  // (the default limit of dynamic LDS)
+            const size_t lds = lds_of(srows);
             int blocks = (ctx->N + PML_WAVES_PER_BLOCK * PML_MFMA_CHUNK - 1) / (PML_WAVES_PER_BLOCK * PML_MFMA_CHUNK);
-            if (blocks > 4096) blocks = 4096;
+            // every wave walks several chunks: the block's set-up (Ainv to LDS, the fragments of A) is paid once
+            const int cap = std::max(64, (int)ctx->tune.get(T_PIJ_BLOCKS, 1024) / std::max(1, ctx->C));
+            if (blocks > cap) blocks = cap;
             dim3 grid(blocks, ctx->C);
             const int ablate = (int)ctx->tune.get(T_PIJ_ABLATE, 0);   // (measurements: 1 = no stores, 2 = no matrix instructions)
 #define PML_MFMA_CASE_R(NT_, KS_, SR_)                                                                             \
@@ -2878,6 +3052,7 @@ int pml_pij_batch(pml_ctx* ctx, double* P_out) {
         }
         (void)hipFree(d_out);
         if (e != hipSuccess) return fail(PML_ERR_HIP, "pml_pij_batch failed: %s", hipGetErrorString(e));
+        rows_to_api_inplace(ctx, P_out, kk, (size_t)ctx->C);
     }
     return PML_OK;
 }
@@ -3276,7 +3451,8 @@ static int collect_bottom_up(pml_ctx* ctx, int is_marginal, double* loglik_out, 
         int ep = -1, ec = -1;
         if (err[c] != ~0ull && flags[c] != 0.0) {  // (a column that sat the sweep out reports nothing)
             ec = (int)(err[c] & 0xffffffffull);
-            ep = ctx->h_parent[ec];
+            ep = api_id(ctx, ctx->h_parent[ec]);
+            ec = api_id(ctx, ec);
             if (status == PML_OK)
                 status = fail(PML_ZERO_LIKELIHOOD, "zero likelihood in column %d between parent %d and child %d", c, ep, ec);
         }
@@ -3549,6 +3725,9 @@ static int fetch_marginals(pml_ctx* ctx, double* posterior_out, double* lh_sum_o
         const double l2 = std::log10(2.0);
         for (size_t i = 0; i < CN; ++i) lh_sf_out[i] = -(double)lhe[i] * l2;
     }
+    rows_to_api_inplace(ctx, posterior_out, (size_t)ctx->k, (size_t)ctx->C);
+    rows_to_api_inplace(ctx, lh_sum_out, 1, (size_t)ctx->C);
+    rows_to_api_inplace(ctx, lh_sf_out, 1, (size_t)ctx->C);
     return PML_OK;
 }
 
@@ -3868,6 +4047,7 @@ static int fetch_joint_states(pml_ctx* ctx, int32_t* joint_state_out) {
         HIP_TRY(hipMemcpyAsync(joint_state_out, ctx->d_js, (size_t)ctx->C * ctx->N * sizeof(int), hipMemcpyDeviceToHost,
                                ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    rows_to_api_inplace(ctx, joint_state_out, 1, (size_t)ctx->C);
     return PML_OK;
 }
 
@@ -3949,6 +4129,7 @@ int pml_select_states(pml_ctx* ctx, int method, int force_joint, const uint64_t*
     const size_t CN = (size_t)ctx->C * ctx->N;
     if (!ctx->d_nsel) PML_TRY(dev_alloc(ctx, &ctx->d_nsel, CN));
     u64* d_lh_mask = nullptr;
+    std::vector<u64> lh_mask_own;   // (the caller's rows in the library's numbering, alive until the call has waited for its copies)
     if (lh_mask) {
         if (ctx->k % 64) {
             const u64 valid = (1ull << (ctx->k % 64)) - 1ull;
@@ -3956,6 +4137,11 @@ int pml_select_states(pml_ctx* ctx, int method, int force_joint, const uint64_t*
                 if (lh_mask[i] & ~valid) return fail(PML_ERR_INVALID, "lh_mask word %zu has bits beyond k", i);
         }
         HIP_TRY(hipMalloc((void**)&d_lh_mask, CN * ctx->W * sizeof(u64)));
+        if (permuted(ctx)) {
+            lh_mask_own.resize(CN * ctx->W);
+            rows_to_internal(ctx, (const u64*)lh_mask, lh_mask_own.data(), (size_t)ctx->W, (size_t)ctx->C);
+            lh_mask = (const uint64_t*)lh_mask_own.data();
+        }
         hipError_t e = hipMemcpyAsync(d_lh_mask, lh_mask, CN * ctx->W * sizeof(u64), hipMemcpyHostToDevice, ctx->stream);
         if (e != hipSuccess) {
             (void)hipFree(d_lh_mask);
@@ -3993,6 +4179,8 @@ int pml_select_states(pml_ctx* ctx, int method, int force_joint, const uint64_t*
     if (status != PML_OK) return fail(status, "no selection kernel for G=%d R=%d", ctx->G, ctx->R);
     if (e != hipSuccess) return fail(PML_ERR_HIP, "pml_select_states failed: %s", hipGetErrorString(e));
     if (e2 != hipSuccess) return fail(PML_ERR_HIP, "pml_select_states failed: %s", hipGetErrorString(e2));
+    rows_to_api_inplace(ctx, (u64*)masks_out, (size_t)ctx->W, (size_t)ctx->C);
+    rows_to_api_inplace(ctx, n_states_out, 1, (size_t)ctx->C);
     // the columns' masks changed: sweeps must be redone, the posteriors themselves stay valid for inspection
     ctx->prep_dirty = true;
     ctx->bu_mode = -1;
@@ -4049,7 +4237,32 @@ static int materialize_cherries(pml_ctx* ctx) {
     return PML_OK;
 }
 
+static int download_internal(pml_ctx* ctx, int what, int32_t col, void* out);
+
 int pml_download(pml_ctx* ctx, int what, int32_t col, void* out) {
+    PML_TRY(download_internal(ctx, what, col, out));   // rows in the library's numbering
+    if (permuted(ctx)) {
+        switch (what) {
+            case PML_BUF_BU:
+            case PML_BUF_TD:
+            case PML_BUF_POSTERIOR:
+                rows_to_api_inplace(ctx, (double*)out, (size_t)ctx->k, 1);
+                break;
+            case PML_BUF_JOINT_TABLE:
+                rows_to_api_inplace(ctx, (int32_t*)out, (size_t)ctx->k, 1);
+                break;
+            case PML_BUF_JOINT_STATE:
+                rows_to_api_inplace(ctx, (int32_t*)out, 1, 1);
+                break;
+            default:
+                rows_to_api_inplace(ctx, (double*)out, 1, 1);
+                break;
+        }
+    }
+    return PML_OK;
+}
+
+static int download_internal(pml_ctx* ctx, int what, int32_t col, void* out) {
     PML_TRY(require_model(ctx));
     if (col < 0 || col >= ctx->C || !out) return fail(PML_ERR_INVALID, "bad column / output");
     // (a pass that ended in a spin on the completion word may have left the stream busy, and the blocking copies below run
@@ -4343,7 +4556,18 @@ int pml_download_strided(pml_ctx* ctx, int what, int32_t col, int32_t first, int
         default:
             return fail(PML_ERR_INVALID, "pml_download_strided serves PML_BUF_POSTERIOR, _LH_SUM, _LH_SF, _JOINT_STATE");
     }
-    HIP_TRY(hipMemcpy2DAsync(out, row_bytes, src, src_row_bytes * stride, row_bytes, count, hipMemcpyDeviceToHost, ctx->stream));
+    if (permuted(ctx)) {
+        // the rows asked for are scattered in the library's numbering: one small copy each (src points at row `first` of the
+        // column; step back to the column's row 0 first)
+        const char* col0 = (const char*)src - (size_t)first * src_row_bytes;
+        for (int i = 0; i < count; ++i) {
+            const size_t row = (size_t)ctx->new_of_old[first + (size_t)i * stride];
+            HIP_TRY(hipMemcpyAsync((char*)out + (size_t)i * row_bytes, col0 + row * src_row_bytes, row_bytes, hipMemcpyDeviceToHost,
+                                   ctx->stream));
+        }
+    } else {
+        HIP_TRY(hipMemcpy2DAsync(out, row_bytes, src, src_row_bytes * stride, row_bytes, count, hipMemcpyDeviceToHost, ctx->stream));
+    }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (what == PML_BUF_LH_SF) {  // base-2 exponents -> the reference's base-10 scale, in place (same width)
         const double l2 = std::log10(2.0);

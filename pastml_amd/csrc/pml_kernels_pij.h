@@ -131,6 +131,7 @@ struct PijStage {
     static constexpr int KP = 4 * KS;
     static constexpr int ROWS = SROWS;
     static constexpr int DOUBLES = ROWS * KP;
+    static constexpr int WAVE_DOUBLES = DOUBLES + 64;   // + a slot per lane for the columns beyond ks
 };
 
 template <int NT, int KS, int SROWS, int ABLATE = 0>
@@ -147,7 +148,7 @@ pij_eigen_mfma_kernel(PmlTree t, PmlCols c, PmlModel m, double* __restrict__ P) 
     typedef PijStage<KS, SROWS> ST;
     typedef double dbl2 __attribute__((ext_vector_type(2)));
     double* sB = smem;                                  // Ainv padded: [KP][k]   (rows >= k are zero)
-    double* sE = sB + KP * k + wave * (PML_MFMA_CHUNK * KP + ST::DOUBLES);  // per wave: exp(d_m t_b)  [CHUNK][KP]
+    double* sE = sB + KP * k + wave * (PML_MFMA_CHUNK * KP + ST::WAVE_DOUBLES);  // per wave: exp(d_m t_b)  [CHUNK][KP]
     double* sO = sE + PML_MFMA_CHUNK * KP;              // per wave: staged rows of the result [ROWS][ks]
     const double* gA = m.A + (size_t)col * k * k;
     const double* gB = m.Ainv + (size_t)col * k * k;
@@ -180,37 +181,53 @@ pij_eigen_mfma_kernel(PmlTree t, PmlCols c, PmlModel m, double* __restrict__ P) 
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const int rows = nb * k;
         double* const chunk_out = P + (colN + b0) * (size_t)k * ks;   // rows (b, j) of the chunk, ks doubles each
+        // A operand row of this lane in the current tile: row r0 + lo = (branch qa, state ja), advanced by 16 rows per tile
+        // without a division (16 <= k: at most one wrap per step).  Rows beyond the chunk's last (a short last chunk) are
+        // computed from the zero rows of the exp table and never written.
+        int qa = 0, ja = lo;
+        if (ja >= k) {
+            ja -= k;
+            qa = 1;
+        }
         for (int g0 = 0; g0 < rows; g0 += ST::ROWS) {
             const int grows = min(ST::ROWS, rows - g0);
 #pragma unroll
             for (int tt = 0; tt < ST::ROWS / 16; ++tt) {
-                const int r0 = g0 + 16 * tt;
-                if (r0 >= rows) break;
-                // A operand row of this lane: (branch q, state j)
-                const int ra = r0 + lo;
-                const bool va = ra < rows;
-                const int qa = va ? ra / k : 0, ja = va ? ra % k : 0;
+                if (g0 + 16 * tt >= rows) break;
+                // the left factor of the tile's rows: Ainv[m][ja] exp(d_m t_qa), all K steps read before the first product
+                double a[KS];
+                {
+                    const double* pb = sB + ja;
+                    const double* pe = sE + min(qa, PML_MFMA_CHUNK - 1) * KP;
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) a[s] = pb[(4 * s + hi) * k] * pe[4 * s + hi];
+                }
+                ja += 16;
+                if (ja >= k) {
+                    ja -= k;
+                    ++qa;
+                }
                 pml_v4f64 acc[NT];
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) acc[nt] = (pml_v4f64){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                 for (int s = 0; s < KS; ++s) {
-                    const int mm = 4 * s + hi;
-                    const double a = va ? sB[mm * k + ja] * sE[qa * KP + mm] : 0.0;
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
-                        if (ABLATE == 2) acc[nt][0] += a * bfrag[nt][s];   // (measurement only: no matrix instructions)
-                        else acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bfrag[nt][s], acc[nt], 0, 0, 0);
+                        if (ABLATE == 2) acc[nt][0] += a[s] * bfrag[nt][s];   // (measurement only: no matrix instructions)
+                        else acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], bfrag[nt][s], acc[nt], 0, 0, 0);
                     }
                 }
-                // D: row = hi + 4 * reg, col = lo  ->  staged row (r0 - g0) + hi + 4 reg, columns 16 nt + lo
+                // D: row = hi + 4 * reg, col = lo  ->  staged row 16 tt + hi + 4 reg, columns 16 nt + lo
+                // (a lane whose column lies beyond ks writes to a slot of its own behind the staged rows instead of branching)
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
                     double* srow = sO + (16 * tt + hi + 4 * reg) * ks;
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
                         const int i = 16 * nt + lo;
-                        if (i < ks) srow[i] = acc[nt][reg];  // columns k..ks-1 are exact zeros (zero B fragments)
+                        double* dst = i < ks ? srow + i : sO + ST::DOUBLES + lane;
+                        *dst = acc[nt][reg];  // columns k..ks-1 are exact zeros (zero B fragments)
                     }
                 }
             }

@@ -71,6 +71,7 @@ SIGNATURES = {
     'pml_ctx_memory': [_ctx_p, _c_uint64_p, _c_uint64_p],
     'pml_schedule_info': [_ctx_p, _c_int32_p, _c_int32_p, _c_int32_p],
     'pml_sweep_schedule': [_ctx_p, _c_int32_p, _c_int32_p, _c_int32_p],
+    'pml_tree_order': [_ctx_p, _c_int32_p],
     'pml_tree_upload': [_ctx_p, ctypes.c_int32, ctypes.c_int32, _c_int32_p, _c_int32_p, _c_int32_p, _c_double_p,
                         ctypes.c_int32, _c_int32_p, _c_int32_p, ctypes.c_int32, _c_int32_p, _c_int32_p, _c_int32_p,
                         _c_int32_p],
@@ -359,6 +360,13 @@ class BareContext(object):
         a, b, c = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0)
         _check(self._lib.pml_sweep_schedule(self._ctx, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
         return a.value, b.value, c.value
+
+    def node_order(self):
+        """new_of_old: the library's id of every node of the forest as it was uploaded (pml_tree_order); the identity unless
+        pml_tree_upload renumbered a ragged forest into height order."""
+        out = np.empty(self.n_nodes, dtype=np.int32)
+        _check(self._lib.pml_tree_order(self._ctx, _ptr(out, ctypes.c_int32)))
+        return out
 
     def comm_init(self, rank, world, unique_id=None):
         """Attaches a communicator (RCCL for world > 1; unique_id: the 128 bytes of rank 0's comm_unique_id())."""

@@ -741,6 +741,21 @@ class FlatForest(object):
                 n.name = 't{}_{}'.format(ti, i) if n.is_leaf() else 'n{}_{}'.format(ti, i)
         return cls.from_trees(roots)
 
+    def renumbered(self, new_of_old):
+        """
+        The same forest under another breadth-first numbering (new_of_old[i] = the new id of node i; the order of the sibling
+        groups inside a depth may differ, a node's own children keep their order) -- e.g. the numbering the device library
+        works in, ``Engine.node_order()``.  Arrays only: ``nodes`` and columns stay with this forest.
+        """
+        new_of_old = np.asarray(new_of_old, dtype=np.int64)
+        old_of_new = np.empty_like(new_of_old)
+        old_of_new[new_of_old] = np.arange(self.n_nodes)
+        parent = self.parent[old_of_new].astype(np.int64)
+        parent = np.where(parent >= 0, new_of_old[np.maximum(parent, 0)], -1)
+        n_children = self.n_children[old_of_new]
+        first_child = np.where(n_children > 0, new_of_old[np.minimum(self.first_child[old_of_new], self.n_nodes - 1)], 0)
+        return FlatForest(parent, n_children, first_child, self.dist[old_of_new], np.arange(len(self.roots)))
+
     def children_of(self, i):
         a = self.first_child[i]
         return range(a, a + self.n_children[i])

@@ -894,9 +894,9 @@ def test_byte_model_counts_the_units_the_library_schedules(monkeypatch):
                 monkeypatch.delenv(var, raising=False)
         for flat in forests:
             for k, n_cols in ((64, 64), (64, 1), (33, 16), (20, 64)):
-                sb = bench.schedule_bytes(flat, k, n_cols)
                 with hip.Engine(flat, n_cols, k) as eng:
                     on, n2, ns = eng.schedule_info()
+                    sb = bench.schedule_bytes(bench.library_forest(eng, flat), k, n_cols)   # (the library's own numbering)
                 if forced and not on:
                     continue    # (forced thresholds only matter where the level schedule runs at all)
                 assert (n2, ns) == (sb['n_two_level'], sb['n_stacked']), (flat.n_tips, k, n_cols, forced, on, n2, ns)

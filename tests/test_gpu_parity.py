@@ -863,6 +863,86 @@ def test_sweep_of_some_columns_leaves_the_others_alone(n_tips, cols, k):
     assert not np.array_equal(before, after)
 
 
+@pytest.mark.parametrize('kind,k,n_tips,arity,n_trees', [('F81', 4, 3000, 2, 1), ('F81', 12, 900, 4, 3), ('F81', 64, 5000, 2, 1),
+                                                         ('F81', 70, 600, 3, 2), ('HKY', 4, 700, 3, 1), ('EIGEN', 7, 500, 3, 2),
+                                                         ('EIGEN', 20, 2500, 2, 1)])
+def test_height_order_is_invisible_at_the_boundary(kind, k, n_tips, arity, n_trees):
+    """
+    pml_tree_upload renumbers a ragged forest into height order (pml_tree_order); every per-node array of the interface
+    stays in the caller's numbering.  Against a context that keeps the caller's numbering (NO_HEIGHT_ORDER): the same bits
+    in everything that crosses the boundary -- masks in (words and tip states), ln L, the whole-table outputs, every
+    download (whole and strided), joint states and tables, the device selection with likelihood masks, the P(t) batch.
+    """
+    rng = np.random.default_rng(k * 1000 + n_tips)
+    flat = FlatForest.random(n_tips, seed=k + n_tips, max_arity=arity, zero_frac=0.0, n_trees=n_trees)
+    cols = 3
+    masks = np.stack([random_masks(flat, k, rng) for _ in range(cols)])
+    lh_masks = (rng.random((cols, flat.n_nodes, k)) < 0.8).astype(np.int8)
+    lh_masks[..., 0] = 1
+    specs = [(random_spec(kind, k, rng), (float(rng.uniform(0.5, 3)), 0.0, 1.0)) for _ in range(cols)]
+    tips = np.stack([rng.integers(0, k, size=flat.n_tips) for _ in range(cols)])
+    out = {}
+    for name, tune in (('plain', dict(NO_HEIGHT_ORDER=1)), ('ordered', {})):
+        got = {}
+        with hip.Engine(flat, cols, k, tune=tune) as eng:
+            order = eng.node_order()
+            got_identity = np.array_equal(order, np.arange(flat.n_nodes))
+            assert got_identity == (name == 'plain')
+            assert np.array_equal(np.sort(order), np.arange(flat.n_nodes))
+            eng.set_models(specs)
+            eng.set_tip_states(tips)
+            got['lnl_tips'] = eng.bottom_up(True)
+            got['bu_tips'] = eng.download(hip.BUF_BU, 1)
+            eng.set_masks(masks)
+            lnl, post, lh_sum, lh_sf = eng.marginal_pass()
+            got.update(lnl=lnl, post=post, lh_sum=lh_sum, lh_sf=lh_sf)
+            for what in (hip.BUF_BU, hip.BUF_BU_SF, hip.BUF_TD, hip.BUF_TD_SF, hip.BUF_POSTERIOR, hip.BUF_LH_SUM, hip.BUF_LH_SF):
+                got['dl%d' % what] = eng.download(what, 2)
+            if kind == 'F81':
+                got['exp'] = eng.download(hip.BUF_BRANCH_EXP, 0)
+            for what in (hip.BUF_POSTERIOR, hip.BUF_LH_SUM, hip.BUF_LH_SF):
+                got['st%d' % what] = eng.download_strided(what, 1, 3, 7)
+                assert np.array_equal(got['st%d' % what], eng.download(what, 1)[3::7])
+            jl, js = eng.joint_pass()
+            got.update(jl=jl, js=js, jt=eng.download(hip.BUF_JOINT_TABLE, 0), js_dl=eng.download(hip.BUF_JOINT_STATE, 2),
+                       js_st=eng.download_strided(hip.BUF_JOINT_STATE, 2, 1, 5))
+            eng.bottom_up(True)
+            eng.top_down_marginals(posterior=False, lh=False)
+            sel, nsel = eng.select_states('MPPA', force_joint=True, lh_masks=lh_masks)
+            got.update(sel=sel, nsel=nsel)
+            if kind != 'F81' and k <= 20:
+                eng.set_models(specs)
+                got['pij'] = eng.pij_batch(copy_out=True)
+        out[name] = got
+    for key, want in out['plain'].items():
+        assert np.array_equal(want, out['ordered'][key], equal_nan=True), key
+    assert np.array_equal(out['ordered']['js'][2], out['ordered']['js_dl'])
+
+
+def test_zero_likelihood_report_names_the_callers_nodes():
+    """The ids of a PML_ZERO_LIKELIHOOD report are the caller's, whatever numbering the library works in."""
+    flat = FlatForest.random(400, seed=5, max_arity=3, zero_frac=0.0, n_trees=1)
+    k = 4
+    # a zero-length branch between two nodes with different single states: the reference's zero-likelihood case
+    child = int(flat.tips[37])
+    par = int(flat.parent[child])
+    dist = np.array(flat.dist)
+    dist[child] = 0.0
+    bad = FlatForest(flat.parent, flat.n_children, flat.first_child, dist, flat.roots)
+    masks = np.ones((bad.n_nodes, k), dtype=np.int8)
+    masks[child] = [1, 0, 0, 0]
+    masks[par] = [0, 1, 0, 0]
+    seen = []
+    for tune in (dict(NO_HEIGHT_ORDER=1), {}):
+        with hip.Engine(bad, 1, k, tune=tune) as eng:
+            eng.set_models([(dict(kind=0, pi=np.ones(k) / k), (1.0, 0.0, 1.0))])
+            eng.set_masks(masks)
+            with pytest.raises(hip.ZeroLikelihoodError) as e:
+                eng.bottom_up(True)
+            seen.append((int(e.value.err_parent[0]), int(e.value.err_child[0])))
+    assert seen[0] == seen[1] == (par, child)
+
+
 @pytest.mark.parametrize('parts', [2, 3])
 def test_split_marginal_pass_has_the_same_bits(parts):
     """
