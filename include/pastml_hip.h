@@ -306,11 +306,12 @@ int pml_device_sync(int device);
  * tau_out, tf_out [n + 1] (row 0 = x itself) and steps_out[n] = (x_i + h_i) - x_i, the divisors of the differences.
  * Returns PML_OK, or PML_ERR_UNSUPPORTED when some x_i + h_i leaves [lower_i, upper_i] or equals x_i (scipy then mirrors
  * or rescales the step: the caller takes its general path) -- nothing is written in that case.
+ * step: the absolute step h (1e-8 = scipy's; the polish run of a many-parameter search takes 1e-6).
  */
 int pml_host_f81_fd_points(int32_t n, int32_t k, const double* x, const double* lower, const double* upper, int32_t opt_sf,
                            int32_t opt_tau, int32_t free_pi, double sf_fixed, double tau_fixed, const double* pi_fixed,
                            double forest_length, double num_nodes, double* pi_out, double* sf_out, double* tau_out,
-                           double* tf_out, double* steps_out);
+                           double* tf_out, double* steps_out, double step);
 
 /* ---- inspection ------------------------------------------------------------------------------------------------------ */
 int pml_download(pml_ctx* ctx, int what, int32_t col, void* out);

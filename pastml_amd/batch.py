@@ -793,10 +793,10 @@ def search_parameters_steps(model, observed_frequencies, rng, trace=None):
         ps = np.asarray(ps, dtype=np.float64)
         if np.isnan(ps).any():
             return np.nan, np.full(len(ps), np.nan)
-        if fd_block is not None and step == 1e-8:
+        if fd_block is not None:
             # F81 family: the points of the gradient, decoded, in one call into the library (host arithmetic; the numbers of
             # two_point_scheme + kernel_points)
-            made = fd_block(ps, lower_c, upper_c)
+            made = fd_block(ps, lower_c, upper_c, step)
             if made is not None:
                 block, steps = made
                 values = negative((yield block))

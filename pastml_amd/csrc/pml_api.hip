@@ -2943,7 +2943,7 @@ static int run_prep(pml_ctx* ctx, bool force = false) {
             const size_t lds = lds_of(srows);
             int blocks = (ctx->N + PML_WAVES_PER_BLOCK * PML_MFMA_CHUNK - 1) / (PML_WAVES_PER_BLOCK * PML_MFMA_CHUNK);
             // every wave walks several chunks: the block's set-up (Ainv to LDS, the fragments of A) is paid once
-            const int cap = std::max(64, (int)ctx->tune.get(T_PIJ_BLOCKS, 1024) / std::max(1, ctx->C));
+            const int cap = std::max(64, (int)ctx->tune.get(T_PIJ_BLOCKS, 2048) / std::max(1, ctx->C));
             if (blocks > cap) blocks = cap;
             dim3 grid(blocks, ctx->C);
             const int ablate = (int)ctx->tune.get(T_PIJ_ABLATE, 0);   // (measurements: 1 = no stores, 2 = no matrix instructions)
@@ -4479,13 +4479,14 @@ static double np_pairwise_sum(const double* a, int n) {
 int pml_host_f81_fd_points(int32_t n, int32_t k, const double* x, const double* lower, const double* upper, int32_t opt_sf,
                            int32_t opt_tau, int32_t free_pi, double sf_fixed, double tau_fixed, const double* pi_fixed,
                            double forest_length, double num_nodes, double* pi_out, double* sf_out, double* tau_out,
-                           double* tf_out, double* steps_out) {
+                           double* tf_out, double* steps_out, double step) {
     if (n < 0 || k < 1 || !x || !lower || !upper || !pi_out || !sf_out || !tau_out || !tf_out || (n > 0 && !steps_out))
         return fail(PML_ERR_INVALID, "NULL array / bad sizes");
     if (n != (opt_sf ? 1 : 0) + (opt_tau ? 1 : 0) + (free_pi ? k - 1 : 0))
         return fail(PML_ERR_INVALID, "n = %d does not match the parameter layout", n);
     if (!free_pi && !pi_fixed) return fail(PML_ERR_INVALID, "pi_fixed is NULL");
-    const double h = 1e-8;
+    if (!(step > 0.0)) return fail(PML_ERR_INVALID, "step must be positive");
+    const double h = step;
     for (int i = 0; i < n; ++i) {
         const volatile double moved = x[i] + h;   // (scipy: the step as the floating-point numbers see it)
         const double step = moved - x[i];

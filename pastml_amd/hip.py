@@ -110,7 +110,7 @@ SIGNATURES = {
     'pml_device_sync': [ctypes.c_int],
     'pml_host_f81_fd_points': [ctypes.c_int32, ctypes.c_int32] + [ctypes.c_void_p] * 3 + [ctypes.c_int32] * 3 +
                               [ctypes.c_double, ctypes.c_double, ctypes.c_void_p, ctypes.c_double, ctypes.c_double] +
-                              [ctypes.c_void_p] * 5,
+                              [ctypes.c_void_p] * 5 + [ctypes.c_double],
     'pml_download_strided': [_ctx_p, ctypes.c_int, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                              ctypes.c_void_p],
     'pml_timer_start': [_ctx_p],

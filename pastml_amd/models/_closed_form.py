@@ -76,10 +76,10 @@ class F81Model(ModelWithFrequencies):
         return PointBlock(KIND_F81, np.ascontiguousarray(pi), np.array(sf, dtype=np.float64), tau, factor)
 
 
-    def fd_block(self, ps, lower, upper):
+    def fd_block(self, ps, lower, upper, step=1e-8):
         """
         The points of one forward-difference gradient around the optimiser vector ``ps`` (scipy's 2-point scheme with the
-        absolute step 1e-8), decoded: (PointBlock of len(ps) + 1 points -- ps itself first --, steps to divide by), or None
+        absolute step ``step``: 1e-8 is scipy's), decoded: (PointBlock of len(ps) + 1 points -- ps itself first --, steps to divide by), or None
         when the library's helper does not take the case (a step that leaves the bounds, smoothed frequencies, ...) and the
         caller goes through two_point_scheme + kernel_points.  One call into libpastml_hip (pml_host_f81_fd_points, host
         arithmetic only) instead of two dozen small numpy operations per optimiser round; the same numbers, bit for bit
@@ -113,7 +113,7 @@ class F81Model(ModelWithFrequencies):
         if fixed.dtype != np.float64 or not fixed.flags.c_contiguous:
             fixed = np.ascontiguousarray(fixed, dtype=np.float64)
         if call(n, pi.shape[1], x.ctypes.data, lower.ctypes.data, upper.ctypes.data, *flags, float(self._sf), float(self._tau),
-                fixed.ctypes.data, *tail) != 0:
+                fixed.ctypes.data, *tail, float(step)) != 0:
             return None
         if flags[0]:
             self._sf = rows[0, -1]

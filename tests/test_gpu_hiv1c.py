@@ -32,17 +32,11 @@ def inputs():
     return tree, df
 
 
-# The one column whose optimum ours misses by more than 1e-6 relative (round 4: signed differences, all 91 columns): 'Year',
-# k = 30, -4.2e-6 (0.033 in ln L).  Both searches end on the relative-reduction test of L-BFGS-B (ftol 2.2e-9) in a flat valley,
-# after 139 (ours) and 153 (reference) iterations of the 30-parameter stage; the paths part at the first iterate, because the
-# stage starts at the optimum of the one-parameter stage, which the two searches place 4e-6 apart in the scaling factor (the values there agree to 1e-11: the optimum is flat) (fixture
-# hiv1c_year_trace.npz: the reference's own iterates; scripts/r04_year_trace.py).  Where such a search ends is a heavy-tailed
-# random variable: of 16 runs of ours whose start points are moved by j * 1e-12, 13 end within 1.4e-6 of the reference's optimum
-# (median 1.5e-7) and three stop early on a plateau -- the unperturbed run is one of those (profiles/r04e_year_optimiser_path.txt;
-# the reference's own two runs, hiv1c_year_trace_perturbed.npz, are 3e-9 apart: two typical ones).  Not an arithmetic difference:
-# at the reference's parameters ln L agrees to 1e-10 (test_all_columns_at_the_reference_optima), and along a line through the
-# optimum our ln L is as smooth as the numpy restatement's or smoother (scripts/r04_noise.py).
-KNOWN_SHORTFALL = {'Year': 1e-5}
+# Round 4 had one column whose optimum missed the reference's by more than 1e-6 relative: 'Year', k = 30, -4.2e-6 (0.033 in
+# ln L) -- both searches end on the relative-reduction test of L-BFGS-B (ftol 2.2e-9) in a flat valley, and where such a search
+# ends is a heavy-tailed random variable (profiles/r04e_year_optimiser_path.txt).  Round 5: searches of 20 and more parameters
+# polish their accepted optimum (pastml_amd/batch.py, "The end of a many-parameter search"; profiles/r05b_year_polish.txt), and
+# every column is held to north_star's 1e-6 -- no exceptions.
 
 
 def test_all_columns_with_parameter_optimisation():
@@ -77,7 +71,7 @@ def test_all_columns_with_parameter_optimisation():
         # 1e-6 relative (L-BFGS-B stops where its own tolerances say so: the reference's optima of the three identically
         # partitioned Country columns differ by 1e-4 among themselves; binary columns agree to 1e-12 relative)
         signed.append(((res[LOG_LIKELIHOOD] - ref) / max(1.0, abs(ref)), column, k))
-        assert res[LOG_LIKELIHOOD] >= ref - KNOWN_SHORTFALL.get(column, 1e-6) * max(1.0, abs(ref)), \
+        assert res[LOG_LIKELIHOOD] >= ref - 1e-6 * max(1.0, abs(ref)), \
             '{}: our optimum {:.9f} is worse than the reference\'s {:.9f}'.format(column, res[LOG_LIKELIHOOD], ref)
         assert res[LOG_LIKELIHOOD] <= ref + 2e-5 * max(1.0, abs(ref)), column
         if k == 2:
@@ -141,11 +135,12 @@ def test_all_columns_at_the_reference_optima():
 
 def test_year_optimiser_path_against_the_reference():
     """
-    The optimiser's path on the column with the largest shortfall ('Year', k = 30) against the reference's own L-BFGS-B runs
+    The optimiser's path on the column that had the largest shortfall ('Year', k = 30) against the reference's own L-BFGS-B runs
     (hiv1c_year_trace.npz: make_golden.py wraps the `minimize` that pastml/ml.py:231 calls): the one-parameter stage ends at
     the same optimum (1e-10), with the same number of iterations; the 30-parameter stage starts from the same point up to the
-    position of that flat optimum (4e-6), converges by the same test, and ends within the documented 1e-5 of the reference's value --
-    and the reference's two runs (start points as they are / moved by 1e-12) bracket nothing tighter than 3e-9.
+    position of that flat optimum (4e-6) and converges by the same test -- the reference's procedure, untouched.  Then the
+    polish run (step 1e-6, continued once at ftol / 10) takes the accepted optimum past the reference's: the result is at
+    least the reference's value minus 1e-6 relative.  The one-parameter stage is never polished.
     """
     from pastml_amd import batch
     z, zp = load_golden('hiv1c_year_trace'), load_golden('hiv1c_year_trace_perturbed')
@@ -161,11 +156,16 @@ def test_year_optimiser_path_against_the_reference():
     first, second = runs
     assert len(first['x0']) == 1 and len(second['x0']) == 30
     np.testing.assert_allclose(first['fun'], float(z['run0_fun']), rtol=1e-10)
-    assert first['nit'] == int(z['run0_nit'])
+    assert first['nit'] == int(z['run0_nit']) and 'polish' not in first and first['continued_at'] is None
     np.testing.assert_allclose(first['x'], z['run0_x'], rtol=1e-5)             # (a flat optimum: 4e-6 apart, values 1e-11)
     np.testing.assert_allclose(second['x0'], z['run1_x0'], rtol=1e-5)          # (the stage starts where the first one ended)
-    assert 'RELATIVE REDUCTION OF F' in str(z['run1_message'])
-    assert abs(res[LOG_LIKELIHOOD] - float(z['loglik'])) <= 1e-5 * abs(float(z['loglik']))
-    assert abs(float(zp['loglik']) - float(z['loglik'])) <= 1e-8 * abs(float(z['loglik']))
+    assert 'RELATIVE REDUCTION OF F' in str(z['run1_message']) and second['reason'] == batch.RELATIVE_REDUCTION
+    assert second['continued_at'] is None                                      # (the reference's run as it is)
     # the values along our path never increase by more than rounding (a line search accepts decreases only)
     assert np.all(np.diff(second['values']) <= 1e-9 * np.abs(second['values'][:-1]))
+    polish = second['polish']
+    assert np.array_equal(polish['x0'], second['x']) and polish['fun'] <= second['fun']
+    assert np.all(np.diff(polish['values']) <= 1e-9 * np.abs(polish['values'][:-1]))
+    assert res[LOG_LIKELIHOOD] == -min(polish['fun'], second['fun'])
+    assert res[LOG_LIKELIHOOD] >= float(z['loglik']) - 1e-6 * abs(float(z['loglik']))
+    assert abs(float(zp['loglik']) - float(z['loglik'])) <= 1e-8 * abs(float(z['loglik']))
