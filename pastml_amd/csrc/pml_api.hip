@@ -71,7 +71,7 @@ static int fail(int code, const char* fmt, ...) {
     X(STACK_MIN, 0, 1) X(NO_STACK, 1, 1) X(DEBUG, 1, 0) X(BLOCK_NODES, 0, 1) X(BLOCK_MAX_STORED, 0, 1)                 \
     X(BLOCK_HEIGHT_CAP, 0, 1) X(SMALL_MAX_NODES, 0, 1) X(F81_R, 0, 1) X(F81_TD_R, 0, 1) X(NO_GRAPH, 1, 1)              \
     X(NARROW_UNITS, 0, 0) X(NO_EIGG_TIERS, 1, 0) X(NO_ABSORB, 1, 1) X(ABSORB_MIN, 0, 1) X(NO_SPIN_WAIT, 1, 0)   \
-    X(SPLIT_PARTS, 0, 0) X(PIJ_STAGE_ROWS, 0, 0) X(PIJ_ABLATE, 0, 0) X(PIJ_BLOCKS, 0, 0) X(NO_HEIGHT_ORDER, 1, 1)
+    X(SPLIT_PARTS, 0, 0) X(PIJ_STAGE_ROWS, 0, 0) X(PIJ_ABLATE, 0, 0) X(PIJ_BLOCKS, 0, 0) X(NO_HEIGHT_ORDER, 1, 1) X(NO_TD_TAIL, 1, 0)
 enum PmlTunable {
 #define X(name, flag, tree) T_##name,
     PML_TUNABLES(X)
@@ -700,7 +700,7 @@ static void launch_sweep_f81(pml_ctx* ctx, SweepKind what, const int* level, int
 // a large one (bottom-up: levels first_level .. end, then ln L; top-down: roots, then levels 0 .. n_levels - 1).
 template <int G, int R>
 static void launch_small_f81(pml_ctx* ctx, bool bottom_up, int do_prep, const PmlUnit* units, const int* d_offsets,
-                             int n_levels, int reset_err) {
+                             int n_levels, int reset_err, int skip_roots) {
     const PmlTree t = tree_of(ctx, true);
     const PmlCols c = cols_of(ctx);
     const PmlState st = state_of(ctx);
@@ -719,7 +719,7 @@ static void launch_small_f81(pml_ctx* ctx, bool bottom_up, int do_prep, const Pm
         const bool signal = ctx->signal_next_td && ctx->C <= 64 && !ctx->windowed && !ctx->tune.on(T_NO_SPIN_WAIT);
         ctx->signal_next_td = false;
         hipLaunchKernelGGL((td_f81_small_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, units, d_offsets,
-                           n_levels, signal ? ctx->d_done : nullptr, signal ? ctx->h_done : nullptr);
+                           n_levels, signal ? ctx->d_done : nullptr, signal ? ctx->h_done : nullptr, skip_roots);
         ctx->td_final_signals = signal;
         if (signal) ++ctx->signals_enqueued;
     }
@@ -802,7 +802,7 @@ static void multi_level_shape(const pml_ctx* ctx, bool bottom_up, int& g, int& r
 
 // units / d_offsets: the level table to walk (default: the fused lists of the whole forest from first_level on)
 static int dispatch_small_f81(pml_ctx* ctx, bool bottom_up, int do_prep, int first_level = 0, int n_levels = -1,
-                              const PmlUnit* units = nullptr, const int* d_offsets = nullptr) {
+                              const PmlUnit* units = nullptr, const int* d_offsets = nullptr, int skip_roots = 0) {
     int g, r;
     multi_level_shape(ctx, bottom_up, g, r);
     if (n_levels < 0) n_levels = bottom_up ? (int)ctx->bu_offsets_f.size() - 1 - first_level : ctx->n_td_levels;
@@ -812,11 +812,11 @@ static int dispatch_small_f81(pml_ctx* ctx, bool bottom_up, int do_prep, int fir
         // code -- walk_levels; a forest this small sits in the L2, where its rows lie does not matter)
         const bool sorted = ctx->d_bu_units_fs != nullptr && g < 8 && !ctx->tune.on(T_NO_SHAPE_SORT);
         units = bottom_up ? (sorted ? ctx->d_bu_units_fs : ctx->d_bu_units_f) : (sorted ? ctx->d_td_units_fs : ctx->d_td_units_f);
-        d_offsets = bottom_up ? ctx->d_bu_offsets_f + first_level : ctx->d_td_parent_offsets_f;
+        d_offsets = bottom_up ? ctx->d_bu_offsets_f + first_level : ctx->d_td_parent_offsets_f + first_level;
     }
 #define X(G_, R_)                                                                                   \
     if (g == G_ && r == R_) {                                                                       \
-        launch_small_f81<G_, R_>(ctx, bottom_up, do_prep, units, d_offsets, n_levels, reset_err);   \
+        launch_small_f81<G_, R_>(ctx, bottom_up, do_prep, units, d_offsets, n_levels, reset_err, skip_roots);   \
         HIP_TRY(hipGetLastError());                                                                 \
         return PML_OK;                                                                              \
     }
@@ -3065,9 +3065,19 @@ int pml_pij_batch(pml_ctx* ctx, double* P_out) {
 // level over the whole chip, win earlier: the limit shrinks with the number of columns.
 // The fused eigen sweeps pass their own limit: a pass of theirs is a ~10 us dependent chain, so only levels that one
 // workgroup finishes in a single pass per wave belong to the narrow end.
-static int narrow_levels(const pml_ctx* ctx, const std::vector<int>& off, int n_levels, bool from_front, int C, int fixed_limit = 0) {
+static int narrow_levels(const pml_ctx* ctx, const std::vector<int>& off, int n_levels, bool from_front, int C, int fixed_limit = 0,
+                         int top_down = -1) {
     const int limit_env = (int)ctx->tune.get(T_NARROW_UNITS, 0);
-    const int limit = fixed_limit > 0 ? fixed_limit : (limit_env > 0 ? limit_env : std::max(8, 512 / std::max(1, C)));
+    int limit = fixed_limit > 0 ? fixed_limit : (limit_env > 0 ? limit_env : std::max(8, 512 / std::max(1, C)));
+    if (fixed_limit <= 0 && limit_env <= 0 && ctx->kind == PML_MODEL_F81) {
+        // ... but never below half a pass of the walking workgroup (512 threads, g lanes per unit): such a level is one
+        // wavefront's work per SIMD either way, and a launch of its own costs 5 - 10 us where a level step inside the
+        // walk costs 2.  Random 262 144-tip tree x 32 characters, marginal pass: k = 4 1.66 -> 1.52 ms, k = 12 2.56 -> 2.37,
+        // k = 64 unchanged (profiles/r05j_narrow_units.txt, r05l_narrow_ab.txt); same bits (multi_level_shape).
+        const bool td = top_down < 0 ? from_front : top_down != 0;   // (which sweep's lane shape walks the levels)
+        const int g = td ? ctx->Gt : (ctx->bu_wide_lanes ? 8 : ctx->Gf);
+        limit = std::max(limit, 256 / std::max(1, g));
+    }
     int n = 0;
     for (int q = 0; q < n_levels; ++q) {
         const int l = from_front ? q : n_levels - 1 - q;
@@ -3621,7 +3631,16 @@ static int run_top_down(pml_ctx* ctx) {
             PML_TRY(prof_end(ctx, 1, n_launch));
             return PML_OK;
         }
-        for (int l = head; l < (td_small ? 0 : ctx->n_td_levels); ++l) {
+        // F81 family: the thin depths at the DEEP end of a ragged forest (a handful of parents each) in one launch as well
+        // -- a launch of their own costs 9 - 11 us each, a level step of the walk 2 - 3 (round 5)
+        int tail = 0;
+        // (units of fewer than 8 lanes only: at k = 64 a level step inside the walk costs what the launch does)
+        if (td_fused && !td_small && ctx->Gt < 8 && !ctx->tune.on(T_NO_TD_TAIL)) {
+            tail = narrow_levels(ctx, ctx->td_parent_offsets_f, ctx->n_td_levels, false, ctx->C, 0, 1);
+            if (tail > ctx->n_td_levels - head) tail = ctx->n_td_levels - head;
+            if (tail < 2) tail = 0;
+        }
+        for (int l = head; l < (td_small ? 0 : ctx->n_td_levels - tail); ++l) {
             const std::vector<int>& off = td_fused ? ctx->td_parent_offsets_f : ctx->td_parent_offsets;
             const int a = off[l], b = off[l + 1];
             PML_TRY(dispatch_sweep(ctx, td_fused ? SW_TD_FUSED : SW_TD,
@@ -3629,6 +3648,7 @@ static int run_top_down(pml_ctx* ctx) {
             if (b > a) ++n_launch;
         }
         PML_TRY(prof_end(ctx, 1, n_launch));
+        if (tail > 0) PML_TRY(dispatch_small_f81(ctx, false, 0, ctx->n_td_levels - tail, tail, nullptr, nullptr, 1));
         return PML_OK;
     };
     if (ctx->graphs && !ctx->profile && !td_small && ctx->n_td_levels >= 4) {
@@ -4561,10 +4581,20 @@ int pml_download_strided(pml_ctx* ctx, int what, int32_t col, int32_t first, int
         // the rows asked for are scattered in the library's numbering: one small copy each (src points at row `first` of the
         // column; step back to the column's row 0 first)
         const char* col0 = (const char*)src - (size_t)first * src_row_bytes;
-        for (int i = 0; i < count; ++i) {
-            const size_t row = (size_t)ctx->new_of_old[first + (size_t)i * stride];
-            HIP_TRY(hipMemcpyAsync((char*)out + (size_t)i * row_bytes, col0 + row * src_row_bytes, row_bytes, hipMemcpyDeviceToHost,
-                                   ctx->stream));
+        if (count > 2048) {   // many rows: the column in one copy, the rows picked on the host
+            std::vector<char> whole(N * src_row_bytes);
+            HIP_TRY(hipMemcpyAsync(whole.data(), col0, whole.size(), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            for (int i = 0; i < count; ++i) {
+                const size_t row = (size_t)ctx->new_of_old[first + (size_t)i * stride];
+                memcpy((char*)out + (size_t)i * row_bytes, whole.data() + row * src_row_bytes, row_bytes);
+            }
+        } else {
+            for (int i = 0; i < count; ++i) {
+                const size_t row = (size_t)ctx->new_of_old[first + (size_t)i * stride];
+                HIP_TRY(hipMemcpyAsync((char*)out + (size_t)i * row_bytes, col0 + row * src_row_bytes, row_bytes,
+                                       hipMemcpyDeviceToHost, ctx->stream));
+            }
         }
     } else {
         HIP_TRY(hipMemcpy2DAsync(out, row_bytes, src, src_row_bytes * stride, row_bytes, count, hipMemcpyDeviceToHost, ctx->stream));

@@ -2801,14 +2801,16 @@ __device__ __forceinline__ void pml_signal_done(u64* __restrict__ done_state, u6
 template <int G, int R>
 __global__ void __launch_bounds__(PML_SMALL_BLOCK)
 td_f81_small_kernel(PmlTree t, PmlCols c, PmlState st, const PmlUnit* __restrict__ units,
-                    const int* __restrict__ level_offsets, int n_levels, u64* __restrict__ done_state, u64* done_flag) {
+                    const int* __restrict__ level_offsets, int n_levels, u64* __restrict__ done_state, u64* done_flag,
+                    int skip_roots) {
     constexpr int UW = 64 / G;
     const int wave = threadIdx.x >> 6;
     const int n_waves = blockDim.x >> 6;
     const int sub = (threadIdx.x & 63) / G;
     LaneCtx<G, R> L;
     lane_ctx_init<G, R>(L, t, c, st);
-    for (int base = wave * UW; base < t.n_roots; base += n_waves * UW) {
+    // (skip_roots: the launch walks the thin depths at the deep end of a large forest -- the roots were done long before)
+    for (int base = wave * UW; base < t.n_roots && !skip_roots; base += n_waves * UW) {
         const int idx = base + sub;
         if (idx < t.n_roots) f81_root_unit<G, R>(L, t, c, st, idx);
     }

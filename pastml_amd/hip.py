@@ -14,7 +14,9 @@ import numpy as np
 
 from pastml_amd.models import KIND_F81, KIND_HKY, KIND_EIGEN
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libpastml_hip.so')
+# PASTML_HIP_LIBRARY: another build of the library for this process (A/B scripts compare builds without touching the
+# in-tree file); unset: the library built in-tree by pastml_amd/build.py
+_LIB_PATH = os.environ.get('PASTML_HIP_LIBRARY') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libpastml_hip.so')
 
 PML_OK, PML_ERR_INVALID, PML_ERR_HIP, PML_ERR_UNSUPPORTED, PML_ZERO_LIKELIHOOD = 0, 1, 2, 3, 4
 

@@ -3,9 +3,9 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 B=$1; shift
 cd /tmp && export TMPDIR=/tmp
-cp $R/pastml_amd/libpastml_hip.so /tmp/libA.so
+# (build B is selected through PASTML_HIP_LIBRARY: the in-tree library is never overwritten)
 for v in A B A2 B2; do
-  case $v in A*) cp /tmp/libA.so $R/pastml_amd/libpastml_hip.so;; B*) cp $R/scratch/$B $R/pastml_amd/libpastml_hip.so;; esac
+  case $v in A*) unset PASTML_HIP_LIBRARY;; B*) export PASTML_HIP_LIBRARY=$R/scratch/$B;; esac
   echo "== $v"; timeout -k 10 300 python3 "$@" 2>&1 | tail -2
 done
-cp /tmp/libA.so $R/pastml_amd/libpastml_hip.so
+unset PASTML_HIP_LIBRARY

@@ -2,9 +2,9 @@
 # the secondary configs (cfg2, cfg3, cfg5-shaped gradient) with two builds of the library: A = in-tree, B = scratch/$1
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
-cp $R/pastml_amd/libpastml_hip.so /tmp/libA.so
+# (build B is selected through PASTML_HIP_LIBRARY: the in-tree library is never overwritten)
 for v in A B A2 B2; do
-  case $v in A*) cp /tmp/libA.so $R/pastml_amd/libpastml_hip.so;; B*) [ -f "$R/scratch/$1" ] || continue; cp $R/scratch/$1 $R/pastml_amd/libpastml_hip.so;; esac
+  case $v in A*) unset PASTML_HIP_LIBRARY;; B*) [ -f "$R/scratch/$1" ] || continue; export PASTML_HIP_LIBRARY=$R/scratch/$1;; esac
   timeout -k 10 300 python3 -c "
 import sys, json; sys.path.insert(0, '$R')
 import bench
@@ -12,4 +12,4 @@ o = bench.secondary_measurements(0)
 print('$v', {k: round(v.get('ms_per_pass') or v.get('ms_per_gradient') or v.get('seconds') or v.get('ms_per_step'), 4) for k, v in o.items()}, 'cfg3 sweep', round(o['cfg3']['ms_joint_sweep'], 4), 'marg', round(o['cfg3']['ms_marginal_pass'], 4))
 " || exit 1
 done
-cp /tmp/libA.so $R/pastml_amd/libpastml_hip.so
+unset PASTML_HIP_LIBRARY

@@ -2,9 +2,9 @@
 # dense small-k passes (262 144 tips x 32 characters): the in-tree library (A) against scratch/$1 (B), twice each
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
-cp $R/pastml_amd/libpastml_hip.so /tmp/libA.so
+# (build B is selected through PASTML_HIP_LIBRARY: the in-tree library is never overwritten)
 for v in A B A B; do
-  case $v in A) cp /tmp/libA.so $R/pastml_amd/libpastml_hip.so;; B) cp $R/scratch/$1 $R/pastml_amd/libpastml_hip.so;; esac
+  case $v in A) unset PASTML_HIP_LIBRARY;; B) export PASTML_HIP_LIBRARY=$R/scratch/$1;; esac
   echo "== $v"; python3 $R/scripts/r04_ragged.py ${CASES:-balanced4 balanced12 ragged4 ragged12}
 done
-cp /tmp/libA.so $R/pastml_amd/libpastml_hip.so
+unset PASTML_HIP_LIBRARY

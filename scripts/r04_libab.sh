@@ -6,9 +6,9 @@ O=$R/gpurun_out
 B=$R/scratch/$1
 shift
 cd /tmp && export TMPDIR=/tmp
-cp $R/pastml_amd/libpastml_hip.so /tmp/libA.so
+# (build B is selected through PASTML_HIP_LIBRARY: the in-tree library is never overwritten)
 for v in A B A2 B2; do
-  case $v in A*) cp /tmp/libA.so $R/pastml_amd/libpastml_hip.so;; B*) cp $B $R/pastml_amd/libpastml_hip.so;; esac
+  case $v in A*) unset PASTML_HIP_LIBRARY;; B*) export PASTML_HIP_LIBRARY=$B;; esac
   echo "== $v"
   timeout -k 10 300 python3 $R/scripts/r04_ragged.py "$@" 2> $O/r04ab_$v.err || { cat $O/r04ab_$v.err; exit 1; }
   if [ -z "$NO_BENCH" ]; then
@@ -17,4 +17,4 @@ for v in A B A2 B2; do
 import json; d=json.load(open('$O/libab_$v.json')); print('$v cfg4', round(d['ms_per_step'],3), d['kernel_ms_per_step'], 'bu frac', round(d['roofline_bottom_up']['frac'],4), 'td frac', round(d['roofline']['frac'],4))"
   fi
 done
-cp /tmp/libA.so $R/pastml_amd/libpastml_hip.so
+unset PASTML_HIP_LIBRARY

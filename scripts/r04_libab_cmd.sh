@@ -4,9 +4,9 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 B=$R/scratch/$1
 shift
 cd /tmp && export TMPDIR=/tmp
-cp $R/pastml_amd/libpastml_hip.so /tmp/libA.so
+# (build B is selected through PASTML_HIP_LIBRARY: the in-tree library is never overwritten)
 for v in A B A2 B2; do
-  case $v in A*) cp /tmp/libA.so $R/pastml_amd/libpastml_hip.so;; B*) cp $B $R/pastml_amd/libpastml_hip.so;; esac
+  case $v in A*) unset PASTML_HIP_LIBRARY;; B*) export PASTML_HIP_LIBRARY=$B;; esac
   echo "== $v"; "$@" 2>&1 | tail -2
 done
-cp /tmp/libA.so $R/pastml_amd/libpastml_hip.so
+unset PASTML_HIP_LIBRARY

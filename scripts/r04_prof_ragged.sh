@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
 CASE=${1:-ragged64}
 cd /tmp && export TMPDIR=/tmp
-cp $R/pastml_amd/libpastml_hip.so /tmp/libA.so
+# (build B is selected through PASTML_HIP_LIBRARY: the in-tree library is never overwritten)
 run() {
   tag=$1
   rm -rf $O/r04prof_${tag}_*
@@ -21,8 +21,8 @@ run() {
 }
 run A_$CASE || { echo "profile A failed"; tail -5 $O/r04prof_A_${CASE}_*.log; exit 1; }
 if [ -n "$2" ]; then
-  cp $R/scratch/$2 $R/pastml_amd/libpastml_hip.so
-  run B_$CASE || { echo "profile B failed"; cp /tmp/libA.so $R/pastml_amd/libpastml_hip.so; exit 1; }
-  cp /tmp/libA.so $R/pastml_amd/libpastml_hip.so
+  export PASTML_HIP_LIBRARY=$R/scratch/$2
+  run B_$CASE || { echo "profile B failed"; unset PASTML_HIP_LIBRARY; exit 1; }
+  unset PASTML_HIP_LIBRARY
 fi
 cat $O/r04prof_*_${CASE}_summary.txt

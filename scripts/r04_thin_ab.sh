@@ -3,11 +3,11 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-cp $R/pastml_amd/libpastml_hip.so /tmp/libA.so
+# (build B is selected through PASTML_HIP_LIBRARY: the in-tree library is never overwritten)
 for v in A B; do
-  case $v in A) cp /tmp/libA.so $R/pastml_amd/libpastml_hip.so;; B) cp $R/scratch/$1 $R/pastml_amd/libpastml_hip.so;; esac
+  case $v in A) unset PASTML_HIP_LIBRARY;; B) export PASTML_HIP_LIBRARY=$R/scratch/$1;; esac
   rm -rf $O/r04thin_$v
-  rocprofv3 --kernel-trace --output-format csv -d $O/r04thin_$v -o run -- python3 $R/scripts/r04_thin.py > $O/r04thin_$v.log 2>&1 || { tail -5 $O/r04thin_$v.log; cp /tmp/libA.so $R/pastml_amd/libpastml_hip.so; exit 1; }
+  rocprofv3 --kernel-trace --output-format csv -d $O/r04thin_$v -o run -- python3 $R/scripts/r04_thin.py > $O/r04thin_$v.log 2>&1 || { tail -5 $O/r04thin_$v.log; exit 1; }
   echo "== $v"; grep "^hiv1c\|^cfg2" $O/r04thin_$v.log
   python3 - <<PY
 import csv, glob, collections
@@ -23,11 +23,11 @@ for n, d in seq.items():
 PY
   rm -rf $O/r04thin_$v
 done
-cp /tmp/libA.so $R/pastml_amd/libpastml_hip.so
+unset PASTML_HIP_LIBRARY
 if [ -n "$DENSE" ]; then
   for v in A B; do
-    case $v in A) cp /tmp/libA.so $R/pastml_amd/libpastml_hip.so;; B) cp $R/scratch/$1 $R/pastml_amd/libpastml_hip.so;; esac
+    case $v in A) unset PASTML_HIP_LIBRARY;; B) export PASTML_HIP_LIBRARY=$R/scratch/$1;; esac
     echo "== $v dense levels"; python3 $R/scripts/r04_ragged.py balanced4 balanced12 ragged4 ragged12
   done
-  cp /tmp/libA.so $R/pastml_amd/libpastml_hip.so
+  unset PASTML_HIP_LIBRARY
 fi

@@ -1,0 +1,54 @@
+"""
+A/B of schedule switches inside ONE process: engines with different `tune` dictionaries on the same forest, timed alternately
+(three rounds of 20 passes each; the boxes and the first launches of a process differ by more than the effects looked for).
+usage: r05_tune_ab.py <case> <name=SWITCH:value,SWITCH:value> <name=...> ...     (value 'none' = switch not given)
+"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from pastml_amd import hip, synthetic
+from pastml_amd.tree import FlatForest
+
+cases = dict(ragged64=(lambda: FlatForest.random(262144, seed=3, max_arity=2, n_trees=1), 64, 32),
+             ragged12=(lambda: FlatForest.random(262144, seed=3, max_arity=2, n_trees=1), 12, 32),
+             ragged4=(lambda: FlatForest.random(262144, seed=3, max_arity=2, n_trees=1), 4, 32),
+             ragged2=(lambda: FlatForest.random(262144, seed=3, max_arity=2, n_trees=1), 2, 32),
+             poly64=(lambda: FlatForest.random(100000, seed=5, max_arity=5, n_trees=2), 64, 16),
+             poly4=(lambda: FlatForest.random(100000, seed=5, max_arity=5, n_trees=2), 4, 16),
+             balanced4=(lambda: synthetic.balanced_forest(18), 4, 32),
+             balanced12=(lambda: synthetic.balanced_forest(18), 12, 32),
+             mid4=(lambda: FlatForest.random(40000, seed=7, max_arity=2, n_trees=1), 4, 8))
+make, k, C = cases[sys.argv[1]]
+variants = []
+for spec in sys.argv[2:]:
+    name, _, rest = spec.partition('=')
+    tune = {}
+    for item in filter(None, rest.split(',')):
+        sw, _, val = item.partition(':')
+        tune[sw] = None if val == 'none' else int(val)
+    variants.append((name, tune))
+f = make()
+engines = []
+for name, tune in variants:
+    eng = hip.Engine(f, C, k, tune=tune)
+    eng.set_models([(dict(kind=0, pi=synthetic.f81_frequencies(k, c)), (1.0, 0.0, 1.0)) for c in range(C)])
+    eng.set_tip_states(np.stack([synthetic.tip_states(f.n_tips, k, c) for c in range(C)]))
+    for _ in range(3):
+        lnl = eng.marginal_pass(posterior=False, lh=False)[0]
+    engines.append((name, eng, lnl, [], []))
+for rnd in range(3):
+    for name, eng, lnl, passes, sweeps in engines:
+        eng.sync(); t0 = time.perf_counter()
+        for _ in range(20):
+            eng.marginal_pass(posterior=False, lh=False)
+        eng.sync(); passes.append((time.perf_counter() - t0) / 20 * 1e3)
+        t0 = time.perf_counter()
+        for _ in range(20):
+            eng.bottom_up(True)
+        eng.sync(); sweeps.append((time.perf_counter() - t0) / 20 * 1e3)
+ref = engines[0][2]
+for name, eng, lnl, passes, sweeps in engines:
+    print('%-10s %-14s marginal pass %s ms (min %.3f)   bottom-up %s ms (min %.3f)   same ln L: %s'
+          % (sys.argv[1], name, ' '.join('%.3f' % v for v in passes), min(passes), ' '.join('%.3f' % v for v in sweeps), min(sweeps),
+             np.array_equal(lnl, ref)), flush=True)
+    eng.close()
