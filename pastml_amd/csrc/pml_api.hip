@@ -71,7 +71,7 @@ static int fail(int code, const char* fmt, ...) {
     X(STACK_MIN, 0, 1) X(NO_STACK, 1, 1) X(DEBUG, 1, 0) X(BLOCK_NODES, 0, 1) X(BLOCK_MAX_STORED, 0, 1)                 \
     X(BLOCK_HEIGHT_CAP, 0, 1) X(SMALL_MAX_NODES, 0, 1) X(F81_R, 0, 1) X(F81_TD_R, 0, 1) X(NO_GRAPH, 1, 1)              \
     X(NARROW_UNITS, 0, 0) X(NO_EIGG_TIERS, 1, 0) X(NO_ABSORB, 1, 1) X(ABSORB_MIN, 0, 1) X(NO_SPIN_WAIT, 1, 0)   \
-    X(SPLIT_PARTS, 0, 0) X(PIJ_STAGE_ROWS, 0, 0) X(PIJ_ABLATE, 0, 0) X(PIJ_BLOCKS, 0, 0) X(NO_HEIGHT_ORDER, 1, 1) X(NO_TD_TAIL, 1, 0)
+    X(SPLIT_PARTS, 0, 0) X(PIJ_STAGE_ROWS, 0, 0) X(PIJ_ABLATE, 0, 0) X(PIJ_BLOCKS, 0, 0) X(NO_HEIGHT_ORDER, 1, 1) X(NO_TD_TAIL, 1, 0) X(NO_PIJ_VALU, 1, 0) X(PIJ_VALU, 1, 0)
 enum PmlTunable {
 #define X(name, flag, tree) T_##name,
     PML_TUNABLES(X)
@@ -244,6 +244,7 @@ struct pml_ctx {
     int sched_cols = 0;           // the number of columns the schedule of a sweep is chosen for (C; 32 for a few active ones)
     bool bu_signals_few = false;
     double* d_AinvT = nullptr;  // [C][32][32]: Ainv transposed and zero-padded (k <= 32), for eigen_joint_kernel
+    double* d_AT = nullptr;     // [C][32][32]: A transposed and zero-padded (k <= 32), for pij_eigen_valu_kernel
     double *d_sf = nullptr, *d_tau = nullptr, *d_tauf = nullptr;
     std::vector<char> model_set;  // per column
     std::vector<char> tips_observed;  // per column: every tip has exactly one allowed state (known from pml_masks_from_tip_states)
@@ -2877,7 +2878,7 @@ int pml_model_set_eigen(pml_ctx* ctx, int32_t col_begin, int32_t col_end, const 
     PML_TRY(upload(ctx, ctx->d_d + col_begin * k, d, nc * k));
     PML_TRY(upload(ctx, ctx->d_A + col_begin * k * k, A, nc * k * k));
     PML_TRY(upload(ctx, ctx->d_Ainv + col_begin * k * k, Ainv, nc * k * k));
-    std::vector<double> at;
+    std::vector<double> at, a_t;
     if (k <= PML_EIGJ_STRIDE) {
         const size_t sq = (size_t)PML_EIGJ_STRIDE * PML_EIGJ_STRIDE;
         if (!ctx->d_AinvT) PML_TRY(dev_alloc(ctx, &ctx->d_AinvT, (size_t)ctx->C * sq));
@@ -2887,6 +2888,13 @@ int pml_model_set_eigen(pml_ctx* ctx, int32_t col_begin, int32_t col_end, const 
                 for (size_t j = 0; j < k; ++j)
                     at[c * sq + j * PML_EIGJ_STRIDE + mm] = Ainv[(size_t)c * k * k + mm * k + j];
         PML_TRY(upload(ctx, ctx->d_AinvT + (size_t)col_begin * sq, at.data(), at.size()));
+        if (!ctx->d_AT) PML_TRY(dev_alloc(ctx, &ctx->d_AT, (size_t)ctx->C * sq));
+        a_t.assign((size_t)nc * sq, 0.0);
+        for (int c = 0; c < nc; ++c)
+            for (size_t i = 0; i < k; ++i)
+                for (size_t mm = 0; mm < k; ++mm)
+                    a_t[c * sq + mm * PML_EIGJ_STRIDE + i] = A[(size_t)c * k * k + i * k + mm];
+        PML_TRY(upload(ctx, ctx->d_AT + (size_t)col_begin * sq, a_t.data(), a_t.size()));
     }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return PML_OK;
@@ -2929,6 +2937,32 @@ static int run_prep(pml_ctx* ctx, bool force = false) {
         if (ctx->kind == PML_MODEL_HKY) {
             dim3 grid(grid_for(ctx, ctx->N, PML_BLOCK, ctx->C), ctx->C);
             hipLaunchKernelGGL(pij_hky_kernel, grid, dim3(PML_BLOCK), 0, ctx->stream, t, c, m, ctx->d_P);
+        } else if (ctx->k >= 2 && ctx->k <= PML_EIGJ_STRIDE && ctx->d_AT != nullptr && ctx->d_AinvT != nullptr && (ctx->ks & 1) == 0 &&
+                   !ctx->tune.on(T_NO_PIJ_VALU) && (ctx->k < 16 || ctx->tune.on(T_NO_MFMA) || ctx->tune.on(T_PIJ_VALU))) {
+            // vector-unit path: a lane per output row, exact flops, rows written in address order (pml_kernels_eigen_joint.h).
+            // Below 16 states, where the matrix-core kernel does not reach (524 287 branches: k = 8 0.289 -> 0.056 ms, k = 5
+            // 0.292 -> 0.032 against pij_eigen_kernel); from 16 on the matrix-core kernel is the faster one (k = 20 0.380 against
+            // 0.392 ms, k = 32 0.96 against 1.38: the rows of A^T come through the scalar cache a dozen FMAs ahead at best, and
+            // with 1 024 FMAs per lane the wave count halves) -- PASTML_HIP_PIJ_VALU forces this path (profiles/r05o_pij_valu.txt)
+            const int KU = 4 * ((ctx->k + 3) / 4);
+            const long long passes = ((long long)ctx->N * ctx->k + 63) / 64;
+            long long blocks = (passes + PML_WAVES_PER_BLOCK - 1) / PML_WAVES_PER_BLOCK;
+            const long long cap = std::max(64, (int)ctx->tune.get(T_PIJ_BLOCKS, 4096) / std::max(1, ctx->C));
+            if (blocks > cap) blocks = cap;
+            dim3 grid((unsigned)blocks, ctx->C);
+#define PML_PIJV_CASE(KU_)                                                                                          \
+    if (KU == KU_)                                                                                                  \
+        hipLaunchKernelGGL((pij_eigen_valu_kernel<KU_>), grid, dim3(PML_BLOCK), 0, ctx->stream, t, c, m, ctx->d_AinvT, \
+                           ctx->d_AT, ctx->d_P);
+            PML_PIJV_CASE(4)
+            PML_PIJV_CASE(8)
+            PML_PIJV_CASE(12)
+            PML_PIJV_CASE(16)
+            PML_PIJV_CASE(20)
+            PML_PIJV_CASE(24)
+            PML_PIJV_CASE(28)
+            PML_PIJV_CASE(32)
+#undef PML_PIJV_CASE
         } else if (ctx->k >= 16 && ctx->k <= 32 && !ctx->tune.on(T_NO_MFMA)) {
             // FP64 matrix-core path (BASELINE config 3: JTT, k = 20)
             const int k = ctx->k;

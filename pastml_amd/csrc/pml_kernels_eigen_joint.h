@@ -478,3 +478,106 @@ __global__ void __launch_bounds__(PML_BLOCK) eigen_joint_obs_tips_kernel(PmlTree
         wave_lds_sync();  // the chunk has been consumed before the next one overwrites it
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The P(t) batch of the eigen models on the vector units (round 5; 2 <= k <= 32): P(t) = A diag(exp(d t')) Ainv of every
+// branch (pastml/models/generator.py:54-65, CustomRatesModel.py:70-79), stored transposed, Pt[b][j][i], ks doubles per row.
+//
+// The matrix-core kernel (pij_eigen_mfma_kernel) pads k = 20 to 32 columns -- 1.6 x the flops -- and FP64 matrix and vector
+// instructions share one issue resource at the same peak, so the tile shape is all the matrix cores give; without its stores
+// that kernel takes 0.30 ms for 524 287 branches where the 2 k^3 flops are 0.107 ms of the peak (profiles/r05g_pij_kernel.txt).
+// Here a lane stands for one output ROW (b, j): the rows of a column are one contiguous run of memory, a wave takes 64
+// consecutive ones.  The lane forms w[m] = Ainv[m][j] exp(d_m t_b) (Ainv's column j from LDS, the exponentials of the pass's
+// few branches shared through LDS) and then out[i] = sum_m w[m] A[i][m] as k independent chains of k FMAs whose second operand
+// is the same for every lane: row m of a transposed zero-padded copy of A streams through the scalar cache into SGPRs, as
+// Ainv does in eigen_joint_kernel.  No padding (all 64 lanes work, exact 2 k^3 flops for k a multiple of 4), no fold across
+// lanes.  The wave's 64 rows are 64 ks contiguous doubles: staged in LDS half a wave at a time and written in address order,
+// 16 bytes per lane.
+// ---------------------------------------------------------------------------------------------------------------------
+#define PML_PIJV_EXP_LDS 160   // doubles: exp(d_m t) of the branches one pass touches, (64 / k + 2) * KU <= 136
+
+template <int KU>
+__global__ void __launch_bounds__(PML_BLOCK)
+pij_eigen_valu_kernel(PmlTree t, PmlCols c, PmlModel m, const double* __restrict__ ainvT, const double* __restrict__ aT,
+                      double* __restrict__ P) {
+    constexpr int AS = PML_EIGJ_ASTRIDE(KU);
+    __shared__ double smem[32 * AS + PML_WAVES_PER_BLOCK * (PML_PIJV_EXP_LDS + 32 * KU)];
+    typedef double dbl2 __attribute__((ext_vector_type(2)));
+    const int k = c.k, ks = c.ks;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = blockIdx.y;
+    double* sT = smem;   // sT[j * AS + m] = Ainv[m][j]
+    {
+        const double* g = ainvT + (size_t)col * PML_EIGJ_STRIDE * PML_EIGJ_STRIDE;
+        for (int e = threadIdx.x; e < k * AS; e += blockDim.x) {
+            const int r = e / AS, q = e % AS;
+            sT[e] = q < KU ? g[r * PML_EIGJ_STRIDE + q] : 0.0;
+        }
+    }
+    double* sE = smem + 32 * AS + wave * (PML_PIJV_EXP_LDS + 32 * KU);
+    double* sO = sE + PML_PIJV_EXP_LDS;   // 32 staged rows of ks doubles
+    __syncthreads();
+    const double* gd = m.d + (size_t)col * k;
+    const double sfc = m.sf[col], tau = m.tau[col], tf = m.tauf[col];
+    const pml_const_f64 at_col = (pml_const_f64)(aT + (size_t)col * PML_EIGJ_STRIDE * PML_EIGJ_STRIDE);
+    const long long rows_total = (long long)t.N * k;
+    double* const Pcol = P + (size_t)col * t.N * (size_t)k * ks;
+    const long long waves_total = (long long)gridDim.x * PML_WAVES_PER_BLOCK;
+    for (long long r0 = ((long long)blockIdx.x * PML_WAVES_PER_BLOCK + wave) * 64; r0 < rows_total; r0 += waves_total * 64) {
+        const int b_lo = (int)(r0 / k);
+        const long long r_last = (r0 + 63 < rows_total ? r0 + 63 : rows_total - 1);
+        const int nbr = (int)(r_last / k) - b_lo + 1;
+        // exp(d_m t') of the branches of this pass
+        for (int e = lane; e < nbr * KU; e += 64) {
+            const int bl = e / KU, mm = e % KU;
+            double v = 0.0;
+            if (mm < k) v = exp(gd[mm] * ((t.dist[b_lo + bl] + tau) * tf * sfc));
+            sE[e] = v;
+        }
+        wave_lds_sync();
+        const long long r = r0 + lane;
+        const bool act = r < rows_total;
+        const int b = act ? (int)(r / k) : b_lo;
+        const int j = act ? (int)(r - (long long)b * k) : 0;
+        double w[KU];
+        {
+            const double* pt = sT + j * AS;
+            const double* pe = sE + (b - b_lo) * KU;
+#pragma unroll
+            for (int mm = 0; mm < KU; ++mm) w[mm] = pt[mm] * pe[mm];
+        }
+        // out[i] = sum_m w[m] A[i][m]: rows of A^T through the scalar cache (hidden from the compiler, which would otherwise
+        // keep the whole matrix in spilled SGPRs across the passes)
+        pml_const_f64 at = at_col;
+        asm volatile("" : "+s"(at));
+        double out[KU];
+#pragma unroll
+        for (int i = 0; i < KU; ++i) out[i] = w[0] * at[i];
+#pragma unroll
+        for (int mm = 1; mm < KU; ++mm)
+#pragma unroll
+            for (int i = 0; i < KU; ++i) out[i] = __builtin_fma(w[mm], at[mm * PML_EIGJ_STRIDE + i], out[i]);
+        // the wave's rows are contiguous in memory: half a wave's rows through LDS at a time, written in address order
+        double* const gout = Pcol + (size_t)r0 * ks;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            if ((lane >> 5) == half) {
+                double* srow = sO + (lane & 31) * ks;
+#pragma unroll
+                for (int i = 0; i < KU; ++i)
+                    if (i < ks) srow[i] = out[i];   // (columns k .. ks - 1: exact zeros, the padding rows of A^T are zero)
+            }
+            wave_lds_sync();
+            const long long first = r0 + 32 * half;
+            const int hrows = first >= rows_total ? 0 : (int)(rows_total - first < 32 ? rows_total - first : 32);
+            const int pairs = hrows * ks / 2;   // (32 ks is even; a short last half of odd length: the scalar tail below)
+            double* const hout = gout + (size_t)32 * half * ks;
+            for (int e = lane; e < pairs; e += 64) {
+                const dbl2 v = *reinterpret_cast<const dbl2*>(sO + 2 * e);
+                __builtin_nontemporal_store(v, reinterpret_cast<dbl2*>(hout + 2 * e));
+            }
+            if (((hrows * ks) & 1) && lane == 0) hout[hrows * ks - 1] = sO[hrows * ks - 1];
+            wave_lds_sync();
+        }
+    }
+}

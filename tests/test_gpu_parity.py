@@ -50,6 +50,27 @@ def assert_same_scaled(ours, ours_sf, ref, ref_sf, rows=None, what='', ulps=0):
 LEVEL_SCHEDULE = dict(BLOCK_NODES=0, SMALL_MANY_NODES=0, SUPER_MIN=1, STACK_MIN=1)
 
 
+@pytest.mark.parametrize('k', [2, 3, 6, 10, 15, 16, 20, 29, 32])
+def test_pij_batch_kernels_agree(k):
+    """The P(t) batch of an eigen model by each of its kernels -- the vector-unit kernel (default below 16 states, forced by
+    PIJ_VALU), the matrix-core kernel (16 <= k <= 32) and the generic one (NO_PIJ_VALU below 16, odd row strides) -- against
+    the oracle's A diag(exp(d t)) A^-1 and against each other (rounding only), on a forest whose row count is not a multiple of
+    the kernels' pass sizes, two columns with different rates."""
+    rng = np.random.default_rng(k)
+    flat = FlatForest.random(333, seed=k, max_arity=3, zero_frac=0.1, n_trees=2)
+    specs = [(random_spec('EIGEN', k, rng), (float(rng.uniform(0.5, 3)), 0.0, 1.0)) for _ in range(2)]
+    got = {}
+    for name, tune in (('default', {}), ('valu', dict(PIJ_VALU=1)), ('other', dict(NO_PIJ_VALU=1))):
+        with hip.Engine(flat, 2, k, tune=tune) as eng:
+            eng.set_models(specs)
+            got[name] = eng.pij_batch(copy_out=True)
+    for col, (spec, rates) in enumerate(specs):
+        ref = np.array([orc.pij(spec, t, *rates) for t in flat.dist])
+        for name in got:
+            np.testing.assert_allclose(got[name][col], ref, rtol=1e-11, atol=5e-15, err_msg='{} k={}'.format(name, k))
+    np.testing.assert_allclose(got['valu'], got['other'], rtol=1e-11, atol=5e-15)
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 def test_pij_matches_reference():
     z = load_golden('pij')
