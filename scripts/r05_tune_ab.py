@@ -9,6 +9,12 @@ import numpy as np
 from pastml_amd import hip, synthetic
 from pastml_amd.tree import FlatForest
 
+def hiv1c_forest():
+    from pastml_amd.tree import read_tree, get_flat_forest
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    return get_flat_forest([read_tree(os.path.join(repo, 'tests', 'golden', 'data', 'hiv1c', 'pastml_phyml_tree.nwk'))])
+
+
 cases = dict(ragged64=(lambda: FlatForest.random(262144, seed=3, max_arity=2, n_trees=1), 64, 32),
              ragged12=(lambda: FlatForest.random(262144, seed=3, max_arity=2, n_trees=1), 12, 32),
              ragged4=(lambda: FlatForest.random(262144, seed=3, max_arity=2, n_trees=1), 4, 32),
@@ -17,7 +23,9 @@ cases = dict(ragged64=(lambda: FlatForest.random(262144, seed=3, max_arity=2, n_
              poly4=(lambda: FlatForest.random(100000, seed=5, max_arity=5, n_trees=2), 4, 16),
              balanced4=(lambda: synthetic.balanced_forest(18), 4, 32),
              balanced12=(lambda: synthetic.balanced_forest(18), 12, 32),
-             mid4=(lambda: FlatForest.random(40000, seed=7, max_arity=2, n_trees=1), 4, 8))
+             mid4=(lambda: FlatForest.random(40000, seed=7, max_arity=2, n_trees=1), 4, 8),
+             hiv12=(lambda: hiv1c_forest(), 12, 14), hiv2=(lambda: hiv1c_forest(), 2, 246), hiv67=(lambda: hiv1c_forest(), 67, 68),
+             cfg2=(lambda: synthetic.balanced_forest(16), 4, 1))
 make, k, C = cases[sys.argv[1]]
 variants = []
 for spec in sys.argv[2:]:
@@ -42,13 +50,14 @@ for name, tune in variants:
 for rnd in range(3):
     for name, eng, lnl, passes, sweeps in engines:
         eng.sync(); t0 = time.perf_counter()
-        for _ in range(20):
+        reps = 20 if f.n_nodes > 100000 else 200
+        for _ in range(reps):
             eng.marginal_pass(posterior=False, lh=False)
-        eng.sync(); passes.append((time.perf_counter() - t0) / 20 * 1e3)
+        eng.sync(); passes.append((time.perf_counter() - t0) / reps * 1e3)
         t0 = time.perf_counter()
-        for _ in range(20):
+        for _ in range(reps):
             eng.bottom_up(True)
-        eng.sync(); sweeps.append((time.perf_counter() - t0) / 20 * 1e3)
+        eng.sync(); sweeps.append((time.perf_counter() - t0) / reps * 1e3)
 ref = engines[0][2]
 for name, eng, lnl, passes, sweeps in engines:
     if name == '(ballast)':
