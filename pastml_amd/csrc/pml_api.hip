@@ -71,7 +71,7 @@ static int fail(int code, const char* fmt, ...) {
     X(STACK_MIN, 0, 1) X(NO_STACK, 1, 1) X(DEBUG, 1, 0) X(BLOCK_NODES, 0, 1) X(BLOCK_MAX_STORED, 0, 1)                 \
     X(BLOCK_HEIGHT_CAP, 0, 1) X(SMALL_MAX_NODES, 0, 1) X(F81_R, 0, 1) X(F81_TD_R, 0, 1) X(NO_GRAPH, 1, 1)              \
     X(NARROW_UNITS, 0, 0) X(NO_EIGG_TIERS, 1, 0) X(NO_ABSORB, 1, 1) X(ABSORB_MIN, 0, 1) X(NO_SPIN_WAIT, 1, 0)   \
-    X(SPLIT_PARTS, 0, 0) X(PIJ_STAGE_ROWS, 0, 0) X(PIJ_ABLATE, 0, 0) X(PIJ_BLOCKS, 0, 0) X(NO_HEIGHT_ORDER, 1, 1) X(NO_TD_TAIL, 1, 0) X(NO_PIJ_VALU, 1, 0) X(PIJ_VALU, 1, 0)
+    X(SPLIT_PARTS, 0, 0) X(PIJ_STAGE_ROWS, 0, 0) X(PIJ_ABLATE, 0, 0) X(PIJ_BLOCKS, 0, 0) X(NO_HEIGHT_ORDER, 1, 1) X(NO_TD_TAIL, 1, 0) X(NO_PIJ_VALU, 1, 0) X(PIJ_VALU, 1, 0) X(NO_EIGJ_PIPE, 1, 0)
 enum PmlTunable {
 #define X(name, flag, tree) T_##name,
     PML_TUNABLES(X)
@@ -1174,8 +1174,12 @@ static int launch_eigen_joint(pml_ctx* ctx, const PmlUnit* units, const int* d_o
             int blocks = (n + per_block - 1) / per_block;                                                           \
             const int cap = std::max(8, cap_all / std::max(1, ctx->C));                                             \
             if (blocks > cap) blocks = cap;                                                                         \
-            hipLaunchKernelGGL((eigen_joint_kernel<KU_>), dim3(blocks, ctx->C), dim3(PML_BLOCK), 0, ctx->stream,    \
-                               t, c, m, st, ctx->d_AinvT, units, n);                                                \
+            if (ctx->tune.on(T_NO_EIGJ_PIPE))                                                                       \
+                hipLaunchKernelGGL((eigen_joint_kernel<KU_, false>), dim3(blocks, ctx->C), dim3(PML_BLOCK), 0,      \
+                                   ctx->stream, t, c, m, st, ctx->d_AinvT, units, n);                               \
+            else                                                                                                    \
+                hipLaunchKernelGGL((eigen_joint_kernel<KU_, true>), dim3(blocks, ctx->C), dim3(PML_BLOCK), 0,       \
+                                   ctx->stream, t, c, m, st, ctx->d_AinvT, units, n);                               \
         }                                                                                                           \
         HIP_TRY(hipGetLastError());                                                                                 \
         return PML_OK;                                                                                              \

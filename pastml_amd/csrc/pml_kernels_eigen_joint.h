@@ -82,30 +82,68 @@ __device__ __forceinline__ bool eigj_node_any(const EigJWave<KU>& W, bool p) {
     return (__ballot(p) & W.gmask) != 0ull;
 }
 
-// One pass of a wave: npw nodes, lane (b, i) owns state i of the node n of slot b (act: the slot has a node).
+// One pass of a wave: npw nodes, lane (b, i) owns state i of the node n of slot b (act: the slot has a node).  In three
+// parts, so that the level kernel can have the loads of the NEXT pass in flight while it runs the FMAs of this one
+// (eigen_joint_kernel); run one after the other they are the pass as it always was -- the same operations in the same order.
+struct EigJFront {   // what the front of a pass reads from memory: the node's own data and its first two children's
+    u64 word;
+    double dist;
+    i64 cbe[2];
+    double mv[2];
+};
+
 template <int KU>
-__device__ __forceinline__ void eigj_pass(const EigJWave<KU>& W, const PmlTree& t, const PmlCols& c,
-                                          const PmlState& st, bool act, int n, int fc, int nc) {
+__device__ __forceinline__ void eigj_front_issue(const EigJWave<KU>& W, const PmlTree& t, const PmlCols& c,
+                                                 const PmlState& st, bool act, int n, int fc, int nc, EigJFront& f) {
+    f.word = 0ull;
+    f.dist = 0.0;
+    f.cbe[0] = f.cbe[1] = 0;
+    f.mv[0] = f.mv[1] = 0.0;
+    if (act) {
+        const size_t colN = W.colN;
+        f.word = c.masks[colN + n];  // k <= 32: one word
+        f.dist = t.dist[n];
+        if (nc > 0) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int ch = fc + (u < nc ? u : 0);
+                f.cbe[u] = st.be[colN + ch];
+                f.mv[u] = st.msg[(colN + ch) * W.ks + W.i];
+            }
+        }
+    }
+}
+
+// the vector of the node (ml.py:126-148) from what eigj_front_issue asked for; children beyond the first two are read here
+template <int KU>
+__device__ __forceinline__ void eigj_front_finish(const EigJWave<KU>& W, const PmlTree& t, const PmlCols& c,
+                                                  const PmlState& st, bool act, int n, int fc, int nc, const EigJFront& f,
+                                                  double& v_out, double& tq_out) {
     const int k = W.k, ks = W.ks, i = W.i;
     const size_t colN = W.colN;
     const size_t row = (colN + n) * ks;
-    // ------------------------------------------------------------------ the vector of the node (ml.py:126-148)
     double v = 0.0;
     double tq = 0.0;
     if (act) {
-        const u64 word = c.masks[colN + n];  // k <= 32: one word
-        tq = (t.dist[n] + W.tau) * W.tf * W.sfc;
-        v = ((word >> i) & 1ull) ? 1.0 : 0.0;
+        tq = (f.dist + W.tau) * W.tf * W.sfc;
+        v = ((f.word >> i) & 1ull) ? 1.0 : 0.0;
         i64 esum = 0;
         // the children two at a time: the loads of a pair go out together (a tip's exponent word is zero)
         for (int j0 = 0; j0 < nc; j0 += 2) {
             double mv[2];
             i64 cbe[2];
+            if (j0 == 0) {
+                mv[0] = f.mv[0];
+                mv[1] = f.mv[1];
+                cbe[0] = f.cbe[0];
+                cbe[1] = f.cbe[1];
+            } else {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int ch = fc + (j0 + u < nc ? j0 + u : j0);
-                cbe[u] = st.be[colN + ch];
-                mv[u] = st.msg[(colN + ch) * ks + i];
+                for (int u = 0; u < 2; ++u) {
+                    const int ch = fc + (j0 + u < nc ? j0 + u : j0);
+                    cbe[u] = st.be[colN + ch];
+                    mv[u] = st.msg[(colN + ch) * ks + i];
+                }
             }
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -135,17 +173,31 @@ __device__ __forceinline__ void eigj_pass(const EigJWave<KU>& W, const PmlTree& 
                 for (int q = k; q < ks; ++q) st.bu[row + q] = 0.0;
         }
     }
-    // ------------------------------------------------------------------ v and exp(d t') of the node, for its lanes
+    v_out = v;
+    tq_out = tq;
+}
+
+// v and exp(d t') of the node shared between its lanes, and u[m] = A[i][m] exp(d_m t')
+template <int KU>
+__device__ __forceinline__ void eigj_share(const EigJWave<KU>& W, double v, double tq, double (&u)[KU]) {
     const int slot = W.b * KU;
     if (W.lane_ok) {
-        W.sE[slot + i] = exp(W.d_i * tq);
-        W.sV[slot + i] = v;
+        W.sE[slot + W.i] = exp(W.d_i * tq);
+        W.sV[slot + W.i] = v;
     }
     wave_lds_sync();
-    double u[KU];
 #pragma unroll
     for (int mm = 0; mm < KU; ++mm) u[mm] = W.sA[mm] * W.sE[slot + mm];
-    // ------------------------------------------------------------------ P[i][j] v[j], folded as it is produced
+}
+
+// P[i][j] v[j], folded as it is produced, and the results of the node
+template <int KU>
+__device__ __forceinline__ void eigj_back(const EigJWave<KU>& W, const PmlCols& c, const PmlState& st, bool act, int n,
+                                          const double (&u)[KU]) {
+    const int k = W.k, ks = W.ks, i = W.i;
+    const size_t colN = W.colN;
+    const size_t row = (colN + n) * ks;
+    const int slot = W.b * KU;
     double best = -INFINITY;
     int bj = 0;
     // the matrix is the same in every pass, and the compiler would keep all of it in (spilled) SGPRs across the loop
@@ -164,7 +216,6 @@ __device__ __forceinline__ void eigj_pass(const EigJWave<KU>& W, const PmlTree& 
             bj = j;
         }
     }
-    // ------------------------------------------------------------------ results of the node
     if (act) {
         if (c.masks_init != nullptr) {
             // altered nodes get their tables rewritten w.r.t. their initial masks (ml.py:408-428)
@@ -180,6 +231,18 @@ __device__ __forceinline__ void eigj_pass(const EigJWave<KU>& W, const PmlTree& 
             }
     }
     wave_lds_sync();  // the pass's LDS reads are done before the next pass overwrites the slots
+}
+
+template <int KU>
+__device__ __forceinline__ void eigj_pass(const EigJWave<KU>& W, const PmlTree& t, const PmlCols& c,
+                                          const PmlState& st, bool act, int n, int fc, int nc) {
+    EigJFront f;
+    eigj_front_issue<KU>(W, t, c, st, act, n, fc, nc, f);
+    double v, tq;
+    eigj_front_finish<KU>(W, t, c, st, act, n, fc, nc, f, v, tq);
+    double u[KU];
+    eigj_share<KU>(W, v, tq, u);
+    eigj_back<KU>(W, c, st, act, n, u);
 }
 
 #define PML_EIGJ_ATTR __launch_bounds__(PML_BLOCK)
@@ -199,8 +262,11 @@ __device__ __forceinline__ EigJUnit eigj_load_unit(const PmlTree& t, const PmlUn
     return u;
 }
 
-// one launch over the n_nodes internal nodes of one height level (their unit descriptors)
-template <int KU>
+// one launch over the n_nodes internal nodes of one height level (their unit descriptors).  Software pipeline (round 5): half
+// of a wide level's time was not arithmetic but a pass's chain of dependent loads -- descriptor -> the node's and its
+// children's data -> ... (profiles/r05p_cfg3_joint_sweep.txt).  The descriptor of the pass after next and the data of the
+// next pass are now in flight while the FMAs of the current pass run; PIPE = false is the plain loop (same bits).
+template <int KU, bool PIPE = true>
 __global__ void PML_EIGJ_ATTR eigen_joint_kernel(PmlTree t, PmlCols c, PmlModel m, PmlState st,
                                                  const double* __restrict__ ainvT,
                                                  const PmlUnit* __restrict__ units, int n_nodes) {
@@ -209,11 +275,45 @@ __global__ void PML_EIGJ_ATTR eigen_joint_kernel(PmlTree t, PmlCols c, PmlModel 
     eigj_wave_init<KU>(W, t, c, m, ainvT, smem);
     const int wave = threadIdx.x >> 6;
     const int waves_total = gridDim.x * PML_WAVES_PER_BLOCK;
-    for (int b0 = (blockIdx.x * PML_WAVES_PER_BLOCK + wave) * W.npw; b0 < n_nodes; b0 += waves_total * W.npw) {
-        const bool act = W.lane_ok && b0 + W.b < n_nodes;
-        EigJUnit u = {0, 0, 0};
-        if (act) u = eigj_load_unit(t, units, b0 + W.b);
-        eigj_pass<KU>(W, t, c, st, act, u.n, u.fc, u.nc);
+    const int stride = waves_total * W.npw;
+    int b0 = (blockIdx.x * PML_WAVES_PER_BLOCK + wave) * W.npw;
+    if (!PIPE) {
+        for (; b0 < n_nodes; b0 += stride) {
+            const bool act = W.lane_ok && b0 + W.b < n_nodes;
+            EigJUnit u = {0, 0, 0};
+            if (act) u = eigj_load_unit(t, units, b0 + W.b);
+            eigj_pass<KU>(W, t, c, st, act, u.n, u.fc, u.nc);
+        }
+        return;
+    }
+    if (b0 >= n_nodes) return;
+    // prologue: the first pass's descriptor and data, the second pass's descriptor
+    bool act = W.lane_ok && b0 + W.b < n_nodes;
+    EigJUnit cur = {0, 0, 0};
+    if (act) cur = eigj_load_unit(t, units, b0 + W.b);
+    bool act1 = W.lane_ok && b0 + stride + W.b < n_nodes;
+    EigJUnit nxt = {0, 0, 0};
+    if (act1) nxt = eigj_load_unit(t, units, b0 + stride + W.b);
+    EigJFront f;
+    eigj_front_issue<KU>(W, t, c, st, act, cur.n, cur.fc, cur.nc, f);
+    for (; b0 < n_nodes; b0 += stride) {
+        // the descriptor of the pass after next
+        const bool act2 = W.lane_ok && b0 + 2 * stride + W.b < n_nodes;
+        EigJUnit nn = {0, 0, 0};
+        if (act2) nn = eigj_load_unit(t, units, b0 + 2 * stride + W.b);
+        double v, tq;
+        eigj_front_finish<KU>(W, t, c, st, act, cur.n, cur.fc, cur.nc, f, v, tq);
+        double u[KU];
+        eigj_share<KU>(W, v, tq, u);
+        // the next pass's data go out before this pass's FMAs (its nodes are of this level: nothing this pass writes)
+        EigJFront fn;
+        eigj_front_issue<KU>(W, t, c, st, act1, nxt.n, nxt.fc, nxt.nc, fn);
+        eigj_back<KU>(W, c, st, act, cur.n, u);
+        f = fn;
+        cur = nxt;
+        act = act1;
+        nxt = nn;
+        act1 = act2;
     }
 }
 
