@@ -663,10 +663,10 @@ def secondary_measurements(device):
                               frac=gb / (ms * 1e-3) / HBM_PEAK_GBS,
                               bottom_up=dict(model_gb=sb['bottom_up'] * C / 1e9,
                                              achieved=sb['bottom_up'] * C / 1e9 / (ms_bu * 1e-3))))
-    # (HBM counters of the k = 64 pass, profiles/r04b_ragged_tree_memory_counters.md: 28.8 GB moved for the 22.2 GB of this
-    # model -- the gathered 8-byte scalars cost 128-byte lines -- at 5.1 TB/s, the same rate as on the balanced tree)
-    ragged['k64']['roofline']['traffic_note'] = ('rocprofv3 TCC_EA0_RDREQ / WRREQ, round 4: 28.8 GB per pass at 5.1 TB/s '
-                                                 '(profiles/r04b_ragged_tree_memory_counters.md)')
+    # (HBM counters of the k = 64 pass, profiles/r05t_ragged_tree_memory_counters.md: 25.2 GB moved for the 22.2 GB of this model
+    # since the library numbers the nodes in height order -- round 4: 28.8 GB, every gathered 8-byte scalar cost a 128-byte line)
+    ragged['k64']['roofline']['traffic_note'] = ('rocprofv3 FETCH_SIZE / WRITE_SIZE, round 5: 25.2 GB per pass = 1.14 x the model '
+                                                 '(profiles/r05t_ragged_tree_memory_counters.md; round 4: 28.8 GB = 1.30 x)')
     out['ragged262k'] = dict(workload='random binary tree, 262 144 tips (FlatForest.random seed 3), 32 characters, F81 with '
                                       'per-character frequencies, marginal pass (model upload + BU + TD + posteriors)', **ragged)
     # ---- cfg3: 262 144 tips, JTT k=20, joint sweep (P(t) built and folded in registers on the FP64 vector units,
