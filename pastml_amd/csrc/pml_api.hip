@@ -71,7 +71,8 @@ static int fail(int code, const char* fmt, ...) {
     X(STACK_MIN, 0, 1) X(NO_STACK, 1, 1) X(DEBUG, 1, 0) X(BLOCK_NODES, 0, 1) X(BLOCK_MAX_STORED, 0, 1)                 \
     X(BLOCK_HEIGHT_CAP, 0, 1) X(SMALL_MAX_NODES, 0, 1) X(F81_R, 0, 1) X(F81_TD_R, 0, 1) X(NO_GRAPH, 1, 1)              \
     X(NARROW_UNITS, 0, 0) X(NO_EIGG_TIERS, 1, 0) X(NO_ABSORB, 1, 1) X(ABSORB_MIN, 0, 1) X(NO_SPIN_WAIT, 1, 0)   \
-    X(SPLIT_PARTS, 0, 0) X(PIJ_STAGE_ROWS, 0, 0) X(PIJ_ABLATE, 0, 0) X(PIJ_BLOCKS, 0, 0) X(NO_HEIGHT_ORDER, 1, 1) X(NO_TD_TAIL, 1, 0) X(NO_PIJ_VALU, 1, 0) X(PIJ_VALU, 1, 0) X(NO_EIGJ_PIPE, 1, 0)
+    X(SPLIT_PARTS, 0, 0) X(PIJ_STAGE_ROWS, 0, 0) X(PIJ_ABLATE, 0, 0) X(PIJ_BLOCKS, 0, 0) X(NO_HEIGHT_ORDER, 1, 1) X(NO_TD_TAIL, 1, 0) X(NO_PIJ_VALU, 1, 0) X(PIJ_VALU, 1, 0) X(NO_EIGJ_PIPE, 1, 0) \
+    X(THIN_UNITS, 0, 1) X(THIN_BLOCK_NODES, 0, 1) X(NO_THIN, 1, 0) X(NO_THIN_WIDE, 1, 0)
 enum PmlTunable {
 #define X(name, flag, tree) T_##name,
     PML_TUNABLES(X)
@@ -168,6 +169,26 @@ struct pml_ctx {
         std::vector<int> top_bu_offsets, top_td_offsets;               // host copies (launch geometry)
         std::vector<char> top_bu_vec;                                   // per top level: stored node among children 0, 1
     } blocks;
+    // Thin ends of a large ragged forest, units of fewer than 8 lanes (round 5).  Bottom-up: the fused levels from
+    // floor_level on (each of at most PASTML_HIP_THIN_UNITS units) in tiers of subtree blocks, like `blocks` but of that
+    // part of the forest only and with several small subtrees per workgroup; the wide levels below stay level launches.
+    struct ThinSchedule {
+        bool ok = false;
+        int floor_level = 0;  // the fused levels below stay level launches
+        int top_level = 0;    // ... and from this one on they are the narrow end's (level launches where still wide)
+        struct Tier { int first_block, n_blocks; };
+        std::vector<Tier> tiers;   // runs of levels, each cut into subtrees of at most THIN_BLOCK_NODES units: a launch per tier
+        PmlUnit* d_units = nullptr;
+        int *d_start = nullptr, *d_levels = nullptr, *d_lv = nullptr;
+    } thin;
+    // Top-down: the depths from first_depth on (each of at most THIN_UNITS parents): the subtrees hanging at first_depth,
+    // packed into bins of about THIN_BLOCK_NODES units, ONE launch walks them all, a workgroup per (bin, column).
+    struct DeepSchedule {
+        bool ok = false;
+        int first_depth = 0, n_blocks = 0;
+        PmlUnit* d_units = nullptr;
+        int *d_start = nullptr, *d_levels = nullptr, *d_lv = nullptr;
+    } deep;
     // two-level units (pml_kernels_f81.h): nodes with two stored children that each carry two cherries of two tips run
     // both levels in one unit; they and their children leave the level lists ("rest" lists, same level structure)
     struct SuperSchedule {
@@ -727,12 +748,31 @@ static void launch_small_f81(pml_ctx* ctx, bool bottom_up, int do_prep, const Pm
 }
 
 // one workgroup per (subtree block, column) walks the block's levels (pml_kernels_f81.h, bottom)
+// (the tables of one launch: `blocks`, or the thin ends of a large forest -- `thin` bottom-up, `deep` top-down)
+struct BlockTables {
+    const PmlUnit* units;
+    const int *start, *levels, *lv;
+    int n_blocks;
+};
+static BlockTables block_tables(const pml_ctx* ctx, bool bottom_up, int which) {
+    if (which >= 1) {   // (bottom-up: tier which - 1 of the thin levels)
+        if (bottom_up) {
+            const pml_ctx::ThinSchedule::Tier& T = ctx->thin.tiers[which - 1];
+            return {ctx->thin.d_units, ctx->thin.d_start + T.first_block, ctx->thin.d_levels + T.first_block, ctx->thin.d_lv, T.n_blocks};
+        }
+        return {ctx->deep.d_units, ctx->deep.d_start, ctx->deep.d_levels, ctx->deep.d_lv, ctx->deep.n_blocks};
+    }
+    const pml_ctx::BlockSchedule& B = ctx->blocks;
+    if (bottom_up) return {B.d_bu_units, B.d_bu_start, B.d_bu_levels, B.d_bu_lv, B.n_blocks};
+    return {B.d_td_units, B.d_td_start, B.d_td_levels, B.d_td_lv, B.n_blocks};
+}
+
 template <int G, int R>
-static void launch_blocks_f81(pml_ctx* ctx, bool bottom_up) {
+static void launch_blocks_f81(pml_ctx* ctx, bool bottom_up, int which) {
     const PmlTree t = tree_of(ctx, true);
     const PmlCols c = cols_of(ctx);
     const PmlState st = state_of(ctx);
-    const pml_ctx::BlockSchedule& B = ctx->blocks;
+    const BlockTables B = block_tables(ctx, bottom_up, which);
     // Workgroup size: 512 threads while every (block, column) workgroup is resident at once; with more workgroups than
     // the chip holds the launch runs in rounds of long-lived workgroups (HIV1C x 14 columns: 980 workgroups of 8 waves,
     // one per CU at 3 waves per SIMD -> four rounds, 97 us for blocks of <= 24 level steps), so the workgroups shrink
@@ -757,13 +797,12 @@ static void launch_blocks_f81(pml_ctx* ctx, bool bottom_up) {
     if (forced >= 64 && forced <= PML_SMALL_BLOCK) threads = forced;
     dim3 grid(B.n_blocks, ctx->C), block(threads);
     if (bottom_up)
-        hipLaunchKernelGGL((bu_f81_blocks_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, B.d_bu_units, B.d_bu_start,
-                           B.d_bu_levels, B.d_bu_lv);
+        hipLaunchKernelGGL((bu_f81_blocks_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, B.units, B.start, B.levels, B.lv);
     else {
         const bool signal = ctx->signal_next_td && ctx->C <= 64 && !ctx->windowed && !ctx->tune.on(T_NO_SPIN_WAIT);
         ctx->signal_next_td = false;
-        hipLaunchKernelGGL((td_f81_blocks_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, B.d_td_units, B.d_td_start,
-                           B.d_td_levels, B.d_td_lv, signal ? ctx->d_done : nullptr, signal ? ctx->h_done : nullptr);
+        hipLaunchKernelGGL((td_f81_blocks_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, B.units, B.start, B.levels,
+                           B.lv, signal ? ctx->d_done : nullptr, signal ? ctx->h_done : nullptr);
         ctx->td_final_signals = signal;
         if (signal) ++ctx->signals_enqueued;
     }
@@ -826,14 +865,14 @@ static int dispatch_small_f81(pml_ctx* ctx, bool bottom_up, int do_prep, int fir
     return fail(PML_ERR_UNSUPPORTED, "no F81 kernel for G=%d R=%d", g, r);
 }
 
-static int dispatch_blocks_f81(pml_ctx* ctx, bool bottom_up) {
+static int dispatch_blocks_f81(pml_ctx* ctx, bool bottom_up, int which = 0) {
     int g, r;
     multi_level_shape(ctx, bottom_up, g, r);
-#define X(G_, R_)                                    \
-    if (g == G_ && r == R_) {                        \
-        launch_blocks_f81<G_, R_>(ctx, bottom_up);   \
-        HIP_TRY(hipGetLastError());                  \
-        return PML_OK;                               \
+#define X(G_, R_)                                           \
+    if (g == G_ && r == R_) {                               \
+        launch_blocks_f81<G_, R_>(ctx, bottom_up, which);   \
+        HIP_TRY(hipGetLastError());                         \
+        return PML_OK;                                      \
     }
     PML_F81_CASES(X)
 #undef X
@@ -896,6 +935,18 @@ static bool super_units(const pml_ctx* ctx) {
 // the sweeps of this context run the level schedule with two-level units (not one launch per sweep, not subtree blocks)
 static bool super_sweeps(const pml_ctx* ctx) {
     return super_units(ctx) && !single_launch_sweeps(ctx) && !block_schedule(ctx);
+}
+
+// the thin ends of a large forest as subtree blocks (pml_tree_upload).  Measured, marginal pass, default against NO_THIN
+// (profiles/r05u_thin_ends.txt): 100 000 tips with polytomies x 16 characters k = 4 1.43 -> 1.16 ms, k = 20 1.79 -> 1.55;
+// random binary 40 000 tips x 8 k = 4 0.368 -> 0.313, k = 64 0.587 -> 0.504; 262 144 tips x 32 k = 4 1.60 -> 1.54,
+// k = 12 2.54 -> 2.49, k = 20 3.50 -> 3.43 (there the wide levels dominate).  NO_THIN_WIDE: units of fewer than 8 lanes only.
+static bool thin_bottom_up(const pml_ctx* ctx) {
+    return ctx->thin.ok && ctx->kind == PML_MODEL_F81 && !ctx->tune.on(T_NO_THIN) &&
+           ((!ctx->bu_wide_lanes && ctx->Gf < 8) || !ctx->tune.on(T_NO_THIN_WIDE));
+}
+static bool deep_top_down(const pml_ctx* ctx) {
+    return ctx->deep.ok && ctx->kind == PML_MODEL_F81 && !ctx->tune.on(T_NO_THIN) && (ctx->Gt < 8 || !ctx->tune.on(T_NO_THIN_WIDE));
 }
 
 template <int G, int R>
@@ -2524,6 +2575,170 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
                 }
             }
         }
+        // ---- thin ends of a large forest (units of fewer than 8 lanes use them: thin_bottom_up / deep_top_down).
+        // A ragged forest has many levels that hold a few hundred to a few thousand units: a launch of its own costs
+        // 5 - 15 us each, a level step inside a workgroup's walk 2 us.  Bottom-up, the thin levels are the high ones
+        // (every fused level from floor_level on holds at most THIN_UNITS units): subtree blocks + top over that part
+        // of the forest, the blocks in ONE launch behind the wide levels' launches, the top in the narrow end's launch.
+        // Top-down, they are the deep ones: the subtrees hanging at first_depth in ONE launch behind the wide depths.
+        // Small subtrees share a workgroup (bins of up to THIN_BLOCK_NODES units; units of one level of different
+        // subtrees do not depend on each other), so a workgroup's waves have work.
+        {
+            pml_ctx::ThinSchedule& H = ctx->thin;
+            H = pml_ctx::ThinSchedule();
+            pml_ctx::DeepSchedule& D = ctx->deep;
+            D = pml_ctx::DeepSchedule();
+            const int thin = (int)ctx->tune.get(T_THIN_UNITS, 4096);
+            const int S = std::max(8, (int)ctx->tune.get(T_THIN_BLOCK_NODES, 256));
+            const int narrow = std::min(128, std::max(1, thin / 32));  // (levels of about this many units are the single-workgroup launch's anyway)
+            auto put = [&](auto** dst, const auto& v) -> int {
+                PML_TRY(dev_alloc(ctx, dst, v.size()));
+                if (!v.empty()) PML_TRY(upload(ctx, *dst, v.data(), v.size()));
+                return PML_OK;
+            };
+            // bottom-up: levels [L0, Ltop) are thin and not yet narrow
+            int L0 = max_h, Ltop = max_h;
+            while (L0 > 0 && off[L0] - off[L0 - 1] <= thin) --L0;
+            while (Ltop > L0 && off[Ltop] - off[Ltop - 1] <= narrow) --Ltop;
+            if (thin > 0 && L0 > 0 && Ltop - L0 >= 3) {
+                std::vector<int> ssz(n_nodes), blk(n_nodes), bu_list, bu_start, bu_levels, bu_lv;
+                int a = L0;
+                while (a < Ltop) {
+                    // the tier's nodes: fused height in (a, hc), hc = the lowest height at which a subtree of them exceeds S
+                    std::fill(ssz.begin(), ssz.end(), 0);
+                    for (int i = n_nodes - 1; i >= 0; --i) {
+                        if (kind[i] != PML_KIND_STORED || fh[i] <= a) continue;
+                        ssz[i] += 1;
+                        if (parent[i] >= 0) ssz[parent[i]] += ssz[i];
+                    }
+                    int hc = max_h + 1;
+                    for (int q = off[a]; q < n_stored; ++q)
+                        if (ssz[order[q]] > S) hc = std::min(hc, fh[order[q]]);
+                    // subtrees into bins: the open one while it fits (parents have smaller ids)
+                    std::fill(blk.begin(), blk.end(), -1);
+                    int nb = 0, fill = 0;
+                    for (int i = 0; i < n_nodes; ++i) {
+                        if (kind[i] != PML_KIND_STORED || fh[i] <= a || fh[i] >= hc) continue;
+                        const int p = parent[i];
+                        if (p >= 0 && blk[p] >= 0) {
+                            blk[i] = blk[p];
+                        } else {
+                            if (nb == 0 || fill + ssz[i] > S) {
+                                ++nb;
+                                fill = 0;
+                            }
+                            fill += ssz[i];
+                            blk[i] = nb - 1;
+                        }
+                    }
+                    std::vector<std::vector<int>> members(nb);
+                    for (int q = off[a]; q < off[hc - 1]; ++q) members[blk[order[q]]].push_back(order[q]);   // (ascending height)
+                    pml_ctx::ThinSchedule::Tier T;
+                    T.first_block = (int)bu_start.size();
+                    T.n_blocks = nb;
+                    for (int b = 0; b < nb; ++b) {
+                        const std::vector<int>& mem = members[b];
+                        bu_start.push_back((int)bu_lv.size());
+                        int nl = 0;
+                        for (size_t q = 0; q < mem.size(); ++q) {
+                            if (q == 0 || fh[mem[q]] != fh[mem[q - 1]]) {
+                                bu_lv.push_back((int)bu_list.size());
+                                ++nl;
+                            }
+                            bu_list.push_back(mem[q]);
+                        }
+                        bu_lv.push_back((int)bu_list.size());
+                        bu_levels.push_back(nl);
+                    }
+                    H.tiers.push_back(T);
+                    if (ctx->tune.on(T_DEBUG))
+                        fprintf(stderr, "pastml_hip: thin bottom-up tier: levels %d .. %d of %d, %d units in %d bins\n", a, hc - 2,
+                                max_h, off[hc - 1] - off[a], nb);
+                    a = hc - 1;
+                }
+                if ((int)H.tiers.size() + 2 <= a - L0) {   // (launches saved)
+                    std::vector<PmlUnit> u1;
+                    describe(bu_list.data(), (int)bu_list.size(), true, u1);
+                    if (!ctx->tune.on(T_NO_SHAPE_SORT)) u1 = by_shape(u1, bu_lv, bu_list.size());
+                    u1.push_back(u1[0]);  // (slack: walk_levels fetches a level's first unit before it looks at its size)
+                    PML_TRY(put(&H.d_units, u1));
+                    PML_TRY(put(&H.d_start, bu_start));
+                    PML_TRY(put(&H.d_levels, bu_levels));
+                    PML_TRY(put(&H.d_lv, bu_lv));
+                    HIP_TRY(hipStreamSynchronize(ctx->stream));  // the vectors go out of scope
+                    H.floor_level = L0;
+                    H.top_level = a;
+                    H.ok = true;
+                }
+            }
+            // top-down: the depths behind the widest one
+            const std::vector<int>& toff = ctx->td_parent_offsets_f;
+            int widest = 0;
+            for (int l = 1; l < n_td_levels; ++l)
+                if (toff[l + 1] - toff[l] > toff[widest + 1] - toff[widest]) widest = l;
+            int D0 = n_td_levels;
+            while (D0 > widest + 1 && toff[D0] - toff[D0 - 1] <= thin) --D0;
+            int n_mid = 0;
+            for (int l = D0; l < n_td_levels; ++l) n_mid += toff[l + 1] - toff[l] > narrow;
+            if (thin > 0 && D0 > 0 && D0 < n_td_levels && n_mid >= 3) {
+                // a unit's bin: that of its parent's unit; the units of depth D0 open the subtrees
+                std::vector<int> bin(n_nodes, -1), size(n_nodes, 0);
+                for (int q = n_stored - 1; q >= toff[D0]; --q) {   // (the lists ascend in depth: children come later)
+                    const int n = tdp[q];
+                    size[n] += 1;
+                    if (q >= toff[D0 + 1]) size[parent[n]] += size[n];
+                }
+                int nb = 0, fill = 0;
+                for (int q = toff[D0]; q < toff[D0 + 1]; ++q) {
+                    const int n = tdp[q];
+                    if (nb == 0 || fill + size[n] > S) {
+                        ++nb;
+                        fill = 0;
+                    }
+                    fill += size[n];
+                    bin[n] = nb - 1;
+                }
+                std::vector<std::vector<int>> members(nb);
+                for (int q = toff[D0]; q < n_stored; ++q) {
+                    const int n = tdp[q];
+                    if (q >= toff[D0 + 1]) bin[n] = bin[parent[n]];
+                    members[bin[n]].push_back(q);   // (positions: the depth of a unit is that of its list segment)
+                }
+                std::vector<int> depth_of_pos(n_stored - toff[D0]);
+                for (int l = D0; l < n_td_levels; ++l)
+                    for (int q = toff[l]; q < toff[l + 1]; ++q) depth_of_pos[q - toff[D0]] = l;
+                std::vector<int> td_list, td_start(nb), td_levels(nb), td_lv;
+                for (int b = 0; b < nb; ++b) {
+                    const std::vector<int>& mem = members[b];   // ascending positions = non-decreasing depth
+                    td_start[b] = (int)td_lv.size();
+                    int nl = 0;
+                    for (size_t q = 0; q < mem.size(); ++q) {
+                        if (q == 0 || depth_of_pos[mem[q] - toff[D0]] != depth_of_pos[mem[q - 1] - toff[D0]]) {
+                            td_lv.push_back((int)td_list.size());
+                            ++nl;
+                        }
+                        td_list.push_back(tdp[mem[q]]);
+                    }
+                    td_lv.push_back((int)td_list.size());
+                    td_levels[b] = nl;
+                }
+                std::vector<PmlUnit> u2;
+                describe(td_list.data(), (int)td_list.size(), true, u2);
+                if (!ctx->tune.on(T_NO_SHAPE_SORT)) u2 = by_shape(u2, td_lv, td_list.size());
+                u2.push_back(u2[0]);
+                PML_TRY(put(&D.d_units, u2));
+                PML_TRY(put(&D.d_start, td_start));
+                PML_TRY(put(&D.d_levels, td_levels));
+                PML_TRY(put(&D.d_lv, td_lv));
+                HIP_TRY(hipStreamSynchronize(ctx->stream));
+                D.first_depth = D0;
+                D.n_blocks = nb;
+                D.ok = true;
+                if (ctx->tune.on(T_DEBUG))
+                    fprintf(stderr, "pastml_hip: thin top-down depths from %d of %d: %d units in %d bins\n", D0, n_td_levels,
+                            (int)td_list.size(), nb);
+            }
+        }
         }
         PML_TRY(dev_alloc(ctx, &ctx->d_kind, n_nodes));
         PML_TRY(dev_alloc(ctx, &ctx->d_bu_order_f, n_stored));
@@ -3219,6 +3434,24 @@ static int enqueue_bottom_up(pml_ctx* ctx, int is_marginal, bool small_path, boo
             PML_TRY(dispatch_small_f81(ctx, true, 0, 0, tail, U.d_bu_units_r, U.d_bu_offsets_r + (nl - tail)));
             loglik_done = true;
         }
+    } else if (fused && thin_bottom_up(ctx)) {
+        // the wide levels one launch each, the thin ones in tiers of subtree blocks (a launch per tier), then the narrow
+        // end's single launch (in between, level launches where a level is still too wide for it)
+        const pml_ctx::ThinSchedule& H = ctx->thin;
+        auto level_launch = [&](int l) -> int {
+            const int a = ctx->bu_offsets_f[l], b = ctx->bu_offsets_f[l + 1];
+            return dispatch_sweep(ctx, ctx->bu_level_vec_f[l] ? SW_BU_MARG_FUSED : SW_BU_MARG_FUSED_NOVEC, ctx->d_bu_order_f + a, b - a);
+        };
+        for (int l = 0; l < H.floor_level; ++l) PML_TRY(level_launch(l));
+        for (size_t q = 0; q < H.tiers.size(); ++q) PML_TRY(dispatch_blocks_f81(ctx, true, 1 + (int)q));
+        const int nl = (int)ctx->bu_offsets_f.size() - 1;
+        int tail = std::min(nl - H.top_level, narrow_levels(ctx, ctx->bu_offsets_f, nl, false, ctx->sched_cols));
+        for (int l = H.top_level; l < nl - tail; ++l) PML_TRY(level_launch(l));
+        PML_TRY(prof_end(ctx, 0, H.floor_level + (long long)H.tiers.size() + (nl - tail - H.top_level)));
+        if (tail > 0) {
+            PML_TRY(dispatch_small_f81(ctx, true, 0, nl - tail, tail));
+            loglik_done = true;
+        }
     } else if (fused) {
         const int nl = (int)ctx->bu_offsets_f.size() - 1;
         const int tail = narrow_levels(ctx, ctx->bu_offsets_f, nl, false, ctx->sched_cols);
@@ -3673,6 +3906,19 @@ static int run_top_down(pml_ctx* ctx) {
         // -- a launch of their own costs 9 - 11 us each, a level step of the walk 2 - 3 (round 5)
         int tail = 0;
         // (units of fewer than 8 lanes only: at k = 64 a level step inside the walk costs what the launch does)
+        // ... and when many of the deep depths are thin, all of them: the subtrees hanging at the first one, a workgroup per
+        // (bin of subtrees, column) walking its depths (pml_tree_upload, "thin ends")
+        const bool deep = td_fused && !td_small && deep_top_down(ctx) && ctx->deep.first_depth > head;
+        if (deep) {
+            for (int l = head; l < ctx->deep.first_depth; ++l) {
+                const int a = ctx->td_parent_offsets_f[l], b = ctx->td_parent_offsets_f[l + 1];
+                PML_TRY(dispatch_sweep(ctx, SW_TD_FUSED, ctx->d_td_parents_f + a, b - a));
+                if (b > a) ++n_launch;
+            }
+            PML_TRY(dispatch_blocks_f81(ctx, false, 1));
+            PML_TRY(prof_end(ctx, 1, n_launch + 1));
+            return PML_OK;
+        }
         if (td_fused && !td_small && ctx->Gt < 8 && !ctx->tune.on(T_NO_TD_TAIL)) {
             tail = narrow_levels(ctx, ctx->td_parent_offsets_f, ctx->n_td_levels, false, ctx->C, 0, 1);
             if (tail > ctx->n_td_levels - head) tail = ctx->n_td_levels - head;

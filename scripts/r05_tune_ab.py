@@ -21,6 +21,9 @@ cases = dict(ragged64=(lambda: FlatForest.random(262144, seed=3, max_arity=2, n_
              ragged2=(lambda: FlatForest.random(262144, seed=3, max_arity=2, n_trees=1), 2, 32),
              poly64=(lambda: FlatForest.random(100000, seed=5, max_arity=5, n_trees=2), 64, 16),
              poly4=(lambda: FlatForest.random(100000, seed=5, max_arity=5, n_trees=2), 4, 16),
+             poly20=(lambda: FlatForest.random(100000, seed=5, max_arity=5, n_trees=2), 20, 16),
+             ragged20=(lambda: FlatForest.random(262144, seed=3, max_arity=2, n_trees=1), 20, 32),
+             mid64=(lambda: FlatForest.random(40000, seed=7, max_arity=2, n_trees=1), 64, 8),
              balanced4=(lambda: synthetic.balanced_forest(18), 4, 32),
              balanced12=(lambda: synthetic.balanced_forest(18), 12, 32),
              mid4=(lambda: FlatForest.random(40000, seed=7, max_arity=2, n_trees=1), 4, 8),

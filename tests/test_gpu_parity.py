@@ -1643,3 +1643,51 @@ def test_two_level_units_when_roots_are_two_level_nodes(k):
             r = orc.full_marginal_pass(flat, masks[c].astype(int), specs[c][0], *specs[c][1])
             np.testing.assert_allclose(lnl[c], r['loglik'], rtol=LNL_RTOL)
             np.testing.assert_allclose(post[c], r['posterior'], rtol=1e-8, atol=1e-12)
+
+
+@pytest.mark.parametrize('k', [2, 4, 7, 12, 16, 20, 33, 64])
+def test_thin_ends_as_subtree_blocks_have_the_bits_of_the_level_launches(k):
+    """
+    Thin ends of a large ragged forest (pml_tree_upload, "thin ends"): the high fused levels in tiers of subtree blocks (a
+    launch per tier, several small subtrees per workgroup) + the narrow end's launch, the deep depths as bins of subtrees
+    in one launch -- against the same library with NO_THIN (a launch per level), bit for bit: ln L, posteriors, sums,
+    scales, the bottom-up vectors a download materialises, a partial sweep; fewer launches; and against the oracle.
+    THIN_UNITS / THIN_BLOCK_NODES are scaled down so that forests of a few thousand tips have thin ends of several tiers
+    and bins; k > 16: units of 8 lanes (the level schedule without two-level units, which has no thin ends of its own).
+    """
+    rng = np.random.default_rng(2300 + k)
+    forests = [FlatForest.random(6000, seed=k, max_arity=2, n_trees=1), FlatForest.random(5000, seed=k + 1, max_arity=4, n_trees=3)]
+    base = dict(BLOCK_NODES=0, SMALL_MAX_NODES=0, SMALL_MANY_NODES=0, THIN_UNITS=400, THIN_BLOCK_NODES=24, NARROW_UNITS=8,
+                NO_SUPER=1 if k > 16 else None)
+    for fi, flat in enumerate(forests):
+        C = 3
+        specs = [(random_spec('F81', k, rng), (float(rng.uniform(0.5, 3)), 0.0, 1.0)) for _ in range(C)]
+        masks = np.stack([random_masks(flat, k, rng, missing=0.05, multi=0.05, internal=0.02) for _ in range(C)])
+        masks[0] = synthetic.one_hot_masks(flat, k, rng.integers(0, k, size=flat.n_tips))
+        results, launches = [], []
+        for off in (True, False):
+            with hip.Engine(flat, C, k, tune=dict(base, NO_THIN=1 if off else None)) as eng:
+                eng.set_models(specs)
+                eng.set_masks(masks)
+                eng.profile_enable(True)
+                lnl, post, lh_sum, lh_sf = eng.marginal_pass()
+                launches.append((eng.profile_read(0)[1], eng.profile_read(1)[1]))
+                eng.profile_enable(False)
+                assert np.array_equal(lnl, eng.bottom_up(True))
+                lnl2, post2, lh_sum2, lh_sf2 = eng.marginal_pass()    # (the captured graphs)
+                assert np.array_equal(lnl, lnl2) and np.array_equal(post, post2)
+                bu = [eng.download(hip.BUF_BU, c) for c in range(C)]
+                bu_sf = [eng.download(hip.BUF_BU_SF, c) for c in range(C)]
+                # a sweep of one column only
+                specs2 = list(specs)
+                specs2[1] = (specs[1][0], (specs[1][1][0] * 1.25, 0.0, 1.0))
+                eng.set_models(specs2)
+                eng.bottom_up_submit(True, active=np.array([0, 1, 0], dtype=np.uint8))
+                part = np.asarray(eng.bottom_up_collect(True))
+            results.append((lnl, post, lh_sum, lh_sf, np.stack(bu), np.stack(bu_sf), part))
+        assert launches[1][0] < launches[0][0] and launches[1][1] < launches[0][1], launches
+        assert np.isfinite(results[0][1]).all()
+        for a, b in zip(results[0], results[1]):
+            assert np.array_equal(a, b), 'forest {}'.format(fi)
+        ref = orc.bottom_up(flat, masks[1].astype(int), specs[1][0], *specs[1][1])
+        np.testing.assert_allclose(results[1][0][1], ref['loglik'], rtol=LNL_RTOL)
