@@ -72,7 +72,7 @@ static int fail(int code, const char* fmt, ...) {
     X(BLOCK_HEIGHT_CAP, 0, 1) X(SMALL_MAX_NODES, 0, 1) X(F81_R, 0, 1) X(F81_TD_R, 0, 1) X(NO_GRAPH, 1, 1)              \
     X(NARROW_UNITS, 0, 0) X(NO_EIGG_TIERS, 1, 0) X(NO_ABSORB, 1, 1) X(ABSORB_MIN, 0, 1) X(NO_SPIN_WAIT, 1, 0)   \
     X(SPLIT_PARTS, 0, 0) X(PIJ_STAGE_ROWS, 0, 0) X(PIJ_ABLATE, 0, 0) X(PIJ_BLOCKS, 0, 0) X(NO_HEIGHT_ORDER, 1, 1) X(NO_TD_TAIL, 1, 0) X(NO_PIJ_VALU, 1, 0) X(PIJ_VALU, 1, 0) X(NO_EIGJ_PIPE, 1, 0) \
-    X(THIN_UNITS, 0, 1) X(THIN_BLOCK_NODES, 0, 1) X(NO_THIN, 1, 0) X(NO_THIN_WIDE, 1, 0)
+    X(THIN_UNITS, 0, 1) X(THIN_BYTES, 0, 1) X(THIN_BLOCK_NODES, 0, 1) X(NO_THIN, 1, 0) X(NO_THIN_WIDE, 1, 0)
 enum PmlTunable {
 #define X(name, flag, tree) T_##name,
     PML_TUNABLES(X)
@@ -141,6 +141,7 @@ struct pml_ctx {
     int *d_tip_rest = nullptr, *d_tip_rest_count = nullptr;  // eigen joint sweep: [C][n_tips] tips that are not observed, [C]
     double* d_dist = nullptr;
     std::vector<int> bu_offsets, td_offsets, td_parent_offsets, h_parent, h_n_children;
+    std::vector<int> h_first_child, h_fh, h_order_f, h_tdp;  // host copies for build_thin_ends (fused heights, fused lists)
     // Internal node numbering (height_order below): the library numbers the nodes of a ragged forest so that the sibling
     // groups a level's units gather lie next to each other; every per-node array that crosses the C-ABI is in the CALLER's
     // numbering and is permuted on the way in / out.  Both empty when the caller's numbering is kept (balanced trees, ...).
@@ -1615,6 +1616,56 @@ int pml_sweep_schedule(pml_ctx* ctx, int32_t* kind, int32_t* n_blocks, int32_t* 
     return PML_OK;
 }
 
+// unit descriptors (PmlUnit, pml_kernels_f81.h) of a node list
+static int describe_units(const int* first_child, const int* n_children, const unsigned char* kind, const int* list, int count,
+                          bool use_kind, std::vector<PmlUnit>& out) {
+    out.resize(count > 0 ? count : 1);
+    for (int q = 0; q < count; ++q) {
+        const int n = list[q];
+        PmlUnit u;
+        u.n = n;
+        u.fc = first_child[n];
+        u.pad = 0;
+        const int nc = n_children[n];
+        int packed = nc < 15 ? nc : 15;
+        bool cherries_ok = true, stored_first_two_only = true;
+        for (int j = 0; j < 4; ++j) {
+            u.cfc[j] = 0;
+            if (j >= nc) continue;
+            const int ch = u.fc + j;
+            u.cfc[j] = first_child[ch];
+            const int kd = use_kind ? (int)kind[ch] : (n_children[ch] == 0 ? PML_KIND_TIP : PML_KIND_STORED);
+            int code = kd == PML_KIND_TIP ? 0 : 1;
+            if (kd == PML_KIND_CHERRY) {
+                if (n_children[ch] > 4) {
+                    cherries_ok = false;
+                    code = 2;
+                } else {
+                    code = 1 + n_children[ch];
+                }
+            }
+            packed |= code << (8 + 3 * j);
+            if (j >= 2 && code == 1) stored_first_two_only = false;
+        }
+        if (cherries_ok) packed |= 1 << 4;
+        if (stored_first_two_only) packed |= 1 << 5;
+        u.packed = packed;
+        out[q] = u;
+    }
+    return 0;
+}
+
+// the units of every level (offs) sorted by shape, stable (see pml_tree_upload)
+static std::vector<PmlUnit> units_by_shape(const std::vector<PmlUnit>& in, const std::vector<int>& offs, size_t count) {
+    auto shape_less = [](const PmlUnit& x, const PmlUnit& y) { return x.packed < y.packed; };
+    std::vector<PmlUnit> out(in);
+    for (size_t l = 0; l + 1 < offs.size(); ++l) {
+        const size_t a = (size_t)offs[l], b = std::min((size_t)offs[l + 1], count);
+        if (b > a + 1) std::stable_sort(out.begin() + a, out.begin() + b, shape_less);
+    }
+    return out;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_t* parent, const int32_t* first_child,
                     const int32_t* n_children, const double* dist, int32_t n_bu_levels, const int32_t* bu_offsets,
@@ -1859,40 +1910,7 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
         {
             // unit descriptors (PmlUnit, pml_kernels_f81.h) for the three node lists the F81 kernels walk
             auto describe = [&](const int* list, int count, bool use_kind, std::vector<PmlUnit>& out) {
-                out.resize(count > 0 ? count : 1);
-                for (int q = 0; q < count; ++q) {
-                    const int n = list[q];
-                    PmlUnit u;
-                    u.n = n;
-                    u.fc = first_child[n];
-                    u.pad = 0;
-                    const int nc = n_children[n];
-                    int packed = nc < 15 ? nc : 15;
-                    bool cherries_ok = true, stored_first_two_only = true;
-                    for (int j = 0; j < 4; ++j) {
-                        u.cfc[j] = 0;
-                        if (j >= nc) continue;
-                        const int ch = u.fc + j;
-                        u.cfc[j] = first_child[ch];
-                        const int kd = use_kind ? (int)kind[ch] : (n_children[ch] == 0 ? PML_KIND_TIP : PML_KIND_STORED);
-                        int code = kd == PML_KIND_TIP ? 0 : 1;
-                        if (kd == PML_KIND_CHERRY) {
-                            if (n_children[ch] > 4) {
-                                cherries_ok = false;
-                                code = 2;
-                            } else {
-                                code = 1 + n_children[ch];
-                            }
-                        }
-                        packed |= code << (8 + 3 * j);
-                        if (j >= 2 && code == 1) stored_first_two_only = false;
-                    }
-                    if (cherries_ok) packed |= 1 << 4;
-                    if (stored_first_two_only) packed |= 1 << 5;
-                    u.packed = packed;
-                    out[q] = u;
-                }
-                return 0;
+                return describe_units(first_child, n_children, kind.data(), list, count, use_kind, out);
             };
             std::vector<PmlUnit> ub_f, ut_f, ub, uc;
             describe(cherries.data(), (int)cherries.size(), false, uc);
@@ -2575,170 +2593,13 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
                 }
             }
         }
-        // ---- thin ends of a large forest (units of fewer than 8 lanes use them: thin_bottom_up / deep_top_down).
-        // A ragged forest has many levels that hold a few hundred to a few thousand units: a launch of its own costs
-        // 5 - 15 us each, a level step inside a workgroup's walk 2 us.  Bottom-up, the thin levels are the high ones
-        // (every fused level from floor_level on holds at most THIN_UNITS units): subtree blocks + top over that part
-        // of the forest, the blocks in ONE launch behind the wide levels' launches, the top in the narrow end's launch.
-        // Top-down, they are the deep ones: the subtrees hanging at first_depth in ONE launch behind the wide depths.
-        // Small subtrees share a workgroup (bins of up to THIN_BLOCK_NODES units; units of one level of different
-        // subtrees do not depend on each other), so a workgroup's waves have work.
-        {
-            pml_ctx::ThinSchedule& H = ctx->thin;
-            H = pml_ctx::ThinSchedule();
-            pml_ctx::DeepSchedule& D = ctx->deep;
-            D = pml_ctx::DeepSchedule();
-            const int thin = (int)ctx->tune.get(T_THIN_UNITS, 4096);
-            const int S = std::max(8, (int)ctx->tune.get(T_THIN_BLOCK_NODES, 256));
-            const int narrow = std::min(128, std::max(1, thin / 32));  // (levels of about this many units are the single-workgroup launch's anyway)
-            auto put = [&](auto** dst, const auto& v) -> int {
-                PML_TRY(dev_alloc(ctx, dst, v.size()));
-                if (!v.empty()) PML_TRY(upload(ctx, *dst, v.data(), v.size()));
-                return PML_OK;
-            };
-            // bottom-up: levels [L0, Ltop) are thin and not yet narrow
-            int L0 = max_h, Ltop = max_h;
-            while (L0 > 0 && off[L0] - off[L0 - 1] <= thin) --L0;
-            while (Ltop > L0 && off[Ltop] - off[Ltop - 1] <= narrow) --Ltop;
-            if (thin > 0 && L0 > 0 && Ltop - L0 >= 3) {
-                std::vector<int> ssz(n_nodes), blk(n_nodes), bu_list, bu_start, bu_levels, bu_lv;
-                int a = L0;
-                while (a < Ltop) {
-                    // the tier's nodes: fused height in (a, hc), hc = the lowest height at which a subtree of them exceeds S
-                    std::fill(ssz.begin(), ssz.end(), 0);
-                    for (int i = n_nodes - 1; i >= 0; --i) {
-                        if (kind[i] != PML_KIND_STORED || fh[i] <= a) continue;
-                        ssz[i] += 1;
-                        if (parent[i] >= 0) ssz[parent[i]] += ssz[i];
-                    }
-                    int hc = max_h + 1;
-                    for (int q = off[a]; q < n_stored; ++q)
-                        if (ssz[order[q]] > S) hc = std::min(hc, fh[order[q]]);
-                    // subtrees into bins: the open one while it fits (parents have smaller ids)
-                    std::fill(blk.begin(), blk.end(), -1);
-                    int nb = 0, fill = 0;
-                    for (int i = 0; i < n_nodes; ++i) {
-                        if (kind[i] != PML_KIND_STORED || fh[i] <= a || fh[i] >= hc) continue;
-                        const int p = parent[i];
-                        if (p >= 0 && blk[p] >= 0) {
-                            blk[i] = blk[p];
-                        } else {
-                            if (nb == 0 || fill + ssz[i] > S) {
-                                ++nb;
-                                fill = 0;
-                            }
-                            fill += ssz[i];
-                            blk[i] = nb - 1;
-                        }
-                    }
-                    std::vector<std::vector<int>> members(nb);
-                    for (int q = off[a]; q < off[hc - 1]; ++q) members[blk[order[q]]].push_back(order[q]);   // (ascending height)
-                    pml_ctx::ThinSchedule::Tier T;
-                    T.first_block = (int)bu_start.size();
-                    T.n_blocks = nb;
-                    for (int b = 0; b < nb; ++b) {
-                        const std::vector<int>& mem = members[b];
-                        bu_start.push_back((int)bu_lv.size());
-                        int nl = 0;
-                        for (size_t q = 0; q < mem.size(); ++q) {
-                            if (q == 0 || fh[mem[q]] != fh[mem[q - 1]]) {
-                                bu_lv.push_back((int)bu_list.size());
-                                ++nl;
-                            }
-                            bu_list.push_back(mem[q]);
-                        }
-                        bu_lv.push_back((int)bu_list.size());
-                        bu_levels.push_back(nl);
-                    }
-                    H.tiers.push_back(T);
-                    if (ctx->tune.on(T_DEBUG))
-                        fprintf(stderr, "pastml_hip: thin bottom-up tier: levels %d .. %d of %d, %d units in %d bins\n", a, hc - 2,
-                                max_h, off[hc - 1] - off[a], nb);
-                    a = hc - 1;
-                }
-                if ((int)H.tiers.size() + 2 <= a - L0) {   // (launches saved)
-                    std::vector<PmlUnit> u1;
-                    describe(bu_list.data(), (int)bu_list.size(), true, u1);
-                    if (!ctx->tune.on(T_NO_SHAPE_SORT)) u1 = by_shape(u1, bu_lv, bu_list.size());
-                    u1.push_back(u1[0]);  // (slack: walk_levels fetches a level's first unit before it looks at its size)
-                    PML_TRY(put(&H.d_units, u1));
-                    PML_TRY(put(&H.d_start, bu_start));
-                    PML_TRY(put(&H.d_levels, bu_levels));
-                    PML_TRY(put(&H.d_lv, bu_lv));
-                    HIP_TRY(hipStreamSynchronize(ctx->stream));  // the vectors go out of scope
-                    H.floor_level = L0;
-                    H.top_level = a;
-                    H.ok = true;
-                }
-            }
-            // top-down: the depths behind the widest one
-            const std::vector<int>& toff = ctx->td_parent_offsets_f;
-            int widest = 0;
-            for (int l = 1; l < n_td_levels; ++l)
-                if (toff[l + 1] - toff[l] > toff[widest + 1] - toff[widest]) widest = l;
-            int D0 = n_td_levels;
-            while (D0 > widest + 1 && toff[D0] - toff[D0 - 1] <= thin) --D0;
-            int n_mid = 0;
-            for (int l = D0; l < n_td_levels; ++l) n_mid += toff[l + 1] - toff[l] > narrow;
-            if (thin > 0 && D0 > 0 && D0 < n_td_levels && n_mid >= 3) {
-                // a unit's bin: that of its parent's unit; the units of depth D0 open the subtrees
-                std::vector<int> bin(n_nodes, -1), size(n_nodes, 0);
-                for (int q = n_stored - 1; q >= toff[D0]; --q) {   // (the lists ascend in depth: children come later)
-                    const int n = tdp[q];
-                    size[n] += 1;
-                    if (q >= toff[D0 + 1]) size[parent[n]] += size[n];
-                }
-                int nb = 0, fill = 0;
-                for (int q = toff[D0]; q < toff[D0 + 1]; ++q) {
-                    const int n = tdp[q];
-                    if (nb == 0 || fill + size[n] > S) {
-                        ++nb;
-                        fill = 0;
-                    }
-                    fill += size[n];
-                    bin[n] = nb - 1;
-                }
-                std::vector<std::vector<int>> members(nb);
-                for (int q = toff[D0]; q < n_stored; ++q) {
-                    const int n = tdp[q];
-                    if (q >= toff[D0 + 1]) bin[n] = bin[parent[n]];
-                    members[bin[n]].push_back(q);   // (positions: the depth of a unit is that of its list segment)
-                }
-                std::vector<int> depth_of_pos(n_stored - toff[D0]);
-                for (int l = D0; l < n_td_levels; ++l)
-                    for (int q = toff[l]; q < toff[l + 1]; ++q) depth_of_pos[q - toff[D0]] = l;
-                std::vector<int> td_list, td_start(nb), td_levels(nb), td_lv;
-                for (int b = 0; b < nb; ++b) {
-                    const std::vector<int>& mem = members[b];   // ascending positions = non-decreasing depth
-                    td_start[b] = (int)td_lv.size();
-                    int nl = 0;
-                    for (size_t q = 0; q < mem.size(); ++q) {
-                        if (q == 0 || depth_of_pos[mem[q] - toff[D0]] != depth_of_pos[mem[q - 1] - toff[D0]]) {
-                            td_lv.push_back((int)td_list.size());
-                            ++nl;
-                        }
-                        td_list.push_back(tdp[mem[q]]);
-                    }
-                    td_lv.push_back((int)td_list.size());
-                    td_levels[b] = nl;
-                }
-                std::vector<PmlUnit> u2;
-                describe(td_list.data(), (int)td_list.size(), true, u2);
-                if (!ctx->tune.on(T_NO_SHAPE_SORT)) u2 = by_shape(u2, td_lv, td_list.size());
-                u2.push_back(u2[0]);
-                PML_TRY(put(&D.d_units, u2));
-                PML_TRY(put(&D.d_start, td_start));
-                PML_TRY(put(&D.d_levels, td_levels));
-                PML_TRY(put(&D.d_lv, td_lv));
-                HIP_TRY(hipStreamSynchronize(ctx->stream));
-                D.first_depth = D0;
-                D.n_blocks = nb;
-                D.ok = true;
-                if (ctx->tune.on(T_DEBUG))
-                    fprintf(stderr, "pastml_hip: thin top-down depths from %d of %d: %d units in %d bins\n", D0, n_td_levels,
-                            (int)td_list.size(), nb);
-            }
-        }
+        // (the thin ends of a large forest are cut into subtree blocks when the columns are known: build_thin_ends)
+        ctx->h_first_child.assign(first_child, first_child + n_nodes);
+        ctx->h_fh = fh;
+        ctx->h_order_f.assign(order.begin(), order.begin() + n_stored);
+        ctx->h_tdp = tdp;
+        ctx->thin = pml_ctx::ThinSchedule();
+        ctx->deep = pml_ctx::DeepSchedule();
         }
         PML_TRY(dev_alloc(ctx, &ctx->d_kind, n_nodes));
         PML_TRY(dev_alloc(ctx, &ctx->d_bu_order_f, n_stored));
@@ -2761,6 +2622,183 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
         HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PML_OK;
+}
+
+// ---- thin ends of a large forest (thin_bottom_up / deep_top_down).
+// A ragged forest has many levels that hold a few hundred to a few thousand units: a launch of its own costs
+// 5 - 15 us each, a level step inside a workgroup's walk 2 us.  Bottom-up, the thin levels are the high ones
+// (every fused level from floor_level on holds at most THIN_UNITS units): subtree blocks + top over that part
+// of the forest, the blocks in ONE launch behind the wide levels' launches, the top in the narrow end's launch.
+// Top-down, they are the deep ones: the subtrees hanging at first_depth in ONE launch behind the wide depths.
+// Small subtrees share a workgroup (bins of up to THIN_BLOCK_NODES units; units of one level of different
+// subtrees do not depend on each other), so a workgroup's waves have work.
+// thin: the most units a thin level holds (pml_chars_alloc: by the bytes a level of that many units moves).
+static int build_thin_ends(pml_ctx* ctx, int thin) {
+    const int n_nodes = ctx->N, n_td_levels = ctx->n_td_levels;
+    const std::vector<int>& off = ctx->bu_offsets_f;
+    const int max_h = (int)off.size() - 1;
+    if (max_h <= 0) return PML_OK;
+    const int n_stored = off[max_h];
+    const std::vector<unsigned char>& kind = ctx->h_kind;
+    const std::vector<int>&parent = ctx->h_parent, &fh = ctx->h_fh, &order = ctx->h_order_f, &tdp = ctx->h_tdp;
+    auto describe = [&](const int* list, int count, bool use_kind, std::vector<PmlUnit>& out) {
+        describe_units(ctx->h_first_child.data(), ctx->h_n_children.data(), kind.data(), list, count, use_kind, out);
+    };
+    auto by_shape = [&](const std::vector<PmlUnit>& in, const std::vector<int>& offs, size_t count) { return units_by_shape(in, offs, count); };
+    pml_ctx::ThinSchedule& H = ctx->thin;
+    H = pml_ctx::ThinSchedule();
+    pml_ctx::DeepSchedule& D = ctx->deep;
+    D = pml_ctx::DeepSchedule();
+    const int S = std::max(8, (int)ctx->tune.get(T_THIN_BLOCK_NODES, 256));
+    const int narrow = std::min(128, std::max(1, thin / 32));  // (levels of about this many units are the single-workgroup launch's anyway)
+    auto put = [&](auto** dst, const auto& v) -> int {
+        PML_TRY(dev_alloc(ctx, dst, v.size()));
+        if (!v.empty()) PML_TRY(upload(ctx, *dst, v.data(), v.size()));
+        return PML_OK;
+    };
+    // bottom-up: levels [L0, Ltop) are thin and not yet narrow
+    int L0 = max_h, Ltop = max_h;
+    while (L0 > 0 && off[L0] - off[L0 - 1] <= thin) --L0;
+    while (Ltop > L0 && off[Ltop] - off[Ltop - 1] <= narrow) --Ltop;
+    if (thin > 0 && L0 > 0 && Ltop - L0 >= 3) {
+        std::vector<int> ssz(n_nodes), blk(n_nodes), bu_list, bu_start, bu_levels, bu_lv;
+        int a = L0;
+        while (a < Ltop) {
+            // the tier's nodes: fused height in (a, hc), hc = the lowest height at which a subtree of them exceeds S
+            std::fill(ssz.begin(), ssz.end(), 0);
+            for (int i = n_nodes - 1; i >= 0; --i) {
+                if (kind[i] != PML_KIND_STORED || fh[i] <= a) continue;
+                ssz[i] += 1;
+                if (parent[i] >= 0) ssz[parent[i]] += ssz[i];
+            }
+            int hc = max_h + 1;
+            for (int q = off[a]; q < n_stored; ++q)
+                if (ssz[order[q]] > S) hc = std::min(hc, fh[order[q]]);
+            // subtrees into bins: the open one while it fits (parents have smaller ids)
+            std::fill(blk.begin(), blk.end(), -1);
+            int nb = 0, fill = 0;
+            for (int i = 0; i < n_nodes; ++i) {
+                if (kind[i] != PML_KIND_STORED || fh[i] <= a || fh[i] >= hc) continue;
+                const int p = parent[i];
+                if (p >= 0 && blk[p] >= 0) {
+                    blk[i] = blk[p];
+                } else {
+                    if (nb == 0 || fill + ssz[i] > S) {
+                        ++nb;
+                        fill = 0;
+                    }
+                    fill += ssz[i];
+                    blk[i] = nb - 1;
+                }
+            }
+            std::vector<std::vector<int>> members(nb);
+            for (int q = off[a]; q < off[hc - 1]; ++q) members[blk[order[q]]].push_back(order[q]);   // (ascending height)
+            pml_ctx::ThinSchedule::Tier T;
+            T.first_block = (int)bu_start.size();
+            T.n_blocks = nb;
+            for (int b = 0; b < nb; ++b) {
+                const std::vector<int>& mem = members[b];
+                bu_start.push_back((int)bu_lv.size());
+                int nl = 0;
+                for (size_t q = 0; q < mem.size(); ++q) {
+                    if (q == 0 || fh[mem[q]] != fh[mem[q - 1]]) {
+                        bu_lv.push_back((int)bu_list.size());
+                        ++nl;
+                    }
+                    bu_list.push_back(mem[q]);
+                }
+                bu_lv.push_back((int)bu_list.size());
+                bu_levels.push_back(nl);
+            }
+            H.tiers.push_back(T);
+            if (ctx->tune.on(T_DEBUG))
+                fprintf(stderr, "pastml_hip: thin bottom-up tier: levels %d .. %d of %d, %d units in %d bins\n", a, hc - 2,
+                        max_h, off[hc - 1] - off[a], nb);
+            a = hc - 1;
+        }
+        if ((int)H.tiers.size() + 2 <= a - L0) {   // (launches saved)
+            std::vector<PmlUnit> u1;
+            describe(bu_list.data(), (int)bu_list.size(), true, u1);
+            if (!ctx->tune.on(T_NO_SHAPE_SORT)) u1 = by_shape(u1, bu_lv, bu_list.size());
+            u1.push_back(u1[0]);  // (slack: walk_levels fetches a level's first unit before it looks at its size)
+            PML_TRY(put(&H.d_units, u1));
+            PML_TRY(put(&H.d_start, bu_start));
+            PML_TRY(put(&H.d_levels, bu_levels));
+            PML_TRY(put(&H.d_lv, bu_lv));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));  // the vectors go out of scope
+            H.floor_level = L0;
+            H.top_level = a;
+            H.ok = true;
+        }
+    }
+    // top-down: the depths behind the widest one
+    const std::vector<int>& toff = ctx->td_parent_offsets_f;
+    int widest = 0;
+    for (int l = 1; l < n_td_levels; ++l)
+        if (toff[l + 1] - toff[l] > toff[widest + 1] - toff[widest]) widest = l;
+    int D0 = n_td_levels;
+    while (D0 > widest + 1 && toff[D0] - toff[D0 - 1] <= thin) --D0;
+    int n_mid = 0;
+    for (int l = D0; l < n_td_levels; ++l) n_mid += toff[l + 1] - toff[l] > narrow;
+    if (thin > 0 && D0 > 0 && D0 < n_td_levels && n_mid >= 3) {
+        // a unit's bin: that of its parent's unit; the units of depth D0 open the subtrees
+        std::vector<int> bin(n_nodes, -1), size(n_nodes, 0);
+        for (int q = n_stored - 1; q >= toff[D0]; --q) {   // (the lists ascend in depth: children come later)
+            const int n = tdp[q];
+            size[n] += 1;
+            if (q >= toff[D0 + 1]) size[parent[n]] += size[n];
+        }
+        int nb = 0, fill = 0;
+        for (int q = toff[D0]; q < toff[D0 + 1]; ++q) {
+            const int n = tdp[q];
+            if (nb == 0 || fill + size[n] > S) {
+                ++nb;
+                fill = 0;
+            }
+            fill += size[n];
+            bin[n] = nb - 1;
+        }
+        std::vector<std::vector<int>> members(nb);
+        for (int q = toff[D0]; q < n_stored; ++q) {
+            const int n = tdp[q];
+            if (q >= toff[D0 + 1]) bin[n] = bin[parent[n]];
+            members[bin[n]].push_back(q);   // (positions: the depth of a unit is that of its list segment)
+        }
+        std::vector<int> depth_of_pos(n_stored - toff[D0]);
+        for (int l = D0; l < n_td_levels; ++l)
+            for (int q = toff[l]; q < toff[l + 1]; ++q) depth_of_pos[q - toff[D0]] = l;
+        std::vector<int> td_list, td_start(nb), td_levels(nb), td_lv;
+        for (int b = 0; b < nb; ++b) {
+            const std::vector<int>& mem = members[b];   // ascending positions = non-decreasing depth
+            td_start[b] = (int)td_lv.size();
+            int nl = 0;
+            for (size_t q = 0; q < mem.size(); ++q) {
+                if (q == 0 || depth_of_pos[mem[q] - toff[D0]] != depth_of_pos[mem[q - 1] - toff[D0]]) {
+                    td_lv.push_back((int)td_list.size());
+                    ++nl;
+                }
+                td_list.push_back(tdp[mem[q]]);
+            }
+            td_lv.push_back((int)td_list.size());
+            td_levels[b] = nl;
+        }
+        std::vector<PmlUnit> u2;
+        describe(td_list.data(), (int)td_list.size(), true, u2);
+        if (!ctx->tune.on(T_NO_SHAPE_SORT)) u2 = by_shape(u2, td_lv, td_list.size());
+        u2.push_back(u2[0]);
+        PML_TRY(put(&D.d_units, u2));
+        PML_TRY(put(&D.d_start, td_start));
+        PML_TRY(put(&D.d_levels, td_levels));
+        PML_TRY(put(&D.d_lv, td_lv));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        D.first_depth = D0;
+        D.n_blocks = nb;
+        D.ok = true;
+        if (ctx->tune.on(T_DEBUG))
+            fprintf(stderr, "pastml_hip: thin top-down depths from %d of %d: %d units in %d bins\n", D0, n_td_levels,
+                    (int)td_list.size(), nb);
+    }
     return PML_OK;
 }
 
@@ -2864,6 +2902,18 @@ int pml_chars_alloc(pml_ctx* ctx, int32_t n_cols, int32_t k) {
     ctx->prep_dirty = true;
     ctx->bu_mode = -1;
     ctx->td_valid = ctx->js_valid = false;
+    // Thin ends of a large forest.  A level is thin while a launch of its own is mostly latency: up to 4 096 units, and up to
+    // THIN_BYTES (20 MB) of state vectors over all columns -- beyond, the level kernels stream it faster than workgroups
+    // that walk subtrees.  Measured (profiles/r05u_thin_ends.txt, THIN_UNITS sweeps): k = 4 x 32 columns 4 096 (16 384 loses
+    // 20 %); k = 64: x 32 columns 1 024 - 2 048, x 16 2 048, x 8 4 096; k = 20 x 32 4 096.
+    if (!ctx->bu_offsets_f.empty() && (ctx->bu_offsets_f.back() > 2048 || ctx->tune.on(T_THIN_UNITS)) && !ctx->tune.on(T_NO_THIN)) {
+        long long thin = ctx->tune.get(T_THIN_UNITS, 0);
+        if (!ctx->tune.on(T_THIN_UNITS)) {
+            const long long bytes = ctx->tune.get(T_THIN_BYTES, 20ll << 20);
+            thin = std::min(4096ll, std::max(256ll, bytes / ((long long)n_cols * ctx->ks * 8)));
+        }
+        PML_TRY(build_thin_ends(ctx, (int)thin));
+    }
     return PML_OK;
 }
 
