@@ -72,7 +72,7 @@ static int fail(int code, const char* fmt, ...) {
     X(BLOCK_HEIGHT_CAP, 0, 1) X(SMALL_MAX_NODES, 0, 1) X(F81_R, 0, 1) X(F81_TD_R, 0, 1) X(NO_GRAPH, 1, 1)              \
     X(NARROW_UNITS, 0, 0) X(NO_EIGG_TIERS, 1, 0) X(NO_ABSORB, 1, 1) X(ABSORB_MIN, 0, 1) X(NO_SPIN_WAIT, 1, 0)   \
     X(SPLIT_PARTS, 0, 0) X(PIJ_STAGE_ROWS, 0, 0) X(PIJ_ABLATE, 0, 0) X(PIJ_BLOCKS, 0, 0) X(NO_HEIGHT_ORDER, 1, 1) X(NO_TD_TAIL, 1, 0) X(NO_PIJ_VALU, 1, 0) X(PIJ_VALU, 1, 0) X(NO_EIGJ_PIPE, 1, 0) \
-    X(THIN_UNITS, 0, 1) X(THIN_BYTES, 0, 1) X(THIN_BLOCK_NODES, 0, 1) X(NO_THIN, 1, 0) X(NO_THIN_WIDE, 1, 0)
+    X(THIN_UNITS, 0, 1) X(THIN_BYTES, 0, 1) X(THIN_BLOCK_NODES, 0, 1) X(NO_THIN, 1, 0) X(NO_THIN_WIDE, 1, 0) X(BU_WIDE, 0, 1) X(SORT_LEVELS, 0, 1)
 enum PmlTunable {
 #define X(name, flag, tree) T_##name,
     PML_TUNABLES(X)
@@ -254,6 +254,7 @@ struct pml_ctx {
     int C = 0, k = 0, ks = 0, W = 0, G = 0, R = 0;
     int Gf = 0, Rf = 0;  // lane-group shape of the F81-family bottom-up kernels (chunked state ownership)
     bool bu_wide_lanes = false;  // 32 < k <= 64: most bottom-up levels run with 8 states per lane (see dispatch_sweep)
+    bool level_lists_sorted = false;  // 32 < k <= 64: the level launches walk the lists sorted by shape (pml_tree_upload)
     int Gt = 0, Rt = 0;  // ... and of the F81-family top-down kernels
     u64 *d_masks = nullptr, *d_masks_init = nullptr;
     bool has_init = false;
@@ -657,7 +658,7 @@ static void launch_sweep_f81(pml_ctx* ctx, SweepKind what, const int* level, int
     // the level is given as a position in one of the node lists; the kernels read the descriptor list parallel to it
     const PmlUnit* units = nullptr;
     // (level launches of wide units walk the lists sorted by shape, pml_tree_upload)
-    const bool sorted = ctx->bu_wide_lanes && ctx->d_bu_units_fs != nullptr;
+    const bool sorted = ctx->level_lists_sorted && ctx->d_bu_units_fs != nullptr;
     if (fused_lists) units = ctx->d_bu_units_f + (level - ctx->d_bu_order_f);
     if (sorted && (what == SW_BU_MARG_FUSED || what == SW_BU_MARG_FUSED_NOVEC))
         units = ctx->d_bu_units_fs + (level - ctx->d_bu_order_f);
@@ -2837,9 +2838,59 @@ int pml_chars_alloc(pml_ctx* ctx, int32_t n_cols, int32_t k) {
             G = 1;
             while (G < need) G <<= 1;
         };
+        bool polytomies = false;
+        {
+            long long n_inner = 0, n34 = 0;   // (nodes with a child that has children: what is a stored node under cherry fusion)
+            for (int i = 0; i < ctx->N; ++i) {
+                const int nc = ctx->h_n_children[i];
+                bool inner = false;
+                for (int j = 0; j < nc && !inner; ++j) inner = ctx->h_n_children[ctx->h_first_child[i] + j] > 0;
+                if (!inner) continue;
+                ++n_inner;
+                n34 += nc == 3 || nc == 4;
+            }
+            polytomies = n_inner > 0 && n34 * 100 >= 15 * n_inner;
+        }
         shape(T_F81_R, 4, ctx->Gf, ctx->Rf);
-        ctx->bu_wide_lanes = k > 32 && k <= 64 && ctx->Rf == 4 && !ctx->tune.on(T_F81_R);
-        shape(T_F81_TD_R, (k > 32 && k <= 64) ? 8 : 4, ctx->Gt, ctx->Rt);
+        // Balanced parts: nodes whose two children each carry two cherries of two tips, ids consecutive (what pml_tree_upload
+        // makes two-level units of) -- counted on the topology alone, whatever the switches, so that the lane shape, and with
+        // it a column's bits, is a function of k and the forest.
+        bool balanced_parts = false;
+        {
+            const int* fc = ctx->h_first_child.data();
+            const int* nch = ctx->h_n_children.data();
+            auto tips2 = [&](int x) { return nch[x] == 2 && nch[fc[x]] == 0 && nch[fc[x] + 1] == 0; };
+            auto pair = [&](int x) { return nch[x] == 2 && tips2(fc[x]) && tips2(fc[x] + 1) && fc[fc[x] + 1] == fc[fc[x]] + 2; };
+            long long n_internal = 0, n_two = 0;
+            for (int i = 0; i < ctx->N; ++i) {
+                if (nch[i] == 0) continue;
+                ++n_internal;
+                if (nch[i] != 2) continue;
+                const int a = fc[i], b = a + 1;
+                if (pair(a) && pair(b) && fc[b] == fc[a] + 2 && fc[fc[b]] == fc[fc[a]] + 4) ++n_two;
+            }
+            balanced_parts = n_two > 0 && n_two * 32 >= n_internal;
+        }
+        // 8 states per lane bottom-up (32 < k <= 64) where the forest has such parts (cfg4: the level that rebuilds cherries
+        // 1.80 -> 1.58 ms; 262 144-tip balanced tree x 32: bottom-up 0.77 -> 0.63 ms) and few nodes of three or four children
+        // (8 lanes gather two children in parallel, see below); elsewhere 4: polytomies x 16 columns bottom-up 0.64 -> 0.50 ms
+        // (at most 3 children), 0.61 -> 0.52 (at most 5); random binary 40 000 tips x 8 0.184 -> 0.161; 262 144 x 16 1.17 -> 1.13
+        // (profiles/r05y_lane_shapes_and_sorted_levels.txt).
+        ctx->bu_wide_lanes = k > 32 && k <= 64 && ctx->Rf == 4 && !ctx->tune.on(T_F81_R) && balanced_parts && !polytomies;
+        if (ctx->tune.on(T_BU_WIDE)) ctx->bu_wide_lanes = k > 32 && k <= 64 && ctx->Rf == 4 && ctx->tune.get(T_BU_WIDE, 1) != 0;
+        // Level launches walk the lists sorted by shape inside every level (pml_tree_upload) from 4 lanes per unit on: 262 144
+        // tips x 32, marginal pass: k = 8 1.82 -> 1.78 ms, k = 12 2.35 -> 2.26, k = 16 2.38 -> 2.26, k = 20 3.49 -> 3.06, k = 32
+        // 3.53 -> 3.11; polytomies k = 12 1.36 -> 1.28, k = 20 1.55 -> 1.36; two lanes per unit (k <= 4) lose 11 % and keep id order.
+        ctx->level_lists_sorted = ctx->Gf >= 4;
+        if (ctx->tune.on(T_SORT_LEVELS)) ctx->level_lists_sorted = ctx->tune.get(T_SORT_LEVELS, 1) != 0;
+        // Top-down: 8 states per lane for 32 < k <= 64 (above) unless the forest has many nodes of three or four children
+        // (15 % of those with grandchildren): the lane-parallel gather of a unit's children takes
+        // G / 4 of them (Gather<G>::CH: two with 8 lanes, four with 16), a unit with more walks them one after the other and
+        // holds up the other units of its wavefront.  Measured, marginal pass, k = 64 (profiles/r05y_td_shape_polytomies.txt):
+        // 100 000 tips, at most 3 children per node, x 8 / 16 / 32 columns 1.37 -> 0.93 / 1.79 -> 1.38 / 2.84 -> 2.26 ms; at
+        // most 5 children x 16 2.12 -> 1.90; at most 8 2.52 -> 2.28; binary trees lose 5 % with 4 states per lane.  The shape
+        // follows k and the forest, never the columns.
+        shape(T_F81_TD_R, (k > 32 && k <= 64 && !polytomies) ? 8 : 4, ctx->Gt, ctx->Rt);
         if (k >= 2 && (ctx->ks & 1)) ctx->ks += 1;  // 16-byte lane accesses
         {
             const int g = ctx->bu_wide_lanes ? 8 : ctx->Gf;
@@ -3461,7 +3512,7 @@ static int enqueue_bottom_up(pml_ctx* ctx, int is_marginal, bool small_path, boo
         for (int l = 0; l < nl - tail; ++l) {
             const int a = U.bu_offsets_r[l], b = U.bu_offsets_r[l + 1];
             if (b > a) {
-                ctx->units_override = (ctx->bu_wide_lanes && U.d_bu_units_rs ? U.d_bu_units_rs : U.d_bu_units_r) + a;
+                ctx->units_override = (ctx->level_lists_sorted && U.d_bu_units_rs ? U.d_bu_units_rs : U.d_bu_units_r) + a;
                 const int status = dispatch_sweep(ctx, U.bu_level_vec_r[l] ? SW_BU_MARG_FUSED : SW_BU_MARG_FUSED_NOVEC,
                                                   ctx->d_bu_order_f, b - a);
                 ctx->units_override = nullptr;
@@ -3879,7 +3930,7 @@ static int run_top_down(pml_ctx* ctx) {
             for (int l = head; l < ctx->n_td_levels; ++l) {
                 const int a = U.td_offsets_r[l], b = U.td_offsets_r[l + 1];
                 if (b > a) {
-                    ctx->units_override = (ctx->bu_wide_lanes && U.d_td_units_rs ? U.d_td_units_rs : U.d_td_units_r) + a;
+                    ctx->units_override = (ctx->level_lists_sorted && U.d_td_units_rs ? U.d_td_units_rs : U.d_td_units_r) + a;
                     const int status = dispatch_sweep(ctx, SW_TD_FUSED, ctx->d_td_parents_f, b - a);
                     ctx->units_override = nullptr;
                     PML_TRY(status);

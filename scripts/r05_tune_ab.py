@@ -21,9 +21,23 @@ cases = dict(ragged64=(lambda: FlatForest.random(262144, seed=3, max_arity=2, n_
              ragged2=(lambda: FlatForest.random(262144, seed=3, max_arity=2, n_trees=1), 2, 32),
              poly64=(lambda: FlatForest.random(100000, seed=5, max_arity=5, n_trees=2), 64, 16),
              poly4=(lambda: FlatForest.random(100000, seed=5, max_arity=5, n_trees=2), 4, 16),
+             poly64c32=(lambda: FlatForest.random(100000, seed=5, max_arity=5, n_trees=2), 64, 32),
+             ragged64c16=(lambda: FlatForest.random(262144, seed=3, max_arity=2, n_trees=1), 64, 16),
+             poly3_64=(lambda: FlatForest.random(100000, seed=5, max_arity=3, n_trees=2), 64, 16),
+             poly40=(lambda: FlatForest.random(100000, seed=5, max_arity=5, n_trees=2), 40, 16),
+             poly3_64c32=(lambda: FlatForest.random(100000, seed=5, max_arity=3, n_trees=2), 64, 32),
+             poly3_64c8=(lambda: FlatForest.random(100000, seed=5, max_arity=3, n_trees=2), 64, 8),
+             poly64c8=(lambda: FlatForest.random(100000, seed=5, max_arity=5, n_trees=2), 64, 8),
+             poly8_64=(lambda: FlatForest.random(100000, seed=9, max_arity=8, n_trees=1), 64, 16),
+             bigpoly3_64=(lambda: FlatForest.random(262144, seed=11, max_arity=3, n_trees=1), 64, 32),
              poly20=(lambda: FlatForest.random(100000, seed=5, max_arity=5, n_trees=2), 20, 16),
              ragged20=(lambda: FlatForest.random(262144, seed=3, max_arity=2, n_trees=1), 20, 32),
              mid64=(lambda: FlatForest.random(40000, seed=7, max_arity=2, n_trees=1), 64, 8),
+             balanced64=(lambda: synthetic.balanced_forest(18), 64, 32),
+             ragged8=(lambda: FlatForest.random(262144, seed=3, max_arity=2, n_trees=1), 8, 32),
+             ragged16=(lambda: FlatForest.random(262144, seed=3, max_arity=2, n_trees=1), 16, 32),
+             ragged32=(lambda: FlatForest.random(262144, seed=3, max_arity=2, n_trees=1), 32, 32),
+             poly12=(lambda: FlatForest.random(100000, seed=5, max_arity=5, n_trees=2), 12, 16),
              balanced4=(lambda: synthetic.balanced_forest(18), 4, 32),
              balanced12=(lambda: synthetic.balanced_forest(18), 12, 32),
              mid4=(lambda: FlatForest.random(40000, seed=7, max_arity=2, n_trees=1), 4, 8),

@@ -1691,3 +1691,34 @@ def test_thin_ends_as_subtree_blocks_have_the_bits_of_the_level_launches(k):
             assert np.array_equal(a, b), 'forest {}'.format(fi)
         ref = orc.bottom_up(flat, masks[1].astype(int), specs[1][0], *specs[1][1])
         np.testing.assert_allclose(results[1][0][1], ref['loglik'], rtol=LNL_RTOL)
+
+
+@pytest.mark.parametrize('k', [33, 48, 64])
+def test_top_down_lane_shape_follows_the_forests_arity(k):
+    """
+    32 < k <= 64: the top-down kernels take 8 states per lane on (mostly) binary forests and 4 where many nodes have three
+    or four children (pml_chars_alloc: 16 lanes gather four children in parallel, 8 lanes two).  The choice is a function
+    of k and the forest alone: the default's bits are those of the explicit shape (F81_TD_R) it should have taken, whatever
+    the number of columns; and the numbers are right against the oracle either way.
+    """
+    rng = np.random.default_rng(3100 + k)
+    for flat, expected in ((FlatForest.random(1500, seed=k, max_arity=2, n_trees=1), 8),
+                           (FlatForest.random(1500, seed=k + 1, max_arity=3, n_trees=2), 4),
+                           (FlatForest.random(1500, seed=k + 2, max_arity=6, n_trees=1), 4)):
+        specs = [(random_spec('F81', k, rng), (float(rng.uniform(0.5, 3)), 0.0, 1.0)) for _ in range(3)]
+        masks = np.stack([random_masks(flat, k, rng, missing=0.05, multi=0.05, internal=0.02) for _ in range(3)])
+        out = {}
+        for name, C, tune in (('default', 3, {}), ('one column', 1, {}), ('explicit', 3, dict(F81_TD_R=expected)),
+                              ('other', 3, dict(F81_TD_R=12 - expected))):
+            with hip.Engine(flat, C, k, tune=tune) as eng:
+                eng.set_models(specs[:C])
+                eng.set_masks(masks[:C])
+                out[name] = eng.marginal_pass()
+        for a, b in zip(out['default'], out['explicit']):
+            assert np.array_equal(a, b)
+        for a, b in zip(out['default'], out['one column']):
+            assert np.array_equal(a[:1], b)
+        assert not np.array_equal(out['default'][1], out['other'][1])   # (the other shape rounds differently somewhere)
+        np.testing.assert_allclose(out['default'][1], out['other'][1], rtol=1e-11, atol=1e-300)
+        ref = orc.bottom_up(flat, masks[1].astype(int), specs[1][0], *specs[1][1])
+        np.testing.assert_allclose(out['default'][0][1], ref['loglik'], rtol=LNL_RTOL)
