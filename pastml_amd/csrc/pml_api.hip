@@ -2886,7 +2886,7 @@ int pml_chars_alloc(pml_ctx* ctx, int32_t n_cols, int32_t k) {
         // Top-down: 8 states per lane for 32 < k <= 64 (above) unless the forest has many nodes of three or four children
         // (15 % of those with grandchildren): the lane-parallel gather of a unit's children takes
         // G / 4 of them (Gather<G>::CH: two with 8 lanes, four with 16), a unit with more walks them one after the other and
-        // holds up the other units of its wavefront.  Measured, marginal pass, k = 64 (profiles/r05y_td_shape_polytomies.txt):
+        // holds up the other units of its wavefront.  Measured, marginal pass, k = 64 (profiles/r05y_lane_shapes_and_sorted_levels.txt):
         // 100 000 tips, at most 3 children per node, x 8 / 16 / 32 columns 1.37 -> 0.93 / 1.79 -> 1.38 / 2.84 -> 2.26 ms; at
         // most 5 children x 16 2.12 -> 1.90; at most 8 2.52 -> 2.28; binary trees lose 5 % with 4 states per lane.  The shape
         // follows k and the forest, never the columns.

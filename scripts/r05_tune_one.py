@@ -10,8 +10,8 @@ from pastml_amd import hip, synthetic
 from pastml_amd.tree import FlatForest
 
 src = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'r05_tune_ab.py')).read()
-ns = {}
-exec(src[src.index('def hiv1c_forest'):src.index('make, k, C = cases')], dict(globals()), ns)
+ns = dict(globals())
+exec(src[src.index('def hiv1c_forest'):src.index('make, k, C = cases')], ns)
 make, k, C = ns['cases'][sys.argv[1]]
 name, _, rest = sys.argv[2].partition('=')
 tune = {}
