@@ -823,6 +823,7 @@ static void launch_blocks_f81(pml_ctx* ctx, bool bottom_up, int which) {
     X(32, 4)             \
     X(64, 4)             \
     X(32, 2)             \
+    X(16, 2)             \
     X(8, 8)
 
 template <int G, int R>
@@ -929,9 +930,9 @@ static bool super_units(const pml_ctx* ctx) {
     if (!ctx->sup.ok || ctx->kind != PML_MODEL_F81 || ctx->W != 1) return false;
     int g, r;
     super_shape(ctx, true, g, r);
-    if (g < 8) return false;
+    if (g < 8 || (g == 16 && r == 2)) return false;   // (16 x 2: the shape of forests with polytomies, no two-level kernels)
     super_shape(ctx, false, g, r);
-    return g >= 8;
+    return g >= 8 && !(g == 16 && r == 2);
 }
 
 // the sweeps of this context run the level schedule with two-level units (not one launch per sweep, not subtree blocks)
@@ -2819,25 +2820,9 @@ int pml_chars_alloc(pml_ctx* ctx, int32_t n_cols, int32_t k) {
         // F81 family: 4 states per lane (two 16-byte pairs).  Most of a unit's work is scalar (per child, per tip), so
         // the top-down kernels, which have the most of it, take 8 states per lane for 32 < k <= 64: 8 units per
         // wavefront share each scalar instruction.  PASTML_HIP_F81_R / PASTML_HIP_F81_TD_R = 2 / 4 / 8: tuning variants
-        auto shape = [&](int var, int dflt, int& G, int& R) {
-            int rf = k >= 3 ? dflt : k;
-            // Up to 8 states: two per lane (2 or 4 lanes per unit).  In the latency-bound schedules -- small and mid-size
-            // forests -- a level is one wavefront's instruction stream, and half the states per lane are a shorter one
-            // (HIV1C tree, 14 columns: bottom-up sweep k = 4 0.111 -> 0.094 ms, k = 8 0.107 -> 0.095; marginal pass
-            // 0.290 -> 0.262, 0.319 -> 0.262; cfg2 0.0765 -> 0.0713 ms); the level kernels of large forests are
-            // indifferent (262 144 tips x 32 characters, k = 4: balanced 0.73 -> 0.77 ms, ragged 2.46 -> 2.34).  One state
-            // per lane is another 3 - 5 % on the small forests and costs the large balanced one a third: not taken.
-            if (k >= 3 && k <= 8 && dflt == 4) rf = 2;
-            if (ctx->tune.on(var)) {
-                const int v = (int)ctx->tune.get(var, 0);
-                if ((v == 2 || v == 4 || v == 8) && k > 32 && k <= 64) rf = v;
-                if ((v == 2 || v == 4) && k >= 3 && k <= 8) rf = v;
-            }
-            R = rf;
-            const int need = (k + rf - 1) / rf;
-            G = 1;
-            while (G < need) G <<= 1;
-        };
+        // Forests with many nodes of three or four children (15 % of the nodes with grandchildren) take 16 lanes per unit where
+        // k allows it: the lane-parallel gather of a unit's children (Gather<G>) takes G / 4 of them -- two with 8 lanes, four
+        // with 16 --, a unit with more walks them one after the other and holds up the other units of its wavefront.
         bool polytomies = false;
         {
             long long n_inner = 0, n34 = 0;   // (nodes with a child that has children: what is a stored node under cherry fusion)
@@ -2851,6 +2836,29 @@ int pml_chars_alloc(pml_ctx* ctx, int32_t n_cols, int32_t k) {
             }
             polytomies = n_inner > 0 && n34 * 100 >= 15 * n_inner;
         }
+        auto shape = [&](int var, int dflt, int& G, int& R) {
+            int rf = k >= 3 ? dflt : k;
+            // Up to 8 states: two per lane (2 or 4 lanes per unit).  In the latency-bound schedules -- small and mid-size
+            // forests -- a level is one wavefront's instruction stream, and half the states per lane are a shorter one
+            // (HIV1C tree, 14 columns: bottom-up sweep k = 4 0.111 -> 0.094 ms, k = 8 0.107 -> 0.095; marginal pass
+            // 0.290 -> 0.262, 0.319 -> 0.262; cfg2 0.0765 -> 0.0713 ms); the level kernels of large forests are
+            // indifferent (262 144 tips x 32 characters, k = 4: balanced 0.73 -> 0.77 ms, ragged 2.46 -> 2.34).  One state
+            // per lane is another 3 - 5 % on the small forests and costs the large balanced one a third: not taken.
+            if (k >= 3 && k <= 8 && dflt == 4) rf = 2;
+            // 16 < k <= 32 on forests with polytomies: 16 lanes x 2 states instead of 8 x 4 (100 000 tips, at most 3 children, x 16
+            // columns, k = 20 / 32: marginal pass 1.33 -> 0.95 / 1.34 -> 0.96 ms; at most 5 children: no change; binary trees lose 6 %)
+            if (k > 16 && k <= 32 && dflt == 4 && polytomies) rf = 2;
+            if (ctx->tune.on(var)) {
+                const int v = (int)ctx->tune.get(var, 0);
+                if ((v == 2 || v == 4 || v == 8) && k > 32 && k <= 64) rf = v;
+                if ((v == 2 || v == 4) && k >= 3 && k <= 8) rf = v;
+                if ((v == 2 || v == 4) && k > 16 && k <= 32) rf = v;   // (16 lanes x 2 states or 8 x 4)
+            }
+            R = rf;
+            const int need = (k + rf - 1) / rf;
+            G = 1;
+            while (G < need) G <<= 1;
+        };
         shape(T_F81_R, 4, ctx->Gf, ctx->Rf);
         // Balanced parts: nodes whose two children each carry two cherries of two tips, ids consecutive (what pml_tree_upload
         // makes two-level units of) -- counted on the topology alone, whatever the switches, so that the lane shape, and with

@@ -37,6 +37,8 @@ cases = dict(ragged64=(lambda: FlatForest.random(262144, seed=3, max_arity=2, n_
              ragged8=(lambda: FlatForest.random(262144, seed=3, max_arity=2, n_trees=1), 8, 32),
              ragged16=(lambda: FlatForest.random(262144, seed=3, max_arity=2, n_trees=1), 16, 32),
              ragged32=(lambda: FlatForest.random(262144, seed=3, max_arity=2, n_trees=1), 32, 32),
+             poly3_20=(lambda: FlatForest.random(100000, seed=5, max_arity=3, n_trees=2), 20, 16),
+             poly3_32=(lambda: FlatForest.random(100000, seed=5, max_arity=3, n_trees=2), 32, 16),
              poly12=(lambda: FlatForest.random(100000, seed=5, max_arity=5, n_trees=2), 12, 16),
              balanced4=(lambda: synthetic.balanced_forest(18), 4, 32),
              balanced12=(lambda: synthetic.balanced_forest(18), 12, 32),

@@ -1448,6 +1448,8 @@ def test_general_two_level_units_give_the_bits_of_the_level_schedule(k):
     forests = [FlatForest.random(3000, seed=k, max_arity=2, n_trees=1), FlatForest.random(2500, seed=k + 1, max_arity=4, n_trees=3),
                _forest_with_balanced_clumps(400, seed=k + 2)]
     base = dict(LEVEL_SCHEDULE, SMALL_MAX_NODES=0, ABSORB_MIN=1)
+    if k <= 32:
+        base.update(F81_R=4, F81_TD_R=4)   # (8 lanes x 4 states also on the forest with polytomies: 16 x 2 has no two-level kernels)
     for fi, flat in enumerate(forests):
         C = 3
         specs = [(random_spec('F81', k, rng), (float(rng.uniform(0.5, 3)), 0.0, 1.0)) for _ in range(C)]
@@ -1693,23 +1695,34 @@ def test_thin_ends_as_subtree_blocks_have_the_bits_of_the_level_launches(k):
         np.testing.assert_allclose(results[1][0][1], ref['loglik'], rtol=LNL_RTOL)
 
 
-@pytest.mark.parametrize('k', [33, 48, 64])
-def test_top_down_lane_shape_follows_the_forests_arity(k):
+@pytest.mark.parametrize('k', [17, 20, 32, 33, 48, 64])
+def test_lane_shapes_follow_the_forests_arity(k):
     """
-    32 < k <= 64: the top-down kernels take 8 states per lane on (mostly) binary forests and 4 where many nodes have three
-    or four children (pml_chars_alloc: 16 lanes gather four children in parallel, 8 lanes two).  The choice is a function
-    of k and the forest alone: the default's bits are those of the explicit shape (F81_TD_R) it should have taken, whatever
-    the number of columns; and the numbers are right against the oracle either way.
+    The lane shape of the F81 kernels is a function of k and the forest (pml_chars_alloc), never of the columns.  32 < k <= 64:
+    the top-down kernels take 8 states per lane on (mostly) binary forests and 4 where many nodes have three or four children
+    (16 lanes gather four children in parallel, 8 lanes two); the bottom-up levels take 8 only on forests with balanced parts.
+    16 < k <= 32: 8 lanes x 4 states, on forests with polytomies 16 x 2.  The default's bits are those of the explicit shape
+    (F81_R / F81_TD_R / BU_WIDE) it should have taken, whatever the number of columns; the other shape rounds differently
+    somewhere but agrees to 1e-11; and the numbers are right against the oracle.
     """
     rng = np.random.default_rng(3100 + k)
-    for flat, expected in ((FlatForest.random(1500, seed=k, max_arity=2, n_trees=1), 8),
-                           (FlatForest.random(1500, seed=k + 1, max_arity=3, n_trees=2), 4),
-                           (FlatForest.random(1500, seed=k + 2, max_arity=6, n_trees=1), 4)):
+    wide = k > 32
+    for flat, poly, balanced in ((FlatForest.random(1500, seed=k, max_arity=2, n_trees=1), False, False),
+                                 (synthetic.balanced_forest(9), False, True),
+                                 (FlatForest.random(1500, seed=k + 1, max_arity=3, n_trees=2), True, False),
+                                 (FlatForest.random(1500, seed=k + 2, max_arity=6, n_trees=1), True, False)):
+        if wide:
+            explicit = dict(F81_TD_R=4 if poly else 8, BU_WIDE=1 if balanced else 0)
+            other = dict(F81_TD_R=8 if poly else 4, BU_WIDE=0 if balanced else 1)   # (both sweeps in the shape not taken)
+        else:
+            explicit = dict(F81_R=2, F81_TD_R=2) if poly else {}
+            other = {} if poly else dict(F81_R=2, F81_TD_R=2)
         specs = [(random_spec('F81', k, rng), (float(rng.uniform(0.5, 3)), 0.0, 1.0)) for _ in range(3)]
         masks = np.stack([random_masks(flat, k, rng, missing=0.05, multi=0.05, internal=0.02) for _ in range(3)])
         out = {}
-        for name, C, tune in (('default', 3, {}), ('one column', 1, {}), ('explicit', 3, dict(F81_TD_R=expected)),
-                              ('other', 3, dict(F81_TD_R=12 - expected))):
+        for name, C, tune in (('default', 3, {}), ('one column', 1, {}), ('explicit', 3, explicit), ('other', 3, other)):
+            if name == 'other' and not wide and poly:
+                tune = dict(F81_R=4, F81_TD_R=4)
             with hip.Engine(flat, C, k, tune=tune) as eng:
                 eng.set_models(specs[:C])
                 eng.set_masks(masks[:C])
