@@ -1668,7 +1668,7 @@ def test_thin_ends_as_subtree_blocks_have_the_bits_of_the_level_launches(k):
         masks[0] = synthetic.one_hot_masks(flat, k, rng.integers(0, k, size=flat.n_tips))
         results, launches = [], []
         for off in (True, False):
-            with hip.Engine(flat, C, k, tune=dict(base, NO_THIN=1 if off else None)) as eng:
+            with hip.Engine(flat, C, k, tune=dict(base, NO_THIN=1 if off else None), keep_td=(k % 2 == 0)) as eng:
                 eng.set_models(specs)
                 eng.set_masks(masks)
                 eng.profile_enable(True)
@@ -1680,6 +1680,9 @@ def test_thin_ends_as_subtree_blocks_have_the_bits_of_the_level_launches(k):
                 assert np.array_equal(lnl, lnl2) and np.array_equal(post, post2)
                 bu = [eng.download(hip.BUF_BU, c) for c in range(C)]
                 bu_sf = [eng.download(hip.BUF_BU_SF, c) for c in range(C)]
+                if k % 2 == 0:   # (the top-down vectors of PML_OPT_KEEP_TD, written by the deep end's launch as well)
+                    bu.append(eng.download(hip.BUF_TD, 1))
+                    bu_sf.append(eng.download(hip.BUF_TD_SF, 1))
                 # a sweep of one column only
                 specs2 = list(specs)
                 specs2[1] = (specs[1][0], (specs[1][1][0] * 1.25, 0.0, 1.0))
