@@ -39,6 +39,11 @@ cases = dict(ragged64=(lambda: FlatForest.random(262144, seed=3, max_arity=2, n_
              ragged32=(lambda: FlatForest.random(262144, seed=3, max_arity=2, n_trees=1), 32, 32),
              poly3_20=(lambda: FlatForest.random(100000, seed=5, max_arity=3, n_trees=2), 20, 16),
              poly3_32=(lambda: FlatForest.random(100000, seed=5, max_arity=3, n_trees=2), 32, 16),
+             bin100k_4=(lambda: FlatForest.random(100000, seed=5, max_arity=2, n_trees=2), 4, 16),
+             poly3_4=(lambda: FlatForest.random(100000, seed=5, max_arity=3, n_trees=2), 4, 16),
+             bin100k_12=(lambda: FlatForest.random(100000, seed=5, max_arity=2, n_trees=2), 12, 16),
+             poly3_12=(lambda: FlatForest.random(100000, seed=5, max_arity=3, n_trees=2), 12, 16),
+             bin100k_64=(lambda: FlatForest.random(100000, seed=5, max_arity=2, n_trees=2), 64, 16),
              poly12=(lambda: FlatForest.random(100000, seed=5, max_arity=5, n_trees=2), 12, 16),
              balanced4=(lambda: synthetic.balanced_forest(18), 4, 32),
              balanced12=(lambda: synthetic.balanced_forest(18), 12, 32),
