@@ -669,6 +669,25 @@ def secondary_measurements(device):
                                                  '(profiles/r05t_ragged_tree_memory_counters.md; round 4: 28.8 GB = 1.30 x)')
     out['ragged262k'] = dict(workload='random binary tree, 262 144 tips (FlatForest.random seed 3), 32 characters, F81 with '
                                       'per-character frequencies, marginal pass (model upload + BU + TD + posteriors)', **ragged)
+    # ---- a forest with polytomies (round 5): 100 000 tips, at most 3 children per node, 2 trees, 16 characters -- the lane
+    #      shapes follow the forest's arity (16 lanes per unit take four children on the lane-parallel path)
+    flat = FlatForest.random(100000, seed=5, max_arity=3, n_trees=2)
+    poly = {}
+    for k in (64, 20, 4):
+        C = 16
+        with hip.Engine(flat, C, k, device=device) as eng:
+            specs = [(dict(kind=0, pi=synthetic.f81_frequencies(k, c)), (1.0, 0.0, 1.0)) for c in range(C)]
+            eng.set_tip_states(np.stack([synthetic.tip_states(flat.n_tips, k, c) for c in range(C)]))
+
+            def poly_pass():
+                eng.set_models(specs)
+                eng.marginal_pass(posterior=False, lh=False)
+            ms = timed(poly_pass, 50, eng)
+            poly['k{}'.format(k)] = dict(ms_per_pass=ms, value=flat.n_nodes * k * C / (ms * 1e-3), unit='node*state*char/s')
+    out['polytomies100k'] = dict(workload='random forest of 2 trees, 100 000 tips, at most 3 children per node (FlatForest.random '
+                                          'seed 5), {} nodes, 16 characters, F81 with per-character frequencies, marginal pass; round '
+                                          '4\'s lane shapes and level lists: k = 64 1.77 ms, k = 20 1.33 ms '
+                                          '(profiles/r05y_lane_shapes_and_sorted_levels.txt)'.format(flat.n_nodes), **poly)
     # ---- cfg3: 262 144 tips, JTT k=20, joint sweep (P(t) built and folded in registers on the FP64 vector units,
     #      pml_kernels_eigen_joint.h) + back-trace
     from pastml_amd.models.JTTModel import JTT_FREQUENCIES, JTT_RATE_MATRIX
