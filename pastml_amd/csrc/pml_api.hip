@@ -72,7 +72,7 @@ static int fail(int code, const char* fmt, ...) {
     X(BLOCK_HEIGHT_CAP, 0, 1) X(SMALL_MAX_NODES, 0, 1) X(F81_R, 0, 1) X(F81_TD_R, 0, 1) X(NO_GRAPH, 1, 1)              \
     X(NARROW_UNITS, 0, 0) X(NO_EIGG_TIERS, 1, 0) X(NO_ABSORB, 1, 1) X(ABSORB_MIN, 0, 1) X(NO_SPIN_WAIT, 1, 0)   \
     X(SPLIT_PARTS, 0, 0) X(PIJ_STAGE_ROWS, 0, 0) X(PIJ_ABLATE, 0, 0) X(PIJ_BLOCKS, 0, 0) X(NO_HEIGHT_ORDER, 1, 1) X(NO_TD_TAIL, 1, 0) X(NO_PIJ_VALU, 1, 0) X(PIJ_VALU, 1, 0) X(NO_EIGJ_PIPE, 1, 0) \
-    X(THIN_UNITS, 0, 1) X(THIN_BYTES, 0, 1) X(THIN_BLOCK_NODES, 0, 1) X(NO_THIN, 1, 0) X(NO_THIN_WIDE, 1, 0) X(BU_WIDE, 0, 1) X(SORT_LEVELS, 0, 1)
+    X(THIN_UNITS, 0, 1) X(THIN_BYTES, 0, 1) X(THIN_BLOCK_NODES, 0, 1) X(NO_THIN, 1, 0) X(NO_THIN_WIDE, 1, 0) X(BU_WIDE, 0, 1) X(SORT_LEVELS, 0, 1) X(NO_WIDE_LEAN, 1, 0)
 enum PmlTunable {
 #define X(name, flag, tree) T_##name,
     PML_TUNABLES(X)
@@ -457,6 +457,7 @@ static PmlCols cols_of(const pml_ctx* c) {
     s.k = c->k;
     s.ks = c->ks;
     s.W = c->W;
+    s.no_wide_lean = c->tune.on(T_NO_WIDE_LEAN) ? 1 : 0;
     s.masks = c->d_masks;
     s.masks_init = c->has_init ? c->d_masks_init : nullptr;
     s.pi = c->d_pi;

@@ -35,6 +35,7 @@ struct PmlTree {
 
 struct PmlCols {
     int k, ks, W;
+    int no_wide_lean;       // (a test switch: masks of several words on the sequential path, as before round 5)
     const u64* masks;       // [C][N][W]
     const u64* masks_init;  // [C][N][W] or nullptr
     const double* pi;       // [C][ks]
@@ -1159,6 +1160,176 @@ __device__ __forceinline__ bool bu_f81_unit_lean(const LaneCtx<G, R>& L, const P
     return true;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// More than 64 states (masks of several words; units of 32 and 64 lanes).  The lane-parallel and lean paths above take
+// single-word masks, so such units ran the sequential path: a dependent round trip to L2 per child and per tip, twice
+// the level step of k = 64 (HIV1C tree x 68 columns, bottom-up sweep: k = 67 0.36 ms against 0.17 at k = 64).  The lean
+// unit again, with the mask bits of the lane's own state pairs instead of a word: every load up front (own mask, both
+// children's scalars / vectors / mask words, up to two tips under each), then the sequential path's operations in its order
+// (a message entry is a + e or a by the mask bit: fma(e, 1.0, a) and fma(e, 0.0, a) are exactly that).
+// ---------------------------------------------------------------------------------------------------------------------
+// the words that hold the lane's state pairs: pair q of lane g is states 2 G q + 2 g and + 1, word (s >> 6)
+template <int G, int R>
+__device__ __forceinline__ void lane_words_issue(const LaneCtx<G, R>& L, const PmlCols& c, int n, u64 (&w)[(R + 1) / 2]) {
+#pragma unroll
+    for (int q = 0; q < (R + 1) / 2; ++q) {
+        const int s = L.st(2 * q);
+        w[q] = s < c.k ? L.mask[(unsigned)n * (unsigned)c.W + (unsigned)(s >> 6)] : 0ull;
+    }
+}
+// ... and the pair's two bits of it (bit 0: the pair's first state; a state >= k is not allowed)
+template <int G, int R>
+__device__ __forceinline__ void lane_words_bits(const LaneCtx<G, R>& L, const PmlCols& c, const u64 (&w)[(R + 1) / 2],
+                                                unsigned (&b)[(R + 1) / 2]) {
+#pragma unroll
+    for (int q = 0; q < (R + 1) / 2; ++q) {
+        const int s = L.st(2 * q);
+        unsigned x = (unsigned)(w[q] >> (s & 63)) & 3u;
+        if (s + 1 >= c.k) x &= 1u;
+        b[q] = x;
+    }
+}
+template <int R>
+__device__ __forceinline__ void bits_to_vec(const unsigned (&b)[(R + 1) / 2], double (&v)[R]) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) v[r] = ((b[r >> 1] >> (r & 1)) & 1u) ? 1.0 : 0.0;
+}
+template <int R>
+__device__ __forceinline__ void bits_select_vec(const unsigned (&b)[(R + 1) / 2], double a, double e, double (&out)[R]) {
+    const double c1 = a + e;
+#pragma unroll
+    for (int r = 0; r < R; ++r) out[r] = ((b[r >> 1] >> (r & 1)) & 1u) ? c1 : a;
+}
+
+template <int G, int R>
+__device__ __forceinline__ bool bu_f81_unit_lean_w(const LaneCtx<G, R>& L, const PmlTree& t, const PmlCols& c,
+                                                   const PmlState& st, const UnitRegs& u, int cfc0, int cfc1) {
+    constexpr int Q = (R + 1) / 2;
+    const int n = u.n, fc = u.fc;
+    const int nc = unit_nc(u.packed);
+    // ---- loads
+    u64 ow[Q];
+    lane_words_issue<G, R>(L, c, n, ow);
+    double ce[2], cs[2], vv[2][R];
+    u64 cw[2][Q];
+    i64 cbe[2];
+    double te[2][2], ts[2][2];
+    u64 tw[2][2][Q];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int ch = fc + (j < nc ? j : 0);
+        const int code = j < nc ? unit_code(u.packed, j) : 0;
+        ce[j] = L.E[ch];
+        if (code != 1) {
+            lane_words_issue<G, R>(L, c, ch, cw[j]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < Q; ++q) cw[j][q] = 0ull;
+        }
+        cs[j] = code <= 1 ? L.S[ch] : 0.0;
+        cbe[j] = code == 1 ? L.be[ch] : 0;
+        if (code == 1) {
+            node_load_vec<G, R>(L, c, L.bu, ch, vv[j]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) vv[j][r] = 0.0;
+        }
+        const int cfc = j == 0 ? cfc0 : cfc1;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            te[j][q] = 0.0;
+            ts[j][q] = 0.0;
+#pragma unroll
+            for (int x = 0; x < Q; ++x) tw[j][q][x] = 0ull;
+            if (code >= 2 && q < code - 1) {
+                te[j][q] = L.E[cfc + q];
+                ts[j][q] = L.S[cfc + q];
+                lane_words_issue<G, R>(L, c, cfc + q, tw[j][q]);
+            }
+        }
+    }
+    // ---- arithmetic (bu_f81_unit_seq's operations)
+    double acc[R];
+    {
+        unsigned ob[Q];
+        lane_words_bits<G, R>(L, c, ow, ob);
+        bits_to_vec<R>(ob, acc);
+    }
+    i64 esum = 0;
+    double lob = 1.0;
+    bool bounded = true;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        if (j < nc) {
+            const int code = unit_code(u.packed, j);
+            const double e = ce[j];
+            double msg[R];
+            double a;
+            unsigned cb[Q];
+            lane_words_bits<G, R>(L, c, cw[j], cb);
+            if (code == 0) {
+                a = (1.0 - e) * cs[j];
+                bits_select_vec<R>(cb, a, e, msg);
+            } else {
+                double v[R];
+                double s_child;
+                if (code == 1) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) v[r] = vv[j][r];
+                    esum += cbe[j];
+                    s_child = cs[j];
+                    bounded = false;
+                } else {
+                    bits_to_vec<R>(cb, v);
+                    double amin = 1.0;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        if (q < code - 1) {
+                            const double ta = (1.0 - te[j][q]) * ts[j][q];
+                            double tmsg[R];
+                            unsigned tb[Q];
+                            lane_words_bits<G, R>(L, c, tw[j][q], tb);
+                            bits_select_vec<R>(tb, ta, te[j][q], tmsg);
+                            amin *= ta;
+#pragma unroll
+                            for (int r = 0; r < R; ++r) v[r] *= tmsg[r];
+                        }
+                    }
+                    if (!(amin >= 0x1p-190)) esum += lazy_rescale<G, R>(v);
+                    s_child = pi_dot<G, R>(L, v);
+                    if (L.g == 0) L.S[fc + j] = s_child;
+                }
+                a = (1.0 - e) * s_child;
+#pragma unroll
+                for (int r = 0; r < R; ++r) msg[r] = a + e * v[r];
+            }
+            lob *= a;
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r] *= msg[r];
+            if (j == 1 || j == nc - 1) {
+                if (!bounded || !(lob >= 0x1p-190)) {
+                    const int ex = lazy_rescale<G, R>(acc);
+                    esum += ex;
+                    if (ex != 0) bounded = false;
+                }
+            }
+        }
+    }
+    const double s = pi_dot<G, R>(L, acc);
+    if (!(s > 0.0)) {
+        bool nz = false;
+#pragma unroll
+        for (int r = 0; r < R; ++r) nz |= acc[r] != 0.0 && L.st(r) < c.k;
+        if (!group_any<G>(nz)) return false;
+    }
+    if (L.g == 0) {
+        L.S[n] = s;
+        L.be[n] = esum;
+    }
+    node_store_vec<G, R>(L, c, L.bu, n, acc);
+    return true;
+}
+
 template <int G, int R, bool JOINT>
 __device__ __forceinline__ bool bu_f81_unit_is_fast(const PmlCols& c, const UnitRegs& u) {
     return !JOINT && Gather<G>::enabled && c.W == 1 && unit_is_fast_bu<G, true>(u.packed);
@@ -1199,6 +1370,14 @@ __device__ __forceinline__ void bu_f81_unit(const LaneCtx<G, R>& L, const PmlTre
             ok = bu_f81_unit_lean<G, R>(L, t, c, st, u);
         }
         if (ok) return;
+    }
+    if constexpr (G >= 32) {
+        // (masks of several words; where the tips of cherry children 0 and 1 start: units of 8 lanes and more keep the
+        // descriptor's entry of the child their lane gathers for -- lanes 0 and GC hold the two)
+        if (LEAN && !JOINT && c.W > 1 && !c.no_wide_lean && unit_is_lean(u.packed)) {
+            const int cfc0 = __shfl(u.cfc, L.group_base, 64), cfc1 = __shfl(u.cfc, L.group_base + Gather<G>::GC, 64);
+            if (bu_f81_unit_lean_w<G, R>(L, t, c, st, u, cfc0, cfc1)) return;
+        }
     }
     if (bu_f81_unit_is_fast<G, R, JOINT>(c, u)) {
         BuLoads<R> ld;
@@ -1871,6 +2050,120 @@ __device__ __forceinline__ void td_f81_unit_lean(const LaneCtx<G, R>& L, const P
     }
 }
 
+// Lean top-down unit for masks of several words (see bu_f81_unit_lean_w): every load up front, then the operations of
+// td_f81_unit's sequential path in its order -- tips on its general path (the closed form of observed tips needs the
+// single word).
+template <int G, int R>
+__device__ __forceinline__ void td_f81_unit_lean_w(const LaneCtx<G, R>& L, const PmlTree& t, const PmlCols& c,
+                                                   const PmlState& st, const UnitRegs& u, int cfc0, int cfc1) {
+    constexpr int Q = (R + 1) / 2;
+    const int p = u.n, fc = u.fc;
+    const int nc = unit_nc(u.packed);
+    // ---- loads
+    double po[R];
+    node_load_vec<G, R>(L, c, L.post, p, po);
+    const double ls = L.lhsum[p];
+    const i64 pe = L.lhe[p];
+    double ce[2], cs[2], vv[2][R];
+    u64 cw[2][Q];
+    i64 cbe[2];
+    double te[2][2], ts[2][2];
+    u64 tw[2][2][Q];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int ch = fc + (j < nc ? j : 0);
+        const int code = j < nc ? unit_code(u.packed, j) : 0;
+        ce[j] = L.E[ch];
+        lane_words_issue<G, R>(L, c, ch, cw[j]);
+        cs[j] = L.S[ch];
+        cbe[j] = code == 1 ? L.be[ch] : 0;
+        if (code == 1) {
+            node_load_vec<G, R>(L, c, L.bu, ch, vv[j]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) vv[j][r] = 0.0;
+        }
+        const int cfc = j == 0 ? cfc0 : cfc1;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            te[j][q] = 0.0;
+            ts[j][q] = 0.0;
+#pragma unroll
+            for (int x = 0; x < Q; ++x) tw[j][q][x] = 0ull;
+            if (code >= 2 && q < code - 1) {
+                te[j][q] = L.E[cfc + q];
+                ts[j][q] = L.S[cfc + q];
+                lane_words_issue<G, R>(L, c, cfc + q, tw[j][q]);
+            }
+        }
+    }
+    // ---- arithmetic
+    double prod[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) prod[r] = po[r] * (ls * L.ipi_r[r]);  // f81_parent_prod
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        if (j < nc) {
+            const int ch = fc + j;
+            const int code = unit_code(u.packed, j);
+            const double e = ce[j];
+            unsigned cb[Q];
+            lane_words_bits<G, R>(L, c, cw[j], cb);
+            double mb[R], tdc[R], pc[R], lsc;
+            bits_to_vec<R>(cb, mb);
+            i64 xe, le;
+            if (code == 0) {
+                // f81_finish_tip's general path
+                f81_finish_child<G, R>(L, c, prod, pe, ch, e, cs[j], 0, mb, false, mb, tdc, xe, pc, lsc, le, -1);
+            } else if (code == 1) {
+                double v[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) v[r] = vv[j][r];
+                f81_finish_child<G, R>(L, c, prod, pe, ch, e, cs[j], cbe[j], v, false, mb, tdc, xe, pc, lsc, le, -1);
+                if (st.td != nullptr) {
+                    node_store_vec<G, R>(L, c, L.td, ch, tdc);
+                    if (L.g == 0) L.te[ch] = xe;
+                }
+            } else {
+                // cherry: its bottom-up vector again (f81_cherry_vector's operations), finished, then its tips
+                double v[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) v[r] = mb[r];
+                double amin = 1.0;
+                i64 bec = 0;
+                unsigned tb[2][Q];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    lane_words_bits<G, R>(L, c, tw[j][q], tb[q]);
+                    if (q < code - 1) {
+                        const double ta = (1.0 - te[j][q]) * ts[j][q];
+                        double tmsg[R];
+                        bits_select_vec<R>(tb[q], ta, te[j][q], tmsg);
+                        amin *= ta;
+#pragma unroll
+                        for (int r = 0; r < R; ++r) v[r] *= tmsg[r];
+                    }
+                }
+                if (!(amin >= 0x1p-190)) bec = lazy_rescale<G, R>(v);
+                f81_finish_child<G, R>(L, c, prod, pe, ch, e, cs[j], bec, v, false, mb, tdc, xe, pc, lsc, le, -1);
+                double prod2[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) prod2[r] = pc[r] * (lsc * L.ipi_r[r]);
+                const int cfc = j == 0 ? cfc0 : cfc1;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    if (q < code - 1) {
+                        double mt[R], tdt[R], pt[R], lt;
+                        bits_to_vec<R>(tb[q], mt);
+                        i64 xt, et;
+                        f81_finish_child<G, R>(L, c, prod2, le, cfc + q, te[j][q], ts[j][q], 0, mt, false, mt, tdt, xt, pt, lt, et, -1);
+                    }
+                }
+            }
+        }
+    }
+}
+
 // One unit = (stored internal node of the depth level, column): the parent's BU and TD vectors are loaded once and
 // every child is finished from them; cherry children are recomputed and their tips finished in the same unit.
 // replaces calc_node_td_likelihood (ml.py:273-290), calc_node_marginal_likelihood (:454-460) and the normalisation
@@ -1898,6 +2191,13 @@ __device__ __forceinline__ void td_f81_unit(const LaneCtx<G, R>& L, const PmlTre
             td_f81_unit_lean<G, R>(L, t, c, st, u);
         }
         return;
+    }
+    if constexpr (G >= 32) {
+        if (LEAN && c.W > 1 && !c.no_wide_lean && unit_is_lean(u.packed)) {  // (masks of several words: bu_f81_unit)
+            const int cfc0 = __shfl(u.cfc, L.group_base, 64), cfc1 = __shfl(u.cfc, L.group_base + Gather<G>::GC, 64);
+            td_f81_unit_lean_w<G, R>(L, t, c, st, u, cfc0, cfc1);
+            return;
+        }
     }
     if (Gather<G>::enabled && c.W == 1 && unit_is_fast<G>(u.packed)) {
         td_f81_unit_fast<G, R>(L, t, c, st, u);

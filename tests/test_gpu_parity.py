@@ -1738,3 +1738,39 @@ def test_lane_shapes_follow_the_forests_arity(k):
         np.testing.assert_allclose(out['default'][1], out['other'][1], rtol=1e-11, atol=1e-300)
         ref = orc.bottom_up(flat, masks[1].astype(int), specs[1][0], *specs[1][1])
         np.testing.assert_allclose(out['default'][0][1], ref['loglik'], rtol=LNL_RTOL)
+
+
+@pytest.mark.parametrize('k', [65, 67, 128, 130, 256])
+def test_lean_units_with_masks_of_several_words_have_the_sequential_paths_bits(k):
+    """
+    More than 64 states: masks of several words.  Units of at most two children (cherries of at most two tips) issue every
+    load up front and take the mask bits of the lane's own state pairs (bu_f81_unit_lean_w / td_f81_unit_lean_w) instead of
+    walking children and tips one round trip at a time -- against the sequential path (NO_WIDE_LEAN), bit for bit: ln L,
+    posteriors, sums, scales, the bottom-up and top-down vectors; binary, balanced and polytomy forests (there most units
+    stay on the sequential path), observed, ambiguous and unobserved tips, restricted internal nodes; and against the oracle.
+    """
+    rng = np.random.default_rng(4100 + k)
+    forests = [FlatForest.random(1200, seed=k, max_arity=2, n_trees=2), synthetic.balanced_forest(8),
+               FlatForest.random(900, seed=k + 1, max_arity=4, n_trees=1)]
+    for fi, flat in enumerate(forests):
+        C = 3
+        specs = [(random_spec('F81', k, rng), (float(rng.uniform(0.5, 3)), 0.0, 1.0)) for _ in range(C)]
+        masks = np.stack([random_masks(flat, k, rng, missing=0.05, multi=0.05, internal=0.02) for _ in range(C)])
+        masks[0] = synthetic.one_hot_masks(flat, k, rng.integers(0, k, size=flat.n_tips))
+        results = []
+        for off in (True, False):
+            with hip.Engine(flat, C, k, tune=dict(NO_WIDE_LEAN=1 if off else None), keep_td=True) as eng:
+                eng.set_models(specs)
+                eng.set_masks(masks)
+                lnl, post, lh_sum, lh_sf = eng.marginal_pass()
+                bu = np.stack([eng.download(hip.BUF_BU, c) for c in range(C)])
+                bu_sf = np.stack([eng.download(hip.BUF_BU_SF, c) for c in range(C)])
+                td = eng.download(hip.BUF_TD, 1)
+                td_sf = eng.download(hip.BUF_TD_SF, 1)
+                assert np.array_equal(lnl, eng.bottom_up(True))
+            results.append((lnl, post, lh_sum, lh_sf, bu, bu_sf, td, td_sf))
+        assert np.isfinite(results[0][1]).all()
+        for a, b in zip(results[0], results[1]):
+            assert np.array_equal(a, b), 'forest {}'.format(fi)
+        ref = orc.bottom_up(flat, masks[1].astype(int), specs[1][0], *specs[1][1])
+        np.testing.assert_allclose(results[1][0][1], ref['loglik'], rtol=LNL_RTOL)
