@@ -35,7 +35,7 @@ struct PmlTree {
 
 struct PmlCols {
     int k, ks, W;
-    int no_wide_lean;       // (a test switch: masks of several words on the sequential path, as before round 5)
+    int no_wide_lean;       // (a test switch: round 5's lean units -- several mask words, polytomies -- off: the sequential path)
     const u64* masks;       // [C][N][W]
     const u64* masks_init;  // [C][N][W] or nullptr
     const double* pi;       // [C][ks]
@@ -1160,6 +1160,138 @@ __device__ __forceinline__ bool bu_f81_unit_lean(const LaneCtx<G, R>& L, const P
     return true;
 }
 
+// Lean unit for polytomies in the kernels that walk several levels in one launch (units of fewer than 8 lanes): up to four
+// children, cherries of up to four tips -- what the descriptor codes.  The children are taken two at a time: every load of
+// a pair (scalars, stored vectors, the scalars of up to four tips under each) is issued before any of its values is used,
+// so a unit of three or four children is two round trips instead of one per child and per tip (the sequential path) --
+// in those kernels a level step is the latency of one unit.  The arithmetic is the sequential path's, operation by
+// operation (bu_f81_unit_lean's body with the band checks after every second child): the same bits.  Not in the level
+// kernels of large forests: there the registers of the 2 x 4 tips cost binary forests 7 - 10 % and a wavefront that mixes
+// these units with sequential ones loses more than it gains (profiles/r05z_lean_polytomies.txt).
+__device__ __forceinline__ bool unit_is_lean_poly(int packed) {
+    return unit_nc(packed) <= 4 && ((packed >> 4) & 1) && !unit_is_lean(packed);
+}
+
+template <int G, int R>
+__device__ __forceinline__ bool bu_f81_unit_lean_poly(const LaneCtx<G, R>& L, const PmlTree& t, const PmlCols& c,
+                                                      const PmlState& st, const UnitRegs& u) {
+    const int n = u.n, fc = u.fc;
+    const int nc = unit_nc(u.packed);
+    const u64 kbits = state_bits(c.k);
+    const u64 own = L.mask[(unsigned)n];
+    double acc[R];
+    i64 esum = 0;
+    double lob = 1.0;
+    bool bounded = true;
+    for (int j0 = 0; j0 < nc; j0 += 2) {
+        // ---- loads of the pair
+        double ce[2], cs[2], vv[2][R];
+        u64 cm[2];
+        i64 cbe[2];
+        double te[2][4], ts[2][4];
+        u64 tm[2][4];
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int j = j0 + jj;
+            const bool valid = j < nc;
+            const int ch = fc + (valid ? j : j0);
+            const int code = valid ? unit_code(u.packed, j) : 0;
+            ce[jj] = L.E[ch];
+            cm[jj] = code != 1 ? L.mask[(unsigned)ch] : 0ull;
+            cs[jj] = code <= 1 ? L.S[ch] : 0.0;
+            cbe[jj] = code == 1 ? L.be[ch] : 0;
+            if (code == 1) {
+                node_load_vec<G, R>(L, c, L.bu, ch, vv[jj]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < R; ++r) vv[jj][r] = 0.0;
+            }
+            const int cfc = j == 0 ? u.cfc : (j == 1 ? u.cfc1 : (j == 2 ? u.cfc2 : u.cfc3));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                te[jj][q] = 0.0;
+                ts[jj][q] = 0.0;
+                tm[jj][q] = 0ull;
+                if (code >= 2 && q < code - 1) {
+                    te[jj][q] = L.E[cfc + q];
+                    ts[jj][q] = L.S[cfc + q];
+                    tm[jj][q] = L.mask[(unsigned)(cfc + q)];
+                }
+            }
+        }
+        if (j0 == 0) clean_word_to_vec<G, R>(L, c, own & kbits, acc);
+        // ---- arithmetic (bu_f81_unit_seq's operations)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int j = j0 + jj;
+            if (j < nc) {
+                const int code = unit_code(u.packed, j);
+                const double e = ce[jj];
+                double msg[R];
+                double a;
+                if (code == 0) {
+                    a = (1.0 - e) * cs[jj];
+                    word_select_vec<G, R>(L, c, cm[jj] & kbits, a, e, msg);
+                } else {
+                    double v[R];
+                    double s_child;
+                    if (code == 1) {
+#pragma unroll
+                        for (int r = 0; r < R; ++r) v[r] = vv[jj][r];
+                        esum += cbe[jj];
+                        s_child = cs[jj];
+                        bounded = false;
+                    } else {
+                        // cherry: mask, then per tip its message and the product; band check after the last tip
+                        clean_word_to_vec<G, R>(L, c, cm[jj] & kbits, v);
+                        double amin = 1.0;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            if (q < code - 1) {
+                                const double ta = (1.0 - te[jj][q]) * ts[jj][q];
+                                double tmsg[R];
+                                word_select_vec<G, R>(L, c, tm[jj][q] & kbits, ta, te[jj][q], tmsg);
+                                amin *= ta;
+#pragma unroll
+                                for (int r = 0; r < R; ++r) v[r] *= tmsg[r];
+                            }
+                        }
+                        if (!(amin >= 0x1p-190)) esum += lazy_rescale<G, R>(v);
+                        s_child = pi_dot<G, R>(L, v);
+                        if (L.g == 0) L.S[fc + j] = s_child;
+                    }
+                    a = (1.0 - e) * s_child;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) msg[r] = a + e * v[r];
+                }
+                lob *= a;
+#pragma unroll
+                for (int r = 0; r < R; ++r) acc[r] *= msg[r];
+                if (jj == 1 || j == nc - 1) {
+                    if (!bounded || !(lob >= 0x1p-190)) {
+                        const int ex = lazy_rescale<G, R>(acc);
+                        esum += ex;
+                        if (ex != 0) bounded = false;
+                    }
+                }
+            }
+        }
+    }
+    const double s = pi_dot<G, R>(L, acc);
+    if (!(s > 0.0)) {
+        bool nz = false;
+#pragma unroll
+        for (int r = 0; r < R; ++r) nz |= acc[r] != 0.0 && L.st(r) < c.k;
+        if (!group_any<G>(nz)) return false;
+    }
+    if (L.g == 0) {
+        L.S[n] = s;
+        L.be[n] = esum;
+    }
+    node_store_vec<G, R>(L, c, L.bu, n, acc);
+    return true;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // More than 64 states (masks of several words; units of 32 and 64 lanes).  The lane-parallel and lean paths above take
 // single-word masks, so such units ran the sequential path: a dependent round trip to L2 per child and per tip, twice
@@ -1370,6 +1502,13 @@ __device__ __forceinline__ void bu_f81_unit(const LaneCtx<G, R>& L, const PmlTre
             ok = bu_f81_unit_lean<G, R>(L, t, c, st, u);
         }
         if (ok) return;
+    }
+    if (SHAPES && LEAN && !JOINT && G < 8 && c.W == 1 && !c.no_wide_lean) {
+        // (only where none of the wave's remaining units needs the sequential path: a wave that ran both would lose)
+        const bool poly = unit_is_lean_poly(u.packed);
+        if (__ballot(!poly) == 0ull) {
+            if (bu_f81_unit_lean_poly<G, R>(L, t, c, st, u)) return;
+        }
     }
     if constexpr (G >= 32) {
         // (masks of several words; where the tips of cherry children 0 and 1 start: units of 8 lanes and more keep the
@@ -2050,6 +2189,123 @@ __device__ __forceinline__ void td_f81_unit_lean(const LaneCtx<G, R>& L, const P
     }
 }
 
+// Lean top-down unit for polytomies (see bu_f81_unit_lean_poly): up to four children, cherries of up to four tips, the
+// children two at a time -- every load of a pair before any of its values; the operations of td_f81_unit's sequential path
+// in its order (every child is finished from the parent's product on its own).
+template <int G, int R>
+__device__ __forceinline__ void td_f81_unit_lean_poly(const LaneCtx<G, R>& L, const PmlTree& t, const PmlCols& c,
+                                                      const PmlState& st, const UnitRegs& u) {
+    const int p = u.n, fc = u.fc;
+    const int nc = unit_nc(u.packed);
+    const u64 kbits = state_bits(c.k);
+    double po[R];
+    node_load_vec<G, R>(L, c, L.post, p, po);
+    const double ls = L.lhsum[p];
+    const i64 pe = L.lhe[p];
+    double prod[R];
+    double P = 0.0;
+    bool have_P = false;
+    for (int j0 = 0; j0 < nc; j0 += 2) {
+        // ---- loads of the pair
+        double ce[2], cs[2], vv[2][R];
+        u64 cm[2];
+        i64 cbe[2];
+        double te[2][4], ts[2][4];
+        u64 tm[2][4];
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int j = j0 + jj;
+            const bool valid = j < nc;
+            const int ch = fc + (valid ? j : j0);
+            const int code = valid ? unit_code(u.packed, j) : 0;
+            ce[jj] = L.E[ch];
+            cm[jj] = L.mask[(unsigned)ch];
+            cs[jj] = L.S[ch];
+            cbe[jj] = code == 1 ? L.be[ch] : 0;
+            if (code == 1) {
+                node_load_vec<G, R>(L, c, L.bu, ch, vv[jj]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < R; ++r) vv[jj][r] = 0.0;
+            }
+            const int cfc = j == 0 ? u.cfc : (j == 1 ? u.cfc1 : (j == 2 ? u.cfc2 : u.cfc3));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                te[jj][q] = 0.0;
+                ts[jj][q] = 0.0;
+                tm[jj][q] = 0ull;
+                if (code >= 2 && q < code - 1) {
+                    te[jj][q] = L.E[cfc + q];
+                    ts[jj][q] = L.S[cfc + q];
+                    tm[jj][q] = L.mask[(unsigned)(cfc + q)];
+                }
+            }
+        }
+        if (j0 == 0) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) prod[r] = po[r] * (ls * L.ipi_r[r]);  // f81_parent_prod
+        }
+        // ---- arithmetic
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int j = j0 + jj;
+            if (j < nc) {
+                const int ch = fc + j;
+                const int code = unit_code(u.packed, j);
+                const double e = ce[jj];
+                const int slot = j < 2 ? j : -1;  // (staging slots: children 0 and 1 and two tips of each, as on the sequential path)
+                if (code == 0) {
+                    f81_finish_tip_word<G, R>(L, c, prod, pe, P, have_P, ch, cm[jj] & kbits, e, cs[jj], slot);
+                } else {
+                    double mb[R], v[R], tdc[R], pc[R], lsc;
+                    clean_word_to_vec<G, R>(L, c, cm[jj] & kbits, mb);
+                    i64 xe, le;
+                    if (code == 1) {
+#pragma unroll
+                        for (int r = 0; r < R; ++r) v[r] = vv[jj][r];
+                        f81_finish_child<G, R>(L, c, prod, pe, ch, e, cs[jj], cbe[jj], v, false, mb, tdc, xe, pc, lsc, le, slot);
+                        if (st.td != nullptr) {
+                            node_store_vec<G, R>(L, c, L.td, ch, tdc);
+                            if (L.g == 0) L.te[ch] = xe;
+                        }
+                    } else {
+                        // cherry: its bottom-up vector again (f81_cherry_vector's operations), finished, then its tips
+#pragma unroll
+                        for (int r = 0; r < R; ++r) v[r] = mb[r];
+                        double amin = 1.0;
+                        i64 bec = 0;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            if (q < code - 1) {
+                                const double ta = (1.0 - te[jj][q]) * ts[jj][q];
+                                double tmsg[R];
+                                word_select_vec<G, R>(L, c, tm[jj][q] & kbits, ta, te[jj][q], tmsg);
+                                amin *= ta;
+#pragma unroll
+                                for (int r = 0; r < R; ++r) v[r] *= tmsg[r];
+                            }
+                        }
+                        if (!(amin >= 0x1p-190)) bec = lazy_rescale<G, R>(v);
+                        f81_finish_child<G, R>(L, c, prod, pe, ch, e, cs[jj], bec, v, false, mb, tdc, xe, pc, lsc, le, slot);
+                        double prod2[R];
+#pragma unroll
+                        for (int r = 0; r < R; ++r) prod2[r] = pc[r] * (lsc * L.ipi_r[r]);
+                        double P2 = 0.0;
+                        bool have_P2 = false;
+                        const int cfc = j == 0 ? u.cfc : (j == 1 ? u.cfc1 : (j == 2 ? u.cfc2 : u.cfc3));
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            if (q < code - 1)
+                                f81_finish_tip_word<G, R>(L, c, prod2, le, P2, have_P2, cfc + q, tm[jj][q] & kbits, te[jj][q],
+                                                          ts[jj][q], (j < 2 && q < 2) ? 2 + 2 * j + q : -1);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
 // Lean top-down unit for masks of several words (see bu_f81_unit_lean_w): every load up front, then the operations of
 // td_f81_unit's sequential path in its order -- tips on its general path (the closed form of observed tips needs the
 // single word).
@@ -2191,6 +2447,13 @@ __device__ __forceinline__ void td_f81_unit(const LaneCtx<G, R>& L, const PmlTre
             td_f81_unit_lean<G, R>(L, t, c, st, u);
         }
         return;
+    }
+    if (SHAPES && LEAN && G < 8 && c.W == 1 && !c.no_wide_lean) {
+        const bool poly = unit_is_lean_poly(u.packed);   // (a wave of such units only: bu_f81_unit)
+        if (__ballot(!poly) == 0ull) {
+            td_f81_unit_lean_poly<G, R>(L, t, c, st, u);
+            return;
+        }
     }
     if constexpr (G >= 32) {
         if (LEAN && c.W > 1 && !c.no_wide_lean && unit_is_lean(u.packed)) {  // (masks of several words: bu_f81_unit)

@@ -1,19 +1,8 @@
 #!/bin/bash
-: > gpurun_out/r05z_k67.txt
-python - <<'PY' >> gpurun_out/r05z_k67.txt 2>&1
-import sys, time; sys.path.insert(0, '.')
-import numpy as np
-from pastml_amd import hip, synthetic
-from pastml_amd.tree import read_tree, get_flat_forest
-f = get_flat_forest([read_tree('tests/golden/data/hiv1c/pastml_phyml_tree.nwk')])
-for k, C in ((64, 68), (67, 68), (128, 68), (30, 31), (36, 37)):
-    with hip.Engine(f, C, k) as eng:
-        eng.set_models([(dict(kind=0, pi=synthetic.f81_frequencies(k, c)), (1.0, 0.0, 1.0)) for c in range(C)])
-        eng.set_tip_states(np.stack([synthetic.tip_states(f.n_tips, k, c) for c in range(C)]))
-        for _ in range(3): eng.bottom_up(True)
-        eng.sync(); t0 = time.perf_counter()
-        for _ in range(200): eng.bottom_up(True)
-        eng.sync(); ms = (time.perf_counter() - t0) / 200 * 1e3
-        print('hiv tree k=%d C=%d bottom-up %.3f ms  schedule %s' % (k, C, ms, eng.sweep_schedule()), flush=True)
-PY
-cat gpurun_out/r05z_k67.txt
+: > gpurun_out/r05z_poly3.txt
+for case in midpoly3_4 midpoly5_4 midpoly3_12 midpoly5_12 midpoly5_2 smallpoly4_5 poly4 poly3_4 poly12 bin100k_4 ragged4 hiv12; do
+  for v in default= old=NO_WIDE_LEAN:1; do
+    timeout -k 10 120 python scripts/r05_tune_one.py $case $v >> gpurun_out/r05z_poly3.txt 2>&1
+  done
+done
+cat gpurun_out/r05z_poly3.txt

@@ -44,6 +44,12 @@ cases = dict(ragged64=(lambda: FlatForest.random(262144, seed=3, max_arity=2, n_
              bin100k_12=(lambda: FlatForest.random(100000, seed=5, max_arity=2, n_trees=2), 12, 16),
              poly3_12=(lambda: FlatForest.random(100000, seed=5, max_arity=3, n_trees=2), 12, 16),
              bin100k_64=(lambda: FlatForest.random(100000, seed=5, max_arity=2, n_trees=2), 64, 16),
+             midpoly3_4=(lambda: FlatForest.random(3600, seed=6, max_arity=3, n_trees=1), 4, 14),
+             midpoly5_4=(lambda: FlatForest.random(3600, seed=6, max_arity=5, n_trees=1), 4, 14),
+             midpoly3_12=(lambda: FlatForest.random(3600, seed=6, max_arity=3, n_trees=1), 12, 14),
+             midpoly5_12=(lambda: FlatForest.random(3600, seed=6, max_arity=5, n_trees=1), 12, 14),
+             midpoly5_2=(lambda: FlatForest.random(3600, seed=6, max_arity=5, n_trees=1), 2, 246),
+             smallpoly4_5=(lambda: FlatForest.random(300, seed=6, max_arity=4, n_trees=1), 5, 1),
              poly12=(lambda: FlatForest.random(100000, seed=5, max_arity=5, n_trees=2), 12, 16),
              balanced4=(lambda: synthetic.balanced_forest(18), 4, 32),
              balanced12=(lambda: synthetic.balanced_forest(18), 12, 32),

@@ -1774,3 +1774,39 @@ def test_lean_units_with_masks_of_several_words_have_the_sequential_paths_bits(k
             assert np.array_equal(a, b), 'forest {}'.format(fi)
         ref = orc.bottom_up(flat, masks[1].astype(int), specs[1][0], *specs[1][1])
         np.testing.assert_allclose(results[1][0][1], ref['loglik'], rtol=LNL_RTOL)
+
+
+@pytest.mark.parametrize('k', [2, 4, 7, 12, 16])
+def test_lean_units_for_polytomies_have_the_sequential_paths_bits(k):
+    """
+    The kernels that walk several levels in one launch (small forests, subtree blocks, the thin ends of large ones), units of
+    fewer than 8 lanes: a unit of three or four children (cherries of up to four tips) takes its children two at a time, every
+    load of a pair before any of its values (bu_f81_unit_lean_poly / td_f81_unit_lean_poly), where no unit of its wavefront
+    needs the sequential path -- against that path (NO_WIDE_LEAN), bit for bit: ln L, posteriors, sums, scales, the bottom-up
+    and top-down vectors; single-launch and block schedules, at most 3 / 4 / 6 children per node; and against the oracle.
+    """
+    rng = np.random.default_rng(4300 + k)
+    forests = [FlatForest.random(400, seed=k, max_arity=3, n_trees=1), FlatForest.random(3000, seed=k + 1, max_arity=4, n_trees=2),
+               FlatForest.random(2500, seed=k + 2, max_arity=6, n_trees=1), FlatForest.random(2000, seed=k + 3, max_arity=3, n_trees=1)]
+    for fi, flat in enumerate(forests):
+        C = 3
+        specs = [(random_spec('F81', k, rng), (float(rng.uniform(0.5, 3)), 0.0, 1.0)) for _ in range(C)]
+        masks = np.stack([random_masks(flat, k, rng, missing=0.05, multi=0.05, internal=0.02) for _ in range(C)])
+        masks[0] = synthetic.one_hot_masks(flat, k, rng.integers(0, k, size=flat.n_tips))
+        results = []
+        for off in (True, False):
+            with hip.Engine(flat, C, k, tune=dict(NO_WIDE_LEAN=1 if off else None), keep_td=(fi % 2 == 0)) as eng:
+                eng.set_models(specs)
+                eng.set_masks(masks)
+                assert eng.sweep_schedule()[0] in (hip.SCHEDULE_SINGLE_LAUNCH, hip.SCHEDULE_BLOCKS)
+                lnl, post, lh_sum, lh_sf = eng.marginal_pass()
+                bu = np.stack([eng.download(hip.BUF_BU, c) for c in range(C)])
+                bu_sf = np.stack([eng.download(hip.BUF_BU_SF, c) for c in range(C)])
+                extra = (eng.download(hip.BUF_TD, 1), eng.download(hip.BUF_TD_SF, 1)) if fi % 2 == 0 else ()
+                assert np.array_equal(lnl, eng.bottom_up(True))
+            results.append((lnl, post, lh_sum, lh_sf, bu, bu_sf) + extra)
+        assert np.isfinite(results[0][1]).all()
+        for a, b in zip(results[0], results[1]):
+            assert np.array_equal(a, b), 'forest {}'.format(fi)
+        ref = orc.bottom_up(flat, masks[1].astype(int), specs[1][0], *specs[1][1])
+        np.testing.assert_allclose(results[1][0][1], ref['loglik'], rtol=LNL_RTOL)
