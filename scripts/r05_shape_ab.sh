@@ -1,8 +1,9 @@
 #!/bin/bash
-: > gpurun_out/r05z_poly3.txt
-for case in midpoly3_4 midpoly5_4 midpoly3_12 midpoly5_12 midpoly5_2 smallpoly4_5 poly4 poly3_4 poly12 bin100k_4 ragged4 hiv12; do
-  for v in default= old=NO_WIDE_LEAN:1; do
-    timeout -k 10 120 python scripts/r05_tune_one.py $case $v >> gpurun_out/r05z_poly3.txt 2>&1
+: > gpurun_out/r05z_cfg4_libab.txt
+for rep in 1 2; do
+  for lib in "" "$PWD/scratch/r05w/libpastml_hip_oldseq.so"; do
+    PASTML_HIP_LIBRARY=$lib timeout -k 10 300 python bench.py --no-secondary --no-cpu-baseline --steps 10 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('lib=%s' % ('$lib'[-14:] or 'new'), d['ms_per_step'], d['roofline']['frac'], d['library']['build_digest'])" >> gpurun_out/r05z_cfg4_libab.txt
   done
 done
-cat gpurun_out/r05z_poly3.txt
+cat gpurun_out/r05z_cfg4_libab.txt
