@@ -12,6 +12,8 @@ cases = dict(ragged64=(lambda: FlatForest.random(262144, seed=3, max_arity=2, n_
              ragged4=(lambda: FlatForest.random(262144, seed=3, max_arity=2, n_trees=1), 4, 32),
              balanced64=(lambda: synthetic.balanced_forest(18), 64, 32),
              ragged12=(lambda: FlatForest.random(262144, seed=3, max_arity=2, n_trees=1), 12, 32),
+             poly3_64=(lambda: FlatForest.random(100000, seed=5, max_arity=3, n_trees=2), 64, 16),
+             poly3_20=(lambda: FlatForest.random(100000, seed=5, max_arity=3, n_trees=2), 20, 16),
              poly4=(lambda: FlatForest.random(100000, seed=5, max_arity=5, n_trees=2), 4, 16),
              hiv12=(None, 12, 14), cfg2=(lambda: synthetic.balanced_forest(16), 4, 1))
 make, k, C = cases[key]

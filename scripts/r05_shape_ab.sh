@@ -1,9 +1,8 @@
 #!/bin/bash
-: > gpurun_out/r05z_cfg4_libab.txt
-for rep in 1 2; do
-  for lib in "" "$PWD/scratch/r05w/libpastml_hip_oldseq.so"; do
-    PASTML_HIP_LIBRARY=$lib timeout -k 10 300 python bench.py --no-secondary --no-cpu-baseline --steps 10 2>/dev/null | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); print('lib=%s' % ('$lib'[-14:] or 'new'), d['ms_per_step'], d['roofline']['frac'], d['library']['build_digest'])" >> gpurun_out/r05z_cfg4_libab.txt
+: > gpurun_out/r05z_binsize.txt
+for case in poly3_20 poly3_64 poly20 ragged20 mid64 hiv67c204 hiv30c93; do
+  for v in default= s32=THIN_BLOCK_NODES:32 s64=THIN_BLOCK_NODES:64 s128=THIN_BLOCK_NODES:128 s512=THIN_BLOCK_NODES:512; do
+    timeout -k 10 120 python scripts/r05_tune_one.py $case $v >> gpurun_out/r05z_binsize.txt 2>&1
   done
 done
-cat gpurun_out/r05z_cfg4_libab.txt
+cat gpurun_out/r05z_binsize.txt

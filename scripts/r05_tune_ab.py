@@ -54,7 +54,7 @@ cases = dict(ragged64=(lambda: FlatForest.random(262144, seed=3, max_arity=2, n_
              balanced4=(lambda: synthetic.balanced_forest(18), 4, 32),
              balanced12=(lambda: synthetic.balanced_forest(18), 12, 32),
              mid4=(lambda: FlatForest.random(40000, seed=7, max_arity=2, n_trees=1), 4, 8),
-             hiv12=(lambda: hiv1c_forest(), 12, 14), hiv40=(lambda: hiv1c_forest(), 40, 14), hiv64=(lambda: hiv1c_forest(), 64, 64),
+             hiv12=(lambda: hiv1c_forest(), 12, 14), hiv40=(lambda: hiv1c_forest(), 40, 14), hiv67c204=(lambda: hiv1c_forest(), 67, 204), hiv30c93=(lambda: hiv1c_forest(), 30, 93), hiv64=(lambda: hiv1c_forest(), 64, 64),
              small40=(lambda: FlatForest.random(600, seed=2, max_arity=2, n_trees=1), 40, 8), hiv2=(lambda: hiv1c_forest(), 2, 246), hiv67=(lambda: hiv1c_forest(), 67, 68),
              cfg2=(lambda: synthetic.balanced_forest(16), 4, 1))
 make, k, C = cases[sys.argv[1]]
