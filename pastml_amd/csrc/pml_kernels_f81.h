@@ -1503,8 +1503,9 @@ __device__ __forceinline__ void bu_f81_unit(const LaneCtx<G, R>& L, const PmlTre
         }
         if (ok) return;
     }
-    if (SHAPES && LEAN && !JOINT && G < 8 && c.W == 1 && !c.no_wide_lean) {
-        // (only where none of the wave's remaining units needs the sequential path: a wave that ran both would lose)
+    if (SHAPES && LEAN && !JOINT && G >= 2 && G < 8 && c.W == 1 && !c.no_wide_lean) {
+        // (only where none of the wave's remaining units needs the sequential path: a wave that ran both would lose;
+        // not for one-lane units, k <= 2: there the extra code costs binary trees 4 %)
         const bool poly = unit_is_lean_poly(u.packed);
         if (__ballot(!poly) == 0ull) {
             if (bu_f81_unit_lean_poly<G, R>(L, t, c, st, u)) return;
@@ -2448,7 +2449,7 @@ __device__ __forceinline__ void td_f81_unit(const LaneCtx<G, R>& L, const PmlTre
         }
         return;
     }
-    if (SHAPES && LEAN && G < 8 && c.W == 1 && !c.no_wide_lean) {
+    if (SHAPES && LEAN && G >= 2 && G < 8 && c.W == 1 && !c.no_wide_lean) {
         const bool poly = unit_is_lean_poly(u.packed);   // (a wave of such units only: bu_f81_unit)
         if (__ballot(!poly) == 0ull) {
             td_f81_unit_lean_poly<G, R>(L, t, c, st, u);
