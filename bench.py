@@ -35,6 +35,10 @@ FP64_MFMA_PEAK_TFLOPS = 78.6     # dense FP64 matrix-core peak (same guide)
 # SURVEY.md 8d's bytes per node.state.char of the REFERENCE's schedule (every vector of every node written and read
 # back): kept only to say how much traffic the schedule below avoids -- never used for `frac`
 REFERENCE_SCHEDULE_BYTES = {'bottom_up': 16, 'top_down': 32}
+# Schedule-independent yardsticks printed next to `frac` (which rests on this schedule's own byte model):
+HBM_ACHIEVABLE_GBS = 6300.0      # the guide's attainable HBM bandwidth (hipMemsetAsync here: 6.2 TB/s, profiles/r05i_write_streams.txt)
+OUTPUT_FLOOR_BYTES_PER_UNIT = 8  # every posterior entry written once: no schedule of a full marginal pass moves less
+SURVEY_8D_BYTES_PER_UNIT = 48    # the reference schedule's algorithmic bytes of a full marginal pass
 
 WORKLOADS = {
     # name: (tree levels, k, characters per GPU)
@@ -58,9 +62,9 @@ def parse_args():
                    help='leave the HIP-event brackets off: the sweeps are then replayed as hipGraphs (the library\'s '
                         'default outside profiling); roofline fields are null')
     p.add_argument('--cpu-baseline-levels', type=int, default=None,
-                   help='tree levels of the subtree the CPU baseline is timed on (default: about 15 s of work)')
+                   help='tree levels of the subtree the CPU baseline is timed on (default 18: 262 144 tips)')
     p.add_argument('--cpu-baseline-cores', type=int, default=None,
-                   help='worker processes of the CPU baseline (default: the cores this process may run on, at most 16)')
+                   help='worker processes of the CPU baseline (default: the cores this process may run on, at most 32)')
     return p.parse_args()
 
 
@@ -105,42 +109,44 @@ def under_profiler():
 def cpu_baseline(k, levels, model, cores=None):
     """
     PastML-style numpy CPU path (oracle/pastml_oracle.py, the per-node restatement of pastml/ml.py) timed on this
-    box's host cores.  Two figures on a bounded sample of the same workload (full marginal pass of one character per
-    task on a balanced subtree): one thread, and a pool of `cores` worker processes with one character each, which
-    is how the reference spreads characters (acr.py:210-231; it uses threads, processes are the kinder reading).
+    box's host cores, after BASELINE.md section 3: one thread (us per node), and a pool of worker processes with one
+    character each, which is how the reference spreads characters (acr.py:210-231; it uses threads, processes are the
+    kinder reading).  Workers = the cores this process may run on, at most 32; both legs on the same tree of `levels`
+    levels (default 18: 262 144 tips -- about 20 s per character on the GPU box's EPYC; the full 1 048 576-tip tree of
+    section 3 would take the reference 359 s per character, tests/golden/make_golden.py).
     """
     import multiprocessing as mp
     dt1, n_nodes, n_tips, lnl = _cpu_baseline_one((k, levels, model, 0))
     single = n_nodes * k / dt1
+    affinity = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else os.cpu_count()
     if cores is None:
-        # a 1-GPU box gives us 16 of the host's cores (os.cpu_count() reports all of them)
-        cores = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else os.cpu_count()))
+        cores = max(1, min(32, affinity))   # (os.cpu_count() reports the whole host; a 1-GPU box gives us a share of it)
     out = dict(value=single, unit='node*state*char/s', cores=1, kind='port',
                sample='1 character, balanced {}-tip tree ({} nodes), k={}, full marginal pass (BU+TD+posteriors), '
                       'numpy per-node port of pastml/ml.py, {:.1f} s on 1 of {} host cores'
                       .format(n_tips, n_nodes, k, dt1, os.cpu_count()),
                seconds=dt1, us_per_node=dt1 / n_nodes * 1e6, loglik=lnl, single_core_value=single,
-               cpu_model=cpu_model_name(), host_cores=os.cpu_count())
+               cpu_model=cpu_model_name(), host_cores=os.cpu_count(), affinity_cores=affinity, tips=int(n_tips))
     if cores > 1:
-        pl = max(10, levels - 1)  # half the tree per task: the pool leg costs about half the single-thread leg
         ctx = mp.get_context('spawn')  # fresh interpreters: numpy and the oracle only
         t0 = time.perf_counter()
         with ctx.Pool(cores) as pool:
-            res = pool.map(_cpu_baseline_one, [(k, pl, model, c) for c in range(cores)])
+            res = pool.map(_cpu_baseline_one, [(k, levels, model, c) for c in range(cores)], chunksize=1)
         wall = time.perf_counter() - t0
         work = max(r[0] for r in res)  # slowest task, without interpreter start-up
         pooled = sum(r[1] for r in res) * k / work
-        out.update(value=pooled, cores=cores, seconds=dt1 + wall,
-                   sample='{} characters in {} worker processes, one each, balanced {}-tip tree ({} nodes), k={}, full '
-                          'marginal pass (BU+TD+posteriors), numpy per-node port of pastml/ml.py: slowest task {:.1f} s '
-                          '(pool wall {:.1f} s); single thread on a {}-tip tree: {:.3g} units/s in {:.1f} s; host '
-                          'reports {} cores'.format(cores, cores, res[0][2], res[0][1], k, work, wall, n_tips, single,
-                                                    dt1, os.cpu_count()))
+        out.update(value=pooled, cores=cores, seconds=dt1 + wall, pool_us_per_node=work / res[0][1] * 1e6,
+                   sample='{} characters in {} worker processes (= the {} cores this process may run on, at most 32), one '
+                          'each, balanced {}-tip tree ({} nodes), k={}, full marginal pass (BU+TD+posteriors), numpy '
+                          'per-node port of pastml/ml.py: slowest task {:.1f} s = {:.1f} us/node (pool wall {:.1f} s); '
+                          'single thread on the same tree: {:.1f} us/node, {:.3g} units/s in {:.1f} s; host reports {} '
+                          'cores'.format(cores, cores, affinity, res[0][2], res[0][1], k, work, work / res[0][1] * 1e6,
+                                         wall, dt1 / n_nodes * 1e6, single, dt1, os.cpu_count()))
     # BASELINE.md section 3 asks for 2 x cores characters at FULL tree size: the reference needs 359 s per character there
-    # (tests/golden/make_golden.py, 1 048 576 tips: 171 us per node against the ~40 us per node of this sample), so this
-    # bounded sample flatters the CPU by about 4x and the speed-up computed from it is a lower bound
-    out['sample'] += ('; NOT the full-size tree: the reference itself took 359 s per character at 1 048 576 tips '
-                      '(171 us/node, tests/golden/make_golden.py), so this sample overstates the CPU rate about fourfold')
+    # (tests/golden/make_golden.py, 1 048 576 tips: 171 us per node), so a bounded sample on a quarter of the tips still
+    # flatters the CPU and the speed-up computed from it is a lower bound
+    out['sample'] += ('; a quarter of the full tree\'s tips: the reference itself took 359 s per character at 1 048 576 '
+                      'tips (171 us/node, tests/golden/make_golden.py) -- the speed-up from this sample is a lower bound')
     return out
 
 
@@ -421,7 +427,7 @@ def schedule_bytes(flat, k, n_cols, narrow_limit=None):
                 n_cherries=int(cherry.sum()), n_tips=int(tip.sum()), n_two_level=n_sup, n_stacked=n_stack,
                 n_absorbed=n_gc, n_absorbing=n_gp,
                 bottom_up_levels=bu_levels, bottom_up_two_level=bu_two, top_down_levels=td_levels,
-                top_down_two_level=td_two,
+                top_down_two_level=td_two, rows_two_level=14 * n_sup,
                 per_unit=dict(bottom_up=bu / (N * k), top_down=td / (N * k), prep=prep / (N * k)))
 
 
@@ -461,7 +467,7 @@ def run_cpu_baseline(args, levels, k, model):
         return None
     cl = args.cpu_baseline_levels
     if cl is None:
-        cl = min(levels, 17 if k >= 32 else 16)  # 10-20 s of single-thread numpy on the GPU box
+        cl = min(levels, 18)  # 262 144 tips: about 20 s of single-thread numpy per character on the GPU box
     return cpu_baseline(k, cl, model, args.cpu_baseline_cores)
 
 
@@ -1047,6 +1053,22 @@ def main():
             except (OSError, ValueError, KeyError, TypeError) as e:
                 traffic_note = 'profiles/traffic.json unreadable: {}'.format(e)
         avg_launch_s = dom['ms'] / max(1, dom['launches']) * 1e-3
+        # Figures that do not depend on this schedule's own byte model:
+        #   output floor  every posterior entry written once, 8 B per node*state*char -- what ANY schedule must move
+        #   SURVEY 8(d)   the reference schedule's 48 B per unit (every vector of every node written and read back); this
+        #                 schedule keeps cherries / two-level children in registers and never stores TD vectors, so the
+        #                 ratio comes out ABOVE the peak: the 48-byte model is not a bound for it
+        #   achievable    the guide's ~6.3 TB/s of attainable HBM bandwidth next to the 8 TB/s peak
+        units_dom = (float(sb['rows_two_level']) if two_level else float(N)) * k * cpg   # posterior entries the dominant kernel writes
+        def independent(units_per_pass, ms_total, n_pass):
+            if not ms_total or ms_total <= 0:
+                return {}
+            per_s = units_per_pass * n_pass / (ms_total * 1e-3)
+            return {'output_floor_bytes': OUTPUT_FLOOR_BYTES_PER_UNIT * units_per_pass,
+                    'output_floor_gbs': OUTPUT_FLOOR_BYTES_PER_UNIT * per_s / 1e9,
+                    'frac_of_output_floor': OUTPUT_FLOOR_BYTES_PER_UNIT * per_s / 1e9 / HBM_PEAK_GBS,
+                    'frac_of_output_floor_achievable': OUTPUT_FLOOR_BYTES_PER_UNIT * per_s / 1e9 / HBM_ACHIEVABLE_GBS,
+                    'achievable_peak': HBM_ACHIEVABLE_GBS}
         out = {
             'metric': 'ACR nodes*states*chars/sec (full marginal pass: P(t) + bottom-up + top-down + posteriors)',
             'value': value,
@@ -1086,6 +1108,9 @@ def main():
                               'in registers, TD vectors are never stored',
                 'reference_schedule_bytes_avoided': (REFERENCE_SCHEDULE_BYTES['top_down'] * N * k * cpg
                                                      - per_step['top_down']),
+                'frac_of_achievable': (dom_gbs / HBM_ACHIEVABLE_GBS) if dom_gbs else None,
+                'output_rows_per_launch': units_dom / k / cpg,
+                **independent(units_dom, dom['ms'], dom['launches']),
             },
             'roofline_top_down': {
                 'kernel': 'whole top-down sweep: td_f81_kernel (one launch per depth level)'
@@ -1112,6 +1137,14 @@ def main():
                 'model_bytes': sum(per_step.values()),
                 'achieved': sum(per_step.values()) * args.steps / dt / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': sum(per_step.values()) * args.steps / dt / 1e9 / HBM_PEAK_GBS,
+                'frac_of_achievable': sum(per_step.values()) * args.steps / dt / 1e9 / HBM_ACHIEVABLE_GBS,
+                **independent(float(N) * k * cpg, dt * 1e3, args.steps),
+                'survey_8d_bytes': SURVEY_8D_BYTES_PER_UNIT * N * k * cpg,
+                'survey_8d_gbs': SURVEY_8D_BYTES_PER_UNIT * N * k * cpg * args.steps / dt / 1e9,
+                'survey_8d_ratio': SURVEY_8D_BYTES_PER_UNIT * N * k * cpg * args.steps / dt / 1e9 / HBM_PEAK_GBS,
+                'survey_8d_note': 'SURVEY 8(d) counts 48 B per node*state*char (the reference schedule: every BU / TD / '
+                                  'posterior vector of every node written and read back); a ratio above 1 says this '
+                                  'schedule does not move that traffic -- that model is not a bound for it, the output floor is',
             },
             'kernel_ms_per_step': {'bottom_up': bu_ms / args.steps, 'top_down': td_ms / args.steps,
                                    'prep': prep_ms / args.steps},

@@ -1,27 +1,8 @@
-// libpastml_hip.so -- C-ABI (include/pastml_hip.h) over the HIP kernels.  gfx950 only.
-#include "../../include/pastml_hip.h"
-
-#include <algorithm>
-#include <hip/hip_runtime.h>
-
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <functional>
-#include <limits>
-#include <mutex>
-#include <string>
-#include <chrono>
-#include <vector>
-
-#include "pml_kernels_eigen_gemm.h"
-#include "pml_kernels_eigen_joint.h"
+// libpastml_hip.so -- C-ABI (include/pastml_hip.h) over the HIP kernels: contexts, tree upload and schedules, the sweeps'
+// launch sequences, downloads, the communicator.  The kernel families are launched through pml_launch.h.  gfx950 only.
+#include "pml_launch.h"
 #include "pml_kernels_counts.h"
 #include "pml_comm.h"
-
-#define PML_VERSION 101
 
 // sha256 (first 16 hex digits) over the sources this library was compiled from, handed in by pastml_amd/build.py; the
 // marker in front lets build.py read it out of the file without loading it
@@ -32,7 +13,7 @@ static const char kBuildDigest[] = "PML_BUILD_DIGEST=" PML_BUILD_DIGEST;
 
 static thread_local std::string g_last_error;
 
-static int fail(int code, const char* fmt, ...) {
+int pml_fail(int code, const char* fmt, ...) {
     char buf[1024];
     va_list ap;
     va_start(ap, fmt);
@@ -41,1297 +22,6 @@ static int fail(int code, const char* fmt, ...) {
     g_last_error = buf;
     return code;
 }
-
-#define HIP_TRY(expr)                                                                                         \
-    do {                                                                                                      \
-        hipError_t _e = (expr);                                                                               \
-        if (_e != hipSuccess)                                                                                 \
-            return fail(PML_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
-    } while (0)
-
-#define PML_TRY(expr)            \
-    do {                         \
-        int _s = (expr);         \
-        if (_s != PML_OK) return _s; \
-    } while (0)
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Every switch of the schedules in one table per context.  The defaults come from the environment (PASTML_HIP_<NAME>) when
-// the ctx is created, pml_ctx_set_tunable overrides them for that ctx -- there are no function-local statics: two contexts
-// of one process can run different schedules, and a test that sets a switch gets it (round 3 latched several of them at
-// their first use in the process).  FLAG: on when present (environment: whatever the value; set_tunable: value != 0).
-// TREE: read by pml_tree_upload / pml_chars_alloc, so it must be set before the tree is uploaded.
-// ---------------------------------------------------------------------------------------------------------------------
-#define PML_TUNABLES(X)                                                                                              \
-    X(MATRIX_R1, 1, 1) X(GRID_CAP, 0, 0) X(SMALL_MANY_NODES, 0, 0) X(BLOCK_MAX_WORK, 0, 0) X(BLOCK_MAX_STEPS, 0, 0)    \
-    X(NO_MFMA, 1, 0) X(NO_EIGEN_FUSED, 1, 0) X(NO_HKY_FUSED, 1, 0) X(NO_TD_STAGE, 1, 0) X(TD_STAGE_SCALARS, 0, 0)      \
-    X(BLOCK_THREADS, 0, 0) X(EIG_BLOCKS, 0, 0) X(NO_EIGEN_GEMM, 1, 0) X(NO_EIGEN_JOINT_VALU, 1, 0) X(EIGJ_BLOCKS, 0, 0) \
-    X(EIGJ_TIP_BLOCKS, 0, 0) X(EIGJ_ONE_TIPS_KERNEL, 1, 0) X(EIGJ_TIER_THIN, 0, 1) X(EIGJ_TIER_DEPTH, 0, 1)            \
-    X(NO_EIGJ_TIERS, 1, 1) X(NO_BT_TIERS, 1, 1) X(NO_SHAPE_SORT, 1, 1) X(NO_SUPER, 1, 1) X(SUPER_MIN, 0, 1)            \
-    X(STACK_MIN, 0, 1) X(NO_STACK, 1, 1) X(DEBUG, 1, 0) X(BLOCK_NODES, 0, 1) X(BLOCK_MAX_STORED, 0, 1)                 \
-    X(BLOCK_HEIGHT_CAP, 0, 1) X(SMALL_MAX_NODES, 0, 1) X(F81_R, 0, 1) X(F81_TD_R, 0, 1) X(NO_GRAPH, 1, 1)              \
-    X(NARROW_UNITS, 0, 0) X(NO_EIGG_TIERS, 1, 0) X(NO_ABSORB, 1, 1) X(ABSORB_MIN, 0, 1) X(NO_SPIN_WAIT, 1, 0)   \
-    X(SPLIT_PARTS, 0, 0) X(PIJ_STAGE_ROWS, 0, 0) X(PIJ_ABLATE, 0, 0) X(PIJ_BLOCKS, 0, 0) X(NO_HEIGHT_ORDER, 1, 1) X(NO_TD_TAIL, 1, 0) X(NO_PIJ_VALU, 1, 0) X(PIJ_VALU, 1, 0) X(NO_EIGJ_PIPE, 1, 0) \
-    X(THIN_UNITS, 0, 1) X(THIN_BYTES, 0, 1) X(THIN_BLOCK_NODES, 0, 1) X(NO_THIN, 1, 0) X(NO_THIN_WIDE, 1, 0) X(BU_WIDE, 0, 1) X(SORT_LEVELS, 0, 1) X(NO_WIDE_LEAN, 1, 0)
-enum PmlTunable {
-#define X(name, flag, tree) T_##name,
-    PML_TUNABLES(X)
-#undef X
-    T_COUNT
-};
-static const char* const kTunableName[T_COUNT] = {
-#define X(name, flag, tree) #name,
-    PML_TUNABLES(X)
-#undef X
-};
-static const bool kTunableFlag[T_COUNT] = {
-#define X(name, flag, tree) flag != 0,
-    PML_TUNABLES(X)
-#undef X
-};
-static const bool kTunableTree[T_COUNT] = {
-#define X(name, flag, tree) tree != 0,
-    PML_TUNABLES(X)
-#undef X
-};
-struct PmlTune {
-    long long val[T_COUNT];
-    bool has[T_COUNT];
-    PmlTune() {
-        for (int i = 0; i < T_COUNT; ++i) {
-            const std::string var = std::string("PASTML_HIP_") + kTunableName[i];
-            const char* e = getenv(var.c_str());
-            has[i] = e != nullptr;
-            val[i] = e ? atoll(e) : 0;
-        }
-    }
-    bool on(int i) const { return has[i]; }
-    long long get(int i, long long dflt) const { return has[i] ? val[i] : dflt; }
-};
-
-struct pml_ctx {
-    int device = 0;
-    PmlTune tune;  // the schedules' switches (environment at creation, pml_ctx_set_tunable)
-    hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    // kernel timing (pml_profile_*): event pairs around the level launches, read back when the profile is read -- a
-    // bracket never makes the host wait inside a sweep
-    struct ProfBracket {
-        hipEvent_t a, b;
-        int which;
-        long long launches;
-    };
-    std::vector<ProfBracket> prof_pending;
-    std::vector<hipEvent_t> prof_pool;
-    hipEvent_t prof_open = nullptr;
-    bool profile = false;
-    double prof_ms[5] = {0, 0, 0, 0, 0};  // bottom-up levels, top-down levels, per-branch pass, two-level launch TD / BU
-    long long prof_launches[5] = {0, 0, 0, 0, 0};
-    std::vector<void*> allocs;
-    size_t held = 0;
-
-    // tree
-    int N = 0, n_roots = 0, n_bu_levels = 0, n_td_levels = 0;
-    int *d_parent = nullptr, *d_first_child = nullptr, *d_n_children = nullptr, *d_post_rank = nullptr;
-    int *d_bu_order = nullptr, *d_td_parents = nullptr;
-    int* d_tips = nullptr;  // ids of the tips (the fused eigen sweeps give them a launch of their own)
-    int *d_bu_offsets = nullptr, *d_td_offsets = nullptr;  // level tables on the device (narrow end in one launch)
-    int n_tips = 0;
-    double* d_msg = nullptr;  // fused eigen sweeps: messages of the bottom-up sweep
-    int *d_tip_rest = nullptr, *d_tip_rest_count = nullptr;  // eigen joint sweep: [C][n_tips] tips that are not observed, [C]
-    double* d_dist = nullptr;
-    std::vector<int> bu_offsets, td_offsets, td_parent_offsets, h_parent, h_n_children;
-    std::vector<int> h_first_child, h_fh, h_order_f, h_tdp;  // host copies for build_thin_ends (fused heights, fused lists)
-    // Internal node numbering (height_order below): the library numbers the nodes of a ragged forest so that the sibling
-    // groups a level's units gather lie next to each other; every per-node array that crosses the C-ABI is in the CALLER's
-    // numbering and is permuted on the way in / out.  Both empty when the caller's numbering is kept (balanced trees, ...).
-    std::vector<int> new_of_old, old_of_new;
-    // cherry fusion (F81 marginal sweeps): node kinds and level lists over the stored internal nodes only
-    bool fuse = true;
-    unsigned char* d_kind = nullptr;
-    std::vector<unsigned char> h_kind;
-    int *d_bu_order_f = nullptr, *d_td_parents_f = nullptr, *d_cherries = nullptr;
-    // unit descriptors of the F81 kernels, parallel to d_bu_order_f / d_td_parents_f / d_bu_order
-    PmlUnit *d_bu_units_f = nullptr, *d_td_units_f = nullptr, *d_bu_units = nullptr, *d_cherry_units = nullptr;
-    // the same fused lists with every level's units sorted by shape (level launches of wide units, see pml_tree_upload)
-    PmlUnit *d_bu_units_fs = nullptr, *d_td_units_fs = nullptr;
-    int *d_bu_offsets_f = nullptr, *d_td_parent_offsets_f = nullptr;  // level tables for the single-launch kernels
-    // subtree blocks (pml_kernels_f81.h, bottom): the stored nodes cut into subtrees of at most PML_BLOCK_NODES stored
-    // nodes, walked by one workgroup each, and the "top" above the cuts with level tables of its own
-    struct BlockSchedule {
-        bool ok = false;
-        int n_blocks = 0;
-        long long steps = 0;  // sum over the blocks of their levels: workgroup steps of one column's sweep
-        PmlUnit *d_bu_units = nullptr, *d_td_units = nullptr;          // units of the blocks, block by block
-        int *d_bu_start = nullptr, *d_bu_levels = nullptr, *d_bu_lv = nullptr;
-        int *d_td_start = nullptr, *d_td_levels = nullptr, *d_td_lv = nullptr;
-        PmlUnit *d_top_bu_units = nullptr, *d_top_td_units = nullptr;  // units of the top part, level by level
-        int *d_top_bu_offsets = nullptr, *d_top_td_offsets = nullptr;
-        std::vector<int> top_bu_offsets, top_td_offsets;               // host copies (launch geometry)
-        std::vector<char> top_bu_vec;                                   // per top level: stored node among children 0, 1
-    } blocks;
-    // Thin ends of a large ragged forest, units of fewer than 8 lanes (round 5).  Bottom-up: the fused levels from
-    // floor_level on (each of at most PASTML_HIP_THIN_UNITS units) in tiers of subtree blocks, like `blocks` but of that
-    // part of the forest only and with several small subtrees per workgroup; the wide levels below stay level launches.
-    struct ThinSchedule {
-        bool ok = false;
-        int floor_level = 0;  // the fused levels below stay level launches
-        int top_level = 0;    // ... and from this one on they are the narrow end's (level launches where still wide)
-        struct Tier { int first_block, n_blocks; };
-        std::vector<Tier> tiers;   // runs of levels, each cut into subtrees of at most THIN_BLOCK_NODES units: a launch per tier
-        PmlUnit* d_units = nullptr;
-        int *d_start = nullptr, *d_levels = nullptr, *d_lv = nullptr;
-    } thin;
-    // Top-down: the depths from first_depth on (each of at most THIN_UNITS parents): the subtrees hanging at first_depth,
-    // packed into bins of about THIN_BLOCK_NODES units, ONE launch walks them all, a workgroup per (bin, column).
-    struct DeepSchedule {
-        bool ok = false;
-        int first_depth = 0, n_blocks = 0;
-        PmlUnit* d_units = nullptr;
-        int *d_start = nullptr, *d_levels = nullptr, *d_lv = nullptr;
-    } deep;
-    // two-level units (pml_kernels_f81.h): nodes with two stored children that each carry two cherries of two tips run
-    // both levels in one unit; they and their children leave the level lists ("rest" lists, same level structure)
-    struct SuperSchedule {
-        bool ok = false;
-        int n = 0;
-        PmlUnit* d_units = nullptr;
-        PmlUnit* d_child_units = nullptr;  // the 2 n children of the two-level units, as units of their own (downloads)
-        PmlUnit *d_bu_units_r = nullptr, *d_td_units_r = nullptr;
-        PmlUnit *d_bu_units_rs = nullptr, *d_td_units_rs = nullptr;  // ... sorted by shape inside every level
-        // stacked units (pml_kernels_f81.h): nodes with two plain stored children of two stored children each, by
-        // bottom-up level and by depth; their children as units of their own for downloads
-        int n_child_units = 0;  // entries of d_child_units: the children of the two-level units + the absorbed nodes below
-        // general two-level units (pml_kernels_f81.h, round 4): stored nodes whose children are tips and cherries are
-        // absorbed by their parents, whatever the shapes.  Bottom-up: the absorbing nodes by level, three records each;
-        // top-down: one record per absorbed node (pad = the parent), all in one launch
-        int n_absorbing = 0, n_absorbed = 0;
-        PmlUnit *d_absorb_bu = nullptr, *d_absorb_td = nullptr;
-        PmlUnit* d_absorbing_td = nullptr;  // the absorbing nodes' own top-down records (those with tips / cherries to finish)
-        int n_absorbing_td = 0;
-        std::vector<int> absorb_bu_offsets;
-        int n_stack = 0;
-        PmlUnit *d_stack_bu = nullptr, *d_stack_td = nullptr, *d_stack_children = nullptr;
-        std::vector<int> stack_bu_offsets, stack_td_offsets;
-        int *d_bu_offsets_r = nullptr, *d_td_offsets_r = nullptr;
-        std::vector<int> bu_offsets_r, td_offsets_r;
-        std::vector<char> bu_level_vec_r;
-    } sup;
-    // Joint sweep of the eigen models: the thin levels of a large forest (runs of levels of at most 4 096 nodes) in tiers
-    // of four levels; a tier is cut into subtree blocks and ONE launch walks them, a workgroup per (block, column) with a
-    // workgroup barrier between its levels -- a level costs a ~3.5 us pass instead of a ~7.5 us dependent launch.
-    struct EigenTiers {
-        bool ok = false;
-        int first_level = 0;   // plain bottom-up level the first tier starts at
-        int top_level = 0;     // ... and the level from which the single-workgroup launch takes over
-        struct Tier { int first_block, n_blocks, depth; };
-        std::vector<Tier> tiers;
-        PmlUnit* d_units = nullptr;
-        int *d_lv = nullptr, *d_start = nullptr;
-        int* d_nodes = nullptr;  // the node ids parallel to d_units (the sum sweeps walk node lists)
-        int widest = 0;        // nodes of the widest level inside the tiers
-    } eig_tiers;
-    // joint back-trace: the depths beyond its single-workgroup launch in tiers of subtrees (joint_backtrace_blocks_kernel)
-    struct BacktraceTiers {
-        bool ok = false;
-        int first_depth = 0;  // depths 1 .. first_depth - 1 stay with the single-workgroup launch
-        struct Tier { int first_block, n_blocks, depth; };
-        std::vector<Tier> tiers;
-        int *d_nodes = nullptr, *d_lv = nullptr, *d_start = nullptr;
-    } bt_tiers;
-    bool small = false;  // forest small enough for the one-launch-per-sweep kernels
-    bool levels_fit_workgroup = false;  // (nearly) every fused level is one pass of a 512-thread workgroup
-    std::vector<int> bu_offsets_f, td_parent_offsets_f;
-    std::vector<char> bu_level_vec_f;  // per fused bottom-up level: some unit has a stored node as child 0 or 1
-    std::vector<int> td_cherry_prefix; // over the fused top-down units: how many before it have a cherry as child 0 or 1
-    std::vector<char> bu_level_vec;    // the same for the plain levels (joint sweep: every internal node is stored)
-    int n_cherries = 0;
-    bool bu_fused = false;  // the last bottom-up sweep left the cherries unmaterialised
-    bool bu_absorbed = false;  // ... and the children of the two-level units
-    bool bu_fused_joint = false;  // ... and it was a joint sweep
-
-    // columns
-    int C = 0, k = 0, ks = 0, W = 0, G = 0, R = 0;
-    int Gf = 0, Rf = 0;  // lane-group shape of the F81-family bottom-up kernels (chunked state ownership)
-    bool bu_wide_lanes = false;  // 32 < k <= 64: most bottom-up levels run with 8 states per lane (see dispatch_sweep)
-    bool level_lists_sorted = false;  // 32 < k <= 64: the level launches walk the lists sorted by shape (pml_tree_upload)
-    int Gt = 0, Rt = 0;  // ... and of the F81-family top-down kernels
-    u64 *d_masks = nullptr, *d_masks_init = nullptr;
-    bool has_init = false;
-    int kind = -1;
-    double *d_pi = nullptr, *d_mu = nullptr, *d_kappa = nullptr, *d_d = nullptr, *d_A = nullptr, *d_Ainv = nullptr;
-    double* d_active = nullptr;   // last array of the parameter block: 0.0 = the column sits the next bottom-up sweep out
-    bool active_partial = false;  // ... some column does (pml_bottom_up_submit_columns)
-    bool in_bu_enqueue = false;   // the launches being enqueued are a bottom-up sweep's: they look at the flags
-    int n_active = 0;             // columns that take part in the next sweep
-    int sched_cols = 0;           // the number of columns the schedule of a sweep is chosen for (C; 32 for a few active ones)
-    bool bu_signals_few = false;
-    double* d_AinvT = nullptr;  // [C][32][32]: Ainv transposed and zero-padded (k <= 32), for eigen_joint_kernel
-    double* d_AT = nullptr;     // [C][32][32]: A transposed and zero-padded (k <= 32), for pij_eigen_valu_kernel
-    double *d_sf = nullptr, *d_tau = nullptr, *d_tauf = nullptr;
-    std::vector<char> model_set;  // per column
-    std::vector<char> tips_observed;  // per column: every tip has exactly one allowed state (known from pml_masks_from_tip_states)
-    bool prep_dirty = true;
-
-    // state
-    double *d_E = nullptr, *d_P = nullptr, *d_bu = nullptr, *d_S = nullptr, *d_td = nullptr, *d_post = nullptr,
-           *d_lhsum = nullptr;
-    i64 *d_be = nullptr, *d_te = nullptr, *d_lhe = nullptr;
-    pml_jt* d_J = nullptr;  // arg-max tables, one byte per entry
-    int* d_js = nullptr;
-    u64* d_err = nullptr;
-    int bu_mode = -1;  // -1 invalid, 1 marginal, 0 joint
-    bool js_ever = false;  // joint states of some earlier joint sweep are still in d_js
-    bool post_ever = false;  // posteriors of some earlier top-down sweep are still in d_post
-    int* d_nsel = nullptr;
-    // hipGraph replay of the launch sequence of a sweep (level kernels are launch-bound on mid-size trees)
-    struct GraphSlot {
-        hipGraph_t graph = nullptr;
-        hipGraphExec_t exec = nullptr;
-        bool has_init = false;
-        bool has_params = false;  // the captured sequence starts with the copy of the parameter block (params_push)
-    };
-    bool capture_saw_params = false;
-    GraphSlot bu_graph[2], td_graph, bt_graph;
-    GraphSlot bu_graph_few;        // the marginal sweep as scheduled for a few active columns (submit_bottom_up)
-    GraphSlot mp_graph;            // bottom-up + top-down of pml_marginal_pass as ONE graph
-    bool in_outer_capture = false; // the sweeps are being captured into mp_graph: no graphs of their own
-    bool graphs = true;
-    double* h_loglik = nullptr;  // pinned staging of the per-column results
-    // pi, sf, tau, tau factor, mu, kappa of all columns live in ONE device block with a pinned host mirror of the same
-    // layout: a parameter update (every optimiser step) is one asynchronous copy and no synchronisation
-    double *d_params = nullptr, *h_params = nullptr;
-    bool params_dirty = false;  // the pinned mirror holds values the device block has not seen (params_push sends them)
-    bool capturing = false;     // a sweep's launch sequence is being captured into a graph
-    size_t n_params = 0;
-    u64* h_err = nullptr;
-    // completion of a bottom-up sweep whose last launch is the single-workgroup-per-column kernel: that kernel raises a
-    // word in pinned memory when its last column is done (bu_f81_small_kernel), and the collect spins on it
-    u64* h_done = nullptr;      // pinned: generation of the last finished launch
-    u64* d_done = nullptr;      // device: [0] columns done in the running launch, [1] generation
-    u64 done_expect = 0;        // what *h_done shows when the sweep submitted last has finished
-    bool enqueue_signals = false;          // set by the launcher while a sweep is enqueued
-    bool bu_signals[2] = {false, false};   // per captured sweep (joint / marginal): its last launch signals
-    bool wait_signal = false;              // the sweep submitted last signals
-    // the same for a whole marginal pass: its last top-down launch signals where the schedule ends in a multi-level
-    // kernel (single-launch sweeps, subtree blocks); signals_enqueued counts the signalling launches of what is being
-    // enqueued (the bottom-up sweep's and the top-down sweep's), mp_signals / mp_final keep them for the captured pass
-    bool signal_next_td = false, td_final_signals = false, mp_final = false, mp_wants_signal = false;
-    int signals_enqueued = 0, mp_signals = 0;
-    bool td_valid = false, js_valid = false;
-    bool keep_td = false;      // PML_OPT_KEEP_TD (or a pml_download of the TD vectors asked for them)
-    bool td_vec_valid = false; // the TD vectors of the last top-down sweep are in d_td
-    bool td_filled = false;    // ... including those of the nodes the sweeps do not store (td_fill_kernel)
-    bool eig_fused_opt = true; // PML_OPT_EIGEN_FUSED
-    bool eigj_valu_opt = true; // PML_OPT_EIGEN_JOINT_VALU
-    bool implicit_tips = false;    // PML_OPT_IMPLICIT_TIP_POSTERIORS
-    bool tip_post_missing = false; // the last top-down sweep left the observed tips' posteriors implicit
-    const PmlUnit* units_override = nullptr;  // set around a dispatch_sweep on the block schedule's top lists
-
-    PmlComm* comm = nullptr;   // RCCL communicator attached by pml_comm_init (survives tree uploads)
-
-    // marginal pass of a large forest in parts of its columns on two streams (split_marginal_pass): the second stream, the
-    // events that chain the parts, and the flag that says the launches being enqueued see a window of the columns
-    hipStream_t stream2 = nullptr;
-    std::vector<hipEvent_t> split_ev;
-    bool windowed = false;
-};
-
-// ---------------------------------------------------------------------------------------------------------------------
-template <typename T>
-static int dev_alloc(pml_ctx* ctx, T** p, size_t count) {
-    *p = nullptr;
-    if (count == 0) count = 1;
-    void* q = nullptr;
-    hipError_t e = hipMalloc(&q, count * sizeof(T));
-    if (e != hipSuccess)
-        return fail(PML_ERR_HIP, "hipMalloc of %zu bytes failed: %s", count * sizeof(T), hipGetErrorString(e));
-    ctx->allocs.push_back(q);
-    ctx->held += count * sizeof(T);
-    *p = (T*)q;
-    return PML_OK;
-}
-
-static void drop_graph(pml_ctx::GraphSlot& g) {
-    if (g.exec) (void)hipGraphExecDestroy(g.exec);
-    if (g.graph) (void)hipGraphDestroy(g.graph);
-    g.exec = nullptr;
-    g.graph = nullptr;
-}
-
-// every captured launch sequence of the two sweeps (the back-trace's graph depends on the tree and the tunables only)
-static void drop_sweep_graphs(pml_ctx* ctx) {
-    drop_graph(ctx->bu_graph[0]);
-    drop_graph(ctx->bu_graph[1]);
-    drop_graph(ctx->bu_graph_few);
-    drop_graph(ctx->td_graph);
-    drop_graph(ctx->mp_graph);
-}
-
-static void free_all(pml_ctx* ctx) {
-    drop_sweep_graphs(ctx);
-    drop_graph(ctx->bt_graph);
-    if (ctx->h_loglik) (void)hipHostFree(ctx->h_loglik);
-    if (ctx->h_err) (void)hipHostFree(ctx->h_err);
-    if (ctx->h_done) (void)hipHostFree(ctx->h_done);
-    ctx->h_done = nullptr;
-    if (ctx->h_params) (void)hipHostFree(ctx->h_params);
-    ctx->h_params = nullptr;
-    ctx->h_loglik = nullptr;
-    ctx->h_err = nullptr;
-    for (void* p : ctx->allocs) (void)hipFree(p);
-    ctx->allocs.clear();
-    ctx->held = 0;
-}
-
-template <typename T>
-static int upload(pml_ctx* ctx, T* dst, const T* src, size_t count) {
-    HIP_TRY(hipMemcpyAsync(dst, src, count * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
-    return PML_OK;
-}
-
-static void pick_group(const pml_ctx* ctx, int k, int& G, int& R) {
-    R = k <= 32 ? 1 : (k <= 128 ? 2 : 4);
-    if (k > 16 && k <= 32 && !ctx->tune.on(T_MATRIX_R1)) R = 4;  // 8 lanes per unit: 8 units per wavefront
-    const int need = (k + R - 1) / R;
-    G = 1;
-    while (G < need) G <<= 1;
-}
-
-// Blocks along x for a level of n_units units per column (grid-stride loops take the rest).  The cap on the total
-// number of blocks was measured on cfg4 (MI355X): the pipelined bottom-up kernels like ~8192 (a wave then walks several
-// units and its prefetch stage pays off), everything else 32768; persistent-size grids (768-2048) were 5-15 % slower.
-static int grid_for(const pml_ctx* ctx, int n_units, int units_per_block, int C, bool pipelined = false) {
-    int blocks = (n_units + units_per_block - 1) / units_per_block;
-    const int cap_env = (int)ctx->tune.get(T_GRID_CAP, 0);
-    const int total_cap = cap_env > 0 ? cap_env : (pipelined ? 8192 : 32768);
-    int cap = total_cap / (C < 1 ? 1 : C);
-    if (cap < 8) cap = 8;
-    if (blocks > cap) blocks = cap;
-    if (blocks < 1) blocks = 1;
-    return blocks;
-}
-
-// Whole F81 sweeps in ONE launch (one workgroup per column walks every level): forests of up to
-// PASTML_HIP_SMALL_MAX_NODES (2048) nodes, where a sweep is otherwise a chain of latency-bound launches -- and, when
-// there are many columns (the optimiser's batches: one workgroup per column already fills the chip), forests of up to
-// PASTML_HIP_SMALL_MANY_NODES (16384) nodes whose levels each fit one pass of a workgroup (deep, ragged trees:
-// HIV1C-sized sweeps -- 7 237 nodes, 57 height levels -- of 246 binary columns 0.34 -> 0.27 ms; a balanced 4 096-tip
-// tree with 20 states has levels of 16 passes and stays with the level kernels: 0.12 against 0.27 ms).  Same unit
-// functions and lane shapes as the level kernels: identical bits.
-static bool single_launch_sweeps(const pml_ctx* c) {
-    const int many = (int)c->tune.get(T_SMALL_MANY_NODES, 16384);
-    return c->small || (c->sched_cols >= 64 && c->N <= many && c->levels_fit_workgroup);
-}
-
-// The subtree-block schedule pays where a sweep is a chain of latency-bound launches; once the levels carry enough work
-// to fill the chip (stored nodes x columns beyond ~1.6e5: measured on 16 384 - 131 072-tip trees with 1 - 32 columns)
-// the level kernels, which spread every level over all compute units, win again.
-static bool block_schedule(const pml_ctx* c) {
-    const long long limit = c->tune.get(T_BLOCK_MAX_WORK, 160000);
-    // (Round 2 also capped the number of (block, level, column) workgroup steps: with 512-thread workgroups a ragged tree
-    // times many columns ran in rounds of long-lived workgroups and lost to the level kernels.  The workgroups now
-    // shrink until all are resident (launch_blocks_f81) and the blocks end below the top's lowest level
-    // (pml_tree_upload): over scripts/schedule_sweep.py's grid the blocks never lose -- profiles/r03c_schedule_sweep.txt.
-    // PASTML_HIP_BLOCK_MAX_STEPS is kept as a switch.)
-    const long long steps = c->tune.get(T_BLOCK_MAX_STEPS, 1ll << 40);
-    return c->blocks.ok && !c->bu_offsets_f.empty() && (long long)c->bu_offsets_f.back() * c->sched_cols <= limit &&
-           c->blocks.steps * c->sched_cols <= steps;
-}
-
-static PmlTree tree_of(const pml_ctx* c, bool fused = false) {
-    PmlTree t;
-    t.kind = fused ? c->d_kind : nullptr;
-    t.N = c->N;
-    t.n_roots = c->n_roots;
-    t.parent = c->d_parent;
-    t.first_child = c->d_first_child;
-    t.n_children = c->d_n_children;
-    t.dist = c->d_dist;
-    t.post_rank = c->d_post_rank;
-    return t;
-}
-
-static PmlCols cols_of(const pml_ctx* c) {
-    PmlCols s;
-    s.k = c->k;
-    s.ks = c->ks;
-    s.W = c->W;
-    s.no_wide_lean = c->tune.on(T_NO_WIDE_LEAN) ? 1 : 0;
-    s.masks = c->d_masks;
-    s.masks_init = c->has_init ? c->d_masks_init : nullptr;
-    s.pi = c->d_pi;
-    s.active = c->in_bu_enqueue ? c->d_active : nullptr;  // (only the sweep itself: downloads rebuild what they need for all)
-    return s;
-}
-
-static PmlState state_of(const pml_ctx* c) {
-    PmlState s;
-    s.E = c->d_E;
-    s.bu = c->d_bu;
-    s.S = c->d_S;
-    s.be = c->d_be;
-    // F81 family: the top-down sweep runs on the stored posteriors; TD vectors are written only on request
-    const bool td_stored = c->kind != PML_MODEL_F81 || c->keep_td;
-    s.td = td_stored ? c->d_td : nullptr;
-    s.te = td_stored ? c->d_te : nullptr;
-    s.post = c->d_post;
-    s.implicit_tips = c->implicit_tips && c->kind == PML_MODEL_F81 && c->W == 1;
-    s.lhsum = c->d_lhsum;
-    s.lhe = c->d_lhe;
-    s.J = c->d_J;
-    s.js = c->d_js;
-    s.err = c->d_err;
-    s.msg = c->d_msg;
-    return s;
-}
-
-// Eigen models with 16 <= k <= 32 run the fused matrix-core sweeps (pml_kernels_eigen_mfma.h): P(t) is built and
-// consumed in registers.  PASTML_HIP_NO_MFMA / PASTML_HIP_NO_EIGEN_FUSED fall back to the materialised-P kernels.
-static bool eigen_fused(const pml_ctx* c) {
-    const bool off = c->tune.on(T_NO_MFMA) || c->tune.on(T_NO_EIGEN_FUSED);
-    return !off && c->eig_fused_opt && c->kind == PML_MODEL_EIGEN && c->k >= 16 && c->k <= 32 && c->W == 1 &&
-           c->ks == 4 * ((c->k + 3) / 4);
-}
-
-// HKY sweeps build P(t) in registers (pml_kernels_matrix.h, PML_P_HKY); PASTML_HIP_NO_HKY_FUSED reads the batch.
-static bool hky_fused(const pml_ctx* c) {
-    const bool off = c->tune.on(T_NO_HKY_FUSED);
-    return !off && c->kind == PML_MODEL_HKY && c->k == 4 && c->ks == 4 && c->G == 4 && c->R == 1 && c->W == 1;
-}
-
-static PmlModel model_of(const pml_ctx* c) {
-    PmlModel m;
-    m.kind = c->kind;
-    m.mu = c->d_mu;
-    m.kappa = c->d_kappa;
-    m.d = c->d_d;
-    m.A = c->d_A;
-    m.Ainv = c->d_Ainv;
-    m.sf = c->d_sf;
-    m.tau = c->d_tau;
-    m.tauf = c->d_tauf;
-    return m;
-}
-
-static int prof_event(pml_ctx* ctx, hipEvent_t* out) {
-    if (!ctx->prof_pool.empty()) {
-        *out = ctx->prof_pool.back();
-        ctx->prof_pool.pop_back();
-        return PML_OK;
-    }
-    HIP_TRY(hipEventCreate(out));
-    return PML_OK;
-}
-
-// adds up the brackets recorded so far (waits for the stream) and returns their events to the pool
-static int prof_drain(pml_ctx* ctx) {
-    if (ctx->prof_pending.empty()) return PML_OK;
-    HIP_TRY(hipSetDevice(ctx->device));
-    for (const pml_ctx::ProfBracket& br : ctx->prof_pending) {
-        float ms = 0.f;
-        HIP_TRY(hipEventSynchronize(br.b));  // (the brackets of a split pass lie on two streams)
-        HIP_TRY(hipEventElapsedTime(&ms, br.a, br.b));
-        ctx->prof_ms[br.which] += ms;
-        ctx->prof_launches[br.which] += br.launches;
-        ctx->prof_pool.push_back(br.a);
-        ctx->prof_pool.push_back(br.b);
-    }
-    ctx->prof_pending.clear();
-    return PML_OK;
-}
-
-static void prof_release(pml_ctx* ctx) {
-    for (const pml_ctx::ProfBracket& br : ctx->prof_pending) {
-        (void)hipEventDestroy(br.a);
-        (void)hipEventDestroy(br.b);
-    }
-    for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
-    if (ctx->prof_open) (void)hipEventDestroy(ctx->prof_open);
-    ctx->prof_pending.clear();
-    ctx->prof_pool.clear();
-    ctx->prof_open = nullptr;
-}
-
-static int prof_begin(pml_ctx* ctx) {
-    if (!ctx->profile) return PML_OK;
-    if (!ctx->prof_open) PML_TRY(prof_event(ctx, &ctx->prof_open));
-    HIP_TRY(hipEventRecord(ctx->prof_open, ctx->stream));
-    return PML_OK;
-}
-
-static int prof_end(pml_ctx* ctx, int which, long long launches) {
-    if (!ctx->profile || !ctx->prof_open) return PML_OK;
-    hipEvent_t b = nullptr;
-    PML_TRY(prof_event(ctx, &b));
-    HIP_TRY(hipEventRecord(b, ctx->stream));
-    ctx->prof_pending.push_back({ctx->prof_open, b, which, launches});
-    ctx->prof_open = nullptr;
-    if (ctx->prof_pending.size() >= 4096) PML_TRY(prof_drain(ctx));  // (bounds the number of live events)
-    return PML_OK;
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// (G, R) dispatch
-// ---------------------------------------------------------------------------------------------------------------------
-#define PML_GR_CASES(X)  \
-    X(8, 4)              \
-    X(1, 1)              \
-    X(2, 1)              \
-    X(4, 1)              \
-    X(8, 1)              \
-    X(16, 1)             \
-    X(32, 1)             \
-    X(64, 1)             \
-    X(32, 2)             \
-    X(64, 2)             \
-    X(64, 4)
-
-enum SweepKind {
-    SW_BU_MARG, SW_BU_JOINT, SW_TD, SW_ROOTS, SW_BU_MARG_FUSED, SW_TD_FUSED, SW_BU_CHERRIES,
-    SW_BU_MARG_FUSED_NOVEC,  // a fused level none of whose units has a stored node among its first two children
-    SW_BU_JOINT_NOVEC,       // the same for a level of the joint sweep (the level whose children are all tips)
-    SW_BU_JOINT_FUSED, SW_BU_JOINT_FUSED_NOVEC,  // joint sweep over the cherry-fused level lists
-    SW_BU_CHERRIES_JOINT     // materialises the cherries' vectors after a fused joint sweep
-};
-
-// matrix-model sweeps: contiguous state ownership (state = g * R + r)
-template <int G, int R>
-static void launch_sweep(pml_ctx* ctx, SweepKind what, const int* level, int n_level) {
-    const PmlTree t = tree_of(ctx, false);
-    const PmlCols c = cols_of(ctx);
-    const PmlState st = state_of(ctx);
-    const int upb = PML_WAVES_PER_BLOCK * (64 / G);
-    dim3 grid(grid_for(ctx, n_level, upb, ctx->C), ctx->C), block(PML_BLOCK);
-    const PmlModel m = model_of(ctx);
-    if (G == 4 && R == 1 && hky_fused(ctx)) {  // HKY: P(t) from the closed form, in registers (no batch in HBM)
-        constexpr int GG = G == 4 ? 4 : 4, RR = R == 1 ? 1 : 1;  // (keeps the other shapes from instantiating it)
-        switch (what) {
-            case SW_BU_MARG:
-                hipLaunchKernelGGL((bu_matrix_kernel<GG, RR, false, PML_P_HKY>), grid, block, 0, ctx->stream, t, c, st,
-                                   nullptr, m, level, n_level);
-                return;
-            case SW_BU_JOINT:
-                hipLaunchKernelGGL((bu_matrix_kernel<GG, RR, true, PML_P_HKY>), grid, block, 0, ctx->stream, t, c, st,
-                                   nullptr, m, level, n_level);
-                return;
-            case SW_TD:
-                hipLaunchKernelGGL((td_matrix_kernel<GG, RR, PML_P_HKY>), grid, block, 0, ctx->stream, t, c, st, nullptr,
-                                   m, level, n_level);
-                return;
-            default:
-                break;
-        }
-    }
-    switch (what) {
-        case SW_BU_MARG:
-            hipLaunchKernelGGL((bu_matrix_kernel<G, R, false>), grid, block, 0, ctx->stream, t, c, st, ctx->d_P, m, level,
-                               n_level);
-            break;
-        case SW_BU_JOINT:
-            hipLaunchKernelGGL((bu_matrix_kernel<G, R, true>), grid, block, 0, ctx->stream, t, c, st, ctx->d_P, m, level,
-                               n_level);
-            break;
-        case SW_TD:
-            hipLaunchKernelGGL((td_matrix_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, ctx->d_P, m, level,
-                               n_level);
-            break;
-        case SW_ROOTS:
-            hipLaunchKernelGGL((td_roots_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st);
-            break;
-        default:
-            break;
-    }
-}
-
-// F81-family sweeps: chunked state ownership (pml_kernels_f81.h), their own (G, R)
-template <int G, int R>
-static void launch_sweep_f81(pml_ctx* ctx, SweepKind what, const int* level, int n_level) {
-    const bool fused_lists = what == SW_BU_MARG_FUSED || what == SW_BU_MARG_FUSED_NOVEC ||
-                             what == SW_BU_JOINT_FUSED || what == SW_BU_JOINT_FUSED_NOVEC;
-    const PmlTree t = tree_of(ctx, fused_lists || what == SW_TD_FUSED);
-    const PmlCols c = cols_of(ctx);
-    const PmlState st = state_of(ctx);
-    const int upb = PML_WAVES_PER_BLOCK * (64 / G);
-    const bool pipelined = fused_lists || what == SW_BU_MARG || what == SW_BU_CHERRIES || what == SW_BU_JOINT ||
-                           what == SW_BU_JOINT_NOVEC || what == SW_BU_CHERRIES_JOINT;
-    dim3 grid(grid_for(ctx, n_level, upb, ctx->C, pipelined), ctx->C), block(PML_BLOCK);
-    // the level is given as a position in one of the node lists; the kernels read the descriptor list parallel to it
-    const PmlUnit* units = nullptr;
-    // (level launches of wide units walk the lists sorted by shape, pml_tree_upload)
-    const bool sorted = ctx->level_lists_sorted && ctx->d_bu_units_fs != nullptr;
-    if (fused_lists) units = ctx->d_bu_units_f + (level - ctx->d_bu_order_f);
-    if (sorted && (what == SW_BU_MARG_FUSED || what == SW_BU_MARG_FUSED_NOVEC))
-        units = ctx->d_bu_units_fs + (level - ctx->d_bu_order_f);
-    if (what == SW_BU_MARG || what == SW_BU_JOINT || what == SW_BU_JOINT_NOVEC)
-        units = ctx->d_bu_units + (level - ctx->d_bu_order);
-    if (what == SW_TD_FUSED) units = (sorted ? ctx->d_td_units_fs : ctx->d_td_units_f) + (level - ctx->d_td_parents_f);
-    if (what == SW_BU_CHERRIES || what == SW_BU_CHERRIES_JOINT) units = ctx->d_cherry_units + (level - ctx->d_cherries);
-    if (ctx->units_override != nullptr) units = ctx->units_override;  // a level of the block schedule's top part
-    switch (what) {
-        case SW_BU_MARG_FUSED:
-        case SW_BU_MARG:
-            hipLaunchKernelGGL((bu_f81_kernel<G, R, false, true>), grid, block, 0, ctx->stream, t, c, st, units,
-                               n_level);
-            break;
-        case SW_BU_MARG_FUSED_NOVEC:
-        case SW_BU_CHERRIES:
-            hipLaunchKernelGGL((bu_f81_kernel<G, R, false, false>), grid, block, 0, ctx->stream, t, c, st, units,
-                               n_level);
-            break;
-        case SW_BU_JOINT:
-        case SW_BU_JOINT_FUSED:
-            hipLaunchKernelGGL((bu_f81_kernel<G, R, true, true>), grid, block, 0, ctx->stream, t, c, st, units,
-                               n_level);
-            break;
-        case SW_BU_JOINT_NOVEC:
-        case SW_BU_JOINT_FUSED_NOVEC:
-        case SW_BU_CHERRIES_JOINT:
-            hipLaunchKernelGGL((bu_f81_kernel<G, R, true, false>), grid, block, 0, ctx->stream, t, c, st, units,
-                               n_level);
-            break;
-        case SW_TD_FUSED: {
-            // units narrower than 8 lanes stage their posterior rows in LDS (pml_kernels_f81.h, post_row / post_onehot)
-            const bool no_stage = ctx->tune.on(T_NO_TD_STAGE);
-            const int scal_env = (int)ctx->tune.get(T_TD_STAGE_SCALARS, -1);
-            int stage = 0;
-            size_t lds = 0;
-            // (measured, 262 144 tips x 32 columns: k = 2 0.59 -> 0.39 ms, k = 4 0.68 -> 0.45, k = 8 0.83 -> 0.71; with four
-            // lanes per unit, k = 12 / 16, a loss of 5 - 10 %)
-            if (G <= PML_TD_STAGE_MAX_G && !no_stage && (c.ks & 1) == 0) {
-                const bool scalars = scal_env >= 0 ? scal_env != 0 : true;
-                stage = scalars ? 3 : 1;
-                // bit 2: some unit of the level has a cherry among its first two children (tip slots in use)
-                bool cherries = true;
-                if (ctx->units_override == nullptr && !ctx->td_cherry_prefix.empty()) {
-                    const size_t a = (size_t)(level - ctx->d_td_parents_f), b = a + (size_t)n_level;
-                    if (b < ctx->td_cherry_prefix.size()) cherries = ctx->td_cherry_prefix[b] != ctx->td_cherry_prefix[a];
-                }
-                if (cherries) stage |= 4;
-                lds = (size_t)PML_WAVES_PER_BLOCK * td_stage_doubles(64 / G, c.ks, scalars) * sizeof(double);
-            }
-            hipLaunchKernelGGL((td_f81_kernel<G, R>), grid, block, lds, ctx->stream, t, c, st, units, n_level, stage);
-            break;
-        }
-        case SW_ROOTS:
-            hipLaunchKernelGGL((td_f81_roots_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st);
-            break;
-        default:
-            break;
-    }
-}
-
-// Single-workgroup-per-column launch over a range of levels: the whole sweep of a small forest, or the narrow end of
-// a large one (bottom-up: levels first_level .. end, then ln L; top-down: roots, then levels 0 .. n_levels - 1).
-template <int G, int R>
-static void launch_small_f81(pml_ctx* ctx, bool bottom_up, int do_prep, const PmlUnit* units, const int* d_offsets,
-                             int n_levels, int reset_err, int skip_roots) {
-    const PmlTree t = tree_of(ctx, true);
-    const PmlCols c = cols_of(ctx);
-    const PmlState st = state_of(ctx);
-    dim3 grid(1, ctx->C), block(PML_SMALL_BLOCK);
-    if (bottom_up) {
-        // The completion word (bu_f81_small_kernel, wait_bottom_up) for sweeps of few columns, where the host's wait is
-        // a tenth of the sweep (HIV1C tree, k = 12: 14 columns 0.1265 -> 0.1127 ms per sweep; at 128 columns the
-        // system-scope fences in 128 workgroups cost what the spin saves: 0.203 against 0.207 ms)
-        const bool signal = ctx->sched_cols <= 64 && !ctx->windowed && !ctx->tune.on(T_NO_SPIN_WAIT);
-        hipLaunchKernelGGL((bu_f81_small_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, ctx->d_mu, ctx->d_sf,
-                           ctx->d_tau, ctx->d_tauf, do_prep, units, d_offsets, n_levels, ctx->h_loglik, ctx->h_err,
-                           reset_err, signal ? ctx->d_done : nullptr, signal ? ctx->h_done : nullptr);
-        ctx->enqueue_signals = signal;  // (the last launch of a bottom-up sweep whenever it is part of one)
-        if (signal) ++ctx->signals_enqueued;
-    } else {
-        const bool signal = ctx->signal_next_td && ctx->C <= 64 && !ctx->windowed && !ctx->tune.on(T_NO_SPIN_WAIT);
-        ctx->signal_next_td = false;
-        hipLaunchKernelGGL((td_f81_small_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, units, d_offsets,
-                           n_levels, signal ? ctx->d_done : nullptr, signal ? ctx->h_done : nullptr, skip_roots);
-        ctx->td_final_signals = signal;
-        if (signal) ++ctx->signals_enqueued;
-    }
-}
-
-// one workgroup per (subtree block, column) walks the block's levels (pml_kernels_f81.h, bottom)
-// (the tables of one launch: `blocks`, or the thin ends of a large forest -- `thin` bottom-up, `deep` top-down)
-struct BlockTables {
-    const PmlUnit* units;
-    const int *start, *levels, *lv;
-    int n_blocks;
-};
-static BlockTables block_tables(const pml_ctx* ctx, bool bottom_up, int which) {
-    if (which >= 1) {   // (bottom-up: tier which - 1 of the thin levels)
-        if (bottom_up) {
-            const pml_ctx::ThinSchedule::Tier& T = ctx->thin.tiers[which - 1];
-            return {ctx->thin.d_units, ctx->thin.d_start + T.first_block, ctx->thin.d_levels + T.first_block, ctx->thin.d_lv, T.n_blocks};
-        }
-        return {ctx->deep.d_units, ctx->deep.d_start, ctx->deep.d_levels, ctx->deep.d_lv, ctx->deep.n_blocks};
-    }
-    const pml_ctx::BlockSchedule& B = ctx->blocks;
-    if (bottom_up) return {B.d_bu_units, B.d_bu_start, B.d_bu_levels, B.d_bu_lv, B.n_blocks};
-    return {B.d_td_units, B.d_td_start, B.d_td_levels, B.d_td_lv, B.n_blocks};
-}
-
-template <int G, int R>
-static void launch_blocks_f81(pml_ctx* ctx, bool bottom_up, int which) {
-    const PmlTree t = tree_of(ctx, true);
-    const PmlCols c = cols_of(ctx);
-    const PmlState st = state_of(ctx);
-    const BlockTables B = block_tables(ctx, bottom_up, which);
-    // Workgroup size: 512 threads while every (block, column) workgroup is resident at once; with more workgroups than
-    // the chip holds the launch runs in rounds of long-lived workgroups (HIV1C x 14 columns: 980 workgroups of 8 waves,
-    // one per CU at 3 waves per SIMD -> four rounds, 97 us for blocks of <= 24 level steps), so the workgroups shrink
-    // until they all fit: a thin level needs one or two waves, wider ones take more passes (walk_levels).
-    static int waves_per_cu[2] = {0, 0}, n_cus = 0;
-    if (n_cus == 0) {
-        hipDeviceProp_t prop;
-        n_cus = hipGetDeviceProperties(&prop, ctx->device) == hipSuccess ? prop.multiProcessorCount : 256;
-    }
-    int& wpc = waves_per_cu[bottom_up ? 1 : 0];
-    if (wpc == 0) {
-        int nb = 0;
-        const hipError_t e = bottom_up
-            ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, bu_f81_blocks_kernel<G, R>, 64, 0)
-            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, td_f81_blocks_kernel<G, R>, 64, 0);
-        wpc = (e == hipSuccess && nb > 0) ? nb : 8;
-    }
-    const int forced = (int)ctx->tune.get(T_BLOCK_THREADS, 0);
-    int threads = PML_SMALL_BLOCK;
-    const long long n_wg = (long long)B.n_blocks * (bottom_up ? ctx->sched_cols : ctx->C);  // (the workgroups that work)
-    while (threads > 64 && n_wg * (threads / 64) > (long long)n_cus * wpc) threads /= 2;
-    if (forced >= 64 && forced <= PML_SMALL_BLOCK) threads = forced;
-    dim3 grid(B.n_blocks, ctx->C), block(threads);
-    if (bottom_up)
-        hipLaunchKernelGGL((bu_f81_blocks_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, B.units, B.start, B.levels, B.lv);
-    else {
-        const bool signal = ctx->signal_next_td && ctx->C <= 64 && !ctx->windowed && !ctx->tune.on(T_NO_SPIN_WAIT);
-        ctx->signal_next_td = false;
-        hipLaunchKernelGGL((td_f81_blocks_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, B.units, B.start, B.levels,
-                           B.lv, signal ? ctx->d_done : nullptr, signal ? ctx->h_done : nullptr);
-        ctx->td_final_signals = signal;
-        if (signal) ++ctx->signals_enqueued;
-    }
-}
-
-#define PML_F81_CASES(X) \
-    X(2, 2)              \
-    X(4, 2)              \
-    X(1, 1)              \
-    X(1, 2)              \
-    X(1, 4)              \
-    X(2, 4)              \
-    X(4, 4)              \
-    X(8, 4)              \
-    X(16, 4)             \
-    X(32, 4)             \
-    X(64, 4)             \
-    X(32, 2)             \
-    X(16, 2)             \
-    X(8, 8)
-
-template <int G, int R>
-static void launch_select(pml_ctx* ctx, int method, int force_joint, const u64* d_lh_mask) {
-    const int upb = PML_WAVES_PER_BLOCK * (64 / G);
-    dim3 grid(grid_for(ctx, ctx->N, upb, ctx->C), ctx->C), block(PML_BLOCK);
-    hipLaunchKernelGGL((select_states_kernel<G, R>), grid, block, 0, ctx->stream, ctx->N, ctx->k, ctx->ks, ctx->W,
-                       ctx->d_post, d_lh_mask, ctx->d_js, method, force_joint, ctx->d_masks, ctx->d_nsel);
-}
-
-// lane shape of the kernels that walk several levels in one launch.  Bottom-up: the shape the level kernels use for
-// levels of this size (dispatch_sweep: 8 states per lane up to 65 536 units when 32 < k <= 64).  The reductions over a
-// unit's lanes associate differently in different shapes, so a level must get the same shape whether it runs here or in
-// a level launch: where the narrow end begins depends on the number of columns, and a column's bits must not.
-static void multi_level_shape(const pml_ctx* ctx, bool bottom_up, int& g, int& r) {
-    g = bottom_up ? (ctx->bu_wide_lanes ? 8 : ctx->Gf) : ctx->Gt;
-    r = bottom_up ? (ctx->bu_wide_lanes ? 8 : ctx->Rf) : ctx->Rt;
-}
-
-// units / d_offsets: the level table to walk (default: the fused lists of the whole forest from first_level on)
-static int dispatch_small_f81(pml_ctx* ctx, bool bottom_up, int do_prep, int first_level = 0, int n_levels = -1,
-                              const PmlUnit* units = nullptr, const int* d_offsets = nullptr, int skip_roots = 0) {
-    int g, r;
-    multi_level_shape(ctx, bottom_up, g, r);
-    if (n_levels < 0) n_levels = bottom_up ? (int)ctx->bu_offsets_f.size() - 1 - first_level : ctx->n_td_levels;
-    const int reset_err = (units == nullptr && first_level == 0) ? 1 : 0;
-    if (units == nullptr) {
-        // (the lists sorted by shape inside every level where the forest has them: a wave of one shape runs that shape's
-        // code -- walk_levels; a forest this small sits in the L2, where its rows lie does not matter)
-        const bool sorted = ctx->d_bu_units_fs != nullptr && g < 8 && !ctx->tune.on(T_NO_SHAPE_SORT);
-        units = bottom_up ? (sorted ? ctx->d_bu_units_fs : ctx->d_bu_units_f) : (sorted ? ctx->d_td_units_fs : ctx->d_td_units_f);
-        d_offsets = bottom_up ? ctx->d_bu_offsets_f + first_level : ctx->d_td_parent_offsets_f + first_level;
-    }
-#define X(G_, R_)                                                                                   \
-    if (g == G_ && r == R_) {                                                                       \
-        launch_small_f81<G_, R_>(ctx, bottom_up, do_prep, units, d_offsets, n_levels, reset_err, skip_roots);   \
-        HIP_TRY(hipGetLastError());                                                                 \
-        return PML_OK;                                                                              \
-    }
-    PML_F81_CASES(X)
-#undef X
-    return fail(PML_ERR_UNSUPPORTED, "no F81 kernel for G=%d R=%d", g, r);
-}
-
-static int dispatch_blocks_f81(pml_ctx* ctx, bool bottom_up, int which = 0) {
-    int g, r;
-    multi_level_shape(ctx, bottom_up, g, r);
-#define X(G_, R_)                                           \
-    if (g == G_ && r == R_) {                               \
-        launch_blocks_f81<G_, R_>(ctx, bottom_up, which);   \
-        HIP_TRY(hipGetLastError());                         \
-        return PML_OK;                                      \
-    }
-    PML_F81_CASES(X)
-#undef X
-    return fail(PML_ERR_UNSUPPORTED, "no F81 kernel for G=%d R=%d", g, r);
-}
-
-static int dispatch_sweep(pml_ctx* ctx, SweepKind what, const int* level, int n_level) {
-    if (n_level <= 0) return PML_OK;
-    if (ctx->kind == PML_MODEL_F81) {
-        if (what == SW_TD) return fail(PML_ERR_INVALID, "the F81 kernels walk descriptor lists: SW_TD has none");
-        const bool td = what == SW_TD_FUSED || what == SW_ROOTS;
-        int g = td ? ctx->Gt : ctx->Gf, r = td ? ctx->Rt : ctx->Rf;
-        // Fused bottom-up levels, 32 < k <= 64 (measured on cfg4): 8 states per lane (8 units per wavefront share the
-        // per-unit scalar work) wins on the level that rebuilds cherries (1.80 -> 1.58 ms) and on small levels;
-        // 4 states per lane (twice the loads in flight per unit) wins on big levels that stream stored vectors.
-        // (SW_BU_CHERRIES rewrites pi . v of the cherries, which the level that rebuilds them has stored: same shape, or
-        // a download of the bottom-up vectors would change the last bit of what a later top-down sweep reads)
-        if (ctx->bu_wide_lanes && (what == SW_BU_MARG_FUSED_NOVEC || what == SW_BU_CHERRIES ||
-                                   (what == SW_BU_MARG_FUSED && n_level <= 65536))) {
-            g = 8;
-            r = 8;
-        }
-#define X(G_, R_)                                                \
-    if (g == G_ && r == R_) {                                    \
-        launch_sweep_f81<G_, R_>(ctx, what, level, n_level);     \
-        HIP_TRY(hipGetLastError());                              \
-        return PML_OK;                                           \
-    }
-        PML_F81_CASES(X)
-#undef X
-        return fail(PML_ERR_UNSUPPORTED, "no F81 kernel for G=%d R=%d", g, r);
-    }
-#define X(G_, R_)                                             \
-    if (ctx->G == G_ && ctx->R == R_) {                       \
-        launch_sweep<G_, R_>(ctx, what, level, n_level);      \
-        HIP_TRY(hipGetLastError());                           \
-        return PML_OK;                                        \
-    }
-    PML_GR_CASES(X)
-#undef X
-    return fail(PML_ERR_UNSUPPORTED, "no kernel for G=%d R=%d", ctx->G, ctx->R);
-}
-
-// Two-level units run in the lane shape the level kernels give the levels they replace where those do not stream stored
-// vectors (bottom-up: 8 states per lane for 32 < k <= 64) -- units of 8 lanes and more, single-word masks.
-static void super_shape(const pml_ctx* ctx, bool bottom_up, int& g, int& r) {
-    g = bottom_up ? (ctx->bu_wide_lanes ? 8 : ctx->Gf) : ctx->Gt;
-    r = bottom_up ? (ctx->bu_wide_lanes ? 8 : ctx->Rf) : ctx->Rt;
-}
-
-static bool super_units(const pml_ctx* ctx) {
-    if (!ctx->sup.ok || ctx->kind != PML_MODEL_F81 || ctx->W != 1) return false;
-    int g, r;
-    super_shape(ctx, true, g, r);
-    if (g < 8 || (g == 16 && r == 2)) return false;   // (16 x 2: the shape of forests with polytomies, no two-level kernels)
-    super_shape(ctx, false, g, r);
-    return g >= 8 && !(g == 16 && r == 2);
-}
-
-// the sweeps of this context run the level schedule with two-level units (not one launch per sweep, not subtree blocks)
-static bool super_sweeps(const pml_ctx* ctx) {
-    return super_units(ctx) && !single_launch_sweeps(ctx) && !block_schedule(ctx);
-}
-
-// the thin ends of a large forest as subtree blocks (pml_tree_upload).  Measured, marginal pass, default against NO_THIN
-// (profiles/r05u_thin_ends.txt): 100 000 tips with polytomies x 16 characters k = 4 1.43 -> 1.16 ms, k = 20 1.79 -> 1.55;
-// random binary 40 000 tips x 8 k = 4 0.368 -> 0.313, k = 64 0.587 -> 0.504; 262 144 tips x 32 k = 4 1.60 -> 1.54,
-// k = 12 2.54 -> 2.49, k = 20 3.50 -> 3.43 (there the wide levels dominate).  NO_THIN_WIDE: units of fewer than 8 lanes only.
-static bool thin_bottom_up(const pml_ctx* ctx) {
-    return ctx->thin.ok && ctx->kind == PML_MODEL_F81 && !ctx->tune.on(T_NO_THIN) &&
-           ((!ctx->bu_wide_lanes && ctx->Gf < 8) || !ctx->tune.on(T_NO_THIN_WIDE));
-}
-static bool deep_top_down(const pml_ctx* ctx) {
-    return ctx->deep.ok && ctx->kind == PML_MODEL_F81 && !ctx->tune.on(T_NO_THIN) && (ctx->Gt < 8 || !ctx->tune.on(T_NO_THIN_WIDE));
-}
-
-template <int G, int R>
-static void launch_super_f81(pml_ctx* ctx, bool bottom_up) {
-    const PmlTree t = tree_of(ctx, true);
-    const PmlCols c = cols_of(ctx);
-    const PmlState st = state_of(ctx);
-    const int upb = PML_WAVES_PER_BLOCK * (64 / G);
-    // (top-down: one unit per child of a two-level node)
-    dim3 grid(grid_for(ctx, bottom_up ? ctx->sup.n : 2 * ctx->sup.n, upb, ctx->C, bottom_up), ctx->C), block(PML_BLOCK);
-    if (bottom_up)
-        hipLaunchKernelGGL((bu_f81_super_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, ctx->sup.d_units, ctx->sup.n);
-    else
-        hipLaunchKernelGGL((td_f81_super_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, ctx->sup.d_units, ctx->sup.n);
-}
-
-// stacked units of bottom-up level / depth `level` (pml_kernels_f81.h)
-template <int G, int R>
-static void launch_stack_f81(pml_ctx* ctx, bool bottom_up, int a, int n) {
-    const PmlTree t = tree_of(ctx, true);
-    const PmlCols c = cols_of(ctx);
-    const PmlState st = state_of(ctx);
-    const int upb = PML_WAVES_PER_BLOCK * (64 / G);
-    dim3 grid(grid_for(ctx, bottom_up ? n : 2 * n, upb, ctx->C), ctx->C), block(PML_BLOCK);
-    if (bottom_up)
-        hipLaunchKernelGGL((bu_f81_stack_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, ctx->sup.d_stack_bu + a, n);
-    else
-        hipLaunchKernelGGL((td_f81_stack_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, ctx->sup.d_stack_td + a, n);
-}
-
-// general two-level units: the absorbing nodes of bottom-up level `level` (a launch next to the level's plain units), or
-// every absorbed node's top-down unit (one launch behind the depth launches)
-template <int G, int R>
-static void launch_absorb_f81(pml_ctx* ctx, bool bottom_up, int a, int n) {
-    const PmlTree t = tree_of(ctx, true);
-    const PmlCols c = cols_of(ctx);
-    const PmlState st = state_of(ctx);
-    const int upb = PML_WAVES_PER_BLOCK * (64 / G);
-    dim3 grid(grid_for(ctx, n, upb, ctx->C), ctx->C), block(PML_BLOCK);
-    if (bottom_up) {
-        hipLaunchKernelGGL((bu_f81_absorb_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, ctx->sup.d_absorb_bu + 3 * (size_t)a, n);
-    } else {
-        hipLaunchKernelGGL((td_f81_absorb_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, ctx->sup.d_absorb_td + a, n);
-        if (ctx->sup.n_absorbing_td > 0) {
-            dim3 g2(grid_for(ctx, ctx->sup.n_absorbing_td, upb, ctx->C), ctx->C);
-            hipLaunchKernelGGL((td_f81_absorbing_kernel<G, R>), g2, block, 0, ctx->stream, t, c, st, ctx->sup.d_absorbing_td,
-                               ctx->sup.n_absorbing_td);
-        }
-    }
-}
-
-#define PML_SUPER_CASES(X) \
-    X(8, 4)                \
-    X(16, 4)               \
-    X(8, 8)
-
-static int dispatch_super_f81(pml_ctx* ctx, bool bottom_up) {
-    if (ctx->sup.n <= 0) return PML_OK;  // (a schedule of stacked units only)
-    int g, r;
-    super_shape(ctx, bottom_up, g, r);
-#define X(G_, R_)                                   \
-    if (g == G_ && r == R_) {                       \
-        launch_super_f81<G_, R_>(ctx, bottom_up);   \
-        HIP_TRY(hipGetLastError());                 \
-        return PML_OK;                              \
-    }
-    PML_SUPER_CASES(X)
-#undef X
-    return fail(PML_ERR_UNSUPPORTED, "no two-level F81 kernel for G=%d R=%d", g, r);
-}
-
-static int dispatch_absorb_f81(pml_ctx* ctx, bool bottom_up, int level) {
-    const pml_ctx::SuperSchedule& U = ctx->sup;
-    if (U.n_absorbed == 0) return PML_OK;
-    int a = 0, n = U.n_absorbed;
-    if (bottom_up) {
-        if (level + 1 >= (int)U.absorb_bu_offsets.size()) return PML_OK;
-        a = U.absorb_bu_offsets[level];
-        n = U.absorb_bu_offsets[level + 1] - a;
-    }
-    if (n <= 0) return PML_OK;
-    int g, r;
-    super_shape(ctx, bottom_up, g, r);
-#define X(G_, R_)                                          \
-    if (g == G_ && r == R_) {                              \
-        launch_absorb_f81<G_, R_>(ctx, bottom_up, a, n);   \
-        HIP_TRY(hipGetLastError());                        \
-        return PML_OK;                                     \
-    }
-    PML_SUPER_CASES(X)
-#undef X
-    return fail(PML_ERR_UNSUPPORTED, "no general two-level F81 kernel for G=%d R=%d", g, r);
-}
-
-static int dispatch_stack_f81(pml_ctx* ctx, bool bottom_up, int level) {
-    const std::vector<int>& off = bottom_up ? ctx->sup.stack_bu_offsets : ctx->sup.stack_td_offsets;
-    if (ctx->sup.n_stack == 0 || level + 1 >= (int)off.size()) return PML_OK;
-    const int a = off[level], n = off[level + 1] - a;
-    if (n <= 0) return PML_OK;
-    int g, r;
-    super_shape(ctx, bottom_up, g, r);
-#define X(G_, R_)                                         \
-    if (g == G_ && r == R_) {                             \
-        launch_stack_f81<G_, R_>(ctx, bottom_up, a, n);   \
-        HIP_TRY(hipGetLastError());                       \
-        return PML_OK;                                    \
-    }
-    PML_SUPER_CASES(X)
-#undef X
-    return fail(PML_ERR_UNSUPPORTED, "no stacked F81 kernel for G=%d R=%d", g, r);
-}
-
-// fused eigen sweeps: one launch over a list (nodes) or a contiguous id range (first) of n nodes
-static int launch_eigen_fused(pml_ctx* ctx, int mode, const int* nodes, int first, int n, int tips) {
-    if (n <= 0) return PML_OK;
-    const int k = ctx->k;
-    const int KS = (k + 3) / 4, NT = (k + 15) / 16;
-    const PmlTree t = tree_of(ctx);
-    const PmlCols c = cols_of(ctx);
-    const PmlState st = state_of(ctx);
-    const PmlModel m = model_of(ctx);
-#define PML_EIG_CASE(NT_, KS_, MODE_)                                                                              \
-    if (NT == NT_ && KS == KS_ && mode == MODE_) {                                                                 \
-        typedef EigShape<KS_> S;                                                                                   \
-        const size_t lds = ((size_t)S::KP * k + (size_t)PML_WAVES_PER_BLOCK * S::WAVE_LDS) * sizeof(double);       \
-        int blocks = (n + PML_WAVES_PER_BLOCK * S::NB - 1) / (PML_WAVES_PER_BLOCK * S::NB);                        \
-        const int cap_all = (int)ctx->tune.get(T_EIG_BLOCKS, 8192);                                                  \
-        const int cap = std::max(8, cap_all / std::max(1, ctx->C));                                                \
-        if (blocks > cap) blocks = cap;                                                                            \
-        hipLaunchKernelGGL((eigen_fused_kernel<NT_, KS_, MODE_>), dim3(blocks, ctx->C), dim3(PML_BLOCK), lds,      \
-                           ctx->stream, t, c, m, st, nodes, first, n, tips);                                       \
-        HIP_TRY(hipGetLastError());                                                                                \
-        return PML_OK;                                                                                             \
-    }
-#define PML_EIG_MODES(NT_, KS_)               \
-    PML_EIG_CASE(NT_, KS_, PML_EIG_BU_MARG)   \
-    PML_EIG_CASE(NT_, KS_, PML_EIG_BU_JOINT)  \
-    PML_EIG_CASE(NT_, KS_, PML_EIG_TD)
-    PML_EIG_MODES(1, 4)
-    PML_EIG_MODES(2, 5)
-    PML_EIG_MODES(2, 6)
-    PML_EIG_MODES(2, 7)
-    PML_EIG_MODES(2, 8)
-#undef PML_EIG_MODES
-#undef PML_EIG_CASE
-    return fail(PML_ERR_UNSUPPORTED, "no fused eigen kernel for k = %d", k);
-}
-
-// sum sweeps of the eigen models without forming P(t) (pml_kernels_eigen_gemm.h): one launch over a list (nodes) or a
-// contiguous id range (first) of n nodes
-// (any eigen model with up to 32 states: below 16 the joint sweep still reads materialised P(t), see eigen_fused)
-static bool eigen_gemm(const pml_ctx* c) {
-    const bool off = c->tune.on(T_NO_EIGEN_GEMM) || c->tune.on(T_NO_MFMA) || c->tune.on(T_NO_EIGEN_FUSED);
-    return !off && c->eig_fused_opt && c->kind == PML_MODEL_EIGEN && c->k >= 2 && c->k <= 32 && c->W == 1;
-}
-
-static int launch_eigen_gemm(pml_ctx* ctx, int mode, const int* nodes, int first, int n) {
-    if (n <= 0) return PML_OK;
-    const int KS = (ctx->k + 3) / 4;
-    const PmlTree t = tree_of(ctx);
-    const PmlCols c = cols_of(ctx);
-    const PmlState st = state_of(ctx);
-    const PmlModel m = model_of(ctx);
-    int blocks = (n + PML_WAVES_PER_BLOCK * 16 - 1) / (PML_WAVES_PER_BLOCK * 16);
-    const int cap = std::max(8, 16384 / std::max(1, ctx->C));
-    if (blocks > cap) blocks = cap;
-#define PML_EIGG_CASE(KS_, MODE_)                                                                                   \
-    if (KS == KS_ && mode == MODE_) {                                                                               \
-        hipLaunchKernelGGL((eigen_gemm_kernel<KS_, MODE_>), dim3(blocks, ctx->C), dim3(PML_BLOCK), 0, ctx->stream, \
-                           t, c, m, st, nodes, first, n);                                                           \
-        HIP_TRY(hipGetLastError());                                                                                 \
-        return PML_OK;                                                                                              \
-    }
-#define PML_EIGG_MODES(KS_) PML_EIGG_CASE(KS_, PML_EIGG_BU) PML_EIGG_CASE(KS_, PML_EIGG_TIPS) PML_EIGG_CASE(KS_, PML_EIGG_TD)
-    PML_EIGG_MODES(1)
-    PML_EIGG_MODES(2)
-    PML_EIGG_MODES(3)
-    PML_EIGG_MODES(4)
-    PML_EIGG_MODES(5)
-    PML_EIGG_MODES(6)
-    PML_EIGG_MODES(7)
-    PML_EIGG_MODES(8)
-#undef PML_EIGG_MODES
-#undef PML_EIGG_CASE
-    return fail(PML_ERR_UNSUPPORTED, "no eigen kernel for k = %d", ctx->k);
-}
-
-static int launch_eigen_gemm_narrow(pml_ctx* ctx, int mode, const int* nodes, const int* d_offsets, int first_level,
-                                    int n_levels, const int* d_blk_start = nullptr, int n_blocks = 1) {
-    if (n_levels <= 0) return PML_OK;
-    const int KS = (ctx->k + 3) / 4;
-    const PmlTree t = tree_of(ctx);
-    const PmlCols c = cols_of(ctx);
-    const PmlState st = state_of(ctx);
-    const PmlModel m = model_of(ctx);
-#define PML_EIGG_CASE(KS_, MODE_)                                                                                      \
-    if (KS == KS_ && mode == MODE_) {                                                                                  \
-        hipLaunchKernelGGL((eigen_gemm_narrow_kernel<KS_, MODE_>), dim3(n_blocks, ctx->C), dim3(PML_BLOCK), 0,         \
-                           ctx->stream, t, c, m, st, nodes, d_offsets + first_level, n_levels, d_blk_start);           \
-        HIP_TRY(hipGetLastError());                                                                                    \
-        return PML_OK;                                                                                                 \
-    }
-#define PML_EIGG_MODES(KS_) PML_EIGG_CASE(KS_, PML_EIGG_BU) PML_EIGG_CASE(KS_, PML_EIGG_TD)
-    PML_EIGG_MODES(1)
-    PML_EIGG_MODES(2)
-    PML_EIGG_MODES(3)
-    PML_EIGG_MODES(4)
-    PML_EIGG_MODES(5)
-    PML_EIGG_MODES(6)
-    PML_EIGG_MODES(7)
-    PML_EIGG_MODES(8)
-#undef PML_EIGG_MODES
-#undef PML_EIGG_CASE
-    return fail(PML_ERR_UNSUPPORTED, "no eigen kernel for k = %d", ctx->k);
-}
-
-// fused eigen sweeps: levels [first_level, first_level + n_levels) of a level table in one launch
-static int launch_eigen_narrow(pml_ctx* ctx, int mode, const int* nodes, const int* d_offsets, int first_level,
-                               int n_levels) {
-    if (n_levels <= 0) return PML_OK;
-    const int k = ctx->k;
-    const int KS = (k + 3) / 4, NT = (k + 15) / 16;
-    const PmlTree t = tree_of(ctx);
-    const PmlCols c = cols_of(ctx);
-    const PmlState st = state_of(ctx);
-    const PmlModel m = model_of(ctx);
-#define PML_EIG_CASE(NT_, KS_, MODE_)                                                                              \
-    if (NT == NT_ && KS == KS_ && mode == MODE_) {                                                                 \
-        typedef EigShape<KS_> S;                                                                                   \
-        const size_t lds = ((size_t)S::KP * k + (size_t)PML_WAVES_PER_BLOCK * S::WAVE_LDS) * sizeof(double);       \
-        hipLaunchKernelGGL((eigen_narrow_kernel<NT_, KS_, MODE_>), dim3(1, ctx->C), dim3(PML_BLOCK), lds,          \
-                           ctx->stream, t, c, m, st, nodes, d_offsets + first_level, n_levels);                    \
-        HIP_TRY(hipGetLastError());                                                                                \
-        return PML_OK;                                                                                             \
-    }
-#define PML_EIG_MODES(NT_, KS_)               \
-    PML_EIG_CASE(NT_, KS_, PML_EIG_BU_MARG)   \
-    PML_EIG_CASE(NT_, KS_, PML_EIG_BU_JOINT)  \
-    PML_EIG_CASE(NT_, KS_, PML_EIG_TD)
-    PML_EIG_MODES(1, 4)
-    PML_EIG_MODES(2, 5)
-    PML_EIG_MODES(2, 6)
-    PML_EIG_MODES(2, 7)
-    PML_EIG_MODES(2, 8)
-#undef PML_EIG_MODES
-#undef PML_EIG_CASE
-    return fail(PML_ERR_UNSUPPORTED, "no fused eigen kernel for k = %d", k);
-}
-
-// The joint sweep of the eigen models on the vector units (pml_kernels_eigen_joint.h) for 2 <= k <= 32;
-// PASTML_HIP_NO_EIGEN_JOINT_VALU keeps the matrix-core kernels (pml_kernels_eigen_mfma.h).
-static bool eigen_joint_valu(const pml_ctx* c) {
-    const bool off = c->tune.on(T_NO_EIGEN_JOINT_VALU);
-    return !off && c->eigj_valu_opt && c->kind == PML_MODEL_EIGEN && c->k >= 2 && c->k <= PML_EIGJ_STRIDE && c->W == 1 &&
-           c->d_AinvT != nullptr;
-}
-
-// d_offsets == nullptr: one launch over the n nodes of a level (their unit descriptors); otherwise the levels
-// [first, first + n) of the level table in one launch (one workgroup per column)
-static int launch_eigen_joint(pml_ctx* ctx, const PmlUnit* units, const int* d_offsets, int first, int n,
-                              const int* d_blk_start = nullptr, int n_blocks = 1) {
-    if (n <= 0) return PML_OK;
-    const int KU = 4 * ((ctx->k + 3) / 4);
-    const PmlTree t = tree_of(ctx);
-    const PmlCols c = cols_of(ctx);
-    const PmlState st = state_of(ctx);
-    const PmlModel m = model_of(ctx);
-    const int per_block = PML_WAVES_PER_BLOCK * (64 / ctx->k);
-    const int cap_all = (int)ctx->tune.get(T_EIGJ_BLOCKS, 1024);
-#define PML_EIGJ_CASE(KU_)                                                                                          \
-    if (KU == KU_) {                                                                                                \
-        if (d_offsets) {                                                                                            \
-            hipLaunchKernelGGL((eigen_joint_narrow_kernel<KU_>), dim3(n_blocks, ctx->C), dim3(PML_BLOCK), 0,        \
-                               ctx->stream, t, c, m, st, ctx->d_AinvT, units, d_offsets + first, n, d_blk_start);   \
-        } else {                                                                                                    \
-            int blocks = (n + per_block - 1) / per_block;                                                           \
-            const int cap = std::max(8, cap_all / std::max(1, ctx->C));                                             \
-            if (blocks > cap) blocks = cap;                                                                         \
-            if (ctx->tune.on(T_NO_EIGJ_PIPE))                                                                       \
-                hipLaunchKernelGGL((eigen_joint_kernel<KU_, false>), dim3(blocks, ctx->C), dim3(PML_BLOCK), 0,      \
-                                   ctx->stream, t, c, m, st, ctx->d_AinvT, units, n);                               \
-            else                                                                                                    \
-                hipLaunchKernelGGL((eigen_joint_kernel<KU_, true>), dim3(blocks, ctx->C), dim3(PML_BLOCK), 0,       \
-                                   ctx->stream, t, c, m, st, ctx->d_AinvT, units, n);                               \
-        }                                                                                                           \
-        HIP_TRY(hipGetLastError());                                                                                 \
-        return PML_OK;                                                                                              \
-    }
-    PML_EIGJ_CASE(4)
-    PML_EIGJ_CASE(8)
-    PML_EIGJ_CASE(12)
-    PML_EIGJ_CASE(16)
-    PML_EIGJ_CASE(20)
-    PML_EIGJ_CASE(24)
-    PML_EIGJ_CASE(28)
-    PML_EIGJ_CASE(32)
-#undef PML_EIGJ_CASE
-    return fail(PML_ERR_UNSUPPORTED, "no joint eigen kernel for k = %d", ctx->k);
-}
-
-static int launch_eigen_joint_tips(pml_ctx* ctx) {
-    if (ctx->n_tips <= 0) return PML_OK;
-    const int KU = 4 * ((ctx->k + 3) / 4);
-    const PmlTree t = tree_of(ctx);
-    const PmlCols c = cols_of(ctx);
-    const PmlState st = state_of(ctx);
-    const PmlModel m = model_of(ctx);
-    const int per_block = PML_WAVES_PER_BLOCK * (64 / ctx->k);
-    int blocks = (ctx->n_tips + per_block - 1) / per_block;
-    const int cap_all = (int)ctx->tune.get(T_EIGJ_TIP_BLOCKS, 2048);
-    const int cap = std::max(8, cap_all / std::max(1, ctx->C));
-    if (blocks > cap) blocks = cap;
-    // observed tips in the lean kernel; what it leaves on the columns' lists (tips with several or all states allowed)
-    // in one launch of the general kernel -- PASTML_HIP_EIGJ_ONE_TIPS_KERNEL: everything in the general kernel (round 2)
-    const bool one_kernel = ctx->tune.on(T_EIGJ_ONE_TIPS_KERNEL);
-    const int rest_blocks = std::min(blocks, std::max(8, 1024 / std::max(1, ctx->C)));
-    // (every tip of every column known to be observed -- the masks came from pml_masks_from_tip_states: nothing can be
-    // on the lists, their launch is left out)
-    bool all_observed = !ctx->tips_observed.empty();
-    for (char f : ctx->tips_observed) all_observed = all_observed && f != 0;
-#define PML_EIGJ_TIPS(KU_)                                                                                          \
-    if (KU == KU_) {                                                                                                \
-        if (one_kernel) {                                                                                           \
-            hipLaunchKernelGGL((eigen_joint_tips_kernel<KU_>), dim3(blocks, ctx->C), dim3(PML_BLOCK), 0,            \
-                               ctx->stream, t, c, m, st, ctx->d_AinvT, ctx->d_tips, ctx->n_tips, nullptr);          \
-        } else {                                                                                                    \
-            hipLaunchKernelGGL((eigen_joint_obs_tips_kernel<KU_>), dim3(blocks, ctx->C), dim3(PML_BLOCK), 0,        \
-                               ctx->stream, t, c, m, st, ctx->d_AinvT, ctx->d_tips, ctx->n_tips, ctx->d_tip_rest,   \
-                               ctx->d_tip_rest_count);                                                              \
-            if (!all_observed)                                                                                      \
-                hipLaunchKernelGGL((eigen_joint_tips_kernel<KU_>), dim3(rest_blocks, ctx->C), dim3(PML_BLOCK), 0,   \
-                                   ctx->stream, t, c, m, st, ctx->d_AinvT, ctx->d_tip_rest, ctx->n_tips,            \
-                                   ctx->d_tip_rest_count);                                                          \
-        }                                                                                                           \
-        HIP_TRY(hipGetLastError());                                                                                 \
-        return PML_OK;                                                                                              \
-    }
-    PML_EIGJ_TIPS(4)
-    PML_EIGJ_TIPS(8)
-    PML_EIGJ_TIPS(12)
-    PML_EIGJ_TIPS(16)
-    PML_EIGJ_TIPS(20)
-    PML_EIGJ_TIPS(24)
-    PML_EIGJ_TIPS(28)
-    PML_EIGJ_TIPS(32)
-#undef PML_EIGJ_TIPS
-    return fail(PML_ERR_UNSUPPORTED, "no joint eigen kernel for k = %d", ctx->k);
-}
-
-// bottom-up messages of all tips (observed tips 16 to a tile, see eigen_tips_kernel)
-static int launch_eigen_tips(pml_ctx* ctx, int joint) {
-    if (ctx->n_tips <= 0) return PML_OK;
-    const int k = ctx->k;
-    const int KS = (k + 3) / 4, NT = (k + 15) / 16;
-    const PmlTree t = tree_of(ctx);
-    const PmlCols c = cols_of(ctx);
-    const PmlState st = state_of(ctx);
-    const PmlModel m = model_of(ctx);
-#define PML_EIG_TIPS(NT_, KS_, J_)                                                                                   \
-    if (NT == NT_ && KS == KS_ && joint == J_) {                                                                     \
-        typedef EigShape<KS_> S;                                                                                     \
-        const size_t lds = ((size_t)S::KP * k + (size_t)PML_WAVES_PER_BLOCK * S::WAVE_LDS_TIPS) * sizeof(double);    \
-        int blocks = (ctx->n_tips + PML_WAVES_PER_BLOCK * 16 - 1) / (PML_WAVES_PER_BLOCK * 16);                      \
-        const int cap = std::max(8, 8192 / std::max(1, ctx->C));                                                     \
-        if (blocks > cap) blocks = cap;                                                                              \
-        hipLaunchKernelGGL((eigen_tips_kernel<NT_, KS_, J_>), dim3(blocks, ctx->C), dim3(PML_BLOCK), lds,            \
-                           ctx->stream, t, c, m, st, ctx->d_tips, ctx->n_tips);                                      \
-        HIP_TRY(hipGetLastError());                                                                                  \
-        return PML_OK;                                                                                               \
-    }
-#define PML_EIG_TIPS2(NT_, KS_) PML_EIG_TIPS(NT_, KS_, 0) PML_EIG_TIPS(NT_, KS_, 1)
-    PML_EIG_TIPS2(1, 4)
-    PML_EIG_TIPS2(2, 5)
-    PML_EIG_TIPS2(2, 6)
-    PML_EIG_TIPS2(2, 7)
-    PML_EIG_TIPS2(2, 8)
-#undef PML_EIG_TIPS2
-#undef PML_EIG_TIPS
-    return fail(PML_ERR_UNSUPPORTED, "no fused eigen kernel for k = %d", k);
-}
-
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Height-ordered numbering (round 5).  The C-ABI asks for breadth-first ids -- roots first, the children of a node
@@ -3268,65 +1958,9 @@ static int run_prep(pml_ctx* ctx, bool force = false) {
             hipLaunchKernelGGL(pij_hky_kernel, grid, dim3(PML_BLOCK), 0, ctx->stream, t, c, m, ctx->d_P);
         } else if (ctx->k >= 2 && ctx->k <= PML_EIGJ_STRIDE && ctx->d_AT != nullptr && ctx->d_AinvT != nullptr && (ctx->ks & 1) == 0 &&
                    !ctx->tune.on(T_NO_PIJ_VALU) && (ctx->k < 16 || ctx->tune.on(T_NO_MFMA) || ctx->tune.on(T_PIJ_VALU))) {
-            // vector-unit path: a lane per output row, exact flops, rows written in address order (pml_kernels_eigen_joint.h).
-            // Below 16 states, where the matrix-core kernel does not reach (524 287 branches: k = 8 0.289 -> 0.056 ms, k = 5
-            // 0.292 -> 0.032 against pij_eigen_kernel); from 16 on the matrix-core kernel is the faster one (k = 20 0.380 against
-            // 0.392 ms, k = 32 0.96 against 1.38: the rows of A^T come through the scalar cache a dozen FMAs ahead at best, and
-            // with 1 024 FMAs per lane the wave count halves) -- PASTML_HIP_PIJ_VALU forces this path (profiles/r05o_pij_valu.txt)
-            const int KU = 4 * ((ctx->k + 3) / 4);
-            const long long passes = ((long long)ctx->N * ctx->k + 63) / 64;
-            long long blocks = (passes + PML_WAVES_PER_BLOCK - 1) / PML_WAVES_PER_BLOCK;
-            const long long cap = std::max(64, (int)ctx->tune.get(T_PIJ_BLOCKS, 4096) / std::max(1, ctx->C));
-            if (blocks > cap) blocks = cap;
-            dim3 grid((unsigned)blocks, ctx->C);
-#define PML_PIJV_CASE(KU_)                                                                                          \
-    if (KU == KU_)                                                                                                  \
-        hipLaunchKernelGGL((pij_eigen_valu_kernel<KU_>), grid, dim3(PML_BLOCK), 0, ctx->stream, t, c, m, ctx->d_AinvT, \
-                           ctx->d_AT, ctx->d_P);
-            PML_PIJV_CASE(4)
-            PML_PIJV_CASE(8)
-            PML_PIJV_CASE(12)
-            PML_PIJV_CASE(16)
-            PML_PIJV_CASE(20)
-            PML_PIJV_CASE(24)
-            PML_PIJV_CASE(28)
-            PML_PIJV_CASE(32)
-#undef PML_PIJV_CASE
+            PML_TRY(launch_pij_valu(ctx));   // vector-unit path, pml_launch_eigen_joint.hip
         } else if (ctx->k >= 16 && ctx->k <= 32 && !ctx->tune.on(T_NO_MFMA)) {
-            // FP64 matrix-core path (BASELINE config 3: JTT, k = 20)
-            const int k = ctx->k;
-            const int KS = (k + 3) / 4, NT = (k + 15) / 16;
-            // rows of the result a wave stages in LDS per flush (pml_kernels_pij.h)
-            int srows = (int)ctx->tune.get(T_PIJ_STAGE_ROWS, 32);
-            if (srows != 16 && srows != 64) srows = 32;
-            auto lds_of = [&](int sr) {
-                return ((size_t)KS * 4 * k + (size_t)PML_WAVES_PER_BLOCK * ((size_t)(PML_MFMA_CHUNK + sr) * KS * 4 + 64)) * sizeof(double);
-            };
-            if (srows == 64 && lds_of(64) > 64 * 1024) srows = 32;  // (the default limit of dynamic LDS)
-            const size_t lds = lds_of(srows);
-            int blocks = (ctx->N + PML_WAVES_PER_BLOCK * PML_MFMA_CHUNK - 1) / (PML_WAVES_PER_BLOCK * PML_MFMA_CHUNK);
-            // every wave walks several chunks: the block's set-up (Ainv to LDS, the fragments of A) is paid once
-            const int cap = std::max(64, (int)ctx->tune.get(T_PIJ_BLOCKS, 2048) / std::max(1, ctx->C));
-            if (blocks > cap) blocks = cap;
-            dim3 grid(blocks, ctx->C);
-            const int ablate = (int)ctx->tune.get(T_PIJ_ABLATE, 0);   // (measurements: 1 = no stores, 2 = no matrix instructions)
-#define PML_MFMA_CASE_R(NT_, KS_, SR_)                                                                             \
-    if (NT == NT_ && KS == KS_ && srows == SR_) {                                                                  \
-        if (ablate == 1 && KS_ == 5 && SR_ == 32)                                                                  \
-            hipLaunchKernelGGL((pij_eigen_mfma_kernel<NT_, KS_, SR_, 1>), grid, dim3(PML_BLOCK), lds, ctx->stream, t, c, m, ctx->d_P); \
-        else if (ablate == 2 && KS_ == 5 && SR_ == 32)                                                             \
-            hipLaunchKernelGGL((pij_eigen_mfma_kernel<NT_, KS_, SR_, 2>), grid, dim3(PML_BLOCK), lds, ctx->stream, t, c, m, ctx->d_P); \
-        else                                                                                                       \
-            hipLaunchKernelGGL((pij_eigen_mfma_kernel<NT_, KS_, SR_>), grid, dim3(PML_BLOCK), lds, ctx->stream, t, c, m, ctx->d_P);    \
-    }
-#define PML_MFMA_CASE(NT_, KS_) PML_MFMA_CASE_R(NT_, KS_, 16) PML_MFMA_CASE_R(NT_, KS_, 32) PML_MFMA_CASE_R(NT_, KS_, 64)
-            PML_MFMA_CASE(1, 4)
-            PML_MFMA_CASE(2, 5)
-            PML_MFMA_CASE(2, 6)
-            PML_MFMA_CASE(2, 7)
-            PML_MFMA_CASE(2, 8)
-#undef PML_MFMA_CASE_R
-#undef PML_MFMA_CASE
+            PML_TRY(launch_pij_mfma(ctx));   // FP64 matrix-core path, pml_launch_eigen_mfma.hip
         } else {
             const int k = ctx->k;
             size_t lds = ((size_t)2 * k * (k + 1) + k) * sizeof(double);
@@ -4562,27 +3196,7 @@ int pml_select_states(pml_ctx* ctx, int method, int force_joint, const uint64_t*
             return fail(PML_ERR_HIP, "lh_mask upload failed: %s", hipGetErrorString(e));
         }
     }
-    int status = PML_ERR_UNSUPPORTED;
-    // lane shape of the selection kernel: 8 states per lane up to k = 64 (8 units per wavefront share the scalar work
-    // and the arg-max butterflies stay inside a 16-lane row: 3.2 -> 2.6 ms per pass of 4 columns at cfg4 size),
-    // else the matrix shapes
-    int sg = ctx->G, sr = ctx->R;
-    if (ctx->k <= 64) {
-        sr = 8;
-        sg = 1;
-        while (sg * sr < ctx->k) sg <<= 1;
-    }
-#define X(G_, R_)                                                      \
-    if (sg == G_ && sr == R_) {                                        \
-        launch_select<G_, R_>(ctx, method, force_joint, d_lh_mask);    \
-        status = PML_OK;                                               \
-    }
-    PML_GR_CASES(X)
-    X(1, 8)
-    X(2, 8)
-    X(4, 8)
-    X(8, 8)
-#undef X
+    const int status = dispatch_select(ctx, method, force_joint, d_lh_mask);   // pml_launch_matrix.hip
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && masks_out)
         e = hipMemcpyAsync(masks_out, ctx->d_masks, CN * ctx->W * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream);
@@ -4590,7 +3204,7 @@ int pml_select_states(pml_ctx* ctx, int method, int force_joint, const uint64_t*
         e = hipMemcpyAsync(n_states_out, ctx->d_nsel, CN * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
     hipError_t e2 = hipStreamSynchronize(ctx->stream);
     if (d_lh_mask) (void)hipFree(d_lh_mask);
-    if (status != PML_OK) return fail(status, "no selection kernel for G=%d R=%d", ctx->G, ctx->R);
+    if (status != PML_OK) return status;
     if (e != hipSuccess) return fail(PML_ERR_HIP, "pml_select_states failed: %s", hipGetErrorString(e));
     if (e2 != hipSuccess) return fail(PML_ERR_HIP, "pml_select_states failed: %s", hipGetErrorString(e2));
     rows_to_api_inplace(ctx, (u64*)masks_out, (size_t)ctx->W, (size_t)ctx->C);
@@ -5038,3 +3652,4 @@ int pml_timer_stop(pml_ctx* ctx, float* milliseconds) {
 }
 
 }  // extern "C"
+

@@ -11,6 +11,17 @@
 
 #define PML_BLOCK 256
 #define PML_WAVES_PER_BLOCK 4
+#define PML_EIGJ_STRIDE 32                     // row stride (and rows) of the transposed padded copy of Ainv (pml_kernels_eigen_joint.h)
+// modes of eigen_gemm_kernel (pml_kernels_eigen_gemm.h) and of the fused matrix-core sweeps (pml_kernels_eigen_mfma.h)
+#define PML_EIGG_BU 0    // marginal bottom-up, internal nodes
+#define PML_EIGG_TIPS 1  // marginal bottom-up, tips (no children)
+#define PML_EIGG_TD 2    // top-down + marginal likelihoods + posteriors
+#define PML_EIG_BU_MARG 0
+#define PML_EIG_BU_JOINT 1
+#define PML_EIG_TD 2
+// A kernel that is not a template: internal linkage, so that every translation unit that includes its header may hold a
+// copy and only those that launch it emit one.
+#define PML_GLOBAL static __global__
 
 typedef unsigned long long u64;
 typedef long long i64;

@@ -56,7 +56,7 @@ __device__ __forceinline__ double wave_inclusive_scan(double v, int lane) {
 }
 
 // counts of the roots: n_rep draws from the posterior of each root (ml.py:786-793)
-__global__ void __launch_bounds__(64)
+PML_GLOBAL void __launch_bounds__(64)
 counts_roots_kernel(PmlTree t, PmlCols c, PmlState st, int col, int n_rep, u64 seed, int* __restrict__ counts) {
     __shared__ double cdf[PML_COUNTS_MAX_K];
     __shared__ int hist[PML_COUNTS_MAX_K];
@@ -93,7 +93,7 @@ counts_roots_kernel(PmlTree t, PmlCols c, PmlState st, int col, int n_rep, u64 s
 }
 
 // one depth level: parents[0 .. n_parents), one wavefront (= one 64-thread block) per parent
-__global__ void __launch_bounds__(64)
+PML_GLOBAL void __launch_bounds__(64)
 counts_level_kernel(PmlTree t, PmlCols c, PmlState st, PmlModel m, const double* __restrict__ P, int col, int n_rep,
                     u64 seed, const int* __restrict__ parents, int n_parents, int* __restrict__ counts,
                     long long* __restrict__ result) {

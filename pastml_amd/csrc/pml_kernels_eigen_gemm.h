@@ -20,9 +20,6 @@
 #pragma once
 #include "pml_kernels_eigen_mfma.h"
 
-#define PML_EIGG_BU 0    // marginal bottom-up, internal nodes
-#define PML_EIGG_TIPS 1  // marginal bottom-up, tips (no children)
-#define PML_EIGG_TD 2    // top-down + marginal likelihoods + posteriors
 
 template <int KS>
 struct EigGemm {

@@ -20,7 +20,6 @@
 #include "pml_kernels_eigen_mfma.h"
 
 typedef const __attribute__((address_space(4))) double* pml_const_f64;
-#define PML_EIGJ_STRIDE 32                     // row stride (and rows) of the transposed padded copy of Ainv
 #define PML_EIGJ_WAVE_LDS 128                  // doubles per wave and array: (64 / k) * KU <= 128
 // rows of A in LDS: 16-byte aligned, and a stride that is not a multiple of 64 bytes so that the rows of the states
 // of a node start in different banks

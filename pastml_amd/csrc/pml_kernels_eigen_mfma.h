@@ -34,9 +34,6 @@ struct EigShape {
     static constexpr int WAVE_LDS_TIPS = 16 * KP + NB * KP + 16 + 16;
 };
 
-#define PML_EIG_BU_MARG 0
-#define PML_EIG_BU_JOINT 1
-#define PML_EIG_TD 2
 
 // Per-wave state of the fused kernels: LDS slots, the B fragments of A^T, the column's scalars.
 template <int NT, int KS>

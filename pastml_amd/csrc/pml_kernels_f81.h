@@ -74,7 +74,7 @@ __device__ __forceinline__ int node_kind(const PmlTree& t, int n) {
 // ---------------------------------------------------------------------------------------------------------------------
 // A thread takes node n for `cpy` consecutive columns (blockIdx.y = column chunk): the branch length is read once per
 // chunk instead of once per column (a third of this pass's traffic on a wide batch).
-__global__ void __launch_bounds__(PML_BLOCK)
+PML_GLOBAL void __launch_bounds__(PML_BLOCK)
 f81_prep_kernel(PmlTree t, PmlCols c, const double* __restrict__ mu, const double* __restrict__ sf,
                 const double* __restrict__ tau, const double* __restrict__ tauf, PmlState st, int n_cols, int cpy) {
     const int col0 = blockIdx.y * cpy;

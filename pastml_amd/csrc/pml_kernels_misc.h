@@ -5,7 +5,7 @@
 #define PML_MAX_STATES_SEL 256
 
 // masks: internal nodes all ones; tip j one-hot at states[col][j] (all ones if negative = missing data)
-__global__ void __launch_bounds__(PML_BLOCK)
+PML_GLOBAL void __launch_bounds__(PML_BLOCK)
 masks_fill_kernel(int N, int W, int k, u64* __restrict__ masks, int col_begin) {
     const int col = col_begin + blockIdx.y;
     const size_t total = (size_t)N * W;
@@ -16,7 +16,7 @@ masks_fill_kernel(int N, int W, int k, u64* __restrict__ masks, int col_begin) {
     }
 }
 
-__global__ void __launch_bounds__(PML_BLOCK)
+PML_GLOBAL void __launch_bounds__(PML_BLOCK)
 masks_tips_kernel(int N, int W, int k, u64* __restrict__ masks, int col_begin, int n_tips,
                   const int* __restrict__ tip_ids, const int* __restrict__ states) {
     const int col = col_begin + blockIdx.y;
@@ -83,7 +83,7 @@ td_roots_kernel(PmlTree t, PmlCols c, PmlState st) {
 // ln L per column = sum over trees of ln(root term) + E_root ln 2 (ml.py:112-121).
 // marginal: root term = sum_i pi_i BU_i; joint: max_i pi_i BU_i, whose first arg-max is the root's joint state
 // (ml.py:622).  One thread per column; forests have few roots.
-__global__ void __launch_bounds__(PML_BLOCK)
+PML_GLOBAL void __launch_bounds__(PML_BLOCK)
 loglik_kernel(PmlTree t, PmlCols c, PmlState st, int n_cols, int is_marginal, double* __restrict__ loglik,
               u64* __restrict__ err_out) {
     const int col = blockIdx.x * blockDim.x + threadIdx.x;
@@ -97,7 +97,7 @@ loglik_kernel(PmlTree t, PmlCols c, PmlState st, int n_cols, int is_marginal, do
 }
 
 // joint back-trace, one depth level per launch: state[n] = table[n][state[parent]] (ml.py:615-620)
-__global__ void __launch_bounds__(PML_BLOCK)
+PML_GLOBAL void __launch_bounds__(PML_BLOCK)
 joint_backtrace_kernel(PmlTree t, PmlCols c, PmlState st, int begin, int end) {
     const int col = blockIdx.y;
     const size_t colN = (size_t)col * t.N;
@@ -109,7 +109,7 @@ joint_backtrace_kernel(PmlTree t, PmlCols c, PmlState st, int begin, int end) {
 
 // the depth levels right below the roots (a handful of nodes each) in one launch: one workgroup per column, a
 // workgroup barrier between levels; depth_offsets[d] .. depth_offsets[d + 1] are the node ids of depth d
-__global__ void __launch_bounds__(PML_BLOCK)
+PML_GLOBAL void __launch_bounds__(PML_BLOCK)
 joint_backtrace_narrow_kernel(PmlTree t, PmlCols c, PmlState st, const int* __restrict__ depth_offsets, int first_depth,
                               int n_depths) {
     const int col = blockIdx.y;
@@ -128,7 +128,7 @@ joint_backtrace_narrow_kernel(PmlTree t, PmlCols c, PmlState st, const int* __re
 // workgroup per (subtree, column) walks its depths with a workgroup barrier between them -- one launch per tier instead
 // of one per depth (the work is one table look-up per node: a depth is pure launch latency).  nodes: the tier's nodes,
 // subtree by subtree, depth by depth; subtree b's depth table starts at lv[blk_start[b]], n_depths + 1 entries.
-__global__ void __launch_bounds__(PML_BLOCK)
+PML_GLOBAL void __launch_bounds__(PML_BLOCK)
 joint_backtrace_blocks_kernel(PmlTree t, PmlCols c, PmlState st, const int* __restrict__ nodes,
                               const int* __restrict__ lv, const int* __restrict__ blk_start, int n_depths) {
     const int col = blockIdx.y;
@@ -413,7 +413,7 @@ select_states_kernel(int N, int k, int ks, int W, const double* __restrict__ pos
 // Inspection only, not on the measured path: plain loops, k <= 256 states in up to four registers per lane.
 // P: transposed matrices of the matrix models ([C][N][k][ks], Pt[j][i] = P[i][j]) or nullptr for the F81 family, whose
 // P = (1 - e) 1 pi^T + e I is applied in closed form.
-__global__ void __launch_bounds__(PML_BLOCK)
+PML_GLOBAL void __launch_bounds__(PML_BLOCK)
 td_fill_kernel(PmlTree t, PmlCols c, PmlState st, const double* __restrict__ P, int f81, int begin, int end) {
     __shared__ double sv[PML_WAVES_PER_BLOCK][PML_MAX_STATES_SEL];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -504,7 +504,7 @@ td_fill_kernel(PmlTree t, PmlCols c, PmlState st, const double* __restrict__ P, 
 
 // sum of the columns' log-likelihoods in column order (as a host loop over the characters would add them), on the device:
 // the values are where the last kernel of the sweep put them (pinned host memory, visible to the device)
-__global__ void sum_loglik_kernel(const double* __restrict__ loglik, int n, double* __restrict__ total) {
+PML_GLOBAL void sum_loglik_kernel(const double* __restrict__ loglik, int n, double* __restrict__ total) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         double acc = 0.0;
         for (int i = 0; i < n; ++i) acc += loglik[i];
@@ -515,7 +515,7 @@ __global__ void sum_loglik_kernel(const double* __restrict__ loglik, int n, doub
 // PML_OPT_IMPLICIT_TIP_POSTERIORS: the rows the top-down sweep left implicit -- an observed tip (one allowed state) with a
 // positive finite likelihood has the unit vector of its state as its posterior (pastml/ml.py:498-500 gives exactly that)
 // -- written out when somebody reads the table.  One thread per (tip, column).
-__global__ void __launch_bounds__(PML_BLOCK)
+PML_GLOBAL void __launch_bounds__(PML_BLOCK)
 tip_posteriors_kernel(PmlCols c, PmlState st, int N, const int* __restrict__ tips, int n_tips) {
     const int col = blockIdx.y;
     const size_t colN = (size_t)col * N;
@@ -532,7 +532,7 @@ tip_posteriors_kernel(PmlCols c, PmlState st, int N, const int* __restrict__ tip
 
 // start of a bottom-up sweep: the columns' error words, and (if given) the counters of the tips the lean tips kernel of
 // the eigen joint sweep hands on
-__global__ void reset_err_kernel(u64* __restrict__ err, int n, int* __restrict__ counters = nullptr) {
+PML_GLOBAL void reset_err_kernel(u64* __restrict__ err, int n, int* __restrict__ counters = nullptr) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
         err[i] = ~0ull;

@@ -3,7 +3,7 @@
 #include "pml_kernels_matrix.h"
 
 // HKY: one thread per (branch, column); stores the transposed 4x4 (row stride ks = 4)
-__global__ void __launch_bounds__(PML_BLOCK)
+PML_GLOBAL void __launch_bounds__(PML_BLOCK)
 pij_hky_kernel(PmlTree t, PmlCols c, PmlModel m, double* __restrict__ P) {
     const int col = blockIdx.y;
     const size_t colN = (size_t)col * t.N;
@@ -24,7 +24,7 @@ pij_hky_kernel(PmlTree t, PmlCols c, PmlModel m, double* __restrict__ P) {
 // One workgroup walks a chunk of branches of one column; A and Ainv^T are staged once in LDS (rows padded by one
 // double against bank conflicts), exp(d t') per branch in LDS; thread e computes output element (i = e % k, j = e / k)
 // so that the transposed store Pt[j][i] is coalesced.
-__global__ void __launch_bounds__(PML_BLOCK)
+PML_GLOBAL void __launch_bounds__(PML_BLOCK)
 pij_eigen_kernel(PmlTree t, PmlCols c, PmlModel m, double* __restrict__ P, int branches_per_block, int use_lds) {
     extern __shared__ double smem[];
     const int k = c.k, ks = c.ks;
@@ -73,7 +73,7 @@ pij_eigen_kernel(PmlTree t, PmlCols c, PmlModel m, double* __restrict__ P, int b
 }
 
 // Explicit row-major P for a list of branch lengths (API get_Pij_t, tests): one thread per output element.
-__global__ void __launch_bounds__(PML_BLOCK)
+PML_GLOBAL void __launch_bounds__(PML_BLOCK)
 pij_explicit_kernel(PmlCols c, PmlModel m, int col, int n_t, const double* __restrict__ ts, double* __restrict__ out) {
     const int k = c.k;
     const size_t total = (size_t)n_t * k * k;
