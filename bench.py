@@ -211,52 +211,6 @@ def fused_height(flat, stored):
     return fh
 
 
-def general_two_level_nodes(flat, stored, cherry, gone, fh):
-    """
-    The general two-level units of the library (pml_tree_upload, round 4), restated: a stored node of fused height 1 --
-    its children are tips and cherries -- with at most two children and cherries of at most four tips is ABSORBED by its
-    parent when the parent has at most two children (cherries of at most four tips), sits on a level of at most 65 536
-    nodes, is not taken by a two-level unit of the balanced kind (`gone`) and ALL its stored children can be absorbed.
-    Off unless PASTML_HIP_ABSORB_MIN = n is given (then: from n absorbed nodes on) -- they do not pay, profiles/r04c_*.
-    Returns (absorbing, absorbed) boolean arrays.
-    """
-    N = flat.n_nodes
-    nc = np.asarray(flat.n_children)
-    fc = np.asarray(flat.first_child)
-    absorbing = np.zeros(N, dtype=bool)
-    absorbed = np.zeros(N, dtype=bool)
-    if os.environ.get('PASTML_HIP_NO_ABSORB') or os.environ.get('PASTML_HIP_NO_SUPER') or not stored.any() \
-            or 'PASTML_HIP_ABSORB_MIN' not in os.environ:
-        return absorbing, absorbed
-    level_size = np.bincount(fh[stored], minlength=int(fh.max()) + 1)
-    big_cherry = np.zeros(N, dtype=bool)      # some cherry among the first two children has more than four tips
-    for j in (0, 1):
-        idx = np.flatnonzero(nc > j)
-        ch = fc[idx] + j
-        big_cherry[idx] |= cherry[ch] & (nc[ch] > 4)
-    small = (nc <= 2) & ~big_cherry
-    cand = np.flatnonzero(stored & (fh >= 2) & ~gone & small & (level_size[fh] <= 65536))
-    some = np.zeros(len(cand), dtype=bool)
-    every = np.ones(len(cand), dtype=bool)
-    for j in (0, 1):
-        has = nc[cand] > j
-        ch = np.where(has, fc[cand] + j, 0)
-        is_stored = has & stored[ch]
-        ok = is_stored & (fh[ch] == 1) & ~gone[ch] & small[ch]
-        some |= ok
-        every &= ~is_stored | ok
-    parents = cand[some & every]
-    absorbing[parents] = True
-    for j in (0, 1):
-        has = nc[parents] > j
-        ch = fc[parents[has]] + j
-        absorbed[ch[stored[ch]]] = True
-    if int(absorbed.sum()) < int(os.environ['PASTML_HIP_ABSORB_MIN']):
-        absorbing[:] = False
-        absorbed[:] = False
-    return absorbing, absorbed
-
-
 def stacked_nodes(flat, stored, sup, absorbed, fh=None):
     """
     The nodes the library runs as stacked units (pml_tree_upload) once the two-level nodes `sup` (whose
@@ -336,16 +290,13 @@ def schedule_bytes(flat, k, n_cols, narrow_limit=None):
     wide = 17 <= k <= 64 and not os.environ.get('PASTML_HIP_NO_SUPER')
     level_schedule = not (N <= 2048 or (256 < int(stored.sum()) <= 131072 and int(stored.sum()) * n_cols <= 160000))
     fh = fused_height(flat, stored) if wide else None
-    # general two-level units (round 4): stored nodes without stored children absorbed by their parents
-    g_absorbing, g_absorbed = (general_two_level_nodes(flat, stored, cherry, gone, fh) if wide and level_schedule
-                               else (np.zeros(N, dtype=bool), np.zeros(N, dtype=bool)))
-    stacked, taken = (stacked_nodes(flat, stored, sup, absorbed | g_absorbed | g_absorbing, fh) if wide
+    stacked, taken = (stacked_nodes(flat, stored, sup, absorbed, fh) if wide
                       else (np.zeros(N, dtype=bool), np.zeros(N, dtype=bool)))
-    if n_sup == 0 and not g_absorbed.any() and stacked.any() and not level_schedule:
+    if n_sup == 0 and stacked.any() and not level_schedule:
         stacked[:] = False                              # (the level schedule is not used at all: two_level_nodes' rule)
         taken[:] = False
     n_stack = int(stacked.sum())
-    gone = gone | stacked | taken | g_absorbing | g_absorbed
+    gone = gone | stacked | taken
     unit = stored & ~gone                               # units of the level kernels
     nonroot = parent >= 0
     pmask = np.zeros(N, dtype=bool)
@@ -385,37 +336,6 @@ def schedule_bytes(flat, k, n_cols, narrow_limit=None):
     td_stack = n_stack * (32 + vec + 16) + 2 * n_stack * (32 + 64 + 2 * vec + 3 * (vec + 16))
     bu_levels += bu_stack                               # (they run between the level launches, in the same HIP-event slots)
     td_levels += td_stack
-    # general two-level units.  Children of the absorbing nodes / of the absorbed nodes by kind, tips of their cherries:
-    def family(mask):
-        kid = np.zeros(N, dtype=bool)
-        kid[nonroot] = mask[parent[nonroot]]
-        grand = np.zeros(N, dtype=bool)
-        grand[nonroot] = cherry[parent[nonroot]] & kid[gp[nonroot]]
-        return int(kid.sum()), int((kid & cherry).sum()), int(grand.sum())
-    n_gp, n_gc = int(g_absorbing.sum()), int(g_absorbed.sum())
-    p_kids, p_cherries, p_tips = family(g_absorbing)     # (the absorbed nodes are among p_kids)
-    c_kids, c_cherries, c_tips = family(g_absorbed)
-    own_td = g_absorbing.copy()                          # absorbing nodes with tips / cherries of their own to finish
-    own_td[g_absorbing] = nc[g_absorbing] > np.array([int(g_absorbed[fc[n]:fc[n] + nc[n]].sum()) for n in np.flatnonzero(g_absorbing)],
-                                                      dtype=np.int64) if n_gp else False
-    o_kids, o_cherries, o_tips = family(own_td)
-    o_kids -= int((g_absorbed & own_td[gp]).sum())       # (its absorbed children are skipped)
-    # bottom-up, per absorbing node: three descriptors (96), own mask (8), every child's E, mask, S, exponent (32), the tips
-    # of its cherries (24); per absorbed child: own mask (8), its children's scalars (32 each), the tips of its cherries
-    # (24); written: pi . v + exponent of the absorbed children (16) and of all cherries (16), the node's vector, pi . v,
-    # exponent (vec + 16)
-    bu_general = n_gp * (96 + 8 + vec + 16) + p_kids * 32 + p_tips * 24 + p_cherries * 16 \
-        + n_gc * (8 + 16) + c_kids * 32 + c_tips * 24 + c_cherries * 16
-    # top-down, per absorbed child: descriptor 32, its E, S, mask, exponent (32), its children's scalars (32 each), the tips
-    # of its cherries (24); the parent's row, sum, exponent (vec + 16) once per absorbing node; written: the rows, sums and
-    # exponents of the child, of its children and of the tips of its cherries.  The absorbing nodes' own units (those with
-    # tips / cherries of their own): descriptor 32, all children's scalars (32 each), the tips of their cherries (24);
-    # written: the rows of those children and tips
-    td_general = n_gc * (32 + 32 + vec + 16) + c_kids * (32 + vec + 16) + c_tips * (24 + vec + 16) + n_gp * (vec + 16) \
-        + int(own_td.sum()) * 32 + (o_kids + int((g_absorbed & own_td[gp]).sum())) * 32 + o_kids * (vec + 16) \
-        + o_tips * (24 + vec + 16)
-    bu_levels += bu_general
-    td_levels += td_general
     bu, td = bu_levels + bu_two, td_levels + td_two
     # per-branch data: dist in (8, read once per chunk of columns a thread walks: run_prep's cpy), E out (8); tips: mask
     # in (8 W), S out (8)
@@ -425,7 +345,6 @@ def schedule_bytes(flat, k, n_cols, narrow_limit=None):
     prep = N * (8 + 8.0 / cpy) + int(tip.sum()) * (8 * W + 8)
     return dict(bottom_up=bu, top_down=td, prep=prep, total=bu + td + prep, vec_bytes=vec, n_stored=int(stored.sum()),
                 n_cherries=int(cherry.sum()), n_tips=int(tip.sum()), n_two_level=n_sup, n_stacked=n_stack,
-                n_absorbed=n_gc, n_absorbing=n_gp,
                 bottom_up_levels=bu_levels, bottom_up_two_level=bu_two, top_down_levels=td_levels,
                 top_down_two_level=td_two, rows_two_level=14 * n_sup,
                 per_unit=dict(bottom_up=bu / (N * k), top_down=td / (N * k), prep=prep / (N * k)))
@@ -808,6 +727,11 @@ def secondary_measurements(device):
                                                       .format(flat.n_bu_levels), model_bytes=b,
                                                       achieved=b / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit='GB/s',
                                                       frac=b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS))
+    # ---- an optimisation of an eigen model with free frequencies: CUSTOM_RATES, k = 20, on the HIV1C
+    #      tree -- every point of every finite-difference gradient needs its own eigendecomposition on the host
+    #      (CustomRatesModel.py:62-68); host / device split, batched diagonalisation against one per point
+    if os.path.exists(nwk):
+        out['custom_rates_opt'] = custom_rates_optimisation(nwk)
     # ---- cfg4 with the observed tips' posteriors left implicit (PML_OPT_IMPLICIT_TIP_POSTERIORS): NOT the headline --
     #      the headline step writes the posterior row of every node; here the unit-vector rows of observed tips (half
     #      of all nodes of a binary tree) are not written by the sweep but when somebody reads the table.  Own byte model.
@@ -894,6 +818,71 @@ def secondary_measurements(device):
     return out
 
 
+def custom_rates_optimisation(nwk, k=20):
+    """acr() of one 20-state character under CUSTOM_RATES with free frequencies: seconds, and where they go."""
+    import tempfile
+    from pastml_amd.acr import acr
+    from pastml_amd.models import _eigen
+    from pastml_amd.tree import read_tree
+    rng = np.random.default_rng(11)
+    states = np.array(['s{:02d}'.format(i) for i in range(k)])
+    rates = np.triu(rng.uniform(0.2, 3.0, size=(k, k)), 1)
+    rates = rates + rates.T
+    weights = rng.dirichlet(np.ones(k) * 2)
+    fd, rate_file = tempfile.mkstemp(prefix='pastml_amd_rates_', suffix='.txt')
+    os.close(fd)
+    _eigen.save_matrix(states, rates, rate_file)
+    results = {}
+    try:
+        for label, env in (('per_point', '0'), ('batched', '1')):
+            os.environ['PASTML_AMD_EIG_BATCH'] = env
+            best = None
+            for _ in range(2):
+                tree = read_tree(nwk)
+                draw = np.random.default_rng(12)
+                for tip in tree:
+                    tip.add_feature('cr', {states[draw.choice(k, p=weights)]})
+                host = dict(s=0.0, calls=0, points=0)
+                plain = _eigen.CustomRatesModel.kernel_points
+
+                def timed_points(self, vectors, _plain=plain, _host=host):
+                    t0 = time.perf_counter()
+                    try:
+                        return _plain(self, vectors)
+                    finally:
+                        _host['s'] += time.perf_counter() - t0
+                        _host['calls'] += 1
+                        _host['points'] += len(vectors)
+                _eigen.CustomRatesModel.kernel_points = timed_points
+                try:
+                    np.random.seed(239)
+                    t0 = time.perf_counter()
+                    res = acr(tree, columns=['cr'], column2states={'cr': states}, prediction_method='MPPA', model='CUSTOM_RATES',
+                              column2rates={'cr': rate_file})[0]
+                    dt = time.perf_counter() - t0
+                finally:
+                    _eigen.CustomRatesModel.kernel_points = plain
+                if best is None or dt < best['seconds']:
+                    best = dict(seconds=dt, host_points_seconds=host['s'], point_batches=host['calls'], points=host['points'],
+                                ms_per_batch=host['s'] / max(1, host['calls']) * 1e3, log_likelihood=float(res['log_likelihood']))
+            results[label] = best
+    finally:
+        os.environ.pop('PASTML_AMD_EIG_BATCH', None)
+        os.unlink(rate_file)
+    a, b = results['per_point'], results['batched']
+    return dict(workload='CUSTOM_RATES, k={} with free frequencies ({} parameters), one character on the HIV1C tree (3 619 '
+                         'tips), MPPA: one acr() call; host = decoding the optimiser\'s points incl. the '
+                         'eigendecompositions (numpy LAPACK), the rest = device sweeps + L-BFGS-B'.format(k, k + 0),
+                seconds=b['seconds'], host_points_seconds=b['host_points_seconds'], ms_per_point_batch=b['ms_per_batch'],
+                point_batches=b['point_batches'], points=b['points'], log_likelihood=b['log_likelihood'],
+                per_point=a, speedup_host_points=a['host_points_seconds'] / b['host_points_seconds'],
+                speedup_total=a['seconds'] / b['seconds'], same_optimum=a['log_likelihood'] == b['log_likelihood'],
+                note='batched = the distinct frequency vectors of a batch of points diagonalised by ONE stacked '
+                     'numpy.linalg.eig / inv call (same LAPACK per matrix, same bits) and no re-diagonalisation of an '
+                     'unchanged vector; LAPACK itself (dgeev + dgesv, ~85 us per 20 x 20 matrix) is the floor: threads do not '
+                     'help (OpenBLAS serialises its small calls, profiles/r06c_eigen_host.txt)')
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 def main():
     args = parse_args()
@@ -977,8 +966,23 @@ def main():
     for _ in range(args.steps):
         total, lnl = step()
     fence()
-    dt = time.perf_counter() - t0
-    dt = float(comm.allreduce([dt], op='max')[0])
+    dt_own = time.perf_counter() - t0
+    dt = float(comm.allreduce([dt_own], op='max')[0])
+    # who ran where (every N > 1 line says it: the first run on a real multi-GPU node must be readable from its output):
+    # per-rank step time and device UUID -- two ranks with one UUID share a GPU --, and what the library's communicator is
+    per_rank = None
+    comm_report = dict(collective=comm.name)
+    if world > 1:
+        slots = np.zeros((world, 17))
+        slots[rank, 0] = dt_own / args.steps * 1e3
+        slots[rank, 1:] = list(bytes.fromhex(hip.device_uuid(gpu_index)))
+        slots = comm.allreduce(slots.ravel()).reshape(world, 17)
+        per_rank = [dict(rank=r, ms_per_step=float(slots[r, 0]), device_uuid=bytes(int(b) for b in slots[r, 1:]).hex())
+                    for r in range(world)]
+        comm_report['distinct_devices'] = len({p['device_uuid'] for p in per_rank})
+    if comm.name == 'rccl':
+        info = eng.comm_info()
+        comm_report.update(rccl_ranks=info['rccl_ranks'], backend=info['backend'], world=info['world'])
 
     # kernel time by HIP events on the library's stream: the level kernels' launches of the two sweeps (0, 1), the
     # per-branch pass (2), the launches of the two-level units (3 top-down, 4 bottom-up)
@@ -1090,7 +1094,8 @@ def main():
                        'tips': int(flat.n_tips), 'nodes': int(N), 'states': k, 'chars_per_gpu': cpg,
                        'chars_total': cpg * world, 'substitution_model': model,
                        'sharding': 'characters over ranks, no data-path collective; 1 all-reduce (8 B) per step',
-                       'collective': comm.name},
+                       'collective': comm.name, **{k_: v_ for k_, v_ in comm_report.items() if k_ != 'collective'}},
+            'per_rank': per_rank,
             'loglik_sum': total,
             'roofline': {
                 'bound': 'hbm', 'kernel': dom['name'],

@@ -115,8 +115,8 @@ int pml_schedule_info(pml_ctx* ctx, int32_t* level_schedule, int32_t* n_two_leve
  * Which of the schedules the marginal sweeps of the F81 family will take on this context (tree uploaded, columns
  * allocated; enqueue_bottom_up's own decision): the whole sweep in one launch (small forests), subtree blocks + the top
  * above them (mid-size forests; *n_blocks = their number), the level schedule with two-level / stacked units
- * (*n_absorbed = the stored nodes that the general two-level units keep out of memory, beside those pml_schedule_info
- * counts), plain level launches; PML_SCHEDULE_OTHER_MODEL for the matrix / eigen models.  For tests that compare schedules bit for bit: they
+ * (*n_absorbed: always 0 -- round 4's general two-level units for ragged trees lost their A/B twice and were removed in
+ * round 6; the argument is kept for binary compatibility), plain level launches; PML_SCHEDULE_OTHER_MODEL for the matrix / eigen models.  For tests that compare schedules bit for bit: they
  * assert that the schedule under test is the one that runs.
  */
 enum { PML_SCHEDULE_SINGLE_LAUNCH = 0, PML_SCHEDULE_BLOCKS = 1, PML_SCHEDULE_TWO_LEVEL = 2, PML_SCHEDULE_LEVELS = 3,
@@ -276,6 +276,15 @@ enum { PML_COMM_SUM = 0, PML_COMM_MAX = 1 };
 int pml_comm_unique_id(unsigned char* id_out /* [PML_COMM_ID_BYTES] */);
 int pml_comm_init(pml_ctx* ctx, int rank, int world, const unsigned char* id /* [PML_COMM_ID_BYTES] */);
 int pml_comm_destroy(pml_ctx* ctx);
+/*
+ * What the attached communicator is, for a run's report (bench.py prints it in every N > 1 line so that the first run on a
+ * real 8-GPU node can be read without a debugger): *rank, *world as given to pml_comm_init; *backend = 0 for a world of one
+ * without librccl, 1 for RCCL; *rccl_ranks = what ncclCommCount says of the communicator (0 when backend == 0, -1 when the
+ * loaded librccl has no ncclCommCount).  pml_device_uuid: the 16 bytes of hipDeviceGetUuid as 32 hex digits + NUL --
+ * two ranks that report the same UUID share a GPU.
+ */
+int pml_comm_info(pml_ctx* ctx, int32_t* rank, int32_t* world, int32_t* backend, int32_t* rccl_ranks);
+int pml_device_uuid(int device, char* uuid_out /* [33] */);
 /* out[i] = sum / max over the ranks of in[i]; in and out are host arrays of count doubles (may alias); collective */
 int pml_comm_allreduce(pml_ctx* ctx, const double* in, double* out, int32_t count, int op);
 /*

@@ -683,6 +683,15 @@ FD_IN_LIBRARY = os.environ.get('PASTML_AMD_FD_IN_LIBRARY', '1') != '0'
 TRACE = None
 
 
+_WARNED = set()
+
+
+def _warn_once(text):
+    if text not in _WARNED:
+        _WARNED.add(text)
+        logging.getLogger('pastml').warning(text)
+
+
 def lbfgsb_steps(x0, bounds, iterates=None, continue_factor=None):
     """
     Generator form of ``minimize(fun, x0, method='L-BFGS-B', bounds=bounds, jac=True)`` with scipy's default options
@@ -740,10 +749,17 @@ def lbfgsb_steps(x0, bounds, iterates=None, continue_factor=None):
                 task[0], task[1] = 5, 504
             elif nfev > maxfun:
                 task[0], task[1] = 5, 502
-        elif task[0] == 4 and task[1] == RELATIVE_REDUCTION and continue_factor and not continued \
-                and dsave[2] == factr * np.finfo(float).eps:
-            # the routine computes its tolerance (factr * epsmch) when it starts and keeps it in dsave[2] (checked above);
-            # entering again with NEW_X repeats the test that just fired, now at the tighter level, and goes on from there
+        elif task[0] == 4 and task[1] == RELATIVE_REDUCTION and continue_factor and not continued:
+            # the routine computes its tolerance (factr * epsmch) when it starts and keeps it in dsave[2]; entering again with
+            # NEW_X repeats the test that just fired, now at the tighter level, and goes on from there.  That is SciPy's private
+            # workspace layout (checked with SciPy 1.14.1 and 1.15.3): where the word is not what it should be the run ends
+            # here, as the reference's does -- said once, because the end of a many-parameter search then falls a few 1e-6
+            # short of what the continuation reaches (profiles/r05b_year_polish.txt)
+            if dsave[2] != factr * np.finfo(float).eps:
+                _warn_once('L-BFGS-B keeps its tolerance elsewhere in this SciPy build (dsave[2] = {!r}, expected {!r}): '
+                           'runs that stop on the relative-reduction test are not continued'
+                           .format(float(dsave[2]), factr * np.finfo(float).eps))
+                break
             continued = (n_iterations, float(fx))
             dsave[2] *= continue_factor
             task[0], task[1] = 1, 0
@@ -896,17 +912,17 @@ def _search_parameters_scipy(model, observed_frequencies, evaluate, rng):
             return np.nan
         return negative(evaluate([np.asarray(ps, dtype=np.float64)]))[0]
 
-    def objective_and_gradient(ps):
+    def objective_and_gradient(ps, step=1e-8):
         ps = np.asarray(ps, dtype=np.float64)
         if np.any(pd.isnull(ps)):
             return np.nan, np.full(len(ps), np.nan)
         asked = []
         _approx_derivative(lambda x: asked.append(np.array(x, dtype=np.float64)) or 0.0, ps, method='2-point',
-                           abs_step=1e-8, f0=0.0, bounds=(lower, upper))
+                           abs_step=step, f0=0.0, bounds=(lower, upper))
         values = negative(evaluate([ps] + asked))
         table = {x.tobytes(): v for x, v in zip(asked, values[1:])}
         gradient = _approx_derivative(lambda x: table[np.asarray(x, dtype=np.float64).tobytes()], ps,
-                                      method='2-point', abs_step=1e-8, f0=values[0], bounds=(lower, upper))
+                                      method='2-point', abs_step=step, f0=values[0], bounds=(lower, upper))
         return values[0], gradient
 
     frequencies_free = isinstance(model, ModelWithFrequencies) and model._optimise_frequencies
@@ -927,16 +943,28 @@ def _search_parameters_scipy(model, observed_frequencies, evaluate, rng):
             x0 = start_observed
         else:
             x0 = rng.uniform(lower, upper)
-        def run(options=None):
-            if batched:
-                return minimize(objective_and_gradient, x0=x0, method='L-BFGS-B', bounds=bounds, jac=True, options=options)
-            return minimize(objective, x0=x0, method='L-BFGS-B', bounds=bounds, options=options)
-        found = run()
-        # (the continuation of lbfgsb_steps, in the only form scipy's own driver offers: the run again from its start with
-        # the tighter ftol -- the same iterates up to where the first run stopped, then the ones the continuation makes)
-        if found.success and 'RELATIVE REDUCTION OF F' in str(found.message) and len(found.x) >= CONTINUE_MIN_PARAMETERS:
-            found = run(dict(ftol=2.220446049250313e-09 * CONTINUE_FTOL_FACTOR))
+        def minimise(x0, step=1e-8):
+            # one L-BFGS-B run from x0 -- the same rule as search_parameters_steps.minimise: a run of a many-parameter search
+            # that stops on the relative-reduction test is continued (CONTINUE = 1: every run, 2: the polish run only), in
+            # the only form scipy's own driver offers: the run again from its start with the tighter ftol -- the same
+            # iterates up to where the first run stopped, then the ones the continuation makes
+            def run(options=None):
+                if batched:
+                    return minimize(lambda ps: objective_and_gradient(ps, step), x0=x0, method='L-BFGS-B', bounds=bounds,
+                                    jac=True, options=options)
+                return minimize(objective, x0=x0, method='L-BFGS-B', bounds=bounds,
+                                options=dict(options or {}, eps=step))
+            found = run()
+            goes_on = len(x0) >= CONTINUE_MIN_PARAMETERS and (CONTINUE == 1 or (CONTINUE == 2 and step != 1e-8))
+            if goes_on and found.success and 'RELATIVE REDUCTION OF F' in str(found.message):
+                found = run(dict(ftol=2.220446049250313e-09 * CONTINUE_FTOL_FACTOR))
+            return found
+        found = minimise(x0)
         if found.success and not np.any(np.isnan(found.x)) and -found.fun >= to_beat:
+            if POLISH_STEP and len(found.x) >= CONTINUE_MIN_PARAMETERS:   # (the polish of search_parameters_steps)
+                polished = minimise(found.x, POLISH_STEP)
+                if not np.any(np.isnan(polished.x)) and polished.fun < found.fun:
+                    found = polished
             model.set_params_from_optimised(found.x)
             return -found.fun
     model.set_params_from_optimised(start_current if lnl_current >= lnl_observed else start_observed)

@@ -1,5 +1,6 @@
 // libpastml_hip.so -- C-ABI (include/pastml_hip.h) over the HIP kernels: contexts, tree upload and schedules, the sweeps'
 // launch sequences, downloads, the communicator.  The kernel families are launched through pml_launch.h.  gfx950 only.
+#define PML_PLAIN_KERNELS   // the kernels that are not templates are this unit's (pml_device.h, PML_GLOBAL)
 #include "pml_launch.h"
 #include "pml_kernels_counts.h"
 #include "pml_comm.h"
@@ -111,9 +112,53 @@ static inline bool permuted(const pml_ctx* ctx) { return !ctx->old_of_new.empty(
 template <typename T>
 static void rows_to_api_inplace(const pml_ctx* ctx, T* buf, size_t width, size_t n_cols) {
     if (!permuted(ctx) || buf == nullptr) return;
-    const std::vector<T> tmp(buf, buf + n_cols * (size_t)ctx->N * width);
-    rows_to_api(ctx, tmp.data(), buf, width, n_cols);
+    const size_t col = (size_t)ctx->N * width;
+    std::vector<T> tmp(col);   // (a column at a time: the table is never held twice)
+    for (size_t c = 0; c < n_cols; ++c) {
+        std::copy(buf + c * col, buf + (c + 1) * col, tmp.begin());
+        rows_to_api(ctx, tmp.data(), buf + c * col, width, 1);
+    }
 }
+// Per-node rows of n_cols columns from the device to the caller, in the caller's numbering: `width` elements of every row of
+// `src_width` (the device pads rows to ks).  A renumbered forest's rows are gathered on the device, a column at a time, into a
+// staging buffer of one column and copied from there -- no second copy of the table on the host, no serial host pass
+// (round 5 permuted on the host after the copy: +8.6 GB of host memory for 32 columns of 262 144 tips at k = 64).
+// Asynchronous on the ctx's stream; the caller synchronises.
+template <typename T>
+static int fetch_rows(pml_ctx* ctx, const T* d_src, size_t src_width, size_t width, size_t n_cols, T* out) {
+    static_assert(sizeof(T) % 4 == 0, "rows are moved in 4-byte words");
+    if (!out || n_cols == 0) return PML_OK;
+    const size_t N = (size_t)ctx->N;
+    if (!permuted(ctx)) {
+        if (src_width == width)
+            HIP_TRY(hipMemcpyAsync(out, d_src, n_cols * N * width * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+        else
+            HIP_TRY(hipMemcpy2DAsync(out, width * sizeof(T), d_src, src_width * sizeof(T), width * sizeof(T), n_cols * N,
+                                     hipMemcpyDeviceToHost, ctx->stream));
+        return PML_OK;
+    }
+    const size_t col_bytes = N * width * sizeof(T);
+    if (ctx->stage_bytes < col_bytes) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (ctx->d_stage) (void)hipFree(ctx->d_stage);
+        ctx->d_stage = nullptr;
+        ctx->stage_bytes = 0;
+        HIP_TRY(hipMalloc(&ctx->d_stage, col_bytes));
+        ctx->stage_bytes = col_bytes;
+    }
+    const int wd = (int)(width * sizeof(T) / 4), ws = (int)(src_width * sizeof(T) / 4);
+    const long long total = (long long)N * wd;
+    const int blocks = (int)std::min<long long>((total + PML_BLOCK - 1) / PML_BLOCK, 65536);
+    for (size_t c = 0; c < n_cols; ++c) {
+        hipLaunchKernelGGL(gather_rows_kernel, dim3(blocks), dim3(PML_BLOCK), 0, ctx->stream,
+                           (const unsigned*)(d_src + c * N * src_width), (unsigned*)ctx->d_stage, ctx->d_new_of_old, (long long)N, wd,
+                           ws, 0, 1);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(out + c * N * width, ctx->d_stage, col_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    return PML_OK;
+}
+
 static inline int api_id(const pml_ctx* ctx, int internal) { return permuted(ctx) && internal >= 0 ? ctx->old_of_new[internal] : internal; }
 static inline int internal_id(const pml_ctx* ctx, int api) { return permuted(ctx) && api >= 0 ? ctx->new_of_old[api] : api; }
 
@@ -181,8 +226,6 @@ int pml_ctx_destroy(pml_ctx* ctx) {
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     prof_release(ctx);
-    for (hipEvent_t e : ctx->split_ev) (void)hipEventDestroy(e);
-    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return PML_OK;
@@ -305,7 +348,7 @@ int pml_sweep_schedule(pml_ctx* ctx, int32_t* kind, int32_t* n_blocks, int32_t* 
     ctx->kind = model;
     if (kind) *kind = k;
     if (n_blocks) *n_blocks = k == PML_SCHEDULE_BLOCKS ? ctx->blocks.n_blocks : 0;
-    if (n_absorbed) *n_absorbed = k == PML_SCHEDULE_TWO_LEVEL ? ctx->sup.n_absorbed : 0;
+    if (n_absorbed) *n_absorbed = 0;  // (the general two-level units of round 4 are gone: include/pastml_hip.h)
     return PML_OK;
 }
 
@@ -486,12 +529,7 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
                implicit_tips = ctx->implicit_tips;
     PmlComm* comm = ctx->comm;
     const PmlTune tune = ctx->tune;
-    hipStream_t stream2 = ctx->stream2;
-    std::vector<hipEvent_t> split_ev;
-    split_ev.swap(ctx->split_ev);
     *ctx = pml_ctx();
-    ctx->stream2 = stream2;
-    ctx->split_ev.swap(split_ev);
     ctx->tune = tune;
     ctx->fuse = fuse;
     ctx->keep_td = keep_td;
@@ -525,6 +563,12 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
     PML_TRY(dev_alloc(ctx, &ctx->d_bu_order, n_internal));
     PML_TRY(dev_alloc(ctx, &ctx->d_td_parents, n_internal));
     PML_TRY(upload(ctx, ctx->d_parent, parent, n_nodes));
+    if (permuted(ctx)) {
+        PML_TRY(dev_alloc(ctx, &ctx->d_new_of_old, n_nodes));
+        PML_TRY(dev_alloc(ctx, &ctx->d_old_of_new, n_nodes));
+        PML_TRY(upload(ctx, ctx->d_new_of_old, ctx->new_of_old.data(), n_nodes));
+        PML_TRY(upload(ctx, ctx->d_old_of_new, ctx->old_of_new.data(), n_nodes));
+    }
     PML_TRY(upload(ctx, ctx->d_first_child, first_child, n_nodes));
     PML_TRY(upload(ctx, ctx->d_n_children, n_children, n_nodes));
     PML_TRY(upload(ctx, ctx->d_post_rank, post_rank, n_nodes));
@@ -890,58 +934,6 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
                     u.pad = first_child[u.cfc[0]];
                     us[q] = u;
                 }
-                // General two-level units (round 4; pml_kernels_f81.h): what is left of the lowest fused level -- stored nodes
-                // whose children are tips and cherries, at most two of them, cherries of at most four tips -- is absorbed by
-                // the parents, whatever their level and shape (at most two children, stored ones among them in memory or
-                // absorbed; on levels of at most 65 536 nodes: the lane shape of the levels they leave).
-                // OFF unless PASTML_HIP_ABSORB_MIN = n is given (then: from n absorbed nodes on): measured on the random
-                // 262 144-tip tree x 32 characters, k = 64, they take 22 % of the stored nodes and 11 % of the modelled bytes
-                // out of the sweeps -- and the marginal pass takes the same 5.8 ms (profiles/r04c_*): bottom-up -5 %, top-down
-                // +2 %; the units that rebuild a node and go on with its children are bound by their dependent instruction
-                // chain (0.84 ns per unit and column against 0.63 for the plain units they replace), not by the bytes.
-                std::vector<char> absorbed(n_nodes, 0), absorbing(n_nodes, 0);
-                std::vector<int> absorbing_list, absorbed_list;
-                if (!ctx->tune.on(T_NO_ABSORB) && ctx->tune.on(T_ABSORB_MIN)) {
-                    auto level_size_of = [&](int node) { return off[fh[node]] - off[fh[node] - 1]; };
-                    auto small_unit = [&](int i) {   // what the lane-parallel gather of an 8-lane unit takes
-                        if (n_children[i] > 2) return false;
-                        for (int j = 0; j < n_children[i]; ++j) {
-                            const int ch = first_child[i] + j;
-                            if (kind[ch] == PML_KIND_CHERRY && n_children[ch] > 4) return false;
-                        }
-                        return true;
-                    };
-                    for (int q = 0; q < n_stored; ++q) {
-                        const int n = order[q];
-                        if (fh[n] < 2 || gone[n] || !small_unit(n) || level_size_of(n) > 65536) continue;
-                        // (every stored child must go: the node's own top-down unit then finishes tips and cherries only, and
-                        // nothing below depends on it -- it runs behind the depth launches, like its children's units)
-                        bool any = false, all = true;
-                        for (int j = 0; j < n_children[n]; ++j) {
-                            const int ch = first_child[n] + j;
-                            if (kind[ch] != PML_KIND_STORED) continue;
-                            const bool ok = fh[ch] == 1 && !gone[ch] && small_unit(ch);
-                            any |= ok;
-                            all &= ok;
-                        }
-                        if (!any || !all) continue;
-                        absorbing[n] = 1;
-                        for (int j = 0; j < n_children[n]; ++j)
-                            if (kind[first_child[n] + j] == PML_KIND_STORED) absorbed[first_child[n] + j] = 1;
-                    }
-                    int n_abs = 0;
-                    for (int i = 0; i < n_nodes; ++i) n_abs += absorbed[i];
-                    if (n_abs < (int)ctx->tune.get(T_ABSORB_MIN, 64)) {
-                        std::fill(absorbed.begin(), absorbed.end(), 0);
-                        std::fill(absorbing.begin(), absorbing.end(), 0);
-                    }
-                    for (int q = 0; q < n_stored; ++q) {
-                        if (absorbing[order[q]]) absorbing_list.push_back(order[q]);   // (bottom-up level order)
-                        if (absorbed[order[q]]) absorbed_list.push_back(order[q]);
-                    }
-                    for (int c2 : absorbed_list) gone[c2] = 1;   // (neither sweep's lists hold them)
-                    for (int n2 : absorbing_list) gone[n2] = 1;  // (... nor the absorbing nodes: launches of their own)
-                }
                 // stacked units: ascending height, a node takes its two children over when both are plain units (not
                 // two-level nodes, not taken over, not stacked themselves) with two stored children whose vectors are in
                 // memory; only on levels of 1 024 .. 65 536 nodes (below: the narrow end's single launch; above: the
@@ -952,16 +944,15 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
                 const int stack_min = (int)ctx->tune.get(T_STACK_MIN, 1024);
                 if (!ctx->tune.on(T_NO_STACK)) {
                     for (int n : sup_list) novec[first_child[n]] = novec[first_child[n] + 1] = 1;
-                    for (int c2 : absorbed_list) novec[c2] = 1;
                     auto level_size = [&](int node) { return off[fh[node]] - off[fh[node] - 1]; };
                     auto has_vec = [&](int g) { return kind[g] == PML_KIND_STORED && !novec[g]; };
                     auto plain2 = [&](int ch) {
-                        return kind[ch] == PML_KIND_STORED && !gone[ch] && !absorbing[ch] && !stacked[ch] && !taken[ch] && n_children[ch] == 2 &&
+                        return kind[ch] == PML_KIND_STORED && !gone[ch] && !stacked[ch] && !taken[ch] && n_children[ch] == 2 &&
                                has_vec(first_child[ch]) && has_vec(first_child[ch] + 1) && level_size(ch) <= 65536;
                     };
                     for (int q = 0; q < n_stored; ++q) {
                         const int n = order[q];
-                        if (gone[n] || absorbing[n] || taken[n] || n_children[n] != 2 || level_size(n) < stack_min || level_size(n) > 65536) continue;
+                        if (gone[n] || taken[n] || n_children[n] != 2 || level_size(n) < stack_min || level_size(n) > 65536) continue;
                         const int a = first_child[n], b = a + 1;
                         if (!plain2(a) || !plain2(b)) continue;
                         stacked[n] = 1;
@@ -1009,7 +1000,7 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
                     U.n_stack = (int)stack_list.size();
                     if (ctx->tune.on(T_DEBUG)) fprintf(stderr, "pastml_hip: %d stacked units\n", U.n_stack);
                 }
-                if (!sup_list.empty() || !stack_list.empty() || !absorbed_list.empty()) {  // (else: the plain level lists, nothing to build)
+                if (!sup_list.empty() || !stack_list.empty()) {  // (else: the plain level lists, nothing to build)
                 // rest lists: the level structure of the fused lists, without the nodes the two-level units take over
                 std::vector<int> bu_r, td_r;
                 U.bu_offsets_r.assign(1, 0);
@@ -1031,7 +1022,6 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
                         ch_list.push_back(first_child[n]);
                         ch_list.push_back(first_child[n] + 1);
                     }
-                    for (int c2 : absorbed_list) ch_list.push_back(c2);
                     U.n_child_units = (int)ch_list.size();
                     describe(ch_list.data(), (int)ch_list.size(), true, uch);  // (at least one element)
                     PML_TRY(dev_alloc(ctx, &U.d_child_units, uch.size()));
@@ -1039,87 +1029,6 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
                 }
                 describe(bu_r.data(), (int)bu_r.size(), true, ubr);
                 describe(td_r.data(), (int)td_r.size(), true, utr);
-                if (!absorbed_list.empty()) {
-                    // top-down records of the absorbing nodes that have tips or cherries of their own to finish: an absorbed
-                    // child is skipped there (PML_CODE_ABSORBED; its slot of cfc points at the node itself, so that the gather
-                    // of "its tips" reads valid addresses: an absorbed child has at least three descendants after the node in
-                    // the numbering)
-                    std::vector<int> own_td;
-                    for (int n : absorbing_list) {
-                        bool other = false;
-                        for (int j = 0; j < n_children[n]; ++j) other |= !absorbed[first_child[n] + j];
-                        if (other) own_td.push_back(n);
-                    }
-                    std::vector<PmlUnit> uown;
-                    describe(own_td.data(), (int)own_td.size(), true, uown);
-                    for (size_t q = 0; q < own_td.size(); ++q) {
-                        const int n = own_td[q];
-                        for (int j = 0; j < n_children[n] && j < 4; ++j)
-                            if (absorbed[first_child[n] + j]) {
-                                uown[q].packed = (uown[q].packed & ~(7 << (8 + 3 * j))) | (PML_CODE_ABSORBED << (8 + 3 * j));
-                                uown[q].cfc[j] = n;
-                            }
-                    }
-                    std::stable_sort(uown.begin(), uown.begin() + own_td.size(), shape_less);
-                    PML_TRY(dev_alloc(ctx, &U.d_absorbing_td, uown.size()));
-                    PML_TRY(upload(ctx, U.d_absorbing_td, uown.data(), uown.size()));
-                    U.n_absorbing_td = (int)own_td.size();
-                    // bottom-up: the absorbing nodes by level, three records each, one shape next to the other
-                    std::vector<PmlUnit> own, kids;
-                    describe(absorbing_list.data(), (int)absorbing_list.size(), true, own);
-                    struct Triple { PmlUnit r[3]; };
-                    std::vector<Triple> triples(absorbing_list.size());
-                    U.absorb_bu_offsets.assign(max_h + 1, 0);
-                    for (size_t q = 0; q < absorbing_list.size(); ++q) {
-                        const int n = absorbing_list[q];
-                        ++U.absorb_bu_offsets[fh[n]];
-                        Triple& T = triples[q];
-                        T.r[0] = own[q];
-                        T.r[0].pad = 0;
-                        for (int j = 0; j < 2; ++j) {
-                            T.r[1 + j] = own[q];
-                            if (j < n_children[n] && absorbed[first_child[n] + j]) {
-                                const int c2 = first_child[n] + j;
-                                std::vector<PmlUnit> one;
-                                describe(&c2, 1, true, one);
-                                T.r[1 + j] = one[0];
-                                T.r[0].pad |= 1 << j;
-                            }
-                        }
-                    }
-                    for (int l = 0; l < max_h; ++l) U.absorb_bu_offsets[l + 1] += U.absorb_bu_offsets[l];
-                    // (absorb_bu_offsets[l] .. [l + 1]: the units of bottom-up level l = fused height l + 1; the counts above
-                    // were filed under the height)
-                    for (int l = 0; l < max_h; ++l) {
-                        const size_t a = (size_t)U.absorb_bu_offsets[l], b = (size_t)U.absorb_bu_offsets[l + 1];
-                        std::stable_sort(triples.begin() + a, triples.begin() + b, [](const Triple& x, const Triple& y) {
-                            if (x.r[0].pad != y.r[0].pad) return x.r[0].pad < y.r[0].pad;
-                            if (x.r[0].packed != y.r[0].packed) return x.r[0].packed < y.r[0].packed;
-                            if (x.r[1].packed != y.r[1].packed) return x.r[1].packed < y.r[1].packed;
-                            return x.r[2].packed < y.r[2].packed;
-                        });
-                    }
-                    std::vector<PmlUnit> flat3;
-                    flat3.reserve(3 * triples.size() + 3);
-                    for (const Triple& T : triples)
-                        for (int j = 0; j < 3; ++j) flat3.push_back(T.r[j]);
-                    // top-down: one record per absorbed node, pad = the parent, one shape next to the other
-                    std::vector<PmlUnit> down;
-                    describe(absorbed_list.data(), (int)absorbed_list.size(), true, down);
-                    down.resize(absorbed_list.size());
-                    for (size_t q = 0; q < absorbed_list.size(); ++q) down[q].pad = parent[absorbed_list[q]];
-                    std::stable_sort(down.begin(), down.end(), shape_less);
-                    PML_TRY(dev_alloc(ctx, &U.d_absorb_bu, flat3.size()));
-                    PML_TRY(dev_alloc(ctx, &U.d_absorb_td, down.size()));
-                    PML_TRY(upload(ctx, U.d_absorb_bu, flat3.data(), flat3.size()));
-                    PML_TRY(upload(ctx, U.d_absorb_td, down.data(), down.size()));
-                    HIP_TRY(hipStreamSynchronize(ctx->stream));
-                    U.n_absorbing = (int)absorbing_list.size();
-                    U.n_absorbed = (int)absorbed_list.size();
-                    if (ctx->tune.on(T_DEBUG))
-                        fprintf(stderr, "pastml_hip: %d of %d stored nodes absorbed by %d parents\n", U.n_absorbed, n_stored,
-                                U.n_absorbing);
-                }
                 U.bu_level_vec_r.assign(max_h > 0 ? max_h : 1, 0);
                 for (int l = 0; l < max_h; ++l)
                     for (int q = U.bu_offsets_r[l]; q < U.bu_offsets_r[l + 1] && !U.bu_level_vec_r[l]; ++q) {
@@ -1152,7 +1061,7 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
                 HIP_TRY(hipStreamSynchronize(ctx->stream));  // the vectors go out of scope
                 U.n = (int)sup_list.size();
                 // worth its lists: two-level units, or stacked units that take a sixteenth of the stored nodes over
-                U.ok = U.n > 0 || U.n_absorbed > 0 || U.n_stack >= 64 || (U.n_stack > 0 && ctx->tune.on(T_STACK_MIN));
+                U.ok = U.n > 0 || U.n_stack >= 64 || (U.n_stack > 0 && ctx->tune.on(T_STACK_MIN));
                 if (ctx->tune.on(T_DEBUG))
                     fprintf(stderr, "pastml_hip: %d two-level units (%d of %d stored nodes)%s\n", U.n, 3 * U.n, n_stored,
                             U.ok ? "" : " -- plain level lists");
@@ -2145,11 +2054,6 @@ static int enqueue_bottom_up(pml_ctx* ctx, int is_marginal, bool small_path, boo
                 tail = std::min(tail, nl - 1 - l);
                 break;
             }
-        for (int l = nl - 1; l >= 0 && U.n_absorbed > 0; --l)   // (... and above the last level with absorbing nodes)
-            if (U.absorb_bu_offsets[l + 1] > U.absorb_bu_offsets[l]) {
-                tail = std::min(tail, nl - 1 - l);
-                break;
-            }
         if (tail < 2) tail = 0;
         long long n_launch = 0;
         for (int l = 0; l < nl - tail; ++l) {
@@ -2165,11 +2069,6 @@ static int enqueue_bottom_up(pml_ctx* ctx, int is_marginal, bool small_path, boo
             // the level's stacked units (they read vectors of two levels down: independent of the launch above)
             if (U.n_stack > 0 && U.stack_bu_offsets[l + 1] > U.stack_bu_offsets[l]) {
                 PML_TRY(dispatch_stack_f81(ctx, true, l));
-                ++n_launch;
-            }
-            // the level's absorbing nodes (what they read of stored nodes is of lower levels: independent as well)
-            if (U.n_absorbed > 0 && U.absorb_bu_offsets[l + 1] > U.absorb_bu_offsets[l]) {
-                PML_TRY(dispatch_absorb_f81(ctx, true, l));
                 ++n_launch;
             }
         }
@@ -2319,7 +2218,7 @@ static int enqueue_bottom_up(pml_ctx* ctx, int is_marginal, bool small_path, boo
 
 // Captures fn's stream work once and replays it afterwards; falls back to direct submission if capture fails.
 static int run_captured(pml_ctx* ctx, pml_ctx::GraphSlot& slot, const std::function<int()>& enqueue) {
-    if (ctx->in_outer_capture || ctx->windowed) return enqueue();  // part of a larger capture / of a split pass
+    if (ctx->in_outer_capture) return enqueue();  // part of a larger capture
     if (slot.exec && slot.has_init != ctx->has_init) drop_graph(slot);
     if (!slot.exec) {
         HIP_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
@@ -2588,10 +2487,7 @@ static int run_top_down(pml_ctx* ctx) {
             PML_TRY(prof_end(ctx, 1, n_launch));
             PML_TRY(prof_begin(ctx));
             PML_TRY(dispatch_super_f81(ctx, false));
-            // the absorbed nodes' units: each needs its parent's row only (a unit of the rest lists, a two-level unit is
-            // never its parent)
-            PML_TRY(dispatch_absorb_f81(ctx, false, 0));
-            PML_TRY(prof_end(ctx, 3, (U.n > 0 ? 1 : 0) + (U.n_absorbed > 0 ? 1 : 0) + (U.n_absorbed > 0 && U.n_absorbing_td > 0 ? 1 : 0)));
+            PML_TRY(prof_end(ctx, 3, U.n > 0 ? 1 : 0));
             return PML_OK;
         }
         // F81 family: the roots and the levels right below them in one launch
@@ -2754,28 +2650,17 @@ static int fetch_marginals(pml_ctx* ctx, double* posterior_out, double* lh_sum_o
     const size_t CN = (size_t)ctx->C * ctx->N;
     if (posterior_out) {
         PML_TRY(materialize_tip_posteriors(ctx));
-        if (ctx->ks == ctx->k) {
-            HIP_TRY(hipMemcpyAsync(posterior_out, ctx->d_post, CN * ctx->k * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        } else {
-            HIP_TRY(hipMemcpy2DAsync(posterior_out, ctx->k * sizeof(double), ctx->d_post, ctx->ks * sizeof(double),
-                                     ctx->k * sizeof(double), CN, hipMemcpyDeviceToHost, ctx->stream));
-        }
+        PML_TRY(fetch_rows(ctx, ctx->d_post, (size_t)ctx->ks, (size_t)ctx->k, (size_t)ctx->C, posterior_out));
     }
-    if (lh_sum_out)
-        HIP_TRY(hipMemcpyAsync(lh_sum_out, ctx->d_lhsum, CN * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    std::vector<i64> lhe;
-    if (lh_sf_out) {
-        lhe.resize(CN);
-        HIP_TRY(hipMemcpyAsync(lhe.data(), ctx->d_lhe, CN * sizeof(i64), hipMemcpyDeviceToHost, ctx->stream));
-    }
+    PML_TRY(fetch_rows(ctx, ctx->d_lhsum, 1, 1, (size_t)ctx->C, lh_sum_out));
+    // (the exponents arrive in the output array itself -- same width -- and are converted in place)
+    PML_TRY(fetch_rows(ctx, ctx->d_lhe, 1, 1, (size_t)ctx->C, reinterpret_cast<i64*>(lh_sf_out)));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (lh_sf_out) {
         const double l2 = std::log10(2.0);
-        for (size_t i = 0; i < CN; ++i) lh_sf_out[i] = -(double)lhe[i] * l2;
+        const i64* e = reinterpret_cast<const i64*>(lh_sf_out);
+        for (size_t i = 0; i < CN; ++i) lh_sf_out[i] = -(double)e[i] * l2;
     }
-    rows_to_api_inplace(ctx, posterior_out, (size_t)ctx->k, (size_t)ctx->C);
-    rows_to_api_inplace(ctx, lh_sum_out, 1, (size_t)ctx->C);
-    rows_to_api_inplace(ctx, lh_sf_out, 1, (size_t)ctx->C);
     return PML_OK;
 }
 
@@ -2784,150 +2669,6 @@ int pml_top_down_marginals(pml_ctx* ctx, double* posterior_out, double* lh_sum_o
     if (ctx->bu_mode != 1) return fail(PML_ERR_INVALID, "pml_top_down_marginals needs a successful marginal pml_bottom_up first");
     PML_TRY(run_top_down(ctx));
     return fetch_marginals(ctx, posterior_out, lh_sum_out, lh_sf_out);
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Marginal pass of a large forest in PARTS of its columns, on two streams.  Columns are independent, and on a large forest
-// the two sweeps are bound by different things -- the bottom-up launches by their instruction stream, the top-down ones
-// by the rate at which posterior rows can be written -- so part i + 1's bottom-up sweep runs while part i's top-down
-// sweep does: every part's bottom-up sweep waits for the one before it (an event), its top-down sweep follows it on the
-// part's own stream (parts alternate between the ctx's stream and a second one), and the ctx's stream waits for all of
-// them at the end.  A part sees a WINDOW of the columns: every per-column base pointer moved to its first column, C = its
-// width -- the kernels are the same, and a column's bits do not depend on how many columns share its launches (the lane
-// shapes follow k and the level sizes, multi_level_shape).  PASTML_HIP_SPLIT_PARTS = n: n parts (0 / 1: off).
-// ---------------------------------------------------------------------------------------------------------------------
-struct ColumnWindow {
-    pml_ctx* c;
-    u64 *masks, *masks_init, *err, *h_err;
-    double *pi, *sf, *tau, *tauf, *mu, *kappa, *active, *E, *bu, *S, *td, *post, *lhsum, *h_loglik;
-    i64 *be, *te, *lhe;
-    int C, sched_cols;
-    hipStream_t stream;
-    ColumnWindow(pml_ctx* ctx, int col0, int ncol, hipStream_t s)
-        : c(ctx), masks(ctx->d_masks), masks_init(ctx->d_masks_init), err(ctx->d_err), h_err(ctx->h_err), pi(ctx->d_pi),
-          sf(ctx->d_sf), tau(ctx->d_tau), tauf(ctx->d_tauf), mu(ctx->d_mu), kappa(ctx->d_kappa), active(ctx->d_active),
-          E(ctx->d_E), bu(ctx->d_bu), S(ctx->d_S), td(ctx->d_td), post(ctx->d_post), lhsum(ctx->d_lhsum),
-          h_loglik(ctx->h_loglik), be(ctx->d_be), te(ctx->d_te), lhe(ctx->d_lhe), C(ctx->C), sched_cols(ctx->sched_cols),
-          stream(ctx->stream) {
-        const size_t N = (size_t)ctx->N, ks = (size_t)ctx->ks, W = (size_t)ctx->W, o = (size_t)col0;
-        ctx->d_masks += o * N * W;
-        if (ctx->d_masks_init) ctx->d_masks_init += o * N * W;
-        ctx->d_pi += o * ks;
-        ctx->d_sf += o;
-        ctx->d_tau += o;
-        ctx->d_tauf += o;
-        ctx->d_mu += o;
-        ctx->d_kappa += o;
-        ctx->d_active += o;
-        ctx->d_E += o * N;
-        ctx->d_bu += o * N * ks;
-        ctx->d_S += o * N;
-        ctx->d_be += o * N;
-        if (ctx->d_td) ctx->d_td += o * N * ks;
-        if (ctx->d_te) ctx->d_te += o * N;
-        ctx->d_post += o * N * ks;
-        ctx->d_lhsum += o * N;
-        ctx->d_lhe += o * N;
-        ctx->d_err += o;
-        ctx->h_loglik += o;
-        ctx->h_err += o;
-        ctx->C = ncol;
-        ctx->sched_cols = ncol;
-        ctx->stream = s;
-        ctx->windowed = true;
-    }
-    ~ColumnWindow() {
-        c->d_masks = masks;
-        c->d_masks_init = masks_init;
-        c->d_pi = pi;
-        c->d_sf = sf;
-        c->d_tau = tau;
-        c->d_tauf = tauf;
-        c->d_mu = mu;
-        c->d_kappa = kappa;
-        c->d_active = active;
-        c->d_E = E;
-        c->d_bu = bu;
-        c->d_S = S;
-        c->d_be = be;
-        c->d_td = td;
-        c->d_te = te;
-        c->d_post = post;
-        c->d_lhsum = lhsum;
-        c->d_lhe = lhe;
-        c->d_err = err;
-        c->h_loglik = h_loglik;
-        c->h_err = h_err;
-        c->C = C;
-        c->sched_cols = sched_cols;
-        c->stream = stream;
-        c->windowed = false;
-    }
-};
-
-// how many parts the marginal pass of this context runs in (1: the plain pass)
-static int split_parts(pml_ctx* ctx) {
-    const int parts = (int)ctx->tune.get(T_SPLIT_PARTS, 1);   // (off unless asked for: measured, profiles/r05a_split_pass_ab.txt)
-    if (parts < 2 || ctx->kind != PML_MODEL_F81 || ctx->W != 1 ) return 1;
-    // only where the sweeps are the streaming level launches with enough work per part to fill the chip on their own
-    if (ctx->C < 4 * parts || (long long)ctx->N * (ctx->C / parts) < (4ll << 20)) return 1;
-    if (ctx->small || ctx->blocks.ok || single_launch_sweeps(ctx)) return 1;
-    return parts;
-}
-
-static int split_marginal_pass(pml_ctx* ctx, int parts) {
-    if (!ctx->stream2) HIP_TRY(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
-    while ((int)ctx->split_ev.size() < parts + 1) {
-        hipEvent_t e = nullptr;
-        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        ctx->split_ev.push_back(e);
-    }
-    const size_t CN = (size_t)ctx->C * ctx->N;
-    if (ctx->keep_td && !ctx->d_td) {
-        PML_TRY(dev_alloc(ctx, &ctx->d_td, CN * ctx->ks));
-        PML_TRY(dev_alloc(ctx, &ctx->d_te, CN));
-    }
-    if (!ctx->d_post) {
-        PML_TRY(dev_alloc(ctx, &ctx->d_post, CN * ctx->ks));
-        PML_TRY(dev_alloc(ctx, &ctx->d_lhsum, CN));
-        PML_TRY(dev_alloc(ctx, &ctx->d_lhe, CN));
-    }
-    PML_TRY(params_push(ctx));  // the whole parameter block, once, ahead of every part
-    hipStream_t streams[2] = {ctx->stream, ctx->stream2};
-    const int C = ctx->C;
-    int status = PML_OK;
-    bool td_stored = false, implicit = false;
-    for (int i = 0; i < parts && status == PML_OK; ++i) {
-        const int c0 = (int)((long long)C * i / parts), c1 = (int)((long long)C * (i + 1) / parts);
-        hipStream_t s = streams[i & 1];
-        // (part 0 follows the parameter copy in stream order; every later part through the event of the part before it)
-        if (i > 0) HIP_TRY(hipStreamWaitEvent(s, ctx->split_ev[i - 1], 0));
-        ColumnWindow win(ctx, c0, c1 - c0, s);
-        status = enqueue_bottom_up(ctx, 1, false, true);
-        if (status == PML_OK && hipEventRecord(ctx->split_ev[i], s) != hipSuccess)
-            status = fail(PML_ERR_HIP, "hipEventRecord failed in the split pass");
-        if (status == PML_OK) {
-            ctx->bu_mode = 1;  // (provisional, as in the plain pass)
-            status = run_top_down(ctx);
-            td_stored = ctx->td_vec_valid;
-            implicit = ctx->tip_post_missing;
-        }
-    }
-    // the ctx's stream waits for what ran on the other one (also after a failure: nothing may be left running behind it)
-    if (hipEventRecord(ctx->split_ev[parts], ctx->stream2) == hipSuccess)
-        (void)hipStreamWaitEvent(ctx->stream, ctx->split_ev[parts], 0);
-    PML_TRY(status);
-    ctx->js_valid = false;
-    ctx->prep_dirty = false;
-    ctx->bu_fused = ctx->n_cherries > 0;
-    ctx->bu_fused_joint = false;
-    ctx->bu_absorbed = super_sweeps(ctx);
-    ctx->td_valid = true;
-    ctx->td_vec_valid = td_stored;
-    ctx->td_filled = false;
-    ctx->post_ever = true;
-    ctx->tip_post_missing = implicit;
-    return PML_OK;
 }
 
 int pml_marginal_pass(pml_ctx* ctx, double* loglik_out, int32_t* err_parent, int32_t* err_child, double* posterior_out,
@@ -2954,10 +2695,7 @@ int pml_marginal_pass(pml_ctx* ctx, double* loglik_out, int32_t* err_parent, int
     const u64 generation_before = ctx->h_done ? *reinterpret_cast<volatile u64*>(ctx->h_done) : 0;
     int n_signals = 0;
     bool final_signals = false;
-    const int parts = split_parts(ctx);
-    if (parts > 1) {
-        PML_TRY(split_marginal_pass(ctx, parts));
-    } else if (one_graph) {
+    if (one_graph) {
         if (ctx->mp_graph.exec && ctx->mp_graph.has_init == ctx->has_init) {
             HIP_TRY(hipGraphLaunch(ctx->mp_graph.exec, ctx->stream));
             if (ctx->mp_graph.has_params) ctx->params_dirty = false;
@@ -3091,11 +2829,8 @@ static int submit_joint_backtrace(pml_ctx* ctx) {
 static int fetch_joint_states(pml_ctx* ctx, int32_t* joint_state_out) {
     ctx->js_valid = true;
     ctx->js_ever = true;
-    if (joint_state_out)
-        HIP_TRY(hipMemcpyAsync(joint_state_out, ctx->d_js, (size_t)ctx->C * ctx->N * sizeof(int), hipMemcpyDeviceToHost,
-                               ctx->stream));
+    PML_TRY(fetch_rows(ctx, ctx->d_js, 1, 1, (size_t)ctx->C, joint_state_out));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    rows_to_api_inplace(ctx, joint_state_out, 1, (size_t)ctx->C);
     return PML_OK;
 }
 
@@ -3144,13 +2879,14 @@ int pml_marginal_counts(pml_ctx* ctx, int32_t col, int32_t n_repetitions, uint64
         const PmlState st = state_of(ctx);
         const PmlModel m = model_of(ctx);
         const double* P = ctx->kind == PML_MODEL_F81 ? nullptr : ctx->d_P;
+        // (the draws are keyed by the CALLER's node ids: the library's internal numbering must not show in the result)
         hipLaunchKernelGGL(counts_roots_kernel, dim3(std::min(ctx->n_roots, 1024)), dim3(64), 0, ctx->stream, t, c, st, col,
-                           n_repetitions, seed, d_counts);
+                           n_repetitions, seed, d_counts, ctx->d_old_of_new);
         for (int l = 0; l < ctx->n_td_levels; ++l) {
             const int a = ctx->td_parent_offsets[l], b = ctx->td_parent_offsets[l + 1];
             if (b <= a) continue;
             hipLaunchKernelGGL(counts_level_kernel, dim3(std::min(b - a, 65536)), dim3(64), 0, ctx->stream, t, c, st, m, P,
-                               col, n_repetitions, seed, ctx->d_td_parents + a, b - a, d_counts, d_result);
+                               col, n_repetitions, seed, ctx->d_td_parents + a, b - a, d_counts, d_result, ctx->d_old_of_new);
         }
         e = hipGetLastError();
     }
@@ -3198,17 +2934,17 @@ int pml_select_states(pml_ctx* ctx, int method, int force_joint, const uint64_t*
     }
     const int status = dispatch_select(ctx, method, force_joint, d_lh_mask);   // pml_launch_matrix.hip
     hipError_t e = hipGetLastError();
-    if (e == hipSuccess && masks_out)
-        e = hipMemcpyAsync(masks_out, ctx->d_masks, CN * ctx->W * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess && n_states_out)
-        e = hipMemcpyAsync(n_states_out, ctx->d_nsel, CN * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+    int fetched = PML_OK;
+    if (e == hipSuccess && status == PML_OK) {
+        fetched = fetch_rows(ctx, (const u64*)ctx->d_masks, (size_t)ctx->W, (size_t)ctx->W, (size_t)ctx->C, (u64*)masks_out);
+        if (fetched == PML_OK) fetched = fetch_rows(ctx, ctx->d_nsel, 1, 1, (size_t)ctx->C, n_states_out);
+    }
     hipError_t e2 = hipStreamSynchronize(ctx->stream);
     if (d_lh_mask) (void)hipFree(d_lh_mask);
     if (status != PML_OK) return status;
     if (e != hipSuccess) return fail(PML_ERR_HIP, "pml_select_states failed: %s", hipGetErrorString(e));
+    if (fetched != PML_OK) return fetched;
     if (e2 != hipSuccess) return fail(PML_ERR_HIP, "pml_select_states failed: %s", hipGetErrorString(e2));
-    rows_to_api_inplace(ctx, (u64*)masks_out, (size_t)ctx->W, (size_t)ctx->C);
-    rows_to_api_inplace(ctx, n_states_out, 1, (size_t)ctx->C);
     // the columns' masks changed: sweeps must be redone, the posteriors themselves stay valid for inspection
     ctx->prep_dirty = true;
     ctx->bu_mode = -1;
@@ -3415,6 +3151,41 @@ int pml_comm_init(pml_ctx* ctx, int rank, int world, const unsigned char* id) {
     return PML_OK;
 }
 
+int pml_comm_info(pml_ctx* ctx, int32_t* rank, int32_t* world, int32_t* backend, int32_t* rccl_ranks) {
+    if (!ctx || !ctx->comm) return fail(PML_ERR_INVALID, "no communicator: call pml_comm_init first");
+    const PmlComm* c = ctx->comm;
+    if (rank) *rank = c->rank;
+    if (world) *world = c->world;
+    if (backend) *backend = c->comm ? 1 : 0;
+    if (rccl_ranks) {
+        *rccl_ranks = 0;
+        if (c->comm) {
+            PmlRccl* r = pml_rccl();
+            int n = -1;
+            if (r->CommCount) {
+                const ncclResult_t e = r->CommCount(c->comm, &n);
+                if (e != ncclSuccess) return fail(PML_ERR_HIP, "ncclCommCount failed: %s", r->GetErrorString(e));
+            }
+            *rccl_ranks = n;
+        }
+    }
+    return PML_OK;
+}
+
+int pml_device_uuid(int device, char* uuid_out) {
+    if (!uuid_out) return fail(PML_ERR_INVALID, "uuid_out is NULL");
+    hipUUID id;
+    HIP_TRY(hipDeviceGetUuid(&id, device));
+    static const char hex[] = "0123456789abcdef";
+    for (int i = 0; i < 16; ++i) {
+        const unsigned char b = (unsigned char)id.bytes[i];
+        uuid_out[2 * i] = hex[b >> 4];
+        uuid_out[2 * i + 1] = hex[b & 15];
+    }
+    uuid_out[32] = 0;
+    return PML_OK;
+}
+
 int pml_comm_destroy(pml_ctx* ctx) {
     if (!ctx || !ctx->comm) return PML_OK;
     PmlComm* c = ctx->comm;
@@ -3586,24 +3357,24 @@ int pml_download_strided(pml_ctx* ctx, int what, int32_t col, int32_t first, int
             return fail(PML_ERR_INVALID, "pml_download_strided serves PML_BUF_POSTERIOR, _LH_SUM, _LH_SF, _JOINT_STATE");
     }
     if (permuted(ctx)) {
-        // the rows asked for are scattered in the library's numbering: one small copy each (src points at row `first` of the
-        // column; step back to the column's row 0 first)
-        const char* col0 = (const char*)src - (size_t)first * src_row_bytes;
-        if (count > 2048) {   // many rows: the column in one copy, the rows picked on the host
-            std::vector<char> whole(N * src_row_bytes);
-            HIP_TRY(hipMemcpyAsync(whole.data(), col0, whole.size(), hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(hipStreamSynchronize(ctx->stream));
-            for (int i = 0; i < count; ++i) {
-                const size_t row = (size_t)ctx->new_of_old[first + (size_t)i * stride];
-                memcpy((char*)out + (size_t)i * row_bytes, whole.data() + row * src_row_bytes, row_bytes);
-            }
-        } else {
-            for (int i = 0; i < count; ++i) {
-                const size_t row = (size_t)ctx->new_of_old[first + (size_t)i * stride];
-                HIP_TRY(hipMemcpyAsync((char*)out + (size_t)i * row_bytes, col0 + row * src_row_bytes, row_bytes,
-                                       hipMemcpyDeviceToHost, ctx->stream));
-            }
+        // the rows asked for are scattered in the library's numbering: gathered on the device, copied once (round 5 issued one
+        // small copy per row, ~10 us each)
+        const char* col0 = (const char*)src - (size_t)first * src_row_bytes;   // (src points at row `first`: back to the column's row 0)
+        const size_t bytes = (size_t)count * row_bytes;
+        if (ctx->stage_bytes < bytes) {
+            if (ctx->d_stage) (void)hipFree(ctx->d_stage);
+            ctx->d_stage = nullptr;
+            ctx->stage_bytes = 0;
+            HIP_TRY(hipMalloc(&ctx->d_stage, bytes));
+            ctx->stage_bytes = bytes;
         }
+        const int wd = (int)(row_bytes / 4), ws = (int)(src_row_bytes / 4);
+        const long long total = (long long)count * wd;
+        hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)std::min<long long>((total + PML_BLOCK - 1) / PML_BLOCK, 65536)),
+                           dim3(PML_BLOCK), 0, ctx->stream, (const unsigned*)col0, (unsigned*)ctx->d_stage, ctx->d_new_of_old,
+                           (long long)count, wd, ws, first, stride);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(out, ctx->d_stage, bytes, hipMemcpyDeviceToHost, ctx->stream));
     } else {
         HIP_TRY(hipMemcpy2DAsync(out, row_bytes, src, src_row_bytes * stride, row_bytes, count, hipMemcpyDeviceToHost, ctx->stream));
     }

@@ -15,6 +15,7 @@ struct PmlRccl {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;   // optional (reports only)
     std::string error;
 };
 
@@ -36,6 +37,7 @@ static PmlRccl* pml_rccl() {
     r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.handle, "ncclCommDestroy");
     r.AllReduce = (decltype(r.AllReduce))dlsym(r.handle, "ncclAllReduce");
     r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.handle, "ncclGetErrorString");
+    r.CommCount = (decltype(r.CommCount))dlsym(r.handle, "ncclCommCount");
     if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce || !r.GetErrorString) {
         r.error = "librccl lacks one of ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllReduce";
         dlclose(r.handle);

@@ -19,8 +19,9 @@
 #define PML_EIG_BU_MARG 0
 #define PML_EIG_BU_JOINT 1
 #define PML_EIG_TD 2
-// A kernel that is not a template: internal linkage, so that every translation unit that includes its header may hold a
-// copy and only those that launch it emit one.
+// A kernel that is not a template: internal linkage, and compiled only by the translation unit that launches it -- all
+// of them are pml_api.hip's, which defines PML_PLAIN_KERNELS (the compiler emits a static kernel whether it is launched or
+// not, so the definitions are left out elsewhere).
 #define PML_GLOBAL static __global__
 
 typedef unsigned long long u64;

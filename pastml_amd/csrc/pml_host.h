@@ -54,15 +54,15 @@ PML_INTERNAL int pml_fail(int code, const char* fmt, ...) __attribute__((format(
 // TREE: read by pml_tree_upload / pml_chars_alloc, so it must be set before the tree is uploaded.
 // ---------------------------------------------------------------------------------------------------------------------
 #define PML_TUNABLES(X)                                                                                              \
-    X(MATRIX_R1, 1, 1) X(GRID_CAP, 0, 0) X(SMALL_MANY_NODES, 0, 0) X(BLOCK_MAX_WORK, 0, 0) X(BLOCK_MAX_STEPS, 0, 0)    \
-    X(NO_MFMA, 1, 0) X(NO_EIGEN_FUSED, 1, 0) X(NO_HKY_FUSED, 1, 0) X(NO_TD_STAGE, 1, 0) X(TD_STAGE_SCALARS, 0, 0)      \
+    X(GRID_CAP, 0, 0) X(SMALL_MANY_NODES, 0, 0) X(BLOCK_MAX_WORK, 0, 0) X(BLOCK_MAX_STEPS, 0, 0)    \
+    X(NO_MFMA, 1, 0) X(NO_EIGEN_FUSED, 1, 0) X(NO_HKY_FUSED, 1, 0)      \
     X(BLOCK_THREADS, 0, 0) X(EIG_BLOCKS, 0, 0) X(NO_EIGEN_GEMM, 1, 0) X(NO_EIGEN_JOINT_VALU, 1, 0) X(EIGJ_BLOCKS, 0, 0) \
     X(EIGJ_TIP_BLOCKS, 0, 0) X(EIGJ_ONE_TIPS_KERNEL, 1, 0) X(EIGJ_TIER_THIN, 0, 1) X(EIGJ_TIER_DEPTH, 0, 1)            \
     X(NO_EIGJ_TIERS, 1, 1) X(NO_BT_TIERS, 1, 1) X(NO_SHAPE_SORT, 1, 1) X(NO_SUPER, 1, 1) X(SUPER_MIN, 0, 1)            \
     X(STACK_MIN, 0, 1) X(NO_STACK, 1, 1) X(DEBUG, 1, 0) X(BLOCK_NODES, 0, 1) X(BLOCK_MAX_STORED, 0, 1)                 \
     X(BLOCK_HEIGHT_CAP, 0, 1) X(SMALL_MAX_NODES, 0, 1) X(F81_R, 0, 1) X(F81_TD_R, 0, 1) X(NO_GRAPH, 1, 1)              \
-    X(NARROW_UNITS, 0, 0) X(NO_EIGG_TIERS, 1, 0) X(NO_ABSORB, 1, 1) X(ABSORB_MIN, 0, 1) X(NO_SPIN_WAIT, 1, 0)   \
-    X(SPLIT_PARTS, 0, 0) X(PIJ_STAGE_ROWS, 0, 0) X(PIJ_ABLATE, 0, 0) X(PIJ_BLOCKS, 0, 0) X(NO_HEIGHT_ORDER, 1, 1) X(NO_TD_TAIL, 1, 0) X(NO_PIJ_VALU, 1, 0) X(PIJ_VALU, 1, 0) X(NO_EIGJ_PIPE, 1, 0) \
+    X(NARROW_UNITS, 0, 0) X(NO_EIGG_TIERS, 1, 0) X(NO_SPIN_WAIT, 1, 0)   \
+    X(PIJ_STAGE_ROWS, 0, 0) X(PIJ_ABLATE, 0, 0) X(PIJ_BLOCKS, 0, 0) X(NO_HEIGHT_ORDER, 1, 1) X(NO_TD_TAIL, 1, 0) X(NO_PIJ_VALU, 1, 0) X(PIJ_VALU, 1, 0) X(NO_EIGJ_PIPE, 1, 0) \
     X(THIN_UNITS, 0, 1) X(THIN_BYTES, 0, 1) X(THIN_BLOCK_NODES, 0, 1) X(NO_THIN, 1, 0) X(NO_THIN_WIDE, 1, 0) X(BU_WIDE, 0, 1) X(SORT_LEVELS, 0, 1) X(NO_WIDE_LEAN, 1, 0)
 enum PmlTunable {
 #define X(name, flag, tree) T_##name,
@@ -137,6 +137,9 @@ struct pml_ctx {
     // groups a level's units gather lie next to each other; every per-node array that crosses the C-ABI is in the CALLER's
     // numbering and is permuted on the way in / out.  Both empty when the caller's numbering is kept (balanced trees, ...).
     std::vector<int> new_of_old, old_of_new;
+    int *d_new_of_old = nullptr, *d_old_of_new = nullptr;   // the same on the device (outputs are permuted there: gather_rows_kernel)
+    void* d_stage = nullptr;   // one column's rows in the caller's numbering, on their way out
+    size_t stage_bytes = 0;
     // cherry fusion (F81 marginal sweeps): node kinds and level lists over the stored internal nodes only
     bool fuse = true;
     unsigned char* d_kind = nullptr;
@@ -192,15 +195,7 @@ struct pml_ctx {
         PmlUnit *d_bu_units_rs = nullptr, *d_td_units_rs = nullptr;  // ... sorted by shape inside every level
         // stacked units (pml_kernels_f81.h): nodes with two plain stored children of two stored children each, by
         // bottom-up level and by depth; their children as units of their own for downloads
-        int n_child_units = 0;  // entries of d_child_units: the children of the two-level units + the absorbed nodes below
-        // general two-level units (pml_kernels_f81.h, round 4): stored nodes whose children are tips and cherries are
-        // absorbed by their parents, whatever the shapes.  Bottom-up: the absorbing nodes by level, three records each;
-        // top-down: one record per absorbed node (pad = the parent), all in one launch
-        int n_absorbing = 0, n_absorbed = 0;
-        PmlUnit *d_absorb_bu = nullptr, *d_absorb_td = nullptr;
-        PmlUnit* d_absorbing_td = nullptr;  // the absorbing nodes' own top-down records (those with tips / cherries to finish)
-        int n_absorbing_td = 0;
-        std::vector<int> absorb_bu_offsets;
+        int n_child_units = 0;  // entries of d_child_units: the children of the two-level units
         int n_stack = 0;
         PmlUnit *d_stack_bu = nullptr, *d_stack_td = nullptr, *d_stack_children = nullptr;
         std::vector<int> stack_bu_offsets, stack_td_offsets;
@@ -320,12 +315,6 @@ struct pml_ctx {
     const PmlUnit* units_override = nullptr;  // set around a dispatch_sweep on the block schedule's top lists
 
     PmlComm* comm = nullptr;   // RCCL communicator attached by pml_comm_init (survives tree uploads)
-
-    // marginal pass of a large forest in parts of its columns on two streams (split_marginal_pass): the second stream, the
-    // events that chain the parts, and the flag that says the launches being enqueued see a window of the columns
-    hipStream_t stream2 = nullptr;
-    std::vector<hipEvent_t> split_ev;
-    bool windowed = false;
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -371,6 +360,9 @@ static void free_all(pml_ctx* ctx) {
     ctx->h_loglik = nullptr;
     ctx->h_err = nullptr;
     for (void* p : ctx->allocs) (void)hipFree(p);
+    if (ctx->d_stage) (void)hipFree(ctx->d_stage);
+    ctx->d_stage = nullptr;
+    ctx->stage_bytes = 0;
     ctx->allocs.clear();
     ctx->held = 0;
 }
@@ -383,7 +375,7 @@ static int upload(pml_ctx* ctx, T* dst, const T* src, size_t count) {
 
 static void pick_group(const pml_ctx* ctx, int k, int& G, int& R) {
     R = k <= 32 ? 1 : (k <= 128 ? 2 : 4);
-    if (k > 16 && k <= 32 && !ctx->tune.on(T_MATRIX_R1)) R = 4;  // 8 lanes per unit: 8 units per wavefront
+    if (k > 16 && k <= 32) R = 4;  // 8 lanes per unit: 8 units per wavefront
     const int need = (k + R - 1) / R;
     G = 1;
     while (G < need) G <<= 1;
@@ -521,7 +513,7 @@ static int prof_drain(pml_ctx* ctx) {
     HIP_TRY(hipSetDevice(ctx->device));
     for (const pml_ctx::ProfBracket& br : ctx->prof_pending) {
         float ms = 0.f;
-        HIP_TRY(hipEventSynchronize(br.b));  // (the brackets of a split pass lie on two streams)
+        HIP_TRY(hipEventSynchronize(br.b));
         HIP_TRY(hipEventElapsedTime(&ms, br.a, br.b));
         ctx->prof_ms[br.which] += ms;
         ctx->prof_launches[br.which] += br.launches;

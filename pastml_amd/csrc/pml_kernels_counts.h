@@ -56,8 +56,10 @@ __device__ __forceinline__ double wave_inclusive_scan(double v, int lane) {
 }
 
 // counts of the roots: n_rep draws from the posterior of each root (ml.py:786-793)
+#ifdef PML_PLAIN_KERNELS   // (launched by pml_api.hip only: the other translation units leave it out)
 PML_GLOBAL void __launch_bounds__(64)
-counts_roots_kernel(PmlTree t, PmlCols c, PmlState st, int col, int n_rep, u64 seed, int* __restrict__ counts) {
+counts_roots_kernel(PmlTree t, PmlCols c, PmlState st, int col, int n_rep, u64 seed, int* __restrict__ counts,
+                    const int* __restrict__ api_id) {
     __shared__ double cdf[PML_COUNTS_MAX_K];
     __shared__ int hist[PML_COUNTS_MAX_K];
     const int lane = threadIdx.x;
@@ -78,7 +80,7 @@ counts_roots_kernel(PmlTree t, PmlCols c, PmlState st, int col, int n_rep, u64 s
         __syncthreads();
         const double W = run;
         for (int i = lane; i < n_rep; i += 64) {
-            const double u = counts_uniform(seed, (unsigned)r, 0xffffffffu, (unsigned)i) * W;
+            const double u = counts_uniform(seed, (unsigned)(api_id ? api_id[r] : r), 0xffffffffu, (unsigned)i) * W;
             int lo = 0, hi = k - 1;  // first b with cdf[b] > u (the last state if rounding put u at W)
             while (lo < hi) {
                 const int mid = (lo + hi) >> 1;
@@ -91,12 +93,14 @@ counts_roots_kernel(PmlTree t, PmlCols c, PmlState st, int col, int n_rep, u64 s
         __syncthreads();
     }
 }
+#endif
 
 // one depth level: parents[0 .. n_parents), one wavefront (= one 64-thread block) per parent
+#ifdef PML_PLAIN_KERNELS   // (launched by pml_api.hip only: the other translation units leave it out)
 PML_GLOBAL void __launch_bounds__(64)
 counts_level_kernel(PmlTree t, PmlCols c, PmlState st, PmlModel m, const double* __restrict__ P, int col, int n_rep,
                     u64 seed, const int* __restrict__ parents, int n_parents, int* __restrict__ counts,
-                    long long* __restrict__ result) {
+                    long long* __restrict__ result, const int* __restrict__ api_id) {
     __shared__ double cdf[PML_COUNTS_MAX_K];
     __shared__ double base[PML_COUNTS_MAX_K];  // BU_n[b] pi_b mask_n[b]
     __shared__ int pc[PML_COUNTS_MAX_K];       // counts of the parent
@@ -117,6 +121,7 @@ counts_level_kernel(PmlTree t, PmlCols c, PmlState st, PmlModel m, const double*
         const int fc = t.first_child[p], nc = t.n_children[p];
         for (int j = 0; j < nc; ++j) {
             const int n = fc + j;
+            const unsigned key = (unsigned)(api_id ? api_id[n] : n);   // the node as the caller numbers it
             const bool tip = t.n_children[n] == 0;
             for (int b = lane; b < k; b += 64) {
                 const bool allowed = (c.masks[(colN + n) * c.W + (b >> 6)] >> (b & 63)) & 1ull;
@@ -151,7 +156,7 @@ counts_level_kernel(PmlTree t, PmlCols c, PmlState st, PmlModel m, const double*
                 const double W = run;
                 if (W > 0.0) {
                     for (int i = lane; i < ca; i += 64) {
-                        const double u = counts_uniform(seed, (unsigned)n, (unsigned)a, (unsigned)i) * W;
+                        const double u = counts_uniform(seed, key, (unsigned)a, (unsigned)i) * W;
                         int lo = 0, hi = k - 1;
                         while (lo < hi) {
                             const int mid = (lo + hi) >> 1;
@@ -182,3 +187,4 @@ counts_level_kernel(PmlTree t, PmlCols c, PmlState st, PmlModel m, const double*
         __syncthreads();
     }
 }
+#endif

@@ -16,9 +16,6 @@
 #define PML_KIND_TIP 0
 #define PML_KIND_CHERRY 1
 #define PML_KIND_STORED 2
-// child code in the top-down record of an absorbing node (td_f81_absorbing_kernel only) for a child that a unit of its
-// own finishes (codes: 0 tip, 1 stored node, 2 + m cherry with m + 1 <= 4 tips)
-#define PML_CODE_ABSORBED 6
 
 typedef unsigned char pml_jt;  // entry of an arg-max table: a state index, k <= PML_MAX_STATES = 256
 
@@ -74,6 +71,7 @@ __device__ __forceinline__ int node_kind(const PmlTree& t, int n) {
 // ---------------------------------------------------------------------------------------------------------------------
 // A thread takes node n for `cpy` consecutive columns (blockIdx.y = column chunk): the branch length is read once per
 // chunk instead of once per column (a third of this pass's traffic on a wide batch).
+#ifdef PML_PLAIN_KERNELS   // (launched by pml_api.hip only: the other translation units leave it out)
 PML_GLOBAL void __launch_bounds__(PML_BLOCK)
 f81_prep_kernel(PmlTree t, PmlCols c, const double* __restrict__ mu, const double* __restrict__ sf,
                 const double* __restrict__ tau, const double* __restrict__ tauf, PmlState st, int n_cols, int cpy) {
@@ -104,6 +102,7 @@ f81_prep_kernel(PmlTree t, PmlCols c, const double* __restrict__ mu, const doubl
         }
     }
 }
+#endif
 
 // Per-lane context of a unit's lane group: lane geometry and the column's slabs (element offsets inside one column
 // fit 32 bits: N * ks < 2^31 is checked on the host).
@@ -1998,7 +1997,7 @@ __device__ __forceinline__ void f81_finish_tip(const LaneCtx<G, R>& L, const Pml
     }
 }
 
-template <int G, int R, bool SKIP_ABSORBED = false>
+template <int G, int R>
 __device__ __forceinline__ void td_f81_fast_children(const LaneCtx<G, R>& L, const PmlTree& t, const PmlCols& c,
                                                      const PmlState& st, const UnitRegs& u, const double (&prod)[R],
                                                      i64 pe, const ChildLane& cl, const TipLane& tl, double (&vn)[R]);
@@ -2021,9 +2020,7 @@ __device__ __forceinline__ void td_f81_unit_fast(const LaneCtx<G, R>& L, const P
 
 // The children of a fast unit's node, given prod = TD o BU of the node (exponent pe), the gathered scalars and -- if
 // child 0 is a stored node -- its bottom-up vector in vn.
-// SKIP_ABSORBED (the units of absorbing nodes, td_f81_absorbing_kernel): children coded PML_CODE_ABSORBED are left to
-// their own units.  A template parameter, so that the level kernels' code is what it was.
-template <int G, int R, bool SKIP_ABSORBED>
+template <int G, int R>
 __device__ __forceinline__ void td_f81_fast_children(const LaneCtx<G, R>& L, const PmlTree& t, const PmlCols& c,
                                                      const PmlState& st, const UnitRegs& u, const double (&prod)[R],
                                                      i64 pe, const ChildLane& cl, const TipLane& tl, double (&vn)[R]) {
@@ -2048,7 +2045,6 @@ __device__ __forceinline__ void td_f81_fast_children(const LaneCtx<G, R>& L, con
             f81_finish_tip_word<G, R>(L, c, prod, pe, P, have_P, ch, word, e, __shfl(cl.s, src, 64));
             continue;
         }
-        if (SKIP_ABSORBED && code == PML_CODE_ABSORBED) continue;  // (finished by a unit of its own: td_f81_absorb_kernel)
         double mb[R], tdc[R], po[R], ls;
         const bool full = word == state_bits(c.k);
         if (!full) clean_word_to_vec<G, R>(L, c, word, mb);
@@ -2910,236 +2906,6 @@ td_f81_stack_kernel(PmlTree t, PmlCols c, PmlState st, const PmlUnit* __restrict
         const StackRegs nxt = load_stack(units, nxt_idx < n_units ? nxt_idx >> 1 : 0);
         if (idx < n_units) td_f81_stack_unit<G, R>(L, t, c, st, cur, idx & 1);
         cur = nxt;
-        idx = nxt_idx;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// General two-level units (round 4): the two-level idea for trees that are not balanced.  Any stored node c all of whose
-// children are tips and cherries (the lowest level of the fused lists: on a random binary tree 30 % of the stored nodes)
-// is ABSORBED by its parent n, whatever n's level and whatever the shapes of the two: n's bottom-up unit runs c's unit
-// first and takes c's vector from registers -- it is not written, and n does not gather c's pi . v and exponent from
-// memory -- and top-down c gets a unit of its own that reads n's row, rebuilds c's vector from the tips, finishes c and
-// goes on with c's children (tips and cherries) from the row it has just formed, while n's own unit skips c
-// (PML_CODE_ABSORBED in its descriptor).  What a ragged tree's sweeps are short of is memory traffic per node
-// (profiles/r04b_*): an absorbed node saves its vector's round trip and its scalars' gathers in either sweep.
-// The bodies are the level kernels' (descriptor-driven: any mix of tips, cherries of 1 - 4 tips, stored children in memory,
-// absorbed children), called with the same arguments in the same lane shape: the same bits as the plain level schedule.
-// Bottom-up descriptor of an absorbing node: THREE records -- the node's own (original codes; pad = bit j: child j is
-// absorbed), then child 0's and child 1's own records (copies of the node's when not absorbed).  Top-down descriptor of an
-// absorbed child: its own record with pad = the parent.
-// ---------------------------------------------------------------------------------------------------------------------
-// the unit of a node without stored children, run for a caller that goes on with its vector (what bu_f81_unit_fast does
-// for a level's unit: the same choice of body, wave-uniform over the units that are here)
-template <int G, int R>
-__device__ __forceinline__ bool bu_f81_leaf_unit_kept(const LaneCtx<G, R>& L, const PmlTree& t, const PmlCols& c,
-                                                      const PmlState& st, const UnitRegs& u, BuLoads<R>& ld,
-                                                      BuResult<R>* res, bool vec_only) {
-    const u64 kbits = state_bits(c.k);
-    const int nc = unit_nc(u.packed);
-    f81_gather_finish<G, R>(L, ld.cl, ld.tl);
-    const int cj = L.g < nc ? L.g : 0;
-    const bool ones = c.k == G * R && (ld.own & kbits) == kbits && (unit_code(u.packed, cj & 3) < 2 || ld.cl.mask == kbits);
-    if (__all(ones)) {
-        const bool pair = (u.packed & 0x3f0f) == ((3 << 11) | (3 << 8) | 2);
-        if (__all(pair)) return bu_f81_marg_body<G, R, false, true, true>(L, t, c, st, u, ld, res, false, vec_only);
-        return bu_f81_marg_body<G, R, false, true>(L, t, c, st, u, ld, res, false, vec_only);
-    }
-    return bu_f81_marg_body<G, R, false, false>(L, t, c, st, u, ld, res, false, vec_only);
-}
-
-struct AbsorbRegs {
-    UnitRegs n, c0, c1;
-    int flags;
-};
-
-template <int G>
-__device__ __forceinline__ AbsorbRegs load_absorb(const PmlUnit* __restrict__ units, int idx, int g) {
-    AbsorbRegs a;
-    a.n = load_unit<G>(units, 3 * idx, g);
-    a.flags = units[3 * idx].pad;
-    a.c0 = load_unit<G>(units, 3 * idx + 1, g);
-    a.c1 = load_unit<G>(units, 3 * idx + 2, g);
-    return a;
-}
-
-// packed with the code of every absorbed child replaced (3 bits at 8 + 3 j)
-__device__ __forceinline__ int absorb_recode(int packed, int flags, int code) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-        if ((flags >> j) & 1) packed = (packed & ~(7 << (8 + 3 * j))) | (code << (8 + 3 * j));
-    return packed;
-}
-
-template <int G, int R>
-__device__ __forceinline__ bool bu_f81_absorb_unit(const LaneCtx<G, R>& L, const PmlTree& t, const PmlCols& c,
-                                                   const PmlState& st, const AbsorbRegs& a) {
-    // ---- loads: the absorbed children's own (scalars of their children and tips, own mask), then the node's -- for those
-    // an absorbed child counts as a tip (no tips of its own to gather, no vector in memory)
-    BuLoads<R> ld[2], top;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        if ((a.flags >> j) & 1) {
-            const UnitRegs& uc = j ? a.c1 : a.c0;
-            f81_gather_issue<G, R>(L, uc, ld[j].cl, ld[j].tl);
-            ld[j].own = L.mask[(unsigned)uc.n];
-        }
-    }
-    UnitRegs ul = a.n;
-    ul.packed = absorb_recode(a.n.packed, a.flags, 0);
-    f81_gather_issue<G, R>(L, ul, top.cl, top.tl);
-    top.own = L.mask[(unsigned)a.n.n];
-    // ---- the absorbed children's units, one after the other: the vector goes straight into the slot the node's body
-    // reads it from (v0 / v1; a stored child that is in memory is loaded into its slot), pi . v and the exponent into lane
-    // j of the gathered scalars (they are stored as well: the child's top-down unit reads them)
-    double cs[2] = {0.0, 0.0};
-    i64 ce[2] = {0, 0};
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        double (&slot)[R] = j ? top.v1 : top.v0;
-        if ((a.flags >> j) & 1) {
-            BuResult<R> res;
-            if (!bu_f81_leaf_unit_kept<G, R>(L, t, c, st, j ? a.c1 : a.c0, ld[j], &res, false)) return false;
-#pragma unroll
-            for (int r = 0; r < R; ++r) slot[r] = res.v[r];
-            cs[j] = res.s;
-            ce[j] = res.e;
-        } else {
-            const bool stored = j < unit_nc(a.n.packed) && unit_code(a.n.packed, j) == 1;
-            node_load_vec<G, R>(L, c, stored ? L.bu : L.pi, stored ? a.n.fc + j : 0, slot);
-        }
-    }
-    // ---- the node's own unit, as its level's launch would run it
-    f81_gather_finish<G, R>(L, top.cl, top.tl);
-    if (L.g < 2 && ((a.flags >> L.g) & 1)) {
-        top.cl.s = L.g ? cs[1] : cs[0];
-        top.cl.be = L.g ? ce[1] : ce[0];
-    }
-    return bu_f81_marg_body<G, R, true, false>(L, t, c, st, a.n, top);
-}
-
-template <int G, int R>
-__global__ void __launch_bounds__(PML_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
-bu_f81_absorb_kernel(PmlTree t, PmlCols c, PmlState st, const PmlUnit* __restrict__ units, int n_level) {
-    constexpr int UW = 64 / G;
-    const int wave = threadIdx.x >> 6;
-    const int sub = (threadIdx.x & 63) / G;
-    LaneCtx<G, R> L;
-    lane_ctx_init<G, R>(L, t, c, st);
-    const int stride = gridDim.x * PML_WAVES_PER_BLOCK * UW;
-    int idx = (blockIdx.x * PML_WAVES_PER_BLOCK + wave) * UW + sub;
-    AbsorbRegs cur = load_absorb<G>(units, idx < n_level ? idx : 0, L.g);
-    for (int base = idx - sub; base < n_level; base += stride) {
-        const int nxt_idx = idx + stride;
-        const AbsorbRegs nxt = load_absorb<G>(units, nxt_idx < n_level ? nxt_idx : 0, L.g);
-        if (idx < n_level) {
-            if (!bu_f81_absorb_unit<G, R>(L, t, c, st, cur)) {
-                // an all-zero vector: the units one after the other on the sequential path, which names the pair the
-                // reference would (the children's vectors go through memory there)
-                if (cur.flags & 1) bu_f81_unit_seq<G, R, false>(L, t, c, st, cur.c0);
-                if (cur.flags & 2) bu_f81_unit_seq<G, R, false>(L, t, c, st, cur.c1);
-                __threadfence();
-                bu_f81_unit_seq<G, R, false>(L, t, c, st, cur.n);
-            }
-        }
-        cur = nxt;
-        idx = nxt_idx;
-    }
-}
-
-// top-down: one unit per absorbed child (record: its own, pad = the parent)
-template <int G, int R>
-__device__ __forceinline__ void td_f81_absorb_unit(const LaneCtx<G, R>& L, const PmlTree& t, const PmlCols& c,
-                                                   const PmlState& st, const UnitRegs& u, int parent) {
-    const u64 kbits = state_bits(c.k);
-    const int ch = u.n;
-    double prod[R];
-    i64 pe;
-    f81_parent_prod<G, R>(L, c, parent, prod, pe);
-    const double e = L.E[ch];
-    const double s_child = L.S[ch];
-    const i64 bec = L.be[ch];
-    BuLoads<R> ld;
-    ld.own = L.mask[(unsigned)ch];
-    f81_gather_issue<G, R>(L, u, ld.cl, ld.tl);
-    BuResult<R> v;
-    bu_f81_leaf_unit_kept<G, R>(L, t, c, st, u, ld, &v, true);   // the child's vector again, nothing stored
-    ld.own &= kbits;
-    double prod2[R];
-    i64 pe2;
-    {
-        double mb[R], tdc[R], po[R], ls;
-        const bool full = ld.own == kbits;
-        if (!full) clean_word_to_vec<G, R>(L, c, ld.own, mb);
-        i64 xe;
-        f81_finish_child<G, R>(L, c, prod, pe, ch, e, s_child, bec, v.v, full, mb, tdc, xe, po, ls, pe2);
-        if (st.td != nullptr) {
-            node_store_vec<G, R>(L, c, L.td, ch, tdc);
-            if (L.g == 0) L.te[ch] = xe;
-        }
-#pragma unroll
-        for (int r = 0; r < R; ++r) prod2[r] = po[r] * (ls * L.ipi_r[r]);  // f81_parent_prod on the row just stored
-    }
-    // the child's own unit (tips and cherries only) on the row, sum and exponent it has just produced
-    double vn[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) vn[r] = 0.0;
-    td_f81_fast_children<G, R>(L, t, c, st, u, prod2, pe2, ld.cl, ld.tl, vn);
-}
-
-// The own top-down units of the absorbing nodes (all of whose stored children are absorbed): the tips and cherries among
-// their children -- nothing below depends on them, so they run in one launch behind the depth launches as well.
-template <int G, int R>
-__global__ void __launch_bounds__(PML_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
-td_f81_absorbing_kernel(PmlTree t, PmlCols c, PmlState st, const PmlUnit* __restrict__ units, int n_units) {
-    constexpr int UW = 64 / G;
-    const int wave = threadIdx.x >> 6;
-    const int sub = (threadIdx.x & 63) / G;
-    LaneCtx<G, R> L;
-    lane_ctx_init<G, R>(L, t, c, st);
-    const int stride = gridDim.x * PML_WAVES_PER_BLOCK * UW;
-    int idx = (blockIdx.x * PML_WAVES_PER_BLOCK + wave) * UW + sub;
-    UnitRegs cur = load_unit<G>(units, idx < n_units ? idx : 0, L.g);
-    for (int base = idx - sub; base < n_units; base += stride) {
-        const int nxt_idx = idx + stride;
-        const UnitRegs nxt = load_unit<G>(units, nxt_idx < n_units ? nxt_idx : 0, L.g);
-        if (idx < n_units) {
-            double prod[R];
-            i64 pe;
-            f81_parent_prod<G, R>(L, c, cur.n, prod, pe);
-            ChildLane cl;
-            TipLane tl;
-            f81_gather_issue<G, R>(L, cur, cl, tl);
-            f81_gather_finish<G, R>(L, cl, tl);
-            double vn[R];
-#pragma unroll
-            for (int r = 0; r < R; ++r) vn[r] = 0.0;
-            td_f81_fast_children<G, R, true>(L, t, c, st, cur, prod, pe, cl, tl, vn);
-        }
-        cur = nxt;
-        idx = nxt_idx;
-    }
-}
-
-template <int G, int R>
-__global__ void __launch_bounds__(PML_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
-td_f81_absorb_kernel(PmlTree t, PmlCols c, PmlState st, const PmlUnit* __restrict__ units, int n_units) {
-    constexpr int UW = 64 / G;
-    const int wave = threadIdx.x >> 6;
-    const int sub = (threadIdx.x & 63) / G;
-    LaneCtx<G, R> L;
-    lane_ctx_init<G, R>(L, t, c, st);
-    const int stride = gridDim.x * PML_WAVES_PER_BLOCK * UW;
-    int idx = (blockIdx.x * PML_WAVES_PER_BLOCK + wave) * UW + sub;
-    UnitRegs cur = load_unit<G>(units, idx < n_units ? idx : 0, L.g);
-    int cur_parent = units[idx < n_units ? idx : 0].pad;
-    for (int base = idx - sub; base < n_units; base += stride) {
-        const int nxt_idx = idx + stride;
-        const UnitRegs nxt = load_unit<G>(units, nxt_idx < n_units ? nxt_idx : 0, L.g);
-        const int nxt_parent = units[nxt_idx < n_units ? nxt_idx : 0].pad;
-        if (idx < n_units) td_f81_absorb_unit<G, R>(L, t, c, st, cur, cur_parent);
-        cur = nxt;
-        cur_parent = nxt_parent;
         idx = nxt_idx;
     }
 }

@@ -5,6 +5,7 @@
 #define PML_MAX_STATES_SEL 256
 
 // masks: internal nodes all ones; tip j one-hot at states[col][j] (all ones if negative = missing data)
+#ifdef PML_PLAIN_KERNELS   // (launched by pml_api.hip only: the other translation units leave it out)
 PML_GLOBAL void __launch_bounds__(PML_BLOCK)
 masks_fill_kernel(int N, int W, int k, u64* __restrict__ masks, int col_begin) {
     const int col = col_begin + blockIdx.y;
@@ -15,7 +16,9 @@ masks_fill_kernel(int N, int W, int k, u64* __restrict__ masks, int col_begin) {
         masks[(size_t)col * total + i] = bits >= 64 ? ~0ull : ((1ull << bits) - 1ull);
     }
 }
+#endif
 
+#ifdef PML_PLAIN_KERNELS   // (launched by pml_api.hip only: the other translation units leave it out)
 PML_GLOBAL void __launch_bounds__(PML_BLOCK)
 masks_tips_kernel(int N, int W, int k, u64* __restrict__ masks, int col_begin, int n_tips,
                   const int* __restrict__ tip_ids, const int* __restrict__ states) {
@@ -27,6 +30,7 @@ masks_tips_kernel(int N, int W, int k, u64* __restrict__ masks, int col_begin, i
         for (int w = 0; w < W; ++w) m[w] = (s >> 6) == w ? (1ull << (s & 63)) : 0ull;
     }
 }
+#endif
 
 // Roots: TD = 1 with exponent 0 (ml.py:274-277) and their marginal likelihoods / posteriors (BU * pi * mask).
 template <int G, int R>
@@ -83,6 +87,7 @@ td_roots_kernel(PmlTree t, PmlCols c, PmlState st) {
 // ln L per column = sum over trees of ln(root term) + E_root ln 2 (ml.py:112-121).
 // marginal: root term = sum_i pi_i BU_i; joint: max_i pi_i BU_i, whose first arg-max is the root's joint state
 // (ml.py:622).  One thread per column; forests have few roots.
+#ifdef PML_PLAIN_KERNELS   // (launched by pml_api.hip only: the other translation units leave it out)
 PML_GLOBAL void __launch_bounds__(PML_BLOCK)
 loglik_kernel(PmlTree t, PmlCols c, PmlState st, int n_cols, int is_marginal, double* __restrict__ loglik,
               u64* __restrict__ err_out) {
@@ -95,8 +100,10 @@ loglik_kernel(PmlTree t, PmlCols c, PmlState st, int n_cols, int is_marginal, do
     // host before anything that launch publishes)
     __threadfence_system();
 }
+#endif
 
 // joint back-trace, one depth level per launch: state[n] = table[n][state[parent]] (ml.py:615-620)
+#ifdef PML_PLAIN_KERNELS   // (launched by pml_api.hip only: the other translation units leave it out)
 PML_GLOBAL void __launch_bounds__(PML_BLOCK)
 joint_backtrace_kernel(PmlTree t, PmlCols c, PmlState st, int begin, int end) {
     const int col = blockIdx.y;
@@ -106,9 +113,11 @@ joint_backtrace_kernel(PmlTree t, PmlCols c, PmlState st, int begin, int end) {
         st.js[colN + n] = st.J[(colN + n) * c.ks + ps];
     }
 }
+#endif
 
 // the depth levels right below the roots (a handful of nodes each) in one launch: one workgroup per column, a
 // workgroup barrier between levels; depth_offsets[d] .. depth_offsets[d + 1] are the node ids of depth d
+#ifdef PML_PLAIN_KERNELS   // (launched by pml_api.hip only: the other translation units leave it out)
 PML_GLOBAL void __launch_bounds__(PML_BLOCK)
 joint_backtrace_narrow_kernel(PmlTree t, PmlCols c, PmlState st, const int* __restrict__ depth_offsets, int first_depth,
                               int n_depths) {
@@ -123,11 +132,13 @@ joint_backtrace_narrow_kernel(PmlTree t, PmlCols c, PmlState st, const int* __re
         __syncthreads();
     }
 }
+#endif
 
 // The depths below the narrow end in tiers: a tier of depths is cut into the subtrees hanging off its first depth, one
 // workgroup per (subtree, column) walks its depths with a workgroup barrier between them -- one launch per tier instead
 // of one per depth (the work is one table look-up per node: a depth is pure launch latency).  nodes: the tier's nodes,
 // subtree by subtree, depth by depth; subtree b's depth table starts at lv[blk_start[b]], n_depths + 1 entries.
+#ifdef PML_PLAIN_KERNELS   // (launched by pml_api.hip only: the other translation units leave it out)
 PML_GLOBAL void __launch_bounds__(PML_BLOCK)
 joint_backtrace_blocks_kernel(PmlTree t, PmlCols c, PmlState st, const int* __restrict__ nodes,
                               const int* __restrict__ lv, const int* __restrict__ blk_start, int n_depths) {
@@ -144,6 +155,7 @@ joint_backtrace_blocks_kernel(PmlTree t, PmlCols c, PmlState st, const int* __re
         __syncthreads();
     }
 }
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------------
 // State selection from the marginal posteriors: MAP (pastml/ml.py:577-595) and MPPA (pastml/ml.py:505-574).
@@ -413,6 +425,7 @@ select_states_kernel(int N, int k, int ks, int W, const double* __restrict__ pos
 // Inspection only, not on the measured path: plain loops, k <= 256 states in up to four registers per lane.
 // P: transposed matrices of the matrix models ([C][N][k][ks], Pt[j][i] = P[i][j]) or nullptr for the F81 family, whose
 // P = (1 - e) 1 pi^T + e I is applied in closed form.
+#ifdef PML_PLAIN_KERNELS   // (launched by pml_api.hip only: the other translation units leave it out)
 PML_GLOBAL void __launch_bounds__(PML_BLOCK)
 td_fill_kernel(PmlTree t, PmlCols c, PmlState st, const double* __restrict__ P, int f81, int begin, int end) {
     __shared__ double sv[PML_WAVES_PER_BLOCK][PML_MAX_STATES_SEL];
@@ -501,9 +514,11 @@ td_fill_kernel(PmlTree t, PmlCols c, PmlState st, const double* __restrict__ P, 
         __builtin_amdgcn_wave_barrier();
     }
 }
+#endif
 
 // sum of the columns' log-likelihoods in column order (as a host loop over the characters would add them), on the device:
 // the values are where the last kernel of the sweep put them (pinned host memory, visible to the device)
+#ifdef PML_PLAIN_KERNELS   // (launched by pml_api.hip only: the other translation units leave it out)
 PML_GLOBAL void sum_loglik_kernel(const double* __restrict__ loglik, int n, double* __restrict__ total) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         double acc = 0.0;
@@ -511,10 +526,12 @@ PML_GLOBAL void sum_loglik_kernel(const double* __restrict__ loglik, int n, doub
         total[0] = acc;
     }
 }
+#endif
 
 // PML_OPT_IMPLICIT_TIP_POSTERIORS: the rows the top-down sweep left implicit -- an observed tip (one allowed state) with a
 // positive finite likelihood has the unit vector of its state as its posterior (pastml/ml.py:498-500 gives exactly that)
 // -- written out when somebody reads the table.  One thread per (tip, column).
+#ifdef PML_PLAIN_KERNELS   // (launched by pml_api.hip only: the other translation units leave it out)
 PML_GLOBAL void __launch_bounds__(PML_BLOCK)
 tip_posteriors_kernel(PmlCols c, PmlState st, int N, const int* __restrict__ tips, int n_tips) {
     const int col = blockIdx.y;
@@ -529,9 +546,11 @@ tip_posteriors_kernel(PmlCols c, PmlState st, int N, const int* __restrict__ tip
         for (int i = 0; i < c.ks; ++i) row[i] = i == s ? 1.0 : 0.0;
     }
 }
+#endif
 
 // start of a bottom-up sweep: the columns' error words, and (if given) the counters of the tips the lean tips kernel of
 // the eigen joint sweep hands on
+#ifdef PML_PLAIN_KERNELS   // (launched by pml_api.hip only: the other translation units leave it out)
 PML_GLOBAL void reset_err_kernel(u64* __restrict__ err, int n, int* __restrict__ counters = nullptr) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
@@ -539,3 +558,21 @@ PML_GLOBAL void reset_err_kernel(u64* __restrict__ err, int n, int* __restrict__
         if (counters != nullptr) counters[i] = 0;
     }
 }
+#endif
+
+// Rows of a per-node table from the library's numbering into the caller's, on the device (outputs of a renumbered forest:
+// the copy to the host is then one contiguous transfer and the host never holds a second copy of the table).  Row i of dst
+// (words_dst 4-byte words) = the first words_dst words of row map[first + i * stride] of src (rows of words_src words).
+#ifdef PML_PLAIN_KERNELS   // (launched by pml_api.hip only: the other translation units leave it out)
+PML_GLOBAL void __launch_bounds__(PML_BLOCK)
+gather_rows_kernel(const unsigned* __restrict__ src, unsigned* __restrict__ dst, const int* __restrict__ map, long long n_rows,
+                   int words_dst, int words_src, int first, int stride) {
+    const long long total = n_rows * words_dst;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const long long row = idx / words_dst;
+        const int w = (int)(idx - row * words_dst);
+        dst[idx] = src[(size_t)map[first + row * stride] * words_src + w];
+    }
+}
+#endif
+

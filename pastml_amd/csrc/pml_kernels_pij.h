@@ -3,6 +3,7 @@
 #include "pml_kernels_matrix.h"
 
 // HKY: one thread per (branch, column); stores the transposed 4x4 (row stride ks = 4)
+#ifdef PML_PLAIN_KERNELS   // (launched by pml_api.hip only: the other translation units leave it out)
 PML_GLOBAL void __launch_bounds__(PML_BLOCK)
 pij_hky_kernel(PmlTree t, PmlCols c, PmlModel m, double* __restrict__ P) {
     const int col = blockIdx.y;
@@ -19,11 +20,13 @@ pij_hky_kernel(PmlTree t, PmlCols c, PmlModel m, double* __restrict__ P) {
             for (int i = 0; i < 4; ++i) out[j * 4 + i] = p[i][j];
     }
 }
+#endif
 
 // Eigen models: P = A diag(exp(d t')) Ainv (pastml/models/generator.py:54-65).
 // One workgroup walks a chunk of branches of one column; A and Ainv^T are staged once in LDS (rows padded by one
 // double against bank conflicts), exp(d t') per branch in LDS; thread e computes output element (i = e % k, j = e / k)
 // so that the transposed store Pt[j][i] is coalesced.
+#ifdef PML_PLAIN_KERNELS   // (launched by pml_api.hip only: the other translation units leave it out)
 PML_GLOBAL void __launch_bounds__(PML_BLOCK)
 pij_eigen_kernel(PmlTree t, PmlCols c, PmlModel m, double* __restrict__ P, int branches_per_block, int use_lds) {
     extern __shared__ double smem[];
@@ -71,8 +74,10 @@ pij_eigen_kernel(PmlTree t, PmlCols c, PmlModel m, double* __restrict__ P, int b
         }
     }
 }
+#endif
 
 // Explicit row-major P for a list of branch lengths (API get_Pij_t, tests): one thread per output element.
+#ifdef PML_PLAIN_KERNELS   // (launched by pml_api.hip only: the other translation units leave it out)
 PML_GLOBAL void __launch_bounds__(PML_BLOCK)
 pij_explicit_kernel(PmlCols c, PmlModel m, int col, int n_t, const double* __restrict__ ts, double* __restrict__ out) {
     const int k = c.k;
@@ -102,6 +107,7 @@ pij_explicit_kernel(PmlCols c, PmlModel m, int col, int n_t, const double* __res
         out[e] = v;
     }
 }
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Eigen models, 16 <= k <= 32: the P(t) batch as a tall GEMM on the FP64 matrix cores (v_mfma_f64_16x16x4_f64).

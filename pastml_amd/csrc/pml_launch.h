@@ -14,7 +14,6 @@
     X(4, 1)              \
     X(8, 1)              \
     X(16, 1)             \
-    X(32, 1)             \
     X(64, 1)             \
     X(32, 2)             \
     X(64, 2)             \
@@ -125,7 +124,6 @@ PML_INTERNAL int dispatch_small_f81(pml_ctx* ctx, bool bottom_up, int do_prep, i
 PML_INTERNAL int dispatch_blocks_f81(pml_ctx* ctx, bool bottom_up, int which = 0);
 // ---- pml_launch_f81_super.hip: two-level and stacked units
 PML_INTERNAL int dispatch_super_f81(pml_ctx* ctx, bool bottom_up);
-PML_INTERNAL int dispatch_absorb_f81(pml_ctx* ctx, bool bottom_up, int level);
 PML_INTERNAL int dispatch_stack_f81(pml_ctx* ctx, bool bottom_up, int level);
 // ---- pml_launch_eigen_mfma.hip: fused FP64 matrix-core sweeps of the eigen models, P(t) batch on the matrix cores
 PML_INTERNAL int launch_eigen_fused(pml_ctx* ctx, int mode, const int* nodes, int first, int n, int tips);

@@ -53,7 +53,7 @@ static void launch_blocks_f81(pml_ctx* ctx, bool bottom_up, int which) {
     if (bottom_up)
         hipLaunchKernelGGL((bu_f81_blocks_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, B.units, B.start, B.levels, B.lv);
     else {
-        const bool signal = ctx->signal_next_td && ctx->C <= 64 && !ctx->windowed && !ctx->tune.on(T_NO_SPIN_WAIT);
+        const bool signal = ctx->signal_next_td && ctx->C <= 64 && !ctx->tune.on(T_NO_SPIN_WAIT);
         ctx->signal_next_td = false;
         hipLaunchKernelGGL((td_f81_blocks_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, B.units, B.start, B.levels,
                            B.lv, signal ? ctx->d_done : nullptr, signal ? ctx->h_done : nullptr);

@@ -49,15 +49,13 @@ static void launch_sweep_f81(pml_ctx* ctx, SweepKind what, const int* level, int
             break;
         case SW_TD_FUSED: {
             // units narrower than 8 lanes stage their posterior rows in LDS (pml_kernels_f81.h, post_row / post_onehot)
-            const bool no_stage = ctx->tune.on(T_NO_TD_STAGE);
-            const int scal_env = (int)ctx->tune.get(T_TD_STAGE_SCALARS, -1);
             int stage = 0;
             size_t lds = 0;
             // (measured, 262 144 tips x 32 columns: k = 2 0.59 -> 0.39 ms, k = 4 0.68 -> 0.45, k = 8 0.83 -> 0.71; with four
             // lanes per unit, k = 12 / 16, a loss of 5 - 10 %)
-            if (G <= PML_TD_STAGE_MAX_G && !no_stage && (c.ks & 1) == 0) {
-                const bool scalars = scal_env >= 0 ? scal_env != 0 : true;
-                stage = scalars ? 3 : 1;
+            if (G <= PML_TD_STAGE_MAX_G && (c.ks & 1) == 0) {
+                const bool scalars = true;   // (the rows' sums and exponents are staged with them)
+                stage = 3;
                 // bit 2: some unit of the level has a cherry among its first two children (tip slots in use)
                 bool cherries = true;
                 if (ctx->units_override == nullptr && !ctx->td_cherry_prefix.empty()) {

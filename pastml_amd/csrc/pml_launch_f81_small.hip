@@ -15,14 +15,14 @@ static void launch_small_f81(pml_ctx* ctx, bool bottom_up, int do_prep, const Pm
         // The completion word (bu_f81_small_kernel, wait_bottom_up) for sweeps of few columns, where the host's wait is
         // a tenth of the sweep (HIV1C tree, k = 12: 14 columns 0.1265 -> 0.1127 ms per sweep; at 128 columns the
         // system-scope fences in 128 workgroups cost what the spin saves: 0.203 against 0.207 ms)
-        const bool signal = ctx->sched_cols <= 64 && !ctx->windowed && !ctx->tune.on(T_NO_SPIN_WAIT);
+        const bool signal = ctx->sched_cols <= 64 && !ctx->tune.on(T_NO_SPIN_WAIT);
         hipLaunchKernelGGL((bu_f81_small_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, ctx->d_mu, ctx->d_sf,
                            ctx->d_tau, ctx->d_tauf, do_prep, units, d_offsets, n_levels, ctx->h_loglik, ctx->h_err,
                            reset_err, signal ? ctx->d_done : nullptr, signal ? ctx->h_done : nullptr);
         ctx->enqueue_signals = signal;  // (the last launch of a bottom-up sweep whenever it is part of one)
         if (signal) ++ctx->signals_enqueued;
     } else {
-        const bool signal = ctx->signal_next_td && ctx->C <= 64 && !ctx->windowed && !ctx->tune.on(T_NO_SPIN_WAIT);
+        const bool signal = ctx->signal_next_td && ctx->C <= 64 && !ctx->tune.on(T_NO_SPIN_WAIT);
         ctx->signal_next_td = false;
         hipLaunchKernelGGL((td_f81_small_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, units, d_offsets,
                            n_levels, signal ? ctx->d_done : nullptr, signal ? ctx->h_done : nullptr, skip_roots);

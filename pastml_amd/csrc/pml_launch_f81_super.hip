@@ -29,27 +29,6 @@ static void launch_stack_f81(pml_ctx* ctx, bool bottom_up, int a, int n) {
         hipLaunchKernelGGL((td_f81_stack_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, ctx->sup.d_stack_td + a, n);
 }
 
-// general two-level units: the absorbing nodes of bottom-up level `level` (a launch next to the level's plain units), or
-// every absorbed node's top-down unit (one launch behind the depth launches)
-template <int G, int R>
-static void launch_absorb_f81(pml_ctx* ctx, bool bottom_up, int a, int n) {
-    const PmlTree t = tree_of(ctx, true);
-    const PmlCols c = cols_of(ctx);
-    const PmlState st = state_of(ctx);
-    const int upb = PML_WAVES_PER_BLOCK * (64 / G);
-    dim3 grid(grid_for(ctx, n, upb, ctx->C), ctx->C), block(PML_BLOCK);
-    if (bottom_up) {
-        hipLaunchKernelGGL((bu_f81_absorb_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, ctx->sup.d_absorb_bu + 3 * (size_t)a, n);
-    } else {
-        hipLaunchKernelGGL((td_f81_absorb_kernel<G, R>), grid, block, 0, ctx->stream, t, c, st, ctx->sup.d_absorb_td + a, n);
-        if (ctx->sup.n_absorbing_td > 0) {
-            dim3 g2(grid_for(ctx, ctx->sup.n_absorbing_td, upb, ctx->C), ctx->C);
-            hipLaunchKernelGGL((td_f81_absorbing_kernel<G, R>), g2, block, 0, ctx->stream, t, c, st, ctx->sup.d_absorbing_td,
-                               ctx->sup.n_absorbing_td);
-        }
-    }
-}
-
 int dispatch_super_f81(pml_ctx* ctx, bool bottom_up) {
     if (ctx->sup.n <= 0) return PML_OK;  // (a schedule of stacked units only)
     int g, r;
@@ -63,29 +42,6 @@ int dispatch_super_f81(pml_ctx* ctx, bool bottom_up) {
     PML_SUPER_CASES(X)
 #undef X
     return fail(PML_ERR_UNSUPPORTED, "no two-level F81 kernel for G=%d R=%d", g, r);
-}
-
-int dispatch_absorb_f81(pml_ctx* ctx, bool bottom_up, int level) {
-    const pml_ctx::SuperSchedule& U = ctx->sup;
-    if (U.n_absorbed == 0) return PML_OK;
-    int a = 0, n = U.n_absorbed;
-    if (bottom_up) {
-        if (level + 1 >= (int)U.absorb_bu_offsets.size()) return PML_OK;
-        a = U.absorb_bu_offsets[level];
-        n = U.absorb_bu_offsets[level + 1] - a;
-    }
-    if (n <= 0) return PML_OK;
-    int g, r;
-    super_shape(ctx, bottom_up, g, r);
-#define X(G_, R_)                                          \
-    if (g == G_ && r == R_) {                              \
-        launch_absorb_f81<G_, R_>(ctx, bottom_up, a, n);   \
-        HIP_TRY(hipGetLastError());                        \
-        return PML_OK;                                     \
-    }
-    PML_SUPER_CASES(X)
-#undef X
-    return fail(PML_ERR_UNSUPPORTED, "no general two-level F81 kernel for G=%d R=%d", g, r);
 }
 
 int dispatch_stack_f81(pml_ctx* ctx, bool bottom_up, int level) {

@@ -107,6 +107,8 @@ SIGNATURES = {
     'pml_comm_unique_id': [ctypes.POINTER(ctypes.c_ubyte)],
     'pml_comm_init': [_ctx_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_ubyte)],
     'pml_comm_destroy': [_ctx_p],
+    'pml_comm_info': [_ctx_p] + [ctypes.POINTER(ctypes.c_int32)] * 4,
+    'pml_device_uuid': [ctypes.c_int, ctypes.c_char_p],
     'pml_comm_allreduce': [_ctx_p, _c_double_p, _c_double_p, ctypes.c_int32, ctypes.c_int],
     'pml_allreduce_loglik': [_ctx_p, _c_double_p, ctypes.c_int32, _c_double_p],
     'pml_device_sync': [ctypes.c_int],
@@ -146,6 +148,13 @@ def load_library():
                 fn.restype = _RESTYPES.get(name, ctypes.c_int)
             _lib = lib
     return _lib
+
+
+def device_uuid(device=0):
+    """The GPU's UUID as 32 hex digits (pml_device_uuid): two ranks that print the same one share a device."""
+    buf = ctypes.create_string_buffer(33)
+    _check(load_library().pml_device_uuid(int(device), buf))
+    return buf.value.decode()
 
 
 def build_digest():
@@ -380,6 +389,12 @@ class BareContext(object):
         _check(self._lib.pml_comm_init(self._ctx, rank, world, buf))
         self._comm_attached = True
         self._total_fresh = False
+
+    def comm_info(self):
+        """dict(rank, world, backend ('local' / 'rccl'), rccl_ranks = ncclCommCount of the communicator) -- pml_comm_info."""
+        v = [ctypes.c_int32(0) for _ in range(4)]
+        _check(self._lib.pml_comm_info(self._ctx, *[ctypes.byref(x) for x in v]))
+        return dict(rank=v[0].value, world=v[1].value, backend='rccl' if v[2].value else 'local', rccl_ranks=v[3].value)
 
     def comm_destroy(self):
         _check(self._lib.pml_comm_destroy(self._ctx))

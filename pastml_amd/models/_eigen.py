@@ -5,6 +5,7 @@ reference; P(t) = A diag(exp(d t)) A^-1 for every branch is computed by libpastm
 16 <= k <= 32).
 """
 import logging
+import os
 
 import numpy as np
 
@@ -40,11 +41,47 @@ def get_diagonalisation(frequencies, rate_matrix=None):
     q = get_normalised_generator(frequencies, rate_matrix)
     d, a = np.linalg.eig(q)
     if np.iscomplexobj(d):
-        sq = np.sqrt(np.asarray(frequencies, dtype=np.float64))
-        s = (q * sq[:, None]) / sq[None, :]
-        s = (s + s.T) / 2
-        d, u = np.linalg.eigh(s)
-        return d, u / sq[:, None], u.T * sq[None, :]
+        return _symmetric_route(q, frequencies)
+    return d, a, np.linalg.inv(a)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Batched form: the generators of ONE finite-difference gradient diagonalised together.  The reference re-diagonalises at
+# every frequency assignment (CustomRatesModel.py:62-68): k LAPACK calls per gradient, each behind a dozen small numpy
+# calls.  Here the distinct frequency vectors of a batch become one (n, k, k) stack and numpy.linalg.eig / inv run once on
+# it -- LAPACK per matrix inside numpy's gufunc loop, every slice bit-identical to the single call's result
+# (tests/test_host_logic.py).  What it buys is the Python around LAPACK, not LAPACK: k = 20, 21 points: 2.85 -> 1.9 ms, of
+# which dgeev + dgesv are 1.7.  Measured and dropped (round 6): the same LAPACK routines of numpy's bundled OpenBLAS called
+# from 2 - 16 host threads through the C-ABI -- no faster than one thread, OpenBLAS serialises its small calls on its buffer
+# lock (profiles/r06c_eigen_host.txt).
+# ---------------------------------------------------------------------------------------------------------------------
+def _batching():
+    """PASTML_AMD_EIG_BATCH=0: one diagonalisation per assignment of the frequencies, as the reference does it (measurements)."""
+    return os.environ.get('PASTML_AMD_EIG_BATCH', '1') != '0'
+
+
+def _symmetric_route(q, frequencies):
+    sq = np.sqrt(np.asarray(frequencies, dtype=np.float64))
+    s = (q * sq[:, None]) / sq[None, :]
+    s = (s + s.T) / 2
+    d, u = np.linalg.eigh(s)
+    return d, u / sq[:, None], u.T * sq[None, :]
+
+
+def get_diagonalisation_batch(frequencies, rate_matrix=None):
+    """
+    (d, A, A^-1) of get_diagonalisation for every row of ``frequencies`` (n, k): arrays of shapes (n, k), (n, k, k),
+    (n, k, k), each slice bit-identical to the single call's result.
+    """
+    frequencies = np.ascontiguousarray(frequencies, dtype=np.float64)
+    n, k = frequencies.shape
+    q = np.empty((n, k, k), dtype=np.float64)
+    for i in range(n):   # (the normaliser is a BLAS dot in the reference: kept per matrix so that its bits are the same)
+        q[i] = get_normalised_generator(frequencies[i], rate_matrix)
+    d, a = np.linalg.eig(q)
+    if np.iscomplexobj(d):   # some matrix of the stack came back complex: one by one (the real ones keep the real route)
+        out = [get_diagonalisation(frequencies[i], rate_matrix) for i in range(n)]
+        return (np.array([o[0] for o in out]), np.array([o[1] for o in out]), np.array([o[2] for o in out]))
     return d, a, np.linalg.inv(a)
 
 
@@ -104,8 +141,52 @@ class CustomRatesModel(ModelWithFrequencies):
         self._diagonalise()
 
     def _diagonalise(self):
-        # once per frequency change, as the reference does (CustomRatesModel.py:52,68)
+        # once per frequency change, as the reference does (CustomRatesModel.py:52,68) -- but not for an assignment of the
+        # vector that is already diagonalised (the first stage of the search moves the scaling factor only), and not
+        # inside kernel_points, which diagonalises the vectors of a whole gradient together
+        if self.__dict__.get('_defer_diag'):
+            return
+        key = np.asarray(self._frequencies, dtype=np.float64).tobytes()
+        if self.__dict__.get('_diag_key') == key and _batching():
+            return
         self.D_DIAGONAL, self.A, self.A_INV = get_diagonalisation(self._frequencies, self._rate_matrix)
+        self._diag_key = key
+
+    def kernel_points(self, vectors):
+        """The points of a batch (Model.kernel_points) with ONE batched diagonalisation of their distinct frequency vectors."""
+        if len(vectors) < 2 or not _batching():
+            return ModelWithFrequencies.kernel_points(self, vectors)
+        freqs, rates = [], []
+        self._defer_diag = True
+        try:
+            for ps in vectors:
+                self.set_params_from_optimised(ps)
+                freqs.append(np.ascontiguousarray(self._frequencies, dtype=np.float64))
+                rates.append(self.rate_params())
+        finally:
+            self._defer_diag = False
+        slots, index = {}, []
+        for f in freqs:
+            index.append(slots.setdefault(f.tobytes(), len(slots)))
+        first = {}
+        for j, i in enumerate(index):
+            first.setdefault(i, j)
+        known = self.__dict__.get('_diag_key')
+        todo = [i for i in range(len(slots)) if freqs[first[i]].tobytes() != known]
+        d, a, a_inv = [None] * len(slots), [None] * len(slots), [None] * len(slots)
+        for i in range(len(slots)):
+            if i not in todo:
+                d[i], a[i], a_inv[i] = self.D_DIAGONAL, self.A, self.A_INV
+        if todo:
+            bd, ba, bi = get_diagonalisation_batch(np.array([freqs[first[i]] for i in todo]), self._rate_matrix)
+            for q, i in enumerate(todo):
+                d[i], a[i], a_inv[i] = bd[q], ba[q], bi[q]
+        last = index[-1]
+        self.D_DIAGONAL, self.A, self.A_INV = d[last], a[last], a_inv[last]
+        self._diag_key = freqs[-1].tobytes()
+        return [(dict(kind=KIND_EIGEN, pi=freqs[j], d=np.ascontiguousarray(d[i], dtype=np.float64),
+                      A=np.ascontiguousarray(a[i], dtype=np.float64), Ainv=np.ascontiguousarray(a_inv[i], dtype=np.float64)),
+                 rates[j]) for j, i in enumerate(index)]
 
     @property
     def rate_matrix(self):

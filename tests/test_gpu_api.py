@@ -512,6 +512,45 @@ def test_fallback_optimiser_driver_finds_the_same_optima(model, monkeypatch):
     assert abs(res[0][LOG_LIKELIHOOD] - PINNED[model]['lnl']) < 5e-4 and abs(res[0][MODEL].sf - PINNED[model]['sf']) < 5e-3
 
 
+def test_fallback_driver_follows_the_main_drivers_rules_for_many_parameters(monkeypatch):
+    """
+    A search of 20 and more free parameters (F81, 24 states on the Albania tree: 24 parameters) takes the extra steps of
+    pastml_amd/batch.py -- the polish run with the 1e-6 step, continued once when it stops on the relative-reduction test --
+    in BOTH drivers, under the same switches (the scipy fallback re-ran every start at ftol / 10 and never
+    polished).  Same procedure, same routine: the same optimum; and with the switches off both give the reference's plain
+    procedure.
+    """
+    from pastml_amd import batch
+    k = 24
+    states = np.array(['s{:02d}'.format(i) for i in range(k)])
+    draw = np.random.default_rng(4)
+    weights = draw.dirichlet(np.ones(k))
+    assignment = {}
+
+    def run():
+        tree = read_tree(TREE_NWK)
+        for tip in tree:
+            assignment.setdefault(tip.name, states[draw.choice(k, p=weights)])
+            tip.add_feature('many', {assignment[tip.name]})
+        np.random.seed(239)
+        return acr(tree, columns=['many'], column2states={'many': states}, prediction_method=MPPA, model=F81)[0]
+
+    for polish in (1e-6, 0.0):
+        monkeypatch.setattr(batch, 'POLISH_STEP', polish)
+        main = run()
+        with monkeypatch.context() as m:
+            m.setattr(batch, '_setulb', None)
+            assert not batch.single_loop_optimiser_available()
+            fallback = run()
+        assert abs(main[LOG_LIKELIHOOD] - fallback[LOG_LIKELIHOOD]) <= 1e-9 * abs(main[LOG_LIKELIHOOD]), polish
+        np.testing.assert_allclose(main[MODEL].frequencies, fallback[MODEL].frequencies, rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(main[MODEL].sf, fallback[MODEL].sf, rtol=1e-6)
+        if polish:
+            polished = main[LOG_LIKELIHOOD]
+        else:
+            assert polished >= main[LOG_LIKELIHOOD] - 1e-9   # (the polish can only raise ln L)
+
+
 def test_more_than_256_states_is_refused_by_name():
     """The one bound the reference does not have (Limits): the library answers PML_ERR_UNSUPPORTED, acr() says
     which character it is before doing any work."""

@@ -168,10 +168,7 @@ def test_random_case_with_two_level_units(seed):
             ref_errors.append(e)
         except ValueError:
             pytest.skip('the reference fails on this input (all-zero marginal likelihoods)')
-    # (odd seeds: the general two-level units as well -- whatever is left of the lowest fused level absorbed by its parents)
     tune = dict(BLOCK_NODES=0, SMALL_MANY_NODES=0, SMALL_MAX_NODES=0, SUPER_MIN=1, STACK_MIN=1)
-    if seed % 2:
-        tune['ABSORB_MIN'] = 1
     with hip.Engine(flat, C, k, tune=tune) as eng:
         eng.set_models(list(zip(specs, rates)))
         eng.set_masks(masks)

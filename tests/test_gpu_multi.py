@@ -87,6 +87,7 @@ def test_library_rccl_communicator_world_of_one(monkeypatch):
         uid = hip.comm_unique_id()
         assert len(uid) == hip.COMM_ID_BYTES and any(uid)
         eng.comm_init(0, 1, uid)
+        assert eng.comm_info() == dict(rank=0, world=1, backend='rccl', rccl_ranks=1)   # (ncclCommCount of the communicator)
         lnl = eng.bottom_up(True)
         total = eng.allreduce_loglik(lnl)
         assert total == float(lnl[0]) + float(lnl[1]) + float(lnl[2])
@@ -104,6 +105,8 @@ def test_communicator_survives_tree_upload_and_plain_world_of_one():
     flat = synthetic.balanced_forest(4)
     with hip.BareContext() as ctx:
         ctx.comm_init(0, 1)
+        assert ctx.comm_info() == dict(rank=0, world=1, backend='local', rccl_ranks=0)
+        assert len(hip.device_uuid(0)) == 32
         assert ctx.allreduce_loglik([1.0, 2.0, 3.5]) == 6.5
     with pytest.raises(hip.HipError):
         with hip.BareContext() as ctx:
@@ -192,6 +195,10 @@ def test_bench_two_ranks_under_torchrun(tmp_path):
     assert len(lines) == 1                      # rank 0 only
     line = json.loads(lines[0])
     assert line['n_gpus'] == 2 and line['config']['chars_total'] == 4 and line['config']['collective'] == 'gloo'
+    # who ran where: both ranks report, with the UUID of the one GPU they share
+    assert [p['rank'] for p in line['per_rank']] == [0, 1] and all(p['ms_per_step'] > 0 for p in line['per_rank'])
+    assert line['per_rank'][0]['device_uuid'] == line['per_rank'][1]['device_uuid'] == hip.device_uuid(0)
+    assert line['config']['distinct_devices'] == 1
     _assert_complete_line(line)   # (no parent of ours under a launcher: rank 0 timed the CPU path before touching the GPU)
     np.testing.assert_allclose(line['loglik_sum'], _single_process_logliks(4, 14, 64).sum(), rtol=1e-13)
 
@@ -213,6 +220,29 @@ def test_bench_ends_when_a_rank_dies_before_joining(tmp_path):
     assert r.returncode != 0
     assert time.time() - t0 < 30
     assert b'rank 1 exited with code 7' in r.stderr
+
+
+def test_two_ranks_on_one_gpu_over_rccl_fail_loudly(tmp_path):
+    """
+    The RCCL route with more than one rank cannot succeed on a one-GPU box (RCCL refuses two ranks per device) -- but it
+    must FAIL LIKE A JOB SHOULD: ncclCommInitRank really runs with a world of two, its error comes back through
+    pml_comm_init with RCCL's own text, every rank exits non-zero and `bench.py --gpus 2` ends within seconds instead of
+    hanging in a collective.  (What a wrongly pinned rank on a real 8-GPU node would look like.)
+    """
+    import time
+    env = dict(os.environ, BENCH_ALL_RANKS_ON_GPU0='1', PASTML_AMD_COMM='rccl', PASTML_AMD_RDZV_TIMEOUT='30',
+               HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for key in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'PASTML_AMD_RDZV_DIR'):
+        env.pop(key, None)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0',
+                        '--workload', 'cfg4_small', '--chars-per-gpu', '1', '--no-cpu-baseline'], env=env,
+                       capture_output=True, timeout=180)
+    err = r.stderr.decode()
+    assert r.returncode != 0, r.stdout.decode()[-2000:]
+    assert time.time() - t0 < 60, err[-3000:]
+    assert 'ncclCommInitRank failed' in err, err[-3000:]
+    assert not [l for l in r.stdout.decode().splitlines() if l.startswith('{')]   # no result line from a failed job
 
 
 def test_marginal_pass_reduces_the_total_on_the_device(monkeypatch):

@@ -892,7 +892,8 @@ def test_height_order_is_invisible_at_the_boundary(kind, k, n_tips, arity, n_tre
     pml_tree_upload renumbers a ragged forest into height order (pml_tree_order); every per-node array of the interface
     stays in the caller's numbering.  Against a context that keeps the caller's numbering (NO_HEIGHT_ORDER): the same bits
     in everything that crosses the boundary -- masks in (words and tip states), ln L, the whole-table outputs, every
-    download (whole and strided), joint states and tables, the device selection with likelihood masks, the P(t) batch.
+    download (whole and strided), joint states and tables, the device selection with likelihood masks, the P(t) batch, the
+    sampled scenario counts of pml_marginal_counts for a given seed.
     """
     rng = np.random.default_rng(k * 1000 + n_tips)
     flat = FlatForest.random(n_tips, seed=k + n_tips, max_arity=arity, zero_frac=0.0, n_trees=n_trees)
@@ -917,6 +918,8 @@ def test_height_order_is_invisible_at_the_boundary(kind, k, n_tips, arity, n_tre
             eng.set_masks(masks)
             lnl, post, lh_sum, lh_sf = eng.marginal_pass()
             got.update(lnl=lnl, post=post, lh_sum=lh_sum, lh_sf=lh_sf)
+            # (the sampler's draws are keyed by the caller's node ids: the same scenarios whatever the library's numbering)
+            got['counts'] = eng.marginal_counts(500, seed=17, col=1)
             for what in (hip.BUF_BU, hip.BUF_BU_SF, hip.BUF_TD, hip.BUF_TD_SF, hip.BUF_POSTERIOR, hip.BUF_LH_SUM, hip.BUF_LH_SF):
                 got['dl%d' % what] = eng.download(what, 2)
             if kind == 'F81':
@@ -963,35 +966,6 @@ def test_zero_likelihood_report_names_the_callers_nodes():
                 eng.bottom_up(True)
             seen.append((int(e.value.err_parent[0]), int(e.value.err_child[0])))
     assert seen[0] == seen[1] == (par, child)
-
-
-@pytest.mark.parametrize('parts', [2, 3])
-def test_split_marginal_pass_has_the_same_bits(parts):
-    """
-    PASTML_HIP_SPLIT_PARTS: the marginal pass of a large forest in parts of its columns on two streams (windows of the
-    columns, part i + 1's bottom-up sweep beside part i's top-down sweep).  Off by default (profiles/r05a_split_pass_ab.txt);
-    the results -- ln L, posteriors, the sums, a download of bottom-up vectors afterwards -- are those of the plain pass.
-    """
-    flat = synthetic.balanced_forest(17)   # 131 072 tips x 48 columns: every part is past the 4 M node-column threshold
-    k, cols = 64, 48
-    specs = [(dict(kind=0, pi=synthetic.f81_frequencies(k, c)), (1.0 + 0.02 * c, 0.0, 1.0)) for c in range(cols)]
-    states = np.stack([synthetic.tip_states(flat.n_tips, k, c) for c in range(cols)])
-    out = {}
-    for name, tune in (('plain', dict(SPLIT_PARTS=1)), ('split', dict(SPLIT_PARTS=parts))):
-        with hip.Engine(flat, cols, k, tune=tune) as eng:
-            eng.set_tip_states(states)
-            eng.set_models(specs)
-            for _ in range(2):   # (the second pass reuses what the first allocated)
-                eng.set_models(specs)
-                lnl = eng.marginal_pass(posterior=False, lh=False)[0]
-            sample = [(eng.download_strided(hip.BUF_POSTERIOR, c, 0, 997), eng.download_strided(hip.BUF_LH_SUM, c, 0, 997),
-                       eng.download_strided(hip.BUF_LH_SF, c, 0, 997)) for c in (0, cols // parts, cols - 1)]
-            bu = eng.download(hip.BUF_BU, cols - 1)[::1013]
-            out[name] = (lnl, sample, bu)
-    assert np.array_equal(out['plain'][0], out['split'][0])
-    for a, b in zip(out['plain'][1], out['split'][1]):
-        assert all(np.array_equal(x, y) for x, y in zip(a, b))
-    assert np.array_equal(out['plain'][2], out['split'][2])
 
 
 @pytest.mark.parametrize('k,cols', [(20, 48), (64, 40)])
@@ -1212,44 +1186,26 @@ print(json.dumps(dict(lnl=float(lnl[0]), states=states[0].tolist())))
 
 @pytest.mark.parametrize('k', [2, 4, 7])
 def test_staged_posterior_stores_give_the_same_bits(k):
-    """Top-down level kernels of narrow units (k <= 8) write their posteriors through LDS slots (observed tips as
-    (id, state) pairs); PASTML_HIP_NO_TD_STAGE=1 writes them straight from the units.  Same tables, bit for bit -- on a
-    forest with polytomies, unobserved and ambiguous tips and restricted internal nodes, big enough for level launches."""
-    import json
-    import subprocess
-    import sys
-    code = '''
-import hashlib, json, sys
-import numpy as np
-sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})
-from pastml_amd import hip
-from pastml_amd.tree import FlatForest
-from test_gpu_parity import random_spec, random_masks
-k = {k}
-rng = np.random.default_rng(11)
-flat = FlatForest.random(40000, seed=4, max_arity=5, n_trees=2)
-C = 2
-specs = [(random_spec('F81', k, rng), (1.3, 0.0, 1.0)) for _ in range(C)]
-masks = np.stack([random_masks(flat, k, rng) for _ in range(C)])
-with hip.Engine(flat, C, k) as eng:
-    eng.set_models(specs)
-    eng.set_masks(masks)
-    lnl, post, lh_sum, lh_sf = eng.marginal_pass()
-h = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
-print(json.dumps(dict(lnl=h(lnl), post=h(post), lh_sum=h(lh_sum), lh_sf=h(lh_sf), finite=bool(np.isfinite(post).all()))))
-'''.format(root=REPO, tests=os.path.dirname(os.path.abspath(__file__)), k=k)
+    """Top-down LEVEL kernels of narrow units (k <= 8) write their posteriors through LDS slots (observed tips as
+    (id, state) pairs); the subtree-block kernels of the same lane shape write them straight from the units.  Same unit
+    functions, same tables, bit for bit -- on a forest with polytomies, unobserved and ambiguous tips and restricted
+    internal nodes, big enough for level launches."""
+    rng = np.random.default_rng(11)
+    flat = FlatForest.random(40000, seed=4, max_arity=5, n_trees=2)
+    C = 2
+    specs = [(random_spec('F81', k, rng), (1.3, 0.0, 1.0)) for _ in range(C)]
+    masks = np.stack([random_masks(flat, k, rng) for _ in range(C)])
     out = []
-    for off in (False, True):
-        env = dict(os.environ)
-        env['PASTML_HIP_BLOCK_NODES'] = '0'      # level launches, not subtree blocks
-        env['PASTML_HIP_SMALL_MANY_NODES'] = '0'
-        if off:
-            env['PASTML_HIP_NO_TD_STAGE'] = '1'
-        res = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=600)
-        assert res.returncode == 0, res.stderr[-2000:]
-        out.append(json.loads(res.stdout.strip().splitlines()[-1]))
-    assert out[0]['finite']
-    assert out[0] == out[1]
+    for tune, want in ((dict(BLOCK_NODES=0, SMALL_MANY_NODES=0, NO_THIN=1), hip.SCHEDULE_LEVELS),
+                       (dict(SMALL_MANY_NODES=0, BLOCK_MAX_WORK=1 << 30), hip.SCHEDULE_BLOCKS)):
+        with hip.Engine(flat, C, k, tune=tune) as eng:
+            eng.set_models(specs)
+            eng.set_masks(masks)
+            assert eng.sweep_schedule()[0] == want
+            out.append(eng.marginal_pass())
+    assert np.isfinite(out[0][1]).all()
+    for x, y in zip(out[0], out[1]):
+        assert np.array_equal(x, y)
 
 
 def test_hky_sweeps_with_p_in_registers_give_the_bits_of_the_materialised_batch():
@@ -1433,88 +1389,6 @@ def test_two_level_units_give_the_bits_of_the_level_schedule(k):
         # and the numbers are right: column 1 against the oracle
         ref = orc.bottom_up(flat, masks[1].astype(int), specs[1][0], *specs[1][1])
         np.testing.assert_allclose(results[1][0][1], ref['loglik'], rtol=LNL_RTOL)
-
-
-@pytest.mark.parametrize('k', [17, 24, 32, 33, 64])
-def test_general_two_level_units_give_the_bits_of_the_level_schedule(k):
-    """
-    Ragged forests (random binary trees, trees with polytomies and one-child nodes, several roots): the stored nodes whose
-    children are tips and cherries are absorbed by their parents, whatever the shapes (pml_kernels_f81.h, general two-level
-    units: the absorbed node's vector is never written, its parent does not gather its scalars, its top-down unit reads
-    the parent's row).  Against the plain level schedule (NO_SUPER) bit for bit: ln L, posteriors, sums, scales, the
-    bottom-up vectors a download materialises, the top-down vectors of PML_OPT_KEEP_TD; and against the oracle.
-    """
-    rng = np.random.default_rng(1700 + k)
-    forests = [FlatForest.random(3000, seed=k, max_arity=2, n_trees=1), FlatForest.random(2500, seed=k + 1, max_arity=4, n_trees=3),
-               _forest_with_balanced_clumps(400, seed=k + 2)]
-    base = dict(LEVEL_SCHEDULE, SMALL_MAX_NODES=0, ABSORB_MIN=1)
-    if k <= 32:
-        base.update(F81_R=4, F81_TD_R=4)   # (8 lanes x 4 states also on the forest with polytomies: 16 x 2 has no two-level kernels)
-    for fi, flat in enumerate(forests):
-        C = 3
-        specs = [(random_spec('F81', k, rng), (float(rng.uniform(0.5, 3)), 0.0, 1.0)) for _ in range(C)]
-        masks = np.stack([random_masks(flat, k, rng, missing=0.05, multi=0.05, internal=0.02) for _ in range(C)])
-        masks[0] = synthetic.one_hot_masks(flat, k, rng.integers(0, k, size=flat.n_tips))
-        results = []
-        for variant in ('plain', 'absorb'):
-            tune = dict(base, NO_SUPER=1) if variant == 'plain' else base
-            with hip.Engine(flat, C, k, tune=tune, keep_td=True) as eng:
-                eng.set_models(specs)
-                eng.set_masks(masks)
-                kind, _, n_absorbed = eng.sweep_schedule()
-                if variant == 'plain':
-                    assert kind == hip.SCHEDULE_LEVELS and n_absorbed == 0
-                else:
-                    assert kind == hip.SCHEDULE_TWO_LEVEL and (n_absorbed > 0 or fi == 2), (fi, kind, n_absorbed)
-                lnl, post, lh_sum, lh_sf = eng.marginal_pass()
-                again = eng.bottom_up(True)
-                assert np.array_equal(lnl, again)
-                bu = [eng.download(hip.BUF_BU, c) for c in range(C)]
-                bu_sf = [eng.download(hip.BUF_BU_SF, c) for c in range(C)]
-                post2, lh_sum2, lh_sf2 = eng.top_down_marginals()    # after the download's materialisation
-                assert np.array_equal(post, post2) and np.array_equal(lh_sum, lh_sum2)
-                td = eng.download(hip.BUF_TD, 1)
-                td_sf = eng.download(hip.BUF_TD_SF, 1)
-            results.append((lnl, post, lh_sum, lh_sf, np.stack(bu), np.stack(bu_sf), td, td_sf))
-        assert np.isfinite(results[0][1]).all()
-        for a, b in zip(results[0], results[1]):
-            assert np.array_equal(a, b), 'forest {}'.format(fi)
-        ref = orc.full_marginal_pass(flat, masks[1].astype(int), specs[1][0], *specs[1][1])
-        np.testing.assert_allclose(results[1][0][1], ref['loglik'], rtol=LNL_RTOL)
-        np.testing.assert_allclose(results[1][1][1], ref['posterior'], rtol=POST_RTOL, atol=1e-300)
-
-
-def test_general_two_level_units_report_the_reference_pair_on_zero_likelihood():
-    """An absorbed node whose vector comes out all zero (its own mask is empty): the unit falls back to the sequential
-    path, which names the pair the reference would -- the same pair as the plain level schedule."""
-    k = 40
-    flat = FlatForest.random(2000, seed=11, max_arity=2, n_trees=1)
-    rng = np.random.default_rng(6)
-    spec = (random_spec('F81', k, rng), (1.0, 0.0, 1.0))
-    masks = synthetic.one_hot_masks(flat, k, rng.integers(0, k, size=flat.n_tips))
-    # a stored node without stored children: every child a tip or a cherry, not all of them tips
-    kid_tip = np.zeros(flat.n_nodes, dtype=bool)
-    cherry = np.zeros(flat.n_nodes, dtype=bool)
-    for n in range(flat.n_nodes):
-        ch = range(flat.first_child[n], flat.first_child[n] + flat.n_children[n])
-        cherry[n] = flat.n_children[n] > 0 and all(flat.n_children[c] == 0 for c in ch) and flat.parent[n] >= 0
-    node = next(n for n in range(flat.n_nodes) if flat.n_children[n] > 0 and not cherry[n] and flat.parent[n] >= 0 and
-                all(flat.n_children[c] == 0 or cherry[c] for c in range(flat.first_child[n], flat.first_child[n] + flat.n_children[n])))
-    bad = masks.copy()
-    bad[node] = 0
-    out = []
-    base = dict(LEVEL_SCHEDULE, SMALL_MAX_NODES=0, ABSORB_MIN=1)
-    for variant in ('plain', 'absorb'):
-        with hip.Engine(flat, 2, k, tune=dict(base, NO_SUPER=1) if variant == 'plain' else base) as eng:
-            eng.set_models([spec, spec])
-            eng.set_masks(np.stack([masks, bad]))
-            assert (eng.sweep_schedule()[2] > 0) == (variant == 'absorb')
-            with pytest.raises(hip.ZeroLikelihoodError) as e:
-                eng.bottom_up(True)
-            out.append((int(e.value.err_parent[0]), int(e.value.err_child[0]), int(e.value.err_parent[1]),
-                        int(e.value.err_child[1])))
-    assert out[0][:2] == (-1, -1) and out[0][2] == node
-    assert out[0] == out[1]
 
 
 def test_two_level_units_report_the_reference_pair_on_zero_likelihood():

@@ -413,6 +413,60 @@ def test_kernel_points_decodes_a_batch_like_one_vector_at_a_time():
     assert [p[1][0] for p in jc.kernel_points([np.array([v]) for v in (1., 2., 3.)])] == [1., 2., 3.] and jc.sf == 3.
 
 
+def test_batched_diagonalisation_gives_the_single_calls_bits():
+    """
+    CustomRatesModel.kernel_points: the distinct frequency vectors of a batch of optimiser points are diagonalised by one
+    stacked numpy.linalg.eig / inv call.  Every (d, A, A^-1) must be the array the reference's route gives for that vector --
+    one get_diagonalisation per assignment of the frequencies (generator.py:16-30, CustomRatesModel.py:62-68) -- bit for bit:
+    the optimiser's iterates depend on them.  With frequency smoothing a point's frequencies depend on the previous point's
+    (models/__init__.py:331-335), which the deferred decoding must keep.
+    """
+    from pastml_amd.models import ModelWithFrequencies
+    from pastml_amd.models._eigen import CustomRatesModel, get_diagonalisation, get_diagonalisation_batch
+    fs = ForestStats([read_tree(os.path.join(GOLDEN, 'data', 'Albanian.tree.152tax.tre'))])
+    rng = np.random.default_rng(1)
+    for k in (2, 5, 20, 36):
+        rates = np.triu(rng.uniform(0.1, 3, size=(k, k)), 1)
+        rates = rates + rates.T
+        freqs = rng.dirichlet(np.ones(k) * 2, size=7)
+        d, a, ai = get_diagonalisation_batch(freqs, rates)
+        for i in range(len(freqs)):
+            d1, a1, ai1 = get_diagonalisation(freqs[i], rates)
+            assert np.array_equal(d[i], d1) and np.array_equal(a[i], a1) and np.array_equal(ai[i], ai1)
+        states = np.array(['s%02d' % i for i in range(k)])
+        for smoothing in (False, True):
+            m1, m2 = (CustomRatesModel(states=states, forest_stats=fs, rate_matrix=rates, frequencies=freqs[0].copy(),
+                                       frequency_smoothing=smoothing) for _ in range(2))
+            for fixed in (True, False):   # (the first stage of the search moves the scaling factor only)
+                if fixed:
+                    m1.fix_extra_params()
+                    m2.fix_extra_params()
+                else:
+                    m1.unfix_extra_params()
+                    m2.unfix_extra_params()
+                bounds = m1.get_bounds()
+                lo, up = bounds[:, 0], bounds[:, 1]
+                x0 = m1.get_optimised_parameters()
+                vectors = [x0.copy()] + [np.clip(x0 + 1e-8 * (np.arange(len(x0)) == i), lo, up) for i in range(len(x0))] + [x0.copy()]
+                pa, pb = m1.kernel_points(vectors), ModelWithFrequencies.kernel_points(m2, vectors)
+                assert len(pa) == len(pb) == len(vectors)
+                for (sa, ra), (sb, rb) in zip(pa, pb):
+                    assert ra == rb
+                    for key in ('pi', 'd', 'A', 'Ainv'):
+                        assert np.array_equal(sa[key], sb[key]), (k, smoothing, fixed, key)
+                for attr in ('D_DIAGONAL', 'A', 'A_INV', 'frequencies'):
+                    assert np.array_equal(getattr(m1, attr), getattr(m2, attr))
+                # ... and a plain assignment afterwards still re-diagonalises
+                f2 = rng.dirichlet(np.ones(k))
+                if not fixed:
+                    m1.unfix_extra_params()
+                    m1._optimise_frequencies, keep = True, m1._optimise_frequencies
+                    m1.frequencies = f2
+                    m1._optimise_frequencies = keep
+                    assert np.array_equal(m1.D_DIAGONAL, get_diagonalisation(f2, rates)[0])
+                    m1.frequencies = m2.frequencies
+
+
 def test_visible_devices(monkeypatch):
     """Which GPUs one process uses: its own as a rank of a multi-process launch, an explicit list, else all visible."""
     from pastml_amd import batch as B, hip
