@@ -727,6 +727,9 @@ def secondary_measurements(device):
                                                       .format(flat.n_bu_levels), model_bytes=b,
                                                       achieved=b / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit='GB/s',
                                                       frac=b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS))
+    # ---- a codon-sized eigen model: CUSTOM_RATES, k = 61, sum sweeps fused (two matrix-core GEMMs per 16
+    #      nodes, constant operands in LDS) against the generic path (P(t) of every branch materialised in HBM)
+    out['eigen_k61'] = eigen_k61_measurement(device)
     # ---- an optimisation of an eigen model with free frequencies: CUSTOM_RATES, k = 20, on the HIV1C
     #      tree -- every point of every finite-difference gradient needs its own eigendecomposition on the host
     #      (CustomRatesModel.py:62-68); host / device split, batched diagonalisation against one per point
@@ -816,6 +819,71 @@ def secondary_measurements(device):
                                best_rel_loglik_gain=max([d for d, _ in signed] + [0.0]) if signed else None,
                                columns_beyond_1e6={c: d for d, c in signed if abs(d) > 1e-6})
     return out
+
+
+def eigen_k61_measurement(device, levels=16, k=61, C=4):
+    """Marginal pass (and joint sweep) of a 61-state eigen model on a balanced tree, fused against materialised P(t)."""
+    from pastml_amd import hip, synthetic
+    from pastml_amd.models._eigen import get_diagonalisation
+    flat = synthetic.balanced_forest(levels)
+    rng = np.random.default_rng(61)
+    rates = np.triu(rng.uniform(0.05, 3.0, size=(k, k)), 1)
+    rates = rates + rates.T
+    specs = []
+    for c in range(C):
+        pi = rng.dirichlet(np.ones(k) * 4)
+        d, a, ainv = get_diagonalisation(pi, rates)
+        specs.append((dict(kind=2, pi=pi, d=d, A=a, Ainv=ainv), (1.0, 0.0, 1.0)))
+    tips = np.stack([synthetic.tip_states(flat.n_tips, k, c) for c in range(C)])
+    ks = k + (k & 1)
+    res = {}
+    for label, tune in (('fused', {}), ('materialised', dict(NO_EIGEN_GEMM=1))):
+        with hip.Engine(flat, C, k, device=device, tune=tune) as eng:
+            eng.set_tip_states(tips)
+
+            def marginal():
+                eng.set_models(specs)
+                return eng.marginal_pass(posterior=False, lh=False)[0]
+
+            def joint():
+                eng.set_models(specs)
+                return eng.bottom_up(False)
+            out = {}
+            for name, fn, reps in (('marginal', marginal, 10), ('joint', joint, 5)):
+                lnl = fn()
+                eng.sync()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    fn()
+                eng.sync()
+                out['ms_' + name] = (time.perf_counter() - t0) / reps * 1e3
+                out['lnl_' + name] = [float(v) for v in lnl]
+            res[label] = out
+    f, g = res['fused'], res['materialised']
+    rel = max(abs(a - b) / abs(b) for a, b in zip(f['lnl_marginal'], g['lnl_marginal']))
+    # algorithmic bytes of the fused marginal pass per node and column: bottom-up writes the vector and the message and
+    # reads every message once (3 vectors), top-down reads the parent's TD and BU vectors, the node's own vector and
+    # message and writes TD and posterior (6 vectors); flops: two k x k products per sweep, padded to the 16-row tiles
+    vec = 8.0 * ks
+    bytes_pass = 9 * vec * flat.n_nodes * C
+    flops = 2 * 2 * 2.0 * 64 * 64 * flat.n_nodes * C
+    ms = f['ms_marginal']
+    return dict(workload='CUSTOM_RATES-shaped eigen model, k = {} states, balanced {}-tip tree ({} nodes), {} characters: '
+                         'marginal pass (BU + TD + posteriors) and joint sweep; fused = sum sweeps as P v = A (e o (A^-1 v)) on '
+                         'the FP64 matrix cores, operands in LDS (pml_kernels_eigen_gemm.h); materialised = P(t) of every '
+                         'branch in HBM ({:.1f} GB), the path of every k > 32 before round 6'
+                         .format(k, flat.n_tips, flat.n_nodes, C, flat.n_nodes * C * k * ks * 8 / 1e9),
+                ms_marginal_pass=ms, ms_marginal_pass_materialised=g['ms_marginal'],
+                speedup_marginal=g['ms_marginal'] / ms,
+                ms_joint_sweep=f['ms_joint'], ms_joint_sweep_materialised=g['ms_joint'],
+                max_rel_loglik_difference=rel, loglik_fused=f['lnl_marginal'], loglik_materialised=g['lnl_marginal'],
+                value=flat.n_nodes * k * C / (ms * 1e-3), unit='node*state*char/s',
+                roofline=dict(bound='hbm', model_bytes=bytes_pass, achieved=bytes_pass / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS,
+                              unit='GB/s', frac=bytes_pass / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              mfma_tflops=flops / (ms * 1e-3) / 1e12,
+                              mfma_frac=flops / (ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                              byte_model='9 vectors of {} B per node and column (BU: vector + message written, message read; '
+                                         'TD: parent TD + BU, own BU + message read, TD + posterior written)'.format(int(vec))))
 
 
 def custom_rates_optimisation(nwk, k=20):

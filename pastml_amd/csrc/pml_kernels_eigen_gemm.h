@@ -1,4 +1,4 @@
-// Eigen models (CUSTOM_RATES, JTT), 2 <= k <= 32: the SUM sweeps (marginal bottom-up, top-down) without ever forming
+// Eigen models (CUSTOM_RATES, JTT), 2 <= k <= 64: the SUM sweeps (marginal bottom-up, top-down) without ever forming
 // P(t).  Both apply P(t_n) = A diag(exp(d t_n)) A^-1 of the branch above a node n to ONE vector of that node
 //   bottom-up  (ml.py:124-148)   msg_n = P v_n        v_n = mask o prod of the children's messages
 //   top-down   (ml.py:273-290)   td_n  = P x_n        x_n = TD_p o BU_p / msg_n
@@ -14,6 +14,12 @@
 // per node stay in the lane; only per-node reductions (zero check, rescaling, likelihood sum) cross the four lanes
 // (lo, lo + 16, lo + 32, lo + 48) of a node.  20 MFMAs per 16 nodes at k = 20 (the matrix-building sweep: 200).
 //
+// More than 32 states (round 6: codon models, k = 61 / 64; HIV1C's k = 36 / 67 columns under CUSTOM_RATES used to fall back to
+// P(t) materialised in HBM, 32 KB per branch and column at k = 64): the same two GEMMs with 3 or 4 row tiles.  The constant
+// operands no longer fit the register file (2 x 4 x 16 doubles per lane), so the block keeps them in LDS in operand layout --
+// [tile][k-step][lane], one conflict-free ds_read_b64 per MFMA, 64 KB at k = 64, shared by the block's four waves -- and a
+// matrix instruction (64 clocks of its SIMD) hides the read.  EigGemm<KS>::LDS says which form a shape takes.
+//
 // Rounding: P v is evaluated in a different order than the reference's (P built, then applied).  Both carry an
 // absolute error of a few ulps of |A| |A^-1| |v| (cond(A) = 2 for JTT); messages are bounded below by
 // min_j P[i][j] max v, so relative errors stay ~1e-11 (tests: 1e-9 on posteriors, 1e-11 on ln L).
@@ -25,6 +31,8 @@ template <int KS>
 struct EigGemm {
     static constexpr int KP = 4 * KS;             // padded states
     static constexpr int MT = (KP + 15) / 16;     // row tiles of the constant matrices
+    static constexpr bool LDS = KS > 8;           // the constant operands live in LDS, not in registers
+    static constexpr int LDS_DOUBLES = LDS ? 2 * MT * KS * 64 : 0;
 };
 
 // per-node reductions over the four lanes (lo, lo + 16 q) that share a node
@@ -68,12 +76,27 @@ template <int KS>
 struct EigGemmWave {
     int k, ks, col, lo, hi;
     size_t colN;
-    double a1[EigGemm<KS>::MT][KS], a2[EigGemm<KS>::MT][KS], dl[KS], pil[KS];
+    // (registers for k <= 32; one element each when the operands are in LDS: la1 / la2 point at the lane's entries there)
+    double a1[EigGemm<KS>::LDS ? 1 : EigGemm<KS>::MT][EigGemm<KS>::LDS ? 1 : KS];
+    double a2[EigGemm<KS>::LDS ? 1 : EigGemm<KS>::MT][EigGemm<KS>::LDS ? 1 : KS];
+    const double* lds;   // the block's copy of the operands: [2][MT][KS][64]
+    double dl[KS], pil[KS];
     double sfc, tau, tf;
+    // `at`: the lane's offset, made opaque once per pass (eig_gemm_pass) -- the operands are the same in every pass and the
+    // compiler would otherwise hoist all 2 MT KS reads out of the node loop, back into 256 registers
+    __device__ __forceinline__ double op1(int mt, int s, int at) const {
+        return EigGemm<KS>::LDS ? lds[at + (mt * KS + s) * 64] : a1[EigGemm<KS>::LDS ? 0 : mt][EigGemm<KS>::LDS ? 0 : s];
+    }
+    __device__ __forceinline__ double op2(int mt, int s, int at) const {
+        return EigGemm<KS>::LDS ? lds[at + (EigGemm<KS>::MT * KS + mt * KS + s) * 64]
+                                : a2[EigGemm<KS>::LDS ? 0 : mt][EigGemm<KS>::LDS ? 0 : s];
+    }
 };
 
+// smem: EigGemm<KS>::LDS_DOUBLES doubles of dynamic LDS (nullptr for the register form)
 template <int KS>
-__device__ __forceinline__ void eig_gemm_init(EigGemmWave<KS>& W, const PmlTree& t, const PmlCols& c, const PmlModel& m) {
+__device__ __forceinline__ void eig_gemm_init(EigGemmWave<KS>& W, const PmlTree& t, const PmlCols& c, const PmlModel& m,
+                                              double* smem = nullptr) {
     constexpr int MT = EigGemm<KS>::MT;
     const int k = c.k, ks = c.ks;  // k <= ks <= 4 KS: states 4 s + hi >= ks do not exist in memory
     const int col = blockIdx.y;
@@ -88,15 +111,28 @@ __device__ __forceinline__ void eig_gemm_init(EigGemmWave<KS>& W, const PmlTree&
     // constant operands: rows 16 mt + lo of A^-1 (first product) and of A (second), k-step s: column 4 s + hi
     const double* gA = m.A + (size_t)col * k * k;
     const double* gB = m.Ainv + (size_t)col * k * k;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const int row = 16 * mt + lo, cc = 4 * s + hi;
+    W.lds = smem;
+    if (EigGemm<KS>::LDS) {
+        // operand layout [tile][k-step][lane]: entry e of a matrix belongs to lane e % 64 of (mt, s) = (e / 64 / KS, e / 64 % KS)
+        for (int e = threadIdx.x; e < MT * KS * 64; e += blockDim.x) {
+            const int l = e & 63, ms = e >> 6, mt = ms / KS, s2 = ms - mt * KS;
+            const int row = 16 * mt + (l & 15), cc = 4 * s2 + (l >> 4);
             const bool in = row < k && cc < k;
-            W.a1[mt][s] = in ? gB[row * k + cc] : 0.0;
-            W.a2[mt][s] = in ? gA[row * k + cc] : 0.0;
+            smem[e] = in ? gB[row * k + cc] : 0.0;
+            smem[MT * KS * 64 + e] = in ? gA[row * k + cc] : 0.0;
         }
+        __syncthreads();
+    } else {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const int row = 16 * mt + lo, cc = 4 * s + hi;
+                const bool in = row < k && cc < k;
+                W.a1[EigGemm<KS>::LDS ? 0 : mt][EigGemm<KS>::LDS ? 0 : s] = in ? gB[row * k + cc] : 0.0;
+                W.a2[EigGemm<KS>::LDS ? 0 : mt][EigGemm<KS>::LDS ? 0 : s] = in ? gA[row * k + cc] : 0.0;
+            }
+    }
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
         const int j = 4 * s + hi;
@@ -116,9 +152,11 @@ __device__ __forceinline__ void eig_gemm_pass(const EigGemmWave<KS>& W, const Pm
     const int k = W.k, ks = W.ks, col = W.col, lo = W.lo, hi = W.hi;
     const size_t colN = W.colN;
     const double sfc = W.sfc, tau = W.tau, tf = W.tf;
+    int at = threadIdx.x & 63;
+    if (EigGemm<KS>::LDS) asm volatile("" : "+v"(at));
     {
         const size_t row = (colN + n) * ks;
-        const u64 word = c.masks[colN + n];  // k <= 32: one word
+        const u64 word = c.masks[colN + n];  // k <= 64: one word
         const int nc = t.n_children[n];
         const double tt = (t.dist[n] + tau) * tf * sfc;
         double v[KS], mb[KS];
@@ -198,7 +236,7 @@ __device__ __forceinline__ void eig_gemm_pass(const EigGemmWave<KS>& W, const Pm
             acc[mt] = (pml_v4f64){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int s = 0; s < KS; ++s)
-                acc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(W.a1[mt][s], act ? v[s] : 0.0, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(W.op1(mt, s, at), act ? v[s] : 0.0, acc[mt], 0, 0, 0);
         }
         double z[KS];
 #pragma unroll
@@ -207,7 +245,7 @@ __device__ __forceinline__ void eig_gemm_pass(const EigGemmWave<KS>& W, const Pm
         for (int mt = 0; mt < MT; ++mt) {
             acc[mt] = (pml_v4f64){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int s = 0; s < KS; ++s) acc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(W.a2[mt][s], z[s], acc[mt], 0, 0, 0);
+            for (int s = 0; s < KS; ++s) acc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(W.op2(mt, s, at), z[s], acc[mt], 0, 0, 0);
         }
         double out[KS];
 #pragma unroll
@@ -252,8 +290,9 @@ __device__ __forceinline__ void eig_gemm_pass(const EigGemmWave<KS>& W, const Pm
 template <int KS, int MODE>
 __global__ void __launch_bounds__(PML_BLOCK)
 eigen_gemm_kernel(PmlTree t, PmlCols c, PmlModel m, PmlState st, const int* __restrict__ nodes, int first, int n_nodes) {
+    extern __shared__ double eigg_smem[];
     EigGemmWave<KS> W;
-    eig_gemm_init<KS>(W, t, c, m);
+    eig_gemm_init<KS>(W, t, c, m, eigg_smem);
     const int wave = threadIdx.x >> 6;
     const int stride = gridDim.x * PML_WAVES_PER_BLOCK * 16;
     for (int b0 = (blockIdx.x * PML_WAVES_PER_BLOCK + wave) * 16; b0 < n_nodes; b0 += stride) {
@@ -272,8 +311,9 @@ eigen_gemm_narrow_kernel(PmlTree t, PmlCols c, PmlModel m, PmlState st, const in
                          const int* __restrict__ level_offsets, int n_levels, const int* __restrict__ blk_start) {
     // (blk_start: the subtree blocks of a tier of thin levels, one workgroup per (block, column) -- pml_ctx::EigenTiers)
     if (blk_start != nullptr) level_offsets += blk_start[blockIdx.x];
+    extern __shared__ double eigg_smem[];
     EigGemmWave<KS> W;
-    eig_gemm_init<KS>(W, t, c, m);
+    eig_gemm_init<KS>(W, t, c, m, eigg_smem);
     const int wave = threadIdx.x >> 6;
     for (int l = 0; l < n_levels; ++l) {
         const int a = level_offsets[l], n_level = level_offsets[l + 1] - a;

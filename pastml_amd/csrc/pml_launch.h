@@ -96,10 +96,10 @@ static bool deep_top_down(const pml_ctx* ctx) {
 
 // sum sweeps of the eigen models without forming P(t) (pml_kernels_eigen_gemm.h): one launch over a list (nodes) or a
 // contiguous id range (first) of n nodes
-// (any eigen model with up to 32 states: below 16 the joint sweep still reads materialised P(t), see eigen_fused)
+// (any eigen model with up to 64 states; the joint sweep reads materialised P(t) below 16 and beyond 32 states)
 static bool eigen_gemm(const pml_ctx* c) {
     const bool off = c->tune.on(T_NO_EIGEN_GEMM) || c->tune.on(T_NO_MFMA) || c->tune.on(T_NO_EIGEN_FUSED);
-    return !off && c->eig_fused_opt && c->kind == PML_MODEL_EIGEN && c->k >= 2 && c->k <= 32 && c->W == 1;
+    return !off && c->eig_fused_opt && c->kind == PML_MODEL_EIGEN && c->k >= 2 && c->k <= 64 && c->W == 1;
 }
 
 

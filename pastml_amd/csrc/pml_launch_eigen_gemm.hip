@@ -14,8 +14,8 @@ int launch_eigen_gemm(pml_ctx* ctx, int mode, const int* nodes, int first, int n
     if (blocks > cap) blocks = cap;
 #define PML_EIGG_CASE(KS_, MODE_)                                                                                   \
     if (KS == KS_ && mode == MODE_) {                                                                               \
-        hipLaunchKernelGGL((eigen_gemm_kernel<KS_, MODE_>), dim3(blocks, ctx->C), dim3(PML_BLOCK), 0, ctx->stream, \
-                           t, c, m, st, nodes, first, n);                                                           \
+        hipLaunchKernelGGL((eigen_gemm_kernel<KS_, MODE_>), dim3(blocks, ctx->C), dim3(PML_BLOCK),                  \
+                           EigGemm<KS_>::LDS_DOUBLES * sizeof(double), ctx->stream, t, c, m, st, nodes, first, n);  \
         HIP_TRY(hipGetLastError());                                                                                 \
         return PML_OK;                                                                                              \
     }
@@ -28,6 +28,14 @@ int launch_eigen_gemm(pml_ctx* ctx, int mode, const int* nodes, int first, int n
     PML_EIGG_MODES(6)
     PML_EIGG_MODES(7)
     PML_EIGG_MODES(8)
+    PML_EIGG_MODES(9)
+    PML_EIGG_MODES(10)
+    PML_EIGG_MODES(11)
+    PML_EIGG_MODES(12)
+    PML_EIGG_MODES(13)
+    PML_EIGG_MODES(14)
+    PML_EIGG_MODES(15)
+    PML_EIGG_MODES(16)
 #undef PML_EIGG_MODES
 #undef PML_EIGG_CASE
     return fail(PML_ERR_UNSUPPORTED, "no eigen kernel for k = %d", ctx->k);
@@ -43,8 +51,9 @@ int launch_eigen_gemm_narrow(pml_ctx* ctx, int mode, const int* nodes, const int
     const PmlModel m = model_of(ctx);
 #define PML_EIGG_CASE(KS_, MODE_)                                                                                      \
     if (KS == KS_ && mode == MODE_) {                                                                                  \
-        hipLaunchKernelGGL((eigen_gemm_narrow_kernel<KS_, MODE_>), dim3(n_blocks, ctx->C), dim3(PML_BLOCK), 0,         \
-                           ctx->stream, t, c, m, st, nodes, d_offsets + first_level, n_levels, d_blk_start);           \
+        hipLaunchKernelGGL((eigen_gemm_narrow_kernel<KS_, MODE_>), dim3(n_blocks, ctx->C), dim3(PML_BLOCK),            \
+                           EigGemm<KS_>::LDS_DOUBLES * sizeof(double), ctx->stream, t, c, m, st, nodes,                \
+                           d_offsets + first_level, n_levels, d_blk_start);                                            \
         HIP_TRY(hipGetLastError());                                                                                    \
         return PML_OK;                                                                                                 \
     }
@@ -57,6 +66,14 @@ int launch_eigen_gemm_narrow(pml_ctx* ctx, int mode, const int* nodes, const int
     PML_EIGG_MODES(6)
     PML_EIGG_MODES(7)
     PML_EIGG_MODES(8)
+    PML_EIGG_MODES(9)
+    PML_EIGG_MODES(10)
+    PML_EIGG_MODES(11)
+    PML_EIGG_MODES(12)
+    PML_EIGG_MODES(13)
+    PML_EIGG_MODES(14)
+    PML_EIGG_MODES(15)
+    PML_EIGG_MODES(16)
 #undef PML_EIGG_MODES
 #undef PML_EIGG_CASE
     return fail(PML_ERR_UNSUPPORTED, "no eigen kernel for k = %d", ctx->k);

@@ -742,6 +742,43 @@ def case_cfg3_full():
 CASES['cfg3_full'] = case_cfg3_full
 
 
+def case_eigen_k61():
+    """
+    A codon-sized eigen model: the reference's CustomRatesModel (pastml/models/CustomRatesModel.py:35-79,
+    generator.py:54-65) with k = 61 states, seeded symmetric rates and frequencies, on a balanced 4 096-tip tree: the
+    marginal pass and the joint (Pupko) sweep with its back-trace, fixed parameters.  Stored: every scalar, the joint states of
+    all nodes, and the vectors (posteriors, BU / TD / LH with their scales, arg-max rows) at every 7th node.
+    """
+    k, n_levels = 61, 12
+    rng = np.random.default_rng(61)
+    flat = synthetic.balanced_forest(n_levels)
+    roots = flat.to_tree_nodes()
+    fs = RForestStats(roots)
+    states, tips_states = annotate_synthetic(flat, roots, 'c0', k, 0)
+    rates = np.triu(rng.uniform(0.05, 3.0, size=(k, k)), 1)
+    rates = rates + rates.T
+    freqs = rng.dirichlet(np.ones(k) * 4)
+    model = RCR(forest_stats=fs, sf=1., states=np.array(states), rate_matrix=rates, frequencies=freqs)
+    model.freeze()
+    sys.setrecursionlimit(10000)
+    flat2, cap = sweep_capture(roots, 'c0', model)
+    out = dict(forest_stats_arrays(fs))
+    out.update(model_arrays(model))
+    sample = np.arange(0, flat.n_nodes, 7)
+    out['sample'] = sample
+    for key, v in cap.items():
+        if isinstance(v, np.ndarray) and v.ndim == 2 and len(v) == flat.n_nodes:
+            out[key] = v[sample]      # vectors / mask rows: the sample
+        else:
+            out[key] = v              # scalars and per-node scalars (joint states, scales) in full
+    out['tip_states'] = tips_states
+    out['n_levels'] = n_levels
+    save('synthetic_cr_k61_L12', **out)
+
+
+CASES['eigen_k61'] = case_eigen_k61
+
+
 HIV1C_SRC = os.path.join(REF, 'examples', 'HIV1C', 'data')
 HIV1C_DST = os.path.join(DATA, 'hiv1c')
 HIV1C_SCRATCH = os.path.join(REPO, 'scratch', 'hiv1c_all')

@@ -320,6 +320,40 @@ def test_cfg2_full_size_matches_reference_sample():
     np.testing.assert_allclose(np.log10(lh_sum[0]) - lh_sf[0], lnl[0] / np.log(10), rtol=1e-11)
 
 
+@pytest.mark.parametrize('fused', [True, False])
+def test_custom_rates_k61_matches_reference(fused):
+    """
+    A codon-sized eigen model: the reference's CustomRatesModel (pastml/models/CustomRatesModel.py:70-79,
+    generator.py:54-65) with 61 states on a balanced 4 096-tip tree (tests/golden/make_golden.py::case_eigen_k61) --
+    marginal pass and joint sweep + back-trace.  fused: the sum sweeps as two matrix-core GEMMs per 16 nodes with the
+    constant operands in LDS (pml_kernels_eigen_gemm.h, 32 < k <= 64: P(t) is never formed); not fused: P(t) of every branch
+    materialised in HBM (the generic path, what every k > 32 took before round 6).  Both against the reference.
+    """
+    z = load_golden('synthetic_cr_k61_L12')
+    k = 61
+    flat = synthetic.balanced_forest(int(z['n_levels']))
+    spec, rates = golden_spec(z)
+    s = z['sample']
+    with hip.Engine(flat, 1, k, tune={} if fused else dict(NO_EIGEN_GEMM=1)) as eng:
+        eng.set_models([(spec, rates)])
+        eng.set_tip_states(z['tip_states'])
+        lnl = eng.bottom_up(True)
+        np.testing.assert_allclose(lnl[0], z['loglik'], rtol=LNL_RTOL)
+        assert_same_scaled(eng.download(hip.BUF_BU)[s], eng.download(hip.BUF_BU_SF)[s], z['bu'], z['bu_sf'][s], what='BU')
+        post, lh_sum, lh_sf = eng.top_down_marginals()
+        np.testing.assert_allclose(post[0][s], z['posterior'], rtol=POST_RTOL, atol=1e-300)
+        np.testing.assert_allclose(post[0].sum(axis=1), 1, rtol=1e-12)
+        np.testing.assert_allclose(np.log10(lh_sum[0]) - lh_sf[0], lnl[0] / np.log(10), rtol=1e-11)
+        assert_same_scaled(eng.download(hip.BUF_TD)[s], eng.download(hip.BUF_TD_SF)[s], z['td'], z['td_sf'][s], what='TD')
+        lnl_j = eng.bottom_up(False)
+        np.testing.assert_allclose(lnl_j[0], z['loglik_joint'], rtol=LNL_RTOL)
+        nonroot = flat.parent[s] >= 0
+        assert np.array_equal(eng.download(hip.BUF_JOINT_TABLE)[s][nonroot], z['joint_table'][nonroot])
+        assert np.array_equal(eng.joint_backtrace()[0], z['joint_state'])
+        # the marginal sweep again after the joint one (the two share the bottom-up buffers)
+        assert np.array_equal(eng.bottom_up(True), lnl)
+
+
 def test_cfg3_full_size_matches_reference_sample():
     """
     BASELINE config 3 at full size: 262 144 tips, JTT k=20, one character, joint (Pupko) sweep + back-trace
