@@ -821,7 +821,7 @@ def secondary_measurements(device):
     return out
 
 
-def eigen_k61_measurement(device, levels=16, k=61, C=4):
+def eigen_k61_measurement(device, levels=16, k=61, C=4, compare=1):
     """Marginal pass (and joint sweep) of a 61-state eigen model on a balanced tree, fused against materialised P(t)."""
     from pastml_amd import hip, synthetic
     from pastml_amd.models._eigen import get_diagonalisation
@@ -837,7 +837,7 @@ def eigen_k61_measurement(device, levels=16, k=61, C=4):
     tips = np.stack([synthetic.tip_states(flat.n_tips, k, c) for c in range(C)])
     ks = k + (k & 1)
     res = {}
-    for label, tune in (('fused', {}), ('materialised', dict(NO_EIGEN_GEMM=1))):
+    for label, tune in (('fused', {}), ('materialised', dict(NO_EIGEN_GEMM=1)))[:2 if compare else 1]:
         with hip.Engine(flat, C, k, device=device, tune=tune) as eng:
             eng.set_tip_states(tips)
 
@@ -848,8 +848,11 @@ def eigen_k61_measurement(device, levels=16, k=61, C=4):
             def joint():
                 eng.set_models(specs)
                 return eng.bottom_up(False)
+            def bottom_up():
+                eng.set_models(specs)
+                return eng.bottom_up(True)
             out = {}
-            for name, fn, reps in (('marginal', marginal, 10), ('joint', joint, 5)):
+            for name, fn, reps in (('marginal', marginal, 10), ('bottom_up', bottom_up, 10), ('joint', joint, 5))[:3 if compare else 2]:
                 lnl = fn()
                 eng.sync()
                 t0 = time.perf_counter()
@@ -859,7 +862,9 @@ def eigen_k61_measurement(device, levels=16, k=61, C=4):
                 out['ms_' + name] = (time.perf_counter() - t0) / reps * 1e3
                 out['lnl_' + name] = [float(v) for v in lnl]
             res[label] = out
-    f, g = res['fused'], res['materialised']
+    f = res['fused']
+    g = res.get('materialised', f)
+    f.setdefault('ms_joint', None)
     rel = max(abs(a - b) / abs(b) for a, b in zip(f['lnl_marginal'], g['lnl_marginal']))
     # algorithmic bytes of the fused marginal pass per node and column: bottom-up writes the vector and the message and
     # reads every message once (3 vectors), top-down reads the parent's TD and BU vectors, the node's own vector and
@@ -873,9 +878,9 @@ def eigen_k61_measurement(device, levels=16, k=61, C=4):
                          'the FP64 matrix cores, operands in LDS (pml_kernels_eigen_gemm.h); materialised = P(t) of every '
                          'branch in HBM ({:.1f} GB), the path of every k > 32 before round 6'
                          .format(k, flat.n_tips, flat.n_nodes, C, flat.n_nodes * C * k * ks * 8 / 1e9),
-                ms_marginal_pass=ms, ms_marginal_pass_materialised=g['ms_marginal'],
+                ms_marginal_pass=ms, ms_bottom_up_sweep=f['ms_bottom_up'], ms_marginal_pass_materialised=g['ms_marginal'],
                 speedup_marginal=g['ms_marginal'] / ms,
-                ms_joint_sweep=f['ms_joint'], ms_joint_sweep_materialised=g['ms_joint'],
+                ms_joint_sweep=f['ms_joint'], ms_joint_sweep_materialised=g.get('ms_joint'),
                 max_rel_loglik_difference=rel, loglik_fused=f['lnl_marginal'], loglik_materialised=g['lnl_marginal'],
                 value=flat.n_nodes * k * C / (ms * 1e-3), unit='node*state*char/s',
                 roofline=dict(bound='hbm', model_bytes=bytes_pass, achieved=bytes_pass / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS,

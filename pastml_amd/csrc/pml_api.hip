@@ -1807,22 +1807,26 @@ int pml_model_set_eigen(pml_ctx* ctx, int32_t col_begin, int32_t col_end, const 
     PML_TRY(upload(ctx, ctx->d_A + col_begin * k * k, A, nc * k * k));
     PML_TRY(upload(ctx, ctx->d_Ainv + col_begin * k * k, Ainv, nc * k * k));
     std::vector<double> at, a_t;
-    if (k <= PML_EIGJ_STRIDE) {
-        const size_t sq = (size_t)PML_EIGJ_STRIDE * PML_EIGJ_STRIDE;
+    if (k <= 64) {
+        // transposed, zero-padded copies: A^-1 for the joint sweep on the vector units (k <= 32: its rows through the scalar cache) and
+        // for the observed tips of the sum sweeps (a column of A^-1 is a contiguous row here); A for the P(t) batch below 16 states
+        const size_t ld = k <= PML_EIGJ_STRIDE ? PML_EIGJ_STRIDE : 64, sq = ld * ld;
         if (!ctx->d_AinvT) PML_TRY(dev_alloc(ctx, &ctx->d_AinvT, (size_t)ctx->C * sq));
         at.assign((size_t)nc * sq, 0.0);
         for (int c = 0; c < nc; ++c)
             for (size_t mm = 0; mm < k; ++mm)
                 for (size_t j = 0; j < k; ++j)
-                    at[c * sq + j * PML_EIGJ_STRIDE + mm] = Ainv[(size_t)c * k * k + mm * k + j];
+                    at[c * sq + j * ld + mm] = Ainv[(size_t)c * k * k + mm * k + j];
         PML_TRY(upload(ctx, ctx->d_AinvT + (size_t)col_begin * sq, at.data(), at.size()));
-        if (!ctx->d_AT) PML_TRY(dev_alloc(ctx, &ctx->d_AT, (size_t)ctx->C * sq));
-        a_t.assign((size_t)nc * sq, 0.0);
-        for (int c = 0; c < nc; ++c)
-            for (size_t i = 0; i < k; ++i)
-                for (size_t mm = 0; mm < k; ++mm)
-                    a_t[c * sq + mm * PML_EIGJ_STRIDE + i] = A[(size_t)c * k * k + i * k + mm];
-        PML_TRY(upload(ctx, ctx->d_AT + (size_t)col_begin * sq, a_t.data(), a_t.size()));
+        if (k <= PML_EIGJ_STRIDE) {
+            if (!ctx->d_AT) PML_TRY(dev_alloc(ctx, &ctx->d_AT, (size_t)ctx->C * sq));
+            a_t.assign((size_t)nc * sq, 0.0);
+            for (int c = 0; c < nc; ++c)
+                for (size_t i = 0; i < k; ++i)
+                    for (size_t mm = 0; mm < k; ++mm)
+                        a_t[c * sq + mm * ld + i] = A[(size_t)c * k * k + i * k + mm];
+            PML_TRY(upload(ctx, ctx->d_AT + (size_t)col_begin * sq, a_t.data(), a_t.size()));
+        }
     }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return PML_OK;

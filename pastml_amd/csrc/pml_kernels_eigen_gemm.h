@@ -9,10 +9,10 @@
 // the left operands held in registers:
 //   Y[m][node] = sum_j Ainv[m][j] V[j][node],   Z = Y o E,   MSG[i][node] = sum_m A[i][m] Z[m][node].
 // In v_mfma_f64_16x16x4_f64 the right operand of k-step s is held by lane (lo, hi) as element [4 s + hi][column lo] and
-// the result tile hands lane (lo, hi) the rows hi + 4 reg of column lo: a lane that owns the states {hi, 4 + hi, 8 + hi,
-// ..} of node lo gets exactly those states of Y, and then of MSG, back -- both GEMMs, the exponentials and everything
-// per node stay in the lane; only per-node reductions (zero check, rescaling, likelihood sum) cross the four lanes
-// (lo, lo + 16, lo + 32, lo + 48) of a node.  20 MFMAs per 16 nodes at k = 20 (the matrix-building sweep: 200).
+// the result tile hands lane (lo, hi) the rows hi + 4 reg of column lo: with the operands' rows and columns enumerated
+// accordingly (EigGemm<KS>::st) a lane that owns KS states of node lo gets exactly those states of Y, and then of MSG,
+// back -- both GEMMs, the exponentials and everything per node stay in the lane; only per-node reductions (zero check,
+// rescaling, likelihood sum) cross the four lanes (lo, lo + 16, lo + 32, lo + 48) of a node.  20 MFMAs per 16 nodes at k = 20 (the matrix-building sweep: 200).
 //
 // More than 32 states (round 6: codon models, k = 61 / 64; HIV1C's k = 36 / 67 columns under CUSTOM_RATES used to fall back to
 // P(t) materialised in HBM, 32 KB per branch and column at k = 64): the same two GEMMs with 3 or 4 row tiles.  The constant
@@ -32,6 +32,15 @@ struct EigGemm {
     static constexpr int KP = 4 * KS;             // padded states
     static constexpr int MT = (KP + 15) / 16;     // row tiles of the constant matrices
     static constexpr bool LDS = KS > 8;           // the constant operands live in LDS, not in registers
+    // Which state (and which eigenvalue) slot s of lane (lo, hi) stands for.  The matrix instruction only fixes that k-step s
+    // takes its four k-indices from the four hi-lanes and hands rows hi + 4 r back: WHICH index sits there is the operands'
+    // business (both constant operands are loaded with their rows and columns in this order).  For an even KS a lane owns
+    // PAIRS of neighbouring states -- slots 2 q, 2 q + 1 = states 8 q + 2 hi, + 1 -- so that a vector's part of a lane moves
+    // as 16-byte accesses and the four lanes of a node cover 64 contiguous bytes per instruction: half the load / store
+    // instructions and half the (instruction x cache line) touches of 4 s + hi, which is what these sweeps are bound by
+    // (measured: KS consecutive states per lane -- every lane in a line of its own -- lost 25 %; profiles/r06g_eigen_sweeps.txt).
+    static constexpr bool PAIRS = KS % 2 == 0;
+    static __device__ __forceinline__ int st(int s, int hi) { return PAIRS ? 8 * (s >> 1) + 2 * hi + (s & 1) : 4 * s + hi; }
     static constexpr int LDS_DOUBLES = LDS ? 2 * MT * KS * 64 : 0;
 };
 
@@ -80,7 +89,10 @@ struct EigGemmWave {
     double a1[EigGemm<KS>::LDS ? 1 : EigGemm<KS>::MT][EigGemm<KS>::LDS ? 1 : KS];
     double a2[EigGemm<KS>::LDS ? 1 : EigGemm<KS>::MT][EigGemm<KS>::LDS ? 1 : KS];
     const double* lds;   // the block's copy of the operands: [2][MT][KS][64]
-    double dl[KS], pil[KS];
+    const double* ainvT; // the column's transposed A^-1 in memory (observed tips), rows ldT apart; null if there is none
+    int ldT;
+    const double* cst;   // LDS: the column's eigenvalues d [4 KS] and frequencies pi [4 KS], zero beyond k (read when needed:
+                         // as per-lane registers they cost 64 VGPRs through both products)
     double sfc, tau, tf;
     // `at`: the lane's offset, made opaque once per pass (eig_gemm_pass) -- the operands are the same in every pass and the
     // compiler would otherwise hoist all 2 MT KS reads out of the node loop, back into 256 registers
@@ -96,7 +108,7 @@ struct EigGemmWave {
 // smem: EigGemm<KS>::LDS_DOUBLES doubles of dynamic LDS (nullptr for the register form)
 template <int KS>
 __device__ __forceinline__ void eig_gemm_init(EigGemmWave<KS>& W, const PmlTree& t, const PmlCols& c, const PmlModel& m,
-                                              double* smem = nullptr) {
+                                              double* smem, double* cst) {
     constexpr int MT = EigGemm<KS>::MT;
     const int k = c.k, ks = c.ks;  // k <= ks <= 4 KS: states 4 s + hi >= ks do not exist in memory
     const int col = blockIdx.y;
@@ -108,7 +120,9 @@ __device__ __forceinline__ void eig_gemm_init(EigGemmWave<KS>& W, const PmlTree&
     W.lo = lo;
     W.hi = hi;
     W.colN = (size_t)col * t.N;
-    // constant operands: rows 16 mt + lo of A^-1 (first product) and of A (second), k-step s: column 4 s + hi
+    // constant operands: tile mt, lane lo holds the row of index st(4 mt + lo / 4, lo % 4) of A^-1 (first product) and of A
+    // (second) -- the result tile then hands lane (lo, hi), in register r, the row st(4 mt + r, hi): its own slot 4 mt + r --;
+    // k-step s: column st(s, hi)
     const double* gA = m.A + (size_t)col * k * k;
     const double* gB = m.Ainv + (size_t)col * k * k;
     W.lds = smem;
@@ -116,8 +130,9 @@ __device__ __forceinline__ void eig_gemm_init(EigGemmWave<KS>& W, const PmlTree&
         // operand layout [tile][k-step][lane]: entry e of a matrix belongs to lane e % 64 of (mt, s) = (e / 64 / KS, e / 64 % KS)
         for (int e = threadIdx.x; e < MT * KS * 64; e += blockDim.x) {
             const int l = e & 63, ms = e >> 6, mt = ms / KS, s2 = ms - mt * KS;
-            const int row = 16 * mt + (l & 15), cc = 4 * s2 + (l >> 4);
-            const bool in = row < k && cc < k;
+            const int lo2 = l & 15;
+            const int row = EigGemm<KS>::st(4 * mt + (lo2 >> 2), lo2 & 3), cc = EigGemm<KS>::st(s2, l >> 4);
+            const bool in = 4 * mt + (lo2 >> 2) < KS && row < k && cc < k;   // (slots beyond KS: rows nobody reads, kept zero)
             smem[e] = in ? gB[row * k + cc] : 0.0;
             smem[MT * KS * 64 + e] = in ? gA[row * k + cc] : 0.0;
         }
@@ -127,120 +142,209 @@ __device__ __forceinline__ void eig_gemm_init(EigGemmWave<KS>& W, const PmlTree&
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
-                const int row = 16 * mt + lo, cc = 4 * s + hi;
-                const bool in = row < k && cc < k;
+                const int row = EigGemm<KS>::st(4 * mt + (lo >> 2), lo & 3), cc = EigGemm<KS>::st(s, hi);
+                const bool in = 4 * mt + (lo >> 2) < KS && row < k && cc < k;   // (slots beyond KS: rows nobody reads, kept zero)
                 W.a1[EigGemm<KS>::LDS ? 0 : mt][EigGemm<KS>::LDS ? 0 : s] = in ? gB[row * k + cc] : 0.0;
                 W.a2[EigGemm<KS>::LDS ? 0 : mt][EigGemm<KS>::LDS ? 0 : s] = in ? gA[row * k + cc] : 0.0;
             }
     }
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        const int j = 4 * s + hi;
-        W.dl[s] = j < k ? m.d[(size_t)col * k + j] : 0.0;
-        W.pil[s] = j < k ? c.pi[(size_t)col * ks + j] : 0.0;
+    for (int e = threadIdx.x; e < 4 * KS; e += blockDim.x) {
+        cst[e] = e < k ? m.d[(size_t)col * k + e] : 0.0;
+        cst[4 * KS + e] = e < k ? c.pi[(size_t)col * ks + e] : 0.0;
     }
+    W.cst = cst;
+    __syncthreads();
     W.sfc = m.sf[col];
     W.tau = m.tau[col];
     W.tf = m.tauf[col];
+    W.ldT = m.ldT;
+    W.ainvT = (m.AinvT != nullptr && k <= m.ldT) ? m.AinvT + (size_t)col * m.ldT * m.ldT : nullptr;
 }
 
-// One pass of a wave: 16 nodes, lane (lo, hi) owns the states {4 s + hi} of node n (act: slot lo holds a node).
+// A lane's part of a row of ks doubles (states st(s, hi)): 16-byte accesses where the lane owns pairs and the rows are 16-byte
+// aligned (ks even), 8-byte ones otherwise.  Entries at or beyond ks: zero on loads, skipped on stores.
+template <int KS>
+__device__ __forceinline__ void eig_row_load(const double* __restrict__ row, int hi, int ks, double (&v)[KS]) {
+    if (EigGemm<KS>::PAIRS && (ks & 1) == 0) {
+#pragma unroll
+        for (int q = 0; q < KS / 2; ++q) {
+            const int j = 8 * q + 2 * hi;
+            double2 t2 = {0.0, 0.0};
+            if (j < ks) t2 = *reinterpret_cast<const double2*>(row + j);
+            v[2 * q] = t2.x;
+            v[2 * q + 1] = t2.y;
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) v[s] = EigGemm<KS>::st(s, hi) < ks ? row[EigGemm<KS>::st(s, hi)] : 0.0;
+    }
+}
+
+template <int KS>
+__device__ __forceinline__ void eig_row_store(double* __restrict__ row, int hi, int ks, const double (&v)[KS]) {
+    if (EigGemm<KS>::PAIRS && (ks & 1) == 0) {
+#pragma unroll
+        for (int q = 0; q < KS / 2; ++q) {
+            const int j = 8 * q + 2 * hi;
+            if (j < ks) {
+                double2 t2;
+                t2.x = v[2 * q];
+                t2.y = v[2 * q + 1];
+                *reinterpret_cast<double2*>(row + j) = t2;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+            if (EigGemm<KS>::st(s, hi) < ks) row[EigGemm<KS>::st(s, hi)] = v[s];
+    }
+}
+
+// What a pass knows about its node before it reads any vector: the kernels load it ONE PASS AHEAD (round 6: a pass was a chain of
+// dependent round trips -- node list -> tree arrays -> first child's message -> second child's message -- during which the
+// wave did nothing: 73 % of a wave's cycles at k = 61 were waits, profiles/r06g_eigen_sweeps.txt).
+struct EigNode {
+    int n, fc, nc, p;
+    u64 word;     // allowed-state mask (k <= 64: one word)
+    double dist;
+};
+
+template <int MODE>
+__device__ __forceinline__ EigNode eig_node_load(const PmlTree& t, const PmlCols& c, size_t colN, bool act, int n) {
+    EigNode q;
+    q.n = act ? n : 0;
+    q.word = c.masks[colN + q.n];
+    q.nc = t.n_children[q.n];
+    q.dist = t.dist[q.n];
+    q.fc = MODE == PML_EIGG_BU ? t.first_child[q.n] : 0;
+    q.p = MODE == PML_EIGG_TD ? t.parent[q.n] : 0;
+    return q;
+}
+
+// One pass of a wave: 16 nodes, lane (lo, hi) owns the states st(s, hi) = hi KS + s of node n (act: slot lo holds a node).
 template <int KS, int MODE>
 __device__ __forceinline__ void eig_gemm_pass(const EigGemmWave<KS>& W, const PmlTree& t, const PmlCols& c,
-                                              const PmlState& st, bool act, int n) {
+                                              const PmlState& st, bool act, const EigNode& q) {
     constexpr int MT = EigGemm<KS>::MT;
     const int k = W.k, ks = W.ks, col = W.col, lo = W.lo, hi = W.hi;
     const size_t colN = W.colN;
     const double sfc = W.sfc, tau = W.tau, tf = W.tf;
     int at = threadIdx.x & 63;
     if (EigGemm<KS>::LDS) asm volatile("" : "+v"(at));
+    const int n = q.n;
     {
         const size_t row = (colN + n) * ks;
-        const u64 word = c.masks[colN + n];  // k <= 64: one word
-        const int nc = t.n_children[n];
-        const double tt = (t.dist[n] + tau) * tf * sfc;
-        double v[KS], mb[KS];
+        const u64 word = q.word;
+        const int nc = q.nc;
+        const double tt = (q.dist + tau) * tf * sfc;
+        double v[KS];
+        // the node's mask as a 0 / 1 vector (formed where it is used: two registers of mask word instead of 2 KS through the products)
+        auto mask_vec = [&](double (&mb)[KS]) {
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const int j = 4 * s + hi;
-            mb[s] = (j < k && ((word >> j) & 1ull)) ? 1.0 : 0.0;
-        }
+            for (int s = 0; s < KS; ++s) {
+                const int j = EigGemm<KS>::st(s, hi);
+                mb[s] = (j < k && ((word >> j) & 1ull)) ? 1.0 : 0.0;
+            }
+        };
         i64 esum = 0;
         // ------------------------------------------------------------------ the vector P is applied to
-        double vc[KS];  // top-down: the node's own bottom-up vector
         i64 bec = 0;
         bool tipc = false;
         if (MODE != PML_EIGG_TD) {
-#pragma unroll
-            for (int s = 0; s < KS; ++s) v[s] = mb[s];
+            mask_vec(v);
             if (MODE == PML_EIGG_BU) {
                 // mask o prod of the children's messages (ml.py:126-148), zero check and rescaling per child; a tip's
                 // exponent word is zero (never written by these sweeps)
-                const int fc = t.first_child[n];
+                const int fc = q.fc;
                 int most = nc;
                 most = max(most, __shfl_xor(most, 1, 64));
                 most = max(most, __shfl_xor(most, 2, 64));
                 most = max(most, __shfl_xor(most, 4, 64));
                 most = max(most, __shfl_xor(most, 8, 64));
-                for (int j0 = 0; j0 < most; ++j0) {   // wave-uniform trip count (ballots inside)
-                    const bool has = act && j0 < nc;
-                    const int ch = has ? fc + j0 : n;
-                    double mv[KS];
+                // the children two at a time: the loads of a pair go out together (one round trip for a binary node)
+                for (int j0 = 0; j0 < most; j0 += 2) {   // wave-uniform trip count (ballots inside)
+                    double mv[2][KS];
+                    i64 cbe[2];
 #pragma unroll
-                    for (int s = 0; s < KS; ++s) mv[s] = 4 * s + hi < ks ? st.msg[(colN + ch) * ks + 4 * s + hi] : 0.0;
-                    const i64 cbe = st.be[colN + ch];
-                    bool nz = false;
-                    if (has) {
-#pragma unroll
-                        for (int s = 0; s < KS; ++s) {
-                            v[s] *= fmax(mv[s], 0.0);
-                            nz |= v[s] != 0.0;
-                        }
-                        esum += cbe;
+                    for (int u = 0; u < 2; ++u) {
+                        const int ch = (act && j0 + u < nc) ? fc + j0 + u : n;
+                        eig_row_load<KS>(st.msg + (colN + ch) * ks, hi, ks, mv[u]);
+                        cbe[u] = st.be[colN + ch];
                     }
-                    const bool alive = node_any(nz, lo);
-                    if (has && !alive && hi == 0)
-                        atomicMin(&st.err[col], ((u64)(unsigned)t.post_rank[n] << 32) | (u64)(unsigned)ch);
-                    const int ex = node_lazy_rescale<KS>(v, lo);
-                    if (has) esum += ex;
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        if (j0 + u >= most) break;
+                        const bool has = act && j0 + u < nc;
+                        bool nz = false;
+                        if (has) {
+#pragma unroll
+                            for (int s = 0; s < KS; ++s) {
+                                v[s] *= fmax(mv[u][s], 0.0);
+                                nz |= v[s] != 0.0;
+                            }
+                            esum += cbe[u];
+                        }
+                        const bool alive = node_any(nz, lo);
+                        if (has && !alive && hi == 0)
+                            atomicMin(&st.err[col], ((u64)(unsigned)t.post_rank[n] << 32) | (u64)(unsigned)(fc + j0 + u));
+                        const int ex = node_lazy_rescale<KS>(v, lo);
+                        if (has) esum += ex;
+                    }
                 }
                 if (act) {
-#pragma unroll
-                    for (int s = 0; s < KS; ++s)
-                        if (4 * s + hi < ks) st.bu[row + 4 * s + hi] = v[s];
+                    eig_row_store<KS>(st.bu + row, hi, ks, v);
                     if (hi == 0) st.be[colN + n] = esum;
                 }
             }
         } else {
             // x = TD_p o BU_p / msg_n (ml.py:279-283); the message is what the bottom-up sweep left
-            const int p = act ? t.parent[n] : 0;
+            const int p = act ? q.p : 0;
             const size_t prow = (colN + (p < 0 ? 0 : p)) * ks;
             tipc = nc == 0;
             bec = tipc ? 0 : st.be[colN + n];
             const i64 pe = st.te[colN + (p < 0 ? 0 : p)] + st.be[colN + (p < 0 ? 0 : p)];
+            {
+                // (rows at or beyond ks read as zero: 0 * 0 / 1 = 0; a tip's own row is allocated but never written)
+                double tdp[KS], bup[KS], mc[KS];
+                eig_row_load<KS>(st.td + prow, hi, ks, tdp);
+                eig_row_load<KS>(st.bu + prow, hi, ks, bup);
+                eig_row_load<KS>(st.msg + row, hi, ks, mc);
 #pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                const int j = 4 * s + hi < ks ? 4 * s + hi : 0;  // padding lanes read (and ignore) state 0
-                const double prod = st.td[prow + j] * st.bu[prow + j];
-                const double mc = st.msg[row + j];
-                vc[s] = tipc ? mb[s] : st.bu[row + j];  // a tip's row is allocated but never written
-                v[s] = prod / (mc > 0.0 ? mc : 1.0);
+                for (int s = 0; s < KS; ++s) v[s] = (tdp[s] * bup[s]) / (mc[s] > 0.0 ? mc[s] : 1.0);
             }
             esum = pe - bec;
             esum += node_lazy_rescale<KS>(v, lo);
         }
         // ------------------------------------------------------------------ Y = A^-1 V, Z = Y o exp(d t), OUT = A Z
         pml_v4f64 acc[MT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            acc[mt] = (pml_v4f64){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int s = 0; s < KS; ++s)
-                acc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(W.op1(mt, s, at), act ? v[s] : 0.0, acc[mt], 0, 0, 0);
-        }
         double z[KS];
+        // Observed tips (one allowed state s: the vector is the unit vector e_s): Y = A^-1 e_s is COLUMN s of A^-1 -- a row of the
+        // transposed copy, which the four lanes of a node read 32 contiguous bytes at a time -- so the first product is a gather
+        // instead of MT x KS matrix instructions (half of a tip's pass; tips are half of the nodes).  Wave-uniform choice; the sums
+        // of the product degenerate to their one non-zero term, so the bits are those of the GEMM.
+        const u64 kb = k >= 64 ? ~0ull : (1ull << k) - 1ull;
+        if (MODE == PML_EIGG_TIPS && W.ainvT != nullptr && __all(!act || __popcll(word & kb) == 1)) {
+            const double* colT = W.ainvT + (size_t)(act ? __builtin_ctzll(word & kb) : 0) * W.ldT;
+            eig_row_load<KS>(colT, hi, act ? min(W.ldT, 4 * KS) : 0, z);   // (padded with zeros beyond k)
+            {
+                double dl[KS];
+                eig_row_load<KS>(W.cst, hi, 4 * KS, dl);
 #pragma unroll
-        for (int s = 0; s < KS; ++s) z[s] = acc[s / 4][s % 4] * exp(W.dl[s] * tt);  // rows 4 s + hi of Y: the lane's own
+                for (int s = 0; s < KS; ++s) z[s] *= exp(dl[s] * tt);
+            }
+        } else {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                acc[mt] = (pml_v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int s = 0; s < KS; ++s)
+                    acc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(W.op1(mt, s, at), act ? v[s] : 0.0, acc[mt], 0, 0, 0);
+            }
+            double dl[KS];
+            eig_row_load<KS>(W.cst, hi, 4 * KS, dl);
+#pragma unroll
+            for (int s = 0; s < KS; ++s) z[s] = acc[s / 4][s % 4] * exp(dl[s] * tt);  // rows st(s, hi) of Y: the lane's own
+        }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             acc[mt] = (pml_v4f64){0.0, 0.0, 0.0, 0.0};
@@ -249,33 +353,35 @@ __device__ __forceinline__ void eig_gemm_pass(const EigGemmWave<KS>& W, const Pm
         }
         double out[KS];
 #pragma unroll
-        for (int s = 0; s < KS; ++s) out[s] = (4 * s + hi < k) ? acc[s / 4][s % 4] : 0.0;
+        for (int s = 0; s < KS; ++s) out[s] = (EigGemm<KS>::st(s, hi) < k) ? acc[s / 4][s % 4] : 0.0;
         // ------------------------------------------------------------------ results of the node
         if (MODE != PML_EIGG_TD) {
             if (act) {
-#pragma unroll
-                for (int s = 0; s < KS; ++s)
-                    if (4 * s + hi < ks) st.msg[row + 4 * s + hi] = out[s];
+                eig_row_store<KS>(st.msg + row, hi, ks, out);
             }
         } else {
             // marginal likelihoods pi o mask o BU o TD (ml.py:456-460) and posteriors (ml.py:498-500)
-            double tdc[KS], lh[KS];
+            // (the node's own bottom-up vector is read here, behind the products: nothing of the node but its mask word and
+            // scalars lives through them)
+            double tdc[KS], lh[KS], vc[KS], mb[KS], pil[KS];
+            mask_vec(mb);
+            if (!__all(tipc)) eig_row_load<KS>(st.bu + row, hi, ks, vc);   // (a tip's row is allocated but never written)
+            eig_row_load<KS>(W.cst + 4 * KS, hi, 4 * KS, pil);
             double lhs = 0.0;
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
+                if (tipc) vc[s] = mb[s];
                 tdc[s] = fmax(out[s], 0.0);
-                lh[s] = vc[s] * tdc[s] * (W.pil[s] * mb[s]);
+                lh[s] = vc[s] * tdc[s] * (pil[s] * mb[s]);
                 lhs += lh[s];
             }
             lhs = node_sum(lhs);
             const int lex = (lhs > 0.0 && !isinf(lhs)) ? exponent_of(lhs) : 0;
             if (act) {
+                if (!tipc) eig_row_store<KS>(st.td + row, hi, ks, tdc);
 #pragma unroll
-                for (int s = 0; s < KS; ++s) {
-                    if (4 * s + hi >= ks) continue;
-                    if (!tipc) st.td[row + 4 * s + hi] = tdc[s];
-                    st.post[row + 4 * s + hi] = lh[s] / lhs;
-                }
+                for (int s = 0; s < KS; ++s) lh[s] = lh[s] / lhs;
+                eig_row_store<KS>(st.post + row, hi, ks, lh);
                 if (hi == 0) {
                     if (!tipc) st.te[colN + n] = esum;
                     st.lhsum[colN + n] = __builtin_ldexp(lhs, -lex);
@@ -287,18 +393,34 @@ __device__ __forceinline__ void eig_gemm_pass(const EigGemmWave<KS>& W, const Pm
 }
 
 // one level of a sweep
+// (two waves per SIMD wherever the top-down mode's registers allow it: the bottom-up modes of the widest shapes would
+// otherwise settle a few registers above the limit and run one)
 template <int KS, int MODE>
-__global__ void __launch_bounds__(PML_BLOCK)
+__global__ void __launch_bounds__(PML_BLOCK) __attribute__((amdgpu_waves_per_eu((MODE == PML_EIGG_TD && KS >= 8) ? 1 : 2, 8)))
 eigen_gemm_kernel(PmlTree t, PmlCols c, PmlModel m, PmlState st, const int* __restrict__ nodes, int first, int n_nodes) {
     extern __shared__ double eigg_smem[];
+    __shared__ double eigg_cst[8 * KS];
     EigGemmWave<KS> W;
-    eig_gemm_init<KS>(W, t, c, m, eigg_smem);
+    eig_gemm_init<KS>(W, t, c, m, eigg_smem, eigg_cst);
     const int wave = threadIdx.x >> 6;
     const int stride = gridDim.x * PML_WAVES_PER_BLOCK * 16;
-    for (int b0 = (blockIdx.x * PML_WAVES_PER_BLOCK + wave) * 16; b0 < n_nodes; b0 += stride) {
-        const bool act = b0 + W.lo < n_nodes;
-        const int n = act ? (nodes != nullptr ? nodes[b0 + W.lo] : first + b0 + W.lo) : 0;
-        eig_gemm_pass<KS, MODE>(W, t, c, st, act, n);
+    int b0 = (blockIdx.x * PML_WAVES_PER_BLOCK + wave) * 16;
+    if (b0 >= n_nodes) return;
+    auto id_of = [&](int b, bool a) { return a ? (nodes != nullptr ? nodes[b + W.lo] : first + b + W.lo) : 0; };
+    // the node data of the next pass and the node id of the one after it are in flight while this pass runs
+    bool act = b0 + W.lo < n_nodes;
+    EigNode cur = eig_node_load<MODE>(t, c, W.colN, act, id_of(b0, act));
+    bool act1 = b0 + stride + W.lo < n_nodes;
+    int n1 = id_of(b0 + stride, act1);
+    for (; b0 < n_nodes; b0 += stride) {
+        const bool act2 = b0 + 2 * stride + W.lo < n_nodes;
+        const int n2 = id_of(b0 + 2 * stride, act2);
+        const EigNode nxt = eig_node_load<MODE>(t, c, W.colN, act1, n1);
+        eig_gemm_pass<KS, MODE>(W, t, c, st, act, cur);
+        cur = nxt;
+        act = act1;
+        n1 = n2;
+        act1 = act2;
     }
 }
 
@@ -312,15 +434,16 @@ eigen_gemm_narrow_kernel(PmlTree t, PmlCols c, PmlModel m, PmlState st, const in
     // (blk_start: the subtree blocks of a tier of thin levels, one workgroup per (block, column) -- pml_ctx::EigenTiers)
     if (blk_start != nullptr) level_offsets += blk_start[blockIdx.x];
     extern __shared__ double eigg_smem[];
+    __shared__ double eigg_cst[8 * KS];
     EigGemmWave<KS> W;
-    eig_gemm_init<KS>(W, t, c, m, eigg_smem);
+    eig_gemm_init<KS>(W, t, c, m, eigg_smem, eigg_cst);
     const int wave = threadIdx.x >> 6;
     for (int l = 0; l < n_levels; ++l) {
         const int a = level_offsets[l], n_level = level_offsets[l + 1] - a;
         for (int b0 = wave * 16; b0 < n_level; b0 += PML_WAVES_PER_BLOCK * 16) {
             const bool act = b0 + W.lo < n_level;
             const int n = act ? (nodes != nullptr ? nodes[a + b0 + W.lo] : a + b0 + W.lo) : 0;
-            eig_gemm_pass<KS, MODE>(W, t, c, st, act, n);
+            eig_gemm_pass<KS, MODE>(W, t, c, st, act, eig_node_load<MODE>(t, c, W.colN, act, n));
         }
         __threadfence_block();
         __syncthreads();

@@ -10,6 +10,8 @@ struct PmlModel {
     const double* d;      // [C][k]     eigen
     const double* A;      // [C][k][k]
     const double* Ainv;   // [C][k][k]
+    const double* AinvT;  // [C][ldT][ldT]: Ainv transposed, zero-padded (k <= 64; null otherwise): AinvT[j][m] = Ainv[m][j]
+    int ldT;              //   32 for k <= 32, 64 for k <= 64
     const double* sf;     // [C]
     const double* tau;    // [C]
     const double* tauf;   // [C]
