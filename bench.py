@@ -837,7 +837,7 @@ def eigen_k61_measurement(device, levels=16, k=61, C=4, compare=1):
     tips = np.stack([synthetic.tip_states(flat.n_tips, k, c) for c in range(C)])
     ks = k + (k & 1)
     res = {}
-    for label, tune in (('fused', {}), ('materialised', dict(NO_EIGEN_GEMM=1)))[:2 if compare else 1]:
+    for label, tune in (('fused', {}), ('materialised', dict(NO_EIGEN_GEMM=1, NO_EIGEN_JOINT_VALU=1)))[:2 if compare else 1]:
         with hip.Engine(flat, C, k, device=device, tune=tune) as eng:
             eng.set_tip_states(tips)
 
@@ -875,11 +875,13 @@ def eigen_k61_measurement(device, levels=16, k=61, C=4, compare=1):
     ms = f['ms_marginal']
     return dict(workload='CUSTOM_RATES-shaped eigen model, k = {} states, balanced {}-tip tree ({} nodes), {} characters: '
                          'marginal pass (BU + TD + posteriors) and joint sweep; fused = sum sweeps as P v = A (e o (A^-1 v)) on '
-                         'the FP64 matrix cores, operands in LDS (pml_kernels_eigen_gemm.h); materialised = P(t) of every '
+                         'the FP64 matrix cores, operands in LDS (pml_kernels_eigen_gemm.h), joint sweep with P(t) built and folded in '
+                         'registers on the vector units (pml_kernels_eigen_joint.h); materialised = P(t) of every '
                          'branch in HBM ({:.1f} GB), the path of every k > 32 before round 6'
                          .format(k, flat.n_tips, flat.n_nodes, C, flat.n_nodes * C * k * ks * 8 / 1e9),
                 ms_marginal_pass=ms, ms_bottom_up_sweep=f['ms_bottom_up'], ms_marginal_pass_materialised=g['ms_marginal'],
                 speedup_marginal=g['ms_marginal'] / ms,
+                speedup_joint=(g['ms_joint'] / f['ms_joint']) if f.get('ms_joint') and g.get('ms_joint') else None,
                 ms_joint_sweep=f['ms_joint'], ms_joint_sweep_materialised=g.get('ms_joint'),
                 max_rel_loglik_difference=rel, loglik_fused=f['lnl_marginal'], loglik_materialised=g['lnl_marginal'],
                 value=flat.n_nodes * k * C / (ms * 1e-3), unit='node*state*char/s',

@@ -18,7 +18,9 @@
 // P(t) materialised in HBM, 32 KB per branch and column at k = 64): the same two GEMMs with 3 or 4 row tiles.  The constant
 // operands no longer fit the register file (2 x 4 x 16 doubles per lane), so the block keeps them in LDS in operand layout --
 // [tile][k-step][lane], one conflict-free ds_read_b64 per MFMA, 64 KB at k = 64, shared by the block's four waves -- and a
-// matrix instruction (64 clocks of its SIMD) hides the read.  EigGemm<KS>::LDS says which form a shape takes.
+// matrix instruction (64 clocks of its SIMD) hides the read.  EigGemm<KS>::LDS says which form a shape takes: the LDS form
+// from 17 states on -- the registers it frees are a wave more per SIMD (65 536 tips x 32 columns, marginal pass: k = 32
+// 2.75 -> 2.29 ms, k = 24 1.97 -> 1.81, k = 20 1.76 -> 1.67; no difference at 16 states and below).
 //
 // Rounding: P v is evaluated in a different order than the reference's (P built, then applied).  Both carry an
 // absolute error of a few ulps of |A| |A^-1| |v| (cond(A) = 2 for JTT); messages are bounded below by
@@ -31,7 +33,7 @@ template <int KS>
 struct EigGemm {
     static constexpr int KP = 4 * KS;             // padded states
     static constexpr int MT = (KP + 15) / 16;     // row tiles of the constant matrices
-    static constexpr bool LDS = KS > 8;           // the constant operands live in LDS, not in registers
+    static constexpr bool LDS = KS >= 5;          // the constant operands live in LDS, not in registers (k > 16)
     // Which state (and which eigenvalue) slot s of lane (lo, hi) stands for.  The matrix instruction only fixes that k-step s
     // takes its four k-indices from the four hi-lanes and hands rows hi + 4 r back: WHICH index sits there is the operands'
     // business (both constant operands are loaded with their rows and columns in this order).  For an even KS a lane owns

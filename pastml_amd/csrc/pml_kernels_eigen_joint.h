@@ -1,4 +1,4 @@
-// Eigen models (CUSTOM_RATES, JTT), 2 <= k <= 32: the joint (max-product) bottom-up sweep, ml.py:124-148 with
+// Eigen models (CUSTOM_RATES, JTT), 2 <= k <= 64: the joint (max-product) bottom-up sweep, ml.py:124-148 with
 // is_marginal=False, on the vector FP64 units.
 //
 // The joint sweep needs every entry of P(t_n) -- msg_n[i] = max_j P[i][j] v_n[j] and its arg-max -- so P cannot be
@@ -25,7 +25,9 @@ typedef const __attribute__((address_space(4))) double* pml_const_f64;
 // of a node start in different banks
 #define PML_EIGJ_ASTRIDE(KU) ((KU) + 2)
 #define PML_EIGJ_CHUNK_LDS 160                 // doubles per wave: 64 x (branch length, mask word, node id)
-#define PML_EIGJ_LDS(KU) (PML_WAVES_PER_BLOCK * 2 * PML_EIGJ_WAVE_LDS + 32 * PML_EIGJ_ASTRIDE(KU))
+// row stride (and rows) of the transposed zero-padded copy of Ainv: 32 up to 32 states, 64 beyond (pml_model_set_eigen)
+#define PML_EIGJ_LD(KU) ((KU) <= 32 ? 32 : 64)
+#define PML_EIGJ_LDS(KU) (PML_WAVES_PER_BLOCK * 2 * PML_EIGJ_WAVE_LDS + PML_EIGJ_LD(KU) * PML_EIGJ_ASTRIDE(KU))
 
 template <int KU>
 struct EigJWave {
@@ -71,7 +73,7 @@ __device__ __forceinline__ void eigj_wave_init(EigJWave<KU>& w, const PmlTree& t
     w.sfc = m.sf[w.col];
     w.tau = m.tau[w.col];
     w.tf = m.tauf[w.col];
-    w.ainvT = (pml_const_f64)(ainvT + (size_t)w.col * PML_EIGJ_STRIDE * PML_EIGJ_STRIDE);
+    w.ainvT = (pml_const_f64)(ainvT + (size_t)w.col * PML_EIGJ_LD(KU) * PML_EIGJ_LD(KU));
     __syncthreads();
 }
 
@@ -203,11 +205,12 @@ __device__ __forceinline__ void eigj_back(const EigJWave<KU>& W, const PmlCols& 
     // over the passes: hide the pointer from it so that the rows are streamed through the scalar cache pass by pass
     pml_const_f64 at = W.ainvT;
     asm volatile("" : "+s"(at));
-#pragma unroll
+    // (fully unrolled up to 32 states; beyond, KU x KU FMAs would be 32 KB of straight-line code: two columns per iteration)
+#pragma unroll(KU <= 32 ? KU : 2)
     for (int j = 0; j < KU; ++j) {
-        double p = u[0] * at[j * PML_EIGJ_STRIDE];
+        double p = u[0] * at[j * PML_EIGJ_LD(KU)];
 #pragma unroll
-        for (int mm = 1; mm < KU; ++mm) p = __builtin_fma(u[mm], at[j * PML_EIGJ_STRIDE + mm], p);
+        for (int mm = 1; mm < KU; ++mm) p = __builtin_fma(u[mm], at[j * PML_EIGJ_LD(KU) + mm], p);
         double w = p * W.sV[slot + j];
         if (j >= KU - 3 && j >= k) w = -INFINITY;  // padding columns (k > KU - 4) must not win
         if (w > best) {  // j ascends: the first maximum stays
@@ -360,17 +363,20 @@ __global__ void PML_EIGJ_ATTR eigen_joint_tips_kernel(PmlTree t, PmlCols c, PmlM
         if (n_tips <= 0) return;
     }
     constexpr int AS = PML_EIGJ_ASTRIDE(KU);
-    __shared__ double smem[PML_EIGJ_LDS(KU) + 32 * AS + PML_WAVES_PER_BLOCK * PML_EIGJ_CHUNK_LDS];
+    // (beyond 32 states the transposed copy does not fit beside the rows of A -- 2 x 34 KB -- and is left out: every pass is then
+    // the general one; the observed tips have been served by eigen_joint_obs_tips_kernel)
+    constexpr int TS = KU <= 32 ? PML_EIGJ_LD(KU) * AS : 0;
+    __shared__ double smem[PML_EIGJ_LDS(KU) + TS + PML_WAVES_PER_BLOCK * PML_EIGJ_CHUNK_LDS];
     EigJWave<KU> W;
     eigj_wave_init<KU>(W, t, c, m, ainvT, smem);
     const int k = W.k, ks = W.ks, i = W.i;
     const size_t colN = W.colN;
     double* sT = smem + PML_EIGJ_LDS(KU);  // sT[j * AS + m] = Ainv[m][j]
-    {
-        const double* g = ainvT + (size_t)W.col * PML_EIGJ_STRIDE * PML_EIGJ_STRIDE;
+    if (KU <= 32) {
+        const double* g = ainvT + (size_t)W.col * PML_EIGJ_LD(KU) * PML_EIGJ_LD(KU);
         for (int e = threadIdx.x; e < k * AS; e += blockDim.x) {
             const int r = e / AS, q = e % AS;
-            sT[e] = q < KU ? g[r * PML_EIGJ_STRIDE + q] : 0.0;
+            sT[e] = q < KU ? g[r * PML_EIGJ_LD(KU) + q] : 0.0;
         }
     }
     __syncthreads();
@@ -388,7 +394,7 @@ __global__ void PML_EIGJ_ATTR eigen_joint_tips_kernel(PmlTree t, PmlCols c, PmlM
     int cp = (passes_total + waves_total - 1) / waves_total;
     if (cp > 64 / npw) cp = 64 / npw;
     const int chunk = cp * npw;
-    double* sTq = smem + PML_EIGJ_LDS(KU) + 32 * AS + wave * PML_EIGJ_CHUNK_LDS;
+    double* sTq = smem + PML_EIGJ_LDS(KU) + TS + wave * PML_EIGJ_CHUNK_LDS;
     u64* sWord = reinterpret_cast<u64*>(sTq + 64);
     int* sTip = reinterpret_cast<int*>(sWord + 64);
     for (int c0 = (blockIdx.x * PML_WAVES_PER_BLOCK + wave) * chunk; c0 < n_tips; c0 += waves_total * chunk) {
@@ -413,7 +419,7 @@ __global__ void PML_EIGJ_ATTR eigen_joint_tips_kernel(PmlTree t, PmlCols c, PmlM
         const int tip = act ? tip_c : 0;
         const u64 word = act ? sWord[sq] : 0ull;
         const double tq = act ? sTq[sq] : 0.0;
-        if (!__all(!act || __popcll(word) == 1)) {
+        if (KU > 32 || !__all(!act || __popcll(word) == 1)) {
             eigj_pass<KU>(W, t, c, st, act, tip, 0, 0);
             continue;
         }
@@ -473,7 +479,7 @@ __global__ void __launch_bounds__(PML_BLOCK) eigen_joint_obs_tips_kernel(PmlTree
                                                                           int* __restrict__ rest_list,
                                                                           int* __restrict__ rest_count) {
     constexpr int AS = PML_EIGJ_ASTRIDE(KU);
-    __shared__ double smem[32 * AS + PML_WAVES_PER_BLOCK * (128 + PML_EIGJ_CHUNK_LDS)];
+    __shared__ double smem[PML_EIGJ_LD(KU) * AS + PML_WAVES_PER_BLOCK * (128 + PML_EIGJ_CHUNK_LDS)];
     const int k = c.k, ks = c.ks;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = blockIdx.y;
@@ -493,13 +499,13 @@ __global__ void __launch_bounds__(PML_BLOCK) eigen_joint_obs_tips_kernel(PmlTree
     const double sfc = m.sf[col], tau = m.tau[col], tf = m.tauf[col];
     double* sT = smem;  // sT[j * AS + m] = Ainv[m][j]
     {
-        const double* g = ainvT + (size_t)col * PML_EIGJ_STRIDE * PML_EIGJ_STRIDE;
+        const double* g = ainvT + (size_t)col * PML_EIGJ_LD(KU) * PML_EIGJ_LD(KU);
         for (int e = threadIdx.x; e < k * AS; e += blockDim.x) {
             const int r = e / AS, q = e % AS;
-            sT[e] = q < KU ? g[r * PML_EIGJ_STRIDE + q] : 0.0;
+            sT[e] = q < KU ? g[r * PML_EIGJ_LD(KU) + q] : 0.0;
         }
     }
-    double* sW = smem + 32 * AS + wave * (128 + PML_EIGJ_CHUNK_LDS);
+    double* sW = smem + PML_EIGJ_LD(KU) * AS + wave * (128 + PML_EIGJ_CHUNK_LDS);
     for (int e = lane; e < 128; e += 64) sW[e] = 0.0;  // the padding entries (m >= k) stay zero
     double* sTq = sW + 128;
     u64* sWord = reinterpret_cast<u64*>(sTq + 64);
@@ -600,7 +606,7 @@ __global__ void __launch_bounds__(PML_BLOCK)
 pij_eigen_valu_kernel(PmlTree t, PmlCols c, PmlModel m, const double* __restrict__ ainvT, const double* __restrict__ aT,
                       double* __restrict__ P) {
     constexpr int AS = PML_EIGJ_ASTRIDE(KU);
-    __shared__ double smem[32 * AS + PML_WAVES_PER_BLOCK * (PML_PIJV_EXP_LDS + 32 * KU)];
+    __shared__ double smem[PML_EIGJ_STRIDE * AS + PML_WAVES_PER_BLOCK * (PML_PIJV_EXP_LDS + 32 * KU)];
     typedef double dbl2 __attribute__((ext_vector_type(2)));
     const int k = c.k, ks = c.ks;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -613,7 +619,7 @@ pij_eigen_valu_kernel(PmlTree t, PmlCols c, PmlModel m, const double* __restrict
             sT[e] = q < KU ? g[r * PML_EIGJ_STRIDE + q] : 0.0;
         }
     }
-    double* sE = smem + 32 * AS + wave * (PML_PIJV_EXP_LDS + 32 * KU);
+    double* sE = smem + PML_EIGJ_STRIDE * AS + wave * (PML_PIJV_EXP_LDS + 32 * KU);
     double* sO = sE + PML_PIJV_EXP_LDS;   // 32 staged rows of ks doubles
     __syncthreads();
     const double* gd = m.d + (size_t)col * k;

@@ -103,11 +103,11 @@ static bool eigen_gemm(const pml_ctx* c) {
 }
 
 
-// The joint sweep of the eigen models on the vector units (pml_kernels_eigen_joint.h) for 2 <= k <= 32;
+// The joint sweep of the eigen models on the vector units (pml_kernels_eigen_joint.h) for 2 <= k <= 64;
 // PASTML_HIP_NO_EIGEN_JOINT_VALU keeps the matrix-core kernels (pml_kernels_eigen_mfma.h).
 static bool eigen_joint_valu(const pml_ctx* c) {
     const bool off = c->tune.on(T_NO_EIGEN_JOINT_VALU);
-    return !off && c->eigj_valu_opt && c->kind == PML_MODEL_EIGEN && c->k >= 2 && c->k <= PML_EIGJ_STRIDE && c->W == 1 &&
+    return !off && c->eigj_valu_opt && c->kind == PML_MODEL_EIGEN && c->k >= 2 && c->k <= 64 && c->W == 1 &&
            c->d_AinvT != nullptr;
 }
 

@@ -24,7 +24,7 @@ int launch_eigen_joint(pml_ctx* ctx, const PmlUnit* units, const int* d_offsets,
             int blocks = (n + per_block - 1) / per_block;                                                           \
             const int cap = std::max(8, cap_all / std::max(1, ctx->C));                                             \
             if (blocks > cap) blocks = cap;                                                                         \
-            if (ctx->tune.on(T_NO_EIGJ_PIPE))                                                                       \
+            if (ctx->tune.on(T_NO_EIGJ_PIPE) || KU_ > 32)   /* (beyond 32 states the pipelined form needs a SIMD to itself) */ \
                 hipLaunchKernelGGL((eigen_joint_kernel<KU_, false>), dim3(blocks, ctx->C), dim3(PML_BLOCK), 0,      \
                                    ctx->stream, t, c, m, st, ctx->d_AinvT, units, n);                               \
             else                                                                                                    \
@@ -42,6 +42,14 @@ int launch_eigen_joint(pml_ctx* ctx, const PmlUnit* units, const int* d_offsets,
     PML_EIGJ_CASE(24)
     PML_EIGJ_CASE(28)
     PML_EIGJ_CASE(32)
+    PML_EIGJ_CASE(36)
+    PML_EIGJ_CASE(40)
+    PML_EIGJ_CASE(44)
+    PML_EIGJ_CASE(48)
+    PML_EIGJ_CASE(52)
+    PML_EIGJ_CASE(56)
+    PML_EIGJ_CASE(60)
+    PML_EIGJ_CASE(64)
 #undef PML_EIGJ_CASE
     return fail(PML_ERR_UNSUPPORTED, "no joint eigen kernel for k = %d", ctx->k);
 }
@@ -91,6 +99,14 @@ int launch_eigen_joint_tips(pml_ctx* ctx) {
     PML_EIGJ_TIPS(24)
     PML_EIGJ_TIPS(28)
     PML_EIGJ_TIPS(32)
+    PML_EIGJ_TIPS(36)
+    PML_EIGJ_TIPS(40)
+    PML_EIGJ_TIPS(44)
+    PML_EIGJ_TIPS(48)
+    PML_EIGJ_TIPS(52)
+    PML_EIGJ_TIPS(56)
+    PML_EIGJ_TIPS(60)
+    PML_EIGJ_TIPS(64)
 #undef PML_EIGJ_TIPS
     return fail(PML_ERR_UNSUPPORTED, "no joint eigen kernel for k = %d", ctx->k);
 }

@@ -326,15 +326,16 @@ def test_custom_rates_k61_matches_reference(fused):
     A codon-sized eigen model: the reference's CustomRatesModel (pastml/models/CustomRatesModel.py:70-79,
     generator.py:54-65) with 61 states on a balanced 4 096-tip tree (tests/golden/make_golden.py::case_eigen_k61) --
     marginal pass and joint sweep + back-trace.  fused: the sum sweeps as two matrix-core GEMMs per 16 nodes with the
-    constant operands in LDS (pml_kernels_eigen_gemm.h, 32 < k <= 64: P(t) is never formed); not fused: P(t) of every branch
-    materialised in HBM (the generic path, what every k > 32 took before round 6).  Both against the reference.
+    constant operands in LDS (pml_kernels_eigen_gemm.h, P(t) is never formed) and the joint sweep with P(t) built and folded
+    in registers on the vector units (pml_kernels_eigen_joint.h, a node per wavefront beyond 32 states); not fused: P(t) of
+    every branch materialised in HBM (the generic path, what every k > 32 took before round 6).  Both against the reference.
     """
     z = load_golden('synthetic_cr_k61_L12')
     k = 61
     flat = synthetic.balanced_forest(int(z['n_levels']))
     spec, rates = golden_spec(z)
     s = z['sample']
-    with hip.Engine(flat, 1, k, tune={} if fused else dict(NO_EIGEN_GEMM=1)) as eng:
+    with hip.Engine(flat, 1, k, tune={} if fused else dict(NO_EIGEN_GEMM=1, NO_EIGEN_JOINT_VALU=1)) as eng:
         eng.set_models([(spec, rates)])
         eng.set_tip_states(z['tip_states'])
         lnl = eng.bottom_up(True)
