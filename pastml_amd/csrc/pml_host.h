@@ -54,7 +54,7 @@ PML_INTERNAL int pml_fail(int code, const char* fmt, ...) __attribute__((format(
 // TREE: read by pml_tree_upload / pml_chars_alloc, so it must be set before the tree is uploaded.
 // ---------------------------------------------------------------------------------------------------------------------
 #define PML_TUNABLES(X)                                                                                              \
-    X(GRID_CAP, 0, 0) X(SMALL_MANY_NODES, 0, 0) X(BLOCK_MAX_WORK, 0, 0) X(BLOCK_MAX_STEPS, 0, 0)    \
+    X(GRID_CAP, 0, 0) X(SMALL_MANY_NODES, 0, 0) X(BLOCK_MAX_WORK, 0, 0)    \
     X(NO_MFMA, 1, 0) X(NO_EIGEN_FUSED, 1, 0) X(NO_HKY_FUSED, 1, 0)      \
     X(BLOCK_THREADS, 0, 0) X(EIG_BLOCKS, 0, 0) X(NO_EIGEN_GEMM, 1, 0) X(NO_EIGEN_JOINT_VALU, 1, 0) X(EIGJ_BLOCKS, 0, 0) \
     X(EIGJ_TIP_BLOCKS, 0, 0) X(EIGJ_ONE_TIPS_KERNEL, 1, 0) X(EIGJ_TIER_THIN, 0, 1) X(EIGJ_TIER_DEPTH, 0, 1)            \
@@ -62,7 +62,7 @@ PML_INTERNAL int pml_fail(int code, const char* fmt, ...) __attribute__((format(
     X(STACK_MIN, 0, 1) X(NO_STACK, 1, 1) X(DEBUG, 1, 0) X(BLOCK_NODES, 0, 1) X(BLOCK_MAX_STORED, 0, 1)                 \
     X(BLOCK_HEIGHT_CAP, 0, 1) X(SMALL_MAX_NODES, 0, 1) X(F81_R, 0, 1) X(F81_TD_R, 0, 1) X(NO_GRAPH, 1, 1)              \
     X(NARROW_UNITS, 0, 0) X(NO_EIGG_TIERS, 1, 0) X(NO_SPIN_WAIT, 1, 0)   \
-    X(PIJ_STAGE_ROWS, 0, 0) X(PIJ_ABLATE, 0, 0) X(PIJ_BLOCKS, 0, 0) X(NO_HEIGHT_ORDER, 1, 1) X(NO_TD_TAIL, 1, 0) X(NO_PIJ_VALU, 1, 0) X(PIJ_VALU, 1, 0) X(NO_EIGJ_PIPE, 1, 0) \
+    X(PIJ_STAGE_ROWS, 0, 0) X(PIJ_BLOCKS, 0, 0) X(NO_HEIGHT_ORDER, 1, 1) X(NO_TD_TAIL, 1, 0) X(NO_PIJ_VALU, 1, 0) X(PIJ_VALU, 1, 0) X(NO_EIGJ_PIPE, 1, 0) \
     X(THIN_UNITS, 0, 1) X(THIN_BYTES, 0, 1) X(THIN_BLOCK_NODES, 0, 1) X(NO_THIN, 1, 0) X(NO_THIN_WIDE, 1, 0) X(BU_WIDE, 0, 1) X(SORT_LEVELS, 0, 1) X(NO_WIDE_LEAN, 1, 0)
 enum PmlTunable {
 #define X(name, flag, tree) T_##name,
@@ -415,11 +415,8 @@ static bool block_schedule(const pml_ctx* c) {
     // (Round 2 also capped the number of (block, level, column) workgroup steps: with 512-thread workgroups a ragged tree
     // times many columns ran in rounds of long-lived workgroups and lost to the level kernels.  The workgroups now
     // shrink until all are resident (launch_blocks_f81) and the blocks end below the top's lowest level
-    // (pml_tree_upload): over scripts/schedule_sweep.py's grid the blocks never lose -- profiles/r03c_schedule_sweep.txt.
-    // PASTML_HIP_BLOCK_MAX_STEPS is kept as a switch.)
-    const long long steps = c->tune.get(T_BLOCK_MAX_STEPS, 1ll << 40);
-    return c->blocks.ok && !c->bu_offsets_f.empty() && (long long)c->bu_offsets_f.back() * c->sched_cols <= limit &&
-           c->blocks.steps * c->sched_cols <= steps;
+    // (pml_tree_upload): over scripts/schedule_sweep.py's grid the blocks never lose -- profiles/r03c_schedule_sweep.txt.)
+    return c->blocks.ok && !c->bu_offsets_f.empty() && (long long)c->bu_offsets_f.back() * c->sched_cols <= limit;
 }
 
 static PmlTree tree_of(const pml_ctx* c, bool fused = false) {

@@ -140,7 +140,7 @@ struct PijStage {
     static constexpr int WAVE_DOUBLES = DOUBLES + 64;   // + a slot per lane for the columns beyond ks
 };
 
-template <int NT, int KS, int SROWS, int ABLATE = 0>
+template <int NT, int KS, int SROWS>
 __global__ void __launch_bounds__(PML_BLOCK)
 pij_eigen_mfma_kernel(PmlTree t, PmlCols c, PmlModel m, double* __restrict__ P) {
     extern __shared__ double smem[];
@@ -220,8 +220,7 @@ pij_eigen_mfma_kernel(PmlTree t, PmlCols c, PmlModel m, double* __restrict__ P) 
                 for (int s = 0; s < KS; ++s) {
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
-                        if (ABLATE == 2) acc[nt][0] += a[s] * bfrag[nt][s];   // (measurement only: no matrix instructions)
-                        else acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], bfrag[nt][s], acc[nt], 0, 0, 0);
+                        acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], bfrag[nt][s], acc[nt], 0, 0, 0);
                     }
                 }
                 // D: row = hi + 4 * reg, col = lo  ->  staged row 16 tt + hi + 4 reg, columns 16 nt + lo
@@ -246,13 +245,9 @@ pij_eigen_mfma_kernel(PmlTree t, PmlCols c, PmlModel m, double* __restrict__ P) 
                 const int pairs = grows * ks / 2;
                 for (int e = lane; e < pairs; e += 64) {
                     const dbl2 v = *reinterpret_cast<const dbl2*>(sO + 2 * e);
-                    if (ABLATE == 1) {   // (measurement only: one lane in 2^20 stores, the rest of the work stays)
-                        if (v.x == 0x1p-1000) __builtin_nontemporal_store(v, reinterpret_cast<dbl2*>(gout + 2 * e));
-                    } else {
-                        __builtin_nontemporal_store(v, reinterpret_cast<dbl2*>(gout + 2 * e));
-                    }
+                    __builtin_nontemporal_store(v, reinterpret_cast<dbl2*>(gout + 2 * e));
                 }
-            } else {  // (odd row stride -- PASTML_HIP_MATRIX_R1 with an odd k: no 16-byte alignment)
+            } else {  // (odd row stride: no 16-byte alignment)
                 for (int e = lane; e < grows * ks; e += 64) gout[e] = sO[e];
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -129,15 +129,9 @@ int launch_pij_mfma(pml_ctx* ctx) {
     const int cap = std::max(64, (int)ctx->tune.get(T_PIJ_BLOCKS, 2048) / std::max(1, ctx->C));
     if (blocks > cap) blocks = cap;
     dim3 grid(blocks, ctx->C);
-    const int ablate = (int)ctx->tune.get(T_PIJ_ABLATE, 0);   // (measurements: 1 = no stores, 2 = no matrix instructions)
 #define PML_MFMA_CASE_R(NT_, KS_, SR_)                                                                             \
     if (NT == NT_ && KS == KS_ && srows == SR_) {                                                                  \
-if (ablate == 1 && KS_ == 5 && SR_ == 32)                                                                  \
-    hipLaunchKernelGGL((pij_eigen_mfma_kernel<NT_, KS_, SR_, 1>), grid, dim3(PML_BLOCK), lds, ctx->stream, t, c, m, ctx->d_P); \
-else if (ablate == 2 && KS_ == 5 && SR_ == 32)                                                             \
-    hipLaunchKernelGGL((pij_eigen_mfma_kernel<NT_, KS_, SR_, 2>), grid, dim3(PML_BLOCK), lds, ctx->stream, t, c, m, ctx->d_P); \
-else                                                                                                       \
-    hipLaunchKernelGGL((pij_eigen_mfma_kernel<NT_, KS_, SR_>), grid, dim3(PML_BLOCK), lds, ctx->stream, t, c, m, ctx->d_P);    \
+        hipLaunchKernelGGL((pij_eigen_mfma_kernel<NT_, KS_, SR_>), grid, dim3(PML_BLOCK), lds, ctx->stream, t, c, m, ctx->d_P);    \
     }
 #define PML_MFMA_CASE(NT_, KS_) PML_MFMA_CASE_R(NT_, KS_, 16) PML_MFMA_CASE_R(NT_, KS_, 32) PML_MFMA_CASE_R(NT_, KS_, 64)
     PML_MFMA_CASE(1, 4)
