@@ -38,8 +38,11 @@ int pml_fail(int code, const char* fmt, ...) {
 // characters, profiles/r05e_height_order.txt).  A balanced tree is in this order already.
 // Returns false (and leaves the vectors empty) when the caller's numbering is the height order.
 // ---------------------------------------------------------------------------------------------------------------------
+// by_shape (round 6): inside a depth the sibling groups are ordered by (shape, height class) of the unit that gathers them instead of
+// by the class alone -- the level launches of wide units walk their lists sorted by shape (units_by_shape), so only then are the
+// children of CONSECUTIVE units of a launch consecutive in memory (the top-down lists are sorted by (shape, class) to match).
 static bool height_order(int N, int R, const int* parent, const int* first_child, const int* n_children,
-                         const int* td_offsets, int n_td_levels, bool fuse, std::vector<int>& old_of_new,
+                         const int* td_offsets, int n_td_levels, bool fuse, bool by_shape, std::vector<int>& old_of_new,
                          std::vector<int>& new_of_old) {
     old_of_new.clear();
     new_of_old.clear();
@@ -62,6 +65,36 @@ static bool height_order(int N, int R, const int* parent, const int* first_child
     }
     for (int i = 0; i < N; ++i)
         if (n_children[i] > 0) cls[i] = stored[i] ? fh[i] : fh[parent[i]];   // (a cherry is never a root)
+    // the shape of the gathering unit: describe_units' packed word of the stored node (of a cherry's parent for the tips of a cherry)
+    std::vector<long long> key(N, 0);
+    if (by_shape) {
+        auto packed_of = [&](int n) {
+            const int nc = n_children[n];
+            int packed = nc < 15 ? nc : 15;
+            bool cherries_ok = true, first_two = true;
+            for (int j = 0; j < 4 && j < nc; ++j) {
+                const int ch = first_child[n] + j;
+                int code = n_children[ch] == 0 ? 0 : 1;
+                if (n_children[ch] > 0 && !stored[ch]) {
+                    if (n_children[ch] > 4) {
+                        cherries_ok = false;
+                        code = 2;
+                    } else {
+                        code = 1 + n_children[ch];
+                    }
+                }
+                packed |= code << (8 + 3 * j);
+                if (j >= 2 && code == 1) first_two = false;
+            }
+            if (cherries_ok) packed |= 1 << 4;
+            if (first_two) packed |= 1 << 5;
+            return packed;
+        };
+        for (int i = 0; i < N; ++i)
+            if (n_children[i] > 0) key[i] = ((long long)packed_of(stored[i] ? i : parent[i]) << 32) | (unsigned)cls[i];
+    } else {
+        for (int i = 0; i < N; ++i) key[i] = cls[i];
+    }
     std::vector<int> order;
     order.reserve(N);
     for (int i = 0; i < R; ++i) order.push_back(i);
@@ -73,7 +106,7 @@ static bool height_order(int N, int R, const int* parent, const int* first_child
         par.clear();
         for (size_t q = lo; q < hi; ++q)
             if (n_children[order[q]] > 0) par.push_back(order[q]);
-        std::stable_sort(par.begin(), par.end(), [&](int x, int y) { return cls[x] < cls[y]; });
+        std::stable_sort(par.begin(), par.end(), [&](int x, int y) { return key[x] < key[y]; });
         for (int p : par)
             for (int j = 0; j < n_children[p]; ++j) {
                 identity = identity && first_child[p] + j == (int)order.size();
@@ -474,9 +507,29 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
     std::vector<int> perm_old_of_new, perm_new_of_old;
     std::vector<int32_t> p_parent, p_first_child, p_n_children, p_bu_order, p_td_parents, p_post_rank;
     std::vector<double> p_dist;
+    // Shape-aware order (round 6) for large forests without many polytomies: there the level launches walk shape-sorted lists
+    // and a depth's sibling groups follow them.  Measured, marginal pass, class-only -> shape-aware numbering, bits unchanged
+    // (profiles/r06q_shape_order.txt): random binary 262 144 tips x 32, k = 64 5.07 -> 4.94 ms, k = 12 2.29 -> 2.07, k = 8 1.91 ->
+    // 1.68, k = 4 1.46 -> 1.35 (the last two with their lists sorted by shape as well, which the old numbering punished);
+    // forests with polytomies lose 2 - 3 % (many shapes: short runs) and 40 000-tip trees 3 %: they keep the class-only order.
+    bool shape_order = false;
+    {
+        long long n_inner = 0, n34 = 0;   // (the polytomy rule of pml_chars_alloc)
+        for (int i = 0; i < n_nodes; ++i) {
+            const int nc = n_children[i];
+            bool inner = false;
+            for (int j = 0; j < nc && !inner; ++j) inner = n_children[first_child[i] + j] > 0;
+            if (!inner) continue;
+            ++n_inner;
+            n34 += nc == 3 || nc == 4;
+        }
+        const bool polytomies = n_inner > 0 && n34 * 100 >= 15 * n_inner;
+        shape_order = n_nodes >= 150000 && !polytomies;
+        if (ctx->tune.on(T_SHAPE_ORDER)) shape_order = ctx->tune.get(T_SHAPE_ORDER, 1) != 0;
+    }
     if (!ctx->tune.on(T_NO_HEIGHT_ORDER) &&
-        height_order(n_nodes, n_roots, parent, first_child, n_children, td_offsets, n_td_levels, ctx->fuse, perm_old_of_new,
-                     perm_new_of_old)) {
+        height_order(n_nodes, n_roots, parent, first_child, n_children, td_offsets, n_td_levels, ctx->fuse, shape_order,
+                     perm_old_of_new, perm_new_of_old)) {
         const std::vector<int>& o = perm_old_of_new;
         const std::vector<int>& nw = perm_new_of_old;
         p_parent.resize(n_nodes);
@@ -545,6 +598,7 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
     ctx->device = device;
     ctx->old_of_new.swap(perm_old_of_new);
     ctx->new_of_old.swap(perm_new_of_old);
+    ctx->shape_ordered = shape_order && !ctx->old_of_new.empty();
 
     ctx->N = n_nodes;
     ctx->n_roots = n_roots;
@@ -853,13 +907,27 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
                 }
                 return out;
             };
+            // top-down lists: by (shape, height class) -- the order in which height_order lays the children of a depth's units out
+            // (bottom-up lists are per class already)
+            auto by_shape_class = [&](const std::vector<PmlUnit>& in, const std::vector<int>& offs, size_t count) {
+                if (!ctx->shape_ordered) return by_shape(in, offs, count);
+                std::vector<PmlUnit> out(in);
+                auto less = [&](const PmlUnit& x, const PmlUnit& y) {
+                    return x.packed != y.packed ? x.packed < y.packed : fh[x.n] < fh[y.n];
+                };
+                for (size_t l = 0; l + 1 < offs.size(); ++l) {
+                    const size_t a = (size_t)offs[l], b = std::min((size_t)offs[l + 1], count);
+                    if (b > a + 1) std::stable_sort(out.begin() + a, out.begin() + b, less);
+                }
+                return out;
+            };
             // (a balanced tree is in shape order as it is: no second copy, the launches walk the id-ordered lists)
             const bool shape_sort = !ctx->tune.on(T_NO_SHAPE_SORT) && n_stored > 0 &&
                                     !(in_shape_order(ub_f, off, (size_t)n_stored) &&
                                       in_shape_order(ut_f, ctx->td_parent_offsets_f, (size_t)n_stored));
             if (shape_sort) {
                 const std::vector<PmlUnit> sb = by_shape(ub_f, off, (size_t)n_stored);
-                const std::vector<PmlUnit> st_ = by_shape(ut_f, ctx->td_parent_offsets_f, (size_t)n_stored);
+                const std::vector<PmlUnit> st_ = by_shape_class(ut_f, ctx->td_parent_offsets_f, (size_t)n_stored);
                 PML_TRY(dev_alloc(ctx, &ctx->d_bu_units_fs, sb.size()));
                 PML_TRY(dev_alloc(ctx, &ctx->d_td_units_fs, st_.size()));
                 PML_TRY(upload(ctx, ctx->d_bu_units_fs, sb.data(), sb.size()));
@@ -1049,7 +1117,7 @@ int pml_tree_upload(pml_ctx* ctx, int32_t n_nodes, int32_t n_roots, const int32_
                 PML_TRY(upload(ctx, U.d_td_units_r, utr.data(), utr.size()));
                 if (shape_sort) {
                     const std::vector<PmlUnit> sb = by_shape(ubr, U.bu_offsets_r, bu_r.size());
-                    const std::vector<PmlUnit> st_ = by_shape(utr, U.td_offsets_r, td_r.size());
+                    const std::vector<PmlUnit> st_ = by_shape_class(utr, U.td_offsets_r, td_r.size());
                     PML_TRY(dev_alloc(ctx, &U.d_bu_units_rs, sb.size()));
                     PML_TRY(dev_alloc(ctx, &U.d_td_units_rs, st_.size()));
                     PML_TRY(upload(ctx, U.d_bu_units_rs, sb.data(), sb.size()));
@@ -1489,7 +1557,7 @@ int pml_chars_alloc(pml_ctx* ctx, int32_t n_cols, int32_t k) {
         // Level launches walk the lists sorted by shape inside every level (pml_tree_upload) from 4 lanes per unit on: 262 144
         // tips x 32, marginal pass: k = 8 1.82 -> 1.78 ms, k = 12 2.35 -> 2.26, k = 16 2.38 -> 2.26, k = 20 3.49 -> 3.06, k = 32
         // 3.53 -> 3.11; polytomies k = 12 1.36 -> 1.28, k = 20 1.55 -> 1.36; two lanes per unit (k <= 4) lose 11 % and keep id order.
-        ctx->level_lists_sorted = ctx->Gf >= 4;
+        ctx->level_lists_sorted = ctx->Gf >= 4 || ctx->shape_ordered;   // (narrow units too where the numbering follows the shapes)
         if (ctx->tune.on(T_SORT_LEVELS)) ctx->level_lists_sorted = ctx->tune.get(T_SORT_LEVELS, 1) != 0;
         // Top-down: 8 states per lane for 32 < k <= 64 (above) unless the forest has many nodes of three or four children
         // (15 % of those with grandchildren): the lane-parallel gather of a unit's children takes

@@ -63,7 +63,7 @@ PML_INTERNAL int pml_fail(int code, const char* fmt, ...) __attribute__((format(
     X(BLOCK_HEIGHT_CAP, 0, 1) X(SMALL_MAX_NODES, 0, 1) X(F81_R, 0, 1) X(F81_TD_R, 0, 1) X(NO_GRAPH, 1, 1)              \
     X(NARROW_UNITS, 0, 0) X(NO_EIGG_TIERS, 1, 0) X(NO_SPIN_WAIT, 1, 0)   \
     X(PIJ_STAGE_ROWS, 0, 0) X(PIJ_BLOCKS, 0, 0) X(NO_HEIGHT_ORDER, 1, 1) X(NO_TD_TAIL, 1, 0) X(NO_PIJ_VALU, 1, 0) X(PIJ_VALU, 1, 0) X(NO_EIGJ_PIPE, 1, 0) \
-    X(THIN_UNITS, 0, 1) X(THIN_BYTES, 0, 1) X(THIN_BLOCK_NODES, 0, 1) X(NO_THIN, 1, 0) X(NO_THIN_WIDE, 1, 0) X(BU_WIDE, 0, 1) X(SORT_LEVELS, 0, 1) X(NO_WIDE_LEAN, 1, 0)
+    X(THIN_UNITS, 0, 1) X(THIN_BYTES, 0, 1) X(THIN_BLOCK_NODES, 0, 1) X(NO_THIN, 1, 0) X(NO_THIN_WIDE, 1, 0) X(BU_WIDE, 0, 1) X(SORT_LEVELS, 0, 1) X(NO_WIDE_LEAN, 1, 0) X(SHAPE_ORDER, 0, 1)
 enum PmlTunable {
 #define X(name, flag, tree) T_##name,
     PML_TUNABLES(X)
@@ -240,6 +240,7 @@ struct pml_ctx {
     int C = 0, k = 0, ks = 0, W = 0, G = 0, R = 0;
     int Gf = 0, Rf = 0;  // lane-group shape of the F81-family bottom-up kernels (chunked state ownership)
     bool bu_wide_lanes = false;  // 32 < k <= 64: most bottom-up levels run with 8 states per lane (see dispatch_sweep)
+    bool shape_ordered = false;   // the forest's numbering orders a depth's sibling groups by (shape, class) of the gathering unit
     bool level_lists_sorted = false;  // 32 < k <= 64: the level launches walk the lists sorted by shape (pml_tree_upload)
     int Gt = 0, Rt = 0;  // ... and of the F81-family top-down kernels
     u64 *d_masks = nullptr, *d_masks_init = nullptr;

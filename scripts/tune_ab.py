@@ -1,7 +1,7 @@
 """
 A/B of schedule switches inside ONE process: engines with different `tune` dictionaries on the same forest, timed alternately
 (three rounds of 20 passes each; the boxes and the first launches of a process differ by more than the effects looked for).
-usage: r05_tune_ab.py <case> <name=SWITCH:value,SWITCH:value> <name=...> ...     (value 'none' = switch not given)
+usage: tune_ab.py <case> <name=SWITCH:value,SWITCH:value> <name=...> ...     (value 'none' = switch not given)
 """
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,7 +1,7 @@
 """
 One schedule variant per PROCESS (ballast engine first, then the timed one: every variant's buffers land where the others' do --
 engines created one after the other in a process differ by up to 6 % with identical settings).
-usage: r05_tune_one.py <case> <name=SWITCH:value,...>        cases: scripts/r05_tune_ab.py
+usage: tune_one.py <case> <name=SWITCH:value,...>        cases: scripts/tune_ab.py
 """
 import os, sys, time, runpy
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,7 +9,7 @@ import numpy as np
 from pastml_amd import hip, synthetic
 from pastml_amd.tree import FlatForest
 
-src = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'r05_tune_ab.py')).read()
+src = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tune_ab.py')).read()
 ns = dict(globals())
 exec(src[src.index('def hiv1c_forest'):src.index('make, k, C = cases')], ns)
 make, k, C = ns['cases'][sys.argv[1]]

@@ -939,10 +939,13 @@ def test_height_order_is_invisible_at_the_boundary(kind, k, n_tips, arity, n_tre
     specs = [(random_spec(kind, k, rng), (float(rng.uniform(0.5, 3)), 0.0, 1.0)) for _ in range(cols)]
     tips = np.stack([rng.integers(0, k, size=flat.n_tips) for _ in range(cols)])
     out = {}
-    for name, tune in (('plain', dict(NO_HEIGHT_ORDER=1)), ('ordered', {})):
+    # ('shaped': the numbering that also follows the shape-sorted lists -- large forests take it by themselves, round 6)
+    orders = {}
+    for name, tune in (('plain', dict(NO_HEIGHT_ORDER=1)), ('ordered', dict(SHAPE_ORDER=0)), ('shaped', dict(SHAPE_ORDER=1))):
         got = {}
         with hip.Engine(flat, cols, k, tune=tune) as eng:
             order = eng.node_order()
+            orders[name] = order
             got_identity = np.array_equal(order, np.arange(flat.n_nodes))
             assert got_identity == (name == 'plain')
             assert np.array_equal(np.sort(order), np.arange(flat.n_nodes))
@@ -976,6 +979,8 @@ def test_height_order_is_invisible_at_the_boundary(kind, k, n_tips, arity, n_tre
         out[name] = got
     for key, want in out['plain'].items():
         assert np.array_equal(want, out['ordered'][key], equal_nan=True), key
+        assert np.array_equal(want, out['shaped'][key], equal_nan=True), key
+    assert not np.array_equal(orders['ordered'], orders['shaped'])   # (they ARE two numberings)
     assert np.array_equal(out['ordered']['js'][2], out['ordered']['js_dl'])
 
 
