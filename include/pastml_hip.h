@@ -34,7 +34,7 @@ enum {
     PML_OK = 0,
     PML_ERR_INVALID = 1,      /* bad argument / call order */
     PML_ERR_HIP = 2,          /* HIP runtime failure (message has the HIP error string) */
-    PML_ERR_UNSUPPORTED = 3,  /* e.g. k > 256 */
+    PML_ERR_UNSUPPORTED = 3,  /* e.g. k > 512 (F81 family), k > 256 (HKY / eigen models) */
     PML_ZERO_LIKELIHOOD = 4   /* pastml/ml.py:139-145: a parent/child pair has non-intersecting states */
 };
 

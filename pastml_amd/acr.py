@@ -35,7 +35,8 @@ from pastml_amd.models.JCModel import JCModel, JC
 from pastml_amd.models.JTTModel import JTTModel, JTT, JTT_STATES
 from pastml_amd.tree import TreeNode, get_flat_forest, AnnotationColumn
 
-MAX_STATES = 256   # = pastml_amd.hip.MAX_STATES = PML_MAX_STATES of include/pastml_hip.h (tests/test_host_logic.py checks)
+MAX_STATES = 512   # = pastml_amd.hip.MAX_STATES = PML_MAX_STATES of the library (tests/test_host_logic.py checks); F81 family
+MAX_STATES_MATRIX = 256   # ... and the models with a transition matrix per branch (HKY has 4 states; JTT 20; CUSTOM_RATES any)
 
 model2class = {F81: F81Model, JC: JCModel, CUSTOM_RATES: CustomRatesModel, HKY: HKYModel, JTT: JTTModel, EFT: EFTModel}
 
@@ -243,13 +244,15 @@ def acr(forest, df=None, columns=None, column2states=None, prediction_method=MPP
             if model_name not in model2class:
                 raise ValueError('Model {} is unknown, should be one of {}'.format(model_name, ', '.join(model2class)))
             # A boundary difference to the reference, which has no bound on k (int64 arg-max tables, pastml/ml.py:134; its
-            # pipeline only drops columns whose values are mostly unique, acr.py:774): the device path keeps arg-max tables
-            # in bytes and state masks in four words -- pml_chars_alloc answers PML_ERR_UNSUPPORTED beyond 256 states.  Said
-            # here, before any work is done, by name ("Limits").
-            if len(states) > MAX_STATES:
+            # pipeline only drops columns whose values are mostly unique, acr.py:774): the device path's widest lane shape
+            # holds 512 states (F81 / JC / EFT; 256 for CUSTOM_RATES, whose P(t) is a k x k matrix per branch) --
+            # pml_chars_alloc / pml_model_set_eigen answer PML_ERR_UNSUPPORTED beyond.  Said here, before any work is done, by
+            # name ("Limits").
+            most = MAX_STATES if model_name in (F81, JC, EFT) else MAX_STATES_MATRIX
+            if len(states) > most:
                 raise ValueError('Character {} has {} states: the MI355X likelihood path supports at most {} states per '
-                                 'character (PML_ERR_UNSUPPORTED); reconstruct it with a parsimonious method or merge rare '
-                                 'states.'.format(character, len(states), MAX_STATES))
+                                 'character under {} (PML_ERR_UNSUPPORTED); reconstruct it with a parsimonious method or merge '
+                                 'rare states.'.format(character, len(states), most, model_name))
             if model_name in (HKY, JTT):
                 alphabet = HKY_STATES if HKY == model_name else JTT_STATES
                 if not set(states) & set(alphabet):

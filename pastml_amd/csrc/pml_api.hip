@@ -1522,6 +1522,7 @@ int pml_chars_alloc(pml_ctx* ctx, int32_t n_cols, int32_t k) {
                 if ((v == 2 || v == 4) && k >= 3 && k <= 8) rf = v;
                 if ((v == 2 || v == 4) && k > 16 && k <= 32) rf = v;   // (16 lanes x 2 states or 8 x 4)
             }
+            if (k > 256) rf = 8;   // (a wavefront per unit: 64 lanes x 8 states, k <= 512)
             R = rf;
             const int need = (k + rf - 1) / rf;
             G = 1;
@@ -1633,7 +1634,7 @@ int pml_chars_alloc(pml_ctx* ctx, int32_t n_cols, int32_t k) {
     // THIN_BYTES (20 MB) of state vectors over all columns -- beyond, the level kernels stream it faster than workgroups
     // that walk subtrees.  Measured (profiles/r05u_thin_ends.txt, THIN_UNITS sweeps): k = 4 x 32 columns 4 096 (16 384 loses
     // 20 %); k = 64: x 32 columns 1 024 - 2 048, x 16 2 048, x 8 4 096; k = 20 x 32 4 096.
-    if (!ctx->bu_offsets_f.empty() && (ctx->bu_offsets_f.back() > 2048 || ctx->tune.on(T_THIN_UNITS)) && !ctx->tune.on(T_NO_THIN)) {
+    if (!wide_states(ctx) && !ctx->bu_offsets_f.empty() && (ctx->bu_offsets_f.back() > 2048 || ctx->tune.on(T_THIN_UNITS)) && !ctx->tune.on(T_NO_THIN)) {
         long long thin = ctx->tune.get(T_THIN_UNITS, 0);
         if (!ctx->tune.on(T_THIN_UNITS)) {
             const long long bytes = ctx->tune.get(T_THIN_BYTES, 20ll << 20);
@@ -1862,6 +1863,9 @@ int pml_model_set_eigen(pml_ctx* ctx, int32_t col_begin, int32_t col_end, const 
                         const double* A, const double* Ainv, const double* sf, const double* tau,
                         const double* tau_factor) {
     if (!d || !A || !Ainv) return fail(PML_ERR_INVALID, "NULL eigen array");
+    if (ctx && ctx->k > PML_MAX_STATES_MATRIX)
+        return fail(PML_ERR_UNSUPPORTED, "k = %d states: the eigen-decomposed models take at most %d (the F81 family %d)", ctx->k,
+                    PML_MAX_STATES_MATRIX, PML_MAX_STATES);
     PML_TRY(set_common(ctx, PML_MODEL_EIGEN, col_begin, col_end, pi, sf, tau, tau_factor));
     const size_t k = ctx->k;
     if (!ctx->d_d) {
@@ -2045,6 +2049,7 @@ int pml_pij_batch(pml_ctx* ctx, double* P_out) {
 // workgroup finishes in a single pass per wave belong to the narrow end.
 static int narrow_levels(const pml_ctx* ctx, const std::vector<int>& off, int n_levels, bool from_front, int C, int fixed_limit = 0,
                          int top_down = -1) {
+    if (wide_states(ctx)) return 0;   // (no multi-level kernels beyond 256 states)
     const int limit_env = (int)ctx->tune.get(T_NARROW_UNITS, 0);
     int limit = fixed_limit > 0 ? fixed_limit : (limit_env > 0 ? limit_env : std::max(8, 512 / std::max(1, C)));
     if (fixed_limit <= 0 && limit_env <= 0 && ctx->kind == PML_MODEL_F81) {
@@ -2369,7 +2374,7 @@ static int submit_bottom_up(pml_ctx* ctx, int is_marginal, const uint8_t* active
     const bool small_path = single_launch_sweeps(ctx) && is_marginal && ctx->kind == PML_MODEL_F81;
     const size_t CN = (size_t)ctx->C * ctx->N;
     if (!is_marginal && !ctx->d_J) {
-        PML_TRY(dev_alloc(ctx, &ctx->d_J, CN * ctx->ks));
+        PML_TRY(dev_alloc(ctx, &ctx->d_J, CN * ctx->ks * (ctx->k > 256 ? 2 : 1)));
         PML_TRY(dev_alloc(ctx, &ctx->d_js, CN));
     }
     const bool no_p = eigen_fused(ctx) || (is_marginal && eigen_gemm(ctx)) || (!is_marginal && eigen_joint_valu(ctx)) ||
@@ -3148,12 +3153,14 @@ static int download_internal(pml_ctx* ctx, int what, int32_t col, void* out) {
             return fetch_exponents(ctx, ctx->d_lhe, col, (double*)out);
         case PML_BUF_JOINT_TABLE: {
             if (ctx->bu_mode != 0) return fail(PML_ERR_INVALID, "no valid joint sweep");
-            // the tables hold one byte per entry on the device; the interface hands out int32
-            std::vector<pml_jt> tmp(N * ctx->ks);
-            HIP_TRY(hipMemcpy(tmp.data(), ctx->d_J + (size_t)col * N * ctx->ks, tmp.size(), hipMemcpyDeviceToHost));
+            // the tables hold one byte per entry on the device (two beyond 256 states); the interface hands out int32
+            const size_t width = ctx->k > 256 ? 2 : 1;
+            std::vector<pml_jt> tmp(N * ctx->ks * width);
+            HIP_TRY(hipMemcpy(tmp.data(), ctx->d_J + (size_t)col * N * ctx->ks * width, tmp.size(), hipMemcpyDeviceToHost));
             int32_t* o = (int32_t*)out;
+            const unsigned short* wide = reinterpret_cast<const unsigned short*>(tmp.data());
             for (size_t n = 0; n < N; ++n)
-                for (int i = 0; i < ctx->k; ++i) o[n * ctx->k + i] = tmp[n * ctx->ks + i];
+                for (int i = 0; i < ctx->k; ++i) o[n * ctx->k + i] = width == 2 ? (int32_t)wide[n * ctx->ks + i] : (int32_t)tmp[n * ctx->ks + i];
             return PML_OK;
         }
         case PML_BUF_JOINT_STATE:

@@ -264,7 +264,7 @@ struct pml_ctx {
     double *d_E = nullptr, *d_P = nullptr, *d_bu = nullptr, *d_S = nullptr, *d_td = nullptr, *d_post = nullptr,
            *d_lhsum = nullptr;
     i64 *d_be = nullptr, *d_te = nullptr, *d_lhe = nullptr;
-    pml_jt* d_J = nullptr;  // arg-max tables, one byte per entry
+    pml_jt* d_J = nullptr;  // arg-max tables, one byte per entry (two beyond 256 states)
     int* d_js = nullptr;
     u64* d_err = nullptr;
     int bu_mode = -1;  // -1 invalid, 1 marginal, 0 joint
@@ -375,7 +375,7 @@ static int upload(pml_ctx* ctx, T* dst, const T* src, size_t count) {
 }
 
 static void pick_group(const pml_ctx* ctx, int k, int& G, int& R) {
-    R = k <= 32 ? 1 : (k <= 128 ? 2 : 4);
+    R = k <= 32 ? 1 : (k <= 128 ? 2 : (k <= 256 ? 4 : 8));   // (beyond 256 states: the F81 family only, a wavefront per unit)
     if (k > 16 && k <= 32) R = 4;  // 8 lanes per unit: 8 units per wavefront
     const int need = (k + R - 1) / R;
     G = 1;
@@ -403,7 +403,12 @@ static int grid_for(const pml_ctx* ctx, int n_units, int units_per_block, int C,
 // HIV1C-sized sweeps -- 7 237 nodes, 57 height levels -- of 246 binary columns 0.34 -> 0.27 ms; a balanced 4 096-tip
 // tree with 20 states has levels of 16 passes and stays with the level kernels: 0.12 against 0.27 ms).  Same unit
 // functions and lane shapes as the level kernels: identical bits.
+// (more than 256 states -- round 6, the F81 family only, 64 lanes x 8 states -- run the plain level schedule: their one lane
+// shape is instantiated for the level kernels alone)
+static inline bool wide_states(const pml_ctx* c) { return c->k > 256; }
+
 static bool single_launch_sweeps(const pml_ctx* c) {
+    if (wide_states(c)) return false;
     const int many = (int)c->tune.get(T_SMALL_MANY_NODES, 16384);
     return c->small || (c->sched_cols >= 64 && c->N <= many && c->levels_fit_workgroup);
 }
@@ -417,7 +422,7 @@ static bool block_schedule(const pml_ctx* c) {
     // times many columns ran in rounds of long-lived workgroups and lost to the level kernels.  The workgroups now
     // shrink until all are resident (launch_blocks_f81) and the blocks end below the top's lowest level
     // (pml_tree_upload): over scripts/schedule_sweep.py's grid the blocks never lose -- profiles/r03c_schedule_sweep.txt.)
-    return c->blocks.ok && !c->bu_offsets_f.empty() && (long long)c->bu_offsets_f.back() * c->sched_cols <= limit;
+    return c->blocks.ok && !wide_states(c) && !c->bu_offsets_f.empty() && (long long)c->bu_offsets_f.back() * c->sched_cols <= limit;
 }
 
 static PmlTree tree_of(const pml_ctx* c, bool fused = false) {
@@ -461,6 +466,7 @@ static PmlState state_of(const pml_ctx* c) {
     s.lhsum = c->d_lhsum;
     s.lhe = c->d_lhe;
     s.J = c->d_J;
+    s.jt16 = c->k > 256;
     s.js = c->d_js;
     s.err = c->d_err;
     s.msg = c->d_msg;

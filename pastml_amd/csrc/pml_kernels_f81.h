@@ -17,7 +17,8 @@
 #define PML_KIND_CHERRY 1
 #define PML_KIND_STORED 2
 
-typedef unsigned char pml_jt;  // entry of an arg-max table: a state index, k <= PML_MAX_STATES = 256
+typedef unsigned char pml_jt;  // entry of an arg-max table: a state index (k <= 256; beyond, the F81 family stores 16-bit entries
+                               // in the same buffer: PmlState::jt16)
 
 struct PmlTree {
     int N;
@@ -54,7 +55,8 @@ struct PmlState {
     double* lhsum;  // [C][N]
     i64* lhe;       // [C][N]
     bool implicit_tips;  // top-down sweep: the unit-vector posteriors of observed tips are not written (PML_OPT_IMPLICIT_TIP_POSTERIORS)
-    pml_jt* J;      // [C][N][ks]  joint argmax tables (one byte per entry: k <= 256)
+    pml_jt* J;      // [C][N][ks]  joint argmax tables (one byte per entry: k <= 256; two where jt16)
+    bool jt16;      // more than 256 states: the entries of J are unsigned shorts
     int* js;        // [C][N]      joint states
     u64* err;       // [C]         min over failing (post_rank << 32 | child id)
     double* msg;    // [C][N][ks]  fused eigen sweeps: message of a node to its parent, P(t) applied to its BU vector
@@ -695,7 +697,16 @@ __device__ __forceinline__ void f81_joint_message(const LaneCtx<G, R>& L, const 
 template <int G, int R>
 __device__ __forceinline__ void f81_store_table(const LaneCtx<G, R>& L, const PmlCols& c, pml_jt* __restrict__ jp,
                                                 const int (&jj)[R]) {
-    if (R == 1) {
+    if (G * R > 256) {
+        // more than 256 states (64 lanes x 8): 16-bit entries, jp counts entries -- the caller's pointer arithmetic is in entries
+        // of the byte table, so the row starts at twice the offset: rebuilt here from the row's entry index
+        unsigned short* wp = reinterpret_cast<unsigned short*>(jp);
+#pragma unroll
+        for (int r = 0; r < R; r += 2) {
+            if (L.st(r) < c.ks)
+                *reinterpret_cast<unsigned*>(wp + L.st(r)) = (unsigned)(jj[r] & 0xffff) | ((unsigned)(jj[r + 1] & 0xffff) << 16);
+        }
+    } else if (R == 1) {
         if (L.st(0) < c.ks) jp[L.st(0)] = (pml_jt)jj[0];
     } else {
 #pragma unroll
@@ -704,6 +715,14 @@ __device__ __forceinline__ void f81_store_table(const LaneCtx<G, R>& L, const Pm
                 *reinterpret_cast<unsigned short*>(jp + L.st(r)) = (unsigned short)((jj[r] & 0xff) | ((jj[r + 1] & 0xff) << 8));
         }
     }
+}
+
+// the row of node `node` of column L.col in the arg-max tables (entries of one or two bytes)
+template <int G, int R>
+__device__ __forceinline__ pml_jt* f81_table_row(const LaneCtx<G, R>& L, const PmlTree& t, const PmlCols& c, const PmlState& st,
+                                                 int node) {
+    const size_t entry = ((size_t)L.col * t.N + node) * c.ks;
+    return st.J + (G * R > 256 ? 2 * entry : entry);
 }
 
 // Everything a fast bottom-up unit reads, as issued loads: the gathered scalars, the unit's own mask word and the
@@ -963,13 +982,13 @@ __device__ __forceinline__ bool bu_f81_unit_fast(const LaneCtx<G, R>& L, const P
                     int tj[R];
 #pragma unroll
                     for (int r = 0; r < R; ++r) tj[r] = L.st(r) < c.k ? s : 0;
-                    f81_store_table<G, R>(L, c, st.J + ((size_t)L.col * t.N + cfc + q) * c.ks, tj);
+                    f81_store_table<G, R>(L, c, f81_table_row<G, R>(L, t, c, st, cfc + q), tj);
                 }
             }
             if (!closed) f81_joint_message<G, R>(L, c, e, v, msg, jj);
 #pragma unroll
             for (int r = 0; r < R; ++r) acc[r] *= fmax(msg[r], 0.0);
-            f81_store_table<G, R>(L, c, st.J + ((size_t)L.col * t.N + ch) * c.ks, jj);
+            f81_store_table<G, R>(L, c, f81_table_row<G, R>(L, t, c, st, ch), jj);
             esum += lazy_rescale<G, R>(acc);
             continue;
         }
@@ -1571,7 +1590,7 @@ __device__ __forceinline__ void bu_f81_unit_seq(const LaneCtx<G, R>& L, const Pm
                     v[r] *= fmax(tmsg[r], 0.0);
                     tnz |= v[r] != 0.0;
                 }
-                f81_store_table<G, R>(L, c, st.J + ((size_t)L.col * t.N + tip) * c.ks, tj);
+                f81_store_table<G, R>(L, c, f81_table_row<G, R>(L, t, c, st, tip), tj);
                 if (!group_any<G>(tnz)) {
                     if (L.g == 0)
                         atomicMin(&st.err[L.col], ((u64)(unsigned)t.post_rank[ch] << 32) | (u64)(unsigned)tip);
@@ -1616,7 +1635,7 @@ __device__ __forceinline__ void bu_f81_unit_seq(const LaneCtx<G, R>& L, const Pm
                     }
                 }
             }
-            f81_store_table<G, R>(L, c, st.J + ((size_t)L.col * t.N + ch) * c.ks, jj);
+            f81_store_table<G, R>(L, c, f81_table_row<G, R>(L, t, c, st, ch), jj);
             if (!group_any<G>(nz)) {
                 if (L.g == 0)
                     atomicMin(&st.err[L.col], ((u64)(unsigned)t.post_rank[n] << 32) | (u64)(unsigned)ch);

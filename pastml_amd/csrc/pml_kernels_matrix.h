@@ -4,7 +4,8 @@
 #pragma once
 #include "pml_model.h"
 
-#define PML_MAX_STATES 256
+#define PML_MAX_STATES 512       // F81 family; the matrix / eigen models stop at PML_MAX_STATES_MATRIX
+#define PML_MAX_STATES_MATRIX 256
 
 // Stages the R values of every lane of a unit into the unit's LDS slot; the unit's lanes belong to one wavefront and
 // LDS operations of a wavefront complete in order, so the following reads by other lanes of the unit see them.

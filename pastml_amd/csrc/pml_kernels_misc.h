@@ -2,7 +2,7 @@
 #pragma once
 #include "pml_kernels_f81.h"
 
-#define PML_MAX_STATES_SEL 256
+#define PML_MAX_STATES_SEL 512
 
 // masks: internal nodes all ones; tip j one-hot at states[col][j] (all ones if negative = missing data)
 #ifdef PML_PLAIN_KERNELS   // (launched by pml_api.hip only: the other translation units leave it out)
@@ -102,6 +102,11 @@ loglik_kernel(PmlTree t, PmlCols c, PmlState st, int n_cols, int is_marginal, do
 }
 #endif
 
+// an entry of the arg-max tables (one byte; two beyond 256 states)
+__device__ __forceinline__ int table_entry(const PmlState& st, size_t entry) {
+    return st.jt16 ? (int)reinterpret_cast<const unsigned short*>(st.J)[entry] : (int)st.J[entry];
+}
+
 // joint back-trace, one depth level per launch: state[n] = table[n][state[parent]] (ml.py:615-620)
 #ifdef PML_PLAIN_KERNELS   // (launched by pml_api.hip only: the other translation units leave it out)
 PML_GLOBAL void __launch_bounds__(PML_BLOCK)
@@ -110,7 +115,7 @@ joint_backtrace_kernel(PmlTree t, PmlCols c, PmlState st, int begin, int end) {
     const size_t colN = (size_t)col * t.N;
     for (int n = begin + blockIdx.x * blockDim.x + threadIdx.x; n < end; n += gridDim.x * blockDim.x) {
         const int ps = st.js[colN + t.parent[n]];
-        st.js[colN + n] = st.J[(colN + n) * c.ks + ps];
+        st.js[colN + n] = table_entry(st, (colN + n) * c.ks + ps);
     }
 }
 #endif
@@ -127,7 +132,7 @@ joint_backtrace_narrow_kernel(PmlTree t, PmlCols c, PmlState st, const int* __re
         const int begin = depth_offsets[d], end = depth_offsets[d + 1];
         for (int n = begin + threadIdx.x; n < end; n += blockDim.x) {
             const int ps = st.js[colN + t.parent[n]];
-            st.js[colN + n] = st.J[(colN + n) * c.ks + ps];
+            st.js[colN + n] = table_entry(st, (colN + n) * c.ks + ps);
         }
         __syncthreads();
     }
@@ -150,7 +155,7 @@ joint_backtrace_blocks_kernel(PmlTree t, PmlCols c, PmlState st, const int* __re
         for (int q = begin + threadIdx.x; q < end; q += blockDim.x) {
             const int n = nodes[q];
             const int ps = st.js[colN + t.parent[n]];
-            st.js[colN + n] = st.J[(colN + n) * c.ks + ps];
+            st.js[colN + n] = table_entry(st, (colN + n) * c.ks + ps);
         }
         __syncthreads();
     }
@@ -422,7 +427,7 @@ select_states_kernel(int N, int k, int ks, int W, const double* __restrict__ pos
 // calc_node_td_likelihood (pastml/ml.py:273-290) leaves on it:
 //     msg[i] = sum_j P[i][j] BU_n[j]   (<= 0 -> 1),   X = TD_p o BU_p / msg,   TD_n[i] = max(sum_j P[i][j] X[j], 0)
 // One wavefront per (node, column), the levels of the tree top-down (a cherry's tips need the cherry's vector).
-// Inspection only, not on the measured path: plain loops, k <= 256 states in up to four registers per lane.
+// Inspection only, not on the measured path: plain loops, k <= 512 states in up to eight registers per lane.
 // P: transposed matrices of the matrix models ([C][N][k][ks], Pt[j][i] = P[i][j]) or nullptr for the F81 family, whose
 // P = (1 - e) 1 pi^T + e I is applied in closed form.
 #ifdef PML_PLAIN_KERNELS   // (launched by pml_api.hip only: the other translation units leave it out)
@@ -442,8 +447,8 @@ td_fill_kernel(PmlTree t, PmlCols c, PmlState st, const double* __restrict__ P, 
         const size_t row = (colN + n) * ks, prow = (colN + p) * ks;
         const double* Pt = P != nullptr ? P + (colN + n) * (size_t)k * ks : nullptr;
         const i64 be_n = tip ? 0 : st.be[colN + n];
-        double v[4], x[4];
-        for (int q = 0; q < 4; ++q) {
+        double v[PML_MAX_STATES_SEL / 64], x[PML_MAX_STATES_SEL / 64];
+        for (int q = 0; q < PML_MAX_STATES_SEL / 64; ++q) {
             const int i = lane + 64 * q;
             v[q] = 0.0;
             if (i < k) v[q] = tip ? (double)((c.masks[(colN + n) * c.W + (i >> 6)] >> (i & 63)) & 1ull) : st.bu[row + i];
@@ -456,7 +461,7 @@ td_fill_kernel(PmlTree t, PmlCols c, PmlState st, const double* __restrict__ P, 
         const double s_n = f81 ? st.S[colN + n] : 0.0;
         double big = 0.0;
         bool out_of_band = false;
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < PML_MAX_STATES_SEL / 64; ++q) {
             const int i = lane + 64 * q;
             x[q] = 0.0;
             if (i >= k) continue;
@@ -477,12 +482,12 @@ td_fill_kernel(PmlTree t, PmlCols c, PmlState st, const double* __restrict__ P, 
             for (int off = 32; off > 0; off >>= 1) big = fmax(big, __shfl_xor(big, off, 64));
             if (big > 0.0 && !isinf(big)) {
                 const int ex = exponent_of(big);
-                for (int q = 0; q < 4; ++q) x[q] = __builtin_ldexp(x[q], -ex);
+                for (int q = 0; q < PML_MAX_STATES_SEL / 64; ++q) x[q] = __builtin_ldexp(x[q], -ex);
                 xe += ex;
             }
         }
         __builtin_amdgcn_wave_barrier();
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < PML_MAX_STATES_SEL / 64; ++q) {
             const int i = lane + 64 * q;
             if (i < k) sv[wave][i] = x[q];
         }
@@ -491,13 +496,13 @@ td_fill_kernel(PmlTree t, PmlCols c, PmlState st, const double* __restrict__ P, 
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         double dot = 0.0;
         if (f81) {
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < PML_MAX_STATES_SEL / 64; ++q) {
                 const int i = lane + 64 * q;
                 if (i < k) dot += c.pi[(size_t)col * ks + i] * x[q];
             }
             for (int off = 32; off > 0; off >>= 1) dot += __shfl_xor(dot, off, 64);
         }
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < PML_MAX_STATES_SEL / 64; ++q) {
             const int i = lane + 64 * q;
             if (i >= ks) continue;
             double td = 0.0;

@@ -117,6 +117,8 @@ PML_INTERNAL int dispatch_sweep_matrix(pml_ctx* ctx, SweepKind what, const int* 
 PML_INTERNAL int dispatch_select(pml_ctx* ctx, int method, int force_joint, const u64* d_lh_mask);
 // ---- pml_launch_f81_level.hip: F81-family level launches
 PML_INTERNAL int dispatch_sweep_f81(pml_ctx* ctx, SweepKind what, const int* level, int n_level);
+// ---- pml_launch_f81_wide.hip: the same for more than 256 states (64 lanes x 8 states)
+PML_INTERNAL int dispatch_sweep_f81_wide(pml_ctx* ctx, SweepKind what, const int* level, int n_level);
 // ---- pml_launch_f81_small.hip / pml_launch_f81_blocks.hip: several levels in one launch (whole sweeps of small forests and
 //      the narrow ends; subtree blocks and the thin ends)
 PML_INTERNAL int dispatch_small_f81(pml_ctx* ctx, bool bottom_up, int do_prep, int first_level = 0, int n_levels = -1,

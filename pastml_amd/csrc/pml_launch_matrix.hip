@@ -94,6 +94,7 @@ int dispatch_select(pml_ctx* ctx, int method, int force_joint, const u64* d_lh_m
     X(2, 8)
     X(4, 8)
     X(8, 8)
+    X(64, 8)
 #undef X
     return fail(PML_ERR_UNSUPPORTED, "no selection kernel for G=%d R=%d", ctx->G, ctx->R);
 }

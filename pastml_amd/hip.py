@@ -23,7 +23,8 @@ PML_OK, PML_ERR_INVALID, PML_ERR_HIP, PML_ERR_UNSUPPORTED, PML_ZERO_LIKELIHOOD =
 BUF_BU, BUF_BU_SF, BUF_TD, BUF_TD_SF, BUF_POSTERIOR, BUF_LH_SUM, BUF_LH_SF, BUF_JOINT_TABLE, BUF_JOINT_STATE, \
     BUF_BRANCH_EXP = range(10)
 
-MAX_STATES = 256
+MAX_STATES = 512          # the F81 family; HKY / eigen models: MAX_STATES_MATRIX
+MAX_STATES_MATRIX = 256
 SCHEDULE_SINGLE_LAUNCH, SCHEDULE_BLOCKS, SCHEDULE_TWO_LEVEL, SCHEDULE_LEVELS, SCHEDULE_OTHER_MODEL = 0, 1, 2, 3, 4
 OPT_CHERRY_FUSION = 1
 OPT_KEEP_TD = 2

@@ -519,7 +519,7 @@ def marginal_counts(forest, character, model, n_repetitions=1_000, device_sampli
         altered = problem.alter_zero_node_allowed_states() if 0 == model.tau else np.zeros(0, dtype=np.int64)
         problem.bottom_up_loglikelihood(model, is_marginal=True, alter=False)
         posterior, _, _ = problem.top_down_marginals()
-        if device_sampling and not len(altered):
+        if device_sampling and not len(altered) and k <= 256:   # (the device sampler's tables hold 256 states)
             # no node altered by the zero-branch handling: the scenarios are drawn on the device (same scheme, a
             # counter-based generator seeded from numpy's global one, so np.random.seed still fixes the result)
             return problem.engine.marginal_counts(n_repetitions, seed=int(np.random.randint(0, 2 ** 62, dtype=np.int64)))

@@ -779,6 +779,88 @@ def case_eigen_k61():
 CASES['eigen_k61'] = case_eigen_k61
 
 
+def case_f81_k300():
+    """
+    More than 256 states (the reference has no bound on k, pastml/ml.py:134): the reference's F81Model with 300 states on a
+    balanced 1 024-tip tree, a tenth of the tips unannotated -- marginal pass and joint sweep with its back-trace, fixed
+    parameters.  Stored: every scalar, the joint states of all nodes, and the vectors at every 7th node.
+    """
+    k, n_levels = 300, 10
+    flat = synthetic.balanced_forest(n_levels)
+    roots = flat.to_tree_nodes()
+    fs = RForestStats(roots)
+    states, tips_states = annotate_synthetic(flat, roots, 'c0', k, 0, missing_frac=0.1, seed=300)
+    observed = np.array([bool(getattr(flat.nodes[t], 'c0', None)) for t in flat.tips])
+    model = RF81(states=states, forest_stats=fs, sf=1.3, frequencies=synthetic.f81_frequencies(k, 0))
+    model.freeze()
+    flat2, cap = sweep_capture(roots, 'c0', model)
+    out = dict(forest_stats_arrays(fs))
+    out['tip_observed'] = observed
+    out.update(model_arrays(model))
+    sample = np.arange(0, flat.n_nodes, 7)
+    out['sample'] = sample
+    for key, v in cap.items():
+        if isinstance(v, np.ndarray) and v.ndim == 2 and len(v) == flat.n_nodes:
+            out[key] = v[sample]
+        else:
+            out[key] = v
+    out['tip_states'] = tips_states
+    out['n_levels'] = n_levels
+
+    # acr() end to end on the same tree: JC (one free parameter) and EFT, MPPA.  The tip states are simulated down the tree
+    # (400 candidate states, three expected changes per unit of branch length), so that the likelihood has an interior
+    # optimum -- states dealt out without phylogenetic signal drive the scaling factor to its bound, where the posteriors of
+    # the deep nodes are equal up to rounding and every choice among them is noise, in the reference as anywhere.
+    import time
+    sim = np.random.default_rng(3000)
+    n_cand, sf_true = 400, 3.0
+    sim_state = np.zeros(flat.n_nodes, dtype=np.int64)
+    for n in range(flat.n_nodes):   # ids are in level order: parents first
+        p = flat.parent[n]
+        if p < 0:
+            sim_state[n] = sim.integers(n_cand)
+        elif sim.random() < np.exp(-sf_true * flat.dist[n]):
+            sim_state[n] = sim_state[p]
+        else:
+            sim_state[n] = sim.integers(n_cand)
+    acr_tip_states = sim_state[np.asarray(flat.tips)]
+    acr_names = synthetic.state_names(n_cand)
+    out['acr_tip_states'] = acr_tip_states
+    out['acr_n_candidates'] = n_cand
+    for model_name in ('JC', 'EFT'):
+        flat3 = synthetic.balanced_forest(n_levels)
+        tree = flat3.to_tree_nodes()[0]
+        tips = [flat3.nodes[t] for t in flat3.tips]
+        df = pd.DataFrame({'c0': [acr_names[acr_tip_states[j]] if observed[j] else None for j in range(len(tips))]},
+                          index=[t.name for t in tips])
+        t0 = time.time()
+        res = racr(tree, df, prediction_method='MPPA', model=model_name, threads=1)[0]
+        print(model_name, 'acr: {:.1f} s, lnL {:.6f}, sf {:.6f}'.format(time.time() - t0, res['log_likelihood'], res['model'].sf))
+        nodes3 = our_tree.FlatForest.from_trees([tree]).nodes
+        pre = 'acr_{}_'.format(model_name)
+        out[pre + 'states'] = np.array(res['states'], dtype=str)
+        out[pre + 'sf'] = float(res['model'].sf)
+        out[pre + 'loglik'] = res['log_likelihood']
+        for m in ('JOINT', 'MAP', 'MPPA'):
+            out[pre + 'loglik_restricted_' + m] = res['log_likelihood_restricted_' + m]
+        out[pre + 'num_unresolved_nodes'] = res['num_unresolved_nodes']
+        out[pre + 'num_states_per_node_avg'] = res['num_states_per_node_avg']
+        mp = res['marginal_probabilities']
+        out[pre + 'posterior'] = mp.loc[[n.name for n in nodes3]].values[sample]
+        s2i = {s: i for i, s in enumerate(res['states'])}
+        sel = np.zeros((len(nodes3), len(s2i)), dtype=np.int8)
+        for i, n in enumerate(nodes3):
+            for st in getattr(n, 'c0'):
+                sel[i, s2i[st]] = 1
+        out[pre + 'selected_mppa'] = sel[sample]
+        out[pre + 'n_selected'] = sel.sum(axis=1)
+        out[pre + 'joint_state'] = collect(nodes3, 'c0_JOINT_STATE', dtype=np.int64)
+    save('synthetic_f81_k300_L10', **out)
+
+
+CASES['f81_k300'] = case_f81_k300
+
+
 HIV1C_SRC = os.path.join(REF, 'examples', 'HIV1C', 'data')
 HIV1C_DST = os.path.join(DATA, 'hiv1c')
 HIV1C_SCRATCH = os.path.join(REPO, 'scratch', 'hiv1c_all')

@@ -551,17 +551,62 @@ def test_fallback_driver_follows_the_main_drivers_rules_for_many_parameters(monk
             assert polished >= main[LOG_LIKELIHOOD] - 1e-9   # (the polish can only raise ln L)
 
 
-def test_more_than_256_states_is_refused_by_name():
-    """The one bound the reference does not have (Limits): the library answers PML_ERR_UNSUPPORTED, acr() says
-    which character it is before doing any work."""
+def test_too_many_states_are_refused_by_name():
+    """The one bound the reference does not have (Limits): the library answers PML_ERR_UNSUPPORTED -- beyond 512
+    states for the F81 family, beyond 256 for an eigen model --, acr() says which character it is before doing any work."""
     flat = FlatForest.balanced(4)
     with pytest.raises(hip.HipError) as e:
         hip.Engine(flat, 1, hip.MAX_STATES + 1)
-    assert e.value.status == hip.PML_ERR_UNSUPPORTED and 'at most 256' in str(e.value)
+    assert e.value.status == hip.PML_ERR_UNSUPPORTED and 'at most 512' in str(e.value)
     with hip.Engine(flat, 1, hip.MAX_STATES) as eng:   # the bound itself works
         eng.set_models([(dict(kind=0, pi=np.ones(hip.MAX_STATES) / hip.MAX_STATES), (1.0, 0.0, 1.0))])
-        eng.set_tip_states(np.arange(flat.n_tips, dtype=np.int32) * 17 % hip.MAX_STATES)
+        eng.set_tip_states(np.arange(flat.n_tips, dtype=np.int32) * 37 % hip.MAX_STATES)
         assert np.isfinite(eng.bottom_up(True)[0])
+    k = hip.MAX_STATES_MATRIX + 1
+    with hip.Engine(flat, 1, k) as eng:
+        with pytest.raises(hip.HipError) as e:
+            eng.set_models([(dict(kind=2, pi=np.ones(k) / k, d=np.zeros(k), A=np.eye(k), Ainv=np.eye(k)), (1.0, 0.0, 1.0))])
+        assert e.value.status == hip.PML_ERR_UNSUPPORTED and 'at most 256' in str(e.value)
+
+
+@pytest.mark.parametrize('model', [JC, EFT])
+def test_acr_with_300_states_matches_reference_run(model):
+    """
+    acr() end to end beyond 256 states (the F81 family: 64 lanes x 8 states, 16-bit arg-max tables) against the reference's
+    own run (tests/golden/make_golden.py::case_f81_k300: balanced 1 024-tip tree, tip states simulated down the tree -- some 300
+    of them at the tips --, a tenth of the tips unannotated, MPPA with the scaling factor optimised).
+    """
+    from pastml_amd import synthetic
+    z = load_golden('synthetic_f81_k300_L10')
+    flat = synthetic.balanced_forest(int(z['n_levels']))
+    tree = flat.to_tree_nodes()[0]
+    tips = [flat.nodes[t] for t in flat.tips]
+    names = synthetic.state_names(int(z['acr_n_candidates']))
+    df = pd.DataFrame({'c0': [names[z['acr_tip_states'][j]] if z['tip_observed'][j] else None for j in range(len(tips))]},
+                      index=[t.name for t in tips])
+    res = acr(tree, df, prediction_method=MPPA, model=model, threads=1)[0]
+    pre = 'acr_{}_'.format(model)
+    assert list(res[STATES]) == list(z[pre + 'states']) and len(res[STATES]) > 256
+    np.testing.assert_allclose(res[LOG_LIKELIHOOD], z[pre + 'loglik'], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(res[MODEL].sf, z[pre + 'sf'], rtol=2e-4)
+    for m in (JOINT, MAP, MPPA):
+        np.testing.assert_allclose(res[RESTRICTED_LOG_LIKELIHOOD_FORMAT_STR.format(m)], z[pre + 'loglik_restricted_' + m],
+                                   rtol=0, atol=1e-4)
+    nodes = FlatForest.from_trees([tree]).nodes
+    s = z['sample']
+    mps = res[MARGINAL_PROBABILITIES]
+    assert list(mps.index) == [n.name for n in nodes]
+    np.testing.assert_allclose(mps.values[s], z[pre + 'posterior'], rtol=0, atol=2e-5)
+    s2i = {st: i for i, st in enumerate(res[STATES])}
+    sel = np.zeros((len(nodes), len(s2i)), dtype=np.int8)
+    for i, n in enumerate(nodes):
+        for st in getattr(n, 'c0'):
+            sel[i, s2i[st]] = 1
+    assert np.array_equal(sel[s], z[pre + 'selected_mppa'])
+    assert np.array_equal(sel.sum(axis=1), z[pre + 'n_selected'])
+    assert np.array_equal([getattr(n, 'c0_JOINT_STATE') for n in nodes], z[pre + 'joint_state'])
+    assert res['num_unresolved_nodes'] == int(z[pre + 'num_unresolved_nodes'])
+    np.testing.assert_allclose(res['num_states_per_node_avg'], z[pre + 'num_states_per_node_avg'])
 
 
 def test_serialised_tables_round_trip(tmp_path):

@@ -28,7 +28,7 @@ def draw_case(seed):
     elif kind == 'EIGEN':
         k = int(rng.choice([3, 7, 16, 17, 20, 21, 24, 26, 29, 32, 33, 40, 48, 53, 61, 64]))
     else:
-        k = int(rng.choice([2, 3, 4, 5, 9, 16, 20, 31, 32, 33, 48, 64, 65, 100, 130]))
+        k = int(rng.choice([2, 3, 4, 5, 9, 16, 20, 31, 32, 33, 48, 64, 65, 100, 130, 257, 300, 512]))
     big = seed % 10 == 0
     n_tips = int(rng.integers(1500, 3000)) if big else int(rng.integers(3, 160))
     if k > 64:

@@ -355,6 +355,49 @@ def test_custom_rates_k61_matches_reference(fused):
         assert np.array_equal(eng.bottom_up(True), lnl)
 
 
+def test_f81_k300_matches_reference():
+    """
+    More than 256 states against the reference itself (tests/golden/make_golden.py::case_f81_k300: pastml's F81Model with 300
+    states on a balanced 1 024-tip tree, a tenth of the tips unannotated): marginal pass, joint sweep with 16-bit arg-max
+    tables + back-trace, MAP / MPPA selection on the device and the restricted likelihoods of the selected masks.
+    """
+    z = load_golden('synthetic_f81_k300_L10')
+    k = 300
+    flat = synthetic.balanced_forest(int(z['n_levels']))
+    masks = synthetic.one_hot_masks(flat, k, z['tip_states'])
+    masks[np.asarray(flat.tips)[~z['tip_observed']]] = 1
+    spec, rates = golden_spec(z)
+    s = z['sample']
+    with hip.Engine(flat, 1, k, keep_td=True) as eng:
+        eng.set_models([(spec, rates)])
+        eng.set_masks(masks[None])
+        lnl = eng.bottom_up(True)
+        np.testing.assert_allclose(lnl[0], z['loglik'], rtol=LNL_RTOL)
+        assert_same_scaled(eng.download(hip.BUF_BU)[s], eng.download(hip.BUF_BU_SF)[s], z['bu'], z['bu_sf'][s], what='BU')
+        post, lh_sum, lh_sf = eng.top_down_marginals()
+        np.testing.assert_allclose(post[0][s], z['posterior'], rtol=POST_RTOL, atol=1e-300)
+        assert_same_scaled(eng.download(hip.BUF_TD)[s], eng.download(hip.BUF_TD_SF)[s], z['td'], z['td_sf'][s], what='TD')
+        assert_same_scaled((post[0] * lh_sum[0][:, None])[s], lh_sf[0][s], z['lh'], z['lh_sf'][s], what='LH')
+        lnl_j = eng.bottom_up(False)
+        np.testing.assert_allclose(lnl_j[0], z['loglik_joint'], rtol=LNL_RTOL)
+        nonroot = flat.parent[s] >= 0
+        assert np.array_equal(eng.download(hip.BUF_JOINT_TABLE)[s][nonroot], z['joint_table'][nonroot])
+        states = eng.joint_backtrace()
+        assert np.array_equal(states[0], z['joint_state'])
+        eng.bottom_up(True)
+        eng.top_down_marginals()
+        sel, nsel = eng.select_states('MAP')
+        assert np.array_equal(sel[0][s], z['masks_map'])
+        np.testing.assert_allclose(eng.bottom_up(True)[0], z['loglik_restricted_MAP'], rtol=LNL_RTOL)
+        eng.set_masks(masks[None])
+        eng.bottom_up(True)
+        eng.top_down_marginals()
+        sel, nsel = eng.select_states('MPPA', force_joint=bool(z['force_joint']))
+        assert np.array_equal(sel[0][s], z['masks_mppa'])
+        assert int((nsel[0] > 1).sum()) == int(z['mppa_num_unresolved']) and int(nsel[0].sum()) == int(z['mppa_num_states'])
+        np.testing.assert_allclose(eng.bottom_up(True)[0], z['loglik_restricted_MPPA'], rtol=LNL_RTOL)
+
+
 def test_cfg3_full_size_matches_reference_sample():
     """
     BASELINE config 3 at full size: 262 144 tips, JTT k=20, one character, joint (Pupko) sweep + back-trace
@@ -1688,6 +1731,63 @@ def test_lean_units_with_masks_of_several_words_have_the_sequential_paths_bits(k
             assert np.array_equal(a, b), 'forest {}'.format(fi)
         ref = orc.bottom_up(flat, masks[1].astype(int), specs[1][0], *specs[1][1])
         np.testing.assert_allclose(results[1][0][1], ref['loglik'], rtol=LNL_RTOL)
+
+@pytest.mark.parametrize('k,n_tips,arity', [(257, 300, 2), (300, 900, 4), (400, 2500, 2), (512, 600, 3)])
+def test_more_than_256_states_match_the_oracle(k, n_tips, arity):
+    """
+    257 - 512 states (round 6; the F81 family): one wavefront per unit with 8 states per lane, masks of five to eight words,
+    16-bit arg-max tables, the plain level schedule -- against the oracle (the reference has no bound on k, pastml/ml.py:134):
+    ln L, the bottom-up and top-down vectors, the marginal pass, the joint sweep with its tables and back-trace; MAP / MPPA
+    selection against the host rules; the fused pass against the separate calls, bit for bit.
+    """
+    from pastml_amd import ml
+    rng = np.random.default_rng(k)
+    flat = FlatForest.random(n_tips, seed=k, max_arity=arity, n_trees=2)
+    C = 2
+    specs = [random_spec('F81', k, rng) for _ in range(C)]
+    rates = [(float(rng.uniform(0.5, 2)), 0.0, 1.0), (float(rng.uniform(0.5, 2)), 0.02, 0.9)]
+    masks = np.stack([random_masks(flat, k, rng, missing=0.1, multi=0.1, internal=0.02) for _ in range(C)])
+    with hip.Engine(flat, C, k, keep_td=True) as eng:
+        eng.set_models(list(zip(specs, rates)))
+        assert eng.sweep_schedule()[0] == hip.SCHEDULE_LEVELS
+        eng.set_masks(masks)
+        lnl = eng.bottom_up(True)
+        post, lh_sum, lh_sf = eng.top_down_marginals()
+        bus = [(eng.download(hip.BUF_BU, c), eng.download(hip.BUF_BU_SF, c)) for c in range(C)]
+        tds = [(eng.download(hip.BUF_TD, c), eng.download(hip.BUF_TD_SF, c)) for c in range(C)]
+        fused = eng.marginal_pass()
+        for a, b in zip(fused, (lnl, post, lh_sum, lh_sf)):
+            assert np.array_equal(a, b)
+        lnl_j = eng.bottom_up(False)
+        tables = [eng.download(hip.BUF_JOINT_TABLE, c) for c in range(C)]
+        states = eng.joint_backtrace()
+        lnl_j2, states2 = eng.joint_pass()
+        assert np.array_equal(lnl_j, lnl_j2) and np.array_equal(states, states2)
+        eng.bottom_up(True)
+        eng.top_down_marginals()
+        for method, fj in (('MAP', False), ('MPPA', False), ('MPPA', True)):
+            sel, nsel = eng.select_states(method, force_joint=fj)
+            for c in range(C):
+                if method == 'MAP':
+                    ref, ref_k = ml.select_map(post[c]), np.ones(flat.n_nodes, dtype=int)
+                else:
+                    ref, ref_k = ml.select_mppa(post[c], states[c].astype(np.int64) if fj else None)
+                assert np.array_equal(sel[c], ref), (method, fj, c)
+                assert np.array_equal(nsel[c], ref_k)
+            eng.set_masks(masks)
+    nonroot = flat.parent >= 0
+    for c in range(C):
+        r = orc.full_marginal_pass(flat, masks[c].astype(int), specs[c], *rates[c])
+        np.testing.assert_allclose(lnl[c], r['loglik'], rtol=LNL_RTOL, atol=1e-12)
+        assert_same_scaled(bus[c][0], bus[c][1], r['bu'], r['bu_sf'], what='BU col {}'.format(c))
+        assert_same_scaled(tds[c][0], tds[c][1], r['td'], r['td_sf'], rows=nonroot, what='TD col {}'.format(c))
+        np.testing.assert_allclose(post[c], r['posterior'], rtol=POST_RTOL, atol=1e-300)
+        tot = np.log10(lh_sum[c]) - lh_sf[c]
+        np.testing.assert_allclose(tot, r['loglik_per_tree'][flat.tree_id] / np.log(10), rtol=1e-11, atol=1e-12)
+        j = orc.bottom_up(flat, masks[c].astype(int), specs[c], *rates[c], is_marginal=False)
+        np.testing.assert_allclose(lnl_j[c], j['loglik'], rtol=LNL_RTOL, atol=1e-12)
+        assert np.array_equal(tables[c][nonroot], j['joint_table'][nonroot])
+        assert np.array_equal(states[c], orc.joint_backtrace(flat, j['bu'], j['joint_table'], specs[c]['pi']))
 
 
 @pytest.mark.parametrize('k', [2, 4, 7, 12, 16])

@@ -571,18 +571,22 @@ def test_library_fd_points_are_numpys():
     assert len(block) == 2 and np.array_equal(block.pi, np.full((2, 3), 1 / 3)) and block.sf[0] == 1.5
 
 
-def test_acr_names_a_character_with_more_than_256_states():
-    """Boundary difference to the reference (no bound on k there): said up front, by name, before any device work."""
+def test_acr_names_a_character_with_too_many_states():
+    """Boundary difference to the reference (no bound on k there): said up front, by name, before any device work -- 512 states
+    for the F81 family, 256 for the models with a transition matrix per branch."""
     import pandas as pd
     from pastml_amd import acr as acr_module, hip
     from pastml_amd.tree import read_tree as read_newick
-    assert acr_module.MAX_STATES == hip.MAX_STATES == 256
-    n = 300
+    assert acr_module.MAX_STATES == hip.MAX_STATES == 512 and acr_module.MAX_STATES_MATRIX == hip.MAX_STATES_MATRIX == 256
+    n = 600
     tree = read_newick('(' + ','.join('t{}:1'.format(i) for i in range(n)) + ');')
     df = pd.DataFrame({'wide': ['s{:03d}'.format(i) for i in range(n)], 'ok': ['a', 'b'] * (n // 2)},
                       index=['t{}'.format(i) for i in range(n)])
-    with pytest.raises(ValueError, match='wide has 300 states.*at most 256'):
+    with pytest.raises(ValueError, match='wide has 600 states.*at most 512'):
         acr_module.acr(tree, df, prediction_method='MPPA', model='F81')
+    df300 = pd.DataFrame({'wide': ['s{:03d}'.format(i % 300) for i in range(n)]}, index=['t{}'.format(i) for i in range(n)])
+    with pytest.raises(ValueError, match='wide has 300 states.*at most 256.*CUSTOM_RATES'):
+        acr_module.acr(tree, df300, prediction_method='MPPA', model='CUSTOM_RATES', column2rates={'wide': os.devnull})
 
 
 def test_value2list_broadcasts_like_the_reference():

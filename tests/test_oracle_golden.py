@@ -167,6 +167,40 @@ def test_custom_rates_k61_sample():
     assert np.array_equal(orc.joint_backtrace(flat, j['bu'], j['joint_table'], spec['pi']), z['joint_state'])
 
 
+def _k300_inputs(z):
+    from pastml_amd import synthetic
+    k = 300
+    flat = synthetic.balanced_forest(int(z['n_levels']))
+    masks = synthetic.one_hot_masks(flat, k, z['tip_states'])
+    masks[np.asarray(flat.tips)[~z['tip_observed']]] = 1   # unannotated tips: every state allowed (pastml/ml.py:415-432)
+    return flat, masks
+
+
+def test_f81_k300_sample():
+    """
+    synthetic_f81_k300_L10 (the reference's F81Model with 300 states -- beyond one byte of state index -- on a balanced
+    1 024-tip tree with unannotated tips, tests/golden/make_golden.py::case_f81_k300): the oracle's marginal pass, joint sweep
+    and MAP / MPPA choices against the reference's scalars, its joint states on every node and its vectors at every 7th.
+    """
+    z = load_golden('synthetic_f81_k300_L10')
+    flat, masks = _k300_inputs(z)
+    s = z['sample']
+    assert np.array_equal(masks[s], z['masks_altered'])
+    spec, (sf, tau, tf) = golden_spec(z)
+    r = orc.full_marginal_pass(flat, masks.astype(int), spec, sf, tau, tf)
+    np.testing.assert_allclose(r['loglik'], z['loglik'], rtol=1e-12)
+    np.testing.assert_allclose(r['posterior'][s], z['posterior'], rtol=1e-9, atol=1e-300)
+    j = orc.bottom_up(flat, masks.astype(int), spec, sf, tau, tf, False)
+    np.testing.assert_allclose(j['loglik'], z['loglik_joint'], rtol=1e-12)
+    nonroot = flat.parent[s] >= 0
+    assert np.array_equal(j['joint_table'][s][nonroot], z['joint_table'][nonroot])
+    states = orc.joint_backtrace(flat, j['bu'], j['joint_table'], spec['pi'])
+    assert np.array_equal(states, z['joint_state'])
+    assert np.array_equal(orc.choose_map(r['lh'])[s], z['masks_map'].argmax(axis=1)) and np.all(z['masks_map'].sum(axis=1) == 1)
+    mppa_masks, _ = orc.choose_mppa(r['lh'][s], states[s] if bool(z['force_joint']) else None)
+    assert np.array_equal(mppa_masks, z['masks_mppa'])
+
+
 def _cfg4_character(levels, c):
     from pastml_amd import synthetic
     flat = synthetic.balanced_forest(levels)
