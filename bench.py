@@ -730,6 +730,7 @@ def secondary_measurements(device):
     # ---- a codon-sized eigen model: CUSTOM_RATES, k = 61, sum sweeps fused (two matrix-core GEMMs per 16
     #      nodes, constant operands in LDS) against the generic path (P(t) of every branch materialised in HBM)
     out['eigen_k61'] = eigen_k61_measurement(device)
+    out['eigen_k128'] = eigen_wide_measurement(device)
     # ---- an optimisation of an eigen model with free frequencies: CUSTOM_RATES, k = 20, on the HIV1C
     #      tree -- every point of every finite-difference gradient needs its own eigendecomposition on the host
     #      (CustomRatesModel.py:62-68); host / device split, batched diagonalisation against one per point
@@ -837,7 +838,10 @@ def eigen_k61_measurement(device, levels=16, k=61, C=4, compare=1):
     tips = np.stack([synthetic.tip_states(flat.n_tips, k, c) for c in range(C)])
     ks = k + (k & 1)
     res = {}
-    for label, tune in (('fused', {}), ('materialised', dict(NO_EIGEN_GEMM=1, NO_EIGEN_JOINT_VALU=1)))[:2 if compare else 1]:
+    # (materialised: round 5's path for every k > 32 -- P(t) of every branch built by the one-thread-per-entry kernel, NO_PIJ_WIDE;
+    # materialised_wide: the same sweeps behind round 6's matrix-core P(t) batch, what 65 <= k <= 256 run today)
+    for label, tune in (('fused', {}), ('materialised', dict(NO_EIGEN_GEMM=1, NO_EIGEN_JOINT_VALU=1, NO_PIJ_WIDE=1)),
+                        ('materialised_wide', dict(NO_EIGEN_GEMM=1, NO_EIGEN_JOINT_VALU=1)))[:3 if compare else 1]:
         with hip.Engine(flat, C, k, device=device, tune=tune) as eng:
             eng.set_tip_states(tips)
 
@@ -880,6 +884,8 @@ def eigen_k61_measurement(device, levels=16, k=61, C=4, compare=1):
                          'branch in HBM ({:.1f} GB), the path of every k > 32 before round 6'
                          .format(k, flat.n_tips, flat.n_nodes, C, flat.n_nodes * C * k * ks * 8 / 1e9),
                 ms_marginal_pass=ms, ms_bottom_up_sweep=f['ms_bottom_up'], ms_marginal_pass_materialised=g['ms_marginal'],
+                ms_marginal_pass_materialised_wide_pij=res.get('materialised_wide', {}).get('ms_marginal'),
+                ms_joint_sweep_materialised_wide_pij=res.get('materialised_wide', {}).get('ms_joint'),
                 speedup_marginal=g['ms_marginal'] / ms,
                 speedup_joint=(g['ms_joint'] / f['ms_joint']) if f.get('ms_joint') and g.get('ms_joint') else None,
                 ms_joint_sweep=f['ms_joint'], ms_joint_sweep_materialised=g.get('ms_joint'),
@@ -891,6 +897,59 @@ def eigen_k61_measurement(device, levels=16, k=61, C=4, compare=1):
                               mfma_frac=flops / (ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
                               byte_model='9 vectors of {} B per node and column (BU: vector + message written, message read; '
                                          'TD: parent TD + BU, own BU + message read, TD + posterior written)'.format(int(vec))))
+
+
+def eigen_wide_measurement(device, levels=14, k=128, C=4):
+    """P(t) batch and marginal pass of an eigen model beyond 64 states (P(t) of every branch in HBM): round 6's matrix-core
+    batch (pij_eigen_wide_kernel) and, once, the one-thread-per-entry kernel it replaced."""
+    from pastml_amd import hip, synthetic
+    from pastml_amd.models._eigen import get_diagonalisation
+    flat = synthetic.balanced_forest(levels)
+    rng = np.random.default_rng(k)
+    rates = np.triu(rng.uniform(0.05, 3.0, size=(k, k)), 1)
+    rates = rates + rates.T
+    specs = []
+    for c in range(C):
+        pi = rng.dirichlet(np.ones(k) * 4)
+        d, a, ainv = get_diagonalisation(pi, rates)
+        specs.append((dict(kind=2, pi=pi, d=d, A=a, Ainv=ainv), (1.0, 0.0, 1.0)))
+    tips = np.stack([synthetic.tip_states(flat.n_tips, k, c) for c in range(C)])
+    res = {}
+    for label, tune, reps in (('wide', {}, 5), ('round5', dict(NO_PIJ_WIDE=1), 1)):
+        with hip.Engine(flat, C, k, device=device, tune=tune) as eng:
+            eng.set_tip_states(tips)
+
+            def batch():
+                eng.set_models(specs)
+                eng.pij_batch(copy_out=False)
+
+            def marginal():
+                eng.set_models(specs)
+                return eng.marginal_pass(posterior=False, lh=False)[0]
+            out = {}
+            for name, fn in (('pij', batch), ('marginal', marginal)):
+                lnl = fn()
+                eng.sync()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    fn()
+                eng.sync()
+                out['ms_' + name] = (time.perf_counter() - t0) / reps * 1e3
+            out['lnl'] = [float(v) for v in lnl]
+            res[label] = out
+    w, g = res['wide'], res['round5']
+    flops = 2.0 * k ** 3 * flat.n_nodes * C
+    ks = k + (k & 1)
+    return dict(workload='CUSTOM_RATES-shaped eigen model, k = {} states, balanced {}-tip tree ({} branches), {} characters: P(t) of '
+                         'every branch ({:.1f} GB) on the FP64 matrix cores, A^T in LDS slices (pml_kernels_pij_wide.h), and the '
+                         'marginal pass that reads it'.format(k, flat.n_tips, flat.n_nodes, C, flat.n_nodes * C * k * ks * 8 / 1e9),
+                ms_pij_batch=w['ms_pij'], ms_marginal_pass=w['ms_marginal'], ms_pij_batch_round5=g['ms_pij'],
+                ms_marginal_pass_round5=g['ms_marginal'], speedup_pij_batch=g['ms_pij'] / w['ms_pij'],
+                speedup_marginal=g['ms_marginal'] / w['ms_marginal'],
+                max_rel_loglik_difference=max(abs(a - b) / abs(b) for a, b in zip(w['lnl'], g['lnl'])),
+                roofline=dict(bound='mfma', achieved=flops / (w['ms_pij'] * 1e-3) / 1e12, peak=FP64_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
+                              frac=flops / (w['ms_pij'] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                              flop_model='2 k^3 per branch and character'))
 
 
 def custom_rates_optimisation(nwk, k=20):

@@ -1946,6 +1946,8 @@ static int run_prep(pml_ctx* ctx, bool force = false) {
             PML_TRY(launch_pij_valu(ctx));   // vector-unit path, pml_launch_eigen_joint.hip
         } else if (ctx->k >= 16 && ctx->k <= 32 && !ctx->tune.on(T_NO_MFMA)) {
             PML_TRY(launch_pij_mfma(ctx));   // FP64 matrix-core path, pml_launch_eigen_mfma.hip
+        } else if (ctx->k > 32 && !ctx->tune.on(T_NO_MFMA) && !ctx->tune.on(T_NO_PIJ_WIDE)) {
+            PML_TRY(launch_pij_wide(ctx));   // the same beyond 32 states: A^T in LDS slices
         } else {
             const int k = ctx->k;
             size_t lds = ((size_t)2 * k * (k + 1) + k) * sizeof(double);

@@ -132,6 +132,7 @@ PML_INTERNAL int launch_eigen_fused(pml_ctx* ctx, int mode, const int* nodes, in
 PML_INTERNAL int launch_eigen_narrow(pml_ctx* ctx, int mode, const int* nodes, const int* d_offsets, int first_level, int n_levels);
 PML_INTERNAL int launch_eigen_tips(pml_ctx* ctx, int joint);
 PML_INTERNAL int launch_pij_mfma(pml_ctx* ctx);
+PML_INTERNAL int launch_pij_wide(pml_ctx* ctx);
 // ---- pml_launch_eigen_gemm.hip: sum sweeps as two small GEMMs per 16 nodes
 PML_INTERNAL int launch_eigen_gemm(pml_ctx* ctx, int mode, const int* nodes, int first, int n);
 PML_INTERNAL int launch_eigen_gemm_narrow(pml_ctx* ctx, int mode, const int* nodes, const int* d_offsets, int first_level,

@@ -2,6 +2,7 @@
 // the matrix cores.
 #include "pml_launch.h"
 #include "pml_kernels_eigen_mfma.h"
+#include "pml_kernels_pij_wide.h"
 
 // fused eigen sweeps: one launch over a list (nodes) or a contiguous id range (first) of n nodes
 int launch_eigen_fused(pml_ctx* ctx, int mode, const int* nodes, int first, int n, int tips) {
@@ -106,6 +107,33 @@ int launch_eigen_tips(pml_ctx* ctx, int joint) {
     return fail(PML_ERR_UNSUPPORTED, "no fused eigen kernel for k = %d", k);
 }
 
+
+
+// P(t) of every branch on the FP64 matrix cores beyond 32 states: A^T in LDS slices (pml_kernels_pij_wide.h)
+int launch_pij_wide(pml_ctx* ctx) {
+    const PmlTree t = tree_of(ctx);
+    const PmlCols c = cols_of(ctx);
+    const PmlModel m = model_of(ctx);
+    const int k = ctx->k;
+    const int ntc = pijw_tiles(k, ctx->ks);
+    const size_t lds = pijw_lds_bytes(k, ntc);
+    // a workgroup per CU (LDS); several rounds of workgroups so that the tail is short, every wave with a branch of its own
+    int blocks = std::max(1, (int)ctx->tune.get(T_PIJ_BLOCKS, 1024) / std::max(1, ctx->C));
+    blocks = std::min(blocks, (ctx->N + PML_PIJW_WAVES - 1) / PML_PIJW_WAVES);
+    const int bpb = (ctx->N + blocks - 1) / blocks;
+    dim3 grid((ctx->N + bpb - 1) / bpb, ctx->C);
+#define PML_PIJW_CASE(NTC_)                                                                                          \
+    if (ntc == NTC_) {                                                                                               \
+        HIP_TRY(hipFuncSetAttribute((const void*)pij_eigen_wide_kernel<NTC_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                    (int)lds));                                                                      \
+        hipLaunchKernelGGL((pij_eigen_wide_kernel<NTC_>), grid, dim3(PML_PIJW_BLOCK), lds, ctx->stream, t, c, m, ctx->d_P, bpb); \
+    }
+    PML_PIJW_CASE(1) PML_PIJW_CASE(2) PML_PIJW_CASE(3) PML_PIJW_CASE(4)
+    PML_PIJW_CASE(5) PML_PIJW_CASE(6) PML_PIJW_CASE(7) PML_PIJW_CASE(8)
+#undef PML_PIJW_CASE
+    HIP_TRY(hipGetLastError());
+    return PML_OK;
+}
 
 
 // P(t) of every branch on the FP64 matrix cores, 16 <= k <= 32 (run_prep)

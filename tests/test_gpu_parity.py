@@ -71,6 +71,28 @@ def test_pij_batch_kernels_agree(k):
     np.testing.assert_allclose(got['valu'], got['other'], rtol=1e-11, atol=5e-15)
 
 
+@pytest.mark.parametrize('k', [33, 40, 48, 61, 64, 67, 100, 128, 130, 200, 255, 256])
+def test_pij_batch_beyond_32_states(k):
+    """The P(t) batch of an eigen model with more than 32 states: the matrix-core kernel with A^T in LDS slices
+    (pij_eigen_wide_kernel: one slice up to 128 states, two to four beyond; odd k pads its rows to an even stride, the last
+    row and column tiles are partial) against the oracle's A diag(exp(d t)) A^-1 (pastml/models/generator.py:54-65) and against
+    the one-thread-per-entry kernel it replaces (NO_PIJ_WIDE), rounding only; a forest with zero-length branches whose node
+    count is not a multiple of the waves per workgroup, two columns with different rates."""
+    rng = np.random.default_rng(k)
+    flat = FlatForest.random(101 if k > 128 else 333, seed=k, max_arity=3, zero_frac=0.1, n_trees=2)
+    specs = [(random_spec('EIGEN', k, rng), (float(rng.uniform(0.5, 3)), 0.0, 1.0)) for _ in range(2)]
+    got = {}
+    for name, tune in (('wide', {}), ('generic', dict(NO_PIJ_WIDE=1))):
+        with hip.Engine(flat, 2, k, tune=tune) as eng:
+            eng.set_models(specs)
+            got[name] = eng.pij_batch(copy_out=True)
+    for col, (spec, rates) in enumerate(specs):
+        ref = np.array([orc.pij(spec, t, *rates) for t in flat.dist])
+        for name in got:
+            np.testing.assert_allclose(got[name][col], ref, rtol=1e-10, atol=1e-14, err_msg='{} k={}'.format(name, k))
+    np.testing.assert_allclose(got['wide'], got['generic'], rtol=1e-10, atol=1e-14)
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 def test_pij_matches_reference():
     z = load_golden('pij')
