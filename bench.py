@@ -900,8 +900,9 @@ def eigen_k61_measurement(device, levels=16, k=61, C=4, compare=1):
 
 
 def eigen_wide_measurement(device, levels=14, k=128, C=4):
-    """P(t) batch and marginal pass of an eigen model beyond 64 states (P(t) of every branch in HBM): round 6's matrix-core
-    batch (pij_eigen_wide_kernel) and, once, the one-thread-per-entry kernel it replaced."""
+    """An eigen model beyond 64 states: the marginal pass with the sum sweeps fused (two matrix-core GEMMs per 16 nodes, ONE matrix
+    in LDS: a reversible model's A^-1 is A transposed and rescaled), on P(t) of every branch in HBM built by round 6's matrix-core
+    batch (pij_eigen_wide_kernel), and on P(t) built by the one-thread-per-entry kernel of rounds 1 - 5 (once)."""
     from pastml_amd import hip, synthetic
     from pastml_amd.models._eigen import get_diagonalisation
     flat = synthetic.balanced_forest(levels)
@@ -915,7 +916,8 @@ def eigen_wide_measurement(device, levels=14, k=128, C=4):
         specs.append((dict(kind=2, pi=pi, d=d, A=a, Ainv=ainv), (1.0, 0.0, 1.0)))
     tips = np.stack([synthetic.tip_states(flat.n_tips, k, c) for c in range(C)])
     res = {}
-    for label, tune, reps in (('wide', {}, 5), ('round5', dict(NO_PIJ_WIDE=1), 1)):
+    for label, tune, reps in (('fused', {}, 5), ('pij_wide', dict(NO_EIGEN_GEMM=1), 5),
+                              ('round5', dict(NO_EIGEN_GEMM=1, NO_PIJ_WIDE=1), 1)):
         with hip.Engine(flat, C, k, device=device, tune=tune) as eng:
             eng.set_tip_states(tips)
 
@@ -937,19 +939,22 @@ def eigen_wide_measurement(device, levels=14, k=128, C=4):
                 out['ms_' + name] = (time.perf_counter() - t0) / reps * 1e3
             out['lnl'] = [float(v) for v in lnl]
             res[label] = out
-    w, g = res['wide'], res['round5']
+    f, w, g = res['fused'], res['pij_wide'], res['round5']
     flops = 2.0 * k ** 3 * flat.n_nodes * C
     ks = k + (k & 1)
-    return dict(workload='CUSTOM_RATES-shaped eigen model, k = {} states, balanced {}-tip tree ({} branches), {} characters: P(t) of '
-                         'every branch ({:.1f} GB) on the FP64 matrix cores, A^T in LDS slices (pml_kernels_pij_wide.h), and the '
-                         'marginal pass that reads it'.format(k, flat.n_tips, flat.n_nodes, C, flat.n_nodes * C * k * ks * 8 / 1e9),
-                ms_pij_batch=w['ms_pij'], ms_marginal_pass=w['ms_marginal'], ms_pij_batch_round5=g['ms_pij'],
-                ms_marginal_pass_round5=g['ms_marginal'], speedup_pij_batch=g['ms_pij'] / w['ms_pij'],
-                speedup_marginal=g['ms_marginal'] / w['ms_marginal'],
-                max_rel_loglik_difference=max(abs(a - b) / abs(b) for a, b in zip(w['lnl'], g['lnl'])),
-                roofline=dict(bound='mfma', achieved=flops / (w['ms_pij'] * 1e-3) / 1e12, peak=FP64_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
-                              frac=flops / (w['ms_pij'] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
-                              flop_model='2 k^3 per branch and character'))
+    return dict(workload='CUSTOM_RATES-shaped eigen model, k = {} states, balanced {}-tip tree ({} branches), {} characters, model upload '
+                         'included.  marginal pass: sum sweeps fused (pml_kernels_eigen_gemm.h, one matrix in LDS) / on P(t) of every '
+                         'branch in HBM ({:.1f} GB) built on the FP64 matrix cores (pml_kernels_pij_wide.h) / the same built by the '
+                         'per-entry kernel of rounds 1 - 5'.format(k, flat.n_tips, flat.n_nodes, C, flat.n_nodes * C * k * ks * 8 / 1e9),
+                ms_marginal_pass=f['ms_marginal'], ms_marginal_pass_pij_in_hbm=w['ms_marginal'], ms_marginal_pass_round5=g['ms_marginal'],
+                ms_pij_batch=w['ms_pij'], ms_pij_batch_round5=g['ms_pij'], speedup_pij_batch=g['ms_pij'] / w['ms_pij'],
+                speedup_marginal_vs_round5=g['ms_marginal'] / f['ms_marginal'],
+                speedup_marginal_vs_pij_in_hbm=w['ms_marginal'] / f['ms_marginal'],
+                max_rel_loglik_difference=max(max(abs(a - b) / abs(b) for a, b in zip(x['lnl'], g['lnl'])) for x in (f, w)),
+                value=flat.n_nodes * k * C / (f['ms_marginal'] * 1e-3), unit='node*state*char/s',
+                roofline_pij_batch=dict(bound='mfma', achieved=flops / (w['ms_pij'] * 1e-3) / 1e12, peak=FP64_MFMA_PEAK_TFLOPS,
+                                        unit='TFLOP/s', frac=flops / (w['ms_pij'] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                                        flop_model='2 k^3 per branch and character'))
 
 
 def custom_rates_optimisation(nwk, k=20):

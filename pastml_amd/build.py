@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(CSRC, 'build')
 LIB = os.path.join(HERE, 'libpastml_hip.so')
 SOURCES = ['pml_launch_f81_level.hip', 'pml_launch_f81_wide.hip', 'pml_launch_f81_small.hip', 'pml_launch_f81_blocks.hip', 'pml_launch_f81_super.hip',
-           'pml_launch_matrix.hip', 'pml_launch_eigen_mfma.hip', 'pml_launch_eigen_gemm.hip', 'pml_launch_eigen_joint.hip', 'pml_api.hip']
+           'pml_launch_matrix.hip', 'pml_launch_eigen_mfma.hip', 'pml_launch_eigen_gemm.hip', 'pml_launch_eigen_gemm_wide.hip', 'pml_launch_eigen_joint.hip', 'pml_api.hip']
 HEADERS = ['pml_device.h', 'pml_kernels_f81.h', 'pml_kernels_misc.h', 'pml_model.h', 'pml_kernels_matrix.h', 'pml_kernels_pij.h', 'pml_kernels_pij_wide.h',
            'pml_kernels_counts.h',
            'pml_kernels_eigen_mfma.h', 'pml_kernels_eigen_gemm.h', 'pml_kernels_eigen_joint.h', 'pml_comm.h', 'pml_host.h',

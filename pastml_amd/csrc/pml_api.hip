@@ -3,6 +3,7 @@
 #define PML_PLAIN_KERNELS   // the kernels that are not templates are this unit's (pml_device.h, PML_GLOBAL)
 #include "pml_launch.h"
 #include "pml_kernels_counts.h"
+#include "pml_kernels_eigen_gemm.h"   // (eig_sym_kernel)
 #include "pml_comm.h"
 
 // sha256 (first 16 hex digits) over the sources this library was compiled from, handed in by pastml_amd/build.py; the
@@ -1626,6 +1627,8 @@ int pml_chars_alloc(pml_ctx* ctx, int32_t n_cols, int32_t k) {
         HIP_TRY(hipGetLastError());
     }
     ctx->model_set.assign(n_cols, 0);
+    ctx->eig_sym.assign(n_cols, 0);
+    ctx->eig_sym_all = false;
     ctx->tips_observed.assign(n_cols, 0);
     ctx->prep_dirty = true;
     ctx->bu_mode = -1;
@@ -1878,6 +1881,45 @@ int pml_model_set_eigen(pml_ctx* ctx, int32_t col_begin, int32_t col_end, const 
     PML_TRY(upload(ctx, ctx->d_d + col_begin * k, d, nc * k));
     PML_TRY(upload(ctx, ctx->d_A + col_begin * k * k, A, nc * k * k));
     PML_TRY(upload(ctx, ctx->d_Ainv + col_begin * k * k, Ainv, nc * k * k));
+    if (k > 64 && k <= 128) {
+        // More than 64 states: the sum sweeps keep ONE matrix in LDS (pml_kernels_eigen_gemm.h, EigGemm::SYM), which needs
+        //   Ainv[m][j] = c_m A[j][m] pi[j],  c_m = 1 / sum_j pi[j] A[j][m]^2
+        // -- true of a reversible model's eigenvectors (generator.py:33-51 builds nothing else) unless an eigenvalue repeats and
+        // numpy left its eigenvectors far from orthogonal.  Checked entry by entry on what was handed in (to 1e-8: what is left
+        // below that is numpy's rounding, which eig_sym_kernel's Newton-Schulz step removes); the sweeps of a ctx with a column
+        // that fails read materialised P(t).
+        if (!ctx->d_Asym) {
+            PML_TRY(dev_alloc(ctx, &ctx->d_Asym, (size_t)ctx->C * k * k));
+            PML_TRY(dev_alloc(ctx, &ctx->d_eigT, (size_t)ctx->C * k * k));
+        }
+        for (int c = 0; c < nc; ++c) {
+            const double *Ac = A + (size_t)c * k * k, *Bc = Ainv + (size_t)c * k * k, *pc = pi + (size_t)c * k;
+            bool ok = true;
+            for (size_t j = 0; j < k; ++j) ok = ok && pc[j] > 0.0;
+            for (size_t mm = 0; mm < k && ok; ++mm) {
+                double g = 0.0, big = 0.0;
+                for (size_t j = 0; j < k; ++j) {
+                    g += pc[j] * Ac[j * k + mm] * Ac[j * k + mm];
+                    big = std::max(big, std::fabs(Bc[mm * k + j]));
+                }
+                const double cm = 1.0 / g;
+                if (!(g > 0.0) || !std::isfinite(cm)) ok = false;
+                for (size_t j = 0; j < k && ok; ++j)
+                    if (!(std::fabs(Bc[mm * k + j] - cm * Ac[j * k + mm] * pc[j]) <= 1e-8 * big)) ok = false;
+            }
+            ctx->eig_sym[col_begin + c] = ok ? 1 : 0;
+        }
+        PML_TRY(params_push(ctx));   // (the kernel reads the frequencies from the parameter block)
+        HIP_TRY(hipFuncSetAttribute((const void*)eig_sym_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)((k * (k + 1) + k) * sizeof(double))));
+        hipLaunchKernelGGL(eig_sym_kernel, dim3(nc), dim3(PML_BLOCK), (k * (k + 1) + k) * sizeof(double), ctx->stream, (int)k,
+                           ctx->ks, (int)col_begin, ctx->d_A, cols_of(ctx).pi, ctx->d_eigT, ctx->d_Asym);
+        HIP_TRY(hipGetLastError());
+        bool all = true;
+        for (int i = 0; i < ctx->C; ++i) all = all && (ctx->eig_sym[i] != 0 || !ctx->model_set[i]);
+        if (all != ctx->eig_sym_all) drop_sweep_graphs(ctx);   // the sweeps change kernels
+        ctx->eig_sym_all = all;
+    }
     std::vector<double> at, a_t;
     if (k <= 64) {
         // transposed, zero-padded copies: A^-1 for the joint sweep on the vector units (k <= 32: its rows through the scalar cache) and

@@ -253,6 +253,10 @@ struct pml_ctx {
     int n_active = 0;             // columns that take part in the next sweep
     int sched_cols = 0;           // the number of columns the schedule of a sweep is chosen for (C; 32 for a few active ones)
     bool bu_signals_few = false;
+    double* d_Asym = nullptr;   // [C][k][k], 65 <= k <= 128: the one matrix of the sum sweeps (eig_sym_kernel)
+    double* d_eigT = nullptr;   // [C][k][k]: scratch of that kernel
+    std::vector<char> eig_sym;  // per column: the identity holds for the matrices pml_model_set_eigen was given
+    bool eig_sym_all = false;   // ... for every column: the sum sweeps of 65 - 128 states keep one matrix in LDS
     double* d_AinvT = nullptr;  // [C][ld][ld], ld = 32 (k <= 32) or 64 (k <= 64): Ainv transposed and zero-padded -- eigen_joint_kernel (k <= 32), eigen_gemm_kernel's observed tips
     double* d_AT = nullptr;     // [C][32][32]: A transposed and zero-padded (k <= 32), for pij_eigen_valu_kernel
     double *d_sf = nullptr, *d_tau = nullptr, *d_tauf = nullptr;
@@ -496,6 +500,7 @@ static PmlModel model_of(const pml_ctx* c) {
     m.A = c->d_A;
     m.Ainv = c->d_Ainv;
     m.AinvT = c->d_AinvT;
+    m.Asym = c->d_Asym;
     m.ldT = c->k <= PML_EIGJ_STRIDE ? PML_EIGJ_STRIDE : 64;
     m.sf = c->d_sf;
     m.tau = c->d_tau;

@@ -1,4 +1,4 @@
-// Eigen models (CUSTOM_RATES, JTT), 2 <= k <= 64: the SUM sweeps (marginal bottom-up, top-down) without ever forming
+// Eigen models (CUSTOM_RATES, JTT), 2 <= k <= 128: the SUM sweeps (marginal bottom-up, top-down) without ever forming
 // P(t).  Both apply P(t_n) = A diag(exp(d t_n)) A^-1 of the branch above a node n to ONE vector of that node
 //   bottom-up  (ml.py:124-148)   msg_n = P v_n        v_n = mask o prod of the children's messages
 //   top-down   (ml.py:273-290)   td_n  = P x_n        x_n = TD_p o BU_p / msg_n
@@ -22,6 +22,20 @@
 // from 17 states on -- the registers it frees are a wave more per SIMD (65 536 tips x 32 columns, marginal pass: k = 32
 // 2.75 -> 2.29 ms, k = 24 1.97 -> 1.81, k = 20 1.76 -> 1.67; no difference at 16 states and below).
 //
+// More than 64 states (round 6, up to 128): both operands in LDS would be 2 x 128 KB.  The models this library is handed are
+// reversible (pastml/models/generator.py:33-51: Q[i][j] = r[i][j] pi[j] with symmetric r), so Pi^1/2 Q Pi^-1/2 is symmetric,
+// its eigenvectors U = Pi^1/2 A (columns normalised) are orthonormal and
+//     P(t) = As diag(exp(d t)) As^T Pi,     As = Pi^-1/2 U:
+// ONE matrix serves both products -- the first reads it transposed, pi goes into the vector before it (EigGemm<KS>::SYM,
+// KS > 16).  The copy in LDS is a plain [4 KS][4 KS + 1] array (an odd row stride: the 16 rows, or the 16 columns, of an operand
+// tile fall into different banks either way).  numpy's eigenvectors (a general, not a symmetric solver: generator.py:16-30) are
+// orthonormal to 1e-12 only, and 1e-12 of inconsistency between the two products is 1e-9 on the entries of P(t) v that are
+// t q[i][j] small: eig_sym_kernel makes As from A with one Newton-Schulz step U <- U (3 I - U^T U) / 2 (orthonormal to 1e-15;
+// the step moves the eigenvectors by what numpy's error already was), after which the sweeps agree with those on the
+// reference's P(t) to 7e-11.  pml_model_set_eigen checks on what it is handed that A^-1 IS A transposed and rescaled, entry by
+// entry; the sweeps of a model where it is not (a repeated eigenvalue, whose eigenvectors numpy leaves far from orthogonal)
+// read materialised P(t) as before.
+//
 // Rounding: P v is evaluated in a different order than the reference's (P built, then applied).  Both carry an
 // absolute error of a few ulps of |A| |A^-1| |v| (cond(A) = 2 for JTT); messages are bounded below by
 // min_j P[i][j] max v, so relative errors stay ~1e-11 (tests: 1e-9 on posteriors, 1e-11 on ln L).
@@ -43,7 +57,13 @@ struct EigGemm {
     // (measured: KS consecutive states per lane -- every lane in a line of its own -- lost 25 %; profiles/r06g_eigen_sweeps.txt).
     static constexpr bool PAIRS = KS % 2 == 0;
     static __device__ __forceinline__ int st(int s, int hi) { return PAIRS ? 8 * (s >> 1) + 2 * hi + (s & 1) : 4 * s + hi; }
-    static constexpr int LDS_DOUBLES = LDS ? 2 * MT * KS * 64 : 0;
+    // more than 64 states: one matrix, A, as a plain [KP][LD] array; the first product reads it transposed (see above)
+    static constexpr bool SYM = KS > 16;
+    static constexpr int LD = KP + 1;
+    static constexpr int LDS_DOUBLES = SYM ? KP * LD : (LDS ? 2 * MT * KS * 64 : 0);
+    static constexpr int CST_DOUBLES = 8 * KS;   // d, pi of the column, zero beyond k
+    // the part of an operand's LDS address that does not depend on the lane (SYM; pairs: even KS only)
+    static __device__ __forceinline__ int cs(int s) { return 8 * (s >> 1) + (s & 1); }
 };
 
 // per-node reductions over the four lanes (lo, lo + 16 q) that share a node
@@ -90,18 +110,21 @@ struct EigGemmWave {
     // (registers for k <= 32; one element each when the operands are in LDS: la1 / la2 point at the lane's entries there)
     double a1[EigGemm<KS>::LDS ? 1 : EigGemm<KS>::MT][EigGemm<KS>::LDS ? 1 : KS];
     double a2[EigGemm<KS>::LDS ? 1 : EigGemm<KS>::MT][EigGemm<KS>::LDS ? 1 : KS];
-    const double* lds;   // the block's copy of the operands: [2][MT][KS][64]
+    const double* lds;   // the block's copy of the operands: [2][MT][KS][64]; SYM: A as [KP][LD]
     const double* ainvT; // the column's transposed A^-1 in memory (observed tips), rows ldT apart; null if there is none
     int ldT;
-    const double* cst;   // LDS: the column's eigenvalues d [4 KS] and frequencies pi [4 KS], zero beyond k (read when needed:
-                         // as per-lane registers they cost 64 VGPRs through both products)
+    const double* cst;   // LDS: the column's eigenvalues d [4 KS] and frequencies pi [4 KS], zero beyond k
+                         // (read when needed: as per-lane registers they cost 64 VGPRs through both products)
     double sfc, tau, tf;
+    int b1, b2;          // SYM: the lane's part of the operands' addresses -- first product (A read transposed), second product
     // `at`: the lane's offset, made opaque once per pass (eig_gemm_pass) -- the operands are the same in every pass and the
     // compiler would otherwise hoist all 2 MT KS reads out of the node loop, back into 256 registers
     __device__ __forceinline__ double op1(int mt, int s, int at) const {
+        if (EigGemm<KS>::SYM) return lds[at + EigGemm<KS>::cs(s) * EigGemm<KS>::LD + 16 * mt];   // As[st(s, hi)][16 mt + r0]
         return EigGemm<KS>::LDS ? lds[at + (mt * KS + s) * 64] : a1[EigGemm<KS>::LDS ? 0 : mt][EigGemm<KS>::LDS ? 0 : s];
     }
     __device__ __forceinline__ double op2(int mt, int s, int at) const {
+        if (EigGemm<KS>::SYM) return lds[at + 16 * mt * EigGemm<KS>::LD + EigGemm<KS>::cs(s)];   // As[16 mt + r0][st(s, hi)]
         return EigGemm<KS>::LDS ? lds[at + (EigGemm<KS>::MT * KS + mt * KS + s) * 64]
                                 : a2[EigGemm<KS>::LDS ? 0 : mt][EigGemm<KS>::LDS ? 0 : s];
     }
@@ -128,7 +151,21 @@ __device__ __forceinline__ void eig_gemm_init(EigGemmWave<KS>& W, const PmlTree&
     const double* gA = m.A + (size_t)col * k * k;
     const double* gB = m.Ainv + (size_t)col * k * k;
     W.lds = smem;
-    if (EigGemm<KS>::LDS) {
+    W.b1 = W.b2 = 0;
+    if (EigGemm<KS>::SYM) {
+        static_assert(!EigGemm<KS>::SYM || EigGemm<KS>::PAIRS, "more than 64 states: even KS only");
+        constexpr int LD = EigGemm<KS>::LD;
+        const double* gS = m.Asym + (size_t)col * k * k;   // As = Pi^-1/2 U (eig_sym_kernel)
+        for (int e = threadIdx.x; e < 4 * KS * LD; e += blockDim.x) {
+            const int r = e / LD, q = e - r * LD;
+            smem[e] = (r < k && q < k) ? gS[r * k + q] : 0.0;
+        }
+        // row of the lane within an operand tile: st(4 mt + (lo >> 2), lo & 3) = 16 mt + r0
+        const int r0 = 8 * (lo >> 3) + 2 * (lo & 3) + ((lo >> 2) & 1);
+        W.b1 = 2 * hi * LD + r0;
+        W.b2 = r0 * LD + 2 * hi;
+        __syncthreads();
+    } else if (EigGemm<KS>::LDS) {
         // operand layout [tile][k-step][lane]: entry e of a matrix belongs to lane e % 64 of (mt, s) = (e / 64 / KS, e / 64 % KS)
         for (int e = threadIdx.x; e < MT * KS * 64; e += blockDim.x) {
             const int l = e & 63, ms = e >> 6, mt = ms / KS, s2 = ms - mt * KS;
@@ -208,14 +245,16 @@ __device__ __forceinline__ void eig_row_store(double* __restrict__ row, int hi, 
 struct EigNode {
     int n, fc, nc, p;
     u64 word;     // allowed-state mask (k <= 64: one word)
+    u64 word2;    // states 64 .. 127 (more than 64 states: two words per node)
     double dist;
 };
 
-template <int MODE>
+template <int MODE, bool TWO = false>
 __device__ __forceinline__ EigNode eig_node_load(const PmlTree& t, const PmlCols& c, size_t colN, bool act, int n) {
     EigNode q;
     q.n = act ? n : 0;
-    q.word = c.masks[colN + q.n];
+    q.word = TWO ? c.masks[(colN + q.n) * 2] : c.masks[colN + q.n];
+    q.word2 = TWO ? c.masks[(colN + q.n) * 2 + 1] : 0ull;
     q.nc = t.n_children[q.n];
     q.dist = t.dist[q.n];
     q.fc = MODE == PML_EIGG_BU ? t.first_child[q.n] : 0;
@@ -231,12 +270,14 @@ __device__ __forceinline__ void eig_gemm_pass(const EigGemmWave<KS>& W, const Pm
     const int k = W.k, ks = W.ks, col = W.col, lo = W.lo, hi = W.hi;
     const size_t colN = W.colN;
     const double sfc = W.sfc, tau = W.tau, tf = W.tf;
-    int at = threadIdx.x & 63;
+    int at = EigGemm<KS>::SYM ? W.b1 : (int)(threadIdx.x & 63), at2 = EigGemm<KS>::SYM ? W.b2 : at;
     if (EigGemm<KS>::LDS) asm volatile("" : "+v"(at));
+    if (EigGemm<KS>::SYM) asm volatile("" : "+v"(at2));
+    else at2 = at;
     const int n = q.n;
     {
         const size_t row = (colN + n) * ks;
-        const u64 word = q.word;
+        const u64 word = q.word, word2 = q.word2;
         const int nc = q.nc;
         const double tt = (q.dist + tau) * tf * sfc;
         double v[KS];
@@ -245,7 +286,8 @@ __device__ __forceinline__ void eig_gemm_pass(const EigGemmWave<KS>& W, const Pm
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 const int j = EigGemm<KS>::st(s, hi);
-                mb[s] = (j < k && ((word >> j) & 1ull)) ? 1.0 : 0.0;
+                const u64 wj = (EigGemm<KS>::SYM && j >= 64) ? word2 : word;
+                mb[s] = (j < k && ((wj >> (j & 63)) & 1ull)) ? 1.0 : 0.0;
             }
         };
         i64 esum = 0;
@@ -325,9 +367,21 @@ __device__ __forceinline__ void eig_gemm_pass(const EigGemmWave<KS>& W, const Pm
         // instead of MT x KS matrix instructions (half of a tip's pass; tips are half of the nodes).  Wave-uniform choice; the sums
         // of the product degenerate to their one non-zero term, so the bits are those of the GEMM.
         const u64 kb = k >= 64 ? ~0ull : (1ull << k) - 1ull;
-        if (MODE == PML_EIGG_TIPS && W.ainvT != nullptr && __all(!act || __popcll(word & kb) == 1)) {
-            const double* colT = W.ainvT + (size_t)(act ? __builtin_ctzll(word & kb) : 0) * W.ldT;
-            eig_row_load<KS>(colT, hi, act ? min(W.ldT, 4 * KS) : 0, z);   // (padded with zeros beyond k)
+        constexpr bool SYM = EigGemm<KS>::SYM;
+        const u64 kb2 = !SYM || k <= 64 ? 0ull : (k >= 128 ? ~0ull : (1ull << (k - 64)) - 1ull);
+        if (MODE == PML_EIGG_TIPS && (SYM || W.ainvT != nullptr) &&
+            __all(!act || __popcll(word & kb) + (SYM ? __popcll(word2 & kb2) : 0) == 1)) {
+            if (SYM) {
+                // column s of A^-1 = row s of As, times pi_s: from the block's copy of As
+                const int so = !act ? 0 : ((word & kb) ? __builtin_ctzll(word & kb) : 64 + __builtin_ctzll(word2 & kb2));
+                const double* rowA = W.lds + (size_t)so * EigGemm<KS>::LD;
+                const double pis = W.cst[4 * KS + so];
+#pragma unroll
+                for (int s = 0; s < KS; ++s) z[s] = act ? rowA[EigGemm<KS>::st(s, hi)] * pis : 0.0;
+            } else {
+                const double* colT = W.ainvT + (size_t)(act ? __builtin_ctzll(word & kb) : 0) * W.ldT;
+                eig_row_load<KS>(colT, hi, act ? min(W.ldT, 4 * KS) : 0, z);   // (padded with zeros beyond k)
+            }
             {
                 double dl[KS];
                 eig_row_load<KS>(W.cst, hi, 4 * KS, dl);
@@ -335,6 +389,12 @@ __device__ __forceinline__ void eig_gemm_pass(const EigGemmWave<KS>& W, const Pm
                 for (int s = 0; s < KS; ++s) z[s] *= exp(dl[s] * tt);
             }
         } else {
+            if (SYM) {   // A^-1 v = As^T (pi o v)
+                double pil[KS];
+                eig_row_load<KS>(W.cst + 4 * KS, hi, 4 * KS, pil);
+#pragma unroll
+                for (int s = 0; s < KS; ++s) v[s] *= pil[s];
+            }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 acc[mt] = (pml_v4f64){0.0, 0.0, 0.0, 0.0};
@@ -351,7 +411,7 @@ __device__ __forceinline__ void eig_gemm_pass(const EigGemmWave<KS>& W, const Pm
         for (int mt = 0; mt < MT; ++mt) {
             acc[mt] = (pml_v4f64){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int s = 0; s < KS; ++s) acc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(W.op2(mt, s, at), z[s], acc[mt], 0, 0, 0);
+            for (int s = 0; s < KS; ++s) acc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(W.op2(mt, s, at2), z[s], acc[mt], 0, 0, 0);
         }
         double out[KS];
 #pragma unroll
@@ -398,10 +458,10 @@ __device__ __forceinline__ void eig_gemm_pass(const EigGemmWave<KS>& W, const Pm
 // (two waves per SIMD wherever the top-down mode's registers allow it: the bottom-up modes of the widest shapes would
 // otherwise settle a few registers above the limit and run one)
 template <int KS, int MODE>
-__global__ void __launch_bounds__(PML_BLOCK) __attribute__((amdgpu_waves_per_eu((MODE == PML_EIGG_TD && KS >= 8) ? 1 : 2, 8)))
+__global__ void __launch_bounds__(PML_BLOCK) __attribute__((amdgpu_waves_per_eu(((MODE == PML_EIGG_TD && KS >= 8) || KS > 16) ? 1 : 2, 8)))
 eigen_gemm_kernel(PmlTree t, PmlCols c, PmlModel m, PmlState st, const int* __restrict__ nodes, int first, int n_nodes) {
     extern __shared__ double eigg_smem[];
-    __shared__ double eigg_cst[8 * KS];
+    __shared__ double eigg_cst[EigGemm<KS>::CST_DOUBLES];
     EigGemmWave<KS> W;
     eig_gemm_init<KS>(W, t, c, m, eigg_smem, eigg_cst);
     const int wave = threadIdx.x >> 6;
@@ -411,13 +471,13 @@ eigen_gemm_kernel(PmlTree t, PmlCols c, PmlModel m, PmlState st, const int* __re
     auto id_of = [&](int b, bool a) { return a ? (nodes != nullptr ? nodes[b + W.lo] : first + b + W.lo) : 0; };
     // the node data of the next pass and the node id of the one after it are in flight while this pass runs
     bool act = b0 + W.lo < n_nodes;
-    EigNode cur = eig_node_load<MODE>(t, c, W.colN, act, id_of(b0, act));
+    EigNode cur = eig_node_load<MODE, EigGemm<KS>::SYM>(t, c, W.colN, act, id_of(b0, act));
     bool act1 = b0 + stride + W.lo < n_nodes;
     int n1 = id_of(b0 + stride, act1);
     for (; b0 < n_nodes; b0 += stride) {
         const bool act2 = b0 + 2 * stride + W.lo < n_nodes;
         const int n2 = id_of(b0 + 2 * stride, act2);
-        const EigNode nxt = eig_node_load<MODE>(t, c, W.colN, act1, n1);
+        const EigNode nxt = eig_node_load<MODE, EigGemm<KS>::SYM>(t, c, W.colN, act1, n1);
         eig_gemm_pass<KS, MODE>(W, t, c, st, act, cur);
         cur = nxt;
         act = act1;
@@ -436,7 +496,7 @@ eigen_gemm_narrow_kernel(PmlTree t, PmlCols c, PmlModel m, PmlState st, const in
     // (blk_start: the subtree blocks of a tier of thin levels, one workgroup per (block, column) -- pml_ctx::EigenTiers)
     if (blk_start != nullptr) level_offsets += blk_start[blockIdx.x];
     extern __shared__ double eigg_smem[];
-    __shared__ double eigg_cst[8 * KS];
+    __shared__ double eigg_cst[EigGemm<KS>::CST_DOUBLES];
     EigGemmWave<KS> W;
     eig_gemm_init<KS>(W, t, c, m, eigg_smem, eigg_cst);
     const int wave = threadIdx.x >> 6;
@@ -445,9 +505,58 @@ eigen_gemm_narrow_kernel(PmlTree t, PmlCols c, PmlModel m, PmlState st, const in
         for (int b0 = wave * 16; b0 < n_level; b0 += PML_WAVES_PER_BLOCK * 16) {
             const bool act = b0 + W.lo < n_level;
             const int n = act ? (nodes != nullptr ? nodes[a + b0 + W.lo] : a + b0 + W.lo) : 0;
-            eig_gemm_pass<KS, MODE>(W, t, c, st, act, eig_node_load<MODE>(t, c, W.colN, act, n));
+            eig_gemm_pass<KS, MODE>(W, t, c, st, act, eig_node_load<MODE, EigGemm<KS>::SYM>(t, c, W.colN, act, n));
         }
         __threadfence_block();
         __syncthreads();
     }
 }
+
+
+// As = Pi^-1/2 U for the one-matrix form above (65 - 128 states): U = Pi^1/2 A with normalised columns, made orthonormal by one
+// Newton-Schulz step.  One workgroup per column; T = (3 I - U^T U) / 2 goes through `scratch` ([C][k][k], L2).
+#ifdef PML_PLAIN_KERNELS   // (launched by pml_api.hip only)
+PML_GLOBAL void __launch_bounds__(PML_BLOCK)
+eig_sym_kernel(int k, int ks, int col_begin, const double* __restrict__ A, const double* __restrict__ pi, double* __restrict__ scratch,
+               double* __restrict__ Asym) {
+    extern __shared__ double esym_smem[];
+    const int col = col_begin + blockIdx.x;
+    const int LD = k + 1;
+    double* sU = esym_smem;            // [k][LD]
+    double* sG = sU + (size_t)k * LD;  // [k]: 1 / norm of the columns, then unused
+    const double* gA = A + (size_t)col * k * k;
+    const double* gp = pi + (size_t)col * ks;
+    double* T = scratch + (size_t)col * k * k;
+    double* out = Asym + (size_t)col * k * k;
+    for (int e = threadIdx.x; e < k * k; e += blockDim.x) {
+        const int j = e / k, mm = e - j * k;
+        sU[j * LD + mm] = sqrt(gp[j]) * gA[e];
+    }
+    __syncthreads();
+    for (int mm = threadIdx.x; mm < k; mm += blockDim.x) {
+        double g = 0.0;
+        for (int j = 0; j < k; ++j) g = __builtin_fma(sU[j * LD + mm], sU[j * LD + mm], g);
+        sG[mm] = 1.0 / sqrt(g);
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < k * k; e += blockDim.x) {
+        const int j = e / k, mm = e - j * k;
+        sU[j * LD + mm] *= sG[mm];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < k * k; e += blockDim.x) {
+        const int q = e / k, mm = e - q * k;
+        double g = 0.0;
+        for (int j = 0; j < k; ++j) g = __builtin_fma(sU[j * LD + q], sU[j * LD + mm], g);
+        T[e] = (q == mm ? 1.5 : 0.0) - 0.5 * g;
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int e = threadIdx.x; e < k * k; e += blockDim.x) {
+        const int i = e / k, mm = e - i * k;
+        double g = 0.0;
+        for (int q = 0; q < k; ++q) g = __builtin_fma(sU[i * LD + q], T[q * k + mm], g);
+        out[e] = g / sqrt(gp[i]);
+    }
+}
+#endif

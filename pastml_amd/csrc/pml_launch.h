@@ -96,10 +96,13 @@ static bool deep_top_down(const pml_ctx* ctx) {
 
 // sum sweeps of the eigen models without forming P(t) (pml_kernels_eigen_gemm.h): one launch over a list (nodes) or a
 // contiguous id range (first) of n nodes
-// (any eigen model with up to 64 states; the joint sweep reads materialised P(t) below 16 and beyond 32 states)
+// (any eigen model with up to 64 states; 65 - 128 states: the reversible ones -- pml_model_set_eigen checks what it is given --,
+// whose A^-1 is A transposed and rescaled, so that one matrix in LDS serves both products)
 static bool eigen_gemm(const pml_ctx* c) {
     const bool off = c->tune.on(T_NO_EIGEN_GEMM) || c->tune.on(T_NO_MFMA) || c->tune.on(T_NO_EIGEN_FUSED);
-    return !off && c->eig_fused_opt && c->kind == PML_MODEL_EIGEN && c->k >= 2 && c->k <= 64 && c->W == 1;
+    if (off || !c->eig_fused_opt || c->kind != PML_MODEL_EIGEN || c->k < 2) return false;
+    if (c->k <= 64) return c->W == 1;
+    return c->k <= 128 && c->W == 2 && c->eig_sym_all && c->d_Asym != nullptr;
 }
 
 
@@ -137,6 +140,10 @@ PML_INTERNAL int launch_pij_wide(pml_ctx* ctx);
 PML_INTERNAL int launch_eigen_gemm(pml_ctx* ctx, int mode, const int* nodes, int first, int n);
 PML_INTERNAL int launch_eigen_gemm_narrow(pml_ctx* ctx, int mode, const int* nodes, const int* d_offsets, int first_level,
                                           int n_levels, const int* d_blk_start = nullptr, int n_blocks = 1);
+// ---- pml_launch_eigen_gemm_wide.hip: the same for 65 - 128 states (one matrix in LDS)
+PML_INTERNAL int launch_eigen_gemm_wide(pml_ctx* ctx, int mode, const int* nodes, int first, int n);
+PML_INTERNAL int launch_eigen_gemm_narrow_wide(pml_ctx* ctx, int mode, const int* nodes, const int* d_offsets, int first_level,
+                                               int n_levels, const int* d_blk_start, int n_blocks);
 // ---- pml_launch_eigen_joint.hip: joint sweep of the eigen models on the vector units, P(t) batch for k < 16
 PML_INTERNAL int launch_eigen_joint(pml_ctx* ctx, const PmlUnit* units, const int* d_offsets, int first, int n,
                                     const int* d_blk_start = nullptr, int n_blocks = 1);

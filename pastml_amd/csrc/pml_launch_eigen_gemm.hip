@@ -16,6 +16,7 @@ static int eig_gemm_ks(int k, int mode) {
 
 int launch_eigen_gemm(pml_ctx* ctx, int mode, const int* nodes, int first, int n) {
     if (n <= 0) return PML_OK;
+    if (ctx->k > 64) return launch_eigen_gemm_wide(ctx, mode, nodes, first, n);   // pml_launch_eigen_gemm_wide.hip
     const int KS = eig_gemm_ks(ctx->k, mode);
     const PmlTree t = tree_of(ctx);
     const PmlCols c = cols_of(ctx);
@@ -63,6 +64,7 @@ int launch_eigen_gemm(pml_ctx* ctx, int mode, const int* nodes, int first, int n
 int launch_eigen_gemm_narrow(pml_ctx* ctx, int mode, const int* nodes, const int* d_offsets, int first_level,
                                     int n_levels, const int* d_blk_start, int n_blocks) {
     if (n_levels <= 0) return PML_OK;
+    if (ctx->k > 64) return launch_eigen_gemm_narrow_wide(ctx, mode, nodes, d_offsets, first_level, n_levels, d_blk_start, n_blocks);
     const int KS = eig_gemm_ks(ctx->k, mode);
     const PmlTree t = tree_of(ctx);
     const PmlCols c = cols_of(ctx);

@@ -12,6 +12,7 @@ struct PmlModel {
     const double* Ainv;   // [C][k][k]
     const double* AinvT;  // [C][ldT][ldT]: Ainv transposed, zero-padded (k <= 64; null otherwise): AinvT[j][m] = Ainv[m][j]
     int ldT;              //   32 for k <= 32, 64 for k <= 64
+    const double* Asym;   // [C][k][k], 65 <= k <= 128: Pi^-1/2 U with U = Pi^1/2 A orthonormalised (eig_sym_kernel); else null
     const double* sf;     // [C]
     const double* tau;    // [C]
     const double* tauf;   // [C]

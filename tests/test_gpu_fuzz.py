@@ -26,7 +26,7 @@ def draw_case(seed):
     if kind == 'HKY':
         k = 4
     elif kind == 'EIGEN':
-        k = int(rng.choice([3, 7, 16, 17, 20, 21, 24, 26, 29, 32, 33, 40, 48, 53, 61, 64]))
+        k = int(rng.choice([3, 7, 16, 17, 20, 21, 24, 26, 29, 32, 33, 40, 48, 53, 61, 64, 65, 77, 96, 128, 140]))
     else:
         k = int(rng.choice([2, 3, 4, 5, 9, 16, 20, 31, 32, 33, 48, 64, 65, 100, 130, 257, 300, 512]))
     big = seed % 10 == 0

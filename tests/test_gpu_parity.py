@@ -93,6 +93,86 @@ def test_pij_batch_beyond_32_states(k):
     np.testing.assert_allclose(got['wide'], got['generic'], rtol=1e-10, atol=1e-14)
 
 
+@pytest.mark.parametrize('k', [65, 67, 80, 81, 96, 100, 113, 128])
+def test_eigen_sum_sweeps_of_65_to_128_states(k):
+    """
+    Eigen models with 65 - 128 states (round 6): the sum sweeps as two matrix-core GEMMs per 16 nodes with ONE matrix in LDS --
+    a reversible model's A^-1 is A transposed and rescaled (pml_kernels_eigen_gemm.h, EigGemm::SYM; pml_model_set_eigen checks
+    the identity on what it is given) -- against the oracle (pastml/ml.py:124-148, :273-290, :454-460 with the reference's P(t),
+    generator.py:54-65) and against the sweeps on P(t) materialised in HBM (NO_EIGEN_GEMM), which the fused path must not
+    allocate; polytomies, several trees, missing / ambiguous tips (masks of two words), restricted internal nodes, tau > 0.
+    Tolerances: ln L 1e-11 and posteriors 1e-9 as everywhere; the vectors' entries 1e-9 in log10 (elsewhere 2e-10): a product of the
+    one-matrix form agrees with the reference's P(t) v to 7e-11 per entry (numpy's eigenvectors re-orthonormalised; with numpy's
+    own inverse it is 2e-11), and the small entries of vectors 50 levels deep collect several of those.
+    """
+    rng = np.random.default_rng(6500 + k)
+    flat = FlatForest.random(700, seed=k, max_arity=4, n_trees=2)
+    C = 2
+    specs = [random_spec('EIGEN', k, rng) for _ in range(C)]
+    rates = [(float(rng.uniform(0.5, 3)), 0.0, 1.0), (float(rng.uniform(0.5, 3)), 0.01, 0.9)]
+    masks = np.stack([random_masks(flat, k, rng) for _ in range(C)])
+    masks[1] = synthetic.one_hot_masks(flat, k, rng.integers(0, k, size=flat.n_tips))   # every tip observed: the gathered first product
+    got = {}
+    for name, tune in (('fused', {}), ('materialised', dict(NO_EIGEN_GEMM=1))):
+        with hip.Engine(flat, C, k, tune=tune, keep_td=True) as eng:
+            eng.set_models(list(zip(specs, rates)))
+            eng.set_masks(masks)
+            lnl, post, lh_sum, lh_sf = eng.marginal_pass()
+            held = eng.memory()[0]   # (before the top-down vectors are asked for: those of tips are filled in from P(t))
+            bus = [(eng.download(hip.BUF_BU, c), eng.download(hip.BUF_BU_SF, c)) for c in range(C)]
+            tds = [(eng.download(hip.BUF_TD, c), eng.download(hip.BUF_TD_SF, c)) for c in range(C)]
+            lnl2 = eng.bottom_up(True)
+            assert np.array_equal(lnl, lnl2)
+            got[name] = (lnl, post, lh_sum, lh_sf, bus, tds, held)
+    P_bytes = C * flat.n_nodes * k * (k + (k & 1)) * 8
+    assert got['fused'][6] <= got['materialised'][6] - P_bytes // 2, 'the fused sweeps allocated P(t)'
+    nonroot = flat.parent >= 0
+    for c in range(C):
+        r = orc.full_marginal_pass(flat, masks[c].astype(int), specs[c], *rates[c])
+        for name in got:
+            lnl, post, lh_sum, lh_sf, bus, tds, _ = got[name]
+            np.testing.assert_allclose(lnl[c], r['loglik'], rtol=LNL_RTOL, atol=1e-12, err_msg=name)
+            for what, (vec, sf), key in (('BU', bus[c], 'bu'), ('TD', tds[c], 'td')):
+                a, b = log_true(vec, sf)[nonroot], log_true(r[key], r[key + '_sf'])[nonroot]
+                assert np.array_equal(np.isneginf(a), np.isneginf(b)), '{} {} col {}: zero patterns differ'.format(what, name, c)
+                fin = np.isfinite(b)
+                np.testing.assert_allclose(a[fin], b[fin], rtol=0, atol=1e-9 if name == 'fused' else LOG10_ATOL,
+                                           err_msg='{} {} col {}'.format(what, name, c))
+            np.testing.assert_allclose(post[c], r['posterior'], rtol=POST_RTOL, atol=1e-300, err_msg=name)
+            np.testing.assert_allclose(np.log10(lh_sum[c]) - lh_sf[c], r['loglik_per_tree'][flat.tree_id] / np.log(10), rtol=1e-11,
+                                       atol=1e-12)
+
+
+def test_eigen_model_with_a_repeated_eigenvalue_keeps_materialised_transition_matrices():
+    """A 70-state model one of whose eigenvalues repeats, handed over with eigenvectors of that eigenvalue that are not orthogonal
+    (any basis of the eigenspace diagonalises; numpy gives no better for a repeated eigenvalue): A^-1 is then not A transposed
+    and rescaled -- pml_model_set_eigen notices and the sweeps read P(t) from HBM, bit for bit the results of NO_EIGEN_GEMM."""
+    k = 70
+    rng = np.random.default_rng(70)
+    flat = FlatForest.random(300, seed=70, max_arity=3)
+    spec = random_spec('EIGEN', k, rng)
+    order = np.argsort(spec['d'])
+    gaps = np.diff(spec['d'][order])
+    m0, m1 = order[np.argmin(gaps)], order[np.argmin(gaps) + 1]   # the two closest eigenvalues become one
+    d = spec['d'].copy()
+    d[m1] = d[m0]
+    a = spec['A'].copy()
+    a[:, m1] += 0.7 * a[:, m0]
+    spec = dict(kind=2, pi=spec['pi'], d=d, A=a, Ainv=np.linalg.inv(a))
+    masks = random_masks(flat, k, rng)[None]
+    got = []
+    for tune in ({}, dict(NO_EIGEN_GEMM=1)):
+        with hip.Engine(flat, 1, k, tune=tune) as eng:
+            eng.set_models([(spec, (1.3, 0.0, 1.0))])
+            eng.set_masks(masks)
+            got.append(eng.marginal_pass())
+    for x, y in zip(got[0], got[1]):
+        assert np.array_equal(x, y)
+    r = orc.full_marginal_pass(flat, masks[0].astype(int), spec, 1.3, 0.0, 1.0)
+    np.testing.assert_allclose(got[0][0][0], r['loglik'], rtol=LNL_RTOL)
+    np.testing.assert_allclose(got[0][1][0], r['posterior'], rtol=POST_RTOL, atol=1e-300)
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 def test_pij_matches_reference():
     z = load_golden('pij')
