@@ -1909,12 +1909,27 @@ int pml_model_set_eigen(pml_ctx* ctx, int32_t col_begin, int32_t col_end, const 
             }
             ctx->eig_sym[col_begin + c] = ok ? 1 : 0;
         }
-        PML_TRY(params_push(ctx));   // (the kernel reads the frequencies from the parameter block)
-        HIP_TRY(hipFuncSetAttribute((const void*)eig_sym_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)((k * (k + 1) + k) * sizeof(double))));
-        hipLaunchKernelGGL(eig_sym_kernel, dim3(nc), dim3(PML_BLOCK), (k * (k + 1) + k) * sizeof(double), ctx->stream, (int)k,
-                           ctx->ks, (int)col_begin, ctx->d_A, cols_of(ctx).pi, ctx->d_eigT, ctx->d_Asym);
-        HIP_TRY(hipGetLastError());
+        // (an optimiser that moves the scaling factor alone hands in the same matrices evaluation after evaluation)
+        const size_t kk = k * k;
+        if (ctx->h_symA.size() != (size_t)ctx->C * (kk + k)) ctx->h_symA.assign((size_t)ctx->C * (kk + k), 0.0);
+        bool same = true;
+        for (int c = 0; c < nc; ++c) {
+            double* last = ctx->h_symA.data() + (size_t)(col_begin + c) * (kk + k);
+            if (memcmp(last, A + (size_t)c * kk, kk * sizeof(double)) != 0 || memcmp(last + kk, pi + (size_t)c * k, k * sizeof(double)) != 0) {
+                same = false;
+                memcpy(last, A + (size_t)c * kk, kk * sizeof(double));
+                memcpy(last + kk, pi + (size_t)c * k, k * sizeof(double));
+            }
+        }
+        if (!same) {
+            PML_TRY(params_push(ctx));   // (the kernel reads the frequencies from the parameter block)
+            const size_t lds = (k * (k + 1) + k) * sizeof(double);
+            HIP_TRY(hipFuncSetAttribute((const void*)eig_sym_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            for (int phase = 0; phase < 2; ++phase)
+                hipLaunchKernelGGL(eig_sym_kernel, dim3(PML_ESYM_PARTS, nc), dim3(PML_BLOCK), lds, ctx->stream, (int)k, ctx->ks,
+                                   (int)col_begin, phase, ctx->d_A, cols_of(ctx).pi, ctx->d_eigT, ctx->d_Asym);
+            HIP_TRY(hipGetLastError());
+        }
         bool all = true;
         for (int i = 0; i < ctx->C; ++i) all = all && (ctx->eig_sym[i] != 0 || !ctx->model_set[i]);
         if (all != ctx->eig_sym_all) drop_sweep_graphs(ctx);   // the sweeps change kernels

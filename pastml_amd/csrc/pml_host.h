@@ -255,6 +255,7 @@ struct pml_ctx {
     bool bu_signals_few = false;
     double* d_Asym = nullptr;   // [C][k][k], 65 <= k <= 128: the one matrix of the sum sweeps (eig_sym_kernel)
     double* d_eigT = nullptr;   // [C][k][k]: scratch of that kernel
+    std::vector<double> h_symA; // [C][k k + k]: the A and pi d_Asym was made from (an unchanged model is not orthonormalised again)
     std::vector<char> eig_sym;  // per column: the identity holds for the matrices pml_model_set_eigen was given
     bool eig_sym_all = false;   // ... for every column: the sum sweeps of 65 - 128 states keep one matrix in LDS
     double* d_AinvT = nullptr;  // [C][ld][ld], ld = 32 (k <= 32) or 64 (k <= 64): Ainv transposed and zero-padded -- eigen_joint_kernel (k <= 32), eigen_gemm_kernel's observed tips

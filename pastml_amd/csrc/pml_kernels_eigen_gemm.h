@@ -514,16 +514,18 @@ eigen_gemm_narrow_kernel(PmlTree t, PmlCols c, PmlModel m, PmlState st, const in
 
 
 // As = Pi^-1/2 U for the one-matrix form above (65 - 128 states): U = Pi^1/2 A with normalised columns, made orthonormal by one
-// Newton-Schulz step.  One workgroup per column; T = (3 I - U^T U) / 2 goes through `scratch` ([C][k][k], L2).
+// Newton-Schulz step.  Two launches of PML_ESYM_PARTS workgroups per column (every workgroup holds U in LDS and makes its share of
+// the k^2 entries): T = (3 I - U^T U) / 2 into `scratch` ([C][k][k], L2), then As = Pi^-1/2 U T.
+#define PML_ESYM_PARTS 8
 #ifdef PML_PLAIN_KERNELS   // (launched by pml_api.hip only)
 PML_GLOBAL void __launch_bounds__(PML_BLOCK)
-eig_sym_kernel(int k, int ks, int col_begin, const double* __restrict__ A, const double* __restrict__ pi, double* __restrict__ scratch,
-               double* __restrict__ Asym) {
+eig_sym_kernel(int k, int ks, int col_begin, int phase, const double* __restrict__ A, const double* __restrict__ pi,
+               double* __restrict__ scratch, double* __restrict__ Asym) {
     extern __shared__ double esym_smem[];
-    const int col = col_begin + blockIdx.x;
+    const int col = col_begin + blockIdx.y;
     const int LD = k + 1;
     double* sU = esym_smem;            // [k][LD]
-    double* sG = sU + (size_t)k * LD;  // [k]: 1 / norm of the columns, then unused
+    double* sG = sU + (size_t)k * LD;  // [k]: 1 / norm of the columns
     const double* gA = A + (size_t)col * k * k;
     const double* gp = pi + (size_t)col * ks;
     double* T = scratch + (size_t)col * k * k;
@@ -544,19 +546,23 @@ eig_sym_kernel(int k, int ks, int col_begin, const double* __restrict__ A, const
         sU[j * LD + mm] *= sG[mm];
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < k * k; e += blockDim.x) {
-        const int q = e / k, mm = e - q * k;
-        double g = 0.0;
-        for (int j = 0; j < k; ++j) g = __builtin_fma(sU[j * LD + q], sU[j * LD + mm], g);
-        T[e] = (q == mm ? 1.5 : 0.0) - 0.5 * g;
-    }
-    __threadfence_block();
-    __syncthreads();
-    for (int e = threadIdx.x; e < k * k; e += blockDim.x) {
-        const int i = e / k, mm = e - i * k;
-        double g = 0.0;
-        for (int q = 0; q < k; ++q) g = __builtin_fma(sU[i * LD + q], T[q * k + mm], g);
-        out[e] = g / sqrt(gp[i]);
+    const int stride = gridDim.x * blockDim.x;
+    if (phase == 0) {
+        for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < k * k; e += stride) {
+            const int q = e / k, mm = e - q * k;
+            double g = 0.0;
+#pragma unroll 4
+            for (int j = 0; j < k; ++j) g = __builtin_fma(sU[j * LD + q], sU[j * LD + mm], g);
+            T[e] = (q == mm ? 1.5 : 0.0) - 0.5 * g;
+        }
+    } else {
+        for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < k * k; e += stride) {
+            const int i = e / k, mm = e - i * k;
+            double g = 0.0;
+#pragma unroll 4
+            for (int q = 0; q < k; ++q) g = __builtin_fma(sU[i * LD + q], T[q * k + mm], g);
+            out[e] = g / sqrt(gp[i]);
+        }
     }
 }
 #endif

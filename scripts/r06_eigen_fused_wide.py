@@ -7,7 +7,7 @@ from pastml_amd import hip, synthetic
 from pastml_amd.models._eigen import get_diagonalisation
 
 ks = [int(a) for a in sys.argv[1:]] or [67, 80, 96, 100, 112, 128]
-levels = 14
+levels = int(os.environ.get("LEVELS", "14"))
 flat = synthetic.balanced_forest(levels)
 C = 4
 print('balanced {}-tip tree ({} nodes) x {} characters; ms per call incl. the model upload, wall clock around the C-ABI'.format(flat.n_tips, flat.n_nodes, C))
