@@ -710,6 +710,63 @@ def test_eigen_models_optimised_match_reference():
     np.testing.assert_allclose(res[MARGINAL_PROBABILITIES].values, z['cr_posterior'], rtol=0, atol=5e-4)
 
 
+def test_acr_custom_rates_with_72_states_fused_and_materialised_agree(tmp_path, monkeypatch):
+    """
+    acr() end to end with a CUSTOM_RATES model of 72 states (beyond 64: the sum sweeps with one matrix in LDS, the joint sweep on
+    P(t) built by the matrix-core batch): frequencies given, scaling factor optimised -- the same matrices evaluation after
+    evaluation -- and then frequencies free as well (every point of every gradient its own eigendecomposition and its own
+    re-orthonormalisation on the device).  Against the same call with the fused sweeps switched off (P(t) of every branch in
+    HBM in every evaluation): the optimum, the posteriors, the selected states.
+    """
+    from pastml_amd import synthetic
+    k, n_tips = 76, 300   # (72 of the 76 candidate states are observed at the tips)
+    rng = np.random.default_rng(7070)
+    flat = FlatForest.random(n_tips, seed=70, max_arity=3, lo=0.02, hi=0.4)
+    tree = flat.to_tree_nodes()[0]
+    names = synthetic.state_names(k)
+    st = np.zeros(flat.n_nodes, dtype=np.int64)
+    for n in range(flat.n_nodes):   # ids are in level order: parents first
+        p = flat.parent[n]
+        st[n] = rng.integers(k) if p < 0 or rng.random() > np.exp(-4.0 * flat.dist[n]) else st[p]
+    tips = [flat.nodes[t] for t in flat.tips]
+    df = pd.DataFrame({'c': [names[st[t]] for t in flat.tips]}, index=[t.name for t in tips])
+    states = np.array(sorted(set(df['c'])))
+    kk = len(states)
+    assert 64 < kk <= 128
+    rates = np.triu(rng.uniform(0.2, 2.0, size=(kk, kk)), 1)
+    rates = rates + rates.T
+    rate_file = str(tmp_path / 'rates.txt')
+    save_matrix(states, rates, rate_file)
+    freqs = rng.dirichlet(np.ones(kk) * 5)
+    params = {s: f for s, f in zip(states, freqs)}
+
+    def run(fused, fixed_frequencies):
+        hip.drain_engine_pool()   # (the switches of a context are read when it is created)
+        if fused:
+            monkeypatch.delenv('PASTML_HIP_NO_EIGEN_GEMM', raising=False)
+        else:
+            monkeypatch.setenv('PASTML_HIP_NO_EIGEN_GEMM', '1')
+        t = flat.to_tree_nodes()[0]
+        return t, acr(t, df, prediction_method=MPPA, model=CUSTOM_RATES, column2rates={'c': rate_file},
+                      column2parameters={'c': params} if fixed_frequencies else None)[0]
+
+    try:
+        for fixed in (True, False):
+            (ta, a), (tb, b) = run(True, fixed), run(False, fixed)
+            np.testing.assert_allclose(a[LOG_LIKELIHOOD], b[LOG_LIKELIHOOD], rtol=0, atol=1e-5 if fixed else 2e-3)
+            np.testing.assert_allclose(a[MODEL].sf, b[MODEL].sf, rtol=1e-5 if fixed else 2e-2)
+            np.testing.assert_allclose(a[MARGINAL_PROBABILITIES].values, b[MARGINAL_PROBABILITIES].values, rtol=0,
+                                       atol=1e-6 if fixed else 2e-2)
+            if fixed:
+                np.testing.assert_array_equal(a[MODEL].frequencies, b[MODEL].frequencies)
+                for na, nb in zip(FlatForest.from_trees([ta]).nodes, FlatForest.from_trees([tb]).nodes):
+                    assert getattr(na, 'c') == getattr(nb, 'c') and getattr(na, 'c_JOINT_STATE') == getattr(nb, 'c_JOINT_STATE')
+                assert a['num_unresolved_nodes'] == b['num_unresolved_nodes']
+    finally:
+        monkeypatch.delenv('PASTML_HIP_NO_EIGEN_GEMM', raising=False)
+        hip.drain_engine_pool()
+
+
 @pytest.mark.parametrize('model_name,k', [('F81', 5), ('HKY', 4), ('JTT', 20)])
 def test_marginal_counts_device_sampler_agrees_with_host_sampler(model_name, k):
     """
