@@ -169,7 +169,11 @@ int pml_model_set_f81(pml_ctx* ctx, int32_t col_begin, int32_t col_end, const do
                       const double* sf, const double* tau, const double* tau_factor);
 int pml_model_set_hky(pml_ctx* ctx, int32_t col_begin, int32_t col_end, const double* pi, const double* kappa,
                       const double* sf, const double* tau, const double* tau_factor);
-/* d[k], A[k][k], Ainv[k][k] (row-major) per column: pastml/models/generator.py:16-30 */
+/* d[k], A[k][k], Ainv[k][k] (row-major) per column: pastml/models/generator.py:16-30.  k <= 256 (PML_ERR_UNSUPPORTED beyond).
+ * 65 <= k <= 128: the sum sweeps keep one matrix in LDS, which a reversible model allows (generator.py:33-51 builds no other):
+ * the call checks that Ainv is A transposed and rescaled (Ainv[m][j] = c_m A[j][m] pi[j], to 1e-8) and re-orthonormalises the
+ * eigenvectors on the device (they come from a general solver, orthonormal to 1e-12); where the check fails -- an eigenvalue that
+ * repeats, handed over with a non-orthogonal basis -- the sweeps read P(t) of every branch from HBM, as they do beyond 128 states. */
 int pml_model_set_eigen(pml_ctx* ctx, int32_t col_begin, int32_t col_end, const double* pi,
                         const double* d, const double* A, const double* Ainv,
                         const double* sf, const double* tau, const double* tau_factor);

@@ -779,6 +779,45 @@ def case_eigen_k61():
 CASES['eigen_k61'] = case_eigen_k61
 
 
+def case_eigen_k100():
+    """
+    An eigen model beyond 64 states (round 6: sum sweeps with one matrix in LDS, P(t) batch on the matrix cores): the reference's
+    CustomRatesModel (pastml/models/CustomRatesModel.py:35-79, generator.py:54-65) with k = 100 states, seeded symmetric rates
+    and frequencies, on a balanced 2 048-tip tree, a twentieth of the tips unannotated: marginal pass and joint sweep with its
+    back-trace, fixed parameters.  Stored: every scalar, the joint states of all nodes, the vectors at every 13th node.
+    """
+    k, n_levels = 100, 11
+    rng = np.random.default_rng(100)
+    flat = synthetic.balanced_forest(n_levels)
+    roots = flat.to_tree_nodes()
+    fs = RForestStats(roots)
+    states, tips_states = annotate_synthetic(flat, roots, 'c0', k, 0, missing_frac=0.05, seed=100)
+    observed = np.array([bool(getattr(flat.nodes[t], 'c0', None)) for t in flat.tips])
+    rates = np.triu(rng.uniform(0.05, 3.0, size=(k, k)), 1)
+    rates = rates + rates.T
+    freqs = rng.dirichlet(np.ones(k) * 4)
+    model = RCR(forest_stats=fs, sf=0.8, states=np.array(states), rate_matrix=rates, frequencies=freqs)
+    model.freeze()
+    sys.setrecursionlimit(10000)
+    flat2, cap = sweep_capture(roots, 'c0', model)
+    out = dict(forest_stats_arrays(fs))
+    out.update(model_arrays(model))
+    sample = np.arange(0, flat.n_nodes, 13)
+    out['sample'] = sample
+    for key, v in cap.items():
+        if isinstance(v, np.ndarray) and v.ndim == 2 and len(v) == flat.n_nodes:
+            out[key] = v[sample]
+        else:
+            out[key] = v
+    out['tip_states'] = tips_states
+    out['tip_observed'] = observed
+    out['n_levels'] = n_levels
+    save('synthetic_cr_k100_L11', **out)
+
+
+CASES['eigen_k100'] = case_eigen_k100
+
+
 def case_f81_k300():
     """
     More than 256 states (the reference has no bound on k, pastml/ml.py:134): the reference's F81Model with 300 states on a

@@ -500,6 +500,44 @@ def test_f81_k300_matches_reference():
         np.testing.assert_allclose(eng.bottom_up(True)[0], z['loglik_restricted_MPPA'], rtol=LNL_RTOL)
 
 
+@pytest.mark.parametrize('fused', [True, False])
+def test_custom_rates_k100_matches_reference(fused):
+    """
+    An eigen model beyond 64 states against the reference itself (tests/golden/make_golden.py::case_eigen_k100: pastml's
+    CustomRatesModel with 100 states on a balanced 2 048-tip tree, a twentieth of the tips unannotated) -- marginal pass, joint
+    sweep + back-trace.  fused: the sum sweeps as two matrix-core GEMMs per 16 nodes with ONE matrix in LDS (the model is
+    reversible: pml_kernels_eigen_gemm.h, EigGemm::SYM); not fused: every sweep on P(t) of every branch in HBM, built by the
+    matrix-core batch (pml_kernels_pij_wide.h) -- which the joint sweep reads in both.
+    """
+    z = load_golden('synthetic_cr_k100_L11')
+    k = 100
+    flat = synthetic.balanced_forest(int(z['n_levels']))
+    masks = synthetic.one_hot_masks(flat, k, z['tip_states'])
+    masks[np.asarray(flat.tips)[~z['tip_observed']]] = 1
+    spec, rates = golden_spec(z)
+    s = z['sample']
+    with hip.Engine(flat, 1, k, tune={} if fused else dict(NO_EIGEN_GEMM=1), keep_td=True) as eng:
+        eng.set_models([(spec, rates)])
+        eng.set_masks(masks[None])
+        lnl = eng.bottom_up(True)
+        np.testing.assert_allclose(lnl[0], z['loglik'], rtol=LNL_RTOL)
+        assert_same_scaled(eng.download(hip.BUF_BU)[s], eng.download(hip.BUF_BU_SF)[s], z['bu'], z['bu_sf'][s], what='BU')
+        post, lh_sum, lh_sf = eng.top_down_marginals()
+        np.testing.assert_allclose(post[0][s], z['posterior'], rtol=POST_RTOL, atol=1e-300)
+        np.testing.assert_allclose(post[0].sum(axis=1), 1, rtol=1e-12)
+        np.testing.assert_allclose(np.log10(lh_sum[0]) - lh_sf[0], lnl[0] / np.log(10), rtol=1e-11)
+        assert_same_scaled(eng.download(hip.BUF_TD)[s], eng.download(hip.BUF_TD_SF)[s], z['td'], z['td_sf'][s], what='TD')
+        lnl_j = eng.bottom_up(False)
+        np.testing.assert_allclose(lnl_j[0], z['loglik_joint'], rtol=LNL_RTOL)
+        nonroot = flat.parent[s] >= 0
+        table = eng.download(hip.BUF_JOINT_TABLE)[s]
+        # (the reference's P(t) is numpy's product; arg-max rows may differ where two products agree to rounding)
+        diff = np.argwhere((table != z['joint_table']) & nonroot[:, None])
+        assert len(diff) <= 2, len(diff)
+        assert np.array_equal(eng.joint_backtrace()[0], z['joint_state'])
+        assert np.array_equal(eng.bottom_up(True), lnl)
+
+
 def test_cfg3_full_size_matches_reference_sample():
     """
     BASELINE config 3 at full size: 262 144 tips, JTT k=20, one character, joint (Pupko) sweep + back-trace

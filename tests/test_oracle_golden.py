@@ -167,6 +167,31 @@ def test_custom_rates_k61_sample():
     assert np.array_equal(orc.joint_backtrace(flat, j['bu'], j['joint_table'], spec['pi']), z['joint_state'])
 
 
+def test_custom_rates_k100_sample():
+    """
+    synthetic_cr_k100_L11 (the reference's CustomRatesModel with 100 states on a balanced 2 048-tip tree, a twentieth of the tips
+    unannotated, tests/golden/make_golden.py::case_eigen_k100): the oracle's marginal pass and joint sweep against the reference's
+    ln L, its joint states on every node and its vectors at every 13th node.
+    """
+    from pastml_amd import synthetic
+    z = load_golden('synthetic_cr_k100_L11')
+    k = 100
+    flat = synthetic.balanced_forest(int(z['n_levels']))
+    masks = synthetic.one_hot_masks(flat, k, z['tip_states']).astype(int)
+    masks[np.asarray(flat.tips)[~z['tip_observed']]] = 1
+    s = z['sample']
+    assert np.array_equal(masks[s], z['masks_altered'])
+    spec, (sf, tau, tf) = golden_spec(z)
+    r = orc.full_marginal_pass(flat, masks, spec, sf, tau, tf)
+    np.testing.assert_allclose(r['loglik'], z['loglik'], rtol=1e-12)
+    np.testing.assert_allclose(r['posterior'][s], z['posterior'], rtol=1e-9, atol=1e-300)
+    j = orc.bottom_up(flat, masks, spec, sf, tau, tf, False)
+    np.testing.assert_allclose(j['loglik'], z['loglik_joint'], rtol=1e-12)
+    nonroot = flat.parent[s] >= 0
+    assert np.array_equal(j['joint_table'][s][nonroot], z['joint_table'][nonroot])
+    assert np.array_equal(orc.joint_backtrace(flat, j['bu'], j['joint_table'], spec['pi']), z['joint_state'])
+
+
 def _k300_inputs(z):
     from pastml_amd import synthetic
     k = 300
