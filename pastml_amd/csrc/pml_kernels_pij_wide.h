@@ -21,13 +21,17 @@
 #define PML_PIJW_WAVES (PML_PIJW_BLOCK / 64)
 #define PML_PIJW_AHEAD 4                       // K steps whose Ainv operands are in flight
 
-// columns tiles per slice for k states: the slice [KP][16 NTC] must fit 128 KB
+// column tiles per slice for k states: the slice [KP][16 NTC] must fit 128 KB; the NT tiles in as few slices as that allows, of
+// equal width (every slice runs all NTC accumulator tiles -- a tile beyond the matrix multiplies zeros: the last slice of 13
+// tiles in widths of 5 wastes two of fifteen --: a matrix instruction under a condition costs the compiler a copy of every
+// accumulator, ~100 moves per instruction when it was tried)
 static inline int pijw_tiles(int k, int ks) {
     const int KP = (k + 3) & ~3, NT = (ks + 15) / 16;
-    int ntc = 1024 / KP;
-    if (ntc > NT) ntc = NT;
-    if (ntc > 8) ntc = 8;
-    return ntc < 1 ? 1 : ntc;
+    int most = 1024 / KP;
+    if (most > 8) most = 8;
+    if (most < 1) most = 1;
+    const int slices = (NT + most - 1) / most;
+    return (NT + slices - 1) / slices;
 }
 static inline size_t pijw_lds_bytes(int k, int ntc) {
     const int KP = (k + 3) & ~3;
@@ -56,7 +60,6 @@ pij_eigen_wide_kernel(PmlTree t, PmlCols c, PmlModel m, double* __restrict__ P, 
     const int b_hi = min(t.N, b_lo + branches_per_block);
     for (int nt0 = 0; nt0 < NT; nt0 += NTC) {
         const int i_base = 16 * nt0;
-        const int ntl = min(NTC, NT - nt0);   // (a short last slice skips the tiles it does not have)
         __syncthreads();   // the previous slice has been consumed
         // (read along m: consecutive addresses; the transposing LDS writes are paid once per slice and workgroup)
         for (int e = threadIdx.x; e < LDR * KP; e += PML_PIJW_BLOCK) {
@@ -77,30 +80,37 @@ pij_eigen_wide_kernel(PmlTree t, PmlCols c, PmlModel m, double* __restrict__ P, 
                 pml_v4f64 acc[NTC];
 #pragma unroll
                 for (int nt = 0; nt < NTC; ++nt) acc[nt] = (pml_v4f64){0.0, 0.0, 0.0, 0.0};
-                double abuf[2][PML_PIJW_AHEAD];
+                // K steps in groups of PML_PIJW_AHEAD, the operands of the next group in flight; no matrix instruction under a condition
+                // (see pijw_tiles); the last KS % PML_PIJW_AHEAD steps in a loop of their own
+                double abuf[PML_PIJW_AHEAD], anext[PML_PIJW_AHEAD];
 #pragma unroll
-                for (int u = 0; u < PML_PIJW_AHEAD; ++u) abuf[0][u] = pa[(size_t)min(4 * u + hi, k - 1) * k];
-                for (int s0 = 0; s0 < KS; s0 += 2 * PML_PIJW_AHEAD) {
+                for (int u = 0; u < PML_PIJW_AHEAD; ++u) abuf[u] = pa[(size_t)min(4 * u + hi, k - 1) * k];
+                int s0 = 0;
+                for (; s0 + PML_PIJW_AHEAD <= KS; s0 += PML_PIJW_AHEAD) {
+                    // (rows beyond the matrix: row k - 1, multiplied by a zero exponential or never used)
 #pragma unroll
-                    for (int half = 0; half < 2; ++half) {
-                        const int sb = s0 + half * PML_PIJW_AHEAD;
-                        if (sb >= KS) break;
-                        // the operands of the steps after these (rows beyond the matrix: row k - 1, multiplied by a zero below)
+                    for (int u = 0; u < PML_PIJW_AHEAD; ++u)
+                        anext[u] = pa[(size_t)min(4 * (s0 + PML_PIJW_AHEAD + u) + hi, k - 1) * k];
 #pragma unroll
-                        for (int u = 0; u < PML_PIJW_AHEAD; ++u)
-                            abuf[half ^ 1][u] = pa[(size_t)min(4 * (sb + PML_PIJW_AHEAD + u) + hi, k - 1) * k];
+                    for (int u = 0; u < PML_PIJW_AHEAD; ++u) {
+                        const int mm = 4 * (s0 + u) + hi;
+                        const double a = abuf[u] * sE[mm];
+                        const double* pr = sR + (size_t)mm * LDR + lo;
 #pragma unroll
-                        for (int u = 0; u < PML_PIJW_AHEAD; ++u) {
-                            const int s = sb + u;
-                            if (s >= KS) break;
-                            const int mm = 4 * s + hi;
-                            const double a = abuf[half][u] * sE[mm];
-                            const double* pr = sR + (size_t)mm * LDR + lo;
-#pragma unroll
-                            for (int nt = 0; nt < NTC; ++nt)
-                                if (nt < ntl) acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, pr[16 * nt], acc[nt], 0, 0, 0);
-                        }
+                        for (int nt = 0; nt < NTC; ++nt)
+                            acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, pr[16 * nt], acc[nt], 0, 0, 0);
                     }
+#pragma unroll
+                    for (int u = 0; u < PML_PIJW_AHEAD; ++u) abuf[u] = anext[u];
+                }
+#pragma unroll 1
+                for (int s = s0; s < KS; ++s) {
+                    const int mm = 4 * s + hi;
+                    const double a = pa[(size_t)min(mm, k - 1) * k] * sE[mm];
+                    const double* pr = sR + (size_t)mm * LDR + lo;
+#pragma unroll
+                    for (int nt = 0; nt < NTC; ++nt)
+                        acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, pr[16 * nt], acc[nt], 0, 0, 0);
                 }
                 // D: row = hi + 4 reg, column = lo
 #pragma unroll
