@@ -814,6 +814,30 @@ def test_marginal_counts_device_sampler_agrees_with_host_sampler(model_name, k):
     assert np.array_equal(dev, ml.marginal_counts(roots, 'c', model, n_repetitions=n_rep))
 
 
+def test_marginal_counts_beyond_256_states_take_the_host_sampler():
+    """ml.marginal_counts with 300 states (the device sampler's tables hold 256): the host sampler on the device's bottom-up and
+    top-down vectors, as for forests with altered nodes -- every scenario has one state change per differing parent / child pair,
+    so the counts of an all-observed cherry-free star of tips are known; here: shape, non-negativity, total within the number of
+    branches, and the same matrix from the same numpy seed."""
+    from pastml_amd.tree import FlatForest
+    k = 300
+    rng = np.random.default_rng(300)
+    flat = FlatForest.random(60, seed=300, max_arity=3)
+    roots = flat.to_tree_nodes()
+    states = np.array(['s{:03d}'.format(i) for i in range(k)])
+    for t in flat.tips:
+        flat.nodes[t].add_feature('c', {states[rng.integers(k)]})
+    fs = ForestStats(roots)
+    model = F81Model(states=states, forest_stats=fs, sf=1.0 / fs.avg_nonzero_brlen, frequencies=rng.dirichlet(np.ones(k) * 3))
+    model.freeze()
+    np.random.seed(4)
+    a = ml.marginal_counts(roots, 'c', model, n_repetitions=200)
+    assert a.shape == (k, k) and np.all(a >= -1e-12) and np.isfinite(a).all()
+    assert 0 < a.sum() <= flat.n_nodes
+    np.random.seed(4)
+    assert np.array_equal(a, ml.marginal_counts(roots, 'c', model, n_repetitions=200))
+
+
 def test_engine_pool_reuse_and_model_kind_switch():
     """
     A released engine is handed out again for the same forest / width / k, with no state of the previous analysis
