@@ -1339,10 +1339,19 @@ def reconstruct(batch, tasks, lnl, force_joint=True):
     return results
 
 
-# bytes of device memory per column and node, generously: bottom-up vector, posterior, arg-max rows, scalars
-def _column_bytes(flat, k, widths):
+# bytes of device memory per character and node, generously: bottom-up vector, posterior, arg-max rows, scalars of the
+# character's own column + what each of the (on average) `widths` columns of its optimiser block holds.  Eigen models beyond 64
+# states read P(t) of every branch from HBM, k x k doubles per node and column (Limits): the joint sweep of the
+# character's own column always (65 - 128 states: the sum sweeps are fused, so the optimiser's columns need none), every column
+# beyond 128 states.
+def _column_bytes(flat, k, widths, kind=hip.KIND_F81):
     ks = k + (k & 1)
-    return flat.n_nodes * ((17 * ks + 96) + sum(widths) / max(1, len(widths)) * (8 * ks + 64))
+    own, point = 17 * ks + 96, 8 * ks + 64
+    if kind == hip.KIND_EIGEN and k > 64:
+        own += 8 * k * ks
+        if k > 128:
+            point += 8 * k * ks
+    return flat.n_nodes * (own + sum(widths) / max(1, len(widths)) * point)
 
 
 def visible_devices(device=None):
@@ -1393,7 +1402,7 @@ def run_tasks(forest, tasks, force_joint=True, device=None, flat=None, seeds=Non
     jobs, job_bytes = [], []
     for key, members in groups.items():
         k = key[0]
-        per_char = _column_bytes(flat, k, [block_width(tasks[i].model) for i in members])
+        per_char = _column_bytes(flat, k, [block_width(tasks[i].model) for i in members], kind=key[1])
         chunk = max(1, min(len(members), 4096, int(0.6 * free / max(1.0, per_char))))
         if len(devices) > 1 and len(members) >= 2 and flat.n_nodes * len(members) >= split_min:
             chunk = min(chunk, -(-len(members) // len(devices)))

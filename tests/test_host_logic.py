@@ -589,6 +589,22 @@ def test_acr_names_a_character_with_too_many_states():
         acr_module.acr(tree, df300, prediction_method='MPPA', model='CUSTOM_RATES', column2rates={'wide': os.devnull})
 
 
+def test_memory_plan_counts_the_transition_matrices_of_wide_eigen_models():
+    """run_tasks cuts a group of characters to what the device holds (batch._column_bytes): eigen models beyond 64 states keep
+    P(t) of every branch in HBM -- for the joint sweep of a character's own column (65 - 128 states: the optimiser's sum sweeps
+    are fused), for every column beyond 128 states."""
+    from pastml_amd import batch, hip
+    from pastml_amd.tree import FlatForest
+    flat = FlatForest.balanced(8)
+    for k in (20, 64):
+        assert batch._column_bytes(flat, k, [k + 1], kind=hip.KIND_EIGEN) == batch._column_bytes(flat, k, [k + 1])
+    base = batch._column_bytes(flat, 100, [101])
+    assert batch._column_bytes(flat, 100, [101], kind=hip.KIND_EIGEN) == base + flat.n_nodes * 8 * 100 * 100
+    base = batch._column_bytes(flat, 200, [201])
+    assert batch._column_bytes(flat, 200, [201], kind=hip.KIND_EIGEN) == base + flat.n_nodes * 8 * 200 * 200 * 202
+    assert batch._column_bytes(flat, 300, [2], kind=hip.KIND_F81) == batch._column_bytes(flat, 300, [2])
+
+
 def test_value2list_broadcasts_like_the_reference():
     from pastml_amd import value2list
     given = ['a', 'b']
