@@ -1924,7 +1924,7 @@ int pml_model_set_eigen(pml_ctx* ctx, int32_t col_begin, int32_t col_end, const 
         if (!same) {
             PML_TRY(params_push(ctx));   // (the kernel reads the frequencies from the parameter block)
             const size_t lds = (k * (k + 1) + k) * sizeof(double);
-            HIP_TRY(hipFuncSetAttribute((const void*)eig_sym_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            PML_TRY(with_lds(ctx, eig_sym_kernel, lds));
             for (int phase = 0; phase < 2; ++phase)
                 hipLaunchKernelGGL(eig_sym_kernel, dim3(PML_ESYM_PARTS, nc), dim3(PML_BLOCK), lds, ctx->stream, (int)k, ctx->ks,
                                    (int)col_begin, phase, ctx->d_A, cols_of(ctx).pi, ctx->d_eigT, ctx->d_Asym);

@@ -150,6 +150,29 @@ PML_INTERNAL int launch_eigen_joint(pml_ctx* ctx, const PmlUnit* units, const in
 PML_INTERNAL int launch_eigen_joint_tips(pml_ctx* ctx);
 PML_INTERNAL int launch_pij_valu(pml_ctx* ctx);
 
+// More than 64 KB of dynamic LDS must be asked for: once per kernel, device and size (the largest asked for so far is what is
+// set) -- not per launch: the call is not free and should not sit inside a stream capture.  (A template: one table per kernel
+// type and translation unit; the kernels that share a type are told apart by their address.)
+template <typename K>
+static inline int with_lds(const pml_ctx* ctx, K kernel, size_t bytes) {
+    struct Entry {
+        const void* fn;
+        int device;
+        size_t bytes;
+    };
+    static std::mutex mu;
+    static std::vector<Entry> done;
+    std::lock_guard<std::mutex> lock(mu);
+    Entry* e = nullptr;
+    for (auto& d : done)
+        if (d.fn == (const void*)kernel && d.device == ctx->device) e = &d;
+    if (e != nullptr && e->bytes >= bytes) return PML_OK;
+    HIP_TRY(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    if (e != nullptr) e->bytes = bytes;
+    else done.push_back(Entry{(const void*)kernel, ctx->device, bytes});
+    return PML_OK;
+}
+
 static inline int dispatch_sweep(pml_ctx* ctx, SweepKind what, const int* level, int n_level) {
     if (n_level <= 0) return PML_OK;
     return ctx->kind == PML_MODEL_F81 ? dispatch_sweep_f81(ctx, what, level, n_level) : dispatch_sweep_matrix(ctx, what, level, n_level);

@@ -6,21 +6,6 @@
 // states per lane: k / 4 rounded up to a multiple of four (20, 24, 28, 32 -- four shapes instead of sixteen)
 static int eig_gemm_wide_ks(int k) { return ((k + 15) / 16) * 4; }
 
-// more than 64 KB of dynamic LDS must be asked for, once per kernel and device (not per launch: the call is not free and must
-// not sit inside a stream capture)
-template <typename K>
-static int with_lds(const pml_ctx* ctx, K kernel, size_t bytes) {
-    static std::mutex mu;
-    static std::vector<std::pair<const void*, int>> done;
-    std::lock_guard<std::mutex> lock(mu);
-    const std::pair<const void*, int> key((const void*)kernel, ctx->device);
-    for (const auto& d : done)
-        if (d == key) return PML_OK;
-    HIP_TRY(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    done.push_back(key);
-    return PML_OK;
-}
-
 int launch_eigen_gemm_wide(pml_ctx* ctx, int mode, const int* nodes, int first, int n) {
     if (n <= 0) return PML_OK;
     const int KS = eig_gemm_wide_ks(ctx->k);

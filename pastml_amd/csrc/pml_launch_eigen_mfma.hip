@@ -124,8 +124,7 @@ int launch_pij_wide(pml_ctx* ctx) {
     dim3 grid((ctx->N + bpb - 1) / bpb, ctx->C);
 #define PML_PIJW_CASE(NTC_)                                                                                          \
     if (ntc == NTC_) {                                                                                               \
-        HIP_TRY(hipFuncSetAttribute((const void*)pij_eigen_wide_kernel<NTC_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                    (int)lds));                                                                      \
+        PML_TRY(with_lds(ctx, pij_eigen_wide_kernel<NTC_>, lds));                                                    \
         hipLaunchKernelGGL((pij_eigen_wide_kernel<NTC_>), grid, dim3(PML_PIJW_BLOCK), lds, ctx->stream, t, c, m, ctx->d_P, bpb); \
     }
     PML_PIJW_CASE(1) PML_PIJW_CASE(2) PML_PIJW_CASE(3) PML_PIJW_CASE(4)
