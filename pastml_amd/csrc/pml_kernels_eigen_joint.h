@@ -206,7 +206,8 @@ __device__ __forceinline__ void eigj_back(const EigJWave<KU>& W, const PmlCols& 
     pml_const_f64 at = W.ainvT;
     asm volatile("" : "+s"(at));
     // (fully unrolled up to 32 states; beyond, KU x KU FMAs would be 32 KB of straight-line code: two columns per iteration)
-#pragma unroll(KU <= 32 ? KU : 2)
+    constexpr int COLUMNS_UNROLLED = KU <= 32 ? KU : 2;
+#pragma unroll COLUMNS_UNROLLED
     for (int j = 0; j < KU; ++j) {
         double p = u[0] * at[j * PML_EIGJ_LD(KU)];
 #pragma unroll
