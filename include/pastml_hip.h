@@ -259,11 +259,22 @@ int pml_select_states(pml_ctx* ctx, int method, int force_joint, const uint64_t*
 /*
  * Expected numbers of state changes i -> j per scenario, estimated from n_repetitions ancestral scenarios drawn from
  * the marginal posterior of column col: the sampling scheme of pastml/ml.py:753-862 (marginal_counts) for forests
- * without nodes altered by the zero-branch handling (ml.py:352-387; the host keeps that case), with a counter-based
+ * without nodes altered by the zero-branch handling (ml.py:352-387; with them: pml_marginal_counts_altered), with a counter-based
  * generator (Philox-4x32-10 keyed by seed): statistical, not bitwise, parity with the reference's numpy draws.
  * Needs pml_bottom_up (marginal) and pml_top_down_marginals first.  counts_out[k][k].
  */
 int pml_marginal_counts(pml_ctx* ctx, int32_t col, int32_t n_repetitions, uint64_t seed, double* counts_out);
+/*
+ * The same for a forest with nodes altered by the zero-branch handling (altered[n_nodes], 1 = altered; pastml/ml.py:352-387).  The
+ * scenarios are drawn as above.  A (parent, child) pair with an altered end does not enter the sums, and a parent of such a pair
+ * keeps its diagonal correction: the reference gives those pairs fractional counts from the state counts of their two nodes
+ * (ml.py:806-812, 840-853, 857-858), which the caller forms from what comes back -- sums_out[k][k]: the sums of the draws of all
+ * other pairs, diagonal corrected for all other parents, NOT divided by n_repetitions; state_counts_out[n_nodes][k]: how often
+ * each node was in each state; same_out[n_nodes][k]: for a parent of such a pair, its same-state draws over its other children
+ * (rows of other nodes are zero).  pastml_amd.ml.marginal_counts is that caller.
+ */
+int pml_marginal_counts_altered(pml_ctx* ctx, int32_t col, int32_t n_repetitions, uint64_t seed, const uint8_t* altered,
+                                double* sums_out, int32_t* state_counts_out, int32_t* same_out);
 
 /* ---- multi-GPU (one process per GPU) ----------------------------------------------------------------------------------- */
 /*

@@ -2993,9 +2993,12 @@ int pml_joint_pass(pml_ctx* ctx, double* loglik_out, int32_t* err_parent, int32_
     return fetched;
 }
 
-int pml_marginal_counts(pml_ctx* ctx, int32_t col, int32_t n_repetitions, uint64_t seed, double* counts_out) {
+// altered (caller's ids, or null): see counts_level_kernel.  result_out: the k x k sums of the draws (not divided by
+// n_repetitions when altered is given); state_counts_out / same_out: [N][k] in the caller's numbering.
+static int marginal_counts_impl(pml_ctx* ctx, int32_t col, int32_t n_repetitions, uint64_t seed, const uint8_t* altered,
+                                double* result_out, int32_t* state_counts_out, int32_t* same_out) {
     PML_TRY(require_model(ctx));
-    if (col < 0 || col >= ctx->C || !counts_out) return fail(PML_ERR_INVALID, "bad column / output");
+    if (col < 0 || col >= ctx->C || !result_out) return fail(PML_ERR_INVALID, "bad column / output");
     if (n_repetitions <= 0) return fail(PML_ERR_INVALID, "n_repetitions must be positive");
     if (ctx->bu_mode != 1 || !ctx->td_valid)
         return fail(PML_ERR_INVALID, "pml_marginal_counts needs a marginal pml_bottom_up and pml_top_down_marginals first");
@@ -3003,12 +3006,22 @@ int pml_marginal_counts(pml_ctx* ctx, int32_t col, int32_t n_repetitions, uint64
     PML_TRY(materialize_cherries(ctx));  // the conditional probabilities need every bottom-up vector
     PML_TRY(materialize_tip_posteriors(ctx));
     PML_TRY(run_prep(ctx));  // P(t) of every branch (the fused eigen sweeps never materialise it) / exp(-mu t')
-    const size_t k = ctx->k;
-    int* d_counts = nullptr;
+    const size_t k = ctx->k, N = (size_t)ctx->N;
+    int *d_counts = nullptr, *d_same = nullptr;
     long long* d_result = nullptr;
-    HIP_TRY(hipMalloc((void**)&d_counts, (size_t)ctx->N * k * sizeof(int)));
-    hipError_t e = hipMalloc((void**)&d_result, k * k * sizeof(long long));
+    unsigned char* d_alt = nullptr;
+    hipError_t e = hipMalloc((void**)&d_counts, N * k * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_result, k * k * sizeof(long long));
     if (e == hipSuccess) e = hipMemsetAsync(d_result, 0, k * k * sizeof(long long), ctx->stream);
+    std::vector<unsigned char> alt;
+    if (e == hipSuccess && altered != nullptr) {
+        alt.assign(N, 0);
+        for (size_t i = 0; i < N; ++i) alt[(size_t)internal_id(ctx, (int)i)] = altered[i] ? 1 : 0;
+        e = hipMalloc((void**)&d_alt, N);
+        if (e == hipSuccess) e = hipMalloc((void**)&d_same, N * k * sizeof(int));
+        if (e == hipSuccess) e = hipMemcpyAsync(d_alt, alt.data(), N, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(d_same, 0, N * k * sizeof(int), ctx->stream);
+    }
     if (e == hipSuccess) {
         const PmlTree t = tree_of(ctx);
         const PmlCols c = cols_of(ctx);
@@ -3022,19 +3035,39 @@ int pml_marginal_counts(pml_ctx* ctx, int32_t col, int32_t n_repetitions, uint64
             const int a = ctx->td_parent_offsets[l], b = ctx->td_parent_offsets[l + 1];
             if (b <= a) continue;
             hipLaunchKernelGGL(counts_level_kernel, dim3(std::min(b - a, 65536)), dim3(64), 0, ctx->stream, t, c, st, m, P,
-                               col, n_repetitions, seed, ctx->d_td_parents + a, b - a, d_counts, d_result, ctx->d_old_of_new);
+                               col, n_repetitions, seed, ctx->d_td_parents + a, b - a, d_counts, d_result, ctx->d_old_of_new,
+                               d_alt, d_same);
         }
         e = hipGetLastError();
     }
     std::vector<long long> h(k * k);
     if (e == hipSuccess) e = hipMemcpyAsync(h.data(), d_result, k * k * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream);
+    int fetched = PML_OK;
+    if (e == hipSuccess && altered != nullptr) {
+        // (tips' rows of d_counts are written by their parents' passes: every node has its row)
+        if (state_counts_out) fetched = fetch_rows(ctx, d_counts, k, k, 1, state_counts_out);
+        if (fetched == PML_OK && same_out) fetched = fetch_rows(ctx, d_same, k, k, 1, same_out);
+    }
     const hipError_t e2 = hipStreamSynchronize(ctx->stream);
     (void)hipFree(d_counts);
     if (d_result) (void)hipFree(d_result);
+    if (d_alt) (void)hipFree(d_alt);
+    if (d_same) (void)hipFree(d_same);
     if (e != hipSuccess) return fail(PML_ERR_HIP, "pml_marginal_counts failed: %s", hipGetErrorString(e));
     if (e2 != hipSuccess) return fail(PML_ERR_HIP, "pml_marginal_counts failed: %s", hipGetErrorString(e2));
-    for (size_t i = 0; i < k * k; ++i) counts_out[i] = (double)h[i] / (double)n_repetitions;
+    PML_TRY(fetched);
+    for (size_t i = 0; i < k * k; ++i) result_out[i] = altered != nullptr ? (double)h[i] : (double)h[i] / (double)n_repetitions;
     return PML_OK;
+}
+
+int pml_marginal_counts(pml_ctx* ctx, int32_t col, int32_t n_repetitions, uint64_t seed, double* counts_out) {
+    return marginal_counts_impl(ctx, col, n_repetitions, seed, nullptr, counts_out, nullptr, nullptr);
+}
+
+int pml_marginal_counts_altered(pml_ctx* ctx, int32_t col, int32_t n_repetitions, uint64_t seed, const uint8_t* altered,
+                                double* sums_out, int32_t* state_counts_out, int32_t* same_out) {
+    if (!altered || !state_counts_out || !same_out) return fail(PML_ERR_INVALID, "NULL array");
+    return marginal_counts_impl(ctx, col, n_repetitions, seed, altered, sums_out, state_counts_out, same_out);
 }
 
 int pml_select_states(pml_ctx* ctx, int method, int force_joint, const uint64_t* lh_mask, uint64_t* masks_out,

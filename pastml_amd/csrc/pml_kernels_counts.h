@@ -100,7 +100,12 @@ counts_roots_kernel(PmlTree t, PmlCols c, PmlState st, int col, int n_rep, u64 s
 PML_GLOBAL void __launch_bounds__(64)
 counts_level_kernel(PmlTree t, PmlCols c, PmlState st, PmlModel m, const double* __restrict__ P, int col, int n_rep,
                     u64 seed, const int* __restrict__ parents, int n_parents, int* __restrict__ counts,
-                    long long* __restrict__ result, const int* __restrict__ api_id) {
+                    long long* __restrict__ result, const int* __restrict__ api_id,
+                    const unsigned char* __restrict__ altered, int* __restrict__ same_out) {
+    // altered (or null): the nodes whose masks the zero-branch handling changed (ml.py:352-387).  A (parent, child) pair with an
+    // altered end adds nothing to the result here and a parent with such a pair keeps its diagonal correction: the reference gives
+    // those pairs fractional counts (ml.py:806-812, 840-853), which the caller forms from the state counts of the nodes (`counts`)
+    // and this parent's same-state draws over its other children (same_out) -- pml_marginal_counts_altered.
     __shared__ double cdf[PML_COUNTS_MAX_K];
     __shared__ double base[PML_COUNTS_MAX_K];  // BU_n[b] pi_b mask_n[b]
     __shared__ int pc[PML_COUNTS_MAX_K];       // counts of the parent
@@ -119,8 +124,11 @@ counts_level_kernel(PmlTree t, PmlCols c, PmlState st, PmlModel m, const double*
         }
         __syncthreads();
         const int fc = t.first_child[p], nc = t.n_children[p];
+        bool dirty = altered != nullptr && altered[p] != 0;
         for (int j = 0; j < nc; ++j) {
             const int n = fc + j;
+            const bool upd = altered == nullptr || !(altered[p] | altered[n]);   // (block-uniform)
+            dirty |= !upd;
             const unsigned key = (unsigned)(api_id ? api_id[n] : n);   // the node as the caller numbers it
             const bool tip = t.n_children[n] == 0;
             for (int b = lane; b < k; b += 64) {
@@ -170,8 +178,10 @@ counts_level_kernel(PmlTree t, PmlCols c, PmlState st, PmlModel m, const double*
                     const int h = hist[b];
                     if (h) {
                         cc[b] += h;
-                        atomicAdd((unsigned long long*)&result[(size_t)a * k + b], (unsigned long long)h);
-                        if (b == a) same[a] += h;
+                        if (upd) {
+                            atomicAdd((unsigned long long*)&result[(size_t)a * k + b], (unsigned long long)h);
+                            if (b == a) same[a] += h;
+                        }
                     }
                 }
                 __syncthreads();
@@ -179,10 +189,14 @@ counts_level_kernel(PmlTree t, PmlCols c, PmlState st, PmlModel m, const double*
             for (int b = lane; b < k; b += 64) counts[(size_t)n * k + b] = cc[b];
             __syncthreads();
         }
-        // result[a][a] -= min(c_a, same-state draws)   (ml.py:857-858)
+        // result[a][a] -= min(c_a, same-state draws)   (ml.py:857-858); a parent with an altered end of a pair: the caller's
         for (int a = lane; a < k; a += 64) {
-            const int d = min(pc[a], same[a]);
-            if (d) atomicAdd((unsigned long long*)&result[(size_t)a * k + a], (unsigned long long)(-(long long)d));
+            if (dirty) {
+                same_out[(size_t)p * k + a] = same[a];
+            } else {
+                const int d = min(pc[a], same[a]);
+                if (d) atomicAdd((unsigned long long*)&result[(size_t)a * k + a], (unsigned long long)(-(long long)d));
+            }
         }
         __syncthreads();
     }

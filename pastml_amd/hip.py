@@ -104,6 +104,8 @@ SIGNATURES = {
     'pml_joint_pass': [_ctx_p, _c_double_p, _c_int32_p, _c_int32_p, _c_int32_p],
     'pml_select_states': [_ctx_p, ctypes.c_int, ctypes.c_int, _c_uint64_p, _c_uint64_p, _c_int32_p],
     'pml_marginal_counts': [_ctx_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_uint64, _c_double_p],
+    'pml_marginal_counts_altered': [_ctx_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint8),
+                                    _c_double_p, _c_int32_p, _c_int32_p],
     'pml_download': [_ctx_p, ctypes.c_int, ctypes.c_int32, ctypes.c_void_p],
     'pml_comm_unique_id': [ctypes.POINTER(ctypes.c_ubyte)],
     'pml_comm_init': [_ctx_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_ubyte)],
@@ -735,6 +737,23 @@ class Engine(BareContext):
         _check(self._lib.pml_marginal_counts(self._ctx, col, int(n_repetitions), ctypes.c_uint64(int(seed)),
                                              _ptr(out, ctypes.c_double)))
         return out
+
+    def marginal_counts_altered(self, n_repetitions, seed, altered, col=0):
+        """
+        The device's part of marginal_counts on a forest with altered nodes (pml_marginal_counts_altered): altered is a 0/1 array
+        [N].  Returns (sums [k, k] float -- not divided by n_repetitions --, state counts [N, k] int32, same-state draws [N, k]
+        int32); pastml_amd.ml.marginal_counts adds the fractional counts of the pairs with an altered end.
+        """
+        alt = np.ascontiguousarray(altered, dtype=np.uint8)
+        if alt.shape != (self.n_nodes,):
+            raise ValueError('one flag per node expected')
+        sums = np.empty((self.k, self.k), dtype=np.float64)
+        counts = np.empty((self.n_nodes, self.k), dtype=np.int32)
+        same = np.empty((self.n_nodes, self.k), dtype=np.int32)
+        _check(self._lib.pml_marginal_counts_altered(self._ctx, col, int(n_repetitions), ctypes.c_uint64(int(seed)),
+                                                     _ptr(alt, ctypes.c_uint8), _ptr(sums, ctypes.c_double),
+                                                     _ptr(counts, ctypes.c_int32), _ptr(same, ctypes.c_int32)))
+        return sums, counts, same
 
     def download(self, what, col=0):
         N, k = self.n_nodes, self.k

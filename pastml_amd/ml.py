@@ -502,9 +502,11 @@ def marginal_counts(forest, character, model, n_repetitions=1_000, device_sampli
 
     The likelihood part -- bottom-up and top-down sweeps, root posteriors, per-branch P(t) -- runs on the GPU, and so
     does the scenario sampling (draws of child states given the parent's state counts, ml.py:818-857:
-    ``pml_marginal_counts``) unless zero-branch handling altered some nodes: their special rules (ml.py:806-812,
-    840-853) stay on the host with numpy's generator, as in the reference.  Either way only statistical parity with the
-    reference is meaningful.
+    ``pml_marginal_counts``).  Where zero-branch handling altered some nodes the draws are still the device's
+    (``pml_marginal_counts_altered``); the fractional counts the reference gives the (parent, child) pairs with an altered end
+    (ml.py:806-812, 840-853) are formed here from the nodes' state counts.  More than 256 states, or
+    ``device_sampling=False``: the host sampler with numpy's generator, line by line the reference's.  Either way only
+    statistical parity with the reference is meaningful.
 
     :param device_sampling: False forces the host sampler (tests compare the two)
     :return: k x k array, entry [i, j] = average number of i -> j changes per scenario
@@ -523,8 +525,44 @@ def marginal_counts(forest, character, model, n_repetitions=1_000, device_sampli
             # no node altered by the zero-branch handling: the scenarios are drawn on the device (same scheme, a
             # counter-based generator seeded from numpy's global one, so np.random.seed still fixes the result)
             return problem.engine.marginal_counts(n_repetitions, seed=int(np.random.randint(0, 2 ** 62, dtype=np.int64)))
+        if device_sampling and k <= 256:
+            # altered nodes: the draws are the device's all the same; the pairs with an altered end get their fractional counts
+            # here (ml.py:806-812, 840-853), from the nodes' state counts, and their parents the diagonal correction (:857-858)
+            is_altered = np.zeros(problem.N, dtype=bool)
+            is_altered[altered] = True
+            sums, counts, same_int = problem.engine.marginal_counts_altered(
+                n_repetitions, int(np.random.randint(0, 2 ** 62, dtype=np.int64)), is_altered)
+            initial = problem.init_masks
+
+            def to_initial(cnt, n):
+                c = cnt * initial[n]
+                if np.count_nonzero(c):
+                    return n_repetitions * c / c.sum()
+                return n_repetitions * initial[n] / initial[n].sum()
+
+            result = sums
+            internal = np.flatnonzero(flat.n_children > 0)
+            fcs, ncs = flat.first_child, flat.n_children
+            has_altered_child = np.zeros(problem.N, dtype=bool)
+            has_altered_child[flat.parent[altered][flat.parent[altered] >= 0]] = True
+            for parent in internal[is_altered[internal] | has_altered_child[internal]]:
+                pcounts = counts[parent].astype(np.float64)
+                ps = to_initial(pcounts, parent) if is_altered[parent] else pcounts
+                same = same_int[parent].astype(np.float64)
+                pos = ps > 0
+                for node in range(fcs[parent], fcs[parent] + ncs[parent]):
+                    if not (is_altered[parent] or is_altered[node]):
+                        continue
+                    ccounts = counts[node].astype(np.float64)
+                    ci = to_initial(ccounts, node) if is_altered[node] else ccounts
+                    norm = ci / ci.sum()
+                    result[pos] += ps[pos, None] * norm[None, :]
+                    same[pos] += ps[pos] * norm[pos]
+                result[np.arange(k), np.arange(k)] -= np.minimum(ps, same)
+            return result / n_repetitions
         bu = problem.engine.download(hip.BUF_BU)
-        P = problem.engine.pij_batch(copy_out=True)[0]
+        # (an eigen model's P(0) carries +-1e-17 where the exact value is 0: clamped, as the device sampler and the sweeps do)
+        P = np.maximum(problem.engine.pij_batch(copy_out=True)[0], 0.0)
         frequencies = np.asarray(model.frequencies, dtype=np.float64)
         is_altered = np.zeros(problem.N, dtype=bool)
         is_altered[altered] = True

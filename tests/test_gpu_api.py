@@ -814,6 +814,53 @@ def test_marginal_counts_device_sampler_agrees_with_host_sampler(model_name, k):
     assert np.array_equal(dev, ml.marginal_counts(roots, 'c', model, n_repetitions=n_rep))
 
 
+@pytest.mark.parametrize('model_name,k', [('F81', 6), ('JTT', 20)])
+def test_marginal_counts_with_altered_nodes_on_the_device(model_name, k):
+    """
+    Forests with zero-length branches: the zero-branch handling alters nodes (pastml/ml.py:352-387), and the reference gives the
+    (parent, child) pairs with an altered end fractional counts (ml.py:806-812, 840-853).  Round 6: the scenarios are drawn on the
+    device all the same (pml_marginal_counts_altered), the host adds those pairs from the nodes' state counts -- against the host
+    sampler that follows the reference line by line (two Monte-Carlo estimates of one expectation), and reproducibly.
+    """
+    from pastml_amd.models.JTTModel import JTTModel, JTT_STATES
+    from pastml_amd.tree import FlatForest
+    rng = np.random.default_rng(50 + k)
+    flat = FlatForest.random(90, seed=23 + k, max_arity=3, zero_frac=0.3)
+    roots = flat.to_tree_nodes()
+    states = np.array(JTT_STATES) if model_name == 'JTT' else np.array(['s{}'.format(i) for i in range(k)])
+    # (tips of one zero-length cluster with different states: what the alteration is there for)
+    for t in flat.tips:
+        if rng.random() < 0.9:
+            flat.nodes[t].add_feature('c', {states[rng.integers(len(states))]})
+    fs = ForestStats(roots)
+    if model_name == 'F81':
+        model = F81Model(states=states, forest_stats=fs, sf=1.2 / fs.avg_nonzero_brlen, frequencies=rng.dirichlet(np.ones(k) * 3))
+    else:
+        model = JTTModel(states=states, forest_stats=fs, sf=0.8 / fs.avg_nonzero_brlen)
+    model.freeze()
+    n_rep = 20000
+    calls = []
+    real = hip.Engine.marginal_counts_altered
+
+    def spy(self, *a, **kw):
+        calls.append(1)
+        return real(self, *a, **kw)
+    hip.Engine.marginal_counts_altered = spy
+    try:
+        np.random.seed(3)
+        dev = ml.marginal_counts(roots, 'c', model, n_repetitions=n_rep)
+        assert calls, 'no node was altered: the test does not test what it says'
+        host = ml.marginal_counts(roots, 'c', model, n_repetitions=n_rep, device_sampling=False)
+        assert dev.shape == host.shape == (len(states), len(states))
+        tol = 8 * np.sqrt(np.maximum(host, 0.02) / n_rep) + 0.01
+        assert np.all(np.abs(dev - host) < tol), (np.abs(dev - host).max(), (np.abs(dev - host) / tol).max())
+        assert abs(dev.sum() - host.sum()) < 0.05 * max(1.0, host.sum())
+        np.random.seed(3)
+        np.testing.assert_allclose(dev, ml.marginal_counts(roots, 'c', model, n_repetitions=n_rep), rtol=0, atol=1e-12)
+    finally:
+        hip.Engine.marginal_counts_altered = real
+
+
 def test_marginal_counts_beyond_256_states_take_the_host_sampler():
     """ml.marginal_counts with 300 states (the device sampler's tables hold 256): the host sampler on the device's bottom-up and
     top-down vectors, as for forests with altered nodes -- every scenario has one state change per differing parent / child pair,
